@@ -1,0 +1,152 @@
+"""Oracle: AutoEncoder.encode / .decode (reference
+after/autoencoder/networks/SimpleNetsStream.py, pqmf.py, core.py).
+
+Test infrastructure -- see oracle/__init__.py.  Functional restatement on the
+reference-format state dict; `cfg` holds the AutoEncoder
+constructor arguments of baseAE.gin plus `padding_mode` ("centered"|"causal",
+the cached_conv.get_padding gin switch, baseAE.gin:32-33)."""
+import torch
+import torch.nn.functional as F
+
+
+def get_padding(kernel_size, stride=1, dilation=1, mode="centered"):
+    """cached_conv.get_padding (third-party, absent here; restated from its
+    published behaviour -- see oracle/__init__.py caveat)."""
+    if kernel_size == 1:
+        return (0, 0)
+    p = (kernel_size - 1) * dilation + 1
+    if mode == "centered":
+        return ((p - 1) // 2, p // 2)
+    return (p // 2 + (p - 1) // 2, 0)
+
+
+def fold_weight_norm(g, v):
+    """torch.nn.utils.weight_norm(dim=0): w = g * v / ||v|| with the norm over
+    every dim but 0 (SimpleNetsStream.py:84-92)."""
+    n = v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, *([1] * (v.dim() - 1)))
+    return v * (g / n)
+
+
+def _wn(sd, pre):
+    return fold_weight_norm(sd[pre + "weight_g"], sd[pre + "weight_v"]), sd.get(pre + "bias")
+
+
+def snake_beta(x, alpha, beta):
+    """core.py:217-260 (SnakeBeta, linear-scale): x + sin^2(alpha x)/(beta+1e-9)."""
+    a = alpha.reshape(1, -1, 1)
+    b = beta.reshape(1, -1, 1)
+    return x + (1.0 / (b + 0.000000001)) * torch.sin(x * a).pow(2)
+
+
+def reverse_half(x):
+    """pqmf.py:16-20: negate odd bands at even time indices."""
+    m = torch.ones_like(x)
+    m[..., 1::2, ::2] = -1
+    return x * m
+
+
+def pqmf_forward(sd, x, mode="centered"):
+    """pqmf.py:286-290 (CachedPQMF.forward): Conv1d(1->M, k=513, stride M,
+    pad get_padding(513) = (256,256) centred / (512,0) under the causal gin
+    switch, pqmf.py:263-270) then reverse_half."""
+    w = sd["pqmf.forward_conv.weight"]
+    M = w.shape[0]
+    if M == 1:
+        return x
+    x = F.pad(x, get_padding(w.shape[-1], mode=mode))
+    return reverse_half(F.conv1d(x, w, stride=M))
+
+
+def pqmf_inverse(sd, x, mode="centered"):
+    """pqmf.py:292-301 (CachedPQMF.inverse); conv pad get_padding(33) (pqmf.py:272-280)."""
+    w = sd["pqmf.inverse_conv.weight"]
+    m = w.shape[0]
+    if m == 1:
+        return x
+    x = reverse_half(x)
+    x = F.conv1d(F.pad(x, get_padding(w.shape[-1], mode=mode)), w) * m
+    x = x.flip(1)
+    x = x.permute(0, 2, 1)
+    x = x.reshape(x.shape[0], x.shape[1], -1, m).permute(0, 2, 1, 3)
+    return x.reshape(x.shape[0], x.shape[1], -1)
+
+
+def conv_block(sd, pre, x, cfg, kernel_size=3, dilation=1):
+    """SimpleNetsStream.py:150-194 (ConvBlock1d): GroupNorm(min(C,8)) ->
+    SnakeBeta -> weight-normed Conv1d with get_padding(k, dilation)."""
+    c = x.shape[1]
+    if cfg["use_norm"]:
+        x = F.group_norm(x, min(c, 8), sd[pre + "net.0.gn.weight"], sd[pre + "net.0.gn.bias"],
+                         1e-5)
+    x = snake_beta(x, sd[pre + "net.1.alpha"], sd[pre + "net.1.beta"])
+    w, b = _wn(sd, pre + "net.2.")
+    x = F.pad(x, get_padding(kernel_size, dilation=dilation, mode=cfg["padding_mode"]))
+    return F.conv1d(x, w, b, dilation=dilation)
+
+
+def resnet_block(sd, pre, x, cfg, dilation=1, use_res=True):
+    """SimpleNetsStream.py:197-254 (ResnetBlock1d) / :257-298 (NoRes)."""
+    k = cfg["kernel_size"]
+    if use_res:
+        y = conv_block(sd, pre + "net.branches.0.0.", x, cfg, k, dilation)
+        y = conv_block(sd, pre + "net.branches.0.1.", y, cfg, 1, 1)
+        if (pre + "net.branches.1.weight_v") in sd:
+            w, b = _wn(sd, pre + "net.branches.1.")
+            res = F.conv1d(x, w, b)
+        else:
+            res = x
+        return y + res
+    y = conv_block(sd, pre + "net.0.", x, cfg, k, dilation)
+    return conv_block(sd, pre + "net.1.", y, cfg, 1, 1)
+
+
+def encoder_forward(sd, x, cfg):
+    """SimpleNetsStream.py:400-459 (Encoder1d) with DownsampleBlock1d :301-341."""
+    pre = "encoder.net."
+    x = resnet_block(sd, pre + "0.", x, cfg)
+    n = len(cfg["factors"])
+    for i in range(n):
+        bp = f"{pre}{i + 1}.net."
+        for j, d in enumerate(cfg["dilations"]):
+            x = resnet_block(sd, f"{bp}{j}.", x, cfg, d)
+        nb = len(cfg["dilations"])
+        x = snake_beta(x, sd[f"{bp}{nb}.alpha"], sd[f"{bp}{nb}.beta"])
+        f = cfg["factors"][i]
+        w, b = _wn(sd, f"{bp}{nb + 1}.")
+        x = F.pad(x, get_padding(2 * f, f, mode=cfg["padding_mode"]))
+        x = F.conv1d(x, w, b, stride=f)
+    x = snake_beta(x, sd[f"{pre}{n + 1}.alpha"], sd[f"{pre}{n + 1}.beta"])
+    w, b = _wn(sd, f"{pre}{n + 2}.")
+    x = F.pad(x, get_padding(3, mode=cfg["padding_mode"]))
+    return F.conv1d(x, w, b)
+
+
+def decoder_forward(sd, z, cfg):
+    """SimpleNetsStream.py:552-651 (Decoder1d) with UpsampleBlock1d :344-384."""
+    pre = "decoder.net."
+    w, b = _wn(sd, pre + "0.")
+    x = F.conv1d(F.pad(z, get_padding(cfg["kernel_size"], mode=cfg["padding_mode"])), w, b)
+    factors = cfg["factors"][::-1]
+    for i, f in enumerate(factors):
+        bp = f"{pre}{i + 1}.net."
+        x = snake_beta(x, sd[bp + "0.alpha"], sd[bp + "0.beta"])
+        w, b = _wn(sd, bp + "1.")
+        x = F.conv_transpose1d(x, w, b, stride=f, padding=f // 2)
+        for j, d in enumerate(cfg["dilations"]):
+            x = resnet_block(sd, f"{bp}{j + 2}.", x, cfg, d)
+    x = resnet_block(sd, "decoder.synth.branches.0.", x, cfg, 1, use_res=False)
+    if cfg["use_loudness"]:
+        x, amp = x.split(x.shape[1] // 2, 1)
+        x = x * torch.sigmoid(amp)
+    return x
+
+
+def ae_encode(sd, x, cfg):
+    """SimpleNetsStream.py:918-941; ReluBottleneck is the identity on z at
+    inference (:753-760, apply_noise=False)."""
+    return encoder_forward(sd, pqmf_forward(sd, x, cfg["padding_mode"]), cfg)
+
+
+def ae_decode(sd, z, cfg):
+    """SimpleNetsStream.py:943-954."""
+    return pqmf_inverse(sd, decoder_forward(sd, z, cfg), cfg["padding_mode"])

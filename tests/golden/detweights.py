@@ -1,0 +1,66 @@
+"""Deterministic, order-independent weight filler shared by make_golden.py (which
+writes these values INTO the reference modules before running them) and by the
+tests (which rebuild the identical state dict for the oracle / the HIP path
+without the reference).  Each tensor is drawn from numpy's frozen legacy
+RandomState seeded with crc32(canonical key) ^ seed, so only shapes + a seed
+need to be stored in the fixtures."""
+import re
+import zlib
+
+import numpy as np
+import torch
+
+# buffers that carry real values (filters, frequency tables, caches): never refilled
+KEEP = re.compile(r"(rotary_emb\.freqs|precomputed_pos_enc|^pqmf\.|\.pad$|k_cache$|v_cache$)")
+
+
+def canonical(key: str) -> str:
+    """Encoder1D registers each BatchNorm twice (encoder.py:51-58): gn1/gn2 and
+    the same modules inside the CachedSequential.  Map both names to one."""
+    key = re.sub(r"\.gn1\.", ".net.branches.0.0.", key)
+    key = re.sub(r"\.gn2\.", ".net.branches.0.3.", key)
+    return key
+
+
+def _rng(key: str, seed: int):
+    return np.random.RandomState((zlib.crc32(canonical(key).encode()) ^ (seed * 2654435761)) &
+                                 0x7FFFFFFF)
+
+
+def fill_one(key: str, shape, seed: int) -> torch.Tensor:
+    r = _rng(key, seed)
+    shape = tuple(shape)
+    leaf = key.rsplit(".", 1)[-1]
+    if leaf == "num_batches_tracked":
+        return torch.zeros(shape, dtype=torch.long)
+    if leaf in ("weight_g", "running_var", "alpha", "beta"):
+        a = r.uniform(0.5, 1.5, size=shape)
+    elif leaf in ("weight_v", ) or (leaf == "weight" and len(shape) >= 2):
+        fan_in = int(np.prod(shape[1:]))
+        a = r.standard_normal(size=shape) / np.sqrt(fan_in)
+    elif leaf == "weight":  # norm scales
+        a = r.uniform(0.5, 1.5, size=shape)
+    elif leaf in ("bias", "running_mean"):
+        a = 0.1 * r.standard_normal(size=shape)
+    else:
+        raise KeyError(f"detweights: no fill rule for {key}")
+    return torch.from_numpy(np.asarray(a, dtype=np.float32).reshape(shape))
+
+
+def fill(shapes: dict, seed: int, keep: dict = None) -> dict:
+    """shapes: key -> shape (reference state_dict layout).  keep: key -> tensor
+    for the KEEP buffers (taken from the fixture)."""
+    out = {}
+    for k, s in shapes.items():
+        if KEEP.search(k):
+            if keep is not None and k in keep:
+                out[k] = torch.as_tensor(keep[k])
+            continue
+        out[k] = fill_one(k, s, seed)
+    return out
+
+
+def seeded_tensor(name: str, shape, seed: int, scale: float = 1.0) -> torch.Tensor:
+    """Deterministic N(0, scale^2) input tensor."""
+    a = _rng("input:" + name, seed).standard_normal(size=tuple(shape)) * scale
+    return torch.from_numpy(a.astype(np.float32))

@@ -1,0 +1,142 @@
+"""Pins the CPU oracle (oracle/) against vectors computed by the reference's own
+Python (tests/golden/make_golden.py).  CPU only.
+
+Tolerances: the oracle and the reference are both fp32 torch-CPU programs that
+differ only in summation order (banded gather vs dense masked SDPA, folded
+weight-norm), so agreement is at fp32 round-off: 2e-5 abs on O(1) outputs for a
+single forward, 1e-4 abs after a 50-step Euler integration."""
+import pytest
+import torch
+
+import oracle
+from after_amd import configs
+from fixtures import Fixture, max_abs
+
+torch.set_grad_enabled(False)
+
+
+def test_band_bounds_match_reference_masks():
+    fx = Fixture("mask_rope")
+    for name, m in fx.arrays.items():
+        if not (name.startswith("sw_") or name.startswith("cw_")):
+            continue
+        parts = name.split("_")
+        L, cs = int(parts[1]), int(parts[2])
+        W = int(parts[3]) if parts[0] == "sw" else None
+        m = torch.from_numpy(m)
+        for j in range(L):
+            lo, hi = oracle.band_bounds(j, cs, W, L)
+            want = torch.ones(L)
+            want[lo:hi] = 0
+            assert torch.equal(want, m[j]), (name, j, lo, hi)
+
+
+def test_rope_and_time_embedding():
+    fx = Fixture("mask_rope")
+    from oracle.denoiser import _apply_rope
+    q, k = fx.t("q"), fx.t("k")
+    cos, sin = oracle.rope_tables(k.shape[2])
+    off = k.shape[2] - q.shape[2]
+    assert max_abs(_apply_rope(q, cos[off:], sin[off:]), fx.t("rq")) < 2e-6
+    assert max_abs(_apply_rope(k, cos, sin), fx.t("rk")) < 2e-6
+    pe = oracle.positional_embedding(torch.linspace(0, 1, 11))
+    assert max_abs(pe, fx.t("pos_emb")) < 1e-5
+
+
+@pytest.mark.parametrize("case,tol_fwd,tol_sample", [
+    ("denoiser_micro", 2e-5, 5e-5),
+    ("denoiser_micro_ragged", 2e-5, 5e-5),
+    ("denoiser_micro_midi", 2e-5, 5e-5),
+    ("denoiser_midi", 5e-5, 1e-4),
+    ("denoiser_tiny", 5e-5, 1e-4),
+    ("denoiser_base", 5e-5, 1e-4),
+])
+def test_denoiser_matches_reference(case, tol_fwd, tol_sample):
+    fx = Fixture(case)
+    dcfg = configs.diffusion_config(fx.meta["config"])
+    ncfg = dcfg["net"]
+    sd = fx.state_dict()
+    x, cond, tc, tvec = fx.t("x"), fx.t("cond"), fx.t("time_cond"), fx.t("tvec")
+    out = oracle.denoiser_forward(sd, ncfg, x, tvec, cond, tc)
+    assert max_abs(out, fx.t("net_out")) < tol_fwd
+    t03 = torch.full((x.shape[0], 1, 1), 0.3)
+    assert max_abs(oracle.model_forward(sd, ncfg, x, t03, cond, tc, 2.0, 1.0),
+                   fx.t("mf_2_1")) < tol_fwd * 2
+    assert max_abs(oracle.model_forward(sd, ncfg, x, t03, cond, tc, 1.0, 3.0),
+                   fx.t("mf_1_3")) < tol_fwd * 3
+    for n in fx.meta["steps"]:
+        if n > 8 and case == "denoiser_base":
+            continue  # 50-step base run is covered by the slow test below
+        got = oracle.sample(sd, ncfg, x, cond, tc, n, 2.0, 1.0)
+        assert max_abs(got, fx.t(f"sample_{n}_2_1")) < tol_sample
+
+
+def test_base_50_step_sample_matches_reference():
+    fx = Fixture("denoiser_base")
+    ncfg = configs.diffusion_config("base")["net"]
+    sd = fx.state_dict()
+    got = oracle.sample(sd, ncfg, fx.t("x"), fx.t("cond"), fx.t("time_cond"), 50, 2.0, 1.0)
+    assert max_abs(got, fx.t("sample_50_2_1")) < 1e-4
+
+
+def test_streaming_cache_matches_reference():
+    fx = Fixture("stream_micro")
+    ncfg = configs.diffusion_config(fx.meta["config"])["net"]
+    sd = fx.state_dict()
+    x, cond, tc = fx.t("x"), fx.t("cond"), fx.t("time_cond")
+    B, chunk, steps = fx.meta["B"], fx.meta["chunk"], fx.meta["steps"]
+    H = ncfg["embed_dim"] // 64
+    cache = oracle.DenoiserCache(ncfg["n_layers"], 6, steps, H, ncfg["local_attention_size"], 64)
+    want = fx.t("out")
+    for c in range(want.shape[0]):
+        sl = slice(c * chunk, (c + 1) * chunk)
+        for i, t in enumerate(fx.t("tvals")):
+            tt = t.reshape(1, 1, 1).repeat(B, 1, 1)
+            got = oracle.denoiser_forward(sd, ncfg, x[..., sl], tt, cond, tc[..., sl],
+                                          cache=cache, cache_index=i)
+            cache.roll(chunk, i)
+            assert max_abs(got, want[c, i]) < 2e-5, (c, i)
+
+
+@pytest.mark.parametrize("case", ["ae_micro", "ae_micro_causal", "ae_base"])
+def test_autoencoder_matches_reference(case):
+    fx = Fixture(case)
+    cfg = configs.autoencoder_config(fx.meta["config"])
+    sd = fx.state_dict()
+    x = fx.t("x")
+    mode = cfg["padding_mode"]
+    assert max_abs(oracle.pqmf_forward(sd, x, mode), fx.t("multiband")) < 1e-6
+    assert max_abs(oracle.pqmf_inverse(sd, fx.t("multiband"), mode),
+                   fx.t("pqmf_roundtrip")) < 1e-6
+    # The codec is ~80 conv layers deep with GroupNorm + sin^2: fp32 round-off of
+    # the REFERENCE itself vs an fp64 run is ~1e-5 of the output range (measured),
+    # so the bound is relative to the output's max magnitude.
+    # Without GroupNorm (the causal/streaming variant) the random-weight net is
+    # ill-conditioned (|y| ~ 3e3): the reference's own fp32-vs-fp64 error is 1e-3
+    # rel-L2 there (measured), hence the looser bound for that case.
+    rz, ry = (5e-5, 5e-5) if cfg["use_norm"] else (1e-3, 1e-2)
+    z = oracle.ae_encode(sd, x, cfg)
+    assert z.shape == fx.t("z").shape
+    assert max_abs(z, fx.t("z")) < rz * fx.t("z").abs().max().item()
+    y = oracle.ae_decode(sd, fx.t("zin"), cfg)
+    assert y.shape == fx.t("y").shape
+    assert max_abs(y, fx.t("y")) < ry * fx.t("y").abs().max().item()
+
+
+@pytest.mark.parametrize("case", ["encoders_micro", "encoders_tiny", "encoders_base"])
+def test_encoders_match_reference(case):
+    fx = Fixture(case)
+    dcfg = configs.diffusion_config(fx.meta["config"])
+    z = fx.t("z")
+    if dcfg["encoder_time"] is not None:
+        sd = fx.state_dict("shapes_encoder_time")
+        got = oracle.encoder1d_forward(sd, z, dcfg["encoder_time"])
+        assert max_abs(got, fx.t("time_cond")) < 5e-5
+        # the scoped causal binding (base.gin:55): perturbing the future must not leak back
+        z2 = z.clone()
+        z2[..., z.shape[-1] // 2:] += 1.0
+        got2 = oracle.encoder1d_forward(sd, z2, dcfg["encoder_time"])
+        assert max_abs(got2[..., :z.shape[-1] // 2], got[..., :z.shape[-1] // 2]) == 0.0
+    sd = fx.state_dict("shapes_encoder", seed_offset=1)
+    got = oracle.ecapa_forward(sd, z[..., :z.shape[-1] // 2], dcfg["encoder"])
+    assert max_abs(got, fx.t("cond")) < 5e-5
