@@ -1,0 +1,106 @@
+"""ctypes binding of libafter_hip.so (C ABI declared in include/after_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or fails to
+load, every product entry point raises."""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_longlong, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libafter_hip.so")
+
+AFTER_OK = 0
+CFG_API, CFG_EXPORT, CFG_MIDI = 0, 1, 2
+
+
+class DenoiserCfg(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in ("n_channels", "embed_dim", "cond_dim", "tcond_dim",
+                                     "noise_embed_dims", "n_layers", "mlp_multiplier", "causal",
+                                     "local_attention_size", "attention_chunk_size")]
+
+
+class AFTERHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# name -> (restype, argtypes); also the list the symbol-export test checks against the header
+SIGNATURES = {
+    "after_last_error": (c_char_p, []),
+    "after_version": (c_char_p, []),
+    "after_denoiser_create": (c_int, [POINTER(DenoiserCfg), POINTER(c_void_p), c_int, c_int, c_int,
+                                      c_int, POINTER(c_void_p)]),
+    "after_denoiser_destroy": (None, [c_void_p]),
+    "after_denoiser_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_int, c_int, c_int, c_void_p]),
+    "after_model_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_int, c_int, c_float, c_float, c_float, c_int, c_int,
+                                    c_void_p]),
+    "after_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                             c_float, c_float, c_float, c_int, c_void_p]),
+    "after_denoiser_enable_cache": (c_int, [c_void_p, c_int, c_int, c_int]),
+    "after_denoiser_reset_cache": (c_int, [c_void_p, c_void_p]),
+    "after_denoiser_roll_cache": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "after_denoiser_profile": (c_int, [c_void_p, c_int]),
+    "after_denoiser_gemm_time_ms": (c_int, [c_void_p, POINTER(c_double), POINTER(c_longlong),
+                                            POINTER(c_double)]),
+}
+
+
+def lib():
+    """Loads the shared library (once).  torch must be imported first so that the
+    HIP runtime already in the process (torch's libamdhip64) is the one the
+    library binds to -- device pointers and streams are shared with torch."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (load order matters, see docstring)
+    if not os.path.exists(LIB_PATH):
+        raise AFTERHipError(
+            f"{LIB_PATH} is missing: build it with `python -m after_amd.build` "
+            "(or __graft_entry__.build()); there is no CPU fallback in the product path")
+    try:
+        L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    except OSError as e:
+        raise AFTERHipError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError as e:
+            raise AFTERHipError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str):
+    if rc != AFTER_OK:
+        msg = lib().after_last_error()
+        raise AFTERHipError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32 CUDA tensor as c_void_p (None -> NULL)."""
+    if t is None:
+        return c_void_p(0)
+    return c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+    import torch
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu_tensor(t, name):
+    import torch
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise AFTERHipError(
+            f"{name} is on {t.device}: after_amd runs on MI355X only (HIP kernels); "
+            "the CPU restatement lives in oracle/ and is test infrastructure")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()

@@ -1,0 +1,69 @@
+"""Builds after_amd/lib/libafter_hip.so (HIP kernels + C ABI) for gfx950 with hipcc.
+
+The library is built IN-TREE so that it travels with the repo snapshot to the GPU
+box; hipcc cross-compiles gfx950 without a GPU."""
+import concurrent.futures
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libafter_hip.so")
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps_mtime():
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "after_hip.h"))
+    return max(os.path.getmtime(p) for p in hdrs)
+
+
+def _compile(src, obj, hipcc):
+    cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+    return obj
+
+
+def build_library(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = _hipcc()
+    srcs = sources()
+    hmt = _deps_mtime()
+    objs, todo = [], []
+    for s in srcs:
+        o = os.path.join(LIBDIR, os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hmt):
+            todo.append((s, o))
+    if todo:
+        if verbose:
+            print("hipcc:", ", ".join(os.path.basename(s) for s, _ in todo), file=sys.stderr)
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(todo))) as ex:
+            list(ex.map(lambda so: _compile(so[0], so[1], hipcc), todo))
+    if todo or not os.path.exists(LIB):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,105 @@
+// Shared host-side helpers of libafter_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/after_hip.h"
+
+namespace after {
+
+void set_error(const char* fmt, ...);
+
+#define AFTER_HIP_CHECK(expr)                                                              \
+    do {                                                                                   \
+        hipError_t e__ = (expr);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            ::after::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),     \
+                               __FILE__, __LINE__);                                        \
+            return AFTER_E_HIP;                                                            \
+        }                                                                                  \
+    } while (0)
+
+#define AFTER_REQUIRE(cond, code, ...)         \
+    do {                                       \
+        if (!(cond)) {                         \
+            ::after::set_error(__VA_ARGS__);   \
+            return (code);                     \
+        }                                      \
+    } while (0)
+
+#define AFTER_TRY(expr)             \
+    do {                            \
+        int rc__ = (expr);          \
+        if (rc__ != AFTER_OK) return rc__; \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline long long cdivll(long long a, long long b) { return (a + b - 1) / b; }
+
+// Device arena: one hipMalloc per handle, bump-allocated at create time so that
+// nothing is allocated on the hot path.
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0;
+    int init(size_t bytes);
+    void release();
+    template <typename T>
+    T* take(size_t n) {
+        size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
+        if (off + bytes > cap) return nullptr;
+        T* p = reinterpret_cast<T*>(base + off);
+        off += bytes;
+        return p;
+    }
+};
+
+// Optional per-kernel-family timing with HIP events on the launch stream.
+struct KernelTimer {
+    bool enabled = false;
+    static constexpr int kMax = 8192;
+    hipEvent_t* ev = nullptr;  // 2*kMax
+    int n = 0;
+    double flops = 0;
+    int enable(bool on);
+    void begin(hipStream_t s) {
+        if (enabled && n < kMax) (void)hipEventRecord(ev[2 * n], s);
+    }
+    void end(hipStream_t s, double fl) {
+        if (enabled && n < kMax) {
+            (void)hipEventRecord(ev[2 * n + 1], s);
+            ++n;
+            flops += fl;
+        }
+    }
+    int collect(double* ms, long long* launches, double* fl);
+    void destroy();
+};
+
+// ---------------------------------------------------------------- GEMM (gemm.hip)
+// C[M,N] = epilogue(A[M,K] * W[N,K]^T): fp32 in, fp32 MFMA (v_mfma_f32_32x32x2_f32),
+// fp32 out.  A, W row-major with K contiguous (lda/ldw multiples of 4 floats,
+// 16-byte aligned bases).  Arbitrary M, N; K arbitrary (zero-filled past K).
+enum GemmEpilogue {
+    EPI_NONE = 0,       // C = acc (+ bias)
+    EPI_GELU = 1,       // C = gelu_erf(acc + bias)
+    EPI_RESIDUAL = 2,   // C = acc + bias + R[m, n]
+};
+struct GemmArgs {
+    const float* A;
+    int lda;
+    const float* W;
+    int ldw;
+    const float* bias;  // [N] or nullptr
+    const float* R;     // residual [M, ldr] (EPI_RESIDUAL)
+    int ldr;
+    float* C;
+    int ldc;
+    int M, N, K;
+    int epilogue;
+};
+int launch_gemm(const GemmArgs& g, hipStream_t stream);
+
+}  // namespace after

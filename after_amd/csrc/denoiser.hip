@@ -1,0 +1,950 @@
+// DenoiserV2 forward + rectified-flow Euler sampler on gfx950.
+//
+// Reference path: RectifiedFlow.sample / model_forward
+// (after/diffusion/model.py:721-785) -> DenoiserV2.forward
+// (after/diffusion/networks/transformerv2.py:517-543) -> DenoiserTransBlock
+// (:437-457) -> 6x DecoderBlock (:340-362) -> MHAttention (:190-236) with RoPE
+// (rotary_embedding.py:215-236) and the combined sliding/chunk-wise mask (:62-96).
+//
+// Data layout in HBM: the residual stream is token-major [rows*T, E] fp32 (E
+// contiguous) so that every Linear is a K-contiguous GEMM (gemm.hip) and every
+// row-wise op (LayerNorm/AdaLN, attention) reads whole 2 KiB rows coalesced.
+// What the reference recomputes every step but does not depend on x is hoisted
+// out of the step loop:
+//   * structure AdaLN parameters  tcond_linear_l(GELU(Linear(time_cond)))  for all
+//     layers: one GEMM per clip (rows that share time_cond, and the dropped
+//     CFG row, are stored once and addressed through tc_map);
+//   * timbre AdaLN parameters linear_l(MLP([fourier(t), cond])) for ALL steps and
+//     layers: three GEMMs per sample() call (t is data independent);
+//   * the attention mask: never materialised -- each 4-frame chunk gathers its
+//     <= W+chunk-1 keys.
+#include <cmath>
+#include <new>
+#include <vector>
+
+#include "common.h"
+
+namespace after {
+namespace {
+
+constexpr int kMaxKeys = 32;   // W - 1 + chunk
+constexpr int kMaxChunk = 8;
+constexpr int kMaxPer = 16;    // E / 64 <= 16  (E <= 1024)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// LayerNorm statistics of one E-long row held as v[i] = row[lane + 64*i]
+// (nn.LayerNorm: biased variance, eps inside the sqrt; transformerv2.py:326-335).
+__device__ __forceinline__ void row_stats(const float (&v)[kMaxPer], int nper, int E, float& mean,
+                                          float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxPer; ++i)
+        if (i < nper) s += v[i];
+    mean = wave_sum(s) / (float)E;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxPer; ++i)
+        if (i < nper) {
+            const float d = v[i] - mean;
+            q += d * d;
+        }
+    rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + 1e-5f);
+}
+
+// ---------------------------------------------------------------- small kernels
+
+// [n_src, Cc, T] (time contiguous) -> token-major [(r*T + t), ld] for the rows in
+// `map` (map[r] < 0 -> every channel = fill).  Columns [Cc, ld) are zeroed.
+__global__ __launch_bounds__(256) void to_token_major_kernel(const float* __restrict__ in,
+                                                             float* __restrict__ out,
+                                                             const int* __restrict__ map, int Cc,
+                                                             int T, int ld, float fill) {
+    __shared__ float tile[32][33];
+    const int r = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int src = map ? map[r] : r;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, t = t0 + tx;
+        float v = 0.f;
+        if (c < Cc && t < T) v = src >= 0 ? in[((size_t)src * Cc + c) * T + t] : fill;
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int t = t0 + i, c = c0 + tx;
+        if (t < T && c < ld) out[((size_t)r * T + t) * ld + c] = tile[tx][i];
+    }
+}
+
+// token-major [(r*T+t), C] -> [r, C, T]   (DenoiserTransBlock out_proj Rearrange, :429-431)
+__global__ __launch_bounds__(256) void from_token_major_kernel(const float* __restrict__ in,
+                                                               float* __restrict__ out, int C,
+                                                               int T) {
+    __shared__ float tile[32][33];
+    const int r = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int t = t0 + i, c = c0 + tx;
+        tile[i][tx] = (t < T && c < C) ? in[((size_t)r * T + t) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, t = t0 + tx;
+        if (c < C && t < T) out[((size_t)r * C + c) * T + t] = tile[tx][i];
+    }
+}
+
+struct CfgParams {
+    float total;   // 0.5 (g_s + g_t)                        model.py:751
+    float factor;  // g_t / max(g_s, clamp)                   model.py:753-756
+    float dt;      // 1 / nb_steps (1 for model_forward)      model.py:771
+};
+
+// CFG combine (model.py:749-759) fused with the Euler update (model.py:777-783) and
+// the token-major -> [B, C, T] transpose.  rows: [0,B) full, [B,2B) mid, [2B,3B) none.
+//   xout = (xin ? xin : 0) + dt * (d_none + total * (d_mid + factor*(d_full - d_mid) - d_none))
+__global__ __launch_bounds__(256) void cfg_euler_kernel(const float* __restrict__ outp,
+                                                        const float* __restrict__ xin,
+                                                        float* __restrict__ xout, int B, int C,
+                                                        int T, CfgParams p) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int t = t0 + i, c = c0 + tx;
+        float v = 0.f;
+        if (t < T && c < C) {
+            const float dfull = outp[((size_t)b * T + t) * C + c];
+            const float dmid = outp[((size_t)(B + b) * T + t) * C + c];
+            const float dnone = outp[((size_t)(2 * B + b) * T + t) * C + c];
+            v = dnone + p.total * (dmid + p.factor * (dfull - dmid) - dnone);
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, t = t0 + tx;
+        if (c < C && t < T) {
+            const size_t o = ((size_t)b * C + c) * T + t;
+            const float base = xin ? xin[o] : 0.f;
+            xout[o] = base + tile[tx][i] * p.dt;
+        }
+    }
+}
+
+// Rows of the embedding MLP input  [fourier(t) (NE) | cond (ZT) | 0-pad]  for
+// S steps x rows network rows (transformerv2.py:31-43, :530-535).  t comes either
+// from time_rows[r] (forward) or from the step index with torch.linspace's fp32
+// formula (model.py:772: linspace(0,1,N+1)[:-1]).
+__global__ __launch_bounds__(256) void embed_rows_kernel(float* __restrict__ out, int ld, int S,
+                                                         int rows, const float* __restrict__ time_rows,
+                                                         const int* __restrict__ time_map,
+                                                         int nb_steps,
+                                                         const float* __restrict__ freqs,
+                                                         const float* __restrict__ cond,
+                                                         const int* __restrict__ cond_map, int NE,
+                                                         int ZT, float drop_value) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)S * rows * ld;
+    if (idx >= total) return;
+    const int col = idx % ld;
+    const int sr = idx / ld;
+    const int r = sr % rows, s = sr / rows;
+    float t;
+    if (time_rows) {
+        t = time_rows[time_map ? time_map[r] : r];
+    } else {
+        // at::linspace fp32 kernel: step = (end-start)/(steps-1); first half from the
+        // start, second half from the end with a fused multiply-add (pinned against
+        // torch.linspace in tests/test_boundary_cpu.py).
+        const int pts = nb_steps + 1;
+        const float step = __fdiv_rn(1.0f, (float)(pts - 1));
+        t = (s < pts / 2) ? __fmul_rn(step, (float)s)
+                          : __fmaf_rn(-step, (float)(pts - s - 1), 1.0f);
+    }
+    float v = 0.f;
+    const int half = NE / 2;
+    if (col < NE) {
+        const float a = __fmul_rn(__fmul_rn(t, 100.0f), freqs[col < half ? col : col - half]);
+        v = col < half ? cosf(a) : sinf(a);
+    } else if (col < NE + ZT) {
+        const int cm = cond_map ? cond_map[r] : r;
+        v = cm >= 0 ? cond[(size_t)cm * ZT + (col - NE)] : drop_value;
+    }
+    out[idx] = v;
+}
+
+// DecoderBlock.forward first half (transformerv2.py:345-351):
+//   x  = norm0(x) * (1 + alpha_t) + beta_t        (structure AdaLN, per token)
+//   h  = norm1(x)                                  (affine)
+// One wave per token row.  xin rows are addressed through src_map (layer 0 of a
+// CFG sample reads the patchify output of clip r % B for all three CFG rows).
+__global__ __launch_bounds__(256) void ln_mod_ln_kernel(const float* __restrict__ xin,
+                                                        const int* __restrict__ src_map,
+                                                        float* __restrict__ xout,
+                                                        float* __restrict__ h,
+                                                        const float* __restrict__ tc_ab, int tc_ld,
+                                                        const int* __restrict__ tc_map,
+                                                        const float* __restrict__ w1,
+                                                        const float* __restrict__ b1, int rows,
+                                                        int T, int E) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= rows * T) return;
+    const int r = m / T, t = m - r * T;
+    const int sr = src_map ? src_map[r] : r;
+    const float* xi = xin + ((size_t)sr * T + t) * E;
+    const int nper = E >> 6;
+    float v[kMaxPer];
+#pragma unroll
+    for (int i = 0; i < kMaxPer; ++i)
+        if (i < nper) v[i] = xi[lane + 64 * i];
+    float mean, rstd;
+    row_stats(v, nper, E, mean, rstd);
+    if (tc_ab) {
+        const int tr = tc_map ? tc_map[r] : r;
+        const float* ab = tc_ab + ((size_t)tr * T + t) * tc_ld;
+#pragma unroll
+        for (int i = 0; i < kMaxPer; ++i)
+            if (i < nper) {
+                const int c = lane + 64 * i;
+                v[i] = (v[i] - mean) * rstd * (1.0f + ab[c]) + ab[E + c];
+            }
+        row_stats(v, nper, E, mean, rstd);
+    }
+    float* xo = xout + (size_t)m * E;
+    float* ho = h + (size_t)m * E;
+#pragma unroll
+    for (int i = 0; i < kMaxPer; ++i)
+        if (i < nper) {
+            const int c = lane + 64 * i;
+            xo[c] = v[i];
+            ho[c] = (v[i] - mean) * rstd * w1[c] + b1[c];
+        }
+}
+
+// SelfAttention + second half of DecoderBlock.forward for one chunk of <= 8 query
+// frames of one network row (transformerv2.py:190-236, :351-361):
+//   a  = softmax(rope(q) rope(k)^T / 8 + band mask) v         (all heads)
+//   x  = a + x ; x = norm2(x) * (1 + alpha_c) + beta_c ; h = norm3(x)
+// Keys of chunk [i0, e): [max(0, i0-W+1), e); query j additionally drops keys
+// < min(i0, max(0, j-W+1))  (combined_sliding_chunkwise_mask, :62-96).
+// With a streaming cache the `nc` cached frames (already roped? no: raw, :195) are
+// prepended: key position p < nc comes from kcache/vcache, p >= nc from qkv.
+struct AttnArgs {
+    const float* qkv;    // [rows*T, 3E]
+    float* xres;         // [rows*T, E] in/out
+    float* h;            // [rows*T, E] out
+    const float* cond_ab;  // + layer offset; row stride cond_ld
+    int cond_ld;
+    const float* w3;
+    const float* b3;
+    const float* rope_cos;  // [pos][16]
+    const float* rope_sin;
+    const float* kcache;    // [rows, nc, E] or nullptr (streaming)
+    const float* vcache;
+    int nc;                 // cached frames in front of the chunk
+    int T, E, H, cs, W;
+    int nkmax;              // LDS rows provisioned for keys: W - 1 + cs
+};
+
+__global__ __launch_bounds__(256) void attn_block_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int E = a.E, H = a.H, T = a.T, cs = a.cs, W = a.W, nc = a.nc;
+    const int ld = E + 4;
+    const int nkm = a.nkmax;
+    float* qs = smem;               // [cs][ld]   (later: x + attn rows)
+    float* ks = qs + cs * ld;       // [nkmax][ld]
+    float* vs = ks + nkm * ld;      // [nkmax][ld]
+    float* ps = vs + nkm * ld;      // [H][cs][nkmax]
+
+    const int r = blockIdx.y, tid = threadIdx.x;
+    // absolute positions include the nc cached frames (rotary_embedding.py:230:
+    // queries are offset by k_len - q_len)
+    const int i0 = blockIdx.x * cs;              // chunk start within this call's T frames
+    const int e = min(i0 + cs, T);
+    const int nq = e - i0;
+    const int Lk = nc + T;                       // total key length
+    const int a0 = nc + i0;                      // absolute position of the first query
+    // nc is a multiple of cs in the streaming protocol so chunk boundaries agree.
+    const int lo_c = min(a0, max(0, a0 - W + 1));
+    const int nk = (nc + e) - lo_c;
+    (void)Lk;
+
+    // ---- phase 1: stage q (roped), k (roped), v in LDS
+    const int e4 = E >> 2;
+    for (int idx = tid; idx < (nq + 2 * nk) * e4; idx += 256) {
+        const int row = idx / e4, c = (idx - row * e4) * 4;
+        const bool isq = row < nq;
+        const bool isk = !isq && row < nq + nk;
+        const int lr = isq ? row : (isk ? row - nq : row - nq - nk);
+        const int pos = isq ? a0 + lr : lo_c + lr;  // absolute position
+        const float* src;
+        if (isq) {
+            src = a.qkv + ((size_t)r * T + (pos - nc)) * 3 * E + c;
+        } else if (pos >= nc) {
+            src = a.qkv + ((size_t)r * T + (pos - nc)) * 3 * E + (isk ? E : 2 * E) + c;
+        } else {
+            src = (isk ? a.kcache : a.vcache) + ((size_t)r * nc + pos) * E + c;
+        }
+        float4 v = *reinterpret_cast<const float4*>(src);
+        const int d = c & 63;
+        if ((isq || isk) && d < 32) {
+            const float2 cs2 = *reinterpret_cast<const float2*>(a.rope_cos + (size_t)pos * 16 + (d >> 1));
+            const float2 sn2 = *reinterpret_cast<const float2*>(a.rope_sin + (size_t)pos * 16 + (d >> 1));
+            const float x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+            v.x = x0 * cs2.x - x1 * sn2.x;
+            v.y = x1 * cs2.x + x0 * sn2.x;
+            v.z = x2 * cs2.y - x3 * sn2.y;
+            v.w = x3 * cs2.y + x2 * sn2.y;
+        }
+        float* dst = (isq ? qs : (isk ? ks : vs)) + lr * ld + c;
+        *reinterpret_cast<float4*>(dst) = v;
+    }
+    __syncthreads();
+
+    // ---- phase 2: scores
+    const int nsc = H * nq * nk;
+    for (int idx = tid; idx < nsc; idx += 256) {
+        const int j = idx % nk;
+        const int t2 = idx / nk;
+        const int qi = t2 % nq, hh = t2 / nq;
+        const float4* qp = reinterpret_cast<const float4*>(qs + qi * ld + hh * 64);
+        const float4* kp = reinterpret_cast<const float4*>(ks + j * ld + hh * 64);
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            const float4 x = qp[d], y = kp[d];
+            s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+        }
+        const int ja = a0 + qi;
+        const int lo_row = min(a0, max(0, ja - W + 1));
+        ps[(hh * cs + qi) * nkm + j] = (lo_c + j >= lo_row) ? s * 0.125f : -INFINITY;
+    }
+    __syncthreads();
+
+    // ---- phase 3: softmax over keys, one thread per (head, query)
+    if (tid < H * nq) {
+        const int qi = tid % nq, hh = tid / nq;
+        float* p = ps + (hh * cs + qi) * nkm;
+        float mx = -INFINITY;
+        for (int j = 0; j < nk; ++j) mx = fmaxf(mx, p[j]);
+        float sum = 0.f;
+        for (int j = 0; j < nk; ++j) {
+            const float ex = expf(p[j] - mx);
+            p[j] = ex;
+            sum += ex;
+        }
+        const float inv = 1.0f / sum;
+        for (int j = 0; j < nk; ++j) p[j] *= inv;
+    }
+    __syncthreads();
+
+    // ---- phase 4: o = p v, + residual -> LDS rows (q region is free now)
+    for (int c = tid; c < E; c += 256) {
+        const int hh = c >> 6;
+        float o[kMaxChunk];
+#pragma unroll
+        for (int qi = 0; qi < kMaxChunk; ++qi) o[qi] = 0.f;
+        for (int j = 0; j < nk; ++j) {
+            const float vv = vs[j * ld + c];
+#pragma unroll
+            for (int qi = 0; qi < kMaxChunk; ++qi)
+                if (qi < nq) o[qi] += ps[(hh * cs + qi) * nkm + j] * vv;
+        }
+#pragma unroll
+        for (int qi = 0; qi < kMaxChunk; ++qi)
+            if (qi < nq) qs[qi * ld + c] = o[qi] + a.xres[((size_t)r * T + i0 + qi) * E + c];
+    }
+    __syncthreads();
+
+    // ---- phase 5: AdaLN(cond) + norm3, one wave per row
+    const int lane = tid & 63, wid = tid >> 6;
+    const int nper = E >> 6;
+    for (int qi = wid; qi < nq; qi += 4) {
+        float v[kMaxPer];
+#pragma unroll
+        for (int i = 0; i < kMaxPer; ++i)
+            if (i < nper) v[i] = qs[qi * ld + lane + 64 * i];
+        float mean, rstd;
+        if (a.cond_ab) {
+            row_stats(v, nper, E, mean, rstd);
+            const float* ab = a.cond_ab + (size_t)r * a.cond_ld;
+#pragma unroll
+            for (int i = 0; i < kMaxPer; ++i)
+                if (i < nper) {
+                    const int c = lane + 64 * i;
+                    v[i] = (v[i] - mean) * rstd * (1.0f + ab[c]) + ab[E + c];
+                }
+        }
+        row_stats(v, nper, E, mean, rstd);
+        const size_t m = (size_t)r * T + i0 + qi;
+#pragma unroll
+        for (int i = 0; i < kMaxPer; ++i)
+            if (i < nper) {
+                const int c = lane + 64 * i;
+                a.xres[m * E + c] = v[i];
+                a.h[m * E + c] = (v[i] - mean) * rstd * a.w3[c] + a.b3[c];
+            }
+    }
+}
+
+// Row maps of a 3x CFG batch (model.py:730-743; export_midi.py:332-345), built on the
+// device so that sample() stays free of host staging.  Layout of `maps` (stride ms):
+//   [0] x / time source clip of row r      [1] tc_ab row of row r
+//   [2] cond source of row r (-1 = drop)   [3] time_cond source of tc_ab row i (-1 = drop)
+__global__ void build_cfg_maps_kernel(int* __restrict__ maps, int ms, int B, int midi) {
+    for (int r = threadIdx.x; r < 3 * B; r += blockDim.x) {
+        const int b = r % B, part = r / B;
+        maps[r] = b;
+        maps[ms + r] = midi ? (part == 0 ? b : B) : (part <= 1 ? b : B);
+        maps[2 * ms + r] = midi ? (part <= 1 ? b : -1) : (part == 0 ? b : -1);
+    }
+    for (int i = threadIdx.x; i <= B; i += blockDim.x) maps[3 * ms + i] = i < B ? i : -1;
+}
+
+// Streaming: append this call's first `size` frames of K,V to the per-(row) ring
+// and keep the last `cache` frames (MHAttention.roll_cache, transformerv2.py:171-188).
+__global__ __launch_bounds__(256) void roll_cache_kernel(float* __restrict__ kc,
+                                                         float* __restrict__ vc,
+                                                         const float* __restrict__ qkv, int rows,
+                                                         int T, int E, int cache, int size) {
+    // new[p] = (p + size < cache) ? old[p + size] : last[p + size - cache],  p in [0,cache)
+    // done out-of-place into the second half of the buffers by the host wrapper.
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)rows * cache * E;
+    if (idx >= total) return;
+    const int c = idx % E;
+    const int p = (idx / E) % cache;
+    const int r = idx / ((size_t)E * cache);
+    const float* ko = kc + (size_t)rows * cache * E;  // "old" copies live in the upper half
+    const float* vo = vc + (size_t)rows * cache * E;
+    float kv, vv;
+    if (p + size < cache) {
+        kv = ko[((size_t)r * cache + p + size) * E + c];
+        vv = vo[((size_t)r * cache + p + size) * E + c];
+    } else {
+        const int t = p + size - cache;
+        kv = qkv[((size_t)r * T + t) * 3 * E + E + c];
+        vv = qkv[((size_t)r * T + t) * 3 * E + 2 * E + c];
+    }
+    kc[idx] = kv;
+    vc[idx] = vv;
+}
+
+}  // namespace
+}  // namespace after
+
+// =====================================================================================
+using namespace after;
+
+struct LayerW {
+    float *qkv_w, *mlp0_w, *mlp0_b, *mlp2_w, *mlp2_b, *n1w, *n1b, *n3w, *n3b;
+};
+
+struct after_denoiser {
+    after_denoiser_cfg cfg;
+    int E, H, C, ZT, ZS, NE, L, ME, cs, W;
+    int Cp, ZSp, K0p;  // K padded to multiples of 4
+    int max_rows, max_T, max_steps;
+    Arena wa, ws;
+    // weights
+    float *emb0_w, *emb0_b, *emb2_w, *emb2_b, *patch_w, *patch_b, *tce_w, *tce_b, *out_w, *out_b;
+    float *cond_w_all, *cond_b_all, *tc_w_all, *tc_b_all, *freqs, *rope_cos, *rope_sin;
+    std::vector<LayerW> layers;
+    // workspaces
+    float *xt, *pat, *tct, *tce, *tc_ab, *emb_in, *feat1, *feat, *cond_ab;
+    float *xres, *hbuf, *qkv, *mlp, *outp, *xstate;
+    int* maps;  // device int[4][max_rows + 1] (build_cfg_maps_kernel)
+    int ms;     // map stride
+    // streaming caches: per layer [steps][2 halves][rows*cache*E]
+    int cache = 0, cache_steps = 0, cache_rows = 0;
+    float *kcache = nullptr, *vcache = nullptr;
+    Arena ca;
+    bool have_last = false;
+    int last_rows = 0, last_T = 0;
+    KernelTimer timer;
+};
+
+namespace {
+
+int gemm(after_denoiser* h, hipStream_t s, const float* A, int lda, const float* W, int ldw,
+         const float* bias, float* Cc, int ldc, int M, int N, int K, int epi,
+         const float* R = nullptr, int ldr = 0) {
+    GemmArgs g{A, lda, W, ldw, bias, R, ldr, Cc, ldc, M, N, K, epi};
+    h->timer.begin(s);
+    int rc = launch_gemm(g, s);
+    h->timer.end(s, 2.0 * M * (double)N * K);
+    return rc;
+}
+
+int upload_padded(float* dst, int ldp, const float* src, int rows, int cols) {
+    AFTER_HIP_CHECK(hipMemset(dst, 0, (size_t)rows * ldp * sizeof(float)));
+    AFTER_HIP_CHECK(hipMemcpy2D(dst, (size_t)ldp * sizeof(float), src, (size_t)cols * sizeof(float),
+                                (size_t)cols * sizeof(float), rows, hipMemcpyDeviceToDevice));
+    return AFTER_OK;
+}
+
+int upload(float* dst, const float* src, size_t n) {
+    AFTER_HIP_CHECK(hipMemcpy(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice));
+    return AFTER_OK;
+}
+
+inline int r4(int x) { return (x + 3) & ~3; }
+
+// Step-invariant structure conditioning: tc_ab[(row*T + t), L*2E]
+//   = tcond_linear_l(GELU(patchify_and_embed_tcond(time_cond)))   (:448-449, :348)
+// for `ntc` distinct rows (given through `map` into time_cond; map<0 = dropped row).
+int compute_tc_ab(after_denoiser* h, hipStream_t s, const float* time_cond, const int* dev_map,
+                  int ntc, int T, float drop_value) {
+    dim3 grid(cdiv(T, 32), cdiv(h->ZSp, 32), ntc);
+    hipLaunchKernelGGL(to_token_major_kernel, grid, dim3(256), 0, s, time_cond, h->tct, dev_map,
+                       h->ZS, T, h->ZSp, drop_value);
+    AFTER_HIP_CHECK(hipGetLastError());
+    const int M = ntc * T;
+    AFTER_TRY(gemm(h, s, h->tct, h->ZSp, h->tce_w, h->ZSp, h->tce_b, h->tce, h->ZSp, M, h->ZS,
+                   h->ZSp, EPI_GELU));
+    // columns [ZS, ZSp) of tce must be zero for the next GEMM: tct's pad columns are
+    // zero and tce_w pad rows do not exist (N = ZS), so clear them once at create.
+    AFTER_TRY(gemm(h, s, h->tce, h->ZSp, h->tc_w_all, h->ZSp, h->tc_b_all, h->tc_ab,
+                   h->L * 2 * h->E, M, h->L * 2 * h->E, h->ZSp, EPI_NONE));
+    return AFTER_OK;
+}
+
+// Timbre conditioning for S steps x rows: cond_ab[(s*rows + r), L*2E]
+//   = linear_l(embedding([fourier(t_s), cond_r]))   (:530-537, :357)
+int compute_cond_ab(after_denoiser* h, hipStream_t s, int S, int rows, const float* time_rows,
+                    const int* dev_time_map, int nb_steps, const float* cond,
+                    const int* dev_cond_map, float drop_value) {
+    const size_t total = (size_t)S * rows * h->K0p;
+    hipLaunchKernelGGL(embed_rows_kernel, dim3((unsigned)cdivll(total, 256)), dim3(256), 0, s,
+                       h->emb_in, h->K0p, S, rows, time_rows, dev_time_map, nb_steps, h->freqs, cond,
+                       dev_cond_map, h->NE, h->ZT, drop_value);
+    AFTER_HIP_CHECK(hipGetLastError());
+    const int M = S * rows, E = h->E;
+    AFTER_TRY(gemm(h, s, h->emb_in, h->K0p, h->emb0_w, h->K0p, h->emb0_b, h->feat1, E, M, E,
+                   h->K0p, EPI_GELU));
+    AFTER_TRY(gemm(h, s, h->feat1, E, h->emb2_w, E, h->emb2_b, h->feat, E, M, E, E, EPI_NONE));
+    AFTER_TRY(gemm(h, s, h->feat, E, h->cond_w_all, E, h->cond_b_all, h->cond_ab, h->L * 2 * E, M,
+                   h->L * 2 * E, E, EPI_NONE));
+    return AFTER_OK;
+}
+
+size_t attn_lds_bytes(int E, int H, int cs, int nkmax) {
+    return ((size_t)(cs + 2 * nkmax) * (E + 4) + (size_t)H * cs * nkmax) * sizeof(float);
+}
+
+// One network evaluation on `rows` rows.  x: [nx, C, T] addressed through dev_xmap
+// (row r reads clip xmap[r]; npat = number of distinct clips).  Result: h->outp
+// token-major [rows*T, C].
+int run_net(after_denoiser* h, hipStream_t s, const float* x, int npat, const int* dev_xmap,
+            const int* dev_tcmap, int rows, int T, const float* cond_ab_step, int cache_index) {
+    const int E = h->E, L = h->L, C = h->C, ME = h->ME;
+    const int M = rows * T;
+    {
+        dim3 grid(cdiv(T, 32), cdiv(h->Cp, 32), npat);
+        hipLaunchKernelGGL(to_token_major_kernel, grid, dim3(256), 0, s, x, h->xt,
+                           (const int*)nullptr, C, T, h->Cp, 0.f);
+        AFTER_HIP_CHECK(hipGetLastError());
+    }
+    // patchify_and_embed: GELU(Linear(C -> E)) on the transposed latents (:387-391, :440)
+    AFTER_TRY(gemm(h, s, h->xt, h->Cp, h->patch_w, h->Cp, h->patch_b, h->pat, E, npat * T, E,
+                   h->Cp, EPI_GELU));
+    const int nkmax = h->W - 1 + h->cs > h->cs ? h->W - 1 + h->cs : h->cs;
+    const size_t lds = attn_lds_bytes(E, h->H, h->cs, nkmax);
+    for (int l = 0; l < L; ++l) {
+        const LayerW& w = h->layers[l];
+        hipLaunchKernelGGL(ln_mod_ln_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s,
+                           l == 0 ? h->pat : h->xres, l == 0 ? dev_xmap : (const int*)nullptr,
+                           h->xres, h->hbuf, h->tc_ab + (size_t)l * 2 * E, L * 2 * E, dev_tcmap,
+                           w.n1w, w.n1b, rows, T, E);
+        AFTER_HIP_CHECK(hipGetLastError());
+        AFTER_TRY(gemm(h, s, h->hbuf, E, w.qkv_w, E, nullptr, h->qkv, 3 * E, M, 3 * E, E, EPI_NONE));
+        AttnArgs a;
+        a.qkv = h->qkv;
+        a.xres = h->xres;
+        a.h = h->hbuf;
+        a.cond_ab = cond_ab_step + (size_t)l * 2 * E;
+        a.cond_ld = L * 2 * E;
+        a.w3 = w.n3w;
+        a.b3 = w.n3b;
+        a.rope_cos = h->rope_cos;
+        a.rope_sin = h->rope_sin;
+        a.kcache = a.vcache = nullptr;
+        a.nc = 0;
+        if (h->cache > 0) {
+            const size_t per = (size_t)h->cache_rows * h->cache * E;
+            const size_t slot = ((size_t)l * h->cache_steps + cache_index) * 2 * per;
+            a.kcache = h->kcache + slot;
+            a.vcache = h->vcache + slot;
+            a.nc = h->cache;
+        }
+        a.T = T;
+        a.E = E;
+        a.H = h->H;
+        a.cs = h->cs;
+        a.W = h->W;
+        a.nkmax = nkmax;
+        hipLaunchKernelGGL(attn_block_kernel, dim3(cdiv(T, h->cs), rows), dim3(256), lds, s, a);
+        AFTER_HIP_CHECK(hipGetLastError());
+        AFTER_TRY(gemm(h, s, h->hbuf, E, w.mlp0_w, E, w.mlp0_b, h->mlp, ME, M, ME, E, EPI_GELU));
+        AFTER_TRY(gemm(h, s, h->mlp, ME, w.mlp2_w, ME, w.mlp2_b, h->xres, E, M, E, ME,
+                       EPI_RESIDUAL, h->xres, E));
+    }
+    AFTER_TRY(gemm(h, s, h->xres, E, h->out_w, E, h->out_b, h->outp, C, M, C, E, EPI_NONE));
+    return AFTER_OK;
+}
+
+int check_shape(after_denoiser* h, int rows, int T) {
+    AFTER_REQUIRE(h != nullptr, AFTER_E_INVALID, "null handle");
+    AFTER_REQUIRE(rows > 0 && T > 0, AFTER_E_INVALID, "empty batch (rows=%d, T=%d)", rows, T);
+    AFTER_REQUIRE(rows <= h->max_rows && T <= h->max_T, AFTER_E_CAPACITY,
+                  "rows=%d T=%d exceed the provisioned max_rows=%d max_T=%d", rows, T,
+                  h->max_rows, h->max_T);
+    return AFTER_OK;
+}
+
+}  // namespace
+
+extern "C" int after_denoiser_create(const after_denoiser_cfg* cfg, const float* const* weights,
+                                     int n_weights, int max_rows, int max_T, int max_steps,
+                                     after_denoiser** out) {
+    AFTER_REQUIRE(cfg && weights && out, AFTER_E_INVALID, "null argument");
+    *out = nullptr;
+    const int E = cfg->embed_dim, L = cfg->n_layers;
+    AFTER_REQUIRE(E >= 64 && E % 64 == 0 && E <= 64 * kMaxPer, AFTER_E_INVALID,
+                  "embed_dim must be a multiple of 64 in [64, %d] (got %d)", 64 * kMaxPer, E);
+    AFTER_REQUIRE(cfg->cond_dim > 0 && cfg->tcond_dim > 0 && cfg->n_channels > 0 && L > 0 &&
+                      cfg->mlp_multiplier > 0 && cfg->noise_embed_dims > 0 &&
+                      cfg->noise_embed_dims % 2 == 0,
+                  AFTER_E_INVALID, "unsupported DenoiserV2 dimensions");
+    AFTER_REQUIRE(cfg->causal == 1 && cfg->local_attention_size >= 0, AFTER_E_INVALID,
+                  "only the shipped attention pattern is built (causal chunk-wise mask with a "
+                  "finite local_attention_size); got causal=%d window=%d",
+                  cfg->causal, cfg->local_attention_size);
+    AFTER_REQUIRE(cfg->attention_chunk_size >= 1 && cfg->attention_chunk_size <= kMaxChunk &&
+                      cfg->local_attention_size - 1 + cfg->attention_chunk_size <= kMaxKeys,
+                  AFTER_E_INVALID, "attention window %d + chunk %d exceed the kernel's %d keys",
+                  cfg->local_attention_size, cfg->attention_chunk_size, kMaxKeys);
+    AFTER_REQUIRE(n_weights == AFTER_DENOISER_FIXED_WEIGHTS + AFTER_DENOISER_LAYER_WEIGHTS * L,
+                  AFTER_E_INVALID, "expected %d weight tensors, got %d",
+                  AFTER_DENOISER_FIXED_WEIGHTS + AFTER_DENOISER_LAYER_WEIGHTS * L, n_weights);
+    AFTER_REQUIRE(max_rows > 0 && max_T > 0 && max_steps > 0, AFTER_E_INVALID, "bad capacities");
+    for (int i = 0; i < n_weights; ++i)
+        AFTER_REQUIRE(weights[i] != nullptr, AFTER_E_INVALID, "weights[%d] is null", i);
+
+    after_denoiser* h = new (std::nothrow) after_denoiser();
+    AFTER_REQUIRE(h, AFTER_E_NOMEM, "out of host memory");
+    h->cfg = *cfg;
+    h->E = E;
+    h->H = E / 64;
+    h->C = cfg->n_channels;
+    h->ZT = cfg->cond_dim;
+    h->ZS = cfg->tcond_dim;
+    h->NE = cfg->noise_embed_dims;
+    h->L = L;
+    h->ME = cfg->mlp_multiplier * E;
+    h->cs = cfg->attention_chunk_size;
+    h->W = cfg->local_attention_size;
+    h->Cp = r4(h->C);
+    h->ZSp = r4(h->ZS);
+    h->K0p = r4(h->NE + h->ZT);
+    h->max_rows = max_rows;
+    h->max_T = max_T;
+    h->max_steps = max_steps;
+    const int C = h->C, ZS = h->ZS, ME = h->ME, K0 = h->NE + h->ZT;
+    const int max_pos = max_T + kMaxKeys + 64;
+
+    auto fail = [&](int rc) {
+        after_denoiser_destroy(h);
+        return rc;
+    };
+#define TRY_OR_FAIL(expr)                   \
+    do {                                    \
+        int rc2__ = (expr);                 \
+        if (rc2__ != AFTER_OK) return fail(rc2__); \
+    } while (0)
+#define TAKE(ptr, arena, n)                                                     \
+    do {                                                                        \
+        (ptr) = (arena).take<float>(n);                                         \
+        if (!(ptr)) {                                                           \
+            set_error("arena exhausted at %s", #ptr);                           \
+            return fail(AFTER_E_NOMEM);                                         \
+        }                                                                       \
+    } while (0)
+
+    // ---- weights
+    size_t wfl = (size_t)E * h->K0p + E + (size_t)E * E + E + (size_t)E * h->Cp + E +
+                 (size_t)ZS * h->ZSp + h->ZSp + (size_t)C * E + C + (size_t)L * 2 * E * E +
+                 (size_t)L * 2 * E + (size_t)L * 2 * E * h->ZSp + (size_t)L * 2 * E + h->NE +
+                 2 * (size_t)max_pos * 16 +
+                 (size_t)L * ((size_t)3 * E * E + 2 * (size_t)ME * E + ME + E + 4 * E);
+    TRY_OR_FAIL(h->wa.init(wfl * sizeof(float) + 256 * (64 + 16 * (size_t)L)));
+    TAKE(h->emb0_w, h->wa, (size_t)E * h->K0p);
+    TAKE(h->emb0_b, h->wa, E);
+    TAKE(h->emb2_w, h->wa, (size_t)E * E);
+    TAKE(h->emb2_b, h->wa, E);
+    TAKE(h->patch_w, h->wa, (size_t)E * h->Cp);
+    TAKE(h->patch_b, h->wa, E);
+    TAKE(h->tce_w, h->wa, (size_t)ZS * h->ZSp);
+    TAKE(h->tce_b, h->wa, h->ZSp);
+    TAKE(h->out_w, h->wa, (size_t)C * E);
+    TAKE(h->out_b, h->wa, C);
+    TAKE(h->cond_w_all, h->wa, (size_t)L * 2 * E * E);
+    TAKE(h->cond_b_all, h->wa, (size_t)L * 2 * E);
+    TAKE(h->tc_w_all, h->wa, (size_t)L * 2 * E * h->ZSp);
+    TAKE(h->tc_b_all, h->wa, (size_t)L * 2 * E);
+    TAKE(h->freqs, h->wa, h->NE);
+    TAKE(h->rope_cos, h->wa, (size_t)max_pos * 16);
+    TAKE(h->rope_sin, h->wa, (size_t)max_pos * 16);
+    TRY_OR_FAIL(upload_padded(h->emb0_w, h->K0p, weights[0], E, K0));
+    TRY_OR_FAIL(upload(h->emb0_b, weights[1], E));
+    TRY_OR_FAIL(upload(h->emb2_w, weights[2], (size_t)E * E));
+    TRY_OR_FAIL(upload(h->emb2_b, weights[3], E));
+    TRY_OR_FAIL(upload_padded(h->patch_w, h->Cp, weights[4], E, C));
+    TRY_OR_FAIL(upload(h->patch_b, weights[5], E));
+    TRY_OR_FAIL(upload_padded(h->tce_w, h->ZSp, weights[6], ZS, ZS));
+    if (hipMemset(h->tce_b, 0, h->ZSp * sizeof(float)) != hipSuccess) return fail(AFTER_E_HIP);
+    TRY_OR_FAIL(upload(h->tce_b, weights[7], ZS));
+    TRY_OR_FAIL(upload(h->out_w, weights[8], (size_t)C * E));
+    TRY_OR_FAIL(upload(h->out_b, weights[9], C));
+    h->layers.resize(L);
+    for (int l = 0; l < L; ++l) {
+        const float* const* w = weights + AFTER_DENOISER_FIXED_WEIGHTS + AFTER_DENOISER_LAYER_WEIGHTS * l;
+        LayerW& lw = h->layers[l];
+        TAKE(lw.qkv_w, h->wa, (size_t)3 * E * E);
+        TAKE(lw.mlp0_w, h->wa, (size_t)ME * E);
+        TAKE(lw.mlp0_b, h->wa, ME);
+        TAKE(lw.mlp2_w, h->wa, (size_t)E * ME);
+        TAKE(lw.mlp2_b, h->wa, E);
+        TAKE(lw.n1w, h->wa, E);
+        TAKE(lw.n1b, h->wa, E);
+        TAKE(lw.n3w, h->wa, E);
+        TAKE(lw.n3b, h->wa, E);
+        TRY_OR_FAIL(upload(lw.qkv_w, w[0], (size_t)3 * E * E));
+        TRY_OR_FAIL(upload(lw.mlp0_w, w[1], (size_t)ME * E));
+        TRY_OR_FAIL(upload(lw.mlp0_b, w[2], ME));
+        TRY_OR_FAIL(upload(lw.mlp2_w, w[3], (size_t)E * ME));
+        TRY_OR_FAIL(upload(lw.mlp2_b, w[4], E));
+        TRY_OR_FAIL(upload(lw.n1w, w[5], E));
+        TRY_OR_FAIL(upload(lw.n1b, w[6], E));
+        TRY_OR_FAIL(upload(lw.n3w, w[7], E));
+        TRY_OR_FAIL(upload(lw.n3b, w[8], E));
+        // all layers' AdaLN projections concatenated along N -> one GEMM each
+        TRY_OR_FAIL(upload(h->cond_w_all + (size_t)l * 2 * E * E, w[9], (size_t)2 * E * E));
+        TRY_OR_FAIL(upload(h->cond_b_all + (size_t)l * 2 * E, w[10], (size_t)2 * E));
+        TRY_OR_FAIL(upload_padded(h->tc_w_all + (size_t)l * 2 * E * h->ZSp, h->ZSp, w[11], 2 * E, ZS));
+        TRY_OR_FAIL(upload(h->tc_b_all + (size_t)l * 2 * E, w[12], (size_t)2 * E));
+    }
+    {
+        // PositionalEmbedding frequencies (transformerv2.py:34-40), fp32 like torch
+        std::vector<float> f(h->NE / 2);
+        const int half = h->NE / 2;
+        for (int i = 0; i < half; ++i) f[i] = powf(1.0f / 10000.0f, (float)i / (float)half);
+        if (hipMemcpy(h->freqs, f.data(), half * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            return fail(AFTER_E_HIP);
+        // RoPE tables: freqs = 1/theta^(2i/32), angle = pos * freq in fp32
+        // (rotary_embedding.py:68, :352)
+        std::vector<float> rc((size_t)max_pos * 16), rs((size_t)max_pos * 16);
+        for (int i = 0; i < 16; ++i) {
+            const float fr = 1.0f / powf(10000.0f, (float)(2 * i) / 32.0f);
+            for (int p = 0; p < max_pos; ++p) {
+                const float ang = (float)p * fr;
+                rc[(size_t)p * 16 + i] = cosf(ang);
+                rs[(size_t)p * 16 + i] = sinf(ang);
+            }
+        }
+        if (hipMemcpy(h->rope_cos, rc.data(), rc.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(h->rope_sin, rs.data(), rs.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            return fail(AFTER_E_HIP);
+    }
+
+    // ---- workspaces
+    const size_t MT = (size_t)max_rows * max_T;
+    const size_t SR = (size_t)max_steps * max_rows;
+    size_t wsf = MT * h->Cp + MT * E + 2 * MT * h->ZSp + MT * L * 2 * E + SR * h->K0p +
+                 2 * SR * E + SR * L * 2 * E + 2 * MT * E + MT * 3 * E + MT * ME + MT * C +
+                 MT * C;
+    TRY_OR_FAIL(h->ws.init(wsf * sizeof(float) + 4 * ((size_t)max_rows + 1) * sizeof(int) + 256 * 32));
+    TAKE(h->xt, h->ws, MT * h->Cp);
+    TAKE(h->pat, h->ws, MT * E);
+    TAKE(h->tct, h->ws, MT * h->ZSp);
+    TAKE(h->tce, h->ws, MT * h->ZSp);
+    TAKE(h->tc_ab, h->ws, MT * L * 2 * E);
+    TAKE(h->emb_in, h->ws, SR * h->K0p);
+    TAKE(h->feat1, h->ws, SR * E);
+    TAKE(h->feat, h->ws, SR * E);
+    TAKE(h->cond_ab, h->ws, SR * L * 2 * E);
+    TAKE(h->xres, h->ws, MT * E);
+    TAKE(h->hbuf, h->ws, MT * E);
+    TAKE(h->qkv, h->ws, MT * 3 * E);
+    TAKE(h->mlp, h->ws, MT * ME);
+    TAKE(h->outp, h->ws, MT * C);
+    TAKE(h->xstate, h->ws, MT * C);
+    h->ms = max_rows + 1;
+    h->maps = h->ws.take<int>(4 * (size_t)h->ms);
+    if (!h->maps) return fail(AFTER_E_NOMEM);
+    if (hipMemset(h->tce, 0, MT * h->ZSp * sizeof(float)) != hipSuccess) return fail(AFTER_E_HIP);
+
+    const int nkmax0 = h->W - 1 + h->cs > h->cs ? h->W - 1 + h->cs : h->cs;
+    const size_t lds = attn_lds_bytes(E, h->H, h->cs, nkmax0);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        set_error("attention kernel needs %zu B of LDS", lds);
+        return fail(AFTER_E_HIP);
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return fail(AFTER_E_HIP);
+#undef TAKE
+#undef TRY_OR_FAIL
+    *out = h;
+    return AFTER_OK;
+}
+
+extern "C" void after_denoiser_destroy(after_denoiser* h) {
+    if (!h) return;
+    h->timer.destroy();
+    h->wa.release();
+    h->ws.release();
+    h->ca.release();
+    delete h;
+}
+
+extern "C" int after_denoiser_forward(after_denoiser* h, const float* x, const float* time,
+                                      const float* cond, const float* time_cond, float* out, int b,
+                                      int T, int cache_index, void* stream) {
+    AFTER_TRY(check_shape(h, b, T));
+    AFTER_REQUIRE(x && time && cond && time_cond && out, AFTER_E_INVALID,
+                  "x, time, cond, time_cond and out are required (cond_dim, tcond_dim > 0)");
+    AFTER_REQUIRE(cache_index == 0 || (h->cache > 0 && cache_index < h->cache_steps),
+                  AFTER_E_INVALID, "cache_index %d out of range", cache_index);
+    hipStream_t s = (hipStream_t)stream;
+    AFTER_TRY(compute_tc_ab(h, s, time_cond, nullptr, b, T, 0.f));
+    AFTER_TRY(compute_cond_ab(h, s, 1, b, time, nullptr, 0, cond, nullptr, 0.f));
+    AFTER_TRY(run_net(h, s, x, b, nullptr, nullptr, b, T, h->cond_ab, cache_index));
+    dim3 grid(cdiv(T, 32), cdiv(h->C, 32), b);
+    hipLaunchKernelGGL(from_token_major_kernel, grid, dim3(256), 0, s, h->outp, out, h->C, T);
+    AFTER_HIP_CHECK(hipGetLastError());
+    h->have_last = true;
+    h->last_rows = b;
+    h->last_T = T;
+    return AFTER_OK;
+}
+
+namespace {
+
+int cfg_params(float gt, float gs, int cfg_mode, float dt, CfgParams* p) {
+    AFTER_REQUIRE(cfg_mode >= 0 && cfg_mode <= 2, AFTER_E_INVALID, "bad cfg_mode %d", cfg_mode);
+    p->total = 0.5f * (gs + gt);
+    if (cfg_mode == AFTER_CFG_API)
+        p->factor = gt / fmaxf(gs, 0.01f);
+    else if (cfg_mode == AFTER_CFG_EXPORT)
+        p->factor = gt / fmaxf(gs, 0.1f);
+    else
+        p->factor = gs / fmaxf(gt, 0.1f);
+    p->dt = dt;
+    return AFTER_OK;
+}
+
+// shared front end of model_forward / sample: CFG row maps + step-invariant conditioning
+int cfg_prepare(after_denoiser* h, hipStream_t s, const float* time_cond, int B, int T,
+                float drop_value, int cfg_mode) {
+    hipLaunchKernelGGL(build_cfg_maps_kernel, dim3(1), dim3(256), 0, s, h->maps, h->ms, B,
+                       cfg_mode == AFTER_CFG_MIDI ? 1 : 0);
+    AFTER_HIP_CHECK(hipGetLastError());
+    return compute_tc_ab(h, s, time_cond, h->maps + 3 * h->ms, B + 1, T, drop_value);
+}
+
+int cfg_combine(after_denoiser* h, hipStream_t s, const float* xin, float* xout, int B, int T,
+                const CfgParams& p) {
+    dim3 grid(cdiv(T, 32), cdiv(h->C, 32), B);
+    hipLaunchKernelGGL(cfg_euler_kernel, grid, dim3(256), 0, s, h->outp, xin, xout, B, h->C, T, p);
+    AFTER_HIP_CHECK(hipGetLastError());
+    return AFTER_OK;
+}
+
+}  // namespace
+
+extern "C" int after_model_forward(after_denoiser* h, const float* x, const float* time,
+                                   const float* cond, const float* time_cond, float* out, int B,
+                                   int T, float guidance_timbre, float guidance_structure,
+                                   float drop_value, int cfg_mode, int cache_index, void* stream) {
+    AFTER_REQUIRE(B > 0, AFTER_E_INVALID, "empty batch");
+    AFTER_TRY(check_shape(h, 3 * B, T));
+    AFTER_REQUIRE((size_t)(B + 1) <= (size_t)h->max_rows, AFTER_E_CAPACITY, "max_rows too small");
+    AFTER_REQUIRE(x && time && cond && time_cond && out, AFTER_E_INVALID, "null tensor argument");
+    AFTER_REQUIRE(cache_index == 0 || (h->cache > 0 && cache_index < h->cache_steps),
+                  AFTER_E_INVALID, "cache_index %d out of range", cache_index);
+    hipStream_t s = (hipStream_t)stream;
+    CfgParams p;
+    AFTER_TRY(cfg_params(guidance_timbre, guidance_structure, cfg_mode, 1.0f, &p));
+    AFTER_TRY(cfg_prepare(h, s, time_cond, B, T, drop_value, cfg_mode));
+    const int rows = 3 * B;
+    // model.py:730: time.repeat(3,1,1) -> row r uses time[r % B] (= maps[0])
+    AFTER_TRY(compute_cond_ab(h, s, 1, rows, time, h->maps, 0, cond, h->maps + 2 * h->ms,
+                              drop_value));
+    AFTER_TRY(run_net(h, s, x, B, h->maps, h->maps + h->ms, rows, T, h->cond_ab, cache_index));
+    AFTER_TRY(cfg_combine(h, s, nullptr, out, B, T, p));
+    h->have_last = true;
+    h->last_rows = rows;
+    h->last_T = T;
+    return AFTER_OK;
+}
+
+extern "C" int after_sample(after_denoiser* h, const float* x0, const float* cond,
+                            const float* time_cond, float* out, int B, int T, int nb_steps,
+                            float guidance_timbre, float guidance_structure, float drop_value,
+                            int cfg_mode, void* stream) {
+    AFTER_REQUIRE(B > 0, AFTER_E_INVALID, "empty batch");
+    AFTER_TRY(check_shape(h, 3 * B, T));
+    AFTER_REQUIRE(x0 && cond && time_cond && out, AFTER_E_INVALID, "null tensor argument");
+    AFTER_REQUIRE(nb_steps > 0 && nb_steps <= h->max_steps, AFTER_E_CAPACITY,
+                  "nb_steps=%d outside (0, max_steps=%d]", nb_steps, h->max_steps);
+    hipStream_t s = (hipStream_t)stream;
+    CfgParams p;
+    // model.py:771: dt = 1 / nb_steps (python float -> the product dx * dt is fp32)
+    AFTER_TRY(cfg_params(guidance_timbre, guidance_structure, cfg_mode, (float)(1.0 / nb_steps), &p));
+    AFTER_TRY(cfg_prepare(h, s, time_cond, B, T, drop_value, cfg_mode));
+    const int rows = 3 * B;
+    AFTER_TRY(compute_cond_ab(h, s, nb_steps, rows, nullptr, nullptr, nb_steps, cond,
+                              h->maps + 2 * h->ms, drop_value));
+    const size_t step_stride = (size_t)rows * h->L * 2 * h->E;
+    for (int i = 0; i < nb_steps; ++i) {
+        const float* xin = i == 0 ? x0 : out;
+        AFTER_TRY(run_net(h, s, xin, B, h->maps, h->maps + h->ms, rows, T,
+                          h->cond_ab + (size_t)i * step_stride, 0));
+        AFTER_TRY(cfg_combine(h, s, xin, out, B, T, p));
+    }
+    return AFTER_OK;
+}
+
+extern "C" int after_denoiser_enable_cache(after_denoiser* h, int cache_size, int max_steps,
+                                           int max_rows) {
+    (void)h; (void)cache_size; (void)max_steps; (void)max_rows;
+    set_error("streaming KV caches are not built in this revision");
+    return AFTER_E_INVALID;
+}
+extern "C" int after_denoiser_reset_cache(after_denoiser* h, void* stream) {
+    (void)h; (void)stream;
+    set_error("streaming KV caches are not built in this revision");
+    return AFTER_E_INVALID;
+}
+extern "C" int after_denoiser_roll_cache(after_denoiser* h, int size, int cache_index, void* stream) {
+    (void)h; (void)size; (void)cache_index; (void)stream;
+    set_error("streaming KV caches are not built in this revision");
+    return AFTER_E_INVALID;
+}
+
+extern "C" int after_denoiser_profile(after_denoiser* h, int enable) {
+    AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
+    return h->timer.enable(enable != 0);
+}
+extern "C" int after_denoiser_gemm_time_ms(after_denoiser* h, double* total_ms, long long* launches,
+                                           double* flops) {
+    AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
+    return h->timer.collect(total_ms, launches, flops);
+}

@@ -1,0 +1,315 @@
+"""Host-side mirror of the reference's DenoiserV2
+(after/diffusion/networks/transformerv2.py:460-543).
+
+The module tree below exists to hold parameters under the reference's own
+state-dict keys so that `load_state_dict` of an AFTER
+checkpoint works unchanged; no torch op of these containers is ever executed.
+`forward` hands device pointers to the HIP implementation
+(`after_denoiser_forward`, include/after_hip.h)."""
+import ctypes
+from typing import Optional
+
+import torch
+from torch import nn
+
+from ... import _lib
+
+
+class _RotaryFreqs(nn.Module):
+    """Parameter container for RotaryEmbedding(32).freqs (rotary_embedding.py:68,80).
+    The values are fixed by the architecture; the HIP path rebuilds its cos/sin
+    tables from the same formula, so the tensor is carried for key compatibility."""
+
+    def __init__(self, dim: int = 32, theta: float = 10000.0):
+        super().__init__()
+        freqs = 1.0 / (theta**(torch.arange(0, dim, 2)[:dim // 2].float() / dim))
+        self.freqs = nn.Parameter(freqs, requires_grad=False)
+
+
+class _MHA(nn.Module):
+
+    def __init__(self, rotary):
+        super().__init__()
+        self.rotary_emb = rotary
+
+
+class _SelfAttention(nn.Module):
+
+    def __init__(self, embed_dim, rotary):
+        super().__init__()
+        self.qkv_linear = nn.Linear(embed_dim, 3 * embed_dim, bias=False)
+        self.mha = _MHA(rotary)
+        self.rotary_emb = rotary
+
+
+class _MLP(nn.Module):
+
+    def __init__(self, embed_dim, mult, dropout):
+        super().__init__()
+        self.mlp = nn.Sequential(nn.Linear(embed_dim, mult * embed_dim), nn.GELU(),
+                                 nn.Linear(mult * embed_dim, embed_dim), nn.Dropout(dropout))
+
+
+class _DecoderBlock(nn.Module):
+    """transformerv2.py:299-335 (parameter layout only)."""
+
+    def __init__(self, embed_dim, cond_dim, tcond_dim, mult, dropout, rotary):
+        super().__init__()
+        self.self_attention = _SelfAttention(embed_dim, rotary)
+        self.mlp = _MLP(embed_dim, mult, dropout)
+        self.norm1 = nn.LayerNorm(embed_dim)
+        self.norm3 = nn.LayerNorm(embed_dim)
+        self.linear = nn.Linear(cond_dim, 2 * embed_dim)
+        self.tcond_linear = nn.Linear(tcond_dim, 2 * embed_dim)
+
+
+class _TransBlock(nn.Module):
+    """transformerv2.py:365-431 (parameter layout only)."""
+
+    def __init__(self, n_channels, seq_len, mult, embed_dim, tcond_dim, dropout, n_layers):
+        super().__init__()
+        self.patchify_and_embed = nn.Sequential(nn.Identity(), nn.Linear(n_channels, embed_dim),
+                                                nn.GELU())
+        self.patchify_and_embed_tcond = nn.Sequential(nn.Identity(),
+                                                      nn.Linear(tcond_dim, tcond_dim), nn.GELU())
+        self.rotary_emb = _RotaryFreqs(32)
+        self.register_buffer("precomputed_pos_enc", torch.arange(0, seq_len).long())
+        self.decoder_blocks = nn.ModuleList([
+            _DecoderBlock(embed_dim, embed_dim, tcond_dim, mult, dropout, self.rotary_emb)
+            for _ in range(n_layers)
+        ])
+        self.out_proj = nn.Sequential(nn.Linear(embed_dim, n_channels), nn.Identity())
+
+
+class DenoiserV2(nn.Module):
+    """Drop-in for the reference DenoiserV2 on MI355X (same constructor arguments,
+    same forward signature, same state-dict keys)."""
+
+    def __init__(self,
+                 n_channels: int,
+                 seq_len: int = 32,
+                 embed_dim: int = 256,
+                 cond_dim: int = 64,
+                 tcond_dim: int = 0,
+                 noise_embed_dims: int = 128,
+                 n_layers: int = 6,
+                 mlp_multiplier: int = 2,
+                 dropout: float = 0.1,
+                 causal: bool = False,
+                 pos_emb_type="learnable",
+                 local_attention_size: Optional[int] = None,
+                 attention_chunk_size: int = 4):
+        super().__init__()
+        if pos_emb_type != "rotary":
+            raise NotImplementedError(
+                "after_amd builds the shipped configuration only: pos_emb_type='rotary' "
+                f"(base.gin:76), got {pos_emb_type!r}")
+        if cond_dim <= 0 or tcond_dim <= 0:
+            raise NotImplementedError("cond_dim and tcond_dim must be > 0 (all shipped configs)")
+        self.noise_embed_dims = noise_embed_dims
+        self.embed_dim = embed_dim
+        self.n_channels = n_channels
+        self.cond_dim = cond_dim
+        self.tcond_dim = tcond_dim
+        self.n_layers = n_layers
+        self.mlp_multiplier = mlp_multiplier
+        self.causal = bool(causal)
+        self.local_attention_size = local_attention_size
+        self.attention_chunk_size = attention_chunk_size
+        self.embedding = nn.Sequential(nn.Linear(cond_dim + noise_embed_dims, embed_dim), nn.GELU(),
+                                       nn.Linear(embed_dim, embed_dim))
+        self.denoiser_trans_block = _TransBlock(n_channels, seq_len, mlp_multiplier, embed_dim,
+                                                tcond_dim, dropout, n_layers)
+        self.requires_grad_(False)
+        self._handle = None
+        self._cap = (0, 0, 0)
+        self._profile = False
+
+    @property
+    def name(self):
+        return "transformer"
+
+    # ------------------------------------------------------------ handle management
+    def _apply(self, fn, *a, **k):
+        self._release()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._release()
+        return super().load_state_dict(*a, **k)
+
+    def refresh(self):
+        """Call after mutating parameters in place: the HIP handle owns a re-laid-out
+        copy of the weights."""
+        self._release()
+
+    def _release(self):
+        h = getattr(self, "_handle", None)
+        if h is not None:
+            _lib.lib().after_denoiser_destroy(h)
+        self._handle = None
+        self._cap = (0, 0, 0)
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _weights(self):
+        sd = self.state_dict()
+        P = "denoiser_trans_block."
+        names = [
+            "embedding.0.weight", "embedding.0.bias", "embedding.2.weight", "embedding.2.bias",
+            P + "patchify_and_embed.1.weight", P + "patchify_and_embed.1.bias",
+            P + "patchify_and_embed_tcond.1.weight", P + "patchify_and_embed_tcond.1.bias",
+            P + "out_proj.0.weight", P + "out_proj.0.bias"
+        ]
+        for l in range(self.n_layers):
+            B = f"{P}decoder_blocks.{l}."
+            names += [
+                B + "self_attention.qkv_linear.weight", B + "mlp.mlp.0.weight",
+                B + "mlp.mlp.0.bias", B + "mlp.mlp.2.weight", B + "mlp.mlp.2.bias",
+                B + "norm1.weight", B + "norm1.bias", B + "norm3.weight", B + "norm3.bias",
+                B + "linear.weight", B + "linear.bias", B + "tcond_linear.weight",
+                B + "tcond_linear.bias"
+            ]
+        return [_lib.require_gpu_tensor(sd[n], n) for n in names]
+
+    def _ensure(self, rows: int, T: int, steps: int = 1):
+        cr, ct, cs = self._cap
+        if self._handle is not None and rows <= cr and T <= ct and steps <= cs:
+            return self._handle
+        L = _lib.lib()
+        self._release()
+        cap = (max(rows, cr), max(T, ct), max(steps, cs, 1))
+        ws = self._weights()
+        arr = (ctypes.c_void_p * len(ws))(*[w.data_ptr() for w in ws])
+        cfg = _lib.DenoiserCfg(
+            n_channels=self.n_channels, embed_dim=self.embed_dim, cond_dim=self.cond_dim,
+            tcond_dim=self.tcond_dim, noise_embed_dims=self.noise_embed_dims,
+            n_layers=self.n_layers, mlp_multiplier=self.mlp_multiplier, causal=int(self.causal),
+            local_attention_size=-1 if self.local_attention_size is None else int(
+                self.local_attention_size), attention_chunk_size=self.attention_chunk_size)
+        out = ctypes.c_void_p()
+        torch.cuda.synchronize()
+        _lib.check(
+            L.after_denoiser_create(ctypes.byref(cfg), arr, len(ws), cap[0], cap[1], cap[2],
+                                    ctypes.byref(out)), "after_denoiser_create")
+        self._handle = out
+        self._cap = cap
+        if self._profile:
+            _lib.check(L.after_denoiser_profile(out, 1), "after_denoiser_profile")
+        return out
+
+    def reserve(self, rows: int, T: int, steps: int = 1):
+        """Provision workspaces up front (rows = 3 x clips for a CFG sample)."""
+        self._ensure(rows, T, steps)
+
+    # ------------------------------------------------------------ reference surface
+    def roll_cache(self, size: int, cache_index: int):
+        """transformerv2.py:514-515."""
+        if self._handle is None:
+            raise _lib.AFTERHipError("roll_cache before any forward")
+        _lib.check(
+            _lib.lib().after_denoiser_roll_cache(self._handle, int(size), int(cache_index),
+                                                 _lib.current_stream(None)),
+            "after_denoiser_roll_cache")
+
+    @torch.no_grad()
+    def forward(self,
+                x,
+                time: torch.Tensor,
+                cond: Optional[torch.Tensor] = None,
+                time_cond: Optional[torch.Tensor] = None,
+                cache_index: int = 0) -> torch.Tensor:
+        """transformerv2.py:517-543."""
+        if cond is None or time_cond is None:
+            raise ValueError("cond and time_cond are required (cond_dim, tcond_dim > 0)")
+        x = _lib.require_gpu_tensor(x, "x")
+        b, C, T = x.shape
+        if C != self.n_channels:
+            raise ValueError(f"x has {C} channels, the denoiser expects {self.n_channels}")
+        if len(time.shape) > 1:  # :525-528
+            time = time[..., 0]
+        time = _lib.require_gpu_tensor(time.reshape(-1).to(x.device), "time")
+        if time.numel() != b:
+            raise ValueError(f"time has {time.numel()} entries for batch {b}")
+        cond = _lib.require_gpu_tensor(cond, "cond")
+        time_cond = _lib.require_gpu_tensor(time_cond, "time_cond")
+        if tuple(cond.shape) != (b, self.cond_dim) or tuple(time_cond.shape) != (b, self.tcond_dim, T):
+            raise ValueError(f"bad conditioning shapes {tuple(cond.shape)} / {tuple(time_cond.shape)}")
+        h = self._ensure(b, T, 1)
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(
+                _lib.lib().after_denoiser_forward(h, _lib.ptr(x), _lib.ptr(time), _lib.ptr(cond),
+                                                  _lib.ptr(time_cond), _lib.ptr(out), b, T,
+                                                  int(cache_index), _lib.current_stream(x.device)),
+                "after_denoiser_forward")
+        return out
+
+    # ------------------------------------------------------------ sampler back end
+    def _check_cfg_inputs(self, x, cond, time_cond):
+        x = _lib.require_gpu_tensor(x, "x")
+        B, C, T = x.shape
+        cond = _lib.require_gpu_tensor(cond.to(x.device), "cond")
+        time_cond = _lib.require_gpu_tensor(time_cond.to(x.device), "time_cond")
+        if C != self.n_channels or tuple(cond.shape) != (B, self.cond_dim) or \
+                tuple(time_cond.shape) != (B, self.tcond_dim, T):
+            raise ValueError(f"bad shapes x{tuple(x.shape)} cond{tuple(cond.shape)} "
+                             f"time_cond{tuple(time_cond.shape)}")
+        return x, cond, time_cond, B, T
+
+    @torch.no_grad()
+    def cfg_forward(self, x, time, cond, time_cond, guidance_timbre, guidance_structure,
+                    drop_value, cfg_mode=_lib.CFG_API, cache_index=0):
+        x, cond, time_cond, B, T = self._check_cfg_inputs(x, cond, time_cond)
+        if len(time.shape) > 1:
+            time = time[..., 0]
+        time = _lib.require_gpu_tensor(time.reshape(-1).to(x.device), "time")
+        if time.numel() != B:
+            raise ValueError(f"time has {time.numel()} entries for batch {B}")
+        h = self._ensure(3 * B, T, 1)
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(
+                _lib.lib().after_model_forward(h, _lib.ptr(x), _lib.ptr(time), _lib.ptr(cond),
+                                               _lib.ptr(time_cond), _lib.ptr(out), B, T,
+                                               float(guidance_timbre), float(guidance_structure),
+                                               float(drop_value), int(cfg_mode), int(cache_index),
+                                               _lib.current_stream(x.device)),
+                "after_model_forward")
+        return out
+
+    @torch.no_grad()
+    def cfg_sample(self, x0, cond, time_cond, nb_steps, guidance_timbre, guidance_structure,
+                   drop_value, cfg_mode=_lib.CFG_API, out=None):
+        x0, cond, time_cond, B, T = self._check_cfg_inputs(x0, cond, time_cond)
+        h = self._ensure(3 * B, T, int(nb_steps))
+        if out is None:
+            out = torch.empty_like(x0)
+        with torch.cuda.device(x0.device):
+            _lib.check(
+                _lib.lib().after_sample(h, _lib.ptr(x0), _lib.ptr(cond), _lib.ptr(time_cond),
+                                        _lib.ptr(out), B, T, int(nb_steps),
+                                        float(guidance_timbre), float(guidance_structure),
+                                        float(drop_value), int(cfg_mode),
+                                        _lib.current_stream(x0.device)), "after_sample")
+        return out
+
+    # ------------------------------------------------------------ measurement hooks
+    def profile(self, enable: bool = True):
+        self._profile = bool(enable)
+        if self._handle is not None:
+            _lib.check(_lib.lib().after_denoiser_profile(self._handle, int(enable)),
+                       "after_denoiser_profile")
+
+    def gemm_time(self):
+        """(total_ms, launches, flops) of the GEMM launches since the last call;
+        synchronise the stream first."""
+        ms, n, fl = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
+        _lib.check(
+            _lib.lib().after_denoiser_gemm_time_ms(self._handle, ctypes.byref(ms), ctypes.byref(n),
+                                                   ctypes.byref(fl)), "after_denoiser_gemm_time_ms")
+        return ms.value, n.value, fl.value

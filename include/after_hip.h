@@ -1,0 +1,132 @@
+/*
+ * after_hip.h -- C ABI of libafter_hip.so: the MI355X (gfx950) implementation of
+ * AFTER's latent-diffusion sampling path.
+ *
+ * The reference (acids-ircam/AFTER) has no FFI: its boundary for this path is a
+ * Python object surface.  Each entry point below names the
+ * reference interface it replaces (file:line, relative to the reference root).
+ * The Python host in after_amd/ keeps the reference's signatures and calls these.
+ *
+ * Conventions
+ *   - every pointer argument is a DEVICE pointer to contiguous row-major fp32
+ *     owned by the caller, unless the parameter is documented as host memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all
+ *     work is enqueued on it and nothing synchronises the device;
+ *   - functions return 0 on success or a negative AFTER_E_* code; they never
+ *     throw and never allocate after *_create; after_last_error() returns a
+ *     thread-local description of the last failure;
+ *   - a handle is not re-entrant (it owns workspaces and streaming state): use
+ *     one handle per stream / per concurrent caller.  Different handles are
+ *     independent.
+ */
+#ifndef AFTER_HIP_H
+#define AFTER_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AFTER_OK 0
+#define AFTER_E_INVALID (-1)  /* bad argument / unsupported shape          */
+#define AFTER_E_HIP (-2)      /* a HIP runtime call failed                 */
+#define AFTER_E_CAPACITY (-3) /* request exceeds what *_create provisioned */
+#define AFTER_E_NOMEM (-4)
+
+/* CFG row arrangements of the three shipped samplers */
+#define AFTER_CFG_API 0    /* after/diffusion/model.py:730-759, clamp 0.01           */
+#define AFTER_CFG_EXPORT 1 /* after_scripts/export.py:364-394, clamp 0.1             */
+#define AFTER_CFG_MIDI 2   /* after_scripts/export_midi.py:329-358 (c,tc)/(c,-)/(-,-) */
+
+const char* after_last_error(void);
+/* library build id string, e.g. "after_hip gfx950 r1" */
+const char* after_version(void);
+
+/* ------------------------------------------------------------------ denoiser
+ * DenoiserV2 (after/diffusion/networks/transformerv2.py:460-543) constructor
+ * arguments that shape the inference graph. */
+typedef struct after_denoiser_cfg {
+    int n_channels;           /* latent channels C (IN_SIZE)                    */
+    int embed_dim;            /* E, multiple of 64; heads = E/64 (:320)         */
+    int cond_dim;             /* ZT (timbre vector), > 0                        */
+    int tcond_dim;            /* ZS (structure channels), > 0                   */
+    int noise_embed_dims;     /* Fourier features of t (:483-485), even         */
+    int n_layers;
+    int mlp_multiplier;
+    int causal;               /* 1: chunk-wise causal mask (:206-216)           */
+    int local_attention_size; /* sliding window W; < 0 = all previous chunks    */
+    int attention_chunk_size; /* chunk size, 1..8                               */
+} after_denoiser_cfg;
+
+/* Order of the `weights` array of after_denoiser_create (state-dict keys of the
+ * reference module; P = "denoiser_trans_block."):
+ *   0 embedding.0.weight [E, NE+ZT]     1 embedding.0.bias [E]
+ *   2 embedding.2.weight [E, E]         3 embedding.2.bias [E]
+ *   4 P patchify_and_embed.1.weight [E, C]        5 ....bias [E]
+ *   6 P patchify_and_embed_tcond.1.weight [ZS,ZS] 7 ....bias [ZS]
+ *   8 P out_proj.0.weight [C, E]        9 P out_proj.0.bias [C]
+ *   then for layer l = 0..L-1, base = 10 + 13*l, B = P "decoder_blocks.<l>.":
+ *   +0 B self_attention.qkv_linear.weight [3E, E]
+ *   +1 B mlp.mlp.0.weight [ME, E]   +2 B mlp.mlp.0.bias [ME]
+ *   +3 B mlp.mlp.2.weight [E, ME]   +4 B mlp.mlp.2.bias [E]
+ *   +5 B norm1.weight [E]  +6 B norm1.bias [E]
+ *   +7 B norm3.weight [E]  +8 B norm3.bias [E]
+ *   +9 B linear.weight [2E, E]      +10 B linear.bias [2E]
+ *   +11 B tcond_linear.weight [2E, ZS]  +12 B tcond_linear.bias [2E]
+ */
+#define AFTER_DENOISER_FIXED_WEIGHTS 10
+#define AFTER_DENOISER_LAYER_WEIGHTS 13
+
+typedef struct after_denoiser after_denoiser;
+
+/* Copies and re-lays-out the weights into device memory owned by the handle and
+ * provisions workspaces for up to `max_rows` network rows (a CFG sample of B
+ * clips uses 3B rows), `max_T` latent frames and `max_steps` Euler steps.
+ * Replaces: DenoiserV2.__init__ + load_state_dict (transformerv2.py:463-508). */
+int after_denoiser_create(const after_denoiser_cfg* cfg, const float* const* weights,
+                          int n_weights, int max_rows, int max_T, int max_steps,
+                          after_denoiser** out);
+void after_denoiser_destroy(after_denoiser* h);
+
+/* out[b,C,T] = net(x, time, cond, time_cond, cache_index)
+ * Replaces: DenoiserV2.forward (transformerv2.py:517-543).  time[b] (the
+ * reference's [b,1,1] / [b,1,T] inputs are reduced to [b] by the host exactly as
+ * :525-528 does).  cache_index must be 0 unless streaming caches were enabled
+ * with after_denoiser_enable_cache. */
+int after_denoiser_forward(after_denoiser* h, const float* x, const float* time,
+                           const float* cond, const float* time_cond, float* out, int b, int T,
+                           int cache_index, void* stream);
+
+/* out[B,C,T] = CFG-combined velocity.  Replaces: RectifiedFlow.model_forward
+ * (after/diffusion/model.py:721-761); cfg_mode selects the export variants. */
+int after_model_forward(after_denoiser* h, const float* x, const float* time, const float* cond,
+                        const float* time_cond, float* out, int B, int T, float guidance_timbre,
+                        float guidance_structure, float drop_value, int cfg_mode,
+                        int cache_index, void* stream);
+
+/* out[B,C,T] = x0 integrated with nb_steps Euler steps of the rectified flow,
+ * t = linspace(0,1,nb_steps+1)[:-1], dt = 1/nb_steps.  Replaces:
+ * RectifiedFlow.sample (after/diffusion/model.py:763-785).  out may alias x0. */
+int after_sample(after_denoiser* h, const float* x0, const float* cond, const float* time_cond,
+                 float* out, int B, int T, int nb_steps, float guidance_timbre,
+                 float guidance_structure, float drop_value, int cfg_mode, void* stream);
+
+/* Streaming KV caches (transformerv2.py:143-204; enabled in the reference by the
+ * gin binding at after_scripts/export.py:77-79).  cache_size frames per layer,
+ * per diffusion step, per row; zero-initialised like the reference buffers. */
+int after_denoiser_enable_cache(after_denoiser* h, int cache_size, int max_steps, int max_rows);
+int after_denoiser_reset_cache(after_denoiser* h, void* stream);
+/* Replaces: DenoiserV2.roll_cache (transformerv2.py:514-515, :171-188). */
+int after_denoiser_roll_cache(after_denoiser* h, int size, int cache_index, void* stream);
+
+/* Per-kernel timing hook for bench.py's roofline leg: when enabled, the GEMM
+ * launches of the denoiser are bracketed by HIP events on the launch stream;
+ * after a stream sync, after_denoiser_gemm_time_ms returns the accumulated
+ * duration and launch count since the last call. */
+int after_denoiser_profile(after_denoiser* h, int enable);
+int after_denoiser_gemm_time_ms(after_denoiser* h, double* total_ms, long long* launches,
+                                double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFTER_HIP_H */

@@ -1,0 +1,89 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports
+every symbol include/after_hip.h declares, the host mirrors keep the reference's
+state-dict layout, and the product path refuses to run without a GPU (no CPU
+fallback).  No compute calls."""
+import os
+import re
+
+import pytest
+import torch
+
+from after_amd import DenoiserV2, RectifiedFlow, _lib, configs
+from fixtures import Fixture
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "after_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(after_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    syms = header_symbols()
+    assert len(syms) >= 12
+    for s in syms:
+        assert hasattr(L, s), f"libafter_hip.so does not export {s}"
+    # and the ctypes table covers the whole header
+    assert set(syms) == set(_lib.SIGNATURES), set(syms) ^ set(_lib.SIGNATURES)
+    assert b"gfx950" in L.after_version()
+
+
+def test_library_is_built_for_gfx950_only():
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    out = subprocess.run([objdump, "--offloading", _lib.LIB_PATH], capture_output=True, text=True)
+    txt = out.stdout + out.stderr
+    archs = set(re.findall(r"gfx[0-9a-f]+", txt))
+    assert archs == {"gfx950"}, archs
+
+
+@pytest.mark.parametrize("case", ["denoiser_micro", "denoiser_micro_midi", "denoiser_tiny",
+                                  "denoiser_base", "denoiser_midi"])
+def test_denoiser_state_dict_matches_reference_layout(case):
+    fx = Fixture(case)
+    net = DenoiserV2(**configs.diffusion_config(fx.meta["config"])["net"])
+    sd = net.state_dict()
+    ref = fx.meta["shapes"]
+    assert set(sd) == set(ref)
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(ref[k]), k
+    # strict load of a reference-layout state dict
+    net.load_state_dict(fx.state_dict(), strict=True)
+
+
+def test_product_path_refuses_cpu_tensors():
+    net = DenoiserV2(**configs.diffusion_config("micro")["net"])
+    model = RectifiedFlow(net=net, sr=44100)
+    x = torch.zeros(1, 16, 8)
+    with pytest.raises(_lib.AFTERHipError):
+        net(x, torch.zeros(1), torch.zeros(1, 6), torch.zeros(1, 12, 8))
+    with pytest.raises(_lib.AFTERHipError):
+        model.sample(x, torch.zeros(1, 6), torch.zeros(1, 12, 8), 2)
+
+
+def test_rectified_flow_rejects_foreign_networks():
+    with pytest.raises(TypeError):
+        RectifiedFlow(net=torch.nn.Linear(2, 2), sr=44100)
+
+
+def test_linspace_formula_matches_torch():
+    """The device computes t = linspace(0,1,N+1)[:-1] with at::linspace's fp32 formula
+    (embed_rows_kernel); check the formula itself against torch on the CPU."""
+    import numpy as np
+    for n in (1, 2, 3, 4, 10, 15, 16, 50, 100, 333):
+        pts = n + 1
+        step = np.float32(1.0) / np.float32(pts - 1)
+        got = []
+        for s in range(n):
+            if s < pts // 2:
+                got.append(np.float32(step * np.float32(s)))
+            else:
+                # fused multiply-add: one rounding (exact product in float64)
+                got.append(np.float32(1.0 - float(step) * (pts - s - 1)))
+        want = torch.linspace(0, 1, n + 1)[:-1].numpy()
+        assert np.array_equal(np.asarray(got, dtype=np.float32), want), n
