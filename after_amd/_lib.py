@@ -45,6 +45,8 @@ SIGNATURES = {
     "after_denoiser_profile": (c_int, [c_void_p, c_int]),
     "after_denoiser_gemm_time_ms": (c_int, [c_void_p, POINTER(c_double), POINTER(c_longlong),
                                             POINTER(c_double)]),
+    "after_gemm_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                               c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
 }
 
 
@@ -103,4 +105,4 @@ def require_gpu_tensor(t, name):
             "the CPU restatement lives in oracle/ and is test infrastructure")
     if t.dtype != torch.float32:
         t = t.float()
-    return t.contiguous()
+    return t if t.dim() == 2 and t.stride(1) == 1 else t.contiguous()

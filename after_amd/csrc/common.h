@@ -101,5 +101,6 @@ struct GemmArgs {
     int epilogue;
 };
 int launch_gemm(const GemmArgs& g, hipStream_t stream);
+int launch_gemm_cfg(const GemmArgs& g, int force_mt, int force_nt, hipStream_t stream);
 
 }  // namespace after

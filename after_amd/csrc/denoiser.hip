@@ -29,7 +29,7 @@ namespace {
 
 constexpr int kMaxKeys = 32;   // W - 1 + chunk
 constexpr int kMaxChunk = 8;
-constexpr int kMaxPer = 16;    // E / 64 <= 16  (E <= 1024)
+constexpr int kMaxPer = 8;     // E / 64 <= 8  (E <= 512: every shipped config)
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -200,21 +200,26 @@ __global__ __launch_bounds__(256) void ln_mod_ln_kernel(const float* __restrict_
     const int sr = src_map ? src_map[r] : r;
     const float* xi = xin + ((size_t)sr * T + t) * E;
     const int nper = E >> 6;
-    float v[kMaxPer];
+    // every operand of the row is requested up front: one exposed memory latency
+    float v[kMaxPer], al[kMaxPer], be[kMaxPer], ww[kMaxPer], bb[kMaxPer];
+    const float* ab = nullptr;
+    if (tc_ab) ab = tc_ab + ((size_t)(tc_map ? tc_map[r] : r) * T + t) * tc_ld;
 #pragma unroll
     for (int i = 0; i < kMaxPer; ++i)
-        if (i < nper) v[i] = xi[lane + 64 * i];
+        if (i < nper) {
+            const int c = lane + 64 * i;
+            v[i] = xi[c];
+            al[i] = ab ? ab[c] : 0.f;
+            be[i] = ab ? ab[E + c] : 0.f;
+            ww[i] = w1[c];
+            bb[i] = b1[c];
+        }
     float mean, rstd;
     row_stats(v, nper, E, mean, rstd);
-    if (tc_ab) {
-        const int tr = tc_map ? tc_map[r] : r;
-        const float* ab = tc_ab + ((size_t)tr * T + t) * tc_ld;
+    if (ab) {
 #pragma unroll
         for (int i = 0; i < kMaxPer; ++i)
-            if (i < nper) {
-                const int c = lane + 64 * i;
-                v[i] = (v[i] - mean) * rstd * (1.0f + ab[c]) + ab[E + c];
-            }
+            if (i < nper) v[i] = (v[i] - mean) * rstd * (1.0f + al[i]) + be[i];
         row_stats(v, nper, E, mean, rstd);
     }
     float* xo = xout + (size_t)m * E;
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(256) void ln_mod_ln_kernel(const float* __restrict_
         if (i < nper) {
             const int c = lane + 64 * i;
             xo[c] = v[i];
-            ho[c] = (v[i] - mean) * rstd * w1[c] + b1[c];
+            ho[c] = (v[i] - mean) * rstd * ww[i] + bb[i];
         }
 }
 
@@ -253,143 +258,139 @@ struct AttnArgs {
     int nkmax;              // LDS rows provisioned for keys: W - 1 + cs
 };
 
-__global__ __launch_bounds__(256) void attn_block_kernel(AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ float group16_sum(float v) {
+    // all-reduce over the 16 lanes of a query group (xor butterfly stays inside the group)
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+// RoPE on 4 consecutive head dims (two interleaved pairs), rotary_embedding.py:132-173
+__device__ __forceinline__ float4 rope4(float4 v, const float* __restrict__ ct,
+                                        const float* __restrict__ st, int pos, int d4) {
+    if (d4 < 32) {
+        const float2 c = *reinterpret_cast<const float2*>(ct + (size_t)pos * 16 + (d4 >> 1));
+        const float2 s = *reinterpret_cast<const float2*>(st + (size_t)pos * 16 + (d4 >> 1));
+        const float x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+        v.x = x0 * c.x - x1 * s.x;
+        v.y = x1 * c.x + x0 * s.x;
+        v.z = x2 * c.y - x3 * s.y;
+        v.w = x3 * c.y + x2 * s.y;
+    }
+    return v;
+}
+
+// One workgroup = one chunk of one network row; wave w = head w (blockDim = 64 * H).
+// Inside a wave the four 16-lane groups are four queries; each lane owns four of the
+// head's 64 dims, so RoPE is lane-local, q.k is 4 FMAs + a 16-lane butterfly and the
+// probabilities never leave registers.  K and V rows are read straight from the qkv
+// buffer (one 256-byte segment per head and key, L2-resident).  The concatenated
+// heads + residual meet in LDS for the row-wise AdaLN / LayerNorm tail.
+template <int NKMAX>
+__global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [cs][E + 4]
     const int E = a.E, H = a.H, T = a.T, cs = a.cs, W = a.W, nc = a.nc;
     const int ld = E + 4;
-    const int nkm = a.nkmax;
-    float* qs = smem;               // [cs][ld]   (later: x + attn rows)
-    float* ks = qs + cs * ld;       // [nkmax][ld]
-    float* vs = ks + nkm * ld;      // [nkmax][ld]
-    float* ps = vs + nkm * ld;      // [H][cs][nkmax]
-
     const int r = blockIdx.y, tid = threadIdx.x;
-    // absolute positions include the nc cached frames (rotary_embedding.py:230:
-    // queries are offset by k_len - q_len)
-    const int i0 = blockIdx.x * cs;              // chunk start within this call's T frames
+    const int lane = tid & 63, hw = tid >> 6;  // head of this wave
+    const int grp = lane >> 4, d4 = (lane & 15) * 4;
+    const int i0 = blockIdx.x * cs;  // chunk start within this call's T frames
     const int e = min(i0 + cs, T);
     const int nq = e - i0;
-    const int Lk = nc + T;                       // total key length
-    const int a0 = nc + i0;                      // absolute position of the first query
-    // nc is a multiple of cs in the streaming protocol so chunk boundaries agree.
+    const int a0 = nc + i0;          // absolute position of the first query (keys: nc cached frames first)
     const int lo_c = min(a0, max(0, a0 - W + 1));
     const int nk = (nc + e) - lo_c;
-    (void)Lk;
+    const size_t rowbase = (size_t)r * T;
 
-    // ---- phase 1: stage q (roped), k (roped), v in LDS
-    const int e4 = E >> 2;
-    for (int idx = tid; idx < (nq + 2 * nk) * e4; idx += 256) {
-        const int row = idx / e4, c = (idx - row * e4) * 4;
-        const bool isq = row < nq;
-        const bool isk = !isq && row < nq + nk;
-        const int lr = isq ? row : (isk ? row - nq : row - nq - nk);
-        const int pos = isq ? a0 + lr : lo_c + lr;  // absolute position
-        const float* src;
-        if (isq) {
-            src = a.qkv + ((size_t)r * T + (pos - nc)) * 3 * E + c;
-        } else if (pos >= nc) {
-            src = a.qkv + ((size_t)r * T + (pos - nc)) * 3 * E + (isk ? E : 2 * E) + c;
-        } else {
-            src = (isk ? a.kcache : a.vcache) + ((size_t)r * nc + pos) * E + c;
-        }
-        float4 v = *reinterpret_cast<const float4*>(src);
-        const int d = c & 63;
-        if ((isq || isk) && d < 32) {
-            const float2 cs2 = *reinterpret_cast<const float2*>(a.rope_cos + (size_t)pos * 16 + (d >> 1));
-            const float2 sn2 = *reinterpret_cast<const float2*>(a.rope_sin + (size_t)pos * 16 + (d >> 1));
-            const float x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
-            v.x = x0 * cs2.x - x1 * sn2.x;
-            v.y = x1 * cs2.x + x0 * sn2.x;
-            v.z = x2 * cs2.y - x3 * sn2.y;
-            v.w = x3 * cs2.y + x2 * sn2.y;
-        }
-        float* dst = (isq ? qs : (isk ? ks : vs)) + lr * ld + c;
-        *reinterpret_cast<float4*>(dst) = v;
-    }
-    __syncthreads();
-
-    // ---- phase 2: scores
-    const int nsc = H * nq * nk;
-    for (int idx = tid; idx < nsc; idx += 256) {
-        const int j = idx % nk;
-        const int t2 = idx / nk;
-        const int qi = t2 % nq, hh = t2 / nq;
-        const float4* qp = reinterpret_cast<const float4*>(qs + qi * ld + hh * 64);
-        const float4* kp = reinterpret_cast<const float4*>(ks + j * ld + hh * 64);
-        float s = 0.f;
-#pragma unroll
-        for (int d = 0; d < 16; ++d) {
-            const float4 x = qp[d], y = kp[d];
-            s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
-        }
-        const int ja = a0 + qi;
+    for (int qb = 0; qb < nq; qb += 4) {
+        const int qi = qb + grp;
+        const bool qok = qi < nq;
+        const int qic = qok ? qi : nq - 1;
+        const int ja = a0 + qic;  // absolute query position
         const int lo_row = min(a0, max(0, ja - W + 1));
-        ps[(hh * cs + qi) * nkm + j] = (lo_c + j >= lo_row) ? s * 0.125f : -INFINITY;
-    }
-    __syncthreads();
-
-    // ---- phase 3: softmax over keys, one thread per (head, query)
-    if (tid < H * nq) {
-        const int qi = tid % nq, hh = tid / nq;
-        float* p = ps + (hh * cs + qi) * nkm;
+        float4 q4 = *reinterpret_cast<const float4*>(a.qkv + (rowbase + i0 + qic) * 3 * E + hw * 64 + d4);
+        const float4 x4 = *reinterpret_cast<const float4*>(a.xres + (rowbase + i0 + qic) * E + hw * 64 + d4);
+        q4 = rope4(q4, a.rope_cos, a.rope_sin, ja, d4);
+        float sc[NKMAX];
         float mx = -INFINITY;
-        for (int j = 0; j < nk; ++j) mx = fmaxf(mx, p[j]);
+#pragma unroll
+        for (int j = 0; j < NKMAX; ++j) {
+            sc[j] = -INFINITY;
+            if (j < nk) {
+                const int pos = lo_c + j;
+                const float* src = pos >= nc
+                                       ? a.qkv + (rowbase + (pos - nc)) * 3 * E + E + hw * 64 + d4
+                                       : a.kcache + ((size_t)r * nc + pos) * E + hw * 64 + d4;
+                float4 k4 = *reinterpret_cast<const float4*>(src);
+                k4 = rope4(k4, a.rope_cos, a.rope_sin, pos, d4);
+                float dot = q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
+                dot = group16_sum(dot);
+                sc[j] = pos >= lo_row ? dot * 0.125f : -INFINITY;
+                mx = fmaxf(mx, sc[j]);
+            }
+        }
         float sum = 0.f;
-        for (int j = 0; j < nk; ++j) {
-            const float ex = expf(p[j] - mx);
-            p[j] = ex;
-            sum += ex;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < NKMAX; ++j) {
+            if (j < nk) {
+                const int pos = lo_c + j;
+                const float* src = pos >= nc
+                                       ? a.qkv + (rowbase + (pos - nc)) * 3 * E + 2 * E + hw * 64 + d4
+                                       : a.vcache + ((size_t)r * nc + pos) * E + hw * 64 + d4;
+                const float4 v4 = *reinterpret_cast<const float4*>(src);
+                const float p = expf(sc[j] - mx);
+                sum += p;
+                o.x += p * v4.x;
+                o.y += p * v4.y;
+                o.z += p * v4.z;
+                o.w += p * v4.w;
+            }
         }
         const float inv = 1.0f / sum;
-        for (int j = 0; j < nk; ++j) p[j] *= inv;
-    }
-    __syncthreads();
-
-    // ---- phase 4: o = p v, + residual -> LDS rows (q region is free now)
-    for (int c = tid; c < E; c += 256) {
-        const int hh = c >> 6;
-        float o[kMaxChunk];
-#pragma unroll
-        for (int qi = 0; qi < kMaxChunk; ++qi) o[qi] = 0.f;
-        for (int j = 0; j < nk; ++j) {
-            const float vv = vs[j * ld + c];
-#pragma unroll
-            for (int qi = 0; qi < kMaxChunk; ++qi)
-                if (qi < nq) o[qi] += ps[(hh * cs + qi) * nkm + j] * vv;
+        if (qok) {
+            float4 res;
+            res.x = o.x * inv + x4.x;
+            res.y = o.y * inv + x4.y;
+            res.z = o.z * inv + x4.z;
+            res.w = o.w * inv + x4.w;
+            *reinterpret_cast<float4*>(smem + qi * ld + hw * 64 + d4) = res;
         }
-#pragma unroll
-        for (int qi = 0; qi < kMaxChunk; ++qi)
-            if (qi < nq) qs[qi * ld + c] = o[qi] + a.xres[((size_t)r * T + i0 + qi) * E + c];
     }
     __syncthreads();
 
-    // ---- phase 5: AdaLN(cond) + norm3, one wave per row
-    const int lane = tid & 63, wid = tid >> 6;
+    // ---- AdaLN(cond) + norm3, one wave per row
     const int nper = E >> 6;
-    for (int qi = wid; qi < nq; qi += 4) {
-        float v[kMaxPer];
+    for (int qi = hw; qi < nq; qi += H) {
+        float v[kMaxPer], al[kMaxPer], be[kMaxPer], ww[kMaxPer], bb[kMaxPer];
+        const float* ab = a.cond_ab ? a.cond_ab + (size_t)r * a.cond_ld : nullptr;
 #pragma unroll
         for (int i = 0; i < kMaxPer; ++i)
-            if (i < nper) v[i] = qs[qi * ld + lane + 64 * i];
+            if (i < nper) {
+                const int c = lane + 64 * i;
+                v[i] = smem[qi * ld + c];
+                al[i] = ab ? ab[c] : 0.f;
+                be[i] = ab ? ab[E + c] : 0.f;
+                ww[i] = a.w3[c];
+                bb[i] = a.b3[c];
+            }
         float mean, rstd;
-        if (a.cond_ab) {
+        if (ab) {
             row_stats(v, nper, E, mean, rstd);
-            const float* ab = a.cond_ab + (size_t)r * a.cond_ld;
 #pragma unroll
             for (int i = 0; i < kMaxPer; ++i)
-                if (i < nper) {
-                    const int c = lane + 64 * i;
-                    v[i] = (v[i] - mean) * rstd * (1.0f + ab[c]) + ab[E + c];
-                }
+                if (i < nper) v[i] = (v[i] - mean) * rstd * (1.0f + al[i]) + be[i];
         }
         row_stats(v, nper, E, mean, rstd);
-        const size_t m = (size_t)r * T + i0 + qi;
+        const size_t m = rowbase + i0 + qi;
 #pragma unroll
         for (int i = 0; i < kMaxPer; ++i)
             if (i < nper) {
                 const int c = lane + 64 * i;
                 a.xres[m * E + c] = v[i];
-                a.h[m * E + c] = (v[i] - mean) * rstd * a.w3[c] + a.b3[c];
+                a.h[m * E + c] = (v[i] - mean) * rstd * ww[i] + bb[i];
             }
     }
 }
@@ -535,8 +536,18 @@ int compute_cond_ab(after_denoiser* h, hipStream_t s, int S, int rows, const flo
     return AFTER_OK;
 }
 
-size_t attn_lds_bytes(int E, int H, int cs, int nkmax) {
-    return ((size_t)(cs + 2 * nkmax) * (E + 4) + (size_t)H * cs * nkmax) * sizeof(float);
+size_t attn_lds_bytes(int E, int cs) { return (size_t)cs * (E + 4) * sizeof(float); }
+
+int launch_attn(const AttnArgs& a, int rows, size_t lds, hipStream_t s) {
+    const dim3 grid(cdiv(a.T, a.cs), rows), block(64 * a.H);
+    if (a.nkmax <= 12)
+        hipLaunchKernelGGL(attn_block_kernel<12>, grid, block, lds, s, a);
+    else if (a.nkmax <= 20)
+        hipLaunchKernelGGL(attn_block_kernel<20>, grid, block, lds, s, a);
+    else
+        hipLaunchKernelGGL(attn_block_kernel<32>, grid, block, lds, s, a);
+    AFTER_HIP_CHECK(hipGetLastError());
+    return AFTER_OK;
 }
 
 // One network evaluation on `rows` rows.  x: [nx, C, T] addressed through dev_xmap
@@ -556,7 +567,7 @@ int run_net(after_denoiser* h, hipStream_t s, const float* x, int npat, const in
     AFTER_TRY(gemm(h, s, h->xt, h->Cp, h->patch_w, h->Cp, h->patch_b, h->pat, E, npat * T, E,
                    h->Cp, EPI_GELU));
     const int nkmax = h->W - 1 + h->cs > h->cs ? h->W - 1 + h->cs : h->cs;
-    const size_t lds = attn_lds_bytes(E, h->H, h->cs, nkmax);
+    const size_t lds = attn_lds_bytes(E, h->cs);
     for (int l = 0; l < L; ++l) {
         const LayerW& w = h->layers[l];
         hipLaunchKernelGGL(ln_mod_ln_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s,
@@ -590,8 +601,7 @@ int run_net(after_denoiser* h, hipStream_t s, const float* x, int npat, const in
         a.cs = h->cs;
         a.W = h->W;
         a.nkmax = nkmax;
-        hipLaunchKernelGGL(attn_block_kernel, dim3(cdiv(T, h->cs), rows), dim3(256), lds, s, a);
-        AFTER_HIP_CHECK(hipGetLastError());
+        AFTER_TRY(launch_attn(a, rows, lds, s));
         AFTER_TRY(gemm(h, s, h->hbuf, E, w.mlp0_w, E, w.mlp0_b, h->mlp, ME, M, ME, E, EPI_GELU));
         AFTER_TRY(gemm(h, s, h->mlp, ME, w.mlp2_w, ME, w.mlp2_b, h->xres, E, M, E, ME,
                        EPI_RESIDUAL, h->xres, E));
@@ -791,13 +801,6 @@ extern "C" int after_denoiser_create(const after_denoiser_cfg* cfg, const float*
     if (!h->maps) return fail(AFTER_E_NOMEM);
     if (hipMemset(h->tce, 0, MT * h->ZSp * sizeof(float)) != hipSuccess) return fail(AFTER_E_HIP);
 
-    const int nkmax0 = h->W - 1 + h->cs > h->cs ? h->W - 1 + h->cs : h->cs;
-    const size_t lds = attn_lds_bytes(E, h->H, h->cs, nkmax0);
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-        set_error("attention kernel needs %zu B of LDS", lds);
-        return fail(AFTER_E_HIP);
-    }
     if (hipDeviceSynchronize() != hipSuccess) return fail(AFTER_E_HIP);
 #undef TAKE
 #undef TRY_OR_FAIL

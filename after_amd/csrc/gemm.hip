@@ -5,26 +5,30 @@
 // [out, in]) so activations and weights are both K-contiguous ("B^T input").
 //
 // Design (gfx950): 256-thread workgroup = 4 waves in a 2x2 arrangement, each wave
-// owning TM x TN tiles of 32x32 accumulated with v_mfma_f32_32x32x2_f32 (exact
-// fp32: the reference computes in fp32).  K is walked in BK=32
-// slabs staged through LDS: coalesced 16-byte global loads (8 lanes cover one
-// 128-byte row segment) -> registers -> ds_write_b128 into rows padded to 36
-// floats (144 B) so that the fragment reads -- one ds_read_b128 per lane giving
-// four consecutive k for one row, i.e. operands of four MFMAs -- are bank-conflict
-// free for every 16-lane service group.  The next slab's global loads are issued
-// before the current slab's MFMAs (register double buffering + two LDS buffers,
-// one barrier per slab).  Workgroup ids are remapped so that each XCD (private
-// 4 MiB L2) owns a contiguous range of N-tiles, i.e. streams only 1/8 of W.
+// owning MT x NT tiles of 16x16 accumulated with v_mfma_f32_16x16x4_f32 (exact
+// fp32: the reference computes in fp32).  The 16x16 granule (rather
+// than 32x32) is what lets the B=1 shapes (M = 768 tokens) fill 256 CUs with >= 2
+// co-resident workgroups each: the fp32 matrix pipe is slow (32 cycles per
+// instruction), so LDS/L2 bandwidth is idle and the only enemy is exposed latency
+// -- which co-resident workgroups hide for each other.  K is walked in BK=32 slabs
+// staged through LDS: coalesced 16-byte global loads (8 lanes cover one 128-byte row
+// segment) -> registers -> ds_write_b128 into rows padded to 40 floats (160 B), the
+// stride for which the fragment reads -- one ds_read_b128 per lane = four
+// consecutive k of one row = operands of four MFMAs -- are bank-conflict free in
+// every 16-lane service group of ds_read_b128.  The next slab's global loads are
+// issued before the current slab's MFMAs (register double buffering + two LDS
+// buffers, one barrier per slab).  Workgroup ids are remapped so that each XCD
+// (private 4 MiB L2) owns a contiguous range of N-tiles, i.e. streams 1/8 of W.
 #include "common.h"
 
 namespace after {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
 constexpr int BK = 32;
-constexpr int LDS_LD = 36;  // floats per LDS row (32 + 4 pad)
+constexpr int LDS_LD = 40;  // floats per LDS row (32 + 8 pad): conflict-free b128 fragment reads
 
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
@@ -47,14 +51,13 @@ __device__ __forceinline__ void tile_sstore(const float4 (&r)[NL], float* dst) {
     for (int i = 0; i < NL; ++i) *reinterpret_cast<float4*>(dst + 32 * i * LDS_LD) = r[i];
 }
 
-template <int BM, int BN>
+template <int MT, int NT>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g, int tiles_m, int tiles_n) {
-    constexpr int WM = BM / 2, WN = BN / 2;  // wave tile
-    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int BM = 32 * MT, BN = 32 * NT;            // workgroup tile
     constexpr int A_LOADS = BM / 32, W_LOADS = BN / 32;  // float4 per thread per slab
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                       // [2][BM][LDS_LD]
-    float* Ws = smem + 2 * BM * LDS_LD;     // [2][BN][LDS_LD]
+    float* As = smem;                    // [2][BM][LDS_LD]
+    float* Ws = smem + 2 * BM * LDS_LD;  // [2][BN][LDS_LD]
 
     // XCD-aware bijective remap (cdna guide T1): block b runs on XCD b % 8.
     const int nwg = tiles_m * tiles_n;
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g, int tiles_m, 
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm0 = (wid >> 1) * WM, wn0 = (wid & 1) * WN;
+    const int wm0 = (wid >> 1) * (16 * MT), wn0 = (wid & 1) * (16 * NT);
     const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
 
     const float* __restrict__ gA = g.A;
@@ -89,13 +92,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g, int tiles_m, 
         Woff[i] = (size_t)(Wok[i] ? gn : 0) * ldw + lc4;
     }
 
-    f32x16 acc[TM][TN];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     float4 ra[A_LOADS], rw[W_LOADS];
     const int nk = (K + BK - 1) / BK;
@@ -104,7 +105,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g, int tiles_m, 
     tile_sstore<A_LOADS>(ra, As + lrow * LDS_LD + lc4);
     tile_sstore<W_LOADS>(rw, Ws + lrow * LDS_LD + lc4);
     __syncthreads();
-    const int frow = lane & 31, fk = (lane >> 5) * 4;
+    // fragment addressing of v_mfma_f32_16x16x4_f32: lane l supplies A[i = l&15][k = l>>4]
+    // and B[k = l>>4][j = l&15]; one b128 read = k-quad (l>>4) of a 16-deep k block.
+    const int frow = lane & 15, fk = (lane >> 4) * 4;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
@@ -115,23 +118,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g, int tiles_m, 
         const float* Ab = &As[(cur * BM + wm0 + frow) * LDS_LD + fk];
         const float* Wb = &Ws[(cur * BN + wn0 + frow) * LDS_LD + fk];
 #pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            float4 a[TM], b[TN];
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            float4 a[MT], b[NT];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                a[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_LD + kk * 8);
+            for (int i = 0; i < MT; ++i)
+                a[i] = *reinterpret_cast<const float4*>(Ab + i * 16 * LDS_LD + kk * 16);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                b[j] = *reinterpret_cast<const float4*>(Wb + j * 32 * LDS_LD + kk * 8);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-                }
+            for (int j = 0; j < NT; ++j)
+                b[j] = *reinterpret_cast<const float4*>(Wb + j * 16 * LDS_LD + kk * 16);
+            // k-step outermost: consecutive MFMAs hit different accumulators, so the
+            // 40-cycle dependent latency of v_mfma_f32_16x16x4_f32 hides behind the
+            // 32-cycle issue interval
+#define AFTER_MFMA_STEP(comp)                                                                   \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NT; ++j) \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].comp, b[j].comp, acc[i][j], 0, 0, 0);
+            AFTER_MFMA_STEP(x)
+            AFTER_MFMA_STEP(y)
+            AFTER_MFMA_STEP(z)
+            AFTER_MFMA_STEP(w)
+#undef AFTER_MFMA_STEP
         }
         if (kt + 1 < nk) {
             tile_sstore<A_LOADS>(ra, As + ((cur ^ 1) * BM + lrow) * LDS_LD + lc4);
@@ -140,18 +145,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g, int tiles_m, 
         __syncthreads();
     }
 
-    // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int ccol = lane & 31, crow0 = 4 * (lane >> 5);
+    // epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + r
+    const int ccol = lane & 15, crow0 = 4 * (lane >> 4);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int gn = n0 + wn0 + j * 32 + ccol;
+    for (int j = 0; j < NT; ++j) {
+        const int gn = n0 + wn0 + j * 16 + ccol;
         if (gn >= N) continue;
         const float bv = g.bias ? g.bias[gn] : 0.f;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < MT; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gm = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + crow0;
+            for (int r = 0; r < 4; ++r) {
+                const int gm = m0 + wm0 + i * 16 + crow0 + r;
                 if (gm >= M) continue;
                 float v = acc[i][j][r] + bv;
                 if (g.epilogue == EPI_GELU) v = gelu_erf(v);
@@ -162,17 +167,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g, int tiles_m, 
     }
 }
 
-template <int BM, int BN>
+template <int MT, int NT>
 int launch_cfg(const GemmArgs& g, hipStream_t stream) {
+    constexpr int BM = 32 * MT, BN = 32 * NT;
     const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
     const size_t lds = size_t(2) * (BM + BN) * LDS_LD * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN>),
+        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<MT, NT>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN>), dim3(tiles_m * tiles_n), dim3(256), lds, stream, g,
+    hipLaunchKernelGGL((gemm_f32_kernel<MT, NT>), dim3(tiles_m * tiles_n), dim3(256), lds, stream, g,
                        tiles_m, tiles_n);
     AFTER_HIP_CHECK(hipGetLastError());
     return AFTER_OK;
@@ -180,18 +186,45 @@ int launch_cfg(const GemmArgs& g, hipStream_t stream) {
 
 }  // namespace
 
-int launch_gemm(const GemmArgs& g, hipStream_t stream) {
+int launch_gemm(const GemmArgs& g, hipStream_t stream) { return launch_gemm_cfg(g, 0, 0, stream); }
+
+int launch_gemm_cfg(const GemmArgs& g, int mt, int nt, hipStream_t stream) {
     AFTER_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, AFTER_E_INVALID, "gemm: empty problem %dx%dx%d",
                   g.M, g.N, g.K);
     AFTER_REQUIRE((g.K % 4) == 0 && (g.lda % 4) == 0 && (g.ldw % 4) == 0, AFTER_E_INVALID,
                   "gemm: K/lda/ldw must be multiples of 4 (K=%d lda=%d ldw=%d)", g.K, g.lda, g.ldw);
     AFTER_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.W % 16) == 0, AFTER_E_INVALID,
                   "gemm: operands must be 16-byte aligned");
-    const long long t128 = (long long)cdiv(g.M, 128) * cdiv(g.N, 128);
-    const long long t12864 = (long long)cdiv(g.M, 128) * cdiv(g.N, 64);
-    if (t128 >= 512) return launch_cfg<128, 128>(g, stream);
-    if (t12864 >= 384) return launch_cfg<128, 64>(g, stream);
-    return launch_cfg<64, 64>(g, stream);
+    AFTER_REQUIRE(g.epilogue != EPI_RESIDUAL || g.R != nullptr, AFTER_E_INVALID,
+                  "gemm: residual epilogue without R");
+    if (mt > 0 || nt > 0) {
+        if (mt == 4 && nt == 4) return launch_cfg<4, 4>(g, stream);
+        if (mt == 4 && nt == 2) return launch_cfg<4, 2>(g, stream);
+        if (mt == 2 && nt == 2) return launch_cfg<2, 2>(g, stream);
+        if (mt == 1 && nt == 2) return launch_cfg<1, 2>(g, stream);
+        if (mt == 1 && nt == 1) return launch_cfg<1, 1>(g, stream);
+        set_error("gemm: no tile configuration %dx%d", mt, nt);
+        return AFTER_E_INVALID;
+    }
+    // Tile choice: the largest workgroup tile that still yields >= 2 workgroups per CU
+    // (co-residency is what hides the LDS/barrier latency of this MFMA-bound loop).
+    auto wgs = [&](int bm, int bn) { return (long long)cdiv(g.M, bm) * cdiv(g.N, bn); };
+    const long long want = 2 * 256;
+    if (wgs(128, 128) >= want) return launch_cfg<4, 4>(g, stream);
+    if (wgs(128, 64) >= want) return launch_cfg<4, 2>(g, stream);
+    if (wgs(64, 64) >= want) return launch_cfg<2, 2>(g, stream);
+    if (wgs(32, 64) >= want) return launch_cfg<1, 2>(g, stream);
+    return launch_cfg<1, 1>(g, stream);
 }
 
 }  // namespace after
+
+// Diagnostic / unit-test entry point (not on the reference's surface): the GEMM used by
+// every Linear of the denoiser, callable on its own for parity and roofline tests.
+// force_mt/force_nt > 0 pin the tile configuration (workgroup tile 32*mt x 32*nt).
+extern "C" int after_gemm_f32(const float* A, int lda, const float* W, int ldw, const float* bias,
+                              const float* R, int ldr, float* C, int ldc, int M, int N, int K,
+                              int epilogue, int force_mt, int force_nt, void* stream) {
+    after::GemmArgs g{A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, epilogue};
+    return after::launch_gemm_cfg(g, force_mt, force_nt, (hipStream_t)stream);
+}

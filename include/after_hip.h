@@ -126,6 +126,15 @@ int after_denoiser_profile(after_denoiser* h, int enable);
 int after_denoiser_gemm_time_ms(after_denoiser* h, double* total_ms, long long* launches,
                                 double* flops);
 
+/* ------------------------------------------------------------ diagnostics
+ * Not part of the reference's surface: the fp32 MFMA GEMM behind every Linear,
+ * exposed for unit parity tests and roofline measurements.
+ *   C[M,N] = epi(A[M,K] * W[N,K]^T + bias);  epilogue 0 none, 1 GELU(erf), 2 + R[M,N]
+ * force_mt/force_nt = 0 lets the library pick the tile. */
+int after_gemm_f32(const float* A, int lda, const float* W, int ldw, const float* bias,
+                   const float* R, int ldr, float* C, int ldc, int M, int N, int K, int epilogue,
+                   int force_mt, int force_nt, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

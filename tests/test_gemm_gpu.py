@@ -1,0 +1,39 @@
+"""fp32 MFMA GEMM (after_gemm_f32) against torch fp64 on the GPU box: every tile
+configuration, ragged M/N/K, all epilogues.  v_mfma_f32_16x16x4_f32 is an exact
+fp32 fma chain, so the error bound is fp32 round-off: |err| <= 2e-6 * sum|a||w|."""
+import pytest
+import torch
+
+from after_amd import diag
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tile", [(0, 0), (1, 1), (1, 2), (2, 2), (4, 2), (4, 4)])
+@pytest.mark.parametrize("M,N,K", [(768, 1536, 512), (150, 512, 72), (33, 17, 12), (257, 130, 100),
+                                   (1, 64, 512), (768, 64, 512)])
+def test_gemm_shapes(tile, M, N, K, hip_device):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g)  # asymmetric: catches transposed C/D maps
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    ref = a.double() @ w.double().t() + b.double()
+    bound = 2e-6 * (a.abs().double() @ w.abs().double().t()).max().item() + 1e-6
+    ad, wd, bd, rd = (t.to(hip_device) for t in (a, w, b, r))
+    out = diag.gemm(ad, wd, bd, tile=tile).cpu().double()
+    assert (out - ref).abs().max().item() < bound
+    out = diag.gemm(ad, wd, bd, epilogue=1, tile=tile).cpu().double()
+    assert (out - torch.nn.functional.gelu(ref)).abs().max().item() < bound
+    out = diag.gemm(ad, wd, None, residual=rd, epilogue=2, tile=tile).cpu().double()
+    assert (out - (ref - b.double() + r.double())).abs().max().item() < bound
+
+
+def test_gemm_strided_operands(hip_device):
+    g = torch.Generator().manual_seed(5)
+    big = torch.randn(100, 96, generator=g).to(hip_device)
+    a = big[:, :64]  # lda = 96
+    w = torch.randn(40, 64, generator=g).to(hip_device)
+    out = diag.gemm(a, w)
+    ref = a.double() @ w.double().t()
+    assert (out.double() - ref).abs().max().item() < 1e-4
