@@ -4,5 +4,6 @@ AFTER's own Python model/sampler API.  Compute runs in hand-written HIP kernels
 (after_amd/csrc) reached through the C ABI of include/after_hip.h."""
 from . import configs  # noqa: F401
 from .diffusion import DenoiserV2, RectifiedFlow  # noqa: F401
+from .autoencoder import AutoEncoder  # noqa: F401
 
-__all__ = ["configs", "DenoiserV2", "RectifiedFlow"]
+__all__ = ["configs", "DenoiserV2", "RectifiedFlow", "AutoEncoder"]

@@ -19,6 +19,14 @@ class DenoiserCfg(ctypes.Structure):
                                      "local_attention_size", "attention_chunk_size")]
 
 
+class AECfg(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in ("pqmf_bands", "channels", "z_channels", "n_stages",
+                                     "n_dilations", "kernel_size", "use_norm", "use_loudness",
+                                     "causal")] + [("multipliers", c_int * 9),
+                                                   ("dec_multipliers", c_int * 9),
+                                                   ("factors", c_int * 8), ("dilations", c_int * 8)]
+
+
 class AFTERHipError(RuntimeError):
     pass
 
@@ -45,6 +53,14 @@ SIGNATURES = {
     "after_denoiser_profile": (c_int, [c_void_p, c_int]),
     "after_denoiser_gemm_time_ms": (c_int, [c_void_p, POINTER(c_double), POINTER(c_longlong),
                                             POINTER(c_double)]),
+    "after_ae_create": (c_int, [POINTER(AECfg), POINTER(c_void_p), c_int, c_int, c_int,
+                                POINTER(c_void_p)]),
+    "after_ae_destroy": (None, [c_void_p]),
+    "after_ae_ratio": (c_int, [c_void_p]),
+    "after_ae_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "after_ae_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "after_ae_pqmf_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "after_ae_pqmf_inverse": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "after_gemm_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
 }

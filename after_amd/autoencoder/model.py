@@ -1,0 +1,347 @@
+"""Host-side mirror of the reference's AutoEncoder
+(after/autoencoder/networks/SimpleNetsStream.py:831-954) and of the exported
+encode / decode / forward surface (after_scripts/export_autoencoder.py:235-265).
+
+The module tree only carries parameters under the reference's state-dict keys
+(weight-normed convs as weight_g / weight_v, CachedGroupNorm
+with its `pad` buffer, SnakeBeta alpha / beta, the four PQMF buffers); compute runs
+in libafter_hip (after_ae_encode / after_ae_decode)."""
+import ctypes
+import math
+from typing import Sequence
+
+import torch
+from torch import nn
+
+from .. import _lib
+from . import pqmf as pqmf_design
+
+
+class _Snake(nn.Module):
+
+    def __init__(self, dim):
+        super().__init__()
+        self.alpha = nn.Parameter(torch.ones(dim))
+        self.beta = nn.Parameter(torch.ones(dim))
+
+
+class _CachedGroupNorm(nn.Module):
+
+    def __init__(self, groups, channels):
+        super().__init__()
+        self.gn = nn.GroupNorm(groups, channels)
+        self.register_buffer("pad", torch.zeros(4, channels, 1))
+
+
+class _WNConv(nn.Module):
+    """Parameters of torch.nn.utils.weight_norm(nn.Conv1d / nn.ConvTranspose1d)."""
+
+    def __init__(self, cin, cout, k, transposed=False):
+        super().__init__()
+        ref = nn.ConvTranspose1d(cin, cout, k) if transposed else nn.Conv1d(cin, cout, k)
+        v = ref.weight.detach()
+        self.bias = nn.Parameter(ref.bias.detach().clone())
+        self.weight_g = nn.Parameter(v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, 1, 1).clone())
+        self.weight_v = nn.Parameter(v.clone())
+
+
+class _ConvBlock(nn.Module):
+
+    def __init__(self, cin, cout, k, use_norm):
+        super().__init__()
+        gn = _CachedGroupNorm(min(cin, 8), cin) if use_norm else nn.Identity()
+        self.net = nn.Sequential(gn, _Snake(cin), _WNConv(cin, cout, k))
+
+
+class _Branches(nn.Module):
+
+    def __init__(self, *mods):
+        super().__init__()
+        self.branches = nn.ModuleList(mods)
+
+
+class _ResBlock(nn.Module):
+
+    def __init__(self, cin, cout, k, use_norm):
+        super().__init__()
+        main = nn.Sequential(_ConvBlock(cin, cout, k, use_norm), _ConvBlock(cout, cout, 1, use_norm))
+        short = _WNConv(cin, cout, 1) if cin != cout else nn.Identity()
+        self.net = _Branches(main, short)
+
+
+class _NoRes(nn.Module):
+
+    def __init__(self, cin, cout, k, use_norm):
+        super().__init__()
+        self.net = nn.Sequential(_ConvBlock(cin, cout, k, use_norm), _ConvBlock(cout, cout, 1, use_norm))
+
+
+class _Down(nn.Module):
+
+    def __init__(self, cin, cout, f, nd, k, use_norm):
+        super().__init__()
+        mods = [_ResBlock(cin, cin, k, use_norm) for _ in range(nd)]
+        mods += [_Snake(cin), _WNConv(cin, cout, 2 * f)]
+        self.net = nn.Sequential(*mods)
+
+
+class _Up(nn.Module):
+
+    def __init__(self, cin, cout, f, nd, k, use_norm):
+        super().__init__()
+        mods = [_Snake(cin), _WNConv(cin, cout, 2 * f, transposed=True)]
+        mods += [_ResBlock(cout, cout, k, use_norm) for _ in range(nd)]
+        self.net = nn.Sequential(*mods)
+
+
+class _Encoder(nn.Module):
+
+    def __init__(self, cin, channels, mult, factors, nd, k, zc, use_norm):
+        super().__init__()
+        mods = [_ResBlock(cin, channels * mult[0], k, use_norm)]
+        for i, f in enumerate(factors):
+            mods.append(_Down(channels * mult[i], channels * mult[i + 1], f, nd, k, use_norm))
+        mods += [_Snake(channels * mult[-1]), _WNConv(channels * mult[-1], zc, 3)]
+        self.net = nn.Sequential(*mods)
+
+
+class _Decoder(nn.Module):
+
+    def __init__(self, cout, channels, mult, factors, nd, k, zc, use_norm, use_loudness):
+        super().__init__()
+        mods = [_WNConv(zc, channels * mult[0], k)]
+        for i, f in enumerate(factors):
+            mods.append(_Up(channels * mult[i], channels * mult[i + 1], f, nd, k, use_norm))
+        self.net = nn.Sequential(*mods)
+        self.synth = _Branches(_NoRes(channels * mult[-1], cout * 2 if use_loudness else cout, k,
+                                      use_norm))
+
+
+class _PQMF(nn.Module):
+
+    def __init__(self, attenuation, n_band):
+        super().__init__()
+        h, hk, fw, iw = pqmf_design.design(attenuation, n_band)
+        self.register_buffer("hk", torch.from_numpy(hk))
+        self.register_buffer("h", torch.from_numpy(h))
+        self.forward_conv = nn.Module()
+        self.forward_conv.register_parameter("weight", nn.Parameter(torch.from_numpy(fw)))
+        self.inverse_conv = nn.Module()
+        self.inverse_conv.register_parameter("weight", nn.Parameter(torch.from_numpy(iw)))
+
+
+class AutoEncoder(nn.Module):
+    """Drop-in for the reference AutoEncoder on MI355X: same constructor arguments
+    (`bottleneck` is accepted and ignored: ReluBottleneck is the identity on z at
+    inference, SimpleNetsStream.py:753-760), same encode/decode/forward signatures."""
+
+    def __init__(self,
+                 in_channels: int,
+                 channels: int,
+                 z_channels: int,
+                 multipliers: Sequence[int],
+                 factors: Sequence[int],
+                 dilations: Sequence[int],
+                 kernel_size: int,
+                 resnet_groups: int = 8,
+                 bottleneck=None,
+                 activation=None,
+                 use_norm: bool = True,
+                 decoder_ratio: float = 1,
+                 pqmf_bands: int = 0,
+                 use_loudness: bool = False,
+                 use_noise: bool = False,
+                 padding_mode: str = "centered"):
+        super().__init__()
+        if pqmf_bands <= 1 or in_channels != pqmf_bands:
+            raise NotImplementedError("after_amd builds the shipped codec: pqmf_bands = in_channels > 1")
+        if use_noise:
+            raise NotImplementedError("use_noise=True (NoiseGenerator) is not built (baseAE.gin: False)")
+        if resnet_groups != 8:
+            raise NotImplementedError("resnet_groups must be 8 (every shipped config)")
+        self.cfg = dict(in_channels=in_channels, channels=channels, z_channels=z_channels,
+                        multipliers=list(multipliers), factors=list(factors),
+                        dilations=list(dilations), kernel_size=kernel_size, use_norm=use_norm,
+                        decoder_ratio=decoder_ratio, pqmf_bands=pqmf_bands,
+                        use_loudness=use_loudness, padding_mode=padding_mode)
+        self.pqmf_bands = pqmf_bands
+        self.z_channels = z_channels
+        self.ratio = pqmf_bands * math.prod(factors)
+        nd = len(dilations)
+        self.dec_multipliers = [int(m * decoder_ratio) for m in list(multipliers)[::-1]]
+        self.pqmf = _PQMF(100, pqmf_bands)
+        self.encoder = _Encoder(in_channels, channels, list(multipliers), list(factors), nd,
+                                kernel_size, z_channels, use_norm)
+        self.decoder = _Decoder(in_channels, channels, self.dec_multipliers, list(factors)[::-1], nd,
+                                kernel_size, z_channels, use_norm, use_loudness)
+        self.requires_grad_(False)
+        self._handle = None
+        self._cap = (0, 0)
+
+    # ------------------------------------------------------------ handle management
+    def _apply(self, fn, *a, **k):
+        self._release()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._release()
+        return super().load_state_dict(*a, **k)
+
+    def refresh(self):
+        self._release()
+
+    def _release(self):
+        h = getattr(self, "_handle", None)
+        if h is not None:
+            _lib.lib().after_ae_destroy(h)
+        self._handle = None
+        self._cap = (0, 0)
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _weight_names(self):
+        """State-dict keys in the order documented in include/after_hip.h."""
+        c = self.cfg
+        nd, n = len(c["dilations"]), len(c["factors"])
+
+        def CB(p):
+            return [p + "net.0.gn.weight", p + "net.0.gn.bias", p + "net.1.alpha", p + "net.1.beta",
+                    p + "net.2.weight_g", p + "net.2.weight_v", p + "net.2.bias"]
+
+        def WN(p):
+            return [p + "weight_g", p + "weight_v", p + "bias"]
+
+        def SN(p):
+            return [p + "alpha", p + "beta"]
+
+        names = ["pqmf.forward_conv.weight", "pqmf.inverse_conv.weight"]
+        e = "encoder.net."
+        names += CB(e + "0.net.branches.0.0.") + CB(e + "0.net.branches.0.1.")
+        if c["in_channels"] != c["channels"] * c["multipliers"][0]:
+            names += WN(e + "0.net.branches.1.")
+        for i in range(n):
+            s = f"{e}{i + 1}.net."
+            for j in range(nd):
+                names += CB(f"{s}{j}.net.branches.0.0.") + CB(f"{s}{j}.net.branches.0.1.")
+            names += SN(f"{s}{nd}.") + WN(f"{s}{nd + 1}.")
+        names += SN(f"{e}{n + 1}.") + WN(f"{e}{n + 2}.")
+        d = "decoder.net."
+        names += WN(d + "0.")
+        for i in range(n):
+            s = f"{d}{i + 1}.net."
+            names += SN(s + "0.") + WN(s + "1.")
+            for j in range(nd):
+                names += CB(f"{s}{j + 2}.net.branches.0.0.") + CB(f"{s}{j + 2}.net.branches.0.1.")
+        names += CB("decoder.synth.branches.0.net.0.") + CB("decoder.synth.branches.0.net.1.")
+        return names
+
+    def _ensure(self, batch: int, samples: int):
+        cb, cs = self._cap
+        if self._handle is not None and batch <= cb and samples <= cs:
+            return self._handle
+        L = _lib.lib()
+        self._release()
+        cap = (max(batch, cb), max(samples, cs))
+        sd = self.state_dict()
+        ws = []
+        for name in self._weight_names():
+            if name.endswith("gn.weight") or name.endswith("gn.bias"):
+                ws.append(_lib.require_gpu_tensor(sd[name], name) if name in sd else None)
+            else:
+                ws.append(_lib.require_gpu_tensor(sd[name], name))
+        arr = (ctypes.c_void_p * len(ws))(*[w.data_ptr() if w is not None else None for w in ws])
+        c = self.cfg
+        cfg = _lib.AECfg()
+        cfg.pqmf_bands = c["pqmf_bands"]
+        cfg.channels = c["channels"]
+        cfg.z_channels = c["z_channels"]
+        cfg.n_stages = len(c["factors"])
+        cfg.n_dilations = len(c["dilations"])
+        cfg.kernel_size = c["kernel_size"]
+        cfg.use_norm = int(c["use_norm"])
+        cfg.use_loudness = int(c["use_loudness"])
+        cfg.causal = int(c["padding_mode"] == "causal")
+        for i, m in enumerate(c["multipliers"]):
+            cfg.multipliers[i] = m
+        for i, m in enumerate(self.dec_multipliers):
+            cfg.dec_multipliers[i] = m
+        for i, f in enumerate(c["factors"]):
+            cfg.factors[i] = f
+        for i, dd in enumerate(c["dilations"]):
+            cfg.dilations[i] = dd
+        out = ctypes.c_void_p()
+        torch.cuda.synchronize()
+        _lib.check(L.after_ae_create(ctypes.byref(cfg), arr, len(ws), cap[0], cap[1], ctypes.byref(out)),
+                   "after_ae_create")
+        self._handle = out
+        self._cap = cap
+        return out
+
+    def reserve(self, batch: int, samples: int):
+        self._ensure(batch, samples)
+
+    # ------------------------------------------------------------ reference surface
+    @torch.no_grad()
+    def encode(self, x, with_multi: bool = False, return_mean: bool = False):
+        """SimpleNetsStream.py:918-941 -> (z, regloss); export: z only."""
+        x = _lib.require_gpu_tensor(x, "x")
+        if x.dim() != 3 or x.shape[1] != 1:
+            raise ValueError(f"encode expects [B, 1, L], got {tuple(x.shape)}")
+        B, _, L = x.shape
+        if L % self.ratio:
+            raise ValueError(f"length {L} is not a multiple of the codec ratio {self.ratio}")
+        h = self._ensure(B, L)
+        z = torch.empty(B, self.z_channels, L // self.ratio, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().after_ae_encode(h, _lib.ptr(x), _lib.ptr(z), B, L,
+                                                  _lib.current_stream(x.device)), "after_ae_encode")
+        reg = torch.zeros((), device=x.device)  # training-only regulariser (:757), not computed
+        if with_multi:
+            return z, self.pqmf_forward(x), reg
+        return z, reg
+
+    @torch.no_grad()
+    def decode(self, z, with_multi: bool = False):
+        """SimpleNetsStream.py:943-954."""
+        if with_multi:
+            raise NotImplementedError("decode(with_multi=True) is not built")
+        z = _lib.require_gpu_tensor(z, "z")
+        if z.dim() != 3 or z.shape[1] != self.z_channels:
+            raise ValueError(f"decode expects [B, {self.z_channels}, T], got {tuple(z.shape)}")
+        B, _, T = z.shape
+        h = self._ensure(B, T * self.ratio)
+        x = torch.empty(B, 1, T * self.ratio, device=z.device, dtype=torch.float32)
+        with torch.cuda.device(z.device):
+            _lib.check(_lib.lib().after_ae_decode(h, _lib.ptr(z), _lib.ptr(x), B, T,
+                                                  _lib.current_stream(z.device)), "after_ae_decode")
+        return x
+
+    def forward(self, x):
+        """export_autoencoder.py:235-249: decode(encode(x))."""
+        return self.decode(self.encode(x)[0])
+
+    @torch.no_grad()
+    def pqmf_forward(self, x):
+        x = _lib.require_gpu_tensor(x, "x")
+        B, _, L = x.shape
+        h = self._ensure(B, max(L, self.ratio))
+        mb = torch.empty(B, self.pqmf_bands, L // self.pqmf_bands, device=x.device)
+        _lib.check(_lib.lib().after_ae_pqmf_forward(h, _lib.ptr(x), _lib.ptr(mb), B, L,
+                                                    _lib.current_stream(x.device)),
+                   "after_ae_pqmf_forward")
+        return mb
+
+    @torch.no_grad()
+    def pqmf_inverse(self, mb):
+        mb = _lib.require_gpu_tensor(mb, "mb")
+        B, M, Tm = mb.shape
+        h = self._ensure(B, max(Tm * M, self.ratio))
+        x = torch.empty(B, 1, Tm * M, device=mb.device)
+        _lib.check(_lib.lib().after_ae_pqmf_inverse(h, _lib.ptr(mb), _lib.ptr(x), B, Tm,
+                                                    _lib.current_stream(mb.device)),
+                   "after_ae_pqmf_inverse")
+        return x

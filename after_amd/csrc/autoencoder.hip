@@ -1,0 +1,715 @@
+// AutoEncoder.encode / .decode on gfx950 (reference
+// after/autoencoder/networks/SimpleNetsStream.py:831-954, pqmf.py:252-301).
+//
+// Every conv layer is one launch of the implicit-GEMM kernel of conv.hip with the
+// GroupNorm-apply + SnakeBeta prologue and bias / residual epilogue fused; the
+// full-sequence GroupNorm statistics (offline semantics: one (mean, var) per
+// (clip, group) over the WHOLE time axis, SimpleNetsStream.py:146-147) come from a
+// split reduction whose last-arriving block folds them into a per-(clip, channel)
+// affine.  The two PQMF filter banks are HBM-bound polyphase FIRs on the vector
+// ALUs with their taps in scalar registers.
+#include <new>
+#include <vector>
+
+#include "conv.h"
+
+namespace after {
+namespace {
+
+// ------------------------------------------------------------------ PQMF analysis
+// mb[b, c, n] = sgn(c, n) * sum_k w[c][k] x[b, 16 n + k - pl]      (pqmf.py:286-290, 16-20)
+// polyphase form: k = 16 q + r  ->  sum_r sum_q w[c][16 q + r] xp[r][n + q],
+// xp[r][m] = x[16 m + r - pl] staged de-interleaved in LDS, so lanes (= consecutive n)
+// read consecutive addresses.  Wave = one band group: taps are wave-uniform (SGPRs).
+constexpr int PQ_BT = 64;  // frames per block
+
+__global__ __launch_bounds__(256) void pqmf_forward_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ w,
+                                                           float* __restrict__ mb, int L, int M,
+                                                           int K, int pl) {
+    extern __shared__ float xp[];  // [M][PQ_BT + Q]  (Q = ceil(K / M))
+    const int Q = (K + M - 1) / M;
+    const int ldp = PQ_BT + Q + 1;
+    const int b = blockIdx.y, n0 = blockIdx.x * PQ_BT;
+    const int Tm = L / M;
+    const float* xb = x + (size_t)b * L;
+    for (int idx = threadIdx.x; idx < M * (PQ_BT + Q); idx += 256) {
+        // consecutive threads read consecutive samples: idx = m * M + r
+        const int m = idx / M, r = idx - m * M;
+        const long long s = (long long)(n0 + m) * M + r - pl;
+        xp[r * ldp + m] = (s >= 0 && s < L) ? xb[s] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = n0 + lane;
+    // wave wv handles bands wv, wv + 4, ...
+    for (int c = wv; c < M; c += 4) {
+        const float* wc = w + (size_t)c * K;
+        float acc = 0.f;
+        for (int r = 0; r < M; ++r) {
+            const float* xr = xp + r * ldp + lane;
+            for (int q = 0; q * M + r < K; ++q) acc += wc[q * M + r] * xr[q];
+        }
+        if (n < Tm) {
+            const bool neg = (c & 1) && !(n & 1);  // reverse_half: odd bands, even frames
+            mb[((size_t)b * M + c) * Tm + n] = neg ? -acc : acc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ PQMF synthesis
+// audio[b, M t + m] = M * sum_c sum_k w[M-1-m][c][k] z[c][t + k - pl],
+// z[c][t] = sgn(c, t) * band(c, t),  band = y[c] * sigmoid(y[M + c]) with the loudness
+// gate (SimpleNetsStream.py:644-646) or y[c] without.          (pqmf.py:292-301)
+// One lane = one frame t, all M phases in registers; taps are wave-uniform.
+template <int M>
+__global__ __launch_bounds__(256) void pqmf_inverse_kernel(const float* __restrict__ y,
+                                                           const float* __restrict__ w,
+                                                           float* __restrict__ audio, int Tm,
+                                                           int K, int pl, int gated, int ychan) {
+    extern __shared__ float zs[];  // [M][256 + K]
+    const int ldz = 256 + K;
+    const int b = blockIdx.y, t0 = blockIdx.x * 256;
+    const float* yb = y + (size_t)b * ychan * Tm;
+    for (int idx = threadIdx.x; idx < M * ldz; idx += 256) {
+        const int c = idx / ldz, col = idx - c * ldz;
+        const int t = t0 + col - pl;
+        float v = 0.f;
+        if (t >= 0 && t < Tm) {
+            v = yb[(size_t)c * Tm + t];
+            if (gated) v *= 1.0f / (1.0f + expf(-yb[(size_t)(M + c) * Tm + t]));
+            if ((c & 1) && !(t & 1)) v = -v;
+        }
+        zs[idx] = v;
+    }
+    __syncthreads();
+    float acc[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) acc[m] = 0.f;
+    for (int c = 0; c < M; ++c) {
+        const float* zc = zs + c * ldz + threadIdx.x;
+        for (int k = 0; k < K; ++k) {
+            const float zv = zc[k];
+#pragma unroll
+            for (int m = 0; m < M; ++m) acc[m] += w[((size_t)(M - 1 - m) * M + c) * K + k] * zv;
+        }
+    }
+    const int t = t0 + threadIdx.x;
+    if (t < Tm) {
+        float* o = audio + (size_t)b * Tm * M + (size_t)t * M;
+#pragma unroll
+        for (int m = 0; m < M; m += 4)
+            *reinterpret_cast<float4*>(o + m) = make_float4(acc[m] * M, acc[m + 1] * M,
+                                                            acc[m + 2] * M, acc[m + 3] * M);
+    }
+}
+
+// generic (any M) fallback of the synthesis bank: one thread per output sample
+__global__ __launch_bounds__(256) void pqmf_inverse_generic_kernel(const float* __restrict__ y,
+                                                                   const float* __restrict__ w,
+                                                                   float* __restrict__ audio,
+                                                                   int Tm, int M, int K, int pl,
+                                                                   int gated, int ychan) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (idx >= (size_t)Tm * M) return;
+    const int t = idx / M, m = idx - (size_t)t * M;
+    const float* yb = y + (size_t)b * ychan * Tm;
+    float acc = 0.f;
+    for (int c = 0; c < M; ++c)
+        for (int k = 0; k < K; ++k) {
+            const int tt = t + k - pl;
+            if (tt < 0 || tt >= Tm) continue;
+            float v = yb[(size_t)c * Tm + tt];
+            if (gated) v *= 1.0f / (1.0f + expf(-yb[(size_t)(M + c) * Tm + tt]));
+            if ((c & 1) && !(tt & 1)) v = -v;
+            acc += w[((size_t)(M - 1 - m) * M + c) * K + k] * v;
+        }
+    audio[(size_t)b * Tm * M + idx] = acc * M;
+}
+
+}  // namespace
+}  // namespace after
+
+using namespace after;
+
+namespace {
+
+struct ConvBlockW {
+    float *gn_w = nullptr, *gn_b = nullptr, *alpha = nullptr, *invb = nullptr, *w = nullptr,
+          *bias = nullptr;
+    int cin = 0, cout = 0, k = 1, dil = 1;
+};
+struct ResBlockW {
+    ConvBlockW cb0, cb1;
+    float *to_w = nullptr, *to_b = nullptr;  // 1x1 shortcut when cin != cout
+};
+struct ResampleW {
+    float *alpha = nullptr, *invb = nullptr, *w = nullptr, *bias = nullptr;
+    int cin = 0, cout = 0, f = 1;
+};
+struct PlainConvW {
+    float *w = nullptr, *bias = nullptr;
+    int cin = 0, cout = 0, k = 3;
+};
+
+}  // namespace
+
+struct after_ae {
+    after_ae_cfg cfg;
+    int M, ratio, max_batch, max_samples;
+    bool causal, norm;
+    Arena wa, ws;
+    float *pq_fw = nullptr, *pq_iw = nullptr;
+    int pq_fk = 0, pq_ik = 0;
+    // encoder
+    ResBlockW enc_stem;
+    std::vector<std::vector<ResBlockW>> enc_res;
+    std::vector<ResampleW> enc_down;
+    float *enc_tail_alpha = nullptr, *enc_tail_invb = nullptr;
+    PlainConvW enc_tail;
+    // decoder
+    PlainConvW dec_head;
+    std::vector<ResampleW> dec_up;
+    std::vector<std::vector<ResBlockW>> dec_res;
+    ConvBlockW synth0, synth1;
+    // workspaces
+    float *buf[3] = {nullptr, nullptr, nullptr};
+    size_t buf_elems = 0;
+    float *scale = nullptr, *shift = nullptr;
+    double* gn_part = nullptr;
+    unsigned* gn_tick = nullptr;
+    int cmax = 0;
+};
+
+namespace {
+
+struct WeightCursor {
+    const float* const* w;
+    int n, i = 0;
+    bool ok = true;
+    const float* next(bool optional = false) {
+        if (i >= n) {
+            ok = false;
+            return nullptr;
+        }
+        const float* p = w[i++];
+        if (!p && !optional) ok = false;
+        return p;
+    }
+};
+
+#define AE_TAKE(ptr, n)                                              \
+    do {                                                             \
+        (ptr) = h->wa.take<float>(n);                                \
+        if (!(ptr)) {                                                \
+            set_error("autoencoder: weight arena exhausted");        \
+            return AFTER_E_NOMEM;                                    \
+        }                                                            \
+    } while (0)
+
+int copy_vec(after_ae* h, float** dst, const float* src, int n) {
+    AE_TAKE(*dst, n);
+    AFTER_HIP_CHECK(hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyDeviceToDevice));
+    return AFTER_OK;
+}
+
+int load_snake(after_ae* h, WeightCursor& c, float** alpha, float** invb, int C) {
+    const float* a = c.next();
+    const float* b = c.next();
+    AFTER_REQUIRE(c.ok, AFTER_E_INVALID, "autoencoder: missing snake parameters");
+    AFTER_TRY(copy_vec(h, alpha, a, C));
+    AE_TAKE(*invb, C);
+    return snake_inv_beta(b, *invb, C, 0);
+}
+
+int load_wnconv(after_ae* h, WeightCursor& c, float** w, float** bias, int cout, int cin, int k) {
+    const float* g = c.next();
+    const float* v = c.next();
+    const float* b = c.next();
+    AFTER_REQUIRE(c.ok, AFTER_E_INVALID, "autoencoder: missing conv weights");
+    AE_TAKE(*w, (size_t)cout * k * pad16(cin));
+    AFTER_TRY(pack_conv_weight(v, g, *w, cout, cin, k, pad16(cin), 0));
+    return copy_vec(h, bias, b, cout);
+}
+
+int load_convblock(after_ae* h, WeightCursor& c, ConvBlockW& cb, int cin, int cout, int k, int dil) {
+    cb.cin = cin;
+    cb.cout = cout;
+    cb.k = k;
+    cb.dil = dil;
+    const float* gw = c.next(true);
+    const float* gb = c.next(true);
+    if (h->norm) {
+        AFTER_REQUIRE(gw && gb, AFTER_E_INVALID, "autoencoder: GroupNorm parameters missing");
+        AFTER_TRY(copy_vec(h, &cb.gn_w, gw, cin));
+        AFTER_TRY(copy_vec(h, &cb.gn_b, gb, cin));
+    }
+    AFTER_TRY(load_snake(h, c, &cb.alpha, &cb.invb, cin));
+    return load_wnconv(h, c, &cb.w, &cb.bias, cout, cin, k);
+}
+
+int load_resblock(after_ae* h, WeightCursor& c, ResBlockW& rb, int cin, int cout, int k, int dil) {
+    AFTER_TRY(load_convblock(h, c, rb.cb0, cin, cout, k, dil));
+    AFTER_TRY(load_convblock(h, c, rb.cb1, cout, cout, 1, 1));
+    if (cin != cout) AFTER_TRY(load_wnconv(h, c, &rb.to_w, &rb.to_b, cout, cin, 1));
+    return AFTER_OK;
+}
+
+// cached_conv.get_padding left pad (stride ignored): p = (k-1) d + 1
+int left_pad(int k, int dil, bool causal) {
+    if (k == 1) return 0;
+    const int p = (k - 1) * dil + 1;
+    return causal ? p / 2 + (p - 1) / 2 : (p - 1) / 2;
+}
+
+void base_args(ConvArgs& a, int B, int cin, int cout, int Tin, int Tout) {
+    memset(&a, 0, sizeof(a));
+    a.B = B;
+    a.Cin = cin;
+    a.Cin_pad = pad16(cin);
+    a.Cout = cout;
+    a.Tin = Tin;
+    a.Tout = Tout;
+    a.x_bstride = cin * Tin;
+    a.y_bstride = cout * Tout;
+    a.res_bstride = cout * Tout;
+    a.taps = 1;
+    a.phases = 1;
+    a.istride = 1;
+    a.ostride = 1;
+    a.Nn = Tout;
+    a.act = ACT_NONE;
+    a.pad = PAD_ZERO;
+    a.out_act = ACT_NONE;
+}
+
+int run_gn(after_ae* h, hipStream_t s, const float* x, const ConvBlockW& cb, int B, int T) {
+    GnArgs g;
+    g.x = x;
+    g.gamma = cb.gn_w;
+    g.beta = cb.gn_b;
+    g.scale = h->scale;
+    g.shift = h->shift;
+    g.partials = h->gn_part;
+    g.tickets = h->gn_tick;
+    g.B = B;
+    g.C = cb.cin;
+    g.T = T;
+    g.G = cb.cin < 8 ? cb.cin : 8;  // SimpleNetsStream.py:165: min(in_channels, num_groups)
+    g.splits = gn_splits(g.C, T, g.G);
+    g.eps = 1e-5f;
+    return launch_gn_affine(g, s);
+}
+
+// ConvBlock1d (SimpleNetsStream.py:150-194)
+int run_convblock(after_ae* h, hipStream_t s, const ConvBlockW& cb, const float* x, float* y,
+                  const float* res, int B, int T) {
+    if (h->norm) AFTER_TRY(run_gn(h, s, x, cb, B, T));
+    ConvArgs a;
+    base_args(a, B, cb.cin, cb.cout, T, T);
+    a.x = x;
+    a.y = y;
+    a.w = cb.w;
+    a.bias = cb.bias;
+    a.res = res;
+    a.scale = h->norm ? h->scale : nullptr;
+    a.shift = h->norm ? h->shift : nullptr;
+    a.act = ACT_SNAKE;
+    a.act_a = cb.alpha;
+    a.act_b = cb.invb;
+    a.taps = cb.k;
+    const int pl = left_pad(cb.k, cb.dil, h->causal);
+    for (int t = 0; t < cb.k; ++t) a.toff[0][t] = t * cb.dil - pl;
+    return launch_conv(a, s);
+}
+
+// ResnetBlock1d (SimpleNetsStream.py:197-254): y = cb1(cb0(x)) + (to_out(x) | x)
+// x in bx, scratch in bt, result in by (all distinct).
+int run_resblock(after_ae* h, hipStream_t s, const ResBlockW& rb, const float* bx, float* bt,
+                 float* by, int B, int T) {
+    const float* res = bx;
+    if (rb.to_w) {
+        ConvArgs a;
+        base_args(a, B, rb.cb0.cin, rb.cb0.cout, T, T);
+        a.x = bx;
+        a.y = by;
+        a.w = rb.to_w;
+        a.bias = rb.to_b;
+        a.toff[0][0] = 0;
+        AFTER_TRY(launch_conv(a, s));
+        res = by;  // residual read and result write hit the same element in one thread
+    }
+    AFTER_TRY(run_convblock(h, s, rb.cb0, bx, bt, nullptr, B, T));
+    return run_convblock(h, s, rb.cb1, bt, by, res, B, T);
+}
+
+int check_ae(after_ae* h, int B, long long samples) {
+    AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
+    AFTER_REQUIRE(B > 0 && samples > 0, AFTER_E_INVALID, "empty batch");
+    AFTER_REQUIRE(B <= h->max_batch && samples <= h->max_samples, AFTER_E_CAPACITY,
+                  "B=%d samples=%lld exceed max_batch=%d max_samples=%d", B, samples, h->max_batch,
+                  h->max_samples);
+    AFTER_REQUIRE(samples % h->ratio == 0, AFTER_E_INVALID,
+                  "length %lld is not a multiple of the codec ratio %d", samples, h->ratio);
+    return AFTER_OK;
+}
+
+int pqmf_forward(after_ae* h, hipStream_t s, const float* x, float* mb, int B, int L) {
+    const int M = h->M, K = h->pq_fk;
+    const int Q = (K + M - 1) / M;
+    const int pl = h->causal ? K - 1 : (K - 1) / 2;
+    const size_t lds = (size_t)M * (PQ_BT + Q + 1) * sizeof(float);
+    hipLaunchKernelGGL(pqmf_forward_kernel, dim3(cdiv(L / M, PQ_BT), B), dim3(256), lds, s, x,
+                       h->pq_fw, mb, L, M, K, pl);
+    AFTER_HIP_CHECK(hipGetLastError());
+    return AFTER_OK;
+}
+
+int pqmf_inverse(after_ae* h, hipStream_t s, const float* y, float* audio, int B, int Tm, int gated,
+                 int ychan) {
+    const int M = h->M, K = h->pq_ik;
+    const int pl = h->causal ? K - 1 : (K - 1) / 2;
+    if (M == 16) {
+        const size_t lds = (size_t)M * (256 + K) * sizeof(float);
+        hipLaunchKernelGGL(pqmf_inverse_kernel<16>, dim3(cdiv(Tm, 256), B), dim3(256), lds, s, y,
+                           h->pq_iw, audio, Tm, K, pl, gated, ychan);
+    } else {
+        hipLaunchKernelGGL(pqmf_inverse_generic_kernel, dim3((unsigned)cdivll((long long)Tm * M, 256), B),
+                           dim3(256), 0, s, y, h->pq_iw, audio, Tm, M, K, pl, gated, ychan);
+    }
+    AFTER_HIP_CHECK(hipGetLastError());
+    return AFTER_OK;
+}
+
+}  // namespace
+
+extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weights, int n_weights,
+                               int max_batch, int max_samples, after_ae** out) {
+    AFTER_REQUIRE(cfg && weights && out, AFTER_E_INVALID, "null argument");
+    *out = nullptr;
+    AFTER_REQUIRE(cfg->n_stages >= 1 && cfg->n_stages <= AFTER_AE_MAX_STAGES &&
+                      cfg->n_dilations >= 1 && cfg->n_dilations <= AFTER_AE_MAX_STAGES,
+                  AFTER_E_INVALID, "autoencoder: bad stage / dilation count");
+    AFTER_REQUIRE(cfg->pqmf_bands >= 2 && cfg->kernel_size % 2 == 1 && cfg->kernel_size <= 7,
+                  AFTER_E_INVALID, "autoencoder: pqmf_bands >= 2 and odd kernel_size <= 7 required");
+    AFTER_REQUIRE(max_batch > 0 && max_samples > 0, AFTER_E_INVALID, "bad capacities");
+    after_ae* h = new (std::nothrow) after_ae();
+    AFTER_REQUIRE(h, AFTER_E_NOMEM, "out of host memory");
+    h->cfg = *cfg;
+    h->M = cfg->pqmf_bands;
+    h->causal = cfg->causal != 0;
+    h->norm = cfg->use_norm != 0;
+    h->max_batch = max_batch;
+    int ratio = h->M;
+    for (int i = 0; i < cfg->n_stages; ++i) ratio *= cfg->factors[i];
+    h->ratio = ratio;
+    h->max_samples = (max_samples / ratio) * ratio;
+    const int n = cfg->n_stages, nd = cfg->n_dilations, k = cfg->kernel_size, C0 = cfg->channels;
+    const int out_ch = cfg->use_loudness ? 2 * h->M : h->M;
+
+    auto fail = [&](int rc) {
+        after_ae_destroy(h);
+        return rc;
+    };
+    // weight arena size: walk the architecture
+    size_t wf = 0;
+    auto cbsz = [&](int cin, int cout, int kk) {
+        return (size_t)cout * kk * pad16(cin) + cout + 4 * (size_t)cin + 6 * 64;
+    };
+    {
+        int c = C0 * cfg->multipliers[0];
+        wf += cbsz(h->M, c, k) + cbsz(c, c, 1) + cbsz(h->M, c, 1);
+        for (int i = 0; i < n; ++i) {
+            c = C0 * cfg->multipliers[i];
+            const int cn = C0 * cfg->multipliers[i + 1];
+            wf += nd * (cbsz(c, c, k) + cbsz(c, c, 1)) + cbsz(c, cn, 2 * cfg->factors[i]);
+        }
+        wf += cbsz(C0 * cfg->multipliers[n], cfg->z_channels, 3);
+        c = C0 * cfg->dec_multipliers[0];
+        wf += cbsz(cfg->z_channels, c, k);
+        for (int i = 0; i < n; ++i) {
+            c = C0 * cfg->dec_multipliers[i];
+            const int cn = C0 * cfg->dec_multipliers[i + 1];
+            wf += cbsz(c, cn, 2 * cfg->factors[n - 1 - i]) + nd * (cbsz(cn, cn, k) + cbsz(cn, cn, 1));
+        }
+        c = C0 * cfg->dec_multipliers[n];
+        wf += cbsz(c, out_ch, k) + cbsz(out_ch, out_ch, 1);
+        wf += (size_t)h->M * 1024 + (size_t)h->M * h->M * 64;
+    }
+    int rc = h->wa.init(wf * sizeof(float) + (1 << 20));
+    if (rc != AFTER_OK) return fail(rc);
+
+    WeightCursor cur{weights, n_weights};
+#define AE_TRY(expr)                        \
+    do {                                    \
+        int rc2__ = (expr);                 \
+        if (rc2__ != AFTER_OK) return fail(rc2__); \
+    } while (0)
+    // PQMF banks (pqmf.py:258-280): forward [M,1,Kf], inverse [M,M,Ki]; the kernel sizes
+    // follow from the arena request below (Kf = 32 M + 1, Ki = 2 M + 1 for hk of 32 M taps)
+    h->pq_fk = 32 * h->M + 1;
+    h->pq_ik = 2 * h->M + 1;
+    {
+        const float* fw = cur.next();
+        const float* iw = cur.next();
+        if (!cur.ok) {
+            set_error("autoencoder: missing pqmf filters");
+            return fail(AFTER_E_INVALID);
+        }
+        AE_TRY(copy_vec(h, &h->pq_fw, fw, h->M * h->pq_fk));
+        AE_TRY(copy_vec(h, &h->pq_iw, iw, h->M * h->M * h->pq_ik));
+    }
+    // encoder (SimpleNetsStream.py:400-459)
+    AE_TRY(load_resblock(h, cur, h->enc_stem, h->M, C0 * cfg->multipliers[0], k, 1));
+    h->enc_res.resize(n);
+    h->enc_down.resize(n);
+    for (int i = 0; i < n; ++i) {
+        const int c = C0 * cfg->multipliers[i], cn = C0 * cfg->multipliers[i + 1];
+        h->enc_res[i].resize(nd);
+        for (int j = 0; j < nd; ++j)
+            AE_TRY(load_resblock(h, cur, h->enc_res[i][j], c, c, k, cfg->dilations[j]));
+        ResampleW& d = h->enc_down[i];
+        d.cin = c;
+        d.cout = cn;
+        d.f = cfg->factors[i];
+        AE_TRY(load_snake(h, cur, &d.alpha, &d.invb, c));
+        AE_TRY(load_wnconv(h, cur, &d.w, &d.bias, cn, c, 2 * d.f));
+    }
+    {
+        const int c = C0 * cfg->multipliers[n];
+        AE_TRY(load_snake(h, cur, &h->enc_tail_alpha, &h->enc_tail_invb, c));
+        h->enc_tail.cin = c;
+        h->enc_tail.cout = cfg->z_channels;
+        h->enc_tail.k = 3;
+        AE_TRY(load_wnconv(h, cur, &h->enc_tail.w, &h->enc_tail.bias, cfg->z_channels, c, 3));
+    }
+    // decoder (SimpleNetsStream.py:552-651)
+    h->dec_head.cin = cfg->z_channels;
+    h->dec_head.cout = C0 * cfg->dec_multipliers[0];
+    h->dec_head.k = k;
+    AE_TRY(load_wnconv(h, cur, &h->dec_head.w, &h->dec_head.bias, h->dec_head.cout, cfg->z_channels, k));
+    h->dec_up.resize(n);
+    h->dec_res.resize(n);
+    for (int i = 0; i < n; ++i) {
+        const int c = C0 * cfg->dec_multipliers[i], cn = C0 * cfg->dec_multipliers[i + 1];
+        ResampleW& u = h->dec_up[i];
+        u.cin = c;
+        u.cout = cn;
+        u.f = cfg->factors[n - 1 - i];
+        if (!(u.f >= 2 && u.f <= kMaxPhases && u.f % 2 == 0)) {
+            set_error("autoencoder: upsampling factor %d unsupported (even, <= %d)", u.f, kMaxPhases);
+            return fail(AFTER_E_INVALID);
+        }
+        AE_TRY(load_snake(h, cur, &u.alpha, &u.invb, c));
+        {
+            const float* g = cur.next();
+            const float* v = cur.next();
+            const float* b = cur.next();
+            if (!cur.ok) {
+                set_error("autoencoder: missing transposed conv weights");
+                return fail(AFTER_E_INVALID);
+            }
+            u.w = h->wa.take<float>((size_t)u.f * cn * 2 * pad16(c));
+            if (!u.w) return fail(AFTER_E_NOMEM);
+            AE_TRY(pack_convT_weight(v, g, u.w, c, cn, u.f, pad16(c), 0));
+            AE_TRY(copy_vec(h, &u.bias, b, cn));
+        }
+        h->dec_res[i].resize(nd);
+        for (int j = 0; j < nd; ++j)
+            AE_TRY(load_resblock(h, cur, h->dec_res[i][j], cn, cn, k, cfg->dilations[j]));
+    }
+    {
+        const int c = C0 * cfg->dec_multipliers[n];
+        AE_TRY(load_convblock(h, cur, h->synth0, c, out_ch, k, 1));
+        AE_TRY(load_convblock(h, cur, h->synth1, out_ch, out_ch, 1, 1));
+    }
+    if (!cur.ok || cur.i != n_weights) {
+        set_error("autoencoder: expected %d weight tensors, got %d", cur.i, n_weights);
+        return fail(AFTER_E_INVALID);
+    }
+#undef AE_TRY
+
+    // workspaces: three rotating activation buffers of the largest C x T footprint
+    size_t elems = 0;
+    int cmax = h->M;
+    {
+        const size_t Tm = h->max_samples / h->M;
+        size_t T = Tm;
+        auto upd = [&](int c, size_t t) {
+            elems = (size_t)c * t > elems ? (size_t)c * t : elems;
+            cmax = c > cmax ? c : cmax;
+        };
+        upd(out_ch, Tm);
+        for (int i = 0; i <= n; ++i) {
+            upd(C0 * cfg->multipliers[i], T);
+            if (i < n) T /= cfg->factors[i];
+        }
+        T = h->max_samples / h->ratio;
+        for (int i = 0; i <= n; ++i) {
+            upd(C0 * cfg->dec_multipliers[i], T);
+            if (i < n) {
+                T *= cfg->factors[n - 1 - i];
+                upd(C0 * cfg->dec_multipliers[i + 1], T);
+            }
+        }
+    }
+    h->buf_elems = elems * max_batch;
+    h->cmax = cmax;
+    rc = h->ws.init(3 * h->buf_elems * sizeof(float) + 2 * (size_t)max_batch * cmax * sizeof(float) +
+                    (size_t)max_batch * 8 * 64 * 2 * sizeof(double) + (size_t)max_batch * 8 * 4 + 4096);
+    if (rc != AFTER_OK) return fail(rc);
+    for (int i = 0; i < 3; ++i) h->buf[i] = h->ws.take<float>(h->buf_elems);
+    h->scale = h->ws.take<float>((size_t)max_batch * cmax);
+    h->shift = h->ws.take<float>((size_t)max_batch * cmax);
+    h->gn_part = h->ws.take<double>((size_t)max_batch * 8 * 64 * 2);
+    h->gn_tick = h->ws.take<unsigned>((size_t)max_batch * 8);
+    if (!h->buf[2] || !h->scale || !h->shift || !h->gn_part || !h->gn_tick) return fail(AFTER_E_NOMEM);
+    if (hipMemset(h->gn_tick, 0, (size_t)max_batch * 8 * sizeof(unsigned)) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess) {
+        set_error("autoencoder: device initialisation failed");
+        return fail(AFTER_E_HIP);
+    }
+    *out = h;
+    return AFTER_OK;
+}
+
+extern "C" void after_ae_destroy(after_ae* h) {
+    if (!h) return;
+    h->wa.release();
+    h->ws.release();
+    delete h;
+}
+
+extern "C" int after_ae_ratio(const after_ae* h) { return h ? h->ratio : 0; }
+
+extern "C" int after_ae_pqmf_forward(after_ae* h, const float* x, float* mb, int B, int L,
+                                     void* stream) {
+    AFTER_REQUIRE(h && x && mb, AFTER_E_INVALID, "null argument");
+    AFTER_REQUIRE(B > 0 && L > 0 && L % h->M == 0, AFTER_E_INVALID, "pqmf: L must be a multiple of %d", h->M);
+    return pqmf_forward(h, (hipStream_t)stream, x, mb, B, L);
+}
+
+extern "C" int after_ae_pqmf_inverse(after_ae* h, const float* mb, float* x, int B, int Tm,
+                                     void* stream) {
+    AFTER_REQUIRE(h && x && mb && B > 0 && Tm > 0, AFTER_E_INVALID, "bad argument");
+    return pqmf_inverse(h, (hipStream_t)stream, mb, x, B, Tm, 0, h->M);
+}
+
+extern "C" int after_ae_encode(after_ae* h, const float* x, float* z, int B, int L, void* stream) {
+    AFTER_TRY(check_ae(h, B, L));
+    AFTER_REQUIRE(x && z, AFTER_E_INVALID, "null tensor");
+    hipStream_t s = (hipStream_t)stream;
+    const after_ae_cfg& c = h->cfg;
+    const int n = c.n_stages, nd = c.n_dilations;
+    int T = L / h->M;
+    float *b0 = h->buf[0], *b1 = h->buf[1], *b2 = h->buf[2];
+    AFTER_TRY(pqmf_forward(h, s, x, b0, B, L));
+    AFTER_TRY(run_resblock(h, s, h->enc_stem, b0, b1, b2, B, T));
+    float *cur = b2, *t1 = b0, *t2 = b1;
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < nd; ++j) {
+            AFTER_TRY(run_resblock(h, s, h->enc_res[i][j], cur, t1, t2, B, T));
+            float* o = cur;
+            cur = t2;
+            t2 = o;
+        }
+        // Snake -> strided conv (Downsample1d, :32-48): k = 2f, stride f, pad get_padding(2f)
+        const ResampleW& d = h->enc_down[i];
+        ConvArgs a;
+        base_args(a, B, d.cin, d.cout, T, T / d.f);
+        a.x = cur;
+        a.y = t1;
+        a.w = d.w;
+        a.bias = d.bias;
+        a.act = ACT_SNAKE;
+        a.act_a = d.alpha;
+        a.act_b = d.invb;
+        a.taps = 2 * d.f;
+        a.istride = d.f;
+        const int pl = left_pad(2 * d.f, 1, h->causal);
+        for (int t = 0; t < a.taps; ++t) a.toff[0][t] = t - pl;
+        AFTER_TRY(launch_conv(a, s));
+        float* o = cur;
+        cur = t1;
+        t1 = o;
+        T /= d.f;
+    }
+    {
+        ConvArgs a;
+        base_args(a, B, h->enc_tail.cin, h->enc_tail.cout, T, T);
+        a.x = cur;
+        a.y = z;
+        a.w = h->enc_tail.w;
+        a.bias = h->enc_tail.bias;
+        a.act = ACT_SNAKE;
+        a.act_a = h->enc_tail_alpha;
+        a.act_b = h->enc_tail_invb;
+        a.taps = 3;
+        const int pl = left_pad(3, 1, h->causal);
+        for (int t = 0; t < 3; ++t) a.toff[0][t] = t - pl;
+        AFTER_TRY(launch_conv(a, s));
+    }
+    return AFTER_OK;
+}
+
+extern "C" int after_ae_decode(after_ae* h, const float* z, float* x, int B, int T, void* stream) {
+    AFTER_TRY(check_ae(h, B, (long long)T * (h ? h->ratio : 1)));
+    AFTER_REQUIRE(z && x, AFTER_E_INVALID, "null tensor");
+    hipStream_t s = (hipStream_t)stream;
+    const after_ae_cfg& c = h->cfg;
+    const int n = c.n_stages, nd = c.n_dilations;
+    float *cur = h->buf[0], *t1 = h->buf[1], *t2 = h->buf[2];
+    {
+        ConvArgs a;
+        base_args(a, B, h->dec_head.cin, h->dec_head.cout, T, T);
+        a.x = z;
+        a.y = cur;
+        a.w = h->dec_head.w;
+        a.bias = h->dec_head.bias;
+        a.taps = h->dec_head.k;
+        const int pl = left_pad(a.taps, 1, h->causal);
+        for (int t = 0; t < a.taps; ++t) a.toff[0][t] = t - pl;
+        AFTER_TRY(launch_conv(a, s));
+    }
+    for (int i = 0; i < n; ++i) {
+        // Snake -> ConvTranspose1d(k = 2f, stride f, padding f/2) as f two-tap phases
+        const ResampleW& u = h->dec_up[i];
+        ConvArgs a;
+        base_args(a, B, u.cin, u.cout, T, T * u.f);
+        a.x = cur;
+        a.y = t1;
+        a.w = u.w;
+        a.bias = u.bias;
+        a.act = ACT_SNAKE;
+        a.act_a = u.alpha;
+        a.act_b = u.invb;
+        a.taps = 2;
+        a.phases = u.f;
+        a.ostride = u.f;
+        a.Nn = T;
+        for (int r = 0; r < u.f; ++r) {
+            const int cc = (r + u.f / 2) / u.f;
+            a.toff[r][0] = cc - 1;
+            a.toff[r][1] = cc;
+            a.ooff[r] = r;
+        }
+        AFTER_TRY(launch_conv(a, s));
+        float* o = cur;
+        cur = t1;
+        t1 = o;
+        T *= u.f;
+        for (int j = 0; j < nd; ++j) {
+            AFTER_TRY(run_resblock(h, s, h->dec_res[i][j], cur, t1, t2, B, T));
+            o = cur;
+            cur = t2;
+            t2 = o;
+        }
+    }
+    // synth: ResnetBlock1dNoRes (:257-298), loudness gate + PQMF synthesis fused
+    AFTER_TRY(run_convblock(h, s, h->synth0, cur, t1, nullptr, B, T));
+    AFTER_TRY(run_convblock(h, s, h->synth1, t1, t2, nullptr, B, T));
+    const int out_ch = c.use_loudness ? 2 * h->M : h->M;
+    return pqmf_inverse(h, s, t2, x, B, T, c.use_loudness, out_ch);
+}

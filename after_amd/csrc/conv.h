@@ -1,0 +1,76 @@
+// 1-D convolution family of the AFTER autoencoder / conditioning encoders on gfx950.
+#pragma once
+#include "common.h"
+
+namespace after {
+
+enum ConvAct { ACT_NONE = 0, ACT_SNAKE = 1, ACT_SILU = 2, ACT_RELU = 3, ACT_TANH = 4 };
+enum ConvPad { PAD_ZERO = 0, PAD_REFLECT = 1 };
+
+constexpr int kMaxTaps = 8;
+constexpr int kMaxPhases = 4;
+
+// y[b, co, n*ostride + ooff[ph]] = bias[co] + res[...] +
+//     sum_{tap, ci} w[ph][co][tap][ci] * A(x[b, ci, n*istride + toff[ph][tap]])
+// with A(v) = act(v * scale[b,ci] + shift[b,ci]) applied BEFORE the (zero / reflect)
+// padding, i.e. out-of-range taps contribute exactly 0 in PAD_ZERO mode -- the
+// reference pads the activated tensor (cached_conv.Conv1d: F.pad then conv).
+struct ConvArgs {
+    const float* x;      // [B, Cin, Tin]
+    const float* w;      // packed [phases][Cout][taps][Cin_pad]
+    const float* bias;   // [Cout] or nullptr
+    const float* res;    // [B, Cout, Tout] or nullptr (added in the epilogue)
+    float* y;            // [B, Cout, Tout]
+    const float* scale;  // [B, Cin] or nullptr (identity affine)
+    const float* shift;  // [B, Cin]
+    const float* act_a;  // snake: alpha[Cin]
+    const float* act_b;  // snake: 1 / (beta[Cin] + 1e-9)
+    float* post_mul;     // nullptr, or gate tensor: y = acc * sigmoid(gate) handled by caller (unused)
+    int act, pad;
+    int B, Cin, Cin_pad, Cout, Tin, Tout;
+    int x_bstride;       // floats between batch items of x (allows channel-sliced views)
+    int x_coff;          // first input channel within x's channel dim
+    int y_bstride, y_coff;  // same for y (write into a channel slice of a wider tensor)
+    int res_bstride, res_coff;
+    int taps, phases, istride, ostride;
+    int Nn;              // output positions per phase
+    int toff[kMaxPhases][kMaxTaps];
+    int ooff[kMaxPhases];
+    int out_act;         // activation applied to the result (ACT_NONE / ACT_RELU / ACT_TANH / ...)
+};
+int launch_conv(const ConvArgs& a, hipStream_t s);
+
+// GroupNorm statistics -> per-(b, channel) affine  scale = rstd*gamma, shift = beta - mean*rstd*gamma
+// (nn.GroupNorm: biased variance over (C/G x T), eps inside the sqrt; reference
+// SimpleNetsStream.py:95-147 offline path).  `scratch` holds partials + tickets.
+struct GnArgs {
+    const float* x;  // [B, C, T]
+    const float* gamma;
+    const float* beta;
+    float* scale;    // [B, C]
+    float* shift;
+    double* partials;  // [B*G*splits*2]
+    unsigned* tickets; // [B*G], zero on entry, zero on exit
+    int B, C, T, G, splits;
+    float eps;
+};
+int launch_gn_affine(const GnArgs& a, hipStream_t s);
+int gn_splits(int C, int T, int G);
+
+// BatchNorm1d (eval) -> per-channel affine, replicated over B (done once at create)
+int launch_bn_affine(const float* w, const float* b, const float* rm, const float* rv, float* scale,
+                     float* shift, int C, int B, float eps, hipStream_t s);
+
+// weight-norm fold + re-layout (done once at create):
+//   conv     v[Cout,Cin,k], g[Cout]  -> out[Cout][k][Cin_pad]
+//   convT    v[Cin,Cout,2f], g[Cin]  -> out[f phases][Cout][2 taps][Cin_pad]
+// g == nullptr: plain weights (no weight norm).
+int pack_conv_weight(const float* v, const float* g, float* out, int Cout, int Cin, int k,
+                     int Cin_pad, hipStream_t s);
+int pack_convT_weight(const float* v, const float* g, float* out, int Cin, int Cout, int f,
+                      int Cin_pad, hipStream_t s);
+int snake_inv_beta(const float* beta, float* out, int C, hipStream_t s);
+
+inline int pad16(int c) { return (c + 15) & ~15; }
+
+}  // namespace after

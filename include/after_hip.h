@@ -126,6 +126,64 @@ int after_denoiser_profile(after_denoiser* h, int enable);
 int after_denoiser_gemm_time_ms(after_denoiser* h, double* total_ms, long long* launches,
                                 double* flops);
 
+/* --------------------------------------------------------------- autoencoder
+ * AutoEncoder (after/autoencoder/networks/SimpleNetsStream.py:831-954): PQMF +
+ * dilated-conv encoder / decoder.  The TorchScript export keeps exactly
+ * encode / decode (after_scripts/export_autoencoder.py:235-265). */
+#define AFTER_AE_MAX_STAGES 8
+typedef struct after_ae_cfg {
+    int pqmf_bands;      /* 16 (= in_channels of the conv nets)                       */
+    int channels;        /* BASE_CHANNELS                                             */
+    int z_channels;      /* LATENT_SIZE                                               */
+    int n_stages;        /* len(factors)                                              */
+    int n_dilations;     /* len(dilations) = ResnetBlock1d per stage                  */
+    int kernel_size;     /* 3                                                         */
+    int use_norm;        /* GroupNorm(min(C,8)) in every ConvBlock1d                  */
+    int use_loudness;    /* decoder emits 2x bands, x * sigmoid(amplitude) (:644-646) */
+    int causal;          /* cached_conv.get_padding mode (baseAE.gin:32-33)           */
+    int multipliers[AFTER_AE_MAX_STAGES + 1];     /* encoder channel multipliers      */
+    int dec_multipliers[AFTER_AE_MAX_STAGES + 1]; /* int(m * decoder_ratio), reversed */
+    int factors[AFTER_AE_MAX_STAGES];             /* encoder order                    */
+    int dilations[AFTER_AE_MAX_STAGES];
+} after_ae_cfg;
+
+/* Order of the `weights` array (reference state-dict keys).
+ * CB(p) = the 7 tensors of a ConvBlock1d under prefix p:
+ *     p.net.0.gn.weight, p.net.0.gn.bias (NULL when use_norm = 0), p.net.1.alpha,
+ *     p.net.1.beta, p.net.2.weight_g, p.net.2.weight_v, p.net.2.bias
+ * WN(p) = p.weight_g, p.weight_v, p.bias ;  SN(p) = p.alpha, p.beta
+ *   pqmf.forward_conv.weight, pqmf.inverse_conv.weight
+ *   encoder.net.0:  CB(.net.branches.0.0) CB(.net.branches.0.1) [WN(.net.branches.1) iff
+ *                   pqmf_bands != channels*multipliers[0]]
+ *   encoder.net.{1+i} (stage i): for j < n_dilations: CB(.net.j.net.branches.0.0)
+ *                   CB(.net.j.net.branches.0.1); SN(.net.{nd}); WN(.net.{nd+1})
+ *   SN(encoder.net.{n+1}) WN(encoder.net.{n+2})
+ *   WN(decoder.net.0)
+ *   decoder.net.{1+i}: SN(.net.0) WN(.net.1) then for j: CB(.net.{2+j}.net.branches.0.0)
+ *                   CB(.net.{2+j}.net.branches.0.1)
+ *   CB(decoder.synth.branches.0.net.0) CB(decoder.synth.branches.0.net.1)
+ */
+typedef struct after_ae after_ae;
+
+/* Folds weight-norm, packs the conv weights for the MFMA kernels and provisions
+ * workspaces for max_batch clips of max_samples audio samples.
+ * Replaces: AutoEncoder.__init__ + load_state_dict (SimpleNetsStream.py:834-896). */
+int after_ae_create(const after_ae_cfg* cfg, const float* const* weights, int n_weights,
+                    int max_batch, int max_samples, after_ae** out);
+void after_ae_destroy(after_ae* h);
+/* total stride of the codec: pqmf_bands * prod(factors) (2048 for baseAE) */
+int after_ae_ratio(const after_ae* h);
+
+/* z[B, Z, L/ratio] = encode(x[B, 1, L]); L a multiple of the ratio.
+ * Replaces: AutoEncoder.encode (SimpleNetsStream.py:918-941; the bottleneck is the
+ * identity on z at inference, :753-760). */
+int after_ae_encode(after_ae* h, const float* x, float* z, int B, int L, void* stream);
+/* x[B, 1, T*ratio] = decode(z[B, Z, T]).  Replaces: AutoEncoder.decode (:943-954). */
+int after_ae_decode(after_ae* h, const float* z, float* x, int B, int T, void* stream);
+/* multiband[B, M, L/M] = pqmf(x) / x = pqmf.inverse(multiband) (pqmf.py:286-301) */
+int after_ae_pqmf_forward(after_ae* h, const float* x, float* mb, int B, int L, void* stream);
+int after_ae_pqmf_inverse(after_ae* h, const float* mb, float* x, int B, int Tm, void* stream);
+
 /* ------------------------------------------------------------ diagnostics
  * Not part of the reference's surface: the fp32 MFMA GEMM behind every Linear,
  * exposed for unit parity tests and roofline measurements.
