@@ -27,6 +27,19 @@ class AECfg(ctypes.Structure):
                                                    ("factors", c_int * 8), ("dilations", c_int * 8)]
 
 
+class Encoder1dCfg(ctypes.Structure):
+    _fields_ = [("in_size", c_int), ("n_blocks", c_int), ("channels", c_int * 8),
+                ("ratios", c_int * 8), ("kernel_size", c_int), ("causal", c_int),
+                ("use_tanh", c_int)]
+
+
+class EcapaCfg(ctypes.Structure):
+    _fields_ = [("in_size", c_int), ("out_dim", c_int), ("n_blocks", c_int),
+                ("channels", c_int * 8), ("kernel_sizes", c_int * 8), ("dilations", c_int * 8),
+                ("res2net_scale", c_int), ("se_channels", c_int), ("attention_channels", c_int),
+                ("use_tanh", c_int)]
+
+
 class AFTERHipError(RuntimeError):
     pass
 
@@ -61,6 +74,14 @@ SIGNATURES = {
     "after_ae_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "after_ae_pqmf_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "after_ae_pqmf_inverse": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "after_encoder1d_create": (c_int, [POINTER(Encoder1dCfg), POINTER(c_void_p), c_int, c_int, c_int,
+                                       POINTER(c_void_p)]),
+    "after_encoder1d_destroy": (None, [c_void_p]),
+    "after_encoder1d_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "after_ecapa_create": (c_int, [POINTER(EcapaCfg), POINTER(c_void_p), c_int, c_int, c_int,
+                                   POINTER(c_void_p)]),
+    "after_ecapa_destroy": (None, [c_void_p]),
+    "after_ecapa_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "after_gemm_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
 }

@@ -257,32 +257,9 @@ int load_resblock(after_ae* h, WeightCursor& c, ResBlockW& rb, int cin, int cout
     return AFTER_OK;
 }
 
-// cached_conv.get_padding left pad (stride ignored): p = (k-1) d + 1
-int left_pad(int k, int dil, bool causal) {
-    if (k == 1) return 0;
-    const int p = (k - 1) * dil + 1;
-    return causal ? p / 2 + (p - 1) / 2 : (p - 1) / 2;
-}
-
+int left_pad(int k, int dil, bool causal) { return conv_left_pad(k, dil, causal); }
 void base_args(ConvArgs& a, int B, int cin, int cout, int Tin, int Tout) {
-    memset(&a, 0, sizeof(a));
-    a.B = B;
-    a.Cin = cin;
-    a.Cin_pad = pad16(cin);
-    a.Cout = cout;
-    a.Tin = Tin;
-    a.Tout = Tout;
-    a.x_bstride = cin * Tin;
-    a.y_bstride = cout * Tout;
-    a.res_bstride = cout * Tout;
-    a.taps = 1;
-    a.phases = 1;
-    a.istride = 1;
-    a.ostride = 1;
-    a.Nn = Tout;
-    a.act = ACT_NONE;
-    a.pad = PAD_ZERO;
-    a.out_act = ACT_NONE;
+    conv_args_init(a, B, cin, cout, Tin, Tout);
 }
 
 int run_gn(after_ae* h, hipStream_t s, const float* x, const ConvBlockW& cb, int B, int T) {

@@ -86,6 +86,8 @@ enum GemmEpilogue {
     EPI_NONE = 0,       // C = acc (+ bias)
     EPI_GELU = 1,       // C = gelu_erf(acc + bias)
     EPI_RESIDUAL = 2,   // C = acc + bias + R[m, n]
+    EPI_RELU = 3,       // C = max(acc + bias, 0)
+    EPI_SIGMOID = 4,    // C = sigmoid(acc + bias)
 };
 struct GemmArgs {
     const float* A;

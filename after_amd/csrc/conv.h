@@ -25,13 +25,19 @@ struct ConvArgs {
     const float* shift;  // [B, Cin]
     const float* act_a;  // snake: alpha[Cin]
     const float* act_b;  // snake: 1 / (beta[Cin] + 1e-9)
-    float* post_mul;     // nullptr, or gate tensor: y = acc * sigmoid(gate) handled by caller (unused)
+    const float* x2;     // optional second input, added to x before the affine/activation
+                         // (Res2Net: x_i + y_{i-1}, ecapa_encoder.py Res2NetBlock.forward)
+    const float* post_scale;  // [Cout] or nullptr: y = out_act(acc + bias) * post_scale + post_shift
+    const float* post_shift;  //   (TDNNBlock: BatchNorm AFTER the ReLU, ecapa_encoder.py:139)
     int act, pad;
     int B, Cin, Cin_pad, Cout, Tin, Tout;
     int x_bstride;       // floats between batch items of x (allows channel-sliced views)
     int x_coff;          // first input channel within x's channel dim
     int y_bstride, y_coff;  // same for y (write into a channel slice of a wider tensor)
     int res_bstride, res_coff;
+    int x2_bstride, x2_coff;
+    int bias_bstride;    // 0: bias[Cout] shared; else bias[b * bias_bstride + co]
+    int scale_bstride;   // 0: scale/shift[Cin] shared over the batch; else [b * stride + ci]
     int taps, phases, istride, ostride;
     int Nn;              // output positions per phase
     int toff[kMaxPhases][kMaxTaps];
@@ -72,5 +78,32 @@ int pack_convT_weight(const float* v, const float* g, float* out, int Cin, int C
 int snake_inv_beta(const float* beta, float* out, int C, hipStream_t s);
 
 inline int pad16(int c) { return (c + 15) & ~15; }
+
+// cached_conv.get_padding left pad (stride ignored): p = (k-1) d + 1
+inline int conv_left_pad(int k, int dil, bool causal) {
+    if (k == 1) return 0;
+    const int p = (k - 1) * dil + 1;
+    return causal ? p / 2 + (p - 1) / 2 : (p - 1) / 2;
+}
+
+inline void conv_args_init(ConvArgs& a, int B, int cin, int cout, int Tin, int Tout) {
+    memset(&a, 0, sizeof(a));
+    a.B = B;
+    a.Cin = cin;
+    a.Cin_pad = pad16(cin);
+    a.Cout = cout;
+    a.Tin = Tin;
+    a.Tout = Tout;
+    a.x_bstride = cin * Tin;
+    a.y_bstride = cout * Tout;
+    a.res_bstride = cout * Tout;
+    a.x2_bstride = cin * Tin;
+    a.scale_bstride = cin;
+    a.taps = 1;
+    a.phases = 1;
+    a.istride = 1;
+    a.ostride = 1;
+    a.Nn = Tout;
+}
 
 }  // namespace after

@@ -79,6 +79,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, ConvGeom gm)
 
     const float* __restrict__ xb = a.x + (size_t)b * a.x_bstride + (size_t)a.x_coff * Tin;
     const float* __restrict__ wp = a.w + (size_t)ph * a.Cout * taps * Cinp;
+    const float* __restrict__ x2b =
+        a.x2 ? a.x2 + (size_t)b * a.x2_bstride + (size_t)a.x2_coff * Tin : nullptr;
 
     // ---- per-thread staging maps (constant over the channel-block loop)
     const int xtotal = KC * XW;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, ConvGeom gm)
     // prologue: fetch stage 0
 #pragma unroll
     for (int i = 0; i < XMAX; ++i)
-        xr[i] = (xok[i] && xci[i] < Cin) ? xb[xg[i]] : 0.f;
+        xr[i] = (xok[i] && xci[i] < Cin) ? (xb[xg[i]] + (x2b ? x2b[xg[i]] : 0.f)) : 0.f;
 #pragma unroll
     for (int i = 0; i < WMAX; ++i)
         wr[i] = wok[i] ? *reinterpret_cast<const float4*>(wp + wg[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -148,7 +150,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, ConvGeom gm)
                 const int c = cb + xci[i];
                 if (xok[i] && c < Cin) {
                     v = xr[i];
-                    if (a.scale) v = v * a.scale[(size_t)b * Cin + c] + a.shift[(size_t)b * Cin + c];
+                    if (a.scale)
+                        v = v * a.scale[(size_t)b * a.scale_bstride + c] +
+                            a.shift[(size_t)b * a.scale_bstride + c];
                     if (a.act != ACT_NONE)
                         v = apply_act(v, a.act, a.act_a ? a.act_a[c] : 0.f, a.act_b ? a.act_b[c] : 0.f);
                 }
@@ -164,7 +168,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, ConvGeom gm)
             const int cn = cb + KC;
 #pragma unroll
             for (int i = 0; i < XMAX; ++i)
-                xr[i] = (xok[i] && cn + xci[i] < Cin) ? xb[(size_t)cn * Tin + xg[i]] : 0.f;
+                xr[i] = (xok[i] && cn + xci[i] < Cin)
+                            ? (xb[(size_t)cn * Tin + xg[i]] + (x2b ? x2b[(size_t)cn * Tin + xg[i]] : 0.f))
+                            : 0.f;
 #pragma unroll
             for (int i = 0; i < WMAX; ++i)
                 wr[i] = (wok[i] && cn + wc[i] < Cinp)
@@ -216,9 +222,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, ConvGeom gm)
             for (int r = 0; r < 4; ++r) {
                 const int co = m0 + wm0 + i * 16 + crow0 + r;
                 if (co >= a.Cout) continue;
-                float v = acc[i][j][r] + (a.bias ? a.bias[co] : 0.f);
+                float v = acc[i][j][r] + (a.bias ? a.bias[(size_t)b * a.bias_bstride + co] : 0.f);
                 if (rb) v += rb[(size_t)co * a.Tout + to];
                 if (a.out_act != ACT_NONE) v = apply_act(v, a.out_act, 0.f, 0.f);
+                if (a.post_scale) v = v * a.post_scale[co] + a.post_shift[co];
                 yb[(size_t)co * a.Tout + to] = v;
             }
         }

@@ -1,0 +1,659 @@
+// The once-per-clip conditioning encoders on gfx950:
+//   encoder_time = Encoder1D   (reference after/diffusion/networks/encoder.py:116-322)
+//   encoder      = ECAPATDNN   (reference after/diffusion/networks/ecapa_encoder.py:458-666)
+// Both are stacks of small 1-D convs: they reuse the implicit-GEMM conv kernel of
+// conv.hip (BatchNorm(eval) folded to per-channel affines: prologue affine + SiLU for
+// V2ConvBlock1D, epilogue ReLU + affine for TDNNBlock, reflect padding for ECAPA) and
+// the fp32 MFMA GEMM for the squeeze-excitation / pooling matvecs.
+#include <new>
+#include <vector>
+
+#include "conv.h"
+
+namespace after {
+namespace {
+
+// per-(b, c) statistics over time (ecapa_encoder.py AttentiveStatisticsPooling):
+//   w = softmax_t(logits[b,c,:]) (or 1/T when logits == nullptr)
+//   mean = sum_t w z ;  std = sqrt(clamp(sum_t w (z - mean)^2, 1e-12))
+// out[b, c] = mean, out[b, C + c] = std, each optionally followed by a per-channel
+// affine (asp_bn).  One wave per (b, c) row.
+__global__ __launch_bounds__(256) void time_stats_kernel(const float* __restrict__ z,
+                                                         const float* __restrict__ logits,
+                                                         float* __restrict__ out,
+                                                         const float* __restrict__ post_scale,
+                                                         const float* __restrict__ post_shift,
+                                                         int B, int C, int T, int z_bstride,
+                                                         int only_mean) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * C) return;
+    const int b = row / C, c = row - b * C;
+    const float* zr = z + (size_t)b * z_bstride + (size_t)c * T;
+    const float* lr = logits ? logits + ((size_t)b * C + c) * T : nullptr;
+    float mx = -INFINITY;
+    if (lr)
+        for (int t = lane; t < T; t += 64) mx = fmaxf(mx, lr[t]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float se = 0.f, sz = 0.f;
+    for (int t = lane; t < T; t += 64) {
+        const float w = lr ? expf(lr[t] - mx) : 1.0f;
+        se += w;
+        sz += w * zr[t];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        se += __shfl_xor(se, o, 64);
+        sz += __shfl_xor(sz, o, 64);
+    }
+    const float inv = 1.0f / se;
+    const float mean = sz * inv;
+    float sv = 0.f;
+    for (int t = lane; t < T; t += 64) {
+        const float w = (lr ? expf(lr[t] - mx) : 1.0f) * inv;
+        const float d = zr[t] - mean;
+        sv += w * d * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sv += __shfl_xor(sv, o, 64);
+    if (lane == 0) {
+        float m = mean, sd = sqrtf(fmaxf(sv, 1e-12f));
+        const int w2 = only_mean ? C : 2 * C;
+        if (post_scale) {
+            m = m * post_scale[c] + post_shift[c];
+            if (!only_mean) sd = sd * post_scale[C + c] + post_shift[C + c];
+        }
+        out[(size_t)b * w2 + c] = m;
+        if (!only_mean) out[(size_t)b * w2 + C + c] = sd;
+    }
+}
+
+// SEBlock tail + residual: y[b,c,t] = s[b,c] * x[b,c,t] + res[b,c,t]   (ecapa SERes2NetBlock)
+__global__ __launch_bounds__(256) void se_scale_add_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ s,
+                                                           const float* __restrict__ res,
+                                                           float* __restrict__ y, int C, int T,
+                                                           int res_bstride, int y_bstride,
+                                                           size_t total) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int t = idx % T;
+    const int c = (idx / T) % C;
+    const int b = idx / ((size_t)T * C);
+    y[(size_t)b * y_bstride + (size_t)c * T + t] =
+        s[(size_t)b * C + c] * x[idx] + res[(size_t)b * res_bstride + (size_t)c * T + t];
+}
+
+__global__ __launch_bounds__(256) void copy_slice_kernel(const float* __restrict__ x,
+                                                         float* __restrict__ y, int Cs, int T,
+                                                         int x_bstride, int y_bstride, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const size_t per = (size_t)Cs * T;
+    const int b = idx / per;
+    const size_t r = idx - (size_t)b * per;
+    y[(size_t)b * y_bstride + r] = x[(size_t)b * x_bstride + r];
+}
+
+__global__ void tanh_kernel(float* x, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] = tanhf(x[i]);
+}
+
+struct WCursor {
+    const float* const* w;
+    int n, i = 0;
+    bool ok = true;
+    const float* next() {
+        if (i >= n || !w[i]) {
+            ok = false;
+            ++i;
+            return nullptr;
+        }
+        return w[i++];
+    }
+};
+
+struct Affine {
+    float *scale = nullptr, *shift = nullptr;
+};
+struct ConvW {
+    float *w = nullptr, *bias = nullptr;
+    int cin = 0, cout = 0, k = 1;
+};
+
+int take(Arena& a, float** p, size_t n) {
+    *p = a.take<float>(n);
+    AFTER_REQUIRE(*p, AFTER_E_NOMEM, "encoder: weight arena exhausted");
+    return AFTER_OK;
+}
+
+int load_bn(Arena& a, WCursor& c, Affine& af, int C) {
+    const float *w = c.next(), *b = c.next(), *rm = c.next(), *rv = c.next();
+    AFTER_REQUIRE(c.ok, AFTER_E_INVALID, "encoder: missing BatchNorm tensors");
+    AFTER_TRY(take(a, &af.scale, C));
+    AFTER_TRY(take(a, &af.shift, C));
+    return launch_bn_affine(w, b, rm, rv, af.scale, af.shift, C, 1, 1e-5f, 0);
+}
+
+int load_conv(Arena& a, WCursor& c, ConvW& cw, int cin, int cout, int k, bool weight_norm) {
+    cw.cin = cin;
+    cw.cout = cout;
+    cw.k = k;
+    const float* g = weight_norm ? c.next() : nullptr;
+    const float* v = c.next();
+    const float* b = c.next();
+    AFTER_REQUIRE(c.ok, AFTER_E_INVALID, "encoder: missing conv tensors");
+    AFTER_TRY(take(a, &cw.w, (size_t)cout * k * pad16(cin)));
+    AFTER_TRY(pack_conv_weight(v, g, cw.w, cout, cin, k, pad16(cin), 0));
+    AFTER_TRY(take(a, &cw.bias, cout));
+    AFTER_HIP_CHECK(hipMemcpy(cw.bias, b, cout * sizeof(float), hipMemcpyDeviceToDevice));
+    return AFTER_OK;
+}
+
+size_t conv_floats(int cin, int cout, int k) { return (size_t)cout * k * pad16(cin) + cout + 256; }
+
+}  // namespace
+}  // namespace after
+
+using namespace after;
+
+// =================================================================== Encoder1D
+struct V2Block {
+    Affine bn0, bn1;
+    ConvW c0, c1;
+};
+struct after_encoder1d {
+    after_encoder1d_cfg cfg;
+    int max_batch, max_T;
+    Arena wa, ws;
+    std::vector<V2Block> blocks;  // n + 1 (last = final V2ConvBlock1D)
+    std::vector<ConvW> pools;     // n
+    float* buf[3] = {nullptr, nullptr, nullptr};
+};
+
+namespace {
+
+int load_v2(Arena& a, WCursor& c, V2Block& b, int ch, int k) {
+    AFTER_TRY(load_bn(a, c, b.bn0, ch));
+    AFTER_TRY(load_conv(a, c, b.c0, ch, ch, k, true));
+    AFTER_TRY(load_bn(a, c, b.bn1, ch));
+    return load_conv(a, c, b.c1, ch, ch, k, true);
+}
+
+// V2ConvBlock1D (encoder.py:25-71): y = conv1(silu(bn1(conv0(silu(bn0(x)))))) + x
+int run_v2(const V2Block& b, hipStream_t s, const float* x, float* tmp, float* y, int B, int T, int k,
+           bool causal) {
+    const int pl = conv_left_pad(k, 1, causal);
+    ConvArgs a;
+    conv_args_init(a, B, b.c0.cin, b.c0.cout, T, T);
+    a.x = x;
+    a.y = tmp;
+    a.w = b.c0.w;
+    a.bias = b.c0.bias;
+    a.scale = b.bn0.scale;
+    a.shift = b.bn0.shift;
+    a.scale_bstride = 0;
+    a.act = ACT_SILU;
+    a.taps = k;
+    for (int t = 0; t < k; ++t) a.toff[0][t] = t - pl;
+    AFTER_TRY(launch_conv(a, s));
+    a.x = tmp;
+    a.y = y;
+    a.w = b.c1.w;
+    a.bias = b.c1.bias;
+    a.scale = b.bn1.scale;
+    a.shift = b.bn1.shift;
+    a.res = x;
+    return launch_conv(a, s);
+}
+
+}  // namespace
+
+extern "C" int after_encoder1d_create(const after_encoder1d_cfg* cfg, const float* const* weights,
+                                      int n_weights, int max_batch, int max_T,
+                                      after_encoder1d** out) {
+    AFTER_REQUIRE(cfg && weights && out, AFTER_E_INVALID, "null argument");
+    *out = nullptr;
+    AFTER_REQUIRE(cfg->n_blocks >= 1 && cfg->n_blocks <= 8 && cfg->kernel_size >= 1 &&
+                      cfg->kernel_size <= kMaxTaps && max_batch > 0 && max_T > 0,
+                  AFTER_E_INVALID, "encoder1d: bad configuration");
+    after_encoder1d* h = new (std::nothrow) after_encoder1d();
+    AFTER_REQUIRE(h, AFTER_E_NOMEM, "out of host memory");
+    h->cfg = *cfg;
+    h->max_batch = max_batch;
+    h->max_T = max_T;
+    const int n = cfg->n_blocks, k = cfg->kernel_size;
+    auto fail = [&](int rc) {
+        after_encoder1d_destroy(h);
+        return rc;
+    };
+    size_t wf = 0;
+    int cmax = cfg->in_size;
+    {
+        int c = cfg->in_size;
+        for (int i = 0; i < n; ++i) {
+            wf += 2 * conv_floats(c, c, k) + 4 * (size_t)c + 1024 +
+                  conv_floats(c, cfg->channels[i], 2 * cfg->ratios[i]);
+            c = cfg->channels[i];
+            cmax = c > cmax ? c : cmax;
+        }
+        wf += 2 * conv_floats(c, c, k) + 4 * (size_t)c + 1024;
+    }
+    int rc = h->wa.init(wf * sizeof(float) + (1 << 16));
+    if (rc) return fail(rc);
+    WCursor cur{weights, n_weights};
+    h->blocks.resize(n + 1);
+    h->pools.resize(n);
+    int c = cfg->in_size;
+    for (int i = 0; i < n; ++i) {
+        if ((rc = load_v2(h->wa, cur, h->blocks[i], c, k))) return fail(rc);
+        const int r = cfg->ratios[i];
+        if (r < 1 || 2 * r > kMaxTaps) {
+            set_error("encoder1d: ratio %d unsupported", r);
+            return fail(AFTER_E_INVALID);
+        }
+        if ((rc = load_conv(h->wa, cur, h->pools[i], c, cfg->channels[i], r == 1 ? 1 : 2 * r, true)))
+            return fail(rc);
+        c = cfg->channels[i];
+    }
+    if ((rc = load_v2(h->wa, cur, h->blocks[n], c, k))) return fail(rc);
+    if (!cur.ok || cur.i != n_weights) {
+        set_error("encoder1d: expected %d weight tensors, got %d", cur.i, n_weights);
+        return fail(AFTER_E_INVALID);
+    }
+    const size_t elems = (size_t)max_batch * cmax * max_T;
+    if ((rc = h->ws.init(3 * elems * sizeof(float) + 4096))) return fail(rc);
+    for (int i = 0; i < 3; ++i) h->buf[i] = h->ws.take<float>(elems);
+    if (!h->buf[2]) return fail(AFTER_E_NOMEM);
+    if (hipDeviceSynchronize() != hipSuccess) return fail(AFTER_E_HIP);
+    *out = h;
+    return AFTER_OK;
+}
+
+extern "C" void after_encoder1d_destroy(after_encoder1d* h) {
+    if (!h) return;
+    h->wa.release();
+    h->ws.release();
+    delete h;
+}
+
+extern "C" int after_encoder1d_forward(after_encoder1d* h, const float* z, float* out, int B, int T,
+                                       void* stream) {
+    AFTER_REQUIRE(h && z && out, AFTER_E_INVALID, "null argument");
+    AFTER_REQUIRE(B > 0 && T > 0, AFTER_E_INVALID, "empty batch");
+    AFTER_REQUIRE(B <= h->max_batch && T <= h->max_T, AFTER_E_CAPACITY,
+                  "B=%d T=%d exceed max_batch=%d max_T=%d", B, T, h->max_batch, h->max_T);
+    hipStream_t s = (hipStream_t)stream;
+    const after_encoder1d_cfg& c = h->cfg;
+    const int n = c.n_blocks, k = c.kernel_size;
+    const bool causal = c.causal != 0;
+    const float* cur = z;
+    float* const P[2] = {h->buf[0], h->buf[2]};
+    float* const Y = h->buf[1];
+    for (int i = 0; i < n; ++i) {
+        // V2EncoderBlock1D (encoder.py:74-113): conv block, then the (strided) 1x1 "pool"
+        float* tmp = (cur == P[0]) ? P[1] : P[0];
+        AFTER_TRY(run_v2(h->blocks[i], s, cur, tmp, Y, B, T, k, causal));
+        const ConvW& p = h->pools[i];
+        const int r = c.ratios[i];
+        AFTER_REQUIRE(T % r == 0, AFTER_E_INVALID, "encoder1d: T=%d not divisible by ratio %d", T, r);
+        ConvArgs a;
+        conv_args_init(a, B, p.cin, p.cout, T, T / r);
+        a.x = Y;
+        a.y = tmp;
+        a.w = p.w;
+        a.bias = p.bias;
+        a.taps = p.k;
+        a.istride = r;
+        const int pl = conv_left_pad(p.k, 1, causal);
+        for (int t = 0; t < p.k; ++t) a.toff[0][t] = t - pl;
+        AFTER_TRY(launch_conv(a, s));
+        T /= r;
+        cur = tmp;
+    }
+    {
+        float* tmp = (cur == P[0]) ? P[1] : P[0];
+        AFTER_TRY(run_v2(h->blocks[n], s, cur, tmp, out, B, T, k, causal));
+    }
+    if (c.use_tanh) {
+        const int tot = B * c.channels[n - 1] * T;
+        hipLaunchKernelGGL(tanh_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, s, out, tot);
+        AFTER_HIP_CHECK(hipGetLastError());
+    }
+    return AFTER_OK;
+}
+
+// ====================================================================== ECAPA
+struct TdnnW {
+    ConvW conv;
+    Affine bn;
+    int dil = 1;
+};
+struct SeResW {
+    TdnnW tdnn1, tdnn2;
+    std::vector<TdnnW> res;
+    ConvW se1, se2, shortcut;
+    bool has_shortcut = false;
+};
+struct after_ecapa {
+    after_ecapa_cfg cfg;
+    int max_batch, max_T;
+    Arena wa, ws;
+    TdnnW first, mfa, asp_tdnn;
+    std::vector<SeResW> blocks;
+    ConvW asp_conv, fc;
+    float* asp_w23 = nullptr;  // asp.tdnn weight columns for the (mean, std) context [A, 2C]
+    Affine asp_bn;
+    // workspaces
+    float *feat = nullptr, *cat = nullptr, *t0 = nullptr, *t1 = nullptr, *t2 = nullptr, *t3 = nullptr;
+    float *vecA = nullptr, *vecB = nullptr, *vecC = nullptr;
+};
+
+namespace {
+
+int load_tdnn(Arena& a, WCursor& c, TdnnW& t, int cin, int cout, int k, int dil) {
+    t.dil = dil;
+    AFTER_TRY(load_conv(a, c, t.conv, cin, cout, k, false));
+    return load_bn(a, c, t.bn, cout);
+}
+
+// TDNNBlock (ecapa_encoder.py:85-139): BN(ReLU(conv_reflect(x)))
+int run_tdnn(const TdnnW& t, hipStream_t s, const float* x, int x_bs, int x_co, const float* x2,
+             int x2_co, float* y, int y_bs, int y_co, int B, int T, const float* bias_override = nullptr,
+             int bias_bs = 0) {
+    ConvArgs a;
+    conv_args_init(a, B, t.conv.cin, t.conv.cout, T, T);
+    a.x = x;
+    a.x_bstride = x_bs;
+    a.x_coff = x_co;
+    a.x2 = x2;
+    a.x2_bstride = x_bs;
+    a.x2_coff = x2_co;
+    a.y = y;
+    a.y_bstride = y_bs;
+    a.y_coff = y_co;
+    a.w = t.conv.w;
+    a.bias = bias_override ? bias_override : t.conv.bias;
+    a.bias_bstride = bias_bs;
+    a.pad = PAD_REFLECT;
+    a.taps = t.conv.k;
+    const int pl = ((t.conv.k - 1) * t.dil) / 2;  // (L_in - L_out) // 2, ecapa_encoder.py:74-78
+    for (int i = 0; i < t.conv.k; ++i) a.toff[0][i] = i * t.dil - pl;
+    a.out_act = ACT_RELU;
+    a.post_scale = t.bn.scale;
+    a.post_shift = t.bn.shift;
+    return launch_conv(a, s);
+}
+
+int gemm_rows(hipStream_t s, const float* A, int lda, const float* W, int ldw, const float* bias,
+              float* C, int ldc, int M, int N, int K, int epi) {
+    GemmArgs g{A, lda, W, ldw, bias, nullptr, 0, C, ldc, M, N, K, epi};
+    return launch_gemm(g, s);
+}
+
+}  // namespace
+
+extern "C" int after_ecapa_create(const after_ecapa_cfg* cfg, const float* const* weights,
+                                  int n_weights, int max_batch, int max_T, after_ecapa** out) {
+    AFTER_REQUIRE(cfg && weights && out, AFTER_E_INVALID, "null argument");
+    *out = nullptr;
+    const int n = cfg->n_blocks;
+    AFTER_REQUIRE(n >= 3 && n <= 8 && max_batch > 0 && max_T > 1, AFTER_E_INVALID,
+                  "ecapa: bad configuration");
+    const int scale = cfg->res2net_scale;
+    AFTER_REQUIRE(scale >= 2 && scale <= 16, AFTER_E_INVALID, "ecapa: res2net_scale %d", scale);
+    for (int i = 0; i < n; ++i)
+        AFTER_REQUIRE(cfg->kernel_sizes[i] >= 1 && cfg->kernel_sizes[i] <= kMaxTaps &&
+                          cfg->kernel_sizes[i] % 2 == 1 && cfg->channels[i] % 4 == 0,
+                      AFTER_E_INVALID, "ecapa: unsupported kernel size / channels");
+    int ccat = 0;
+    for (int i = 1; i < n - 1; ++i) {
+        AFTER_REQUIRE(cfg->channels[i] % scale == 0, AFTER_E_INVALID, "ecapa: channels %% scale");
+        ccat += cfg->channels[i];
+    }
+    AFTER_REQUIRE(ccat == cfg->channels[n - 1], AFTER_E_INVALID,
+                  "ecapa: channels[-1]=%d must equal the concatenated width %d",
+                  cfg->channels[n - 1], ccat);
+    after_ecapa* h = new (std::nothrow) after_ecapa();
+    AFTER_REQUIRE(h, AFTER_E_NOMEM, "out of host memory");
+    h->cfg = *cfg;
+    h->max_batch = max_batch;
+    h->max_T = max_T;
+    auto fail = [&](int rc) {
+        after_ecapa_destroy(h);
+        return rc;
+    };
+    const int CL = cfg->channels[n - 1], A = cfg->attention_channels, SE = cfg->se_channels;
+    size_t wf = conv_floats(cfg->in_size, cfg->channels[0], cfg->kernel_sizes[0]) + 4096;
+    int cmaxc = cfg->channels[0];
+    for (int i = 1; i < n - 1; ++i) {
+        const int ci = cfg->channels[i - 1], co = cfg->channels[i];
+        wf += conv_floats(ci, co, 1) + conv_floats(co, co, 1) +
+              (scale - 1) * conv_floats(co / scale, co / scale, cfg->kernel_sizes[i]) +
+              conv_floats(co, SE, 1) + conv_floats(SE, co, 1) + conv_floats(ci, co, 1) +
+              (size_t)(scale + 4) * 2 * co + 8192;
+        cmaxc = co > cmaxc ? co : cmaxc;
+    }
+    wf += conv_floats(CL, CL, cfg->kernel_sizes[n - 1]) + conv_floats(3 * CL, A, 1) +
+          (size_t)A * 2 * CL + conv_floats(A, CL, 1) + conv_floats(2 * CL, cfg->out_dim, 1) +
+          12 * (size_t)CL + 8192;
+    int rc = h->wa.init(wf * sizeof(float) + (1 << 16));
+    if (rc) return fail(rc);
+    WCursor cur{weights, n_weights};
+    if ((rc = load_tdnn(h->wa, cur, h->first, cfg->in_size, cfg->channels[0], cfg->kernel_sizes[0],
+                        cfg->dilations[0])))
+        return fail(rc);
+    h->blocks.resize(n - 2);
+    for (int i = 1; i < n - 1; ++i) {
+        SeResW& b = h->blocks[i - 1];
+        const int ci = cfg->channels[i - 1], co = cfg->channels[i], cs = co / scale;
+        if ((rc = load_tdnn(h->wa, cur, b.tdnn1, ci, co, 1, 1))) return fail(rc);
+        b.res.resize(scale - 1);
+        for (int j = 0; j < scale - 1; ++j)
+            if ((rc = load_tdnn(h->wa, cur, b.res[j], cs, cs, cfg->kernel_sizes[i], cfg->dilations[i])))
+                return fail(rc);
+        if ((rc = load_tdnn(h->wa, cur, b.tdnn2, co, co, 1, 1))) return fail(rc);
+        if ((rc = load_conv(h->wa, cur, b.se1, co, SE, 1, false))) return fail(rc);
+        if ((rc = load_conv(h->wa, cur, b.se2, SE, co, 1, false))) return fail(rc);
+        b.has_shortcut = ci != co;
+        if (b.has_shortcut && (rc = load_conv(h->wa, cur, b.shortcut, ci, co, 1, false))) return fail(rc);
+    }
+    if ((rc = load_tdnn(h->wa, cur, h->mfa, CL, CL, cfg->kernel_sizes[n - 1], cfg->dilations[n - 1])))
+        return fail(rc);
+    {
+        // asp.tdnn: Conv1d(3 CL -> A, k = 1).  The (mean, std) context is constant over
+        // time (ecapa_encoder.py AttentiveStatisticsPooling.forward), so its 2 CL weight
+        // columns become a per-clip bias: split [A, 3 CL] into [A, CL] (conv) + [A, 2 CL].
+        const float* w = cur.next();
+        const float* b = cur.next();
+        if (!cur.ok) {
+            set_error("ecapa: missing asp.tdnn tensors");
+            return fail(AFTER_E_INVALID);
+        }
+        float* wz = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&wz), (size_t)A * CL * sizeof(float)) != hipSuccess)
+            return fail(AFTER_E_NOMEM);
+        h->asp_w23 = h->wa.take<float>((size_t)A * 2 * CL);
+        h->asp_tdnn.conv.bias = h->wa.take<float>(A);
+        h->asp_tdnn.conv.w = h->wa.take<float>((size_t)A * pad16(CL));
+        if (!h->asp_w23 || !h->asp_tdnn.conv.bias || !h->asp_tdnn.conv.w) {
+            (void)hipFree(wz);
+            return fail(AFTER_E_NOMEM);
+        }
+        bool okc = hipMemcpy2D(wz, (size_t)CL * 4, w, (size_t)3 * CL * 4, (size_t)CL * 4, A,
+                               hipMemcpyDeviceToDevice) == hipSuccess &&
+                   hipMemcpy2D(h->asp_w23, (size_t)2 * CL * 4, w + CL, (size_t)3 * CL * 4,
+                               (size_t)2 * CL * 4, A, hipMemcpyDeviceToDevice) == hipSuccess &&
+                   hipMemcpy(h->asp_tdnn.conv.bias, b, A * sizeof(float), hipMemcpyDeviceToDevice) ==
+                       hipSuccess;
+        rc = okc ? pack_conv_weight(wz, nullptr, h->asp_tdnn.conv.w, A, CL, 1, pad16(CL), 0)
+                 : AFTER_E_HIP;
+        (void)hipFree(wz);
+        if (rc) return fail(rc);
+        h->asp_tdnn.conv.cin = CL;
+        h->asp_tdnn.conv.cout = A;
+        h->asp_tdnn.conv.k = 1;
+        if ((rc = load_bn(h->wa, cur, h->asp_tdnn.bn, A))) return fail(rc);
+    }
+    if ((rc = load_conv(h->wa, cur, h->asp_conv, A, CL, 1, false))) return fail(rc);
+    if ((rc = load_bn(h->wa, cur, h->asp_bn, 2 * CL))) return fail(rc);
+    {
+        // fc as a plain [out_dim, 2 CL] matrix for the GEMM (K contiguous already)
+        const float* w = cur.next();
+        const float* b = cur.next();
+        if (!cur.ok) {
+            set_error("ecapa: missing fc tensors");
+            return fail(AFTER_E_INVALID);
+        }
+        h->fc.w = h->wa.take<float>((size_t)cfg->out_dim * 2 * CL);
+        h->fc.bias = h->wa.take<float>(cfg->out_dim);
+        if (!h->fc.w || !h->fc.bias) return fail(AFTER_E_NOMEM);
+        if (hipMemcpy(h->fc.w, w, (size_t)cfg->out_dim * 2 * CL * 4, hipMemcpyDeviceToDevice) != hipSuccess ||
+            hipMemcpy(h->fc.bias, b, cfg->out_dim * 4, hipMemcpyDeviceToDevice) != hipSuccess)
+            return fail(AFTER_E_HIP);
+    }
+    if (!cur.ok || cur.i != n_weights) {
+        set_error("ecapa: expected %d weight tensors, got %d", cur.i, n_weights);
+        return fail(AFTER_E_INVALID);
+    }
+    // SE convs are used as GEMM weights [N, K] (k = 1): keep unpacked copies
+    const size_t el = (size_t)max_batch * cmaxc * max_T;
+    const size_t elcat = (size_t)max_batch * CL * max_T;
+    if ((rc = h->ws.init((3 * el + 3 * elcat) * sizeof(float) +
+                         3 * (size_t)max_batch * (3 * CL + 1024) * sizeof(float) + 8192)))
+        return fail(rc);
+    h->feat = h->ws.take<float>(el);
+    h->t0 = h->ws.take<float>(el);
+    h->t1 = h->ws.take<float>(el);
+    h->cat = h->ws.take<float>(elcat);
+    h->t2 = h->ws.take<float>(elcat);
+    h->t3 = h->ws.take<float>(elcat);
+    h->vecA = h->ws.take<float>((size_t)max_batch * (3 * CL + 1024));
+    h->vecB = h->ws.take<float>((size_t)max_batch * (3 * CL + 1024));
+    h->vecC = h->ws.take<float>((size_t)max_batch * (3 * CL + 1024));
+    if (!h->t3 || !h->vecC) return fail(AFTER_E_NOMEM);
+    if (hipDeviceSynchronize() != hipSuccess) return fail(AFTER_E_HIP);
+    *out = h;
+    return AFTER_OK;
+}
+
+extern "C" void after_ecapa_destroy(after_ecapa* h) {
+    if (!h) return;
+    h->wa.release();
+    h->ws.release();
+    delete h;
+}
+
+extern "C" int after_ecapa_forward(after_ecapa* h, const float* z, float* out, int B, int T,
+                                   void* stream) {
+    AFTER_REQUIRE(h && z && out, AFTER_E_INVALID, "null argument");
+    AFTER_REQUIRE(B > 0 && T > 1, AFTER_E_INVALID, "ecapa: need T >= 2 (reflect padding)");
+    AFTER_REQUIRE(B <= h->max_batch && T <= h->max_T, AFTER_E_CAPACITY,
+                  "B=%d T=%d exceed max_batch=%d max_T=%d", B, T, h->max_batch, h->max_T);
+    hipStream_t s = (hipStream_t)stream;
+    const after_ecapa_cfg& c = h->cfg;
+    const int n = c.n_blocks, scale = c.res2net_scale, CL = c.channels[n - 1];
+    const int A = c.attention_channels, SE = c.se_channels;
+    // blocks.0
+    AFTER_TRY(run_tdnn(h->first, s, z, c.in_size * T, 0, nullptr, 0, h->feat, c.channels[0] * T, 0, B, T));
+    const float* xin = h->feat;
+    int xin_bs = c.channels[0] * T, xin_co = 0;
+    int cat_off = 0;
+    for (int i = 1; i < n - 1; ++i) {
+        const SeResW& b = h->blocks[i - 1];
+        const int ci = c.channels[i - 1], co = c.channels[i], cs = co / scale;
+        (void)ci;
+        // tdnn1 -> t0 [B, co, T]
+        AFTER_TRY(run_tdnn(b.tdnn1, s, xin, xin_bs, xin_co, nullptr, 0, h->t0, co * T, 0, B, T));
+        // Res2Net chain -> t1 [B, co, T]: y0 = x0 ; y1 = f0(x1) ; yi = f(x_i + y_{i-1})
+        {
+            const size_t tot = (size_t)B * cs * T;
+            hipLaunchKernelGGL(copy_slice_kernel, dim3((unsigned)cdivll(tot, 256)), dim3(256), 0, s,
+                               h->t0, h->t1, cs, T, co * T, co * T, tot);
+            AFTER_HIP_CHECK(hipGetLastError());
+        }
+        for (int j = 0; j < scale - 1; ++j)
+            AFTER_TRY(run_tdnn(b.res[j], s, h->t0, co * T, (j + 1) * cs, j == 0 ? nullptr : h->t1,
+                               j * cs, h->t1, co * T, (j + 1) * cs, B, T));
+        // note: x2 shares x's batch stride (both [B, co, T]); its slice is y_{j}
+        // tdnn2 -> t0
+        AFTER_TRY(run_tdnn(b.tdnn2, s, h->t1, co * T, 0, nullptr, 0, h->t0, co * T, 0, B, T));
+        // SE: s = sigmoid(W2 relu(W1 mean_t(x) + b1) + b2)
+        hipLaunchKernelGGL(time_stats_kernel, dim3(cdiv(B * co, 4)), dim3(256), 0, s, h->t0,
+                           (const float*)nullptr, h->vecA, (const float*)nullptr,
+                           (const float*)nullptr, B, co, T, co * T, 1);
+        AFTER_HIP_CHECK(hipGetLastError());
+        AFTER_TRY(gemm_rows(s, h->vecA, co, b.se1.w, pad16(co), b.se1.bias, h->vecB, SE, B, SE, co,
+                            EPI_RELU));
+        AFTER_TRY(gemm_rows(s, h->vecB, SE, b.se2.w, pad16(SE), b.se2.bias, h->vecC, co, B, co, SE,
+                            EPI_SIGMOID));
+        // residual (identity or 1x1 shortcut) then out = s * x + residual -> cat slice
+        const float* res = xin;
+        int res_bs = xin_bs;
+        if (b.has_shortcut) {
+            ConvArgs a;
+            conv_args_init(a, B, b.shortcut.cin, co, T, T);
+            a.x = xin;
+            a.x_bstride = xin_bs;
+            a.x_coff = xin_co;
+            a.y = h->t1;
+            a.w = b.shortcut.w;
+            a.bias = b.shortcut.bias;
+            a.toff[0][0] = 0;
+            AFTER_TRY(launch_conv(a, s));
+            res = h->t1;
+            res_bs = co * T;
+        } else {
+            res = xin + (size_t)xin_co * T;
+        }
+        {
+            const size_t tot = (size_t)B * co * T;
+            hipLaunchKernelGGL(se_scale_add_kernel, dim3((unsigned)cdivll(tot, 256)), dim3(256), 0, s,
+                               h->t0, h->vecC, res, h->cat + (size_t)cat_off * T, co, T, res_bs,
+                               CL * T, tot);
+            AFTER_HIP_CHECK(hipGetLastError());
+        }
+        xin = h->cat;
+        xin_bs = CL * T;
+        xin_co = cat_off;
+        cat_off += co;
+    }
+    // mfa over the concatenation -> t2 [B, CL, T]
+    AFTER_TRY(run_tdnn(h->mfa, s, h->cat, CL * T, 0, nullptr, 0, h->t2, CL * T, 0, B, T));
+    // attentive statistics pooling with global context
+    hipLaunchKernelGGL(time_stats_kernel, dim3(cdiv(B * CL, 4)), dim3(256), 0, s, h->t2,
+                       (const float*)nullptr, h->vecA, (const float*)nullptr, (const float*)nullptr,
+                       B, CL, T, CL * T, 0);
+    AFTER_HIP_CHECK(hipGetLastError());
+    // per-clip bias = W[:, CL:3CL] [mean | std] + b
+    AFTER_TRY(gemm_rows(s, h->vecA, 2 * CL, h->asp_w23, 2 * CL, h->asp_tdnn.conv.bias, h->vecB, A, B, A,
+                        2 * CL, EPI_NONE));
+    float* attn_h = h->cat;  // [B, A, T] scratch (cat is dead now)
+    AFTER_TRY(run_tdnn(h->asp_tdnn, s, h->t2, CL * T, 0, nullptr, 0, attn_h, A * T, 0, B, T, h->vecB, A));
+    float* logits = h->t3;
+    {
+        // conv(tanh(.)) 1x1: A -> CL
+        ConvArgs a;
+        conv_args_init(a, B, A, CL, T, T);
+        a.x = attn_h;
+        a.y = logits;
+        a.w = h->asp_conv.w;
+        a.bias = h->asp_conv.bias;
+        a.act = ACT_TANH;
+        a.toff[0][0] = 0;
+        AFTER_TRY(launch_conv(a, s));
+    }
+    hipLaunchKernelGGL(time_stats_kernel, dim3(cdiv(B * CL, 4)), dim3(256), 0, s, h->t2, logits, h->vecA,
+                       h->asp_bn.scale, h->asp_bn.shift, B, CL, T, CL * T, 0);
+    AFTER_HIP_CHECK(hipGetLastError());
+    AFTER_TRY(gemm_rows(s, h->vecA, 2 * CL, h->fc.w, 2 * CL, h->fc.bias, out, c.out_dim, B, c.out_dim,
+                        2 * CL, EPI_NONE));
+    if (c.use_tanh) {
+        const int tot = B * c.out_dim;
+        hipLaunchKernelGGL(tanh_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, s, out, tot);
+        AFTER_HIP_CHECK(hipGetLastError());
+    }
+    return AFTER_OK;
+}

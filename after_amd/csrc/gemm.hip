@@ -161,6 +161,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g, int tiles_m, 
                 float v = acc[i][j][r] + bv;
                 if (g.epilogue == EPI_GELU) v = gelu_erf(v);
                 if (g.epilogue == EPI_RESIDUAL) v += g.R[(size_t)gm * g.ldr + gn];
+                if (g.epilogue == EPI_RELU) v = fmaxf(v, 0.f);
+                if (g.epilogue == EPI_SIGMOID) v = 1.0f / (1.0f + expf(-v));
                 g.C[(size_t)gm * g.ldc + gn] = v;
             }
         }

@@ -184,10 +184,59 @@ int after_ae_decode(after_ae* h, const float* z, float* x, int B, int T, void* s
 int after_ae_pqmf_forward(after_ae* h, const float* x, float* mb, int B, int L, void* stream);
 int after_ae_pqmf_inverse(after_ae* h, const float* mb, float* x, int B, int Tm, void* stream);
 
+/* ------------------------------------------------------- conditioning encoders
+ * encoder_time: Encoder1D (after/diffusion/networks/encoder.py:116-322), causal
+ * padding through the scoped gin binding (after/diffusion/configs/base.gin:55). */
+typedef struct after_encoder1d_cfg {
+    int in_size;
+    int n_blocks;     /* len(channels)                                              */
+    int channels[8];
+    int ratios[8];    /* [1] + ratios of the gin config: stride of block i's pool   */
+    int kernel_size;  /* 5                                                          */
+    int causal;
+    int use_tanh;
+} after_encoder1d_cfg;
+/* weights: for block i: BN(.net.i.net.0.net.branches.0.0: weight, bias, running_mean,
+ * running_var) WN(...branches.0.2) BN(...branches.0.3) WN(...branches.0.6)
+ * WN(.net.i.net.1); then the final V2ConvBlock1D .net.n: BN WN BN WN. */
+typedef struct after_encoder1d after_encoder1d;
+int after_encoder1d_create(const after_encoder1d_cfg* cfg, const float* const* weights,
+                           int n_weights, int max_batch, int max_T, after_encoder1d** out);
+void after_encoder1d_destroy(after_encoder1d* h);
+/* out[B, channels[-1], T / prod(ratios)] = encoder_time(z[B, in_size, T])
+ * Replaces: Encoder1D.forward / forward_stream offline (encoder.py:273-322). */
+int after_encoder1d_forward(after_encoder1d* h, const float* z, float* out, int B, int T,
+                            void* stream);
+
+/* encoder: ECAPATDNN (after/diffusion/networks/ecapa_encoder.py:458-666) with
+ * pooling + global context (every shipped config). */
+typedef struct after_ecapa_cfg {
+    int in_size, out_dim;
+    int n_blocks;     /* len(channels) = 1 TDNN + (n-2) SE-Res2Net + MFA            */
+    int channels[8];
+    int kernel_sizes[8];
+    int dilations[8];
+    int res2net_scale, se_channels, attention_channels;
+    int use_tanh;
+} after_ecapa_cfg;
+/* weights: TD(p) = p.conv.conv.weight, p.conv.conv.bias, p.norm.weight, p.norm.bias,
+ * p.norm.running_mean, p.norm.running_var;  CV(p) = p.conv.weight, p.conv.bias
+ *   TD(blocks.0); for i in 1..n-2: TD(blocks.i.tdnn1) TD(blocks.i.res2net_block.blocks.j)
+ *   for j < scale-1, TD(blocks.i.tdnn2) CV(blocks.i.se_block.conv1) CV(blocks.i.se_block.conv2)
+ *   [CV(blocks.i.shortcut) iff channels differ]; TD(mfa); TD(asp.tdnn); CV(asp.conv);
+ *   asp_bn.weight, .bias, .running_mean, .running_var; CV(fc). */
+typedef struct after_ecapa after_ecapa;
+int after_ecapa_create(const after_ecapa_cfg* cfg, const float* const* weights, int n_weights,
+                       int max_batch, int max_T, after_ecapa** out);
+void after_ecapa_destroy(after_ecapa* h);
+/* out[B, out_dim] = encoder(z[B, in_size, T]).  Replaces: ECAPATDNN.forward
+ * (ecapa_encoder.py:567-624; regularisation "ac" leaves Z unchanged). */
+int after_ecapa_forward(after_ecapa* h, const float* z, float* out, int B, int T, void* stream);
+
 /* ------------------------------------------------------------ diagnostics
  * Not part of the reference's surface: the fp32 MFMA GEMM behind every Linear,
  * exposed for unit parity tests and roofline measurements.
- *   C[M,N] = epi(A[M,K] * W[N,K]^T + bias);  epilogue 0 none, 1 GELU(erf), 2 + R[M,N]
+ *   C[M,N] = epi(A[M,K] * W[N,K]^T + bias);  epilogue 0 none, 1 GELU(erf), 2 + R[M,N], 3 ReLU, 4 sigmoid
  * force_mt/force_nt = 0 lets the library pick the tile. */
 int after_gemm_f32(const float* A, int lda, const float* W, int ldw, const float* bias,
                    const float* R, int ldr, float* C, int ldc, int M, int N, int K, int epilogue,
