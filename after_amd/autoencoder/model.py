@@ -274,9 +274,11 @@ class AutoEncoder(nn.Module):
         for i, dd in enumerate(c["dilations"]):
             cfg.dilations[i] = dd
         out = ctypes.c_void_p()
-        torch.cuda.synchronize()
-        _lib.check(L.after_ae_create(ctypes.byref(cfg), arr, len(ws), cap[0], cap[1], ctypes.byref(out)),
-                   "after_ae_create")
+        dev = next(w for w in ws if w is not None).device
+        with torch.cuda.device(dev):
+            torch.cuda.synchronize(dev)
+            rc = L.after_ae_create(ctypes.byref(cfg), arr, len(ws), cap[0], cap[1], ctypes.byref(out))
+        _lib.check(rc, "after_ae_create")
         self._handle = out
         self._cap = cap
         return out

@@ -154,9 +154,11 @@ class ECAPATDNN(nn.Module):
         cfg.attention_channels = self.attention_channels
         cfg.use_tanh = int(self.use_tanh)
         out = ctypes.c_void_p()
-        torch.cuda.synchronize()
-        _lib.check(L.after_ecapa_create(ctypes.byref(cfg), arr, len(ws), cap[0], cap[1],
-                                        ctypes.byref(out)), "after_ecapa_create")
+        dev = next(w for w in ws if w is not None).device
+        with torch.cuda.device(dev):
+            torch.cuda.synchronize(dev)
+            rc = L.after_ecapa_create(ctypes.byref(cfg), arr, len(ws), cap[0], cap[1], ctypes.byref(out))
+        _lib.check(rc, "after_ecapa_create")
         self._handle = out
         self._cap = cap
         return out

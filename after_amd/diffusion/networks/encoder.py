@@ -128,9 +128,11 @@ class Encoder1D(nn.Module):
         cfg.causal = int(self.padding_mode == "causal")
         cfg.use_tanh = int(self.use_tanh)
         out = ctypes.c_void_p()
-        torch.cuda.synchronize()
-        _lib.check(L.after_encoder1d_create(ctypes.byref(cfg), arr, len(ws), cap[0], cap[1],
-                                            ctypes.byref(out)), "after_encoder1d_create")
+        dev = next(w for w in ws if w is not None).device
+        with torch.cuda.device(dev):
+            torch.cuda.synchronize(dev)
+            rc = L.after_encoder1d_create(ctypes.byref(cfg), arr, len(ws), cap[0], cap[1], ctypes.byref(out))
+        _lib.check(rc, "after_encoder1d_create")
         self._handle = out
         self._cap = cap
         return out

@@ -192,10 +192,11 @@ class DenoiserV2(nn.Module):
             local_attention_size=-1 if self.local_attention_size is None else int(
                 self.local_attention_size), attention_chunk_size=self.attention_chunk_size)
         out = ctypes.c_void_p()
-        torch.cuda.synchronize()
-        _lib.check(
-            L.after_denoiser_create(ctypes.byref(cfg), arr, len(ws), cap[0], cap[1], cap[2],
-                                    ctypes.byref(out)), "after_denoiser_create")
+        dev = next(w for w in ws if w is not None).device
+        with torch.cuda.device(dev):
+            torch.cuda.synchronize(dev)
+            rc = L.after_denoiser_create(ctypes.byref(cfg), arr, len(ws), cap[0], cap[1], cap[2], ctypes.byref(out))
+        _lib.check(rc, "after_denoiser_create")
         self._handle = out
         self._cap = cap
         if self._profile:

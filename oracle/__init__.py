@@ -23,7 +23,8 @@ reference's own `state_dict()` keys, so weights move
 1:1 between the reference, the oracle and the HIP path.
 """
 from .denoiser import (denoiser_forward, band_bounds, rope_tables,  # noqa: F401
-                       positional_embedding, DenoiserCache)
+                       positional_embedding, DenoiserCache, banded_attention,
+                       banded_attention_loop)
 from .sampler import model_forward, sample  # noqa: F401
 from .autoencoder import (ae_encode, ae_decode, pqmf_forward, pqmf_inverse,  # noqa: F401
                           fold_weight_norm)

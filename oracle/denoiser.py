@@ -92,12 +92,9 @@ class DenoiserCache:
             self.v[l][:b, cache_index] = vc
 
 
-def banded_attention(q, k, v, chunk: int, window: Optional[int], causal: bool = True,
-                     rot_dim: int = 32):
-    """transformerv2.py:190-236 (MHAttention.forward) on [b, H, n, Dh] tensors,
-    restated WITHOUT the dense mask: each query gathers only its allowed keys
-    (band_bounds), RoPE positions follow rotary_embedding.py:215-236 (queries
-    offset by k_len - q_len)."""
+def banded_attention_loop(q, k, v, chunk: int, window: Optional[int], causal: bool = True,
+                          rot_dim: int = 32):
+    """Per-query restatement (kept as the cross-check of banded_attention)."""
     b, h, qn, dh = q.shape
     kn = k.shape[2]
     off = kn - qn
@@ -115,6 +112,36 @@ def banded_attention(q, k, v, chunk: int, window: Optional[int], causal: bool = 
         p = torch.softmax(s, dim=-1)
         out[:, :, j] = torch.einsum("bhk,bhkd->bhd", p, v[:, :, lo:hi])
     return out
+
+
+def banded_attention(q, k, v, chunk: int, window: Optional[int], causal: bool = True,
+                     rot_dim: int = 32):
+    """transformerv2.py:190-236 (MHAttention.forward) on [b, H, n, Dh] tensors,
+    restated WITHOUT the dense mask: each query gathers only its allowed keys
+    (band_bounds), RoPE positions follow rotary_embedding.py:215-236 (queries
+    offset by k_len - q_len).  Vectorised over queries: key slot m of query j is
+    key lo(j) + m, slots past hi(j) are masked."""
+    b, h, qn, dh = q.shape
+    kn = k.shape[2]
+    off = kn - qn
+    if not causal or window is None or window < 0:
+        return banded_attention_loop(q, k, v, chunk, window, causal, rot_dim)
+    cos, sin = rope_tables(kn, rot_dim, dtype=q.dtype)
+    qr = _apply_rope(q, cos[off:], sin[off:])
+    kr = _apply_rope(k, cos, sin)
+    bounds = [band_bounds(j + off, chunk, window, kn) for j in range(qn)]
+    lo = torch.tensor([x[0] for x in bounds])
+    hi = torch.tensor([x[1] for x in bounds])
+    nk = int((hi - lo).max())
+    idx = lo[:, None] + torch.arange(nk)[None, :]           # [qn, nk]
+    valid = idx < hi[:, None]
+    idx = idx.clamp(max=kn - 1)
+    kg = kr[:, :, idx]                                       # [b, h, qn, nk, dh]
+    vg = v[:, :, idx]
+    s = torch.einsum("bhqd,bhqkd->bhqk", qr, kg) * (1.0 / math.sqrt(dh))
+    s = s.masked_fill(~valid, float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    return torch.einsum("bhqk,bhqkd->bhqd", p, vg)
 
 
 def _ln(x, w=None, b=None, eps=1e-5):

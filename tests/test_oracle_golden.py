@@ -43,6 +43,17 @@ def test_rope_and_time_embedding():
     assert max_abs(pe, fx.t("pos_emb")) < 1e-5
 
 
+def test_vectorised_band_equals_per_query_loop():
+    g = torch.Generator().manual_seed(0)
+    for (qn, kn, cs, W) in [(37, 37, 4, 8), (8, 16, 4, 8), (40, 40, 4, 16), (5, 5, 8, 3)]:
+        q = torch.randn(2, 3, qn, 64, generator=g)
+        k = torch.randn(2, 3, kn, 64, generator=g)
+        v = torch.randn(2, 3, kn, 64, generator=g)
+        a = oracle.banded_attention(q, k, v, cs, W)
+        b = oracle.banded_attention_loop(q, k, v, cs, W)
+        assert max_abs(a, b) < 2e-6
+
+
 @pytest.mark.parametrize("case,tol_fwd,tol_sample", [
     ("denoiser_micro", 2e-5, 5e-5),
     ("denoiser_micro_ragged", 2e-5, 5e-5),
