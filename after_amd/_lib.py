@@ -82,6 +82,7 @@ SIGNATURES = {
                                    POINTER(c_void_p)]),
     "after_ecapa_destroy": (None, [c_void_p]),
     "after_ecapa_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "after_gemm_set_debug": (None, [c_void_p]),
     "after_gemm_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
 }

@@ -101,6 +101,7 @@ struct GemmArgs {
     int ldc;
     int M, N, K;
     int epilogue;
+    unsigned long long* dbg = nullptr;  // diagnostics: 4 s_memtime stamps per workgroup
 };
 int launch_gemm(const GemmArgs& g, hipStream_t stream);
 int launch_gemm_cfg(const GemmArgs& g, int force_mt, int force_nt, hipStream_t stream);

@@ -19,6 +19,7 @@
 //   * the attention mask: never materialised -- each 4-frame chunk gathers its
 //     <= W+chunk-1 keys.
 #include <cmath>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -256,6 +257,7 @@ struct AttnArgs {
     int nc;                 // cached frames in front of the chunk
     int T, E, H, cs, W;
     int nkmax;              // LDS rows provisioned for keys: W - 1 + cs
+    int dbg;                // AFTER_ATTN_DBG bitmask (diagnostics): 1 no rope, 2 no reduce, 4 no LN tail, 8 no KV loads
 };
 
 __device__ __forceinline__ float group16_sum(float v) {
@@ -288,10 +290,12 @@ __device__ __forceinline__ float4 rope4(float4 v, const float* __restrict__ ct,
 // probabilities never leave registers.  K and V rows are read straight from the qkv
 // buffer (one 256-byte segment per head and key, L2-resident).  The concatenated
 // heads + residual meet in LDS for the row-wise AdaLN / LayerNorm tail.
-template <int NKMAX>
+template <bool CACHE>
 __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
+    constexpr int NKMAX = 12;  // key block
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [cs][E + 4]
-    const int E = a.E, H = a.H, T = a.T, cs = a.cs, W = a.W, nc = a.nc;
+    const int E = a.E, H = a.H, T = a.T, cs = a.cs, W = a.W;
+    const int nc = CACHE ? a.nc : 0;
     const int ld = E + 4;
     const int r = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, hw = tid >> 6;  // head of this wave
@@ -304,6 +308,22 @@ __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
     const int nk = (nc + e) - lo_c;
     const size_t rowbase = (size_t)r * T;
 
+    // Operands of the LayerNorm tail are requested before anything else so that their
+    // latency hides behind the attention proper.
+    const int nper = E >> 6;
+    const float* abp = a.cond_ab ? a.cond_ab + (size_t)r * a.cond_ld : nullptr;
+    float al[kMaxPer], be[kMaxPer], ww[kMaxPer], bb[kMaxPer];
+    constexpr bool kPreloadLN = true;
+#pragma unroll
+    for (int i = 0; i < kMaxPer; ++i)
+        if (kPreloadLN && i < nper) {
+            const int c = lane + 64 * i;
+            al[i] = abp ? abp[c] : 0.f;
+            be[i] = abp ? abp[E + c] : 0.f;
+            ww[i] = a.w3[c];
+            bb[i] = a.b3[c];
+        }
+
     for (int qb = 0; qb < nq; qb += 4) {
         const int qi = qb + grp;
         const bool qok = qi < nq;
@@ -312,41 +332,58 @@ __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
         const int lo_row = min(a0, max(0, ja - W + 1));
         float4 q4 = *reinterpret_cast<const float4*>(a.qkv + (rowbase + i0 + qic) * 3 * E + hw * 64 + d4);
         const float4 x4 = *reinterpret_cast<const float4*>(a.xres + (rowbase + i0 + qic) * E + hw * 64 + d4);
-        q4 = rope4(q4, a.rope_cos, a.rope_sin, ja, d4);
-        float sc[NKMAX];
-        float mx = -INFINITY;
+        if (!(a.dbg & 1)) q4 = rope4(q4, a.rope_cos, a.rope_sin, ja, d4);
+        // Keys are walked in blocks of NKMAX with an online softmax (one block for the
+        // shipped window 8 / chunk 4).  Inside a block all K and V rows are requested
+        // unconditionally (slot index clamped, masked later): no control flow between
+        // the loads, so they are all in flight at once instead of one exposed L2 round
+        // trip per key.  Block 0 always holds an allowed key for every query (chunk <=
+        // 8 < NKMAX), so the running max is finite from the first block on.
+        float mrun = -INFINITY, sum = 0.f;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+        for (int kb = 0; kb < nk; kb += NKMAX) {
+            float4 k4[NKMAX], v4[NKMAX];
 #pragma unroll
-        for (int j = 0; j < NKMAX; ++j) {
-            sc[j] = -INFINITY;
-            if (j < nk) {
-                const int pos = lo_c + j;
-                const float* src = pos >= nc
-                                       ? a.qkv + (rowbase + (pos - nc)) * 3 * E + E + hw * 64 + d4
-                                       : a.kcache + ((size_t)r * nc + pos) * E + hw * 64 + d4;
-                float4 k4 = *reinterpret_cast<const float4*>(src);
-                k4 = rope4(k4, a.rope_cos, a.rope_sin, pos, d4);
-                float dot = q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
-                dot = group16_sum(dot);
-                sc[j] = pos >= lo_row ? dot * 0.125f : -INFINITY;
+            for (int j = 0; j < NKMAX; ++j) {
+                const int pos = (a.dbg & 8) ? lo_c : lo_c + min(kb + j, nk - 1);
+                const float* src = a.qkv + (rowbase + (pos - nc)) * 3 * E + E + hw * 64 + d4;
+                if (CACHE && pos < nc) src = a.kcache + ((size_t)r * nc + pos) * E + hw * 64 + d4;
+                k4[j] = *reinterpret_cast<const float4*>(src);
+            }
+#pragma unroll
+            for (int j = 0; j < NKMAX; ++j) {
+                const int pos = lo_c + min(kb + j, nk - 1);
+                const float* src = a.qkv + (rowbase + (pos - nc)) * 3 * E + 2 * E + hw * 64 + d4;
+                if (CACHE && pos < nc) src = a.vcache + ((size_t)r * nc + pos) * E + hw * 64 + d4;
+                v4[j] = *reinterpret_cast<const float4*>(src);
+            }
+            float sc[NKMAX];
+            float mx = mrun;
+#pragma unroll
+            for (int j = 0; j < NKMAX; ++j) {
+                const int pos = lo_c + min(kb + j, nk - 1);
+                const float4 kr = (a.dbg & 1) ? k4[j] : rope4(k4[j], a.rope_cos, a.rope_sin, pos, d4);
+                float dot = q4.x * kr.x + q4.y * kr.y + q4.z * kr.z + q4.w * kr.w;
+                if (!(a.dbg & 2)) dot = group16_sum(dot);
+                sc[j] = (kb + j < nk && pos >= lo_row) ? dot * 0.125f : -INFINITY;
                 mx = fmaxf(mx, sc[j]);
             }
-        }
-        float sum = 0.f;
-        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float resc = expf(mrun - mx);  // 0 on the first block (mrun = -inf)
+            sum *= resc;
+            o.x *= resc;
+            o.y *= resc;
+            o.z *= resc;
+            o.w *= resc;
+            mrun = mx;
 #pragma unroll
-        for (int j = 0; j < NKMAX; ++j) {
-            if (j < nk) {
-                const int pos = lo_c + j;
-                const float* src = pos >= nc
-                                       ? a.qkv + (rowbase + (pos - nc)) * 3 * E + 2 * E + hw * 64 + d4
-                                       : a.vcache + ((size_t)r * nc + pos) * E + hw * 64 + d4;
-                const float4 v4 = *reinterpret_cast<const float4*>(src);
-                const float p = expf(sc[j] - mx);
+            for (int j = 0; j < NKMAX; ++j) {
+                const float p = expf(sc[j] - mx);  // exp(-inf) = 0 for masked / padded slots
                 sum += p;
-                o.x += p * v4.x;
-                o.y += p * v4.y;
-                o.z += p * v4.z;
-                o.w += p * v4.w;
+                o.x += p * v4[j].x;
+                o.y += p * v4[j].y;
+                o.z += p * v4[j].z;
+                o.w += p * v4[j].w;
             }
         }
         const float inv = 1.0f / sum;
@@ -362,22 +399,24 @@ __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
     __syncthreads();
 
     // ---- AdaLN(cond) + norm3, one wave per row
-    const int nper = E >> 6;
-    for (int qi = hw; qi < nq; qi += H) {
-        float v[kMaxPer], al[kMaxPer], be[kMaxPer], ww[kMaxPer], bb[kMaxPer];
-        const float* ab = a.cond_ab ? a.cond_ab + (size_t)r * a.cond_ld : nullptr;
+    if (!kPreloadLN) {
 #pragma unroll
         for (int i = 0; i < kMaxPer; ++i)
             if (i < nper) {
                 const int c = lane + 64 * i;
-                v[i] = smem[qi * ld + c];
-                al[i] = ab ? ab[c] : 0.f;
-                be[i] = ab ? ab[E + c] : 0.f;
+                al[i] = abp ? abp[c] : 0.f;
+                be[i] = abp ? abp[E + c] : 0.f;
                 ww[i] = a.w3[c];
                 bb[i] = a.b3[c];
             }
+    }
+    for (int qi = hw; qi < nq; qi += H) {
+        float v[kMaxPer];
+#pragma unroll
+        for (int i = 0; i < kMaxPer; ++i)
+            if (i < nper) v[i] = smem[qi * ld + lane + 64 * i];
         float mean, rstd;
-        if (ab) {
+        if (abp) {
             row_stats(v, nper, E, mean, rstd);
 #pragma unroll
             for (int i = 0; i < kMaxPer; ++i)
@@ -540,12 +579,10 @@ size_t attn_lds_bytes(int E, int cs) { return (size_t)cs * (E + 4) * sizeof(floa
 
 int launch_attn(const AttnArgs& a, int rows, size_t lds, hipStream_t s) {
     const dim3 grid(cdiv(a.T, a.cs), rows), block(64 * a.H);
-    if (a.nkmax <= 12)
-        hipLaunchKernelGGL(attn_block_kernel<12>, grid, block, lds, s, a);
-    else if (a.nkmax <= 20)
-        hipLaunchKernelGGL(attn_block_kernel<20>, grid, block, lds, s, a);
+    if (a.nc > 0)
+        hipLaunchKernelGGL(attn_block_kernel<true>, grid, block, lds, s, a);
     else
-        hipLaunchKernelGGL(attn_block_kernel<32>, grid, block, lds, s, a);
+        hipLaunchKernelGGL(attn_block_kernel<false>, grid, block, lds, s, a);
     AFTER_HIP_CHECK(hipGetLastError());
     return AFTER_OK;
 }
@@ -601,6 +638,14 @@ int run_net(after_denoiser* h, hipStream_t s, const float* x, int npat, const in
         a.cs = h->cs;
         a.W = h->W;
         a.nkmax = nkmax;
+        {
+            static int dbg = -1;
+            if (dbg < 0) {
+                const char* e = getenv("AFTER_ATTN_DBG");
+                dbg = e ? atoi(e) : 0;
+            }
+            a.dbg = dbg;
+        }
         AFTER_TRY(launch_attn(a, rows, lds, s));
         AFTER_TRY(gemm(h, s, h->hbuf, E, w.mlp0_w, E, w.mlp0_b, h->mlp, ME, M, ME, E, EPI_GELU));
         AFTER_TRY(gemm(h, s, h->mlp, ME, w.mlp2_w, ME, w.mlp2_b, h->xres, E, M, E, ME,

@@ -19,6 +19,9 @@
 // issued before the current slab's MFMAs (register double buffering + two LDS
 // buffers, one barrier per slab).  Workgroup ids are remapped so that each XCD
 // (private 4 MiB L2) owns a contiguous range of N-tiles, i.e. streams 1/8 of W.
+#include <cstdlib>
+#include <type_traits>
+
 #include "common.h"
 
 namespace after {
@@ -27,8 +30,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int LDS_LD = 40;  // floats per LDS row (32 + 8 pad): conflict-free b128 fragment reads
+// LDS row = BK + 8 floats: == 40 (mod 64) for BK = 32 and == 8 (mod 64)... see lds_ld()
+template <int BK>
+constexpr int lds_ld() { return BK == 32 ? 40 : BK + 40; }  // (LD/4) == 10 (mod 16): conflict-free b128 fragments
 
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
@@ -45,16 +49,19 @@ __device__ __forceinline__ void tile_gload(float4 (&r)[NL], const float* __restr
 }
 
 // rows lrow + 32*i of one LDS tile buffer (dst already points at [lrow][lc4])
-template <int NL>
+template <int NL, int ROWS, int LD>
 __device__ __forceinline__ void tile_sstore(const float4 (&r)[NL], float* dst) {
 #pragma unroll
-    for (int i = 0; i < NL; ++i) *reinterpret_cast<float4*>(dst + 32 * i * LDS_LD) = r[i];
+    for (int i = 0; i < NL; ++i) *reinterpret_cast<float4*>(dst + ROWS * i * LD) = r[i];
 }
 
-template <int MT, int NT>
+template <int MT, int NT, int BK>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g, int tiles_m, int tiles_n) {
-    constexpr int BM = 32 * MT, BN = 32 * NT;            // workgroup tile
-    constexpr int A_LOADS = BM / 32, W_LOADS = BN / 32;  // float4 per thread per slab
+    constexpr int BM = 32 * MT, BN = 32 * NT;  // workgroup tile
+    constexpr int LDS_LD = lds_ld<BK>();
+    constexpr int TPR = BK / 4;         // threads per tile row (one float4 each)
+    constexpr int RPP = 256 / TPR;      // tile rows per pass of the 256 threads
+    constexpr int A_LOADS = BM / RPP, W_LOADS = BN / RPP;  // float4 per thread per slab
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                    // [2][BM][LDS_LD]
     float* Ws = smem + 2 * BM * LDS_LD;  // [2][BN][LDS_LD]
@@ -71,7 +78,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g, int tiles_m, 
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm0 = (wid >> 1) * (16 * MT), wn0 = (wid & 1) * (16 * NT);
-    const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
+    const int lrow = tid / TPR, lc4 = (tid % TPR) * 4;
 
     const float* __restrict__ gA = g.A;
     const float* __restrict__ gW = g.W;
@@ -81,13 +88,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g, int tiles_m, 
     bool Aok[A_LOADS], Wok[W_LOADS];
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
-        const int gm = m0 + lrow + 32 * i;
+        const int gm = m0 + lrow + RPP * i;
         Aok[i] = gm < M;
         Aoff[i] = (size_t)(Aok[i] ? gm : 0) * lda + lc4;
     }
 #pragma unroll
     for (int i = 0; i < W_LOADS; ++i) {
-        const int gn = n0 + lrow + 32 * i;
+        const int gn = n0 + lrow + RPP * i;
         Wok[i] = gn < N;
         Woff[i] = (size_t)(Wok[i] ? gn : 0) * ldw + lc4;
     }
@@ -102,8 +109,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g, int tiles_m, 
     const int nk = (K + BK - 1) / BK;
     tile_gload<A_LOADS>(ra, gA, Aoff, Aok, 0, lc4 < K);
     tile_gload<W_LOADS>(rw, gW, Woff, Wok, 0, lc4 < K);
-    tile_sstore<A_LOADS>(ra, As + lrow * LDS_LD + lc4);
-    tile_sstore<W_LOADS>(rw, Ws + lrow * LDS_LD + lc4);
+    tile_sstore<A_LOADS, RPP, LDS_LD>(ra, As + lrow * LDS_LD + lc4);
+    tile_sstore<W_LOADS, RPP, LDS_LD>(rw, Ws + lrow * LDS_LD + lc4);
     __syncthreads();
     // fragment addressing of v_mfma_f32_16x16x4_f32: lane l supplies A[i = l&15][k = l>>4]
     // and B[k = l>>4][j = l&15]; one b128 read = k-quad (l>>4) of a 16-deep k block.
@@ -139,8 +146,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g, int tiles_m, 
 #undef AFTER_MFMA_STEP
         }
         if (kt + 1 < nk) {
-            tile_sstore<A_LOADS>(ra, As + ((cur ^ 1) * BM + lrow) * LDS_LD + lc4);
-            tile_sstore<W_LOADS>(rw, Ws + ((cur ^ 1) * BN + lrow) * LDS_LD + lc4);
+            tile_sstore<A_LOADS, RPP, LDS_LD>(ra, As + ((cur ^ 1) * BM + lrow) * LDS_LD + lc4);
+            tile_sstore<W_LOADS, RPP, LDS_LD>(rw, Ws + ((cur ^ 1) * BN + lrow) * LDS_LD + lc4);
         }
         __syncthreads();
     }
@@ -169,21 +176,332 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g, int tiles_m, 
     }
 }
 
-template <int MT, int NT>
-int launch_cfg(const GemmArgs& g, hipStream_t stream) {
+// ---------------------------------------------------------------------------------
+// LDS-DMA variant (the fast path when K is a multiple of 32): the K slabs are streamed
+// straight from global memory into an NS-deep LDS ring with global_load_lds_dwordx4
+// (no VGPR round trip, no ds_write), NS-1 slabs ahead of the MFMAs, and the ring is
+// guarded by ONE raw s_barrier per slab plus a counted s_waitcnt vmcnt(N) -- the loads
+// of the following slabs stay in flight across the barrier (cdna guide section 5,
+// "Pipelining across barriers").  The DMA writes lane-linear (wave base + lane*16 B),
+// so a tile row is the plain 128-byte k-slab of that row; bank conflicts of the
+// ds_read_b128 fragment reads are removed by an XOR swizzle applied on the SOURCE
+// address: 16-byte chunk c of row r is fetched into chunk position c ^ (r & 7), and
+// the fragment read of chunk c of row r looks at position c ^ (r & 7) (conflict free
+// for every 16-lane service group; derivation in DESIGN.md).  M/N edges read a clamped
+// row (its results are never stored); there is no K tail on this path.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else static_assert(N < 0, "add the vmcnt literal");
+}
+
+template <int MT, int NT, int NS, int BK>
+__global__ __launch_bounds__(256) void gemm_f32_dma_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+    constexpr int BM = 32 * MT, BN = 32 * NT;
+    constexpr int CPR = BK / 4;                    // 16-byte chunks per tile row
+    constexpr int RPP = 64 / CPR;                  // rows per 1 KiB DMA piece (one wave instruction)
+    constexpr int A_PW = BM / RPP / 4, W_PW = BN / RPP / 4;  // DMA pieces per wave per slab
+    constexpr int LPS = A_PW + W_PW;               // DMA instructions per wave per slab
+    constexpr int STAGE = (BM + BN) * BK;          // floats per ring slot
+    constexpr int KK = BK / 16;                    // 16-deep k blocks per slab
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tn = bid / tiles_m, tm = bid - tn * tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wid >> 1) * (16 * MT), wn0 = (wid & 1) * (16 * NT);
+    const int M = g.M, N = g.N, K = g.K;
+
+    // ---- DMA source pointers (per lane) and ring offsets (wave uniform).  Source-side
+    // swizzle: ring position `pos` of row r receives global chunk pos ^ (r & (CPR-1)).
+    const int rsub = lane / CPR, pos = lane % CPR;
+    const float* asrc[A_PW];
+    const float* wsrc[W_PW];
+#pragma unroll
+    for (int i = 0; i < A_PW; ++i) {
+        const int row = (wid * A_PW + i) * RPP + rsub;
+        const int gm = min(m0 + row, M - 1);
+        asrc[i] = g.A + (size_t)gm * g.lda + (pos ^ (row & (CPR - 1))) * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < W_PW; ++i) {
+        const int row = (wid * W_PW + i) * RPP + rsub;
+        const int gn = min(n0 + row, N - 1);
+        wsrc[i] = g.W + (size_t)gn * g.ldw + (pos ^ (row & (CPR - 1))) * 4;
+    }
+    auto issue = [&](int slab, int slot) {
+        float* st = smem + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < A_PW; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(asrc[i] + slab * BK),
+                                             (lds_ptr_t)(st + (wid * A_PW + i) * RPP * BK), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < W_PW; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wsrc[i] + slab * BK),
+                                             (lds_ptr_t)(st + BM * BK + (wid * W_PW + i) * RPP * BK), 16, 0, 0);
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    unsigned long long t_start = 0, t_loop = 0, t_end = 0, r_start = 0;
+    if (g.dbg) {
+        t_start = __builtin_readcyclecounter();
+        r_start = wall_clock64();  // 100 MHz device-wide counter
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        if (s < nk) issue(s, s);
+
+    // fragment addressing: lane l -> row i = l & 15, k-quad kq = l >> 4; chunk (kq + 4 kk) of
+    // row r sits at position (kq + 4 kk) ^ (r & 7)
+    const int frow = lane & 15, kq = lane >> 4, sw = frow & (CPR - 1);
+    const int aoff = (wm0 + frow) * BK, woff = BM * BK + (wn0 + frow) * BK;
+
+    // Software pipeline: while the MFMAs of slab kt run, the fragments of slab kt+1 are
+    // already being read from LDS into the other register set (F0 / F1 alternate, the loop
+    // is unrolled by two so that both are statically named), and slabs kt+2 .. kt+NS are in
+    // flight from global memory.  One barrier per slab: it publishes slab kt+1 (every wave
+    // has waited for ITS share of that slab's DMA) and retires ring slot kt % NS (every wave
+    // has finished reading slab kt's fragments), which is then refilled with slab kt+NS.
+    // The fragment reads are inline asm: a compiler-visible ds_read after an LDS-DMA makes
+    // hipcc insert s_waitcnt vmcnt(0) in front of it (it cannot prove the DMA targets a
+    // different ring slot), which would drain the whole prefetch pipeline every slab.  Their
+    // completion is therefore waited for by hand (lgkmcnt(0) + register fence, cdna guide
+    // 5.7) right before the MFMAs that consume them.
+    f32x4 fa[KK][2][MT], fb[KK][2][NT];
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+    unsigned a_c[KK], w_c[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+        const int c = ((kq + 4 * kk) ^ sw) * 4;
+        a_c[kk] = lds0 + (aoff + c) * 4;
+        w_c[kk] = lds0 + (woff + c) * 4;
+    }
+    // (macros, not lambdas: hipcc rejects asm operands that are lambda captures)
+#define AFTER_LOAD_FRAGS(p, slab)                                                                  \
+    {                                                                                              \
+        const unsigned so__ = (unsigned)((slab) % NS) * (STAGE * 4);                               \
+        _Pragma("unroll") for (int kk = 0; kk < KK; ++kk) {                                        \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i)                                         \
+                asm volatile("ds_read_b128 %0, %1" : "=v"(fa[kk][p][i]) : "v"(a_c[kk] + so__ + i * 16 * BK * 4)); \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                         \
+                asm volatile("ds_read_b128 %0, %1" : "=v"(fb[kk][p][j]) : "v"(w_c[kk] + so__ + j * 16 * BK * 4)); \
+        }                                                                                          \
+    }
+#define AFTER_FENCE_FRAGS(p)                                                 \
+    {                                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   \
+        _Pragma("unroll") for (int kk = 0; kk < KK; ++kk) {                  \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(fa[kk][p][i])); \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(fb[kk][p][j])); \
+        }                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+    }
+#define AFTER_MFMA_STEP(A_, B_, comp)                                                           \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NT; ++j) \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[i][comp], B_[j][comp], acc[i][j], 0, 0, 0);
+#define AFTER_MMA(p)                                      \
+    _Pragma("unroll") for (int kk = 0; kk < KK; ++kk) {   \
+        AFTER_MFMA_STEP(fa[kk][p], fb[kk][p], 0)          \
+        AFTER_MFMA_STEP(fa[kk][p], fb[kk][p], 1)          \
+        AFTER_MFMA_STEP(fa[kk][p], fb[kk][p], 2)          \
+        AFTER_MFMA_STEP(fa[kk][p], fb[kk][p], 3)          \
+    }
+    // wait until slab s_ has landed: slabs s_+1 .. min(last_, nk-1) may stay in flight
+#define AFTER_WAIT_SLAB(s_, last_)                                                      \
+    {                                                                                   \
+        const int rem__ = ((last_) < nk - 1 ? (last_) : nk - 1) - (s_);                 \
+        if (rem__ >= 3 && NS >= 4) wait_vmcnt<(NS >= 4 ? 3 : 0) * LPS>();              \
+        else if (rem__ >= 2 && NS >= 3) wait_vmcnt<(NS >= 3 ? 2 : 0) * LPS>();         \
+        else if (rem__ >= 1 && NS >= 2) wait_vmcnt<(NS >= 2 ? 1 : 0) * LPS>();         \
+        else wait_vmcnt<0>();                                                           \
+    }
+    // Software pipeline: while the MFMAs of slab kt run, the fragments of slab kt+1 are
+    // already being read from LDS into the other register set (sets 0 / 1 alternate, the
+    // loop is unrolled by two so that both are statically named), and slabs kt+2 .. kt+NS
+    // are in flight from global memory.  One barrier per slab: it publishes slab kt+1
+    // (every wave has waited for ITS share of that slab's DMA) and retires ring slot
+    // kt % NS (every wave has finished reading slab kt's fragments), which is then
+    // refilled with slab kt+NS.
+#define AFTER_STEP(pc, pn, kt_)                                                             \
+    {                                                                                       \
+        const int kt__ = (kt_);                                                             \
+        unsigned long long p0__ = 0, p1__ = 0, p2__ = 0, p3__ = 0;                          \
+        if (g.dbg) p0__ = __builtin_readcyclecounter();                                     \
+        AFTER_FENCE_FRAGS(pc) /* slab kt's fragments are in registers, its LDS reads retired */ \
+        if (g.dbg) p1__ = __builtin_readcyclecounter();                                     \
+        if (kt__ + 1 < nk) {                                                                \
+            if (kt__ + NS - 1 <= nk - 1) {                                                  \
+                wait_vmcnt<(NS - 2) * LPS>(); /* steady state: kt+2 .. kt+NS-1 in flight */  \
+            } else {                                                                        \
+                AFTER_WAIT_SLAB(kt__ + 1, kt__ + NS - 1)                                    \
+            }                                                                               \
+            if (g.dbg) p2__ = __builtin_readcyclecounter();                                 \
+            __builtin_amdgcn_s_barrier();                                                   \
+            asm volatile("" ::: "memory");                                                  \
+            if (g.dbg) p3__ = __builtin_readcyclecounter();                                 \
+            if (kt__ + NS < nk) issue(kt__ + NS, kt__ % NS);                                \
+            AFTER_LOAD_FRAGS(pn, kt__ + 1)                                                  \
+        }                                                                                   \
+        if (g.dbg && kt__ + 1 < nk) {                                                       \
+            ph_fence += p1__ - p0__;                                                        \
+            ph_vm += p2__ - p1__;                                                           \
+            ph_bar += p3__ - p2__;                                                          \
+        }                                                                                   \
+        AFTER_MMA(pc)                                                                       \
+    }
+    unsigned long long ph_fence = 0, ph_vm = 0, ph_bar = 0;
+    AFTER_WAIT_SLAB(0, NS - 1)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (g.dbg) t_loop = __builtin_readcyclecounter();
+    AFTER_LOAD_FRAGS(0, 0)
+    for (int kt = 0; kt < nk; kt += 2) {
+        AFTER_STEP(0, 1, kt)
+        if (kt + 1 < nk) AFTER_STEP(1, 0, kt + 1)
+    }
+#undef AFTER_STEP
+#undef AFTER_WAIT_SLAB
+#undef AFTER_MMA
+#undef AFTER_MFMA_STEP
+#undef AFTER_FENCE_FRAGS
+#undef AFTER_LOAD_FRAGS
+    if (g.dbg) {
+        asm volatile("s_nop 0" ::"v"(acc[0][0][0]));
+        t_end = __builtin_readcyclecounter();
+    }
+
+    const int ccol = lane & 15, crow0 = 4 * (lane >> 4);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int gn = n0 + wn0 + j * 16 + ccol;
+        if (gn >= N) continue;
+        const float bv = g.bias ? g.bias[gn] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gm = m0 + wm0 + i * 16 + crow0 + r;
+                if (gm >= M) continue;
+                float v = acc[i][j][r] + bv;
+                if (g.epilogue == EPI_GELU) v = gelu_erf(v);
+                if (g.epilogue == EPI_RESIDUAL) v += g.R[(size_t)gm * g.ldr + gn];
+                if (g.epilogue == EPI_RELU) v = fmaxf(v, 0.f);
+                if (g.epilogue == EPI_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                g.C[(size_t)gm * g.ldc + gn] = v;
+            }
+        }
+    }
+    if (g.dbg && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* d = g.dbg + (size_t)blockIdx.x * 8;
+        d[0] = t_start;
+        d[1] = t_loop;
+        d[2] = t_end;
+        d[3] = __builtin_readcyclecounter();
+        d[4] = r_start;
+        d[5] = wall_clock64();
+        d[6] = __smid();
+        d[7] = (ph_fence & 0xFFFFF) | ((ph_vm & 0xFFFFF) << 20) | ((ph_bar & 0xFFFFF) << 40);
+    }
+}
+
+template <int MT, int NT, int NS, int BK>
+int launch_dma(const GemmArgs& g, hipStream_t stream) {
     constexpr int BM = 32 * MT, BN = 32 * NT;
     const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
-    const size_t lds = size_t(2) * (BM + BN) * LDS_LD * sizeof(float);
+    const size_t lds = size_t(NS) * (BM + BN) * BK * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<MT, NT>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AFTER_HIP_CHECK(hipFuncSetAttribute(
+            reinterpret_cast<const void*>(gemm_f32_dma_kernel<MT, NT, NS, BK>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f32_kernel<MT, NT>), dim3(tiles_m * tiles_n), dim3(256), lds, stream, g,
+    hipLaunchKernelGGL((gemm_f32_dma_kernel<MT, NT, NS, BK>), dim3(tiles_m * tiles_n), dim3(256), lds,
+                       stream, g, tiles_m, tiles_n);
+    AFTER_HIP_CHECK(hipGetLastError());
+    return AFTER_OK;
+}
+
+int g_lds_min = -1, g_bk = -1;  // debug knobs: AFTER_GEMM_LDS_MIN (bytes), AFTER_GEMM_BK (32|64)
+
+template <int MT, int NT, int BK>
+int launch_cfg_bk(const GemmArgs& g, hipStream_t stream) {
+    constexpr int BM = 32 * MT, BN = 32 * NT;
+    const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
+    size_t lds = size_t(2) * (BM + BN) * lds_ld<BK>() * sizeof(float);
+    if (g_lds_min < 0) {
+        const char* e = getenv("AFTER_GEMM_LDS_MIN");
+        g_lds_min = e ? atoi(e) : 0;
+    }
+    if ((size_t)g_lds_min > lds) lds = g_lds_min;
+    static size_t attr = 0;
+    if (lds > attr) {
+        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<MT, NT, BK>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = lds;
+    }
+    hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, BK>), dim3(tiles_m * tiles_n), dim3(256), lds, stream, g,
                        tiles_m, tiles_n);
     AFTER_HIP_CHECK(hipGetLastError());
     return AFTER_OK;
+}
+
+int g_dma = -1;  // AFTER_GEMM_DMA=0 disables the LDS-DMA path (debug)
+
+template <int MT, int NT>
+int launch_cfg(const GemmArgs& g, hipStream_t stream) {
+    if (g_dma < 0) {
+        const char* e = getenv("AFTER_GEMM_DMA");
+        g_dma = e ? atoi(e) : 1;
+    }
+    if (g_bk < 0) {
+        const char* e = getenv("AFTER_GEMM_BK");
+        g_bk = e ? atoi(e) : 32;
+    }
+    if (g_dma && (g.K % 32) == 0) {
+        // measured on MI355X (scripts/bench_gemm.py): a 2-deep ring is as fast as deeper
+        // ones (co-resident workgroups already cover the L2 latency) and leaves LDS for more
+        // workgroups per CU; 64-deep slabs pay off for the long-K, few-workgroup MLP-down GEMM
+        if constexpr (MT * NT <= 2) {
+            if ((g_bk == 64 || (g_bk == 32 && g.K >= 1024)) && (g.K % 64) == 0) {
+                if (g_dma == 3) return launch_dma<MT, NT, 3, 64>(g, stream);
+                return launch_dma<MT, NT, 2, 64>(g, stream);
+            }
+        }
+        if (g_dma == 3) return launch_dma<MT, NT, 3, 32>(g, stream);
+        if (g_dma == 4 && MT * NT <= 4) return launch_dma<MT, NT, 4, 32>(g, stream);
+        return launch_dma<MT, NT, 2, 32>(g, stream);
+    }
+    if (g_bk == 64 && MT * NT <= 4) return launch_cfg_bk<MT, NT, 64>(g, stream);
+    return launch_cfg_bk<MT, NT, 32>(g, stream);
 }
 
 }  // namespace
@@ -212,10 +530,11 @@ int launch_gemm_cfg(const GemmArgs& g, int mt, int nt, hipStream_t stream) {
     // (co-residency is what hides the LDS/barrier latency of this MFMA-bound loop).
     auto wgs = [&](int bm, int bn) { return (long long)cdiv(g.M, bm) * cdiv(g.N, bn); };
     const long long want = 2 * 256;
-    if (wgs(128, 128) >= want) return launch_cfg<4, 4>(g, stream);
-    if (wgs(128, 64) >= want) return launch_cfg<4, 2>(g, stream);
+    // (measured, M = 6144: 64x64 tiles reach 93-105 TFLOP/s, 128x64 87, 128x128 69-82:
+    // the larger tiles hold too few waves per SIMD to cover their own LDS latency)
     if (wgs(64, 64) >= want) return launch_cfg<2, 2>(g, stream);
-    if (wgs(32, 64) >= want) return launch_cfg<1, 2>(g, stream);
+    // below ~3 workgroups per CU the finer 32x32 tile balances the 1024 SIMDs better
+    if (wgs(32, 64) >= 3 * 256) return launch_cfg<1, 2>(g, stream);
     return launch_cfg<1, 1>(g, stream);
 }
 
@@ -224,9 +543,13 @@ int launch_gemm_cfg(const GemmArgs& g, int mt, int nt, hipStream_t stream) {
 // Diagnostic / unit-test entry point (not on the reference's surface): the GEMM used by
 // every Linear of the denoiser, callable on its own for parity and roofline tests.
 // force_mt/force_nt > 0 pin the tile configuration (workgroup tile 32*mt x 32*nt).
+static unsigned long long* g_gemm_dbg = nullptr;
+extern "C" void after_gemm_set_debug(unsigned long long* dbg) { g_gemm_dbg = dbg; }
+
 extern "C" int after_gemm_f32(const float* A, int lda, const float* W, int ldw, const float* bias,
                               const float* R, int ldr, float* C, int ldc, int M, int N, int K,
                               int epilogue, int force_mt, int force_nt, void* stream) {
     after::GemmArgs g{A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, epilogue};
+    g.dbg = g_gemm_dbg;
     return after::launch_gemm_cfg(g, force_mt, force_nt, (hipStream_t)stream);
 }

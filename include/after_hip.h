@@ -238,6 +238,10 @@ int after_ecapa_forward(after_ecapa* h, const float* z, float* out, int B, int T
  * exposed for unit parity tests and roofline measurements.
  *   C[M,N] = epi(A[M,K] * W[N,K]^T + bias);  epilogue 0 none, 1 GELU(erf), 2 + R[M,N], 3 ReLU, 4 sigmoid
  * force_mt/force_nt = 0 lets the library pick the tile. */
+/* diagnostics: when non-NULL, each workgroup of after_gemm_f32's kernel records at
+ * dbg[8*wg..]: four s_memtime stamps (start, operands landed, MFMAs done, stores done),
+ * the 100 MHz wall clock at start and end, and the hardware CU id. */
+void after_gemm_set_debug(unsigned long long* dbg);
 int after_gemm_f32(const float* A, int lda, const float* W, int ldw, const float* bias,
                    const float* R, int ldr, float* C, int ldc, int M, int N, int K, int epilogue,
                    int force_mt, int force_nt, void* stream);

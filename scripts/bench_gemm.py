@@ -1,13 +1,15 @@
-"""GEMM microbench: python scripts/bench_gemm.py M N K [mt nt] ..."""
-import sys, os, time
+"""GEMM microbench: python scripts/bench_gemm.py  (env knobs AFTER_GEMM_BK / AFTER_GEMM_LDS_MIN)"""
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from after_amd import diag
 dev = torch.device("cuda:0")
-shapes = [(768,1536,512),(768,512,1536),(6144,1536,512),(6144,512,1536),(768,64,512)]
-tiles = [(0,0),(1,1),(1,2),(2,2),(4,2),(4,4)]
+shapes = [(768,1536,512),(768,512,1536),(6144,1536,512),(6144,512,1536)]
+tiles = [(1,1),(1,2),(2,2),(4,2),(4,4)]
+want = sys.argv[1:] 
 for (M,N,K) in shapes:
     a = torch.randn(M,K,device=dev); w = torch.randn(N,K,device=dev); out = torch.empty(M,N,device=dev)
+    res = []
     for tile in tiles:
         for _ in range(3): diag.gemm(a,w,tile=tile,out=out)
         torch.cuda.synchronize()
@@ -17,4 +19,5 @@ for (M,N,K) in shapes:
         for _ in range(reps): diag.gemm(a,w,tile=tile,out=out)
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1)/reps*1e3
-        print(f"M={M} N={N} K={K} tile={tile}: {us:.1f} us  {2*M*N*K/us/1e6:.1f} TFLOP/s")
+        res.append(f"{tile}:{us:.1f}us/{2*M*N*K/us/1e6:.0f}TF")
+    print(f"BK={os.environ.get('AFTER_GEMM_BK','32')} LDSMIN={os.environ.get('AFTER_GEMM_LDS_MIN','0')} M={M} N={N} K={K}  " + "  ".join(res))
