@@ -60,6 +60,7 @@ SIGNATURES = {
                                     c_void_p]),
     "after_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                              c_float, c_float, c_float, c_int, c_void_p]),
+    "after_denoiser_set_graph": (c_int, [c_void_p, c_int]),
     "after_denoiser_enable_cache": (c_int, [c_void_p, c_int, c_int, c_int]),
     "after_denoiser_reset_cache": (c_int, [c_void_p, c_void_p]),
     "after_denoiser_roll_cache": (c_int, [c_void_p, c_int, c_int, c_void_p]),

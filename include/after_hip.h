@@ -110,6 +110,13 @@ int after_sample(after_denoiser* h, const float* x0, const float* cond, const fl
                  float* out, int B, int T, int nb_steps, float guidance_timbre,
                  float guidance_structure, float drop_value, int cfg_mode, void* stream);
 
+/* after_sample can replay a hipGraph of the whole Euler loop (captured once per
+ * (B, T, nb_steps, cfg_mode, drop_value) on a private stream; inputs are staged into
+ * handle-owned tensors, guidance scalars live in device memory).  Default: off (plain
+ * launches on the caller's stream measured faster on ROCm 7.2);
+ * enable = 1 or environment AFTER_GRAPH=1 selects the replay. */
+int after_denoiser_set_graph(after_denoiser* h, int enable);
+
 /* Streaming KV caches (transformerv2.py:143-204; enabled in the reference by the
  * gin binding at after_scripts/export.py:77-79).  cache_size frames per layer,
  * per diffusion step, per row; zero-initialised like the reference buffers. */

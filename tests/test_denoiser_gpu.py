@@ -92,3 +92,30 @@ def test_error_paths(hip_device):
         model.net(d("x")[:, :4], d("tvec"), d("cond"), d("time_cond"))
     with pytest.raises(_lib.AFTERHipError):
         model.net.roll_cache(4, 0)  # streaming caches not enabled
+
+
+def test_graph_replay_tracks_new_inputs_and_guidance(hip_device):
+    """after_sample replays a captured hipGraph: new tensors (staged inputs) and new guidance
+    scalars (device-resident parameters) must take effect without re-capture, and the graph
+    path must equal the plain-launch path bit for bit."""
+    fx = Fixture("denoiser_micro")
+    sd = fx.state_dict()
+    model, dcfg = build("micro", sd, hip_device)
+    ncfg = dcfg["net"]
+    model.net.reserve(6, 32, 4)
+    _lib.check(_lib.lib().after_denoiser_set_graph(model.net._handle, 1), "set_graph")
+    g = torch.Generator().manual_seed(5)
+    outs = []
+    for i in range(3):
+        x = torch.randn(2, 16, 32, generator=g)
+        cond = torch.randn(2, 6, generator=g)
+        tc = torch.randn(2, 12, 32, generator=g)
+        gt, gs = 1.0 + i, 2.0 - 0.5 * i
+        got = model.sample(x.to(hip_device), cond.to(hip_device), tc.to(hip_device), 4, gt, gs)
+        want = oracle.sample(sd, ncfg, x, cond, tc, 4, gt, gs)
+        assert max_abs(got.cpu(), want) < 2e-4, i
+        outs.append((x, cond, tc, gt, gs, got))
+    _lib.check(_lib.lib().after_denoiser_set_graph(model.net._handle, 0), "set_graph")
+    for x, cond, tc, gt, gs, got in outs:
+        eager = model.sample(x.to(hip_device), cond.to(hip_device), tc.to(hip_device), 4, gt, gs)
+        assert torch.equal(eager, got)
