@@ -455,33 +455,32 @@ __global__ void build_cfg_maps_kernel(int* __restrict__ maps, int ms, int B, int
     for (int i = threadIdx.x; i <= B; i += blockDim.x) maps[3 * ms + i] = i < B ? i : -1;
 }
 
-// Streaming: append this call's first `size` frames of K,V to the per-(row) ring
-// and keep the last `cache` frames (MHAttention.roll_cache, transformerv2.py:171-188).
-__global__ __launch_bounds__(256) void roll_cache_kernel(float* __restrict__ kc,
-                                                         float* __restrict__ vc,
+// Streaming: new cache = last `cache` frames of (old cache || first `size` frames of the last
+// call's K / V)   (MHAttention.roll_cache, transformerv2.py:171-188).  Out of place: old and
+// new live in the two halves of a flip-flop pair.
+__global__ __launch_bounds__(256) void roll_cache_kernel(const float* __restrict__ kold,
+                                                         const float* __restrict__ vold,
+                                                         float* __restrict__ knew,
+                                                         float* __restrict__ vnew,
                                                          const float* __restrict__ qkv, int rows,
                                                          int T, int E, int cache, int size) {
-    // new[p] = (p + size < cache) ? old[p + size] : last[p + size - cache],  p in [0,cache)
-    // done out-of-place into the second half of the buffers by the host wrapper.
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t total = (size_t)rows * cache * E;
     if (idx >= total) return;
     const int c = idx % E;
     const int p = (idx / E) % cache;
     const int r = idx / ((size_t)E * cache);
-    const float* ko = kc + (size_t)rows * cache * E;  // "old" copies live in the upper half
-    const float* vo = vc + (size_t)rows * cache * E;
     float kv, vv;
     if (p + size < cache) {
-        kv = ko[((size_t)r * cache + p + size) * E + c];
-        vv = vo[((size_t)r * cache + p + size) * E + c];
+        kv = kold[((size_t)r * cache + p + size) * E + c];
+        vv = vold[((size_t)r * cache + p + size) * E + c];
     } else {
         const int t = p + size - cache;
         kv = qkv[((size_t)r * T + t) * 3 * E + E + c];
         vv = qkv[((size_t)r * T + t) * 3 * E + 2 * E + c];
     }
-    kc[idx] = kv;
-    vc[idx] = vv;
+    knew[idx] = kv;
+    vnew[idx] = vv;
 }
 
 }  // namespace
@@ -511,7 +510,9 @@ struct after_denoiser {
     int ms;     // map stride
     // streaming caches: per layer [steps][2 halves][rows*cache*E]
     int cache = 0, cache_steps = 0, cache_rows = 0;
-    float *kcache = nullptr, *vcache = nullptr;
+    float *kcache = nullptr, *vcache = nullptr;  // [L][steps][2 (flip-flop)][rows * cache * E]
+    float* qkv_layers = nullptr;                 // [L][max_rows * max_T * 3E]: last call's K / V
+    std::vector<unsigned char> flip;             // per diffusion step: which half is current
     Arena ca;
     bool have_last = false;
     int last_rows = 0, last_T = 0;
@@ -633,9 +634,10 @@ int run_net(after_denoiser* h, hipStream_t s, const float* x, int npat, const in
                            h->xres, h->hbuf, h->tc_ab + (size_t)l * 2 * E, L * 2 * E, dev_tcmap,
                            w.n1w, w.n1b, rows, T, E);
         AFTER_HIP_CHECK(hipGetLastError());
-        AFTER_TRY(gemm(h, s, h->hbuf, E, w.qkv_w, E, nullptr, h->qkv, 3 * E, M, 3 * E, E, EPI_NONE));
+        float* qkv = h->cache > 0 ? h->qkv_layers + (size_t)l * h->max_rows * h->max_T * 3 * E : h->qkv;
+        AFTER_TRY(gemm(h, s, h->hbuf, E, w.qkv_w, E, nullptr, qkv, 3 * E, M, 3 * E, E, EPI_NONE));
         AttnArgs a;
-        a.qkv = h->qkv;
+        a.qkv = qkv;
         a.xres = h->xres;
         a.h = h->hbuf;
         a.cond_ab = cond_ab_step + (size_t)l * 2 * E;
@@ -648,7 +650,7 @@ int run_net(after_denoiser* h, hipStream_t s, const float* x, int npat, const in
         a.nc = 0;
         if (h->cache > 0) {
             const size_t per = (size_t)h->cache_rows * h->cache * E;
-            const size_t slot = ((size_t)l * h->cache_steps + cache_index) * 2 * per;
+            const size_t slot = (((size_t)l * h->cache_steps + cache_index) * 2 + h->flip[cache_index]) * per;
             a.kcache = h->kcache + slot;
             a.vcache = h->vcache + slot;
             a.nc = h->cache;
@@ -673,6 +675,19 @@ int run_net(after_denoiser* h, hipStream_t s, const float* x, int npat, const in
                        EPI_RESIDUAL, h->xres, E));
     }
     AFTER_TRY(gemm(h, s, h->xres, E, h->out_w, E, h->out_b, h->outp, C, M, C, E, EPI_NONE));
+    return AFTER_OK;
+}
+
+int check_cache(after_denoiser* h, int rows, int cache_index) {
+    if (h->cache == 0) {
+        AFTER_REQUIRE(cache_index == 0, AFTER_E_INVALID,
+                      "cache_index %d without streaming caches (after_denoiser_enable_cache)", cache_index);
+        return AFTER_OK;
+    }
+    AFTER_REQUIRE(cache_index >= 0 && cache_index < h->cache_steps, AFTER_E_CAPACITY,
+                  "cache_index %d outside [0, %d)", cache_index, h->cache_steps);
+    AFTER_REQUIRE(rows <= h->cache_rows, AFTER_E_CAPACITY, "%d rows exceed the cache's %d", rows,
+                  h->cache_rows);
     return AFTER_OK;
 }
 
@@ -914,8 +929,7 @@ extern "C" int after_denoiser_forward(after_denoiser* h, const float* x, const f
     AFTER_TRY(check_shape(h, b, T));
     AFTER_REQUIRE(x && time && cond && time_cond && out, AFTER_E_INVALID,
                   "x, time, cond, time_cond and out are required (cond_dim, tcond_dim > 0)");
-    AFTER_REQUIRE(cache_index == 0 || (h->cache > 0 && cache_index < h->cache_steps),
-                  AFTER_E_INVALID, "cache_index %d out of range", cache_index);
+    AFTER_TRY(check_cache(h, b, cache_index));
     hipStream_t s = (hipStream_t)stream;
     AFTER_TRY(compute_tc_ab(h, s, time_cond, nullptr, b, T, 0.f));
     AFTER_TRY(compute_cond_ab(h, s, 1, b, time, nullptr, 0, cond, nullptr, 0.f));
@@ -995,8 +1009,7 @@ extern "C" int after_model_forward(after_denoiser* h, const float* x, const floa
     AFTER_TRY(check_shape(h, 3 * B, T));
     AFTER_REQUIRE((size_t)(B + 1) <= (size_t)h->max_rows, AFTER_E_CAPACITY, "max_rows too small");
     AFTER_REQUIRE(x && time && cond && time_cond && out, AFTER_E_INVALID, "null tensor argument");
-    AFTER_REQUIRE(cache_index == 0 || (h->cache > 0 && cache_index < h->cache_steps),
-                  AFTER_E_INVALID, "cache_index %d out of range", cache_index);
+    AFTER_TRY(check_cache(h, 3 * B, cache_index));
     hipStream_t s = (hipStream_t)stream;
     CfgParams p;
     AFTER_TRY(cfg_params(guidance_timbre, guidance_structure, cfg_mode, 1.0f, &p));
@@ -1023,6 +1036,10 @@ extern "C" int after_sample(after_denoiser* h, const float* x0, const float* con
     AFTER_REQUIRE(x0 && cond && time_cond && out, AFTER_E_INVALID, "null tensor argument");
     AFTER_REQUIRE(nb_steps > 0 && nb_steps <= h->max_steps, AFTER_E_CAPACITY,
                   "nb_steps=%d outside (0, max_steps=%d]", nb_steps, h->max_steps);
+    AFTER_REQUIRE(h->cache == 0, AFTER_E_INVALID,
+                  "after_sample is the offline sampler; with streaming caches drive "
+                  "after_model_forward(cache_index) + after_denoiser_roll_cache per step "
+                  "(after_scripts/export.py:398-416)");
     hipStream_t s = (hipStream_t)stream;
     CfgParams p;
     // model.py:771: dt = 1 / nb_steps (python float -> the product dx * dt is fp32)
@@ -1085,19 +1102,68 @@ extern "C" int after_denoiser_set_graph(after_denoiser* h, int enable) {
 
 extern "C" int after_denoiser_enable_cache(after_denoiser* h, int cache_size, int max_steps,
                                            int max_rows) {
-    (void)h; (void)cache_size; (void)max_steps; (void)max_rows;
-    set_error("streaming KV caches are not built in this revision");
-    return AFTER_E_INVALID;
+    AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
+    AFTER_REQUIRE(cache_size > 0 && max_steps > 0 && max_rows > 0, AFTER_E_INVALID, "bad cache sizes");
+    AFTER_REQUIRE(cache_size % h->cs == 0, AFTER_E_INVALID,
+                  "cache size %d must be a multiple of the attention chunk %d (the chunk grid of "
+                  "transformerv2.py:81 is laid over cache + new frames)", cache_size, h->cs);
+    AFTER_REQUIRE(max_rows <= h->max_rows, AFTER_E_CAPACITY, "max_rows %d exceeds the handle's %d",
+                  max_rows, h->max_rows);
+    AFTER_HIP_CHECK(hipDeviceSynchronize());
+    h->ca.release();
+    h->cache = 0;
+    const size_t per = (size_t)max_rows * cache_size * h->E;
+    const size_t n = (size_t)h->L * max_steps * 2 * per;
+    const size_t nq = (size_t)h->L * h->max_rows * h->max_T * 3 * h->E;
+    AFTER_TRY(h->ca.init((2 * n + nq) * sizeof(float) + 4096));
+    h->kcache = h->ca.take<float>(n);
+    h->vcache = h->ca.take<float>(n);
+    h->qkv_layers = h->ca.take<float>(nq);
+    AFTER_REQUIRE(h->kcache && h->vcache && h->qkv_layers, AFTER_E_NOMEM, "cache arena exhausted");
+    AFTER_HIP_CHECK(hipMemset(h->kcache, 0, n * sizeof(float)));
+    AFTER_HIP_CHECK(hipMemset(h->vcache, 0, n * sizeof(float)));
+    AFTER_HIP_CHECK(hipDeviceSynchronize());
+    h->cache = cache_size;
+    h->cache_steps = max_steps;
+    h->cache_rows = max_rows;
+    h->flip.assign(max_steps, 0);
+    h->have_last = false;
+    return AFTER_OK;
 }
+
 extern "C" int after_denoiser_reset_cache(after_denoiser* h, void* stream) {
-    (void)h; (void)stream;
-    set_error("streaming KV caches are not built in this revision");
-    return AFTER_E_INVALID;
+    AFTER_REQUIRE(h && h->cache > 0, AFTER_E_INVALID, "streaming caches are not enabled");
+    const size_t n = (size_t)h->L * h->cache_steps * 2 * h->cache_rows * h->cache * h->E;
+    AFTER_HIP_CHECK(hipMemsetAsync(h->kcache, 0, n * sizeof(float), (hipStream_t)stream));
+    AFTER_HIP_CHECK(hipMemsetAsync(h->vcache, 0, n * sizeof(float), (hipStream_t)stream));
+    h->flip.assign(h->cache_steps, 0);
+    h->have_last = false;
+    return AFTER_OK;
 }
+
 extern "C" int after_denoiser_roll_cache(after_denoiser* h, int size, int cache_index, void* stream) {
-    (void)h; (void)size; (void)cache_index; (void)stream;
-    set_error("streaming KV caches are not built in this revision");
-    return AFTER_E_INVALID;
+    AFTER_REQUIRE(h && h->cache > 0, AFTER_E_INVALID, "streaming caches are not enabled");
+    AFTER_REQUIRE(h->have_last, AFTER_E_INVALID, "roll_cache before any forward with the cache");
+    AFTER_REQUIRE(cache_index >= 0 && cache_index < h->cache_steps, AFTER_E_CAPACITY,
+                  "cache_index %d outside [0, %d)", cache_index, h->cache_steps);
+    AFTER_REQUIRE(size > 0 && size <= h->last_T, AFTER_E_INVALID,
+                  "roll size %d outside (0, last call's %d frames]", size, h->last_T);
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = h->last_rows, E = h->E;
+    const size_t per = (size_t)h->cache_rows * h->cache * E;
+    const int cur = h->flip[cache_index];
+    const size_t total = (size_t)rows * h->cache * E;
+    for (int l = 0; l < h->L; ++l) {
+        const size_t base = ((size_t)l * h->cache_steps + cache_index) * 2 * per;
+        const float* qkv = h->qkv_layers + (size_t)l * h->max_rows * h->max_T * 3 * E;
+        hipLaunchKernelGGL(roll_cache_kernel, dim3((unsigned)cdivll(total, 256)), dim3(256), 0, s,
+                           h->kcache + base + cur * per, h->vcache + base + cur * per,
+                           h->kcache + base + (cur ^ 1) * per, h->vcache + base + (cur ^ 1) * per, qkv,
+                           rows, h->last_T, E, h->cache, size);
+        AFTER_HIP_CHECK(hipGetLastError());
+    }
+    h->flip[cache_index] = cur ^ 1;
+    return AFTER_OK;
 }
 
 extern "C" int after_denoiser_profile(after_denoiser* h, int enable) {

@@ -149,6 +149,7 @@ class DenoiserV2(nn.Module):
             _lib.lib().after_denoiser_destroy(h)
         self._handle = None
         self._cap = (0, 0, 0)
+        self._streaming = False
 
     def __del__(self):
         try:
@@ -180,6 +181,10 @@ class DenoiserV2(nn.Module):
         cr, ct, cs = self._cap
         if self._handle is not None and rows <= cr and T <= ct and steps <= cs:
             return self._handle
+        if self._handle is not None and getattr(self, "_streaming", False):
+            raise _lib.AFTERHipError(
+                f"request (rows={rows}, T={T}) exceeds the capacity fixed when the streaming "
+                f"caches were enabled {self._cap}; call enable_streaming_cache with larger limits")
         L = _lib.lib()
         self._release()
         cap = (max(rows, cr), max(T, ct), max(steps, cs, 1))
@@ -206,6 +211,27 @@ class DenoiserV2(nn.Module):
     def reserve(self, rows: int, T: int, steps: int = 1):
         """Provision workspaces up front (rows = 3 x clips for a CFG sample)."""
         self._ensure(rows, T, steps)
+
+    # ------------------------------------------------------------ streaming caches
+    def enable_streaming_cache(self, max_cache_size: Optional[int] = None,
+                               max_diffusion_steps: int = 16, max_batch_size: int = 4,
+                               max_frames: int = 64):
+        """Per-layer, per-diffusion-step K/V ring caches (transformerv2.py:143-155).  The
+        reference enables them with the gin binding `MHAttention.max_cache_size =
+        LOCAL_ATTENTION_SIZE` (after_scripts/export.py:77-79) and sizes them with
+        `max_diffusion_steps` / `max_batch_size` (network rows: 3 x clips under CFG)."""
+        cache = self.local_attention_size if max_cache_size is None else max_cache_size
+        self._ensure(max_batch_size, max_frames, 1)
+        self._cap = (max(self._cap[0], max_batch_size), max(self._cap[1], max_frames), self._cap[2])
+        _lib.check(_lib.lib().after_denoiser_enable_cache(self._handle, int(cache),
+                                                          int(max_diffusion_steps),
+                                                          int(max_batch_size)),
+                   "after_denoiser_enable_cache")
+        self._streaming = True
+
+    def reset_cache(self):
+        _lib.check(_lib.lib().after_denoiser_reset_cache(self._handle, _lib.current_stream(None)),
+                   "after_denoiser_reset_cache")
 
     # ------------------------------------------------------------ reference surface
     def roll_cache(self, size: int, cache_index: int):

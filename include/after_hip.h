@@ -118,8 +118,13 @@ int after_sample(after_denoiser* h, const float* x0, const float* cond, const fl
 int after_denoiser_set_graph(after_denoiser* h, int enable);
 
 /* Streaming KV caches (transformerv2.py:143-204; enabled in the reference by the
- * gin binding at after_scripts/export.py:77-79).  cache_size frames per layer,
- * per diffusion step, per row; zero-initialised like the reference buffers. */
+ * gin binding at after_scripts/export.py:77-79).  cache_size frames (a multiple of
+ * the attention chunk) per layer, per diffusion step, per network row;
+ * zero-initialised like the reference buffers.  max_steps / max_rows generalise the
+ * reference's max_diffusion_steps = 16 / max_batch_size = 4 (:130-131).  After
+ * enabling, drive after_model_forward / after_denoiser_forward with cache_index = i
+ * followed by after_denoiser_roll_cache(size, i) per diffusion step (export.py:398-416);
+ * after_sample (the offline sampler) is rejected while caches are enabled. */
 int after_denoiser_enable_cache(after_denoiser* h, int cache_size, int max_steps, int max_rows);
 int after_denoiser_reset_cache(after_denoiser* h, void* stream);
 /* Replaces: DenoiserV2.roll_cache (transformerv2.py:514-515, :171-188). */

@@ -119,3 +119,30 @@ def test_graph_replay_tracks_new_inputs_and_guidance(hip_device):
     for x, cond, tc, gt, gs, got in outs:
         eager = model.sample(x.to(hip_device), cond.to(hip_device), tc.to(hip_device), 4, gt, gs)
         assert torch.equal(eager, got)
+
+
+def test_streaming_kv_cache_matches_reference(hip_device):
+    """Streaming protocol of after_scripts/export.py:398-416: per diffusion step i, forward
+    with cache_index=i then roll_cache(chunk, i).  The fixture was produced by the
+    reference's own MHAttention caches (zero-initialised, so the warm-up transient of the
+    first chunks is part of the contract)."""
+    fx = Fixture("stream_micro")
+    sd = fx.state_dict()
+    model, dcfg = build("micro", sd, hip_device)
+    B, chunk, steps = fx.meta["B"], fx.meta["chunk"], fx.meta["steps"]
+    model.net.enable_streaming_cache(max_diffusion_steps=steps, max_batch_size=6, max_frames=chunk)
+    d = lambda n: fx.t(n).to(hip_device)
+    x, cond, tc, tvals, want = d("x"), d("cond"), d("time_cond"), fx.t("tvals"), fx.t("out")
+    for rep in range(2):  # second pass after reset_cache must reproduce the first
+        for c in range(want.shape[0]):
+            sl = slice(c * chunk, (c + 1) * chunk)
+            for i, t in enumerate(tvals):
+                tt = torch.full((B, ), float(t), device=hip_device)
+                got = model.net(x[..., sl].contiguous(), tt, cond, tc[..., sl].contiguous(),
+                                cache_index=i)
+                model.net.roll_cache(chunk, i)
+                assert max_abs(got.cpu(), want[c, i]) < 5e-5, (rep, c, i)
+        model.net.reset_cache()
+    with pytest.raises(_lib.AFTERHipError):
+        model.net(x[..., :2 * chunk].contiguous(), torch.zeros(B, device=hip_device), cond,
+                  tc[..., :2 * chunk].contiguous())  # beyond the capacity fixed at enable time
