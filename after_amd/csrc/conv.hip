@@ -22,6 +22,9 @@
 // to [phase][Cout][tap][Cin] so that the A operand -- lane l supplies
 // W[m = l&15][4 consecutive k of k-quad l>>4] -- is one ds_read_b128 from a row
 // padded to == 40 (mod 64) floats (conflict free for every b128 service group).
+#include <cstdio>
+#include <cstdlib>
+
 #include "conv.h"
 
 namespace after {
@@ -273,6 +276,18 @@ int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {
         attr = lds;
     }
     dim3 grid(g.tiles_m * g.tiles_n, a.phases, a.B);
+    {
+        static int log = -1;
+        if (log < 0) {
+            const char* e = getenv("AFTER_CONV_LOG");
+            log = e ? atoi(e) : 0;
+        }
+        if (log)
+            fprintf(stderr, "CONVLOG cfg=%dx%d Cin=%d Cout=%d Tin=%d Nn=%d taps=%d phases=%d istride=%d KC=%d XW=%d lds=%zu wgs=%d gflop=%.3f\n",
+                    MT, NT, a.Cin, a.Cout, a.Tin, a.Nn, a.taps, a.phases, a.istride, g.KC, g.XW, lds,
+                    g.tiles_m * g.tiles_n * a.phases * a.B,
+                    2.0 * a.Cin * a.Cout * a.taps * (double)a.Nn * a.phases * a.B * 1e-9);
+    }
     hipLaunchKernelGGL((conv_mfma_kernel<MT, NT>), grid, dim3(256), lds, s, a, g);
     AFTER_HIP_CHECK(hipGetLastError());
     return AFTER_OK;

@@ -524,6 +524,10 @@ struct after_denoiser {
     float *sx0 = nullptr, *scond = nullptr, *stc = nullptr, *sout = nullptr;
     hipStream_t gstream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    // CFG branch streams (run_net groups)
+    hipStream_t rstream[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    int row_groups = 3, row_groups_forced = 0;
     struct GraphEntry {
         int B, T, steps, cfg_mode;
         float drop;
@@ -612,35 +616,45 @@ int launch_attn(const AttnArgs& a, int rows, size_t lds, hipStream_t s) {
 // One network evaluation on `rows` rows.  x: [nx, C, T] addressed through dev_xmap
 // (row r reads clip xmap[r]; npat = number of distinct clips).  Result: h->outp
 // token-major [rows*T, C].
-int run_net(after_denoiser* h, hipStream_t s, const float* x, int npat, const int* dev_xmap,
-            const int* dev_tcmap, int rows, int T, const float* cond_ab_step, int cache_index) {
+// patchify_and_embed: GELU(Linear(C -> E)) on the transposed latents (:387-391, :440) for the
+// `npat` distinct clips of x -> h->pat
+int run_patchify(after_denoiser* h, hipStream_t s, const float* x, int npat, int T) {
+    dim3 grid(cdiv(T, 32), cdiv(h->Cp, 32), npat);
+    hipLaunchKernelGGL(to_token_major_kernel, grid, dim3(256), 0, s, x, h->xt, (const int*)nullptr,
+                       h->C, T, h->Cp, 0.f);
+    AFTER_HIP_CHECK(hipGetLastError());
+    return gemm(h, s, h->xt, h->Cp, h->patch_w, h->Cp, h->patch_b, h->pat, h->E, npat * T, h->E,
+                h->Cp, EPI_GELU);
+}
+
+// The decoder blocks + out_proj for network rows [row0, row0 + rows) on stream s.  Every
+// activation buffer is row-major over (row, frame), so a row range is a pointer offset.
+int run_layers(after_denoiser* h, hipStream_t s, int row0, int rows, const int* dev_xmap,
+               const int* dev_tcmap, int T, const float* cond_ab_step, int cache_index) {
     const int E = h->E, L = h->L, C = h->C, ME = h->ME;
     const int M = rows * T;
-    {
-        dim3 grid(cdiv(T, 32), cdiv(h->Cp, 32), npat);
-        hipLaunchKernelGGL(to_token_major_kernel, grid, dim3(256), 0, s, x, h->xt,
-                           (const int*)nullptr, C, T, h->Cp, 0.f);
-        AFTER_HIP_CHECK(hipGetLastError());
-    }
-    // patchify_and_embed: GELU(Linear(C -> E)) on the transposed latents (:387-391, :440)
-    AFTER_TRY(gemm(h, s, h->xt, h->Cp, h->patch_w, h->Cp, h->patch_b, h->pat, E, npat * T, E,
-                   h->Cp, EPI_GELU));
+    const size_t r0 = (size_t)row0 * T;
+    float* xres = h->xres + r0 * E;
+    float* hbuf = h->hbuf + r0 * E;
+    float* mlp = h->mlp + r0 * ME;
     const int nkmax = h->W - 1 + h->cs > h->cs ? h->W - 1 + h->cs : h->cs;
     const size_t lds = attn_lds_bytes(E, h->cs);
     for (int l = 0; l < L; ++l) {
         const LayerW& w = h->layers[l];
         hipLaunchKernelGGL(ln_mod_ln_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s,
-                           l == 0 ? h->pat : h->xres, l == 0 ? dev_xmap : (const int*)nullptr,
-                           h->xres, h->hbuf, h->tc_ab + (size_t)l * 2 * E, L * 2 * E, dev_tcmap,
-                           w.n1w, w.n1b, rows, T, E);
+                           l == 0 ? h->pat : xres,
+                           l == 0 ? (dev_xmap ? dev_xmap + row0 : (const int*)nullptr) : (const int*)nullptr,
+                           xres, hbuf, h->tc_ab + (size_t)l * 2 * E, L * 2 * E,
+                           dev_tcmap ? dev_tcmap + row0 : (const int*)nullptr, w.n1w, w.n1b, rows, T, E);
         AFTER_HIP_CHECK(hipGetLastError());
-        float* qkv = h->cache > 0 ? h->qkv_layers + (size_t)l * h->max_rows * h->max_T * 3 * E : h->qkv;
-        AFTER_TRY(gemm(h, s, h->hbuf, E, w.qkv_w, E, nullptr, qkv, 3 * E, M, 3 * E, E, EPI_NONE));
+        float* qkv = (h->cache > 0 ? h->qkv_layers + (size_t)l * h->max_rows * h->max_T * 3 * E : h->qkv) +
+                     r0 * 3 * E;
+        AFTER_TRY(gemm(h, s, hbuf, E, w.qkv_w, E, nullptr, qkv, 3 * E, M, 3 * E, E, EPI_NONE));
         AttnArgs a;
         a.qkv = qkv;
-        a.xres = h->xres;
-        a.h = h->hbuf;
-        a.cond_ab = cond_ab_step + (size_t)l * 2 * E;
+        a.xres = xres;
+        a.h = hbuf;
+        a.cond_ab = cond_ab_step + (size_t)row0 * L * 2 * E + (size_t)l * 2 * E;
         a.cond_ld = L * 2 * E;
         a.w3 = w.n3w;
         a.b3 = w.n3b;
@@ -651,8 +665,8 @@ int run_net(after_denoiser* h, hipStream_t s, const float* x, int npat, const in
         if (h->cache > 0) {
             const size_t per = (size_t)h->cache_rows * h->cache * E;
             const size_t slot = (((size_t)l * h->cache_steps + cache_index) * 2 + h->flip[cache_index]) * per;
-            a.kcache = h->kcache + slot;
-            a.vcache = h->vcache + slot;
+            a.kcache = h->kcache + slot + (size_t)row0 * h->cache * E;
+            a.vcache = h->vcache + slot + (size_t)row0 * h->cache * E;
             a.nc = h->cache;
         }
         a.T = T;
@@ -670,11 +684,37 @@ int run_net(after_denoiser* h, hipStream_t s, const float* x, int npat, const in
             a.dbg = dbg;
         }
         AFTER_TRY(launch_attn(a, rows, lds, s));
-        AFTER_TRY(gemm(h, s, h->hbuf, E, w.mlp0_w, E, w.mlp0_b, h->mlp, ME, M, ME, E, EPI_GELU));
-        AFTER_TRY(gemm(h, s, h->mlp, ME, w.mlp2_w, ME, w.mlp2_b, h->xres, E, M, E, ME,
-                       EPI_RESIDUAL, h->xres, E));
+        AFTER_TRY(gemm(h, s, hbuf, E, w.mlp0_w, E, w.mlp0_b, mlp, ME, M, ME, E, EPI_GELU));
+        AFTER_TRY(gemm(h, s, mlp, ME, w.mlp2_w, ME, w.mlp2_b, xres, E, M, E, ME, EPI_RESIDUAL, xres, E));
     }
-    AFTER_TRY(gemm(h, s, h->xres, E, h->out_w, E, h->out_b, h->outp, C, M, C, E, EPI_NONE));
+    return gemm(h, s, xres, E, h->out_w, E, h->out_b, h->outp + r0 * C, C, M, C, E, EPI_NONE);
+}
+
+// One network evaluation on `rows` rows.  x: [npat, C, T] addressed through dev_xmap (row r
+// reads clip xmap[r]).  Result: h->outp token-major [rows*T, C].  With `groups` > 1 the
+// row range is split into independent groups (the three CFG branches never interact inside
+// the network) that run on their own streams: kernels of different groups overlap, which
+// fills the launch ramps / tails and the SIMD quantisation holes of the small B = 1 grids.
+int run_net(after_denoiser* h, hipStream_t s, const float* x, int npat, const int* dev_xmap,
+            const int* dev_tcmap, int rows, int T, const float* cond_ab_step, int cache_index,
+            int groups = 1) {
+    AFTER_TRY(run_patchify(h, s, x, npat, T));
+    // measured (base, 50 steps): B = 8 -> 108.9 ms with three branch streams vs 112.3 ms on
+    // one; B = 1 -> 26.5 ms vs 23.6 ms (host-bound: 3x the launches of 5-15 us kernels)
+    if (h->row_groups_forced == 0 && (long long)rows * T < 4096) groups = 1;
+    if (groups <= 1 || rows % groups != 0 || h->timer.enabled)
+        return run_layers(h, s, 0, rows, dev_xmap, dev_tcmap, T, cond_ab_step, cache_index);
+    const int per = rows / groups;
+    AFTER_HIP_CHECK(hipEventRecord(h->ev_fork, s));
+    for (int g = 0; g < groups; ++g) {
+        hipStream_t gs = g == 0 ? s : h->rstream[g - 1];
+        if (g > 0) AFTER_HIP_CHECK(hipStreamWaitEvent(gs, h->ev_fork, 0));
+        AFTER_TRY(run_layers(h, gs, g * per, per, dev_xmap, dev_tcmap, T, cond_ab_step, cache_index));
+        if (g > 0) {
+            AFTER_HIP_CHECK(hipEventRecord(h->ev_join[g - 1], gs));
+            AFTER_HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[g - 1], 0));
+        }
+    }
     return AFTER_OK;
 }
 
@@ -894,6 +934,20 @@ extern "C" int after_denoiser_create(const after_denoiser_cfg* cfg, const float*
         set_error("stream / event creation failed");
         return fail(AFTER_E_HIP);
     }
+    for (int i = 0; i < 2; ++i)
+        if (hipStreamCreateWithFlags(&h->rstream[i], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) != hipSuccess) {
+            set_error("stream / event creation failed");
+            return fail(AFTER_E_HIP);
+        }
+    if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(AFTER_E_HIP);
+    {
+        const char* e = getenv("AFTER_ROW_GROUPS");
+        if (e) {
+            h->row_groups = atoi(e) == 3 ? 3 : 1;
+            h->row_groups_forced = 1;
+        }
+    }
     {
         // Measured on MI355X / ROCm 7.2 (base, B=1, 50 steps, 1650 kernel nodes): graph
         // replay 25.3 ms vs 23.7 ms for plain launches -- the path is GPU-bound, the host
@@ -914,6 +968,11 @@ extern "C" void after_denoiser_destroy(after_denoiser* h) {
     (void)hipDeviceSynchronize();
     for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.exec);
     if (h->gstream) (void)hipStreamDestroy(h->gstream);
+    for (int i = 0; i < 2; ++i) {
+        if (h->rstream[i]) (void)hipStreamDestroy(h->rstream[i]);
+        if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->ev_out) (void)hipEventDestroy(h->ev_out);
     h->timer.destroy();
@@ -993,7 +1052,7 @@ int sample_enqueue(after_denoiser* h, hipStream_t s, const float* x0, const floa
     for (int i = 0; i < nb_steps; ++i) {
         const float* xin = i == 0 ? x0 : out;
         AFTER_TRY(run_net(h, s, xin, B, h->maps, h->maps + h->ms, rows, T,
-                          h->cond_ab + (size_t)i * step_stride, 0));
+                          h->cond_ab + (size_t)i * step_stride, 0, h->row_groups));
         AFTER_TRY(cfg_combine(h, s, xin, out, B, T));
     }
     return AFTER_OK;
@@ -1019,7 +1078,8 @@ extern "C" int after_model_forward(after_denoiser* h, const float* x, const floa
     AFTER_TRY(compute_cond_ab(h, s, 1, rows, time, h->maps, 0, cond, h->maps + 2 * h->ms,
                               drop_value));
     AFTER_TRY(set_params(h, s, p));
-    AFTER_TRY(run_net(h, s, x, B, h->maps, h->maps + h->ms, rows, T, h->cond_ab, cache_index));
+    AFTER_TRY(run_net(h, s, x, B, h->maps, h->maps + h->ms, rows, T, h->cond_ab, cache_index,
+                      h->row_groups));
     AFTER_TRY(cfg_combine(h, s, nullptr, out, B, T));
     h->have_last = true;
     h->last_rows = rows;
