@@ -8,6 +8,7 @@
 // split reduction whose last-arriving block folds them into a per-(clip, channel)
 // affine.  The two PQMF filter banks are HBM-bound polyphase FIRs on the vector
 // ALUs with their taps in scalar registers.
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -136,22 +137,32 @@ using namespace after;
 
 namespace {
 
+// plan + repacked weights of one conv for the DMA kernel (conv_dma.hip)
+struct DmaConv {
+    ConvDmaPlanIn in;
+    ConvDmaPlan plan;
+    float* w = nullptr;
+};
 struct ConvBlockW {
     float *gn_w = nullptr, *gn_b = nullptr, *alpha = nullptr, *invb = nullptr, *w = nullptr,
           *bias = nullptr;
     int cin = 0, cout = 0, k = 1, dil = 1;
+    DmaConv d;
 };
 struct ResBlockW {
     ConvBlockW cb0, cb1;
     float *to_w = nullptr, *to_b = nullptr;  // 1x1 shortcut when cin != cout
+    DmaConv to_d;
 };
 struct ResampleW {
     float *alpha = nullptr, *invb = nullptr, *w = nullptr, *bias = nullptr;
     int cin = 0, cout = 0, f = 1;
+    DmaConv d;
 };
 struct PlainConvW {
     float *w = nullptr, *bias = nullptr;
     int cin = 0, cout = 0, k = 3;
+    DmaConv d;
 };
 
 }  // namespace
@@ -181,7 +192,15 @@ struct after_ae {
     double* gn_part = nullptr;
     unsigned* gn_tick = nullptr;
     int cmax = 0;
+    // DMA conv path
+    bool use_dma = true;
+    float* xp = nullptr;          // activated + haloed scratch tensor
+    size_t xp_elems = 0;
+    double* stats_ring = nullptr; // [kStatSlots][max_batch][8][2]
+    int stat_slot = 0;
+    Arena wd;                     // repacked weights
 };
+constexpr int kStatSlots = 96;
 
 namespace {
 
@@ -320,6 +339,98 @@ int run_resblock(after_ae* h, hipStream_t s, const ResBlockW& rb, const float* b
     }
     AFTER_TRY(run_convblock(h, s, rb.cb0, bx, bt, nullptr, B, T));
     return run_convblock(h, s, rb.cb1, bt, by, res, B, T);
+}
+
+// ------------------------------------------------------------------ DMA conv path
+int make_dma(after_ae* h, DmaConv& d, const float* packed, int cin, int cout, int taps, int phases,
+             int istride, int ostride, const int (*toff)[kMaxTaps], const int* ooff, int Nn_hint) {
+    memset(&d.in, 0, sizeof(d.in));
+    d.in.Cin = cin;
+    d.in.Cout = cout;
+    d.in.taps = taps;
+    d.in.phases = phases;
+    d.in.istride = istride;
+    d.in.ostride = ostride;
+    for (int p = 0; p < phases; ++p) {
+        for (int t = 0; t < taps; ++t) d.in.toff[p][t] = toff[p][t];
+        d.in.ooff[p] = ooff ? ooff[p] : 0;
+    }
+    d.in.Nn_hint = Nn_hint;
+    d.in.B_hint = 1;
+    conv_dma_plan(d.in, &d.plan);
+    d.w = h->wd.take<float>(d.plan.w_floats);
+    AFTER_REQUIRE(d.w, AFTER_E_NOMEM, "autoencoder: DMA weight arena exhausted");
+    return conv_dma_repack(packed, d.w, d.in, d.plan, 0);
+}
+
+double* next_stats(after_ae* h, int B) {
+    double* p = h->stats_ring + (size_t)(h->stat_slot % kStatSlots) * h->max_batch * 16;
+    ++h->stat_slot;
+    (void)B;
+    return p;
+}
+
+// act(GroupNorm(x)) -> haloed scratch, then the DMA conv.  stats_in: accumulators of x (or
+// nullptr: no norm); returns in *stats_out the accumulators of y when want_stats.
+int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const double* stats_in,
+            const float* gamma, const float* beta, const float* alpha, const float* invb, int act,
+            const float* bias, const float* res, float* y, int B, int Tin, int Tout, int Nn,
+            bool want_stats, double** stats_out) {
+    const int cin = d.in.Cin, cout = d.in.Cout;
+    AFTER_REQUIRE((size_t)B * cin * conv_dma_row(Tin) <= h->xp_elems, AFTER_E_CAPACITY,
+                  "autoencoder: activation scratch too small");
+    AFTER_TRY(launch_act_pad(x, h->xp, stats_in, gamma, beta, alpha, invb, act, B, cin, Tin,
+                             cin < 8 ? cin : 8, s));
+    ConvDmaRun r;
+    r.xp = h->xp;
+    r.w = d.w;
+    r.bias = bias;
+    r.res = res;
+    r.y = y;
+    r.stats = nullptr;
+    r.G = cout < 8 ? cout : 8;
+    if (want_stats && h->norm) {
+        r.stats = next_stats(h, B);
+        if (stats_out) *stats_out = r.stats;
+    }
+    r.B = B;
+    r.Tp = conv_dma_row(Tin);
+    r.Tout = Tout;
+    r.Nn = Nn;
+    return launch_conv_dma(r, d.in, d.plan, s);
+}
+
+// ConvBlock1d on the DMA path
+int run_convblock2(after_ae* h, hipStream_t s, const ConvBlockW& cb, const float* x,
+                   const double* stats_x, float* y, const float* res, int B, int T, bool want_stats,
+                   double** stats_y) {
+    return run_dma(h, s, cb.d, x, h->norm ? stats_x : nullptr, cb.gn_w, cb.gn_b, cb.alpha, cb.invb,
+                   ACT_SNAKE, cb.bias, res, y, B, T, T, T, want_stats, stats_y);
+}
+
+// ResnetBlock1d on the DMA path; *stats carries the accumulators of the block input in and of
+// the block output out
+int run_resblock2(after_ae* h, hipStream_t s, const ResBlockW& rb, const float* bx, float* bt,
+                  float* by, int B, int T, double** stats) {
+    const float* res = bx;
+    if (rb.to_w) {
+        AFTER_TRY(run_dma(h, s, rb.to_d, bx, nullptr, nullptr, nullptr, nullptr, nullptr, ACT_NONE,
+                          rb.to_b, nullptr, by, B, T, T, T, false, nullptr));
+        res = by;
+    }
+    double* st1 = nullptr;
+    AFTER_TRY(run_convblock2(h, s, rb.cb0, bx, *stats, bt, nullptr, B, T, true, &st1));
+    double* st2 = nullptr;
+    AFTER_TRY(run_convblock2(h, s, rb.cb1, bt, st1, by, res, B, T, true, &st2));
+    *stats = st2;
+    return AFTER_OK;
+}
+
+int begin_pass(after_ae* h, hipStream_t s) {
+    h->stat_slot = 0;
+    if (h->norm)
+        AFTER_HIP_CHECK(hipMemsetAsync(h->stats_ring, 0, (size_t)kStatSlots * h->max_batch * 16 * sizeof(double), s));
+    return AFTER_OK;
 }
 
 int check_ae(after_ae* h, int B, long long samples) {
@@ -506,6 +617,58 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
         set_error("autoencoder: expected %d weight tensors, got %d", cur.i, n_weights);
         return fail(AFTER_E_INVALID);
     }
+    // ---- DMA conv path: per-conv tile plan + repacked weights
+    {
+        const char* e = getenv("AFTER_CONV_OLD");
+        h->use_dma = !(e && atoi(e) != 0);
+    }
+    if (h->use_dma) {
+        AE_TRY(h->wd.init((size_t)(wf * 1.8) * sizeof(float) + (8 << 20)));
+        const size_t Tm = h->max_samples / h->M;
+        auto plan_conv = [&](DmaConv& d, const float* packed, int cin, int cout, int kk, int dil,
+                             size_t T) -> int {
+            int toff[kMaxPhases][kMaxTaps] = {};
+            const int pl = conv_left_pad(kk, dil, h->causal);
+            for (int t = 0; t < kk; ++t) toff[0][t] = t * dil - pl;
+            return make_dma(h, d, packed, cin, cout, kk, 1, 1, 1, toff, nullptr, (int)T);
+        };
+        auto plan_res = [&](ResBlockW& rb, size_t T) -> int {
+            AFTER_TRY(plan_conv(rb.cb0.d, rb.cb0.w, rb.cb0.cin, rb.cb0.cout, rb.cb0.k, rb.cb0.dil, T));
+            AFTER_TRY(plan_conv(rb.cb1.d, rb.cb1.w, rb.cb1.cin, rb.cb1.cout, 1, 1, T));
+            if (rb.to_w) AFTER_TRY(plan_conv(rb.to_d, rb.to_w, rb.cb0.cin, rb.cb0.cout, 1, 1, T));
+            return AFTER_OK;
+        };
+        size_t T = Tm;
+        AE_TRY(plan_res(h->enc_stem, T));
+        for (int i = 0; i < n; ++i) {
+            for (int j = 0; j < nd; ++j) AE_TRY(plan_res(h->enc_res[i][j], T));
+            ResampleW& d = h->enc_down[i];
+            int toff[kMaxPhases][kMaxTaps] = {};
+            const int pl = conv_left_pad(2 * d.f, 1, h->causal);
+            for (int t = 0; t < 2 * d.f; ++t) toff[0][t] = t - pl;
+            AE_TRY(make_dma(h, d.d, d.w, d.cin, d.cout, 2 * d.f, 1, d.f, 1, toff, nullptr, (int)(T / d.f)));
+            T /= d.f;
+        }
+        AE_TRY(plan_conv(h->enc_tail.d, h->enc_tail.w, h->enc_tail.cin, h->enc_tail.cout, 3, 1, T));
+        T = h->max_samples / h->ratio;
+        AE_TRY(plan_conv(h->dec_head.d, h->dec_head.w, h->dec_head.cin, h->dec_head.cout, h->dec_head.k, 1, T));
+        for (int i = 0; i < n; ++i) {
+            ResampleW& u = h->dec_up[i];
+            int toff[kMaxPhases][kMaxTaps] = {};
+            int ooff[kMaxPhases] = {};
+            for (int r = 0; r < u.f; ++r) {
+                const int cc = (r + u.f / 2) / u.f;
+                toff[r][0] = cc - 1;
+                toff[r][1] = cc;
+                ooff[r] = r;
+            }
+            AE_TRY(make_dma(h, u.d, u.w, u.cin, u.cout, 2, u.f, 1, u.f, toff, ooff, (int)T));
+            T *= u.f;
+            for (int j = 0; j < nd; ++j) AE_TRY(plan_res(h->dec_res[i][j], T));
+        }
+        AE_TRY(plan_conv(h->synth0.d, h->synth0.w, h->synth0.cin, h->synth0.cout, h->synth0.k, 1, T));
+        AE_TRY(plan_conv(h->synth1.d, h->synth1.w, h->synth1.cin, h->synth1.cout, 1, 1, T));
+    }
 #undef AE_TRY
 
     // workspaces: three rotating activation buffers of the largest C x T footprint
@@ -534,15 +697,45 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
     }
     h->buf_elems = elems * max_batch;
     h->cmax = cmax;
+    // activated + haloed scratch: largest C x padded-row footprint
+    size_t xpe = 0;
+    {
+        const size_t Tm = h->max_samples / h->M;
+        size_t T = Tm;
+        auto upd = [&](int c, size_t t) {
+            const size_t e2 = (size_t)c * conv_dma_row((int)t);
+            xpe = e2 > xpe ? e2 : xpe;
+        };
+        upd(h->M, Tm);
+        upd(out_ch, Tm);
+        for (int i = 0; i <= n; ++i) {
+            upd(C0 * cfg->multipliers[i], T);
+            if (i < n) T /= cfg->factors[i];
+        }
+        T = h->max_samples / h->ratio;
+        upd(cfg->z_channels, T);
+        for (int i = 0; i <= n; ++i) {
+            upd(C0 * cfg->dec_multipliers[i], T);
+            if (i < n) {
+                T *= cfg->factors[n - 1 - i];
+                upd(C0 * cfg->dec_multipliers[i + 1], T);
+            }
+        }
+    }
+    h->xp_elems = xpe * max_batch + 4096;
     rc = h->ws.init(3 * h->buf_elems * sizeof(float) + 2 * (size_t)max_batch * cmax * sizeof(float) +
-                    (size_t)max_batch * 8 * 64 * 2 * sizeof(double) + (size_t)max_batch * 8 * 4 + 4096);
+                    (size_t)max_batch * 8 * 64 * 2 * sizeof(double) + (size_t)max_batch * 8 * 4 + 8192 +
+                    h->xp_elems * sizeof(float) + (size_t)kStatSlots * max_batch * 16 * sizeof(double));
     if (rc != AFTER_OK) return fail(rc);
     for (int i = 0; i < 3; ++i) h->buf[i] = h->ws.take<float>(h->buf_elems);
     h->scale = h->ws.take<float>((size_t)max_batch * cmax);
     h->shift = h->ws.take<float>((size_t)max_batch * cmax);
     h->gn_part = h->ws.take<double>((size_t)max_batch * 8 * 64 * 2);
     h->gn_tick = h->ws.take<unsigned>((size_t)max_batch * 8);
-    if (!h->buf[2] || !h->scale || !h->shift || !h->gn_part || !h->gn_tick) return fail(AFTER_E_NOMEM);
+    h->xp = h->ws.take<float>(h->xp_elems);
+    h->stats_ring = h->ws.take<double>((size_t)kStatSlots * max_batch * 16);
+    if (!h->buf[2] || !h->scale || !h->shift || !h->gn_part || !h->gn_tick || !h->xp || !h->stats_ring)
+        return fail(AFTER_E_NOMEM);
     if (hipMemset(h->gn_tick, 0, (size_t)max_batch * 8 * sizeof(unsigned)) != hipSuccess ||
         hipDeviceSynchronize() != hipSuccess) {
         set_error("autoencoder: device initialisation failed");
@@ -554,6 +747,7 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
 
 extern "C" void after_ae_destroy(after_ae* h) {
     if (!h) return;
+    h->wd.release();
     h->wa.release();
     h->ws.release();
     delete h;
@@ -583,6 +777,34 @@ extern "C" int after_ae_encode(after_ae* h, const float* x, float* z, int B, int
     int T = L / h->M;
     float *b0 = h->buf[0], *b1 = h->buf[1], *b2 = h->buf[2];
     AFTER_TRY(pqmf_forward(h, s, x, b0, B, L));
+    if (h->use_dma) {
+        AFTER_TRY(begin_pass(h, s));
+        double* st = nullptr;
+        if (h->norm) {  // the first GroupNorm sees the PQMF output: its producer is not a conv
+            st = next_stats(h, B);
+            AFTER_TRY(launch_stats_accum(b0, st, B, h->M, T, h->M < 8 ? h->M : 8, s));
+        }
+        AFTER_TRY(run_resblock2(h, s, h->enc_stem, b0, b1, b2, B, T, &st));
+        float *cur = b2, *t1 = b0, *t2 = b1;
+        for (int i = 0; i < n; ++i) {
+            for (int j = 0; j < nd; ++j) {
+                AFTER_TRY(run_resblock2(h, s, h->enc_res[i][j], cur, t1, t2, B, T, &st));
+                float* o = cur;
+                cur = t2;
+                t2 = o;
+            }
+            const ResampleW& d = h->enc_down[i];
+            AFTER_TRY(run_dma(h, s, d.d, cur, nullptr, nullptr, nullptr, d.alpha, d.invb, ACT_SNAKE, d.bias,
+                              nullptr, t1, B, T, T / d.f, T / d.f, true, &st));
+            float* o = cur;
+            cur = t1;
+            t1 = o;
+            T /= d.f;
+        }
+        return run_dma(h, s, h->enc_tail.d, cur, nullptr, nullptr, nullptr, h->enc_tail_alpha,
+                       h->enc_tail_invb, ACT_SNAKE, h->enc_tail.bias, nullptr, z, B, T, T, T, false,
+                       nullptr);
+    }
     AFTER_TRY(run_resblock(h, s, h->enc_stem, b0, b1, b2, B, T));
     float *cur = b2, *t1 = b0, *t2 = b1;
     for (int i = 0; i < n; ++i) {
@@ -638,6 +860,32 @@ extern "C" int after_ae_decode(after_ae* h, const float* z, float* x, int B, int
     const after_ae_cfg& c = h->cfg;
     const int n = c.n_stages, nd = c.n_dilations;
     float *cur = h->buf[0], *t1 = h->buf[1], *t2 = h->buf[2];
+    if (h->use_dma) {
+        AFTER_TRY(begin_pass(h, s));
+        double* st = nullptr;
+        AFTER_TRY(run_dma(h, s, h->dec_head.d, z, nullptr, nullptr, nullptr, nullptr, nullptr, ACT_NONE,
+                          h->dec_head.bias, nullptr, cur, B, T, T, T, false, nullptr));
+        for (int i = 0; i < n; ++i) {
+            const ResampleW& u = h->dec_up[i];
+            AFTER_TRY(run_dma(h, s, u.d, cur, nullptr, nullptr, nullptr, u.alpha, u.invb, ACT_SNAKE, u.bias,
+                              nullptr, t1, B, T, T * u.f, T, true, &st));
+            float* o = cur;
+            cur = t1;
+            t1 = o;
+            T *= u.f;
+            for (int j = 0; j < nd; ++j) {
+                AFTER_TRY(run_resblock2(h, s, h->dec_res[i][j], cur, t1, t2, B, T, &st));
+                o = cur;
+                cur = t2;
+                t2 = o;
+            }
+        }
+        double* st1 = nullptr;
+        AFTER_TRY(run_convblock2(h, s, h->synth0, cur, st, t1, nullptr, B, T, true, &st1));
+        AFTER_TRY(run_convblock2(h, s, h->synth1, t1, st1, t2, nullptr, B, T, false, nullptr));
+        const int och = c.use_loudness ? 2 * h->M : h->M;
+        return pqmf_inverse(h, s, t2, x, B, T, c.use_loudness, och);
+    }
     {
         ConvArgs a;
         base_args(a, B, h->dec_head.cin, h->dec_head.cout, T, T);

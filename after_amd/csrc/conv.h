@@ -77,6 +77,39 @@ int pack_convT_weight(const float* v, const float* g, float* out, int Cin, int C
                       int Cin_pad, hipStream_t s);
 int snake_inv_beta(const float* beta, float* out, int C, hipStream_t s);
 
+// ---- "activate once, convolve by DMA" path (conv_dma.hip)
+struct ConvDmaPlanIn {
+    int Cin, Cout, taps, phases, istride, ostride;
+    int toff[kMaxPhases][kMaxTaps];
+    int ooff[kMaxPhases];
+    int Nn_hint, B_hint;  // problem size the tile is chosen for
+};
+struct ConvDmaPlan {
+    int mt, nt, KC, XW, LD, nstage, Cout_pad;
+    size_t w_floats;
+};
+struct ConvDmaRun {
+    const float* xp;   // [B][Cin][Tp] activated, haloed input (launch_act_pad)
+    const float* w;    // conv_dma_repack output
+    const float* bias;
+    const float* res;  // [B][Cout][Tout] or nullptr
+    float* y;          // [B][Cout][Tout]
+    double* stats;     // [B][G][2] sum / sum-of-squares accumulators of y, or nullptr
+    int B, Tp, Tout, Nn, G;
+};
+int conv_dma_halo();
+int conv_dma_row(int T);
+void conv_dma_plan(const ConvDmaPlanIn& in, ConvDmaPlan* p);
+int conv_dma_repack(const float* packed, float* out, const ConvDmaPlanIn& in, const ConvDmaPlan& p,
+                    hipStream_t s);
+int launch_conv_dma(const ConvDmaRun& r, const ConvDmaPlanIn& in, const ConvDmaPlan& p, hipStream_t s);
+// y[b,c,halo+t] = act(GroupNorm-affine(x)) with zeroed halo; stats = producer's accumulators
+int launch_act_pad(const float* x, float* y, const double* stats, const float* gamma,
+                   const float* beta, const float* act_a, const float* act_b, int act, int B, int C,
+                   int T, int G, hipStream_t s);
+// stats[b][g] += (sum, sum of squares) of x[b, group g, :]   (for producers that are not convs)
+int launch_stats_accum(const float* x, double* stats, int B, int C, int T, int G, hipStream_t s);
+
 inline int pad16(int c) { return (c + 15) & ~15; }
 
 // cached_conv.get_padding left pad (stride ignored): p = (k-1) d + 1
