@@ -19,60 +19,100 @@ namespace {
 
 // ------------------------------------------------------------------ PQMF analysis
 // mb[b, c, n] = sgn(c, n) * sum_k w[c][k] x[b, 16 n + k - pl]      (pqmf.py:286-290, 16-20)
-// polyphase form: k = 16 q + r  ->  sum_r sum_q w[c][16 q + r] xp[r][n + q],
-// xp[r][m] = x[16 m + r - pl] staged de-interleaved in LDS, so lanes (= consecutive n)
-// read consecutive addresses.  Wave = one band group: taps are wave-uniform (SGPRs).
-constexpr int PQ_BT = 64;  // frames per block
+// polyphase form: k = M q + r  ->  sum_r sum_q w[c][M q + r] xp[r][n + q],
+// xp[r][m] = x[M m + r - pl] staged de-interleaved in LDS, so lanes (= consecutive n) read
+// consecutive addresses.  One lane = one frame, all M = 16 bands in registers; the taps are
+// re-laid-out at create time to wp[r][q][c] so that the 16 band weights of one (r, q) are one
+// wave-uniform s_load_dwordx16 (SGPR operands of the 16 FMAs).
+constexpr int PQ_BT = 256;  // frames per block
 
+template <int M>
 __global__ __launch_bounds__(256) void pqmf_forward_kernel(const float* __restrict__ x,
-                                                           const float* __restrict__ w,
-                                                           float* __restrict__ mb, int L, int M,
-                                                           int K, int pl) {
-    extern __shared__ float xp[];  // [M][PQ_BT + Q]  (Q = ceil(K / M))
-    const int Q = (K + M - 1) / M;
+                                                           const float* __restrict__ wp,
+                                                           float* __restrict__ mb, int L, int Q,
+                                                           int pl) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     const int ldp = PQ_BT + Q + 1;
+    float* ws = sm;                // [M][Q][M] taps, read as wave-uniform (broadcast) float4s
+    float* xp = sm + M * Q * M;    // [M][PQ_BT + Q + 1]
     const int b = blockIdx.y, n0 = blockIdx.x * PQ_BT;
     const int Tm = L / M;
     const float* xb = x + (size_t)b * L;
+    for (int idx = threadIdx.x; idx < M * Q * M / 4; idx += 256)
+        reinterpret_cast<float4*>(ws)[idx] = reinterpret_cast<const float4*>(wp)[idx];
     for (int idx = threadIdx.x; idx < M * (PQ_BT + Q); idx += 256) {
-        // consecutive threads read consecutive samples: idx = m * M + r
-        const int m = idx / M, r = idx - m * M;
+        const int m = idx / M, r = idx - m * M;  // consecutive threads read consecutive samples
         const long long s = (long long)(n0 + m) * M + r - pl;
         xp[r * ldp + m] = (s >= 0 && s < L) ? xb[s] : 0.f;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = n0 + lane;
-    // wave wv handles bands wv, wv + 4, ...
-    for (int c = wv; c < M; c += 4) {
-        const float* wc = w + (size_t)c * K;
-        float acc = 0.f;
-        for (int r = 0; r < M; ++r) {
-            const float* xr = xp + r * ldp + lane;
-            for (int q = 0; q * M + r < K; ++q) acc += wc[q * M + r] * xr[q];
-        }
-        if (n < Tm) {
-            const bool neg = (c & 1) && !(n & 1);  // reverse_half: odd bands, even frames
-            mb[((size_t)b * M + c) * Tm + n] = neg ? -acc : acc;
+    float acc[M];
+#pragma unroll
+    for (int c = 0; c < M; ++c) acc[c] = 0.f;
+    for (int r = 0; r < M; ++r) {
+        const float* xr = xp + r * ldp + threadIdx.x;
+        const float4* wr = reinterpret_cast<const float4*>(ws + (size_t)r * Q * M);
+#pragma unroll 3
+        for (int q = 0; q < Q; ++q) {
+            const float xv = xr[q];
+#pragma unroll
+            for (int c4 = 0; c4 < M / 4; ++c4) {
+                const float4 w4 = wr[q * (M / 4) + c4];
+                acc[4 * c4 + 0] += w4.x * xv;
+                acc[4 * c4 + 1] += w4.y * xv;
+                acc[4 * c4 + 2] += w4.z * xv;
+                acc[4 * c4 + 3] += w4.w * xv;
+            }
         }
     }
+    const int n = n0 + threadIdx.x;
+    if (n < Tm) {
+#pragma unroll
+        for (int c = 0; c < M; ++c) {
+            const bool neg = (c & 1) && !(n & 1);  // reverse_half: odd bands, even frames
+            mb[((size_t)b * M + c) * Tm + n] = neg ? -acc[c] : acc[c];
+        }
+    }
+}
+
+// generic fallback (any M): one thread per (band, frame)
+__global__ __launch_bounds__(256) void pqmf_forward_generic_kernel(const float* __restrict__ x,
+                                                                   const float* __restrict__ w,
+                                                                   float* __restrict__ mb, int L, int M,
+                                                                   int K, int pl) {
+    const int Tm = L / M;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (idx >= (size_t)Tm * M) return;
+    const int c = idx / Tm, n = idx - (size_t)c * Tm;
+    const float* xb = x + (size_t)b * L;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const long long s = (long long)n * M + k - pl;
+        if (s >= 0 && s < L) acc += w[(size_t)c * K + k] * xb[s];
+    }
+    mb[((size_t)b * M + c) * Tm + n] = ((c & 1) && !(n & 1)) ? -acc : acc;
 }
 
 // ------------------------------------------------------------------ PQMF synthesis
 // audio[b, M t + m] = M * sum_c sum_k w[M-1-m][c][k] z[c][t + k - pl],
 // z[c][t] = sgn(c, t) * band(c, t),  band = y[c] * sigmoid(y[M + c]) with the loudness
 // gate (SimpleNetsStream.py:644-646) or y[c] without.          (pqmf.py:292-301)
-// One lane = one frame t, all M phases in registers; taps are wave-uniform.
+// One lane = one frame t, all M phases in registers; taps re-laid-out to wi[c][k][m] =
+// w[M-1-m][c][k] so the 16 phase weights of one (c, k) are one s_load_dwordx16.
 template <int M>
 __global__ __launch_bounds__(256) void pqmf_inverse_kernel(const float* __restrict__ y,
-                                                           const float* __restrict__ w,
+                                                           const float* __restrict__ wi,
                                                            float* __restrict__ audio, int Tm,
                                                            int K, int pl, int gated, int ychan) {
-    extern __shared__ float zs[];  // [M][256 + K]
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     const int ldz = 256 + K;
+    float* ws = sm;              // [M][K][M] taps (broadcast float4 reads)
+    float* zs = sm + M * K * M;  // [M][256 + K]
     const int b = blockIdx.y, t0 = blockIdx.x * 256;
     const float* yb = y + (size_t)b * ychan * Tm;
+    for (int idx = threadIdx.x; idx < M * K * M / 4; idx += 256)
+        reinterpret_cast<float4*>(ws)[idx] = reinterpret_cast<const float4*>(wi)[idx];
     for (int idx = threadIdx.x; idx < M * ldz; idx += 256) {
         const int c = idx / ldz, col = idx - c * ldz;
         const int t = t0 + col - pl;
@@ -90,10 +130,18 @@ __global__ __launch_bounds__(256) void pqmf_inverse_kernel(const float* __restri
     for (int m = 0; m < M; ++m) acc[m] = 0.f;
     for (int c = 0; c < M; ++c) {
         const float* zc = zs + c * ldz + threadIdx.x;
+        const float4* wc = reinterpret_cast<const float4*>(ws + (size_t)c * K * M);
+#pragma unroll 3
         for (int k = 0; k < K; ++k) {
             const float zv = zc[k];
 #pragma unroll
-            for (int m = 0; m < M; ++m) acc[m] += w[((size_t)(M - 1 - m) * M + c) * K + k] * zv;
+            for (int m4 = 0; m4 < M / 4; ++m4) {
+                const float4 w4 = wc[k * (M / 4) + m4];
+                acc[4 * m4 + 0] += w4.x * zv;
+                acc[4 * m4 + 1] += w4.y * zv;
+                acc[4 * m4 + 2] += w4.z * zv;
+                acc[4 * m4 + 3] += w4.w * zv;
+            }
         }
     }
     const int t = t0 + threadIdx.x;
@@ -103,6 +151,22 @@ __global__ __launch_bounds__(256) void pqmf_inverse_kernel(const float* __restri
         for (int m = 0; m < M; m += 4)
             *reinterpret_cast<float4*>(o + m) = make_float4(acc[m] * M, acc[m + 1] * M,
                                                             acc[m + 2] * M, acc[m + 3] * M);
+    }
+}
+
+// wp[r][q][c] = w[c][M q + r] (0 past K);  wi[c][k][m] = w[M-1-m][c][k]
+__global__ void pqmf_relayout_kernel(const float* __restrict__ fw, const float* __restrict__ iw,
+                                     float* __restrict__ wp, float* __restrict__ wi, int M, int Kf,
+                                     int Q, int Ki) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < M * Q * M) {
+        const int c = idx % M, q = (idx / M) % Q, r = idx / (M * Q);
+        const int k = M * q + r;
+        wp[idx] = k < Kf ? fw[(size_t)c * Kf + k] : 0.f;
+    }
+    if (idx < M * Ki * M) {
+        const int m = idx % M, k = (idx / M) % Ki, c = idx / (M * Ki);
+        wi[idx] = iw[((size_t)(M - 1 - m) * M + c) * Ki + k];
     }
 }
 
@@ -172,7 +236,8 @@ struct after_ae {
     int M, ratio, max_batch, max_samples;
     bool causal, norm;
     Arena wa, ws;
-    float *pq_fw = nullptr, *pq_iw = nullptr;
+    float *pq_fw = nullptr, *pq_iw = nullptr;    // reference layouts
+    float *pq_fwp = nullptr, *pq_iwp = nullptr;  // polyphase / phase-major re-layouts
     int pq_fk = 0, pq_ik = 0;
     // encoder
     ResBlockW enc_stem;
@@ -448,9 +513,20 @@ int pqmf_forward(after_ae* h, hipStream_t s, const float* x, float* mb, int B, i
     const int M = h->M, K = h->pq_fk;
     const int Q = (K + M - 1) / M;
     const int pl = h->causal ? K - 1 : (K - 1) / 2;
-    const size_t lds = (size_t)M * (PQ_BT + Q + 1) * sizeof(float);
-    hipLaunchKernelGGL(pqmf_forward_kernel, dim3(cdiv(L / M, PQ_BT), B), dim3(256), lds, s, x,
-                       h->pq_fw, mb, L, M, K, pl);
+    if (M == 16) {
+        const size_t lds = ((size_t)M * Q * M + (size_t)M * (PQ_BT + Q + 1)) * sizeof(float);
+        static bool attr = false;
+        if (!attr) {
+            AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pqmf_forward_kernel<16>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr = true;
+        }
+        hipLaunchKernelGGL(pqmf_forward_kernel<16>, dim3(cdiv(L / M, PQ_BT), B), dim3(256), lds, s, x,
+                           h->pq_fwp, mb, L, Q, pl);
+    } else {
+        hipLaunchKernelGGL(pqmf_forward_generic_kernel, dim3((unsigned)cdivll((long long)L, 256), B),
+                           dim3(256), 0, s, x, h->pq_fw, mb, L, M, K, pl);
+    }
     AFTER_HIP_CHECK(hipGetLastError());
     return AFTER_OK;
 }
@@ -460,9 +536,15 @@ int pqmf_inverse(after_ae* h, hipStream_t s, const float* y, float* audio, int B
     const int M = h->M, K = h->pq_ik;
     const int pl = h->causal ? K - 1 : (K - 1) / 2;
     if (M == 16) {
-        const size_t lds = (size_t)M * (256 + K) * sizeof(float);
-        hipLaunchKernelGGL(pqmf_inverse_kernel<16>, dim3(cdiv(Tm, 256), B), dim3(256), lds, s, y,
-                           h->pq_iw, audio, Tm, K, pl, gated, ychan);
+        const size_t lds = ((size_t)M * K * M + (size_t)M * (256 + K)) * sizeof(float);
+        static bool attr = false;
+        if (!attr) {
+            AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pqmf_inverse_kernel<16>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr = true;
+        }
+        hipLaunchKernelGGL(pqmf_inverse_kernel<16>, dim3(cdiv(Tm, 256), B), dim3(256), lds, s, y, h->pq_iwp,
+                           audio, Tm, K, pl, gated, ychan);
     } else {
         hipLaunchKernelGGL(pqmf_inverse_generic_kernel, dim3((unsigned)cdivll((long long)Tm * M, 256), B),
                            dim3(256), 0, s, y, h->pq_iw, audio, Tm, M, K, pl, gated, ychan);
@@ -548,6 +630,14 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
         }
         AE_TRY(copy_vec(h, &h->pq_fw, fw, h->M * h->pq_fk));
         AE_TRY(copy_vec(h, &h->pq_iw, iw, h->M * h->M * h->pq_ik));
+        const int Q = (h->pq_fk + h->M - 1) / h->M;
+        h->pq_fwp = h->wa.take<float>((size_t)h->M * Q * h->M);
+        h->pq_iwp = h->wa.take<float>((size_t)h->M * h->pq_ik * h->M);
+        if (!h->pq_fwp || !h->pq_iwp) return fail(AFTER_E_NOMEM);
+        const int nmax = h->M * h->M * (Q > h->pq_ik ? Q : h->pq_ik);
+        hipLaunchKernelGGL(pqmf_relayout_kernel, dim3(cdiv(nmax, 256)), dim3(256), 0, 0, h->pq_fw,
+                           h->pq_iw, h->pq_fwp, h->pq_iwp, h->M, h->pq_fk, Q, h->pq_ik);
+        if (hipGetLastError() != hipSuccess) return fail(AFTER_E_HIP);
     }
     // encoder (SimpleNetsStream.py:400-459)
     AE_TRY(load_resblock(h, cur, h->enc_stem, h->M, C0 * cfg->multipliers[0], k, 1));
