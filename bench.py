@@ -136,11 +136,19 @@ def main():
         torch.cuda.synchronize()
         ms, launches, flops = model.net.gemm_time()
         model.net.profile(False)
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r1_pmc_hbm_base_b1.json")
+        if args.config == "base" and args.batch_per_gpu == 1 and os.path.exists(pmc):
+            # not measurable live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+            # command (scripts/pmc_summary.py: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch,
+            # Infinity-Cache hits included), averaged over the GEMM launches
+            traffic = json.load(open(pmc)).get("gemm_f32_mean_bytes_per_launch")
         if launches:
             ach = flops / (ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_16x16x4_f32)",
                     "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "bytes per launch (PMC profile, see profiles/r1_pmc_hbm_base_b1.json)",
                     "launches": int(launches), "avg_launch_us": round(ms * 1e3 / launches, 2),
                     "flops_per_launch": round(flops / launches)}
 
