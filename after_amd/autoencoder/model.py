@@ -281,10 +281,30 @@ class AutoEncoder(nn.Module):
         _lib.check(rc, "after_ae_create")
         self._handle = out
         self._cap = cap
+        if getattr(self, "_streaming", False):  # a re-created handle starts a fresh stream
+            _lib.check(L.after_ae_enable_streaming(out, 1), "after_ae_enable_streaming")
         return out
 
     def reserve(self, batch: int, samples: int):
         self._ensure(batch, samples)
+
+    # ------------------------------------------------------------ streaming (nn~ / real time)
+    def enable_streaming(self, batch: int, chunk_samples: int, enable: bool = True):
+        """`cc.use_cached_conv(True)` twin of the causal codec (export_autoencoder.py:293-303):
+        encode / decode become stateful over consecutive chunks of `batch` streams.  Only the
+        causal, GroupNorm-free configuration streams (baseAE.gin:32-33,49)."""
+        h = self._ensure(batch, chunk_samples)
+        _lib.check(_lib.lib().after_ae_enable_streaming(h, int(enable)), "after_ae_enable_streaming")
+        self._streaming = bool(enable)
+
+    def reset_state(self):
+        """Start of a new stream: zero every conv / PQMF context."""
+        if self._handle is None:
+            raise RuntimeError("enable_streaming first")
+        dev = next(self.parameters()).device
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().after_ae_reset_state(self._handle, _lib.current_stream(dev)),
+                       "after_ae_reset_state")
 
     # ------------------------------------------------------------ reference surface
     @torch.no_grad()

@@ -30,7 +30,8 @@ template <int M>
 __global__ __launch_bounds__(256) void pqmf_forward_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ wp,
                                                            float* __restrict__ mb, int L, int Q,
-                                                           int pl) {
+                                                           int pl,
+                                                           const float* __restrict__ state) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int ldp = PQ_BT + Q + 1;
     float* ws = sm;                // [M][Q][M] taps, read as wave-uniform (broadcast) float4s
@@ -43,7 +44,10 @@ __global__ __launch_bounds__(256) void pqmf_forward_kernel(const float* __restri
     for (int idx = threadIdx.x; idx < M * (PQ_BT + Q); idx += 256) {
         const int m = idx / M, r = idx - m * M;  // consecutive threads read consecutive samples
         const long long s = (long long)(n0 + m) * M + r - pl;
-        xp[r * ldp + m] = (s >= 0 && s < L) ? xb[s] : 0.f;
+        float v = 0.f;
+        if (s >= 0 && s < L) v = xb[s];
+        else if (s < 0 && state) v = state[(size_t)b * pl + (pl + s)];  // streaming: pl = K - 1
+        xp[r * ldp + m] = v;
     }
     __syncthreads();
     float acc[M];
@@ -79,7 +83,8 @@ __global__ __launch_bounds__(256) void pqmf_forward_kernel(const float* __restri
 __global__ __launch_bounds__(256) void pqmf_forward_generic_kernel(const float* __restrict__ x,
                                                                    const float* __restrict__ w,
                                                                    float* __restrict__ mb, int L, int M,
-                                                                   int K, int pl) {
+                                                                   int K, int pl,
+                                                                   const float* __restrict__ state) {
     const int Tm = L / M;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
@@ -90,6 +95,7 @@ __global__ __launch_bounds__(256) void pqmf_forward_generic_kernel(const float* 
     for (int k = 0; k < K; ++k) {
         const long long s = (long long)n * M + k - pl;
         if (s >= 0 && s < L) acc += w[(size_t)c * K + k] * xb[s];
+        else if (s < 0 && state) acc += w[(size_t)c * K + k] * state[(size_t)b * pl + (pl + s)];
     }
     mb[((size_t)b * M + c) * Tm + n] = ((c & 1) && !(n & 1)) ? -acc : acc;
 }
@@ -104,7 +110,8 @@ template <int M>
 __global__ __launch_bounds__(256) void pqmf_inverse_kernel(const float* __restrict__ y,
                                                            const float* __restrict__ wi,
                                                            float* __restrict__ audio, int Tm,
-                                                           int K, int pl, int gated, int ychan) {
+                                                           int K, int pl, int gated, int ychan,
+                                                           const float* __restrict__ zstate) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int ldz = 256 + K;
     float* ws = sm;              // [M][K][M] taps (broadcast float4 reads)
@@ -121,6 +128,8 @@ __global__ __launch_bounds__(256) void pqmf_inverse_kernel(const float* __restri
             v = yb[(size_t)c * Tm + t];
             if (gated) v *= 1.0f / (1.0f + expf(-yb[(size_t)(M + c) * Tm + t]));
             if ((c & 1) && !(t & 1)) v = -v;
+        } else if (t < 0 && zstate) {  // streaming: gated, sign-flipped frames of the last chunk
+            v = zstate[((size_t)b * M + c) * pl + (pl + t)];
         }
         zs[idx] = v;
     }
@@ -175,7 +184,8 @@ __global__ __launch_bounds__(256) void pqmf_inverse_generic_kernel(const float* 
                                                                    const float* __restrict__ w,
                                                                    float* __restrict__ audio,
                                                                    int Tm, int M, int K, int pl,
-                                                                   int gated, int ychan) {
+                                                                   int gated, int ychan,
+                                                                   const float* __restrict__ zstate) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
     if (idx >= (size_t)Tm * M) return;
@@ -185,13 +195,32 @@ __global__ __launch_bounds__(256) void pqmf_inverse_generic_kernel(const float* 
     for (int c = 0; c < M; ++c)
         for (int k = 0; k < K; ++k) {
             const int tt = t + k - pl;
-            if (tt < 0 || tt >= Tm) continue;
-            float v = yb[(size_t)c * Tm + tt];
-            if (gated) v *= 1.0f / (1.0f + expf(-yb[(size_t)(M + c) * Tm + tt]));
-            if ((c & 1) && !(tt & 1)) v = -v;
+            if (tt >= Tm || (tt < 0 && !zstate)) continue;
+            float v;
+            if (tt < 0) {
+                v = zstate[((size_t)b * M + c) * pl + (pl + tt)];
+            } else {
+                v = yb[(size_t)c * Tm + tt];
+                if (gated) v *= 1.0f / (1.0f + expf(-yb[(size_t)(M + c) * Tm + tt]));
+                if ((c & 1) && !(tt & 1)) v = -v;
+            }
             acc += w[((size_t)(M - 1 - m) * M + c) * K + k] * v;
         }
     audio[(size_t)b * Tm * M + idx] = acc * M;
+}
+
+// streaming synthesis state: the last S = K - 1 gated, sign-flipped band frames of the chunk
+__global__ void pqmf_istate_kernel(const float* __restrict__ y, float* __restrict__ zstate, int Tm,
+                                   int M, int S, int gated, int ychan, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int j = idx % S, c = (idx / S) % M, b = idx / (S * M);
+    const int t = Tm - S + j;
+    const float* yb = y + (size_t)b * ychan * Tm;
+    float v = yb[(size_t)c * Tm + t];
+    if (gated) v *= 1.0f / (1.0f + expf(-yb[(size_t)(M + c) * Tm + t]));
+    if ((c & 1) && !(t & 1)) v = -v;
+    zstate[idx] = v;
 }
 
 }  // namespace
@@ -222,6 +251,8 @@ struct ResampleW {
     float *alpha = nullptr, *invb = nullptr, *w = nullptr, *bias = nullptr;
     int cin = 0, cout = 0, f = 1;
     DmaConv d;
+    float* w_stream = nullptr;  // ConvTranspose1d packed with padding 0 (overlap-add form)
+    DmaConv d_stream;
 };
 struct PlainConvW {
     float *w = nullptr, *bias = nullptr;
@@ -264,6 +295,13 @@ struct after_ae {
     double* stats_ring = nullptr; // [kStatSlots][max_batch][8][2]
     int stat_slot = 0;
     Arena wd;                     // repacked weights
+    // streaming (cached-conv semantics): left-context state per conv, in traversal order
+    bool streaming = false;
+    Arena sa;
+    float *enc_state = nullptr, *dec_state = nullptr;  // [slot][max_batch][cmax][HALO]
+    float *pq_fstate = nullptr, *pq_istate = nullptr;  // [B][Kf-1] audio, [B][M][Ki-1] bands
+    int state_slot = 0;
+    size_t slot_elems = 0;
 };
 constexpr int kStatSlots = 96;
 
@@ -440,12 +478,14 @@ double* next_stats(after_ae* h, int B) {
 int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const double* stats_in,
             const float* gamma, const float* beta, const float* alpha, const float* invb, int act,
             const float* bias, const float* res, float* y, int B, int Tin, int Tout, int Nn,
-            bool want_stats, double** stats_out) {
+            bool want_stats, double** stats_out, float* state_base = nullptr) {
     const int cin = d.in.Cin, cout = d.in.Cout;
     AFTER_REQUIRE((size_t)B * cin * conv_dma_row(Tin) <= h->xp_elems, AFTER_E_CAPACITY,
                   "autoencoder: activation scratch too small");
+    float* state = nullptr;
+    if (h->streaming && state_base) state = state_base + (size_t)(h->state_slot++) * h->slot_elems;
     AFTER_TRY(launch_act_pad(x, h->xp, stats_in, gamma, beta, alpha, invb, act, B, cin, Tin,
-                             cin < 8 ? cin : 8, s));
+                             cin < 8 ? cin : 8, s, state));
     ConvDmaRun r;
     r.xp = h->xp;
     r.w = d.w;
@@ -468,23 +508,23 @@ int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const 
 // ConvBlock1d on the DMA path
 int run_convblock2(after_ae* h, hipStream_t s, const ConvBlockW& cb, const float* x,
                    const double* stats_x, float* y, const float* res, int B, int T, bool want_stats,
-                   double** stats_y) {
+                   double** stats_y, float* sb = nullptr) {
     return run_dma(h, s, cb.d, x, h->norm ? stats_x : nullptr, cb.gn_w, cb.gn_b, cb.alpha, cb.invb,
-                   ACT_SNAKE, cb.bias, res, y, B, T, T, T, want_stats, stats_y);
+                   ACT_SNAKE, cb.bias, res, y, B, T, T, T, want_stats, stats_y, sb);
 }
 
 // ResnetBlock1d on the DMA path; *stats carries the accumulators of the block input in and of
 // the block output out
 int run_resblock2(after_ae* h, hipStream_t s, const ResBlockW& rb, const float* bx, float* bt,
-                  float* by, int B, int T, double** stats) {
+                  float* by, int B, int T, double** stats, float* sb = nullptr) {
     const float* res = bx;
-    if (rb.to_w) {
+    if (rb.to_w) {  // 1x1 shortcut: no temporal context, no state
         AFTER_TRY(run_dma(h, s, rb.to_d, bx, nullptr, nullptr, nullptr, nullptr, nullptr, ACT_NONE,
                           rb.to_b, nullptr, by, B, T, T, T, false, nullptr));
         res = by;
     }
     double* st1 = nullptr;
-    AFTER_TRY(run_convblock2(h, s, rb.cb0, bx, *stats, bt, nullptr, B, T, true, &st1));
+    AFTER_TRY(run_convblock2(h, s, rb.cb0, bx, *stats, bt, nullptr, B, T, true, &st1, sb));
     double* st2 = nullptr;
     AFTER_TRY(run_convblock2(h, s, rb.cb1, bt, st1, by, res, B, T, true, &st2));
     *stats = st2;
@@ -493,6 +533,7 @@ int run_resblock2(after_ae* h, hipStream_t s, const ResBlockW& rb, const float* 
 
 int begin_pass(after_ae* h, hipStream_t s) {
     h->stat_slot = 0;
+    h->state_slot = 0;
     if (h->norm)
         AFTER_HIP_CHECK(hipMemsetAsync(h->stats_ring, 0, (size_t)kStatSlots * h->max_batch * 16 * sizeof(double), s));
     return AFTER_OK;
@@ -509,7 +550,8 @@ int check_ae(after_ae* h, int B, long long samples) {
     return AFTER_OK;
 }
 
-int pqmf_forward(after_ae* h, hipStream_t s, const float* x, float* mb, int B, int L) {
+int pqmf_forward(after_ae* h, hipStream_t s, const float* x, float* mb, int B, int L,
+                 float* state = nullptr) {
     const int M = h->M, K = h->pq_fk;
     const int Q = (K + M - 1) / M;
     const int pl = h->causal ? K - 1 : (K - 1) / 2;
@@ -522,17 +564,25 @@ int pqmf_forward(after_ae* h, hipStream_t s, const float* x, float* mb, int B, i
             attr = true;
         }
         hipLaunchKernelGGL(pqmf_forward_kernel<16>, dim3(cdiv(L / M, PQ_BT), B), dim3(256), lds, s, x,
-                           h->pq_fwp, mb, L, Q, pl);
+                           h->pq_fwp, mb, L, Q, pl, state);
     } else {
         hipLaunchKernelGGL(pqmf_forward_generic_kernel, dim3((unsigned)cdivll((long long)L, 256), B),
-                           dim3(256), 0, s, x, h->pq_fw, mb, L, M, K, pl);
+                           dim3(256), 0, s, x, h->pq_fw, mb, L, M, K, pl, state);
     }
     AFTER_HIP_CHECK(hipGetLastError());
+    if (state) {  // keep the last K - 1 input samples of every clip
+        const int S = K - 1;
+        AFTER_REQUIRE(L >= S && (L / M) % 2 == 0, AFTER_E_INVALID,
+                      "pqmf streaming: chunk of %d samples too short / odd frame count", L);
+        AFTER_HIP_CHECK(hipMemcpy2DAsync(state, (size_t)S * sizeof(float), x + (L - S),
+                                         (size_t)L * sizeof(float), (size_t)S * sizeof(float), B,
+                                         hipMemcpyDeviceToDevice, s));
+    }
     return AFTER_OK;
 }
 
 int pqmf_inverse(after_ae* h, hipStream_t s, const float* y, float* audio, int B, int Tm, int gated,
-                 int ychan) {
+                 int ychan, float* zstate = nullptr) {
     const int M = h->M, K = h->pq_ik;
     const int pl = h->causal ? K - 1 : (K - 1) / 2;
     if (M == 16) {
@@ -544,12 +594,21 @@ int pqmf_inverse(after_ae* h, hipStream_t s, const float* y, float* audio, int B
             attr = true;
         }
         hipLaunchKernelGGL(pqmf_inverse_kernel<16>, dim3(cdiv(Tm, 256), B), dim3(256), lds, s, y, h->pq_iwp,
-                           audio, Tm, K, pl, gated, ychan);
+                           audio, Tm, K, pl, gated, ychan, zstate);
     } else {
         hipLaunchKernelGGL(pqmf_inverse_generic_kernel, dim3((unsigned)cdivll((long long)Tm * M, 256), B),
-                           dim3(256), 0, s, y, h->pq_iw, audio, Tm, M, K, pl, gated, ychan);
+                           dim3(256), 0, s, y, h->pq_iw, audio, Tm, M, K, pl, gated, ychan, zstate);
     }
     AFTER_HIP_CHECK(hipGetLastError());
+    if (zstate) {
+        const int S = K - 1;
+        AFTER_REQUIRE(Tm >= S && Tm % 2 == 0, AFTER_E_INVALID,
+                      "pqmf streaming: chunk of %d frames too short / odd", Tm);
+        const int total = B * M * S;
+        hipLaunchKernelGGL(pqmf_istate_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, y, zstate, Tm, M, S,
+                           gated, ychan, total);
+        AFTER_HIP_CHECK(hipGetLastError());
+    }
     return AFTER_OK;
 }
 
@@ -602,7 +661,7 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
         for (int i = 0; i < n; ++i) {
             c = C0 * cfg->dec_multipliers[i];
             const int cn = C0 * cfg->dec_multipliers[i + 1];
-            wf += cbsz(c, cn, 2 * cfg->factors[n - 1 - i]) + nd * (cbsz(cn, cn, k) + cbsz(cn, cn, 1));
+            wf += 2 * cbsz(c, cn, 2 * cfg->factors[n - 1 - i]) + nd * (cbsz(cn, cn, k) + cbsz(cn, cn, 1));
         }
         c = C0 * cfg->dec_multipliers[n];
         wf += cbsz(c, out_ch, k) + cbsz(out_ch, out_ch, 1);
@@ -692,6 +751,11 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
             u.w = h->wa.take<float>((size_t)u.f * cn * 2 * pad16(c));
             if (!u.w) return fail(AFTER_E_NOMEM);
             AE_TRY(pack_convT_weight(v, g, u.w, c, cn, u.f, pad16(c), 0));
+            if (h->causal && !h->norm) {  // streaming twin: padding 0 (cached_conv overlap-add)
+                u.w_stream = h->wa.take<float>((size_t)u.f * cn * 2 * pad16(c));
+                if (!u.w_stream) return fail(AFTER_E_NOMEM);
+                AE_TRY(pack_convT_weight(v, g, u.w_stream, c, cn, u.f, pad16(c), 0, 0));
+            }
             AE_TRY(copy_vec(h, &u.bias, b, cn));
         }
         h->dec_res[i].resize(nd);
@@ -713,7 +777,7 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
         h->use_dma = !(e && atoi(e) != 0);
     }
     if (h->use_dma) {
-        AE_TRY(h->wd.init((size_t)(wf * 1.8) * sizeof(float) + (8 << 20)));
+        AE_TRY(h->wd.init((size_t)(wf * 2.0) * sizeof(float) + (8 << 20)));
         const size_t Tm = h->max_samples / h->M;
         auto plan_conv = [&](DmaConv& d, const float* packed, int cin, int cout, int kk, int dil,
                              size_t T) -> int {
@@ -753,6 +817,13 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
                 ooff[r] = r;
             }
             AE_TRY(make_dma(h, u.d, u.w, u.cin, u.cout, 2, u.f, 1, u.f, toff, ooff, (int)T));
+            if (u.w_stream) {
+                for (int r = 0; r < u.f; ++r) {
+                    toff[r][0] = -1;
+                    toff[r][1] = 0;
+                }
+                AE_TRY(make_dma(h, u.d_stream, u.w_stream, u.cin, u.cout, 2, u.f, 1, u.f, toff, ooff, (int)T));
+            }
             T *= u.f;
             for (int j = 0; j < nd; ++j) AE_TRY(plan_res(h->dec_res[i][j], T));
         }
@@ -837,6 +908,7 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
 
 extern "C" void after_ae_destroy(after_ae* h) {
     if (!h) return;
+    h->sa.release();
     h->wd.release();
     h->wa.release();
     h->ws.release();
@@ -844,6 +916,49 @@ extern "C" void after_ae_destroy(after_ae* h) {
 }
 
 extern "C" int after_ae_ratio(const after_ae* h) { return h ? h->ratio : 0; }
+
+// ---- streaming: cached_conv semantics for the causal, norm-free codec
+// (export_autoencoder.py:293-303: `cc.use_cached_conv(True)` twin of the causal model).
+extern "C" int after_ae_reset_state(after_ae* h, void* stream) {
+    AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
+    AFTER_REQUIRE(h->sa.base, AFTER_E_INVALID, "autoencoder: streaming was never enabled");
+    AFTER_HIP_CHECK(hipMemsetAsync(h->sa.base, 0, h->sa.off, (hipStream_t)stream));
+    return AFTER_OK;
+}
+
+extern "C" int after_ae_enable_streaming(after_ae* h, int enable) {
+    AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
+    if (!enable) {
+        h->streaming = false;
+        return AFTER_OK;
+    }
+    AFTER_REQUIRE(h->causal && !h->norm, AFTER_E_INVALID,
+                  "autoencoder: streaming needs the causal, GroupNorm-free codec "
+                  "(baseAE.gin:32-33,49)");
+    AFTER_REQUIRE(h->use_dma, AFTER_E_INVALID, "autoencoder: streaming needs the DMA conv path");
+    const after_ae_cfg& c = h->cfg;
+    AFTER_REQUIRE((c.kernel_size - 1) * c.dilations[c.n_dilations - 1] <= conv_dma_halo(),
+                  AFTER_E_INVALID, "autoencoder: receptive field exceeds the streaming halo");
+    for (int j = 0; j < c.n_dilations; ++j)
+        AFTER_REQUIRE((c.kernel_size - 1) * c.dilations[j] <= conv_dma_halo(), AFTER_E_INVALID,
+                      "autoencoder: receptive field exceeds the streaming halo");
+    if (!h->sa.base) {
+        const int n = c.n_stages, nd = c.n_dilations;
+        const int enc_slots = 1 + n * nd + n + 1, dec_slots = 1 + n + n * nd + 1;
+        h->slot_elems = (size_t)h->max_batch * h->cmax * conv_dma_halo();
+        const size_t fs = (size_t)h->max_batch * (h->pq_fk - 1);
+        const size_t is = (size_t)h->max_batch * h->M * (h->pq_ik - 1);
+        AFTER_TRY(h->sa.init(((enc_slots + dec_slots) * h->slot_elems + fs + is) * sizeof(float) + 8192));
+        h->enc_state = h->sa.take<float>(enc_slots * h->slot_elems);
+        h->dec_state = h->sa.take<float>(dec_slots * h->slot_elems);
+        h->pq_fstate = h->sa.take<float>(fs);
+        h->pq_istate = h->sa.take<float>(is);
+        AFTER_REQUIRE(h->pq_istate, AFTER_E_NOMEM, "autoencoder: streaming state allocation failed");
+        AFTER_HIP_CHECK(hipMemset(h->sa.base, 0, h->sa.off));
+    }
+    h->streaming = true;
+    return AFTER_OK;
+}
 
 extern "C" int after_ae_pqmf_forward(after_ae* h, const float* x, float* mb, int B, int L,
                                      void* stream) {
@@ -866,26 +981,27 @@ extern "C" int after_ae_encode(after_ae* h, const float* x, float* z, int B, int
     const int n = c.n_stages, nd = c.n_dilations;
     int T = L / h->M;
     float *b0 = h->buf[0], *b1 = h->buf[1], *b2 = h->buf[2];
-    AFTER_TRY(pqmf_forward(h, s, x, b0, B, L));
+    AFTER_TRY(pqmf_forward(h, s, x, b0, B, L, h->streaming ? h->pq_fstate : nullptr));
     if (h->use_dma) {
         AFTER_TRY(begin_pass(h, s));
+        float* sb = h->streaming ? h->enc_state : nullptr;
         double* st = nullptr;
         if (h->norm) {  // the first GroupNorm sees the PQMF output: its producer is not a conv
             st = next_stats(h, B);
             AFTER_TRY(launch_stats_accum(b0, st, B, h->M, T, h->M < 8 ? h->M : 8, s));
         }
-        AFTER_TRY(run_resblock2(h, s, h->enc_stem, b0, b1, b2, B, T, &st));
+        AFTER_TRY(run_resblock2(h, s, h->enc_stem, b0, b1, b2, B, T, &st, sb));
         float *cur = b2, *t1 = b0, *t2 = b1;
         for (int i = 0; i < n; ++i) {
             for (int j = 0; j < nd; ++j) {
-                AFTER_TRY(run_resblock2(h, s, h->enc_res[i][j], cur, t1, t2, B, T, &st));
+                AFTER_TRY(run_resblock2(h, s, h->enc_res[i][j], cur, t1, t2, B, T, &st, sb));
                 float* o = cur;
                 cur = t2;
                 t2 = o;
             }
             const ResampleW& d = h->enc_down[i];
             AFTER_TRY(run_dma(h, s, d.d, cur, nullptr, nullptr, nullptr, d.alpha, d.invb, ACT_SNAKE, d.bias,
-                              nullptr, t1, B, T, T / d.f, T / d.f, true, &st));
+                              nullptr, t1, B, T, T / d.f, T / d.f, true, &st, sb));
             float* o = cur;
             cur = t1;
             t1 = o;
@@ -893,7 +1009,7 @@ extern "C" int after_ae_encode(after_ae* h, const float* x, float* z, int B, int
         }
         return run_dma(h, s, h->enc_tail.d, cur, nullptr, nullptr, nullptr, h->enc_tail_alpha,
                        h->enc_tail_invb, ACT_SNAKE, h->enc_tail.bias, nullptr, z, B, T, T, T, false,
-                       nullptr);
+                       nullptr, sb);
     }
     AFTER_TRY(run_resblock(h, s, h->enc_stem, b0, b1, b2, B, T));
     float *cur = b2, *t1 = b0, *t2 = b1;
@@ -952,29 +1068,31 @@ extern "C" int after_ae_decode(after_ae* h, const float* z, float* x, int B, int
     float *cur = h->buf[0], *t1 = h->buf[1], *t2 = h->buf[2];
     if (h->use_dma) {
         AFTER_TRY(begin_pass(h, s));
+        float* sb = h->streaming ? h->dec_state : nullptr;
         double* st = nullptr;
         AFTER_TRY(run_dma(h, s, h->dec_head.d, z, nullptr, nullptr, nullptr, nullptr, nullptr, ACT_NONE,
-                          h->dec_head.bias, nullptr, cur, B, T, T, T, false, nullptr));
+                          h->dec_head.bias, nullptr, cur, B, T, T, T, false, nullptr, sb));
         for (int i = 0; i < n; ++i) {
             const ResampleW& u = h->dec_up[i];
-            AFTER_TRY(run_dma(h, s, u.d, cur, nullptr, nullptr, nullptr, u.alpha, u.invb, ACT_SNAKE, u.bias,
-                              nullptr, t1, B, T, T * u.f, T, true, &st));
+            AFTER_TRY(run_dma(h, s, h->streaming ? u.d_stream : u.d, cur, nullptr, nullptr, nullptr, u.alpha,
+                              u.invb, ACT_SNAKE, u.bias, nullptr, t1, B, T, T * u.f, T, true, &st, sb));
             float* o = cur;
             cur = t1;
             t1 = o;
             T *= u.f;
             for (int j = 0; j < nd; ++j) {
-                AFTER_TRY(run_resblock2(h, s, h->dec_res[i][j], cur, t1, t2, B, T, &st));
+                AFTER_TRY(run_resblock2(h, s, h->dec_res[i][j], cur, t1, t2, B, T, &st, sb));
                 o = cur;
                 cur = t2;
                 t2 = o;
             }
         }
         double* st1 = nullptr;
-        AFTER_TRY(run_convblock2(h, s, h->synth0, cur, st, t1, nullptr, B, T, true, &st1));
+        AFTER_TRY(run_convblock2(h, s, h->synth0, cur, st, t1, nullptr, B, T, true, &st1, sb));
         AFTER_TRY(run_convblock2(h, s, h->synth1, t1, st1, t2, nullptr, B, T, false, nullptr));
         const int och = c.use_loudness ? 2 * h->M : h->M;
-        return pqmf_inverse(h, s, t2, x, B, T, c.use_loudness, och);
+        return pqmf_inverse(h, s, t2, x, B, T, c.use_loudness, och,
+                            h->streaming ? h->pq_istate : nullptr);
     }
     {
         ConvArgs a;

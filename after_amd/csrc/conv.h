@@ -73,8 +73,10 @@ int launch_bn_affine(const float* w, const float* b, const float* rm, const floa
 // g == nullptr: plain weights (no weight norm).
 int pack_conv_weight(const float* v, const float* g, float* out, int Cout, int Cin, int k,
                      int Cin_pad, hipStream_t s);
+// pad: the ConvTranspose1d `padding` (f/2 offline; 0 for the streaming form, where phase r
+// uses x[n-1], x[n] only: cached_conv's overlap-add transposed conv)
 int pack_convT_weight(const float* v, const float* g, float* out, int Cin, int Cout, int f,
-                      int Cin_pad, hipStream_t s);
+                      int Cin_pad, hipStream_t s, int pad = -1);
 int snake_inv_beta(const float* beta, float* out, int C, hipStream_t s);
 
 // ---- "activate once, convolve by DMA" path (conv_dma.hip)
@@ -104,9 +106,12 @@ int conv_dma_repack(const float* packed, float* out, const ConvDmaPlanIn& in, co
                     hipStream_t s);
 int launch_conv_dma(const ConvDmaRun& r, const ConvDmaPlanIn& in, const ConvDmaPlan& p, hipStream_t s);
 // y[b,c,halo+t] = act(GroupNorm-affine(x)) with zeroed halo; stats = producer's accumulators
+// Without stats, gamma / beta (if given) are a plain per-channel affine (BatchNorm eval).
+// state (streaming): [B][C][conv_dma_halo()] activated samples preceding this chunk; used as
+// the left halo instead of zeros and replaced by the chunk's last samples afterwards.
 int launch_act_pad(const float* x, float* y, const double* stats, const float* gamma,
                    const float* beta, const float* act_a, const float* act_b, int act, int B, int C,
-                   int T, int G, hipStream_t s);
+                   int T, int G, hipStream_t s, float* state = nullptr);
 // stats[b][g] += (sum, sum of squares) of x[b, group g, :]   (for producers that are not convs)
 int launch_stats_accum(const float* x, double* stats, int B, int C, int T, int G, hipStream_t s);
 

@@ -416,7 +416,7 @@ __global__ void pack_conv_kernel(const float* v, const float* scale, float* out,
 //   y[co, n*f + r] = sum_ci w[ci, co, phi] x[ci, n + c] + w[ci, co, phi + f] x[ci, n + c - 1]
 //   with q = r + p, phi = q % f, c = q / f.      out[r][co][tap][ci]: tap 0 <-> x[n + c - 1]
 __global__ void pack_convT_kernel(const float* v, const float* scale, float* out, int Cin, int Cout,
-                                  int f, int Cin_pad) {
+                                  int f, int Cin_pad, int pad) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t total = (size_t)f * Cout * 2 * Cin_pad;
     if (idx >= total) return;
@@ -424,7 +424,7 @@ __global__ void pack_convT_kernel(const float* v, const float* scale, float* out
     const int tap = (idx / Cin_pad) % 2;
     const int co = (idx / ((size_t)Cin_pad * 2)) % Cout;
     const int r = idx / ((size_t)Cin_pad * 2 * Cout);
-    const int q = r + f / 2, phi = q % f;
+    const int q = r + pad, phi = q % f;
     const int kidx = tap == 0 ? phi + f : phi;
     float val = 0.f;
     if (ci < Cin) val = v[((size_t)ci * Cout + co) * (2 * f) + kidx] * (scale ? scale[ci] : 1.f);
@@ -501,12 +501,13 @@ int pack_conv_weight(const float* v, const float* g, float* out, int Cout, int C
 }
 
 int pack_convT_weight(const float* v, const float* g, float* out, int Cin, int Cout, int f,
-                      int Cin_pad, hipStream_t s) {
+                      int Cin_pad, hipStream_t s, int pad) {
+    if (pad < 0) pad = f / 2;
     float* sc = nullptr;
     AFTER_TRY(wn_scale(v, g, &sc, Cin, Cout * 2 * f, s));
     const size_t total = (size_t)f * Cout * 2 * Cin_pad;
     hipLaunchKernelGGL(pack_convT_kernel, dim3((unsigned)cdivll(total, 256)), dim3(256), 0, s, v, sc,
-                       out, Cin, Cout, f, Cin_pad);
+                       out, Cin, Cout, f, Cin_pad, pad);
     AFTER_HIP_CHECK(hipGetLastError());
     AFTER_HIP_CHECK(hipStreamSynchronize(s));
     if (sc) (void)hipFree(sc);

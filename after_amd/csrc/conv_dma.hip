@@ -50,10 +50,11 @@ struct ActArgs {
     const float* x;
     float* y;
     const double* stats;  // [B][G][2] or nullptr
-    const float* gamma;
-    const float* beta;
+    const float* gamma;   // with stats: GroupNorm weight; without: per-channel scale (or nullptr)
+    const float* beta;    // with stats: GroupNorm bias;   without: per-channel shift
     const float* act_a;
     const float* act_b;
+    const float* state;   // streaming: [B][C][HALO] activated samples preceding this chunk, or nullptr
     int act, C, T, Tp, G;
     float eps;
 };
@@ -73,6 +74,9 @@ __global__ __launch_bounds__(256) void act_pad_kernel(ActArgs a) {
         const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
         sc = rstd * a.gamma[c];
         sh = a.beta[c] - (float)mean * sc;
+    } else if (a.gamma) {  // BatchNorm(eval) folded to a per-channel affine
+        sc = a.gamma[c];
+        sh = a.beta[c];
     }
     const float pa = a.act_a ? a.act_a[c] : 0.f, pb = a.act_b ? a.act_b[c] : 0.f;
     // positions in the padded row, 4 per thread
@@ -85,9 +89,21 @@ __global__ __launch_bounds__(256) void act_pad_kernel(ActArgs a) {
         const int t = p0 + k - HALO;
         float v = 0.f;
         if (t >= 0 && t < a.T) v = act_apply(xr[t] * sc + sh, a.act, pa, pb);
+        else if (t < 0 && a.state) v = a.state[((size_t)b * a.C + c) * HALO + (HALO + t)];
         op[k] = v;
     }
     *reinterpret_cast<float4*>(yr + p0) = o;
+}
+
+// streaming: state[b][c][j] = ypad[b][c][T + j], j < HALO  (the last HALO activated samples,
+// old context included when the chunk is shorter than the halo)
+__global__ void state_update_kernel(const float* __restrict__ yp, float* __restrict__ state, int C,
+                                    int T, int Tp, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int j = idx % HALO;
+    const int bc = idx / HALO;
+    state[idx] = yp[(size_t)bc * Tp + T + j];
 }
 
 struct ConvDmaGeom {
@@ -344,11 +360,17 @@ int conv_dma_row(int T) { return ((T + 2 * HALO + 256 + 3) & ~3); }
 
 int launch_act_pad(const float* x, float* y, const double* stats, const float* gamma,
                    const float* beta, const float* act_a, const float* act_b, int act, int B, int C,
-                   int T, int G, hipStream_t s) {
-    ActArgs a{x, y, stats, gamma, beta, act_a, act_b, act, C, T, conv_dma_row(T), G, 1e-5f};
+                   int T, int G, hipStream_t s, float* state) {
+    ActArgs a{x, y, stats, gamma, beta, act_a, act_b, state, act, C, T, conv_dma_row(T), G, 1e-5f};
     dim3 grid(cdiv(a.Tp, 1024), C, B);
     hipLaunchKernelGGL(act_pad_kernel, grid, dim3(256), 0, s, a);
     AFTER_HIP_CHECK(hipGetLastError());
+    if (state) {
+        const int total = B * C * HALO;
+        hipLaunchKernelGGL(state_update_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, y, state, C, T,
+                           a.Tp, total);
+        AFTER_HIP_CHECK(hipGetLastError());
+    }
     return AFTER_OK;
 }
 

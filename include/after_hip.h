@@ -196,6 +196,20 @@ int after_ae_decode(after_ae* h, const float* z, float* x, int B, int T, void* s
 int after_ae_pqmf_forward(after_ae* h, const float* x, float* mb, int B, int L, void* stream);
 int after_ae_pqmf_inverse(after_ae* h, const float* mb, float* x, int B, int Tm, void* stream);
 
+/* Streaming (real-time) mode of the causal, GroupNorm-free codec: after_ae_encode /
+ * after_ae_decode become stateful and process consecutive chunks of the same B streams.
+ * Every temporal conv keeps its left context (the last (k-1)*dilation activated input
+ * samples), the transposed convs run in their padding-0 overlap-add form, the PQMF banks
+ * keep K-1 samples / frames.  This is `cached_conv` (acids-ircam/cached_conv, the
+ * dependency behind `cc.use_cached_conv(True)`) applied to the causal model:
+ * export_autoencoder.py:293-303, CachedConv1d / CachedConvTranspose1d / CachedPadding1d.
+ * Chunked output == the offline causal model with ConvTranspose1d padding 0 on the
+ * concatenated stream.  Returns AFTER_E_INVALID for a non-causal or GroupNorm codec.
+ * enable = 0 returns to the offline path (state is kept). */
+int after_ae_enable_streaming(after_ae* h, int enable);
+/* zero every streaming state (start of a new stream) */
+int after_ae_reset_state(after_ae* h, void* stream);
+
 /* ------------------------------------------------------- conditioning encoders
  * encoder_time: Encoder1D (after/diffusion/networks/encoder.py:116-322), causal
  * padding through the scoped gin binding (after/diffusion/configs/base.gin:55). */

@@ -131,7 +131,14 @@ def decoder_forward(sd, z, cfg):
         bp = f"{pre}{i + 1}.net."
         x = snake_beta(x, sd[bp + "0.alpha"], sd[bp + "0.beta"])
         w, b = _wn(sd, bp + "1.")
-        x = F.conv_transpose1d(x, w, b, stride=f, padding=f // 2)
+        if cfg.get("stream_convT"):
+            # cached_conv.CachedConvTranspose1d (third-party, absent here): conv_transpose1d with
+            # padding 0, overlap-add of the last `stride` samples into the next chunk, bias after.
+            # On a whole stream that is the padding-0 output truncated to f*T samples.
+            x = F.conv_transpose1d(x, w, None, stride=f, padding=0)[..., :f * x.shape[-1]] \
+                + b[None, :, None]
+        else:
+            x = F.conv_transpose1d(x, w, b, stride=f, padding=f // 2)
         for j, d in enumerate(cfg["dilations"]):
             x = resnet_block(sd, f"{bp}{j + 2}.", x, cfg, d)
     x = resnet_block(sd, "decoder.synth.branches.0.", x, cfg, 1, use_res=False)

@@ -73,3 +73,72 @@ def test_autoencoder_rejects_bad_lengths(hip_device):
         ae.encode(torch.zeros(1, 1, 1000, device=hip_device))
     with pytest.raises(ValueError):
         ae.decode(torch.zeros(1, 3, 4, device=hip_device))
+
+
+# ---------------------------------------------------------------- streaming (cached_conv semantics)
+# cached_conv itself is a third-party dependency absent from the reference tree: the streaming
+# codec is pinned (a) against the oracle's offline causal model with padding-0 transposed convs
+# on the concatenated stream (what CachedConv1d / CachedConvTranspose1d compute by construction)
+# and (b) by chunking invariance.  PARITY UNPINNED against a cached_conv run.
+@pytest.mark.parametrize("B,chunks", [(1, [2048] * 4), (2, [4096, 2048, 6144])])
+def test_streaming_encode_matches_offline_causal(B, chunks, hip_device):
+    fx = Fixture("ae_micro_causal")
+    sd = fx.state_dict()
+    ae, cfg = build("microAE_causal", sd, hip_device)
+    g = torch.Generator().manual_seed(7)
+    x = 0.1 * torch.randn(B, 1, sum(chunks), generator=g)
+    want = oracle.ae_encode(sd, x, cfg)  # causal offline == streaming for plain / strided convs
+    ae.enable_streaming(B, max(chunks))
+    ae.reset_state()
+    outs, pos = [], 0
+    for n in chunks:
+        outs.append(ae.encode(x[..., pos:pos + n].contiguous().to(hip_device))[0].cpu())
+        pos += n
+    z = torch.cat(outs, -1)
+    assert z.shape == want.shape
+    assert max_abs(z, want) < 2e-2 * want.abs().max().item(), rel_l2(z, want)
+    # chunking invariance: one chunk of the whole stream
+    ae.enable_streaming(B, sum(chunks))
+    ae.reset_state()
+    z1 = ae.encode(x.to(hip_device))[0].cpu()
+    assert max_abs(z, z1) < 1e-4 * want.abs().max().item()
+    # leaving streaming mode restores the offline path
+    ae.enable_streaming(B, sum(chunks), enable=False)
+    z0 = ae.encode(x.to(hip_device))[0].cpu()
+    assert max_abs(z0, want) < 2e-2 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("B,chunks", [(1, [1, 1, 1, 1, 1]), (2, [2, 1, 4])])
+def test_streaming_decode_matches_padding0_offline(B, chunks, hip_device):
+    fx = Fixture("ae_micro_causal")
+    sd = fx.state_dict()
+    ae, cfg = build("microAE_causal", sd, hip_device)
+    g = torch.Generator().manual_seed(9)
+    T = sum(chunks)
+    zin = torch.randn(B, cfg["z_channels"], T, generator=g)
+    want = oracle.ae_decode(sd, zin, dict(cfg, stream_convT=True))
+    ae.enable_streaming(B, max(chunks) * ae.ratio)
+    ae.reset_state()
+    outs, pos = [], 0
+    for n in chunks:
+        outs.append(ae.decode(zin[..., pos:pos + n].contiguous().to(hip_device)).cpu())
+        pos += n
+    y = torch.cat(outs, -1)
+    assert y.shape == want.shape
+    assert max_abs(y, want) < 2e-2 * want.abs().max().item(), rel_l2(y, want)
+    ae.enable_streaming(B, T * ae.ratio)
+    ae.reset_state()
+    y1 = ae.decode(zin.to(hip_device)).cpu()
+    assert max_abs(y, y1) < 1e-4 * want.abs().max().item()
+    # reset_state really starts a new stream
+    ae.reset_state()
+    y2 = ae.decode(zin.to(hip_device)).cpu()
+    assert torch.equal(y1, y2)
+
+
+def test_streaming_refused_for_normalised_codec(hip_device):
+    from after_amd._lib import AFTERHipError
+    fx = Fixture("ae_micro")
+    ae, _ = build("microAE", fx.state_dict(), hip_device)
+    with pytest.raises(AFTERHipError):
+        ae.enable_streaming(1, 2048)
