@@ -81,6 +81,8 @@ SIGNATURES = {
                                        POINTER(c_void_p)]),
     "after_encoder1d_destroy": (None, [c_void_p]),
     "after_encoder1d_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "after_encoder1d_enable_streaming": (c_int, [c_void_p, c_int]),
+    "after_encoder1d_reset_state": (c_int, [c_void_p, c_void_p]),
     "after_ecapa_create": (c_int, [POINTER(EcapaCfg), POINTER(c_void_p), c_int, c_int, c_int,
                                    POINTER(c_void_p)]),
     "after_ecapa_destroy": (None, [c_void_p]),

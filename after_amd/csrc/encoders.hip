@@ -1,10 +1,11 @@
 // The once-per-clip conditioning encoders on gfx950:
 //   encoder_time = Encoder1D   (reference after/diffusion/networks/encoder.py:116-322)
 //   encoder      = ECAPATDNN   (reference after/diffusion/networks/ecapa_encoder.py:458-666)
-// Both are stacks of small 1-D convs: they reuse the implicit-GEMM conv kernel of
-// conv.hip (BatchNorm(eval) folded to per-channel affines: prologue affine + SiLU for
-// V2ConvBlock1D, epilogue ReLU + affine for TDNNBlock, reflect padding for ECAPA) and
-// the fp32 MFMA GEMM for the squeeze-excitation / pooling matvecs.
+// Both are stacks of small 1-D convs.  Encoder1D runs on the LDS-DMA conv path of
+// conv_dma.hip (BatchNorm(eval) + SiLU applied once into a haloed row; streaming state).
+// ECAPA reuses the implicit-GEMM conv kernel of conv.hip (epilogue ReLU + BatchNorm affine
+// for TDNNBlock, reflect padding) and the fp32 MFMA GEMM for the squeeze-excitation /
+// pooling matvecs.
 #include <new>
 #include <vector>
 
@@ -160,53 +161,93 @@ size_t conv_floats(int cin, int cout, int k) { return (size_t)cout * k * pad16(c
 using namespace after;
 
 // =================================================================== Encoder1D
+// Every conv runs on the "activate once, convolve by LDS-DMA" path of conv_dma.hip:
+// BatchNorm(eval) + SiLU are applied once into a haloed scratch row, whose left halo is
+// either zeros (offline) or the previous chunk's tail (streaming, cached_conv semantics).
+struct EncConv {
+    ConvW cw;
+    ConvDmaPlanIn in;
+    ConvDmaPlan plan;
+    float* wd = nullptr;  // repacked for the DMA kernel
+};
 struct V2Block {
     Affine bn0, bn1;
-    ConvW c0, c1;
+    EncConv c0, c1;
 };
+
 struct after_encoder1d {
     after_encoder1d_cfg cfg;
-    int max_batch, max_T;
-    Arena wa, ws;
+    int max_batch, max_T, cmax = 0;
+    Arena wa, ws, sa;
     std::vector<V2Block> blocks;  // n + 1 (last = final V2ConvBlock1D)
-    std::vector<ConvW> pools;     // n
+    std::vector<EncConv> pools;   // n
     float* buf[3] = {nullptr, nullptr, nullptr};
+    float* xp = nullptr;          // activated + haloed scratch
+    size_t xp_elems = 0;
+    // streaming: one left-context slot [max_batch][cmax][halo] per temporal conv
+    bool streaming = false;
+    float* state = nullptr;
+    size_t slot_elems = 0;
+    int slot = 0;
 };
 
 namespace {
 
+int plan_enc(Arena& a, EncConv& e, int stride, bool causal, int T_hint) {
+    memset(&e.in, 0, sizeof(e.in));
+    e.in.Cin = e.cw.cin;
+    e.in.Cout = e.cw.cout;
+    e.in.taps = e.cw.k;
+    e.in.phases = 1;
+    e.in.istride = stride;
+    e.in.ostride = 1;
+    const int pl = conv_left_pad(e.cw.k, 1, causal);
+    for (int t = 0; t < e.cw.k; ++t) e.in.toff[0][t] = t - pl;
+    e.in.Nn_hint = T_hint / stride;
+    e.in.B_hint = 1;
+    conv_dma_plan(e.in, &e.plan);
+    e.wd = a.take<float>(e.plan.w_floats);
+    AFTER_REQUIRE(e.wd, AFTER_E_NOMEM, "encoder1d: weight arena exhausted");
+    return conv_dma_repack(e.cw.w, e.wd, e.in, e.plan, 0);
+}
+
 int load_v2(Arena& a, WCursor& c, V2Block& b, int ch, int k) {
     AFTER_TRY(load_bn(a, c, b.bn0, ch));
-    AFTER_TRY(load_conv(a, c, b.c0, ch, ch, k, true));
+    AFTER_TRY(load_conv(a, c, b.c0.cw, ch, ch, k, true));
     AFTER_TRY(load_bn(a, c, b.bn1, ch));
-    return load_conv(a, c, b.c1, ch, ch, k, true);
+    return load_conv(a, c, b.c1.cw, ch, ch, k, true);
+}
+
+// act(affine(x)) -> haloed scratch (+ streaming left context), then the DMA conv
+int run_enc(after_encoder1d* h, hipStream_t s, const EncConv& e, const float* x, const Affine* bn,
+            int act, const float* res, float* y, int B, int Tin) {
+    const int cin = e.cw.cin;
+    AFTER_REQUIRE((size_t)B * cin * conv_dma_row(Tin) <= h->xp_elems, AFTER_E_CAPACITY,
+                  "encoder1d: activation scratch too small");
+    float* st = nullptr;
+    if (h->streaming && e.cw.k > 1) st = h->state + (size_t)(h->slot++) * h->slot_elems;
+    AFTER_TRY(launch_act_pad(x, h->xp, nullptr, bn ? bn->scale : nullptr, bn ? bn->shift : nullptr,
+                             nullptr, nullptr, act, B, cin, Tin, 1, s, st));
+    ConvDmaRun r;
+    r.xp = h->xp;
+    r.w = e.wd;
+    r.bias = e.cw.bias;
+    r.res = res;
+    r.y = y;
+    r.stats = nullptr;
+    r.G = 1;
+    r.B = B;
+    r.Tp = conv_dma_row(Tin);
+    r.Tout = Tin / e.in.istride;
+    r.Nn = r.Tout;
+    return launch_conv_dma(r, e.in, e.plan, s);
 }
 
 // V2ConvBlock1D (encoder.py:25-71): y = conv1(silu(bn1(conv0(silu(bn0(x)))))) + x
-int run_v2(const V2Block& b, hipStream_t s, const float* x, float* tmp, float* y, int B, int T, int k,
-           bool causal) {
-    const int pl = conv_left_pad(k, 1, causal);
-    ConvArgs a;
-    conv_args_init(a, B, b.c0.cin, b.c0.cout, T, T);
-    a.x = x;
-    a.y = tmp;
-    a.w = b.c0.w;
-    a.bias = b.c0.bias;
-    a.scale = b.bn0.scale;
-    a.shift = b.bn0.shift;
-    a.scale_bstride = 0;
-    a.act = ACT_SILU;
-    a.taps = k;
-    for (int t = 0; t < k; ++t) a.toff[0][t] = t - pl;
-    AFTER_TRY(launch_conv(a, s));
-    a.x = tmp;
-    a.y = y;
-    a.w = b.c1.w;
-    a.bias = b.c1.bias;
-    a.scale = b.bn1.scale;
-    a.shift = b.bn1.shift;
-    a.res = x;
-    return launch_conv(a, s);
+int run_v2(after_encoder1d* h, const V2Block& b, hipStream_t s, const float* x, float* tmp, float* y,
+           int B, int T) {
+    AFTER_TRY(run_enc(h, s, b.c0, x, &b.bn0, ACT_SILU, nullptr, tmp, B, T));
+    return run_enc(h, s, b.c1, tmp, &b.bn1, ACT_SILU, x, y, B, T);
 }
 
 }  // namespace
@@ -225,6 +266,7 @@ extern "C" int after_encoder1d_create(const after_encoder1d_cfg* cfg, const floa
     h->max_batch = max_batch;
     h->max_T = max_T;
     const int n = cfg->n_blocks, k = cfg->kernel_size;
+    const bool causal = cfg->causal != 0;
     auto fail = [&](int rc) {
         after_encoder1d_destroy(h);
         return rc;
@@ -241,32 +283,43 @@ extern "C" int after_encoder1d_create(const after_encoder1d_cfg* cfg, const floa
         }
         wf += 2 * conv_floats(c, c, k) + 4 * (size_t)c + 1024;
     }
-    int rc = h->wa.init(wf * sizeof(float) + (1 << 16));
+    h->cmax = cmax;
+    // packed weights + their DMA re-layout (rows padded to the tile, taps to the K chunk)
+    int rc = h->wa.init(wf * 4 * sizeof(float) + (4 << 20));
     if (rc) return fail(rc);
     WCursor cur{weights, n_weights};
     h->blocks.resize(n + 1);
     h->pools.resize(n);
     int c = cfg->in_size;
+    int T = max_T;
     for (int i = 0; i < n; ++i) {
         if ((rc = load_v2(h->wa, cur, h->blocks[i], c, k))) return fail(rc);
+        if ((rc = plan_enc(h->wa, h->blocks[i].c0, 1, causal, T))) return fail(rc);
+        if ((rc = plan_enc(h->wa, h->blocks[i].c1, 1, causal, T))) return fail(rc);
         const int r = cfg->ratios[i];
         if (r < 1 || 2 * r > kMaxTaps) {
             set_error("encoder1d: ratio %d unsupported", r);
             return fail(AFTER_E_INVALID);
         }
-        if ((rc = load_conv(h->wa, cur, h->pools[i], c, cfg->channels[i], r == 1 ? 1 : 2 * r, true)))
+        if ((rc = load_conv(h->wa, cur, h->pools[i].cw, c, cfg->channels[i], r == 1 ? 1 : 2 * r, true)))
             return fail(rc);
+        if ((rc = plan_enc(h->wa, h->pools[i], r, causal, T))) return fail(rc);
+        T = T / r > 0 ? T / r : 1;
         c = cfg->channels[i];
     }
     if ((rc = load_v2(h->wa, cur, h->blocks[n], c, k))) return fail(rc);
+    if ((rc = plan_enc(h->wa, h->blocks[n].c0, 1, causal, T))) return fail(rc);
+    if ((rc = plan_enc(h->wa, h->blocks[n].c1, 1, causal, T))) return fail(rc);
     if (!cur.ok || cur.i != n_weights) {
         set_error("encoder1d: expected %d weight tensors, got %d", cur.i, n_weights);
         return fail(AFTER_E_INVALID);
     }
     const size_t elems = (size_t)max_batch * cmax * max_T;
-    if ((rc = h->ws.init(3 * elems * sizeof(float) + 4096))) return fail(rc);
+    h->xp_elems = (size_t)max_batch * cmax * conv_dma_row(max_T) + 4096;
+    if ((rc = h->ws.init((3 * elems + h->xp_elems) * sizeof(float) + 8192))) return fail(rc);
     for (int i = 0; i < 3; ++i) h->buf[i] = h->ws.take<float>(elems);
-    if (!h->buf[2]) return fail(AFTER_E_NOMEM);
+    h->xp = h->ws.take<float>(h->xp_elems);
+    if (!h->buf[2] || !h->xp) return fail(AFTER_E_NOMEM);
     if (hipDeviceSynchronize() != hipSuccess) return fail(AFTER_E_HIP);
     *out = h;
     return AFTER_OK;
@@ -274,9 +327,39 @@ extern "C" int after_encoder1d_create(const after_encoder1d_cfg* cfg, const floa
 
 extern "C" void after_encoder1d_destroy(after_encoder1d* h) {
     if (!h) return;
+    h->sa.release();
     h->wa.release();
     h->ws.release();
     delete h;
+}
+
+// streaming: `encoder_time.forward_stream` under cc.use_cached_conv(True) (export.py:17,
+// 438-441; encoder.py:301-322): every causal conv keeps its k-1 (2r-1 for the strided pool)
+// input samples between chunks.
+extern "C" int after_encoder1d_enable_streaming(after_encoder1d* h, int enable) {
+    AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
+    if (!enable) {
+        h->streaming = false;
+        return AFTER_OK;
+    }
+    AFTER_REQUIRE(h->cfg.causal, AFTER_E_INVALID,
+                  "encoder1d: streaming needs causal padding (base.gin:55)");
+    if (!h->sa.base) {
+        const int slots = 3 * h->cfg.n_blocks + 2;
+        h->slot_elems = (size_t)h->max_batch * h->cmax * conv_dma_halo();
+        AFTER_TRY(h->sa.init(slots * h->slot_elems * sizeof(float) + 4096));
+        h->state = h->sa.take<float>(slots * h->slot_elems);
+        AFTER_REQUIRE(h->state, AFTER_E_NOMEM, "encoder1d: streaming state allocation failed");
+        AFTER_HIP_CHECK(hipMemset(h->sa.base, 0, h->sa.off));
+    }
+    h->streaming = true;
+    return AFTER_OK;
+}
+
+extern "C" int after_encoder1d_reset_state(after_encoder1d* h, void* stream) {
+    AFTER_REQUIRE(h && h->sa.base, AFTER_E_INVALID, "encoder1d: streaming was never enabled");
+    AFTER_HIP_CHECK(hipMemsetAsync(h->sa.base, 0, h->sa.off, (hipStream_t)stream));
+    return AFTER_OK;
 }
 
 extern "C" int after_encoder1d_forward(after_encoder1d* h, const float* z, float* out, int B, int T,
@@ -287,35 +370,24 @@ extern "C" int after_encoder1d_forward(after_encoder1d* h, const float* z, float
                   "B=%d T=%d exceed max_batch=%d max_T=%d", B, T, h->max_batch, h->max_T);
     hipStream_t s = (hipStream_t)stream;
     const after_encoder1d_cfg& c = h->cfg;
-    const int n = c.n_blocks, k = c.kernel_size;
-    const bool causal = c.causal != 0;
+    const int n = c.n_blocks;
+    h->slot = 0;
     const float* cur = z;
     float* const P[2] = {h->buf[0], h->buf[2]};
     float* const Y = h->buf[1];
     for (int i = 0; i < n; ++i) {
-        // V2EncoderBlock1D (encoder.py:74-113): conv block, then the (strided) 1x1 "pool"
+        // V2EncoderBlock1D (encoder.py:74-113): conv block, then the (strided) "pool" conv
         float* tmp = (cur == P[0]) ? P[1] : P[0];
-        AFTER_TRY(run_v2(h->blocks[i], s, cur, tmp, Y, B, T, k, causal));
-        const ConvW& p = h->pools[i];
+        AFTER_TRY(run_v2(h, h->blocks[i], s, cur, tmp, Y, B, T));
         const int r = c.ratios[i];
         AFTER_REQUIRE(T % r == 0, AFTER_E_INVALID, "encoder1d: T=%d not divisible by ratio %d", T, r);
-        ConvArgs a;
-        conv_args_init(a, B, p.cin, p.cout, T, T / r);
-        a.x = Y;
-        a.y = tmp;
-        a.w = p.w;
-        a.bias = p.bias;
-        a.taps = p.k;
-        a.istride = r;
-        const int pl = conv_left_pad(p.k, 1, causal);
-        for (int t = 0; t < p.k; ++t) a.toff[0][t] = t - pl;
-        AFTER_TRY(launch_conv(a, s));
+        AFTER_TRY(run_enc(h, s, h->pools[i], Y, nullptr, ACT_NONE, nullptr, tmp, B, T));
         T /= r;
         cur = tmp;
     }
     {
         float* tmp = (cur == P[0]) ? P[1] : P[0];
-        AFTER_TRY(run_v2(h->blocks[n], s, cur, tmp, out, B, T, k, causal));
+        AFTER_TRY(run_v2(h, h->blocks[n], s, cur, tmp, out, B, T));
     }
     if (c.use_tanh) {
         const int tot = B * c.channels[n - 1] * T;

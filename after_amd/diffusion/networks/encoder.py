@@ -135,6 +135,8 @@ class Encoder1D(nn.Module):
         _lib.check(rc, "after_encoder1d_create")
         self._handle = out
         self._cap = cap
+        if getattr(self, "_streaming", False):  # a re-created handle starts a fresh stream
+            _lib.check(L.after_encoder1d_enable_streaming(out, 1), "after_encoder1d_enable_streaming")
         return out
 
     @torch.no_grad()
@@ -157,5 +159,21 @@ class Encoder1D(nn.Module):
         return out
 
     def forward_stream(self, x):
-        """encoder.py:300-322 (offline semantics; the cached-conv state is not built)."""
+        """encoder.py:300-322.  Offline semantics unless `enable_streaming` was called: then the
+        causal convs keep their left context between calls (cc.use_cached_conv(True),
+        export.py:17,438-441) and consecutive chunks continue one stream."""
         return self.forward(x)
+
+    def enable_streaming(self, batch: int, chunk_frames: int, enable: bool = True):
+        h = self._ensure(batch, chunk_frames)
+        _lib.check(_lib.lib().after_encoder1d_enable_streaming(h, int(enable)),
+                   "after_encoder1d_enable_streaming")
+        self._streaming = bool(enable)
+
+    def reset_state(self):
+        if self._handle is None:
+            raise RuntimeError("enable_streaming first")
+        dev = next(self.parameters()).device
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().after_encoder1d_reset_state(self._handle, _lib.current_stream(dev)),
+                       "after_encoder1d_reset_state")

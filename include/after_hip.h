@@ -233,6 +233,12 @@ void after_encoder1d_destroy(after_encoder1d* h);
  * Replaces: Encoder1D.forward / forward_stream offline (encoder.py:273-322). */
 int after_encoder1d_forward(after_encoder1d* h, const float* z, float* out, int B, int T,
                             void* stream);
+/* Streaming twin (`encoder_time.forward_stream` under cc.use_cached_conv(True): export.py:17,
+ * 438-441): after_encoder1d_forward becomes stateful over consecutive chunks, each causal
+ * conv keeping its left context.  Chunked output == offline causal output of the whole
+ * stream.  AFTER_E_INVALID unless cfg.causal. */
+int after_encoder1d_enable_streaming(after_encoder1d* h, int enable);
+int after_encoder1d_reset_state(after_encoder1d* h, void* stream);
 
 /* encoder: ECAPATDNN (after/diffusion/networks/ecapa_encoder.py:458-666) with
  * pooling + global context (every shipped config). */

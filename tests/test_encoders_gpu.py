@@ -51,3 +51,36 @@ def test_encoders_vs_oracle_shapes(B, T, hip_device):
     ec.load_state_dict(sd)
     want = oracle.ecapa_forward(sd, z, dcfg["encoder"])
     assert max_abs(ec.to(hip_device)(z.to(hip_device)).cpu(), want) < 1e-4
+
+
+@pytest.mark.parametrize("config,B,chunks", [("micro", 2, [4, 4, 4, 4]), ("base", 1, [4, 8, 1, 3, 16])])
+def test_encoder1d_streaming_matches_offline_causal(config, B, chunks, hip_device):
+    """forward_stream with the cached-conv state: chunk by chunk == the offline causal pass over
+    the concatenated stream (every conv of encoder_time is causal, base.gin:55, so cached_conv's
+    CachedConv1d is exact)."""
+    fx = Fixture("encoders_micro" if config == "micro" else "encoders_base")
+    dcfg = configs.diffusion_config(config)
+    assert dcfg["encoder_time"]["padding_mode"] == "causal"
+    sd = fx.state_dict("shapes_encoder_time")
+    et = Encoder1D(**dcfg["encoder_time"])
+    et.load_state_dict(sd)
+    et = et.to(hip_device)
+    T = sum(chunks)
+    z = torch.randn(B, et.in_size, T, generator=torch.Generator().manual_seed(T))
+    want = oracle.encoder1d_forward(sd, z, dcfg["encoder_time"])
+    et.enable_streaming(B, max(chunks))
+    et.reset_state()
+    outs, pos = [], 0
+    for n in chunks:
+        outs.append(et.forward_stream(z[..., pos:pos + n].contiguous().to(hip_device)).cpu())
+        pos += n
+    got = torch.cat(outs, -1)
+    assert got.shape == want.shape
+    assert max_abs(got, want) < 1e-4
+    # a second stream after reset reproduces the first bit for bit
+    et.reset_state()
+    again = torch.cat([et.forward_stream(c.contiguous().to(hip_device)).cpu()
+                       for c in z.split(chunks, -1)], -1)
+    assert torch.equal(got, again)
+    et.enable_streaming(B, T, enable=False)
+    assert max_abs(et(z.to(hip_device)).cpu(), want) < 1e-4
