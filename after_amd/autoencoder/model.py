@@ -178,6 +178,10 @@ class AutoEncoder(nn.Module):
         self._handle = None
         self._cap = (0, 0)
 
+    def cfg_kwargs(self):
+        """Constructor arguments of an identical codec (streaming twin, after_amd.streaming)."""
+        return dict(self.cfg)
+
     # ------------------------------------------------------------ handle management
     def _apply(self, fn, *a, **k):
         self._release()

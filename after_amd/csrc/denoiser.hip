@@ -1040,7 +1040,29 @@ int cfg_combine(after_denoiser* h, hipStream_t s, const float* xin, float* xout,
     return AFTER_OK;
 }
 
+// MHAttention.roll_cache over every layer for one sampler step (transformerv2.py:171-188,
+// DenoiserV2.roll_cache :514-515): flip-flop halves, out of place.
+int roll_cache_step(after_denoiser* h, hipStream_t s, int rows, int T, int size, int cache_index) {
+    const int E = h->E;
+    const size_t per = (size_t)h->cache_rows * h->cache * E;
+    const int cur = h->flip[cache_index];
+    const size_t total = (size_t)rows * h->cache * E;
+    for (int l = 0; l < h->L; ++l) {
+        const size_t base = ((size_t)l * h->cache_steps + cache_index) * 2 * per;
+        const float* qkv = h->qkv_layers + (size_t)l * h->max_rows * h->max_T * 3 * E;
+        hipLaunchKernelGGL(roll_cache_kernel, dim3((unsigned)cdivll(total, 256)), dim3(256), 0, s,
+                           h->kcache + base + cur * per, h->vcache + base + cur * per,
+                           h->kcache + base + (cur ^ 1) * per, h->vcache + base + (cur ^ 1) * per, qkv,
+                           rows, T, E, h->cache, size);
+        AFTER_HIP_CHECK(hipGetLastError());
+    }
+    h->flip[cache_index] = cur ^ 1;
+    return AFTER_OK;
+}
+
 // The whole sampler as a sequence of launches on `s` (eager path and graph capture body).
+// With streaming caches (h->cache > 0) this is Streamer.sample of export.py:398-416: step i
+// attends over its own cache slot i, which is rolled by the chunk length after the step.
 int sample_enqueue(after_denoiser* h, hipStream_t s, const float* x0, const float* cond,
                    const float* time_cond, float* out, int B, int T, int nb_steps, float drop_value,
                    int cfg_mode) {
@@ -1052,8 +1074,14 @@ int sample_enqueue(after_denoiser* h, hipStream_t s, const float* x0, const floa
     for (int i = 0; i < nb_steps; ++i) {
         const float* xin = i == 0 ? x0 : out;
         AFTER_TRY(run_net(h, s, xin, B, h->maps, h->maps + h->ms, rows, T,
-                          h->cond_ab + (size_t)i * step_stride, 0, h->row_groups));
+                          h->cond_ab + (size_t)i * step_stride, h->cache > 0 ? i : 0, h->row_groups));
         AFTER_TRY(cfg_combine(h, s, xin, out, B, T));
+        if (h->cache > 0) AFTER_TRY(roll_cache_step(h, s, rows, T, T, i));
+    }
+    if (h->cache > 0) {
+        h->have_last = true;
+        h->last_rows = rows;
+        h->last_T = T;
     }
     return AFTER_OK;
 }
@@ -1096,16 +1124,17 @@ extern "C" int after_sample(after_denoiser* h, const float* x0, const float* con
     AFTER_REQUIRE(x0 && cond && time_cond && out, AFTER_E_INVALID, "null tensor argument");
     AFTER_REQUIRE(nb_steps > 0 && nb_steps <= h->max_steps, AFTER_E_CAPACITY,
                   "nb_steps=%d outside (0, max_steps=%d]", nb_steps, h->max_steps);
-    AFTER_REQUIRE(h->cache == 0, AFTER_E_INVALID,
-                  "after_sample is the offline sampler; with streaming caches drive "
-                  "after_model_forward(cache_index) + after_denoiser_roll_cache per step "
-                  "(after_scripts/export.py:398-416)");
+    if (h->cache > 0) {  // streaming sampler: one cache slot per step
+        AFTER_REQUIRE(nb_steps <= h->cache_steps, AFTER_E_CAPACITY,
+                      "nb_steps=%d exceeds the %d cache slots", nb_steps, h->cache_steps);
+        AFTER_TRY(check_cache(h, 3 * B, 0));
+    }
     hipStream_t s = (hipStream_t)stream;
     CfgParams p;
     // model.py:771: dt = 1 / nb_steps (python float -> the product dx * dt is fp32)
     AFTER_TRY(cfg_params(guidance_timbre, guidance_structure, cfg_mode, (float)(1.0 / nb_steps), &p));
     AFTER_TRY(set_params(h, s, p));
-    if (!h->use_graph || h->timer.enabled)
+    if (!h->use_graph || h->timer.enabled || h->cache > 0)
         return sample_enqueue(h, s, x0, cond, time_cond, out, B, T, nb_steps, drop_value, cfg_mode);
 
     // ---- graph path: stage the (small) inputs, replay the captured loop, copy the result out
@@ -1208,22 +1237,7 @@ extern "C" int after_denoiser_roll_cache(after_denoiser* h, int size, int cache_
                   "cache_index %d outside [0, %d)", cache_index, h->cache_steps);
     AFTER_REQUIRE(size > 0 && size <= h->last_T, AFTER_E_INVALID,
                   "roll size %d outside (0, last call's %d frames]", size, h->last_T);
-    hipStream_t s = (hipStream_t)stream;
-    const int rows = h->last_rows, E = h->E;
-    const size_t per = (size_t)h->cache_rows * h->cache * E;
-    const int cur = h->flip[cache_index];
-    const size_t total = (size_t)rows * h->cache * E;
-    for (int l = 0; l < h->L; ++l) {
-        const size_t base = ((size_t)l * h->cache_steps + cache_index) * 2 * per;
-        const float* qkv = h->qkv_layers + (size_t)l * h->max_rows * h->max_T * 3 * E;
-        hipLaunchKernelGGL(roll_cache_kernel, dim3((unsigned)cdivll(total, 256)), dim3(256), 0, s,
-                           h->kcache + base + cur * per, h->vcache + base + cur * per,
-                           h->kcache + base + (cur ^ 1) * per, h->vcache + base + (cur ^ 1) * per, qkv,
-                           rows, h->last_T, E, h->cache, size);
-        AFTER_HIP_CHECK(hipGetLastError());
-    }
-    h->flip[cache_index] = cur ^ 1;
-    return AFTER_OK;
+    return roll_cache_step(h, (hipStream_t)stream, h->last_rows, h->last_T, size, cache_index);
 }
 
 extern "C" int after_denoiser_profile(after_denoiser* h, int enable) {

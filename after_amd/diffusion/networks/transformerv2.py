@@ -221,7 +221,7 @@ class DenoiserV2(nn.Module):
         LOCAL_ATTENTION_SIZE` (after_scripts/export.py:77-79) and sizes them with
         `max_diffusion_steps` / `max_batch_size` (network rows: 3 x clips under CFG)."""
         cache = self.local_attention_size if max_cache_size is None else max_cache_size
-        self._ensure(max_batch_size, max_frames, 1)
+        self._ensure(max_batch_size, max_frames, int(max_diffusion_steps))
         self._cap = (max(self._cap[0], max_batch_size), max(self._cap[1], max_frames), self._cap[2])
         _lib.check(_lib.lib().after_denoiser_enable_cache(self._handle, int(cache),
                                                           int(max_diffusion_steps),

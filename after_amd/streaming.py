@@ -1,0 +1,169 @@
+"""Real-time (chunk by chunk) audio-to-audio transfer: the `Streamer` of
+after_scripts/export.py:145-506 on MI355X, minus the nn~ / TorchScript packaging.
+
+Per chunk of `chunk_size` latent frames (= chunk_size * ae_ratio audio samples):
+
+    structure(x)  emb_model_structure.encode (streaming codec) -> encoder_time.forward_stream
+    timbre(x)     emb_model_timbre.encode -> rolling `previous_timbre` window -> encoder
+    diffuse(c)    nb_steps Euler steps of the CFG'd denoiser, each step attending over its own
+                  K/V cache slot which is rolled by the chunk length (export.py:398-416)
+    decode(z)     emb_model_structure.decode (streaming codec)
+
+All state lives in HBM inside the C-ABI handles (conv left contexts, PQMF tails, K/V caches);
+one call of `forward` enqueues ~1.2k kernels on the current stream and never synchronises.
+
+Differences from the reference, all opt-in:
+  * `share_first_stream=False` samples every row of the batch independently; the reference
+    (`x[:1]` then `.repeat(n)`, export.py:447-452) runs ONE diffusion per nn~ instance and copies
+    it -- keep True for drop-in behaviour.
+  * the initial noise can be supplied (`noise=`) so that runs are reproducible.
+"""
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .autoencoder.model import AutoEncoder
+from .diffusion.model import RectifiedFlow
+
+
+def clone_codec(ae: AutoEncoder) -> AutoEncoder:
+    """A second instance of the codec with its own streaming state (the reference loads the
+    TorchScript file twice: emb_model_structure / emb_model_timbre, export.py:161-166)."""
+    twin = AutoEncoder(**ae.cfg_kwargs())
+    twin.load_state_dict(ae.state_dict(), strict=False)
+    return twin.to(next(ae.parameters()).device)
+
+
+class Streamer:
+
+    def __init__(self, blender: RectifiedFlow, emb_model: AutoEncoder, chunk_size: int = 4,
+                 n_signal_timbre: int = 128, latent_range: float = 1.0, max_batch: int = 4,
+                 max_nb_steps: int = 16, emb_model_timbre: Optional[AutoEncoder] = None,
+                 share_first_stream: bool = True):
+        self.blender = blender
+        self.net = blender.net
+        self.encoder = blender.encoder
+        self.encoder_time = blender.encoder_time
+        self.emb_model_structure = emb_model
+        self.emb_model_timbre = emb_model_timbre if emb_model_timbre is not None else clone_codec(emb_model)
+        self.chunk_size = int(chunk_size)
+        self.n_signal_timbre = int(n_signal_timbre)
+        self.latent_range = float(latent_range)
+        self.drop_value = blender.drop_value
+        self.ae_ratio = emb_model.ratio
+        self.ae_latents = emb_model.z_channels
+        self.zs_channels = self.net.tcond_dim
+        self.zt_channels = self.net.cond_dim
+        self.sr = getattr(blender, "sr", 44100)
+        self.max_batch = int(max_batch)
+        self.share_first_stream = bool(share_first_stream)
+        # nn~ attributes (export.py:184-186)
+        self.nb_steps = 1
+        self.guidance_timbre = 1.0
+        self.guidance_structure = 1.0
+        dev = next(self.net.parameters()).device
+        self.device = dev
+        # export.py:189-191 (4 = nn~'s maximum batch; here max_batch)
+        self.previous_timbre = torch.zeros(self.max_batch, self.ae_latents, self.n_signal_timbre,
+                                           device=dev)
+        # ---- streaming state in the handles
+        chunk_samples = self.chunk_size * self.ae_ratio
+        self.emb_model_structure.enable_streaming(self.max_batch, chunk_samples)
+        self.emb_model_timbre.enable_streaming(self.max_batch, chunk_samples)
+        if self.encoder_time is not None:
+            self.encoder_time.enable_streaming(self.max_batch, self.chunk_size)
+        rows = 3 * (1 if share_first_stream else self.max_batch)
+        # export.py:73-79: MHAttention.max_cache_size = LOCAL_ATTENTION_SIZE
+        self.net.enable_streaming_cache(max_diffusion_steps=int(max_nb_steps), max_batch_size=rows,
+                                        max_frames=self.chunk_size)
+        self.max_nb_steps = int(max_nb_steps)
+        self.blender.cfg_mode = _lib.CFG_EXPORT  # export.py:364-394: clamp 0.1
+
+    # ------------------------------------------------------------ nn~ attribute accessors
+    def get_guidance_timbre(self):
+        return self.guidance_timbre
+
+    def set_guidance_timbre(self, v: float):
+        self.guidance_timbre = float(v)
+        return 0
+
+    def get_guidance_structure(self):
+        return self.guidance_structure
+
+    def set_guidance_structure(self, v: float):
+        self.guidance_structure = float(v)
+        return 0
+
+    def get_nb_steps(self):
+        return self.nb_steps
+
+    def set_nb_steps(self, n: int):
+        if not 0 < int(n) <= self.max_nb_steps:
+            raise ValueError(f"nb_steps {n} outside (0, {self.max_nb_steps}] (cache slots)")
+        self.nb_steps = int(n)
+        return 0
+
+    def reset(self):
+        """Start of a new stream: zero the codec / encoder contexts, K/V caches and timbre window."""
+        self.emb_model_structure.reset_state()
+        self.emb_model_timbre.reset_state()
+        if self.encoder_time is not None:
+            self.encoder_time.reset_state()
+        self.net.reset_cache()
+        self.previous_timbre.zero_()
+
+    # ------------------------------------------------------------ export.py:398-416
+    @torch.no_grad()
+    def sample(self, x_last, cond, time_cond):
+        return self.net.cfg_sample(x_last, cond, time_cond, self.nb_steps, self.guidance_timbre,
+                                   self.guidance_structure, self.drop_value, _lib.CFG_EXPORT)
+
+    # ------------------------------------------------------------ export.py:418-441
+    @torch.no_grad()
+    def timbre(self, x):
+        z = self.emb_model_timbre.encode(x)[0]
+        n = z.shape[0]
+        self.previous_timbre[:n] = torch.cat((self.previous_timbre[:n], z), -1)[..., z.shape[-1]:]
+        zsem = self.encoder.forward_stream(self.previous_timbre[:n].contiguous())
+        zsem = zsem / self.latent_range
+        return zsem.unsqueeze(-1).repeat(1, 1, self.chunk_size)
+
+    @torch.no_grad()
+    def structure(self, x):
+        z = self.emb_model_structure.encode(x)[0]
+        return self.encoder_time.forward_stream(z)
+
+    # ------------------------------------------------------------ export.py:443-455
+    @torch.no_grad()
+    def diffuse(self, x, noise=None):
+        n = x.shape[0]
+        zsem = x[:, -self.zt_channels:].mean(-1) * self.latent_range
+        time_cond = x[:, :self.zs_channels].contiguous()
+        if noise is None:
+            noise = torch.randn(n, self.ae_latents, x.shape[-1], device=x.device)
+        if self.share_first_stream:
+            out = self.sample(noise[:1].contiguous(), zsem[:1].contiguous(), time_cond[:1].contiguous())
+            return out.repeat(n, 1, 1) if n > 1 else out
+        return self.sample(noise.contiguous(), zsem.contiguous(), time_cond)
+
+    @torch.no_grad()
+    def decode(self, z):
+        return self.emb_model_structure.decode(z)
+
+    @torch.no_grad()
+    def generate(self, x, noise=None):
+        return self.decode(self.diffuse(x, noise))
+
+    # ------------------------------------------------------------ export.py:486-493
+    @torch.no_grad()
+    def forward(self, x, noise=None):
+        """x[n, 2, chunk_size * ae_ratio]: channel 0 = structure audio, 1 = timbre audio."""
+        x = _lib.require_gpu_tensor(x, "x")
+        if x.dim() != 3 or x.shape[1] != 2 or x.shape[-1] != self.chunk_size * self.ae_ratio:
+            raise ValueError(f"forward expects [n, 2, {self.chunk_size * self.ae_ratio}], got {tuple(x.shape)}")
+        structure = self.structure(x[:, :1].contiguous())
+        timbre = self.timbre(x[:, 1:].contiguous())
+        return self.generate(torch.cat((structure, timbre), 1), noise)
+
+    __call__ = forward

@@ -18,6 +18,9 @@ package is absent from the image, so its offline padding arithmetic
 `tests/golden/_refshim/cached_conv` and is pinned only by the identities the
 reference itself asserts (decode(encode(x)).shape == x.shape, ratio 2048).
 
+The streaming codec (cached_conv state across chunks) is PARITY UNPINNED for
+the same reason -- see oracle/streaming.py for what it is anchored on instead.
+
 All functions are *functional*: they take a state dict whose keys are the
 reference's own `state_dict()` keys, so weights move
 1:1 between the reference, the oracle and the HIP path.
@@ -29,3 +32,4 @@ from .sampler import model_forward, sample  # noqa: F401
 from .autoencoder import (ae_encode, ae_decode, pqmf_forward, pqmf_inverse,  # noqa: F401
                           fold_weight_norm)
 from .encoders import encoder1d_forward, ecapa_forward  # noqa: F401
+from .streaming import stream_forward  # noqa: F401
