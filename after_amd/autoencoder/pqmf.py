@@ -13,7 +13,7 @@ import numpy as np
 
 def _kaiser_filter(wc, atten, N=None):
     from scipy.signal import firwin, kaiserord
-    N_, beta = kaiserord(atten, wc / np.pi)
+    N_, beta = kaiserord(atten, float(np.asarray(wc).reshape(-1)[0]) / np.pi)
     N_ = 2 * (N_ // 2) + 1
     N = N if N is not None else N_
     # scipy >= 1.13 dropped firwin(nyq=...): nyq = pi  <=>  fs = 2 pi
