@@ -1,0 +1,91 @@
+"""The exported-codec surface: what `after_scripts/export_autoencoder.py` packages as
+`export.ts` / `export_stream.ts` and what the rest of AFTER calls as `emb_model`
+(`emb_model.encode(x) -> z`, `.decode(z) -> x`, `.forward(x)`; prepare_dataset.py:317-323,
+update_dataset.py:59-61, export.py:161-166).
+
+Three variants, as in the reference:
+  offline            AE_notcausal / AE_causal, `export.ts`          (export_autoencoder.py:235-265)
+  causal streaming   AE_causal under cc.use_cached_conv(True), `export_stream.ts` (:293-303):
+                     the HIP codec keeps every conv's left context in HBM (after_ae_enable_streaming)
+  non-causal stream  AE_notcausal.decode (:128-153): the last `n_fade` latent frames are decoded
+                     again in front of each chunk and the overlap is cross-faded; the output lags
+                     by n_fade frames.  Its encoder twin (cached non-causal convs with delay
+                     compensation, :305-312) is NOT built: use the offline encoder per chunk or a
+                     causal model.
+"""
+import torch
+
+from .. import _lib
+from .model import AutoEncoder
+
+
+class ExportedAutoEncoder:
+
+    def __init__(self, model: AutoEncoder, stream: bool = False, n_fade: int = 4, max_batch: int = 4,
+                 chunk_frames: int = 4):
+        self.model = model
+        self.comp_ratio = model.ratio
+        self.latent_size = model.z_channels
+        self.target_channels = 1
+        self.n_fade = int(n_fade)
+        self.stream = bool(stream)
+        self.causal = model.cfg["padding_mode"] == "causal"
+        self.max_batch = int(max_batch)
+        dev = next(model.parameters()).device
+        if self.stream and self.causal:
+            model.enable_streaming(self.max_batch, chunk_frames * self.comp_ratio)
+        elif self.stream:
+            # export_autoencoder.py:62-65 (4 = nn~'s maximum batch; here max_batch)
+            self.out_buffer = torch.zeros(self.max_batch, 1, self.comp_ratio * self.n_fade, device=dev)
+            self.z_buffer = torch.zeros(self.max_batch, self.latent_size, self.n_fade, device=dev)
+            self.alpha = torch.linspace(0, 1, self.n_fade * self.comp_ratio, device=dev)[None, None, :]
+
+    def reset(self):
+        if self.stream and self.causal:
+            self.model.reset_state()
+        elif self.stream:
+            self.out_buffer.zero_()
+            self.z_buffer.zero_()
+
+    @torch.no_grad()
+    def encode(self, x):
+        return self.model.encode(x)[0]
+
+    @torch.no_grad()
+    def decode(self, z):
+        if not self.stream or self.causal:
+            return self.model.decode(z)
+        z = _lib.require_gpu_tensor(z, "z")
+        n = z.shape[0]
+        if n > self.max_batch:
+            raise ValueError(f"batch {n} exceeds max_batch {self.max_batch}")
+        nf = self.comp_ratio * self.n_fade
+        z = torch.cat((self.z_buffer[:n], z), -1)
+        x = self.model.decode(z.contiguous())
+        self.z_buffer[:n] = z[:, :, -self.n_fade:]
+        x[..., :nf] = (1 - self.alpha) * self.out_buffer[:n] + self.alpha * x[..., :nf]
+        self.out_buffer[:n] = x[:, :, -nf:]
+        return x[..., :-nf].contiguous()
+
+    @torch.no_grad()
+    def forward(self, x):
+        """:106-121 / :235-249: the plain decode(encode(x)) (no cross-fade)."""
+        return self.model.decode(self.model.encode(x)[0])
+
+    __call__ = forward
+
+
+@torch.no_grad()
+def embed_dataset(emb_model, waveforms, batch_size: int = 32):
+    """prepare_dataset.py:313-323 / update_dataset.py:52-61: z for every `num_signal`-sample
+    chunk, `batch_size` chunks per codec call.  waveforms: [N, L] or [N, 1, L] (any device;
+    moved to the codec's device per batch).  Returns [N, Z, L / ratio] on the CPU."""
+    model = emb_model.model if isinstance(emb_model, ExportedAutoEncoder) else emb_model
+    dev = next(model.parameters()).device
+    w = waveforms if waveforms.dim() == 3 else waveforms[:, None, :]
+    model.reserve(min(batch_size, w.shape[0]), w.shape[-1])
+    out = []
+    for i in range(0, w.shape[0], batch_size):
+        z = model.encode(w[i:i + batch_size].to(dev, torch.float32).contiguous())[0]
+        out.append(z.cpu())
+    return torch.cat(out, 0)
