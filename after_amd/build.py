@@ -13,7 +13,12 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libafter_hip.so")
 ARCH = "gfx950"
-FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs.  Without it hipcc allocates them to
+# AGPRs inside the MFMA block and copies every accumulator VGPR<->AGPR around it, once per K
+# slab (3064 v_accvgpr moves in gemm.hip alone; measured +25 % loop time in the 9-accumulator
+# split-K GEMM).  gfx950 has a unified 512-register file, so nothing is gained by AGPRs here.
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _hipcc():

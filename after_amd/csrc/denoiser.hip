@@ -527,7 +527,7 @@ struct after_denoiser {
     // CFG branch streams (run_net groups)
     hipStream_t rstream[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
-    int row_groups = 3, row_groups_forced = 0;
+    int row_groups = 1, row_groups_forced = 0;
     struct GraphEntry {
         int B, T, steps, cfg_mode;
         float drop;
@@ -942,6 +942,9 @@ extern "C" int after_denoiser_create(const after_denoiser_cfg* cfg, const float*
         }
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(AFTER_E_HIP);
     {
+        // Three concurrent CFG-branch streams helped the classic GEMM tiles at large batch
+        // (B=8: 108.9 vs 112.3 ms); with the balanced split-K GEMMs one stream is faster
+        // (107.4 vs 111.1 ms), so a single stream is the default and 3 is opt-in.
         const char* e = getenv("AFTER_ROW_GROUPS");
         if (e) {
             h->row_groups = atoi(e) == 3 ? 3 : 1;

@@ -432,6 +432,367 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(GemmArgs g, int tiles
     }
 }
 
+// ---- the software pipeline of the DMA kernels as file-scope macros (hipcc rejects asm
+// operands that are lambda captures).  They expect in scope: NS, STAGE, KK, MT, NT, BK, LPS,
+// nk, a_c[], w_c[], fa[][][], fb[][][], acc[][], issue(slab, slot).
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_imm() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+#define AFTER_GEMM_LOAD_FRAGS(p, slab)                                                             \
+    {                                                                                              \
+        const unsigned so__ = (unsigned)((slab) % NS) * (STAGE * 4);                               \
+        _Pragma("unroll") for (int kk = 0; kk < KK; ++kk) {                                        \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i)                                         \
+                asm volatile("ds_read_b128 %0, %1" : "=v"(fa[kk][p][i]) : "v"(a_c[kk] + so__ + i * 16 * BK * 4)); \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                         \
+                asm volatile("ds_read_b128 %0, %1" : "=v"(fb[kk][p][j]) : "v"(w_c[kk] + so__ + j * 16 * BK * 4)); \
+        }                                                                                          \
+    }
+#define AFTER_GEMM_FENCE_FRAGS(p)                                            \
+    {                                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   \
+        _Pragma("unroll") for (int kk = 0; kk < KK; ++kk) {                  \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(fa[kk][p][i])); \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(fb[kk][p][j])); \
+        }                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+    }
+#define AFTER_GEMM_MFMA_STEP(A_, B_, comp)                                                      \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NT; ++j) \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[i][comp], B_[j][comp], acc[i][j], 0, 0, 0);
+#define AFTER_GEMM_MMA(p)                                 \
+    _Pragma("unroll") for (int kk = 0; kk < KK; ++kk) {   \
+        AFTER_GEMM_MFMA_STEP(fa[kk][p], fb[kk][p], 0)     \
+        AFTER_GEMM_MFMA_STEP(fa[kk][p], fb[kk][p], 1)     \
+        AFTER_GEMM_MFMA_STEP(fa[kk][p], fb[kk][p], 2)     \
+        AFTER_GEMM_MFMA_STEP(fa[kk][p], fb[kk][p], 3)     \
+    }
+// wait until slab s_ has landed: slabs s_+1 .. min(last_, nk-1) may stay in flight
+#define AFTER_GEMM_WAIT_SLAB(s_, last_)                                                 \
+    {                                                                                   \
+        const int rem__ = ((last_) < nk - 1 ? (last_) : nk - 1) - (s_);                 \
+        if (rem__ >= 3 && NS >= 4) wait_vmcnt_imm<(NS >= 4 ? 3 : 0) * LPS>();          \
+        else if (rem__ >= 2 && NS >= 3) wait_vmcnt_imm<(NS >= 3 ? 2 : 0) * LPS>();     \
+        else if (rem__ >= 1 && NS >= 2) wait_vmcnt_imm<(NS >= 2 ? 1 : 0) * LPS>();     \
+        else wait_vmcnt_imm<0>();                                                       \
+    }
+// one slab: retire slab kt's fragment reads, publish slab kt+1 (one barrier), refill the
+// freed ring slot with slab kt+NS, start reading slab kt+1's fragments, then slab kt's MFMAs
+#define AFTER_GEMM_STEP(pc, pn, kt_)                                                        \
+    {                                                                                       \
+        const int kt__ = (kt_);                                                             \
+        unsigned long long p0__ = 0, p1__ = 0, p2__ = 0, p3__ = 0;                          \
+        if (g.dbg) p0__ = __builtin_readcyclecounter();                                     \
+        AFTER_GEMM_FENCE_FRAGS(pc)                                                          \
+        if (g.dbg) p1__ = __builtin_readcyclecounter();                                     \
+        if (kt__ + 1 < nk) {                                                                \
+            if (kt__ + NS - 1 <= nk - 1) {                                                  \
+                wait_vmcnt_imm<(NS - 2) * LPS>();                                           \
+            } else {                                                                        \
+                AFTER_GEMM_WAIT_SLAB(kt__ + 1, kt__ + NS - 1)                               \
+            }                                                                               \
+            if (g.dbg) p2__ = __builtin_readcyclecounter();                                 \
+            __builtin_amdgcn_s_barrier();                                                   \
+            asm volatile("" ::: "memory");                                                  \
+            if (g.dbg) p3__ = __builtin_readcyclecounter();                                 \
+            if (kt__ + NS < nk) issue(kt__ + NS, kt__ % NS);                                \
+            AFTER_GEMM_LOAD_FRAGS(pn, kt__ + 1)                                             \
+        }                                                                                   \
+        if (g.dbg && kt__ + 1 < nk) {                                                       \
+            ph_fence += p1__ - p0__;                                                        \
+            ph_vm += p2__ - p1__;                                                           \
+            ph_bar += p3__ - p2__;                                                          \
+        }                                                                                   \
+        AFTER_GEMM_MMA(pc)                                                                  \
+    }
+
+// Interleaved slab step for kernels that run ONE wave per SIMD: nothing else can feed the matrix
+// pipe while this wave issues the next slab's DMA and fragment reads, so those instructions are
+// dealt out one by one behind individual MFMAs (each MFMA occupies the pipe for 32 cycles; the
+// wave's issue slot is free meanwhile).  Work item w of the slab: w < LPS -> DMA piece w of slab
+// kt+NS into the ring slot just retired; then the KK*(MT+NT) fragment reads of slab kt+1.
+// Expects additionally: src[], wid, smem, RPP.
+#define AFTER_GEMM_STEP_IL(pc, pn, kt_, steady_)                                                     \
+    {                                                                                         \
+        const int kt__ = (kt_);                                                               \
+        constexpr int NMMA__ = KK * 4 * MT * NT, NWORK__ = LPS + KK * (MT + NT);              \
+        constexpr int SP__ = NMMA__ / NWORK__ > 0 ? NMMA__ / NWORK__ : 1;                     \
+        static_assert(NWORK__ <= NMMA__, "more side work than MFMA slots");                   \
+        unsigned long long p0__ = 0, p1__ = 0, p2__ = 0, p3__ = 0;                            \
+        if (g.dbg) p0__ = __builtin_readcyclecounter();                                       \
+        AFTER_GEMM_FENCE_FRAGS(pc)                                                            \
+        if (g.dbg) p1__ = __builtin_readcyclecounter();                                       \
+        const bool more__ = (steady_) || kt__ + 1 < nk, refill__ = (steady_) || kt__ + NS < nk; \
+        if (more__) {                                                                         \
+            if ((steady_) || kt__ + NS - 1 <= nk - 1) {                                       \
+                wait_vmcnt_imm<(NS - 2) * LPS>();                                             \
+            } else {                                                                          \
+                AFTER_GEMM_WAIT_SLAB(kt__ + 1, kt__ + NS - 1)                                 \
+            }                                                                                 \
+            if (g.dbg) p2__ = __builtin_readcyclecounter();                                   \
+            __builtin_amdgcn_s_barrier();                                                     \
+            asm volatile("" ::: "memory");                                                    \
+            if (g.dbg) p3__ = __builtin_readcyclecounter();                                   \
+        }                                                                                     \
+        if (g.dbg && more__) {                                                                \
+            ph_fence += p1__ - p0__;                                                          \
+            ph_vm += p2__ - p1__;                                                             \
+            ph_bar += p3__ - p2__;                                                            \
+        }                                                                                     \
+        const unsigned so__ = (unsigned)((kt__ + 1) % NS) * (STAGE * 4);                      \
+        const int rs__ = kt__ % NS;                                                           \
+        _Pragma("unroll") for (int kk = 0; kk < KK; ++kk)                                     \
+        _Pragma("unroll") for (int comp = 0; comp < 4; ++comp)                                \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                        \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                      \
+            /* W fragment as srcA: the accumulator holds C^T, i.e. four consecutive output      \
+               columns of one row per lane -> float4 stores / residual loads in the epilogue */ \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[kk][pc][j][comp], fa[kk][pc][i][comp], \
+                                                             acc[i][j], 0, 0, 0);             \
+            const int slot__ = ((kk * 4 + comp) * MT + i) * NT + j;                           \
+            if (slot__ % SP__ == 0 && slot__ / SP__ < NWORK__) {                              \
+                const int w__ = slot__ / SP__;                                                \
+                if (w__ < LPS) {                                                              \
+                    if (refill__) AFTER_BAL_DMA((w__ < LPS ? w__ : 0), kt__ + NS, rs__)       \
+                } else if (more__) {                                                          \
+                    const int r__ = w__ - LPS, k2__ = r__ / (MT + NT), q__ = r__ % (MT + NT); \
+                    if (q__ < MT) {                                                           \
+                        asm volatile("ds_read_b128 %0, %1"                                    \
+                                     : "=v"(fa[k2__ < KK ? k2__ : 0][pn][q__ < MT ? q__ : 0]) \
+                                     : "v"(a_c[k2__ < KK ? k2__ : 0] + so__ + q__ * 16 * BK * 4)); \
+                    } else {                                                                  \
+                        asm volatile("ds_read_b128 %0, %1"                                    \
+                                     : "=v"(fb[k2__ < KK ? k2__ : 0][pn][q__ >= MT ? q__ - MT : 0]) \
+                                     : "v"(w_c[k2__ < KK ? k2__ : 0] + so__ + (q__ - MT) * 16 * BK * 4)); \
+                    }                                                                         \
+                }                                                                             \
+            }                                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+        }                                                                                     \
+    }
+
+// ---------------------------------------------------------------------------------
+// Balanced split-K variant for the few-token (B = 1..4) shapes.  With M = 768 tokens the
+// 768 x 1536 output is 4.5 16x16 blocks per SIMD and the 768 x 512 one 1.5: whatever the
+// tile, whole blocks quantise to 5 / 2 rounds (10 % / 25 % of the matrix pipe idle) and the
+// finer the tile, the more single-accumulator waves whose dependent MFMAs cannot overlap.
+// Here each workgroup owns a (16 MB) x (32 NB) output tile and BOTH halves of K: wave w
+// accumulates k-half (w & 1) of column part (w >> 1), i.e. MB x NB blocks over K/2 -- with
+// (MB, NB) = (3, 3) / (3, 1) that is exactly 9 / 3 half-blocks per SIMD and ONE workgroup
+// per CU at M = 768 (256 workgroups; 256 B at batch B), every wave carrying MB*NB
+// independent accumulators (72 / 24 MFMAs per 32-deep slab between barriers).  The two
+// k-halves are summed through LDS in the epilogue: each wave finalises half of the blocks as
+// (own + partner), a commutative two-term sum -> bit-deterministic, no atomics.
+// Ring slot = [A k-half 0 | A k-half 1 | W k-half 0 | W k-half 1] rows of 32 floats, filled
+// by LDS-DMA with the same source-side XOR swizzle as above.  Requires K % 64 == 0.
+template <int MB, int NB, int KS, int NS>
+__global__ __launch_bounds__(128 * KS) void gemm_f32_bal_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+    constexpr int BK = 32, CPR = 8, RPP = 8, KK = 2;
+    constexpr int MT = MB, NT = NB;               // blocks per wave (names used by the macros)
+    constexpr int BM = 16 * MB, BN = 32 * NB;
+    constexpr int NW = 2 * KS;                    // waves: KS k-parts x 2 column parts
+    constexpr int ROWS = KS * (BM + BN);          // ring slot: [A k-part 0..KS-1 | W k-part 0..KS-1]
+    constexpr int LPS = ROWS / RPP / NW;          // DMA instructions per wave per slab
+    static_assert(ROWS % (RPP * NW) == 0, "ring slot must split evenly over the waves");
+    constexpr int STAGE = ROWS * BK;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tn = bid / tiles_m, tm = bid - tn * tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = wid % KS, part = wid / KS;     // k-part, column part
+    const int M = g.M, N = g.N, Kh = g.K / KS;
+
+    // DMA addressing: wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset, so that
+    // a piece costs one s_mov m0 + one global_load_lds (no per-slab VALU address arithmetic).
+    const int rsub = lane / CPR, pos = lane % CPR;
+    unsigned voff[LPS];
+    const float* sbase[LPS];
+#pragma unroll
+    for (int i = 0; i < LPS; ++i) {
+        const int row0 = (wid * LPS + i) * RPP;  // first row of the piece: wave uniform
+        const int row = row0 + rsub;
+        if (row0 < KS * BM) {
+            const int half = row0 / BM;
+            const int gm = min(m0 + row - half * BM, M - 1);
+            sbase[i] = g.A + half * Kh;
+            voff[i] = ((unsigned)gm * (unsigned)g.lda + (unsigned)((pos ^ (row & (CPR - 1))) * 4)) * 4u;
+        } else {
+            const int rr0 = row0 - KS * BM;
+            const int half = rr0 / BN;
+            const int gn = min(n0 + (row - KS * BM) - half * BN, N - 1);
+            sbase[i] = g.W + half * Kh;
+            voff[i] = ((unsigned)gn * (unsigned)g.ldw + (unsigned)((pos ^ (row & (CPR - 1))) * 4)) * 4u;
+        }
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+#define AFTER_BAL_DMA(w_, slab_, slot_)                                                          \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                  \
+                 :                                                                                \
+                 : "s"(lds0 + (unsigned)(((slot_) * STAGE + (wid * LPS + (w_)) * RPP * BK) * 4)), \
+                   "v"(voff[w_]), "s"(sbase[w_] + (slab_) * BK)                                   \
+                 : "memory");
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = Kh / BK;
+    unsigned long long t_start = 0, t_loop = 0, t_end = 0, r_start = 0;
+    unsigned long long ph_fence = 0, ph_vm = 0, ph_bar = 0;
+    if (g.dbg) {
+        t_start = __builtin_readcyclecounter();
+        r_start = wall_clock64();
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        if (s < nk) {
+#pragma unroll
+            for (int i = 0; i < LPS; ++i) AFTER_BAL_DMA(i, s, s)
+        }
+
+    const int frow = lane & 15, kq = lane >> 4, sw = frow & (CPR - 1);
+    const int aoff = (kh * BM + frow) * BK;
+    const int woff = (KS * BM + kh * BN + part * 16 * NB + frow) * BK;
+    f32x4 fa[KK][2][MT], fb[KK][2][NT];
+    unsigned a_c[KK], w_c[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+        const int c = ((kq + 4 * kk) ^ sw) * 4;
+        a_c[kk] = lds0 + (aoff + c) * 4;
+        w_c[kk] = lds0 + (woff + c) * 4;
+    }
+    AFTER_GEMM_WAIT_SLAB(0, NS - 1)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (g.dbg) t_loop = __builtin_readcyclecounter();
+    AFTER_GEMM_LOAD_FRAGS(0, 0)
+    int kt = 0;
+    for (; kt + 1 + NS < nk; kt += 2) {  // steady state: no tail predicates in the MFMA stream
+        AFTER_GEMM_STEP_IL(0, 1, kt, true)
+        AFTER_GEMM_STEP_IL(1, 0, kt + 1, true)
+    }
+    for (; kt < nk; kt += 2) {
+        AFTER_GEMM_STEP_IL(0, 1, kt, false)
+        if (kt + 1 < nk) AFTER_GEMM_STEP_IL(1, 0, kt + 1, false)
+    }
+    if (g.dbg) {
+        asm volatile("s_nop 0" ::"v"(acc[MT - 1][NT - 1][0]));
+        t_end = __builtin_readcyclecounter();
+    }
+
+    // ---- split-K reduction through LDS (the ring is free: every wave is past its last read).
+    // Wave (kh, part) finalises the blocks b with b % KS == kh as p0 + p1 + ... in k-part order:
+    // a fixed summation order, i.e. bit-deterministic.
+    __syncthreads();
+    float* red = smem;  // [wave][block][lane][4]
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            *reinterpret_cast<f32x4*>(red + ((wid * MT * NT + i * NT + j) * 64 + lane) * 4) = acc[i][j];
+    __syncthreads();
+    unsigned long long t_red = 0, t_st = 0;
+    if (g.dbg) t_red = __builtin_readcyclecounter();
+    // accumulator layout (transposed MFMA): lane l holds C[row = l & 15][col = 4 (l >> 4) + r]
+    const int crow = lane & 15, ccol0 = 4 * (lane >> 4);
+    const bool vec_ok = ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0) &&
+                        (g.epilogue != EPI_RESIDUAL ||
+                         (((g.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.R) & 15) == 0)));
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int gn = n0 + part * 16 * NB + j * 16 + ccol0;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (gn + r < N) bv[r] = g.bias[gn + r];
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            if ((i * NT + j) % KS != kh) continue;
+            f32x4 o = *reinterpret_cast<const f32x4*>(red + (((part * KS) * MT * NT + i * NT + j) * 64 + lane) * 4);
+#pragma unroll
+            for (int q = 1; q < KS; ++q)
+                o += *reinterpret_cast<const f32x4*>(red + (((part * KS + q) * MT * NT + i * NT + j) * 64 + lane) * 4);
+            const int gm = m0 + i * 16 + crow;
+            if (gm >= M || gn >= N) continue;
+            o += bv;
+            if (g.epilogue == EPI_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r]);
+            } else if (g.epilogue == EPI_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
+            } else if (g.epilogue == EPI_SIGMOID) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = 1.0f / (1.0f + expf(-o[r]));
+            }
+            float* cp = g.C + (size_t)gm * g.ldc + gn;
+            if (vec_ok && gn + 3 < N) {
+                if (g.epilogue == EPI_RESIDUAL)
+                    o += *reinterpret_cast<const f32x4*>(g.R + (size_t)gm * g.ldr + gn);
+                *reinterpret_cast<f32x4*>(cp) = o;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (gn + r < N) {
+                        float v = o[r];
+                        if (g.epilogue == EPI_RESIDUAL) v += g.R[(size_t)gm * g.ldr + gn + r];
+                        cp[r] = v;
+                    }
+            }
+        }
+    }
+    if (g.dbg) t_st = __builtin_readcyclecounter();
+    if (g.dbg && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* d = g.dbg + (size_t)blockIdx.x * 8;
+        d[0] = t_start;
+        d[1] = t_loop;
+        d[2] = t_end;
+        d[3] = __builtin_readcyclecounter();
+        d[4] = r_start;
+        d[5] = wall_clock64();
+        d[6] = __smid();
+        d[7] = (ph_fence & 0xFFFFF) | ((ph_vm & 0xFFFFF) << 20) | ((ph_bar & 0xFFFFF) << 40);
+        if (g.epilogue & 0x100) d[7] = ((t_red - t_end) & 0xFFFFF) | (((t_st - t_red) & 0xFFFFF) << 20);
+    }
+}
+
+#undef AFTER_BAL_DMA
+
+template <int MB, int NB, int KS, int NS>
+int launch_bal(const GemmArgs& g, hipStream_t stream) {
+    constexpr int BM = 16 * MB, BN = 32 * NB;
+    const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
+    const size_t ring = size_t(NS) * KS * (BM + BN) * 32 * sizeof(float);
+    const size_t red = size_t(2 * KS) * MB * NB * 256 * sizeof(float);
+    const size_t lds = ring > red ? ring : red;
+    static_assert(size_t(NS) * KS * (BM + BN) * 32 * sizeof(float) <= 160 * 1024, "ring exceeds the LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_bal_kernel<MB, NB, KS, NS>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_f32_bal_kernel<MB, NB, KS, NS>), dim3(tiles_m * tiles_n), dim3(128 * KS), lds,
+                       stream, g, tiles_m, tiles_n);
+    AFTER_HIP_CHECK(hipGetLastError());
+    return AFTER_OK;
+}
+
 template <int MT, int NT, int NS, int BK>
 int launch_dma(const GemmArgs& g, hipStream_t stream) {
     constexpr int BM = 32 * MT, BN = 32 * NT;
@@ -517,6 +878,20 @@ int launch_gemm_cfg(const GemmArgs& g, int mt, int nt, hipStream_t stream) {
                   "gemm: operands must be 16-byte aligned");
     AFTER_REQUIRE(g.epilogue != EPI_RESIDUAL || g.R != nullptr, AFTER_E_INVALID,
                   "gemm: residual epilogue without R");
+    if (mt >= 100) {  // balanced split-K kernels: mt = 100 + MB (2 k-parts) / 200 + MB (4), nt = 10 NS + NB
+        const int ks = mt >= 200 ? 4 : 2, mb = mt % 100, nb = nt % 10, ns = nt / 10;
+        AFTER_REQUIRE((g.K % (32 * ks)) == 0, AFTER_E_INVALID, "gemm: %d-way split-K needs K %% %d == 0", ks, 32 * ks);
+        AFTER_REQUIRE((size_t)g.M * g.lda < (1u << 30) && (size_t)g.N * g.ldw < (1u << 30), AFTER_E_INVALID,
+                      "gemm: operand too large for 32-bit DMA offsets");
+#define AFTER_BAL_CASE(MB_, NB_, KS_, NS_) \
+    if (mb == MB_ && nb == NB_ && ks == KS_ && ns == NS_) return launch_bal<MB_, NB_, KS_, NS_>(g, stream);
+        AFTER_BAL_CASE(3, 3, 2, 2) AFTER_BAL_CASE(3, 3, 2, 3) AFTER_BAL_CASE(3, 1, 2, 2) AFTER_BAL_CASE(3, 1, 2, 4)
+        AFTER_BAL_CASE(3, 3, 4, 2) AFTER_BAL_CASE(3, 1, 4, 2) AFTER_BAL_CASE(3, 1, 4, 3) AFTER_BAL_CASE(3, 1, 4, 4)
+        AFTER_BAL_CASE(3, 2, 4, 2) AFTER_BAL_CASE(2, 2, 4, 2) AFTER_BAL_CASE(2, 2, 4, 3)
+#undef AFTER_BAL_CASE
+        set_error("gemm: no split-K configuration MB=%d NB=%d KS=%d NS=%d", mb, nb, ks, ns);
+        return AFTER_E_INVALID;
+    }
     if (mt > 0 || nt > 0) {
         if (mt == 4 && nt == 4) return launch_cfg<4, 4>(g, stream);
         if (mt == 4 && nt == 2) return launch_cfg<4, 2>(g, stream);
@@ -526,7 +901,31 @@ int launch_gemm_cfg(const GemmArgs& g, int mt, int nt, hipStream_t stream) {
         set_error("gemm: no tile configuration %dx%d", mt, nt);
         return AFTER_E_INVALID;
     }
-    // Tile choice: the largest workgroup tile that still yields >= 2 workgroups per CU
+    // Tile choice (measured on MI355X, scripts/bench_gemm.py).  The balanced
+    // split-K kernels win whenever K allows the split: they quantise to whole CUs (48-row tiles:
+    // 768 B tokens -> 256 B workgroups per 96 / 32 columns), keep >= 2 waves per SIMD busy and
+    // have no ragged last round.  A wave cannot overlap its own non-MFMA instructions with its
+    // MFMAs (scripts/ubench/mfma_coissue.hip), so a second wave per SIMD is what hides the
+    // DMA / LDS / barrier work of the first.
+    static int use_bal = -1;
+    if (use_bal < 0) {
+        const char* e = getenv("AFTER_GEMM_BAL");
+        use_bal = e ? atoi(e) : 1;
+    }
+    const bool fits32 = (size_t)g.M * g.lda < (1u << 30) && (size_t)g.N * g.ldw < (1u << 30);
+    if (use_bal && fits32 && g.M >= 192 && g.N >= 128) {
+        const bool long_k = g.K >= 2 * g.N;  // "down" projections: narrow N, long K
+        if (long_k && (g.K % 128) == 0) {
+            if (g.M <= 1024) return launch_bal<3, 1, 4, 2>(g, stream);
+            if (g.M <= 2048) return launch_bal<3, 2, 4, 2>(g, stream);
+            return launch_bal<3, 3, 2, 2>(g, stream);
+        }
+        if ((g.K % 64) == 0) {
+            if (g.M <= 1024) return launch_bal<3, 1, 2, 2>(g, stream);
+            return launch_bal<3, 3, 2, 2>(g, stream);
+        }
+    }
+    // Classic 2x2-wave tiles: the largest workgroup tile that still yields >= 2 workgroups per CU
     // (co-residency is what hides the LDS/barrier latency of this MFMA-bound loop).
     auto wgs = [&](int bm, int bn) { return (long long)cdiv(g.M, bm) * cdiv(g.N, bn); };
     const long long want = 2 * 256;

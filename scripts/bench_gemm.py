@@ -1,16 +1,20 @@
-"""GEMM microbench: python scripts/bench_gemm.py  (env knobs AFTER_GEMM_BK / AFTER_GEMM_LDS_MIN)"""
+"""GEMM microbench: python scripts/bench_gemm.py  (env knobs AFTER_GEMM_BK / AFTER_GEMM_LDS_MIN).
+Tiles (mt, nt): classic 2x2-wave kernels; (100+MB, 10*NS+NB): balanced split-K kernels."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from after_amd import diag
 dev = torch.device("cuda:0")
-shapes = [(768,1536,512),(768,512,1536),(6144,1536,512),(6144,512,1536)]
-tiles = [(1,1),(1,2),(2,2),(4,2),(4,4)]
-want = sys.argv[1:] 
+shapes = [(768,1536,512),(768,512,1536),(1536,1536,512),(1536,512,1536),(6144,1536,512),(6144,512,1536)]
+tiles = [(1,1),(2,2),(103,23),(103,33),(103,21),(103,41),(203,23),(203,21),(203,31),(203,41),(203,22),(202,22),(202,32)]
 for (M,N,K) in shapes:
     a = torch.randn(M,K,device=dev); w = torch.randn(N,K,device=dev); out = torch.empty(M,N,device=dev)
+    ref = (a.double() @ w.double().T)
     res = []
     for tile in tiles:
+        out.zero_()
+        diag.gemm(a,w,tile=tile,out=out)
+        err = (out.double()-ref).abs().max().item()
         for _ in range(3): diag.gemm(a,w,tile=tile,out=out)
         torch.cuda.synchronize()
         e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
@@ -19,5 +23,5 @@ for (M,N,K) in shapes:
         for _ in range(reps): diag.gemm(a,w,tile=tile,out=out)
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1)/reps*1e3
-        res.append(f"{tile}:{us:.1f}us/{2*M*N*K/us/1e6:.0f}TF")
-    print(f"BK={os.environ.get('AFTER_GEMM_BK','32')} LDSMIN={os.environ.get('AFTER_GEMM_LDS_MIN','0')} M={M} N={N} K={K}  " + "  ".join(res))
+        res.append(f"{tile}:{us:.1f}us/{2*M*N*K/us/1e6:.0f}TF" + ("" if err < 1e-3 else f"/ERR{err:.1e}"))
+    print(f"M={M} N={N} K={K}  " + "  ".join(res), flush=True)

@@ -4,15 +4,20 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 from after_amd import diag, _lib
 dev = torch.device("cuda:0")
+EPI = int(os.environ.get("GEMM_EPI", "0"))
 M, N, K = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (768, 1536, 512)
 tile = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (1, 2)
 a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev); out = torch.empty(M, N, device=dev)
-nwg = ((M + 32*tile[0]-1)//(32*tile[0])) * ((N + 32*tile[1]-1)//(32*tile[1]))
+if tile[0] >= 100:  # balanced split-K kernels: (100 + MB, 10 * NS + NB)
+    bm, bn = 16 * (tile[0] % 100), 32 * (tile[1] % 10)
+else:
+    bm, bn = 32 * tile[0], 32 * tile[1]
+nwg = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
 dbg = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
 for _ in range(5): diag.gemm(a, w, tile=tile, out=out)
 torch.cuda.synchronize()
 _lib.lib().after_gemm_set_debug(dbg.data_ptr())
-diag.gemm(a, w, tile=tile, out=out)
+diag.gemm(a, w, tile=tile, out=out, epilogue=EPI)
 torch.cuda.synchronize()
 _lib.lib().after_gemm_set_debug(None)
 d = dbg.cpu().numpy().reshape(nwg, 8).astype(np.float64)

@@ -29,6 +29,38 @@ def test_gemm_shapes(tile, M, N, K, hip_device):
     assert (out - (ref - b.double() + r.double())).abs().max().item() < bound
 
 
+# balanced split-K kernels: tile = (100 * KS / 2 + MB, 10 * NS + NB); K must be a multiple of 32 * KS
+@pytest.mark.parametrize("tile", [(103, 23), (103, 33), (103, 21), (103, 41), (203, 23), (203, 21),
+                                  (203, 31), (203, 41), (203, 22), (202, 22), (202, 32)])
+@pytest.mark.parametrize("M,N,K", [(768, 1536, 512), (768, 512, 1536), (150, 520, 128), (33, 17, 256),
+                                   (257, 130, 384), (1, 64, 512), (3072, 96, 128)])
+def test_gemm_split_k_shapes(tile, M, N, K, hip_device):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g)
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    ref = a.double() @ w.double().t() + b.double()
+    bound = 2e-6 * (a.abs().double() @ w.abs().double().t()).max().item() + 1e-6
+    ad, wd, bd, rd = (t.to(hip_device) for t in (a, w, b, r))
+    out = diag.gemm(ad, wd, bd, tile=tile)
+    assert (out.cpu().double() - ref).abs().max().item() < bound
+    # fixed summation order of the k-parts: bit-identical on every run
+    assert torch.equal(out, diag.gemm(ad, wd, bd, tile=tile))
+    out = diag.gemm(ad, wd, bd, epilogue=1, tile=tile).cpu().double()
+    assert (out - torch.nn.functional.gelu(ref)).abs().max().item() < bound
+    out = diag.gemm(ad, wd, None, residual=rd, epilogue=2, tile=tile).cpu().double()
+    assert (out - (ref - b.double() + r.double())).abs().max().item() < bound
+
+
+def test_gemm_split_k_rejects_short_k(hip_device):
+    from after_amd._lib import AFTERHipError
+    a = torch.randn(64, 96, device=hip_device)
+    w = torch.randn(64, 96, device=hip_device)
+    with pytest.raises(AFTERHipError):
+        diag.gemm(a, w, tile=(203, 23))
+
+
 def test_gemm_strided_operands(hip_device):
     g = torch.Generator().manual_seed(5)
     big = torch.randn(100, 96, generator=g).to(hip_device)
