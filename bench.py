@@ -145,7 +145,7 @@ def main():
             traffic = json.load(open(pmc)).get("gemm_f32_mean_bytes_per_launch")
         if launches:
             ach = flops / (ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_16x16x4_f32)",
+            roof = {"bound": "mfma", "kernel": "gemm_f32_bal_kernel / gemm_f32_dma_kernel (v_mfma_f32_16x16x4_f32)",
                     "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "bytes per launch (PMC profile, see profiles/r1_pmc_hbm_base_b1.json)",
