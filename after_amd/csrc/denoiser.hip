@@ -261,21 +261,31 @@ struct AttnArgs {
     int dbg;                // AFTER_ATTN_DBG bitmask (diagnostics): 1 no rope, 2 no reduce, 4 no LN tail, 8 no KV loads
 };
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false);
+    return v + __int_as_float(t);
+}
+
 __device__ __forceinline__ float group16_sum(float v) {
-    // all-reduce over the 16 lanes of a query group (xor butterfly stays inside the group)
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
+    // all-reduce over the 16 lanes of a query group with DPP row operations (VALU, no LDS round
+    // trip): quad xor 1, quad xor 2, then the mirrored half / row partner -- once the quads are
+    // uniform the mirror lane holds the other quad's (half's) sum, so this is the same
+    // ((a+b)+(c+d)) tree as an xor butterfly and every lane ends with the identical value.
+    v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);  // row_half_mirror
+    v = dpp_add<0x140>(v);  // row_mirror
     return v;
 }
 
-// RoPE on 4 consecutive head dims (two interleaved pairs), rotary_embedding.py:132-173
+// RoPE on 4 consecutive head dims (two interleaved pairs), rotary_embedding.py:132-173.
+// ct / st: [pos][16] tables (global, or the chunk's slice staged in LDS)
 __device__ __forceinline__ float4 rope4(float4 v, const float* __restrict__ ct,
                                         const float* __restrict__ st, int pos, int d4) {
     if (d4 < 32) {
-        const float2 c = *reinterpret_cast<const float2*>(ct + (size_t)pos * 16 + (d4 >> 1));
-        const float2 s = *reinterpret_cast<const float2*>(st + (size_t)pos * 16 + (d4 >> 1));
+        const float2 c = *reinterpret_cast<const float2*>(ct + pos * 16 + (d4 >> 1));
+        const float2 s = *reinterpret_cast<const float2*>(st + pos * 16 + (d4 >> 1));
         const float x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
         v.x = x0 * c.x - x1 * s.x;
         v.y = x1 * c.x + x0 * s.x;
@@ -294,7 +304,7 @@ __device__ __forceinline__ float4 rope4(float4 v, const float* __restrict__ ct,
 template <bool CACHE>
 __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
     constexpr int NKMAX = 12;  // key block
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [cs][E + 4]
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [cs][E + 4] | cos, sin [nkmax][16]
     const int E = a.E, H = a.H, T = a.T, cs = a.cs, W = a.W;
     const int nc = CACHE ? a.nc : 0;
     const int ld = E + 4;
@@ -308,7 +318,21 @@ __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
     const int lo_c = min(a0, max(0, a0 - W + 1));
     const int nk = (nc + e) - lo_c;
     const size_t rowbase = (size_t)r * T;
-
+    // The chunk touches positions [lo_c, lo_c + nk) only (its queries are the last nq of them):
+    // every wave stages that slice of the RoPE tables in its own LDS region (float4 per lane,
+    // no workgroup barrier: a wave's LDS accesses execute in order) instead of two dependent
+    // global loads per key and lane (measured: 3.9 of the kernel's 14 us).
+    float* const rc = smem + cs * (E + 4) + hw * (2 * a.nkmax * 16);
+    float* const rs = rc + a.nkmax * 16;
+    float4 tcv[2], tsv[2];  // nkmax <= 32 positions -> at most 2 float4 per lane and table
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = lane + 64 * u;
+        if (i < nk * 4) {
+            tcv[u] = *reinterpret_cast<const float4*>(a.rope_cos + (size_t)lo_c * 16 + i * 4);
+            tsv[u] = *reinterpret_cast<const float4*>(a.rope_sin + (size_t)lo_c * 16 + i * 4);
+        }
+    }
     // Operands of the LayerNorm tail are requested before anything else so that their
     // latency hides behind the attention proper.
     const int nper = E >> 6;
@@ -333,7 +357,6 @@ __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
         const int lo_row = min(a0, max(0, ja - W + 1));
         float4 q4 = *reinterpret_cast<const float4*>(a.qkv + (rowbase + i0 + qic) * 3 * E + hw * 64 + d4);
         const float4 x4 = *reinterpret_cast<const float4*>(a.xres + (rowbase + i0 + qic) * E + hw * 64 + d4);
-        if (!(a.dbg & 1)) q4 = rope4(q4, a.rope_cos, a.rope_sin, ja, d4);
         // Keys are walked in blocks of NKMAX with an online softmax (one block for the
         // shipped window 8 / chunk 4).  Inside a block all K and V rows are requested
         // unconditionally (slot index clamped, masked later): no control flow between
@@ -359,12 +382,26 @@ __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
                 if (CACHE && pos < nc) src = a.vcache + ((size_t)r * nc + pos) * E + hw * 64 + d4;
                 v4[j] = *reinterpret_cast<const float4*>(src);
             }
+            if (qb == 0 && kb == 0) {  // K / V requests are in flight: now land the RoPE slice
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = lane + 64 * u;
+                    if (i < nk * 4) {
+                        *reinterpret_cast<float4*>(rc + i * 4) = tcv[u];
+                        *reinterpret_cast<float4*>(rs + i * 4) = tsv[u];
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            if (kb == 0 && !(a.dbg & 1)) q4 = rope4(q4, rc, rs, ja - lo_c, d4);
             float sc[NKMAX];
             float mx = mrun;
 #pragma unroll
             for (int j = 0; j < NKMAX; ++j) {
                 const int pos = lo_c + min(kb + j, nk - 1);
-                const float4 kr = (a.dbg & 1) ? k4[j] : rope4(k4[j], a.rope_cos, a.rope_sin, pos, d4);
+                const float4 kr = (a.dbg & 1) ? k4[j] : rope4(k4[j], rc, rs, pos - lo_c, d4);
                 float dot = q4.x * kr.x + q4.y * kr.y + q4.z * kr.z + q4.w * kr.w;
                 if (!(a.dbg & 2)) dot = group16_sum(dot);
                 sc[j] = (kb + j < nk && pos >= lo_row) ? dot * 0.125f : -INFINITY;
@@ -601,7 +638,9 @@ int compute_cond_ab(after_denoiser* h, hipStream_t s, int S, int rows, const flo
     return AFTER_OK;
 }
 
-size_t attn_lds_bytes(int E, int cs) { return (size_t)cs * (E + 4) * sizeof(float); }
+size_t attn_lds_bytes(int E, int cs, int nkmax) {  // residual rows + per-wave RoPE slices
+    return ((size_t)cs * (E + 4) + (size_t)(E / 64) * 2 * nkmax * 16) * sizeof(float);
+}
 
 int launch_attn(const AttnArgs& a, int rows, size_t lds, hipStream_t s) {
     const dim3 grid(cdiv(a.T, a.cs), rows), block(64 * a.H);
@@ -638,7 +677,7 @@ int run_layers(after_denoiser* h, hipStream_t s, int row0, int rows, const int* 
     float* hbuf = h->hbuf + r0 * E;
     float* mlp = h->mlp + r0 * ME;
     const int nkmax = h->W - 1 + h->cs > h->cs ? h->W - 1 + h->cs : h->cs;
-    const size_t lds = attn_lds_bytes(E, h->cs);
+    const size_t lds = attn_lds_bytes(E, h->cs, h->W - 1 + h->cs > h->cs ? h->W - 1 + h->cs : h->cs);
     for (int l = 0; l < L; ++l) {
         const LayerW& w = h->layers[l];
         hipLaunchKernelGGL(ln_mod_ln_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s,
