@@ -6,7 +6,7 @@ from . import configs  # noqa: F401
 from .diffusion import DenoiserV2, RectifiedFlow, Encoder1D, ECAPATDNN  # noqa: F401
 from .autoencoder import AutoEncoder  # noqa: F401
 
-from .streaming import Streamer  # noqa: F401
+from .streaming import Streamer, MidiStreamer  # noqa: F401
 
 __all__ = ["configs", "DenoiserV2", "RectifiedFlow", "AutoEncoder", "Encoder1D", "ECAPATDNN",
-           "Streamer"]
+           "Streamer", "MidiStreamer"]

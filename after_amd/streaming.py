@@ -36,6 +36,8 @@ def clone_codec(ae: AutoEncoder) -> AutoEncoder:
 
 
 class Streamer:
+    cfg_mode = _lib.CFG_EXPORT  # export.py:364-394 (clamp 0.1)
+    uses_structure_encoder = True
 
     def __init__(self, blender: RectifiedFlow, emb_model: AutoEncoder, chunk_size: int = 4,
                  n_signal_timbre: int = 128, latent_range: float = 1.0, max_batch: int = 4,
@@ -46,7 +48,10 @@ class Streamer:
         self.encoder = blender.encoder
         self.encoder_time = blender.encoder_time
         self.emb_model_structure = emb_model
-        self.emb_model_timbre = emb_model_timbre if emb_model_timbre is not None else clone_codec(emb_model)
+        if not self.uses_structure_encoder:  # export_midi.py: ONE codec instance (timbre encode + decode)
+            self.emb_model_timbre = emb_model
+        else:
+            self.emb_model_timbre = emb_model_timbre if emb_model_timbre is not None else clone_codec(emb_model)
         self.chunk_size = int(chunk_size)
         self.n_signal_timbre = int(n_signal_timbre)
         self.latent_range = float(latent_range)
@@ -70,7 +75,8 @@ class Streamer:
         # ---- streaming state in the handles
         chunk_samples = self.chunk_size * self.ae_ratio
         self.emb_model_structure.enable_streaming(self.max_batch, chunk_samples)
-        self.emb_model_timbre.enable_streaming(self.max_batch, chunk_samples)
+        if self.emb_model_timbre is not self.emb_model_structure:
+            self.emb_model_timbre.enable_streaming(self.max_batch, chunk_samples)
         if self.encoder_time is not None:
             self.encoder_time.enable_streaming(self.max_batch, self.chunk_size)
         rows = 3 * (1 if share_first_stream else self.max_batch)
@@ -78,7 +84,7 @@ class Streamer:
         self.net.enable_streaming_cache(max_diffusion_steps=int(max_nb_steps), max_batch_size=rows,
                                         max_frames=self.chunk_size)
         self.max_nb_steps = int(max_nb_steps)
-        self.blender.cfg_mode = _lib.CFG_EXPORT  # export.py:364-394: clamp 0.1
+        self.blender.cfg_mode = self.cfg_mode
 
     # ------------------------------------------------------------ nn~ attribute accessors
     def get_guidance_timbre(self):
@@ -107,7 +113,8 @@ class Streamer:
     def reset(self):
         """Start of a new stream: zero the codec / encoder contexts, K/V caches and timbre window."""
         self.emb_model_structure.reset_state()
-        self.emb_model_timbre.reset_state()
+        if self.emb_model_timbre is not self.emb_model_structure:
+            self.emb_model_timbre.reset_state()
         if self.encoder_time is not None:
             self.encoder_time.reset_state()
         self.net.reset_cache()
@@ -117,7 +124,7 @@ class Streamer:
     @torch.no_grad()
     def sample(self, x_last, cond, time_cond):
         return self.net.cfg_sample(x_last, cond, time_cond, self.nb_steps, self.guidance_timbre,
-                                   self.guidance_structure, self.drop_value, _lib.CFG_EXPORT)
+                                   self.guidance_structure, self.drop_value, self.cfg_mode)
 
     # ------------------------------------------------------------ export.py:418-441
     @torch.no_grad()
@@ -165,5 +172,69 @@ class Streamer:
         structure = self.structure(x[:, :1].contiguous())
         timbre = self.timbre(x[:, 1:].contiguous())
         return self.generate(torch.cat((structure, timbre), 1), noise)
+
+    __call__ = forward
+
+
+
+class MidiStreamer(Streamer):
+    """`Streamer` of after_scripts/export_midi.py:150-470 (MIDI-conditioned models: no structure
+    encoder, `time_cond` is a 128-row piano roll built from `n_poly` (pitch, velocity) signal pairs,
+    CFG rows (c, tc) / (c, -4) / (-4, -4) with factor g_s / max(g_t, 0.1), :329-358)."""
+    cfg_mode = _lib.CFG_MIDI
+    uses_structure_encoder = False
+
+    def __init__(self, blender: RectifiedFlow, emb_model: AutoEncoder, n_poly: int = 4, **kw):
+        if blender.encoder_time is not None:
+            raise ValueError("MidiStreamer is for MIDI-structure models (encoder_time = None, midi.gin:66)")
+        self.n_poly = int(n_poly)
+        super().__init__(blender, emb_model, **kw)
+        if getattr(blender, "post_encoder", None) is not None:
+            raise NotImplementedError("post_encoder is not built (every shipped config: None)")
+
+    def structure(self, x):
+        raise AttributeError("the MIDI streamer has no structure encoder (export_midi.py)")
+
+    @torch.no_grad()
+    def timbre(self, x):
+        """export_midi.py:399-414: like the audio streamer, repeated over the chunk's latent frames."""
+        z = self.emb_model_timbre.encode(x)[0]
+        n = z.shape[0]
+        self.previous_timbre[:n] = torch.cat((self.previous_timbre[:n], z), -1)[..., z.shape[-1]:]
+        zsem = self.encoder.forward_stream(self.previous_timbre[:n].contiguous())
+        return zsem.unsqueeze(-1).repeat(1, 1, z.shape[-1]) / self.latent_range
+
+    @torch.no_grad()
+    def piano_roll(self, notes):
+        """export_midi.py:424-432.  notes: [n, 2 * n_poly, T] = (pitch, velocity) rows per voice.
+        Where voice i sounds at frame j (velocity > 0), the rows of every pitch that voice holds
+        within the chunk get velocity(j) / 128; later voices overwrite earlier ones.  Only stream 0
+        conditions the diffusion (the reference samples `x[:1]`), so the roll is [1, 128, T]."""
+        T = notes.shape[-1]
+        n_rows = self.zs_channels  # 128 for MIDI models (midi.gin:13); the reference hard-codes it
+        tc = torch.zeros(1, n_rows, T, device=notes.device)
+        jj = torch.arange(T, device=notes.device)
+        for i in range(self.n_poly):
+            pitch = notes[0, 2 * i].long().clamp(0, n_rows - 1)
+            vel = notes[0, 2 * i + 1]
+            on = vel > 0
+            rows = pitch[:, None].expand(T, T)[:, on]          # every held pitch x sounding frames
+            cols = jj[None, :].expand(T, T)[:, on]
+            tc[0].index_put_((rows.reshape(-1), cols.reshape(-1)), (vel[None, :].expand(T, T)[:, on] / 128).reshape(-1))
+        return tc
+
+    @torch.no_grad()
+    def diffuse(self, x, noise=None):
+        """export_midi.py:416-441.  x: [n, 2 * n_poly + zt_channels, T]."""
+        n = x.shape[0]
+        zsem = x[:, -self.zt_channels:].mean(-1) * self.latent_range
+        time_cond = self.piano_roll(x[:, :2 * self.n_poly])
+        if noise is None:
+            noise = torch.randn(n, self.ae_latents, x.shape[-1], device=x.device)
+        out = self.sample(noise[:1].contiguous(), zsem[:1].contiguous(), time_cond)
+        return out.repeat(n, 1, 1) if n > 1 else out
+
+    def forward(self, x, noise=None):
+        raise AttributeError("export_midi.py registers timbre / diffuse / generate / decode only")
 
     __call__ = forward

@@ -70,3 +70,51 @@ def test_streamer_forward_shapes_and_limits(hip_device):
         st.set_nb_steps(3)
     with pytest.raises(ValueError):
         st(torch.randn(1, 2, 1000, device=hip_device))
+
+
+def test_midi_streamer_matches_oracle(hip_device):
+    """export_midi.py's Streamer: piano-roll conditioning + CFG_MIDI cached sampler, chunk by chunk
+    against the oracle's K/V-cache sampler (pinned by stream_micro.npz) with the same roll."""
+    from after_amd import MidiStreamer
+    from oracle.sampler import CFG_MIDI
+    model, dcfg, acfg = pipeline.build_models("micro_midi", "microAE_causal", hip_device, seed=8)
+    sd_net, sd_enc, _ = split_sd(model)
+    ncfg = dcfg["net"]
+    chunk, steps, n_chunks, nsig, n_poly = 4, 3, 4, 16, 2
+    st = MidiStreamer(model, model.emb_model, n_poly=n_poly, chunk_size=chunk, n_signal_timbre=nsig,
+                      max_batch=1, max_nb_steps=steps)
+    st.set_nb_steps(steps)
+    st.set_guidance_timbre(1.5)
+    st.set_guidance_structure(2.0)
+    g = torch.Generator().manual_seed(21)
+    H = ncfg["embed_dim"] // 64
+    cache = oracle.DenoiserCache(ncfg["n_layers"], 3, steps, H, ncfg["local_attention_size"], 64)
+    tvals = torch.linspace(0, 1, steps + 1)[:-1]
+    for c in range(n_chunks):
+        notes = torch.zeros(1, 2 * n_poly, chunk)
+        notes[0, 0] = float(5 + c)            # voice 0: one held pitch
+        notes[0, 1] = torch.tensor([0., 90., 90., 40.])
+        notes[0, 2] = torch.tensor([9., 9., 12., 12.])  # voice 1 changes pitch inside the chunk
+        notes[0, 3] = torch.tensor([64., 0., 64., 100.])
+        zsem = torch.randn(1, st.zt_channels, generator=g)
+        x = torch.cat((notes, zsem.unsqueeze(-1).repeat(1, 1, chunk)), 1)
+        noise = torch.randn(1, st.ae_latents, chunk, generator=g)
+        # reference recipe, literally (export_midi.py:424-432, n = 1)
+        tc = torch.zeros(1, ncfg["tcond_dim"], chunk)
+        for i in range(n_poly):
+            for j in range(chunk):
+                if notes[0, 2 * i + 1, j] > 0:
+                    tc[:, notes[:, 2 * i].long(), j] = notes[:, 2 * i + 1, j] / 128
+        assert torch.equal(st.piano_roll(notes.to(hip_device)).cpu(), tc)
+        want = noise
+        for i, t in enumerate(tvals):
+            tt = t.reshape(1, 1, 1)
+            want = want + oracle.model_forward(sd_net, ncfg, want, tt, zsem, tc, 1.5, 2.0, -4.0, CFG_MIDI,
+                                               cache=cache, cache_index=i) * (1 / steps)
+            cache.roll(chunk, i)
+        got = st.diffuse(x.to(hip_device), noise.to(hip_device)).cpu()
+        assert max_abs(got, want) < 5e-4, (c, max_abs(got, want))
+    y = st.decode(got.to(hip_device))
+    assert y.shape == (1, 1, chunk * st.ae_ratio) and torch.isfinite(y).all()
+    z = st.timbre(torch.randn(1, 1, chunk * st.ae_ratio, device=hip_device))
+    assert z.shape == (1, st.zt_channels, chunk)
