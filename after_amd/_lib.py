@@ -33,6 +33,13 @@ class Encoder1dCfg(ctypes.Structure):
                 ("use_tanh", c_int)]
 
 
+class Unet1dCfg(ctypes.Structure):
+    _fields_ = [("in_size", c_int), ("out_size", c_int), ("n_blocks", c_int), ("channels", c_int * 8),
+                ("ratios", c_int * 8), ("kernel_size", c_int), ("time_channels", c_int),
+                ("time_cond_in_channels", c_int), ("time_cond_channels", c_int),
+                ("cond_channels", c_int), ("use_res_last", c_int)]
+
+
 class EcapaCfg(ctypes.Structure):
     _fields_ = [("in_size", c_int), ("out_dim", c_int), ("n_blocks", c_int),
                 ("channels", c_int * 8), ("kernel_sizes", c_int * 8), ("dilations", c_int * 8),
@@ -87,6 +94,11 @@ SIGNATURES = {
                                    POINTER(c_void_p)]),
     "after_ecapa_destroy": (None, [c_void_p]),
     "after_ecapa_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "after_unet1d_create": (c_int, [POINTER(Unet1dCfg), POINTER(c_void_p), c_int, c_int, c_int,
+                                    POINTER(c_void_p)]),
+    "after_unet1d_destroy": (None, [c_void_p]),
+    "after_unet1d_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                     c_int, c_void_p]),
     "after_gemm_set_debug": (None, [c_void_p]),
     "after_gemm_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

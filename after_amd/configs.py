@@ -96,6 +96,28 @@ def diffusion_config(name: str) -> dict:
     return copy.deepcopy(DIFFUSION[name])
 
 
+# UNET1D (after/diffusion/networks/unet1d.py:254-268): no shipped gin config selects it; these are
+# the constructor defaults adapted to the codec latent sizes, plus a reduced one for the fixtures
+UNET = {
+    "unet_base": dict(in_size=IN_SIZE, channels=[128, 128, 256, 256], ratios=[2, 2, 2, 2, 2], kernel_size=5,
+                      time_channels=64, time_cond_in_channels=12, time_cond_channels=64, cond_channels=6,
+                      n_attn_layers=0, use_res_last=False),
+    "unet_micro": dict(in_size=16, channels=[32, 32, 64, 64], ratios=[2, 2, 2, 2, 2], kernel_size=5,
+                       time_channels=64, time_cond_in_channels=12, time_cond_channels=16, cond_channels=6,
+                       n_attn_layers=0, use_res_last=False),
+    "unet_micro_flat": dict(in_size=16, out_size=16, channels=[32, 64], ratios=[1, 2], kernel_size=3,
+                            time_channels=32, time_cond_in_channels=12, time_cond_channels=16,
+                            cond_channels=6, n_attn_layers=0, use_res_last=True),
+}
+
+
+def unet_config(name: str = "unet_base") -> dict:
+    import copy
+    if name not in UNET:
+        raise KeyError(f"unknown UNET1D config {name!r}; have {sorted(UNET)}")
+    return copy.deepcopy(UNET[name])
+
+
 def autoencoder_config(name: str = "baseAE") -> dict:
     if name not in AUTOENCODER:
         raise KeyError(f"unknown autoencoder config {name!r}; have {sorted(AUTOENCODER)}")

@@ -37,6 +37,7 @@ struct ConvArgs {
     int res_bstride, res_coff;
     int x2_bstride, x2_coff;
     int bias_bstride;    // 0: bias[Cout] shared; else bias[b * bias_bstride + co]
+    int post_bstride;    // 0: post_scale/shift[Cout] shared; else [b * post_bstride + co] (FiLM)
     int scale_bstride;   // 0: scale/shift[Cin] shared over the batch; else [b * stride + ci]
     int taps, phases, istride, ostride;
     int Nn;              // output positions per phase

@@ -228,7 +228,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, ConvGeom gm)
                 float v = acc[i][j][r] + (a.bias ? a.bias[(size_t)b * a.bias_bstride + co] : 0.f);
                 if (rb) v += rb[(size_t)co * a.Tout + to];
                 if (a.out_act != ACT_NONE) v = apply_act(v, a.out_act, 0.f, 0.f);
-                if (a.post_scale) v = v * a.post_scale[co] + a.post_shift[co];
+                if (a.post_scale)
+                    v = v * a.post_scale[(size_t)b * a.post_bstride + co] + a.post_shift[(size_t)b * a.post_bstride + co];
                 yb[(size_t)co * a.Tout + to] = v;
             }
         }

@@ -1,0 +1,501 @@
+// UNET1D: the Conv1d / GroupNorm / SiLU / FiLM denoiser (reference
+// after/diffusion/networks/unet1d.py:254-429, blocks :29-252) on gfx950.
+//
+// Not selected by any shipped gin config (all four use DenoiserV2); built from SURVEY 8(f)-4 on
+// the conv family of conv.hip: GroupNorm folded to a per-(clip, channel) affine
+// (gn_affine_kernel), SiLU applied while the tile is staged, implicit-GEMM conv on the fp32
+// MFMA pipe, FiLM (time and cond modulation, unet1d.py:100-110) as a per-(clip, channel)
+// affine in the conv epilogue, strided pools via istride, nearest upsampling materialised.
+// Supported: time_cond_channels > 0, cond_channels > 0, n_attn_layers = 0 (the defaults).
+#include <new>
+#include <vector>
+
+#include "conv.h"
+
+namespace after {
+namespace {
+
+// SPE (unet1d.py:7-24): cat[sin(w x), cos(w x)], x = 32 t, w_i = (1/10000)^(2 i / dim)
+__global__ void spe_kernel(const float* __restrict__ t, float* __restrict__ out, int B, int dim,
+                           float max_positions, float scale) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int half = dim / 2;
+    if (idx >= B * half) return;
+    const int b = idx / half, i = idx - b * half;
+    const float x = t[b] * scale;
+    const float w = powf(1.0f / max_positions, (2.0f * (float)i) / (float)dim);
+    out[(size_t)b * dim + i] = sinf(w * x);
+    out[(size_t)b * dim + half + i] = cosf(w * x);
+}
+
+// FiLM parameters of one ConvBlock1D (unet1d.py:100-110): for clip b
+//   [tm | ta] = W2t silu(W1t emb_t + b1t) + b2t,  [cm | ca] = W2c silu(W1c cond + b1c) + b2c
+//   (conv + bias) * tm + ta, then * cm + ca   ==   (conv + bias) * ps + pt
+//   ps = tm cm,  pt = ta cm + ca.                 One workgroup per clip.
+struct FilmArgs {
+    const float *emb, *cond;             // [B, TC], [B, CC]
+    const float *w1t, *b1t, *w2t, *b2t;  // [128, TC], [128], [2C, 128], [2C]
+    const float *w1c, *b1c, *w2c, *b2c;  // [128, CC], ...
+    float *ps, *pt;                      // [B, C]
+    int TC, CC, C, H;                    // H = 128
+};
+__global__ __launch_bounds__(256) void film_kernel(FilmArgs a) {
+    __shared__ float ht[256], hc[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int j = tid; j < a.H; j += 256) {
+        float st = a.b1t[j], sc = a.b1c[j];
+        for (int k = 0; k < a.TC; ++k) st += a.w1t[(size_t)j * a.TC + k] * a.emb[(size_t)b * a.TC + k];
+        for (int k = 0; k < a.CC; ++k) sc += a.w1c[(size_t)j * a.CC + k] * a.cond[(size_t)b * a.CC + k];
+        ht[j] = st / (1.0f + expf(-st));
+        hc[j] = sc / (1.0f + expf(-sc));
+    }
+    __syncthreads();
+    for (int c = tid; c < a.C; c += 256) {
+        float tm = a.b2t[c], ta = a.b2t[a.C + c], cm = a.b2c[c], ca = a.b2c[a.C + c];
+        for (int k = 0; k < a.H; ++k) {
+            tm += a.w2t[(size_t)c * a.H + k] * ht[k];
+            ta += a.w2t[(size_t)(a.C + c) * a.H + k] * ht[k];
+            cm += a.w2c[(size_t)c * a.H + k] * hc[k];
+            ca += a.w2c[(size_t)(a.C + c) * a.H + k] * hc[k];
+        }
+        a.ps[(size_t)b * a.C + c] = tm * cm;
+        a.pt[(size_t)b * a.C + c] = ta * cm + ca;
+    }
+}
+
+// dst[b, coff + c, t] = src[b, c, t]
+__global__ __launch_bounds__(256) void put_slice_kernel(const float* __restrict__ src,
+                                                        float* __restrict__ dst, int Cs, int T,
+                                                        int Cd, int coff, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const size_t per = (size_t)Cs * T;
+    const int b = idx / per;
+    const size_t r = idx - (size_t)b * per;
+    dst[((size_t)b * Cd + coff) * T + r] = src[idx];
+}
+
+// nn.Upsample(mode='nearest', scale_factor=r): y[b, c, t] = x[b, c, t / r]
+__global__ __launch_bounds__(256) void upsample_nearest_kernel(const float* __restrict__ x,
+                                                               float* __restrict__ y, int T, int r,
+                                                               size_t total) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const size_t row = idx / ((size_t)T * r);
+    const int t = idx - row * ((size_t)T * r);
+    y[idx] = x[row * T + t / r];
+}
+
+struct WCur {
+    const float* const* w;
+    int n, i = 0;
+    bool ok = true;
+    const float* next() {
+        if (i >= n || !w[i]) {
+            ok = false;
+            ++i;
+            return nullptr;
+        }
+        return w[i++];
+    }
+    const float* opt() {  // may legitimately be null
+        if (i >= n) {
+            ok = false;
+            return nullptr;
+        }
+        return w[i++];
+    }
+};
+
+struct PackedConv {
+    float *w = nullptr, *bias = nullptr;
+    int cin = 0, cout = 0, k = 1;
+};
+struct BlockW {  // ConvBlock1D
+    PackedConv c1, c2, to_out;
+    float *gn1_w = nullptr, *gn1_b = nullptr, *gn2_w = nullptr, *gn2_b = nullptr;
+    float *w1t, *b1t, *w2t, *b2t, *w1c, *b1c, *w2c, *b2c;
+    int in_c = 0, skip_c = 0, tc_c = 0, out_c = 0;
+    bool res = true, has_to_out = false;
+};
+
+}  // namespace
+}  // namespace after
+
+using namespace after;
+
+struct after_unet1d {
+    after_unet1d_cfg cfg;
+    int max_batch, max_T, n;
+    Arena wa, ws;
+    std::vector<PackedConv> cond_emb;  // n + 1
+    std::vector<BlockW> down, up;      // n each
+    std::vector<PackedConv> pool, upconv;
+    std::vector<char> up_has_conv;
+    BlockW mid;
+    // workspaces
+    float *emb = nullptr, *ps = nullptr, *pt = nullptr, *scale = nullptr, *shift = nullptr;
+    double* gn_part = nullptr;
+    unsigned* gn_tick = nullptr;
+    float *cat = nullptr, *tmp = nullptr, *resb = nullptr, *xa = nullptr, *xb = nullptr, *ups = nullptr;
+    std::vector<float*> skips, tconds;  // n each (+1 tcond for the middle block)
+    int cmax = 0, ccat_max = 0;
+};
+
+namespace {
+
+int dev_copy(Arena& a, float** dst, const float* src, size_t n) {
+    *dst = a.take<float>(n);
+    AFTER_REQUIRE(*dst, AFTER_E_NOMEM, "unet1d: weight arena exhausted");
+    AFTER_HIP_CHECK(hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyDeviceToDevice));
+    return AFTER_OK;
+}
+
+int load_pconv(Arena& a, WCur& c, PackedConv& p, int cin, int cout, int k) {
+    p.cin = cin;
+    p.cout = cout;
+    p.k = k;
+    const float* w = c.next();
+    const float* b = c.next();
+    AFTER_REQUIRE(c.ok, AFTER_E_INVALID, "unet1d: missing conv tensors");
+    p.w = a.take<float>((size_t)cout * k * pad16(cin));
+    AFTER_REQUIRE(p.w, AFTER_E_NOMEM, "unet1d: weight arena exhausted");
+    AFTER_TRY(pack_conv_weight(w, nullptr, p.w, cout, cin, k, pad16(cin), 0));
+    return dev_copy(a, &p.bias, b, cout);
+}
+
+int gn_groups(int C) { return C / 4 < 16 ? C / 4 : 16; }  // unet1d.py:52-54,65
+
+int load_block(Arena& a, WCur& c, BlockW& b, int in_c, int out_c, int skip_c, int tc_c, int k, int TC,
+               int CC, bool res) {
+    b.in_c = in_c;
+    b.out_c = out_c;
+    b.skip_c = skip_c;
+    b.tc_c = tc_c;
+    b.res = res;
+    const int ccat = in_c + skip_c + tc_c;
+    AFTER_REQUIRE(gn_groups(ccat) > 0 && ccat % gn_groups(ccat) == 0 && gn_groups(out_c) > 0 &&
+                      out_c % gn_groups(out_c) == 0,
+                  AFTER_E_INVALID,
+                  "unet1d: GroupNorm(min(16, C/4), C) undefined for C=%d / %d (the reference "
+                  "silently replaces it by Identity; not built)", ccat, out_c);
+    AFTER_TRY(load_pconv(a, c, b.c1, ccat, out_c, k));
+    const float *g1w = c.next(), *g1b = c.next();
+    AFTER_REQUIRE(c.ok, AFTER_E_INVALID, "unet1d: missing gn1");
+    AFTER_TRY(dev_copy(a, &b.gn1_w, g1w, ccat));
+    AFTER_TRY(dev_copy(a, &b.gn1_b, g1b, ccat));
+    AFTER_TRY(load_pconv(a, c, b.c2, out_c, out_c, k));
+    const float *g2w = c.next(), *g2b = c.next();
+    AFTER_REQUIRE(c.ok, AFTER_E_INVALID, "unet1d: missing gn2");
+    AFTER_TRY(dev_copy(a, &b.gn2_w, g2w, out_c));
+    AFTER_TRY(dev_copy(a, &b.gn2_b, g2b, out_c));
+    const float* m[8];
+    for (int i = 0; i < 8; ++i) m[i] = c.next();
+    AFTER_REQUIRE(c.ok, AFTER_E_INVALID, "unet1d: missing FiLM MLP tensors");
+    AFTER_TRY(dev_copy(a, &b.w1t, m[0], (size_t)128 * TC));
+    AFTER_TRY(dev_copy(a, &b.b1t, m[1], 128));
+    AFTER_TRY(dev_copy(a, &b.w2t, m[2], (size_t)2 * out_c * 128));
+    AFTER_TRY(dev_copy(a, &b.b2t, m[3], 2 * out_c));
+    AFTER_TRY(dev_copy(a, &b.w1c, m[4], (size_t)128 * CC));
+    AFTER_TRY(dev_copy(a, &b.b1c, m[5], 128));
+    AFTER_TRY(dev_copy(a, &b.w2c, m[6], (size_t)2 * out_c * 128));
+    AFTER_TRY(dev_copy(a, &b.b2c, m[7], 2 * out_c));
+    b.has_to_out = skip_c > 0;  // unet1d.py:78-81
+    if (b.has_to_out) AFTER_TRY(load_pconv(a, c, b.to_out, in_c, out_c, 1));
+    AFTER_REQUIRE(b.has_to_out || in_c == out_c || !res, AFTER_E_INVALID,
+                  "unet1d: identity shortcut with in_c != out_c");
+    return AFTER_OK;
+}
+
+size_t conv_fl(int cin, int cout, int k) { return (size_t)cout * k * pad16(cin) + cout + 128; }
+size_t block_fl(int in_c, int out_c, int skip_c, int tc_c, int k, int TC, int CC) {
+    const int ccat = in_c + skip_c + tc_c;
+    return conv_fl(ccat, out_c, k) + conv_fl(out_c, out_c, k) + conv_fl(in_c, out_c, 1) + 2 * (size_t)ccat +
+           2 * (size_t)out_c + 128 * (size_t)(TC + CC) + 256 + 4 * (size_t)out_c * 128 + 4 * (size_t)out_c + 2048;
+}
+
+int conv_same(after_unet1d* h, hipStream_t s, const PackedConv& p, const float* x, float* y, int B, int Tin,
+              int stride, const float* scale, const float* shift, int act, int out_act,
+              const float* res, const float* ps, const float* pt) {
+    (void)h;
+    const int Tout = Tin / stride;
+    ConvArgs a;
+    conv_args_init(a, B, p.cin, p.cout, Tin, Tout);
+    a.x = x;
+    a.y = y;
+    a.w = p.w;
+    a.bias = p.bias;
+    a.res = res;
+    a.scale = scale;
+    a.shift = shift;
+    a.act = act;
+    a.out_act = out_act;
+    a.taps = p.k;
+    a.istride = stride;
+    a.post_scale = ps;
+    a.post_shift = pt;
+    a.post_bstride = ps ? p.cout : 0;
+    for (int t = 0; t < p.k; ++t) a.toff[0][t] = t - p.k / 2;  // padding "same" (odd k) / k // 2
+    return launch_conv(a, s);
+}
+
+int put_slice(hipStream_t s, const float* src, float* dst, int B, int Cs, int T, int Cd, int coff) {
+    const size_t total = (size_t)B * Cs * T;
+    hipLaunchKernelGGL(put_slice_kernel, dim3((unsigned)cdivll((long long)total, 256)), dim3(256), 0, s, src,
+                       dst, Cs, T, Cd, coff, total);
+    AFTER_HIP_CHECK(hipGetLastError());
+    return AFTER_OK;
+}
+
+int group_affine(after_unet1d* h, hipStream_t s, const float* x, const float* gamma, const float* beta,
+                 int B, int C, int T) {
+    GnArgs g;
+    g.x = x;
+    g.gamma = gamma;
+    g.beta = beta;
+    g.scale = h->scale;
+    g.shift = h->shift;
+    g.partials = h->gn_part;
+    g.tickets = h->gn_tick;
+    g.B = B;
+    g.C = C;
+    g.T = T;
+    g.G = gn_groups(C);
+    g.splits = gn_splits(C, T, g.G);
+    g.eps = 1e-5f;
+    return launch_gn_affine(g, s);
+}
+
+// ConvBlock1D.forward (unet1d.py:83-118)
+int run_block(after_unet1d* h, hipStream_t s, const BlockW& b, const float* x, const float* skip,
+              const float* tcond, const float* cond, float* y, int B, int T) {
+    const int ccat = b.in_c + b.skip_c + b.tc_c;
+    const float* in = x;
+    if (b.skip_c || b.tc_c) {
+        AFTER_TRY(put_slice(s, x, h->cat, B, b.in_c, T, ccat, 0));
+        if (b.skip_c) AFTER_TRY(put_slice(s, skip, h->cat, B, b.skip_c, T, ccat, b.in_c));
+        if (b.tc_c) AFTER_TRY(put_slice(s, tcond, h->cat, B, b.tc_c, T, ccat, b.in_c + b.skip_c));
+        in = h->cat;
+    }
+    FilmArgs f{h->emb, cond, b.w1t, b.b1t, b.w2t, b.b2t, b.w1c, b.b1c, b.w2c, b.b2c, h->ps, h->pt,
+               h->cfg.time_channels, h->cfg.cond_channels, b.out_c, 128};
+    hipLaunchKernelGGL(film_kernel, dim3(B), dim3(256), 0, s, f);
+    AFTER_HIP_CHECK(hipGetLastError());
+    AFTER_TRY(group_affine(h, s, in, b.gn1_w, b.gn1_b, B, ccat, T));
+    AFTER_TRY(conv_same(h, s, b.c1, in, h->tmp, B, T, 1, h->scale, h->shift, ACT_SILU, ACT_NONE, nullptr,
+                        h->ps, h->pt));
+    const float* res = nullptr;
+    if (b.res) {
+        res = x;
+        if (b.has_to_out) {
+            AFTER_TRY(conv_same(h, s, b.to_out, x, h->resb, B, T, 1, nullptr, nullptr, ACT_NONE, ACT_NONE,
+                                nullptr, nullptr, nullptr));
+            res = h->resb;
+        }
+    }
+    AFTER_TRY(group_affine(h, s, h->tmp, b.gn2_w, b.gn2_b, B, b.out_c, T));
+    return conv_same(h, s, b.c2, h->tmp, y, B, T, 1, h->scale, h->shift, ACT_SILU, ACT_NONE, res, nullptr,
+                     nullptr);
+}
+
+}  // namespace
+
+extern "C" int after_unet1d_create(const after_unet1d_cfg* cfg, const float* const* weights,
+                                   int n_weights, int max_batch, int max_T, after_unet1d** out) {
+    AFTER_REQUIRE(cfg && weights && out, AFTER_E_INVALID, "null argument");
+    *out = nullptr;
+    const int n = cfg->n_blocks, k = cfg->kernel_size;
+    AFTER_REQUIRE(n >= 1 && n <= 8 && k % 2 == 1 && k <= kMaxTaps, AFTER_E_INVALID,
+                  "unet1d: 1..8 blocks and an odd kernel_size <= %d required", kMaxTaps);
+    AFTER_REQUIRE(cfg->time_cond_channels > 0 && cfg->cond_channels > 0 && cfg->time_channels > 0 &&
+                      cfg->time_channels % 2 == 0,
+                  AFTER_E_INVALID,
+                  "unet1d: built for time_cond_channels > 0, cond_channels > 0, even time_channels");
+    AFTER_REQUIRE(cfg->ratios[0] == 1, AFTER_E_INVALID, "unet1d: ratios[0] is the prepended 1 (unet1d.py:283)");
+    AFTER_REQUIRE(max_batch > 0 && max_T > 0, AFTER_E_INVALID, "bad capacities");
+    after_unet1d* h = new (std::nothrow) after_unet1d();
+    AFTER_REQUIRE(h, AFTER_E_NOMEM, "out of host memory");
+    h->cfg = *cfg;
+    h->n = n;
+    h->max_batch = max_batch;
+    int total_ratio = 1;
+    for (int i = 0; i < n; ++i) total_ratio *= cfg->ratios[i];
+    h->max_T = (max_T / total_ratio) * total_ratio;
+    auto fail = [&](int rc) {
+        after_unet1d_destroy(h);
+        return rc;
+    };
+    const int TC = cfg->time_channels, CC = cfg->cond_channels, tcc = cfg->time_cond_channels;
+    const int in0 = cfg->in_size, outsz = cfg->out_size > 0 ? cfg->out_size : cfg->in_size;
+    const int* ch = cfg->channels;
+    auto in_of = [&](int i) { return i == 0 ? in0 : ch[i - 1]; };
+    size_t wf = conv_fl(cfg->time_cond_in_channels, tcc, k) + n * conv_fl(tcc, tcc, k);
+    int cmax = in0 > outsz ? in0 : outsz, ccat_max = 0;
+    for (int i = 0; i < n; ++i) {
+        wf += block_fl(in_of(i), in_of(i), 0, tcc, k, TC, CC) + conv_fl(in_of(i), ch[i], k);
+        cmax = ch[i] > cmax ? ch[i] : cmax;
+        ccat_max = in_of(i) + tcc > ccat_max ? in_of(i) + tcc : ccat_max;
+    }
+    wf += block_fl(ch[n - 1], ch[n - 1], 0, tcc, k, TC, CC);
+    ccat_max = ch[n - 1] + tcc > ccat_max ? ch[n - 1] + tcc : ccat_max;
+    for (int i = 1; i <= n; ++i) {
+        const int ic = ch[n - i], oc = i < n ? ch[n - i - 1] : outsz;
+        const int sk = i < n ? oc : in0;
+        wf += conv_fl(ic, oc, 3) + block_fl(oc, oc, sk, tcc, k, TC, CC);
+        ccat_max = oc + sk + tcc > ccat_max ? oc + sk + tcc : ccat_max;
+        cmax = oc > cmax ? oc : cmax;
+    }
+    h->cmax = cmax;
+    h->ccat_max = ccat_max;
+    int rc = h->wa.init(wf * sizeof(float) + (1 << 20));
+    if (rc) return fail(rc);
+    WCur cur{weights, n_weights};
+#define U_TRY(expr)                            \
+    do {                                       \
+        int rc2__ = (expr);                    \
+        if (rc2__ != AFTER_OK) return fail(rc2__); \
+    } while (0)
+    // cond_emb_time (unet1d.py:296-313): entry 0: in -> tcc stride 1; entry i: stride ratios[i-1]
+    h->cond_emb.resize(n + 1);
+    U_TRY(load_pconv(h->wa, cur, h->cond_emb[0], cfg->time_cond_in_channels, tcc, k));
+    for (int i = 1; i <= n; ++i) U_TRY(load_pconv(h->wa, cur, h->cond_emb[i], tcc, tcc, k));
+    // down layers (:318-340): ConvBlock(in -> in) then pool(in -> channels[i], stride ratios[i])
+    h->down.resize(n);
+    h->pool.resize(n);
+    for (int i = 0; i < n; ++i) {
+        U_TRY(load_block(h->wa, cur, h->down[i], in_of(i), in_of(i), 0, tcc, k, TC, CC, true));
+        U_TRY(load_pconv(h->wa, cur, h->pool[i], in_of(i), ch[i], k));
+    }
+    U_TRY(load_block(h->wa, cur, h->mid, ch[n - 1], ch[n - 1], 0, tcc, k, TC, CC, true));
+    // up layers (:341-372): i = 1..n-1: channels[n-i] -> channels[n-i-1], ratio ratios[n-i];
+    // last: channels[0] -> out_size, ratio ratios[0], skip = in_size, res = use_res_last
+    h->up.resize(n);
+    h->upconv.resize(n);
+    h->up_has_conv.assign(n, 0);
+    for (int i = 1; i <= n; ++i) {
+        const int ic = ch[n - i], oc = i < n ? ch[n - i - 1] : outsz;
+        const int sk = i < n ? oc : in0;
+        const int ratio = cfg->ratios[n - i];
+        const bool has_conv = ratio != 1 || ic != oc;  // blocks DecoderBlock1D.__init__ :206-221
+        h->up_has_conv[i - 1] = has_conv;
+        if (has_conv) {
+            U_TRY(load_pconv(h->wa, cur, h->upconv[i - 1], ic, oc, 3));
+        } else {
+            (void)cur.opt();
+            (void)cur.opt();
+        }
+        U_TRY(load_block(h->wa, cur, h->up[i - 1], oc, oc, sk, tcc, k, TC, CC, i < n ? true : cfg->use_res_last != 0));
+    }
+#undef U_TRY
+    if (!cur.ok || cur.i != n_weights) {
+        set_error("unet1d: expected %d weight tensors, got %d", cur.i, n_weights);
+        return fail(AFTER_E_INVALID);
+    }
+    // workspaces
+    const size_t T = h->max_T, Bm = max_batch;
+    const size_t act = Bm * cmax * T, catn = Bm * ccat_max * T, tcn = Bm * tcc * T;
+    size_t bytes = (Bm * TC + 2 * Bm * cmax + 2 * Bm * ccat_max) * sizeof(float) +
+                   Bm * 16 * 64 * 2 * sizeof(double) + Bm * 16 * sizeof(unsigned) +
+                   (catn + 5 * act + (size_t)n * act + (size_t)(n + 2) * tcn) * sizeof(float) + (1 << 16);
+    if ((rc = h->ws.init(bytes))) return fail(rc);
+    h->emb = h->ws.take<float>(Bm * TC);
+    h->ps = h->ws.take<float>(Bm * cmax);
+    h->pt = h->ws.take<float>(Bm * cmax);
+    h->scale = h->ws.take<float>(Bm * ccat_max);
+    h->shift = h->ws.take<float>(Bm * ccat_max);
+    h->gn_part = h->ws.take<double>(Bm * 16 * 64 * 2);
+    h->gn_tick = h->ws.take<unsigned>(Bm * 16);
+    h->cat = h->ws.take<float>(catn);
+    h->tmp = h->ws.take<float>(act);
+    h->resb = h->ws.take<float>(act);
+    h->xa = h->ws.take<float>(act);
+    h->xb = h->ws.take<float>(act);
+    h->ups = h->ws.take<float>(act);
+    h->skips.resize(n);
+    h->tconds.resize(n + 2);
+    for (int i = 0; i < n; ++i) h->skips[i] = h->ws.take<float>(act);
+    for (int i = 0; i < n + 2; ++i) h->tconds[i] = h->ws.take<float>(tcn);
+    if (!h->tconds[n + 1] || !h->skips[n - 1] || !h->ups) return fail(AFTER_E_NOMEM);
+    if (hipMemset(h->gn_tick, 0, Bm * 16 * sizeof(unsigned)) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess) {
+        set_error("unet1d: device initialisation failed");
+        return fail(AFTER_E_HIP);
+    }
+    *out = h;
+    return AFTER_OK;
+}
+
+extern "C" void after_unet1d_destroy(after_unet1d* h) {
+    if (!h) return;
+    h->wa.release();
+    h->ws.release();
+    delete h;
+}
+
+// UNET1D.forward, time_cond_channels > 0 branch (unet1d.py:374-414)
+extern "C" int after_unet1d_forward(after_unet1d* h, const float* x, const float* time, const float* cond,
+                                    const float* time_cond, float* out, int B, int T, void* stream) {
+    AFTER_REQUIRE(h && x && time && cond && time_cond && out, AFTER_E_INVALID, "null argument");
+    AFTER_REQUIRE(B > 0 && T > 0, AFTER_E_INVALID, "empty batch");
+    AFTER_REQUIRE(B <= h->max_batch && T <= h->max_T, AFTER_E_CAPACITY,
+                  "B=%d T=%d exceed max_batch=%d max_T=%d", B, T, h->max_batch, h->max_T);
+    const after_unet1d_cfg& c = h->cfg;
+    const int n = h->n;
+    int total_ratio = 1;
+    for (int i = 0; i < n; ++i) total_ratio *= c.ratios[i];
+    AFTER_REQUIRE(T % total_ratio == 0, AFTER_E_INVALID, "unet1d: T=%d not a multiple of %d", T, total_ratio);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(spe_kernel, dim3(cdiv(B * c.time_channels / 2, 256)), dim3(256), 0, s, time, h->emb, B,
+                       c.time_channels, 10000.0f, 32.0f);
+    AFTER_HIP_CHECK(hipGetLastError());
+    // ---- encoder: time_cond is re-embedded (conv + SiLU) at every scale
+    const float* cur = x;
+    const float* tc = time_cond;
+    int Tc = T;  // length of x == length of the time_cond of this scale
+    std::vector<int> Ts(n);
+    for (int i = 0; i < n; ++i) {
+        const int tstride = i == 0 ? 1 : c.ratios[i - 1];
+        AFTER_TRY(conv_same(h, s, h->cond_emb[i], tc, h->tconds[i], B, i == 0 ? T : Ts[i - 1], tstride, nullptr,
+                            nullptr, ACT_NONE, ACT_SILU, nullptr, nullptr, nullptr));
+        tc = h->tconds[i];
+        Ts[i] = Tc;
+        AFTER_TRY(run_block(h, s, h->down[i], cur, nullptr, tc, cond, h->skips[i], B, Tc));
+        float* nx = (cur == h->xa) ? h->xb : h->xa;
+        AFTER_TRY(conv_same(h, s, h->pool[i], h->skips[i], nx, B, Tc, c.ratios[i], nullptr, nullptr, ACT_NONE,
+                            ACT_NONE, nullptr, nullptr, nullptr));
+        cur = nx;
+        Tc /= c.ratios[i];
+    }
+    AFTER_TRY(conv_same(h, s, h->cond_emb[n], tc, h->tconds[n], B, Ts[n - 1], c.ratios[n - 1], nullptr, nullptr,
+                        ACT_NONE, ACT_SILU, nullptr, nullptr, nullptr));
+    {
+        float* nx = (cur == h->xa) ? h->xb : h->xa;
+        AFTER_TRY(run_block(h, s, h->mid, cur, nullptr, h->tconds[n], cond, nx, B, Tc));
+        cur = nx;
+    }
+    // ---- decoder
+    for (int i = 1; i <= n; ++i) {
+        const int ratio = c.ratios[n - i];
+        const float* up_in = cur;
+        if (ratio != 1) {
+            const size_t total = (size_t)B * h->upconv[i - 1].cin * Tc * ratio;
+            hipLaunchKernelGGL(upsample_nearest_kernel, dim3((unsigned)cdivll((long long)total, 256)), dim3(256),
+                               0, s, cur, h->ups, Tc, ratio, total);
+            AFTER_HIP_CHECK(hipGetLastError());
+            up_in = h->ups;
+            Tc *= ratio;
+        }
+        float* ux = (cur == h->xa) ? h->xb : h->xa;
+        const float* bx = up_in;
+        if (h->up_has_conv[i - 1]) {
+            AFTER_TRY(conv_same(h, s, h->upconv[i - 1], up_in, ux, B, Tc, 1, nullptr, nullptr, ACT_NONE, ACT_NONE,
+                                nullptr, nullptr, nullptr));
+            bx = ux;
+        }
+        float* y = i == n ? out : ((bx == h->xa) ? h->xb : h->xa);
+        if (i < n && y == bx) y = h->ups;  // (identity `up`: keep input and output apart)
+        AFTER_TRY(run_block(h, s, h->up[i - 1], bx, h->skips[n - i], h->tconds[n - i], cond, y, B, Tc));
+        cur = y;
+    }
+    return AFTER_OK;
+}

@@ -1,2 +1,2 @@
-from .networks import DenoiserV2, Encoder1D, ECAPATDNN  # noqa: F401
+from .networks import DenoiserV2, Encoder1D, ECAPATDNN, UNET1D  # noqa: F401
 from .model import RectifiedFlow  # noqa: F401

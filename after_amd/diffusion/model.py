@@ -8,6 +8,7 @@ from torch import nn
 
 from .. import _lib
 from .networks.transformerv2 import DenoiserV2
+from .networks.unet1d import UNET1D
 
 
 class Base(nn.Module):
@@ -27,8 +28,8 @@ class Base(nn.Module):
                  device="cpu",
                  **kwargs):
         super().__init__()
-        if not isinstance(net, DenoiserV2):
-            raise TypeError("after_amd.RectifiedFlow needs an after_amd.DenoiserV2 as `net` "
+        if not isinstance(net, (DenoiserV2, UNET1D)):
+            raise TypeError("after_amd.RectifiedFlow needs an after_amd.DenoiserV2 (or UNET1D) as `net` "
                             f"(got {type(net).__name__}); there is no generic torch fallback")
         self.net = net
         self.encoder = encoder
@@ -66,12 +67,39 @@ class RectifiedFlow(Base):
                       guidance_structure: float,
                       cache_index: int = 0) -> torch.Tensor:
         """model.py:721-761."""
-        return self.net.cfg_forward(x, time, cond, time_cond, guidance_timbre, guidance_structure,
-                                    self.drop_value, self.cfg_mode, cache_index)
+        if isinstance(self.net, DenoiserV2):
+            return self.net.cfg_forward(x, time, cond, time_cond, guidance_timbre, guidance_structure,
+                                        self.drop_value, self.cfg_mode, cache_index)
+        # UNET1D: the 3x CFG batch is assembled on the device with torch ops (plumbing), the
+        # network evaluation itself runs in libafter_hip
+        full_time = time.reshape(-1).repeat(3)
+        full_x = x.repeat(3, 1, 1)
+        dc, dt_ = self.drop_value * torch.ones_like(cond), self.drop_value * torch.ones_like(time_cond)
+        if self.cfg_mode == _lib.CFG_MIDI:
+            full_cond, full_tc = torch.cat([cond, cond, dc]), torch.cat([time_cond, dt_, dt_])
+        else:
+            full_cond, full_tc = torch.cat([cond, dc, dc]), torch.cat([time_cond, time_cond, dt_])
+        dx = self.net(full_x, time=full_time, cond=full_cond, time_cond=full_tc)
+        dx_full, dx_mid, dx_none = torch.chunk(dx, 3, dim=0)
+        total = 0.5 * (guidance_structure + guidance_timbre)
+        if self.cfg_mode == _lib.CFG_API:
+            factor = guidance_timbre / max(guidance_structure, 0.01)
+        elif self.cfg_mode == _lib.CFG_EXPORT:
+            factor = guidance_timbre / max(guidance_structure, 0.1)
+        else:
+            factor = guidance_structure / max(guidance_timbre, 0.1)
+        return dx_none + total * (dx_mid + factor * (dx_full - dx_mid) - dx_none)
 
     @torch.no_grad()
     def sample(self, x0, cond, time_cond, nb_steps, guidance_timbre=1., guidance_structure=1.):
         """model.py:763-785."""
         x0 = x0.to(self.device)
-        return self.net.cfg_sample(x0, cond, time_cond, nb_steps, guidance_timbre,
-                                   guidance_structure, self.drop_value, self.cfg_mode)
+        if isinstance(self.net, DenoiserV2):
+            return self.net.cfg_sample(x0, cond, time_cond, nb_steps, guidance_timbre,
+                                       guidance_structure, self.drop_value, self.cfg_mode)
+        dt = 1 / nb_steps
+        x = x0
+        for t in torch.linspace(0, 1, nb_steps + 1)[:-1]:
+            tt = t.to(x0.device).repeat(x.shape[0], 1, 1)
+            x = x + self.model_forward(x, tt, cond, time_cond, guidance_timbre, guidance_structure) * dt
+        return x

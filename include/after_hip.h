@@ -265,6 +265,36 @@ void after_ecapa_destroy(after_ecapa* h);
  * (ecapa_encoder.py:567-624; regularisation "ac" leaves Z unchanged). */
 int after_ecapa_forward(after_ecapa* h, const float* z, float* out, int B, int T, void* stream);
 
+/* ---------------------------------------------------------------- UNET1D denoiser
+ * The Conv1d / GroupNorm / SiLU / FiLM alternative to DenoiserV2
+ * (after/diffusion/networks/unet1d.py:254-429; no shipped gin config selects it).
+ * Built for the default topology: time_cond_channels > 0, cond_channels > 0,
+ * n_attn_layers = 0; GroupNorm(min(16, C/4), C) must be well defined for every block. */
+typedef struct after_unet1d_cfg {
+    int in_size, out_size;   /* out_size <= 0: = in_size                                  */
+    int n_blocks;            /* len(channels)                                             */
+    int channels[8];
+    int ratios[8];           /* [1] + ratios of the constructor (unet1d.py:283)           */
+    int kernel_size;         /* odd                                                       */
+    int time_channels, time_cond_in_channels, time_cond_channels, cond_channels;
+    int use_res_last;
+} after_unet1d_cfg;
+/* weights (reference state_dict keys), CB(p) = p.conv1.{weight,bias} p.gn1.{weight,bias}
+ * p.conv2.{weight,bias} p.gn2.{weight,bias} p.time_mlp.{0,2}.{weight,bias}
+ * p.cond_mlp.{0,2}.{weight,bias} [p.to_out.{weight,bias} when the block takes a skip]:
+ *   cond_emb_time.i.0.{weight,bias}, i = 0..n
+ *   for i < n: CB(down_layers.i.conv) down_layers.i.pool.{weight,bias}
+ *   CB(middle_block.conv)
+ *   for j < n: up_layers.j.up[.1].{weight,bias} (NULL, NULL when `up` is Identity) CB(up_layers.j.conv) */
+typedef struct after_unet1d after_unet1d;
+int after_unet1d_create(const after_unet1d_cfg* cfg, const float* const* weights, int n_weights,
+                        int max_batch, int max_T, after_unet1d** out);
+void after_unet1d_destroy(after_unet1d* h);
+/* out[B, out_size, T] = net(x[B, in_size, T], time[B], cond[B, cond_channels],
+ * time_cond[B, time_cond_in_channels, T]).  Replaces: UNET1D.forward (unet1d.py:374-414). */
+int after_unet1d_forward(after_unet1d* h, const float* x, const float* time, const float* cond,
+                         const float* time_cond, float* out, int B, int T, void* stream);
+
 /* ------------------------------------------------------------ diagnostics
  * Not part of the reference's surface: the fp32 MFMA GEMM behind every Linear,
  * exposed for unit parity tests and roofline measurements.

@@ -33,3 +33,4 @@ from .autoencoder import (ae_encode, ae_decode, pqmf_forward, pqmf_inverse,  # n
                           fold_weight_norm)
 from .encoders import encoder1d_forward, ecapa_forward  # noqa: F401
 from .streaming import stream_forward  # noqa: F401
+from .unet1d import unet1d_forward  # noqa: F401

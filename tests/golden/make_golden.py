@@ -207,6 +207,19 @@ def encoders_case(case, cfg_name, B, T, seed):
     save(case, meta, **arrays)
 
 
+# ---------------------------------------------------------------- UNET1D
+def unet_case(case, cfg_name, B, T, seed):
+    cfg = configs.unet_config(cfg_name)
+    net = R.unet1d.UNET1D(**cfg)
+    meta = dict(kind="unet1d", config=cfg_name, seed=seed, B=B, T=T)
+    meta["shapes"], _ = refill(net, seed)
+    x = detweights.seeded_tensor("x", (B, cfg["in_size"], T), seed)
+    tc = detweights.seeded_tensor("time_cond", (B, cfg["time_cond_in_channels"], T), seed)
+    cond = detweights.seeded_tensor("cond", (B, cfg["cond_channels"]), seed)
+    time = torch.linspace(0.1, 0.9, B).reshape(B, 1, 1)
+    save(case, meta, x=x, time_cond=tc, cond=cond, time=time, y=net(x, time=time, time_cond=tc, cond=cond))
+
+
 CASES = {
     "pqmf_bank": pqmf_case,
     "mask_rope": mask_case,
@@ -223,6 +236,8 @@ CASES = {
     "encoders_micro": lambda: encoders_case("encoders_micro", "micro", 2, 64, 51),
     "encoders_tiny": lambda: encoders_case("encoders_tiny", "tiny", 1, 256, 52),
     "encoders_base": lambda: encoders_case("encoders_base", "base", 1, 256, 53),
+    "unet_micro": lambda: unet_case("unet_micro", "unet_micro", 2, 64, 61),
+    "unet_micro_flat": lambda: unet_case("unet_micro_flat", "unet_micro_flat", 3, 24, 62),
 }
 
 if __name__ == "__main__":

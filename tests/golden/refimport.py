@@ -85,4 +85,5 @@ def modules():
     out.ecapa = importlib.import_module("after.diffusion.networks.ecapa_encoder")
     out.ae = importlib.import_module("after.autoencoder.networks.SimpleNetsStream")
     out.pqmf = importlib.import_module("after.autoencoder.networks.pqmf")
+    out.unet1d = importlib.import_module("after.diffusion.networks.unet1d")
     return out

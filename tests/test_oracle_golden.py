@@ -151,3 +151,14 @@ def test_encoders_match_reference(case):
     sd = fx.state_dict("shapes_encoder", seed_offset=1)
     got = oracle.ecapa_forward(sd, z[..., :z.shape[-1] // 2], dcfg["encoder"])
     assert max_abs(got, fx.t("cond")) < 5e-5
+
+
+@pytest.mark.parametrize("case", ["unet_micro", "unet_micro_flat"])
+def test_unet1d_matches_reference(case):
+    fx = Fixture(case)
+    cfg = configs.unet_config(fx.meta["config"])
+    sd = fx.state_dict()
+    got = oracle.unet1d_forward(sd, cfg, fx.t("x"), fx.t("time"), fx.t("cond"), fx.t("time_cond"))
+    want = fx.t("y")
+    assert got.shape == want.shape
+    assert max_abs(got, want) < 2e-5 * max(1.0, want.abs().max().item())

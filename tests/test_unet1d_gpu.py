@@ -1,0 +1,76 @@
+"""UNET1D (after_unet1d_* through the C ABI) against the reference-generated golden vectors and the
+oracle on ragged shapes.  -m gpu.  Tolerance: ~20 conv layers with GroupNorm in fp32: 2e-4 x max|ref|."""
+import pytest
+import torch
+
+import oracle
+from after_amd import UNET1D, RectifiedFlow, configs
+from after_amd import _lib
+from fixtures import Fixture, max_abs
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def build(cfg_name, sd, dev):
+    net = UNET1D(**configs.unet_config(cfg_name))
+    res = net.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    return net.to(dev)
+
+
+@pytest.mark.parametrize("case", ["unet_micro", "unet_micro_flat"])
+def test_unet1d_golden(case, hip_device):
+    fx = Fixture(case)
+    net = build(fx.meta["config"], fx.state_dict(), hip_device)
+    d = lambda n: fx.t(n).to(hip_device)
+    got = net(d("x"), time=d("time"), time_cond=d("time_cond"), cond=d("cond")).cpu()
+    want = fx.t("y")
+    assert got.shape == want.shape
+    assert max_abs(got, want) < 2e-4 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("cfg_name,B,T", [("unet_micro", 1, 8), ("unet_micro", 3, 40), ("unet_micro_flat", 2, 6)])
+def test_unet1d_vs_oracle_shapes(cfg_name, B, T, hip_device):
+    fx = Fixture(cfg_name)
+    sd = fx.state_dict()
+    cfg = configs.unet_config(cfg_name)
+    net = build(cfg_name, sd, hip_device)
+    g = torch.Generator().manual_seed(B * 100 + T)
+    x = torch.randn(B, cfg["in_size"], T, generator=g)
+    tc = torch.randn(B, cfg["time_cond_in_channels"], T, generator=g)
+    cond = torch.randn(B, cfg["cond_channels"], generator=g)
+    time = torch.rand(B, generator=g)
+    want = oracle.unet1d_forward(sd, cfg, x, time, cond, tc)
+    got = net(x.to(hip_device), time=time.to(hip_device), time_cond=tc.to(hip_device),
+              cond=cond.to(hip_device)).cpu()
+    assert max_abs(got, want) < 2e-4 * max(1.0, want.abs().max().item())
+    if net.total_ratio > 1:  # lengths must be a multiple of the total down-sampling ratio
+        with pytest.raises(ValueError):
+            net(x[..., :T - 1].contiguous().to(hip_device), time=time.to(hip_device),
+                time_cond=tc[..., :T - 1].contiguous().to(hip_device), cond=cond.to(hip_device))
+
+
+def test_rectified_flow_samples_with_unet(hip_device):
+    """RectifiedFlow.sample with a UNET1D net: the Euler / CFG loop of model.py:721-785 around
+    after_unet1d_forward, against the same loop on the oracle."""
+    fx = Fixture("unet_micro")
+    sd = fx.state_dict()
+    cfg = configs.unet_config("unet_micro")
+    net = build("unet_micro", sd, hip_device)
+    model = RectifiedFlow(net=net, sr=44100, device=hip_device)
+    g = torch.Generator().manual_seed(5)
+    B, T, N = 2, 16, 3
+    x0 = torch.randn(B, 16, T, generator=g)
+    tc = torch.randn(B, 12, T, generator=g)
+    cond = torch.randn(B, 6, generator=g)
+    x = x0
+    for t in torch.linspace(0, 1, N + 1)[:-1]:
+        tt = t.repeat(3 * B)
+        dc, dt_ = -4.0 * torch.ones_like(cond), -4.0 * torch.ones_like(tc)
+        dx = oracle.unet1d_forward(sd, cfg, x.repeat(3, 1, 1), tt, torch.cat([cond, dc, dc]),
+                                   torch.cat([tc, tc, dt_]))
+        d_full, d_mid, d_none = dx.chunk(3, 0)
+        x = x + (d_none + 1.5 * (d_mid + 2.0 / max(1.0, 0.01) * (d_full - d_mid) - d_none)) * (1 / N)
+    got = model.sample(x0.to(hip_device), cond.to(hip_device), tc.to(hip_device), N, 2.0, 1.0).cpu()
+    assert max_abs(got, x) < 5e-4 * max(1.0, x.abs().max().item())
