@@ -588,7 +588,7 @@ __device__ __forceinline__ void wait_vmcnt_imm() {
 // Ring slot = [A k-half 0 | A k-half 1 | W k-half 0 | W k-half 1] rows of 32 floats, filled
 // by LDS-DMA with the same source-side XOR swizzle as above.  Requires K % 64 == 0.
 template <int MB, int NB, int KS, int NS>
-__global__ __launch_bounds__(128 * KS) void gemm_f32_bal_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(128 * KS) void gemm_f32_bal_kernel(GemmArgs g, int tiles_m, int tiles_n, int xcd_pm) {
     constexpr int BK = 32, CPR = 8, RPP = 8, KK = 2;
     constexpr int MT = MB, NT = NB;               // blocks per wave (names used by the macros)
     constexpr int BM = 16 * MB, BN = 32 * NB;
@@ -599,13 +599,28 @@ __global__ __launch_bounds__(128 * KS) void gemm_f32_bal_kernel(GemmArgs g, int 
     constexpr int STAGE = ROWS * BK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
+    // Workgroup -> tile map.  Block b runs on XCD b % 8 (round-robin dispatch) and every XCD has
+    // a private L2, so the 8 XCDs are laid out as a pm x pn grid over the tile matrix: an XCD
+    // then fetches 1/pm of A and 1/pn of W (launch_bal picks pm minimising A/pm + W/pn; a 1 x 8
+    // grid makes every XCD re-read all of A: 44 MB per MLP-down launch against 9.4 MB
+    // algorithmic).  Needs tiles_m % pm == 0 and tiles_n % pn == 0, else pm arrives as 0 and
+    // XCDs take contiguous ranges of the tm-fastest order.
     const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
+    int tm, tn;
+    if (xcd_pm > 0) {
+        const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+        const int pn = 8 / xcd_pm;
+        const int cm = tiles_m / xcd_pm, cn = tiles_n / pn;
+        const int xi = xcd % xcd_pm, xj = xcd / xcd_pm;
+        tm = xi * cm + li % cm;
+        tn = xj * cn + li / cm;
+    } else {
+        int bid = blockIdx.x;
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        tn = bid / tiles_m;
+        tm = bid - tn * tiles_m;
     }
-    const int tn = bid / tiles_m, tm = bid - tn * tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -787,8 +802,26 @@ int launch_bal(const GemmArgs& g, hipStream_t stream) {
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    // XCD grid pm x (8 / pm): minimise the per-XCD operand footprint A / pm + W / pn
+    static int xcd2d = -1;
+    if (xcd2d < 0) {
+        const char* e = getenv("AFTER_GEMM_XCD2D");
+        xcd2d = e ? atoi(e) : 1;
+    }
+    int pm = 0;
+    if (xcd2d) {
+        double best = 0;
+        for (int c = 1; c <= 8; c *= 2) {
+            if (tiles_m % c || tiles_n % (8 / c)) continue;
+            const double cost = (double)g.M / c + (double)g.N / (8 / c);  // x K x 4 bytes
+            if (pm == 0 || cost < best) {
+                pm = c;
+                best = cost;
+            }
+        }
+    }
     hipLaunchKernelGGL((gemm_f32_bal_kernel<MB, NB, KS, NS>), dim3(tiles_m * tiles_n), dim3(128 * KS), lds,
-                       stream, g, tiles_m, tiles_n);
+                       stream, g, tiles_m, tiles_n, pm);
     AFTER_HIP_CHECK(hipGetLastError());
     return AFTER_OK;
 }
