@@ -921,6 +921,8 @@ int launch_gemm_cfg(const GemmArgs& g, int mt, int nt, hipStream_t stream) {
         AFTER_BAL_CASE(3, 3, 2, 2) AFTER_BAL_CASE(3, 3, 2, 3) AFTER_BAL_CASE(3, 1, 2, 2) AFTER_BAL_CASE(3, 1, 2, 4)
         AFTER_BAL_CASE(3, 3, 4, 2) AFTER_BAL_CASE(3, 1, 4, 2) AFTER_BAL_CASE(3, 1, 4, 3) AFTER_BAL_CASE(3, 1, 4, 4)
         AFTER_BAL_CASE(3, 2, 4, 2) AFTER_BAL_CASE(2, 2, 4, 2) AFTER_BAL_CASE(2, 2, 4, 3)
+        AFTER_BAL_CASE(2, 2, 2, 2) AFTER_BAL_CASE(3, 2, 2, 2) AFTER_BAL_CASE(2, 3, 2, 2) AFTER_BAL_CASE(2, 2, 2, 3)
+        AFTER_BAL_CASE(4, 2, 2, 2) AFTER_BAL_CASE(4, 3, 2, 2)
 #undef AFTER_BAL_CASE
         set_error("gemm: no split-K configuration MB=%d NB=%d KS=%d NS=%d", mb, nb, ks, ns);
         return AFTER_E_INVALID;
@@ -948,14 +950,12 @@ int launch_gemm_cfg(const GemmArgs& g, int mt, int nt, hipStream_t stream) {
     const bool fits32 = (size_t)g.M * g.lda < (1u << 30) && (size_t)g.N * g.ldw < (1u << 30);
     if (use_bal && fits32 && g.M >= 192 && g.N >= 128) {
         const bool long_k = g.K >= 2 * g.N;  // "down" projections: narrow N, long K
-        if (long_k && (g.K % 128) == 0) {
-            if (g.M <= 1024) return launch_bal<3, 1, 4, 2>(g, stream);
-            if (g.M <= 2048) return launch_bal<3, 2, 4, 2>(g, stream);
-            return launch_bal<3, 3, 2, 2>(g, stream);
-        }
+        if (long_k && (g.K % 128) == 0 && g.M <= 1024) return launch_bal<3, 1, 4, 2>(g, stream);
         if ((g.K % 64) == 0) {
-            if (g.M <= 1024) return launch_bal<3, 1, 2, 2>(g, stream);
-            return launch_bal<3, 3, 2, 2>(g, stream);
+            if (g.M < 2048) return long_k || g.M <= 1024 ? launch_bal<3, 1, 2, 2>(g, stream)
+                                                          : launch_bal<3, 3, 2, 2>(g, stream);
+            // many tokens: 64-row tiles (M = 6144: 117 / 133 TFLOP/s for the up / down shapes)
+            return long_k ? launch_bal<4, 2, 2, 2>(g, stream) : launch_bal<4, 3, 2, 2>(g, stream);
         }
     }
     // Classic 2x2-wave tiles: the largest workgroup tile that still yields >= 2 workgroups per CU
