@@ -324,14 +324,17 @@ __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
     // global loads per key and lane (measured: 3.9 of the kernel's 14 us).
     float* const rc = smem + cs * (E + 4) + hw * (2 * a.nkmax * 16);
     float* const rs = rc + a.nkmax * 16;
-    float4 tcv[2], tsv[2];  // nkmax <= 32 positions -> at most 2 float4 per lane and table
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int i = lane + 64 * u;
-        if (i < nk * 4) {
-            tcv[u] = *reinterpret_cast<const float4*>(a.rope_cos + (size_t)lo_c * 16 + i * 4);
-            tsv[u] = *reinterpret_cast<const float4*>(a.rope_sin + (size_t)lo_c * 16 + i * 4);
-        }
+    // nkmax <= 32 positions -> at most 2 float4 per lane and table (scalars, not an array: an
+    // indexed array here ended up in scratch memory)
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 tc0 = z4, tc1 = z4, ts0 = z4, ts1 = z4;
+    if (lane < nk * 4) {
+        tc0 = *reinterpret_cast<const float4*>(a.rope_cos + (size_t)lo_c * 16 + lane * 4);
+        ts0 = *reinterpret_cast<const float4*>(a.rope_sin + (size_t)lo_c * 16 + lane * 4);
+    }
+    if (lane + 64 < nk * 4) {
+        tc1 = *reinterpret_cast<const float4*>(a.rope_cos + (size_t)lo_c * 16 + (lane + 64) * 4);
+        ts1 = *reinterpret_cast<const float4*>(a.rope_sin + (size_t)lo_c * 16 + (lane + 64) * 4);
     }
     // Operands of the LayerNorm tail are requested before anything else so that their
     // latency hides behind the attention proper.
@@ -383,13 +386,13 @@ __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
                 v4[j] = *reinterpret_cast<const float4*>(src);
             }
             if (qb == 0 && kb == 0) {  // K / V requests are in flight: now land the RoPE slice
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int i = lane + 64 * u;
-                    if (i < nk * 4) {
-                        *reinterpret_cast<float4*>(rc + i * 4) = tcv[u];
-                        *reinterpret_cast<float4*>(rs + i * 4) = tsv[u];
-                    }
+                if (lane < nk * 4) {
+                    *reinterpret_cast<float4*>(rc + lane * 4) = tc0;
+                    *reinterpret_cast<float4*>(rs + lane * 4) = ts0;
+                }
+                if (lane + 64 < nk * 4) {
+                    *reinterpret_cast<float4*>(rc + (lane + 64) * 4) = tc1;
+                    *reinterpret_cast<float4*>(rs + (lane + 64) * 4) = ts1;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
