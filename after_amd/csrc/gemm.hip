@@ -655,7 +655,7 @@ __global__ __launch_bounds__(128 * KS) void gemm_f32_bal_kernel(GemmArgs g, int 
                  :                                                                                \
                  : "s"(lds0 + (unsigned)(((slot_) * STAGE + (wid * LPS + (w_)) * RPP * BK) * 4)), \
                    "v"(voff[w_]), "s"(sbase[w_] + (slab_) * BK)                                   \
-                 : "memory");
+                 : "memory", "m0");
 
     f32x4 acc[MT][NT];
 #pragma unroll
