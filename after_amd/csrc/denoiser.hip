@@ -301,9 +301,18 @@ __device__ __forceinline__ float4 rope4(float4 v, const float* __restrict__ ct,
 // probabilities never leave registers.  K and V rows are read straight from the qkv
 // buffer (one 256-byte segment per head and key, L2-resident).  The concatenated
 // heads + residual meet in LDS for the row-wise AdaLN / LayerNorm tail.
-template <bool CACHE>
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+constexpr int kAttnKeyBlock = 12;
+
+// Two register / LDS budgets, chosen by grid size (launch_attn):
+//   PRELOAD (grid <= one workgroup per CU, batch 1): latency first -- K / V blocks land in
+//     registers (96 VGPRs), the LayerNorm-tail operands are requested up front (32 VGPRs).
+//   !PRELOAD (larger grids): occupancy first -- K / V blocks land in LDS by DMA, no preloads:
+//     102 VGPRs and 68 KB LDS = two co-resident workgroups per CU (B=8: 93.8 -> 90.0 ms).
+template <bool CACHE, bool PRELOAD>
 __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
-    constexpr int NKMAX = 12;  // key block
+    constexpr int NKMAX = kAttnKeyBlock;  // key block
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [cs][E + 4] | cos, sin [nkmax][16]
     const int E = a.E, H = a.H, T = a.T, cs = a.cs, W = a.W;
     const int nc = CACHE ? a.nc : 0;
@@ -324,6 +333,8 @@ __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
     // global loads per key and lane (measured: 3.9 of the kernel's 14 us).
     float* const rc = smem + cs * (E + 4) + hw * (2 * a.nkmax * 16);
     float* const rs = rc + a.nkmax * 16;
+    // per-wave K / V landing zone: [2][NKMAX][64]
+    float* const kvs = smem + cs * (E + 4) + H * (2 * a.nkmax * 16) + hw * (2 * NKMAX * 64);
     // nkmax <= 32 positions -> at most 2 float4 per lane and table (scalars, not an array: an
     // indexed array here ended up in scratch memory)
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -341,7 +352,7 @@ __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
     const int nper = E >> 6;
     const float* abp = a.cond_ab ? a.cond_ab + (size_t)r * a.cond_ld : nullptr;
     float al[kMaxPer], be[kMaxPer], ww[kMaxPer], bb[kMaxPer];
-    constexpr bool kPreloadLN = true;
+    constexpr bool kPreloadLN = PRELOAD;
 #pragma unroll
     for (int i = 0; i < kMaxPer; ++i)
         if (kPreloadLN && i < nper) {
@@ -370,20 +381,38 @@ __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 1
         for (int kb = 0; kb < nk; kb += NKMAX) {
-            float4 k4[NKMAX], v4[NKMAX];
+            float4 k4[PRELOAD ? NKMAX : 1], v4[PRELOAD ? NKMAX : 1];
+            if constexpr (PRELOAD) {
+                // all K and V rows requested unconditionally (slot index clamped, masked later)
 #pragma unroll
-            for (int j = 0; j < NKMAX; ++j) {
-                const int pos = (a.dbg & 8) ? lo_c : lo_c + min(kb + j, nk - 1);
-                const float* src = a.qkv + (rowbase + (pos - nc)) * 3 * E + E + hw * 64 + d4;
-                if (CACHE && pos < nc) src = a.kcache + ((size_t)r * nc + pos) * E + hw * 64 + d4;
-                k4[j] = *reinterpret_cast<const float4*>(src);
-            }
+                for (int j = 0; j < NKMAX; ++j) {
+                    const int pos = (a.dbg & 8) ? lo_c : lo_c + min(kb + j, nk - 1);
+                    const float* ksrc = a.qkv + (rowbase + (pos - nc)) * 3 * E + E + hw * 64 + d4;
+                    const float* vsrc = ksrc + E;
+                    if (CACHE && pos < nc) {
+                        ksrc = a.kcache + ((size_t)r * nc + pos) * E + hw * 64 + d4;
+                        vsrc = a.vcache + ((size_t)r * nc + pos) * E + hw * 64 + d4;
+                    }
+                    k4[j] = *reinterpret_cast<const float4*>(ksrc);
+                    v4[j] = *reinterpret_cast<const float4*>(vsrc);
+                }
+            } else {
+                // K / V rows go global -> LDS by DMA (no VGPR landing zone).  One instruction
+                // moves 4 keys: 16-lane group g fetches the 256-byte head slice of key 4u + g,
+                // lane-linear into [key][64 dims].
+                if (kb > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous block consumed
 #pragma unroll
-            for (int j = 0; j < NKMAX; ++j) {
-                const int pos = lo_c + min(kb + j, nk - 1);
-                const float* src = a.qkv + (rowbase + (pos - nc)) * 3 * E + 2 * E + hw * 64 + d4;
-                if (CACHE && pos < nc) src = a.vcache + ((size_t)r * nc + pos) * E + hw * 64 + d4;
-                v4[j] = *reinterpret_cast<const float4*>(src);
+                for (int u = 0; u < NKMAX / 4; ++u) {
+                    const int pos = (a.dbg & 8) ? lo_c : lo_c + min(kb + 4 * u + grp, nk - 1);
+                    const float* ksrc = a.qkv + (rowbase + (pos - nc)) * 3 * E + E + hw * 64 + d4;
+                    const float* vsrc = ksrc + E;
+                    if (CACHE && pos < nc) {
+                        ksrc = a.kcache + ((size_t)r * nc + pos) * E + hw * 64 + d4;
+                        vsrc = a.vcache + ((size_t)r * nc + pos) * E + hw * 64 + d4;
+                    }
+                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)ksrc, (lds_ptr_t)(kvs + 4 * u * 64), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)vsrc, (lds_ptr_t)(kvs + (NKMAX + 4 * u) * 64), 16, 0, 0);
+                }
             }
             if (qb == 0 && kb == 0) {  // K / V requests are in flight: now land the RoPE slice
                 if (lane < nk * 4) {
@@ -398,13 +427,20 @@ __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
+            if constexpr (!PRELOAD) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // K / V block (and q, x) have landed
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
             if (kb == 0 && !(a.dbg & 1)) q4 = rope4(q4, rc, rs, ja - lo_c, d4);
             float sc[NKMAX];
             float mx = mrun;
 #pragma unroll
             for (int j = 0; j < NKMAX; ++j) {
                 const int pos = lo_c + min(kb + j, nk - 1);
-                const float4 kr = (a.dbg & 1) ? k4[j] : rope4(k4[j], rc, rs, pos - lo_c, d4);
+                float4 kj;
+                if constexpr (PRELOAD) kj = k4[j];
+                else kj = *reinterpret_cast<const float4*>(kvs + j * 64 + d4);
+                const float4 kr = (a.dbg & 1) ? kj : rope4(kj, rc, rs, pos - lo_c, d4);
                 float dot = q4.x * kr.x + q4.y * kr.y + q4.z * kr.z + q4.w * kr.w;
                 if (!(a.dbg & 2)) dot = group16_sum(dot);
                 sc[j] = (kb + j < nk && pos >= lo_row) ? dot * 0.125f : -INFINITY;
@@ -421,10 +457,13 @@ __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
             for (int j = 0; j < NKMAX; ++j) {
                 const float p = expf(sc[j] - mx);  // exp(-inf) = 0 for masked / padded slots
                 sum += p;
-                o.x += p * v4[j].x;
-                o.y += p * v4[j].y;
-                o.z += p * v4[j].z;
-                o.w += p * v4[j].w;
+                float4 vj;
+                if constexpr (PRELOAD) vj = v4[j];
+                else vj = *reinterpret_cast<const float4*>(kvs + (NKMAX + j) * 64 + d4);
+                o.x += p * vj.x;
+                o.y += p * vj.y;
+                o.z += p * vj.z;
+                o.w += p * vj.w;
             }
         }
         const float inv = 1.0f / sum;
@@ -641,16 +680,30 @@ int compute_cond_ab(after_denoiser* h, hipStream_t s, int S, int rows, const flo
     return AFTER_OK;
 }
 
-size_t attn_lds_bytes(int E, int cs, int nkmax) {  // residual rows + per-wave RoPE slices
-    return ((size_t)cs * (E + 4) + (size_t)(E / 64) * 2 * nkmax * 16) * sizeof(float);
+size_t attn_lds_bytes(int E, int cs, int nkmax) {  // residual rows + per-wave RoPE slices + K/V blocks
+    return ((size_t)cs * (E + 4) + (size_t)(E / 64) * (2 * nkmax * 16 + 2 * kAttnKeyBlock * 64)) * sizeof(float);
 }
 
 int launch_attn(const AttnArgs& a, int rows, size_t lds, hipStream_t s) {
     const dim3 grid(cdiv(a.T, a.cs), rows), block(64 * a.H);
-    if (a.nc > 0)
-        hipLaunchKernelGGL(attn_block_kernel<true>, grid, block, lds, s, a);
-    else
-        hipLaunchKernelGGL(attn_block_kernel<false>, grid, block, lds, s, a);
+    static size_t attr = 0;
+    if (lds > attr) {  // > 64 KiB of dynamic LDS needs the opt-in
+        const void* fns[4] = {reinterpret_cast<const void*>(attn_block_kernel<true, true>),
+                              reinterpret_cast<const void*>(attn_block_kernel<true, false>),
+                              reinterpret_cast<const void*>(attn_block_kernel<false, true>),
+                              reinterpret_cast<const void*>(attn_block_kernel<false, false>)};
+        for (const void* f : fns)
+            AFTER_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = lds;
+    }
+    const bool preload = (long long)grid.x * grid.y <= 256;
+    if (a.nc > 0) {
+        if (preload) hipLaunchKernelGGL((attn_block_kernel<true, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((attn_block_kernel<true, false>), grid, block, lds, s, a);
+    } else {
+        if (preload) hipLaunchKernelGGL((attn_block_kernel<false, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((attn_block_kernel<false, false>), grid, block, lds, s, a);
+    }
     AFTER_HIP_CHECK(hipGetLastError());
     return AFTER_OK;
 }
