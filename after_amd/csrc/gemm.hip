@@ -587,12 +587,13 @@ __device__ __forceinline__ void wait_vmcnt_imm() {
 // (own + partner), a commutative two-term sum -> bit-deterministic, no atomics.
 // Ring slot = [A k-half 0 | A k-half 1 | W k-half 0 | W k-half 1] rows of 32 floats, filled
 // by LDS-DMA with the same source-side XOR swizzle as above.  Requires K % 64 == 0.
-template <int MB, int NB, int KS, int NS>
-__global__ __launch_bounds__(128 * KS) void gemm_f32_bal_kernel(GemmArgs g, int tiles_m, int tiles_n, int xcd_pm) {
+template <int MB, int NB, int KS, int NS, int RS>
+__global__ __launch_bounds__(128 * KS * RS) void gemm_f32_bal_kernel(GemmArgs g, int tiles_m, int tiles_n, int xcd_pm) {
     constexpr int BK = 32, CPR = 8, RPP = 8, KK = 2;
-    constexpr int MT = MB, NT = NB;               // blocks per wave (names used by the macros)
+    static_assert(MB % RS == 0, "row parts must divide the tile's block rows");
+    constexpr int MT = MB / RS, NT = NB;          // blocks per wave (names used by the macros)
     constexpr int BM = 16 * MB, BN = 32 * NB;
-    constexpr int NW = 2 * KS;                    // waves: KS k-parts x 2 column parts
+    constexpr int NW = 2 * KS * RS;               // waves: KS k-parts x RS row parts x 2 column parts
     constexpr int ROWS = KS * (BM + BN);          // ring slot: [A k-part 0..KS-1 | W k-part 0..KS-1]
     constexpr int LPS = ROWS / RPP / NW;          // DMA instructions per wave per slab
     static_assert(ROWS % (RPP * NW) == 0, "ring slot must split evenly over the waves");
@@ -624,7 +625,7 @@ __global__ __launch_bounds__(128 * KS) void gemm_f32_bal_kernel(GemmArgs g, int 
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kh = wid % KS, part = wid / KS;     // k-part, column part
+    const int kh = wid % KS, rp = (wid / KS) % RS, part = wid / (KS * RS);  // k-part, row part, column part
     const int M = g.M, N = g.N, Kh = g.K / KS;
 
     // DMA addressing: wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset, so that
@@ -678,7 +679,7 @@ __global__ __launch_bounds__(128 * KS) void gemm_f32_bal_kernel(GemmArgs g, int 
         }
 
     const int frow = lane & 15, kq = lane >> 4, sw = frow & (CPR - 1);
-    const int aoff = (kh * BM + frow) * BK;
+    const int aoff = (kh * BM + rp * (BM / RS) + frow) * BK;
     const int woff = (KS * BM + kh * BN + part * 16 * NB + frow) * BK;
     f32x4 fa[KK][2][MT], fb[KK][2][NT];
     unsigned a_c[KK], w_c[KK];
@@ -708,16 +709,18 @@ __global__ __launch_bounds__(128 * KS) void gemm_f32_bal_kernel(GemmArgs g, int 
     }
 
     // ---- split-K reduction through LDS (the ring is free: every wave is past its last read).
-    // Wave (kh, part) finalises the blocks b with b % KS == kh as p0 + p1 + ... in k-part order:
-    // a fixed summation order, i.e. bit-deterministic.
-    __syncthreads();
+    // Wave (kh, rp, part) finalises the blocks b with b % KS == kh as p0 + p1 + ... in k-part
+    // order: a fixed summation order, i.e. bit-deterministic.  KS = 1: nothing to reduce.
     float* red = smem;  // [wave][block][lane][4]
+    if constexpr (KS > 1) {
+        __syncthreads();
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-            *reinterpret_cast<f32x4*>(red + ((wid * MT * NT + i * NT + j) * 64 + lane) * 4) = acc[i][j];
-    __syncthreads();
+            for (int j = 0; j < NT; ++j)
+                *reinterpret_cast<f32x4*>(red + ((wid * MT * NT + i * NT + j) * 64 + lane) * 4) = acc[i][j];
+        __syncthreads();
+    }
     unsigned long long t_red = 0, t_st = 0;
     if (g.dbg) t_red = __builtin_readcyclecounter();
     // accumulator layout (transposed MFMA): lane l holds C[row = l & 15][col = 4 (l >> 4) + r]
@@ -737,11 +740,15 @@ __global__ __launch_bounds__(128 * KS) void gemm_f32_bal_kernel(GemmArgs g, int 
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             if ((i * NT + j) % KS != kh) continue;
-            f32x4 o = *reinterpret_cast<const f32x4*>(red + (((part * KS) * MT * NT + i * NT + j) * 64 + lane) * 4);
+            f32x4 o = acc[i][j];
+            if constexpr (KS > 1) {
+                const int w0 = (part * RS + rp) * KS;  // first wave of this (row part, column part)
+                o = *reinterpret_cast<const f32x4*>(red + ((w0 * MT * NT + i * NT + j) * 64 + lane) * 4);
 #pragma unroll
-            for (int q = 1; q < KS; ++q)
-                o += *reinterpret_cast<const f32x4*>(red + (((part * KS + q) * MT * NT + i * NT + j) * 64 + lane) * 4);
-            const int gm = m0 + i * 16 + crow;
+                for (int q = 1; q < KS; ++q)
+                    o += *reinterpret_cast<const f32x4*>(red + (((w0 + q) * MT * NT + i * NT + j) * 64 + lane) * 4);
+            }
+            const int gm = m0 + rp * (BM / RS) + i * 16 + crow;
             if (gm >= M || gn >= N) continue;
             o += bv;
             if (g.epilogue == EPI_GELU) {
@@ -788,17 +795,17 @@ __global__ __launch_bounds__(128 * KS) void gemm_f32_bal_kernel(GemmArgs g, int 
 
 #undef AFTER_BAL_DMA
 
-template <int MB, int NB, int KS, int NS>
+template <int MB, int NB, int KS, int NS, int RS = 1>
 int launch_bal(const GemmArgs& g, hipStream_t stream) {
     constexpr int BM = 16 * MB, BN = 32 * NB;
     const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
     const size_t ring = size_t(NS) * KS * (BM + BN) * 32 * sizeof(float);
-    const size_t red = size_t(2 * KS) * MB * NB * 256 * sizeof(float);
+    const size_t red = KS > 1 ? size_t(2 * KS) * MB * NB * 256 * sizeof(float) : 0;
     const size_t lds = ring > red ? ring : red;
     static_assert(size_t(NS) * KS * (BM + BN) * 32 * sizeof(float) <= 160 * 1024, "ring exceeds the LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_bal_kernel<MB, NB, KS, NS>),
+        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_bal_kernel<MB, NB, KS, NS, RS>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
@@ -820,8 +827,8 @@ int launch_bal(const GemmArgs& g, hipStream_t stream) {
             }
         }
     }
-    hipLaunchKernelGGL((gemm_f32_bal_kernel<MB, NB, KS, NS>), dim3(tiles_m * tiles_n), dim3(128 * KS), lds,
-                       stream, g, tiles_m, tiles_n, pm);
+    hipLaunchKernelGGL((gemm_f32_bal_kernel<MB, NB, KS, NS, RS>), dim3(tiles_m * tiles_n), dim3(128 * KS * RS),
+                       lds, stream, g, tiles_m, tiles_n, pm);
     AFTER_HIP_CHECK(hipGetLastError());
     return AFTER_OK;
 }
@@ -912,6 +919,20 @@ int launch_gemm_cfg(const GemmArgs& g, int mt, int nt, hipStream_t stream) {
     AFTER_REQUIRE(g.epilogue != EPI_RESIDUAL || g.R != nullptr, AFTER_E_INVALID,
                   "gemm: residual epilogue without R");
     if (mt >= 100) {  // balanced split-K kernels: mt = 100 + MB (2 k-parts) / 200 + MB (4), nt = 10 NS + NB
+        if (mt >= 300) {  // no K split: 2 row parts x 2 column parts (mt = 300 + MB)
+            const int mb3 = mt % 100, nb3 = nt % 10, ns3 = nt / 10;
+            AFTER_REQUIRE((g.K % 32) == 0, AFTER_E_INVALID, "gemm: K %% 32 != 0");
+            AFTER_REQUIRE((size_t)g.M * g.lda < (1u << 30) && (size_t)g.N * g.ldw < (1u << 30), AFTER_E_INVALID,
+                          "gemm: operand too large for 32-bit DMA offsets");
+            if (mb3 == 4 && nb3 == 3 && ns3 == 2) return launch_bal<4, 3, 1, 2, 2>(g, stream);
+            if (mb3 == 4 && nb3 == 3 && ns3 == 3) return launch_bal<4, 3, 1, 3, 2>(g, stream);
+            if (mb3 == 4 && nb3 == 2 && ns3 == 2) return launch_bal<4, 2, 1, 2, 2>(g, stream);
+            if (mb3 == 4 && nb3 == 2 && ns3 == 3) return launch_bal<4, 2, 1, 3, 2>(g, stream);
+            if (mb3 == 6 && nb3 == 3 && ns3 == 2) return launch_bal<6, 3, 1, 2, 2>(g, stream);
+            if (mb3 == 6 && nb3 == 2 && ns3 == 2) return launch_bal<6, 2, 1, 2, 2>(g, stream);
+            set_error("gemm: no row-split configuration MB=%d NB=%d NS=%d", mb3, nb3, ns3);
+            return AFTER_E_INVALID;
+        }
         const int ks = mt >= 200 ? 4 : 2, mb = mt % 100, nb = nt % 10, ns = nt / 10;
         AFTER_REQUIRE((g.K % (32 * ks)) == 0, AFTER_E_INVALID, "gemm: %d-way split-K needs K %% %d == 0", ks, 32 * ks);
         AFTER_REQUIRE((size_t)g.M * g.lda < (1u << 30) && (size_t)g.N * g.ldw < (1u << 30), AFTER_E_INVALID,
@@ -952,10 +973,13 @@ int launch_gemm_cfg(const GemmArgs& g, int mt, int nt, hipStream_t stream) {
         const bool long_k = g.K >= 2 * g.N;  // "down" projections: narrow N, long K
         if (long_k && (g.K % 128) == 0 && g.M <= 1024) return launch_bal<3, 1, 4, 2>(g, stream);
         if ((g.K % 64) == 0) {
-            if (g.M < 2048) return long_k || g.M <= 1024 ? launch_bal<3, 1, 2, 2>(g, stream)
-                                                          : launch_bal<3, 3, 2, 2>(g, stream);
-            // many tokens: 64-row tiles (M = 6144: 117 / 133 TFLOP/s for the up / down shapes)
-            return long_k ? launch_bal<4, 2, 2, 2>(g, stream) : launch_bal<4, 3, 2, 2>(g, stream);
+            if (g.M <= 1024) return launch_bal<3, 1, 2, 2>(g, stream);
+            if (long_k)  // K is long enough to keep splitting it
+                return g.M < 4096 ? launch_bal<3, 1, 2, 2>(g, stream) : launch_bal<4, 2, 2, 2>(g, stream);
+            // wide-N, short-K GEMMs with many tokens: enough tiles to balance without a K split,
+            // so the waves split the tile's rows instead (no reduction, half the ring per
+            // workgroup -> more co-resident workgroups).  M = 6144: 129 TFLOP/s vs 115 split.
+            return g.M < 2048 ? launch_bal<6, 3, 1, 2, 2>(g, stream) : launch_bal<4, 3, 1, 2, 2>(g, stream);
         }
     }
     // Classic 2x2-wave tiles: the largest workgroup tile that still yields >= 2 workgroups per CU

@@ -5,8 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from after_amd import diag
 dev = torch.device("cuda:0")
-shapes = [(2048,1536,512),(2048,512,1536),(6144,1536,512),(6144,512,1536)]
-tiles = [(2,2),(103,23),(103,21),(102,22),(103,22),(102,23),(102,32),(104,22),(104,23),(203,22),(203,21)]
+shapes = [(1536,1536,512),(1536,512,1536),(3072,1536,512),(3072,512,1536)]
+tiles = [(103,23),(103,21),(104,22),(104,23),(304,23),(304,22),(306,22),(306,23),(203,22)]
 for (M,N,K) in shapes:
     a = torch.randn(M,K,device=dev); w = torch.randn(N,K,device=dev); out = torch.empty(M,N,device=dev)
     ref = (a.double() @ w.double().T)

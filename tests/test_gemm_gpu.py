@@ -31,7 +31,8 @@ def test_gemm_shapes(tile, M, N, K, hip_device):
 
 # balanced split-K kernels: tile = (100 * KS / 2 + MB, 10 * NS + NB); K must be a multiple of 32 * KS
 @pytest.mark.parametrize("tile", [(103, 23), (103, 33), (103, 21), (103, 41), (203, 23), (203, 21),
-                                  (203, 31), (203, 41), (203, 22), (202, 22), (202, 32), (104, 22), (104, 23), (102, 22)])
+                                  (203, 31), (203, 41), (203, 22), (202, 22), (202, 32), (104, 22), (104, 23), (102, 22),
+                                  (304, 23), (304, 22), (306, 23), (306, 22)])
 @pytest.mark.parametrize("M,N,K", [(768, 1536, 512), (768, 512, 1536), (150, 520, 128), (33, 17, 256),
                                    (257, 130, 384), (1, 64, 512), (3072, 96, 128)])
 def test_gemm_split_k_shapes(tile, M, N, K, hip_device):
