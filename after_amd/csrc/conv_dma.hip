@@ -121,6 +121,7 @@ struct ConvDmaArgs {
     float* y;
     double* stats;  // [B][G][2] accumulators of y (or nullptr)
     int B, Cin, Cout, Tp, Tout, taps, phases, istride, ostride, Nn, G;
+    int dbg;  // AFTER_CONV_DBG (timing experiments, results invalid): 1 no DMA after stage 0, 2 no fragment reads, 4 no epilogue
     int toff[kMaxPhases][kMaxTaps];
     int ooff[kMaxPhases];
 };
@@ -158,23 +159,45 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(ConvDmaArgs a, ConvDmaGeo
     const int wcpr = LD >> 2;
     const float* wb = a.w + (size_t)ph * gm.nstage * (gm.tiles_m * BM) * LD + (size_t)m0 * LD;
     const int xtot = KC * xcpr, wtot = BM * wcpr;
+    // Per-lane source offsets of this wave's pieces, computed ONCE: the per-stage issue is then an
+    // add / min per piece.  (Recomputing row = idx / xcpr per piece and stage cost ~300 VALU
+    // instructions per stage and wave -- and a wave's VALU work is lost matrix-pipe time.)
+    constexpr int XP = 4, WP = 12;  // pieces per wave: KC * XW <= 4096 floats -> <= 16 X pieces;
+                                    // BM * LD / 256 <= 42 W pieces for taps * KC <= 128
+    int xrow[XP], xcol[XP];
+    unsigned woffs[WP];
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+        int idx = (wid + 4 * i) * 64 + lane;
+        idx = idx < xtot ? idx : xtot - 1;  // tail lanes re-fetch the last chunk into slack
+        xrow[i] = idx / xcpr;
+        xcol[i] = t0 + (idx - xrow[i] * xcpr) * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+        int idx = (wid + 4 * i) * 64 + lane;
+        idx = idx < wtot ? idx : wtot - 1;
+        woffs[i] = (unsigned)idx * 4u;
+    }
     auto issue = [&](int st, int slot) {
         float* base = smem + slot * STAGE;
-        for (int p = wid; p < gm.xpieces; p += 4) {
-            int idx = p * 64 + lane;
-            idx = idx < xtot ? idx : xtot - 1;  // tail lanes re-fetch the last chunk into slack
-            const int row = idx / xcpr, ch = idx - row * xcpr;
-            int c = st * KC + row;
-            c = c < a.Cin ? c : a.Cin - 1;  // rows past Cin meet zero weights
-            const float* src = xb + (size_t)c * a.Tp + t0 + ch * 4;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + p * 256), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const int p = wid + 4 * i;
+            if (p < gm.xpieces) {
+                int c = st * KC + xrow[i];
+                c = c < a.Cin ? c : a.Cin - 1;  // rows past Cin meet zero weights
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(xb + (size_t)c * a.Tp + xcol[i]),
+                                                 (lds_ptr_t)(base + p * 256), 16, 0, 0);
+            }
         }
         const float* ws = wb + (size_t)st * (gm.tiles_m * BM) * LD;
-        for (int p = wid; p < gm.wpieces; p += 4) {
-            int idx = p * 64 + lane;
-            idx = idx < wtot ? idx : wtot - 1;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ws + (size_t)idx * 4),
-                                             (lds_ptr_t)(base + XS + p * 256), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WP; ++i) {
+            const int p = wid + 4 * i;
+            if (p < gm.wpieces)
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ws + woffs[i]), (lds_ptr_t)(base + XS + p * 256),
+                                                 16, 0, 0);
         }
     };
 
@@ -192,85 +215,124 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(ConvDmaArgs a, ConvDmaGeo
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of stage st landed
         __builtin_amdgcn_s_barrier();                      // everyone's share landed; slot (st+1)&1 free
         asm volatile("" ::: "memory");
-        if (st + 1 < nstage) issue(st + 1, (st + 1) & 1);
+        if (st + 1 < nstage && !(a.dbg & 1)) issue(st + 1, (st + 1) & 1);
         const unsigned xs = lds0 + ((st & 1) * STAGE) * 4;
         const unsigned wsb = xs + XS * 4;
-        for (int tap = 0; tap < taps; ++tap) {
-            const int xc = a.toff[ph][tap] - tmin + skew;
-            for (int c16 = 0; c16 < KC; c16 += 16) {
-                f32x4 wa[MT];
-                float xv[NT][4];
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    asm volatile("ds_read_b128 %0, %1"
-                                 : "=v"(wa[i])
-                                 : "v"(wsb + ((wm0 + i * 16 + frow) * LD + tap * KC + c16 + kq * 4) * 4));
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        asm volatile("ds_read_b32 %0, %1"
-                                     : "=v"(xv[j][t])
-                                     : "v"(xs + ((c16 + kq * 4 + t) * XW + (wn0 + j * 16 + frow) * a.istride + xc) * 4));
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(wa[i]));
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(xv[j][t]));
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int i = 0; i < MT; ++i)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[i][t], xv[j][t], acc[i][j], 0, 0, 0);
+        // k-blocks of 16 input channels x 1 tap, flattened over (tap, c16): the fragments of
+        // k-block kb+1 are read from LDS while the MFMAs of k-block kb run (two register sets,
+        // loop unrolled by two); only the first read of a stage is exposed.
+        const int nkb = taps * (KC >> 4);
+        const unsigned wrow = wsb + ((wm0 + frow) * LD + kq * 4) * 4;
+        const unsigned xcol = xs + (kq * 4 * XW + (wn0 + frow) * a.istride + skew - tmin) * 4;
+        f32x4 wa[2][MT];
+        float xv[2][NT][4];
+        int tap_n = 0, c16_n = 0;  // (tap, c16) of the next k-block to load
+#define CONV_LOAD(p)                                                                                 \
+    {                                                                                                \
+        const unsigned wo__ = wrow + (tap_n * KC + c16_n) * 4;                                       \
+        const unsigned xo__ = xcol + (c16_n * XW + a.toff[ph][tap_n]) * 4;                           \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                               \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(wa[p][i]) : "v"(wo__ + i * 16 * LD * 4));       \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                               \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                            \
+                asm volatile("ds_read_b32 %0, %1"                                                    \
+                             : "=v"(xv[p][j][t])                                                     \
+                             : "v"(xo__ + (t * XW + j * 16 * a.istride) * 4));                       \
+        c16_n += 16;                                                                                 \
+        if (c16_n >= KC) {                                                                           \
+            c16_n = 0;                                                                               \
+            ++tap_n;                                                                                 \
+        }                                                                                            \
+    }
+#define CONV_FENCE(p)                                                                                \
+    {                                                                                                \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                           \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(wa[p][i]));            \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                               \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(xv[p][j][t]));      \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+    }
+#define CONV_MMA(p)                                                                                  \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                    \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                               \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                           \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[p][j][t], wa[p][i][t], acc[i][j], 0, 0, 0);
+        const bool rd = !(a.dbg & 2);
+        if (rd) CONV_LOAD(0)
+        for (int kb = 0; kb < nkb; kb += 2) {
+            CONV_FENCE(0)
+            if (kb + 1 < nkb && rd) CONV_LOAD(1)
+            CONV_MMA(0)
+            if (kb + 1 < nkb) {
+                CONV_FENCE(1)
+                if (kb + 2 < nkb && rd) CONV_LOAD(0)
+                CONV_MMA(1)
             }
         }
+#undef CONV_LOAD
+#undef CONV_FENCE
+#undef CONV_MMA
     }
 
     // ---- epilogue
-    const int ccol = lane & 15, crow0 = 4 * (lane >> 4);
+    if (a.dbg & 4) {
+        if (acc[0][0][0] == 123.456f) a.y[0] = 0.f;  // keep the accumulators alive
+        return;
+    }
+    // The X fragment is fed as srcA, so the accumulator holds the transposed tile: lane l owns
+    // output channel (l & 15) of W block i and four CONSECUTIVE positions 4 (l >> 4) + r of X block
+    // j -> one float4 store / residual load per block, and the per-channel sums of the next
+    // GroupNorm need only two cross-row shuffles.
+    const int cl = lane & 15, tq = 4 * (lane >> 4);
     float* yb = a.y + (size_t)b * a.Cout * a.Tout;
     const float* rb = a.res ? a.res + (size_t)b * a.Cout * a.Tout : nullptr;
     const int Cg = a.stats ? a.Cout / a.G : 1;
     if (a.stats && tid < 16) gsum[tid >> 3][tid & 7] = 0.f;
     if (a.stats) __syncthreads();
+    const bool vec = a.ostride == 1 && a.ooff[ph] == 0 && (a.Tout & 3) == 0;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
+        const int co = m0 + wm0 + i * 16 + cl;
+        float rs = 0.f, rq = 0.f;
+        if (co < a.Cout) {
+            const float bv = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = m0 + wm0 + i * 16 + crow0 + r;
-            float rs = 0.f, rq = 0.f;
-            if (co < a.Cout) {
-                const float bv = a.bias ? a.bias[co] : 0.f;
+            for (int j = 0; j < NT; ++j) {
+                const int n = n0 + wn0 + j * 16 + tq;
+                f32x4 v = acc[i][j];
+                v += bv;
+                if (vec && n + 3 < a.Nn) {
+                    const size_t o = (size_t)co * a.Tout + n;
+                    if (rb) v += *reinterpret_cast<const f32x4*>(rb + o);
+                    *reinterpret_cast<f32x4*>(yb + o) = v;
+                    rs += (v[0] + v[1]) + (v[2] + v[3]);
+                    rq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                } else {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const int n = n0 + wn0 + j * 16 + ccol;
-                    const int to = n * a.ostride + a.ooff[ph];
-                    if (n < a.Nn && to < a.Tout) {
-                        float v = acc[i][j][r] + bv;
-                        if (rb) v += rb[(size_t)co * a.Tout + to];
-                        yb[(size_t)co * a.Tout + to] = v;
-                        rs += v;
-                        rq += v * v;
+                    for (int r = 0; r < 4; ++r) {
+                        const int to = (n + r) * a.ostride + a.ooff[ph];
+                        if (n + r < a.Nn && to < a.Tout) {
+                            float u = v[r];
+                            if (rb) u += rb[(size_t)co * a.Tout + to];
+                            yb[(size_t)co * a.Tout + to] = u;
+                            rs += u;
+                            rq += u * u;
+                        }
                     }
                 }
             }
-            if (a.stats) {
-                // reduce over the 16 columns of this lane group, then one LDS atomic per row
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) {
-                    rs += __shfl_xor(rs, o, 64);
-                    rq += __shfl_xor(rq, o, 64);
-                }
-                if (ccol == 0 && co < a.Cout) {
-                    const int gl = co / Cg - m0 / Cg;  // group index local to the tile (< 8)
-                    atomicAdd(&gsum[0][gl & 7], rs);
-                    atomicAdd(&gsum[1][gl & 7], rq);
-                }
+        }
+        if (a.stats) {
+            // sum over the four position groups (lanes l, l ^ 16, l ^ 32, l ^ 48), then one LDS
+            // atomic per channel
+            rs += __shfl_xor(rs, 16, 64);
+            rq += __shfl_xor(rq, 16, 64);
+            rs += __shfl_xor(rs, 32, 64);
+            rq += __shfl_xor(rq, 32, 64);
+            if (lane < 16 && co < a.Cout) {
+                const int gl = co / Cg - m0 / Cg;  // group index local to the tile (< 8)
+                atomicAdd(&gsum[0][gl & 7], rs);
+                atomicAdd(&gsum[1][gl & 7], rq);
             }
         }
     }
@@ -434,6 +496,8 @@ static int launch_dma_cfg(const ConvDmaRun& r, const ConvDmaPlanIn& in, const Co
     g.nstage = p.nstage;
     g.xpieces = cdiv(p.KC * (p.XW / 4), 64);
     g.wpieces = cdiv(BM * (p.LD / 4), 64);
+    AFTER_REQUIRE(g.xpieces <= 16 && g.wpieces <= 48, AFTER_E_INVALID,
+                  "conv_dma: tile needs %d + %d DMA pieces (kernel holds 16 + 48)", g.xpieces, g.wpieces);
     for (int ph = 0; ph < kMaxPhases; ++ph) {
         int lo = 0;
         if (ph < in.phases) {
@@ -461,6 +525,14 @@ static int launch_dma_cfg(const ConvDmaRun& r, const ConvDmaPlanIn& in, const Co
     a.ostride = in.ostride;
     a.Nn = r.Nn;
     a.G = r.G;
+    {
+        static int dbg = -1;
+        if (dbg < 0) {
+            const char* e = getenv("AFTER_CONV_DBG");
+            dbg = e ? atoi(e) : 0;
+        }
+        a.dbg = dbg;
+    }
     for (int ph = 0; ph < in.phases; ++ph) {
         for (int t = 0; t < in.taps; ++t) a.toff[ph][t] = in.toff[ph][t];
         a.ooff[ph] = in.ooff[ph];
