@@ -542,7 +542,14 @@ __global__ __launch_bounds__(256) void roll_cache_kernel(const float* __restrict
                                                          float* __restrict__ knew,
                                                          float* __restrict__ vnew,
                                                          const float* __restrict__ qkv, int rows,
-                                                         int T, int E, int cache, int size) {
+                                                         int T, int E, int cache, int size,
+                                                         size_t cache_lstride, size_t qkv_lstride) {
+    // blockIdx.y = layer: all layers of one diffusion step roll in ONE launch
+    kold += blockIdx.y * cache_lstride;
+    vold += blockIdx.y * cache_lstride;
+    knew += blockIdx.y * cache_lstride;
+    vnew += blockIdx.y * cache_lstride;
+    qkv += blockIdx.y * qkv_lstride;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t total = (size_t)rows * cache * E;
     if (idx >= total) return;
@@ -1145,15 +1152,13 @@ int roll_cache_step(after_denoiser* h, hipStream_t s, int rows, int T, int size,
     const size_t per = (size_t)h->cache_rows * h->cache * E;
     const int cur = h->flip[cache_index];
     const size_t total = (size_t)rows * h->cache * E;
-    for (int l = 0; l < h->L; ++l) {
-        const size_t base = ((size_t)l * h->cache_steps + cache_index) * 2 * per;
-        const float* qkv = h->qkv_layers + (size_t)l * h->max_rows * h->max_T * 3 * E;
-        hipLaunchKernelGGL(roll_cache_kernel, dim3((unsigned)cdivll(total, 256)), dim3(256), 0, s,
-                           h->kcache + base + cur * per, h->vcache + base + cur * per,
-                           h->kcache + base + (cur ^ 1) * per, h->vcache + base + (cur ^ 1) * per, qkv,
-                           rows, T, E, h->cache, size);
-        AFTER_HIP_CHECK(hipGetLastError());
-    }
+    const size_t base = (size_t)cache_index * 2 * per;           // layer 0
+    const size_t lstride = (size_t)h->cache_steps * 2 * per;      // cache slot of the next layer
+    hipLaunchKernelGGL(roll_cache_kernel, dim3((unsigned)cdivll(total, 256), h->L), dim3(256), 0, s,
+                       h->kcache + base + cur * per, h->vcache + base + cur * per,
+                       h->kcache + base + (cur ^ 1) * per, h->vcache + base + (cur ^ 1) * per, h->qkv_layers,
+                       rows, T, E, h->cache, size, lstride, (size_t)h->max_rows * h->max_T * 3 * E);
+    AFTER_HIP_CHECK(hipGetLastError());
     h->flip[cache_index] = cur ^ 1;
     return AFTER_OK;
 }
