@@ -969,9 +969,9 @@ int launch_gemm_cfg(const GemmArgs& g, int mt, int nt, hipStream_t stream) {
         use_bal = e ? atoi(e) : 1;
     }
     const bool fits32 = (size_t)g.M * g.lda < (1u << 30) && (size_t)g.N * g.ldw < (1u << 30);
-    if (use_bal && fits32 && g.M >= 192 && g.N >= 128) {
+    if (use_bal && fits32 && g.M >= 64 && g.N >= 128) {
         const bool long_k = g.K >= 2 * g.N;  // "down" projections: narrow N, long K
-        if (long_k && (g.K % 128) == 0 && g.M <= 1024) return launch_bal<3, 1, 4, 2>(g, stream);
+        if ((long_k || g.M < 192) && (g.K % 128) == 0 && g.M <= 1024) return launch_bal<3, 1, 4, 2>(g, stream);
         if ((g.K % 64) == 0) {
             if (g.M <= 1024) return launch_bal<3, 1, 2, 2>(g, stream);
             if (long_k)  // K is long enough to keep splitting it
