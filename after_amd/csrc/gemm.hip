@@ -833,6 +833,84 @@ int launch_bal(const GemmArgs& g, hipStream_t stream) {
     return AFTER_OK;
 }
 
+// ---------------------------------------------------------------------------------
+// Skinny GEMM for the streaming path (M <= 96 tokens: 3 CFG rows x 4 frames x 1..8 streams).
+// Such a launch is pure weight streaming (3 MB of W against <= 0.6 MB of A), so the tile is
+// turned around: one workgroup owns 16 output COLUMNS (16 rows of W) for all M rows, its 8 waves
+// split K eight ways and load their fragments straight from global memory into registers (no
+// LDS staging: every W element is used by exactly one wave), several k-blocks in flight per
+// wave; the eight partial tiles are summed through LDS in wave order (deterministic).
+// N / 16 workgroups pull W at ~100 KB per CU, i.e. one memory round trip.
+template <int MB>
+__global__ __launch_bounds__(512) void gemm_f32_skinny_kernel(GemmArgs g) {
+    constexpr int U = MB <= 3 ? 4 : 2;  // k-blocks (16 deep) in flight per wave
+    __shared__ __attribute__((aligned(16))) float red[8 * MB * 256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row = lane & 15, kq = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int M = g.M, N = g.N, Kw = g.K >> 3;
+    const float* wp = g.W + (size_t)min(n0 + row, N - 1) * g.ldw + w * Kw + kq * 4;
+    const float* ap[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) ap[i] = g.A + (size_t)min(i * 16 + row, M - 1) * g.lda + w * Kw + kq * 4;
+    f32x4 acc[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < Kw; kb += 16 * U) {
+        f32x4 bw[U], a[U][MB];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = kb + 16 * u;
+            if (k < Kw) {
+                bw[u] = *reinterpret_cast<const f32x4*>(wp + k);
+#pragma unroll
+                for (int i = 0; i < MB; ++i) a[u][i] = *reinterpret_cast<const f32x4*>(ap[i] + k);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (kb + 16 * u < Kw) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int i = 0; i < MB; ++i)  // W fragment as srcA: the accumulator holds C^T
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[u][c], a[u][i][c], acc[i], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MB; ++i) *reinterpret_cast<f32x4*>(red + ((w * MB + i) * 64 + lane) * 4) = acc[i];
+    __syncthreads();
+    // wave w finalises row blocks w, w + 8, ...: lane owns row m = 16 i + (lane & 15), columns
+    // n0 + 4 (lane >> 4) + r
+    const int gn = n0 + 4 * kq;
+    for (int i = w; i < MB; i += 8) {
+        f32x4 o = *reinterpret_cast<const f32x4*>(red + (i * 64 + lane) * 4);
+#pragma unroll
+        for (int q = 1; q < 8; ++q) o += *reinterpret_cast<const f32x4*>(red + ((q * MB + i) * 64 + lane) * 4);
+        const int gm = i * 16 + row;
+        if (gm >= M) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (gn + r >= N) continue;
+            float v = o[r] + (g.bias ? g.bias[gn + r] : 0.f);
+            if (g.epilogue == EPI_GELU) v = gelu_erf(v);
+            if (g.epilogue == EPI_RESIDUAL) v += g.R[(size_t)gm * g.ldr + gn + r];
+            if (g.epilogue == EPI_RELU) v = fmaxf(v, 0.f);
+            if (g.epilogue == EPI_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+            g.C[(size_t)gm * g.ldc + gn + r] = v;
+        }
+    }
+}
+
+template <int MB>
+int launch_skinny(const GemmArgs& g, hipStream_t stream) {
+    hipLaunchKernelGGL((gemm_f32_skinny_kernel<MB>), dim3(cdiv(g.N, 16)), dim3(512), 0, stream, g);
+    AFTER_HIP_CHECK(hipGetLastError());
+    return AFTER_OK;
+}
+
 template <int MT, int NT, int NS, int BK>
 int launch_dma(const GemmArgs& g, hipStream_t stream) {
     constexpr int BM = 32 * MT, BN = 32 * NT;
@@ -918,6 +996,15 @@ int launch_gemm_cfg(const GemmArgs& g, int mt, int nt, hipStream_t stream) {
                   "gemm: operands must be 16-byte aligned");
     AFTER_REQUIRE(g.epilogue != EPI_RESIDUAL || g.R != nullptr, AFTER_E_INVALID,
                   "gemm: residual epilogue without R");
+    if (mt >= 400) {  // skinny kernels: mt = 400 + MB
+        AFTER_REQUIRE((g.K % 128) == 0 && g.M <= 16 * (mt - 400), AFTER_E_INVALID,
+                      "gemm: skinny tiles need K %% 128 == 0 and M <= 16 MB");
+        if (mt == 401) return launch_skinny<1>(g, stream);
+        if (mt == 403) return launch_skinny<3>(g, stream);
+        if (mt == 406) return launch_skinny<6>(g, stream);
+        set_error("gemm: no skinny configuration MB=%d", mt - 400);
+        return AFTER_E_INVALID;
+    }
     if (mt >= 100) {  // balanced split-K kernels: mt = 100 + MB (2 k-parts) / 200 + MB (4), nt = 10 NS + NB
         if (mt >= 300) {  // no K split: 2 row parts x 2 column parts (mt = 300 + MB)
             const int mb3 = mt % 100, nb3 = nt % 10, ns3 = nt / 10;
@@ -967,6 +1054,16 @@ int launch_gemm_cfg(const GemmArgs& g, int mt, int nt, hipStream_t stream) {
     if (use_bal < 0) {
         const char* e = getenv("AFTER_GEMM_BAL");
         use_bal = e ? atoi(e) : 1;
+    }
+    static int use_skinny = -1;
+    if (use_skinny < 0) {
+        const char* e = getenv("AFTER_GEMM_SKINNY");
+        use_skinny = e ? atoi(e) : 1;
+    }
+    if (use_skinny && g.M <= (use_skinny > 1 ? 96 : 48) && (g.K % 128) == 0 && g.N >= 256) {
+        if (g.M <= 16) return launch_skinny<1>(g, stream);
+        if (g.M <= 48) return launch_skinny<3>(g, stream);
+        return launch_skinny<6>(g, stream);  // AFTER_GEMM_SKINNY=2 only: slower than split-K at M = 96
     }
     const bool fits32 = (size_t)g.M * g.lda < (1u << 30) && (size_t)g.N * g.ldw < (1u << 30);
     if (use_bal && fits32 && g.M >= 64 && g.N >= 128) {

@@ -54,6 +54,28 @@ def test_gemm_split_k_shapes(tile, M, N, K, hip_device):
     assert (out - (ref - b.double() + r.double())).abs().max().item() < bound
 
 
+@pytest.mark.parametrize("tile,M", [((401, 0), 12), ((401, 0), 16), ((403, 0), 33), ((403, 0), 48), ((406, 0), 96),
+                                    ((406, 0), 70), ((0, 0), 12), ((0, 0), 96)])
+@pytest.mark.parametrize("N,K", [(1536, 512), (512, 1536), (264, 128)])
+def test_gemm_skinny_shapes(tile, M, N, K, hip_device):
+    """Few-token (streaming) shapes: column-owning workgroups, 8-way K split inside the workgroup."""
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g)
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    ref = a.double() @ w.double().t() + b.double()
+    bound = 2e-6 * (a.abs().double() @ w.abs().double().t()).max().item() + 1e-6
+    ad, wd, bd, rd = (t.to(hip_device) for t in (a, w, b, r))
+    out = diag.gemm(ad, wd, bd, tile=tile)
+    assert (out.cpu().double() - ref).abs().max().item() < bound
+    assert torch.equal(out, diag.gemm(ad, wd, bd, tile=tile))
+    out = diag.gemm(ad, wd, bd, epilogue=1, tile=tile).cpu().double()
+    assert (out - torch.nn.functional.gelu(ref)).abs().max().item() < bound
+    out = diag.gemm(ad, wd, None, residual=rd, epilogue=2, tile=tile).cpu().double()
+    assert (out - (ref - b.double() + r.double())).abs().max().item() < bound
+
+
 def test_gemm_split_k_rejects_short_k(hip_device):
     from after_amd._lib import AFTERHipError
     a = torch.randn(64, 96, device=hip_device)
