@@ -36,7 +36,12 @@ def test_library_is_built_for_gfx950_only():
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
     if not os.path.exists(objdump):
         pytest.skip("llvm-objdump not available")
-    out = subprocess.run([objdump, "--offloading", _lib.LIB_PATH], capture_output=True, text=True)
+    # --offloading extracts the bundles next to its input: work on a copy in a scratch directory
+    import shutil
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        so = shutil.copy(_lib.LIB_PATH, tmp)
+        out = subprocess.run([objdump, "--offloading", so], capture_output=True, text=True, cwd=tmp)
     txt = out.stdout + out.stderr
     archs = set(re.findall(r"gfx[0-9a-f]+", txt))
     assert archs == {"gfx950"}, archs
