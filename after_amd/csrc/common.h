@@ -88,6 +88,7 @@ enum GemmEpilogue {
     EPI_RESIDUAL = 2,   // C = acc + bias + R[m, n]
     EPI_RELU = 3,       // C = max(acc + bias, 0)
     EPI_SIGMOID = 4,    // C = sigmoid(acc + bias)
+    EPI_CFG_EULER = 5,  // fused sampler tail (launch_gemm_cfg_euler only)
 };
 struct GemmArgs {
     const float* A;
@@ -102,7 +103,19 @@ struct GemmArgs {
     int M, N, K;
     int epilogue;
     unsigned long long* dbg = nullptr;  // diagnostics: 4 s_memtime stamps per workgroup
+    // ---- EPI_CFG_EULER (launch_gemm_cfg_euler): A = final residual stream [3 * BT, K] with the
+    // CFG branches stacked (full | mid | none), W / bias = out_proj.  Per token and channel:
+    //   d = d_none + total (d_mid + factor (d_full - d_mid) - d_none);  x' = xin + dt d
+    // written to xout [B, N, T] (reference layout) and xt [BT, xt_ld] (token-major, the next
+    // step's patchify input).  cfg -> {total, factor, dt} in device memory.
+    const float* xin = nullptr;
+    float* xout = nullptr;
+    float* xt = nullptr;
+    const float* cfg = nullptr;
+    int T = 0, xt_ld = 0;
 };
+// out_proj + CFG combine + Euler update of one sampler step in ONE launch; g.M = 3 * B * T
+int launch_gemm_cfg_euler(const GemmArgs& g, hipStream_t stream);
 int launch_gemm(const GemmArgs& g, hipStream_t stream);
 int launch_gemm_cfg(const GemmArgs& g, int force_mt, int force_nt, hipStream_t stream);
 

@@ -587,6 +587,7 @@ struct after_denoiser {
     Arena wa, ws;
     // weights
     float *emb0_w, *emb0_b, *emb2_w, *emb2_b, *patch_w, *patch_b, *tce_w, *tce_b, *out_w, *out_b;
+    int fuse_tail = 1;  // AFTER_FUSE_TAIL=0: separate out_proj / cfg_euler / to_token_major launches
     float *cond_w_all, *cond_b_all, *tc_w_all, *tc_b_all, *freqs, *rope_cos, *rope_sin;
     std::vector<LayerW> layers;
     // workspaces
@@ -720,11 +721,14 @@ int launch_attn(const AttnArgs& a, int rows, size_t lds, hipStream_t s) {
 // token-major [rows*T, C].
 // patchify_and_embed: GELU(Linear(C -> E)) on the transposed latents (:387-391, :440) for the
 // `npat` distinct clips of x -> h->pat
-int run_patchify(after_denoiser* h, hipStream_t s, const float* x, int npat, int T) {
-    dim3 grid(cdiv(T, 32), cdiv(h->Cp, 32), npat);
-    hipLaunchKernelGGL(to_token_major_kernel, grid, dim3(256), 0, s, x, h->xt, (const int*)nullptr,
-                       h->C, T, h->Cp, 0.f);
-    AFTER_HIP_CHECK(hipGetLastError());
+int run_patchify(after_denoiser* h, hipStream_t s, const float* x, int npat, int T,
+                 bool transpose = true) {
+    if (transpose) {  // (the fused sampler tail already left x in token-major form in h->xt)
+        dim3 grid(cdiv(T, 32), cdiv(h->Cp, 32), npat);
+        hipLaunchKernelGGL(to_token_major_kernel, grid, dim3(256), 0, s, x, h->xt, (const int*)nullptr,
+                           h->C, T, h->Cp, 0.f);
+        AFTER_HIP_CHECK(hipGetLastError());
+    }
     return gemm(h, s, h->xt, h->Cp, h->patch_w, h->Cp, h->patch_b, h->pat, h->E, npat * T, h->E,
                 h->Cp, EPI_GELU);
 }
@@ -732,7 +736,8 @@ int run_patchify(after_denoiser* h, hipStream_t s, const float* x, int npat, int
 // The decoder blocks + out_proj for network rows [row0, row0 + rows) on stream s.  Every
 // activation buffer is row-major over (row, frame), so a row range is a pointer offset.
 int run_layers(after_denoiser* h, hipStream_t s, int row0, int rows, const int* dev_xmap,
-               const int* dev_tcmap, int T, const float* cond_ab_step, int cache_index) {
+               const int* dev_tcmap, int T, const float* cond_ab_step, int cache_index,
+               bool out_proj = true) {
     const int E = h->E, L = h->L, C = h->C, ME = h->ME;
     const int M = rows * T;
     const size_t r0 = (size_t)row0 * T;
@@ -789,6 +794,7 @@ int run_layers(after_denoiser* h, hipStream_t s, int row0, int rows, const int* 
         AFTER_TRY(gemm(h, s, hbuf, E, w.mlp0_w, E, w.mlp0_b, mlp, ME, M, ME, E, EPI_GELU));
         AFTER_TRY(gemm(h, s, mlp, ME, w.mlp2_w, ME, w.mlp2_b, xres, E, M, E, ME, EPI_RESIDUAL, xres, E));
     }
+    if (!out_proj) return AFTER_OK;  // fused into the sampler tail (launch_gemm_cfg_euler)
     return gemm(h, s, xres, E, h->out_w, E, h->out_b, h->outp + r0 * C, C, M, C, E, EPI_NONE);
 }
 
@@ -799,19 +805,19 @@ int run_layers(after_denoiser* h, hipStream_t s, int row0, int rows, const int* 
 // fills the launch ramps / tails and the SIMD quantisation holes of the small B = 1 grids.
 int run_net(after_denoiser* h, hipStream_t s, const float* x, int npat, const int* dev_xmap,
             const int* dev_tcmap, int rows, int T, const float* cond_ab_step, int cache_index,
-            int groups = 1) {
-    AFTER_TRY(run_patchify(h, s, x, npat, T));
+            int groups = 1, bool transpose = true, bool out_proj = true) {
+    AFTER_TRY(run_patchify(h, s, x, npat, T, transpose));
     // measured (base, 50 steps): B = 8 -> 108.9 ms with three branch streams vs 112.3 ms on
     // one; B = 1 -> 26.5 ms vs 23.6 ms (host-bound: 3x the launches of 5-15 us kernels)
     if (h->row_groups_forced == 0 && (long long)rows * T < 4096) groups = 1;
     if (groups <= 1 || rows % groups != 0 || h->timer.enabled)
-        return run_layers(h, s, 0, rows, dev_xmap, dev_tcmap, T, cond_ab_step, cache_index);
+        return run_layers(h, s, 0, rows, dev_xmap, dev_tcmap, T, cond_ab_step, cache_index, out_proj);
     const int per = rows / groups;
     AFTER_HIP_CHECK(hipEventRecord(h->ev_fork, s));
     for (int g = 0; g < groups; ++g) {
         hipStream_t gs = g == 0 ? s : h->rstream[g - 1];
         if (g > 0) AFTER_HIP_CHECK(hipStreamWaitEvent(gs, h->ev_fork, 0));
-        AFTER_TRY(run_layers(h, gs, g * per, per, dev_xmap, dev_tcmap, T, cond_ab_step, cache_index));
+        AFTER_TRY(run_layers(h, gs, g * per, per, dev_xmap, dev_tcmap, T, cond_ab_step, cache_index, out_proj));
         if (g > 0) {
             AFTER_HIP_CHECK(hipEventRecord(h->ev_join[g - 1], gs));
             AFTER_HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[g - 1], 0));
@@ -1060,6 +1066,9 @@ extern "C" int after_denoiser_create(const after_denoiser_cfg* cfg, const float*
         // the default; AFTER_GRAPH=1 / after_denoiser_set_graph(h, 1) selects the replay.
         const char* e = getenv("AFTER_GRAPH");
         h->use_graph = (e && atoi(e) != 0);
+        const char* f = getenv("AFTER_FUSE_TAIL");
+        h->fuse_tail = f ? atoi(f) : 1;
+        if (h->E % 128 != 0) h->fuse_tail = 0;  // the fused GEMM splits K four ways
     }
     if (hipDeviceSynchronize() != hipSuccess) return fail(AFTER_E_HIP);
 #undef TAKE
@@ -1174,11 +1183,28 @@ int sample_enqueue(after_denoiser* h, hipStream_t s, const float* x0, const floa
     AFTER_TRY(compute_cond_ab(h, s, nb_steps, rows, nullptr, nullptr, nb_steps, cond,
                               h->maps + 2 * h->ms, drop_value));
     const size_t step_stride = (size_t)rows * h->L * 2 * h->E;
+    // Fused tail: out_proj + CFG + Euler in ONE GEMM launch that also leaves the new latents in
+    // token-major form for the next step's patchify (instead of GEMM, cfg_euler, to_token_major).
+    // The GEMM timer (bench roofline pass) keeps the separate launches.
+    const bool fuse = h->fuse_tail && !h->timer.enabled && h->Cp == h->C;
     for (int i = 0; i < nb_steps; ++i) {
         const float* xin = i == 0 ? x0 : out;
         AFTER_TRY(run_net(h, s, xin, B, h->maps, h->maps + h->ms, rows, T,
-                          h->cond_ab + (size_t)i * step_stride, h->cache > 0 ? i : 0, h->row_groups));
-        AFTER_TRY(cfg_combine(h, s, xin, out, B, T));
+                          h->cond_ab + (size_t)i * step_stride, h->cache > 0 ? i : 0, h->row_groups,
+                          !fuse || i == 0, !fuse));
+        if (fuse) {
+            GemmArgs g{h->xres, h->E, h->out_w, h->E, h->out_b, nullptr, 0, nullptr, 0, rows * T, h->C, h->E,
+                       EPI_CFG_EULER};
+            g.xin = xin;
+            g.xout = out;
+            g.xt = i + 1 < nb_steps ? h->xt : nullptr;
+            g.xt_ld = h->Cp;
+            g.cfg = reinterpret_cast<const float*>(h->dparams);
+            g.T = T;
+            AFTER_TRY(launch_gemm_cfg_euler(g, s));
+        } else {
+            AFTER_TRY(cfg_combine(h, s, xin, out, B, T));
+        }
         if (h->cache > 0) AFTER_TRY(roll_cache_step(h, s, rows, T, T, i));
     }
     if (h->cache > 0) {

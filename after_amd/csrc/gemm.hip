@@ -587,8 +587,13 @@ __device__ __forceinline__ void wait_vmcnt_imm() {
 // (own + partner), a commutative two-term sum -> bit-deterministic, no atomics.
 // Ring slot = [A k-half 0 | A k-half 1 | W k-half 0 | W k-half 1] rows of 32 floats, filled
 // by LDS-DMA with the same source-side XOR swizzle as above.  Requires K % 64 == 0.
-template <int MB, int NB, int KS, int NS, int RS>
+// MODE 1 (EPI_CFG_EULER, MB = 3): the tile's three row blocks are the three CFG branches of the
+// same 16 tokens (tile row 16 r + tt <-> A row r * BT + 16 tm + tt), so after the k-part reduction a
+// lane holds d_full, d_mid, d_none of one token and four channels and the CFG combination, the
+// Euler update and both output layouts are finished in registers.
+template <int MB, int NB, int KS, int NS, int RS, int MODE = 0>
 __global__ __launch_bounds__(128 * KS * RS) void gemm_f32_bal_kernel(GemmArgs g, int tiles_m, int tiles_n, int xcd_pm) {
+    static_assert(MODE == 0 || (MB == 3 && RS == 1), "MODE 1: three row blocks = the three CFG branches");
     constexpr int BK = 32, CPR = 8, RPP = 8, KK = 2;
     static_assert(MB % RS == 0, "row parts must divide the tile's block rows");
     constexpr int MT = MB / RS, NT = NB;          // blocks per wave (names used by the macros)
@@ -639,7 +644,11 @@ __global__ __launch_bounds__(128 * KS * RS) void gemm_f32_bal_kernel(GemmArgs g,
         const int row = row0 + rsub;
         if (row0 < KS * BM) {
             const int half = row0 / BM;
-            const int gm = min(m0 + row - half * BM, M - 1);
+            int gm = min(m0 + row - half * BM, M - 1);
+            if constexpr (MODE == 1) {
+                const int rin = row - half * BM, bt = M / 3;  // branch rin / 16, token 16 tm + rin % 16
+                gm = (rin >> 4) * bt + min(tm * 16 + (rin & 15), bt - 1);
+            }
             sbase[i] = g.A + half * Kh;
             voff[i] = ((unsigned)gm * (unsigned)g.lda + (unsigned)((pos ^ (row & (CPR - 1))) * 4)) * 4u;
         } else {
@@ -723,6 +732,47 @@ __global__ __launch_bounds__(128 * KS * RS) void gemm_f32_bal_kernel(GemmArgs g,
     }
     unsigned long long t_red = 0, t_st = 0;
     if (g.dbg) t_red = __builtin_readcyclecounter();
+    if constexpr (MODE == 1) {
+        const int bt = M / 3, T = g.T;
+        const float total = g.cfg[0], factor = g.cfg[1], dt = g.cfg[2];
+        const int tok = tm * 16 + (lane & 15);
+        const int bq = tok / T, t = tok - bq * T;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (j % KS != kh) continue;  // wave (kh, part) finishes column blocks j = kh (mod KS), all branches
+            const int gn = n0 + part * 16 * NB + j * 16 + 4 * (lane >> 4);
+            f32x4 d[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int w0 = part * KS;
+                d[i] = *reinterpret_cast<const f32x4*>(red + ((w0 * MT * NT + i * NT + j) * 64 + lane) * 4);
+#pragma unroll
+                for (int q = 1; q < KS; ++q)
+                    d[i] += *reinterpret_cast<const f32x4*>(red + (((w0 + q) * MT * NT + i * NT + j) * 64 + lane) * 4);
+            }
+            if (tok >= bt) continue;
+            f32x4 xn = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = gn + r;
+                if (n >= N) continue;
+                const float bo = g.bias ? g.bias[n] : 0.f;
+                const float dfull = d[0][r] + bo, dmid = d[1][r] + bo, dnone = d[2][r] + bo;
+                const float v = dnone + total * (dmid + factor * (dfull - dmid) - dnone);
+                const size_t o = ((size_t)bq * N + n) * T + t;
+                xn[r] = (g.xin ? g.xin[o] : 0.f) + v * dt;
+                g.xout[o] = xn[r];
+            }
+            if (g.xt) {
+                float* xp = g.xt + (size_t)tok * g.xt_ld + gn;
+                if (gn + 3 < g.xt_ld) *reinterpret_cast<f32x4*>(xp) = xn;  // columns >= N carry zeros (padding)
+                else
+                    for (int r = 0; r < 4; ++r)
+                        if (gn + r < g.xt_ld) xp[r] = xn[r];
+            }
+        }
+        return;
+    }
     // accumulator layout (transposed MFMA): lane l holds C[row = l & 15][col = 4 (l >> 4) + r]
     const int crow = lane & 15, ccol0 = 4 * (lane >> 4);
     const bool vec_ok = ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0) &&
@@ -986,6 +1036,33 @@ int launch_cfg(const GemmArgs& g, hipStream_t stream) {
 }  // namespace
 
 int launch_gemm(const GemmArgs& g, hipStream_t stream) { return launch_gemm_cfg(g, 0, 0, stream); }
+
+int launch_gemm_cfg_euler(const GemmArgs& g, hipStream_t stream) {
+    constexpr int MB = 3, NB = 1, KS = 4, NS = 2;  // 16 tokens x 32 channels per workgroup, 4 k-parts (8 waves)
+    AFTER_REQUIRE(g.M > 0 && g.M % 3 == 0 && g.N > 0 && g.T > 0 && (g.M / 3) % g.T == 0, AFTER_E_INVALID,
+                  "cfg_euler gemm: M = 3 * B * T expected (M=%d T=%d)", g.M, g.T);
+    AFTER_REQUIRE((g.K % (32 * KS)) == 0 && (g.lda % 4) == 0 && (g.ldw % 4) == 0 && g.xout && g.cfg,
+                  AFTER_E_INVALID, "cfg_euler gemm: K %% %d != 0 or missing operands", 32 * KS);
+    AFTER_REQUIRE((size_t)g.M * g.lda < (1u << 30) && (size_t)g.N * g.ldw < (1u << 30), AFTER_E_INVALID,
+                  "cfg_euler gemm: operand too large for 32-bit DMA offsets");
+    AFTER_REQUIRE(!g.xt || (g.xt_ld >= g.N && (g.xt_ld % 4) == 0), AFTER_E_INVALID, "cfg_euler gemm: bad xt_ld");
+    const int bt = g.M / 3;
+    const int tiles_m = cdiv(bt, 16), tiles_n = cdiv(g.N, 32 * NB);
+    const size_t ring = size_t(NS) * KS * (16 * MB + 32 * NB) * 32 * sizeof(float);
+    const size_t red = size_t(2 * KS) * MB * NB * 256 * sizeof(float);
+    const size_t lds = ring > red ? ring : red;
+    static bool attr_set = false;
+    if (!attr_set) {
+        AFTER_HIP_CHECK(hipFuncSetAttribute(
+            reinterpret_cast<const void*>(gemm_f32_bal_kernel<MB, NB, KS, NS, 1, 1>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_f32_bal_kernel<MB, NB, KS, NS, 1, 1>), dim3(tiles_m * tiles_n), dim3(128 * KS), lds,
+                       stream, g, tiles_m, tiles_n, 0);
+    AFTER_HIP_CHECK(hipGetLastError());
+    return AFTER_OK;
+}
 
 int launch_gemm_cfg(const GemmArgs& g, int mt, int nt, hipStream_t stream) {
     AFTER_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, AFTER_E_INVALID, "gemm: empty problem %dx%dx%d",
