@@ -32,10 +32,26 @@ constexpr int kMaxKeys = 32;   // W - 1 + chunk
 constexpr int kMaxChunk = 8;
 constexpr int kMaxPer = 8;     // E / 64 <= 8  (E <= 512: every shipped config)
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false);
+    return v + __int_as_float(t);
+}
+
+// Sum over the 64 lanes, same value in every lane: DPP row operations inside each 16-lane row
+// (VALU, no LDS round trip), then the four row totals through v_readlane in a fixed order.
+// (Six dependent ds_bpermute butterflies cost ~1 us of the 6 us LayerNorm kernels.)
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);  // row_half_mirror
+    v = dpp_add<0x140>(v);  // row_mirror
+    const int iv = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(iv, 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(iv, 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(iv, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 // LayerNorm statistics of one E-long row held as v[i] = row[lane + 64*i]
@@ -260,12 +276,6 @@ struct AttnArgs {
     int nkmax;              // LDS rows provisioned for keys: W - 1 + cs
     int dbg;                // AFTER_ATTN_DBG bitmask (diagnostics): 1 no rope, 2 no reduce, 4 no LN tail, 8 no KV loads
 };
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false);
-    return v + __int_as_float(t);
-}
 
 __device__ __forceinline__ float group16_sum(float v) {
     // all-reduce over the 16 lanes of a query group with DPP row operations (VALU, no LDS round
