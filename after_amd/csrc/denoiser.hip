@@ -217,38 +217,69 @@ __global__ __launch_bounds__(256) void ln_mod_ln_kernel(const float* __restrict_
     const int r = m / T, t = m - r * T;
     const int sr = src_map ? src_map[r] : r;
     const float* xi = xin + ((size_t)sr * T + t) * E;
-    const int nper = E >> 6;
-    // every operand of the row is requested up front: one exposed memory latency
-    float v[kMaxPer], al[kMaxPer], be[kMaxPer], ww[kMaxPer], bb[kMaxPer];
+    // lane owns 4 consecutive channels per 256-channel slice (float4 traffic); every operand of
+    // the row is requested up front: one exposed memory latency
+    constexpr int NV = kMaxPer / 4;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v[NV], al[NV], be[NV], ww[NV], bb[NV];
     const float* ab = nullptr;
     if (tc_ab) ab = tc_ab + ((size_t)(tc_map ? tc_map[r] : r) * T + t) * tc_ld;
 #pragma unroll
-    for (int i = 0; i < kMaxPer; ++i)
-        if (i < nper) {
-            const int c = lane + 64 * i;
-            v[i] = xi[c];
-            al[i] = ab ? ab[c] : 0.f;
-            be[i] = ab ? ab[E + c] : 0.f;
-            ww[i] = w1[c];
-            bb[i] = b1[c];
+    for (int i = 0; i < NV; ++i) {
+        const int c = 4 * lane + 256 * i;
+        v[i] = al[i] = be[i] = ww[i] = bb[i] = z4;
+        if (c < E) {
+            v[i] = *reinterpret_cast<const float4*>(xi + c);
+            if (ab) {
+                al[i] = *reinterpret_cast<const float4*>(ab + c);
+                be[i] = *reinterpret_cast<const float4*>(ab + E + c);
+            }
+            ww[i] = *reinterpret_cast<const float4*>(w1 + c);
+            bb[i] = *reinterpret_cast<const float4*>(b1 + c);
         }
+    }
+    auto stats = [&](float& mean, float& rstd) {  // lanes past E hold zeros: they add nothing to the sums
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        mean = wave_sum(s) / (float)E;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (4 * lane + 256 * i < E) {
+                const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+                q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+        rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + 1e-5f);
+    };
     float mean, rstd;
-    row_stats(v, nper, E, mean, rstd);
+    stats(mean, rstd);
     if (ab) {
 #pragma unroll
-        for (int i = 0; i < kMaxPer; ++i)
-            if (i < nper) v[i] = (v[i] - mean) * rstd * (1.0f + al[i]) + be[i];
-        row_stats(v, nper, E, mean, rstd);
+        for (int i = 0; i < NV; ++i)
+            if (4 * lane + 256 * i < E) {
+                v[i].x = (v[i].x - mean) * rstd * (1.0f + al[i].x) + be[i].x;
+                v[i].y = (v[i].y - mean) * rstd * (1.0f + al[i].y) + be[i].y;
+                v[i].z = (v[i].z - mean) * rstd * (1.0f + al[i].z) + be[i].z;
+                v[i].w = (v[i].w - mean) * rstd * (1.0f + al[i].w) + be[i].w;
+            }
+        stats(mean, rstd);
     }
     float* xo = xout + (size_t)m * E;
     float* ho = h + (size_t)m * E;
 #pragma unroll
-    for (int i = 0; i < kMaxPer; ++i)
-        if (i < nper) {
-            const int c = lane + 64 * i;
-            xo[c] = v[i];
-            ho[c] = (v[i] - mean) * rstd * ww[i] + bb[i];
+    for (int i = 0; i < NV; ++i) {
+        const int c = 4 * lane + 256 * i;
+        if (c < E) {
+            *reinterpret_cast<float4*>(xo + c) = v[i];
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * ww[i].x + bb[i].x;
+            o.y = (v[i].y - mean) * rstd * ww[i].y + bb[i].y;
+            o.z = (v[i].z - mean) * rstd * ww[i].z + bb[i].z;
+            o.w = (v[i].w - mean) * rstd * ww[i].w + bb[i].w;
+            *reinterpret_cast<float4*>(ho + c) = o;
         }
+    }
 }
 
 // SelfAttention + second half of DecoderBlock.forward for one chunk of <= 8 query
