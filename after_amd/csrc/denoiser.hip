@@ -54,25 +54,6 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 
-// LayerNorm statistics of one E-long row held as v[i] = row[lane + 64*i]
-// (nn.LayerNorm: biased variance, eps inside the sqrt; transformerv2.py:326-335).
-__device__ __forceinline__ void row_stats(const float (&v)[kMaxPer], int nper, int E, float& mean,
-                                          float& rstd) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < kMaxPer; ++i)
-        if (i < nper) s += v[i];
-    mean = wave_sum(s) / (float)E;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < kMaxPer; ++i)
-        if (i < nper) {
-            const float d = v[i] - mean;
-            q += d * d;
-        }
-    rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + 1e-5f);
-}
-
 // ---------------------------------------------------------------- small kernels
 
 // [n_src, Cc, T] (time contiguous) -> token-major [(r*T + t), ld] for the rows in
@@ -390,19 +371,27 @@ __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
     }
     // Operands of the LayerNorm tail are requested before anything else so that their
     // latency hides behind the attention proper.
-    const int nper = E >> 6;
     const float* abp = a.cond_ab ? a.cond_ab + (size_t)r * a.cond_ld : nullptr;
-    float al[kMaxPer], be[kMaxPer], ww[kMaxPer], bb[kMaxPer];
+    constexpr int NV = kMaxPer / 4;  // lane owns 4 consecutive channels per 256-channel slice
+    const float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 al[NV], be[NV], ww[NV], bb[NV];
     constexpr bool kPreloadLN = PRELOAD;
+    auto load_ln = [&]() {
 #pragma unroll
-    for (int i = 0; i < kMaxPer; ++i)
-        if (kPreloadLN && i < nper) {
-            const int c = lane + 64 * i;
-            al[i] = abp ? abp[c] : 0.f;
-            be[i] = abp ? abp[E + c] : 0.f;
-            ww[i] = a.w3[c];
-            bb[i] = a.b3[c];
+        for (int i = 0; i < NV; ++i) {
+            const int c = 4 * lane + 256 * i;
+            al[i] = be[i] = ww[i] = bb[i] = zv;
+            if (c < E) {
+                if (abp) {
+                    al[i] = *reinterpret_cast<const float4*>(abp + c);
+                    be[i] = *reinterpret_cast<const float4*>(abp + E + c);
+                }
+                ww[i] = *reinterpret_cast<const float4*>(a.w3 + c);
+                bb[i] = *reinterpret_cast<const float4*>(a.b3 + c);
+            }
         }
+    };
+    if (kPreloadLN) load_ln();
 
     for (int qb = 0; qb < nq; qb += 4) {
         const int qi = qb + grp;
@@ -520,38 +509,55 @@ __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
     __syncthreads();
 
     // ---- AdaLN(cond) + norm3, one wave per row
-    if (!kPreloadLN) {
-#pragma unroll
-        for (int i = 0; i < kMaxPer; ++i)
-            if (i < nper) {
-                const int c = lane + 64 * i;
-                al[i] = abp ? abp[c] : 0.f;
-                be[i] = abp ? abp[E + c] : 0.f;
-                ww[i] = a.w3[c];
-                bb[i] = a.b3[c];
-            }
-    }
+    if (!kPreloadLN) load_ln();
     for (int qi = hw; qi < nq; qi += H) {
-        float v[kMaxPer];
+        float4 v[NV];
 #pragma unroll
-        for (int i = 0; i < kMaxPer; ++i)
-            if (i < nper) v[i] = smem[qi * ld + lane + 64 * i];
+        for (int i = 0; i < NV; ++i) {
+            const int c = 4 * lane + 256 * i;
+            v[i] = c < E ? *reinterpret_cast<const float4*>(smem + qi * ld + c) : zv;
+        }
+        auto stats = [&](float& mean, float& rstd) {  // lanes past E hold zeros
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            mean = wave_sum(sum) / (float)E;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (4 * lane + 256 * i < E) {
+                    const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+                    q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                }
+            rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + 1e-5f);
+        };
         float mean, rstd;
         if (abp) {
-            row_stats(v, nper, E, mean, rstd);
+            stats(mean, rstd);
 #pragma unroll
-            for (int i = 0; i < kMaxPer; ++i)
-                if (i < nper) v[i] = (v[i] - mean) * rstd * (1.0f + al[i]) + be[i];
+            for (int i = 0; i < NV; ++i)
+                if (4 * lane + 256 * i < E) {
+                    v[i].x = (v[i].x - mean) * rstd * (1.0f + al[i].x) + be[i].x;
+                    v[i].y = (v[i].y - mean) * rstd * (1.0f + al[i].y) + be[i].y;
+                    v[i].z = (v[i].z - mean) * rstd * (1.0f + al[i].z) + be[i].z;
+                    v[i].w = (v[i].w - mean) * rstd * (1.0f + al[i].w) + be[i].w;
+                }
         }
-        row_stats(v, nper, E, mean, rstd);
+        stats(mean, rstd);
         const size_t m = rowbase + i0 + qi;
 #pragma unroll
-        for (int i = 0; i < kMaxPer; ++i)
-            if (i < nper) {
-                const int c = lane + 64 * i;
-                a.xres[m * E + c] = v[i];
-                a.h[m * E + c] = (v[i] - mean) * rstd * ww[i] + bb[i];
+        for (int i = 0; i < NV; ++i) {
+            const int c = 4 * lane + 256 * i;
+            if (c < E) {
+                *reinterpret_cast<float4*>(a.xres + m * E + c) = v[i];
+                float4 o;
+                o.x = (v[i].x - mean) * rstd * ww[i].x + bb[i].x;
+                o.y = (v[i].y - mean) * rstd * ww[i].y + bb[i].y;
+                o.z = (v[i].z - mean) * rstd * ww[i].z + bb[i].z;
+                o.w = (v[i].w - mean) * rstd * ww[i].w + bb[i].w;
+                *reinterpret_cast<float4*>(a.h + m * E + c) = o;
             }
+        }
     }
 }
 
