@@ -105,7 +105,8 @@ int after_model_forward(after_denoiser* h, const float* x, const float* time, co
 
 /* out[B,C,T] = x0 integrated with nb_steps Euler steps of the rectified flow,
  * t = linspace(0,1,nb_steps+1)[:-1], dt = 1/nb_steps.  Replaces:
- * RectifiedFlow.sample (after/diffusion/model.py:763-785).  out may alias x0. */
+ * RectifiedFlow.sample (after/diffusion/model.py:763-785); with streaming caches enabled:
+ * Streamer.sample (after_scripts/export.py:398-416).  out may alias x0. */
 int after_sample(after_denoiser* h, const float* x0, const float* cond, const float* time_cond,
                  float* out, int B, int T, int nb_steps, float guidance_timbre,
                  float guidance_structure, float drop_value, int cfg_mode, void* stream);
@@ -122,9 +123,10 @@ int after_denoiser_set_graph(after_denoiser* h, int enable);
  * the attention chunk) per layer, per diffusion step, per network row;
  * zero-initialised like the reference buffers.  max_steps / max_rows generalise the
  * reference's max_diffusion_steps = 16 / max_batch_size = 4 (:130-131).  After
- * enabling, drive after_model_forward / after_denoiser_forward with cache_index = i
- * followed by after_denoiser_roll_cache(size, i) per diffusion step (export.py:398-416);
- * after_sample (the offline sampler) is rejected while caches are enabled. */
+ * enabling, either drive after_model_forward / after_denoiser_forward with cache_index = i
+ * followed by after_denoiser_roll_cache(size, i) per diffusion step, or call after_sample,
+ * which then IS that loop (Streamer.sample, export.py:398-416): step i attends over cache
+ * slot i and rolls it by the chunk length T (nb_steps <= max_steps). */
 int after_denoiser_enable_cache(after_denoiser* h, int cache_size, int max_steps, int max_rows);
 int after_denoiser_reset_cache(after_denoiser* h, void* stream);
 /* Replaces: DenoiserV2.roll_cache (transformerv2.py:514-515, :171-188). */
