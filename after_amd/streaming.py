@@ -162,6 +162,23 @@ class Streamer:
     def generate(self, x, noise=None):
         return self.decode(self.diffuse(x, noise))
 
+    # ------------------------------------------------------------ export.py:495-506
+    project_model = None  # optional 2-D latent-map autoencoder (export.py --latent_project); None = DummyIdentity
+
+    @torch.no_grad()
+    def map2latent(self, x):
+        v = x.mean(-1)
+        if self.project_model is not None:
+            v = self.project_model.decoder(v)
+        return v.unsqueeze(-1).repeat(1, 1, x.shape[-1])
+
+    @torch.no_grad()
+    def latent2map(self, x):
+        v = x.mean(-1)
+        if self.project_model is not None:
+            v = self.project_model.encoder(v)
+        return v.unsqueeze(-1).repeat(1, 1, x.shape[-1])
+
     # ------------------------------------------------------------ export.py:486-493
     @torch.no_grad()
     def forward(self, x, noise=None):
