@@ -154,6 +154,21 @@ class Streamer:
             return out.repeat(n, 1, 1) if n > 1 else out
         return self.sample(noise.contiguous(), zsem.contiguous(), time_cond)
 
+    # ------------------------------------------------------------ export.py:457-470
+    @torch.no_grad()
+    def diffuse_timbre(self, x, noise=None):
+        """x[n, 1 + zt_channels, chunk audio samples]: channel 0 = structure AUDIO, the rest the
+        timbre embedding as audio-rate signals (their mean over the chunk is used)."""
+        n = x.shape[0]
+        zsem = x[:, 1:].mean(-1) * self.latent_range
+        time_cond = self.structure(x[:, :1].contiguous())
+        if noise is None:
+            noise = torch.randn(n, self.ae_latents, time_cond.shape[-1], device=x.device)
+        if self.share_first_stream:
+            out = self.sample(noise[:1].contiguous(), zsem[:1].contiguous(), time_cond[:1].contiguous())
+            return out.repeat(n, 1, 1) if n > 1 else out
+        return self.sample(noise.contiguous(), zsem.contiguous(), time_cond.contiguous())
+
     @torch.no_grad()
     def decode(self, z):
         return self.emb_model_structure.decode(z)
@@ -161,6 +176,10 @@ class Streamer:
     @torch.no_grad()
     def generate(self, x, noise=None):
         return self.decode(self.diffuse(x, noise))
+
+    @torch.no_grad()
+    def generate_timbre(self, x, noise=None):
+        return self.decode(self.diffuse_timbre(x, noise))
 
     # ------------------------------------------------------------ export.py:495-506
     project_model = None  # optional 2-D latent-map autoencoder (export.py --latent_project); None = DummyIdentity

@@ -70,6 +70,14 @@ def test_streamer_forward_shapes_and_limits(hip_device):
         st.set_nb_steps(3)
     with pytest.raises(ValueError):
         st(torch.randn(1, 2, 1000, device=hip_device))
+    # the remaining nn~ methods of export.py: generate_timbre (audio structure + timbre signals),
+    # latent2map / map2latent (identity projection without --latent_project)
+    xt = torch.randn(2, 1 + st.zt_channels, 4 * st.ae_ratio, device=hip_device)
+    yt = st.generate_timbre(xt)
+    assert yt.shape == (2, 1, 4 * st.ae_ratio) and torch.isfinite(yt).all()
+    lat = torch.randn(2, st.zt_channels, 4, device=hip_device)
+    m = st.latent2map(lat)
+    assert torch.equal(m, lat.mean(-1, keepdim=True).repeat(1, 1, 4)) and torch.equal(st.map2latent(m), m)
 
 
 def test_midi_streamer_matches_oracle(hip_device):
