@@ -2,23 +2,26 @@
 //
 // Used for every Linear of the denoiser (reference transformerv2.py:251,275-283,
 // 330-334,387-398,430,488-492 -- all `nn.Linear`, i.e. x @ W^T + b with W stored
-// [out, in]) so activations and weights are both K-contiguous ("B^T input").
+// [out, in]) so activations and weights are both K-contiguous ("B^T input").  Everything
+// accumulates with v_mfma_f32_16x16x4_f32 (exact fp32: the reference computes in fp32,
+// SURVEY.md 2.1).  Four kernel families, chosen per shape in launch_gemm_cfg:
 //
-// Design (gfx950): 256-thread workgroup = 4 waves in a 2x2 arrangement, each wave
-// owning MT x NT tiles of 16x16 accumulated with v_mfma_f32_16x16x4_f32 (exact
-// fp32: the reference computes in fp32).  The 16x16 granule (rather
-// than 32x32) is what lets the B=1 shapes (M = 768 tokens) fill 256 CUs with >= 2
-// co-resident workgroups each: the fp32 matrix pipe is slow (32 cycles per
-// instruction), so LDS/L2 bandwidth is idle and the only enemy is exposed latency
-// -- which co-resident workgroups hide for each other.  K is walked in BK=32 slabs
-// staged through LDS: coalesced 16-byte global loads (8 lanes cover one 128-byte row
-// segment) -> registers -> ds_write_b128 into rows padded to 40 floats (160 B), the
-// stride for which the fragment reads -- one ds_read_b128 per lane = four
-// consecutive k of one row = operands of four MFMAs -- are bank-conflict free in
-// every 16-lane service group of ds_read_b128.  The next slab's global loads are
-// issued before the current slab's MFMAs (register double buffering + two LDS
-// buffers, one barrier per slab).  Workgroup ids are remapped so that each XCD
-// (private 4 MiB L2) owns a contiguous range of N-tiles, i.e. streams 1/8 of W.
+//   gemm_f32_bal_kernel     the workhorse: balanced split-K / row-split tiles of 16x16 blocks
+//                           sized so that M = 768 B tokens fills 256 CUs with equal work, >= 2
+//                           waves per SIMD, operands by asm LDS-DMA, deterministic LDS
+//                           reduction of the k-parts; MODE 1 fuses out_proj + CFG + Euler
+//   gemm_f32_skinny_kernel  <= 48 tokens (streaming): column-owning workgroups, 8-way K split
+//                           inside the workgroup, fragments straight from global memory
+//   gemm_f32_dma_kernel     first-generation 2x2-wave tiles with an LDS-DMA ring (small
+//                           Linears, K % 64 != 0)
+//   gemm_f32_kernel         register-staged fallback for K % 32 != 0
+//
+// Common ground (gfx950): K is walked in 32-deep slabs staged through LDS; a tile row in LDS is
+// the plain 128-byte k-slab of that row and bank conflicts of the ds_read_b128 fragment reads
+// are removed by an XOR swizzle applied on the DMA SOURCE address; one raw s_barrier per slab
+// with counted vmcnt; workgroup ids are remapped so that the 8 XCDs (private 4 MiB L2s) each
+// own a compact part of the tile matrix.  DESIGN.md section 4 has the measurements behind the
+// choices (matrix-pipe co-issue, SIMD quantisation, XCD traffic).
 #include <cstdlib>
 #include <type_traits>
 
