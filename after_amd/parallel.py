@@ -29,6 +29,12 @@ def is_distributed() -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+def _host_staged() -> bool:
+    """gloo has no device path for these collectives: stage GPU tensors through the host (CPU tests,
+    and the AFTER_BENCH_SHARE_GPU test hook of bench.py).  RCCL ("nccl") works on device memory."""
+    return dist.get_backend() == "gloo"
+
+
 def broadcast_module(module: torch.nn.Module, src: int = 0) -> None:
     """One bucketed broadcast of every parameter / float buffer from `src` (start-up only)."""
     if not is_distributed():
@@ -38,7 +44,12 @@ def broadcast_module(module: torch.nn.Module, src: int = 0) -> None:
     if not tensors:
         return
     flat = torch.cat([t.detach().reshape(-1) for t in tensors])
-    dist.broadcast(flat, src=src)
+    if flat.is_cuda and _host_staged():
+        host = flat.cpu()
+        dist.broadcast(host, src=src)
+        flat = host.to(flat.device)
+    else:
+        dist.broadcast(flat, src=src)
     off = 0
     with torch.no_grad():
         for t in tensors:
@@ -64,6 +75,9 @@ def gather_clips(local: torch.Tensor, n_clips: int) -> torch.Tensor:
     pad = local
     if local.shape[0] < m:
         pad = torch.cat([local, local.new_zeros((m - local.shape[0], ) + tuple(local.shape[1:]))])
+    dev = pad.device
+    if pad.is_cuda and _host_staged():
+        pad = pad.cpu()
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad.contiguous())
-    return torch.cat([o[:s] for o, s in zip(out, sizes)])
+    return torch.cat([o[:s] for o, s in zip(out, sizes)]).to(dev)

@@ -74,11 +74,19 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    # test hook: AFTER_BENCH_SHARE_GPU=1 runs all ranks on cuda:0 over gloo, to exercise the
+    # multi-rank flow on a single-GPU box (the numbers of such a run mean nothing)
+    share = os.environ.get("AFTER_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from after_amd import parallel, pipeline
     torch.set_grad_enabled(False)
@@ -101,11 +109,11 @@ def main():
         tcond = torch.zeros(hi - lo, dcfg["net"]["tcond_dim"], T_FRAMES, device=dev)
         tcond[:, 60:64, 32:96] = 0.7
 
-    def step():
+    def step(gather=True):
         audio, z = pipeline.generate_from_latents(model, zs, zt, x0, nb_steps=NB_STEPS,
                                                   guidance_timbre=2.0, guidance_structure=1.0,
                                                   time_cond=tcond)
-        if world > 1:
+        if world > 1 and gather:
             audio = parallel.gather_clips(audio, n_clips)
         return audio
 
@@ -132,7 +140,7 @@ def main():
     roof = None
     if rank == 0:
         model.net.profile(True)
-        step()
+        step(gather=False)  # rank 0 only: no collective in this pass
         torch.cuda.synchronize()
         ms, launches, flops = model.net.gemm_time()
         model.net.profile(False)
@@ -213,6 +221,7 @@ def main():
         }
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()  # rank 0's roofline pass is done: leave together
         dist.destroy_process_group()
 
 
