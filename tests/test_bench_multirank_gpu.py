@@ -1,0 +1,27 @@
+"""The N > 1 flow of bench.py (one process per GPU under torch.distributed.run) exercised with two
+ranks sharing cuda:0 over gloo (AFTER_BENCH_SHARE_GPU=1): sharding, weight broadcast, the per-step
+clip all-gather, max-over-ranks timing, and that only rank 0 prints.  -m gpu.
+(Regression: a rank-0-only pass once entered the all-gather and hung the multi-GPU runs.)"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_rank_bench_flow(hip_device):
+    env = dict(os.environ, AFTER_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "1", "--warmup", "1", "--config", "tiny", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0
