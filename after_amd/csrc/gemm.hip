@@ -1140,7 +1140,7 @@ int launch_gemm_cfg(const GemmArgs& g, int mt, int nt, hipStream_t stream) {
         const char* e = getenv("AFTER_GEMM_SKINNY");
         use_skinny = e ? atoi(e) : 1;
     }
-    if (use_skinny && g.M <= (use_skinny > 1 ? 96 : 48) && (g.K % 128) == 0 && g.N >= 256) {
+    if (use_skinny && g.M <= (use_skinny > 1 ? 96 : 48) && (g.K % 128) == 0 && g.N >= 64) {
         if (g.M <= 16) return launch_skinny<1>(g, stream);
         if (g.M <= 48) return launch_skinny<3>(g, stream);
         return launch_skinny<6>(g, stream);  // AFTER_GEMM_SKINNY=2 only: slower than split-K at M = 96

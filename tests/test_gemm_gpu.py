@@ -56,7 +56,7 @@ def test_gemm_split_k_shapes(tile, M, N, K, hip_device):
 
 @pytest.mark.parametrize("tile,M", [((401, 0), 12), ((401, 0), 16), ((403, 0), 33), ((403, 0), 48), ((406, 0), 96),
                                     ((406, 0), 70), ((0, 0), 12), ((0, 0), 96)])
-@pytest.mark.parametrize("N,K", [(1536, 512), (512, 1536), (264, 128)])
+@pytest.mark.parametrize("N,K", [(1536, 512), (512, 1536), (264, 128), (72, 1024)])
 def test_gemm_skinny_shapes(tile, M, N, K, hip_device):
     """Few-token (streaming) shapes: column-owning workgroups, 8-way K split inside the workgroup."""
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
