@@ -668,7 +668,9 @@ __global__ __launch_bounds__(128 * KS * RS) void gemm_f32_bal_kernel(GemmArgs g,
                  :                                                                                \
                  : "s"(lds0 + (unsigned)(((slot_) * STAGE + (wid * LPS + (w_)) * RPP * BK) * 4)), \
                    "v"(voff[w_]), "s"(sbase[w_] + (slab_) * BK)                                   \
-                 : "memory", "m0");
+                 : "memory"); /* m0 is a reserved register: hipcc never keeps a value in it across \
+                                 statements (it rejects it in a clobber list), it re-materialises it \
+                                 before each of its own uses */
 
     f32x4 acc[MT][NT];
 #pragma unroll
