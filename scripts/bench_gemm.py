@@ -5,8 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from after_amd import diag
 dev = torch.device("cuda:0")
-shapes = [(1536,1536,512),(1536,512,1536),(3072,1536,512),(3072,512,1536)]
-tiles = [(103,23),(103,21),(104,22),(104,23),(304,23),(304,22),(306,22),(306,23),(203,22)]
+shapes = [(6144,1536,512),(6144,512,1536)]
+tiles = [(2,2),(104,23),(104,22),(304,23),(304,33),(304,22),(306,23),(306,22)]
 for (M,N,K) in shapes:
     a = torch.randn(M,K,device=dev); w = torch.randn(N,K,device=dev); out = torch.empty(M,N,device=dev)
     ref = (a.double() @ w.double().T)
@@ -15,7 +15,7 @@ for (M,N,K) in shapes:
         out.zero_()
         diag.gemm(a,w,tile=tile,out=out)
         err = (out.double()-ref).abs().max().item()
-        for _ in range(3): diag.gemm(a,w,tile=tile,out=out)
+        for _ in range(30): diag.gemm(a,w,tile=tile,out=out)   # also lets the clocks settle: the first config of a run is otherwise ~15 % slow
         torch.cuda.synchronize()
         e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
         reps=50
