@@ -459,7 +459,7 @@ int make_dma(after_ae* h, DmaConv& d, const float* packed, int cin, int cout, in
         d.in.ooff[p] = ooff ? ooff[p] : 0;
     }
     d.in.Nn_hint = Nn_hint;
-    d.in.B_hint = 1;
+    d.in.B_hint = h->max_batch;  // the handle is (re)built for the batch it serves
     conv_dma_plan(d.in, &d.plan);
     d.w = h->wd.take<float>(d.plan.w_floats);
     AFTER_REQUIRE(d.w, AFTER_E_NOMEM, "autoencoder: DMA weight arena exhausted");

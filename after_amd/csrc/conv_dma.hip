@@ -444,7 +444,9 @@ void conv_dma_plan(const ConvDmaPlanIn& in, ConvDmaPlan* p) {
     int mt = 1, nt = 1;
     if (wgs(64, 64) >= 512) mt = 2, nt = 2;
     else if (wgs(32, 64) >= 512) mt = 1, nt = 2;
-    else if (in.Cout >= 64 && wgs(64, 32) >= 384) mt = 2, nt = 1;
+    else if (in.Cout >= 64 && wgs(64, 32) >= 512) mt = 2, nt = 1;
+    // (below two workgroups per CU the 32x32 tile spreads the work over more CUs: 768 -> 768 @
+    // T = 1024 is 384 tiles of 64x32 = 1.5 per CU, but 768 tiles of 32x32 = 3 per CU)
     if (in.istride > 1 && nt > 1) nt = 1, mt = in.Cout >= 64 ? 2 : 1;  // keep strided tiles narrow
     p->mt = mt;
     p->nt = nt;
