@@ -624,6 +624,11 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
     AFTER_REQUIRE(cfg->pqmf_bands >= 2 && cfg->kernel_size % 2 == 1 && cfg->kernel_size <= 7,
                   AFTER_E_INVALID, "autoencoder: pqmf_bands >= 2 and odd kernel_size <= 7 required");
     AFTER_REQUIRE(max_batch > 0 && max_samples > 0, AFTER_E_INVALID, "bad capacities");
+    // one statistics slot per normalised conv of a pass (the larger of encode / decode):
+    // 2 per ResnetBlock + 1 per resampling conv + stem / synth
+    AFTER_REQUIRE(2 * (cfg->n_stages * cfg->n_dilations + 1) + cfg->n_stages + 4 <= kStatSlots,
+                  AFTER_E_CAPACITY, "autoencoder: %d stages x %d dilations need more than %d statistics slots",
+                  cfg->n_stages, cfg->n_dilations, kStatSlots);
     after_ae* h = new (std::nothrow) after_ae();
     AFTER_REQUIRE(h, AFTER_E_NOMEM, "out of host memory");
     h->cfg = *cfg;
