@@ -80,6 +80,8 @@ SIGNATURES = {
     "after_ae_ratio": (c_int, [c_void_p]),
     "after_ae_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "after_ae_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "after_ae_decode_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "after_latent_reg": (c_int, [c_void_p, ctypes.c_longlong, ctypes.c_float, c_void_p, c_void_p]),
     "after_ae_pqmf_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "after_ae_pqmf_inverse": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "after_ae_enable_streaming": (c_int, [c_void_p, c_int]),
@@ -150,7 +152,10 @@ def current_stream(device):
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def require_gpu_tensor(t, name):
+def require_gpu_tensor(t, name, allow_row_stride=False):
+    """A dense fp32 CUDA tensor.  The C ABI takes bare pointers and assumes row-major contiguous
+    data everywhere except after_gemm_f32, whose lda/ldw arguments carry a row stride:
+    only that caller passes allow_row_stride=True."""
     import torch
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor")
@@ -160,4 +165,6 @@ def require_gpu_tensor(t, name):
             "the CPU restatement lives in oracle/ and is test infrastructure")
     if t.dtype != torch.float32:
         t = t.float()
-    return t if t.dim() == 2 and t.stride(1) == 1 else t.contiguous()
+    if allow_row_stride and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]:
+        return t
+    return t.contiguous()

@@ -130,10 +130,41 @@ class _PQMF(nn.Module):
         self.inverse_conv.register_parameter("weight", nn.Parameter(torch.from_numpy(iw)))
 
 
+class ReluBottleneck(nn.Module):
+    """SimpleNetsStream.py:742-760: identity on z at inference (`apply_noise=False`), plus the
+    regulariser mean(ELU(|z| - scale)) + 1 (core.py:189-198) that `encode` returns beside z."""
+
+    def __init__(self, scale: float = 3, sigma: float = 0.):
+        super().__init__()
+        self.scale = float(scale)
+        self.sigma = float(sigma)
+
+
+def _resolve_bottleneck(b):
+    """The bottleneck shapes what `encode` returns, and it has no parameters -- a checkpoint of a
+    codec trained with another one loads cleanly -- so anything but ReluBottleneck (the binding of
+    baseAE.gin:41-43,58) is refused instead of silently returning un-squashed latents."""
+    if b is None or (isinstance(b, str) and b.lower() in ("relu", "relubottleneck")):
+        return ReluBottleneck()
+    if isinstance(b, ReluBottleneck):
+        return b
+    name = b if isinstance(b, str) else type(b).__name__
+    raise NotImplementedError(
+        f"bottleneck {name!r}: after_amd builds ReluBottleneck only (TanhBottleneck would squash z "
+        "to scale*tanh(z), VAEBottleneck doubles the encoder's output channels)")
+
+
+def _check_activation(a):
+    name = None if a is None else (a if isinstance(a, str) else getattr(a, "__name__", type(a).__name__))
+    if name is not None and name.split(".")[-1] not in ("Snake", "SnakeBeta"):
+        raise NotImplementedError(f"activation {name!r}: after_amd builds SnakeBeta only "
+                                  "(SimpleNetsStream.py:15, core.py:217-260)")
+
+
 class AutoEncoder(nn.Module):
-    """Drop-in for the reference AutoEncoder on MI355X: same constructor arguments
-    (`bottleneck` is accepted and ignored: ReluBottleneck is the identity on z at
-    inference, SimpleNetsStream.py:753-760), same encode/decode/forward signatures."""
+    """Drop-in for the reference AutoEncoder on MI355X: same constructor arguments, same
+    encode/decode/forward signatures.  `bottleneck`: None / "relu" / a ReluBottleneck
+    (identity on z at inference + the regulariser, SimpleNetsStream.py:742-760)."""
 
     def __init__(self,
                  in_channels: int,
@@ -159,6 +190,8 @@ class AutoEncoder(nn.Module):
             raise NotImplementedError("use_noise=True (NoiseGenerator) is not built (baseAE.gin: False)")
         if resnet_groups != 8:
             raise NotImplementedError("resnet_groups must be 8 (every shipped config)")
+        _check_activation(activation)
+        self.bottleneck = _resolve_bottleneck(bottleneck)
         self.cfg = dict(in_channels=in_channels, channels=channels, z_channels=z_channels,
                         multipliers=list(multipliers), factors=list(factors),
                         dilations=list(dilations), kernel_size=kernel_size, use_norm=use_norm,
@@ -180,7 +213,7 @@ class AutoEncoder(nn.Module):
 
     def cfg_kwargs(self):
         """Constructor arguments of an identical codec (streaming twin, after_amd.streaming)."""
-        return dict(self.cfg)
+        return dict(self.cfg, bottleneck=self.bottleneck)
 
     # ------------------------------------------------------------ handle management
     def _apply(self, fn, *a, **k):
@@ -314,6 +347,8 @@ class AutoEncoder(nn.Module):
     @torch.no_grad()
     def encode(self, x, with_multi: bool = False, return_mean: bool = False):
         """SimpleNetsStream.py:918-941 -> (z, regloss); export: z only."""
+        if return_mean:  # :932-934 is the VAEBottleneck protocol
+            raise NotImplementedError("return_mean=True needs a VAEBottleneck (not built)")
         x = _lib.require_gpu_tensor(x, "x")
         if x.dim() != 3 or x.shape[1] != 1:
             raise ValueError(f"encode expects [B, 1, L], got {tuple(x.shape)}")
@@ -325,16 +360,19 @@ class AutoEncoder(nn.Module):
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().after_ae_encode(h, _lib.ptr(x), _lib.ptr(z), B, L,
                                                   _lib.current_stream(x.device)), "after_ae_encode")
-        reg = torch.zeros((), device=x.device)  # training-only regulariser (:757), not computed
+            # ReluBottleneck: z unchanged, reg = mean(ELU(|z| - scale)) + 1 (:753-760)
+            reg = torch.empty((), device=x.device, dtype=torch.float32)
+            _lib.check(_lib.lib().after_latent_reg(_lib.ptr(z), z.numel(), self.bottleneck.scale,
+                                                   _lib.ptr(reg), _lib.current_stream(x.device)),
+                       "after_latent_reg")
         if with_multi:
             return z, self.pqmf_forward(x), reg
         return z, reg
 
     @torch.no_grad()
     def decode(self, z, with_multi: bool = False):
-        """SimpleNetsStream.py:943-954."""
-        if with_multi:
-            raise NotImplementedError("decode(with_multi=True) is not built")
+        """SimpleNetsStream.py:943-954; with_multi=True also returns x_multiband, the decoder
+        output before the PQMF synthesis bank."""
         z = _lib.require_gpu_tensor(z, "z")
         if z.dim() != 3 or z.shape[1] != self.z_channels:
             raise ValueError(f"decode expects [B, {self.z_channels}, T], got {tuple(z.shape)}")
@@ -342,6 +380,13 @@ class AutoEncoder(nn.Module):
         h = self._ensure(B, T * self.ratio)
         x = torch.empty(B, 1, T * self.ratio, device=z.device, dtype=torch.float32)
         with torch.cuda.device(z.device):
+            if with_multi:
+                mb = torch.empty(B, self.pqmf_bands, T * self.ratio // self.pqmf_bands, device=z.device,
+                                 dtype=torch.float32)
+                _lib.check(_lib.lib().after_ae_decode_multi(h, _lib.ptr(z), _lib.ptr(x), _lib.ptr(mb), B, T,
+                                                            _lib.current_stream(z.device)),
+                           "after_ae_decode_multi")
+                return x, mb
             _lib.check(_lib.lib().after_ae_decode(h, _lib.ptr(z), _lib.ptr(x), B, T,
                                                   _lib.current_stream(z.device)), "after_ae_decode")
         return x

@@ -17,7 +17,7 @@ from typing import Optional
 
 import torch
 
-from .autoencoder.model import AutoEncoder
+from .autoencoder.model import AutoEncoder, ReluBottleneck
 from .diffusion.model import RectifiedFlow
 from .diffusion.networks.ecapa_encoder import ECAPATDNN
 from .diffusion.networks.encoder import Encoder1D
@@ -29,7 +29,7 @@ _IGNORED = {
     "DenoiserV2": set(),
     "ECAPATDNN": {"activation"},
     "Encoder1D": set(),
-    "AutoEncoder": {"bottleneck", "activation", "resnet_groups"},
+    "AutoEncoder": set(),
 }
 
 
@@ -110,15 +110,33 @@ def autoencoder_from_config(cfg: GinConfig, device="cuda:0") -> AutoEncoder:
     kw = cfg.kwargs("AutoEncoder")
     if not kw:
         raise GinError("config has no AutoEncoder bindings")
-    for k in _IGNORED["AutoEncoder"]:
-        kw.pop(k, None)
-    return AutoEncoder(padding_mode=_padding_mode(cfg, ""), **kw).to(device)
+    # the bottleneck has no parameters, so the checkpoint cannot reveal a mismatch: resolve the
+    # binding (baseAE.gin:41-43,58) and refuse what the MI355X path does not compute
+    b = kw.pop("bottleneck", None)
+    if isinstance(b, Ref):
+        name = b.selector.split(".")[-1]
+        if name == "ReluBottleneck":
+            b = ReluBottleneck(**cfg.kwargs(b.selector, b.scope))
+        elif name == "Identity":
+            raise NotImplementedError("bottleneck = nn.Identity is not callable as a bottleneck in the "
+                                      "reference either (encode unpacks `z, regloss`)")
+        else:
+            b = name  # TanhBottleneck / VAEBottleneck -> refused by AutoEncoder with the reason
+    a = kw.pop("activation", None)
+    if isinstance(a, Ref):
+        a = a.selector
+    return AutoEncoder(padding_mode=_padding_mode(cfg, ""), bottleneck=b, activation=a, **kw).to(device)
 
 
-def _load_state(path):
+def _load_state(path, trust_pickle: bool = False):
+    """`weights_only=True` unless the caller vouches for the file: a full unpickle executes
+    arbitrary code from the checkpoint (the reference's own `torch.load`, export.py:87, does)."""
     try:
         d = torch.load(path, map_location="cpu", weights_only=True)
-    except Exception:  # optimizer states etc. pickled with non-tensor objects
+    except Exception as e:
+        if not trust_pickle:
+            raise RuntimeError(f"{path} holds objects beyond tensors / plain containers ({e}); pass "
+                               "trust_pickle=True to unpickle it fully if you trust its origin") from e
         d = torch.load(path, map_location="cpu", weights_only=False)
     return d["model_state"] if "model_state" in d else d
 
@@ -132,24 +150,26 @@ def _check_load(res, allowed_missing=(), allowed_unexpected=()):
 
 
 def load_diffusion(folder: str, step: Optional[int] = None, device="cuda:0", ema: bool = True,
-                   in_size: Optional[int] = None, n_signal: Optional[int] = None) -> RectifiedFlow:
+                   in_size: Optional[int] = None, n_signal: Optional[int] = None,
+                   trust_pickle: bool = False) -> RectifiedFlow:
     """export.py:52-101.  Networks outside the sampling path that the checkpoint also holds
     (classifier, post_encoder, EMA shadow of the codec) are skipped, like `strict=False`
     skips them in the reference once those attributes are None."""
     cfg = GinConfig.parse_file(os.path.join(folder, "config.gin"))
     model = diffusion_from_config(cfg, device, in_size, n_signal)
-    sd = _load_state(find_checkpoint(folder, step, ema))
+    sd = _load_state(find_checkpoint(folder, step, ema), trust_pickle)
     res = model.load_state_dict(sd, strict=False)
     _check_load(res, allowed_unexpected=(r"^classifier\.", r"^post_encoder\.", r"^emb_model\.",
                                          r"^extra_modules\.", r"^time_transform\."))
     return model
 
 
-def load_autoencoder(folder: str, step: Optional[int] = None, device="cuda:0") -> AutoEncoder:
+def load_autoencoder(folder: str, step: Optional[int] = None, device="cuda:0",
+                     trust_pickle: bool = False) -> AutoEncoder:
     """export_autoencoder.py:19-45 (codec checkpoints carry no EMA suffix, trainer.py:352-361)."""
     cfg = GinConfig.parse_file(os.path.join(folder, "config.gin"))
     ae = autoencoder_from_config(cfg, device)
-    sd = _load_state(find_checkpoint(folder, step, ema=False))
+    sd = _load_state(find_checkpoint(folder, step, ema=False), trust_pickle)
     res = ae.load_state_dict(sd, strict=False)
     # bottleneck has no parameters; CachedGroupNorm `pad` buffers are re-created lazily
     _check_load(res, allowed_missing=(r"\.pad$", ), allowed_unexpected=(r"\.pad$", r"^bottleneck\."))

@@ -1064,7 +1064,29 @@ extern "C" int after_ae_encode(after_ae* h, const float* x, float* z, int B, int
     return AFTER_OK;
 }
 
-extern "C" int after_ae_decode(after_ae* h, const float* z, float* x, int B, int T, void* stream) {
+// x_multiband of Decoder1d.forward (SimpleNetsStream.py:643-646): y[:, :M] * sigmoid(y[:, M:])
+__global__ __launch_bounds__(256) void loudness_gate_kernel(const float* __restrict__ y,
+                                                            float* __restrict__ mb, int M, int Tm,
+                                                            int gated, int ychan) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (idx >= (size_t)M * Tm) return;
+    const float* yb = y + (size_t)b * ychan * Tm;
+    float v = yb[idx];
+    if (gated) v *= 1.0f / (1.0f + expf(-yb[(size_t)M * Tm + idx]));
+    mb[(size_t)b * M * Tm + idx] = v;
+}
+
+static int write_multiband(after_ae* h, hipStream_t s, const float* y, float* mb, int B, int Tm, int gated,
+                           int ychan) {
+    if (!mb) return AFTER_OK;
+    dim3 grid((unsigned)(((size_t)h->M * Tm + 255) / 256), B);
+    hipLaunchKernelGGL(loudness_gate_kernel, grid, dim3(256), 0, s, y, mb, h->M, Tm, gated, ychan);
+    AFTER_HIP_CHECK(hipGetLastError());
+    return AFTER_OK;
+}
+
+static int decode_impl(after_ae* h, const float* z, float* x, float* mb, int B, int T, void* stream) {
     AFTER_TRY(check_ae(h, B, (long long)T * (h ? h->ratio : 1)));
     AFTER_REQUIRE(z && x, AFTER_E_INVALID, "null tensor");
     hipStream_t s = (hipStream_t)stream;
@@ -1096,6 +1118,7 @@ extern "C" int after_ae_decode(after_ae* h, const float* z, float* x, int B, int
         AFTER_TRY(run_convblock2(h, s, h->synth0, cur, st, t1, nullptr, B, T, true, &st1, sb));
         AFTER_TRY(run_convblock2(h, s, h->synth1, t1, st1, t2, nullptr, B, T, false, nullptr));
         const int och = c.use_loudness ? 2 * h->M : h->M;
+        AFTER_TRY(write_multiband(h, s, t2, mb, B, T, c.use_loudness, och));
         return pqmf_inverse(h, s, t2, x, B, T, c.use_loudness, och,
                             h->streaming ? h->pq_istate : nullptr);
     }
@@ -1149,5 +1172,43 @@ extern "C" int after_ae_decode(after_ae* h, const float* z, float* x, int B, int
     AFTER_TRY(run_convblock(h, s, h->synth0, cur, t1, nullptr, B, T));
     AFTER_TRY(run_convblock(h, s, h->synth1, t1, t2, nullptr, B, T));
     const int out_ch = c.use_loudness ? 2 * h->M : h->M;
+    AFTER_TRY(write_multiband(h, s, t2, mb, B, T, c.use_loudness, out_ch));
     return pqmf_inverse(h, s, t2, x, B, T, c.use_loudness, out_ch);
+}
+
+extern "C" int after_ae_decode(after_ae* h, const float* z, float* x, int B, int T, void* stream) {
+    return decode_impl(h, z, x, nullptr, B, T, stream);
+}
+
+extern "C" int after_ae_decode_multi(after_ae* h, const float* z, float* x, float* multiband, int B, int T,
+                                     void* stream) {
+    AFTER_REQUIRE(multiband, AFTER_E_INVALID, "null multiband output");
+    return decode_impl(h, z, x, multiband, B, T, stream);
+}
+
+// SimpleLatentReg (core.py:189-198) as ReluBottleneck.forward returns it next to z
+// (SimpleNetsStream.py:742-760): mean(ELU(|z| - scale)) + 1.  One workgroup, fixed summation
+// order (bit-deterministic); fp64 accumulation of the per-thread fp32 partial sums.
+__global__ __launch_bounds__(1024) void latent_reg_kernel(const float* __restrict__ z, long long n,
+                                                          float scale, float* __restrict__ out) {
+    __shared__ double red[1024];
+    double acc = 0.0;
+    for (long long i = threadIdx.x; i < n; i += 1024) {
+        const float v = fabsf(z[i]) - scale;
+        acc += (double)(v > 0.f ? v : expm1f(v));
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)(red[0] / (double)n + 1.0);
+}
+
+extern "C" int after_latent_reg(const float* z, long long n, float scale, float* out, void* stream) {
+    AFTER_REQUIRE(z && out && n > 0, AFTER_E_INVALID, "latent_reg: bad argument");
+    hipLaunchKernelGGL(latent_reg_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, z, n, scale, out);
+    AFTER_HIP_CHECK(hipGetLastError());
+    return AFTER_OK;
 }

@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256) void roll_cache_kernel(const float* __restrict
                                                          float* __restrict__ knew,
                                                          float* __restrict__ vnew,
                                                          const float* __restrict__ qkv, int rows,
-                                                         int T, int E, int cache, int size,
+                                                         int cache_rows, int T, int E, int cache, int size,
                                                          size_t cache_lstride, size_t qkv_lstride) {
     // blockIdx.y = layer: all layers of one diffusion step roll in ONE launch
     kold += blockIdx.y * cache_lstride;
@@ -598,13 +598,18 @@ __global__ __launch_bounds__(256) void roll_cache_kernel(const float* __restrict
     vnew += blockIdx.y * cache_lstride;
     qkv += blockIdx.y * qkv_lstride;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t total = (size_t)rows * cache * E;
+    const size_t total = (size_t)cache_rows * cache * E;
     if (idx >= total) return;
     const int c = idx % E;
     const int p = (idx / E) % cache;
     const int r = idx / ((size_t)E * cache);
     float kv, vv;
-    if (p + size < cache) {
+    if (r >= rows) {
+        // rows this call did not run keep their history (set_buffers writes `k_cache[:k.shape[0]]`
+        // only, transformerv2.py:157-169): carry them into the other flip-flop half unchanged
+        kv = kold[idx];
+        vv = vold[idx];
+    } else if (p + size < cache) {
         kv = kold[((size_t)r * cache + p + size) * E + c];
         vv = vold[((size_t)r * cache + p + size) * E + c];
     } else {
@@ -1207,13 +1212,14 @@ int roll_cache_step(after_denoiser* h, hipStream_t s, int rows, int T, int size,
     const int E = h->E;
     const size_t per = (size_t)h->cache_rows * h->cache * E;
     const int cur = h->flip[cache_index];
-    const size_t total = (size_t)rows * h->cache * E;
+    const size_t total = (size_t)h->cache_rows * h->cache * E;
     const size_t base = (size_t)cache_index * 2 * per;           // layer 0
     const size_t lstride = (size_t)h->cache_steps * 2 * per;      // cache slot of the next layer
     hipLaunchKernelGGL(roll_cache_kernel, dim3((unsigned)cdivll(total, 256), h->L), dim3(256), 0, s,
                        h->kcache + base + cur * per, h->vcache + base + cur * per,
                        h->kcache + base + (cur ^ 1) * per, h->vcache + base + (cur ^ 1) * per, h->qkv_layers,
-                       rows, T, E, h->cache, size, lstride, (size_t)h->max_rows * h->max_T * 3 * E);
+                       rows, h->cache_rows, T, E, h->cache, size, lstride,
+                       (size_t)h->max_rows * h->max_T * 3 * E);
     AFTER_HIP_CHECK(hipGetLastError());
     h->flip[cache_index] = cur ^ 1;
     return AFTER_OK;

@@ -7,8 +7,8 @@ from . import _lib
 
 def gemm(a, w, bias=None, residual=None, epilogue=0, tile=(0, 0), out=None):
     """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias) through after_gemm_f32."""
-    a = _lib.require_gpu_tensor(a, "a")
-    w = _lib.require_gpu_tensor(w, "w")
+    a = _lib.require_gpu_tensor(a, "a", allow_row_stride=True)
+    w = _lib.require_gpu_tensor(w, "w", allow_row_stride=True)
     M, K = a.shape
     N = w.shape[0]
     if out is None:

@@ -124,6 +124,8 @@ class DenoiserV2(nn.Module):
         self._handle = None
         self._cap = (0, 0, 0)
         self._profile = False
+        self._streaming = False
+        self._stream_args = None  # (cache, steps, rows, frames) of the last enable_streaming_cache
 
     @property
     def name(self):
@@ -206,6 +208,12 @@ class DenoiserV2(nn.Module):
         self._cap = cap
         if self._profile:
             _lib.check(L.after_denoiser_profile(out, 1), "after_denoiser_profile")
+        if self._stream_args is not None and not getattr(self, "_enabling", False):
+            # the handle was rebuilt (.to(), load_state_dict, refresh): a Streamer still expects
+            # its K/V caches -- re-create them (zeroed = a new stream), as AutoEncoder / Encoder1D do
+            cache, steps_, rows_, _ = self._stream_args
+            _lib.check(L.after_denoiser_enable_cache(out, cache, steps_, rows_), "after_denoiser_enable_cache")
+            self._streaming = True
         return out
 
     def reserve(self, rows: int, T: int, steps: int = 1):
@@ -221,13 +229,21 @@ class DenoiserV2(nn.Module):
         LOCAL_ATTENTION_SIZE` (after_scripts/export.py:77-79) and sizes them with
         `max_diffusion_steps` / `max_batch_size` (network rows: 3 x clips under CFG)."""
         cache = self.local_attention_size if max_cache_size is None else max_cache_size
-        self._ensure(max_batch_size, max_frames, int(max_diffusion_steps))
+        # re-enabling with larger limits (a second Streamer on the same net) must be able to grow
+        # the handle: the capacity lock of _ensure only guards forwards of an enabled stream
+        self._streaming = False
+        self._enabling = True
+        try:
+            self._ensure(max_batch_size, max_frames, int(max_diffusion_steps))
+        finally:
+            self._enabling = False
         self._cap = (max(self._cap[0], max_batch_size), max(self._cap[1], max_frames), self._cap[2])
         _lib.check(_lib.lib().after_denoiser_enable_cache(self._handle, int(cache),
                                                           int(max_diffusion_steps),
                                                           int(max_batch_size)),
                    "after_denoiser_enable_cache")
         self._streaming = True
+        self._stream_args = (int(cache), int(max_diffusion_steps), int(max_batch_size), int(max_frames))
 
     def reset_cache(self):
         _lib.check(_lib.lib().after_denoiser_reset_cache(self._handle, _lib.current_stream(None)),

@@ -118,6 +118,10 @@ class UNET1D(nn.Module):
         self._release()
         return super().load_state_dict(*a, **k)
 
+    def refresh(self):
+        """Call after mutating parameters in place: the HIP handle owns a re-laid-out copy."""
+        self._release()
+
     def _release(self):
         h = getattr(self, "_handle", None)
         if h is not None:

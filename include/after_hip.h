@@ -194,6 +194,14 @@ int after_ae_ratio(const after_ae* h);
 int after_ae_encode(after_ae* h, const float* x, float* z, int B, int L, void* stream);
 /* x[B, 1, T*ratio] = decode(z[B, Z, T]).  Replaces: AutoEncoder.decode (:943-954). */
 int after_ae_decode(after_ae* h, const float* z, float* x, int B, int T, void* stream);
+/* decode(z, with_multi=True) (:943-954): additionally writes x_multiband[B, M, T*ratio/M], the
+ * decoder output after the loudness gate and before the PQMF synthesis bank (:643-646). */
+int after_ae_decode_multi(after_ae* h, const float* z, float* x, float* multiband, int B, int T,
+                          void* stream);
+/* out[0] = mean(ELU(|z| - scale)) + 1 over the n elements of z: the regulariser
+ * ReluBottleneck.forward returns beside z (SimpleNetsStream.py:742-760 -> SimpleLatentReg,
+ * after/autoencoder/core.py:189-198).  Deterministic (one workgroup, fixed order). */
+int after_latent_reg(const float* z, long long n, float scale, float* out, void* stream);
 /* multiband[B, M, L/M] = pqmf(x) / x = pqmf.inverse(multiband) (pqmf.py:286-301) */
 int after_ae_pqmf_forward(after_ae* h, const float* x, float* mb, int B, int L, void* stream);
 int after_ae_pqmf_inverse(after_ae* h, const float* mb, float* x, int B, int Tm, void* stream);

@@ -220,6 +220,189 @@ def unet_case(case, cfg_name, B, T, seed):
     save(case, meta, x=x, time_cond=tc, cond=cond, time=time, y=net(x, time=time, time_cond=tc, cond=cond))
 
 
+
+# ---------------------------------------------------------------- run folders
+# config.gin texts in the two styles AFTER leaves next to its checkpoints: the flat
+# `gin.operative_config_str()` dump (model.py:262-265) for the diffusion model and the hand-written
+# block style of baseAE.gin for the codec.  gin-config is absent from the image, so these are
+# written here (dims of a reduced "nano" model so that the REAL checkpoint files fit in the repo).
+NANO_RUN_GIN = """# Macros:
+# ==============================================================================
+IN_SIZE = 16
+LOCAL_ATTENTION_SIZE = 8
+N_SIGNAL = 128
+SR = 44100
+ZS_CHANNELS = 12
+ZT_CHANNELS = 6
+
+# Parameters for Base:
+# ==============================================================================
+Base.classifier = @classifier/Encoder1D()
+Base.drop_rate = 0.2
+Base.drop_value = -4.0
+Base.encoder = @encoder/ECAPATDNN()
+Base.encoder_time = @encoder_time/Encoder1D()
+Base.net = @DenoiserV2()
+Base.sr = %SR
+Base.time_transform = None
+
+# Parameters for DenoiserV2:
+# ==============================================================================
+DenoiserV2.attention_chunk_size = 4
+DenoiserV2.causal = True
+DenoiserV2.cond_dim = %ZT_CHANNELS
+DenoiserV2.dropout = 0.1
+DenoiserV2.embed_dim = 128
+DenoiserV2.local_attention_size = %LOCAL_ATTENTION_SIZE
+DenoiserV2.mlp_multiplier = 3
+DenoiserV2.n_channels = %IN_SIZE
+DenoiserV2.n_layers = 1
+DenoiserV2.noise_embed_dims = 64
+DenoiserV2.pos_emb_type = 'rotary'
+DenoiserV2.seq_len = %N_SIGNAL
+DenoiserV2.tcond_dim = %ZS_CHANNELS
+
+# Parameters for encoder/ECAPATDNN:
+# ==============================================================================
+encoder/ECAPATDNN.attention_channels = 16
+encoder/ECAPATDNN.channels = [32, 32, 32, 64]
+encoder/ECAPATDNN.dilations = [1, 1, 1, 1]
+encoder/ECAPATDNN.global_context = True
+encoder/ECAPATDNN.groups = [1, 1, 1, 1]
+encoder/ECAPATDNN.in_size = %IN_SIZE
+encoder/ECAPATDNN.kernel_sizes = [3, 3, 3, 3]
+encoder/ECAPATDNN.out_dim = %ZT_CHANNELS
+encoder/ECAPATDNN.pooling = True
+encoder/ECAPATDNN.regularisation = 'ac'
+encoder/ECAPATDNN.res2net_scale = 8
+encoder/ECAPATDNN.se_channels = 16
+encoder/ECAPATDNN.spherical_normalisation = False
+encoder/ECAPATDNN.use_tanh = False
+
+# Parameters for encoder_time/Encoder1D:
+# ==============================================================================
+encoder_time/Encoder1D.ac_regularisation = True
+encoder_time/Encoder1D.average_out = False
+encoder_time/Encoder1D.channels = [16, 16, 32, 32, %ZS_CHANNELS]
+encoder_time/Encoder1D.in_size = %IN_SIZE
+encoder_time/Encoder1D.kernel_size = 5
+encoder_time/Encoder1D.ratios = [1, 1, 1, 1]
+encoder_time/Encoder1D.spherical_normalization = False
+encoder_time/Encoder1D.upscale_out = False
+encoder_time/Encoder1D.use_tanh = False
+encoder_time/Encoder1D.vae_regularisation = False
+
+# Parameters for encoder_time/get_padding:
+# ==============================================================================
+encoder_time/get_padding.mode = 'causal'
+
+# Parameters for classifier/Encoder1D:
+# ==============================================================================
+classifier/Encoder1D.ac_regularisation = False
+classifier/Encoder1D.average_out = True
+classifier/Encoder1D.channels = [16, 16, 16, 16, %ZT_CHANNELS]
+classifier/Encoder1D.in_size = %ZS_CHANNELS
+classifier/Encoder1D.kernel_size = 5
+classifier/Encoder1D.ratios = [1, 2, 2, 1]
+
+# Parameters for Base.fit:
+# ==============================================================================
+Base.fit.lr = 0.0001
+Base.fit.use_ema = True
+"""
+
+NANO_CODEC_GIN = """from __gin__ import dynamic_registration
+from after.autoencoder.networks import SimpleNetsStream
+import cached_conv
+
+SR = 44100
+LATENT_SIZE = 16
+PQMF_BANDS = 16
+BASE_CHANNELS = 8
+KERNEL_SIZE = 3
+DECODER_RATIO = 1.5
+
+SimpleNetsStream.ReluBottleneck:
+    sigma = 0.01
+    scale = 3
+
+SimpleNetsStream.AutoEncoder:
+    in_channels = %PQMF_BANDS
+    channels = %BASE_CHANNELS
+    pqmf_bands = %PQMF_BANDS
+    z_channels = %LATENT_SIZE
+    multipliers = [1, 2, 4, 4, 8, 8]
+    factors = [2, 2, 2, 4, 4]
+    dilations = [1, 3, 9]
+    kernel_size = %KERNEL_SIZE
+    bottleneck = @SimpleNetsStream.ReluBottleneck()
+    use_norm = True
+    decoder_ratio = %DECODER_RATIO
+    use_loudness = True
+    use_noise = False
+"""
+
+
+def checkpoint_case(case="ckpt_nano", seed=71):
+    """A run folder as the REFERENCE leaves it: `checkpoint<step>_EMA.pt` written by the
+    reference's own `Base.save_model` (model.py:144-176: EMA context, `emb_model.*` stripped,
+    `opt_state` beside `model_state`) from reference modules, the codec checkpoint in the layout of
+    `Trainer.fit` (trainer.py:350-361), `config.gin` next to each -- plus the reference's outputs
+    on seeded inputs.  The .pt files are committed as they were written (a few hundred KiB)."""
+    from after_amd.ginfile import GinConfig
+    root = os.path.join(HERE, case)
+    run, codec = os.path.join(root, "run"), os.path.join(root, "codec")
+    os.makedirs(run, exist_ok=True)
+    os.makedirs(codec, exist_ok=True)
+    open(os.path.join(run, "config.gin"), "w").write(NANO_RUN_GIN)
+    open(os.path.join(codec, "config.gin"), "w").write(NANO_CODEC_GIN)
+    g = GinConfig.parse_string(NANO_RUN_GIN)
+    net = build_denoiser(g.kwargs("DenoiserV2"))
+    refill(net, seed)
+    ec = build_ecapa(g.kwargs("ECAPATDNN", "encoder"))
+    refill(ec, seed + 1)
+    et = build_encoder_time(dict(g.kwargs("Encoder1D", "encoder_time"), padding_mode="causal"))
+    refill(et, seed + 2)
+    cl = R.encoder.Encoder1D(**g.kwargs("Encoder1D", "classifier"))  # outside the sampling path
+    refill(cl, seed + 3)
+    ga = GinConfig.parse_string(NANO_CODEC_GIN)
+    akw = {k: v for k, v in ga.kwargs("AutoEncoder").items() if k != "bottleneck"}
+    ae = R.ae.AutoEncoder(bottleneck=R.ae.ReluBottleneck(**ga.kwargs("ReluBottleneck")), **akw)
+    refill(ae, seed + 4)
+    model = R.model.RectifiedFlow(net=net, sr=44100, encoder=ec, encoder_time=et, classifier=cl,
+                                  emb_model=ae, drop_value=-4.0, drop_rate=0.2)
+    model.eval()
+    # the state save_model expects after fit() has run (model.py:215-231, 401-405)
+    model.use_ema = True
+    model.ema = R.model.ExponentialMovingAverage(list(model.net.parameters()), decay=0.999)
+    model.opt = torch.optim.AdamW(model.net.parameters(), lr=1e-4)
+    model.step = 1000
+    model.save_model(run)
+    opt = torch.optim.AdamW(ae.parameters(), lr=1e-4)
+    torch.save({"model_state": ae.state_dict(), "opt_state": opt.state_dict(), "dis_state": {},
+                "opt_dis_state": {}}, os.path.join(codec, "checkpoint500.pt"))
+    # reference outputs
+    B, C, T, nsig = 2, 16, 32, 16
+    zs = detweights.seeded_tensor("zs", (B, C, T), seed)
+    zt = detweights.seeded_tensor("zt", (B, C, T), seed)
+    x0 = detweights.seeded_tensor("x0", (B, C, T), seed)
+    audio = detweights.seeded_tensor("audio", (B, 1, 8192), seed, 0.1)
+    cond = model.encoder(zt[..., :nsig])
+    tc = model.encoder_time(zs)
+    z = model.sample(x0, cond, tc, 5, 2.0, 1.5)
+    y = ae.decode(z)
+    ze, reg = ae.encode(audio)
+    saved = torch.load(os.path.join(run, "checkpoint1000_EMA.pt"), map_location="cpu")
+    meta = dict(kind="checkpoint", seed=seed, nb_steps=5, guidance=[2.0, 1.5], n_signal_timbre=nsig,
+                run_keys=sorted(saved["model_state"].keys()),
+                codec_keys=sorted(ae.state_dict().keys()))
+    save(case, meta, zs=zs, zt=zt, x0=x0, audio=audio, cond=cond, time_cond=tc, z=z, y=y, z_enc=ze,
+         reg=reg)
+    for d in (run, codec):
+        for f in sorted(os.listdir(d)):
+            print(f"  {d}/{f}: {os.path.getsize(os.path.join(d, f)) / 1024:.1f} KiB")
+
+
 CASES = {
     "pqmf_bank": pqmf_case,
     "mask_rope": mask_case,
@@ -238,6 +421,7 @@ CASES = {
     "encoders_base": lambda: encoders_case("encoders_base", "base", 1, 256, 53),
     "unet_micro": lambda: unet_case("unet_micro", "unet_micro", 2, 64, 61),
     "unet_micro_flat": lambda: unet_case("unet_micro_flat", "unet_micro_flat", 3, 24, 62),
+    "ckpt_nano": checkpoint_case,
 }
 
 if __name__ == "__main__":

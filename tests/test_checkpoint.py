@@ -195,24 +195,79 @@ def test_load_diffusion_and_autoencoder_from_run_folders(tmp_path):
     assert all(torch.equal(got[k], v) for k, v in ae_sd.items())
 
 
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _reference_run():
+    """tests/golden/ckpt_nano: a run folder + codec folder written by the REFERENCE's own code
+    (make_golden.py:checkpoint_case -- `Base.save_model`, model.py:144-176, on reference modules;
+    the codec in `Trainer.fit`'s layout, trainer.py:350-361) and the reference's outputs."""
+    from fixtures import Fixture
+    root = os.path.join(GOLDEN, "ckpt_nano")
+    return Fixture("ckpt_nano"), os.path.join(root, "run"), os.path.join(root, "codec")
+
+
+def test_reference_written_checkpoint_loads_and_pins_the_oracle():
+    """The files the reference saved go through config.gin + checkpoint ingestion: every key of the
+    sampling path is consumed (weight_g/weight_v pairs, the duplicated BatchNorm names of Encoder1D,
+    the three rotary aliases), `classifier.*` is skipped, `emb_model.*` was never saved; and the
+    oracle, fed the LOADED state dict, reproduces the reference's vectors."""
+    import oracle
+    from fixtures import max_abs
+    fx, run, codec = _reference_run()
+    saved = torch.load(checkpoint.find_checkpoint(run), map_location="cpu", weights_only=True)
+    assert set(saved) == {"model_state", "opt_state"}
+    assert sorted(saved["model_state"]) == fx.meta["run_keys"]
+    assert not any("emb_model" in k for k in saved["model_state"])  # model.py:149-153
+    assert any(k.startswith("classifier.") for k in saved["model_state"])
+    model = checkpoint.load_diffusion(run, device="cpu")
+    ae = checkpoint.load_autoencoder(codec, device="cpu")
+    got = model.state_dict()
+    for k, v in saved["model_state"].items():
+        if not k.startswith("classifier."):
+            assert k in got and torch.equal(got[k], v), k
+    sd_codec = torch.load(checkpoint.find_checkpoint(codec, ema=False), map_location="cpu",
+                          weights_only=True)["model_state"]
+    assert sorted(sd_codec) == fx.meta["codec_keys"]
+    gota = ae.state_dict()
+    assert all(torch.equal(gota[k], v) for k, v in sd_codec.items())
+    # oracle on the loaded weights vs the reference's outputs
+    pick = lambda pre: {k[len(pre):]: v for k, v in got.items() if k.startswith(pre)}
+    cfg = GinConfig.parse_file(os.path.join(run, "config.gin"))
+    ncfg = cfg.kwargs("DenoiserV2")
+    ecfg = cfg.kwargs("ECAPATDNN", "encoder")
+    tcfg = dict(cfg.kwargs("Encoder1D", "encoder_time"), padding_mode="causal")
+    nsig, (gt, gs) = fx.meta["n_signal_timbre"], fx.meta["guidance"]
+    cond = oracle.ecapa_forward(pick("encoder."), fx.t("zt")[..., :nsig], ecfg)
+    tc = oracle.encoder1d_forward(pick("encoder_time."), fx.t("zs"), tcfg)
+    assert max_abs(cond, fx.t("cond")) < 2e-5 and max_abs(tc, fx.t("time_cond")) < 2e-5
+    z = oracle.sample(pick("net."), ncfg, fx.t("x0"), cond, tc, fx.meta["nb_steps"], gt, gs)
+    assert max_abs(z, fx.t("z")) < 2e-5
+    y = oracle.ae_decode(gota, z, ae.cfg)
+    assert max_abs(y, fx.t("y")) < 2e-5 * fx.t("y").abs().max().item()
+    assert max_abs(oracle.ae_encode(gota, fx.t("audio"), ae.cfg), fx.t("z_enc")) < \
+        2e-5 * fx.t("z_enc").abs().max().item()
+
+
 @pytest.mark.gpu
-def test_loaded_checkpoint_samples_like_its_source(tmp_path, hip_device):
-    """A run folder loaded through config.gin + checkpoint gives bit-identical latents and audio
-    to the model it was saved from (same weights, same kernels)."""
-    src, dcfg, acfg = pipeline.build_models("micro", "microAE_causal", hip_device, seed=6)
-    run, codec = tmp_path / "run", tmp_path / "codec"
-    run.mkdir()
-    codec.mkdir()
-    (run / "config.gin").write_text(OPERATIVE)
-    (codec / "config.gin").write_text(BLOCK_AE)
-    torch.save({"model_state": {k: v.cpu() for k, v in src.state_dict().items() if "emb_model" not in k}},
-               run / "checkpoint10_EMA.pt")
-    torch.save({"model_state": {k: v.cpu() for k, v in src.emb_model.state_dict().items()}},
-               codec / "checkpoint10.pt")
-    model = checkpoint.load_diffusion(str(run), device=hip_device)
-    model.emb_model = checkpoint.load_autoencoder(str(codec), device=hip_device)
-    g = torch.Generator().manual_seed(1)
-    zs, zt, x0 = (torch.randn(2, 16, 32, generator=g).to(hip_device) for _ in range(3))
-    a, za = pipeline.generate_from_latents(src, zs, zt, x0, nb_steps=3, n_signal_timbre=16)
-    b, zb = pipeline.generate_from_latents(model, zs, zt, x0, nb_steps=3, n_signal_timbre=16)
-    assert torch.equal(za, zb) and torch.equal(a, b)
+def test_reference_written_checkpoint_reproduces_reference_outputs(hip_device):
+    """f2 end to end on the MI355X path: the reference's checkpoint files + config.gin ->
+    load_diffusion / load_autoencoder -> encoders, 5-step CFG sampler, decode, encode ==
+    the vectors the reference computed from the same weights."""
+    from fixtures import max_abs
+    fx, run, codec = _reference_run()
+    model = checkpoint.load_diffusion(run, device=hip_device)
+    model.emb_model = checkpoint.load_autoencoder(codec, device=hip_device)
+    d = lambda n: fx.t(n).to(hip_device)
+    nsig, (gt, gs) = fx.meta["n_signal_timbre"], fx.meta["guidance"]
+    cond = model.encoder(d("zt")[..., :nsig].contiguous())
+    tc = model.encoder_time(d("zs"))
+    assert max_abs(cond.cpu(), fx.t("cond")) < 1e-4 and max_abs(tc.cpu(), fx.t("time_cond")) < 1e-4
+    z = model.sample(d("x0"), cond, tc, fx.meta["nb_steps"], gt, gs)
+    assert max_abs(z.cpu(), fx.t("z")) < 2e-4, max_abs(z.cpu(), fx.t("z"))
+    y = model.emb_model.decode(d("z")).cpu()
+    assert max_abs(y, fx.t("y")) < 1e-4 * fx.t("y").abs().max().item()
+    ze, reg = model.emb_model.encode(d("audio"))
+    assert max_abs(ze.cpu(), fx.t("z_enc")) < 1e-4 * fx.t("z_enc").abs().max().item()
+    # SimpleLatentReg of the ReluBottleneck (SimpleNetsStream.py:742-760, core.py:189-198)
+    assert abs(float(reg) - float(fx.t("reg"))) < 1e-4 * max(1.0, abs(float(fx.t("reg"))))

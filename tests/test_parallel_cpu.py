@@ -36,15 +36,33 @@ def _free_port():
 def _worker(rank, world, port, n_clips, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    except Exception as e:  # e.g. the probed port was taken in between: report, do not hang the parent
+        q.put((rank, repr(e), None))
+        raise
     try:
         torch.manual_seed(rank)  # ranks start with DIFFERENT weights
-        lin = torch.nn.Linear(5, 3)
-        parallel.broadcast_module(lin, src=0)
+
+        class Leaf(torch.nn.Linear):  # a handle-owning module: must be refreshed after the broadcast
+            refreshed = 0
+
+            def refresh(self):
+                self.refreshed += 1
+
+        # small tensors (bucketed) + one >= 1 MiB weight (in-place path) + a nested handle owner
+        net = torch.nn.Sequential(Leaf(5, 3), torch.nn.Sequential(Leaf(600, 500)))
+        net[1][0].alias = net[0].bias  # an aliased parameter is sent once
+        parallel.broadcast_module(net, src=0)
+        assert net[0].refreshed == 1 and net[1][0].refreshed == 1
+        assert parallel.ranks_seen() == world
         full = torch.arange(n_clips * 6, dtype=torch.float32).reshape(n_clips, 2, 3)
         local = parallel.shard(full, rank, world) * 1.0
         got = parallel.gather_clips(local, n_clips)
-        q.put((rank, lin.weight.detach().clone(), got))
+        buf = torch.empty(n_clips, 2, 3)
+        again = parallel.gather_clips(local, n_clips, out=buf)  # preallocated result, reused per step
+        assert again is buf and torch.equal(buf, got)
+        q.put((rank, torch.cat([net[0].weight.detach().reshape(-1), net[1][0].weight.detach().reshape(-1)]), got))
     finally:
         dist.destroy_process_group()
 
@@ -61,7 +79,7 @@ def test_broadcast_and_ragged_gather_world2(n_clips):
     res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
     for p in procs:
         p.join(60)
-        assert p.exitcode == 0
+        assert p.exitcode == 0, [r[1] for r in res if r[2] is None]
     full = torch.arange(n_clips * 6, dtype=torch.float32).reshape(n_clips, 2, 3)
     assert torch.equal(res[0][1], res[1][1])  # broadcast made the weights identical
     for _, _, got in res:
