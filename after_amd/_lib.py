@@ -102,6 +102,11 @@ SIGNATURES = {
     "after_unet1d_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                      c_int, c_void_p]),
     "after_gemm_set_debug": (None, [c_void_p]),
+    "after_convtm_create": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                    c_int, c_int, POINTER(c_void_p)]),
+    "after_convtm_run": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "after_convtm_destroy": (None, [c_void_p]),
+    "after_convtm_set_tile": (None, [c_int]),
     "after_gemm_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
 }

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void pqmf_forward_kernel(const float* __restri
                                                            const float* __restrict__ wp,
                                                            float* __restrict__ mb, int L, int Q,
                                                            int pl,
-                                                           const float* __restrict__ state) {
+                                                           const float* __restrict__ state, int cs, int ts) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int ldp = PQ_BT + Q + 1;
     float* ws = sm;                // [M][Q][M] taps, read as wave-uniform (broadcast) float4s
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void pqmf_forward_kernel(const float* __restri
 #pragma unroll
         for (int c = 0; c < M; ++c) {
             const bool neg = (c & 1) && !(n & 1);  // reverse_half: odd bands, even frames
-            mb[((size_t)b * M + c) * Tm + n] = neg ? -acc[c] : acc[c];
+            mb[(size_t)b * M * Tm + (size_t)c * cs + (size_t)n * ts] = neg ? -acc[c] : acc[c];
         }
     }
 }
@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void pqmf_forward_generic_kernel(const float* 
                                                                    const float* __restrict__ w,
                                                                    float* __restrict__ mb, int L, int M,
                                                                    int K, int pl,
-                                                                   const float* __restrict__ state) {
+                                                                   const float* __restrict__ state, int cs,
+                                                                   int ts) {
     const int Tm = L / M;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void pqmf_forward_generic_kernel(const float* 
         if (s >= 0 && s < L) acc += w[(size_t)c * K + k] * xb[s];
         else if (s < 0 && state) acc += w[(size_t)c * K + k] * state[(size_t)b * pl + (pl + s)];
     }
-    mb[((size_t)b * M + c) * Tm + n] = ((c & 1) && !(n & 1)) ? -acc : acc;
+    mb[(size_t)b * M * Tm + (size_t)c * cs + (size_t)n * ts] = ((c & 1) && !(n & 1)) ? -acc : acc;
 }
 
 // ------------------------------------------------------------------ PQMF synthesis
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void pqmf_inverse_kernel(const float* __restri
                                                            const float* __restrict__ wi,
                                                            float* __restrict__ audio, int Tm,
                                                            int K, int pl, int gated, int ychan,
-                                                           const float* __restrict__ zstate) {
+                                                           const float* __restrict__ zstate, int cs, int ts) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int ldz = 256 + K;
     float* ws = sm;              // [M][K][M] taps (broadcast float4 reads)
@@ -125,8 +126,8 @@ __global__ __launch_bounds__(256) void pqmf_inverse_kernel(const float* __restri
         const int t = t0 + col - pl;
         float v = 0.f;
         if (t >= 0 && t < Tm) {
-            v = yb[(size_t)c * Tm + t];
-            if (gated) v *= 1.0f / (1.0f + expf(-yb[(size_t)(M + c) * Tm + t]));
+            v = yb[(size_t)c * cs + (size_t)t * ts];
+            if (gated) v *= 1.0f / (1.0f + expf(-yb[(size_t)(M + c) * cs + (size_t)t * ts]));
             if ((c & 1) && !(t & 1)) v = -v;
         } else if (t < 0 && zstate) {  // streaming: gated, sign-flipped frames of the last chunk
             v = zstate[((size_t)b * M + c) * pl + (pl + t)];
@@ -185,7 +186,8 @@ __global__ __launch_bounds__(256) void pqmf_inverse_generic_kernel(const float* 
                                                                    float* __restrict__ audio,
                                                                    int Tm, int M, int K, int pl,
                                                                    int gated, int ychan,
-                                                                   const float* __restrict__ zstate) {
+                                                                   const float* __restrict__ zstate, int cs,
+                                                                   int ts) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
     if (idx >= (size_t)Tm * M) return;
@@ -200,8 +202,8 @@ __global__ __launch_bounds__(256) void pqmf_inverse_generic_kernel(const float* 
             if (tt < 0) {
                 v = zstate[((size_t)b * M + c) * pl + (pl + tt)];
             } else {
-                v = yb[(size_t)c * Tm + tt];
-                if (gated) v *= 1.0f / (1.0f + expf(-yb[(size_t)(M + c) * Tm + tt]));
+                v = yb[(size_t)c * cs + (size_t)tt * ts];
+                if (gated) v *= 1.0f / (1.0f + expf(-yb[(size_t)(M + c) * cs + (size_t)tt * ts]));
                 if ((c & 1) && !(tt & 1)) v = -v;
             }
             acc += w[((size_t)(M - 1 - m) * M + c) * K + k] * v;
@@ -211,14 +213,14 @@ __global__ __launch_bounds__(256) void pqmf_inverse_generic_kernel(const float* 
 
 // streaming synthesis state: the last S = K - 1 gated, sign-flipped band frames of the chunk
 __global__ void pqmf_istate_kernel(const float* __restrict__ y, float* __restrict__ zstate, int Tm,
-                                   int M, int S, int gated, int ychan, int total) {
+                                   int M, int S, int gated, int ychan, int total, int cs, int ts) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int j = idx % S, c = (idx / S) % M, b = idx / (S * M);
     const int t = Tm - S + j;
     const float* yb = y + (size_t)b * ychan * Tm;
-    float v = yb[(size_t)c * Tm + t];
-    if (gated) v *= 1.0f / (1.0f + expf(-yb[(size_t)(M + c) * Tm + t]));
+    float v = yb[(size_t)c * cs + (size_t)t * ts];
+    if (gated) v *= 1.0f / (1.0f + expf(-yb[(size_t)(M + c) * cs + (size_t)t * ts]));
     if ((c & 1) && !(t & 1)) v = -v;
     zstate[idx] = v;
 }
@@ -233,7 +235,8 @@ namespace {
 // plan + repacked weights of one conv for the DMA kernel (conv_dma.hip)
 struct DmaConv {
     ConvDmaPlanIn in;
-    ConvDmaPlan plan;
+    ConvDmaPlan plan;    // conv_dma.hip ([B][C][T] layout)
+    ConvTmPlan tplan;    // conv_tm.hip ([B][T][C] layout, the default)
     float* w = nullptr;
 };
 struct ConvBlockW {
@@ -290,9 +293,11 @@ struct after_ae {
     int cmax = 0;
     // DMA conv path
     bool use_dma = true;
+    bool tm = true;               // time-major activations + conv_tm.hip (AFTER_CONV_TM=0: conv_dma.hip)
     float* xp = nullptr;          // activated + haloed scratch tensor
     size_t xp_elems = 0;
-    double* stats_ring = nullptr; // [kStatSlots][max_batch][8][2]
+    double* stats_ring = nullptr; // [kStatSlots][stat_sub][max_batch][8][2]
+    int stat_sub = 1;             // accumulator pairs per (clip, group): conv_tm_stat_sub() on the time-major path
     int stat_slot = 0;
     Arena wd;                     // repacked weights
     // streaming (cached-conv semantics): left-context state per conv, in traversal order
@@ -460,6 +465,13 @@ int make_dma(after_ae* h, DmaConv& d, const float* packed, int cin, int cout, in
     }
     d.in.Nn_hint = Nn_hint;
     d.in.B_hint = h->max_batch;  // the handle is (re)built for the batch it serves
+    if (h->tm) {
+        conv_tm_plan(d.in, &d.tplan);
+        AFTER_REQUIRE(d.tplan.ok, AFTER_E_INVALID, "autoencoder: tap pattern outside the time-major conv path");
+        d.w = h->wd.take<float>(d.tplan.w_floats);
+        AFTER_REQUIRE(d.w, AFTER_E_NOMEM, "autoencoder: conv weight arena exhausted");
+        return conv_tm_repack(packed, d.w, d.in, d.tplan, 0);
+    }
     conv_dma_plan(d.in, &d.plan);
     d.w = h->wd.take<float>(d.plan.w_floats);
     AFTER_REQUIRE(d.w, AFTER_E_NOMEM, "autoencoder: DMA weight arena exhausted");
@@ -467,7 +479,7 @@ int make_dma(after_ae* h, DmaConv& d, const float* packed, int cin, int cout, in
 }
 
 double* next_stats(after_ae* h, int B) {
-    double* p = h->stats_ring + (size_t)(h->stat_slot % kStatSlots) * h->max_batch * 16;
+    double* p = h->stats_ring + (size_t)(h->stat_slot % kStatSlots) * h->stat_sub * h->max_batch * 16;
     ++h->stat_slot;
     (void)B;
     return p;
@@ -478,12 +490,53 @@ double* next_stats(after_ae* h, int B) {
 int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const double* stats_in,
             const float* gamma, const float* beta, const float* alpha, const float* invb, int act,
             const float* bias, const float* res, float* y, int B, int Tin, int Tout, int Nn,
-            bool want_stats, double** stats_out, float* state_base = nullptr) {
+            bool want_stats, double** stats_out, float* state_base = nullptr, int x_cm = 0, int y_cm = 0) {
     const int cin = d.in.Cin, cout = d.in.Cout;
-    AFTER_REQUIRE((size_t)B * cin * conv_dma_row(Tin) <= h->xp_elems, AFTER_E_CAPACITY,
-                  "autoencoder: activation scratch too small");
     float* state = nullptr;
     if (h->streaming && state_base) state = state_base + (size_t)(h->state_slot++) * h->slot_elems;
+    if (h->tm) {  // x, res, y time-major [B][T][C] (x_cm / y_cm: the reference's [B][C][T] at the API edges)
+        AFTER_REQUIRE((size_t)B * conv_tm_cp(cin) * conv_tm_rows(Tin) <= h->xp_elems, AFTER_E_CAPACITY,
+                      "autoencoder: activation scratch too small");
+        ActPadTm p;
+        memset(&p, 0, sizeof(p));
+        p.x = x;
+        p.y = h->xp;
+        p.stats = stats_in;
+        p.gamma = gamma;
+        p.beta = beta;
+        p.act_a = alpha;
+        p.act_b = invb;
+        p.state = state;
+        p.act = act;
+        p.B = B;
+        p.C = cin;
+        p.T = Tin;
+        p.G = cin < 8 ? cin : 8;
+        p.x_cm = x_cm;
+        p.sub_stride = h->max_batch * 16;
+        AFTER_TRY(launch_act_pad_tm(p, s));
+        ConvTmRun r;
+        memset(&r, 0, sizeof(r));
+        r.xp = h->xp;
+        r.w = d.w;
+        r.bias = bias;
+        r.res = res;
+        r.y = y;
+        r.G = cout < 8 ? cout : 8;
+        if (want_stats && h->norm) {
+            r.stats = next_stats(h, B);
+            if (stats_out) *stats_out = r.stats;
+        }
+        r.B = B;
+        r.Tp = conv_tm_rows(Tin);
+        r.Tout = Tout;
+        r.Nn = Nn;
+        r.y_cm = y_cm;
+        r.sub_stride = h->max_batch * 16;
+        return launch_conv_tm(r, d.in, d.tplan, s);
+    }
+    AFTER_REQUIRE((size_t)B * cin * conv_dma_row(Tin) <= h->xp_elems, AFTER_E_CAPACITY,
+                  "autoencoder: activation scratch too small");
     AFTER_TRY(launch_act_pad(x, h->xp, stats_in, gamma, beta, alpha, invb, act, B, cin, Tin,
                              cin < 8 ? cin : 8, s, state));
     ConvDmaRun r;
@@ -535,7 +588,8 @@ int begin_pass(after_ae* h, hipStream_t s) {
     h->stat_slot = 0;
     h->state_slot = 0;
     if (h->norm)
-        AFTER_HIP_CHECK(hipMemsetAsync(h->stats_ring, 0, (size_t)kStatSlots * h->max_batch * 16 * sizeof(double), s));
+        AFTER_HIP_CHECK(hipMemsetAsync(h->stats_ring, 0,
+                                       (size_t)kStatSlots * h->stat_sub * h->max_batch * 16 * sizeof(double), s));
     return AFTER_OK;
 }
 
@@ -550,9 +604,11 @@ int check_ae(after_ae* h, int B, long long samples) {
     return AFTER_OK;
 }
 
+// tm: multiband in the time-major layout of the conv path ([B][L/M][M]) instead of [B][M][L/M]
 int pqmf_forward(after_ae* h, hipStream_t s, const float* x, float* mb, int B, int L,
-                 float* state = nullptr) {
+                 float* state = nullptr, bool tm = false) {
     const int M = h->M, K = h->pq_fk;
+    const int cs = tm ? 1 : L / M, ts = tm ? M : 1;
     const int Q = (K + M - 1) / M;
     const int pl = h->causal ? K - 1 : (K - 1) / 2;
     if (M == 16) {
@@ -564,10 +620,10 @@ int pqmf_forward(after_ae* h, hipStream_t s, const float* x, float* mb, int B, i
             attr = true;
         }
         hipLaunchKernelGGL(pqmf_forward_kernel<16>, dim3(cdiv(L / M, PQ_BT), B), dim3(256), lds, s, x,
-                           h->pq_fwp, mb, L, Q, pl, state);
+                           h->pq_fwp, mb, L, Q, pl, state, cs, ts);
     } else {
         hipLaunchKernelGGL(pqmf_forward_generic_kernel, dim3((unsigned)cdivll((long long)L, 256), B),
-                           dim3(256), 0, s, x, h->pq_fw, mb, L, M, K, pl, state);
+                           dim3(256), 0, s, x, h->pq_fw, mb, L, M, K, pl, state, cs, ts);
     }
     AFTER_HIP_CHECK(hipGetLastError());
     if (state) {  // keep the last K - 1 input samples of every clip
@@ -582,8 +638,9 @@ int pqmf_forward(after_ae* h, hipStream_t s, const float* x, float* mb, int B, i
 }
 
 int pqmf_inverse(after_ae* h, hipStream_t s, const float* y, float* audio, int B, int Tm, int gated,
-                 int ychan, float* zstate = nullptr) {
+                 int ychan, float* zstate = nullptr, bool tm = false) {
     const int M = h->M, K = h->pq_ik;
+    const int cs = tm ? 1 : Tm, ts = tm ? ychan : 1;
     const int pl = h->causal ? K - 1 : (K - 1) / 2;
     if (M == 16) {
         const size_t lds = ((size_t)M * K * M + (size_t)M * (256 + K)) * sizeof(float);
@@ -594,10 +651,10 @@ int pqmf_inverse(after_ae* h, hipStream_t s, const float* y, float* audio, int B
             attr = true;
         }
         hipLaunchKernelGGL(pqmf_inverse_kernel<16>, dim3(cdiv(Tm, 256), B), dim3(256), lds, s, y, h->pq_iwp,
-                           audio, Tm, K, pl, gated, ychan, zstate);
+                           audio, Tm, K, pl, gated, ychan, zstate, cs, ts);
     } else {
         hipLaunchKernelGGL(pqmf_inverse_generic_kernel, dim3((unsigned)cdivll((long long)Tm * M, 256), B),
-                           dim3(256), 0, s, y, h->pq_iw, audio, Tm, M, K, pl, gated, ychan, zstate);
+                           dim3(256), 0, s, y, h->pq_iw, audio, Tm, M, K, pl, gated, ychan, zstate, cs, ts);
     }
     AFTER_HIP_CHECK(hipGetLastError());
     if (zstate) {
@@ -606,7 +663,7 @@ int pqmf_inverse(after_ae* h, hipStream_t s, const float* y, float* audio, int B
                       "pqmf streaming: chunk of %d frames too short / odd", Tm);
         const int total = B * M * S;
         hipLaunchKernelGGL(pqmf_istate_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, y, zstate, Tm, M, S,
-                           gated, ychan, total);
+                           gated, ychan, total, cs, ts);
         AFTER_HIP_CHECK(hipGetLastError());
     }
     return AFTER_OK;
@@ -780,6 +837,9 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
     {
         const char* e = getenv("AFTER_CONV_OLD");
         h->use_dma = !(e && atoi(e) != 0);
+        const char* e2 = getenv("AFTER_CONV_TM");
+        h->tm = h->use_dma && !(e2 && atoi(e2) == 0);
+        h->stat_sub = h->tm ? conv_tm_stat_sub() : 1;
     }
     if (h->use_dma) {
         AE_TRY(h->wd.init((size_t)(wf * 2.0) * sizeof(float) + (8 << 20)));
@@ -869,7 +929,8 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
         const size_t Tm = h->max_samples / h->M;
         size_t T = Tm;
         auto upd = [&](int c, size_t t) {
-            const size_t e2 = (size_t)c * conv_dma_row((int)t);
+            const size_t e2 = h->tm ? (size_t)conv_tm_cp(c) * conv_tm_rows((int)t)
+                                    : (size_t)c * conv_dma_row((int)t);
             xpe = e2 > xpe ? e2 : xpe;
         };
         upd(h->M, Tm);
@@ -891,7 +952,7 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
     h->xp_elems = xpe * max_batch + 4096;
     rc = h->ws.init(3 * h->buf_elems * sizeof(float) + 2 * (size_t)max_batch * cmax * sizeof(float) +
                     (size_t)max_batch * 8 * 64 * 2 * sizeof(double) + (size_t)max_batch * 8 * 4 + 8192 +
-                    h->xp_elems * sizeof(float) + (size_t)kStatSlots * max_batch * 16 * sizeof(double));
+                    h->xp_elems * sizeof(float) + (size_t)kStatSlots * h->stat_sub * max_batch * 16 * sizeof(double));
     if (rc != AFTER_OK) return fail(rc);
     for (int i = 0; i < 3; ++i) h->buf[i] = h->ws.take<float>(h->buf_elems);
     h->scale = h->ws.take<float>((size_t)max_batch * cmax);
@@ -899,7 +960,7 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
     h->gn_part = h->ws.take<double>((size_t)max_batch * 8 * 64 * 2);
     h->gn_tick = h->ws.take<unsigned>((size_t)max_batch * 8);
     h->xp = h->ws.take<float>(h->xp_elems);
-    h->stats_ring = h->ws.take<double>((size_t)kStatSlots * max_batch * 16);
+    h->stats_ring = h->ws.take<double>((size_t)kStatSlots * h->stat_sub * max_batch * 16);
     if (!h->buf[2] || !h->scale || !h->shift || !h->gn_part || !h->gn_tick || !h->xp || !h->stats_ring)
         return fail(AFTER_E_NOMEM);
     if (hipMemset(h->gn_tick, 0, (size_t)max_batch * 8 * sizeof(unsigned)) != hipSuccess ||
@@ -950,7 +1011,8 @@ extern "C" int after_ae_enable_streaming(after_ae* h, int enable) {
     if (!h->sa.base) {
         const int n = c.n_stages, nd = c.n_dilations;
         const int enc_slots = 1 + n * nd + n + 1, dec_slots = 1 + n + n * nd + 1;
-        h->slot_elems = (size_t)h->max_batch * h->cmax * conv_dma_halo();
+        h->slot_elems = h->tm ? (size_t)h->max_batch * conv_tm_cp(h->cmax) * conv_tm_halo()
+                              : (size_t)h->max_batch * h->cmax * conv_dma_halo();
         const size_t fs = (size_t)h->max_batch * (h->pq_fk - 1);
         const size_t is = (size_t)h->max_batch * h->M * (h->pq_ik - 1);
         AFTER_TRY(h->sa.init(((enc_slots + dec_slots) * h->slot_elems + fs + is) * sizeof(float) + 8192));
@@ -986,14 +1048,15 @@ extern "C" int after_ae_encode(after_ae* h, const float* x, float* z, int B, int
     const int n = c.n_stages, nd = c.n_dilations;
     int T = L / h->M;
     float *b0 = h->buf[0], *b1 = h->buf[1], *b2 = h->buf[2];
-    AFTER_TRY(pqmf_forward(h, s, x, b0, B, L, h->streaming ? h->pq_fstate : nullptr));
+    AFTER_TRY(pqmf_forward(h, s, x, b0, B, L, h->streaming ? h->pq_fstate : nullptr, h->use_dma && h->tm));
     if (h->use_dma) {
         AFTER_TRY(begin_pass(h, s));
         float* sb = h->streaming ? h->enc_state : nullptr;
         double* st = nullptr;
         if (h->norm) {  // the first GroupNorm sees the PQMF output: its producer is not a conv
             st = next_stats(h, B);
-            AFTER_TRY(launch_stats_accum(b0, st, B, h->M, T, h->M < 8 ? h->M : 8, s));
+            if (h->tm) AFTER_TRY(launch_stats_accum_tm(b0, st, B, h->M, T, h->M < 8 ? h->M : 8, s));
+            else AFTER_TRY(launch_stats_accum(b0, st, B, h->M, T, h->M < 8 ? h->M : 8, s));
         }
         AFTER_TRY(run_resblock2(h, s, h->enc_stem, b0, b1, b2, B, T, &st, sb));
         float *cur = b2, *t1 = b0, *t2 = b1;
@@ -1014,7 +1077,7 @@ extern "C" int after_ae_encode(after_ae* h, const float* x, float* z, int B, int
         }
         return run_dma(h, s, h->enc_tail.d, cur, nullptr, nullptr, nullptr, h->enc_tail_alpha,
                        h->enc_tail_invb, ACT_SNAKE, h->enc_tail.bias, nullptr, z, B, T, T, T, false,
-                       nullptr, sb);
+                       nullptr, sb, 0, 1);  // z leaves in the reference's [B][Z][T] layout
     }
     AFTER_TRY(run_resblock(h, s, h->enc_stem, b0, b1, b2, B, T));
     float *cur = b2, *t1 = b0, *t2 = b1;
@@ -1067,13 +1130,14 @@ extern "C" int after_ae_encode(after_ae* h, const float* x, float* z, int B, int
 // x_multiband of Decoder1d.forward (SimpleNetsStream.py:643-646): y[:, :M] * sigmoid(y[:, M:])
 __global__ __launch_bounds__(256) void loudness_gate_kernel(const float* __restrict__ y,
                                                             float* __restrict__ mb, int M, int Tm,
-                                                            int gated, int ychan) {
+                                                            int gated, int ychan, int cs, int ts) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
     if (idx >= (size_t)M * Tm) return;
+    const int c = idx / Tm, t = idx - (size_t)c * Tm;  // output [B][M][Tm] (the reference's layout)
     const float* yb = y + (size_t)b * ychan * Tm;
-    float v = yb[idx];
-    if (gated) v *= 1.0f / (1.0f + expf(-yb[(size_t)M * Tm + idx]));
+    float v = yb[(size_t)c * cs + (size_t)t * ts];
+    if (gated) v *= 1.0f / (1.0f + expf(-yb[(size_t)(M + c) * cs + (size_t)t * ts]));
     mb[(size_t)b * M * Tm + idx] = v;
 }
 
@@ -1081,7 +1145,8 @@ static int write_multiband(after_ae* h, hipStream_t s, const float* y, float* mb
                            int ychan) {
     if (!mb) return AFTER_OK;
     dim3 grid((unsigned)(((size_t)h->M * Tm + 255) / 256), B);
-    hipLaunchKernelGGL(loudness_gate_kernel, grid, dim3(256), 0, s, y, mb, h->M, Tm, gated, ychan);
+    const int cs = h->tm ? 1 : Tm, ts = h->tm ? ychan : 1;
+    hipLaunchKernelGGL(loudness_gate_kernel, grid, dim3(256), 0, s, y, mb, h->M, Tm, gated, ychan, cs, ts);
     AFTER_HIP_CHECK(hipGetLastError());
     return AFTER_OK;
 }
@@ -1098,7 +1163,7 @@ static int decode_impl(after_ae* h, const float* z, float* x, float* mb, int B, 
         float* sb = h->streaming ? h->dec_state : nullptr;
         double* st = nullptr;
         AFTER_TRY(run_dma(h, s, h->dec_head.d, z, nullptr, nullptr, nullptr, nullptr, nullptr, ACT_NONE,
-                          h->dec_head.bias, nullptr, cur, B, T, T, T, false, nullptr, sb));
+                          h->dec_head.bias, nullptr, cur, B, T, T, T, false, nullptr, sb, 1, 0));  // z: [B][Z][T]
         for (int i = 0; i < n; ++i) {
             const ResampleW& u = h->dec_up[i];
             AFTER_TRY(run_dma(h, s, h->streaming ? u.d_stream : u.d, cur, nullptr, nullptr, nullptr, u.alpha,
@@ -1120,7 +1185,7 @@ static int decode_impl(after_ae* h, const float* z, float* x, float* mb, int B, 
         const int och = c.use_loudness ? 2 * h->M : h->M;
         AFTER_TRY(write_multiband(h, s, t2, mb, B, T, c.use_loudness, och));
         return pqmf_inverse(h, s, t2, x, B, T, c.use_loudness, och,
-                            h->streaming ? h->pq_istate : nullptr);
+                            h->streaming ? h->pq_istate : nullptr, h->tm);
     }
     {
         ConvArgs a;

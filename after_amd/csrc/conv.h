@@ -116,6 +116,49 @@ int launch_act_pad(const float* x, float* y, const double* stats, const float* g
 // stats[b][g] += (sum, sum of squares) of x[b, group g, :]   (for producers that are not convs)
 int launch_stats_accum(const float* x, double* stats, int B, int C, int T, int G, hipStream_t s);
 
+// ---- time-major conv path (conv_tm.hip): activations [B][T][C], conv = balanced LDS-DMA GEMM.
+// Shares ConvDmaPlanIn (the conv's geometry); weights are the plain [phase][Cout][taps * Cp]
+// GEMM operand, independent of the tile configuration (chosen per launch).
+struct ConvTmPlan {
+    int Cp, K, dil;
+    bool ok;  // uniform tap spacing and |toff| within the halo
+    size_t w_floats;
+};
+struct ConvTmRun {
+    const float* xp;   // [B][Tp][Cp] activated, haloed input (launch_act_pad_tm)
+    const float* w;    // conv_tm_repack output
+    const float* bias;
+    const float* res;  // [B][Tout][Cout] time-major, or nullptr
+    float* y;          // [B][Tout][Cout] time-major ([B][Cout][Tout] when y_cm)
+    double* stats;     // [conv_tm_stat_sub()][sub_stride] doubles, [B][G][2] in each: accumulators of y, or nullptr
+    int B, Tp, Tout, Nn, G, y_cm, sub_stride;
+    const float* post_scale;  // y = out_act(acc + bias) * post_scale[b * post_bstride + co] + post_shift[...]
+    const float* post_shift;
+    int post_bstride, out_act;
+};
+struct ActPadTm {
+    const float* x;       // [B][T][ldx] time-major ([B][C][T] when x_cm)
+    float* y;             // [B][conv_tm_rows(T)][conv_tm_cp(C)]
+    const double* stats;  // producer's accumulators ([sub][sub_stride], see ConvTmRun) -> GroupNorm, or nullptr
+    const float* gamma;   // with stats: GroupNorm weight; without: per-channel scale (BatchNorm eval) or nullptr
+    const float* beta;
+    const float* act_a;
+    const float* act_b;
+    float* state;         // streaming: [B][halo][Cp] left context, used and then replaced; or nullptr
+    const float* scale_b; // per-(clip, channel) affine [B][C] (takes the place of gamma / beta), or nullptr
+    const float* shift_b;
+    int act, B, C, T, G, x_cm, ldx, pad_reflect, sub_stride;
+};
+int conv_tm_halo();
+int conv_tm_stat_sub();   // accumulator pairs per (clip, group): see conv_tm.hip
+int conv_tm_cp(int C);    // channels rounded up to the 32-deep K slab
+int conv_tm_rows(int T);  // rows of the haloed buffer
+void conv_tm_plan(const ConvDmaPlanIn& in, ConvTmPlan* p);
+int conv_tm_repack(const float* packed, float* out, const ConvDmaPlanIn& in, const ConvTmPlan& p, hipStream_t s);
+int launch_conv_tm(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan& p, hipStream_t s);
+int launch_act_pad_tm(const ActPadTm& p, hipStream_t s);
+int launch_stats_accum_tm(const float* x, double* stats, int B, int C, int T, int G, hipStream_t s);
+
 inline int pad16(int c) { return (c + 15) & ~15; }
 
 // cached_conv.get_padding left pad (stride ignored): p = (k-1) d + 1

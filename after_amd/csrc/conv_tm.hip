@@ -1,0 +1,881 @@
+// Third-generation conv path of the codec and the conditioning encoders: TIME-MAJOR
+// activations ([B][T][C], channels contiguous) so that a 1-D convolution IS a GEMM with
+// K-contiguous operands on both sides and runs on the balanced LDS-DMA GEMM machinery of
+// gemm.hip (gemm_pipe.h):
+//
+//   y[b, n * ostride + ooff, co] = bias[co] + res[...] +
+//        sum_{tap, ci} xp[b, HALO + n * istride + toff0 + tap * dil, ci] * w[co, tap * Cp + ci]
+//
+//   M = output positions of one clip (and phase), N = Cout, K = taps * Cp.  A row n of the
+//   implicit A matrix starts at xp row (HALO + n*istride + toff0); with dil == 1 its K = taps*Cp
+//   floats are CONTIGUOUS in memory (a plain GEMM with lda = istride * Cp: the strided
+//   Downsample1d, the two-tap phases of the transposed Upsample1d, every k = 1 conv and the
+//   undilated k = 3 / k = 5 convs); with dil > 1 the 32-deep slab s of K lives at
+//   s*32 + tap(s) * (dil-1) * Cp, one scalar multiply-shift per DMA piece.
+//
+// What this buys over conv_dma.hip ([B][C][T] layout, time along N): the X operand is read from
+// LDS as ds_read_b128 k-quads like the weights (was 4 x ds_read_b32 per 16x16 block and k-step),
+// the DMA pieces need no per-stage address arithmetic, the XCD tile map keeps an XCD on a compact
+// range of output positions so the haloed input is fetched once and the weights once per XCD
+// (conv_dma: every XCD re-read everything, 6.5x the algorithmic bytes), and small-T layers
+// (conditioning encoders, first decoder stage) get the split-K tiles that fill 256 CUs.
+//
+// act_pad_tm_kernel materialises act(GroupNorm / BatchNorm-affine(x)) once per conv into the
+// zero-haloed buffer (conv padding = reading the halo = the reference's pad-after-activation,
+// cached_conv.Conv1d); the conv epilogue accumulates the NEXT GroupNorm's statistics.
+#include <cstdio>
+#include <cstdlib>
+#include <new>
+
+#include "conv.h"
+#include "gemm_pipe.h"
+
+namespace after {
+namespace {
+
+constexpr int HALO = 32;  // zero rows on both sides of every clip
+// The statistics of one (clip, group) are spread over kStatSub accumulator pairs (workgroup id
+// mod kStatSub) so that the fp64 atomics of several hundred workgroups do not serialise on 16
+// addresses; the consumer adds the sub-slots in a fixed order.
+constexpr int kStatSub = 8;
+
+__device__ __forceinline__ float act_apply(float v, int act, float pa, float pb) {
+    switch (act) {
+        case ACT_SNAKE: {
+            const float s = sinf(v * pa);
+            return v + pb * (s * s);
+        }
+        case ACT_SILU:
+            return v / (1.0f + expf(-v));
+        case ACT_RELU:
+            return fmaxf(v, 0.f);
+        case ACT_TANH:
+            return tanhf(v);
+        default:
+            return v;
+    }
+}
+
+// ------------------------------------------------------------------ activate + halo
+struct ActTmArgs {
+    const float* x;       // [B][T][ldx] time-major, or [B][C][T] when x_cm
+    float* y;             // [B][Tp][Cp]
+    const double* stats;  // [B][G][2] or nullptr
+    const float* gamma;   // with stats: GroupNorm weight; without: per-channel scale (or nullptr)
+    const float* beta;
+    const float* act_a;
+    const float* act_b;
+    const float* state;   // streaming: [B][HALO][Cp] activated rows preceding this chunk, or nullptr
+    const float* scale_b; // optional per-(b, channel) affine [B][C] applied instead of gamma / beta
+    const float* shift_b;
+    int act, C, Cp, T, Tp, G, x_cm, ldx, rows_per_block, pad_reflect, sub_stride;
+    float eps;
+};
+
+// One thread = one 4-channel quad; a block walks `rows_per_block` consecutive rows of the
+// padded buffer (the quad's parameters stay in registers).
+__global__ __launch_bounds__(256) void act_pad_tm_kernel(ActTmArgs a) {
+    const int Q = a.Cp >> 2;
+    const int R = 256 / Q;  // rows per pass (Q <= 256)
+    const int r = threadIdx.x / Q, q = threadIdx.x - r * Q;
+    const int b = blockIdx.y, c0 = 4 * q;
+    // GroupNorm statistics -> (mean, rstd) per group: one lane per group adds the sub-slots (fixed
+    // order) and does the fp64 arithmetic once per block instead of once per thread and channel
+    __shared__ float gmean[8], grstd[8];
+    if (a.stats) {
+        if (threadIdx.x < a.G) {
+            const int gI = threadIdx.x;
+            const double n = (double)(a.C / a.G) * a.T;
+            double s = 0, qq = 0;
+            for (int u = 0; u < kStatSub; ++u) {
+                s += a.stats[(size_t)u * a.sub_stride + ((size_t)b * a.G + gI) * 2];
+                qq += a.stats[(size_t)u * a.sub_stride + ((size_t)b * a.G + gI) * 2 + 1];
+            }
+            const double mean = s / n;
+            double var = qq / n - mean * mean;
+            var = var < 0 ? 0 : var;
+            gmean[gI] = (float)mean;
+            grstd[gI] = (float)(1.0 / sqrt(var + (double)a.eps));
+        }
+        __syncthreads();
+    }
+    if (r >= R) return;
+    float sc[4], sh[4], pa[4], pb[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + k;
+        sc[k] = 1.f;
+        sh[k] = 0.f;
+        pa[k] = pb[k] = 0.f;
+        if (c >= a.C) continue;
+        if (a.stats) {
+            const int g = c / (a.C / a.G);
+            sc[k] = grstd[g] * a.gamma[c];
+            sh[k] = a.beta[c] - gmean[g] * sc[k];
+        } else if (a.scale_b) {
+            sc[k] = a.scale_b[(size_t)b * a.C + c];
+            sh[k] = a.shift_b[(size_t)b * a.C + c];
+        } else if (a.gamma) {
+            sc[k] = a.gamma[c];
+            sh[k] = a.beta[c];
+        }
+        if (a.act_a) pa[k] = a.act_a[c];
+        if (a.act_b) pb[k] = a.act_b[c];
+    }
+    const int p_lo = blockIdx.x * a.rows_per_block;
+    const int p_hi = min(p_lo + a.rows_per_block, a.Tp);
+    float* yb = a.y + (size_t)b * a.Tp * a.Cp;
+    constexpr int U = 4;  // rows in flight per thread: all loads are requested before the first use
+    const bool vec = !a.x_cm && c0 + 3 < a.C;
+    for (int pb0 = p_lo + r; pb0 < p_hi; pb0 += U * R) {
+        f32x4 v[U];
+        int tt[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = pb0 + u * R;
+            int t = p - HALO;
+            if (a.pad_reflect && (t < 0 || t >= a.T) && t > -a.T && t < 2 * a.T - 1)
+                t = t < 0 ? -t : 2 * (a.T - 1) - t;  // 'reflect' padding (TDNNBlock, ecapa_encoder.py:85-139)
+            tt[u] = t;
+            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p >= p_hi) continue;
+            if (t >= 0 && t < a.T) {
+                if (vec) {
+                    v[u] = *reinterpret_cast<const f32x4*>(a.x + ((size_t)b * a.T + t) * a.ldx + c0);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (c0 + k < a.C)
+                            v[u][k] = a.x_cm ? a.x[((size_t)b * a.C + c0 + k) * a.T + t]
+                                             : a.x[((size_t)b * a.T + t) * a.ldx + c0 + k];
+                }
+            } else if (t < 0 && a.state) {
+                v[u] = *reinterpret_cast<const f32x4*>(a.state + ((size_t)b * HALO + (HALO + t)) * a.Cp + c0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = pb0 + u * R;
+            if (p >= p_hi) continue;
+            f32x4 o = v[u];
+            if (tt[u] >= 0 && tt[u] < a.T) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    o[k] = c0 + k < a.C ? act_apply(o[k] * sc[k] + sh[k], a.act, pa[k], pb[k]) : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(yb + (size_t)p * a.Cp + c0) = o;
+        }
+    }
+}
+
+// streaming: state[b][j][:] = ypad[b][T + j][:], j < HALO (the last HALO activated rows; the old
+// context included when the chunk is shorter than the halo)
+__global__ void state_update_tm_kernel(const float* __restrict__ yp, float* __restrict__ state, int Cp,
+                                       int T, int Tp, int total4) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total4) return;
+    const int per = HALO * Cp / 4;
+    const int b = idx / per, e = idx - b * per;
+    reinterpret_cast<f32x4*>(state)[idx] =
+        reinterpret_cast<const f32x4*>(yp + ((size_t)b * Tp + T) * Cp)[e];
+}
+
+// ------------------------------------------------------------------ the conv GEMM
+struct ConvTmArgs {
+    const float* xp;    // [B][Tp][Cp]
+    const float* w;     // [phases][Cout][K]
+    const float* bias;  // [Cout] or nullptr
+    const float* res;   // [B][Tout][Cout] or nullptr
+    float* y;           // [B][Tout][Cout]  (y_cm: [B][Cout][Tout])
+    double* stats;      // [kStatSub][sub_stride] with [B][G][2] inside: accumulators of y, or nullptr
+    int Cp, Cout, Tp, Tout, K, phases, lda, ostride, Nn, G, y_cm, sub_stride;
+    int magic, extra;   // tap(s) = (s * magic) >> 16,  extra = (dil - 1) * Cp
+    int abase[kMaxPhases];  // (HALO + toff[ph][0]) * Cp
+    int ooff[kMaxPhases];
+    int gs_off;         // float offset of the statistics scratch inside the dynamic LDS
+    int gs_in_ring;     // 1: the scratch overlays the (then idle) ring
+    // post-activation epilogue of the TDNN / FiLM layers: y = out_act(acc + bias) * post_scale + post_shift
+    const float* post_scale;
+    const float* post_shift;
+    int out_act, post_bstride;
+};
+
+template <int MB, int NB, int KS, int NS, int RS, bool DIL>
+__global__ __launch_bounds__(128 * KS * RS) void conv_tm_kernel(ConvTmArgs g, int tiles_m, int tiles_n,
+                                                                int xcd_pm, int ny) {
+    constexpr int BK = 32, CPR = 8, RPP = 8, KK = 2;
+    static_assert(MB % RS == 0, "row parts must divide the tile's block rows");
+    constexpr int MT = MB / RS, NT = NB;
+    constexpr int BM = 16 * MB, BN = 32 * NB;
+    constexpr int NW = 2 * KS * RS;
+    constexpr int ROWS = KS * (BM + BN);
+    constexpr int LPS = ROWS / RPP / NW;
+    static_assert(ROWS % (RPP * NW) == 0, "ring slot must split evenly over the waves");
+    constexpr int STAGE = ROWS * BK;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    // ---- workgroup -> (clip / phase, tile).  Block id b runs on XCD b % 8 (private L2s): with
+    // nwg % 8 == 0 the XCDs are laid out as a pm x pn grid over each clip's tile matrix and walk
+    // the clips in the same order, otherwise XCDs take contiguous ranges of the linear order.
+    const int nwg = tiles_m * tiles_n;
+    int tm, tn, yi;
+    if (xcd_pm > 0) {
+        const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+        const int per = nwg >> 3;
+        yi = li / per;
+        const int l2 = li - yi * per;
+        const int pn = 8 / xcd_pm;
+        const int cm = tiles_m / xcd_pm, cn = tiles_n / pn;
+        const int xi = xcd % xcd_pm, xj = xcd / xcd_pm;
+        (void)cn;
+        tm = xi * cm + l2 % cm;
+        tn = xj * cn + l2 / cm;
+    } else {
+        const int total = nwg * ny;
+        int bid = blockIdx.x;
+        const int xcd = bid & 7, q = total >> 3, r = total & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        yi = bid / nwg;
+        const int t = bid - yi * nwg;
+        tn = t / tiles_m;
+        tm = t - tn * tiles_m;
+    }
+    const int b = yi / g.phases, ph = yi - b * g.phases;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = wid % KS, rp = (wid / KS) % RS, part = wid / (KS * RS);
+    const int M = g.Nn, N = g.Cout, Kh = g.K / KS;
+    const int nk = Kh / BK;
+
+    // ---- DMA addressing: wave-uniform 64-bit base + per-lane 32-bit byte offset (+ a scalar
+    // slab offset).  A pieces: slab S = half * nk + s of the flattened (tap, channel) axis.
+    const float* xb = g.xp + (size_t)b * g.Tp * g.Cp + g.abase[ph];
+    const float* wb = g.w + (size_t)ph * g.Cout * g.K;
+    const int rsub = lane / CPR, pos = lane % CPR;
+    unsigned voff[LPS];
+    const float* sbase[LPS];
+    int kb[LPS], ex[LPS];
+#pragma unroll
+    for (int i = 0; i < LPS; ++i) {
+        const int row0 = (wid * LPS + i) * RPP;
+        const int row = row0 + rsub;
+        if (row0 < KS * BM) {
+            const int half = row0 / BM;
+            const int gm = min(m0 + row - half * BM, M - 1);
+            sbase[i] = xb;
+            kb[i] = half * nk;
+            ex[i] = g.extra;
+            voff[i] = ((unsigned)gm * (unsigned)g.lda + (unsigned)((pos ^ (row & (CPR - 1))) * 4)) * 4u;
+        } else {
+            const int rr0 = row0 - KS * BM;
+            const int half = rr0 / BN;
+            const int gn = min(n0 + (row - KS * BM) - half * BN, N - 1);
+            sbase[i] = wb + half * Kh;
+            kb[i] = 0;
+            ex[i] = 0;
+            voff[i] = ((unsigned)gn * (unsigned)g.K + (unsigned)((pos ^ (row & (CPR - 1))) * 4)) * 4u;
+        }
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+    const int magic = g.magic;
+#define AFTER_BAL_DMA(w_, slab_, slot_)                                                              \
+    {                                                                                                \
+        const int S__ = kb[w_] + (slab_);                                                            \
+        int o__ = S__ * BK;                                                                          \
+        if constexpr (DIL) o__ += ((S__ * magic) >> 16) * ex[w_];                                    \
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                 \
+                     :                                                                               \
+                     : "s"(lds0 + (unsigned)(((slot_) * STAGE + (wid * LPS + (w_)) * RPP * BK) * 4)), \
+                       "v"(voff[w_]), "s"(sbase[w_] + o__)                                           \
+                     : "memory"); /* m0: see gemm.hip (reserved, re-materialised by hipcc) */        \
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // statistics scratch behind the ring: zeroed here, long before the epilogue (the main loop's
+    // barriers order it); inside the ring (gs_in_ring) it is zeroed after the last ring read
+    float* gs = smem + g.gs_off;  // [2][16] per-group partial sums of this tile
+    if (g.stats && !g.gs_in_ring && tid < 32) gs[tid] = 0.f;
+
+    unsigned long long ph_fence = 0, ph_vm = 0, ph_bar = 0;  // cycle-stamp sinks of the pipeline macros
+    (void)ph_fence;
+    (void)ph_vm;
+    (void)ph_bar;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        if (s < nk) {
+#pragma unroll
+            for (int i = 0; i < LPS; ++i) AFTER_BAL_DMA(i, s, s)
+        }
+
+    const int frow = lane & 15, kq = lane >> 4, sw = frow & (CPR - 1);
+    const int aoff = (kh * BM + rp * (BM / RS) + frow) * BK;
+    const int woff = (KS * BM + kh * BN + part * 16 * NB + frow) * BK;
+    f32x4 fa[KK][2][MT], fb[KK][2][NT];
+    unsigned a_c[KK], w_c[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+        const int c = ((kq + 4 * kk) ^ sw) * 4;
+        a_c[kk] = lds0 + (aoff + c) * 4;
+        w_c[kk] = lds0 + (woff + c) * 4;
+    }
+    // the pipeline macros test `g.dbg` for their optional cycle stamps (gemm.hip's timeline
+    // diagnostics): inside the main loop `g` names a constant-null stand-in, so they fold away
+    struct DbgNull {
+        unsigned long long* dbg = nullptr;
+    };
+    const DbgNull conv_tm_dbg_null__{};
+#define g conv_tm_dbg_null__
+    AFTER_GEMM_WAIT_SLAB(0, NS - 1)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    AFTER_GEMM_LOAD_FRAGS(0, 0)
+    int kt = 0;
+    for (; kt + 1 + NS < nk; kt += 2) {
+        AFTER_GEMM_STEP_IL(0, 1, kt, true)
+        AFTER_GEMM_STEP_IL(1, 0, kt + 1, true)
+    }
+    for (; kt < nk; kt += 2) {
+        AFTER_GEMM_STEP_IL(0, 1, kt, false)
+        if (kt + 1 < nk) AFTER_GEMM_STEP_IL(1, 0, kt + 1, false)
+    }
+#undef g
+
+    // ---- split-K reduction through LDS in k-part order (bit-deterministic), as in gemm.hip
+    float* red = smem;
+    if (KS > 1 || (g.stats && g.gs_in_ring)) __syncthreads();  // every wave is past its last ring read
+    if constexpr (KS > 1) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                *reinterpret_cast<f32x4*>(red + ((wid * MT * NT + i * NT + j) * 64 + lane) * 4) = acc[i][j];
+    }
+    if (g.stats && g.gs_in_ring && tid < 32) gs[tid] = 0.f;
+    if (KS > 1 || (g.stats && g.gs_in_ring)) __syncthreads();
+
+    // accumulator layout (W fragment as srcA): lane l holds C[row = l & 15][col = 4 (l >> 4) + r]
+    const int crow = lane & 15, ccol0 = 4 * (lane >> 4);
+    const int Cg = g.stats ? g.Cout / g.G : 1;
+    const int g0 = n0 / Cg;
+    const bool quad = (Cg & 3) == 0;  // a lane's four channels sit in one group (every shipped width)
+    float* yb = g.y + (size_t)b * g.Tout * g.Cout;
+    const float* rb = g.res ? g.res + (size_t)b * g.Tout * g.Cout : nullptr;
+    const bool vec_ok = (g.Cout & 3) == 0 && !g.y_cm;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int gn = n0 + part * 16 * NB + j * 16 + ccol0;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f}, ps = {1.f, 1.f, 1.f, 1.f}, pt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (gn + r < N) {
+                if (g.bias) bv[r] = g.bias[gn + r];
+                if (g.post_scale) {
+                    ps[r] = g.post_scale[(size_t)b * g.post_bstride + gn + r];
+                    pt[r] = g.post_shift[(size_t)b * g.post_bstride + gn + r];
+                }
+            }
+        float ssum = 0.f, qsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            if ((i * NT + j) % KS != kh) continue;
+            f32x4 o = acc[i][j];
+            if constexpr (KS > 1) {
+                const int w0 = (part * RS + rp) * KS;
+                o = *reinterpret_cast<const f32x4*>(red + ((w0 * MT * NT + i * NT + j) * 64 + lane) * 4);
+#pragma unroll
+                for (int q = 1; q < KS; ++q)
+                    o += *reinterpret_cast<const f32x4*>(red + (((w0 + q) * MT * NT + i * NT + j) * 64 + lane) * 4);
+            }
+            const int gm = m0 + rp * (BM / RS) + i * 16 + crow;
+            if (gm >= M || gn >= N) continue;
+            o += bv;
+            if (g.out_act == ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
+            } else if (g.out_act == ACT_TANH) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = tanhf(o[r]);
+            } else if (g.out_act == ACT_SILU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = o[r] / (1.0f + expf(-o[r]));
+            }
+            if (g.post_scale) o = o * ps + pt;
+            const int trow = gm * g.ostride + g.ooff[ph];
+            if (trow >= g.Tout) continue;
+            const size_t off = (size_t)trow * g.Cout + gn;
+            if (vec_ok && gn + 3 < N) {
+                if (rb) o += *reinterpret_cast<const f32x4*>(rb + off);
+                *reinterpret_cast<f32x4*>(yb + off) = o;
+                if (quad) {
+                    ssum += (o[0] + o[1]) + (o[2] + o[3]);
+                    qsum += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+                } else if (g.stats) {  // narrow test configurations: one LDS atomic per element
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int gl = (gn + r) / Cg - g0;
+                        atomicAdd(&gs[gl & 15], o[r]);
+                        atomicAdd(&gs[16 + (gl & 15)], o[r] * o[r]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (gn + r < N) {
+                        float v = o[r];
+                        if (rb) v += rb[off + r];
+                        if (g.y_cm) yb[(size_t)(gn + r) * g.Tout + trow] = v;
+                        else yb[off + r] = v;
+                        if (quad) {
+                            ssum += v;
+                            qsum += v * v;
+                        } else if (g.stats) {
+                            const int gl = (gn + r) / Cg - g0;
+                            atomicAdd(&gs[gl & 15], v);
+                            atomicAdd(&gs[16 + (gl & 15)], v * v);
+                        }
+                    }
+            }
+        }
+        if (g.stats && quad) {
+            // the 16 lanes l & 15 of a quad share the channel quad: butterfly over the rows
+#pragma unroll
+            for (int o2 = 1; o2 < 16; o2 <<= 1) {
+                ssum += __shfl_xor(ssum, o2, 64);
+                qsum += __shfl_xor(qsum, o2, 64);
+            }
+            if (crow == 0 && gn < N) {
+                const int gl = gn / Cg - g0;  // Cg % 4 == 0: the quad sits in one group
+                atomicAdd(&gs[gl & 15], ssum);
+                atomicAdd(&gs[16 + (gl & 15)], qsum);
+            }
+        }
+    }
+    if (g.stats) {
+        __syncthreads();
+        if (tid < 16) {
+            const int grp = g0 + tid;
+            const int glast = (min(n0 + BN, N) - 1) / Cg;
+            if (grp <= glast) {
+                double* sp = g.stats + (size_t)(blockIdx.x % kStatSub) * g.sub_stride + ((size_t)b * g.G + grp) * 2;
+                atomicAdd(sp, (double)gs[tid]);
+                atomicAdd(sp + 1, (double)gs[16 + tid]);
+            }
+        }
+    }
+}
+#undef AFTER_BAL_DMA
+
+// w_out[ph][co][tap * Cp + ci] = packed[ph][co][tap][ci] (packed: conv.hip's weight-norm-folded
+// [phase][Cout][taps][pad16(Cin)]), zero past Cin
+__global__ void repack_tm_kernel(const float* __restrict__ w, float* __restrict__ out, int phases, int Cout,
+                                 int taps, int Cin, int Cin_pad, int Cp) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)phases * Cout * taps * Cp;
+    if (idx >= total) return;
+    const int ci = idx % Cp;
+    const int tap = (idx / Cp) % taps;
+    const size_t pc = idx / ((size_t)Cp * taps);  // ph * Cout + co
+    out[idx] = ci < Cin ? w[(pc * taps + tap) * Cin_pad + ci] : 0.f;
+}
+
+// stats[b][g] += (sum, sum of squares) of x[b, :, group g] (time-major) for producers that are
+// not convs (the PQMF analysis bank)
+__global__ __launch_bounds__(256) void stats_accum_tm_kernel(const float* __restrict__ x,
+                                                             double* __restrict__ stats, int C, int T,
+                                                             int G, int rows_per_block) {
+    __shared__ float sh[2][16];
+    const int b = blockIdx.y;
+    const int Cg = C / G;
+    if (threadIdx.x < 32) (&sh[0][0])[threadIdx.x] = 0.f;
+    __syncthreads();
+    const int R = 256 / C > 0 ? 256 / C : 1;
+    const int r = threadIdx.x / C, c = threadIdx.x - r * C;
+    float s = 0.f, q = 0.f;
+    if (r < R && c < C) {
+        const int lo = blockIdx.x * rows_per_block, hi = min(lo + rows_per_block, T);
+        for (int t = lo + r; t < hi; t += R) {
+            const float v = x[((size_t)b * T + t) * C + c];
+            s += v;
+            q += v * v;
+        }
+        atomicAdd(&sh[0][c / Cg], s);
+        atomicAdd(&sh[1][c / Cg], q);
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {
+        double* sp = stats + ((size_t)b * G + threadIdx.x) * 2;
+        atomicAdd(sp, (double)sh[0][threadIdx.x]);
+        atomicAdd(sp + 1, (double)sh[1][threadIdx.x]);
+    }
+}
+
+template <int MB, int NB, int KS, int NS, int RS>
+int launch_tm_cfg(ConvTmArgs a, int B, bool dil, hipStream_t s) {
+    constexpr int BM = 16 * MB, BN = 32 * NB;
+    const int tiles_m = cdiv(a.Nn, BM), tiles_n = cdiv(a.Cout, BN);
+    const size_t ring = size_t(NS) * KS * (BM + BN) * 32 * sizeof(float);
+    const size_t red = KS > 1 ? size_t(2 * KS * RS) * (MB / RS) * NB * 256 * sizeof(float) : 0;
+    // the statistics scratch (32 floats) lives behind the reduction slabs inside the ring when it
+    // fits: 128 extra bytes would cost the 80-KiB split-K-4 ring its second workgroup per CU
+    size_t lds = ring > red ? ring : red;
+    if (lds + 128 > 80 * 1024 && lds <= 80 * 1024) {
+        a.gs_off = (int)(red / sizeof(float));
+        a.gs_in_ring = 1;
+        if (red + 128 > lds) lds = red + 128;
+    } else {
+        a.gs_off = (int)(lds / sizeof(float));
+        a.gs_in_ring = 0;
+        lds += 128;
+    }
+    static_assert(size_t(NS) * KS * (BM + BN) * 32 * sizeof(float) <= 160 * 1024, "ring exceeds the LDS");
+    const int nwg = tiles_m * tiles_n, ny = B * a.phases;
+    // XCD grid pm x (8 / pm) over the tile matrix: an XCD fetches 1/pm of the input rows (each
+    // Cp floats, shared by the taps) and 1/pn of the weights (K = taps * Cp floats per row)
+    int pm = 0;
+    if ((nwg & 7) == 0) {
+        double best = 0;
+        for (int c = 1; c <= 8; c *= 2) {
+            if (tiles_m % c || tiles_n % (8 / c)) continue;
+            const double cost = (double)a.Nn * a.Cp / c + (double)a.Cout * a.K / (8 / c);
+            if (pm == 0 || cost < best) {
+                pm = c;
+                best = cost;
+            }
+        }
+    }
+    auto go = [&](auto kern) -> int {
+        static size_t attr = 0;
+        if (lds > attr) {
+            AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr = lds;
+        }
+        hipLaunchKernelGGL(kern, dim3(nwg * ny), dim3(128 * KS * RS), lds, s, a, tiles_m, tiles_n, pm, ny);
+        AFTER_HIP_CHECK(hipGetLastError());
+        return AFTER_OK;
+    };
+    if (dil) return go(conv_tm_kernel<MB, NB, KS, NS, RS, true>);
+    return go(conv_tm_kernel<MB, NB, KS, NS, RS, false>);
+}
+
+int g_tm_force = -1;  // AFTER_CONV_TM_TILE / after_convtm_set_tile: tile configuration id (0 = heuristic)
+
+// tile configurations by id (scripts/bench_conv.py sweeps them per layer shape)
+int launch_tm_id(int id, const ConvTmArgs& a, int B, bool dil, hipStream_t s) {
+    switch (id) {
+        case 1: return launch_tm_cfg<4, 3, 1, 2, 2>(a, B, dil, s);   // 64 x 96, rows split over the waves
+        case 2: return launch_tm_cfg<4, 2, 1, 2, 2>(a, B, dil, s);   // 64 x 64
+        case 3: return launch_tm_cfg<4, 1, 1, 2, 2>(a, B, dil, s);   // 64 x 32
+        case 4: return launch_tm_cfg<3, 1, 2, 2, 1>(a, B, dil, s);   // 48 x 32, 2 k-parts
+        case 5: return launch_tm_cfg<3, 1, 4, 2, 1>(a, B, dil, s);   // 48 x 32, 4 k-parts (8 waves)
+        case 6: return launch_tm_cfg<2, 3, 2, 2, 1>(a, B, dil, s);   // 32 x 96, 2 k-parts
+        case 7: return launch_tm_cfg<3, 3, 2, 2, 1>(a, B, dil, s);   // 48 x 96, 2 k-parts
+        case 8: return launch_tm_cfg<4, 3, 2, 2, 2>(a, B, dil, s);   // 64 x 96, 2 k-parts x 2 row parts (8 waves)
+        case 9: return launch_tm_cfg<2, 2, 2, 2, 1>(a, B, dil, s);   // 32 x 64, 2 k-parts
+        case 10: return launch_tm_cfg<6, 3, 1, 2, 2>(a, B, dil, s);  // 96 x 96
+        case 11: return launch_tm_cfg<4, 2, 2, 2, 2>(a, B, dil, s);  // 64 x 64, 2 k-parts x 2 row parts
+        default: break;
+    }
+    set_error("conv_tm: no tile configuration %d", id);
+    return AFTER_E_INVALID;
+}
+
+}  // namespace
+
+int conv_tm_halo() { return HALO; }
+int conv_tm_stat_sub() { return kStatSub; }
+int conv_tm_cp(int C) { return (C + 31) & ~31; }
+int conv_tm_rows(int T) { return T + 2 * HALO; }
+
+int launch_act_pad_tm(const ActPadTm& p, hipStream_t s) {
+    ActTmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = p.x;
+    a.y = p.y;
+    a.stats = p.stats;
+    a.gamma = p.gamma;
+    a.beta = p.beta;
+    a.act_a = p.act_a;
+    a.act_b = p.act_b;
+    a.state = p.state;
+    a.scale_b = p.scale_b;
+    a.shift_b = p.shift_b;
+    a.act = p.act;
+    a.C = p.C;
+    a.Cp = conv_tm_cp(p.C);
+    a.T = p.T;
+    a.Tp = conv_tm_rows(p.T);
+    a.G = p.G;
+    a.x_cm = p.x_cm;
+    a.ldx = p.ldx > 0 ? p.ldx : p.C;
+    a.pad_reflect = p.pad_reflect;
+    a.sub_stride = p.sub_stride;
+    a.eps = 1e-5f;
+    AFTER_REQUIRE(a.Cp <= 1024, AFTER_E_INVALID, "act_pad_tm: at most 1024 channels (got %d)", p.C);
+    AFTER_REQUIRE(!p.x_cm ? ((a.ldx & 3) == 0 || p.C < 4) : true, AFTER_E_INVALID, "act_pad_tm: ldx %% 4 != 0");
+    AFTER_REQUIRE(!p.stats || (p.C % p.G) == 0, AFTER_E_INVALID, "act_pad_tm: C %% G != 0");
+    const int Q = a.Cp / 4, R = 256 / Q;
+    // >= ~3 blocks per CU where the tensor allows, >= 4 passes per block
+    int rpb = R * 4;
+    while ((long long)cdiv(a.Tp, rpb) * p.B > 2048) rpb *= 2;
+    a.rows_per_block = rpb;
+    AFTER_REQUIRE(R >= 1, AFTER_E_INVALID, "act_pad_tm: too many channels");
+    hipLaunchKernelGGL(act_pad_tm_kernel, dim3(cdiv(a.Tp, rpb), p.B), dim3(256), 0, s, a);
+    AFTER_HIP_CHECK(hipGetLastError());
+    if (p.state) {
+        const int total4 = p.B * HALO * a.Cp / 4;
+        hipLaunchKernelGGL(state_update_tm_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, s, p.y, p.state, a.Cp,
+                           p.T, a.Tp, total4);
+        AFTER_HIP_CHECK(hipGetLastError());
+    }
+    return AFTER_OK;
+}
+
+int launch_stats_accum_tm(const float* x, double* stats, int B, int C, int T, int G, hipStream_t s) {
+    AFTER_REQUIRE(C <= 256 && G <= 16 && C % G == 0, AFTER_E_INVALID, "stats_accum_tm: C <= 256, G <= 16");
+    int rpb = 64;
+    while ((long long)cdiv(T, rpb) * B > 1024) rpb *= 2;
+    hipLaunchKernelGGL(stats_accum_tm_kernel, dim3(cdiv(T, rpb), B), dim3(256), 0, s, x, stats, C, T, G, rpb);
+    AFTER_HIP_CHECK(hipGetLastError());
+    return AFTER_OK;
+}
+
+void conv_tm_plan(const ConvDmaPlanIn& in, ConvTmPlan* p) {
+    p->Cp = conv_tm_cp(in.Cin);
+    p->K = in.taps * p->Cp;
+    p->dil = in.taps > 1 ? in.toff[0][1] - in.toff[0][0] : 1;
+    p->ok = true;
+    for (int ph = 0; ph < in.phases; ++ph) {
+        for (int t = 1; t < in.taps; ++t)
+            if (in.toff[ph][t] - in.toff[ph][t - 1] != p->dil) p->ok = false;  // uniform tap spacing only
+        if (HALO + in.toff[ph][0] < 0 || in.toff[ph][in.taps - 1] > HALO) p->ok = false;
+    }
+    if (p->dil < 1) p->ok = false;
+    p->w_floats = (size_t)in.phases * in.Cout * p->K;
+}
+
+int conv_tm_repack(const float* packed, float* out, const ConvDmaPlanIn& in, const ConvTmPlan& p,
+                   hipStream_t s) {
+    AFTER_REQUIRE(p.ok, AFTER_E_INVALID, "conv_tm: unsupported tap pattern");
+    hipLaunchKernelGGL(repack_tm_kernel, dim3((unsigned)cdivll(p.w_floats, 256)), dim3(256), 0, s, packed, out,
+                       in.phases, in.Cout, in.taps, in.Cin, pad16(in.Cin), p.Cp);
+    AFTER_HIP_CHECK(hipGetLastError());
+    return AFTER_OK;
+}
+
+int launch_conv_tm(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan& p, hipStream_t s) {
+    AFTER_REQUIRE(p.ok, AFTER_E_INVALID, "conv_tm: unsupported tap pattern");
+    ConvTmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xp = r.xp;
+    a.w = r.w;
+    a.bias = r.bias;
+    a.res = r.res;
+    a.y = r.y;
+    a.stats = r.stats;
+    a.Cp = p.Cp;
+    a.Cout = in.Cout;
+    a.Tp = r.Tp;
+    a.Tout = r.Tout;
+    a.K = p.K;
+    a.phases = in.phases;
+    a.lda = in.istride * p.Cp;
+    a.ostride = in.ostride;
+    a.Nn = r.Nn;
+    a.G = r.G;
+    a.sub_stride = r.sub_stride;
+    a.y_cm = r.y_cm;
+    a.post_scale = r.post_scale;
+    a.post_shift = r.post_shift;
+    a.post_bstride = r.post_bstride;
+    a.out_act = r.out_act;
+    const int npt = p.Cp / 32;
+    a.magic = (65536 + npt - 1) / npt;  // exact for slab < 65536 / npt ... (taps * npt <= 8 * 32)
+    a.extra = (p.dil - 1) * p.Cp;
+    for (int ph = 0; ph < in.phases; ++ph) {
+        a.abase[ph] = (HALO + in.toff[ph][0]) * p.Cp;
+        a.ooff[ph] = in.ooff[ph];
+    }
+    AFTER_REQUIRE(!r.stats || (in.Cout % r.G == 0 && r.G <= 8), AFTER_E_INVALID,
+                  "conv_tm: fused statistics need G | Cout, G <= 8 (Cout=%d G=%d)", in.Cout, r.G);
+    AFTER_REQUIRE((size_t)r.Tp * p.Cp < (1u << 28) && (size_t)in.Cout * p.K < (1u << 28), AFTER_E_INVALID,
+                  "conv_tm: operand too large for 32-bit DMA offsets");
+    const bool dil = in.taps > 1 && p.dil != 1;
+    if (g_tm_force < 0) {
+        const char* e = getenv("AFTER_CONV_TM_TILE");
+        g_tm_force = e ? atoi(e) : 0;
+    }
+    const int N = in.Cout, K = p.K;
+    const long long ny = (long long)r.B * in.phases;
+    if (g_tm_force > 0) {
+        static const int ksof[] = {0, 1, 1, 1, 2, 4, 2, 2, 2, 2, 1, 2};
+        AFTER_REQUIRE(g_tm_force <= 11 && K % (32 * ksof[g_tm_force]) == 0, AFTER_E_INVALID,
+                      "conv_tm: tile %d needs K %% %d == 0 (K=%d)", g_tm_force, 32 * ksof[g_tm_force > 11 ? 0 : g_tm_force], K);
+        return launch_tm_id(g_tm_force, a, r.B, dil, s);
+    }
+    // Tile choice by a small cost model fitted to the per-layer sweeps (scripts/bench_conv.py,
+    // profiles/r2_bench_conv_*.jsonl): a launch costs the longest per-CU chain of MFMAs -- workgroups
+    // per CU (ceil: 528 workgroups on 256 CUs run as 3 rounds, which is why 48 x 32 tiles lost 35 % to
+    // 32 x 96 ones on the 768-channel stage) x waves sharing a SIMD x MFMAs per wave -- plus a per-round
+    // fixed cost, plus the L2 -> LDS operand traffic of the tile shape (bytes per flop).
+    struct Cand {
+        int id, mb, nb, ks, rs;
+    };
+    static const Cand cands[] = {{1, 4, 3, 1, 2}, {2, 4, 2, 1, 2}, {3, 4, 1, 1, 2}, {6, 2, 3, 2, 1},
+                                 {9, 2, 2, 2, 1}, {4, 3, 1, 2, 1}, {5, 3, 1, 4, 1}};
+    int best = 0;
+    double best_cost = 0;
+    for (const Cand& c : cands) {
+        if (K % (32 * c.ks)) continue;
+        const int bm = 16 * c.mb, bn = 32 * c.nb;
+        if (bn > 32 && N <= bn - 32) continue;  // a tile wider than the layer wastes whole column blocks
+        const double wgs = (double)cdiv(r.Nn, bm) * cdiv(N, bn) * (double)ny;
+        const double rounds = wgs <= 256 ? 1.0 : (wgs < 2048 ? (double)cdivll((long long)wgs, 256) : wgs / 256.0);
+        const int waves = 2 * c.ks * c.rs;
+        const double per_wave = (double)(c.mb / c.rs) * c.nb * (K / c.ks) / 4.0;  // MFMAs
+        // waves resident per SIMD: with 3 or more a wave's DMA / barrier / fragment-read stalls hide
+        // behind its neighbours' MFMAs (64 x 32 tiles beat 64 x 96 ones by 5-8 % at one clip)
+        double wps = wgs * waves / 1024.0;
+        wps = wps < 1 ? 1 : (wps > 4 ? 4 : wps);
+        const double mfma = rounds * (waves / 4.0) * per_wave * 32.0 * (1.0 + 0.15 / wps);  // cycles
+        const double fixed = rounds * 2500.0;
+        const double bytes_per_flop = (bm + bn) * 4.0 / (2.0 * bm * bn);
+        const double traffic = 2.0 * r.Nn * (double)N * K * ny * bytes_per_flop / (256.0 * 40.0);  // ~40 B/clk/CU
+        const double cost = (mfma > traffic ? mfma : traffic) + fixed + 0.25 * (mfma < traffic ? mfma : traffic);
+        if (!best || cost < best_cost) {
+            best = c.id;
+            best_cost = cost;
+        }
+    }
+    AFTER_REQUIRE(best, AFTER_E_INVALID, "conv_tm: no tile configuration for K=%d", K);
+    return launch_tm_id(best, a, r.B, dil, s);
+}
+
+}  // namespace after
+
+// ---------------------------------------------------------------------------------------------
+// Diagnostic / unit-test entry points (not on the reference's surface): one Conv1d layer on the
+// time-major path -- act(x) into the haloed buffer, then the conv GEMM -- callable on its own for
+// parity tests against a plain fp32 conv and for the per-layer tile sweeps of scripts/bench_conv.py.
+struct after_convtm {
+    after::ConvDmaPlanIn in;
+    after::ConvTmPlan plan;
+    after::Arena ar;
+    float *w = nullptr, *bias = nullptr, *xp = nullptr, *xtm = nullptr, *ytm = nullptr, *res = nullptr;
+    double* stats = nullptr;
+    int B, Cin, Cout, T, Tout, act;
+};
+
+extern "C" void after_convtm_destroy(after_convtm* h) {
+    if (!h) return;
+    h->ar.release();
+    delete h;
+}
+
+extern "C" void after_convtm_set_tile(int id) { after::g_tm_force = id; }
+
+// w: [Cout, Cin, k] (torch Conv1d layout), bias [Cout] or null.  Output length
+// Tout = (T + pad_l + pad_r - (k-1) dil - 1) / stride + 1 with pad_r implied by Tout_hint.
+extern "C" int after_convtm_create(const float* w, const float* bias, int B, int Cin, int Cout, int T, int Tout,
+                                   int k, int dil, int stride, int left_pad, int act, after_convtm** out) {
+    using namespace after;
+    AFTER_REQUIRE(w && out && B > 0 && k >= 1 && k <= kMaxTaps, AFTER_E_INVALID, "convtm: bad argument");
+    *out = nullptr;
+    after_convtm* h = new (std::nothrow) after_convtm();
+    AFTER_REQUIRE(h, AFTER_E_NOMEM, "out of host memory");
+    memset(&h->in, 0, sizeof(h->in));
+    h->in.Cin = Cin;
+    h->in.Cout = Cout;
+    h->in.taps = k;
+    h->in.phases = 1;
+    h->in.istride = stride;
+    h->in.ostride = 1;
+    for (int t = 0; t < k; ++t) h->in.toff[0][t] = t * dil - left_pad;
+    conv_tm_plan(h->in, &h->plan);
+    h->B = B;
+    h->Cin = Cin;
+    h->Cout = Cout;
+    h->T = T;
+    h->Tout = Tout;
+    h->act = act;
+    const size_t xpn = (size_t)B * conv_tm_rows(T) * h->plan.Cp, yn = (size_t)B * Tout * Cout;
+    const size_t packed = (size_t)Cout * k * pad16(Cin);
+    int rc = h->ar.init((h->plan.w_floats + packed + Cout + xpn + (size_t)B * T * Cin + 2 * yn) * sizeof(float) +
+                        (size_t)conv_tm_stat_sub() * B * 16 * sizeof(double) + (1 << 16));
+    auto fail = [&](int code) {
+        after_convtm_destroy(h);
+        return code;
+    };
+    if (rc != AFTER_OK) return fail(rc);
+    float* pk = h->ar.take<float>(packed);
+    h->w = h->ar.take<float>(h->plan.w_floats);
+    h->bias = h->ar.take<float>(Cout);
+    h->xp = h->ar.take<float>(xpn);
+    h->xtm = h->ar.take<float>((size_t)B * T * Cin);
+    h->ytm = h->ar.take<float>(yn);
+    h->res = h->ar.take<float>(yn);
+    h->stats = h->ar.take<double>((size_t)conv_tm_stat_sub() * B * 16);
+    if (!h->stats || !h->plan.ok) {
+        set_error("convtm: allocation failed or unsupported tap pattern");
+        return fail(AFTER_E_INVALID);
+    }
+    if ((rc = pack_conv_weight(w, nullptr, pk, Cout, Cin, k, pad16(Cin), 0)) != AFTER_OK) return fail(rc);
+    if ((rc = conv_tm_repack(pk, h->w, h->in, h->plan, 0)) != AFTER_OK) return fail(rc);
+    if (bias) (void)hipMemcpy(h->bias, bias, Cout * sizeof(float), hipMemcpyDeviceToDevice);
+    else (void)hipMemset(h->bias, 0, Cout * sizeof(float));
+    (void)hipMemset(h->res, 0, yn * sizeof(float));
+    (void)hipMemset(h->xtm, 0, (size_t)B * T * Cin * sizeof(float));
+    if (hipDeviceSynchronize() != hipSuccess) return fail(AFTER_E_HIP);
+    *out = h;
+    return AFTER_OK;
+}
+
+// mode bit 0: act_pad (x: [B][Cin][T] when given, else the handle's time-major scratch);
+// bit 1: conv (y: [B][Cout][Tout] when given, else time-major into the handle's scratch);
+// bit 2: accumulate GroupNorm statistics in the conv epilogue; bit 3: add a (zero) residual.
+extern "C" int after_convtm_run(after_convtm* h, const float* x, float* y, int mode, void* stream) {
+    using namespace after;
+    AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
+    hipStream_t s = (hipStream_t)stream;
+    if (mode & 1) {
+        ActPadTm p;
+        memset(&p, 0, sizeof(p));
+        p.x = x ? x : h->xtm;
+        p.y = h->xp;
+        p.act = h->act;
+        p.B = h->B;
+        p.C = h->Cin;
+        p.T = h->T;
+        p.G = h->Cin < 8 ? h->Cin : 8;
+        p.x_cm = x ? 1 : 0;
+        AFTER_TRY(launch_act_pad_tm(p, s));
+    }
+    if (mode & 2) {
+        ConvTmRun r;
+        memset(&r, 0, sizeof(r));
+        r.xp = h->xp;
+        r.w = h->w;
+        r.bias = h->bias;
+        r.res = (mode & 8) ? h->res : nullptr;
+        r.y = y ? y : h->ytm;
+        r.y_cm = y ? 1 : 0;
+        r.B = h->B;
+        r.Tp = conv_tm_rows(h->T);
+        r.Tout = h->Tout;
+        r.Nn = h->Tout;
+        r.G = h->Cout < 8 ? h->Cout : 8;
+        r.sub_stride = h->B * 16;
+        if ((mode & 4) && h->Cout % r.G == 0) {
+            AFTER_HIP_CHECK(hipMemsetAsync(h->stats, 0, (size_t)conv_tm_stat_sub() * h->B * 16 * sizeof(double), s));
+            r.stats = h->stats;
+        }
+        AFTER_TRY(launch_conv_tm(r, h->in, h->plan, s));
+    }
+    return AFTER_OK;
+}
+

@@ -318,6 +318,21 @@ int after_gemm_f32(const float* A, int lda, const float* W, int ldw, const float
                    const float* R, int ldr, float* C, int ldc, int M, int N, int K, int epilogue,
                    int force_mt, int force_nt, void* stream);
 
+/* One Conv1d layer on the time-major conv path (act(x) into the zero-haloed [B][T][C] buffer, then
+ * the conv as a balanced LDS-DMA GEMM) for parity tests against a plain fp32 conv and for the
+ * per-layer tile sweeps (scripts/bench_conv.py).  w [Cout, Cin, k] (torch.nn.Conv1d layout),
+ * y[b, co, n] = bias[co] + sum_{t, ci} w[co, ci, t] act(x)[b, ci, n*stride + t*dil - left_pad] (0 outside).
+ * act: 0 none, 1 snake(alpha = beta = 1), 2 SiLU, 3 ReLU, 4 tanh.
+ * run mode bits: 1 activate + halo (x [B][Cin][T] or NULL = internal buffer), 2 conv (y [B][Cout][Tout]
+ * or NULL = internal time-major buffer), 4 fused GroupNorm statistics, 8 residual add. */
+typedef struct after_convtm after_convtm;
+int after_convtm_create(const float* w, const float* bias, int B, int Cin, int Cout, int T, int Tout,
+                        int k, int dil, int stride, int left_pad, int act, after_convtm** out);
+int after_convtm_run(after_convtm* h, const float* x, float* y, int mode, void* stream);
+void after_convtm_destroy(after_convtm* h);
+/* 0 = heuristic; 1..11 pin a tile configuration (conv_tm.hip: launch_tm_id) */
+void after_convtm_set_tile(int id);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,76 @@
+"""The time-major conv path (conv_tm.hip: activate + halo, then the conv as a balanced LDS-DMA GEMM)
+against a plain fp64 torch conv1d of the same layer, through the C ABI (after_convtm_*).  -m gpu.
+
+Covers what the codec / encoders ask of it: k = 1 / 3 / 5 / 8, dilation 1 / 3 / 9, stride 1 / 2 / 4,
+centred and causal padding, ragged channel counts (K padding to the 32-deep slab, N tails), ragged
+lengths, every tile configuration (row-split, 2- and 4-way split-K), fused statistics and residual."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from after_amd import diag
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def ref_conv(x, w, b, dil, stride, lp, rp, act):
+    x = x.double()
+    if act == 2:
+        x = F.silu(x)
+    elif act == 3:
+        x = F.relu(x)
+    y = F.conv1d(F.pad(x, (lp, rp)), w.double(), b.double() if b is not None else None, stride=stride, dilation=dil)
+    return y
+
+
+CASES = [
+    # B, Cin, Cout, T, k, dil, stride, lp, rp, act
+    (1, 64, 64, 256, 3, 1, 1, 1, 1, 0),
+    (2, 96, 192, 300, 3, 3, 1, 3, 3, 2),
+    (1, 128, 96, 1000, 3, 9, 1, 9, 9, 0),
+    (2, 64, 32, 515, 3, 9, 1, 18, 0, 2),     # causal dilated
+    (1, 16, 64, 2048, 3, 1, 1, 1, 1, 0),     # Cin below one K slab (PQMF bands -> stem)
+    (3, 64, 12, 256, 5, 1, 1, 4, 0, 2),      # Encoder1D: causal k = 5, narrow output
+    (1, 128, 256, 1024, 4, 1, 2, 1, 2, 0),   # Downsample1d f = 2: pad (1, 2)
+    (2, 64, 128, 2048, 8, 1, 4, 3, 4, 0),    # Downsample1d f = 4: pad (3, 4)
+    (1, 384, 384, 512, 1, 1, 1, 0, 0, 0),    # 1 x 1
+    (1, 768, 768, 256, 3, 1, 1, 1, 1, 0),    # small T, long K -> split-K
+    (1, 40, 72, 130, 3, 1, 1, 1, 1, 3),      # ragged everything
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_tm_matches_torch(case, hip_device):
+    B, Cin, Cout, T, k, dil, stride, lp, rp, act = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, k, generator=g) / (Cin * k) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    want = ref_conv(x, w, b, dil, stride, lp, rp, act)
+    c = diag.ConvTm(w.to(hip_device), b.to(hip_device), B, T, dil, stride, lp, rp, act)
+    assert c.Tout == want.shape[-1]
+    got = c(x.to(hip_device)).cpu().double()
+    assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+    got2 = c(x.to(hip_device), stats=Cout % min(Cout, 8) == 0, residual=True).cpu().double()
+    assert (got2 - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("tile", list(range(1, 12)))
+def test_conv_tm_every_tile_configuration(tile, hip_device):
+    """All tile configurations give the same result on a shape every one of them accepts
+    (K = 3 * 128 = 384: multiple of 128), with a dilated and an undilated conv."""
+    g = torch.Generator().manual_seed(tile)
+    B, Cin, Cout, T = 2, 128, 200, 777
+    x = torch.randn(B, Cin, T, generator=g)
+    try:
+        diag.set_conv_tile(tile)
+        for dil in (1, 3):
+            w = torch.randn(Cout, Cin, 3, generator=g) / (Cin * 3) ** 0.5
+            b = torch.randn(Cout, generator=g)
+            want = ref_conv(x, w, b, dil, 1, dil, dil, 0)
+            c = diag.ConvTm(w.to(hip_device), b.to(hip_device), B, T, dil, 1, dil, dil, 0)
+            got = c(x.to(hip_device), stats=True).cpu().double()
+            assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item()), (tile, dil)
+    finally:
+        diag.set_conv_tile(0)
