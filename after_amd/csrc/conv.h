@@ -135,6 +135,20 @@ struct ConvTmRun {
     const float* post_scale;  // y = out_act(acc + bias) * post_scale[b * post_bstride + co] + post_shift[...]
     const float* post_shift;
     int post_bstride, out_act;
+    int bias_bstride;         // 0: bias[Cout] shared; else bias[b * bias_bstride + co]
+    // optional strides (0 = dense defaults): channel-sliced views of wider time-major tensors.
+    // x_ld: row pitch of xp (an un-haloed tensor can serve a k = 1 conv as xp = t - halo * x_ld, Tp = T)
+    int x_ld, y_ld, y_coff, res_ld, res_coff, res_cm;
+    long long x_bs, y_bs, res_bs;
+    // optional second output: the next conv's activated + haloed input (see conv_tm.hip)
+    float* y2;
+    const float* y2_scale;
+    const float* y2_shift;
+    const float* y2_pa;
+    const float* y2_pb;
+    const float* y2_add;
+    long long y2_bs, y2_add_bs;
+    int y2_ld, y2_coff, y2_clo, y2_chi, y2_act, y2_add_ld, y2_add_coff, y2_reflect;
 };
 struct ActPadTm {
     const float* x;       // [B][T][ldx] time-major ([B][C][T] when x_cm)

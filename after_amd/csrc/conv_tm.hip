@@ -73,63 +73,24 @@ struct ActTmArgs {
 };
 
 // One thread = one 4-channel quad; a block walks `rows_per_block` consecutive rows of the
-// padded buffer (the quad's parameters stay in registers).
+// padded buffer, U rows in flight per thread.  Everything the kernel needs -- the first rows, the
+// per-channel parameters, the statistics sub-slots -- is requested up front so that the block pays
+// ONE exposed memory latency (these launches are 6-25 MB: latency, not bandwidth, is the cost).
 __global__ __launch_bounds__(256) void act_pad_tm_kernel(ActTmArgs a) {
     const int Q = a.Cp >> 2;
     const int R = 256 / Q;  // rows per pass (Q <= 256)
     const int r = threadIdx.x / Q, q = threadIdx.x - r * Q;
     const int b = blockIdx.y, c0 = 4 * q;
-    // GroupNorm statistics -> (mean, rstd) per group: one lane per group adds the sub-slots (fixed
-    // order) and does the fp64 arithmetic once per block instead of once per thread and channel
+    const bool active = r < R;
     __shared__ float gmean[8], grstd[8];
-    if (a.stats) {
-        if (threadIdx.x < a.G) {
-            const int gI = threadIdx.x;
-            const double n = (double)(a.C / a.G) * a.T;
-            double s = 0, qq = 0;
-            for (int u = 0; u < kStatSub; ++u) {
-                s += a.stats[(size_t)u * a.sub_stride + ((size_t)b * a.G + gI) * 2];
-                qq += a.stats[(size_t)u * a.sub_stride + ((size_t)b * a.G + gI) * 2 + 1];
-            }
-            const double mean = s / n;
-            double var = qq / n - mean * mean;
-            var = var < 0 ? 0 : var;
-            gmean[gI] = (float)mean;
-            grstd[gI] = (float)(1.0 / sqrt(var + (double)a.eps));
-        }
-        __syncthreads();
-    }
-    if (r >= R) return;
-    float sc[4], sh[4], pa[4], pb[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = c0 + k;
-        sc[k] = 1.f;
-        sh[k] = 0.f;
-        pa[k] = pb[k] = 0.f;
-        if (c >= a.C) continue;
-        if (a.stats) {
-            const int g = c / (a.C / a.G);
-            sc[k] = grstd[g] * a.gamma[c];
-            sh[k] = a.beta[c] - gmean[g] * sc[k];
-        } else if (a.scale_b) {
-            sc[k] = a.scale_b[(size_t)b * a.C + c];
-            sh[k] = a.shift_b[(size_t)b * a.C + c];
-        } else if (a.gamma) {
-            sc[k] = a.gamma[c];
-            sh[k] = a.beta[c];
-        }
-        if (a.act_a) pa[k] = a.act_a[c];
-        if (a.act_b) pb[k] = a.act_b[c];
-    }
+    constexpr int U = 4;
     const int p_lo = blockIdx.x * a.rows_per_block;
     const int p_hi = min(p_lo + a.rows_per_block, a.Tp);
     float* yb = a.y + (size_t)b * a.Tp * a.Cp;
-    constexpr int U = 4;  // rows in flight per thread: all loads are requested before the first use
     const bool vec = !a.x_cm && c0 + 3 < a.C;
-    for (int pb0 = p_lo + r; pb0 < p_hi; pb0 += U * R) {
-        f32x4 v[U];
-        int tt[U];
+    f32x4 v[U];
+    int tt[U];
+    auto load_rows = [&](int pb0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int p = pb0 + u * R;
@@ -153,17 +114,84 @@ __global__ __launch_bounds__(256) void act_pad_tm_kernel(ActTmArgs a) {
                 v[u] = *reinterpret_cast<const f32x4*>(a.state + ((size_t)b * HALO + (HALO + t)) * a.Cp + c0);
             }
         }
+    };
+    if (active) load_rows(p_lo + r);
+    // raw per-channel parameters (independent of the statistics)
+    float ga[4], be[4], pa[4], pb[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + k;
+        ga[k] = 1.f;
+        be[k] = 0.f;
+        pa[k] = pb[k] = 0.f;
+        if (!active || c >= a.C) continue;
+        if (a.scale_b && !a.stats) {
+            ga[k] = a.scale_b[(size_t)b * a.C + c];
+            be[k] = a.shift_b[(size_t)b * a.C + c];
+        } else if (a.gamma) {
+            ga[k] = a.gamma[c];
+            be[k] = a.beta[c];
+        }
+        if (a.act_a) pa[k] = a.act_a[c];
+        if (a.act_b) pb[k] = a.act_b[c];
+    }
+    // GroupNorm statistics -> (mean, rstd) per group: one lane per group adds the sub-slots (fixed
+    // order) and does the fp64 arithmetic once per block
+    if (a.stats) {
+        if (threadIdx.x < a.G) {
+            const int gI = threadIdx.x;
+            const double n = (double)(a.C / a.G) * a.T;
+            double sv[kStatSub], qv[kStatSub];
+#pragma unroll
+            for (int u = 0; u < kStatSub; ++u) {
+                sv[u] = a.stats[(size_t)u * a.sub_stride + ((size_t)b * a.G + gI) * 2];
+                qv[u] = a.stats[(size_t)u * a.sub_stride + ((size_t)b * a.G + gI) * 2 + 1];
+            }
+            double s = 0, qq = 0;
+#pragma unroll
+            for (int u = 0; u < kStatSub; ++u) {
+                s += sv[u];
+                qq += qv[u];
+            }
+            const double mean = s / n;
+            double var = qq / n - mean * mean;
+            var = var < 0 ? 0 : var;
+            gmean[gI] = (float)mean;
+            grstd[gI] = (float)(1.0 / sqrt(var + (double)a.eps));
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+    float sc[4], sh[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sc[k] = ga[k];
+        sh[k] = be[k];
+        if (a.stats && c0 + k < a.C) {
+            const int g = (c0 + k) / (a.C / a.G);
+            sc[k] = grstd[g] * ga[k];
+            sh[k] = be[k] - gmean[g] * sc[k];
+        }
+    }
+    for (int pb0 = p_lo + r; pb0 < p_hi; pb0 += U * R) {
+        f32x4 o[U];
+        int to[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            o[u] = v[u];
+            to[u] = tt[u];
+        }
+        if (pb0 + U * R < p_hi) load_rows(pb0 + U * R);  // next rows in flight behind this batch's math
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int p = pb0 + u * R;
             if (p >= p_hi) continue;
-            f32x4 o = v[u];
-            if (tt[u] >= 0 && tt[u] < a.T) {
+            if (to[u] >= 0 && to[u] < a.T) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    o[k] = c0 + k < a.C ? act_apply(o[k] * sc[k] + sh[k], a.act, pa[k], pb[k]) : 0.f;
+                    o[u][k] = c0 + k < a.C ? act_apply(o[u][k] * sc[k] + sh[k], a.act, pa[k], pb[k]) : 0.f;
             }
-            *reinterpret_cast<f32x4*>(yb + (size_t)p * a.Cp + c0) = o;
+            *reinterpret_cast<f32x4*>(yb + (size_t)p * a.Cp + c0) = o[u];
         }
     }
 }
@@ -197,7 +225,22 @@ struct ConvTmArgs {
     // post-activation epilogue of the TDNN / FiLM layers: y = out_act(acc + bias) * post_scale + post_shift
     const float* post_scale;
     const float* post_shift;
-    int out_act, post_bstride;
+    int out_act, post_bstride, bias_bstride;
+    // generalised addressing (channel-sliced views of wider tensors, the reference's [B][C][T] at
+    // the API edges): element (b, row, col) of the input sits at xp[b * x_bs + row * x_ld + col]
+    long long x_bs, y_bs, res_bs;
+    int x_ld, y_ld, y_coff, res_ld, res_coff, res_cm;
+    // second output: the NEXT conv's activated, haloed input written by this epilogue (no act_pad
+    // launch in between) -- y2[b][HALO + row][y2_coff + col - y2_clo] = act2((v + add) * sc + sh) for
+    // the output channels col in [y2_clo, y2_chi).  Halo: zeros, or mirrored rows (TDNN 'reflect').
+    float* y2;
+    const float* y2_scale;  // [Cout] or nullptr
+    const float* y2_shift;
+    const float* y2_pa;     // snake alpha / 1 / (beta + eps), indexed by output channel
+    const float* y2_pb;
+    const float* y2_add;    // [B][Tout][y2_add_ld] tensor whose columns y2_add_coff + (col - y2_clo) are added first
+    long long y2_bs, y2_add_bs;
+    int y2_ld, y2_coff, y2_clo, y2_chi, y2_act, y2_add_ld, y2_add_coff, y2_reflect, y2_zero_halo, tiles_m_last;
 };
 
 template <int MB, int NB, int KS, int NS, int RS, bool DIL>
@@ -250,7 +293,7 @@ __global__ __launch_bounds__(128 * KS * RS) void conv_tm_kernel(ConvTmArgs g, in
 
     // ---- DMA addressing: wave-uniform 64-bit base + per-lane 32-bit byte offset (+ a scalar
     // slab offset).  A pieces: slab S = half * nk + s of the flattened (tap, channel) axis.
-    const float* xb = g.xp + (size_t)b * g.Tp * g.Cp + g.abase[ph];
+    const float* xb = g.xp + (size_t)b * g.x_bs + g.abase[ph];
     const float* wb = g.w + (size_t)ph * g.Cout * g.K;
     const int rsub = lane / CPR, pos = lane % CPR;
     unsigned voff[LPS];
@@ -363,20 +406,34 @@ __global__ __launch_bounds__(128 * KS * RS) void conv_tm_kernel(ConvTmArgs g, in
     const int Cg = g.stats ? g.Cout / g.G : 1;
     const int g0 = n0 / Cg;
     const bool quad = (Cg & 3) == 0;  // a lane's four channels sit in one group (every shipped width)
-    float* yb = g.y + (size_t)b * g.Tout * g.Cout;
-    const float* rb = g.res ? g.res + (size_t)b * g.Tout * g.Cout : nullptr;
-    const bool vec_ok = (g.Cout & 3) == 0 && !g.y_cm;
+    float* yb = g.y ? g.y + (size_t)b * g.y_bs + g.y_coff : nullptr;
+    const float* rb = g.res ? g.res + (size_t)b * g.res_bs + g.res_coff : nullptr;
+    float* y2b = g.y2 ? g.y2 + (size_t)b * g.y2_bs + g.y2_coff : nullptr;
+    const float* a2b = g.y2_add ? g.y2_add + (size_t)b * g.y2_add_bs + g.y2_add_coff : nullptr;
+    const bool vec_ok = !g.y_cm && !g.res_cm && ((g.y_ld | g.y_coff) & 3) == 0 &&
+                        (!g.res || ((g.res_ld | g.res_coff) & 3) == 0);
+    const bool vec2_ok = ((g.y2_ld | g.y2_coff | g.y2_clo | g.y2_add_ld | g.y2_add_coff) & 3) == 0;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int gn = n0 + part * 16 * NB + j * 16 + ccol0;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f}, ps = {1.f, 1.f, 1.f, 1.f}, pt = {0.f, 0.f, 0.f, 0.f};
+        f32x4 s2 = {1.f, 1.f, 1.f, 1.f}, t2 = {0.f, 0.f, 0.f, 0.f}, pa2 = t2, pb2 = t2;
+        const bool in2 = y2b && gn >= g.y2_clo && gn < g.y2_chi;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (gn + r < N) {
-                if (g.bias) bv[r] = g.bias[gn + r];
+                if (g.bias) bv[r] = g.bias[(size_t)b * g.bias_bstride + gn + r];
                 if (g.post_scale) {
                     ps[r] = g.post_scale[(size_t)b * g.post_bstride + gn + r];
                     pt[r] = g.post_shift[(size_t)b * g.post_bstride + gn + r];
+                }
+                if (in2) {
+                    if (g.y2_scale) {
+                        s2[r] = g.y2_scale[gn + r];
+                        t2[r] = g.y2_shift[gn + r];
+                    }
+                    if (g.y2_pa) pa2[r] = g.y2_pa[gn + r];
+                    if (g.y2_pb) pb2[r] = g.y2_pb[gn + r];
                 }
             }
         float ssum = 0.f, qsum = 0.f;
@@ -407,38 +464,76 @@ __global__ __launch_bounds__(128 * KS * RS) void conv_tm_kernel(ConvTmArgs g, in
             if (g.post_scale) o = o * ps + pt;
             const int trow = gm * g.ostride + g.ooff[ph];
             if (trow >= g.Tout) continue;
-            const size_t off = (size_t)trow * g.Cout + gn;
-            if (vec_ok && gn + 3 < N) {
-                if (rb) o += *reinterpret_cast<const f32x4*>(rb + off);
-                *reinterpret_cast<f32x4*>(yb + off) = o;
-                if (quad) {
-                    ssum += (o[0] + o[1]) + (o[2] + o[3]);
-                    qsum += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
-                } else if (g.stats) {  // narrow test configurations: one LDS atomic per element
+            const bool full4 = gn + 3 < N;
+            // residual
+            if (rb) {
+                if (vec_ok && full4) {
+                    o += *reinterpret_cast<const f32x4*>(rb + (size_t)trow * g.res_ld + gn);
+                } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int gl = (gn + r) / Cg - g0;
-                        atomicAdd(&gs[gl & 15], o[r]);
-                        atomicAdd(&gs[16 + (gl & 15)], o[r] * o[r]);
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        if (gn + r < N)
+                            o[r] += g.res_cm ? rb[(size_t)(gn + r) * g.Tout + trow] : rb[(size_t)trow * g.res_ld + gn + r];
                 }
-            } else {
+            }
+            // primary output
+            if (yb) {
+                if (vec_ok && full4) {
+                    *reinterpret_cast<f32x4*>(yb + (size_t)trow * g.y_ld + gn) = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (gn + r < N) {
+                            if (g.y_cm) yb[(size_t)(gn + r) * g.Tout + trow] = o[r];
+                            else yb[(size_t)trow * g.y_ld + gn + r] = o[r];
+                        }
+                }
+            }
+            // statistics of the primary output
+            if (g.stats) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (gn + r < N) {
-                        float v = o[r];
-                        if (rb) v += rb[off + r];
-                        if (g.y_cm) yb[(size_t)(gn + r) * g.Tout + trow] = v;
-                        else yb[off + r] = v;
                         if (quad) {
-                            ssum += v;
-                            qsum += v * v;
-                        } else if (g.stats) {
+                            ssum += o[r];
+                            qsum += o[r] * o[r];
+                        } else {  // narrow test configurations: one LDS atomic per element
                             const int gl = (gn + r) / Cg - g0;
-                            atomicAdd(&gs[gl & 15], v);
-                            atomicAdd(&gs[16 + (gl & 15)], v * v);
+                            atomicAdd(&gs[gl & 15], o[r]);
+                            atomicAdd(&gs[16 + (gl & 15)], o[r] * o[r]);
                         }
                     }
+            }
+            // the next conv's activated, haloed input
+            if (in2) {
+                f32x4 v2 = o;
+                const int c2 = gn - g.y2_clo;
+                if (a2b) {
+                    if (vec2_ok && full4) v2 += *reinterpret_cast<const f32x4*>(a2b + (size_t)trow * g.y2_add_ld + c2);
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (gn + r < g.y2_chi) v2[r] += a2b[(size_t)trow * g.y2_add_ld + c2 + r];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v2[r] = act_apply(v2[r] * s2[r] + t2[r], g.y2_act, pa2[r], pb2[r]);
+                int rows[3] = {trow, -1, -1};
+                if (g.y2_reflect) {  // mirrored halo rows (no edge repeat): -j <- j, T-1+j <- T-1-j
+                    if (trow >= 1 && trow <= g.y2_reflect) rows[1] = -trow;
+                    if (trow <= g.Tout - 2 && trow >= g.Tout - 1 - g.y2_reflect) rows[2] = 2 * (g.Tout - 1) - trow;
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    if (q && rows[q] == -1) continue;
+                    float* dp = y2b + (size_t)(HALO + rows[q]) * g.y2_ld + c2;
+                    if (vec2_ok && gn + 3 < g.y2_chi) *reinterpret_cast<f32x4*>(dp) = v2;
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (gn + r < g.y2_chi) dp[r] = v2[r];
+                    }
+                }
             }
         }
         if (g.stats && quad) {
@@ -452,6 +547,22 @@ __global__ __launch_bounds__(128 * KS * RS) void conv_tm_kernel(ConvTmArgs g, in
                 const int gl = gn / Cg - g0;  // Cg % 4 == 0: the quad sits in one group
                 atomicAdd(&gs[gl & 15], ssum);
                 atomicAdd(&gs[16 + (gl & 15)], qsum);
+            }
+        }
+    }
+    // zero halo of the second output: first / last row tile of phase 0, each for its own columns
+    if (y2b && g.y2_zero_halo && ph == 0 && (tm == 0 || tm == g.tiles_m_last)) {
+        const int c_lo = max(n0, g.y2_clo), c_hi = min(min(n0 + BN, N), g.y2_chi);
+        const int w4 = (c_hi - c_lo) > 0 ? (c_hi - c_lo + 3) / 4 : 0;
+        for (int side = 0; side < 2; ++side) {
+            if ((side == 0 && tm != 0) || (side == 1 && tm != g.tiles_m_last)) continue;
+            const int row0 = side == 0 ? 0 : HALO + g.Tout;
+            for (int idx = tid; idx < HALO * w4; idx += 128 * KS * RS) {
+                const int rr = idx / w4, c = c_lo + 4 * (idx - rr * w4);
+                float* dp = y2b + (size_t)(row0 + rr) * g.y2_ld + (c - g.y2_clo);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c + r < c_hi) dp[r] = 0.f;
             }
         }
     }
@@ -534,6 +645,7 @@ int launch_tm_cfg(ConvTmArgs a, int B, bool dil, hipStream_t s) {
     }
     static_assert(size_t(NS) * KS * (BM + BN) * 32 * sizeof(float) <= 160 * 1024, "ring exceeds the LDS");
     const int nwg = tiles_m * tiles_n, ny = B * a.phases;
+    a.tiles_m_last = tiles_m - 1;
     // XCD grid pm x (8 / pm) over the tile matrix: an XCD fetches 1/pm of the input rows (each
     // Cp floats, shared by the taps) and 1/pn of the weights (K = taps * Cp floats per row)
     int pm = 0;
@@ -684,8 +796,40 @@ int launch_conv_tm(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan
     a.Tout = r.Tout;
     a.K = p.K;
     a.phases = in.phases;
-    a.lda = in.istride * p.Cp;
+    // row pitch / batch stride of the input (defaults: the dense haloed buffer of act_pad_tm)
+    a.x_ld = r.x_ld > 0 ? r.x_ld : p.Cp;
+    a.x_bs = r.x_bs > 0 ? r.x_bs : (long long)r.Tp * a.x_ld;
+    a.lda = in.istride * a.x_ld;
     a.ostride = in.ostride;
+    a.y_ld = r.y_ld > 0 ? r.y_ld : in.Cout;
+    a.y_coff = r.y_coff;
+    a.y_bs = r.y_bs > 0 ? r.y_bs : (long long)r.Tout * in.Cout;
+    a.res_ld = r.res_ld > 0 ? r.res_ld : in.Cout;
+    a.res_coff = r.res_coff;
+    a.res_cm = r.res_cm;
+    a.res_bs = r.res_bs > 0 ? r.res_bs : (long long)r.Tout * in.Cout;
+    a.bias_bstride = r.bias_bstride;
+    a.y2 = r.y2;
+    if (r.y2) {
+        a.y2_scale = r.y2_scale;
+        a.y2_shift = r.y2_shift;
+        a.y2_pa = r.y2_pa;
+        a.y2_pb = r.y2_pb;
+        a.y2_act = r.y2_act;
+        a.y2_clo = r.y2_clo;
+        a.y2_chi = r.y2_chi > 0 ? r.y2_chi : in.Cout;
+        a.y2_ld = r.y2_ld > 0 ? r.y2_ld : conv_tm_cp(a.y2_chi - a.y2_clo);
+        a.y2_coff = r.y2_coff;
+        a.y2_bs = r.y2_bs > 0 ? r.y2_bs : (long long)conv_tm_rows(r.Tout) * a.y2_ld;
+        a.y2_add = r.y2_add;
+        a.y2_add_ld = r.y2_add_ld;
+        a.y2_add_coff = r.y2_add_coff;
+        a.y2_add_bs = r.y2_add_bs > 0 ? r.y2_add_bs : (long long)r.Tout * r.y2_add_ld;
+        a.y2_reflect = r.y2_reflect;
+        a.y2_zero_halo = r.y2_reflect ? 0 : 1;
+        AFTER_REQUIRE(r.y2_reflect <= HALO && r.y2_reflect < r.Tout, AFTER_E_INVALID, "conv_tm: reflect pad too wide");
+        AFTER_REQUIRE(in.ostride == 1 || !r.y2_reflect, AFTER_E_INVALID, "conv_tm: reflect halo with phases");
+    }
     a.Nn = r.Nn;
     a.G = r.G;
     a.sub_stride = r.sub_stride;
@@ -696,16 +840,17 @@ int launch_conv_tm(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan
     a.out_act = r.out_act;
     const int npt = p.Cp / 32;
     a.magic = (65536 + npt - 1) / npt;  // exact for slab < 65536 / npt ... (taps * npt <= 8 * 32)
-    a.extra = (p.dil - 1) * p.Cp;
+    a.extra = p.dil * a.x_ld - p.Cp;  // slab S of tap t starts at S * 32 + t * (dil * x_ld - Cp)
     for (int ph = 0; ph < in.phases; ++ph) {
-        a.abase[ph] = (HALO + in.toff[ph][0]) * p.Cp;
+        a.abase[ph] = (HALO + in.toff[ph][0]) * a.x_ld;
         a.ooff[ph] = in.ooff[ph];
     }
     AFTER_REQUIRE(!r.stats || (in.Cout % r.G == 0 && r.G <= 8), AFTER_E_INVALID,
                   "conv_tm: fused statistics need G | Cout, G <= 8 (Cout=%d G=%d)", in.Cout, r.G);
-    AFTER_REQUIRE((size_t)r.Tp * p.Cp < (1u << 28) && (size_t)in.Cout * p.K < (1u << 28), AFTER_E_INVALID,
+    AFTER_REQUIRE((size_t)r.Tp * a.x_ld < (1u << 28) && (size_t)in.Cout * p.K < (1u << 28), AFTER_E_INVALID,
                   "conv_tm: operand too large for 32-bit DMA offsets");
-    const bool dil = in.taps > 1 && p.dil != 1;
+    AFTER_REQUIRE((a.x_ld & 3) == 0 && ((uintptr_t)r.xp & 15) == 0, AFTER_E_INVALID, "conv_tm: input row pitch / base alignment");
+    const bool dil = in.taps > 1 && a.extra != 0;
     if (g_tm_force < 0) {
         const char* e = getenv("AFTER_CONV_TM_TILE");
         g_tm_force = e ? atoi(e) : 0;
@@ -746,7 +891,8 @@ int launch_conv_tm(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan
         const double fixed = rounds * 2500.0;
         const double bytes_per_flop = (bm + bn) * 4.0 / (2.0 * bm * bn);
         const double traffic = 2.0 * r.Nn * (double)N * K * ny * bytes_per_flop / (256.0 * 40.0);  // ~40 B/clk/CU
-        const double cost = (mfma > traffic ? mfma : traffic) + fixed + 0.25 * (mfma < traffic ? mfma : traffic);
+        double cost = (mfma > traffic ? mfma : traffic) + fixed + 0.25 * (mfma < traffic ? mfma : traffic);
+        if (c.id == 1) cost *= 1.04;  // measured: 64 x 96 trails 64 x 64 by 1-4 % wherever both balance
         if (!best || cost < best_cost) {
             best = c.id;
             best_cost = cost;

@@ -161,14 +161,16 @@ size_t conv_floats(int cin, int cout, int k) { return (size_t)cout * k * pad16(c
 using namespace after;
 
 // =================================================================== Encoder1D
-// Every conv runs on the "activate once, convolve by LDS-DMA" path of conv_dma.hip:
-// BatchNorm(eval) + SiLU are applied once into a haloed scratch row, whose left halo is
-// either zeros (offline) or the previous chunk's tail (streaming, cached_conv semantics).
+// Time-major conv path (conv_tm.hip).  BatchNorm(eval) + SiLU have no data dependency on the whole
+// tensor, so OFFLINE every conv's epilogue writes the next conv's activated, haloed input itself
+// (ConvTmRun::y2): one act_pad launch for the network input, none in between.  STREAMING
+// (cached_conv semantics: the left halo is the previous chunk's tail) keeps one act_pad per conv,
+// which owns the state hand-over.
 struct EncConv {
     ConvW cw;
     ConvDmaPlanIn in;
-    ConvDmaPlan plan;
-    float* wd = nullptr;  // repacked for the DMA kernel
+    ConvTmPlan plan;
+    float* wd = nullptr;  // [Cout][taps * Cp] GEMM operand
 };
 struct V2Block {
     Affine bn0, bn1;
@@ -181,10 +183,10 @@ struct after_encoder1d {
     Arena wa, ws, sa;
     std::vector<V2Block> blocks;  // n + 1 (last = final V2ConvBlock1D)
     std::vector<EncConv> pools;   // n
-    float* buf[3] = {nullptr, nullptr, nullptr};
-    float* xp = nullptr;          // activated + haloed scratch
+    float* buf[3] = {nullptr, nullptr, nullptr};  // raw time-major activations [B][T][C]
+    float* xp[2] = {nullptr, nullptr};            // activated + haloed conv inputs
     size_t xp_elems = 0;
-    // streaming: one left-context slot [max_batch][cmax][halo] per temporal conv
+    // streaming: one left-context slot [max_batch][halo][Cp(cmax)] per temporal conv
     bool streaming = false;
     float* state = nullptr;
     size_t slot_elems = 0;
@@ -193,7 +195,7 @@ struct after_encoder1d {
 
 namespace {
 
-int plan_enc(Arena& a, EncConv& e, int stride, bool causal, int T_hint) {
+int plan_enc(Arena& a, EncConv& e, int stride, bool causal) {
     memset(&e.in, 0, sizeof(e.in));
     e.in.Cin = e.cw.cin;
     e.in.Cout = e.cw.cout;
@@ -203,12 +205,11 @@ int plan_enc(Arena& a, EncConv& e, int stride, bool causal, int T_hint) {
     e.in.ostride = 1;
     const int pl = conv_left_pad(e.cw.k, 1, causal);
     for (int t = 0; t < e.cw.k; ++t) e.in.toff[0][t] = t - pl;
-    e.in.Nn_hint = T_hint / stride;
-    e.in.B_hint = 1;
-    conv_dma_plan(e.in, &e.plan);
+    conv_tm_plan(e.in, &e.plan);
+    AFTER_REQUIRE(e.plan.ok, AFTER_E_INVALID, "encoder1d: tap pattern outside the conv path");
     e.wd = a.take<float>(e.plan.w_floats);
     AFTER_REQUIRE(e.wd, AFTER_E_NOMEM, "encoder1d: weight arena exhausted");
-    return conv_dma_repack(e.cw.w, e.wd, e.in, e.plan, 0);
+    return conv_tm_repack(e.cw.w, e.wd, e.in, e.plan, 0);
 }
 
 int load_v2(Arena& a, WCursor& c, V2Block& b, int ch, int k) {
@@ -218,37 +219,67 @@ int load_v2(Arena& a, WCursor& c, V2Block& b, int ch, int k) {
     return load_conv(a, c, b.c1.cw, ch, ch, k, true);
 }
 
-// act(affine(x)) -> haloed scratch (+ streaming left context), then the DMA conv
-int run_enc(after_encoder1d* h, hipStream_t s, const EncConv& e, const float* x, const Affine* bn,
-            int act, const float* res, float* y, int B, int Tin) {
-    const int cin = e.cw.cin;
-    AFTER_REQUIRE((size_t)B * cin * conv_dma_row(Tin) <= h->xp_elems, AFTER_E_CAPACITY,
+// what a conv's epilogue prepares for its consumer
+struct Next {
+    float* y2 = nullptr;       // haloed buffer to fill, or nullptr
+    const Affine* bn = nullptr;
+    int act = ACT_NONE;
+};
+
+// act(affine(x)) -> haloed scratch (+ streaming left context)
+int enc_act(after_encoder1d* h, hipStream_t s, const float* x, int x_cm, const Affine* bn, int act, int C,
+            int B, int T, float* dst, bool temporal) {
+    AFTER_REQUIRE((size_t)B * conv_tm_cp(C) * conv_tm_rows(T) <= h->xp_elems, AFTER_E_CAPACITY,
                   "encoder1d: activation scratch too small");
-    float* st = nullptr;
-    if (h->streaming && e.cw.k > 1) st = h->state + (size_t)(h->slot++) * h->slot_elems;
-    AFTER_TRY(launch_act_pad(x, h->xp, nullptr, bn ? bn->scale : nullptr, bn ? bn->shift : nullptr,
-                             nullptr, nullptr, act, B, cin, Tin, 1, s, st));
-    ConvDmaRun r;
-    r.xp = h->xp;
+    ActPadTm p;
+    memset(&p, 0, sizeof(p));
+    p.x = x;
+    p.y = dst;
+    p.gamma = bn ? bn->scale : nullptr;
+    p.beta = bn ? bn->shift : nullptr;
+    p.act = act;
+    p.B = B;
+    p.C = C;
+    p.T = T;
+    p.G = 1;
+    p.x_cm = x_cm;
+    if (h->streaming && temporal) p.state = h->state + (size_t)(h->slot++) * h->slot_elems;
+    return launch_act_pad_tm(p, s);
+}
+
+// one conv: src = haloed input (src_raw = 0) or a raw time-major tensor used in place (k = 1)
+int enc_conv(after_encoder1d* h, hipStream_t s, const EncConv& e, const float* src, bool src_raw,
+             const float* res, int res_cm, float* y, int y_cm, const Next& nx, int B, int Tin) {
+    ConvTmRun r;
+    memset(&r, 0, sizeof(r));
     r.w = e.wd;
     r.bias = e.cw.bias;
     r.res = res;
+    r.res_cm = res_cm;
     r.y = y;
-    r.stats = nullptr;
+    r.y_cm = y_cm;
     r.G = 1;
     r.B = B;
-    r.Tp = conv_dma_row(Tin);
     r.Tout = Tin / e.in.istride;
     r.Nn = r.Tout;
-    return launch_conv_dma(r, e.in, e.plan, s);
+    if (src_raw) {  // k = 1, stride 1, Cin % 32 == 0: row n of the raw tensor is "haloed row halo + n"
+        r.xp = src - (size_t)conv_tm_halo() * e.cw.cin;
+        r.Tp = Tin;
+        r.x_ld = e.cw.cin;
+    } else {
+        r.xp = src;
+        r.Tp = conv_tm_rows(Tin);
+    }
+    if (nx.y2) {
+        r.y2 = nx.y2;
+        r.y2_scale = nx.bn ? nx.bn->scale : nullptr;
+        r.y2_shift = nx.bn ? nx.bn->shift : nullptr;
+        r.y2_act = nx.act;
+    }
+    return launch_conv_tm(r, e.in, e.plan, s);
 }
 
-// V2ConvBlock1D (encoder.py:25-71): y = conv1(silu(bn1(conv0(silu(bn0(x)))))) + x
-int run_v2(after_encoder1d* h, const V2Block& b, hipStream_t s, const float* x, float* tmp, float* y,
-           int B, int T) {
-    AFTER_TRY(run_enc(h, s, b.c0, x, &b.bn0, ACT_SILU, nullptr, tmp, B, T));
-    return run_enc(h, s, b.c1, tmp, &b.bn1, ACT_SILU, x, y, B, T);
-}
+bool fusable(int C) { return (C & 31) == 0; }  // y2 rows are written without channel padding
 
 }  // namespace
 
@@ -284,18 +315,17 @@ extern "C" int after_encoder1d_create(const after_encoder1d_cfg* cfg, const floa
         wf += 2 * conv_floats(c, c, k) + 4 * (size_t)c + 1024;
     }
     h->cmax = cmax;
-    // packed weights + their DMA re-layout (rows padded to the tile, taps to the K chunk)
-    int rc = h->wa.init(wf * 4 * sizeof(float) + (4 << 20));
+    // packed weights + their GEMM re-layout (channels padded to the 32-deep K slab)
+    int rc = h->wa.init(wf * 5 * sizeof(float) + (4 << 20));
     if (rc) return fail(rc);
     WCursor cur{weights, n_weights};
     h->blocks.resize(n + 1);
     h->pools.resize(n);
     int c = cfg->in_size;
-    int T = max_T;
     for (int i = 0; i < n; ++i) {
         if ((rc = load_v2(h->wa, cur, h->blocks[i], c, k))) return fail(rc);
-        if ((rc = plan_enc(h->wa, h->blocks[i].c0, 1, causal, T))) return fail(rc);
-        if ((rc = plan_enc(h->wa, h->blocks[i].c1, 1, causal, T))) return fail(rc);
+        if ((rc = plan_enc(h->wa, h->blocks[i].c0, 1, causal))) return fail(rc);
+        if ((rc = plan_enc(h->wa, h->blocks[i].c1, 1, causal))) return fail(rc);
         const int r = cfg->ratios[i];
         if (r < 1 || 2 * r > kMaxTaps) {
             set_error("encoder1d: ratio %d unsupported", r);
@@ -303,23 +333,22 @@ extern "C" int after_encoder1d_create(const after_encoder1d_cfg* cfg, const floa
         }
         if ((rc = load_conv(h->wa, cur, h->pools[i].cw, c, cfg->channels[i], r == 1 ? 1 : 2 * r, true)))
             return fail(rc);
-        if ((rc = plan_enc(h->wa, h->pools[i], r, causal, T))) return fail(rc);
-        T = T / r > 0 ? T / r : 1;
+        if ((rc = plan_enc(h->wa, h->pools[i], r, causal))) return fail(rc);
         c = cfg->channels[i];
     }
     if ((rc = load_v2(h->wa, cur, h->blocks[n], c, k))) return fail(rc);
-    if ((rc = plan_enc(h->wa, h->blocks[n].c0, 1, causal, T))) return fail(rc);
-    if ((rc = plan_enc(h->wa, h->blocks[n].c1, 1, causal, T))) return fail(rc);
+    if ((rc = plan_enc(h->wa, h->blocks[n].c0, 1, causal))) return fail(rc);
+    if ((rc = plan_enc(h->wa, h->blocks[n].c1, 1, causal))) return fail(rc);
     if (!cur.ok || cur.i != n_weights) {
         set_error("encoder1d: expected %d weight tensors, got %d", cur.i, n_weights);
         return fail(AFTER_E_INVALID);
     }
     const size_t elems = (size_t)max_batch * cmax * max_T;
-    h->xp_elems = (size_t)max_batch * cmax * conv_dma_row(max_T) + 4096;
-    if ((rc = h->ws.init((3 * elems + h->xp_elems) * sizeof(float) + 8192))) return fail(rc);
+    h->xp_elems = (size_t)max_batch * conv_tm_cp(cmax) * conv_tm_rows(max_T) + 4096;
+    if ((rc = h->ws.init((3 * elems + 2 * h->xp_elems) * sizeof(float) + 16384))) return fail(rc);
     for (int i = 0; i < 3; ++i) h->buf[i] = h->ws.take<float>(elems);
-    h->xp = h->ws.take<float>(h->xp_elems);
-    if (!h->buf[2] || !h->xp) return fail(AFTER_E_NOMEM);
+    for (int i = 0; i < 2; ++i) h->xp[i] = h->ws.take<float>(h->xp_elems);
+    if (!h->buf[2] || !h->xp[1]) return fail(AFTER_E_NOMEM);
     if (hipDeviceSynchronize() != hipSuccess) return fail(AFTER_E_HIP);
     *out = h;
     return AFTER_OK;
@@ -346,7 +375,7 @@ extern "C" int after_encoder1d_enable_streaming(after_encoder1d* h, int enable) 
                   "encoder1d: streaming needs causal padding (base.gin:55)");
     if (!h->sa.base) {
         const int slots = 3 * h->cfg.n_blocks + 2;
-        h->slot_elems = (size_t)h->max_batch * h->cmax * conv_dma_halo();
+        h->slot_elems = (size_t)h->max_batch * conv_tm_cp(h->cmax) * conv_tm_halo();
         AFTER_TRY(h->sa.init(slots * h->slot_elems * sizeof(float) + 4096));
         h->state = h->sa.take<float>(slots * h->slot_elems);
         AFTER_REQUIRE(h->state, AFTER_E_NOMEM, "encoder1d: streaming state allocation failed");
@@ -372,22 +401,67 @@ extern "C" int after_encoder1d_forward(after_encoder1d* h, const float* z, float
     const after_encoder1d_cfg& c = h->cfg;
     const int n = c.n_blocks;
     h->slot = 0;
-    const float* cur = z;
-    float* const P[2] = {h->buf[0], h->buf[2]};
-    float* const Y = h->buf[1];
-    for (int i = 0; i < n; ++i) {
-        // V2EncoderBlock1D (encoder.py:74-113): conv block, then the (strided) "pool" conv
-        float* tmp = (cur == P[0]) ? P[1] : P[0];
-        AFTER_TRY(run_v2(h, h->blocks[i], s, cur, tmp, Y, B, T));
-        const int r = c.ratios[i];
+    // x: the block input, raw.  Block 0 reads the caller's [B][C][T] tensor in place (x_cm); later
+    // blocks read time-major buffers.  xa: x already activated + haloed by the producer's epilogue.
+    const float* x = z;
+    int x_cm = 1;
+    const float* xa = nullptr;
+    int ch = c.in_size;
+    float* const R[3] = {h->buf[0], h->buf[1], h->buf[2]};
+    int ri = 0;  // next free raw buffer (round robin: a block needs x, Y and the pool output alive)
+    for (int i = 0; i <= n; ++i) {
+        // V2ConvBlock1D (encoder.py:25-71): y = conv1(silu(bn1(conv0(silu(bn0(x)))))) + x
+        const V2Block& b = h->blocks[i];
+        const bool fuse = !h->streaming && fusable(ch);
+        if (!xa) {
+            AFTER_TRY(enc_act(h, s, x, x_cm, &b.bn0, ACT_SILU, ch, B, T, h->xp[0], true));
+            xa = h->xp[0];
+        }
+        const bool last = i == n;
+        const int r = last ? 1 : c.ratios[i];
+        float* Y = last ? out : R[ri++ % 3];
+        float* mid = (xa == h->xp[0]) ? h->xp[1] : h->xp[0];
+        if (fuse) {
+            Next nx;
+            nx.y2 = mid;
+            nx.bn = &b.bn1;
+            nx.act = ACT_SILU;
+            AFTER_TRY(enc_conv(h, s, b.c0, xa, false, nullptr, 0, nullptr, 0, nx, B, T));
+        } else {
+            float* t = R[ri % 3];  // scratch only until the act_pad below has consumed it
+            AFTER_TRY(enc_conv(h, s, b.c0, xa, false, nullptr, 0, t, 0, Next(), B, T));
+            AFTER_TRY(enc_act(h, s, t, 0, &b.bn1, ACT_SILU, ch, B, T, mid, true));
+        }
+        // the strided pool (r > 1) needs Y with a halo: let conv1's epilogue write that copy
+        float* pool_in = (xa == h->xp[0]) ? h->xp[0] : h->xp[1];  // xa's buffer: free once conv0 has run
+        Next n1;
+        if (!last && r > 1 && fuse) n1.y2 = pool_in;
+        AFTER_TRY(enc_conv(h, s, b.c1, mid, false, x, x_cm, Y, last ? 1 : 0, n1, B, T));
+        if (last) break;
+        // V2EncoderBlock1D (encoder.py:74-113): the (strided) "pool" conv c -> channels[i]
         AFTER_REQUIRE(T % r == 0, AFTER_E_INVALID, "encoder1d: T=%d not divisible by ratio %d", T, r);
-        AFTER_TRY(run_enc(h, s, h->pools[i], Y, nullptr, ACT_NONE, nullptr, tmp, B, T));
+        const int cn = c.channels[i];
+        float* X2 = R[ri++ % 3];
+        const V2Block& nb = h->blocks[i + 1];
+        Next nx;
+        const bool nfuse = !h->streaming && fusable(cn);
+        float* na = (pool_in == h->xp[0]) ? h->xp[1] : h->xp[0];
+        if (nfuse) {
+            nx.y2 = na;
+            nx.bn = &nb.bn0;
+            nx.act = ACT_SILU;
+        }
+        if (r == 1 && fusable(ch)) {
+            AFTER_TRY(enc_conv(h, s, h->pools[i], Y, true, nullptr, 0, X2, 0, nx, B, T));
+        } else {
+            if (!n1.y2) AFTER_TRY(enc_act(h, s, Y, 0, nullptr, ACT_NONE, ch, B, T, pool_in, r > 1));
+            AFTER_TRY(enc_conv(h, s, h->pools[i], pool_in, false, nullptr, 0, X2, 0, nx, B, T));
+        }
         T /= r;
-        cur = tmp;
-    }
-    {
-        float* tmp = (cur == P[0]) ? P[1] : P[0];
-        AFTER_TRY(run_v2(h, h->blocks[n], s, cur, tmp, out, B, T));
+        x = X2;
+        x_cm = 0;
+        xa = nfuse ? na : nullptr;
+        ch = cn;
     }
     if (c.use_tanh) {
         const int tot = B * c.channels[n - 1] * T;
