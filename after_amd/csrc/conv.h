@@ -162,6 +162,8 @@ struct ActPadTm {
     const float* scale_b; // per-(clip, channel) affine [B][C] (takes the place of gamma / beta), or nullptr
     const float* shift_b;
     int act, B, C, T, G, x_cm, ldx, pad_reflect, sub_stride;
+    const float* x2;      // optional second time-major input [B][T][ldx2], added to x before the affine
+    int ldx2;
 };
 int conv_tm_halo();
 int conv_tm_stat_sub();   // accumulator pairs per (clip, group): see conv_tm.hip

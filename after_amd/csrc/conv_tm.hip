@@ -68,6 +68,8 @@ struct ActTmArgs {
     const float* state;   // streaming: [B][HALO][Cp] activated rows preceding this chunk, or nullptr
     const float* scale_b; // optional per-(b, channel) affine [B][C] applied instead of gamma / beta
     const float* shift_b;
+    const float* x2;      // optional second time-major input added to x first (Res2Net: x_i + y_{i-1})
+    int ldx2;
     int act, C, Cp, T, Tp, G, x_cm, ldx, rows_per_block, pad_reflect, sub_stride;
     float eps;
 };
@@ -103,12 +105,14 @@ __global__ __launch_bounds__(256) void act_pad_tm_kernel(ActTmArgs a) {
             if (t >= 0 && t < a.T) {
                 if (vec) {
                     v[u] = *reinterpret_cast<const f32x4*>(a.x + ((size_t)b * a.T + t) * a.ldx + c0);
+                    if (a.x2) v[u] += *reinterpret_cast<const f32x4*>(a.x2 + ((size_t)b * a.T + t) * a.ldx2 + c0);
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if (c0 + k < a.C)
                             v[u][k] = a.x_cm ? a.x[((size_t)b * a.C + c0 + k) * a.T + t]
-                                             : a.x[((size_t)b * a.T + t) * a.ldx + c0 + k];
+                                             : a.x[((size_t)b * a.T + t) * a.ldx + c0 + k] +
+                                                   (a.x2 ? a.x2[((size_t)b * a.T + t) * a.ldx2 + c0 + k] : 0.f);
                 }
             } else if (t < 0 && a.state) {
                 v[u] = *reinterpret_cast<const f32x4*>(a.state + ((size_t)b * HALO + (HALO + t)) * a.Cp + c0);
@@ -518,14 +522,15 @@ __global__ __launch_bounds__(128 * KS * RS) void conv_tm_kernel(ConvTmArgs g, in
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v2[r] = act_apply(v2[r] * s2[r] + t2[r], g.y2_act, pa2[r], pb2[r]);
-                int rows[3] = {trow, -1, -1};
+                constexpr int kNone = -(1 << 30);
+                int rows[3] = {trow, kNone, kNone};
                 if (g.y2_reflect) {  // mirrored halo rows (no edge repeat): -j <- j, T-1+j <- T-1-j
                     if (trow >= 1 && trow <= g.y2_reflect) rows[1] = -trow;
                     if (trow <= g.Tout - 2 && trow >= g.Tout - 1 - g.y2_reflect) rows[2] = 2 * (g.Tout - 1) - trow;
                 }
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    if (q && rows[q] == -1) continue;
+                    if (q && rows[q] == kNone) continue;
                     float* dp = y2b + (size_t)(HALO + rows[q]) * g.y2_ld + c2;
                     if (vec2_ok && gn + 3 < g.y2_chi) *reinterpret_cast<f32x4*>(dp) = v2;
                     else {
@@ -727,6 +732,9 @@ int launch_act_pad_tm(const ActPadTm& p, hipStream_t s) {
     a.ldx = p.ldx > 0 ? p.ldx : p.C;
     a.pad_reflect = p.pad_reflect;
     a.sub_stride = p.sub_stride;
+    a.x2 = p.x2;
+    a.ldx2 = p.ldx2;
+    AFTER_REQUIRE(!p.x2 || (!p.x_cm && (p.ldx2 & 3) == 0), AFTER_E_INVALID, "act_pad_tm: x2 needs time-major inputs");
     a.eps = 1e-5f;
     AFTER_REQUIRE(a.Cp <= 1024, AFTER_E_INVALID, "act_pad_tm: at most 1024 channels (got %d)", p.C);
     AFTER_REQUIRE(!p.x_cm ? ((a.ldx & 3) == 0 || p.C < 4) : true, AFTER_E_INVALID, "act_pad_tm: ldx %% 4 != 0");

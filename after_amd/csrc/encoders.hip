@@ -14,6 +14,8 @@
 namespace after {
 namespace {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 // per-(b, c) statistics over time (ecapa_encoder.py AttentiveStatisticsPooling):
 //   w = softmax_t(logits[b,c,:]) (or 1/T when logits == nullptr)
 //   mean = sum_t w z ;  std = sqrt(clamp(sum_t w (z - mean)^2, 1e-12))
@@ -100,6 +102,80 @@ __global__ __launch_bounds__(256) void copy_slice_kernel(const float* __restrict
 __global__ void tanh_kernel(float* x, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) x[i] = tanhf(x[i]);
+}
+
+// ---- time-major ([B][T][C]) variants used by ECAPA on the conv_tm path
+// per-(b, c) statistics over time, one thread per channel (consecutive threads = consecutive
+// channels: coalesced rows).  Same arithmetic as time_stats_kernel.
+__global__ __launch_bounds__(256) void time_stats_tm_kernel(const float* __restrict__ z, int ldz,
+                                                            const float* __restrict__ logits, int ldl,
+                                                            float* __restrict__ out,
+                                                            const float* __restrict__ post_scale,
+                                                            const float* __restrict__ post_shift, int C,
+                                                            int T, int only_mean) {
+    const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (c >= C) return;
+    const float* zr = z + (size_t)b * T * ldz + c;
+    const float* lr = logits ? logits + (size_t)b * T * ldl + c : nullptr;
+    float mx = -INFINITY;
+    if (lr) {
+#pragma unroll 8
+        for (int t = 0; t < T; ++t) mx = fmaxf(mx, lr[(size_t)t * ldl]);
+    }
+    float se = 0.f, sz = 0.f;
+#pragma unroll 8
+    for (int t = 0; t < T; ++t) {
+        const float w = lr ? expf(lr[(size_t)t * ldl] - mx) : 1.0f;
+        se += w;
+        sz += w * zr[(size_t)t * ldz];
+    }
+    const float inv = 1.0f / se;
+    const float mean = sz * inv;
+    float sv = 0.f;
+#pragma unroll 8
+    for (int t = 0; t < T; ++t) {
+        const float w = (lr ? expf(lr[(size_t)t * ldl] - mx) : 1.0f) * inv;
+        const float d = zr[(size_t)t * ldz] - mean;
+        sv += w * d * d;
+    }
+    float m = mean, sd = sqrtf(fmaxf(sv, 1e-12f));
+    const int w2 = only_mean ? C : 2 * C;
+    if (post_scale) {
+        m = m * post_scale[c] + post_shift[c];
+        if (!only_mean) sd = sd * post_scale[C + c] + post_shift[C + c];
+    }
+    out[(size_t)b * w2 + c] = m;
+    if (!only_mean) out[(size_t)b * w2 + C + c] = sd;
+}
+
+// y[b][t][c] = s[b][c] * x[b][t][c] + res[b][t][c] on row-pitched views (4 channels per thread)
+__global__ __launch_bounds__(256) void se_scale_add_tm_kernel(const float* __restrict__ x, int ldx,
+                                                              const float* __restrict__ sc,
+                                                              const float* __restrict__ res, int ldr,
+                                                              float* __restrict__ y, int ldy, int C, int T,
+                                                              size_t total4) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total4) return;
+    const int q = C / 4;
+    const int c = 4 * (idx % q);
+    const size_t bt = idx / q;  // b * T + t
+    const int b = bt / T;
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + bt * ldx + c);
+    const f32x4 sv = *reinterpret_cast<const f32x4*>(sc + (size_t)b * C + c);
+    const f32x4 rv = *reinterpret_cast<const f32x4*>(res + bt * ldr + c);
+    *reinterpret_cast<f32x4*>(y + bt * ldy + c) = sv * xv + rv;
+}
+
+// y[b][t][0:Cs] = x[b][t][0:Cs] (row-pitched slice copy)
+__global__ __launch_bounds__(256) void copy_slice_tm_kernel(const float* __restrict__ x, int ldx,
+                                                            float* __restrict__ y, int ldy, int Cs,
+                                                            size_t total4) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total4) return;
+    const int q = Cs / 4;
+    const int c = 4 * (idx % q);
+    const size_t bt = idx / q;
+    *reinterpret_cast<f32x4*>(y + bt * ldy + c) = *reinterpret_cast<const f32x4*>(x + bt * ldx + c);
 }
 
 struct WCursor {
@@ -476,12 +552,16 @@ struct TdnnW {
     ConvW conv;
     Affine bn;
     int dil = 1;
+    ConvDmaPlanIn in;  // time-major conv path (conv_tm.hip)
+    ConvTmPlan plan;
+    float* wd = nullptr;
 };
 struct SeResW {
     TdnnW tdnn1, tdnn2;
     std::vector<TdnnW> res;
     ConvW se1, se2, shortcut;
     bool has_shortcut = false;
+    TdnnW shortcut_t;
 };
 struct after_ecapa {
     after_ecapa_cfg cfg;
@@ -495,6 +575,9 @@ struct after_ecapa {
     // workspaces
     float *feat = nullptr, *cat = nullptr, *t0 = nullptr, *t1 = nullptr, *t2 = nullptr, *t3 = nullptr;
     float *vecA = nullptr, *vecB = nullptr, *vecC = nullptr;
+    float* xp[2] = {nullptr, nullptr};  // haloed conv inputs [B][rows(T)][Cp]
+    size_t xp_elems = 0;
+    TdnnW asp_conv_t;                   // asp.conv / shortcuts as plain convs on the same path
 };
 
 namespace {
@@ -505,32 +588,83 @@ int load_tdnn(Arena& a, WCursor& c, TdnnW& t, int cin, int cout, int k, int dil)
     return load_bn(a, c, t.bn, cout);
 }
 
-// TDNNBlock (ecapa_encoder.py:85-139): BN(ReLU(conv_reflect(x)))
-int run_tdnn(const TdnnW& t, hipStream_t s, const float* x, int x_bs, int x_co, const float* x2,
-             int x2_co, float* y, int y_bs, int y_co, int B, int T, const float* bias_override = nullptr,
-             int bias_bs = 0) {
-    ConvArgs a;
-    conv_args_init(a, B, t.conv.cin, t.conv.cout, T, T);
-    a.x = x;
-    a.x_bstride = x_bs;
-    a.x_coff = x_co;
-    a.x2 = x2;
-    a.x2_bstride = x_bs;
-    a.x2_coff = x2_co;
-    a.y = y;
-    a.y_bstride = y_bs;
-    a.y_coff = y_co;
-    a.w = t.conv.w;
-    a.bias = bias_override ? bias_override : t.conv.bias;
-    a.bias_bstride = bias_bs;
-    a.pad = PAD_REFLECT;
-    a.taps = t.conv.k;
-    const int pl = ((t.conv.k - 1) * t.dil) / 2;  // (L_in - L_out) // 2, ecapa_encoder.py:74-78
-    for (int i = 0; i < t.conv.k; ++i) a.toff[0][i] = i * t.dil - pl;
-    a.out_act = ACT_RELU;
-    a.post_scale = t.bn.scale;
-    a.post_shift = t.bn.shift;
-    return launch_conv(a, s);
+// geometry + GEMM operand of one conv for the time-major path (reflect / zero 'same' padding:
+// pl = (k - 1) dil / 2, ecapa_encoder.py:74-78)
+int plan_tdnn(Arena& a, TdnnW& t) {
+    memset(&t.in, 0, sizeof(t.in));
+    t.in.Cin = t.conv.cin;
+    t.in.Cout = t.conv.cout;
+    t.in.taps = t.conv.k;
+    t.in.phases = 1;
+    t.in.istride = 1;
+    t.in.ostride = 1;
+    const int pl = ((t.conv.k - 1) * t.dil) / 2;
+    for (int i = 0; i < t.conv.k; ++i) t.in.toff[0][i] = i * t.dil - pl;
+    conv_tm_plan(t.in, &t.plan);
+    AFTER_REQUIRE(t.plan.ok, AFTER_E_INVALID, "ecapa: tap pattern outside the conv path");
+    t.wd = a.take<float>(t.plan.w_floats);
+    AFTER_REQUIRE(t.wd, AFTER_E_NOMEM, "ecapa: weight arena exhausted");
+    return conv_tm_repack(t.conv.w, t.wd, t.in, t.plan, 0);
+}
+
+// TDNNBlock (ecapa_encoder.py:85-139): BN(ReLU(conv_reflect(x))) as ONE conv launch.  The input is
+// either a haloed buffer (mirrored rows already in place) or, for k = 1, a raw row-pitched view.
+struct TdnnIo {
+    const float* src = nullptr;  // haloed [B][rows(T)][Cp]   (raw_ld == 0)
+    int raw_ld = 0;              // > 0: src is raw [B][T][raw_ld], read in place (k = 1)
+    float* y = nullptr;          // raw output view [B][T][y_ld] at column y_coff, or nullptr
+    int y_ld = 0, y_coff = 0;
+    const float* bias = nullptr; // override (per-clip with bias_bs > 0)
+    int bias_bs = 0;
+    bool plain = false;          // no ReLU / BatchNorm (shortcut, asp.conv)
+    // second output: the next conv's haloed input = act2(o [+ add]) for channels [clo, chi)
+    float* y2 = nullptr;
+    int y2_clo = 0, y2_chi = 0, y2_act = ACT_NONE, y2_reflect = 0;
+    const float* y2_add = nullptr;
+    int y2_add_ld = 0, y2_add_coff = 0;
+};
+
+int run_tdnn(const TdnnW& t, hipStream_t s, const TdnnIo& io, int B, int T) {
+    ConvTmRun r;
+    memset(&r, 0, sizeof(r));
+    r.w = t.wd;
+    r.bias = io.bias ? io.bias : t.conv.bias;
+    r.bias_bstride = io.bias_bs;
+    r.y = io.y;
+    r.y_ld = io.y_ld;
+    r.y_coff = io.y_coff;
+    r.y_bs = io.y ? (long long)T * io.y_ld : 0;
+    r.G = 1;
+    r.B = B;
+    r.Tout = T;
+    r.Nn = T;
+    if (io.raw_ld > 0) {
+        AFTER_REQUIRE(t.conv.k == 1 && (t.conv.cin & 31) == 0 && (io.raw_ld & 3) == 0, AFTER_E_INVALID,
+                      "ecapa: in-place input needs k = 1 and 32 | Cin");
+        r.xp = io.src - (size_t)conv_tm_halo() * io.raw_ld;
+        r.x_ld = io.raw_ld;
+        r.x_bs = (long long)T * io.raw_ld;
+        r.Tp = T;
+    } else {
+        r.xp = io.src;
+        r.Tp = conv_tm_rows(T);
+    }
+    if (!io.plain) {
+        r.out_act = ACT_RELU;
+        r.post_scale = t.bn.scale;
+        r.post_shift = t.bn.shift;
+    }
+    if (io.y2) {
+        r.y2 = io.y2;
+        r.y2_clo = io.y2_clo;
+        r.y2_chi = io.y2_chi;
+        r.y2_act = io.y2_act;
+        r.y2_reflect = io.y2_reflect;
+        r.y2_add = io.y2_add;
+        r.y2_add_ld = io.y2_add_ld;
+        r.y2_add_coff = io.y2_add_coff;
+    }
+    return launch_conv_tm(r, t.in, t.plan, s);
 }
 
 int gemm_rows(hipStream_t s, const float* A, int lda, const float* W, int ldw, const float* bias,
@@ -585,7 +719,7 @@ extern "C" int after_ecapa_create(const after_ecapa_cfg* cfg, const float* const
     wf += conv_floats(CL, CL, cfg->kernel_sizes[n - 1]) + conv_floats(3 * CL, A, 1) +
           (size_t)A * 2 * CL + conv_floats(A, CL, 1) + conv_floats(2 * CL, cfg->out_dim, 1) +
           12 * (size_t)CL + 8192;
-    int rc = h->wa.init(wf * sizeof(float) + (1 << 16));
+    int rc = h->wa.init(wf * 4 * sizeof(float) + (1 << 20));
     if (rc) return fail(rc);
     WCursor cur{weights, n_weights};
     if ((rc = load_tdnn(h->wa, cur, h->first, cfg->in_size, cfg->channels[0], cfg->kernel_sizes[0],
@@ -664,11 +798,28 @@ extern "C" int after_ecapa_create(const after_ecapa_cfg* cfg, const float* const
         set_error("ecapa: expected %d weight tensors, got %d", cur.i, n_weights);
         return fail(AFTER_E_INVALID);
     }
+    // ---- time-major conv path: GEMM operands of every conv
+    if ((rc = plan_tdnn(h->wa, h->first))) return fail(rc);
+    for (auto& b : h->blocks) {
+        if ((rc = plan_tdnn(h->wa, b.tdnn1)) || (rc = plan_tdnn(h->wa, b.tdnn2))) return fail(rc);
+        for (auto& t : b.res)
+            if ((rc = plan_tdnn(h->wa, t))) return fail(rc);
+        if (b.has_shortcut) {
+            b.shortcut_t.conv = b.shortcut;
+            if ((rc = plan_tdnn(h->wa, b.shortcut_t))) return fail(rc);
+        }
+    }
+    if ((rc = plan_tdnn(h->wa, h->mfa)) || (rc = plan_tdnn(h->wa, h->asp_tdnn))) return fail(rc);
+    h->asp_conv_t.conv = h->asp_conv;
+    if ((rc = plan_tdnn(h->wa, h->asp_conv_t))) return fail(rc);
     // SE convs are used as GEMM weights [N, K] (k = 1): keep unpacked copies
     const size_t el = (size_t)max_batch * cmaxc * max_T;
     const size_t elcat = (size_t)max_batch * CL * max_T;
-    if ((rc = h->ws.init((3 * el + 3 * elcat) * sizeof(float) +
-                         3 * (size_t)max_batch * (3 * CL + 1024) * sizeof(float) + 8192)))
+    int cpmax = conv_tm_cp(CL > cfg->in_size ? CL : cfg->in_size);
+    cpmax = conv_tm_cp(cmaxc) > cpmax ? conv_tm_cp(cmaxc) : cpmax;
+    h->xp_elems = (size_t)max_batch * conv_tm_rows(max_T) * cpmax + 4096;
+    if ((rc = h->ws.init((3 * el + 3 * elcat + 2 * h->xp_elems) * sizeof(float) +
+                         3 * (size_t)max_batch * (3 * CL + 1024) * sizeof(float) + 16384)))
         return fail(rc);
     h->feat = h->ws.take<float>(el);
     h->t0 = h->ws.take<float>(el);
@@ -679,7 +830,9 @@ extern "C" int after_ecapa_create(const after_ecapa_cfg* cfg, const float* const
     h->vecA = h->ws.take<float>((size_t)max_batch * (3 * CL + 1024));
     h->vecB = h->ws.take<float>((size_t)max_batch * (3 * CL + 1024));
     h->vecC = h->ws.take<float>((size_t)max_batch * (3 * CL + 1024));
-    if (!h->t3 || !h->vecC) return fail(AFTER_E_NOMEM);
+    h->xp[0] = h->ws.take<float>(h->xp_elems);
+    h->xp[1] = h->ws.take<float>(h->xp_elems);
+    if (!h->t3 || !h->vecC || !h->xp[1]) return fail(AFTER_E_NOMEM);
     if (hipDeviceSynchronize() != hipSuccess) return fail(AFTER_E_HIP);
     *out = h;
     return AFTER_OK;
@@ -702,97 +855,178 @@ extern "C" int after_ecapa_forward(after_ecapa* h, const float* z, float* out, i
     const after_ecapa_cfg& c = h->cfg;
     const int n = c.n_blocks, scale = c.res2net_scale, CL = c.channels[n - 1];
     const int A = c.attention_channels, SE = c.se_channels;
-    // blocks.0
-    AFTER_TRY(run_tdnn(h->first, s, z, c.in_size * T, 0, nullptr, 0, h->feat, c.channels[0] * T, 0, B, T));
-    const float* xin = h->feat;
-    int xin_bs = c.channels[0] * T, xin_co = 0;
+    auto reflect_pad = [](const TdnnW& t) { return ((t.conv.k - 1) * t.dil) / 2; };
+    auto halo_copy = [&](const float* x, int x_cm, int ldx, int C, float* dst, int reflect,
+                         const float* x2 = nullptr, int ldx2 = 0, int act = ACT_NONE) -> int {
+        ActPadTm p;
+        memset(&p, 0, sizeof(p));
+        p.x = x;
+        p.x2 = x2;
+        p.ldx2 = ldx2;
+        p.y = dst;
+        p.act = act;
+        p.B = B;
+        p.C = C;
+        p.T = T;
+        p.G = 1;
+        p.x_cm = x_cm;
+        p.ldx = ldx;
+        p.pad_reflect = reflect;
+        AFTER_REQUIRE(reflect < T, AFTER_E_INVALID, "ecapa: T=%d too short for the reflect padding", T);
+        return launch_act_pad_tm(p, s);
+    };
+    // All activations are time-major [B][T][C] from here on (channel slices = column ranges).
+    // blocks.0: TDNN(in -> C0) on the caller's [B][C][T] tensor
+    AFTER_TRY(halo_copy(z, 1, 0, c.in_size, h->xp[0], 1));
+    {
+        TdnnIo io;
+        io.src = h->xp[0];
+        io.y = h->feat;
+        io.y_ld = c.channels[0];
+        AFTER_TRY(run_tdnn(h->first, s, io, B, T));
+    }
+    const float* xin = h->feat;  // view [B][T][xin_ld] starting at the block's first channel
+    int xin_ld = c.channels[0];
     int cat_off = 0;
     for (int i = 1; i < n - 1; ++i) {
         const SeResW& b = h->blocks[i - 1];
-        const int ci = c.channels[i - 1], co = c.channels[i], cs = co / scale;
-        (void)ci;
-        // tdnn1 -> t0 [B, co, T]
-        AFTER_TRY(run_tdnn(b.tdnn1, s, xin, xin_bs, xin_co, nullptr, 0, h->t0, co * T, 0, B, T));
-        // Res2Net chain -> t1 [B, co, T]: y0 = x0 ; y1 = f0(x1) ; yi = f(x_i + y_{i-1})
+        const int co = c.channels[i], cs = co / scale;
+        AFTER_REQUIRE((c.channels[i - 1] & 31) == 0 && (co & 31) == 0, AFTER_E_INVALID,
+                      "ecapa: channel widths must be multiples of 32");
+        // a conv epilogue can write the next conv's haloed input itself when the slice fills whole
+        // 32-deep K slabs (every shipped width); narrower test configurations take one act_pad more
+        const bool fuse = (cs & 31) == 0;
+        // tdnn1 (k = 1) on the raw view -> t0 [B][T][co]; its epilogue also lays out x_1 (channels
+        // [cs, 2 cs)) with mirrored halo rows for the first Res2Net conv
         {
-            const size_t tot = (size_t)B * cs * T;
-            hipLaunchKernelGGL(copy_slice_kernel, dim3((unsigned)cdivll(tot, 256)), dim3(256), 0, s,
-                               h->t0, h->t1, cs, T, co * T, co * T, tot);
+            TdnnIo io;
+            io.src = xin;
+            io.raw_ld = xin_ld;
+            io.y = h->t0;
+            io.y_ld = co;
+            if (fuse) {
+                io.y2 = h->xp[0];
+                io.y2_clo = cs;
+                io.y2_chi = 2 * cs;
+                io.y2_reflect = reflect_pad(b.res[0]);
+            }
+            AFTER_TRY(run_tdnn(b.tdnn1, s, io, B, T));
+            if (!fuse) AFTER_TRY(halo_copy(h->t0 + cs, 0, co, cs, h->xp[0], reflect_pad(b.res[0])));
+        }
+        // Res2Net chain -> t1 [B][T][co]: y_0 = x_0 ; y_1 = f_0(x_1) ; y_j+1 = f_j(x_j+1 + y_j)
+        {
+            const size_t tot4 = (size_t)B * T * cs / 4;
+            hipLaunchKernelGGL(copy_slice_tm_kernel, dim3((unsigned)cdivll(tot4, 256)), dim3(256), 0, s, h->t0,
+                               co, h->t1, co, cs, tot4);
             AFTER_HIP_CHECK(hipGetLastError());
         }
-        for (int j = 0; j < scale - 1; ++j)
-            AFTER_TRY(run_tdnn(b.res[j], s, h->t0, co * T, (j + 1) * cs, j == 0 ? nullptr : h->t1,
-                               j * cs, h->t1, co * T, (j + 1) * cs, B, T));
-        // note: x2 shares x's batch stride (both [B, co, T]); its slice is y_{j}
-        // tdnn2 -> t0
-        AFTER_TRY(run_tdnn(b.tdnn2, s, h->t1, co * T, 0, nullptr, 0, h->t0, co * T, 0, B, T));
+        for (int j = 0; j < scale - 1; ++j) {
+            TdnnIo io;
+            io.src = h->xp[j & 1];
+            io.y = h->t1;
+            io.y_ld = co;
+            io.y_coff = (j + 1) * cs;
+            const bool more = j + 1 < scale - 1;
+            if (more && fuse) {  // the next conv's input: this output + the next slice of tdnn1's
+                io.y2 = h->xp[(j + 1) & 1];
+                io.y2_chi = cs;
+                io.y2_reflect = reflect_pad(b.res[j + 1]);
+                io.y2_add = h->t0;
+                io.y2_add_ld = co;
+                io.y2_add_coff = (j + 2) * cs;
+            }
+            AFTER_TRY(run_tdnn(b.res[j], s, io, B, T));
+            if (more && !fuse)
+                AFTER_TRY(halo_copy(h->t0 + (j + 2) * cs, 0, co, cs, h->xp[(j + 1) & 1], reflect_pad(b.res[j + 1]),
+                                    h->t1 + (j + 1) * cs, co));
+        }
+        // tdnn2 (k = 1) on t1 -> t0
+        {
+            TdnnIo io;
+            io.src = h->t1;
+            io.raw_ld = co;
+            io.y = h->t0;
+            io.y_ld = co;
+            AFTER_TRY(run_tdnn(b.tdnn2, s, io, B, T));
+        }
         // SE: s = sigmoid(W2 relu(W1 mean_t(x) + b1) + b2)
-        hipLaunchKernelGGL(time_stats_kernel, dim3(cdiv(B * co, 4)), dim3(256), 0, s, h->t0,
-                           (const float*)nullptr, h->vecA, (const float*)nullptr,
-                           (const float*)nullptr, B, co, T, co * T, 1);
+        hipLaunchKernelGGL(time_stats_tm_kernel, dim3(cdiv(co, 256), B), dim3(256), 0, s, h->t0, co,
+                           (const float*)nullptr, 0, h->vecA, (const float*)nullptr, (const float*)nullptr, co,
+                           T, 1);
         AFTER_HIP_CHECK(hipGetLastError());
         AFTER_TRY(gemm_rows(s, h->vecA, co, b.se1.w, pad16(co), b.se1.bias, h->vecB, SE, B, SE, co,
                             EPI_RELU));
         AFTER_TRY(gemm_rows(s, h->vecB, SE, b.se2.w, pad16(SE), b.se2.bias, h->vecC, co, B, co, SE,
                             EPI_SIGMOID));
-        // residual (identity or 1x1 shortcut) then out = s * x + residual -> cat slice
+        // residual (identity or 1x1 shortcut), then out = s * x + residual -> cat slice
         const float* res = xin;
-        int res_bs = xin_bs;
+        int res_ld = xin_ld;
         if (b.has_shortcut) {
-            ConvArgs a;
-            conv_args_init(a, B, b.shortcut.cin, co, T, T);
-            a.x = xin;
-            a.x_bstride = xin_bs;
-            a.x_coff = xin_co;
-            a.y = h->t1;
-            a.w = b.shortcut.w;
-            a.bias = b.shortcut.bias;
-            a.toff[0][0] = 0;
-            AFTER_TRY(launch_conv(a, s));
+            TdnnIo io;
+            io.src = xin;
+            io.raw_ld = xin_ld;
+            io.y = h->t1;
+            io.y_ld = co;
+            io.plain = true;
+            AFTER_TRY(run_tdnn(b.shortcut_t, s, io, B, T));
             res = h->t1;
-            res_bs = co * T;
-        } else {
-            res = xin + (size_t)xin_co * T;
+            res_ld = co;
         }
         {
-            const size_t tot = (size_t)B * co * T;
-            hipLaunchKernelGGL(se_scale_add_kernel, dim3((unsigned)cdivll(tot, 256)), dim3(256), 0, s,
-                               h->t0, h->vecC, res, h->cat + (size_t)cat_off * T, co, T, res_bs,
-                               CL * T, tot);
+            const size_t tot4 = (size_t)B * T * co / 4;
+            hipLaunchKernelGGL(se_scale_add_tm_kernel, dim3((unsigned)cdivll(tot4, 256)), dim3(256), 0, s, h->t0,
+                               co, h->vecC, res, res_ld, h->cat + cat_off, CL, co, T, tot4);
             AFTER_HIP_CHECK(hipGetLastError());
         }
-        xin = h->cat;
-        xin_bs = CL * T;
-        xin_co = cat_off;
+        xin = h->cat + cat_off;
+        xin_ld = CL;
         cat_off += co;
     }
-    // mfa over the concatenation -> t2 [B, CL, T]
-    AFTER_TRY(run_tdnn(h->mfa, s, h->cat, CL * T, 0, nullptr, 0, h->t2, CL * T, 0, B, T));
+    // mfa over the concatenation -> t2 [B][T][CL]
+    AFTER_TRY(halo_copy(h->cat, 0, CL, CL, h->xp[0], reflect_pad(h->mfa)));
+    {
+        TdnnIo io;
+        io.src = h->xp[0];
+        io.y = h->t2;
+        io.y_ld = CL;
+        AFTER_TRY(run_tdnn(h->mfa, s, io, B, T));
+    }
     // attentive statistics pooling with global context
-    hipLaunchKernelGGL(time_stats_kernel, dim3(cdiv(B * CL, 4)), dim3(256), 0, s, h->t2,
-                       (const float*)nullptr, h->vecA, (const float*)nullptr, (const float*)nullptr,
-                       B, CL, T, CL * T, 0);
+    hipLaunchKernelGGL(time_stats_tm_kernel, dim3(cdiv(CL, 256), B), dim3(256), 0, s, h->t2, CL,
+                       (const float*)nullptr, 0, h->vecA, (const float*)nullptr, (const float*)nullptr, CL, T, 0);
     AFTER_HIP_CHECK(hipGetLastError());
     // per-clip bias = W[:, CL:3CL] [mean | std] + b
     AFTER_TRY(gemm_rows(s, h->vecA, 2 * CL, h->asp_w23, 2 * CL, h->asp_tdnn.conv.bias, h->vecB, A, B, A,
                         2 * CL, EPI_NONE));
-    float* attn_h = h->cat;  // [B, A, T] scratch (cat is dead now)
-    AFTER_TRY(run_tdnn(h->asp_tdnn, s, h->t2, CL * T, 0, nullptr, 0, attn_h, A * T, 0, B, T, h->vecB, A));
+    // asp.tdnn (k = 1, per-clip bias) -> tanh -> the haloed input of asp.conv, no raw copy needed
+    {
+        TdnnIo io;
+        io.src = h->t2;
+        io.raw_ld = CL;
+        io.bias = h->vecB;
+        io.bias_bs = A;
+        if ((A & 31) == 0) {
+            io.y2 = h->xp[1];
+            io.y2_chi = A;
+            io.y2_act = ACT_TANH;
+        } else {
+            io.y = h->t0;
+            io.y_ld = A;
+        }
+        AFTER_TRY(run_tdnn(h->asp_tdnn, s, io, B, T));
+        if (io.y) AFTER_TRY(halo_copy(h->t0, 0, A, A, h->xp[1], 0, nullptr, 0, ACT_TANH));
+    }
     float* logits = h->t3;
     {
-        // conv(tanh(.)) 1x1: A -> CL
-        ConvArgs a;
-        conv_args_init(a, B, A, CL, T, T);
-        a.x = attn_h;
-        a.y = logits;
-        a.w = h->asp_conv.w;
-        a.bias = h->asp_conv.bias;
-        a.act = ACT_TANH;
-        a.toff[0][0] = 0;
-        AFTER_TRY(launch_conv(a, s));
+        TdnnIo io;  // conv 1x1: A -> CL
+        io.src = h->xp[1];
+        io.y = logits;
+        io.y_ld = CL;
+        io.plain = true;
+        AFTER_TRY(run_tdnn(h->asp_conv_t, s, io, B, T));
     }
-    hipLaunchKernelGGL(time_stats_kernel, dim3(cdiv(B * CL, 4)), dim3(256), 0, s, h->t2, logits, h->vecA,
-                       h->asp_bn.scale, h->asp_bn.shift, B, CL, T, CL * T, 0);
+    hipLaunchKernelGGL(time_stats_tm_kernel, dim3(cdiv(CL, 256), B), dim3(256), 0, s, h->t2, CL, logits, CL,
+                       h->vecA, h->asp_bn.scale, h->asp_bn.shift, CL, T, 0);
     AFTER_HIP_CHECK(hipGetLastError());
     AFTER_TRY(gemm_rows(s, h->vecA, 2 * CL, h->fc.w, 2 * CL, h->fc.bias, out, c.out_dim, B, c.out_dim,
                         2 * CL, EPI_NONE));
