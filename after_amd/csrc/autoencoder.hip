@@ -295,6 +295,10 @@ struct after_ae {
     bool use_dma = true;
     bool tm = true;               // time-major activations + conv_tm.hip (AFTER_CONV_TM=0: conv_dma.hip)
     float* xp = nullptr;          // activated + haloed scratch tensor
+    float* xp2 = nullptr;         // second one: a conv epilogue prepares the NEXT conv's input there
+    const float* prepared = nullptr;  // haloed input already laid out by the producer (time-major path)
+    const float* next_alpha = nullptr;  // Snake of the following resampling conv: request to the next
+    const float* next_invb = nullptr;   //   run_dma to emit that conv's activated input itself
     size_t xp_elems = 0;
     double* stats_ring = nullptr; // [kStatSlots][stat_sub][max_batch][8][2]
     int stat_sub = 1;             // accumulator pairs per (clip, group): conv_tm_stat_sub() on the time-major path
@@ -497,27 +501,34 @@ int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const 
     if (h->tm) {  // x, res, y time-major [B][T][C] (x_cm / y_cm: the reference's [B][C][T] at the API edges)
         AFTER_REQUIRE((size_t)B * conv_tm_cp(cin) * conv_tm_rows(Tin) <= h->xp_elems, AFTER_E_CAPACITY,
                       "autoencoder: activation scratch too small");
-        ActPadTm p;
-        memset(&p, 0, sizeof(p));
-        p.x = x;
-        p.y = h->xp;
-        p.stats = stats_in;
-        p.gamma = gamma;
-        p.beta = beta;
-        p.act_a = alpha;
-        p.act_b = invb;
-        p.state = state;
-        p.act = act;
-        p.B = B;
-        p.C = cin;
-        p.T = Tin;
-        p.G = cin < 8 ? cin : 8;
-        p.x_cm = x_cm;
-        p.sub_stride = h->max_batch * 16;
-        AFTER_TRY(launch_act_pad_tm(p, s));
+        // Snake-only inputs (the resampling convs, the encoder tail) carry no full-tensor statistics:
+        // offline their producer's epilogue has already written the activated, haloed tensor
+        const float* xin = h->prepared;
+        h->prepared = nullptr;
+        if (!xin) {
+            ActPadTm p;
+            memset(&p, 0, sizeof(p));
+            p.x = x;
+            p.y = h->xp;
+            p.stats = stats_in;
+            p.gamma = gamma;
+            p.beta = beta;
+            p.act_a = alpha;
+            p.act_b = invb;
+            p.state = state;
+            p.act = act;
+            p.B = B;
+            p.C = cin;
+            p.T = Tin;
+            p.G = cin < 8 ? cin : 8;
+            p.x_cm = x_cm;
+            p.sub_stride = h->max_batch * 16;
+            AFTER_TRY(launch_act_pad_tm(p, s));
+            xin = h->xp;
+        }
         ConvTmRun r;
         memset(&r, 0, sizeof(r));
-        r.xp = h->xp;
+        r.xp = xin;
         r.w = d.w;
         r.bias = bias;
         r.res = res;
@@ -533,8 +544,24 @@ int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const 
         r.Nn = Nn;
         r.y_cm = y_cm;
         r.sub_stride = h->max_batch * 16;
+        static int fuse_snake = -1;  // AFTER_AE_FUSE_SNAKE=0: A/B switch (separate act_pad launches)
+        if (fuse_snake < 0) {
+            const char* e = getenv("AFTER_AE_FUSE_SNAKE");
+            fuse_snake = e ? atoi(e) : 1;
+        }
+        if (fuse_snake && h->next_alpha && !h->streaming && (cout & 31) == 0 && d.in.ostride == 1 &&
+            (size_t)B * cout * conv_tm_rows(Tout) <= h->xp_elems) {
+            r.y2 = xin == h->xp2 ? h->xp : h->xp2;
+            r.y2_act = ACT_SNAKE;
+            r.y2_pa = h->next_alpha;
+            r.y2_pb = h->next_invb;
+            r.y = nullptr;  // the raw tensor has no other reader
+            h->prepared = r.y2;
+        }
+        h->next_alpha = h->next_invb = nullptr;
         return launch_conv_tm(r, d.in, d.tplan, s);
     }
+    h->next_alpha = h->next_invb = nullptr;
     AFTER_REQUIRE((size_t)B * cin * conv_dma_row(Tin) <= h->xp_elems, AFTER_E_CAPACITY,
                   "autoencoder: activation scratch too small");
     AFTER_TRY(launch_act_pad(x, h->xp, stats_in, gamma, beta, alpha, invb, act, B, cin, Tin,
@@ -568,8 +595,11 @@ int run_convblock2(after_ae* h, hipStream_t s, const ConvBlockW& cb, const float
 
 // ResnetBlock1d on the DMA path; *stats carries the accumulators of the block input in and of
 // the block output out
+// (na, nb): Snake parameters of a resampling conv that consumes this block's output -- its
+// activated input is then written by the block's last conv (see run_dma)
 int run_resblock2(after_ae* h, hipStream_t s, const ResBlockW& rb, const float* bx, float* bt,
-                  float* by, int B, int T, double** stats, float* sb = nullptr) {
+                  float* by, int B, int T, double** stats, float* sb = nullptr, const float* na = nullptr,
+                  const float* nb = nullptr) {
     const float* res = bx;
     if (rb.to_w) {  // 1x1 shortcut: no temporal context, no state
         AFTER_TRY(run_dma(h, s, rb.to_d, bx, nullptr, nullptr, nullptr, nullptr, nullptr, ACT_NONE,
@@ -579,6 +609,8 @@ int run_resblock2(after_ae* h, hipStream_t s, const ResBlockW& rb, const float* 
     double* st1 = nullptr;
     AFTER_TRY(run_convblock2(h, s, rb.cb0, bx, *stats, bt, nullptr, B, T, true, &st1, sb));
     double* st2 = nullptr;
+    h->next_alpha = na;
+    h->next_invb = nb;
     AFTER_TRY(run_convblock2(h, s, rb.cb1, bt, st1, by, res, B, T, true, &st2));
     *stats = st2;
     return AFTER_OK;
@@ -587,6 +619,8 @@ int run_resblock2(after_ae* h, hipStream_t s, const ResBlockW& rb, const float* 
 int begin_pass(after_ae* h, hipStream_t s) {
     h->stat_slot = 0;
     h->state_slot = 0;
+    h->prepared = nullptr;
+    h->next_alpha = h->next_invb = nullptr;
     if (h->norm)
         AFTER_HIP_CHECK(hipMemsetAsync(h->stats_ring, 0,
                                        (size_t)kStatSlots * h->stat_sub * h->max_batch * 16 * sizeof(double), s));
@@ -952,7 +986,7 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
     h->xp_elems = xpe * max_batch + 4096;
     rc = h->ws.init(3 * h->buf_elems * sizeof(float) + 2 * (size_t)max_batch * cmax * sizeof(float) +
                     (size_t)max_batch * 8 * 64 * 2 * sizeof(double) + (size_t)max_batch * 8 * 4 + 8192 +
-                    h->xp_elems * sizeof(float) + (size_t)kStatSlots * h->stat_sub * max_batch * 16 * sizeof(double));
+                    2 * h->xp_elems * sizeof(float) + (size_t)kStatSlots * h->stat_sub * max_batch * 16 * sizeof(double));
     if (rc != AFTER_OK) return fail(rc);
     for (int i = 0; i < 3; ++i) h->buf[i] = h->ws.take<float>(h->buf_elems);
     h->scale = h->ws.take<float>((size_t)max_batch * cmax);
@@ -960,8 +994,9 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
     h->gn_part = h->ws.take<double>((size_t)max_batch * 8 * 64 * 2);
     h->gn_tick = h->ws.take<unsigned>((size_t)max_batch * 8);
     h->xp = h->ws.take<float>(h->xp_elems);
+    h->xp2 = h->ws.take<float>(h->xp_elems);
     h->stats_ring = h->ws.take<double>((size_t)kStatSlots * h->stat_sub * max_batch * 16);
-    if (!h->buf[2] || !h->scale || !h->shift || !h->gn_part || !h->gn_tick || !h->xp || !h->stats_ring)
+    if (!h->buf[2] || !h->scale || !h->shift || !h->gn_part || !h->gn_tick || !h->xp || !h->xp2 || !h->stats_ring)
         return fail(AFTER_E_NOMEM);
     if (hipMemset(h->gn_tick, 0, (size_t)max_batch * 8 * sizeof(unsigned)) != hipSuccess ||
         hipDeviceSynchronize() != hipSuccess) {
@@ -1061,13 +1096,19 @@ extern "C" int after_ae_encode(after_ae* h, const float* x, float* z, int B, int
         AFTER_TRY(run_resblock2(h, s, h->enc_stem, b0, b1, b2, B, T, &st, sb));
         float *cur = b2, *t1 = b0, *t2 = b1;
         for (int i = 0; i < n; ++i) {
+            const ResampleW& d = h->enc_down[i];
             for (int j = 0; j < nd; ++j) {
-                AFTER_TRY(run_resblock2(h, s, h->enc_res[i][j], cur, t1, t2, B, T, &st, sb));
+                const bool lastj = j == nd - 1;
+                AFTER_TRY(run_resblock2(h, s, h->enc_res[i][j], cur, t1, t2, B, T, &st, sb,
+                                        lastj ? d.alpha : nullptr, lastj ? d.invb : nullptr));
                 float* o = cur;
                 cur = t2;
                 t2 = o;
             }
-            const ResampleW& d = h->enc_down[i];
+            if (i == n - 1) {  // the tail conv's Snake'd input comes out of the last strided conv
+                h->next_alpha = h->enc_tail_alpha;
+                h->next_invb = h->enc_tail_invb;
+            }
             AFTER_TRY(run_dma(h, s, d.d, cur, nullptr, nullptr, nullptr, d.alpha, d.invb, ACT_SNAKE, d.bias,
                               nullptr, t1, B, T, T / d.f, T / d.f, true, &st, sb));
             float* o = cur;
@@ -1173,7 +1214,10 @@ static int decode_impl(after_ae* h, const float* z, float* x, float* mb, int B, 
             t1 = o;
             T *= u.f;
             for (int j = 0; j < nd; ++j) {
-                AFTER_TRY(run_resblock2(h, s, h->dec_res[i][j], cur, t1, t2, B, T, &st, sb));
+                const bool feed = j == nd - 1 && i + 1 < n;  // the next stage starts with Snake -> ConvTranspose
+                AFTER_TRY(run_resblock2(h, s, h->dec_res[i][j], cur, t1, t2, B, T, &st, sb,
+                                        feed ? h->dec_up[i + 1].alpha : nullptr,
+                                        feed ? h->dec_up[i + 1].invb : nullptr));
                 o = cur;
                 cur = t2;
                 t2 = o;

@@ -247,7 +247,7 @@ struct ConvTmArgs {
     int y2_ld, y2_coff, y2_clo, y2_chi, y2_act, y2_add_ld, y2_add_coff, y2_reflect, y2_zero_halo, tiles_m_last;
 };
 
-template <int MB, int NB, int KS, int NS, int RS, bool DIL>
+template <int MB, int NB, int KS, int NS, int RS, bool DIL, bool Y2>
 __global__ __launch_bounds__(128 * KS * RS) void conv_tm_kernel(ConvTmArgs g, int tiles_m, int tiles_n,
                                                                 int xcd_pm, int ny) {
     constexpr int BK = 32, CPR = 8, RPP = 8, KK = 2;
@@ -412,17 +412,20 @@ __global__ __launch_bounds__(128 * KS * RS) void conv_tm_kernel(ConvTmArgs g, in
     const bool quad = (Cg & 3) == 0;  // a lane's four channels sit in one group (every shipped width)
     float* yb = g.y ? g.y + (size_t)b * g.y_bs + g.y_coff : nullptr;
     const float* rb = g.res ? g.res + (size_t)b * g.res_bs + g.res_coff : nullptr;
-    float* y2b = g.y2 ? g.y2 + (size_t)b * g.y2_bs + g.y2_coff : nullptr;
-    const float* a2b = g.y2_add ? g.y2_add + (size_t)b * g.y2_add_bs + g.y2_add_coff : nullptr;
+    float* y2b = (Y2 && g.y2) ? g.y2 + (size_t)b * g.y2_bs + g.y2_coff : nullptr;
+    const float* a2b = (Y2 && g.y2_add) ? g.y2_add + (size_t)b * g.y2_add_bs + g.y2_add_coff : nullptr;
     const bool vec_ok = !g.y_cm && !g.res_cm && ((g.y_ld | g.y_coff) & 3) == 0 &&
                         (!g.res || ((g.res_ld | g.res_coff) & 3) == 0);
     const bool vec2_ok = ((g.y2_ld | g.y2_coff | g.y2_clo | g.y2_add_ld | g.y2_add_coff) & 3) == 0;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
+        // keep the column blocks' parameter loads from being hoisted together: the epilogue must not
+        // need more registers than the main loop (64 x 96 tiles: 128 VGPRs = 4 waves per SIMD)
+        __builtin_amdgcn_sched_barrier(0);
         const int gn = n0 + part * 16 * NB + j * 16 + ccol0;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f}, ps = {1.f, 1.f, 1.f, 1.f}, pt = {0.f, 0.f, 0.f, 0.f};
         f32x4 s2 = {1.f, 1.f, 1.f, 1.f}, t2 = {0.f, 0.f, 0.f, 0.f}, pa2 = t2, pb2 = t2;
-        const bool in2 = y2b && gn >= g.y2_clo && gn < g.y2_chi;
+        const bool in2 = Y2 && y2b && gn >= g.y2_clo && gn < g.y2_chi;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (gn + r < N) {
@@ -556,7 +559,7 @@ __global__ __launch_bounds__(128 * KS * RS) void conv_tm_kernel(ConvTmArgs g, in
         }
     }
     // zero halo of the second output: first / last row tile of phase 0, each for its own columns
-    if (y2b && g.y2_zero_halo && ph == 0 && (tm == 0 || tm == g.tiles_m_last)) {
+    if (Y2 && y2b && g.y2_zero_halo && ph == 0 && (tm == 0 || tm == g.tiles_m_last)) {
         const int c_lo = max(n0, g.y2_clo), c_hi = min(min(n0 + BN, N), g.y2_chi);
         const int w4 = (c_hi - c_lo) > 0 ? (c_hi - c_lo + 3) / 4 : 0;
         for (int side = 0; side < 2; ++side) {
@@ -639,7 +642,7 @@ int launch_tm_cfg(ConvTmArgs a, int B, bool dil, hipStream_t s) {
     // the statistics scratch (32 floats) lives behind the reduction slabs inside the ring when it
     // fits: 128 extra bytes would cost the 80-KiB split-K-4 ring its second workgroup per CU
     size_t lds = ring > red ? ring : red;
-    if (lds + 128 > 80 * 1024 && lds <= 80 * 1024) {
+    if (KS > 1) {  // the split-K epilogue synchronises anyway; rings of 80 / 120 KiB must not grow
         a.gs_off = (int)(red / sizeof(float));
         a.gs_in_ring = 1;
         if (red + 128 > lds) lds = red + 128;
@@ -665,19 +668,23 @@ int launch_tm_cfg(ConvTmArgs a, int B, bool dil, hipStream_t s) {
             }
         }
     }
-    auto go = [&](auto kern) -> int {
-        static size_t attr = 0;
-        if (lds > attr) {
+    static size_t attr[4] = {0, 0, 0, 0};  // per (DIL, Y2) variant of this configuration
+    auto go = [&](auto kern, int v) -> int {
+        if (lds > attr[v]) {
             AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr = lds;
+            attr[v] = lds;
         }
         hipLaunchKernelGGL(kern, dim3(nwg * ny), dim3(128 * KS * RS), lds, s, a, tiles_m, tiles_n, pm, ny);
         AFTER_HIP_CHECK(hipGetLastError());
         return AFTER_OK;
     };
-    if (dil) return go(conv_tm_kernel<MB, NB, KS, NS, RS, true>);
-    return go(conv_tm_kernel<MB, NB, KS, NS, RS, false>);
+    if (a.y2) {
+        if (dil) return go(conv_tm_kernel<MB, NB, KS, NS, RS, true, true>, 3);
+        return go(conv_tm_kernel<MB, NB, KS, NS, RS, false, true>, 2);
+    }
+    if (dil) return go(conv_tm_kernel<MB, NB, KS, NS, RS, true, false>, 1);
+    return go(conv_tm_kernel<MB, NB, KS, NS, RS, false, false>, 0);
 }
 
 int g_tm_force = -1;  // AFTER_CONV_TM_TILE / after_convtm_set_tile: tile configuration id (0 = heuristic)
@@ -691,11 +698,14 @@ int launch_tm_id(int id, const ConvTmArgs& a, int B, bool dil, hipStream_t s) {
         case 4: return launch_tm_cfg<3, 1, 2, 2, 1>(a, B, dil, s);   // 48 x 32, 2 k-parts
         case 5: return launch_tm_cfg<3, 1, 4, 2, 1>(a, B, dil, s);   // 48 x 32, 4 k-parts (8 waves)
         case 6: return launch_tm_cfg<2, 3, 2, 2, 1>(a, B, dil, s);   // 32 x 96, 2 k-parts
-        case 7: return launch_tm_cfg<3, 3, 2, 2, 1>(a, B, dil, s);   // 48 x 96, 2 k-parts
-        case 8: return launch_tm_cfg<4, 3, 2, 2, 2>(a, B, dil, s);   // 64 x 96, 2 k-parts x 2 row parts (8 waves)
         case 9: return launch_tm_cfg<2, 2, 2, 2, 1>(a, B, dil, s);   // 32 x 64, 2 k-parts
-        case 10: return launch_tm_cfg<6, 3, 1, 2, 2>(a, B, dil, s);  // 96 x 96
-        case 11: return launch_tm_cfg<4, 2, 2, 2, 2>(a, B, dil, s);  // 64 x 64, 2 k-parts x 2 row parts
+        // (measured and dropped, profiles/r2_bench_conv_*.jsonl: 48 x 96 and 64 x 96 split-K, 96 x 96,
+        //  64 x 64 split-K, 32 x 32 split-K 4, and 3- / 4-deep rings of the split-K tiles -- a deeper
+        //  ring does not help launches of one workgroup per CU)
+        // 16-row tiles for the conditioning encoders (T = 128 / 256 positions): the only way to put
+        // a 256 x 512 output on all 256 CUs
+        case 15: return launch_tm_cfg<1, 1, 4, 2, 1>(a, B, dil, s);  // 16 x 32, 4 k-parts (8 waves)
+        case 16: return launch_tm_cfg<1, 1, 2, 2, 1>(a, B, dil, s);  // 16 x 32, 2 k-parts
         default: break;
     }
     set_error("conv_tm: no tile configuration %d", id);
@@ -866,9 +876,9 @@ int launch_conv_tm(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan
     const int N = in.Cout, K = p.K;
     const long long ny = (long long)r.B * in.phases;
     if (g_tm_force > 0) {
-        static const int ksof[] = {0, 1, 1, 1, 2, 4, 2, 2, 2, 2, 1, 2};
-        AFTER_REQUIRE(g_tm_force <= 11 && K % (32 * ksof[g_tm_force]) == 0, AFTER_E_INVALID,
-                      "conv_tm: tile %d needs K %% %d == 0 (K=%d)", g_tm_force, 32 * ksof[g_tm_force > 11 ? 0 : g_tm_force], K);
+        static const int ksof[] = {0, 1, 1, 1, 2, 4, 2, 0, 0, 2, 0, 0, 0, 0, 0, 4, 2};
+        AFTER_REQUIRE(g_tm_force <= 16 && ksof[g_tm_force] > 0 && K % (32 * ksof[g_tm_force]) == 0, AFTER_E_INVALID,
+                      "conv_tm: tile %d needs K %% %d == 0 (K=%d)", g_tm_force, 32 * ksof[g_tm_force > 16 ? 1 : g_tm_force], K);
         return launch_tm_id(g_tm_force, a, r.B, dil, s);
     }
     // Tile choice by a small cost model fitted to the per-layer sweeps (scripts/bench_conv.py,
@@ -879,8 +889,8 @@ int launch_conv_tm(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan
     struct Cand {
         int id, mb, nb, ks, rs;
     };
-    static const Cand cands[] = {{1, 4, 3, 1, 2}, {2, 4, 2, 1, 2}, {3, 4, 1, 1, 2}, {6, 2, 3, 2, 1},
-                                 {9, 2, 2, 2, 1}, {4, 3, 1, 2, 1}, {5, 3, 1, 4, 1}};
+    static const Cand cands[] = {{1, 4, 3, 1, 2}, {2, 4, 2, 1, 2}, {3, 4, 1, 1, 2}, {6, 2, 3, 2, 1}, {9, 2, 2, 2, 1},
+                                 {4, 3, 1, 2, 1}, {5, 3, 1, 4, 1}, {16, 1, 1, 2, 1}, {15, 1, 1, 4, 1}};
     int best = 0;
     double best_cost = 0;
     for (const Cand& c : cands) {
@@ -895,7 +905,9 @@ int launch_conv_tm(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan
         // behind its neighbours' MFMAs (64 x 32 tiles beat 64 x 96 ones by 5-8 % at one clip)
         double wps = wgs * waves / 1024.0;
         wps = wps < 1 ? 1 : (wps > 4 ? 4 : wps);
-        const double mfma = rounds * (waves / 4.0) * per_wave * 32.0 * (1.0 + 0.15 / wps);  // cycles
+        // one accumulator per wave: the 40-cycle dependent latency of the MFMA, not its 32-cycle issue
+        const double cyc = (c.mb / c.rs) * c.nb == 1 ? 40.0 : 32.0;
+        const double mfma = rounds * (waves / 4.0) * per_wave * cyc * (1.0 + 0.15 / wps);  // cycles
         const double fixed = rounds * 2500.0;
         const double bytes_per_flop = (bm + bn) * 4.0 / (2.0 * bm * bn);
         const double traffic = 2.0 * r.Nn * (double)N * K * ny * bytes_per_flop / (256.0 * 40.0);  // ~40 B/clk/CU

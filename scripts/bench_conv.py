@@ -30,7 +30,10 @@ LAYERS = [
     ("enc1 k3 128@16384", 128, 128, 16384, 3, 1, 1), ("enc2 k3 256@8192", 256, 256, 8192, 3, 1, 1),
     ("enc4 k3 512@1024", 512, 512, 1024, 3, 1, 1), ("enc5 k3 512@256", 512, 512, 256, 3, 1, 1),
     ("down 256->512 f4 @4096", 256, 512, 4096, 8, 1, 4),
-    ("enct k5 512@256", 512, 512, 256, 5, 1, 1), ("ecapa k3 512@128", 512, 512, 128, 3, 1, 1),
+    ("enct k5 512@256", 512, 512, 256, 5, 1, 1), ("enct k5 256@256", 256, 256, 256, 5, 1, 1),
+    ("enct k5 64@256", 64, 64, 256, 5, 1, 1), ("ecapa k3 512@128", 512, 512, 128, 3, 1, 1),
+    ("ecapa k1 512@128", 512, 512, 128, 1, 1, 1), ("ecapa k3 64@128", 64, 64, 128, 3, 1, 1),
+    ("ecapa k3 1024@128", 1024, 1024, 128, 3, 1, 1),
 ]
 
 
@@ -49,7 +52,7 @@ def timeit(fn, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1)
-    ap.add_argument("--tiles", default="0,1,2,3,4,5,6,7,8,9,10,11")
+    ap.add_argument("--tiles", default="0,1,2,3,4,5,6,9,15,16")
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--layers", default="")
     a = ap.parse_args()

@@ -56,7 +56,7 @@ def test_conv_tm_matches_torch(case, hip_device):
     assert (got2 - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
 
 
-@pytest.mark.parametrize("tile", list(range(1, 12)))
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 9, 15, 16])
 def test_conv_tm_every_tile_configuration(tile, hip_device):
     """All tile configurations give the same result on a shape every one of them accepts
     (K = 3 * 128 = 384: multiple of 128), with a dilated and an undilated conv."""
