@@ -74,6 +74,9 @@ SIGNATURES = {
     "after_denoiser_profile": (c_int, [c_void_p, c_int]),
     "after_denoiser_gemm_time_ms": (c_int, [c_void_p, POINTER(c_double), POINTER(c_longlong),
                                             POINTER(c_double)]),
+    "after_denoiser_profile_min_flops": (c_int, [c_void_p, c_double]),
+    "after_denoiser_gemm_time2": (c_int, [c_void_p, POINTER(c_double), POINTER(c_longlong), POINTER(c_double),
+                                          POINTER(c_double)]),
     "after_ae_create": (c_int, [POINTER(AECfg), POINTER(c_void_p), c_int, c_int, c_int,
                                 POINTER(c_void_p)]),
     "after_ae_destroy": (None, [c_void_p]),

@@ -62,19 +62,20 @@ struct KernelTimer {
     static constexpr int kMax = 8192;
     hipEvent_t* ev = nullptr;  // 2*kMax
     int n = 0;
-    double flops = 0;
+    double flops = 0, bytes = 0;  // algorithmic work of the bracketed launches
     int enable(bool on);
     void begin(hipStream_t s) {
         if (enabled && n < kMax) (void)hipEventRecord(ev[2 * n], s);
     }
-    void end(hipStream_t s, double fl) {
+    void end(hipStream_t s, double fl, double by = 0) {
         if (enabled && n < kMax) {
             (void)hipEventRecord(ev[2 * n + 1], s);
             ++n;
             flops += fl;
+            bytes += by;
         }
     }
-    int collect(double* ms, long long* launches, double* fl);
+    int collect(double* ms, long long* launches, double* fl, double* by = nullptr);
     void destroy();
 };
 

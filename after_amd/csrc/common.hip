@@ -43,11 +43,11 @@ int KernelTimer::enable(bool on) {
     }
     enabled = on;
     n = 0;
-    flops = 0;
+    flops = bytes = 0;
     return AFTER_OK;
 }
 
-int KernelTimer::collect(double* ms, long long* launches, double* fl) {
+int KernelTimer::collect(double* ms, long long* launches, double* fl, double* by) {
     double tot = 0;
     for (int i = 0; i < n; ++i) {
         float t = 0;
@@ -62,8 +62,9 @@ int KernelTimer::collect(double* ms, long long* launches, double* fl) {
     if (ms) *ms = tot;
     if (launches) *launches = n;
     if (fl) *fl = flops;
+    if (by) *by = bytes;
     n = 0;
-    flops = 0;
+    flops = bytes = 0;
     return AFTER_OK;
 }
 

@@ -342,17 +342,19 @@ class DenoiserV2(nn.Module):
         return out
 
     # ------------------------------------------------------------ measurement hooks
-    def profile(self, enable: bool = True):
+    def profile(self, enable: bool = True, min_flops: float = 0.0):
         self._profile = bool(enable)
         if self._handle is not None:
+            _lib.check(_lib.lib().after_denoiser_profile_min_flops(self._handle, float(min_flops)),
+                       "after_denoiser_profile_min_flops")
             _lib.check(_lib.lib().after_denoiser_profile(self._handle, int(enable)),
                        "after_denoiser_profile")
 
-    def gemm_time(self):
-        """(total_ms, launches, flops) of the GEMM launches since the last call;
-        synchronise the stream first."""
-        ms, n, fl = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
+    def gemm_time(self, with_bytes: bool = False):
+        """(total_ms, launches, flops[, algorithmic bytes]) of the bracketed GEMM launches since the
+        last call; synchronise the stream first."""
+        ms, n, fl, by = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double(), ctypes.c_double()
         _lib.check(
-            _lib.lib().after_denoiser_gemm_time_ms(self._handle, ctypes.byref(ms), ctypes.byref(n),
-                                                   ctypes.byref(fl)), "after_denoiser_gemm_time_ms")
-        return ms.value, n.value, fl.value
+            _lib.lib().after_denoiser_gemm_time2(self._handle, ctypes.byref(ms), ctypes.byref(n),
+                                                 ctypes.byref(fl), ctypes.byref(by)), "after_denoiser_gemm_time2")
+        return (ms.value, n.value, fl.value, by.value) if with_bytes else (ms.value, n.value, fl.value)

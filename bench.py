@@ -8,10 +8,23 @@ One "step" = one pass of the hot path over one batch of synthetic clips per GPU:
 conditioning encoders -> 50-step CFG rectified-flow sampler -> AutoEncoder.decode
 (BASELINE.json configs[1]: base audio-to-audio, 50 steps, batch 1 per GPU, random
 init, synthetic latents; one clip = 524288 samples = 11.889 s @ 44.1 kHz).
-Prints ONE JSON line on rank 0."""
+Other BASELINE configs: `--batch-per-gpu 8` (configs[2]'s per-GPU shard),
+`--config midi --batch-per-gpu 8` (configs[3]), `--stream` (configs[4]: base + cycle,
+100-step cached sampler, causal cached-conv codec, 8 independent streams; one step =
+one 4-frame chunk of every stream).  Prints ONE JSON line on rank 0.
+
+`--pmc` (single GPU): re-measures the HBM traffic of the dominant GEMM with two
+rocprofv3 counter passes of this same command and writes profiles/<round>_pmc_hbm_<cfg>.json
+together with the hash of the kernel sources; the default run reports `roofline.traffic`
+from that file only while the hash still matches."""
 import argparse
+import csv
+import glob
+import hashlib
 import json
 import os
+import re
+import subprocess
 import sys
 import time
 
@@ -25,10 +38,36 @@ CLIP_SAMPLES = 524288
 CLIP_SECONDS = CLIP_SAMPLES / 44100.0
 T_FRAMES = 256
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_* dense peak
-NB_STEPS = 50
+ROUND = "r2"
+# sources whose change invalidates a committed traffic measurement of the dominant GEMM
+TRAFFIC_SOURCES = ["after_amd/csrc/gemm.hip", "after_amd/csrc/gemm_pipe.h", "after_amd/csrc/denoiser.hip"]
 
 
-def cpu_baseline(diffusion, nb_steps, state_dicts, dcfg, acfg):
+def source_hash():
+    h = hashlib.sha256()
+    for rel in TRAFFIC_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_path(config, batch):
+    return os.path.join(ROOT, "profiles", f"{ROUND}_pmc_hbm_{config}_b{batch}.json")
+
+
+def piano_roll(n, tcond_dim, dev, seed=77):
+    """Synthetic piano roll: zeros with 4 notes per clip, velocities U(0.3, 1)."""
+    g = torch.Generator().manual_seed(seed)
+    roll = torch.zeros(n, tcond_dim, T_FRAMES)
+    for b in range(n):
+        for _ in range(4):
+            p = int(torch.randint(20, min(110, tcond_dim), (1, ), generator=g))
+            a = int(torch.randint(0, T_FRAMES - 64, (1, ), generator=g))
+            roll[b, p, a:a + 64] = 0.3 + 0.7 * float(torch.rand((), generator=g))
+    return roll.to(dev)
+
+
+def cpu_baseline(nb_steps, state_dicts, dcfg, acfg, tcond=None):
     """The CPU oracle (port of the reference's algorithm, oracle/) on this host's cores,
     on ONE clip of the same workload (full path), bounded to a few seconds of CPU."""
     import oracle
@@ -44,7 +83,7 @@ def cpu_baseline(diffusion, nb_steps, state_dicts, dcfg, acfg):
     with torch.no_grad():
         t0 = time.perf_counter()
         cond = oracle.ecapa_forward(sd_enc, zt[..., :128], dcfg["encoder"])
-        tc = oracle.encoder1d_forward(sd_et, zs, dcfg["encoder_time"])
+        tc = tcond if tcond is not None else oracle.encoder1d_forward(sd_et, zs, dcfg["encoder_time"])
         z = oracle.sample(sd_net, dcfg["net"], x0, cond, tc, nb_steps, 2.0, 1.0)
         y = oracle.ae_decode(sd_ae, z, acfg)
         dt = time.perf_counter() - t0
@@ -54,6 +93,148 @@ def cpu_baseline(diffusion, nb_steps, state_dicts, dcfg, acfg):
                       f"{dt:.2f} s on {cores} threads, torch {torch.__version__} CPU fp32"}
 
 
+def cpu_baseline_stream(model, dcfg, acfg, chunk, nb_steps, nsig):
+    """oracle.stream_forward on a bounded sample: 1 stream, 2 chunks, the same step count."""
+    import oracle
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    pick = lambda pre: {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+    sd_ae = {k: v.detach().cpu() for k, v in model.emb_model.state_dict().items()}
+    n, n_chunks = 1, 2
+    g = torch.Generator().manual_seed(5)
+    L = n_chunks * chunk * 2048
+    xs, xt = 0.1 * torch.randn(n, 1, L, generator=g), 0.1 * torch.randn(n, 1, L, generator=g)
+    noise = torch.randn(n, 64, n_chunks * chunk, generator=g)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        oracle.stream_forward(pick("net."), pick("encoder."), pick("encoder_time."), sd_ae, dcfg, acfg, xs, xt,
+                              noise, chunk, nb_steps, 2.0, 1.0, nsig)
+        dt = time.perf_counter() - t0
+    return {"value": n * L / 44100.0 / dt, "unit": "audio_s_per_wall_s", "cores": cores, "kind": "port",
+            "sample": f"{n} stream x {n_chunks} chunks of {chunk} frames, {nb_steps}-step cached sampler + causal "
+                      f"codec (oracle.stream_forward), {dt:.2f} s on {cores} threads"}
+
+
+def gemm_roofline(model, run_once, dev, dcfg, B, config, args):
+    """Roofline of the dominant kernel (the fp32 MFMA GEMM behind qkv / MLP), measured live with HIP
+    events on the launch stream in one extra, untimed pass."""
+    # the dominant launches: qkv / MLP-up / MLP-down (1.208 GFLOP each for base at B=1); the patchify /
+    # AdaLN / out_proj launches share the kernel template but are a tenth of the size
+    E_, ME_ = dcfg["net"]["embed_dim"], dcfg["net"]["embed_dim"] * dcfg["net"]["mlp_multiplier"]
+    big = 0.5 * 2.0 * (3 * B * T_FRAMES) * E_ * ME_
+    model.net.profile(True, min_flops=0.0 if args.stream else big)
+    run_once()
+    torch.cuda.synchronize()
+    ms, launches, flops, nbytes = model.net.gemm_time(with_bytes=True)
+    model.net.profile(False)
+    if not launches:
+        return None
+    if args.stream:
+        # <= 96 tokens per launch: weight-streaming GEMMs (3 MB of W against 0.2 MB of activations),
+        # priced against HBM bandwidth; in practice they sit at the launch / dependency floor
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": "gemm_f32_skinny_kernel / gemm_f32_bal_kernel on <= 96 tokens "
+                                          "(weight streaming)",
+                "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+                "traffic": None, "launches": int(launches), "avg_launch_us": round(ms * 1e3 / launches, 2),
+                "bytes_per_launch": round(nbytes / launches),
+                "note": "algorithmic bytes (A + W + C) / HIP-event launch duration; the launches are 6-9 us each, "
+                        "i.e. latency-bound, and the weights are Infinity-Cache resident after the first step"}
+    traffic, traffic_note = None, "no committed PMC profile for this configuration (python bench.py --pmc)"
+    pth = pmc_path(config, B)
+    if os.path.exists(pth):
+        prof = json.load(open(pth))
+        if prof.get("source_hash") == source_hash():
+            traffic = prof.get("gemm_big_mean_bytes_per_launch")
+            traffic_note = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command ({os.path.basename(pth)}, "
+                            f"sources {prof.get('source_hash')}): (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, "
+                            "Infinity-Cache hits included")
+        else:
+            traffic_note = f"{os.path.basename(pth)} is stale (kernel sources changed since it was measured)"
+    # the same launches without per-launch event bracketing: trains of 100 back-to-back
+    # launches of the two dominant shapes (qkv / MLP-up and MLP-down), one event pair per train
+    b2b = None
+    try:
+        from after_amd import diag
+        M = 3 * B * (T_FRAMES if not args.stream else args.chunk)
+        tot_t, tot_f = 0.0, 0.0
+        for (n_, k_) in ((ME_, E_), (E_, ME_)):
+            a_ = torch.randn(M, k_, device=dev)
+            w_ = torch.randn(n_, k_, device=dev)
+            o_ = torch.empty(M, n_, device=dev)
+            for _ in range(5):
+                diag.gemm(a_, w_, out=o_)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(100):
+                diag.gemm(a_, w_, out=o_)
+            e1.record()
+            torch.cuda.synchronize()
+            tot_t += e0.elapsed_time(e1) * 1e-3 / 100
+            tot_f += 2.0 * M * n_ * k_
+        b2b = round(tot_f / tot_t / 1e12, 2)
+    except Exception:  # diagnostics only
+        b2b = None
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "gemm_f32_bal_kernel (v_mfma_f32_16x16x4_f32): the qkv / MLP-up / MLP-down "
+                                       f"launches (>= {big / 1e9:.2f} GFLOP each)",
+            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes per launch",
+            "traffic_note": traffic_note, "launches": int(launches),
+            "avg_launch_us": round(ms * 1e3 / launches, 2), "achieved_back_to_back": b2b,
+            "note": "achieved = per-launch HIP-event bracketing inside the sampler (launch latency included: the "
+                    "rocprofv3 kernel durations in profiles/ are ~2 us shorter per launch); achieved_back_to_back = "
+                    "same kernels in trains of 100 launches",
+            "flops_per_launch": round(flops / launches)}
+
+
+def run_pmc(args):
+    """Two rocprofv3 counter passes (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2: separate runs) of this
+    very command; kernel trace only, no other trace domain."""
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out", f"{ROUND}_pmc")
+    os.makedirs(out, exist_ok=True)
+    inner = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+             "--batch-per-gpu", str(args.batch_per_gpu), "--config", args.config]
+    agg = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(out, ctr)
+        env = dict(os.environ, TMPDIR="/tmp")
+        r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--"] + inner,
+                           cwd="/tmp", env=env, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise SystemExit(f"rocprofv3 --pmc {ctr} failed:\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}")
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            raise SystemExit(f"no counter_collection.csv under {d}")
+        for row in csv.DictReader(open(files[0])):
+            if row["Counter_Name"] != ctr:
+                continue
+            key = (row["Kernel_Name"], int(row["Grid_Size"]))
+            agg.setdefault(key, {}).setdefault(ctr, []).append(float(row["Counter_Value"]))
+    rows, big_bytes, big_n = [], 0.0, 0
+    for (name, grid), v in agg.items():
+        f, w = v.get("FETCH_SIZE", [0.0]), v.get("WRITE_SIZE", [0.0])
+        fm, wm = sum(f) / len(f), sum(w) / len(w)
+        total = (2 * fm + wm) * 1024  # KiB; gfx950 FETCH_SIZE counts 64 B per 128-B request (MI355X_MICROARCH.md)
+        short = name.replace("void ", "").replace("(anonymous namespace)::", "").replace("after::", "")[:100]
+        rows.append({"kernel": short, "grid_threads": grid, "launches": len(f), "FETCH_SIZE_KiB_mean": round(fm, 1),
+                     "WRITE_SIZE_KiB_mean": round(wm, 1), "bytes_per_launch_corrected": round(total)})
+        # the dominant launches: split-K balanced GEMM with the 768 / 256 workgroup grids of the qkv / MLP shapes
+        m = re.search(r"gemm_f32_bal_kernel<([^>]*)>", name)
+        if m and m.group(1).split(",")[-1].strip() == "0" and total > 5e6:  # MODE 0, not the small launches
+            big_bytes += total * len(f)
+            big_n += len(f)
+    rows.sort(key=lambda r: -r["bytes_per_launch_corrected"] * r["launches"])
+    prof = {"note": "bytes_per_launch_corrected = (2 * FETCH_SIZE + WRITE_SIZE) * 1024; includes Infinity-Cache hits",
+            "command": " ".join(inner[1:]), "source_hash": source_hash(), "sources": TRAFFIC_SOURCES,
+            "gemm_big_mean_bytes_per_launch": round(big_bytes / max(1, big_n)), "gemm_big_launches": big_n,
+            "kernels": rows[:24]}
+    json.dump(prof, open(pmc_path(args.config, args.batch_per_gpu), "w"), indent=1)
+    json.dump(prof, open(os.path.join(out, os.path.basename(pmc_path(args.config, args.batch_per_gpu))), "w"), indent=1)
+    print(json.dumps({k: prof[k] for k in ("gemm_big_mean_bytes_per_launch", "gemm_big_launches", "source_hash")}))
+
+
 def main():
     import faulthandler
     faulthandler.dump_traceback_later(900, exit=True)  # never hang a GPU box silently
@@ -61,10 +242,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch-per-gpu", type=int, default=1)
+    ap.add_argument("--batch-per-gpu", type=int, default=None)
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="total clips over all ranks (default batch-per-gpu x ranks); ragged shards allowed")
     ap.add_argument("--config", default="base")
+    ap.add_argument("--stream", action="store_true", help="BASELINE config 5: streaming, 100 cached steps")
+    ap.add_argument("--nb-steps", type=int, default=None, help="Euler steps (50; 100 with --stream)")
+    ap.add_argument("--chunk", type=int, default=4, help="--stream: latent frames per chunk")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pmc", action="store_true", help="measure the GEMM's HBM traffic with rocprofv3 and exit")
     args = ap.parse_args()
+    if args.batch_per_gpu is None:
+        args.batch_per_gpu = 8 if args.stream else 1
+    if args.stream and args.config == "base":
+        args.config = "cycle"
+    nb_steps = args.nb_steps or (100 if args.stream else 50)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -74,6 +266,10 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    if args.pmc:
+        if world != 1:
+            raise SystemExit("--pmc is a single-GPU measurement")
+        return run_pmc(args)
     # test hook: AFTER_BENCH_SHARE_GPU=1 runs all ranks on cuda:0 over gloo, to exercise the
     # multi-rank flow on a single-GPU box (the numbers of such a run mean nothing)
     share = os.environ.get("AFTER_BENCH_SHARE_GPU") == "1"
@@ -90,32 +286,67 @@ def main():
 
     from after_amd import parallel, pipeline
     torch.set_grad_enabled(False)
-    model, dcfg, acfg = pipeline.build_models(args.config, "baseAE", dev, seed=0)
+    codec = "baseAE_causal" if args.stream else "baseAE"
+    model, dcfg, acfg = pipeline.build_models(args.config, codec, dev, seed=0)
     if world > 1:  # identical models everywhere: one RCCL broadcast at start-up
-        for m in (model.net, model.encoder, model.encoder_time, model.emb_model):
-            if m is not None:
-                parallel.broadcast_module(m)
+        parallel.broadcast_module(model)  # net, both encoders and the codec (a registered sub-module)
+    n_ranks_seen = parallel.ranks_seen() if world > 1 else 1
 
-    B = args.batch_per_gpu
-    n_clips = B * world
+    n_clips = args.global_batch if args.global_batch else args.batch_per_gpu * world
     g = torch.Generator(device="cpu").manual_seed(1000)
-    zs_all = torch.randn(n_clips, 64, T_FRAMES, generator=g)
-    zt_all = torch.randn(n_clips, 64, T_FRAMES, generator=g)
-    x0_all = torch.randn(n_clips, 64, T_FRAMES, generator=g)
     lo, hi = parallel.shard_bounds(n_clips, rank, world)
-    zs, zt, x0 = (t[lo:hi].to(dev) for t in (zs_all, zt_all, x0_all))
-    tcond = None
-    if dcfg["encoder_time"] is None:  # midi: synthetic piano roll
-        tcond = torch.zeros(hi - lo, dcfg["net"]["tcond_dim"], T_FRAMES, device=dev)
-        tcond[:, 60:64, 32:96] = 0.7
+    B = hi - lo  # this rank's clips (ragged when world does not divide the global batch)
+    if B < 1:
+        raise SystemExit("every rank needs at least one clip")
 
-    def step(gather=True):
-        audio, z = pipeline.generate_from_latents(model, zs, zt, x0, nb_steps=NB_STEPS,
-                                                  guidance_timbre=2.0, guidance_structure=1.0,
-                                                  time_cond=tcond)
-        if world > 1 and gather:
-            audio = parallel.gather_clips(audio, n_clips)
-        return audio
+    if args.stream:
+        # ---- BASELINE config 5: every rank runs B independent streams; one step = one chunk of each
+        from after_amd import Streamer
+        if dcfg["encoder_time"] is None:
+            raise SystemExit("--stream needs an audio-structure config (base / cycle / tiny)")
+        st = Streamer(model, model.emb_model, chunk_size=args.chunk, n_signal_timbre=128, max_batch=B,
+                      max_nb_steps=nb_steps, share_first_stream=False)
+        st.set_nb_steps(nb_steps)
+        st.set_guidance_timbre(2.0)
+        st.set_guidance_structure(1.0)
+        n_samp = args.chunk * st.ae_ratio
+        x_all = 0.1 * torch.randn(n_clips, 2, n_samp, generator=g)
+        x = x_all[lo:hi].to(dev)
+        unit_seconds = n_samp / 44100.0
+        out_shape = (n_clips, 1, n_samp)
+        gather_buf = torch.empty(out_shape, device=dev) if world > 1 else None
+
+        def step(gather=True):
+            audio = st(x)
+            if world > 1 and gather:
+                audio = parallel.gather_clips(audio, n_clips, out=gather_buf)
+            return audio
+        workload = (f"{args.config} streaming audio-to-audio: {B} independent streams per GPU, chunk = {args.chunk} "
+                    f"latent frames ({unit_seconds * 1e3:.1f} ms of audio), {nb_steps}-step cached CFG sampler "
+                    f"(per-step K/V ring caches), causal cached-conv codec + structure encoder, random-init weights")
+    else:
+        zs_all = torch.randn(n_clips, 64, T_FRAMES, generator=g)
+        zt_all = torch.randn(n_clips, 64, T_FRAMES, generator=g)
+        x0_all = torch.randn(n_clips, 64, T_FRAMES, generator=g)
+        zs, zt, x0 = (t[lo:hi].to(dev) for t in (zs_all, zt_all, x0_all))
+        tcond = None
+        if dcfg["encoder_time"] is None:  # midi: synthetic piano roll
+            tcond = piano_roll(n_clips, dcfg["net"]["tcond_dim"], dev)[lo:hi].contiguous()
+        unit_seconds = CLIP_SECONDS
+        out_shape = (n_clips, 1, CLIP_SAMPLES)
+        gather_buf = torch.empty(out_shape, device=dev) if world > 1 else None
+
+        def step(gather=True):
+            audio, z = pipeline.generate_from_latents(model, zs, zt, x0, nb_steps=nb_steps,
+                                                      guidance_timbre=2.0, guidance_structure=1.0,
+                                                      time_cond=tcond)
+            if world > 1 and gather:
+                audio = parallel.gather_clips(audio, n_clips, out=gather_buf)
+            return audio
+        src = "synthetic piano roll + timbre latents" if tcond is not None else "synthetic latents"
+        workload = (f"{args.config} {'midi' if tcond is not None else 'audio'}-to-audio from {src}, "
+                    f"{nb_steps} Euler steps with 3-way CFG (g_t=2, g_s=1), "
+                    f"T=256 frames = 11.889 s clips, encoders + sampler + AE decode, random-init weights")
 
     for _ in range(args.warmup):
         out = step()
@@ -133,75 +364,32 @@ def main():
         te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = te.item()
-    assert out.shape == (n_clips, 1, CLIP_SAMPLES) and torch.isfinite(out).all()
+    assert tuple(out.shape) == out_shape and torch.isfinite(out).all()
 
-    # ---- roofline of the dominant kernel (the fp32 MFMA GEMM of the denoiser), measured
-    # live with HIP events on the launch stream in one extra, untimed pass
     roof = None
-    if rank == 0:
-        model.net.profile(True)
-        step(gather=False)  # rank 0 only: no collective in this pass
-        torch.cuda.synchronize()
-        ms, launches, flops = model.net.gemm_time()
-        model.net.profile(False)
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r1_pmc_hbm_base_b1.json")
-        if args.config == "base" and args.batch_per_gpu == 1 and os.path.exists(pmc):
-            # not measurable live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
-            # command (scripts/pmc_summary.py: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch,
-            # Infinity-Cache hits included), averaged over the GEMM launches
-            traffic = json.load(open(pmc)).get("gemm_f32_mean_bytes_per_launch")
-        # the same launches without per-launch event bracketing: trains of 100 back-to-back
-        # launches of the two dominant shapes (qkv / MLP-up and MLP-down), one event pair per train
-        b2b = None
-        try:
-            from after_amd import diag
-            M = 3 * B * T_FRAMES
-            E_, ME_ = dcfg["net"]["embed_dim"], dcfg["net"]["embed_dim"] * dcfg["net"]["mlp_multiplier"]
-            tot_t, tot_f = 0.0, 0.0
-            for (n_, k_) in ((ME_, E_), (E_, ME_)):
-                a_ = torch.randn(M, k_, device=dev)
-                w_ = torch.randn(n_, k_, device=dev)
-                o_ = torch.empty(M, n_, device=dev)
-                for _ in range(5):
-                    diag.gemm(a_, w_, out=o_)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(100):
-                    diag.gemm(a_, w_, out=o_)
-                e1.record()
-                torch.cuda.synchronize()
-                tot_t += e0.elapsed_time(e1) * 1e-3 / 100
-                tot_f += 2.0 * M * n_ * k_
-            b2b = round(tot_f / tot_t / 1e12, 2)
-        except Exception:  # diagnostics only
-            b2b = None
-        if launches:
-            ach = flops / (ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "gemm_f32_bal_kernel / gemm_f32_dma_kernel (v_mfma_f32_16x16x4_f32)",
-                    "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "traffic_unit": "bytes per launch (PMC profile, see profiles/r1_pmc_hbm_base_b1.json)",
-                    "launches": int(launches), "avg_launch_us": round(ms * 1e3 / launches, 2),
-                    "achieved_back_to_back": b2b,
-                    "note": "achieved = per-launch HIP-event bracketing inside the sampler (launch latency "
-                            "included); achieved_back_to_back = same kernels in trains of 100 launches",
-                    "flops_per_launch": round(flops / launches)}
+    if rank == 0:  # rank 0 only: no collective in this pass
+        roof = gemm_roofline(model, lambda: step(gather=False), dev, dcfg, B, args.config, args)
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and dcfg["encoder_time"] is not None:
-        sds = tuple({k: v.detach().cpu() for k, v in m.state_dict().items()}
-                    for m in (model.net, model.encoder, model.encoder_time, model.emb_model))
-        cpu = cpu_baseline(args.config, NB_STEPS, sds, dcfg, acfg)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if args.stream:
+            cpu = cpu_baseline_stream(model, dcfg, acfg, args.chunk, nb_steps, 128)
+        else:
+            sds = tuple(({k: v.detach().cpu() for k, v in m.state_dict().items()} if m is not None else None)
+                        for m in (model.net, model.encoder, model.encoder_time, model.emb_model))
+            tc_cpu = piano_roll(1, dcfg["net"]["tcond_dim"], "cpu") if dcfg["encoder_time"] is None else None
+            cpu = cpu_baseline(nb_steps, sds, dcfg, acfg, tc_cpu)
 
     if rank == 0:
-        audio_s = args.steps * n_clips * CLIP_SECONDS
+        audio_s = args.steps * n_clips * unit_seconds
         line = {
             "metric": "audio sec generated / wall sec (xRT), base 50-step @44.1 kHz",
             "value": round(audio_s / elapsed, 2),
             "unit": "audio_s_per_wall_s",
-            "clips_per_s": round(args.steps * n_clips / elapsed, 3),
+            "clips_per_s": round(args.steps * n_clips / elapsed, 3) if not args.stream else None,
+            "xrt_per_stream": round(unit_seconds / (elapsed / args.steps), 3) if args.stream else None,
             "n_gpus": world,
+            "n_ranks_seen": n_ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -210,15 +398,15 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.config} audio-to-audio from synthetic latents, "
-                                   f"{NB_STEPS} Euler steps with 3-way CFG (g_t=2, g_s=1), "
-                                   f"T=256 frames = 11.889 s clips, encoders + sampler + AE decode, "
-                                   f"random-init weights",
-                       "batch_per_gpu": B, "global_batch": n_clips,
-                       "parallelism": f"clip-sharded x{world}"},
+            "config": {"workload": workload,
+                       "batch_per_gpu": args.batch_per_gpu if not args.global_batch else None,
+                       "global_batch": n_clips, "nb_steps": nb_steps,
+                       "parallelism": f"clip-sharded x{world}" if not args.stream else f"stream-sharded x{world}"},
             "roofline": roof,
             "cpu_baseline": cpu,
         }
+        if args.stream:
+            line["metric"] = "audio sec generated / wall sec (xRT, all streams), base+cycle 100-step streaming @44.1 kHz"
         print(json.dumps(line))
     if world > 1:
         dist.barrier()  # rank 0's roofline pass is done: leave together

@@ -139,6 +139,13 @@ int after_denoiser_roll_cache(after_denoiser* h, int size, int cache_index, void
 int after_denoiser_profile(after_denoiser* h, int enable);
 int after_denoiser_gemm_time_ms(after_denoiser* h, double* total_ms, long long* launches,
                                 double* flops);
+/* only launches of at least min_flops are bracketed (the dominant qkv / MLP GEMMs: the small
+ * patchify / AdaLN projections share the kernel template but not its roofline) */
+int after_denoiser_profile_min_flops(after_denoiser* h, double min_flops);
+/* as after_denoiser_gemm_time_ms, plus the algorithmic bytes (A + W + C, fp32) of those launches:
+ * the streaming path's GEMMs (<= 96 tokens) are weight-streaming launches priced against HBM */
+int after_denoiser_gemm_time2(after_denoiser* h, double* total_ms, long long* launches, double* flops,
+                              double* bytes);
 
 /* --------------------------------------------------------------- autoencoder
  * AutoEncoder (after/autoencoder/networks/SimpleNetsStream.py:831-954): PQMF +

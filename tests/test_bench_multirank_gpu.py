@@ -13,15 +13,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_rank_bench_flow(hip_device):
+@pytest.mark.parametrize("extra,n_clips", [([], 2), (["--global-batch", "3"], 3)])
+def test_two_rank_bench_flow(extra, n_clips, hip_device):
+    """Even shards (all_gather_into_tensor on RCCL; the host-staged list form under gloo) and a
+    ragged global batch (3 clips over 2 ranks: shards of 2 and 1)."""
     env = dict(os.environ, AFTER_BENCH_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "1", "--warmup", "1", "--config", "tiny", "--no-cpu-baseline"]
+           "--master-addr", "127.0.0.1", "--master-port", str(29533 + n_clips), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "1", "--warmup", "1", "--config", "tiny", "--no-cpu-baseline"] + extra
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 and d["scaling"] == "weak"
-    assert d["value"] > 0 and d["roofline"]["frac"] > 0
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["config"]["global_batch"] == n_clips
+    assert d["scaling"] == "weak" and d["value"] > 0 and d["roofline"]["frac"] > 0
