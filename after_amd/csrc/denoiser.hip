@@ -286,6 +286,7 @@ struct AttnArgs {
     int nc;                 // cached frames in front of the chunk
     int T, E, H, cs, W;
     int nkmax;              // LDS rows provisioned for keys: W - 1 + cs
+    int causal;             // 0: no mask (WIDE kernels only)
     int dbg;                // AFTER_ATTN_DBG bitmask (diagnostics): 1 no rope, 2 no reduce, 4 no LN tail, 8 no KV loads
 };
 
@@ -332,7 +333,10 @@ constexpr int kAttnKeyBlock = 12;
 //     registers (96 VGPRs), the LayerNorm-tail operands are requested up front (32 VGPRs).
 //   !PRELOAD (larger grids): occupancy first -- K / V blocks land in LDS by DMA, no preloads:
 //     102 VGPRs and 68 KB LDS = two co-resident workgroups per CU (B=8: 93.8 -> 90.0 ms).
-template <bool CACHE, bool PRELOAD>
+// WIDE (no shipped config): the unlimited windows of transformerv2.py:204-220 -- chunk-wise causal
+// over ALL previous chunks (local_attention_size None / negative) or no mask at all (causal=False).
+// Keys start at 0, the RoPE tables are read from global memory per key (no per-chunk slice).
+template <bool CACHE, bool PRELOAD, bool WIDE = false>
 __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
     constexpr int NKMAX = kAttnKeyBlock;  // key block
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [cs][E + 4] | cos, sin [nkmax][16]
@@ -346,8 +350,8 @@ __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
     const int e = min(i0 + cs, T);
     const int nq = e - i0;
     const int a0 = nc + i0;          // absolute position of the first query (keys: nc cached frames first)
-    const int lo_c = min(a0, max(0, a0 - W + 1));
-    const int nk = (nc + e) - lo_c;
+    const int lo_c = WIDE ? 0 : min(a0, max(0, a0 - W + 1));
+    const int nk = ((WIDE && !a.causal) ? nc + T : nc + e) - lo_c;
     const size_t rowbase = (size_t)r * T;
     // The chunk touches positions [lo_c, lo_c + nk) only (its queries are the last nq of them):
     // every wave stages that slice of the RoPE tables in its own LDS region (float4 per lane,
@@ -361,11 +365,11 @@ __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
     // indexed array here ended up in scratch memory)
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 tc0 = z4, tc1 = z4, ts0 = z4, ts1 = z4;
-    if (lane < nk * 4) {
+    if (!WIDE && lane < nk * 4) {
         tc0 = *reinterpret_cast<const float4*>(a.rope_cos + (size_t)lo_c * 16 + lane * 4);
         ts0 = *reinterpret_cast<const float4*>(a.rope_sin + (size_t)lo_c * 16 + lane * 4);
     }
-    if (lane + 64 < nk * 4) {
+    if (!WIDE && lane + 64 < nk * 4) {
         tc1 = *reinterpret_cast<const float4*>(a.rope_cos + (size_t)lo_c * 16 + (lane + 64) * 4);
         ts1 = *reinterpret_cast<const float4*>(a.rope_sin + (size_t)lo_c * 16 + (lane + 64) * 4);
     }
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
         const bool qok = qi < nq;
         const int qic = qok ? qi : nq - 1;
         const int ja = a0 + qic;  // absolute query position
-        const int lo_row = min(a0, max(0, ja - W + 1));
+        const int lo_row = WIDE ? 0 : min(a0, max(0, ja - W + 1));
         float4 q4 = *reinterpret_cast<const float4*>(a.qkv + (rowbase + i0 + qic) * 3 * E + hw * 64 + d4);
         const float4 x4 = *reinterpret_cast<const float4*>(a.xres + (rowbase + i0 + qic) * E + hw * 64 + d4);
         // Keys are walked in blocks of NKMAX with an online softmax (one block for the
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
                     __builtin_amdgcn_global_load_lds((gbl_ptr_t)vsrc, (lds_ptr_t)(kvs + (NKMAX + 4 * u) * 64), 16, 0, 0);
                 }
             }
-            if (qb == 0 && kb == 0) {  // K / V requests are in flight: now land the RoPE slice
+            if (!WIDE && qb == 0 && kb == 0) {  // K / V requests are in flight: now land the RoPE slice
                 if (lane < nk * 4) {
                     *reinterpret_cast<float4*>(rc + lane * 4) = tc0;
                     *reinterpret_cast<float4*>(rs + lane * 4) = ts0;
@@ -461,7 +465,8 @@ __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // K / V block (and q, x) have landed
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-            if (kb == 0 && !(a.dbg & 1)) q4 = rope4(q4, rc, rs, ja - lo_c, d4);
+            if (kb == 0 && !(a.dbg & 1))
+                q4 = WIDE ? rope4(q4, a.rope_cos, a.rope_sin, ja, d4) : rope4(q4, rc, rs, ja - lo_c, d4);
             float sc[NKMAX];
             float mx = mrun;
 #pragma unroll
@@ -470,7 +475,9 @@ __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
                 float4 kj;
                 if constexpr (PRELOAD) kj = k4[j];
                 else kj = *reinterpret_cast<const float4*>(kvs + j * 64 + d4);
-                const float4 kr = (a.dbg & 1) ? kj : rope4(kj, rc, rs, pos - lo_c, d4);
+                const float4 kr = (a.dbg & 1) ? kj
+                                              : (WIDE ? rope4(kj, a.rope_cos, a.rope_sin, pos, d4)
+                                                      : rope4(kj, rc, rs, pos - lo_c, d4));
                 float dot = q4.x * kr.x + q4.y * kr.y + q4.z * kr.z + q4.w * kr.w;
                 if (!(a.dbg & 2)) dot = group16_sum(dot);
                 sc[j] = (kb + j < nk && pos >= lo_row) ? dot * 0.125f : -INFINITY;
@@ -751,15 +758,22 @@ int launch_attn(const AttnArgs& a, int rows, size_t lds, hipStream_t s) {
     const dim3 grid(cdiv(a.T, a.cs), rows), block(64 * a.H);
     static size_t attr = 0;
     if (lds > attr) {  // > 64 KiB of dynamic LDS needs the opt-in
-        const void* fns[4] = {reinterpret_cast<const void*>(attn_block_kernel<true, true>),
+        const void* fns[5] = {reinterpret_cast<const void*>(attn_block_kernel<true, true>),
                               reinterpret_cast<const void*>(attn_block_kernel<true, false>),
                               reinterpret_cast<const void*>(attn_block_kernel<false, true>),
-                              reinterpret_cast<const void*>(attn_block_kernel<false, false>)};
+                              reinterpret_cast<const void*>(attn_block_kernel<false, false>),
+                              reinterpret_cast<const void*>(attn_block_kernel<false, false, true>)};
         for (const void* f : fns)
             AFTER_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = lds;
     }
     const bool preload = (long long)grid.x * grid.y <= 256;
+    if (a.W < 0 || !a.causal) {  // unlimited window / no mask: the general (slow) instantiation
+        AFTER_REQUIRE(a.nc == 0, AFTER_E_INVALID, "attention: K/V caches need a finite window");
+        hipLaunchKernelGGL((attn_block_kernel<false, false, true>), grid, block, lds, s, a);
+        AFTER_HIP_CHECK(hipGetLastError());
+        return AFTER_OK;
+    }
     if (a.nc > 0) {
         if (preload) hipLaunchKernelGGL((attn_block_kernel<true, true>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((attn_block_kernel<true, false>), grid, block, lds, s, a);
@@ -799,8 +813,9 @@ int run_layers(after_denoiser* h, hipStream_t s, int row0, int rows, const int* 
     float* xres = h->xres + r0 * E;
     float* hbuf = h->hbuf + r0 * E;
     float* mlp = h->mlp + r0 * ME;
-    const int nkmax = h->W - 1 + h->cs > h->cs ? h->W - 1 + h->cs : h->cs;
-    const size_t lds = attn_lds_bytes(E, h->cs, h->W - 1 + h->cs > h->cs ? h->W - 1 + h->cs : h->cs);
+    const bool wide = h->W < 0 || !h->cfg.causal;
+    const int nkmax = wide ? 1 : (h->W - 1 + h->cs > h->cs ? h->W - 1 + h->cs : h->cs);
+    const size_t lds = attn_lds_bytes(E, h->cs, nkmax);
     for (int l = 0; l < L; ++l) {
         const LayerW& w = h->layers[l];
         hipLaunchKernelGGL(ln_mod_ln_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s,
@@ -837,6 +852,7 @@ int run_layers(after_denoiser* h, hipStream_t s, int row0, int rows, const int* 
         a.cs = h->cs;
         a.W = h->W;
         a.nkmax = nkmax;
+        a.causal = h->cfg.causal;
         {
             static int dbg = -1;
             if (dbg < 0) {
@@ -917,12 +933,11 @@ extern "C" int after_denoiser_create(const after_denoiser_cfg* cfg, const float*
                       cfg->mlp_multiplier > 0 && cfg->noise_embed_dims > 0 &&
                       cfg->noise_embed_dims % 2 == 0,
                   AFTER_E_INVALID, "unsupported DenoiserV2 dimensions");
-    AFTER_REQUIRE(cfg->causal == 1 && cfg->local_attention_size >= 0, AFTER_E_INVALID,
-                  "only the shipped attention pattern is built (causal chunk-wise mask with a "
-                  "finite local_attention_size); got causal=%d window=%d",
-                  cfg->causal, cfg->local_attention_size);
+    // shipped pattern: causal, finite window (banded kernel).  local_attention_size < 0 = all previous
+    // chunks and causal = 0 = no mask run on the general instantiation (transformerv2.py:204-220).
     AFTER_REQUIRE(cfg->attention_chunk_size >= 1 && cfg->attention_chunk_size <= kMaxChunk &&
-                      cfg->local_attention_size - 1 + cfg->attention_chunk_size <= kMaxKeys,
+                      (cfg->local_attention_size < 0 || !cfg->causal ||
+                       cfg->local_attention_size - 1 + cfg->attention_chunk_size <= kMaxKeys),
                   AFTER_E_INVALID, "attention window %d + chunk %d exceed the kernel's %d keys",
                   cfg->local_attention_size, cfg->attention_chunk_size, kMaxKeys);
     AFTER_REQUIRE(n_weights == AFTER_DENOISER_FIXED_WEIGHTS + AFTER_DENOISER_LAYER_WEIGHTS * L,
@@ -1378,6 +1393,8 @@ extern "C" int after_denoiser_enable_cache(after_denoiser* h, int cache_size, in
                                            int max_rows) {
     AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
     AFTER_REQUIRE(cache_size > 0 && max_steps > 0 && max_rows > 0, AFTER_E_INVALID, "bad cache sizes");
+    AFTER_REQUIRE(h->W >= 0 && h->cfg.causal, AFTER_E_INVALID,
+                  "streaming K/V caches need the causal, finite-window attention of the shipped configs");
     AFTER_REQUIRE(cache_size % h->cs == 0, AFTER_E_INVALID,
                   "cache size %d must be a multiple of the attention chunk %d (the chunk grid of "
                   "transformerv2.py:81 is laid over cache + new frames)", cache_size, h->cs);

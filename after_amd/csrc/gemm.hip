@@ -525,7 +525,10 @@ __global__ __launch_bounds__(128 * KS * RS) void gemm_f32_bal_kernel(GemmArgs g,
                    "v"(voff[w_]), "s"(sbase[w_] + (slab_) * BK)                                   \
                  : "memory"); /* m0 is a reserved register: hipcc never keeps a value in it across \
                                  statements (it rejects it in a clobber list), it re-materialises it \
-                                 before each of its own uses */
+                                 before each of its own uses.  ASSUMPTION tied to the compiler: the    \
+                                 hipcc version is pinned in after_amd/build.py (TESTED_HIP) and every   \
+                                 tile configuration has a bit-exact test (tests/test_gemm_gpu.py) to    \
+                                 re-run after a toolchain change */
 
     f32x4 acc[MT][NT];
 #pragma unroll

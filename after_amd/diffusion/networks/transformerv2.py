@@ -229,6 +229,9 @@ class DenoiserV2(nn.Module):
         LOCAL_ATTENTION_SIZE` (after_scripts/export.py:77-79) and sizes them with
         `max_diffusion_steps` / `max_batch_size` (network rows: 3 x clips under CFG)."""
         cache = self.local_attention_size if max_cache_size is None else max_cache_size
+        if cache is None or cache < 0 or not self.causal:
+            raise ValueError("streaming K/V caches need causal attention with a finite local_attention_size "
+                             "(export.py:73-79 binds max_cache_size = LOCAL_ATTENTION_SIZE)")
         # re-enabling with larger limits (a second Streamer on the same net) must be able to grow
         # the handle: the capacity lock of _ensure only guards forwards of an enabled stream
         self._streaming = False

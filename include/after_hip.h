@@ -52,8 +52,9 @@ typedef struct after_denoiser_cfg {
     int noise_embed_dims;     /* Fourier features of t (:483-485), even         */
     int n_layers;
     int mlp_multiplier;
-    int causal;               /* 1: chunk-wise causal mask (:206-216)           */
-    int local_attention_size; /* sliding window W; < 0 = all previous chunks    */
+    int causal;               /* 1: chunk-wise causal mask (:206-216); 0: no mask (general, slower kernel) */
+    int local_attention_size; /* sliding window W >= 0 (the shipped, banded kernel);
+                                 < 0 = all previous chunks (:211-213, general kernel, no K/V caches) */
     int attention_chunk_size; /* chunk size, 1..8                               */
 } after_denoiser_cfg;
 

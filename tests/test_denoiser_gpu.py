@@ -69,6 +69,34 @@ def test_denoiser_vs_oracle_shapes(B, T, hip_device):
         assert max_abs(gs.cpu(), w) < 2e-4, mode
 
 
+@pytest.mark.parametrize("causal,window", [(True, None), (True, -1), (False, 8), (False, None)])
+def test_unlimited_window_and_non_causal_attention(causal, window, hip_device):
+    """transformerv2.py:204-220: local_attention_size None / negative = chunk-wise causal over ALL
+    previous chunks (chunk_wise_causal_mask), causal=False = no mask.  No shipped config uses them;
+    they run on the general attention instantiation."""
+    fx = Fixture("denoiser_micro")
+    sd = fx.state_dict()
+    dcfg = configs.diffusion_config("micro")
+    ncfg = dict(dcfg["net"], causal=causal, local_attention_size=window)
+    net = DenoiserV2(**ncfg)
+    net.load_state_dict(sd, strict=True)
+    model = RectifiedFlow(net=net, sr=dcfg["sr"], drop_value=dcfg["drop_value"], device=hip_device)
+    g = torch.Generator().manual_seed(17)
+    B, T = 2, 45
+    x = torch.randn(B, ncfg["n_channels"], T, generator=g)
+    cond = torch.randn(B, ncfg["cond_dim"], generator=g)
+    tc = torch.randn(B, ncfg["tcond_dim"], T, generator=g)
+    t = torch.rand(B, generator=g)
+    want = oracle.denoiser_forward(sd, ncfg, x, t, cond, tc)
+    got = model.net(x.to(hip_device), t.to(hip_device), cond.to(hip_device), tc.to(hip_device))
+    assert max_abs(got.cpu(), want) < 5e-5
+    w = oracle.sample(sd, ncfg, x, cond, tc, 3, 2.0, 1.0)
+    gs = model.sample(x.to(hip_device), cond.to(hip_device), tc.to(hip_device), 3, 2.0, 1.0)
+    assert max_abs(gs.cpu(), w) < 2e-4
+    with pytest.raises(ValueError):
+        model.net.enable_streaming_cache()
+
+
 def test_sample_is_deterministic_and_reusable(hip_device):
     fx = Fixture("denoiser_micro")
     model, _ = build("micro", fx.state_dict(), hip_device)
