@@ -104,6 +104,10 @@ SIGNATURES = {
     "after_unet1d_destroy": (None, [c_void_p]),
     "after_unet1d_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                      c_int, c_void_p]),
+    "after_unet1d_model_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                           c_int, c_float, c_float, c_float, c_int, c_void_p]),
+    "after_unet1d_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                    c_float, c_float, c_float, c_int, c_void_p]),
     "after_gemm_set_debug": (None, [c_void_p]),
     "after_convtm_create": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                     c_int, c_int, POINTER(c_void_p)]),

@@ -86,6 +86,61 @@ __global__ __launch_bounds__(256) void upsample_nearest_kernel(const float* __re
     y[idx] = x[row * T + t / r];
 }
 
+// ---- classifier-free guidance around the network (model.py:721-785): everything on the device.
+// 3x batch of one evaluation: rows r = part * B + b;  x3 = x repeated; t3 = the step's time;
+// cond3 / tc3 = the conditioning or `drop` per the CFG arrangement (mode 2 = export_midi.py:329-358).
+__global__ __launch_bounds__(256) void cfg3_cond_kernel(const float* __restrict__ cond,
+                                                        const float* __restrict__ tc,
+                                                        float* __restrict__ cond3, float* __restrict__ tc3,
+                                                        int B, int CC, size_t tc_per, float drop, int midi) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n_c = (size_t)3 * B * CC, n_t = (size_t)3 * B * tc_per;
+    if (idx < n_c) {
+        const int r = idx / CC, b = r % B, part = r / B;
+        const bool keep = midi ? part <= 1 : part == 0;
+        cond3[idx] = keep ? cond[(size_t)b * CC + idx % CC] : drop;
+    }
+    if (idx < n_t) {
+        const size_t r = idx / tc_per;
+        const int b = r % B, part = r / B;
+        const bool keep = midi ? part == 0 : part <= 1;
+        tc3[idx] = keep ? tc[(size_t)b * tc_per + idx % tc_per] : drop;
+    }
+}
+
+// x3[r] = x[r % B];  t3[r] = time[r % B] (forward) or torch.linspace(0, 1, N + 1)[step] (sampler,
+// at::linspace's fp32 formula as in denoiser.hip / tests/test_boundary_cpu.py)
+__global__ __launch_bounds__(256) void cfg3_x_kernel(const float* __restrict__ x, float* __restrict__ x3,
+                                                     const float* __restrict__ time, float* __restrict__ t3,
+                                                     int B, size_t per, int step, int nb_steps) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx < (size_t)3 * B * per) x3[idx] = x[idx % ((size_t)B * per)];
+    if (idx < (size_t)3 * B) {
+        float t;
+        if (time) {
+            t = time[idx % B];
+        } else {
+            const int pts = nb_steps + 1;
+            const float st = __fdiv_rn(1.0f, (float)(pts - 1));
+            t = (step < pts / 2) ? __fmul_rn(st, (float)step) : __fmaf_rn(-st, (float)(pts - step - 1), 1.0f);
+        }
+        t3[idx] = t;
+    }
+}
+
+// out = xin * keep + dt * (d_none + total (d_mid + factor (d_full - d_mid) - d_none))
+// (keep = 1, dt = 1/N: Euler step; keep = 0, dt = 1: model_forward)
+__global__ __launch_bounds__(256) void cfg3_combine_kernel(const float* __restrict__ d3,
+                                                           const float* __restrict__ xin,
+                                                           float* __restrict__ out, size_t n, float total,
+                                                           float factor, float dt, float keep) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const float df = d3[idx], dm = d3[n + idx], dn = d3[2 * n + idx];
+    const float v = dn + total * (dm + factor * (df - dm) - dn);
+    out[idx] = (xin ? xin[idx] * keep : 0.f) + v * dt;
+}
+
 struct WCur {
     const float* const* w;
     int n, i = 0;
@@ -140,6 +195,8 @@ struct after_unet1d {
     float *cat = nullptr, *tmp = nullptr, *resb = nullptr, *xa = nullptr, *xb = nullptr, *ups = nullptr;
     std::vector<float*> skips, tconds;  // n each (+1 tcond for the middle block)
     int cmax = 0, ccat_max = 0;
+    // CFG workspaces (3x batch): allocated with the handle when max_batch is a multiple of 3
+    float *x3 = nullptr, *t3 = nullptr, *cond3 = nullptr, *tc3 = nullptr, *d3 = nullptr, *xs = nullptr;
 };
 
 namespace {
@@ -396,7 +453,9 @@ extern "C" int after_unet1d_create(const after_unet1d_cfg* cfg, const float* con
     const size_t act = Bm * cmax * T, catn = Bm * ccat_max * T, tcn = Bm * tcc * T;
     size_t bytes = (Bm * TC + 2 * Bm * cmax + 2 * Bm * ccat_max) * sizeof(float) +
                    Bm * 16 * 64 * 2 * sizeof(double) + Bm * 16 * sizeof(unsigned) +
-                   (catn + 5 * act + (size_t)n * act + (size_t)(n + 2) * tcn) * sizeof(float) + (1 << 16);
+                   (catn + 5 * act + (size_t)n * act + (size_t)(n + 2) * tcn) * sizeof(float) + (1 << 16) +
+                   (Bm * T * (size_t)(2 * in0 + outsz + cfg->time_cond_in_channels) + Bm * (CC + 1)) * sizeof(float) +
+                   8192;
     if ((rc = h->ws.init(bytes))) return fail(rc);
     h->emb = h->ws.take<float>(Bm * TC);
     h->ps = h->ws.take<float>(Bm * cmax);
@@ -415,7 +474,13 @@ extern "C" int after_unet1d_create(const after_unet1d_cfg* cfg, const float* con
     h->tconds.resize(n + 2);
     for (int i = 0; i < n; ++i) h->skips[i] = h->ws.take<float>(act);
     for (int i = 0; i < n + 2; ++i) h->tconds[i] = h->ws.take<float>(tcn);
-    if (!h->tconds[n + 1] || !h->skips[n - 1] || !h->ups) return fail(AFTER_E_NOMEM);
+    h->x3 = h->ws.take<float>(Bm * in0 * T);
+    h->d3 = h->ws.take<float>(Bm * outsz * T);
+    h->xs = h->ws.take<float>(Bm * in0 * T);
+    h->tc3 = h->ws.take<float>(Bm * cfg->time_cond_in_channels * T);
+    h->cond3 = h->ws.take<float>(Bm * CC);
+    h->t3 = h->ws.take<float>(Bm);
+    if (!h->tconds[n + 1] || !h->skips[n - 1] || !h->ups || !h->t3) return fail(AFTER_E_NOMEM);
     if (hipMemset(h->gn_tick, 0, Bm * 16 * sizeof(unsigned)) != hipSuccess ||
         hipDeviceSynchronize() != hipSuccess) {
         set_error("unet1d: device initialisation failed");
@@ -496,6 +561,89 @@ extern "C" int after_unet1d_forward(after_unet1d* h, const float* x, const float
         if (i < n && y == bx) y = h->ups;  // (identity `up`: keep input and output apart)
         AFTER_TRY(run_block(h, s, h->up[i - 1], bx, h->skips[n - i], h->tconds[n - i], cond, y, B, Tc));
         cur = y;
+    }
+    return AFTER_OK;
+}
+
+// ---- RectifiedFlow.model_forward / .sample around UNET1D (model.py:721-785), all on the device:
+// the 3x CFG batch is assembled by kernels, the network runs on 3B rows, the combination and the
+// Euler update are one kernel.  The handle must have been created with max_batch >= 3 B.
+namespace {
+
+int cfg_factors(int cfg_mode, float gt, float gs, float* total, float* factor) {
+    *total = 0.5f * (gs + gt);
+    if (cfg_mode == 0) *factor = gt / (gs > 0.01f ? gs : 0.01f);       // model.py:749-759
+    else if (cfg_mode == 1) *factor = gt / (gs > 0.1f ? gs : 0.1f);    // export.py:364-394
+    else if (cfg_mode == 2) *factor = gs / (gt > 0.1f ? gt : 0.1f);    // export_midi.py:329-358
+    else {
+        set_error("unet1d: unknown cfg_mode %d", cfg_mode);
+        return AFTER_E_INVALID;
+    }
+    return AFTER_OK;
+}
+
+int cfg_eval(after_unet1d* h, hipStream_t s, const float* x, const float* time, int step, int nb_steps, int B,
+             int T) {
+    const size_t per = (size_t)h->cfg.in_size * T;
+    const size_t n3 = 3 * (size_t)B * per;
+    hipLaunchKernelGGL(cfg3_x_kernel, dim3((unsigned)cdivll((long long)n3, 256)), dim3(256), 0, s, x, h->x3, time,
+                       h->t3, B, per, step, nb_steps);
+    AFTER_HIP_CHECK(hipGetLastError());
+    return after_unet1d_forward(h, h->x3, h->t3, h->cond3, h->tc3, h->d3, 3 * B, T, s);
+}
+
+int cfg_prepare(after_unet1d* h, hipStream_t s, const float* cond, const float* tc, int B, int T, float drop,
+                int cfg_mode) {
+    AFTER_REQUIRE(3 * B <= h->max_batch, AFTER_E_CAPACITY, "unet1d: CFG needs max_batch >= 3 B (B=%d, max_batch=%d)",
+                  B, h->max_batch);
+    AFTER_REQUIRE((h->cfg.out_size > 0 ? h->cfg.out_size : h->cfg.in_size) == h->cfg.in_size, AFTER_E_INVALID,
+                  "unet1d: the sampler needs out_size == in_size");
+    const size_t tc_per = (size_t)h->cfg.time_cond_in_channels * T;
+    const size_t n = 3 * (size_t)B * (tc_per > (size_t)h->cfg.cond_channels ? tc_per : h->cfg.cond_channels);
+    hipLaunchKernelGGL(cfg3_cond_kernel, dim3((unsigned)cdivll((long long)n, 256)), dim3(256), 0, s, cond, tc,
+                       h->cond3, h->tc3, B, h->cfg.cond_channels, tc_per, drop, cfg_mode == 2 ? 1 : 0);
+    AFTER_HIP_CHECK(hipGetLastError());
+    return AFTER_OK;
+}
+
+}  // namespace
+
+extern "C" int after_unet1d_model_forward(after_unet1d* h, const float* x, const float* time, const float* cond,
+                                          const float* time_cond, float* out, int B, int T, float g_timbre,
+                                          float g_structure, float drop_value, int cfg_mode, void* stream) {
+    AFTER_REQUIRE(h && x && time && cond && time_cond && out && B > 0 && T > 0, AFTER_E_INVALID, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    float total, factor;
+    AFTER_TRY(cfg_factors(cfg_mode, g_timbre, g_structure, &total, &factor));
+    AFTER_TRY(cfg_prepare(h, s, cond, time_cond, B, T, drop_value, cfg_mode));
+    AFTER_TRY(cfg_eval(h, s, x, time, 0, 1, B, T));
+    const size_t n = (size_t)B * h->cfg.in_size * T;
+    hipLaunchKernelGGL(cfg3_combine_kernel, dim3((unsigned)cdivll((long long)n, 256)), dim3(256), 0, s, h->d3,
+                       (const float*)nullptr, out, n, total, factor, 1.0f, 0.0f);
+    AFTER_HIP_CHECK(hipGetLastError());
+    return AFTER_OK;
+}
+
+extern "C" int after_unet1d_sample(after_unet1d* h, const float* x0, const float* cond, const float* time_cond,
+                                   float* out, int B, int T, int nb_steps, float g_timbre, float g_structure,
+                                   float drop_value, int cfg_mode, void* stream) {
+    AFTER_REQUIRE(h && x0 && cond && time_cond && out && B > 0 && T > 0 && nb_steps > 0, AFTER_E_INVALID,
+                  "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    float total, factor;
+    AFTER_TRY(cfg_factors(cfg_mode, g_timbre, g_structure, &total, &factor));
+    AFTER_TRY(cfg_prepare(h, s, cond, time_cond, B, T, drop_value, cfg_mode));
+    const size_t n = (size_t)B * h->cfg.in_size * T;
+    const float dt = 1.0f / (float)nb_steps;
+    const float* xin = x0;
+    for (int i = 0; i < nb_steps; ++i) {
+        AFTER_TRY(cfg_eval(h, s, xin, nullptr, i, nb_steps, B, T));
+        // ping-pong between out and the handle's scratch so that the last step lands in `out`
+        float* dst = ((nb_steps - 1 - i) & 1) ? h->xs : out;
+        hipLaunchKernelGGL(cfg3_combine_kernel, dim3((unsigned)cdivll((long long)n, 256)), dim3(256), 0, s, h->d3,
+                           xin, dst, n, total, factor, dt, 1.0f);
+        AFTER_HIP_CHECK(hipGetLastError());
+        xin = dst;
     }
     return AFTER_OK;
 }

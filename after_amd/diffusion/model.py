@@ -66,40 +66,14 @@ class RectifiedFlow(Base):
                       guidance_timbre: float,
                       guidance_structure: float,
                       cache_index: int = 0) -> torch.Tensor:
-        """model.py:721-761."""
-        if isinstance(self.net, DenoiserV2):
-            return self.net.cfg_forward(x, time, cond, time_cond, guidance_timbre, guidance_structure,
-                                        self.drop_value, self.cfg_mode, cache_index)
-        # UNET1D: the 3x CFG batch is assembled on the device with torch ops (plumbing), the
-        # network evaluation itself runs in libafter_hip
-        full_time = time.reshape(-1).repeat(3)
-        full_x = x.repeat(3, 1, 1)
-        dc, dt_ = self.drop_value * torch.ones_like(cond), self.drop_value * torch.ones_like(time_cond)
-        if self.cfg_mode == _lib.CFG_MIDI:
-            full_cond, full_tc = torch.cat([cond, cond, dc]), torch.cat([time_cond, dt_, dt_])
-        else:
-            full_cond, full_tc = torch.cat([cond, dc, dc]), torch.cat([time_cond, time_cond, dt_])
-        dx = self.net(full_x, time=full_time, cond=full_cond, time_cond=full_tc)
-        dx_full, dx_mid, dx_none = torch.chunk(dx, 3, dim=0)
-        total = 0.5 * (guidance_structure + guidance_timbre)
-        if self.cfg_mode == _lib.CFG_API:
-            factor = guidance_timbre / max(guidance_structure, 0.01)
-        elif self.cfg_mode == _lib.CFG_EXPORT:
-            factor = guidance_timbre / max(guidance_structure, 0.1)
-        else:
-            factor = guidance_structure / max(guidance_timbre, 0.1)
-        return dx_none + total * (dx_mid + factor * (dx_full - dx_mid) - dx_none)
+        """model.py:721-761.  Both networks evaluate the 3x CFG batch, the guidance combination (and,
+        in `sample`, the Euler update) inside libafter_hip."""
+        return self.net.cfg_forward(x, time, cond, time_cond, guidance_timbre, guidance_structure,
+                                    self.drop_value, self.cfg_mode, cache_index)
 
     @torch.no_grad()
     def sample(self, x0, cond, time_cond, nb_steps, guidance_timbre=1., guidance_structure=1.):
         """model.py:763-785."""
         x0 = x0.to(self.device)
-        if isinstance(self.net, DenoiserV2):
-            return self.net.cfg_sample(x0, cond, time_cond, nb_steps, guidance_timbre,
-                                       guidance_structure, self.drop_value, self.cfg_mode)
-        dt = 1 / nb_steps
-        x = x0
-        for t in torch.linspace(0, 1, nb_steps + 1)[:-1]:
-            tt = t.to(x0.device).repeat(x.shape[0], 1, 1)
-            x = x + self.model_forward(x, tt, cond, time_cond, guidance_timbre, guidance_structure) * dt
-        return x
+        return self.net.cfg_sample(x0, cond, time_cond, nb_steps, guidance_timbre, guidance_structure,
+                                   self.drop_value, self.cfg_mode)

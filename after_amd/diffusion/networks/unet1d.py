@@ -210,3 +210,47 @@ class UNET1D(nn.Module):
                                                        _lib.ptr(time_cond), _lib.ptr(out), B, T,
                                                        _lib.current_stream(x.device)), "after_unet1d_forward")
         return out
+
+    # ------------------------------------------------------------ sampler back end (RectifiedFlow)
+    def _check_cfg_inputs(self, x, cond, time_cond):
+        x = _lib.require_gpu_tensor(x, "x")
+        B, C, T = x.shape
+        cond = _lib.require_gpu_tensor(cond.to(x.device), "cond")
+        time_cond = _lib.require_gpu_tensor(time_cond.to(x.device), "time_cond")
+        if C != self.in_size or self.out_size != self.in_size or T % self.total_ratio or \
+                tuple(cond.shape) != (B, self.cond_channels) or \
+                tuple(time_cond.shape) != (B, self.time_cond_in_channels, T):
+            raise ValueError(f"bad shapes x{tuple(x.shape)} cond{tuple(cond.shape)} time_cond{tuple(time_cond.shape)}")
+        return x, cond, time_cond, B, T
+
+    @torch.no_grad()
+    def cfg_forward(self, x, time, cond, time_cond, guidance_timbre, guidance_structure, drop_value,
+                    cfg_mode=_lib.CFG_API, cache_index=0):
+        """RectifiedFlow.model_forward (model.py:721-761) on the device (after_unet1d_model_forward)."""
+        x, cond, time_cond, B, T = self._check_cfg_inputs(x, cond, time_cond)
+        time = _lib.require_gpu_tensor(time.reshape(-1).to(x.device), "time")
+        if time.numel() != B:
+            raise ValueError(f"time has {time.numel()} entries for batch {B}")
+        h = self._ensure(3 * B, T)
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().after_unet1d_model_forward(
+                h, _lib.ptr(x), _lib.ptr(time), _lib.ptr(cond), _lib.ptr(time_cond), _lib.ptr(out), B, T,
+                float(guidance_timbre), float(guidance_structure), float(drop_value), int(cfg_mode),
+                _lib.current_stream(x.device)), "after_unet1d_model_forward")
+        return out
+
+    @torch.no_grad()
+    def cfg_sample(self, x0, cond, time_cond, nb_steps, guidance_timbre, guidance_structure, drop_value,
+                   cfg_mode=_lib.CFG_API, out=None):
+        """RectifiedFlow.sample (model.py:763-785): the whole Euler loop inside after_unet1d_sample."""
+        x0, cond, time_cond, B, T = self._check_cfg_inputs(x0, cond, time_cond)
+        h = self._ensure(3 * B, T)
+        if out is None:
+            out = torch.empty_like(x0)
+        with torch.cuda.device(x0.device):
+            _lib.check(_lib.lib().after_unet1d_sample(
+                h, _lib.ptr(x0), _lib.ptr(cond), _lib.ptr(time_cond), _lib.ptr(out), B, T, int(nb_steps),
+                float(guidance_timbre), float(guidance_structure), float(drop_value), int(cfg_mode),
+                _lib.current_stream(x0.device)), "after_unet1d_sample")
+        return out

@@ -312,6 +312,16 @@ void after_unet1d_destroy(after_unet1d* h);
  * time_cond[B, time_cond_in_channels, T]).  Replaces: UNET1D.forward (unet1d.py:374-414). */
 int after_unet1d_forward(after_unet1d* h, const float* x, const float* time, const float* cond,
                          const float* time_cond, float* out, int B, int T, void* stream);
+/* RectifiedFlow.model_forward / .sample (model.py:721-785) around UNET1D, entirely on the device:
+ * the 3x classifier-free-guidance batch, the network on 3 B rows, the guidance combination and the
+ * Euler update.  cfg_mode as after_sample.  Needs a handle created with max_batch >= 3 B and
+ * out_size == in_size. */
+int after_unet1d_model_forward(after_unet1d* h, const float* x, const float* time, const float* cond,
+                               const float* time_cond, float* out, int B, int T, float g_timbre,
+                               float g_structure, float drop_value, int cfg_mode, void* stream);
+int after_unet1d_sample(after_unet1d* h, const float* x0, const float* cond, const float* time_cond,
+                        float* out, int B, int T, int nb_steps, float g_timbre, float g_structure,
+                        float drop_value, int cfg_mode, void* stream);
 
 /* ------------------------------------------------------------ diagnostics
  * Not part of the reference's surface: the fp32 MFMA GEMM behind every Linear,

@@ -74,3 +74,35 @@ def test_rectified_flow_samples_with_unet(hip_device):
         x = x + (d_none + 1.5 * (d_mid + 2.0 / max(1.0, 0.01) * (d_full - d_mid) - d_none)) * (1 / N)
     got = model.sample(x0.to(hip_device), cond.to(hip_device), tc.to(hip_device), N, 2.0, 1.0).cpu()
     assert max_abs(got, x) < 5e-4 * max(1.0, x.abs().max().item())
+
+
+@pytest.mark.parametrize("mode", [_lib.CFG_API, _lib.CFG_EXPORT, _lib.CFG_MIDI])
+def test_unet_model_forward_cfg_modes(mode, hip_device):
+    """model_forward's three CFG arrangements (model.py:730-759, export.py:364-394,
+    export_midi.py:329-358) assembled, evaluated and combined on the device."""
+    fx = Fixture("unet_micro")
+    sd = fx.state_dict()
+    cfg = configs.unet_config("unet_micro")
+    net = build("unet_micro", sd, hip_device)
+    model = RectifiedFlow(net=net, sr=44100, device=hip_device)
+    model.cfg_mode = mode
+    g = torch.Generator().manual_seed(9)
+    B, T = 3, 32
+    x = torch.randn(B, 16, T, generator=g)
+    tc = torch.randn(B, 12, T, generator=g)
+    cond = torch.randn(B, 6, generator=g)
+    t = torch.rand(B, generator=g)
+    gt, gs = 1.7, 0.05
+    dc, dt_ = -4.0 * torch.ones_like(cond), -4.0 * torch.ones_like(tc)
+    if mode == _lib.CFG_MIDI:
+        c3, t3 = torch.cat([cond, cond, dc]), torch.cat([tc, dt_, dt_])
+        factor = gs / max(gt, 0.1)
+    else:
+        c3, t3 = torch.cat([cond, dc, dc]), torch.cat([tc, tc, dt_])
+        factor = gt / max(gs, 0.01 if mode == _lib.CFG_API else 0.1)
+    dx = oracle.unet1d_forward(sd, cfg, x.repeat(3, 1, 1), t.repeat(3), c3, t3)
+    d_full, d_mid, d_none = dx.chunk(3, 0)
+    want = d_none + 0.5 * (gt + gs) * (d_mid + factor * (d_full - d_mid) - d_none)
+    got = model.model_forward(x.to(hip_device), t.reshape(B, 1, 1).to(hip_device), cond.to(hip_device),
+                              tc.to(hip_device), gt, gs).cpu()
+    assert max_abs(got, want) < 5e-4 * max(1.0, want.abs().max().item())
