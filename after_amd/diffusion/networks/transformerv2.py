@@ -190,6 +190,9 @@ class DenoiserV2(nn.Module):
         L = _lib.lib()
         self._release()
         cap = (max(rows, cr), max(T, ct), max(steps, cs, 1))
+        if self._stream_args is not None and not getattr(self, "_enabling", False):
+            _, st_steps, st_rows, st_frames = self._stream_args  # a rebuilt handle must hold the caches again
+            cap = (max(cap[0], st_rows), max(cap[1], st_frames), max(cap[2], st_steps))
         ws = self._weights()
         arr = (ctypes.c_void_p * len(ws))(*[w.data_ptr() for w in ws])
         cfg = _lib.DenoiserCfg(

@@ -195,6 +195,34 @@ def test_load_diffusion_and_autoencoder_from_run_folders(tmp_path):
     assert all(torch.equal(got[k], v) for k, v in ae_sd.items())
 
 
+def test_unsupported_bottleneck_and_activation_are_refused(tmp_path):
+    """The bottleneck has no parameters, so a checkpoint cannot reveal that the codec was trained with
+    TanhBottleneck (z = scale * tanh(z)) or VAEBottleneck (2x encoder channels): the config decides."""
+    for bn in ("TanhBottleneck", "VAEBottleneck"):
+        cfg = GinConfig.parse_string(BLOCK_AE.replace("@SimpleNetsStream.ReluBottleneck()", f"@SimpleNetsStream.{bn}()"))
+        with pytest.raises(NotImplementedError):
+            checkpoint.autoencoder_from_config(cfg, device="cpu")
+    cfg = GinConfig.parse_string(BLOCK_AE + "\nSimpleNetsStream.AutoEncoder.activation = @torch.nn.ReLU\n")
+    with pytest.raises(NotImplementedError):
+        checkpoint.autoencoder_from_config(cfg, device="cpu")
+    ae = checkpoint.autoencoder_from_config(GinConfig.parse_string(BLOCK_AE), device="cpu")
+    assert ae.bottleneck.scale == 3.0
+    # torch.load stays weights_only unless the caller vouches for the file
+    import pickle
+
+    class Evil:
+        def __reduce__(self):
+            return (print, ("unpickled",))
+
+    run = tmp_path / "run"
+    run.mkdir()
+    (run / "config.gin").write_text(OPERATIVE)
+    with open(run / "checkpoint1_EMA.pt", "wb") as f:
+        pickle.dump({"model_state": {}, "x": Evil()}, f)
+    with pytest.raises(RuntimeError):
+        checkpoint.load_diffusion(str(run), device="cpu")
+
+
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 

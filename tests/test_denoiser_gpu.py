@@ -174,3 +174,29 @@ def test_streaming_kv_cache_matches_reference(hip_device):
     with pytest.raises(_lib.AFTERHipError):
         model.net(x[..., :2 * chunk].contiguous(), torch.zeros(B, device=hip_device), cond,
                   tc[..., :2 * chunk].contiguous())  # beyond the capacity fixed at enable time
+
+
+def test_strided_views_and_cache_reenable(hip_device):
+    """Host-side hardening: row-strided conditioning views are densified before their bare pointer
+    crosses the C ABI; the streaming caches can be re-enabled with larger limits and survive a
+    handle rebuild (.to / load_state_dict)."""
+    fx = Fixture("denoiser_micro")
+    sd = fx.state_dict()
+    model, dcfg = build("micro", sd, hip_device)
+    d = lambda n: fx.t(n).to(hip_device)
+    x, cond, tc, tvec = d("x"), d("cond"), d("time_cond"), d("tvec")
+    wide = torch.cat((cond, torch.full_like(cond, 7.0)), 1)  # [B, 2 ZT]: cond is a column slice of it
+    view = wide[:, :cond.shape[1]]
+    assert not view.is_contiguous()
+    a = model.net(x, time=tvec, cond=cond, time_cond=tc)
+    b = model.net(x, time=tvec, cond=view, time_cond=tc)
+    assert torch.equal(a, b)
+    net = model.net
+    net.enable_streaming_cache(max_diffusion_steps=2, max_batch_size=3, max_frames=4)
+    net.enable_streaming_cache(max_diffusion_steps=4, max_batch_size=6, max_frames=8)  # grow: must not raise
+    B = x.shape[0]
+    y1 = net(x[..., :8].contiguous(), tvec, cond, tc[..., :8].contiguous(), cache_index=3)
+    net.refresh()  # handle rebuilt: the cache comes back (zeroed = new stream), same first-chunk output
+    y2 = net(x[..., :8].contiguous(), tvec, cond, tc[..., :8].contiguous(), cache_index=3)
+    assert torch.equal(y1, y2)
+    net.roll_cache(8, 3)
