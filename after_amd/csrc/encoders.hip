@@ -105,39 +105,57 @@ __global__ void tanh_kernel(float* x, int n) {
 }
 
 // ---- time-major ([B][T][C]) variants used by ECAPA on the conv_tm path
-// per-(b, c) statistics over time, one thread per channel (consecutive threads = consecutive
-// channels: coalesced rows).  Same arithmetic as time_stats_kernel.
+// per-(b, c) statistics over time: a block owns 64 consecutive channels (coalesced rows) and
+// splits T over its 4 waves; the three passes of time_stats_kernel (max, weighted sums, weighted
+// variance) each end in a 4-way LDS combine.  Same arithmetic as time_stats_kernel up to the
+// association of the T sums.
 __global__ __launch_bounds__(256) void time_stats_tm_kernel(const float* __restrict__ z, int ldz,
                                                             const float* __restrict__ logits, int ldl,
                                                             float* __restrict__ out,
                                                             const float* __restrict__ post_scale,
                                                             const float* __restrict__ post_shift, int C,
                                                             int T, int only_mean) {
-    const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (c >= C) return;
-    const float* zr = z + (size_t)b * T * ldz + c;
-    const float* lr = logits ? logits + (size_t)b * T * ldl + c : nullptr;
+    __shared__ float sh[3][4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl, b = blockIdx.y;
+    const bool ok = c < C;
+    const int per = (T + 3) / 4, t_lo = sl * per, t_hi = min(T, t_lo + per);
+    const float* zr = z + (size_t)b * T * ldz + (ok ? c : 0);
+    const float* lr = logits ? logits + (size_t)b * T * ldl + (ok ? c : 0) : nullptr;
     float mx = -INFINITY;
     if (lr) {
 #pragma unroll 8
-        for (int t = 0; t < T; ++t) mx = fmaxf(mx, lr[(size_t)t * ldl]);
+        for (int t = t_lo; t < t_hi; ++t) mx = fmaxf(mx, lr[(size_t)t * ldl]);
+        sh[0][sl][cl] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(sh[0][0][cl], sh[0][1][cl]), fmaxf(sh[0][2][cl], sh[0][3][cl]));
     }
     float se = 0.f, sz = 0.f;
 #pragma unroll 8
-    for (int t = 0; t < T; ++t) {
+    for (int t = t_lo; t < t_hi; ++t) {
         const float w = lr ? expf(lr[(size_t)t * ldl] - mx) : 1.0f;
         se += w;
         sz += w * zr[(size_t)t * ldz];
     }
+    sh[1][sl][cl] = se;
+    sh[2][sl][cl] = sz;
+    __syncthreads();
+    se = (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]);
+    sz = (sh[2][0][cl] + sh[2][1][cl]) + (sh[2][2][cl] + sh[2][3][cl]);
     const float inv = 1.0f / se;
     const float mean = sz * inv;
     float sv = 0.f;
 #pragma unroll 8
-    for (int t = 0; t < T; ++t) {
+    for (int t = t_lo; t < t_hi; ++t) {
         const float w = (lr ? expf(lr[(size_t)t * ldl] - mx) : 1.0f) * inv;
         const float d = zr[(size_t)t * ldz] - mean;
         sv += w * d * d;
     }
+    __syncthreads();  // the sums above have been read by every wave
+    sh[0][sl][cl] = sv;
+    __syncthreads();
+    if (sl != 0 || !ok) return;
+    sv = (sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]);
     float m = mean, sd = sqrtf(fmaxf(sv, 1e-12f));
     const int w2 = only_mean ? C : 2 * C;
     if (post_scale) {
@@ -146,6 +164,34 @@ __global__ __launch_bounds__(256) void time_stats_tm_kernel(const float* __restr
     }
     out[(size_t)b * w2 + c] = m;
     if (!only_mean) out[(size_t)b * w2 + C + c] = sd;
+}
+
+// out[m, n] = epi(sum_k a[m, k] w[n, k] + bias[n]) for the handful of per-clip vectors of ECAPA
+// (SE squeeze, attention context bias, final fc: M = B rows, K up to 3072): one wave per output.
+__global__ __launch_bounds__(256) void rowvec_gemm_kernel(const float* __restrict__ a, int lda,
+                                                          const float* __restrict__ w, int ldw,
+                                                          const float* __restrict__ bias,
+                                                          float* __restrict__ out, int ldo, int M, int N,
+                                                          int K, int epi) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (o >= M * N) return;
+    const int m = o / N, n = o - m * N;
+    const float* ar = a + (size_t)m * lda;
+    const float* wr = w + (size_t)n * ldw;
+    float acc = 0.f;
+    for (int k = 4 * lane; k < K; k += 256) {  // K % 4 == 0, rows 16-byte aligned
+        const f32x4 av = *reinterpret_cast<const f32x4*>(ar + k);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k);
+        acc += (av[0] * wv[0] + av[1] * wv[1]) + (av[2] * wv[2] + av[3] * wv[3]);
+    }
+#pragma unroll
+    for (int s2 = 32; s2 > 0; s2 >>= 1) acc += __shfl_xor(acc, s2, 64);
+    if (lane == 0) {
+        float v = acc + (bias ? bias[n] : 0.f);
+        if (epi == EPI_RELU) v = fmaxf(v, 0.f);
+        else if (epi == EPI_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+        out[(size_t)m * ldo + n] = v;
+    }
 }
 
 // y[b][t][c] = s[b][c] * x[b][t][c] + res[b][t][c] on row-pitched views (4 channels per thread)
@@ -669,6 +715,15 @@ int run_tdnn(const TdnnW& t, hipStream_t s, const TdnnIo& io, int B, int T) {
 
 int gemm_rows(hipStream_t s, const float* A, int lda, const float* W, int ldw, const float* bias,
               float* C, int ldc, int M, int N, int K, int epi) {
+    if ((long long)M * N <= 16384 && (K & 3) == 0 && (lda & 3) == 0 && (ldw & 3) == 0 &&
+        (epi == EPI_NONE || epi == EPI_RELU || epi == EPI_SIGMOID)) {
+        // a few rows x a few hundred outputs: one wave per output beats any tile (the MFMA GEMM needs
+        // 16 rows and pays ~8-16 us for M = 1)
+        hipLaunchKernelGGL(rowvec_gemm_kernel, dim3(cdiv(M * N, 4)), dim3(256), 0, s, A, lda, W, ldw, bias, C, ldc,
+                           M, N, K, epi);
+        AFTER_HIP_CHECK(hipGetLastError());
+        return AFTER_OK;
+    }
     GemmArgs g{A, lda, W, ldw, bias, nullptr, 0, C, ldc, M, N, K, epi};
     return launch_gemm(g, s);
 }
@@ -950,7 +1005,7 @@ extern "C" int after_ecapa_forward(after_ecapa* h, const float* z, float* out, i
             AFTER_TRY(run_tdnn(b.tdnn2, s, io, B, T));
         }
         // SE: s = sigmoid(W2 relu(W1 mean_t(x) + b1) + b2)
-        hipLaunchKernelGGL(time_stats_tm_kernel, dim3(cdiv(co, 256), B), dim3(256), 0, s, h->t0, co,
+        hipLaunchKernelGGL(time_stats_tm_kernel, dim3(cdiv(co, 64), B), dim3(256), 0, s, h->t0, co,
                            (const float*)nullptr, 0, h->vecA, (const float*)nullptr, (const float*)nullptr, co,
                            T, 1);
         AFTER_HIP_CHECK(hipGetLastError());
@@ -992,7 +1047,7 @@ extern "C" int after_ecapa_forward(after_ecapa* h, const float* z, float* out, i
         AFTER_TRY(run_tdnn(h->mfa, s, io, B, T));
     }
     // attentive statistics pooling with global context
-    hipLaunchKernelGGL(time_stats_tm_kernel, dim3(cdiv(CL, 256), B), dim3(256), 0, s, h->t2, CL,
+    hipLaunchKernelGGL(time_stats_tm_kernel, dim3(cdiv(CL, 64), B), dim3(256), 0, s, h->t2, CL,
                        (const float*)nullptr, 0, h->vecA, (const float*)nullptr, (const float*)nullptr, CL, T, 0);
     AFTER_HIP_CHECK(hipGetLastError());
     // per-clip bias = W[:, CL:3CL] [mean | std] + b
@@ -1025,7 +1080,7 @@ extern "C" int after_ecapa_forward(after_ecapa* h, const float* z, float* out, i
         io.plain = true;
         AFTER_TRY(run_tdnn(h->asp_conv_t, s, io, B, T));
     }
-    hipLaunchKernelGGL(time_stats_tm_kernel, dim3(cdiv(CL, 256), B), dim3(256), 0, s, h->t2, CL, logits, CL,
+    hipLaunchKernelGGL(time_stats_tm_kernel, dim3(cdiv(CL, 64), B), dim3(256), 0, s, h->t2, CL, logits, CL,
                        h->vecA, h->asp_bn.scale, h->asp_bn.shift, CL, T, 0);
     AFTER_HIP_CHECK(hipGetLastError());
     AFTER_TRY(gemm_rows(s, h->vecA, 2 * CL, h->fc.w, 2 * CL, h->fc.bias, out, c.out_dim, B, c.out_dim,
