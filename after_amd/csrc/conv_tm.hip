@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void act_pad_tm_kernel(ActTmArgs a) {
     const int r = threadIdx.x / Q, q = threadIdx.x - r * Q;
     const int b = blockIdx.y, c0 = 4 * q;
     const bool active = r < R;
-    __shared__ float gmean[8], grstd[8];
+    __shared__ float gmean[16], grstd[16];
     constexpr int U = 4;
     // Block id i runs on XCD i % 8 (private L2s).  With xcd_rows the row blocks are dealt so that XCD j
     // owns the j-th eighth of the rows -- the same rows XCD j wrote as the previous conv's output and
@@ -612,9 +612,10 @@ __global__ void repack_tm_kernel(const float* __restrict__ w, float* __restrict_
     out[idx] = ci < Cin ? w[(pc * taps + tap) * Cin_pad + ci] : 0.f;
 }
 
-// stats[b][g] += (sum, sum of squares) of x[b, :, group g] (time-major) for producers that are
-// not convs (the PQMF analysis bank)
-__global__ __launch_bounds__(256) void stats_accum_tm_kernel(const float* __restrict__ x,
+// stats[b][g] += (sum, sum of squares) of x[b, :, group g] (time-major, row pitch ld) for producers
+// that are not convs (the PQMF analysis bank) and for concatenated tensors (UNET1D).  A thread keeps
+// its channels (tid, tid + 256, ...) across the block's rows and adds its sums to LDS once.
+__global__ __launch_bounds__(256) void stats_accum_tm_kernel(const float* __restrict__ x, int ld,
                                                              double* __restrict__ stats, int C, int T,
                                                              int G, int rows_per_block) {
     __shared__ float sh[2][16];
@@ -622,18 +623,31 @@ __global__ __launch_bounds__(256) void stats_accum_tm_kernel(const float* __rest
     const int Cg = C / G;
     if (threadIdx.x < 32) (&sh[0][0])[threadIdx.x] = 0.f;
     __syncthreads();
-    const int R = 256 / C > 0 ? 256 / C : 1;
-    const int r = threadIdx.x / C, c = threadIdx.x - r * C;
-    float s = 0.f, q = 0.f;
-    if (r < R && c < C) {
-        const int lo = blockIdx.x * rows_per_block, hi = min(lo + rows_per_block, T);
-        for (int t = lo + r; t < hi; t += R) {
-            const float v = x[((size_t)b * T + t) * C + c];
-            s += v;
-            q += v * v;
+    const int lo = blockIdx.x * rows_per_block, hi = min(lo + rows_per_block, T);
+    if (C <= 128) {  // several rows per pass
+        const int R = 256 / C;
+        const int r = threadIdx.x / C, c = threadIdx.x - r * C;
+        float s = 0.f, q = 0.f;
+        if (r < R) {
+            for (int t = lo + r; t < hi; t += R) {
+                const float v = x[((size_t)b * T + t) * ld + c];
+                s += v;
+                q += v * v;
+            }
+            atomicAdd(&sh[0][c / Cg], s);
+            atomicAdd(&sh[1][c / Cg], q);
         }
-        atomicAdd(&sh[0][c / Cg], s);
-        atomicAdd(&sh[1][c / Cg], q);
+    } else {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float s = 0.f, q = 0.f;
+            for (int t = lo; t < hi; ++t) {
+                const float v = x[((size_t)b * T + t) * ld + c];
+                s += v;
+                q += v * v;
+            }
+            atomicAdd(&sh[0][c / Cg], s);
+            atomicAdd(&sh[1][c / Cg], q);
+        }
     }
     __syncthreads();
     if (threadIdx.x < G) {
@@ -641,6 +655,55 @@ __global__ __launch_bounds__(256) void stats_accum_tm_kernel(const float* __rest
         atomicAdd(sp, (double)sh[0][threadIdx.x]);
         atomicAdd(sp + 1, (double)sh[1][threadIdx.x]);
     }
+}
+
+// dst[b][t][coff + c] = src[b][t][c]  (row-pitched views; one thread per 4 channels when aligned)
+__global__ __launch_bounds__(256) void copy_cols_tm_kernel(const float* __restrict__ src, int lds_,
+                                                           float* __restrict__ dst, int ldd, int C, size_t rows,
+                                                           int vec) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (vec) {
+        const int q = C >> 2;
+        if (idx >= rows * q) return;
+        const size_t r = idx / q;
+        const int c = 4 * (int)(idx - r * q);
+        *reinterpret_cast<f32x4*>(dst + r * ldd + c) = *reinterpret_cast<const f32x4*>(src + r * lds_ + c);
+    } else {
+        if (idx >= rows * C) return;
+        const size_t r = idx / C;
+        const int c = (int)(idx - r * C);
+        dst[r * ldd + c] = src[r * lds_ + c];
+    }
+}
+
+// [B][C][T] -> [B][T][ld] (columns coff ..): 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void cm_to_tm_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
+                                                       int T, int ld) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, t = t0 + tx;
+        tile[i][tx] = (c < C && t < T) ? x[((size_t)b * C + c) * T + t] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int t = t0 + i, c = c0 + tx;
+        if (t < T && c < C) y[((size_t)b * T + t) * ld + c] = tile[tx][i];
+    }
+}
+
+// nn.Upsample(mode='nearest', scale_factor=r) on time-major rows: y[b][t][:] = x[b][t / r][:]
+__global__ __launch_bounds__(256) void upsample_rows_tm_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                               int C, int T, int r, size_t total4) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total4) return;
+    const int q = C >> 2;
+    const size_t row = idx / q;  // b * T * r + t_out
+    const int c = 4 * (int)(idx - row * q);
+    const size_t b = row / ((size_t)T * r);
+    const size_t to = row - b * (size_t)T * r;
+    *reinterpret_cast<f32x4*>(y + row * C + c) = *reinterpret_cast<const f32x4*>(x + (b * T + to / r) * C + c);
 }
 
 template <int MB, int NB, int KS, int NS, int RS>
@@ -758,7 +821,7 @@ int launch_act_pad_tm(const ActPadTm& p, hipStream_t s) {
     a.eps = 1e-5f;
     AFTER_REQUIRE(a.Cp <= 1024, AFTER_E_INVALID, "act_pad_tm: at most 1024 channels (got %d)", p.C);
     AFTER_REQUIRE(!p.x_cm ? ((a.ldx & 3) == 0 || p.C < 4) : true, AFTER_E_INVALID, "act_pad_tm: ldx %% 4 != 0");
-    AFTER_REQUIRE(!p.stats || (p.C % p.G) == 0, AFTER_E_INVALID, "act_pad_tm: C %% G != 0");
+    AFTER_REQUIRE(!p.stats || ((p.C % p.G) == 0 && p.G <= 16), AFTER_E_INVALID, "act_pad_tm: G | C, G <= 16");
     const int Q = a.Cp / 4, R = 256 / Q;
     // >= ~3 blocks per CU where the tensor allows, >= 4 passes per block
     int rpb = R * 4;
@@ -784,11 +847,36 @@ int launch_act_pad_tm(const ActPadTm& p, hipStream_t s) {
     return AFTER_OK;
 }
 
-int launch_stats_accum_tm(const float* x, double* stats, int B, int C, int T, int G, hipStream_t s) {
-    AFTER_REQUIRE(C <= 256 && G <= 16 && C % G == 0, AFTER_E_INVALID, "stats_accum_tm: C <= 256, G <= 16");
-    int rpb = 64;
+int launch_stats_accum_tm(const float* x, double* stats, int B, int C, int T, int G, hipStream_t s, int ld) {
+    AFTER_REQUIRE(G >= 1 && G <= 16 && C % G == 0, AFTER_E_INVALID, "stats_accum_tm: G <= 16, G | C");
+    int rpb = C <= 128 ? 64 : 16;
     while ((long long)cdiv(T, rpb) * B > 1024) rpb *= 2;
-    hipLaunchKernelGGL(stats_accum_tm_kernel, dim3(cdiv(T, rpb), B), dim3(256), 0, s, x, stats, C, T, G, rpb);
+    hipLaunchKernelGGL(stats_accum_tm_kernel, dim3(cdiv(T, rpb), B), dim3(256), 0, s, x, ld > 0 ? ld : C, stats, C,
+                       T, G, rpb);
+    AFTER_HIP_CHECK(hipGetLastError());
+    return AFTER_OK;
+}
+
+int launch_copy_cols_tm(const float* src, int ld_src, float* dst, int ld_dst, int C, size_t rows, hipStream_t s) {
+    const int vec = ((C | ld_src | ld_dst) & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
+    const size_t n = vec ? rows * (C >> 2) : rows * C;
+    hipLaunchKernelGGL(copy_cols_tm_kernel, dim3((unsigned)cdivll((long long)n, 256)), dim3(256), 0, s, src, ld_src,
+                       dst, ld_dst, C, rows, vec);
+    AFTER_HIP_CHECK(hipGetLastError());
+    return AFTER_OK;
+}
+
+int launch_cm_to_tm(const float* x, float* y, int B, int C, int T, int ld, hipStream_t s) {
+    hipLaunchKernelGGL(cm_to_tm_kernel, dim3(cdiv(T, 32), cdiv(C, 32), B), dim3(256), 0, s, x, y, C, T, ld);
+    AFTER_HIP_CHECK(hipGetLastError());
+    return AFTER_OK;
+}
+
+int launch_upsample_rows_tm(const float* x, float* y, int B, int C, int T, int r, hipStream_t s) {
+    AFTER_REQUIRE((C & 3) == 0, AFTER_E_INVALID, "upsample_rows_tm: C %% 4 != 0");
+    const size_t total4 = (size_t)B * T * r * (C >> 2);
+    hipLaunchKernelGGL(upsample_rows_tm_kernel, dim3((unsigned)cdivll((long long)total4, 256)), dim3(256), 0, s, x, y,
+                       C, T, r, total4);
     AFTER_HIP_CHECK(hipGetLastError());
     return AFTER_OK;
 }
@@ -881,8 +969,8 @@ int launch_conv_tm(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan
         a.abase[ph] = (HALO + in.toff[ph][0]) * a.x_ld;
         a.ooff[ph] = in.ooff[ph];
     }
-    AFTER_REQUIRE(!r.stats || (in.Cout % r.G == 0 && r.G <= 8), AFTER_E_INVALID,
-                  "conv_tm: fused statistics need G | Cout, G <= 8 (Cout=%d G=%d)", in.Cout, r.G);
+    AFTER_REQUIRE(!r.stats || (in.Cout % r.G == 0 && r.G <= 16), AFTER_E_INVALID,
+                  "conv_tm: fused statistics need G | Cout, G <= 16 (Cout=%d G=%d)", in.Cout, r.G);
     AFTER_REQUIRE((size_t)r.Tp * a.x_ld < (1u << 28) && (size_t)in.Cout * p.K < (1u << 28), AFTER_E_INVALID,
                   "conv_tm: operand too large for 32-bit DMA offsets");
     AFTER_REQUIRE((a.x_ld & 3) == 0 && ((uintptr_t)r.xp & 15) == 0, AFTER_E_INVALID, "conv_tm: input row pitch / base alignment");

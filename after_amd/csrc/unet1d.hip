@@ -2,10 +2,12 @@
 // after/diffusion/networks/unet1d.py:254-429, blocks :29-252) on gfx950.
 //
 // Not selected by any shipped gin config (all four use DenoiserV2); built from SURVEY 8(f)-4 on
-// the conv family of conv.hip: GroupNorm folded to a per-(clip, channel) affine
-// (gn_affine_kernel), SiLU applied while the tile is staged, implicit-GEMM conv on the fp32
-// MFMA pipe, FiLM (time and cond modulation, unet1d.py:100-110) as a per-(clip, channel)
-// affine in the conv epilogue, strided pools via istride, nearest upsampling materialised.
+// the time-major conv path of conv_tm.hip: activations [B][T][C], channel concatenation = column
+// ranges of one row-pitched buffer, GroupNorm statistics by a pass over the concatenated tensor
+// (or by the producing conv's epilogue), GroupNorm-apply + SiLU + zero halo in act_pad_tm, the
+// conv as the balanced LDS-DMA GEMM, FiLM (time and cond modulation, unet1d.py:100-110) as a
+// per-(clip, channel) affine in the conv epilogue, strided pools via the row stride of the A
+// operand, nearest upsampling as a row copy.
 // Supported: time_cond_channels > 0, cond_channels > 0, n_attn_layers = 0 (the defaults).
 #include <new>
 #include <vector>
@@ -61,29 +63,6 @@ __global__ __launch_bounds__(256) void film_kernel(FilmArgs a) {
         a.ps[(size_t)b * a.C + c] = tm * cm;
         a.pt[(size_t)b * a.C + c] = ta * cm + ca;
     }
-}
-
-// dst[b, coff + c, t] = src[b, c, t]
-__global__ __launch_bounds__(256) void put_slice_kernel(const float* __restrict__ src,
-                                                        float* __restrict__ dst, int Cs, int T,
-                                                        int Cd, int coff, size_t total) {
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const size_t per = (size_t)Cs * T;
-    const int b = idx / per;
-    const size_t r = idx - (size_t)b * per;
-    dst[((size_t)b * Cd + coff) * T + r] = src[idx];
-}
-
-// nn.Upsample(mode='nearest', scale_factor=r): y[b, c, t] = x[b, c, t / r]
-__global__ __launch_bounds__(256) void upsample_nearest_kernel(const float* __restrict__ x,
-                                                               float* __restrict__ y, int T, int r,
-                                                               size_t total) {
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const size_t row = idx / ((size_t)T * r);
-    const int t = idx - row * ((size_t)T * r);
-    y[idx] = x[row * T + t / r];
 }
 
 // ---- classifier-free guidance around the network (model.py:721-785): everything on the device.
@@ -165,6 +144,9 @@ struct WCur {
 struct PackedConv {
     float *w = nullptr, *bias = nullptr;
     int cin = 0, cout = 0, k = 1;
+    ConvDmaPlanIn in;   // geometry + GEMM operand for conv_tm.hip
+    ConvTmPlan plan;
+    float* wd = nullptr;
 };
 struct BlockW {  // ConvBlock1D
     PackedConv c1, c2, to_out;
@@ -189,10 +171,13 @@ struct after_unet1d {
     std::vector<char> up_has_conv;
     BlockW mid;
     // workspaces
-    float *emb = nullptr, *ps = nullptr, *pt = nullptr, *scale = nullptr, *shift = nullptr;
-    double* gn_part = nullptr;
-    unsigned* gn_tick = nullptr;
+    float *emb = nullptr, *ps = nullptr, *pt = nullptr;
+    double* stats = nullptr;  // [kSlots][conv_tm_stat_sub()][max_batch][16][2] GroupNorm accumulators
+    int stat_slot = 0;
     float *cat = nullptr, *tmp = nullptr, *resb = nullptr, *xa = nullptr, *xb = nullptr, *ups = nullptr;
+    float *xtm = nullptr;     // the network input in time-major form
+    float* xp = nullptr;      // activated + haloed conv input
+    size_t xp_elems = 0;
     std::vector<float*> skips, tconds;  // n each (+1 tcond for the middle block)
     int cmax = 0, ccat_max = 0;
     // CFG workspaces (3x batch): allocated with the handle when max_batch is a multiple of 3
@@ -208,7 +193,24 @@ int dev_copy(Arena& a, float** dst, const float* src, size_t n) {
     return AFTER_OK;
 }
 
-int load_pconv(Arena& a, WCur& c, PackedConv& p, int cin, int cout, int k) {
+// geometry of a "same"-padded conv (odd k: pad k // 2 both sides) with an optional stride
+int plan_pconv(Arena& a, PackedConv& p, int stride) {
+    memset(&p.in, 0, sizeof(p.in));
+    p.in.Cin = p.cin;
+    p.in.Cout = p.cout;
+    p.in.taps = p.k;
+    p.in.phases = 1;
+    p.in.istride = stride;
+    p.in.ostride = 1;
+    for (int t = 0; t < p.k; ++t) p.in.toff[0][t] = t - p.k / 2;
+    conv_tm_plan(p.in, &p.plan);
+    AFTER_REQUIRE(p.plan.ok, AFTER_E_INVALID, "unet1d: tap pattern outside the conv path");
+    p.wd = a.take<float>(p.plan.w_floats);
+    AFTER_REQUIRE(p.wd, AFTER_E_NOMEM, "unet1d: weight arena exhausted");
+    return conv_tm_repack(p.w, p.wd, p.in, p.plan, 0);
+}
+
+int load_pconv(Arena& a, WCur& c, PackedConv& p, int cin, int cout, int k, int stride = 1) {
     p.cin = cin;
     p.cout = cout;
     p.k = k;
@@ -218,7 +220,8 @@ int load_pconv(Arena& a, WCur& c, PackedConv& p, int cin, int cout, int k) {
     p.w = a.take<float>((size_t)cout * k * pad16(cin));
     AFTER_REQUIRE(p.w, AFTER_E_NOMEM, "unet1d: weight arena exhausted");
     AFTER_TRY(pack_conv_weight(w, nullptr, p.w, cout, cin, k, pad16(cin), 0));
-    return dev_copy(a, &p.bias, b, cout);
+    AFTER_TRY(dev_copy(a, &p.bias, b, cout));
+    return plan_pconv(a, p, stride);
 }
 
 int gn_groups(int C) { return C / 4 < 16 ? C / 4 : 16; }  // unet1d.py:52-54,65
@@ -264,95 +267,149 @@ int load_block(Arena& a, WCur& c, BlockW& b, int in_c, int out_c, int skip_c, in
     return AFTER_OK;
 }
 
-size_t conv_fl(int cin, int cout, int k) { return (size_t)cout * k * pad16(cin) + cout + 128; }
+size_t conv_fl(int cin, int cout, int k) {  // staging copy + GEMM operand + bias
+    return (size_t)cout * k * (pad16(cin) + conv_tm_cp(cin)) + cout + 256;
+}
 size_t block_fl(int in_c, int out_c, int skip_c, int tc_c, int k, int TC, int CC) {
     const int ccat = in_c + skip_c + tc_c;
     return conv_fl(ccat, out_c, k) + conv_fl(out_c, out_c, k) + conv_fl(in_c, out_c, 1) + 2 * (size_t)ccat +
            2 * (size_t)out_c + 128 * (size_t)(TC + CC) + 256 + 4 * (size_t)out_c * 128 + 4 * (size_t)out_c + 2048;
 }
 
-int conv_same(after_unet1d* h, hipStream_t s, const PackedConv& p, const float* x, float* y, int B, int Tin,
-              int stride, const float* scale, const float* shift, int act, int out_act,
-              const float* res, const float* ps, const float* pt) {
-    (void)h;
-    const int Tout = Tin / stride;
-    ConvArgs a;
-    conv_args_init(a, B, p.cin, p.cout, Tin, Tout);
-    a.x = x;
-    a.y = y;
-    a.w = p.w;
-    a.bias = p.bias;
-    a.res = res;
-    a.scale = scale;
-    a.shift = shift;
-    a.act = act;
-    a.out_act = out_act;
-    a.taps = p.k;
-    a.istride = stride;
-    a.post_scale = ps;
-    a.post_shift = pt;
-    a.post_bstride = ps ? p.cout : 0;
-    for (int t = 0; t < p.k; ++t) a.toff[0][t] = t - p.k / 2;  // padding "same" (odd k) / k // 2
-    return launch_conv(a, s);
+constexpr int kSlots = 48;  // GroupNorm statistics slots per forward: 2 per ConvBlock1D, 2 n + 1 blocks
+
+double* next_slot(after_unet1d* h) {
+    double* p = h->stats + (size_t)(h->stat_slot % kSlots) * conv_tm_stat_sub() * h->max_batch * 32;
+    ++h->stat_slot;
+    return p;
 }
 
-int put_slice(hipStream_t s, const float* src, float* dst, int B, int Cs, int T, int Cd, int coff) {
-    const size_t total = (size_t)B * Cs * T;
-    hipLaunchKernelGGL(put_slice_kernel, dim3((unsigned)cdivll((long long)total, 256)), dim3(256), 0, s, src,
-                       dst, Cs, T, Cd, coff, total);
-    AFTER_HIP_CHECK(hipGetLastError());
-    return AFTER_OK;
+// One conv on time-major tensors: act(GroupNorm-affine(x)) into the haloed scratch, then the GEMM.
+struct ConvIo {
+    const float* x = nullptr;  // [B][T][x_ld] (x_cm: the caller's [B][C][T])
+    int x_ld = 0, x_cm = 0;
+    const double* stats = nullptr;  // GroupNorm accumulators of x (with gamma / beta), or nullptr
+    const float *gamma = nullptr, *beta = nullptr;
+    int G = 1, act = ACT_NONE, out_act = ACT_NONE;
+    float* y = nullptr;  // [B][Tout][cout] (y_cm: [B][cout][Tout])
+    int y_cm = 0;
+    const float* res = nullptr;  // [B][Tout][res_ld]
+    int res_ld = 0;
+    const float *ps = nullptr, *pt = nullptr;  // FiLM: per-(clip, channel) scale / shift
+    double* stats_out = nullptr;               // accumulate the statistics of y (G_out groups)
+    int G_out = 1;
+};
+
+int conv_tm_run(after_unet1d* h, hipStream_t s, const PackedConv& p, const ConvIo& io, int B, int Tin) {
+    const int stride = p.in.istride, Tout = Tin / stride;
+    AFTER_REQUIRE((size_t)B * conv_tm_cp(p.cin) * conv_tm_rows(Tin) <= h->xp_elems, AFTER_E_CAPACITY,
+                  "unet1d: activation scratch too small");
+    ActPadTm a;
+    memset(&a, 0, sizeof(a));
+    a.x = io.x;
+    a.ldx = io.x_ld;
+    a.x_cm = io.x_cm;
+    a.y = h->xp;
+    a.stats = io.stats;
+    a.gamma = io.gamma;
+    a.beta = io.beta;
+    a.act = io.act;
+    a.B = B;
+    a.C = p.cin;
+    a.T = Tin;
+    a.G = io.G;
+    a.sub_stride = h->max_batch * 32;
+    AFTER_TRY(launch_act_pad_tm(a, s));
+    ConvTmRun r;
+    memset(&r, 0, sizeof(r));
+    r.xp = h->xp;
+    r.w = p.wd;
+    r.bias = p.bias;
+    r.res = io.res;
+    r.res_ld = io.res_ld;
+    r.res_bs = io.res ? (long long)Tout * io.res_ld : 0;
+    r.y = io.y;
+    r.y_cm = io.y_cm;
+    r.out_act = io.out_act;
+    r.post_scale = io.ps;
+    r.post_shift = io.pt;
+    r.post_bstride = io.ps ? p.cout : 0;
+    r.stats = io.stats_out;
+    r.G = io.G_out;
+    r.sub_stride = h->max_batch * 32;
+    r.B = B;
+    r.Tp = conv_tm_rows(Tin);
+    r.Tout = Tout;
+    r.Nn = Tout;
+    return launch_conv_tm(r, p.in, p.plan, s);
 }
 
-int group_affine(after_unet1d* h, hipStream_t s, const float* x, const float* gamma, const float* beta,
-                 int B, int C, int T) {
-    GnArgs g;
-    g.x = x;
-    g.gamma = gamma;
-    g.beta = beta;
-    g.scale = h->scale;
-    g.shift = h->shift;
-    g.partials = h->gn_part;
-    g.tickets = h->gn_tick;
-    g.B = B;
-    g.C = C;
-    g.T = T;
-    g.G = gn_groups(C);
-    g.splits = gn_splits(C, T, g.G);
-    g.eps = 1e-5f;
-    return launch_gn_affine(g, s);
-}
-
-// ConvBlock1D.forward (unet1d.py:83-118)
-int run_block(after_unet1d* h, hipStream_t s, const BlockW& b, const float* x, const float* skip,
-              const float* tcond, const float* cond, float* y, int B, int T) {
+// ConvBlock1D.forward (unet1d.py:83-118).  x: [B][T][x_ld] view of in_c channels.
+int run_block(after_unet1d* h, hipStream_t s, const BlockW& b, const float* x, int x_ld, const float* skip,
+              const float* tcond, const float* cond, float* y, int y_cm, int B, int T) {
     const int ccat = b.in_c + b.skip_c + b.tc_c;
+    const size_t rows = (size_t)B * T;
     const float* in = x;
-    if (b.skip_c || b.tc_c) {
-        AFTER_TRY(put_slice(s, x, h->cat, B, b.in_c, T, ccat, 0));
-        if (b.skip_c) AFTER_TRY(put_slice(s, skip, h->cat, B, b.skip_c, T, ccat, b.in_c));
-        if (b.tc_c) AFTER_TRY(put_slice(s, tcond, h->cat, B, b.tc_c, T, ccat, b.in_c + b.skip_c));
+    int in_ld = x_ld;
+    if (b.skip_c || b.tc_c) {  // torch.cat((x, skip, time_cond), 1) = column ranges of one buffer
+        AFTER_TRY(launch_copy_cols_tm(x, x_ld, h->cat, ccat, b.in_c, rows, s));
+        if (b.skip_c) AFTER_TRY(launch_copy_cols_tm(skip, b.skip_c, h->cat + b.in_c, ccat, b.skip_c, rows, s));
+        if (b.tc_c) AFTER_TRY(launch_copy_cols_tm(tcond, b.tc_c, h->cat + b.in_c + b.skip_c, ccat, b.tc_c, rows, s));
         in = h->cat;
+        in_ld = ccat;
     }
     FilmArgs f{h->emb, cond, b.w1t, b.b1t, b.w2t, b.b2t, b.w1c, b.b1c, b.w2c, b.b2c, h->ps, h->pt,
                h->cfg.time_channels, h->cfg.cond_channels, b.out_c, 128};
     hipLaunchKernelGGL(film_kernel, dim3(B), dim3(256), 0, s, f);
     AFTER_HIP_CHECK(hipGetLastError());
-    AFTER_TRY(group_affine(h, s, in, b.gn1_w, b.gn1_b, B, ccat, T));
-    AFTER_TRY(conv_same(h, s, b.c1, in, h->tmp, B, T, 1, h->scale, h->shift, ACT_SILU, ACT_NONE, nullptr,
-                        h->ps, h->pt));
+    // GroupNorm 1 over the concatenation: its parts have three different producers -> one pass
+    double* st1 = next_slot(h);
+    AFTER_TRY(launch_stats_accum_tm(in, st1, B, ccat, T, gn_groups(ccat), s, in_ld));
+    double* st2 = next_slot(h);
+    {
+        ConvIo io;
+        io.x = in;
+        io.x_ld = in_ld;
+        io.stats = st1;
+        io.gamma = b.gn1_w;
+        io.beta = b.gn1_b;
+        io.G = gn_groups(ccat);
+        io.act = ACT_SILU;
+        io.y = h->tmp;
+        io.ps = h->ps;
+        io.pt = h->pt;
+        io.stats_out = st2;  // GroupNorm 2 sees exactly this conv's (FiLM'd) output
+        io.G_out = gn_groups(b.out_c);
+        AFTER_TRY(conv_tm_run(h, s, b.c1, io, B, T));
+    }
     const float* res = nullptr;
+    int res_ld = 0;
     if (b.res) {
         res = x;
+        res_ld = x_ld;
         if (b.has_to_out) {
-            AFTER_TRY(conv_same(h, s, b.to_out, x, h->resb, B, T, 1, nullptr, nullptr, ACT_NONE, ACT_NONE,
-                                nullptr, nullptr, nullptr));
+            ConvIo io;
+            io.x = x;
+            io.x_ld = x_ld;
+            io.y = h->resb;
+            AFTER_TRY(conv_tm_run(h, s, b.to_out, io, B, T));
             res = h->resb;
+            res_ld = b.out_c;
         }
     }
-    AFTER_TRY(group_affine(h, s, h->tmp, b.gn2_w, b.gn2_b, B, b.out_c, T));
-    return conv_same(h, s, b.c2, h->tmp, y, B, T, 1, h->scale, h->shift, ACT_SILU, ACT_NONE, res, nullptr,
-                     nullptr);
+    ConvIo io;
+    io.x = h->tmp;
+    io.x_ld = b.out_c;
+    io.stats = st2;
+    io.gamma = b.gn2_w;
+    io.beta = b.gn2_b;
+    io.G = gn_groups(b.out_c);
+    io.act = ACT_SILU;
+    io.y = y;
+    io.y_cm = y_cm;
+    io.res = res;
+    io.res_ld = res_ld;
+    return conv_tm_run(h, s, b.c2, io, B, T);
 }
 
 }  // namespace
@@ -415,13 +472,13 @@ extern "C" int after_unet1d_create(const after_unet1d_cfg* cfg, const float* con
     // cond_emb_time (unet1d.py:296-313): entry 0: in -> tcc stride 1; entry i: stride ratios[i-1]
     h->cond_emb.resize(n + 1);
     U_TRY(load_pconv(h->wa, cur, h->cond_emb[0], cfg->time_cond_in_channels, tcc, k));
-    for (int i = 1; i <= n; ++i) U_TRY(load_pconv(h->wa, cur, h->cond_emb[i], tcc, tcc, k));
+    for (int i = 1; i <= n; ++i) U_TRY(load_pconv(h->wa, cur, h->cond_emb[i], tcc, tcc, k, cfg->ratios[i - 1]));
     // down layers (:318-340): ConvBlock(in -> in) then pool(in -> channels[i], stride ratios[i])
     h->down.resize(n);
     h->pool.resize(n);
     for (int i = 0; i < n; ++i) {
         U_TRY(load_block(h->wa, cur, h->down[i], in_of(i), in_of(i), 0, tcc, k, TC, CC, true));
-        U_TRY(load_pconv(h->wa, cur, h->pool[i], in_of(i), ch[i], k));
+        U_TRY(load_pconv(h->wa, cur, h->pool[i], in_of(i), ch[i], k, cfg->ratios[i]));
     }
     U_TRY(load_block(h->wa, cur, h->mid, ch[n - 1], ch[n - 1], 0, tcc, k, TC, CC, true));
     // up layers (:341-372): i = 1..n-1: channels[n-i] -> channels[n-i-1], ratio ratios[n-i];
@@ -448,41 +505,43 @@ extern "C" int after_unet1d_create(const after_unet1d_cfg* cfg, const float* con
         set_error("unet1d: expected %d weight tensors, got %d", cur.i, n_weights);
         return fail(AFTER_E_INVALID);
     }
-    // workspaces
+    // workspaces (all activations time-major [B][T][C])
     const size_t T = h->max_T, Bm = max_batch;
     const size_t act = Bm * cmax * T, catn = Bm * ccat_max * T, tcn = Bm * tcc * T;
-    size_t bytes = (Bm * TC + 2 * Bm * cmax + 2 * Bm * ccat_max) * sizeof(float) +
-                   Bm * 16 * 64 * 2 * sizeof(double) + Bm * 16 * sizeof(unsigned) +
-                   (catn + 5 * act + (size_t)n * act + (size_t)(n + 2) * tcn) * sizeof(float) + (1 << 16) +
-                   (Bm * T * (size_t)(2 * in0 + outsz + cfg->time_cond_in_channels) + Bm * (CC + 1)) * sizeof(float) +
+    int cin_max = ccat_max > cmax ? ccat_max : cmax;
+    cin_max = cfg->time_cond_in_channels > cin_max ? cfg->time_cond_in_channels : cin_max;
+    h->xp_elems = Bm * (size_t)conv_tm_cp(cin_max) * conv_tm_rows((int)T);
+    const size_t stat_d = (size_t)kSlots * conv_tm_stat_sub() * Bm * 32;
+    size_t bytes = (Bm * TC + 2 * Bm * cmax) * sizeof(float) + stat_d * sizeof(double) +
+                   (catn + 5 * act + (size_t)n * act + (size_t)(n + 2) * tcn + h->xp_elems) * sizeof(float) +
+                   (1 << 16) +
+                   (Bm * T * (size_t)(3 * in0 + outsz + cfg->time_cond_in_channels) + Bm * (CC + 1)) * sizeof(float) +
                    8192;
     if ((rc = h->ws.init(bytes))) return fail(rc);
     h->emb = h->ws.take<float>(Bm * TC);
     h->ps = h->ws.take<float>(Bm * cmax);
     h->pt = h->ws.take<float>(Bm * cmax);
-    h->scale = h->ws.take<float>(Bm * ccat_max);
-    h->shift = h->ws.take<float>(Bm * ccat_max);
-    h->gn_part = h->ws.take<double>(Bm * 16 * 64 * 2);
-    h->gn_tick = h->ws.take<unsigned>(Bm * 16);
+    h->stats = h->ws.take<double>(stat_d);
     h->cat = h->ws.take<float>(catn);
     h->tmp = h->ws.take<float>(act);
     h->resb = h->ws.take<float>(act);
     h->xa = h->ws.take<float>(act);
     h->xb = h->ws.take<float>(act);
     h->ups = h->ws.take<float>(act);
+    h->xp = h->ws.take<float>(h->xp_elems);
     h->skips.resize(n);
     h->tconds.resize(n + 2);
     for (int i = 0; i < n; ++i) h->skips[i] = h->ws.take<float>(act);
     for (int i = 0; i < n + 2; ++i) h->tconds[i] = h->ws.take<float>(tcn);
+    h->xtm = h->ws.take<float>(Bm * in0 * T);
     h->x3 = h->ws.take<float>(Bm * in0 * T);
     h->d3 = h->ws.take<float>(Bm * outsz * T);
     h->xs = h->ws.take<float>(Bm * in0 * T);
     h->tc3 = h->ws.take<float>(Bm * cfg->time_cond_in_channels * T);
     h->cond3 = h->ws.take<float>(Bm * CC);
     h->t3 = h->ws.take<float>(Bm);
-    if (!h->tconds[n + 1] || !h->skips[n - 1] || !h->ups || !h->t3) return fail(AFTER_E_NOMEM);
-    if (hipMemset(h->gn_tick, 0, Bm * 16 * sizeof(unsigned)) != hipSuccess ||
-        hipDeviceSynchronize() != hipSuccess) {
+    if (!h->tconds[n + 1] || !h->skips[n - 1] || !h->ups || !h->t3 || !h->xp || !h->xtm) return fail(AFTER_E_NOMEM);
+    if (hipDeviceSynchronize() != hipSuccess) {  // weight repacks done before the staging copies are reused
         set_error("unet1d: device initialisation failed");
         return fail(AFTER_E_HIP);
     }
@@ -513,54 +572,73 @@ extern "C" int after_unet1d_forward(after_unet1d* h, const float* x, const float
     hipLaunchKernelGGL(spe_kernel, dim3(cdiv(B * c.time_channels / 2, 256)), dim3(256), 0, s, time, h->emb, B,
                        c.time_channels, 10000.0f, 32.0f);
     AFTER_HIP_CHECK(hipGetLastError());
+    // GroupNorm accumulators of this forward: one slot per normalisation, zeroed together
+    h->stat_slot = 0;
+    AFTER_HIP_CHECK(hipMemsetAsync(h->stats, 0, (size_t)kSlots * conv_tm_stat_sub() * h->max_batch * 32 * sizeof(double), s));
+    AFTER_REQUIRE(2 * (2 * n + 1) <= kSlots, AFTER_E_INVALID, "unet1d: statistics slots");
+    // the network input is read twice (concatenation, shortcut): one transpose
+    AFTER_TRY(launch_cm_to_tm(x, h->xtm, B, c.in_size, T, c.in_size, s));
     // ---- encoder: time_cond is re-embedded (conv + SiLU) at every scale
-    const float* cur = x;
-    const float* tc = time_cond;
+    const float* cur = h->xtm;
+    int cur_c = c.in_size;
     int Tc = T;  // length of x == length of the time_cond of this scale
     std::vector<int> Ts(n);
     for (int i = 0; i < n; ++i) {
-        const int tstride = i == 0 ? 1 : c.ratios[i - 1];
-        AFTER_TRY(conv_same(h, s, h->cond_emb[i], tc, h->tconds[i], B, i == 0 ? T : Ts[i - 1], tstride, nullptr,
-                            nullptr, ACT_NONE, ACT_SILU, nullptr, nullptr, nullptr));
-        tc = h->tconds[i];
+        ConvIo io;
+        io.x = i == 0 ? time_cond : h->tconds[i - 1];
+        io.x_ld = c.time_cond_channels;
+        io.x_cm = i == 0;
+        io.y = h->tconds[i];
+        io.out_act = ACT_SILU;
+        AFTER_TRY(conv_tm_run(h, s, h->cond_emb[i], io, B, i == 0 ? T : Ts[i - 1]));
         Ts[i] = Tc;
-        AFTER_TRY(run_block(h, s, h->down[i], cur, nullptr, tc, cond, h->skips[i], B, Tc));
+        AFTER_TRY(run_block(h, s, h->down[i], cur, cur_c, nullptr, h->tconds[i], cond, h->skips[i], 0, B, Tc));
         float* nx = (cur == h->xa) ? h->xb : h->xa;
-        AFTER_TRY(conv_same(h, s, h->pool[i], h->skips[i], nx, B, Tc, c.ratios[i], nullptr, nullptr, ACT_NONE,
-                            ACT_NONE, nullptr, nullptr, nullptr));
+        ConvIo pl;
+        pl.x = h->skips[i];
+        pl.x_ld = h->down[i].out_c;
+        pl.y = nx;
+        AFTER_TRY(conv_tm_run(h, s, h->pool[i], pl, B, Tc));
         cur = nx;
+        cur_c = h->pool[i].cout;
         Tc /= c.ratios[i];
     }
-    AFTER_TRY(conv_same(h, s, h->cond_emb[n], tc, h->tconds[n], B, Ts[n - 1], c.ratios[n - 1], nullptr, nullptr,
-                        ACT_NONE, ACT_SILU, nullptr, nullptr, nullptr));
     {
+        ConvIo io;
+        io.x = h->tconds[n - 1];
+        io.x_ld = c.time_cond_channels;
+        io.y = h->tconds[n];
+        io.out_act = ACT_SILU;
+        AFTER_TRY(conv_tm_run(h, s, h->cond_emb[n], io, B, Ts[n - 1]));
         float* nx = (cur == h->xa) ? h->xb : h->xa;
-        AFTER_TRY(run_block(h, s, h->mid, cur, nullptr, h->tconds[n], cond, nx, B, Tc));
+        AFTER_TRY(run_block(h, s, h->mid, cur, cur_c, nullptr, h->tconds[n], cond, nx, 0, B, Tc));
         cur = nx;
     }
     // ---- decoder
     for (int i = 1; i <= n; ++i) {
         const int ratio = c.ratios[n - i];
         const float* up_in = cur;
-        if (ratio != 1) {
-            const size_t total = (size_t)B * h->upconv[i - 1].cin * Tc * ratio;
-            hipLaunchKernelGGL(upsample_nearest_kernel, dim3((unsigned)cdivll((long long)total, 256)), dim3(256),
-                               0, s, cur, h->ups, Tc, ratio, total);
-            AFTER_HIP_CHECK(hipGetLastError());
+        if (ratio != 1) {  // nn.Upsample(mode="nearest"): every row `ratio` times
+            AFTER_TRY(launch_upsample_rows_tm(cur, h->ups, B, cur_c, Tc, ratio, s));
             up_in = h->ups;
             Tc *= ratio;
         }
         float* ux = (cur == h->xa) ? h->xb : h->xa;
         const float* bx = up_in;
         if (h->up_has_conv[i - 1]) {
-            AFTER_TRY(conv_same(h, s, h->upconv[i - 1], up_in, ux, B, Tc, 1, nullptr, nullptr, ACT_NONE, ACT_NONE,
-                                nullptr, nullptr, nullptr));
+            ConvIo io;
+            io.x = up_in;
+            io.x_ld = cur_c;
+            io.y = ux;
+            AFTER_TRY(conv_tm_run(h, s, h->upconv[i - 1], io, B, Tc));
             bx = ux;
+            cur_c = h->upconv[i - 1].cout;
         }
         float* y = i == n ? out : ((bx == h->xa) ? h->xb : h->xa);
         if (i < n && y == bx) y = h->ups;  // (identity `up`: keep input and output apart)
-        AFTER_TRY(run_block(h, s, h->up[i - 1], bx, h->skips[n - i], h->tconds[n - i], cond, y, B, Tc));
+        AFTER_TRY(run_block(h, s, h->up[i - 1], bx, cur_c, h->skips[n - i], h->tconds[n - i], cond, y, i == n, B, Tc));
         cur = y;
+        cur_c = h->up[i - 1].out_c;
     }
     return AFTER_OK;
 }
