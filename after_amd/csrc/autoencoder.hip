@@ -1,13 +1,14 @@
 // AutoEncoder.encode / .decode on gfx950 (reference
 // after/autoencoder/networks/SimpleNetsStream.py:831-954, pqmf.py:252-301).
 //
-// Every conv layer is one launch of the implicit-GEMM kernel of conv.hip with the
-// GroupNorm-apply + SnakeBeta prologue and bias / residual epilogue fused; the
-// full-sequence GroupNorm statistics (offline semantics: one (mean, var) per
-// (clip, group) over the WHOLE time axis, SimpleNetsStream.py:146-147) come from a
-// split reduction whose last-arriving block folds them into a per-(clip, channel)
-// affine.  The two PQMF filter banks are HBM-bound polyphase FIRs on the vector
-// ALUs with their taps in scalar registers.
+// Activations are time-major [B][T][C] between the API edges.  Every conv layer is
+// GroupNorm-apply + SnakeBeta + halo (act_pad_tm) followed by the balanced LDS-DMA GEMM of
+// conv_tm.hip with bias / residual in its epilogue; the full-sequence GroupNorm statistics
+// (offline semantics: one (mean, var) per (clip, group) over the WHOLE time axis,
+// SimpleNetsStream.py:146-147) are accumulated by the producing conv's epilogue, and a
+// conv that feeds a Snake-only consumer writes that consumer's activated input itself.
+// The two PQMF filter banks are HBM-bound polyphase FIRs on the vector ALUs with their
+// taps in scalar registers.
 #include <cstdlib>
 #include <new>
 #include <vector>
@@ -232,11 +233,10 @@ using namespace after;
 
 namespace {
 
-// plan + repacked weights of one conv for the DMA kernel (conv_dma.hip)
+// geometry + GEMM-operand weights of one conv (conv_tm.hip)
 struct DmaConv {
     ConvDmaPlanIn in;
-    ConvDmaPlan plan;    // conv_dma.hip ([B][C][T] layout)
-    ConvTmPlan tplan;    // conv_tm.hip ([B][T][C] layout, the default)
+    ConvTmPlan tplan;
     float* w = nullptr;
 };
 struct ConvBlockW {
@@ -287,13 +287,8 @@ struct after_ae {
     // workspaces
     float *buf[3] = {nullptr, nullptr, nullptr};
     size_t buf_elems = 0;
-    float *scale = nullptr, *shift = nullptr;
-    double* gn_part = nullptr;
-    unsigned* gn_tick = nullptr;
     int cmax = 0;
-    // DMA conv path
-    bool use_dma = true;
-    bool tm = true;               // time-major activations + conv_tm.hip (AFTER_CONV_TM=0: conv_dma.hip)
+    // conv path (conv_tm.hip): activations time-major [B][T][C] between the API edges
     float* xp = nullptr;          // activated + haloed scratch tensor
     float* xp2 = nullptr;         // second one: a conv epilogue prepares the NEXT conv's input there
     const float* prepared = nullptr;  // haloed input already laid out by the producer (time-major path)
@@ -388,72 +383,7 @@ int load_resblock(after_ae* h, WeightCursor& c, ResBlockW& rb, int cin, int cout
     return AFTER_OK;
 }
 
-int left_pad(int k, int dil, bool causal) { return conv_left_pad(k, dil, causal); }
-void base_args(ConvArgs& a, int B, int cin, int cout, int Tin, int Tout) {
-    conv_args_init(a, B, cin, cout, Tin, Tout);
-}
-
-int run_gn(after_ae* h, hipStream_t s, const float* x, const ConvBlockW& cb, int B, int T) {
-    GnArgs g;
-    g.x = x;
-    g.gamma = cb.gn_w;
-    g.beta = cb.gn_b;
-    g.scale = h->scale;
-    g.shift = h->shift;
-    g.partials = h->gn_part;
-    g.tickets = h->gn_tick;
-    g.B = B;
-    g.C = cb.cin;
-    g.T = T;
-    g.G = cb.cin < 8 ? cb.cin : 8;  // SimpleNetsStream.py:165: min(in_channels, num_groups)
-    g.splits = gn_splits(g.C, T, g.G);
-    g.eps = 1e-5f;
-    return launch_gn_affine(g, s);
-}
-
-// ConvBlock1d (SimpleNetsStream.py:150-194)
-int run_convblock(after_ae* h, hipStream_t s, const ConvBlockW& cb, const float* x, float* y,
-                  const float* res, int B, int T) {
-    if (h->norm) AFTER_TRY(run_gn(h, s, x, cb, B, T));
-    ConvArgs a;
-    base_args(a, B, cb.cin, cb.cout, T, T);
-    a.x = x;
-    a.y = y;
-    a.w = cb.w;
-    a.bias = cb.bias;
-    a.res = res;
-    a.scale = h->norm ? h->scale : nullptr;
-    a.shift = h->norm ? h->shift : nullptr;
-    a.act = ACT_SNAKE;
-    a.act_a = cb.alpha;
-    a.act_b = cb.invb;
-    a.taps = cb.k;
-    const int pl = left_pad(cb.k, cb.dil, h->causal);
-    for (int t = 0; t < cb.k; ++t) a.toff[0][t] = t * cb.dil - pl;
-    return launch_conv(a, s);
-}
-
-// ResnetBlock1d (SimpleNetsStream.py:197-254): y = cb1(cb0(x)) + (to_out(x) | x)
-// x in bx, scratch in bt, result in by (all distinct).
-int run_resblock(after_ae* h, hipStream_t s, const ResBlockW& rb, const float* bx, float* bt,
-                 float* by, int B, int T) {
-    const float* res = bx;
-    if (rb.to_w) {
-        ConvArgs a;
-        base_args(a, B, rb.cb0.cin, rb.cb0.cout, T, T);
-        a.x = bx;
-        a.y = by;
-        a.w = rb.to_w;
-        a.bias = rb.to_b;
-        a.toff[0][0] = 0;
-        AFTER_TRY(launch_conv(a, s));
-        res = by;  // residual read and result write hit the same element in one thread
-    }
-    AFTER_TRY(run_convblock(h, s, rb.cb0, bx, bt, nullptr, B, T));
-    return run_convblock(h, s, rb.cb1, bt, by, res, B, T);
-}
-
-// ------------------------------------------------------------------ DMA conv path
+// ------------------------------------------------------------------ conv plans (time-major path)
 int make_dma(after_ae* h, DmaConv& d, const float* packed, int cin, int cout, int taps, int phases,
              int istride, int ostride, const int (*toff)[kMaxTaps], const int* ooff, int Nn_hint) {
     memset(&d.in, 0, sizeof(d.in));
@@ -469,17 +399,11 @@ int make_dma(after_ae* h, DmaConv& d, const float* packed, int cin, int cout, in
     }
     d.in.Nn_hint = Nn_hint;
     d.in.B_hint = h->max_batch;  // the handle is (re)built for the batch it serves
-    if (h->tm) {
-        conv_tm_plan(d.in, &d.tplan);
-        AFTER_REQUIRE(d.tplan.ok, AFTER_E_INVALID, "autoencoder: tap pattern outside the time-major conv path");
-        d.w = h->wd.take<float>(d.tplan.w_floats);
-        AFTER_REQUIRE(d.w, AFTER_E_NOMEM, "autoencoder: conv weight arena exhausted");
-        return conv_tm_repack(packed, d.w, d.in, d.tplan, 0);
-    }
-    conv_dma_plan(d.in, &d.plan);
-    d.w = h->wd.take<float>(d.plan.w_floats);
-    AFTER_REQUIRE(d.w, AFTER_E_NOMEM, "autoencoder: DMA weight arena exhausted");
-    return conv_dma_repack(packed, d.w, d.in, d.plan, 0);
+    conv_tm_plan(d.in, &d.tplan);
+    AFTER_REQUIRE(d.tplan.ok, AFTER_E_INVALID, "autoencoder: tap pattern outside the time-major conv path");
+    d.w = h->wd.take<float>(d.tplan.w_floats);
+    AFTER_REQUIRE(d.w, AFTER_E_NOMEM, "autoencoder: conv weight arena exhausted");
+    return conv_tm_repack(packed, d.w, d.in, d.tplan, 0);
 }
 
 double* next_stats(after_ae* h, int B) {
@@ -498,91 +422,68 @@ int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const 
     const int cin = d.in.Cin, cout = d.in.Cout;
     float* state = nullptr;
     if (h->streaming && state_base) state = state_base + (size_t)(h->state_slot++) * h->slot_elems;
-    if (h->tm) {  // x, res, y time-major [B][T][C] (x_cm / y_cm: the reference's [B][C][T] at the API edges)
-        AFTER_REQUIRE((size_t)B * conv_tm_cp(cin) * conv_tm_rows(Tin) <= h->xp_elems, AFTER_E_CAPACITY,
-                      "autoencoder: activation scratch too small");
-        // Snake-only inputs (the resampling convs, the encoder tail) carry no full-tensor statistics:
-        // offline their producer's epilogue has already written the activated, haloed tensor
-        const float* xin = h->prepared;
-        h->prepared = nullptr;
-        if (!xin) {
-            ActPadTm p;
-            memset(&p, 0, sizeof(p));
-            p.x = x;
-            p.y = h->xp;
-            p.stats = stats_in;
-            p.gamma = gamma;
-            p.beta = beta;
-            p.act_a = alpha;
-            p.act_b = invb;
-            p.state = state;
-            p.act = act;
-            p.B = B;
-            p.C = cin;
-            p.T = Tin;
-            p.G = cin < 8 ? cin : 8;
-            p.x_cm = x_cm;
-            p.sub_stride = h->max_batch * 16;
-            AFTER_TRY(launch_act_pad_tm(p, s));
-            xin = h->xp;
-        }
-        ConvTmRun r;
-        memset(&r, 0, sizeof(r));
-        r.xp = xin;
-        r.w = d.w;
-        r.bias = bias;
-        r.res = res;
-        r.y = y;
-        r.G = cout < 8 ? cout : 8;
-        if (want_stats && h->norm) {
-            r.stats = next_stats(h, B);
-            if (stats_out) *stats_out = r.stats;
-        }
-        r.B = B;
-        r.Tp = conv_tm_rows(Tin);
-        r.Tout = Tout;
-        r.Nn = Nn;
-        r.y_cm = y_cm;
-        r.sub_stride = h->max_batch * 16;
-        static int fuse_snake = -1;  // AFTER_AE_FUSE_SNAKE=0: A/B switch (separate act_pad launches)
-        if (fuse_snake < 0) {
-            const char* e = getenv("AFTER_AE_FUSE_SNAKE");
-            fuse_snake = e ? atoi(e) : 1;
-        }
-        if (fuse_snake && h->next_alpha && !h->streaming && (cout & 31) == 0 && d.in.ostride == 1 &&
-            (size_t)B * cout * conv_tm_rows(Tout) <= h->xp_elems) {
-            r.y2 = xin == h->xp2 ? h->xp : h->xp2;
-            r.y2_act = ACT_SNAKE;
-            r.y2_pa = h->next_alpha;
-            r.y2_pb = h->next_invb;
-            r.y = nullptr;  // the raw tensor has no other reader
-            h->prepared = r.y2;
-        }
-        h->next_alpha = h->next_invb = nullptr;
-        return launch_conv_tm(r, d.in, d.tplan, s);
-    }
-    h->next_alpha = h->next_invb = nullptr;
-    AFTER_REQUIRE((size_t)B * cin * conv_dma_row(Tin) <= h->xp_elems, AFTER_E_CAPACITY,
+    // x, res, y time-major [B][T][C] (x_cm / y_cm: the reference's [B][C][T] at the API edges)
+    AFTER_REQUIRE((size_t)B * conv_tm_cp(cin) * conv_tm_rows(Tin) <= h->xp_elems, AFTER_E_CAPACITY,
                   "autoencoder: activation scratch too small");
-    AFTER_TRY(launch_act_pad(x, h->xp, stats_in, gamma, beta, alpha, invb, act, B, cin, Tin,
-                             cin < 8 ? cin : 8, s, state));
-    ConvDmaRun r;
-    r.xp = h->xp;
+    // Snake-only inputs (the resampling convs, the encoder tail) carry no full-tensor statistics:
+    // offline their producer's epilogue has already written the activated, haloed tensor
+    const float* xin = h->prepared;
+    h->prepared = nullptr;
+    if (!xin) {
+        ActPadTm p;
+        memset(&p, 0, sizeof(p));
+        p.x = x;
+        p.y = h->xp;
+        p.stats = stats_in;
+        p.gamma = gamma;
+        p.beta = beta;
+        p.act_a = alpha;
+        p.act_b = invb;
+        p.state = state;
+        p.act = act;
+        p.B = B;
+        p.C = cin;
+        p.T = Tin;
+        p.G = cin < 8 ? cin : 8;
+        p.x_cm = x_cm;
+        p.sub_stride = h->max_batch * 16;
+        AFTER_TRY(launch_act_pad_tm(p, s));
+        xin = h->xp;
+    }
+    ConvTmRun r;
+    memset(&r, 0, sizeof(r));
+    r.xp = xin;
     r.w = d.w;
     r.bias = bias;
     r.res = res;
     r.y = y;
-    r.stats = nullptr;
     r.G = cout < 8 ? cout : 8;
     if (want_stats && h->norm) {
         r.stats = next_stats(h, B);
         if (stats_out) *stats_out = r.stats;
     }
     r.B = B;
-    r.Tp = conv_dma_row(Tin);
+    r.Tp = conv_tm_rows(Tin);
     r.Tout = Tout;
     r.Nn = Nn;
-    return launch_conv_dma(r, d.in, d.plan, s);
+    r.y_cm = y_cm;
+    r.sub_stride = h->max_batch * 16;
+    static int fuse_snake = -1;  // AFTER_AE_FUSE_SNAKE=0: A/B switch (separate act_pad launches)
+    if (fuse_snake < 0) {
+        const char* e = getenv("AFTER_AE_FUSE_SNAKE");
+        fuse_snake = e ? atoi(e) : 1;
+    }
+    if (fuse_snake && h->next_alpha && !h->streaming && (cout & 31) == 0 && d.in.ostride == 1 &&
+        (size_t)B * cout * conv_tm_rows(Tout) <= h->xp_elems) {
+        r.y2 = xin == h->xp2 ? h->xp : h->xp2;
+        r.y2_act = ACT_SNAKE;
+        r.y2_pa = h->next_alpha;
+        r.y2_pb = h->next_invb;
+        r.y = nullptr;  // the raw tensor has no other reader
+        h->prepared = r.y2;
+    }
+    h->next_alpha = h->next_invb = nullptr;
+    return launch_conv_tm(r, d.in, d.tplan, s);
 }
 
 // ConvBlock1d on the DMA path
@@ -867,15 +768,9 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
         set_error("autoencoder: expected %d weight tensors, got %d", cur.i, n_weights);
         return fail(AFTER_E_INVALID);
     }
-    // ---- DMA conv path: per-conv tile plan + repacked weights
+    // ---- per-conv geometry + GEMM-operand weights
+    h->stat_sub = conv_tm_stat_sub();
     {
-        const char* e = getenv("AFTER_CONV_OLD");
-        h->use_dma = !(e && atoi(e) != 0);
-        const char* e2 = getenv("AFTER_CONV_TM");
-        h->tm = h->use_dma && !(e2 && atoi(e2) == 0);
-        h->stat_sub = h->tm ? conv_tm_stat_sub() : 1;
-    }
-    if (h->use_dma) {
         AE_TRY(h->wd.init((size_t)(wf * 2.0) * sizeof(float) + (8 << 20)));
         const size_t Tm = h->max_samples / h->M;
         auto plan_conv = [&](DmaConv& d, const float* packed, int cin, int cout, int kk, int dil,
@@ -963,8 +858,7 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
         const size_t Tm = h->max_samples / h->M;
         size_t T = Tm;
         auto upd = [&](int c, size_t t) {
-            const size_t e2 = h->tm ? (size_t)conv_tm_cp(c) * conv_tm_rows((int)t)
-                                    : (size_t)c * conv_dma_row((int)t);
+            const size_t e2 = (size_t)conv_tm_cp(c) * conv_tm_rows((int)t);
             xpe = e2 > xpe ? e2 : xpe;
         };
         upd(h->M, Tm);
@@ -984,22 +878,14 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
         }
     }
     h->xp_elems = xpe * max_batch + 4096;
-    rc = h->ws.init(3 * h->buf_elems * sizeof(float) + 2 * (size_t)max_batch * cmax * sizeof(float) +
-                    (size_t)max_batch * 8 * 64 * 2 * sizeof(double) + (size_t)max_batch * 8 * 4 + 8192 +
-                    2 * h->xp_elems * sizeof(float) + (size_t)kStatSlots * h->stat_sub * max_batch * 16 * sizeof(double));
+    rc = h->ws.init(3 * h->buf_elems * sizeof(float) + 8192 + 2 * h->xp_elems * sizeof(float) + (size_t)kStatSlots * h->stat_sub * max_batch * 16 * sizeof(double));
     if (rc != AFTER_OK) return fail(rc);
     for (int i = 0; i < 3; ++i) h->buf[i] = h->ws.take<float>(h->buf_elems);
-    h->scale = h->ws.take<float>((size_t)max_batch * cmax);
-    h->shift = h->ws.take<float>((size_t)max_batch * cmax);
-    h->gn_part = h->ws.take<double>((size_t)max_batch * 8 * 64 * 2);
-    h->gn_tick = h->ws.take<unsigned>((size_t)max_batch * 8);
     h->xp = h->ws.take<float>(h->xp_elems);
     h->xp2 = h->ws.take<float>(h->xp_elems);
     h->stats_ring = h->ws.take<double>((size_t)kStatSlots * h->stat_sub * max_batch * 16);
-    if (!h->buf[2] || !h->scale || !h->shift || !h->gn_part || !h->gn_tick || !h->xp || !h->xp2 || !h->stats_ring)
-        return fail(AFTER_E_NOMEM);
-    if (hipMemset(h->gn_tick, 0, (size_t)max_batch * 8 * sizeof(unsigned)) != hipSuccess ||
-        hipDeviceSynchronize() != hipSuccess) {
+    if (!h->buf[2] || !h->xp || !h->xp2 || !h->stats_ring) return fail(AFTER_E_NOMEM);
+    if (hipDeviceSynchronize() != hipSuccess) {
         set_error("autoencoder: device initialisation failed");
         return fail(AFTER_E_HIP);
     }
@@ -1036,18 +922,16 @@ extern "C" int after_ae_enable_streaming(after_ae* h, int enable) {
     AFTER_REQUIRE(h->causal && !h->norm, AFTER_E_INVALID,
                   "autoencoder: streaming needs the causal, GroupNorm-free codec "
                   "(baseAE.gin:32-33,49)");
-    AFTER_REQUIRE(h->use_dma, AFTER_E_INVALID, "autoencoder: streaming needs the DMA conv path");
     const after_ae_cfg& c = h->cfg;
-    AFTER_REQUIRE((c.kernel_size - 1) * c.dilations[c.n_dilations - 1] <= conv_dma_halo(),
+    AFTER_REQUIRE((c.kernel_size - 1) * c.dilations[c.n_dilations - 1] <= conv_tm_halo(),
                   AFTER_E_INVALID, "autoencoder: receptive field exceeds the streaming halo");
     for (int j = 0; j < c.n_dilations; ++j)
-        AFTER_REQUIRE((c.kernel_size - 1) * c.dilations[j] <= conv_dma_halo(), AFTER_E_INVALID,
+        AFTER_REQUIRE((c.kernel_size - 1) * c.dilations[j] <= conv_tm_halo(), AFTER_E_INVALID,
                       "autoencoder: receptive field exceeds the streaming halo");
     if (!h->sa.base) {
         const int n = c.n_stages, nd = c.n_dilations;
         const int enc_slots = 1 + n * nd + n + 1, dec_slots = 1 + n + n * nd + 1;
-        h->slot_elems = h->tm ? (size_t)h->max_batch * conv_tm_cp(h->cmax) * conv_tm_halo()
-                              : (size_t)h->max_batch * h->cmax * conv_dma_halo();
+        h->slot_elems = (size_t)h->max_batch * conv_tm_cp(h->cmax) * conv_tm_halo();
         const size_t fs = (size_t)h->max_batch * (h->pq_fk - 1);
         const size_t is = (size_t)h->max_batch * h->M * (h->pq_ik - 1);
         AFTER_TRY(h->sa.init(((enc_slots + dec_slots) * h->slot_elems + fs + is) * sizeof(float) + 8192));
@@ -1083,89 +967,40 @@ extern "C" int after_ae_encode(after_ae* h, const float* x, float* z, int B, int
     const int n = c.n_stages, nd = c.n_dilations;
     int T = L / h->M;
     float *b0 = h->buf[0], *b1 = h->buf[1], *b2 = h->buf[2];
-    AFTER_TRY(pqmf_forward(h, s, x, b0, B, L, h->streaming ? h->pq_fstate : nullptr, h->use_dma && h->tm));
-    if (h->use_dma) {
-        AFTER_TRY(begin_pass(h, s));
-        float* sb = h->streaming ? h->enc_state : nullptr;
-        double* st = nullptr;
-        if (h->norm) {  // the first GroupNorm sees the PQMF output: its producer is not a conv
-            st = next_stats(h, B);
-            if (h->tm) AFTER_TRY(launch_stats_accum_tm(b0, st, B, h->M, T, h->M < 8 ? h->M : 8, s));
-            else AFTER_TRY(launch_stats_accum(b0, st, B, h->M, T, h->M < 8 ? h->M : 8, s));
-        }
-        AFTER_TRY(run_resblock2(h, s, h->enc_stem, b0, b1, b2, B, T, &st, sb));
-        float *cur = b2, *t1 = b0, *t2 = b1;
-        for (int i = 0; i < n; ++i) {
-            const ResampleW& d = h->enc_down[i];
-            for (int j = 0; j < nd; ++j) {
-                const bool lastj = j == nd - 1;
-                AFTER_TRY(run_resblock2(h, s, h->enc_res[i][j], cur, t1, t2, B, T, &st, sb,
-                                        lastj ? d.alpha : nullptr, lastj ? d.invb : nullptr));
-                float* o = cur;
-                cur = t2;
-                t2 = o;
-            }
-            if (i == n - 1) {  // the tail conv's Snake'd input comes out of the last strided conv
-                h->next_alpha = h->enc_tail_alpha;
-                h->next_invb = h->enc_tail_invb;
-            }
-            AFTER_TRY(run_dma(h, s, d.d, cur, nullptr, nullptr, nullptr, d.alpha, d.invb, ACT_SNAKE, d.bias,
-                              nullptr, t1, B, T, T / d.f, T / d.f, true, &st, sb));
-            float* o = cur;
-            cur = t1;
-            t1 = o;
-            T /= d.f;
-        }
-        return run_dma(h, s, h->enc_tail.d, cur, nullptr, nullptr, nullptr, h->enc_tail_alpha,
-                       h->enc_tail_invb, ACT_SNAKE, h->enc_tail.bias, nullptr, z, B, T, T, T, false,
-                       nullptr, sb, 0, 1);  // z leaves in the reference's [B][Z][T] layout
+    AFTER_TRY(pqmf_forward(h, s, x, b0, B, L, h->streaming ? h->pq_fstate : nullptr, true));
+    AFTER_TRY(begin_pass(h, s));
+    float* sb = h->streaming ? h->enc_state : nullptr;
+    double* st = nullptr;
+    if (h->norm) {  // the first GroupNorm sees the PQMF output: its producer is not a conv
+        st = next_stats(h, B);
+        AFTER_TRY(launch_stats_accum_tm(b0, st, B, h->M, T, h->M < 8 ? h->M : 8, s));
     }
-    AFTER_TRY(run_resblock(h, s, h->enc_stem, b0, b1, b2, B, T));
+    AFTER_TRY(run_resblock2(h, s, h->enc_stem, b0, b1, b2, B, T, &st, sb));
     float *cur = b2, *t1 = b0, *t2 = b1;
     for (int i = 0; i < n; ++i) {
+        const ResampleW& d = h->enc_down[i];
         for (int j = 0; j < nd; ++j) {
-            AFTER_TRY(run_resblock(h, s, h->enc_res[i][j], cur, t1, t2, B, T));
+            const bool lastj = j == nd - 1;
+            AFTER_TRY(run_resblock2(h, s, h->enc_res[i][j], cur, t1, t2, B, T, &st, sb,
+                                    lastj ? d.alpha : nullptr, lastj ? d.invb : nullptr));
             float* o = cur;
             cur = t2;
             t2 = o;
         }
-        // Snake -> strided conv (Downsample1d, :32-48): k = 2f, stride f, pad get_padding(2f)
-        const ResampleW& d = h->enc_down[i];
-        ConvArgs a;
-        base_args(a, B, d.cin, d.cout, T, T / d.f);
-        a.x = cur;
-        a.y = t1;
-        a.w = d.w;
-        a.bias = d.bias;
-        a.act = ACT_SNAKE;
-        a.act_a = d.alpha;
-        a.act_b = d.invb;
-        a.taps = 2 * d.f;
-        a.istride = d.f;
-        const int pl = left_pad(2 * d.f, 1, h->causal);
-        for (int t = 0; t < a.taps; ++t) a.toff[0][t] = t - pl;
-        AFTER_TRY(launch_conv(a, s));
+        if (i == n - 1) {  // the tail conv's Snake'd input comes out of the last strided conv
+            h->next_alpha = h->enc_tail_alpha;
+            h->next_invb = h->enc_tail_invb;
+        }
+        AFTER_TRY(run_dma(h, s, d.d, cur, nullptr, nullptr, nullptr, d.alpha, d.invb, ACT_SNAKE, d.bias,
+                          nullptr, t1, B, T, T / d.f, T / d.f, true, &st, sb));
         float* o = cur;
         cur = t1;
         t1 = o;
         T /= d.f;
     }
-    {
-        ConvArgs a;
-        base_args(a, B, h->enc_tail.cin, h->enc_tail.cout, T, T);
-        a.x = cur;
-        a.y = z;
-        a.w = h->enc_tail.w;
-        a.bias = h->enc_tail.bias;
-        a.act = ACT_SNAKE;
-        a.act_a = h->enc_tail_alpha;
-        a.act_b = h->enc_tail_invb;
-        a.taps = 3;
-        const int pl = left_pad(3, 1, h->causal);
-        for (int t = 0; t < 3; ++t) a.toff[0][t] = t - pl;
-        AFTER_TRY(launch_conv(a, s));
-    }
-    return AFTER_OK;
+    return run_dma(h, s, h->enc_tail.d, cur, nullptr, nullptr, nullptr, h->enc_tail_alpha,
+                   h->enc_tail_invb, ACT_SNAKE, h->enc_tail.bias, nullptr, z, B, T, T, T, false,
+                   nullptr, sb, 0, 1);  // z leaves in the reference's [B][Z][T] layout
 }
 
 // x_multiband of Decoder1d.forward (SimpleNetsStream.py:643-646): y[:, :M] * sigmoid(y[:, M:])
@@ -1186,7 +1021,7 @@ static int write_multiband(after_ae* h, hipStream_t s, const float* y, float* mb
                            int ychan) {
     if (!mb) return AFTER_OK;
     dim3 grid((unsigned)(((size_t)h->M * Tm + 255) / 256), B);
-    const int cs = h->tm ? 1 : Tm, ts = h->tm ? ychan : 1;
+    const int cs = 1, ts = ychan;  // y is time-major
     hipLaunchKernelGGL(loudness_gate_kernel, grid, dim3(256), 0, s, y, mb, h->M, Tm, gated, ychan, cs, ts);
     AFTER_HIP_CHECK(hipGetLastError());
     return AFTER_OK;
@@ -1199,90 +1034,36 @@ static int decode_impl(after_ae* h, const float* z, float* x, float* mb, int B, 
     const after_ae_cfg& c = h->cfg;
     const int n = c.n_stages, nd = c.n_dilations;
     float *cur = h->buf[0], *t1 = h->buf[1], *t2 = h->buf[2];
-    if (h->use_dma) {
-        AFTER_TRY(begin_pass(h, s));
-        float* sb = h->streaming ? h->dec_state : nullptr;
-        double* st = nullptr;
-        AFTER_TRY(run_dma(h, s, h->dec_head.d, z, nullptr, nullptr, nullptr, nullptr, nullptr, ACT_NONE,
-                          h->dec_head.bias, nullptr, cur, B, T, T, T, false, nullptr, sb, 1, 0));  // z: [B][Z][T]
-        for (int i = 0; i < n; ++i) {
-            const ResampleW& u = h->dec_up[i];
-            AFTER_TRY(run_dma(h, s, h->streaming ? u.d_stream : u.d, cur, nullptr, nullptr, nullptr, u.alpha,
-                              u.invb, ACT_SNAKE, u.bias, nullptr, t1, B, T, T * u.f, T, true, &st, sb));
-            float* o = cur;
-            cur = t1;
-            t1 = o;
-            T *= u.f;
-            for (int j = 0; j < nd; ++j) {
-                const bool feed = j == nd - 1 && i + 1 < n;  // the next stage starts with Snake -> ConvTranspose
-                AFTER_TRY(run_resblock2(h, s, h->dec_res[i][j], cur, t1, t2, B, T, &st, sb,
-                                        feed ? h->dec_up[i + 1].alpha : nullptr,
-                                        feed ? h->dec_up[i + 1].invb : nullptr));
-                o = cur;
-                cur = t2;
-                t2 = o;
-            }
-        }
-        double* st1 = nullptr;
-        AFTER_TRY(run_convblock2(h, s, h->synth0, cur, st, t1, nullptr, B, T, true, &st1, sb));
-        AFTER_TRY(run_convblock2(h, s, h->synth1, t1, st1, t2, nullptr, B, T, false, nullptr));
-        const int och = c.use_loudness ? 2 * h->M : h->M;
-        AFTER_TRY(write_multiband(h, s, t2, mb, B, T, c.use_loudness, och));
-        return pqmf_inverse(h, s, t2, x, B, T, c.use_loudness, och,
-                            h->streaming ? h->pq_istate : nullptr, h->tm);
-    }
-    {
-        ConvArgs a;
-        base_args(a, B, h->dec_head.cin, h->dec_head.cout, T, T);
-        a.x = z;
-        a.y = cur;
-        a.w = h->dec_head.w;
-        a.bias = h->dec_head.bias;
-        a.taps = h->dec_head.k;
-        const int pl = left_pad(a.taps, 1, h->causal);
-        for (int t = 0; t < a.taps; ++t) a.toff[0][t] = t - pl;
-        AFTER_TRY(launch_conv(a, s));
-    }
+    AFTER_TRY(begin_pass(h, s));
+    float* sb = h->streaming ? h->dec_state : nullptr;
+    double* st = nullptr;
+    AFTER_TRY(run_dma(h, s, h->dec_head.d, z, nullptr, nullptr, nullptr, nullptr, nullptr, ACT_NONE,
+                      h->dec_head.bias, nullptr, cur, B, T, T, T, false, nullptr, sb, 1, 0));  // z: [B][Z][T]
     for (int i = 0; i < n; ++i) {
-        // Snake -> ConvTranspose1d(k = 2f, stride f, padding f/2) as f two-tap phases
         const ResampleW& u = h->dec_up[i];
-        ConvArgs a;
-        base_args(a, B, u.cin, u.cout, T, T * u.f);
-        a.x = cur;
-        a.y = t1;
-        a.w = u.w;
-        a.bias = u.bias;
-        a.act = ACT_SNAKE;
-        a.act_a = u.alpha;
-        a.act_b = u.invb;
-        a.taps = 2;
-        a.phases = u.f;
-        a.ostride = u.f;
-        a.Nn = T;
-        for (int r = 0; r < u.f; ++r) {
-            const int cc = (r + u.f / 2) / u.f;
-            a.toff[r][0] = cc - 1;
-            a.toff[r][1] = cc;
-            a.ooff[r] = r;
-        }
-        AFTER_TRY(launch_conv(a, s));
+        AFTER_TRY(run_dma(h, s, h->streaming ? u.d_stream : u.d, cur, nullptr, nullptr, nullptr, u.alpha,
+                          u.invb, ACT_SNAKE, u.bias, nullptr, t1, B, T, T * u.f, T, true, &st, sb));
         float* o = cur;
         cur = t1;
         t1 = o;
         T *= u.f;
         for (int j = 0; j < nd; ++j) {
-            AFTER_TRY(run_resblock(h, s, h->dec_res[i][j], cur, t1, t2, B, T));
+            const bool feed = j == nd - 1 && i + 1 < n;  // the next stage starts with Snake -> ConvTranspose
+            AFTER_TRY(run_resblock2(h, s, h->dec_res[i][j], cur, t1, t2, B, T, &st, sb,
+                                    feed ? h->dec_up[i + 1].alpha : nullptr,
+                                    feed ? h->dec_up[i + 1].invb : nullptr));
             o = cur;
             cur = t2;
             t2 = o;
         }
     }
-    // synth: ResnetBlock1dNoRes (:257-298), loudness gate + PQMF synthesis fused
-    AFTER_TRY(run_convblock(h, s, h->synth0, cur, t1, nullptr, B, T));
-    AFTER_TRY(run_convblock(h, s, h->synth1, t1, t2, nullptr, B, T));
-    const int out_ch = c.use_loudness ? 2 * h->M : h->M;
-    AFTER_TRY(write_multiband(h, s, t2, mb, B, T, c.use_loudness, out_ch));
-    return pqmf_inverse(h, s, t2, x, B, T, c.use_loudness, out_ch);
+    double* st1 = nullptr;
+    AFTER_TRY(run_convblock2(h, s, h->synth0, cur, st, t1, nullptr, B, T, true, &st1, sb));
+    AFTER_TRY(run_convblock2(h, s, h->synth1, t1, st1, t2, nullptr, B, T, false, nullptr));
+    const int och = c.use_loudness ? 2 * h->M : h->M;
+    AFTER_TRY(write_multiband(h, s, t2, mb, B, T, c.use_loudness, och));
+    return pqmf_inverse(h, s, t2, x, B, T, c.use_loudness, och,
+                        h->streaming ? h->pq_istate : nullptr, true);
 }
 
 extern "C" int after_ae_decode(after_ae* h, const float* z, float* x, int B, int T, void* stream) {

@@ -10,60 +10,6 @@ enum ConvPad { PAD_ZERO = 0, PAD_REFLECT = 1 };
 constexpr int kMaxTaps = 8;
 constexpr int kMaxPhases = 4;
 
-// y[b, co, n*ostride + ooff[ph]] = bias[co] + res[...] +
-//     sum_{tap, ci} w[ph][co][tap][ci] * A(x[b, ci, n*istride + toff[ph][tap]])
-// with A(v) = act(v * scale[b,ci] + shift[b,ci]) applied BEFORE the (zero / reflect)
-// padding, i.e. out-of-range taps contribute exactly 0 in PAD_ZERO mode -- the
-// reference pads the activated tensor (cached_conv.Conv1d: F.pad then conv).
-struct ConvArgs {
-    const float* x;      // [B, Cin, Tin]
-    const float* w;      // packed [phases][Cout][taps][Cin_pad]
-    const float* bias;   // [Cout] or nullptr
-    const float* res;    // [B, Cout, Tout] or nullptr (added in the epilogue)
-    float* y;            // [B, Cout, Tout]
-    const float* scale;  // [B, Cin] or nullptr (identity affine)
-    const float* shift;  // [B, Cin]
-    const float* act_a;  // snake: alpha[Cin]
-    const float* act_b;  // snake: 1 / (beta[Cin] + 1e-9)
-    const float* x2;     // optional second input, added to x before the affine/activation
-                         // (Res2Net: x_i + y_{i-1}, ecapa_encoder.py Res2NetBlock.forward)
-    const float* post_scale;  // [Cout] or nullptr: y = out_act(acc + bias) * post_scale + post_shift
-    const float* post_shift;  //   (TDNNBlock: BatchNorm AFTER the ReLU, ecapa_encoder.py:139)
-    int act, pad;
-    int B, Cin, Cin_pad, Cout, Tin, Tout;
-    int x_bstride;       // floats between batch items of x (allows channel-sliced views)
-    int x_coff;          // first input channel within x's channel dim
-    int y_bstride, y_coff;  // same for y (write into a channel slice of a wider tensor)
-    int res_bstride, res_coff;
-    int x2_bstride, x2_coff;
-    int bias_bstride;    // 0: bias[Cout] shared; else bias[b * bias_bstride + co]
-    int post_bstride;    // 0: post_scale/shift[Cout] shared; else [b * post_bstride + co] (FiLM)
-    int scale_bstride;   // 0: scale/shift[Cin] shared over the batch; else [b * stride + ci]
-    int taps, phases, istride, ostride;
-    int Nn;              // output positions per phase
-    int toff[kMaxPhases][kMaxTaps];
-    int ooff[kMaxPhases];
-    int out_act;         // activation applied to the result (ACT_NONE / ACT_RELU / ACT_TANH / ...)
-};
-int launch_conv(const ConvArgs& a, hipStream_t s);
-
-// GroupNorm statistics -> per-(b, channel) affine  scale = rstd*gamma, shift = beta - mean*rstd*gamma
-// (nn.GroupNorm: biased variance over (C/G x T), eps inside the sqrt; reference
-// SimpleNetsStream.py:95-147 offline path).  `scratch` holds partials + tickets.
-struct GnArgs {
-    const float* x;  // [B, C, T]
-    const float* gamma;
-    const float* beta;
-    float* scale;    // [B, C]
-    float* shift;
-    double* partials;  // [B*G*splits*2]
-    unsigned* tickets; // [B*G], zero on entry, zero on exit
-    int B, C, T, G, splits;
-    float eps;
-};
-int launch_gn_affine(const GnArgs& a, hipStream_t s);
-int gn_splits(int C, int T, int G);
-
 // BatchNorm1d (eval) -> per-channel affine, replicated over B (done once at create)
 int launch_bn_affine(const float* w, const float* b, const float* rm, const float* rv, float* scale,
                      float* shift, int C, int B, float eps, hipStream_t s);
@@ -80,45 +26,18 @@ int pack_convT_weight(const float* v, const float* g, float* out, int Cin, int C
                       int Cin_pad, hipStream_t s, int pad = -1);
 int snake_inv_beta(const float* beta, float* out, int C, hipStream_t s);
 
-// ---- "activate once, convolve by DMA" path (conv_dma.hip)
+// geometry of one conv: out[n * ostride + ooff[ph]] = sum_tap W[ph][tap] x[n * istride + toff[ph][tap]]
+// (strided convs: istride; ConvTranspose1d: `phases` two-tap convs interleaved by ostride)
 struct ConvDmaPlanIn {
     int Cin, Cout, taps, phases, istride, ostride;
     int toff[kMaxPhases][kMaxTaps];
     int ooff[kMaxPhases];
-    int Nn_hint, B_hint;  // problem size the tile is chosen for
+    int Nn_hint, B_hint;  // problem size the handle is built for
 };
-struct ConvDmaPlan {
-    int mt, nt, KC, XW, LD, nstage, Cout_pad;
-    size_t w_floats;
-};
-struct ConvDmaRun {
-    const float* xp;   // [B][Cin][Tp] activated, haloed input (launch_act_pad)
-    const float* w;    // conv_dma_repack output
-    const float* bias;
-    const float* res;  // [B][Cout][Tout] or nullptr
-    float* y;          // [B][Cout][Tout]
-    double* stats;     // [B][G][2] sum / sum-of-squares accumulators of y, or nullptr
-    int B, Tp, Tout, Nn, G;
-};
-int conv_dma_halo();
-int conv_dma_row(int T);
-void conv_dma_plan(const ConvDmaPlanIn& in, ConvDmaPlan* p);
-int conv_dma_repack(const float* packed, float* out, const ConvDmaPlanIn& in, const ConvDmaPlan& p,
-                    hipStream_t s);
-int launch_conv_dma(const ConvDmaRun& r, const ConvDmaPlanIn& in, const ConvDmaPlan& p, hipStream_t s);
-// y[b,c,halo+t] = act(GroupNorm-affine(x)) with zeroed halo; stats = producer's accumulators
-// Without stats, gamma / beta (if given) are a plain per-channel affine (BatchNorm eval).
-// state (streaming): [B][C][conv_dma_halo()] activated samples preceding this chunk; used as
-// the left halo instead of zeros and replaced by the chunk's last samples afterwards.
-int launch_act_pad(const float* x, float* y, const double* stats, const float* gamma,
-                   const float* beta, const float* act_a, const float* act_b, int act, int B, int C,
-                   int T, int G, hipStream_t s, float* state = nullptr);
-// stats[b][g] += (sum, sum of squares) of x[b, group g, :]   (for producers that are not convs)
-int launch_stats_accum(const float* x, double* stats, int B, int C, int T, int G, hipStream_t s);
 
 // ---- time-major conv path (conv_tm.hip): activations [B][T][C], conv = balanced LDS-DMA GEMM.
-// Shares ConvDmaPlanIn (the conv's geometry); weights are the plain [phase][Cout][taps * Cp]
-// GEMM operand, independent of the tile configuration (chosen per launch).
+// Weights are the plain [phase][Cout][taps * Cp] GEMM operand, independent of the tile
+// configuration (chosen per launch).
 struct ConvTmPlan {
     int Cp, K, dil;
     bool ok;  // uniform tap spacing and |toff| within the halo
@@ -186,26 +105,6 @@ inline int conv_left_pad(int k, int dil, bool causal) {
     if (k == 1) return 0;
     const int p = (k - 1) * dil + 1;
     return causal ? p / 2 + (p - 1) / 2 : (p - 1) / 2;
-}
-
-inline void conv_args_init(ConvArgs& a, int B, int cin, int cout, int Tin, int Tout) {
-    memset(&a, 0, sizeof(a));
-    a.B = B;
-    a.Cin = cin;
-    a.Cin_pad = pad16(cin);
-    a.Cout = cout;
-    a.Tin = Tin;
-    a.Tout = Tout;
-    a.x_bstride = cin * Tin;
-    a.y_bstride = cout * Tout;
-    a.res_bstride = cout * Tout;
-    a.x2_bstride = cin * Tin;
-    a.scale_bstride = cin;
-    a.taps = 1;
-    a.phases = 1;
-    a.istride = 1;
-    a.ostride = 1;
-    a.Nn = Tout;
 }
 
 }  // namespace after

@@ -13,12 +13,13 @@
 //   undilated k = 3 / k = 5 convs); with dil > 1 the 32-deep slab s of K lives at
 //   s*32 + tap(s) * (dil-1) * Cp, one scalar multiply-shift per DMA piece.
 //
-// What this buys over conv_dma.hip ([B][C][T] layout, time along N): the X operand is read from
-// LDS as ds_read_b128 k-quads like the weights (was 4 x ds_read_b32 per 16x16 block and k-step),
-// the DMA pieces need no per-stage address arithmetic, the XCD tile map keeps an XCD on a compact
-// range of output positions so the haloed input is fetched once and the weights once per XCD
-// (conv_dma: every XCD re-read everything, 6.5x the algorithmic bytes), and small-T layers
-// (conditioning encoders, first decoder stage) get the split-K tiles that fill 256 CUs.
+// What this buys over a [B][C][T] layout with time along N (round 1's conv kernels): the X
+// operand is read from LDS as ds_read_b128 k-quads like the weights (was 4 x ds_read_b32 per
+// 16x16 block and k-step), the DMA pieces need no per-stage address arithmetic, the XCD tile map
+// keeps an XCD on a compact range of output positions so the haloed input is fetched once and the
+// weights once per XCD (round 1: every XCD re-read everything, 6.5x the algorithmic bytes), and
+// small-T layers (conditioning encoders, first decoder stage) get the split-K tiles that fill
+// 256 CUs.
 //
 // act_pad_tm_kernel materialises act(GroupNorm / BatchNorm-affine(x)) once per conv into the
 // zero-haloed buffer (conv padding = reading the halo = the reference's pad-after-activation,

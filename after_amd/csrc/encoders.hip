@@ -1,11 +1,11 @@
 // The once-per-clip conditioning encoders on gfx950:
 //   encoder_time = Encoder1D   (reference after/diffusion/networks/encoder.py:116-322)
 //   encoder      = ECAPATDNN   (reference after/diffusion/networks/ecapa_encoder.py:458-666)
-// Both are stacks of small 1-D convs.  Encoder1D runs on the LDS-DMA conv path of
-// conv_dma.hip (BatchNorm(eval) + SiLU applied once into a haloed row; streaming state).
-// ECAPA reuses the implicit-GEMM conv kernel of conv.hip (epilogue ReLU + BatchNorm affine
-// for TDNNBlock, reflect padding) and the fp32 MFMA GEMM for the squeeze-excitation /
-// pooling matvecs.
+// Both are stacks of small 1-D convs on the time-major conv path of conv_tm.hip.  Encoder1D:
+// BatchNorm(eval) + SiLU of the NEXT conv applied by the producing conv's second output
+// (offline) or by act_pad_tm with the streaming state.  ECAPA: epilogue ReLU + BatchNorm affine
+// for TDNNBlock, reflect padding, the Res2Net chain through second outputs, T-parallel pooling
+// statistics and one-wave-per-output GEMMs for the per-clip vectors.
 #include <new>
 #include <vector>
 
