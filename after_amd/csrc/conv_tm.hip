@@ -40,9 +40,28 @@ constexpr int HALO = 32;  // zero rows on both sides of every clip
 // addresses; the consumer adds the sub-slots in a fixed order.
 constexpr int kStatSub = 8;
 
+// sin(x) on the hardware sine unit (v_sin_f32 takes revolutions): the argument is reduced to
+// [-0.5, 0.5] revolutions with 1 / 2pi split in two floats and FMAs, so its error does not grow with
+// |x|.  Measured against fp64 on 4 M uniform samples each of |x| < 4, 50, 400: max abs error
+// 2.5e-7 (libm sinf: 6.9e-8, __sinf: 3.9e-7 / 3.4e-6 / 2.8e-5) at 2.8x the throughput of sinf.
+__device__ __forceinline__ float sin_rev(float x) {
+    constexpr float kInv2Pi = 0.15915494309189535f;
+    constexpr float kInv2PiLo = (float)(0.15915494309189535 - (double)kInv2Pi);
+    const float k = rintf(x * kInv2Pi);
+    float f = fmaf(x, kInv2Pi, -k);
+    f = fmaf(x, kInv2PiLo, f);
+    return __builtin_amdgcn_sinf(f);
+}
+
+constexpr int ACT_SNAKE_LIBM = 17;  // SnakeBeta with libm's sinf (AFTER_SNAKE_LIBM=1: A/B switch)
+
 __device__ __forceinline__ float act_apply(float v, int act, float pa, float pb) {
     switch (act) {
         case ACT_SNAKE: {
+            const float s = sin_rev(v * pa);
+            return v + pb * (s * s);
+        }
+        case ACT_SNAKE_LIBM: {
             const float s = sinf(v * pa);
             return v + pb * (s * s);
         }
@@ -793,6 +812,15 @@ int conv_tm_stat_sub() { return kStatSub; }
 int conv_tm_cp(int C) { return (C + 31) & ~31; }
 int conv_tm_rows(int T) { return T + 2 * HALO; }
 
+int snake_variant(int act) {
+    static int libm = -1;
+    if (libm < 0) {
+        const char* e = getenv("AFTER_SNAKE_LIBM");
+        libm = e ? atoi(e) : 0;
+    }
+    return act == ACT_SNAKE && libm ? ACT_SNAKE_LIBM : act;
+}
+
 int launch_act_pad_tm(const ActPadTm& p, hipStream_t s) {
     ActTmArgs a;
     memset(&a, 0, sizeof(a));
@@ -806,7 +834,7 @@ int launch_act_pad_tm(const ActPadTm& p, hipStream_t s) {
     a.state = p.state;
     a.scale_b = p.scale_b;
     a.shift_b = p.shift_b;
-    a.act = p.act;
+    a.act = snake_variant(p.act);
     a.C = p.C;
     a.Cp = conv_tm_cp(p.C);
     a.T = p.T;
@@ -940,7 +968,7 @@ int launch_conv_tm(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan
         a.y2_shift = r.y2_shift;
         a.y2_pa = r.y2_pa;
         a.y2_pb = r.y2_pb;
-        a.y2_act = r.y2_act;
+        a.y2_act = snake_variant(r.y2_act);
         a.y2_clo = r.y2_clo;
         a.y2_chi = r.y2_chi > 0 ? r.y2_chi : in.Cout;
         a.y2_ld = r.y2_ld > 0 ? r.y2_ld : conv_tm_cp(a.y2_chi - a.y2_clo);

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=20)
     ap.add_argument("--batches", default="1,8")
     ap.add_argument("--config", default="baseAE")
+    ap.add_argument("--only", default="", help="decode | encode")
     a = ap.parse_args()
     torch.set_grad_enabled(False)
     dev = torch.device("cuda:0")
@@ -33,6 +34,8 @@ def main():
         x = 0.1 * torch.randn(B, 1, 524288, device=dev)
         res = {"workload": f"{a.config} whole clips, B={B}"}
         for name, fn, gflop in (("decode", lambda: ae.decode(z), 95.3), ("encode", lambda: ae.encode(x), 45.2)):
+            if a.only and a.only != name:
+                continue
             for _ in range(3):
                 fn()
             ts = []
