@@ -1047,12 +1047,22 @@ int launch_conv_tm(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan
         const double bytes_per_flop = (bm + bn) * 4.0 / (2.0 * bm * bn);
         const double traffic = 2.0 * r.Nn * (double)N * K * ny * bytes_per_flop / (256.0 * 40.0);  // ~40 B/clk/CU
         double cost = (mfma > traffic ? mfma : traffic) + fixed + 0.25 * (mfma < traffic ? mfma : traffic);
-        if (c.id == 1) cost *= 1.04;  // measured: 64 x 96 trails 64 x 64 by 1-4 % wherever both balance
+        if (c.id == 1) cost *= 1.08;  // measured: 64 x 96 trails 64 x 64 by 1-5 % wherever both balance
+        // k = 1 convs with a residual / statistics / second-output epilogue: the K loop is 6-24 slabs, the
+        // epilogue moves as many bytes as the main loop, and the workgroups of a CU run in phase -- the
+        // narrow tiles (7 waves per SIMD instead of 4-5) overlap them best.  Measured inside the decoder
+        // (per-launch traces with forced tiles, B = 1 and 8): 64 x 32 beats 64 x 96 by 10-30 %, 64 x 64
+        // by 0-15 %.
+        if (in.taps == 1 && in.phases == 1 && (r.res || r.stats || r.y2)) cost *= c.nb == 3 ? 1.6 : (c.nb == 2 ? 1.3 : 1.0);
         if (!best || cost < best_cost) {
             best = c.id;
             best_cost = cost;
         }
     }
+    // (same measurement: once 64 x 32 tiles fill the chip twice over they win every such launch)
+    if (in.taps == 1 && in.phases == 1 && (r.res || r.stats || r.y2) &&
+        (double)cdiv(r.Nn, 64) * cdiv(N, 32) * (double)ny >= 512)
+        best = 3;
     AFTER_REQUIRE(best, AFTER_E_INVALID, "conv_tm: no tile configuration for K=%d", K);
     return launch_tm_id(best, a, r.B, dil, s);
 }
