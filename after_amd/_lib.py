@@ -89,6 +89,9 @@ SIGNATURES = {
     "after_ae_pqmf_inverse": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "after_ae_enable_streaming": (c_int, [c_void_p, c_int]),
     "after_ae_reset_state": (c_int, [c_void_p, c_void_p]),
+    "after_ae_enable_encoder_streaming": (c_int, [c_void_p, c_int, c_int]),
+    "after_ae_encoder_delay": (c_int, [c_void_p]),
+    "after_ae_set_decoder_gn_window": (c_int, [c_void_p, c_int]),
     "after_encoder1d_create": (c_int, [POINTER(Encoder1dCfg), POINTER(c_void_p), c_int, c_int, c_int,
                                        POINTER(c_void_p)]),
     "after_encoder1d_destroy": (None, [c_void_p]),

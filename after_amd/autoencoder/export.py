@@ -7,11 +7,15 @@ Three variants, as in the reference:
   offline            AE_notcausal / AE_causal, `export.ts`          (export_autoencoder.py:235-265)
   causal streaming   AE_causal under cc.use_cached_conv(True), `export_stream.ts` (:293-303):
                      the HIP codec keeps every conv's left context in HBM (after_ae_enable_streaming)
-  non-causal stream  AE_notcausal.decode (:128-153): the last `n_fade` latent frames are decoded
-                     again in front of each chunk and the overlap is cross-faded; the output lags
-                     by n_fade frames.  Its encoder twin (cached non-causal convs with delay
-                     compensation, :305-312) is NOT built: use the offline encoder per chunk or a
-                     causal model.
+  non-causal stream  `export_stream.ts` of a non-causal codec (:305-312): `model.encoder` is the
+                     cached twin (cached centred-padding convs with delay compensation:
+                     after_ae_enable_encoder_streaming; its latents lag by `encoder_delay` frames),
+                     every GroupNorm is CachedGroupNorm(stream=True) (sliding-window statistics,
+                     also in the offline decoder twin: after_ae_set_decoder_gn_window), and
+                     AE_notcausal.decode (:128-153) decodes the last `n_fade` latent frames again in
+                     front of each chunk and cross-fades the overlap; the output lags by n_fade frames.
+                     The windows are the lengths of the export script's first calls (131072 samples,
+                     64 latent frames); pass others through `gn_window_samples` / `gn_window_frames`.
 """
 import torch
 
@@ -22,7 +26,7 @@ from .model import AutoEncoder
 class ExportedAutoEncoder:
 
     def __init__(self, model: AutoEncoder, stream: bool = False, n_fade: int = 4, max_batch: int = 4,
-                 chunk_frames: int = 4):
+                 chunk_frames: int = 4, gn_window_samples: int = 131072, gn_window_frames: int = 64):
         self.model = model
         self.comp_ratio = model.ratio
         self.latent_size = model.z_channels
@@ -35,6 +39,12 @@ class ExportedAutoEncoder:
         if self.stream and self.causal:
             model.enable_streaming(self.max_batch, chunk_frames * self.comp_ratio)
         elif self.stream:
+            # :305-312: cached encoder twin + CachedGroupNorm.stream on both twins
+            self.encoder_delay = model.enable_encoder_streaming(self.max_batch, chunk_frames * self.comp_ratio,
+                                                                gn_window_samples=gn_window_samples)
+            if model.cfg["use_norm"]:
+                model.set_decoder_gn_window(self.max_batch, (chunk_frames + self.n_fade) * self.comp_ratio,
+                                            window_latent_frames=gn_window_frames)
             # export_autoencoder.py:62-65 (4 = nn~'s maximum batch; here max_batch)
             self.out_buffer = torch.zeros(self.max_batch, 1, self.comp_ratio * self.n_fade, device=dev)
             self.z_buffer = torch.zeros(self.max_batch, self.latent_size, self.n_fade, device=dev)
@@ -44,6 +54,7 @@ class ExportedAutoEncoder:
         if self.stream and self.causal:
             self.model.reset_state()
         elif self.stream:
+            self.model.reset_state()
             self.out_buffer.zero_()
             self.z_buffer.zero_()
 

@@ -320,6 +320,12 @@ class AutoEncoder(nn.Module):
         self._cap = cap
         if getattr(self, "_streaming", False):  # a re-created handle starts a fresh stream
             _lib.check(L.after_ae_enable_streaming(out, 1), "after_ae_enable_streaming")
+        if getattr(self, "_dec_gn_window", None):
+            _lib.check(L.after_ae_set_decoder_gn_window(out, int(self._dec_gn_window)),
+                       "after_ae_set_decoder_gn_window")
+        if getattr(self, "_enc_stream_window", None) is not None:
+            _lib.check(L.after_ae_enable_encoder_streaming(out, 1, int(self._enc_stream_window)),
+                       "after_ae_enable_encoder_streaming")
         return out
 
     def reserve(self, batch: int, samples: int):
@@ -333,6 +339,36 @@ class AutoEncoder(nn.Module):
         h = self._ensure(batch, chunk_samples)
         _lib.check(_lib.lib().after_ae_enable_streaming(h, int(enable)), "after_ae_enable_streaming")
         self._streaming = bool(enable)
+
+    def enable_encoder_streaming(self, batch: int, chunk_samples: int, gn_window_samples: int = 131072,
+                                 enable: bool = True) -> int:
+        """The streaming twin of a NON-causal codec's encoder, as export_autoencoder.py:305-312 builds it
+        (`model.encoder` under cc.use_cached_conv(True) with CachedGroupNorm.stream = True; PQMF and
+        decoder stay offline): `encode` becomes stateful over consecutive chunks of `batch` streams, every
+        conv reading cached past context, shortcuts and strided convs delay-compensated, GroupNorm
+        statistics taken over the previous `gn_window_samples` + the chunk (the reference's window is the
+        length of the module's first call: 131072 in the export script).  Returns the lag of the latents
+        behind the offline encoder, in latent frames."""
+        h = self._ensure(batch, max(chunk_samples, self.ratio))
+        L = _lib.lib()
+        _lib.check(L.after_ae_enable_encoder_streaming(h, int(enable), int(gn_window_samples)),
+                   "after_ae_enable_encoder_streaming")
+        self._enc_stream_window = int(gn_window_samples) if enable else None
+        return int(L.after_ae_encoder_delay(h))
+
+    def set_decoder_gn_window(self, batch: int, chunk_samples: int, window_latent_frames: int = 64):
+        """CachedGroupNorm(stream=True) on the decoder, as the same export binds it (SimpleNetsStream.py:
+        95-147): GroupNorm statistics over the previous `window_latent_frames` + the call (the reference's
+        window is the length of the first decode after construction: 64 frames in the export script).
+        0 = plain GroupNorm.  `reset_state` starts a new stream."""
+        h = self._ensure(batch, max(chunk_samples, self.ratio))
+        _lib.check(_lib.lib().after_ae_set_decoder_gn_window(h, int(window_latent_frames)),
+                   "after_ae_set_decoder_gn_window")
+        self._dec_gn_window = int(window_latent_frames) or None
+
+    @property
+    def encoder_delay(self) -> int:
+        return int(_lib.lib().after_ae_encoder_delay(self._handle)) if self._handle is not None else 0
 
     def reset_state(self):
         """Start of a new stream: zero every conv / PQMF context."""

@@ -226,6 +226,78 @@ __global__ void pqmf_istate_kernel(const float* __restrict__ y, float* __restric
     zstate[idx] = v;
 }
 
+// CachedGroupNorm(stream=True) (SimpleNetsStream.py:95-147): GroupNorm statistics over the previous
+// P frames + this chunk.  ring[b][g][i] = (sum, sum of squares) over the group's channels of one of
+// the last P frames (circular, `head` = oldest).  One block per (group, clip): adds the ring (before
+// overwriting it), the chunk's frames, stores the totals where act_pad_tm reads its sub-slot 0 and
+// moves the chunk's last min(T, P) frames into the ring.  Fixed summation order.
+__global__ __launch_bounds__(256) void gn_window_kernel(const float* __restrict__ x, float* __restrict__ ring,
+                                                        double* __restrict__ stats, int T, int C, int G, int P,
+                                                        int head) {
+    __shared__ double red[2][256];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int Cg = C / G;
+    float* rg = ring + ((size_t)b * G + g) * P * 2;
+    double s = 0, q = 0;
+    for (int i = tid; i < P; i += 256) {
+        s += rg[2 * i];
+        q += rg[2 * i + 1];
+    }
+    __syncthreads();  // every ring entry is read before any is replaced
+    const int keep0 = T > P ? T - P : 0;  // first chunk frame that stays in the window
+    for (int t = tid; t < T; t += 256) {
+        const float* xr = x + ((size_t)b * T + t) * C + (size_t)g * Cg;
+        float fs = 0.f, fq = 0.f;
+        for (int c = 0; c < Cg; ++c) {
+            const float v = xr[c];
+            fs += v;
+            fq += v * v;
+        }
+        s += fs;
+        q += fq;
+        if (t >= keep0) {
+            const int slot = T >= P ? t - keep0 : (head + t) % P;
+            rg[2 * slot] = fs;
+            rg[2 * slot + 1] = fq;
+        }
+    }
+    red[0][tid] = s;
+    red[1][tid] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            red[0][tid] += red[0][tid + o];
+            red[1][tid] += red[1][tid + o];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        stats[((size_t)b * G + g) * 2] = red[0][0];
+        stats[((size_t)b * G + g) * 2 + 1] = red[1][0];
+    }
+}
+
+// cached_conv.CachedPadding1d(d, crop=True) on a time-major tensor: out[t] = t < d ? state[t] : x[t - d];
+// the new state is the last d rows of (state, x), written to the other half of the ping-pong pair.
+__global__ void delay_rows_kernel(const float* __restrict__ x, const float* __restrict__ st_in,
+                                  float* __restrict__ st_out, float* __restrict__ out, int T, int C, int d,
+                                  size_t total) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const size_t per = (size_t)(T + d) * C;
+    const int b = (int)(idx / per);
+    const size_t e = idx - (size_t)b * per;
+    const int r = (int)(e / C), c = (int)(e - (size_t)r * C);
+    const float* xb = x + (size_t)b * T * C;
+    const float* sb = st_in + (size_t)b * d * C;
+    if (r < T) {
+        out[((size_t)b * T + r) * C + c] = r < d ? sb[(size_t)r * C + c] : xb[(size_t)(r - d) * C + c];
+    } else {
+        const int j = r - T;  // new state row j = row (j + T) of (state, x)
+        st_out[((size_t)b * d + j) * C + c] = j + T < d ? sb[(size_t)(j + T) * C + c] : xb[(size_t)(j + T - d) * C + c];
+    }
+}
+
 }  // namespace
 }  // namespace after
 
@@ -238,17 +310,26 @@ struct DmaConv {
     ConvDmaPlanIn in;
     ConvTmPlan tplan;
     float* w = nullptr;
+    int toff_offline[kMaxTaps] = {};  // phase-0 taps of the offline plan while a cached (streaming) form is active
 };
 struct ConvBlockW {
     float *gn_w = nullptr, *gn_b = nullptr, *alpha = nullptr, *invb = nullptr, *w = nullptr,
           *bias = nullptr;
     int cin = 0, cout = 0, k = 1, dil = 1;
     DmaConv d;
+    // CachedGroupNorm(stream=True): per-frame group sums of the previous gn_P frames (circular)
+    float* gn_ring = nullptr;  // [max_batch][G][gn_P][2]
+    int gn_P = 0;
+    mutable int gn_head = 0;
 };
 struct ResBlockW {
     ConvBlockW cb0, cb1;
     float *to_w = nullptr, *to_b = nullptr;  // 1x1 shortcut when cin != cout
     DmaConv to_d;
+    // cached_conv.AlignBranches: the shortcut's input runs `delay` frames late (ping-pong delay line)
+    float* dline[2] = {nullptr, nullptr};  // [max_batch][delay][cin]
+    int delay = 0;
+    mutable int dflip = 0;
 };
 struct ResampleW {
     float *alpha = nullptr, *invb = nullptr, *w = nullptr, *bias = nullptr;
@@ -306,6 +387,19 @@ struct after_ae {
     float *pq_fstate = nullptr, *pq_istate = nullptr;  // [B][Kf-1] audio, [B][M][Ki-1] bands
     int state_slot = 0;
     size_t slot_elems = 0;
+    // streaming NON-causal encoder (export_autoencoder.py:305-312): cached centred-padding convs with
+    // delay compensation + CachedGroupNorm(stream=True); the PQMF and the decoder stay offline
+    bool enc_cached = false;   // mode enabled
+    bool pass_stream = false;  // the pass being issued keeps conv state
+    bool pass_cached = false;  // ... and is the cached non-causal encoder
+    bool pass_gnwin = false;   // GroupNorm statistics over a sliding window (CachedGroupNorm.stream)
+    int dec_gn_frames = 0;     // decoder: CachedGroupNorm window in latent frames (0: plain GroupNorm)
+    int dec_gn_alloc = 0;
+    Arena sg;                  // the decoder's GroupNorm rings
+    int gn_window = 0;         // CachedGroupNorm window, in audio samples
+    int enc_delay = 0;         // latent frames the cached encoder lags the offline one
+    Arena sn;                  // its state: conv contexts, delay lines, GroupNorm rings
+    float* nc_state = nullptr;
 };
 constexpr int kStatSlots = 96;
 
@@ -418,10 +512,11 @@ double* next_stats(after_ae* h, int B) {
 int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const double* stats_in,
             const float* gamma, const float* beta, const float* alpha, const float* invb, int act,
             const float* bias, const float* res, float* y, int B, int Tin, int Tout, int Nn,
-            bool want_stats, double** stats_out, float* state_base = nullptr, int x_cm = 0, int y_cm = 0) {
+            bool want_stats, double** stats_out, float* state_base = nullptr, int x_cm = 0, int y_cm = 0,
+            int stat_T = 0) {
     const int cin = d.in.Cin, cout = d.in.Cout;
     float* state = nullptr;
-    if (h->streaming && state_base) state = state_base + (size_t)(h->state_slot++) * h->slot_elems;
+    if (h->pass_stream && state_base) state = state_base + (size_t)(h->state_slot++) * h->slot_elems;
     // x, res, y time-major [B][T][C] (x_cm / y_cm: the reference's [B][C][T] at the API edges)
     AFTER_REQUIRE((size_t)B * conv_tm_cp(cin) * conv_tm_rows(Tin) <= h->xp_elems, AFTER_E_CAPACITY,
                   "autoencoder: activation scratch too small");
@@ -446,6 +541,7 @@ int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const 
         p.T = Tin;
         p.G = cin < 8 ? cin : 8;
         p.x_cm = x_cm;
+        p.stat_T = stat_T;
         p.sub_stride = h->max_batch * 16;
         AFTER_TRY(launch_act_pad_tm(p, s));
         xin = h->xp;
@@ -458,7 +554,7 @@ int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const 
     r.res = res;
     r.y = y;
     r.G = cout < 8 ? cout : 8;
-    if (want_stats && h->norm) {
+    if (want_stats && h->norm && !h->pass_gnwin) {  // (streaming GroupNorm: window statistics, taken by the consumer)
         r.stats = next_stats(h, B);
         if (stats_out) *stats_out = r.stats;
     }
@@ -473,7 +569,7 @@ int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const 
         const char* e = getenv("AFTER_AE_FUSE_SNAKE");
         fuse_snake = e ? atoi(e) : 1;
     }
-    if (fuse_snake && h->next_alpha && !h->streaming && (cout & 31) == 0 && d.in.ostride == 1 &&
+    if (fuse_snake && h->next_alpha && !h->pass_stream && (cout & 31) == 0 && d.in.ostride == 1 &&
         (size_t)B * cout * conv_tm_rows(Tout) <= h->xp_elems) {
         r.y2 = xin == h->xp2 ? h->xp : h->xp2;
         r.y2_act = ACT_SNAKE;
@@ -490,6 +586,20 @@ int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const 
 int run_convblock2(after_ae* h, hipStream_t s, const ConvBlockW& cb, const float* x,
                    const double* stats_x, float* y, const float* res, int B, int T, bool want_stats,
                    double** stats_y, float* sb = nullptr) {
+    if (h->pass_gnwin && h->norm) {
+        // CachedGroupNorm(stream=True): statistics of (the previous gn_P frames, this chunk), taken here
+        // from the raw input; the ring then holds the newest gn_P frames
+        AFTER_REQUIRE(cb.gn_ring && cb.gn_P > 0, AFTER_E_INVALID, "autoencoder: streaming GroupNorm state missing");
+        const int G = cb.cin < 8 ? cb.cin : 8;
+        double* st = next_stats(h, B);
+        hipLaunchKernelGGL(gn_window_kernel, dim3(G, B), dim3(256), 0, s, x, cb.gn_ring, st, T, cb.cin, G, cb.gn_P,
+                           cb.gn_head);
+        AFTER_HIP_CHECK(hipGetLastError());
+        if (T < cb.gn_P) cb.gn_head = (cb.gn_head + T) % cb.gn_P;
+        else cb.gn_head = 0;
+        return run_dma(h, s, cb.d, x, st, cb.gn_w, cb.gn_b, cb.alpha, cb.invb, ACT_SNAKE, cb.bias, res, y, B, T,
+                       T, T, false, nullptr, sb, 0, 0, cb.gn_P + T);
+    }
     return run_dma(h, s, cb.d, x, h->norm ? stats_x : nullptr, cb.gn_w, cb.gn_b, cb.alpha, cb.invb,
                    ACT_SNAKE, cb.bias, res, y, B, T, T, T, want_stats, stats_y, sb);
 }
@@ -502,8 +612,21 @@ int run_resblock2(after_ae* h, hipStream_t s, const ResBlockW& rb, const float* 
                   float* by, int B, int T, double** stats, float* sb = nullptr, const float* na = nullptr,
                   const float* nb = nullptr) {
     const float* res = bx;
+    const float* sx = bx;  // the shortcut branch's input
+    if (h->pass_cached && rb.delay > 0) {
+        // cached_conv.AlignBranches(net, to_out, delays = [block1's delay, 0]): the shortcut sees its input
+        // rb.delay frames late (the second haloed scratch is free: no fused second outputs while streaming)
+        const int C = rb.cb0.cin;
+        AFTER_REQUIRE((size_t)B * T * C <= h->xp_elems, AFTER_E_CAPACITY, "autoencoder: delay scratch too small");
+        const size_t total = (size_t)B * (T + rb.delay) * C;
+        hipLaunchKernelGGL(delay_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, bx,
+                           rb.dline[rb.dflip], rb.dline[rb.dflip ^ 1], h->xp2, T, C, rb.delay, total);
+        AFTER_HIP_CHECK(hipGetLastError());
+        rb.dflip ^= 1;
+        sx = res = h->xp2;
+    }
     if (rb.to_w) {  // 1x1 shortcut: no temporal context, no state
-        AFTER_TRY(run_dma(h, s, rb.to_d, bx, nullptr, nullptr, nullptr, nullptr, nullptr, ACT_NONE,
+        AFTER_TRY(run_dma(h, s, rb.to_d, sx, nullptr, nullptr, nullptr, nullptr, nullptr, ACT_NONE,
                           rb.to_b, nullptr, by, B, T, T, T, false, nullptr));
         res = by;
     }
@@ -897,6 +1020,8 @@ extern "C" void after_ae_destroy(after_ae* h) {
     if (!h) return;
     h->sa.release();
     h->wd.release();
+    h->sn.release();
+    h->sg.release();
     h->wa.release();
     h->ws.release();
     delete h;
@@ -906,12 +1031,202 @@ extern "C" int after_ae_ratio(const after_ae* h) { return h ? h->ratio : 0; }
 
 // ---- streaming: cached_conv semantics for the causal, norm-free codec
 // (export_autoencoder.py:293-303: `cc.use_cached_conv(True)` twin of the causal model).
-extern "C" int after_ae_reset_state(after_ae* h, void* stream) {
-    AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
-    AFTER_REQUIRE(h->sa.base, AFTER_E_INVALID, "autoencoder: streaming was never enabled");
-    AFTER_HIP_CHECK(hipMemsetAsync(h->sa.base, 0, h->sa.off, (hipStream_t)stream));
+namespace {
+
+template <class F>
+void for_each_enc_resblock(after_ae* h, F fn) {
+    fn(h->enc_stem, 0);
+    for (size_t i = 0; i < h->enc_res.size(); ++i)
+        for (ResBlockW& rb : h->enc_res[i]) fn(rb, (int)i);
+}
+
+// decoder ConvBlock1d's in traversal order; stage = UpsampleBlock1d index (n_stages: the synth blocks)
+template <class F>
+void for_each_dec_convblock(after_ae* h, F fn) {
+    for (size_t i = 0; i < h->dec_res.size(); ++i)
+        for (ResBlockW& rb : h->dec_res[i]) {
+            fn(rb.cb0, (int)i);
+            fn(rb.cb1, (int)i);
+        }
+    fn(h->synth0, (int)h->dec_res.size());
+    fn(h->synth1, (int)h->dec_res.size());
+}
+
+// phase-0 taps of a conv <- `toff` (weights do not depend on them); keeps the offline ones for restore
+int set_taps(DmaConv& d, const int* toff, bool save) {
+    for (int t = 0; t < d.in.taps; ++t) {
+        if (save) d.toff_offline[t] = d.in.toff[0][t];
+        d.in.toff[0][t] = toff[t];
+    }
+    conv_tm_plan(d.in, &d.tplan);
+    AFTER_REQUIRE(d.tplan.ok, AFTER_E_INVALID, "autoencoder: cached conv context exceeds the %d-frame halo",
+                  conv_tm_halo());
     return AFTER_OK;
 }
+
+int right_pad(int k, int dil) { return k == 1 ? 0 : ((k - 1) * dil + 1) / 2; }  // cached_conv.get_padding, centred
+
+}  // namespace
+
+extern "C" int after_ae_reset_state(after_ae* h, void* stream) {
+    AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
+    AFTER_REQUIRE(h->sa.base || h->sn.base || h->sg.base, AFTER_E_INVALID, "autoencoder: streaming was never enabled");
+    if (h->sa.base) AFTER_HIP_CHECK(hipMemsetAsync(h->sa.base, 0, h->sa.off, (hipStream_t)stream));
+    if (h->sn.base) {
+        AFTER_HIP_CHECK(hipMemsetAsync(h->sn.base, 0, h->sn.off, (hipStream_t)stream));
+        for_each_enc_resblock(h, [](ResBlockW& rb, int) {
+            rb.dflip = 0;
+            rb.cb0.gn_head = rb.cb1.gn_head = 0;
+        });
+    }
+    if (h->sg.base) {
+        AFTER_HIP_CHECK(hipMemsetAsync(h->sg.base, 0, h->sg.off, (hipStream_t)stream));
+        for_each_dec_convblock(h, [](ConvBlockW& cb, int) { cb.gn_head = 0; });
+    }
+    return AFTER_OK;
+}
+
+// The streaming twin of a NON-causal codec's encoder (export_autoencoder.py:305-312: an Encoder1d built
+// under cc.use_cached_conv(True) with CachedGroupNorm.stream = True; PQMF, bottleneck and decoder stay
+// the offline modules).  cached_conv.CachedConv1d turns the centred padding (l, r) of every conv into
+// l + r frames of left context -- here: the same weights with all taps shifted to the past and the
+// activated context kept in HBM like the causal codec's -- and accounts for the r frames of lag:
+//   ResnetBlock1d   AlignBranches delays the shortcut's input by block1's r (SimpleNetsStream.py:236-249)
+//   Downsample1d    stride_delay = (f - (r + cd) % f) % f extra frames of input delay so that the
+//                   running delay stays a whole number of output frames; cd <- (r + stride_delay + cd) / f
+// gn_window_samples: CachedGroupNorm's window ("automatic" in the reference = the length of the first
+// call after construction, 131072 samples in the export script), in samples of the audio stream.
+extern "C" int after_ae_enable_encoder_streaming(after_ae* h, int enable, int gn_window_samples) {
+    AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
+    const after_ae_cfg& c = h->cfg;
+    const int n = c.n_stages, k = c.kernel_size;
+    if (!enable) {
+        if (h->enc_cached) {
+            for_each_enc_resblock(h, [&](ResBlockW& rb, int) { (void)set_taps(rb.cb0.d, rb.cb0.d.toff_offline, false); });
+            for (ResampleW& d : h->enc_down) (void)set_taps(d.d, d.d.toff_offline, false);
+            (void)set_taps(h->enc_tail.d, h->enc_tail.d.toff_offline, false);
+        }
+        h->enc_cached = false;
+        return AFTER_OK;
+    }
+    AFTER_REQUIRE(!h->causal, AFTER_E_INVALID,
+                  "autoencoder: the causal codec streams through after_ae_enable_streaming");
+    AFTER_REQUIRE(!h->streaming, AFTER_E_INVALID, "autoencoder: already streaming");
+    AFTER_REQUIRE(!h->norm || (gn_window_samples > 0 && gn_window_samples % h->ratio == 0), AFTER_E_INVALID,
+                  "autoencoder: CachedGroupNorm needs a window that is a multiple of %d samples (got %d)", h->ratio,
+                  gn_window_samples);
+    if (h->enc_cached) {
+        AFTER_REQUIRE(!h->norm || gn_window_samples == h->gn_window, AFTER_E_INVALID,
+                      "autoencoder: GroupNorm window is fixed at %d samples", h->gn_window);
+        return AFTER_OK;
+    }
+    // ---- delays and cached tap patterns, in the order the reference builds the modules
+    int rc = AFTER_OK, cd = 0;
+    int toff[kMaxTaps];
+    for_each_enc_resblock(h, [&](ResBlockW& rb, int) {
+        rb.delay = right_pad(rb.cb0.k, rb.cb0.dil);
+        for (int t = 0; t < rb.cb0.k; ++t) toff[t] = (t - (rb.cb0.k - 1)) * rb.cb0.dil;
+        const int r2 = set_taps(rb.cb0.d, toff, true);
+        rc = rc ? rc : r2;
+    });
+    if (rc) return rc;
+    cd = h->enc_stem.delay;
+    size_t fl = 0;  // floats of state
+    for (int i = 0; i < n; ++i) {
+        for (const ResBlockW& rb : h->enc_res[i]) cd += rb.delay;
+        ResampleW& d = h->enc_down[i];
+        const int f = d.f, r = f;                      // get_padding(2f) = (f - 1, f)
+        const int sd = (f - (r + cd) % f) % f;
+        cd = (r + sd + cd) / f;
+        for (int t = 0; t < 2 * f; ++t) toff[t] = t - (2 * f - 1) - sd;
+        AFTER_TRY(set_taps(d.d, toff, true));
+    }
+    for (int t = 0; t < 3; ++t) toff[t] = t - 2;
+    AFTER_TRY(set_taps(h->enc_tail.d, toff, true));
+    h->enc_delay = cd + right_pad(3, 1);
+    (void)k;
+    // ---- state: activated conv contexts, delay lines, GroupNorm rings
+    const int nd = c.n_dilations;
+    const int enc_slots = 1 + n * nd + n + 1;
+    h->slot_elems = (size_t)h->max_batch * conv_tm_cp(h->cmax) * conv_tm_halo();
+    auto pad64 = [](size_t v) { return (v + 63) & ~(size_t)63; };
+    fl = pad64(enc_slots * h->slot_elems);
+    for_each_enc_resblock(h, [&](ResBlockW& rb, int stage) {
+        fl += 2 * pad64((size_t)h->max_batch * rb.delay * rb.cb0.cin);
+        if (h->norm) {
+            int rate = h->M;  // samples per frame at this block
+            for (int q = 0; q < stage; ++q) rate *= c.factors[q];
+            // (stage = index of the DownsampleBlock1d holding the block; the stem and stage 0 share the rate)
+            rb.cb0.gn_P = rb.cb1.gn_P = gn_window_samples / rate;
+            fl += 2 * pad64((size_t)h->max_batch * 8 * rb.cb0.gn_P * 2);
+        }
+    });
+    AFTER_TRY(h->sn.init(fl * sizeof(float) + (64 << 10)));
+    h->nc_state = h->sn.take<float>(enc_slots * h->slot_elems);
+    bool ok = h->nc_state != nullptr;
+    for_each_enc_resblock(h, [&](ResBlockW& rb, int) {
+        for (int q = 0; q < 2; ++q) {
+            rb.dline[q] = h->sn.take<float>((size_t)h->max_batch * rb.delay * rb.cb0.cin + 4);
+            ok = ok && rb.dline[q];
+        }
+        if (h->norm) {
+            rb.cb0.gn_ring = h->sn.take<float>((size_t)h->max_batch * 8 * rb.cb0.gn_P * 2);
+            rb.cb1.gn_ring = h->sn.take<float>((size_t)h->max_batch * 8 * rb.cb1.gn_P * 2);
+            ok = ok && rb.cb0.gn_ring && rb.cb1.gn_ring && rb.cb0.gn_P > 0;
+        }
+        rb.dflip = 0;
+        rb.cb0.gn_head = rb.cb1.gn_head = 0;
+    });
+    AFTER_REQUIRE(ok, AFTER_E_NOMEM, "autoencoder: cached-encoder state allocation failed");
+    AFTER_HIP_CHECK(hipMemset(h->sn.base, 0, h->sn.off));
+    h->gn_window = gn_window_samples;
+    h->enc_cached = true;
+    return AFTER_OK;
+}
+
+// CachedGroupNorm(stream=True) on the (offline) decoder: what the reference's export_stream.ts of a
+// non-causal codec runs (export_autoencoder.py:305-312 binds CachedGroupNorm.stream = True before BOTH
+// twins are built) -- every GroupNorm of the decoder normalises over the previous window + the call's
+// frames.  window_latent_frames: the window in latent frames (the reference: the length of the first
+// decode after construction, 64 frames in the export script); 0 returns to plain GroupNorm.
+extern "C" int after_ae_set_decoder_gn_window(after_ae* h, int window_latent_frames) {
+    AFTER_REQUIRE(h && window_latent_frames >= 0, AFTER_E_INVALID, "bad argument");
+    if (!h->norm || window_latent_frames == 0) {
+        h->dec_gn_frames = 0;
+        return AFTER_OK;
+    }
+    AFTER_REQUIRE(!h->streaming, AFTER_E_INVALID, "autoencoder: the causal streaming codec has no GroupNorm");
+    if (h->sg.base) {
+        AFTER_REQUIRE(window_latent_frames == h->dec_gn_alloc, AFTER_E_INVALID,
+                      "autoencoder: decoder GroupNorm window is fixed at %d frames", h->dec_gn_alloc);
+        h->dec_gn_frames = window_latent_frames;
+        return AFTER_OK;
+    }
+    const after_ae_cfg& c = h->cfg;
+    const int n = c.n_stages;
+    size_t fl = 0;
+    for_each_dec_convblock(h, [&](ConvBlockW& cb, int stage) {
+        int up = 1;  // frames per latent frame at this block: the stage's own upsampling included
+        for (int q = 0; q <= stage && q < n; ++q) up *= c.factors[n - 1 - q];
+        cb.gn_P = window_latent_frames * up;
+        fl += ((size_t)h->max_batch * 8 * cb.gn_P * 2 + 63) & ~(size_t)63;
+    });
+    AFTER_TRY(h->sg.init(fl * sizeof(float) + (64 << 10)));
+    bool ok = true;
+    for_each_dec_convblock(h, [&](ConvBlockW& cb, int) {
+        cb.gn_ring = h->sg.take<float>((size_t)h->max_batch * 8 * cb.gn_P * 2);
+        cb.gn_head = 0;
+        ok = ok && cb.gn_ring;
+    });
+    AFTER_REQUIRE(ok, AFTER_E_NOMEM, "autoencoder: decoder GroupNorm state allocation failed");
+    AFTER_HIP_CHECK(hipMemset(h->sg.base, 0, h->sg.off));
+    h->dec_gn_alloc = window_latent_frames;
+    h->dec_gn_frames = window_latent_frames;
+    return AFTER_OK;
+}
+
+// latent frames by which the cached encoder's output lags the offline encoder's (0 when not enabled)
+extern "C" int after_ae_encoder_delay(const after_ae* h) { return h && h->enc_cached ? h->enc_delay : 0; }
 
 extern "C" int after_ae_enable_streaming(after_ae* h, int enable) {
     AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
@@ -921,7 +1236,9 @@ extern "C" int after_ae_enable_streaming(after_ae* h, int enable) {
     }
     AFTER_REQUIRE(h->causal && !h->norm, AFTER_E_INVALID,
                   "autoencoder: streaming needs the causal, GroupNorm-free codec "
-                  "(baseAE.gin:32-33,49)");
+                  "(baseAE.gin:32-33,49); a non-causal codec's encoder streams through "
+                  "after_ae_enable_encoder_streaming");
+    AFTER_REQUIRE(!h->enc_cached, AFTER_E_INVALID, "autoencoder: the cached encoder is active");
     const after_ae_cfg& c = h->cfg;
     AFTER_REQUIRE((c.kernel_size - 1) * c.dilations[c.n_dilations - 1] <= conv_tm_halo(),
                   AFTER_E_INVALID, "autoencoder: receptive field exceeds the streaming halo");
@@ -967,11 +1284,15 @@ extern "C" int after_ae_encode(after_ae* h, const float* x, float* z, int B, int
     const int n = c.n_stages, nd = c.n_dilations;
     int T = L / h->M;
     float *b0 = h->buf[0], *b1 = h->buf[1], *b2 = h->buf[2];
+    // (cached non-causal encoder: the PQMF analysis stays the offline, zero-padded one per chunk, as in the
+    // reference's export_stream.ts, where only `model.encoder` is the cached twin)
     AFTER_TRY(pqmf_forward(h, s, x, b0, B, L, h->streaming ? h->pq_fstate : nullptr, true));
     AFTER_TRY(begin_pass(h, s));
-    float* sb = h->streaming ? h->enc_state : nullptr;
+    h->pass_cached = h->pass_gnwin = h->enc_cached;
+    h->pass_stream = h->streaming || h->enc_cached;
+    float* sb = h->streaming ? h->enc_state : (h->enc_cached ? h->nc_state : nullptr);
     double* st = nullptr;
-    if (h->norm) {  // the first GroupNorm sees the PQMF output: its producer is not a conv
+    if (h->norm && !h->pass_gnwin) {  // the first GroupNorm sees the PQMF output: its producer is not a conv
         st = next_stats(h, B);
         AFTER_TRY(launch_stats_accum_tm(b0, st, B, h->M, T, h->M < 8 ? h->M : 8, s));
     }
@@ -1035,6 +1356,9 @@ static int decode_impl(after_ae* h, const float* z, float* x, float* mb, int B, 
     const int n = c.n_stages, nd = c.n_dilations;
     float *cur = h->buf[0], *t1 = h->buf[1], *t2 = h->buf[2];
     AFTER_TRY(begin_pass(h, s));
+    h->pass_cached = false;
+    h->pass_gnwin = h->norm && h->dec_gn_frames > 0;
+    h->pass_stream = h->streaming;
     float* sb = h->streaming ? h->dec_state : nullptr;
     double* st = nullptr;
     AFTER_TRY(run_dma(h, s, h->dec_head.d, z, nullptr, nullptr, nullptr, nullptr, nullptr, ACT_NONE,

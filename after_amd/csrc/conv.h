@@ -83,6 +83,7 @@ struct ActPadTm {
     int act, B, C, T, G, x_cm, ldx, pad_reflect, sub_stride;
     const float* x2;      // optional second time-major input [B][T][ldx2], added to x before the affine
     int ldx2;
+    int stat_T;           // frames the statistics cover (0: T; streaming GroupNorm: window + T)
 };
 int conv_tm_halo();
 int conv_tm_stat_sub();   // accumulator pairs per (clip, group): see conv_tm.hip

@@ -90,7 +90,7 @@ struct ActTmArgs {
     const float* shift_b;
     const float* x2;      // optional second time-major input added to x first (Res2Net: x_i + y_{i-1})
     int ldx2;
-    int act, C, Cp, T, Tp, G, x_cm, ldx, rows_per_block, pad_reflect, sub_stride, xcd_rows;
+    int act, C, Cp, T, Tp, G, x_cm, ldx, rows_per_block, pad_reflect, sub_stride, xcd_rows, stat_T;
     float eps;
 };
 
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void act_pad_tm_kernel(ActTmArgs a) {
     if (a.stats) {
         if (threadIdx.x < a.G) {
             const int gI = threadIdx.x;
-            const double n = (double)(a.C / a.G) * a.T;
+            const double n = (double)(a.C / a.G) * a.stat_T;
             double sv[kStatSub], qv[kStatSub];
 #pragma unroll
             for (int u = 0; u < kStatSub; ++u) {
@@ -846,6 +846,7 @@ int launch_act_pad_tm(const ActPadTm& p, hipStream_t s) {
     a.sub_stride = p.sub_stride;
     a.x2 = p.x2;
     a.ldx2 = p.ldx2;
+    a.stat_T = p.stat_T > 0 ? p.stat_T : p.T;
     AFTER_REQUIRE(!p.x2 || (!p.x_cm && (p.ldx2 & 3) == 0), AFTER_E_INVALID, "act_pad_tm: x2 needs time-major inputs");
     a.eps = 1e-5f;
     AFTER_REQUIRE(a.Cp <= 1024, AFTER_E_INVALID, "act_pad_tm: at most 1024 channels (got %d)", p.C);

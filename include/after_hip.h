@@ -228,6 +228,30 @@ int after_ae_enable_streaming(after_ae* h, int enable);
 /* zero every streaming state (start of a new stream) */
 int after_ae_reset_state(after_ae* h, void* stream);
 
+/* Streaming twin of a NON-causal codec's encoder: what export_autoencoder.py:305-312 packs into
+ * export_stream.ts for a non-causal model -- `model.encoder` rebuilt under cc.use_cached_conv(True)
+ * with CachedGroupNorm.stream = True (SimpleNetsStream.py:95-147), while the PQMF, the bottleneck and
+ * the decoder stay the offline modules.  after_ae_encode becomes stateful over consecutive chunks of
+ * the same B streams:
+ *   - every conv keeps its l + r frames of (activated) context and reads only the past
+ *     (cached_conv.CachedConv1d on the centred padding (l, r));
+ *   - ResnetBlock1d's shortcut input is delayed by block1's r frames (cc.AlignBranches,
+ *     SimpleNetsStream.py:236-249); Downsample1d adds (f - (r + cd) % f) % f frames of input delay;
+ *   - GroupNorm statistics cover the previous `gn_window_samples` of the stream + the chunk
+ *     (the reference's "automatic" window = the length of the first call, 131072 samples in the
+ *     export script); ignored for a GroupNorm-free codec;
+ *   - the PQMF analysis is the offline, zero-padded one on each chunk, as in the reference.
+ * The latents lag the offline encoder by after_ae_encoder_delay() frames; without GroupNorm they are
+ * the offline latents of the concatenated multiband stream, that many frames late, for any chunking.
+ * after_ae_decode is unaffected.  AFTER_E_INVALID for a causal codec (use after_ae_enable_streaming). */
+int after_ae_enable_encoder_streaming(after_ae* h, int enable, int gn_window_samples);
+int after_ae_encoder_delay(const after_ae* h);
+/* CachedGroupNorm(stream=True) on the decoder (the same export binds it for both twins): every
+ * GroupNorm of after_ae_decode normalises over the previous `window_latent_frames` of the stream +
+ * the call's frames (the reference: the length of the first decode after construction, 64 frames in
+ * the export script).  0 = plain per-call GroupNorm.  after_ae_reset_state zeroes the windows. */
+int after_ae_set_decoder_gn_window(after_ae* h, int window_latent_frames);
+
 /* ------------------------------------------------------- conditioning encoders
  * encoder_time: Encoder1D (after/diffusion/networks/encoder.py:116-322), causal
  * padding through the scoped gin binding (after/diffusion/configs/base.gin:55). */

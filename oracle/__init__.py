@@ -19,7 +19,11 @@ package is absent from the image, so its offline padding arithmetic
 reference itself asserts (decode(encode(x)).shape == x.shape, ratio 2048).
 
 The streaming codec (cached_conv state across chunks) is PARITY UNPINNED for
-the same reason -- see oracle/streaming.py for what it is anchored on instead.
+the same reason -- see oracle/streaming.py (causal codec) and oracle/cached.py
+(the non-causal codec's cached encoder twin; its CachedGroupNorm part IS pinned,
+tests/golden/cached_gn.npz) for what they are anchored on instead.  The
+checkpoint / gin ingestion is pinned by a run folder the reference itself wrote
+(tests/golden/ckpt_nano).
 
 All functions are *functional*: they take a state dict whose keys are the
 reference's own `state_dict()` keys, so weights move
@@ -33,4 +37,5 @@ from .autoencoder import (ae_encode, ae_decode, pqmf_forward, pqmf_inverse,  # n
                           fold_weight_norm)
 from .encoders import encoder1d_forward, ecapa_forward  # noqa: F401
 from .streaming import stream_forward  # noqa: F401
+from .cached import NonCausalStreamEncoder, StreamGroupNorm, StreamNormDecoder  # noqa: F401
 from .unet1d import unet1d_forward  # noqa: F401

@@ -71,11 +71,15 @@ def pqmf_inverse(sd, x, mode="centered"):
     return x.reshape(x.shape[0], x.shape[1], -1)
 
 
-def conv_block(sd, pre, x, cfg, kernel_size=3, dilation=1):
+def conv_block(sd, pre, x, cfg, kernel_size=3, dilation=1, norm=None):
     """SimpleNetsStream.py:150-194 (ConvBlock1d): GroupNorm(min(C,8)) ->
-    SnakeBeta -> weight-normed Conv1d with get_padding(k, dilation)."""
+    SnakeBeta -> weight-normed Conv1d with get_padding(k, dilation).
+    norm: optional stateful stand-in for the GroupNorm, norm(prefix, x) (CachedGroupNorm.stream,
+    oracle/cached.py)."""
     c = x.shape[1]
-    if cfg["use_norm"]:
+    if cfg["use_norm"] and norm is not None:
+        x = norm(pre, x)
+    elif cfg["use_norm"]:
         x = F.group_norm(x, min(c, 8), sd[pre + "net.0.gn.weight"], sd[pre + "net.0.gn.bias"],
                          1e-5)
     x = snake_beta(x, sd[pre + "net.1.alpha"], sd[pre + "net.1.beta"])
@@ -84,20 +88,20 @@ def conv_block(sd, pre, x, cfg, kernel_size=3, dilation=1):
     return F.conv1d(x, w, b, dilation=dilation)
 
 
-def resnet_block(sd, pre, x, cfg, dilation=1, use_res=True):
+def resnet_block(sd, pre, x, cfg, dilation=1, use_res=True, norm=None):
     """SimpleNetsStream.py:197-254 (ResnetBlock1d) / :257-298 (NoRes)."""
     k = cfg["kernel_size"]
     if use_res:
-        y = conv_block(sd, pre + "net.branches.0.0.", x, cfg, k, dilation)
-        y = conv_block(sd, pre + "net.branches.0.1.", y, cfg, 1, 1)
+        y = conv_block(sd, pre + "net.branches.0.0.", x, cfg, k, dilation, norm)
+        y = conv_block(sd, pre + "net.branches.0.1.", y, cfg, 1, 1, norm)
         if (pre + "net.branches.1.weight_v") in sd:
             w, b = _wn(sd, pre + "net.branches.1.")
             res = F.conv1d(x, w, b)
         else:
             res = x
         return y + res
-    y = conv_block(sd, pre + "net.0.", x, cfg, k, dilation)
-    return conv_block(sd, pre + "net.1.", y, cfg, 1, 1)
+    y = conv_block(sd, pre + "net.0.", x, cfg, k, dilation, norm)
+    return conv_block(sd, pre + "net.1.", y, cfg, 1, 1, norm)
 
 
 def encoder_forward(sd, x, cfg):
@@ -121,7 +125,7 @@ def encoder_forward(sd, x, cfg):
     return F.conv1d(x, w, b)
 
 
-def decoder_forward(sd, z, cfg):
+def decoder_forward(sd, z, cfg, norm=None):
     """SimpleNetsStream.py:552-651 (Decoder1d) with UpsampleBlock1d :344-384."""
     pre = "decoder.net."
     w, b = _wn(sd, pre + "0.")
@@ -140,8 +144,8 @@ def decoder_forward(sd, z, cfg):
         else:
             x = F.conv_transpose1d(x, w, b, stride=f, padding=f // 2)
         for j, d in enumerate(cfg["dilations"]):
-            x = resnet_block(sd, f"{bp}{j + 2}.", x, cfg, d)
-    x = resnet_block(sd, "decoder.synth.branches.0.", x, cfg, 1, use_res=False)
+            x = resnet_block(sd, f"{bp}{j + 2}.", x, cfg, d, norm=norm)
+    x = resnet_block(sd, "decoder.synth.branches.0.", x, cfg, 1, use_res=False, norm=norm)
     if cfg["use_loudness"]:
         x, amp = x.split(x.shape[1] // 2, 1)
         x = x * torch.sigmoid(amp)

@@ -184,6 +184,22 @@ def ae_case(case, cfg_name, B, L, seed):
     save(case, meta, x=x, z=z, zin=zin, y=y, multiband=mb, pqmf_roundtrip=xr, **keepdict(keep))
 
 
+def cached_gn_case():
+    """CachedGroupNorm(stream=True) (SimpleNetsStream.py:95-147), AFTER's own streaming GroupNorm:
+    three chunks of different lengths through one module (window = the first chunk's length)."""
+    C, G, B = 12, 4, 3
+    gn = R.ae.CachedGroupNorm(G, C, stream=True)
+    w = detweights.seeded_tensor("gn_w", (C, ), 71) * 0.3 + 1.0
+    b = detweights.seeded_tensor("gn_b", (C, ), 72) * 0.2
+    gn.gn.weight.data.copy_(w)
+    gn.gn.bias.data.copy_(b)
+    lens = (24, 8, 40)
+    xs = [detweights.seeded_tensor(f"x{i}", (B, C, n), 73 + i) * (1.0 + i) + 0.5 * i for i, n in enumerate(lens)]
+    ys = [gn(x).clone() for x in xs]
+    save("cached_gn", dict(kind="cached_gn", C=C, G=G, B=B, lens=list(lens)), weight=w, bias=b,
+         **{f"x{i}": x for i, x in enumerate(xs)}, **{f"y{i}": y for i, y in enumerate(ys)})
+
+
 def pqmf_case():
     p = R.pqmf.CachedPQMF(attenuation=100, n_band=16)
     save("pqmf_bank", dict(kind="pqmf"), hk=p.hk, h=p.h, forward_w=p.forward_conv.weight,
@@ -405,6 +421,7 @@ def checkpoint_case(case="ckpt_nano", seed=71):
 
 CASES = {
     "pqmf_bank": pqmf_case,
+    "cached_gn": cached_gn_case,
     "mask_rope": mask_case,
     "denoiser_micro": lambda: denoiser_case("denoiser_micro", "micro", 2, 32, 11, [4]),
     "denoiser_micro_ragged": lambda: denoiser_case("denoiser_micro_ragged", "micro", 3, 27, 12, [3]),

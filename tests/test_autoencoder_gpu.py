@@ -144,22 +144,33 @@ def test_streaming_refused_for_normalised_codec(hip_device):
         ae.enable_streaming(1, 2048)
 
 
-def test_exported_noncausal_stream_decode_crossfade(hip_device):
-    """AE_notcausal.decode (export_autoencoder.py:128-153) against the same recipe on the oracle."""
+def test_exported_noncausal_stream_twin(hip_device):
+    """export_stream.ts of a non-causal codec (export_autoencoder.py:305-312, :127-153): the cached
+    encoder twin, CachedGroupNorm(stream=True) on both twins and the cross-faded decode, against the
+    same recipe on the oracle (oracle/cached.py)."""
     from after_amd.autoencoder import ExportedAutoEncoder, embed_dataset
     fx = Fixture("ae_micro")
     sd = fx.state_dict()
     ae, cfg = build("microAE", sd, hip_device)
-    ex = ExportedAutoEncoder(ae, stream=True, n_fade=4, max_batch=2)
-    g = torch.Generator().manual_seed(3)
     Z, ratio, nf = cfg["z_channels"], ae.ratio, 4
+    # windows = the lengths of the first calls, as CachedGroupNorm's "automatic" padding sets them
+    ex = ExportedAutoEncoder(ae, stream=True, n_fade=nf, max_batch=2, chunk_frames=4,
+                             gn_window_samples=4 * ratio, gn_window_frames=4 + nf)
+    ref_enc = oracle.NonCausalStreamEncoder(sd, cfg)
+    ref_dec = oracle.StreamNormDecoder(sd, cfg)
+    assert ex.encoder_delay == ref_enc.delay
+    g = torch.Generator().manual_seed(3)
     zbuf = torch.zeros(2, Z, nf)
     obuf = torch.zeros(2, 1, ratio * nf)
     alpha = torch.linspace(0, 1, nf * ratio)[None, None, :]
     for chunk in (4, 4, 2):
+        audio = 0.1 * torch.randn(2, 1, chunk * ratio, generator=g)
+        zw = ref_enc.encode(audio)
+        zg = ex.encode(audio.to(hip_device)).cpu()
+        assert max_abs(zg, zw) < 1e-4 * max(zw.abs().max().item(), 1.0)
         z = torch.randn(2, Z, chunk, generator=g)
         zz = torch.cat((zbuf, z), -1)
-        x = oracle.ae_decode(sd, zz, cfg)
+        x = ref_dec.decode(zz)
         zbuf = zz[..., -nf:].clone()
         x[..., :ratio * nf] = (1 - alpha) * obuf + alpha * x[..., :ratio * nf]
         obuf = x[..., -ratio * nf:].clone()
@@ -167,8 +178,10 @@ def test_exported_noncausal_stream_decode_crossfade(hip_device):
         got = ex.decode(z.to(hip_device)).cpu()
         assert got.shape == want.shape == (2, 1, chunk * ratio)
         assert max_abs(got, want) < 1e-4 * max(want.abs().max().item(), 1.0)
-    # dataset embedding helper: batches of chunks through encode (prepare_dataset.py:313-323)
+    # dataset embedding helper on the offline export: batches of chunks through encode
+    # (prepare_dataset.py:313-323)
+    ae2, _ = build("microAE", sd, hip_device)
     w = 0.1 * torch.randn(5, 4096, generator=g)
-    z = embed_dataset(ex, w, batch_size=2)
+    z = embed_dataset(ExportedAutoEncoder(ae2), w, batch_size=2)
     want = oracle.ae_encode(sd, w[:, None, :], cfg)
     assert z.shape == want.shape and max_abs(z, want) < 1e-4 * want.abs().max().item()

@@ -3,13 +3,14 @@
 cached_conv (acids-ircam/cached_conv, pinned by the reference's requirements) is absent
 from /root/reference; its published algorithm is restated here chunk by chunk in plain
 torch and compared with the whole-stream forms the oracle uses."""
+import pytest
 import torch
 import torch.nn.functional as F
 
 import oracle
 from after_amd import configs
 from fixtures import Fixture, max_abs
-from oracle.autoencoder import get_padding
+from oracle.autoencoder import encoder_forward, get_padding
 
 torch.set_grad_enabled(False)
 
@@ -76,3 +77,54 @@ def test_oracle_stream_decoder_differs_only_by_convT_alignment():
     b = oracle.ae_decode(sd, z, dict(cfg, stream_convT=True))
     assert a.shape == b.shape and torch.isfinite(b).all()
     assert max_abs(a, b) > 0
+
+
+# ---- the streaming NON-causal codec encoder (export_autoencoder.py:305-312), oracle/cached.py
+def test_stream_groupnorm_matches_reference_class():
+    """CachedGroupNorm(stream=True) is AFTER's own code: the restatement against the reference
+    class's outputs over three chunks of different lengths (tests/golden/cached_gn.npz)."""
+    fx = Fixture("cached_gn")
+    gn = oracle.StreamGroupNorm(fx.meta["G"], fx.t("weight"), fx.t("bias"))
+    for i in range(len(fx.meta["lens"])):
+        y = gn(fx.t(f"x{i}"))
+        assert max_abs(y, fx.t(f"y{i}")) < 2e-6, i
+
+
+@pytest.mark.parametrize("chunks", [[128] * 32, [256, 128, 384, 1280, 2048], [4096]])
+def test_noncausal_stream_encoder_is_the_delayed_offline_encoder(chunks):
+    """What cached_conv exists to provide, checked on the restatement: without GroupNorm the cached
+    centred-padding Encoder1d fed chunk by chunk equals the offline encoder on the whole stream,
+    `delay` latent frames late, for any chunking (multiband frames; 128 = the product of the strides)
+    -- once the start-up transient has left the receptive field (the delayed branches emit
+    bias-only frames for "negative time", where the offline encoder pads zeros)."""
+    fx = Fixture("ae_micro")
+    sd = fx.state_dict()
+    cfg = dict(configs.autoencoder_config("microAE"), use_norm=False)
+    g = torch.Generator().manual_seed(5)
+    mb = torch.randn(2, 16, sum(chunks), generator=g)
+    enc = oracle.NonCausalStreamEncoder(sd, cfg)
+    z = torch.cat([enc.encoder(c) for c in mb.split(chunks, -1)], -1)
+    want = encoder_forward(sd, mb, cfg)
+    D = enc.delay
+    W = D + 2  # left receptive field in latent frames (same construction as the delay) + margin
+    assert D > 0 and z.shape == want.shape
+    a, b = z[..., D + W:], want[..., W:-D]
+    assert a.shape[-1] >= 8
+    assert max_abs(a, b) < 1e-4 * want.abs().max().item(), (D, max_abs(a, b))
+    # and the chunking itself never matters (every state is exact)
+    whole = oracle.NonCausalStreamEncoder(sd, cfg).encoder(mb)
+    assert max_abs(z, whole) < 1e-4 * want.abs().max().item()
+
+
+def test_noncausal_stream_encoder_delay_bookkeeping():
+    """The reference's own call sites fix the delays (SimpleNetsStream.py:236-249, :323-338, :441-456):
+    microAE (k = 3, dilations 1, 3, 9, strides 2, 2, 2, 4, 4) by hand."""
+    fx = Fixture("ae_micro")
+    cfg = dict(configs.autoencoder_config("microAE"), use_norm=False)
+    enc = oracle.NonCausalStreamEncoder(fx.state_dict(), cfg)
+    cd = 1  # stem: block1's right padding
+    for f in cfg["factors"]:
+        cd += 1 + 3 + 9  # three residual blocks, right padding = dilation
+        sd_ = (f - (f + cd) % f) % f  # Downsample1d: right padding f, stride f
+        cd = (f + sd_ + cd) // f
+    assert enc.delay == cd + 1  # tail conv k = 3
