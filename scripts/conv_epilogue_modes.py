@@ -1,5 +1,9 @@
+"""Cost of the conv epilogue features on the codec's k = 1 / k = 3 layers: bare conv, + statistics,
++ residual, both; heuristic tile and the 64 x 96 / 64 x 64 tiles.
+
+    python scripts/conv_epilogue_modes.py [batch]"""
 import sys, os, json
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from after_amd import diag
 from scripts.bench_conv import timeit, PEAK

@@ -1,3 +1,6 @@
+// Accuracy (against fp64) and throughput of sin variants for SnakeBeta: libm sinf, __sinf, the hardware
+// sine with a two-float FMA range reduction (conv_tm.hip sin_rev), a degree-11 polynomial.
+//   hipcc --offload-arch=gfx950 -O3 -o sin_probe.bin sin_probe.hip && ./sin_probe.bin
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
