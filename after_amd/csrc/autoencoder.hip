@@ -1407,10 +1407,22 @@ __global__ __launch_bounds__(1024) void latent_reg_kernel(const float* __restric
                                                           float scale, float* __restrict__ out) {
     __shared__ double red[1024];
     double acc = 0.0;
-    for (long long i = threadIdx.x; i < n; i += 1024) {
-        const float v = fabsf(z[i]) - scale;
-        acc += (double)(v > 0.f ? v : expm1f(v));
+    auto term = [scale](float x) {
+        const float v = fabsf(x) - scale;
+        return (double)(v > 0.f ? v : expm1f(v));
+    };
+    // four float4 in flight per thread (the loads of one trip are independent), scalar tail
+    const long long n4 = ((uintptr_t)z & 15) == 0 ? n / 4 : 0;
+    const float4* z4 = reinterpret_cast<const float4*>(z);
+    for (long long i = threadIdx.x; i < n4; i += 4096) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = i + 1024 * u < n4 ? z4[i + 1024 * u] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + 1024 * u < n4) acc += (term(v[u].x) + term(v[u].y)) + (term(v[u].z) + term(v[u].w));
     }
+    for (long long i = 4 * n4 + threadIdx.x; i < n; i += 1024) acc += term(z[i]);
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int w = 512; w > 0; w >>= 1) {
