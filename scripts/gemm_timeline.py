@@ -34,3 +34,15 @@ pf, pv, pb = pk & 0xFFFFF, (pk >> 20) & 0xFFFFF, (pk >> 40) & 0xFFFFF
 print(f"  loop phases (wave 0, cycles summed over slabs): frag-fence med {np.median(pf):.0f}  vmcnt-wait med {np.median(pv):.0f}  barrier med {np.median(pb):.0f}  (loop med {np.median(d[:,2]-d[:,1]):.0f})")
 u, c = np.unique(smid, return_counts=True)
 print(f"  distinct CU ids {len(u)}; WGs per CU histogram:", dict(zip(*np.unique(c, return_counts=True))))
+# per-CU residency slots: start time of the k-th workgroup that landed on each CU
+order = np.argsort(rs)
+slots = {}
+for i in order:
+    slots.setdefault(int(smid[i]), []).append(rs[i])
+mx = max(len(v) for v in slots.values())
+for k in range(min(mx, 6)):
+    v = np.array([s[k] for s in slots.values() if len(s) > k])
+    print(f"  slot {k}: start ns min {v.min():.0f} med {np.median(v):.0f} max {v.max():.0f}  (n={len(v)})")
+xcd = smid  # start order within an XCD-sized group
+print("  first 24 start times (ns):", [int(x) for x in np.sort(rs)[:24]])
+print("  every 32nd start time (ns):", [int(x) for x in np.sort(rs)[::32]])
