@@ -1322,8 +1322,9 @@ extern "C" int after_sample(after_denoiser* h, const float* x0, const float* con
     AFTER_REQUIRE(B > 0, AFTER_E_INVALID, "empty batch");
     AFTER_TRY(check_shape(h, 3 * B, T));
     AFTER_REQUIRE(x0 && cond && time_cond && out, AFTER_E_INVALID, "null tensor argument");
-    AFTER_REQUIRE(nb_steps > 0 && nb_steps <= h->max_steps, AFTER_E_CAPACITY,
-                  "nb_steps=%d outside (0, max_steps=%d]", nb_steps, h->max_steps);
+    AFTER_REQUIRE(nb_steps > 0, AFTER_E_INVALID, "nb_steps=%d", nb_steps);
+    AFTER_REQUIRE(nb_steps <= h->max_steps, AFTER_E_CAPACITY, "nb_steps=%d exceeds max_steps=%d", nb_steps,
+                  h->max_steps);
     if (h->cache > 0) {  // streaming sampler: one cache slot per step
         AFTER_REQUIRE(nb_steps <= h->cache_steps, AFTER_E_CAPACITY,
                       "nb_steps=%d exceeds the %d cache slots", nb_steps, h->cache_steps);
