@@ -1,3 +1,5 @@
+"""Streaming-size GEMMs (M = 48 / 96 tokens: 4 frames x 3 CFG rows x 4 / 8 streams) over tile configurations.
+    python scripts/bench_gemm_stream.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
