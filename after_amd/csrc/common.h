@@ -119,5 +119,8 @@ struct GemmArgs {
 int launch_gemm_cfg_euler(const GemmArgs& g, hipStream_t stream);
 int launch_gemm(const GemmArgs& g, hipStream_t stream);
 int launch_gemm_cfg(const GemmArgs& g, int force_mt, int force_nt, hipStream_t stream);
+// fp32 GEMM through the bf16 matrix pipe (gemm_x6.hip; experimental, opt-in): W3 = [N][3][K] bf16 planes of W
+int gemm_x6_split(const float* W, int ldw, unsigned short* W3, int N, int K, hipStream_t s);
+int launch_gemm_x6(const GemmArgs& g, const unsigned short* W3, int tile, hipStream_t stream);
 
 }  // namespace after

@@ -22,6 +22,30 @@ def gemm(a, w, bias=None, residual=None, epilogue=0, tile=(0, 0), out=None):
     return out
 
 
+def split_x6(w):
+    """The three bf16 planes [N, 3, K] (int16 storage) of an fp32 weight, for gemm_x6."""
+    w = _lib.require_gpu_tensor(w, "w")
+    N, K = w.shape
+    w3 = torch.empty(N, 3, K, device=w.device, dtype=torch.int16)
+    _lib.check(_lib.lib().after_gemm_x6_split(_lib.ptr(w), w.stride(0), _lib.ptr(w3), N, K,
+                                              _lib.current_stream(w.device)), "after_gemm_x6_split")
+    return w3
+
+
+def gemm_x6(a, w3, bias=None, residual=None, epilogue=0, tile=0, out=None):
+    """EXPERIMENTAL: out[M,N] = epi(a @ w^T + bias) with fp32 products formed on the bf16 matrix pipe."""
+    a = _lib.require_gpu_tensor(a, "a", allow_row_stride=True)
+    M, K = a.shape
+    N = w3.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    rc = _lib.lib().after_gemm_x6(_lib.ptr(a), a.stride(0), _lib.ptr(w3), _lib.ptr(bias), _lib.ptr(residual),
+                                  residual.stride(0) if residual is not None else 0, _lib.ptr(out), out.stride(0),
+                                  M, N, K, int(epilogue), int(tile), _lib.current_stream(a.device))
+    _lib.check(rc, "after_gemm_x6")
+    return out
+
+
 class ConvTm:
     """One Conv1d layer on the time-major conv path (after_convtm_*): parity tests / tile sweeps."""
 

@@ -360,6 +360,13 @@ int after_gemm_f32(const float* A, int lda, const float* W, int ldw, const float
                    const float* R, int ldr, float* C, int ldc, int M, int N, int K, int epilogue,
                    int force_mt, int force_nt, void* stream);
 
+/* EXPERIMENTAL (diagnostics / tests; see after_amd/csrc/gemm_x6.hip): the same GEMM with every fp32 product
+ * formed from three-way bf16 splits of its operands on the bf16 matrix pipe (six v_mfma_f32_16x16x32_bf16
+ * per 32-deep step, fp32 accumulation).  after_gemm_x6_split writes the [N][3][K] bf16 planes of W once. */
+int after_gemm_x6_split(const float* W, int ldw, unsigned short* W3, int N, int K, void* stream);
+int after_gemm_x6(const float* A, int lda, const unsigned short* W3, const float* bias, const float* R,
+                  int ldr, float* C, int ldc, int M, int N, int K, int epilogue, int tile, void* stream);
+
 /* One Conv1d layer on the time-major conv path (act(x) into the zero-haloed [B][T][C] buffer, then
  * the conv as a balanced LDS-DMA GEMM) for parity tests against a plain fp32 conv and for the
  * per-layer tile sweeps (scripts/bench_conv.py).  w [Cout, Cin, k] (torch.nn.Conv1d layout),

@@ -92,3 +92,31 @@ def test_gemm_strided_operands(hip_device):
     out = diag.gemm(a, w)
     ref = a.double() @ w.double().t()
     assert (out.double() - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("tile", [0, 332, 312, 322, 314, 431, 421, 631])
+@pytest.mark.parametrize("M,N,K,epi", [(768, 1536, 512, 0), (100, 96, 128, 1), (6144, 512, 1536, 2), (49, 33, 256, 0)])
+def test_gemm_x6_experimental(tile, M, N, K, epi, hip_device):
+    """The experimental bf16-split GEMM (gemm_x6.hip: fp32 products as six bf16 MFMAs, fp32 accumulation)
+    against fp64, every tile, ragged shapes, bias + GELU / residual epilogues: it has to be at least as
+    accurate as the fp32 MFMA kernel up to the spread between summation orders (3 x its error)."""
+    from after_amd import diag
+    g = torch.Generator().manual_seed(M + N + K + tile)
+    a = (1.3 * torch.randn(M, K, generator=g))
+    a[::5, ::11] *= 25.0
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g) if epi == 2 else None
+    ref = a.double() @ w.double().T + bias.double()
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    if epi == 2:
+        ref = ref + res.double()
+    w3 = diag.split_x6(w.to(hip_device))
+    got = diag.gemm_x6(a.to(hip_device), w3, bias=bias.to(hip_device),
+                       residual=res.to(hip_device) if res is not None else None, epilogue=epi, tile=tile).cpu()
+    base = diag.gemm(a.to(hip_device), w.to(hip_device), bias=bias.to(hip_device),
+                     residual=res.to(hip_device) if res is not None else None, epilogue=epi).cpu()
+    e6 = (got.double() - ref).abs().max().item()
+    e32 = (base.double() - ref).abs().max().item()
+    assert e6 <= max(3.0 * e32, 2e-7 * ref.abs().max().item()), (e6, e32)
