@@ -16,12 +16,14 @@
 // changes.  Pipeline: double-buffered LDS stages filled by LDS-DMA (A rows of 128 B with the 8-chunk
 // XOR swizzle of gemm.hip, W plane rows of 64 B with a 4-chunk swizzle), one barrier per 32-deep slab.
 //
-// Status (round 2): correct (errors at or below the fp32 kernel's on every shape tried) and, with this
-// plain two-stage pipeline, 62-68 us at 6144 x 1536 x 512 against 74.4 us for gemm.hip, 15.7 us against
-// 13.5 us at 768 rows.  With the split and five of the six MFMAs disabled the launch still takes 51 us:
-// the skeleton (DMA waits, one barrier per slab, 15 ds_read_b128 per wave and slab on an LDS that four
-// waves share) is what binds, not the matrix pipe.  Making it pay needs gemm.hip's counted-vmcnt ring with
-// the side work dealt out behind the MFMAs, and 96 x 96+ register tiles (LDS bytes per MFMA cycle).
+// Status (round 2): correct (errors at or below the fp32 kernel's on every shape tried).  Best tiles:
+// 128 x 96 with eight waves, 58 us at 6144 x 1536 x 512 against 74.4 us for gemm.hip; 48 x 32 with two
+// k-parts, 15.4 us against 13.5 us at 768 rows.  A third ring stage is slower (fewer workgroups per CU).
+// With the split and five of the six MFMAs disabled the 64 x 96 tile still takes 51 of its 64 us: the
+// skeleton (operand traffic L2 -> LDS at 15 flop / byte, one barrier per slab, 15 ds_read_b128 per wave
+// and slab on an LDS that the CU's waves share) binds, not the matrix pipe.  Making it pay needs
+// gemm.hip's ring with the side work dealt out behind the MFMAs and tiles of >= 128 x 192 (operand bytes
+// per MFMA cycle are 4x those of the fp32 kernel).
 #include <cstdint>
 #include <cstdlib>
 
@@ -80,7 +82,7 @@ __global__ void split3_kernel(const float* __restrict__ W, int ldw, unsigned sho
     o[2 * (size_t)K] = (unsigned short)(l >> 16);
 }
 
-template <int MB, int NB, int KS, int RS>
+template <int MB, int NB, int KS, int RS, int NS>
 __global__ __launch_bounds__(128 * KS * RS) void gemm_x6_kernel(GemmArgs g, const unsigned short* __restrict__ W3,
                                                                 int tiles_m, int tiles_n, int xcd_pm) {
     constexpr int BM = 16 * MB, BN = 32 * NB, MT = MB / RS, NT = NB;
@@ -168,15 +170,29 @@ __global__ __launch_bounds__(128 * KS * RS) void gemm_x6_kernel(GemmArgs g, cons
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, kq = lane >> 4;
-    AFTER_X6_ISSUE(0, 0)
+    // pieces this wave moves per slab (ragged when P is not a multiple of the wave count)
+    int npw = 0;
+#pragma unroll
+    for (int i = 0; i < LPS; ++i) npw += (wid + NW * i < P) ? 1 : 0;
+    const bool full = npw == LPS;
+    // NS-stage ring: slabs s + 1 .. s + NS - 2 stay in flight while slab s is consumed
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) AFTER_X6_ISSUE(s, s)
     for (int s = 0; s < nk; ++s) {
-        const int st = s & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of slab s have landed
-        __syncthreads();                                   // everyone's have; stage st ^ 1 is free again
-        if (s + 1 < nk) AFTER_X6_ISSUE(s + 1, st ^ 1)
+        const int st = s % NS;
+        if (s + NS - 2 <= nk - 1) {  // steady state: NS - 2 later slabs may still be in flight
+            if (full) wait_vmcnt_imm<(NS - 2) * LPS>();
+            else wait_vmcnt_imm<(NS - 2) * (LPS > 1 ? LPS - 1 : 0)>();
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();  // slab s has landed for every wave; the stage read in iteration s - 1 is free
+        if (s + NS - 1 < nk) AFTER_X6_ISSUE(s + NS - 1, (s + NS - 1) % NS)
         const unsigned char* sa = smem_raw + st * STAGE + kh * PART;
         const unsigned char* sw = sa + A_BYTES;
         u32x4 wf[3][NT];
+        f32x4 xr[MT][2];
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
@@ -187,32 +203,33 @@ __global__ __launch_bounds__(128 * KS * RS) void gemm_x6_kernel(GemmArgs g, cons
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int row = rp * (BM / RS) + i * 16 + frow;
-            const f32x4 x0 = *reinterpret_cast<const f32x4*>(sa + row * 128 + (((2 * kq) ^ (row & 7)) * 16));
-            const f32x4 x1 = *reinterpret_cast<const f32x4*>(sa + row * 128 + (((2 * kq + 1) ^ (row & 7)) * 16));
+            xr[i][0] = *reinterpret_cast<const f32x4*>(sa + row * 128 + (((2 * kq) ^ (row & 7)) * 16));
+            xr[i][1] = *reinterpret_cast<const f32x4*>(sa + row * 128 + (((2 * kq + 1) ^ (row & 7)) * 16));
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
             unsigned h_[4], m_[4], l_[4];
-            split_pair(x0[0], x0[1], h_[0], m_[0], l_[0]);
-            split_pair(x0[2], x0[3], h_[1], m_[1], l_[1]);
-            split_pair(x1[0], x1[1], h_[2], m_[2], l_[2]);
-            split_pair(x1[2], x1[3], h_[3], m_[3], l_[3]);
+            split_pair(xr[i][0][0], xr[i][0][1], h_[0], m_[0], l_[0]);
+            split_pair(xr[i][0][2], xr[i][0][3], h_[1], m_[1], l_[1]);
+            split_pair(xr[i][1][0], xr[i][1][1], h_[2], m_[2], l_[2]);
+            split_pair(xr[i][1][2], xr[i][1][3], h_[3], m_[3], l_[3]);
             const u32x4 ah = {h_[0], h_[1], h_[2], h_[3]}, am = {m_[0], m_[1], m_[2], m_[3]},
                         al = {l_[0], l_[1], l_[2], l_[3]};
             const bf16x8 Ah = __builtin_bit_cast(bf16x8, ah), Am = __builtin_bit_cast(bf16x8, am),
                          Al = __builtin_bit_cast(bf16x8, al);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const bf16x8 Wh = __builtin_bit_cast(bf16x8, wf[0][j]), Wm = __builtin_bit_cast(bf16x8, wf[1][j]),
-                             Wl = __builtin_bit_cast(bf16x8, wf[2][j]);
-                // W fragment as srcA: the accumulator holds C^T (four consecutive columns of one row per lane);
-                // smallest products first
-                f32x4 c = acc[i][j];
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wl, Ah, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wh, Al, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wm, Am, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wm, Ah, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wh, Am, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wh, Ah, c, 0, 0, 0);
-                acc[i][j] = c;
-            }
+            // W fragment as srcA: the accumulator holds C^T (four consecutive columns of one row per lane).
+            // Smallest products first; the NT accumulators of a row block alternate, so that no MFMA
+            // waits for the one issued just before it.
+#define AFTER_X6_PROD(WP_, AP_)                                                                   \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[WP_][j]), AP_, acc[i][j], 0, 0, 0);
+            AFTER_X6_PROD(2, Ah)
+            AFTER_X6_PROD(0, Al)
+            AFTER_X6_PROD(1, Am)
+            AFTER_X6_PROD(1, Ah)
+            AFTER_X6_PROD(0, Am)
+            AFTER_X6_PROD(0, Ah)
+#undef AFTER_X6_PROD
         }
     }
 #undef AFTER_X6_ISSUE
@@ -282,17 +299,18 @@ __global__ __launch_bounds__(128 * KS * RS) void gemm_x6_kernel(GemmArgs g, cons
     }
 }
 
-template <int MB, int NB, int KS, int RS>
+template <int MB, int NB, int KS, int RS, int NS = 2>
 int launch_x6(const GemmArgs& g, const unsigned short* W3, hipStream_t stream) {
     constexpr int BM = 16 * MB, BN = 32 * NB;
     const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
     const size_t stage = (size_t)KS * (BM * 128 + 3 * BN * 64);
     const size_t red = KS > 1 ? (size_t)2 * KS * MB * NB * 256 * sizeof(float) : 0;
-    const size_t lds = 2 * stage > red ? 2 * stage : red;
-    static_assert((size_t)2 * KS * (BM * 128 + 3 * BN * 64) <= 160 * 1024, "stages exceed the LDS");
+    const size_t lds = NS * stage > red ? NS * stage : red;
+    static_assert((size_t)NS * KS * (BM * 128 + 3 * BN * 64) <= 160 * 1024, "stages exceed the LDS");
+    static_assert(128 * KS * RS <= 1024, "too many waves");
     static bool attr_set = false;
     if (!attr_set) {
-        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6_kernel<MB, NB, KS, RS>),
+        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6_kernel<MB, NB, KS, RS, NS>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
@@ -306,7 +324,7 @@ int launch_x6(const GemmArgs& g, const unsigned short* W3, hipStream_t stream) {
             best = cost;
         }
     }
-    hipLaunchKernelGGL((gemm_x6_kernel<MB, NB, KS, RS>), dim3(tiles_m * tiles_n), dim3(128 * KS * RS), lds, stream, g,
+    hipLaunchKernelGGL((gemm_x6_kernel<MB, NB, KS, RS, NS>), dim3(tiles_m * tiles_n), dim3(128 * KS * RS), lds, stream, g,
                        W3, tiles_m, tiles_n, pm);
     AFTER_HIP_CHECK(hipGetLastError());
     return AFTER_OK;
@@ -330,10 +348,10 @@ int launch_gemm_x6(const GemmArgs& g, const unsigned short* W3, int tile, hipStr
     AFTER_REQUIRE(g.epilogue != EPI_RESIDUAL || g.R != nullptr, AFTER_E_INVALID, "gemm_x6: residual epilogue without R");
     if (tile == 0) {
         const bool long_k = g.K >= 2 * g.N;
-        if (g.M >= 1536) tile = long_k ? 421 : 431;
+        if (g.M >= 1536) tile = long_k ? 631 : 831;
         else tile = (g.K % 64 == 0) ? (long_k ? 312 : 332) : 431;
     }
-    if (tile % 10 > 1) AFTER_REQUIRE(g.K % (32 * (tile % 10)) == 0, AFTER_E_INVALID, "gemm_x6: K not divisible by the k-parts");
+    if (tile % 10 > 1 && tile < 1000) AFTER_REQUIRE(g.K % (32 * (tile % 10)) == 0, AFTER_E_INVALID, "gemm_x6: K not divisible by the k-parts");
     switch (tile) {
         case 332: return launch_x6<3, 3, 2, 1>(g, W3, stream);
         case 312: return launch_x6<3, 1, 2, 1>(g, W3, stream);
@@ -342,6 +360,13 @@ int launch_gemm_x6(const GemmArgs& g, const unsigned short* W3, int tile, hipStr
         case 431: return launch_x6<4, 3, 1, 2>(g, W3, stream);
         case 421: return launch_x6<4, 2, 1, 2>(g, W3, stream);
         case 631: return launch_x6<6, 3, 1, 2>(g, W3, stream);
+        case 1431: return launch_x6<4, 3, 1, 2, 3>(g, W3, stream);  // 1000 + tile: three stages
+        case 1631: return launch_x6<6, 3, 1, 2, 3>(g, W3, stream);
+        case 1332: return launch_x6<3, 3, 2, 1, 3>(g, W3, stream);
+        case 1312: return launch_x6<3, 1, 2, 1, 3>(g, W3, stream);
+        case 831: return launch_x6<8, 3, 1, 4, 2>(g, W3, stream);   // 128 x 96, 8 waves
+        case 1831: return launch_x6<8, 3, 1, 4, 3>(g, W3, stream);
+        case 861: return launch_x6<8, 6, 1, 4, 2>(g, W3, stream);   // 128 x 192, 8 waves
         default:
             set_error("gemm_x6: no tile %d", tile);
             return AFTER_E_INVALID;

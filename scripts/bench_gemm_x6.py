@@ -39,7 +39,7 @@ for (M, N, K) in [(768, 1536, 512), (768, 512, 1536), (6144, 1536, 512), (6144, 
     e32 = (out.double() - ref).abs().max().item()
     t32 = timeit(lambda: diag.gemm(a, w, bias=bias, out=out)) if M >= 768 else 0.0
     line = f"M={M} N={N} K={K}  fp32: {t32:.2f}us err {e32:.2e} |"
-    tiles = [0, 332, 312, 322, 314, 431, 421, 631] if M >= 768 else [0, 431, 332]
+    tiles = [0, 332, 312, 1332, 1312, 431, 1431, 631, 1631, 831, 1831, 861] if M >= 768 else [0, 431, 332, 1431, 831]
     for t in tiles:
         try:
             out.zero_()

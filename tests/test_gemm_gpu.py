@@ -94,7 +94,7 @@ def test_gemm_strided_operands(hip_device):
     assert (out.double() - ref).abs().max().item() < 1e-4
 
 
-@pytest.mark.parametrize("tile", [0, 332, 312, 322, 314, 431, 421, 631])
+@pytest.mark.parametrize("tile", [0, 332, 312, 322, 314, 431, 421, 631, 1431, 1332, 831, 1831, 861])
 @pytest.mark.parametrize("M,N,K,epi", [(768, 1536, 512, 0), (100, 96, 128, 1), (6144, 512, 1536, 2), (49, 33, 256, 0)])
 def test_gemm_x6_experimental(tile, M, N, K, epi, hip_device):
     """The experimental bf16-split GEMM (gemm_x6.hip: fp32 products as six bf16 MFMAs, fp32 accumulation)
