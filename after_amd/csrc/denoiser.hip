@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -647,6 +648,9 @@ struct after_denoiser {
     // weights
     float *emb0_w, *emb0_b, *emb2_w, *emb2_b, *patch_w, *patch_b, *tce_w, *tce_b, *out_w, *out_b;
     int fuse_tail = 1;  // AFTER_FUSE_TAIL=0: separate out_proj / cfg_euler / to_token_major launches
+    // EXPERIMENT (AFTER_GEMM_X6=1, off by default): the big Linears through gemm_x6.hip for >= x6_min_rows tokens
+    int x6 = 0, x6_min_rows = 1536;
+    std::vector<std::pair<const float*, unsigned short*>> x6_w;  // fp32 weight -> its [N][3][K] bf16 planes
     float *cond_w_all, *cond_b_all, *tc_w_all, *tc_b_all, *freqs, *rope_cos, *rope_sin;
     std::vector<LayerW> layers;
     // workspaces
@@ -693,7 +697,13 @@ int gemm(after_denoiser* h, hipStream_t s, const float* A, int lda, const float*
     const double fl = 2.0 * M * (double)N * K;
     const bool timed = fl >= h->timer_min_flops;  // the roofline leg looks at the dominant launches only
     if (timed) h->timer.begin(s);
-    int rc = launch_gemm(g, s);
+    int rc = AFTER_OK;
+    const unsigned short* w3 = nullptr;
+    if (h->x6 && M >= h->x6_min_rows && (K & 31) == 0 && ldw == K)
+        for (const auto& e : h->x6_w)
+            if (e.first == W) w3 = e.second;
+    if (w3) rc = launch_gemm_x6(g, w3, 0, s);
+    else rc = launch_gemm(g, s);
     if (timed) h->timer.end(s, fl, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     return rc;
 }
@@ -1138,6 +1148,24 @@ extern "C" int after_denoiser_create(const after_denoiser_cfg* cfg, const float*
         h->use_graph = (e && atoi(e) != 0);
         const char* f = getenv("AFTER_FUSE_TAIL");
         h->fuse_tail = f ? atoi(f) : 1;
+        const char* x6 = getenv("AFTER_GEMM_X6");
+        h->x6 = x6 ? atoi(x6) : 0;
+        const char* x6r = getenv("AFTER_GEMM_X6_MINROWS");
+        if (x6r) h->x6_min_rows = atoi(x6r);
+        if (h->x6) {
+            for (int l = 0; l < h->L; ++l) {
+                const LayerW& w = h->layers[l];
+                const float* ws_[3] = {w.qkv_w, w.mlp0_w, w.mlp2_w};
+                const int ns_[3] = {3 * h->E, h->ME, h->E}, ks_[3] = {h->E, h->E, h->ME};
+                for (int q = 0; q < 3; ++q) {
+                    unsigned short* w3 = nullptr;
+                    if (hipMalloc(reinterpret_cast<void**>(&w3), (size_t)ns_[q] * 3 * ks_[q] * sizeof(unsigned short)) != hipSuccess)
+                        return fail(AFTER_E_NOMEM);
+                    h->x6_w.emplace_back(ws_[q], w3);
+                    if (gemm_x6_split(ws_[q], ks_[q], w3, ns_[q], ks_[q], 0) != AFTER_OK) return fail(AFTER_E_HIP);
+                }
+            }
+        }
         if (h->E % 128 != 0) h->fuse_tail = 0;  // the fused GEMM splits K four ways
     }
     if (hipDeviceSynchronize() != hipSuccess) return fail(AFTER_E_HIP);
@@ -1159,6 +1187,7 @@ extern "C" void after_denoiser_destroy(after_denoiser* h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->ev_out) (void)hipEventDestroy(h->ev_out);
+    for (auto& e : h->x6_w) (void)hipFree(e.second);
     h->timer.destroy();
     h->wa.release();
     h->ws.release();

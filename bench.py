@@ -38,6 +38,7 @@ CLIP_SAMPLES = 524288
 CLIP_SECONDS = CLIP_SAMPLES / 44100.0
 T_FRAMES = 256
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (the experimental gemm_x6 path only)
 ROUND = "r2"
 # sources whose change invalidates a committed traffic measurement of the dominant GEMM
 TRAFFIC_SOURCES = ["after_amd/csrc/gemm.hip", "after_amd/csrc/gemm_pipe.h", "after_amd/csrc/denoiser.hip"]
@@ -116,6 +117,10 @@ def cpu_baseline_stream(model, dcfg, acfg, chunk, nb_steps, nsig):
                       f"codec (oracle.stream_forward), {dt:.2f} s on {cores} threads"}
 
 
+def x6_experiment():
+    return os.environ.get("AFTER_GEMM_X6", "0") not in ("", "0")
+
+
 def gemm_roofline(model, run_once, dev, dcfg, B, config, args):
     """Roofline of the dominant kernel (the fp32 MFMA GEMM behind qkv / MLP), measured live with HIP
     events on the launch stream in one extra, untimed pass."""
@@ -177,6 +182,15 @@ def gemm_roofline(model, run_once, dev, dcfg, B, config, args):
     except Exception:  # diagnostics only
         b2b = None
     ach = flops / (ms * 1e-3) / 1e12
+    if x6_experiment():
+        # EXPERIMENT (never the default): the big Linears run on the bf16 matrix pipe, six bf16 MFMAs per
+        # fp32 product block -> priced against the dense bf16 MFMA peak / 6, not the fp32 MFMA peak
+        peak = PEAK_BF16_MFMA_TFLOPS / 6.0
+        return {"bound": "mfma", "kernel": "gemm_x6_kernel (6 x v_mfma_f32_16x16x32_bf16 per 32-deep fp32 block)",
+                "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "traffic": None, "launches": int(launches), "avg_launch_us": round(ms * 1e3 / launches, 2),
+                "note": "EXPERIMENT AFTER_GEMM_X6=1: algorithmic fp32 flops / HIP-event launch duration against "
+                        "the dense bf16 MFMA peak (2500 TFLOP/s) / 6", "flops_per_launch": round(flops / launches)}
     return {"bound": "mfma", "kernel": "gemm_f32_bal_kernel (v_mfma_f32_16x16x4_f32): the qkv / MLP-up / MLP-down "
                                        f"launches (>= {big / 1e9:.2f} GFLOP each)",
             "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -396,7 +410,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if not x6_experiment() else "f32 (EXPERIMENT: products as six bf16 MFMAs, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": workload,
                        "batch_per_gpu": args.batch_per_gpu if not args.global_batch else None,
@@ -405,6 +419,9 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         }
+        if x6_experiment():
+            line["experiment"] = ("AFTER_GEMM_X6=1: the denoiser's qkv / MLP Linears through after_amd/csrc/gemm_x6.hip "
+                                  "for >= 1536 token rows; not the default path, see DESIGN.md section 10")
         if args.stream:
             line["metric"] = "audio sec generated / wall sec (xRT, all streams), base+cycle 100-step streaming @44.1 kHz"
         print(json.dumps(line))
