@@ -119,6 +119,7 @@ SIGNATURES = {
     "after_convtm_set_tile": (None, [c_int]),
     "after_gemm_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "after_gemm_x6_set_debug": (None, [c_void_p]),
     "after_gemm_x6_split": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "after_gemm_x6": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                               c_int, c_int, c_int, c_void_p]),

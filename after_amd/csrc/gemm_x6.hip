@@ -19,11 +19,13 @@
 // Status (round 2): correct (errors at or below the fp32 kernel's on every shape tried).  Best tiles:
 // 128 x 96 with eight waves, 58 us at 6144 x 1536 x 512 against 74.4 us for gemm.hip; 48 x 32 with two
 // k-parts, 15.4 us against 13.5 us at 768 rows.  A third ring stage is slower (fewer workgroups per CU).
-// With the split and five of the six MFMAs disabled the 64 x 96 tile still takes 51 of its 64 us: the
-// skeleton (operand traffic L2 -> LDS at 15 flop / byte, one barrier per slab, 15 ds_read_b128 per wave
-// and slab on an LDS that the CU's waves share) binds, not the matrix pipe.  Making it pay needs
-// gemm.hip's ring with the side work dealt out behind the MFMAs and tiles of >= 128 x 192 (operand bytes
-// per MFMA cycle are 4x those of the fp32 kernel).
+// With the split and five of the six MFMAs disabled the 64 x 96 tile still takes 51 of its 64 us, and the
+// per-phase cycle counts (after_gemm_x6_set_debug, scripts/gemm_x6_timeline.py: per slab 530 cycles to
+// issue its seven 1-KB LDS-DMA loads, 480 for the 15 fragment reads, 1170 for split + MFMAs of which 576
+// are MFMA issue) say why: three co-resident workgroups pull 80 KB per slab round through a CU's 64 B/clk
+// load path -- 1250 cycles against 1730 of MFMA issue per SIMD, and the two do not overlap here.  The
+// fp32 kernel moves 60 KB per 4600 MFMA cycles.  Making it pay needs >= 128 x 192 tiles (operand bytes per
+// MFMA cycle are 4x the fp32 kernel's) in gemm.hip's ring with the side work dealt out behind the MFMAs.
 #include <cstdint>
 #include <cstdlib>
 
@@ -152,13 +154,25 @@ __global__ __launch_bounds__(128 * KS * RS) void gemm_x6_kernel(GemmArgs g, cons
         }
     }
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem_raw;
+    // the per-piece bases are wave-uniform (functions of the wave id): pin them in SGPRs once, so that a DMA
+    // costs two scalar adds + s_mov m0 + the load
+    unsigned sb_lo[LPS], sb_hi[LPS], sl_dst[LPS], sl_step[LPS];
+#pragma unroll
+    for (int i = 0; i < LPS; ++i) {
+        const unsigned long long v = (unsigned long long)(uintptr_t)sbase[i];
+        sb_lo[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+        sb_hi[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+        sl_dst[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + ldst[i]));
+        sl_step[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)sstep[i]);
+    }
 #define AFTER_X6_ISSUE(slab_, st_)                                                                         \
     _Pragma("unroll") for (int i__ = 0; i__ < LPS; ++i__) {                                                \
         if (wid + NW * i__ < P) {                                                                          \
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                   \
                          :                                                                                 \
-                         : "s"(__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)((st_) * STAGE) + ldst[i__]))), \
-                           "v"(voff[i__]), "s"(uniform_ptr(sbase[i__] + (size_t)(slab_) * sstep[i__]))     \
+                         : "s"(sl_dst[i__] + (unsigned)((st_) * STAGE)), "v"(voff[i__]),                    \
+                           "s"((((unsigned long long)sb_hi[i__] << 32) | sb_lo[i__]) +                       \
+                               (unsigned long long)((unsigned)(slab_) * sl_step[i__]))                      \
                          : "memory"); /* m0: see gemm.hip */                                               \
         }                                                                                                  \
     }
@@ -170,6 +184,18 @@ __global__ __launch_bounds__(128 * KS * RS) void gemm_x6_kernel(GemmArgs g, cons
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, kq = lane >> 4;
+    unsigned w_off[NT], a_off[MT][2];  // per-lane LDS byte offsets of the fragments within a k-part of a stage
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int row = part * 16 * NB + j * 16 + frow;
+        w_off[j] = (unsigned)(A_BYTES + row * 64 + ((kq ^ ((row >> 2) & 3)) * 16));
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int row = rp * (BM / RS) + i * 16 + frow;
+        a_off[i][0] = (unsigned)(row * 128 + (((2 * kq) ^ (row & 7)) * 16));
+        a_off[i][1] = (unsigned)(row * 128 + (((2 * kq + 1) ^ (row & 7)) * 16));
+    }
     // pieces this wave moves per slab (ragged when P is not a multiple of the wave count)
     int npw = 0;
 #pragma unroll
@@ -179,32 +205,51 @@ __global__ __launch_bounds__(128 * KS * RS) void gemm_x6_kernel(GemmArgs g, cons
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) AFTER_X6_ISSUE(s, s)
+    unsigned long long t_wait = 0, t_bar = 0, t_issue = 0, t_lds = 0, t_split = 0, t_mma = 0, t0_ = 0, t_begin = 0;
+    if (g.dbg) t_begin = __builtin_readcyclecounter();
     for (int s = 0; s < nk; ++s) {
         const int st = s % NS;
+        if (g.dbg) t0_ = __builtin_readcyclecounter();
         if (s + NS - 2 <= nk - 1) {  // steady state: NS - 2 later slabs may still be in flight
             if (full) wait_vmcnt_imm<(NS - 2) * LPS>();
             else wait_vmcnt_imm<(NS - 2) * (LPS > 1 ? LPS - 1 : 0)>();
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        if (g.dbg) {
+            const unsigned long long t = __builtin_readcyclecounter();
+            t_wait += t - t0_;
+            t0_ = t;
+        }
         __syncthreads();  // slab s has landed for every wave; the stage read in iteration s - 1 is free
+        if (g.dbg) {
+            const unsigned long long t = __builtin_readcyclecounter();
+            t_bar += t - t0_;
+            t0_ = t;
+        }
         if (s + NS - 1 < nk) AFTER_X6_ISSUE(s + NS - 1, (s + NS - 1) % NS)
+        if (g.dbg) {
+            const unsigned long long t = __builtin_readcyclecounter();
+            t_issue += t - t0_;
+            t0_ = t;
+        }
         const unsigned char* sa = smem_raw + st * STAGE + kh * PART;
-        const unsigned char* sw = sa + A_BYTES;
         u32x4 wf[3][NT];
         f32x4 xr[MT][2];
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int row = part * 16 * NB + j * 16 + frow;
-                wf[p][j] = *reinterpret_cast<const u32x4*>(sw + (p * BN + row) * 64 + ((kq ^ ((row >> 2) & 3)) * 16));
-            }
+            for (int j = 0; j < NT; ++j) wf[p][j] = *reinterpret_cast<const u32x4*>(sa + w_off[j] + p * BN * 64);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const int row = rp * (BM / RS) + i * 16 + frow;
-            xr[i][0] = *reinterpret_cast<const f32x4*>(sa + row * 128 + (((2 * kq) ^ (row & 7)) * 16));
-            xr[i][1] = *reinterpret_cast<const f32x4*>(sa + row * 128 + (((2 * kq + 1) ^ (row & 7)) * 16));
+            xr[i][0] = *reinterpret_cast<const f32x4*>(sa + a_off[i][0]);
+            xr[i][1] = *reinterpret_cast<const f32x4*>(sa + a_off[i][1]);
+        }
+        if (g.dbg) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long t = __builtin_readcyclecounter();
+            t_lds += t - t0_;
+            t0_ = t;
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -231,6 +276,21 @@ __global__ __launch_bounds__(128 * KS * RS) void gemm_x6_kernel(GemmArgs g, cons
             AFTER_X6_PROD(0, Ah)
 #undef AFTER_X6_PROD
         }
+        if (g.dbg) {
+            asm volatile("s_nop 0" ::"v"(acc[MT - 1][NT - 1][0]));
+            const unsigned long long t = __builtin_readcyclecounter();
+            t_mma += t - t0_;
+        }
+    }
+    if (g.dbg && tid == 0) {
+        unsigned long long* d = g.dbg + (size_t)blockIdx.x * 8;
+        d[0] = t_wait;
+        d[1] = t_bar;
+        d[2] = t_issue;
+        d[3] = t_lds;
+        d[4] = t_mma;  // split + MFMAs
+        d[5] = __builtin_readcyclecounter() - t_begin;
+        d[6] = t_split;
     }
 #undef AFTER_X6_ISSUE
 
@@ -381,8 +441,12 @@ extern "C" int after_gemm_x6_split(const float* W, int ldw, unsigned short* W3, 
     return after::gemm_x6_split(W, ldw, W3, N, K, (hipStream_t)stream);
 }
 
+static unsigned long long* g_x6_dbg = nullptr;
+extern "C" void after_gemm_x6_set_debug(unsigned long long* dbg) { g_x6_dbg = dbg; }
+
 extern "C" int after_gemm_x6(const float* A, int lda, const unsigned short* W3, const float* bias, const float* R,
                              int ldr, float* C, int ldc, int M, int N, int K, int epilogue, int tile, void* stream) {
     after::GemmArgs g{A, lda, nullptr, 0, bias, R, ldr, C, ldc, M, N, K, epilogue};
+    g.dbg = g_x6_dbg;
     return after::launch_gemm_x6(g, W3, tile, (hipStream_t)stream);
 }

@@ -364,6 +364,7 @@ int after_gemm_f32(const float* A, int lda, const float* W, int ldw, const float
  * formed from three-way bf16 splits of its operands on the bf16 matrix pipe (six v_mfma_f32_16x16x32_bf16
  * per 32-deep step, fp32 accumulation).  after_gemm_x6_split writes the [N][3][K] bf16 planes of W once. */
 int after_gemm_x6_split(const float* W, int ldw, unsigned short* W3, int N, int K, void* stream);
+void after_gemm_x6_set_debug(unsigned long long* dbg); /* per-workgroup cycle counts of the pipeline phases */
 int after_gemm_x6(const float* A, int lda, const unsigned short* W3, const float* bias, const float* R,
                   int ldr, float* C, int ldc, int M, int N, int K, int epilogue, int tile, void* stream);
 
