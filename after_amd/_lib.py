@@ -68,6 +68,8 @@ SIGNATURES = {
     "after_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                              c_float, c_float, c_float, c_int, c_void_p]),
     "after_denoiser_set_graph": (c_int, [c_void_p, c_int]),
+    "after_denoiser_set_gemm_path": (c_int, [c_void_p, c_int, c_int]),
+    "after_denoiser_gemm_path": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     "after_denoiser_enable_cache": (c_int, [c_void_p, c_int, c_int, c_int]),
     "after_denoiser_reset_cache": (c_int, [c_void_p, c_void_p]),
     "after_denoiser_roll_cache": (c_int, [c_void_p, c_int, c_int, c_void_p]),
@@ -75,6 +77,7 @@ SIGNATURES = {
     "after_denoiser_gemm_time_ms": (c_int, [c_void_p, POINTER(c_double), POINTER(c_longlong),
                                             POINTER(c_double)]),
     "after_denoiser_profile_min_flops": (c_int, [c_void_p, c_double]),
+    "after_denoiser_profile_kernel": (c_int, [c_void_p, c_int]),
     "after_denoiser_gemm_time2": (c_int, [c_void_p, POINTER(c_double), POINTER(c_longlong), POINTER(c_double),
                                           POINTER(c_double)]),
     "after_ae_create": (c_int, [POINTER(AECfg), POINTER(c_void_p), c_int, c_int, c_int,
@@ -121,8 +124,10 @@ SIGNATURES = {
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "after_gemm_x6_set_debug": (None, [c_void_p]),
     "after_gemm_x6_split": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
-    "after_gemm_x6": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
-                              c_int, c_int, c_int, c_void_p]),
+    "after_gemm_x6_pick_tile": (c_int, [c_int, c_int, c_int]),
+    "after_gemm_x6_offset": (ctypes.c_longlong, [c_int, c_int, c_int, c_int]),
+    "after_gemm_x6": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                              c_int, c_int, c_int, c_int, c_void_p]),
 }
 
 

@@ -119,8 +119,66 @@ struct GemmArgs {
 int launch_gemm_cfg_euler(const GemmArgs& g, hipStream_t stream);
 int launch_gemm(const GemmArgs& g, hipStream_t stream);
 int launch_gemm_cfg(const GemmArgs& g, int force_mt, int force_nt, hipStream_t stream);
-// fp32 GEMM through the bf16 matrix pipe (gemm_x6.hip; experimental, opt-in): W3 = [N][3][K] bf16 planes of W
+// fp32 GEMM through the bf16 matrix pipe (gemm_x6.hip): both operands as three bf16 planes (x = h + m + l
+// exactly), six v_mfma_f32_16x16x32_bf16 per 32-deep step, fp32 accumulate, fp32 result -- or, for a producer of
+// the next GEMM's A operand, the result's three planes (C3).
+//
+// Plane storage ("x6 blocks"): a [R][K] matrix (K % 32 == 0, rows padded to a multiple of 16) is a sequence of
+// 1-KB blocks [R / 16][K / 32][plane]: 16 rows x 32 k of one plane, row r at byte 64 r, its four 16-byte chunks
+// XOR-permuted (chunk c at slot c ^ f((r / 4) % 4), f = {0, 2, 3, 1}).  A block is exactly one LDS-DMA piece of
+// the GEMM and already its LDS image: a wave instruction moves 1 KB of contiguous memory (eight full 128-byte
+// lines; row-major planes would be sixteen 64-byte segments, half the rate of the CU's load path) and the
+// fragment reads (lane l: row l & 15, chunk l >> 4) are bank-conflict free.
+__host__ __device__ inline size_t x6_rows_padded(int rows) { return ((size_t)rows + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t x6_elems(int rows, int K) { return x6_rows_padded(rows) * 3 * (size_t)K; }
+// element (unsigned short) offset of (row r, plane p, column k) -- k % 8 consecutive elements stay contiguous
+__host__ __device__ inline size_t x6_offset(int r, int p, int k, int K) {
+    const int rr = r & 15, c = (k & 31) >> 3;
+    const int slot = c ^ ((0x78 >> (2 * ((rr >> 2) & 3))) & 3);
+    return (((size_t)(r >> 4) * (size_t)(K >> 5) + (size_t)(k >> 5)) * 3 + (size_t)p) * 512 + (size_t)(rr * 32 + slot * 8 + (k & 7));
+}
+struct X6GemmArgs {
+    const unsigned short* A3;  // x6 blocks of A [M][K]
+    const unsigned short* W3;  // x6 blocks of W [N][K] (padding rows zero)
+    const float* bias;
+    const float* R;            // residual [M, ldr] (EPI_RESIDUAL, fp32 output only)
+    int ldr;
+    float* C;                  // fp32 output [M][ldc], or nullptr
+    unsigned short* C3;        // x6 blocks of the output [M][N] (N % 32 == 0), or nullptr
+    int ldc;
+    int M, N, K;
+    int epilogue;
+    unsigned long long* dbg = nullptr;
+};
 int gemm_x6_split(const float* W, int ldw, unsigned short* W3, int N, int K, hipStream_t s);
-int launch_gemm_x6(const GemmArgs& g, const unsigned short* W3, int tile, hipStream_t stream);
+int gemm_x6_pick_tile(int M, int N, int K);
+int launch_gemm_x6(const X6GemmArgs& g, int tile, hipStream_t stream);
+
+// four consecutive floats of a row (columns k .. k + 3, k % 4 == 0) -> their bf16 planes, stored into the x6
+// blocks at `base`: what the producers of a gemm_x6 A operand do (ln_mod_ln / attention LayerNorm tail in
+// denoiser.hip, gemm_x6's own plane-output epilogue)
+__device__ __forceinline__ void x6_split4(float x0, float x1, float x2, float x3, uint2& h, uint2& m, uint2& l) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v0 = {x0, x1}, v1 = {x2, x3};
+    h.x = __builtin_bit_cast(unsigned, __builtin_convertvector(v0, bf2));
+    h.y = __builtin_bit_cast(unsigned, __builtin_convertvector(v1, bf2));
+    const f2 r0 = {x0 - __uint_as_float(h.x << 16), x1 - __uint_as_float(h.x & 0xFFFF0000u)};
+    const f2 r1 = {x2 - __uint_as_float(h.y << 16), x3 - __uint_as_float(h.y & 0xFFFF0000u)};
+    m.x = __builtin_bit_cast(unsigned, __builtin_convertvector(r0, bf2));
+    m.y = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf2));
+    const f2 t0 = {r0[0] - __uint_as_float(m.x << 16), r0[1] - __uint_as_float(m.x & 0xFFFF0000u)};
+    const f2 t1 = {r1[0] - __uint_as_float(m.y << 16), r1[1] - __uint_as_float(m.y & 0xFFFF0000u)};
+    l.x = __builtin_bit_cast(unsigned, __builtin_convertvector(t0, bf2));
+    l.y = __builtin_bit_cast(unsigned, __builtin_convertvector(t1, bf2));
+}
+__device__ __forceinline__ void x6_store4(unsigned short* base, int r, int k, int K, float x0, float x1, float x2, float x3) {
+    uint2 h, m, l;
+    x6_split4(x0, x1, x2, x3, h, m, l);
+    unsigned short* p = base + x6_offset(r, 0, k, K);
+    *reinterpret_cast<uint2*>(p) = h;
+    *reinterpret_cast<uint2*>(p + 512) = m;
+    *reinterpret_cast<uint2*>(p + 1024) = l;
+}
 
 }  // namespace after

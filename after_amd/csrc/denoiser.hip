@@ -184,10 +184,13 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(float* __restrict__ out
 //   h  = norm1(x)                                  (affine)
 // One wave per token row.  xin rows are addressed through src_map (layer 0 of a
 // CFG sample reads the patchify output of clip r % B for all three CFG rows).
+// h3 != nullptr: h is written as its three bf16 planes (x6 blocks of [rows * T][E], common.h: the A operand of
+// gemm_x6.hip) instead of fp32.
 __global__ __launch_bounds__(256) void ln_mod_ln_kernel(const float* __restrict__ xin,
                                                         const int* __restrict__ src_map,
                                                         float* __restrict__ xout,
                                                         float* __restrict__ h,
+                                                        unsigned short* __restrict__ h3,
                                                         const float* __restrict__ tc_ab, int tc_ld,
                                                         const int* __restrict__ tc_map,
                                                         const float* __restrict__ w1,
@@ -248,7 +251,6 @@ __global__ __launch_bounds__(256) void ln_mod_ln_kernel(const float* __restrict_
         stats(mean, rstd);
     }
     float* xo = xout + (size_t)m * E;
-    float* ho = h + (size_t)m * E;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = 4 * lane + 256 * i;
@@ -259,7 +261,11 @@ __global__ __launch_bounds__(256) void ln_mod_ln_kernel(const float* __restrict_
             o.y = (v[i].y - mean) * rstd * ww[i].y + bb[i].y;
             o.z = (v[i].z - mean) * rstd * ww[i].z + bb[i].z;
             o.w = (v[i].w - mean) * rstd * ww[i].w + bb[i].w;
-            *reinterpret_cast<float4*>(ho + c) = o;
+            if (h3) {
+                x6_store4(h3, m, c, E, o.x, o.y, o.z, o.w);
+            } else {
+                *reinterpret_cast<float4*>(h + (size_t)m * E + c) = o;
+            }
         }
     }
 }
@@ -275,7 +281,8 @@ __global__ __launch_bounds__(256) void ln_mod_ln_kernel(const float* __restrict_
 struct AttnArgs {
     const float* qkv;    // [rows*T, 3E]
     float* xres;         // [rows*T, E] in/out
-    float* h;            // [rows*T, E] out
+    float* h;            // [rows*T, E] out (fp32) ...
+    unsigned short* h3;  // ... or, when non-null, its three bf16 planes (x6 blocks of [rows*T][E]: gemm_x6.hip's A operand)
     const float* cond_ab;  // + layer offset; row stride cond_ld
     int cond_ld;
     const float* w3;
@@ -563,7 +570,11 @@ __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
                 o.y = (v[i].y - mean) * rstd * ww[i].y + bb[i].y;
                 o.z = (v[i].z - mean) * rstd * ww[i].z + bb[i].z;
                 o.w = (v[i].w - mean) * rstd * ww[i].w + bb[i].w;
-                *reinterpret_cast<float4*>(a.h + m * E + c) = o;
+                if (a.h3) {
+                    x6_store4(a.h3, (int)m, c, E, o.x, o.y, o.z, o.w);
+                } else {
+                    *reinterpret_cast<float4*>(a.h + m * E + c) = o;
+                }
             }
         }
     }
@@ -637,6 +648,7 @@ using namespace after;
 
 struct LayerW {
     float *qkv_w, *mlp0_w, *mlp0_b, *mlp2_w, *mlp2_b, *n1w, *n1b, *n3w, *n3b;
+    unsigned short *qkv_w3, *mlp0_w3, *mlp2_w3;  // bf16 planes (x6 blocks) of the three big Linears (gemm_x6.hip)
 };
 
 struct after_denoiser {
@@ -648,9 +660,12 @@ struct after_denoiser {
     // weights
     float *emb0_w, *emb0_b, *emb2_w, *emb2_b, *patch_w, *patch_b, *tce_w, *tce_b, *out_w, *out_b;
     int fuse_tail = 1;  // AFTER_FUSE_TAIL=0: separate out_proj / cfg_euler / to_token_major launches
-    // EXPERIMENT (AFTER_GEMM_X6=1, off by default): the big Linears through gemm_x6.hip for >= x6_min_rows tokens
-    int x6 = 0, x6_min_rows = 1536;
-    std::vector<std::pair<const float*, unsigned short*>> x6_w;  // fp32 weight -> its [N][3][K] bf16 planes
+    // GEMM path of the qkv / MLP Linears: 0 = fp32 MFMA (gemm.hip) always; 1 = gemm_x6.hip (fp32 products as
+    // six exact bf16 MFMAs, fp32 accumulate; activations travel as three bf16 planes between the producers and
+    // the GEMMs) for >= x6_min_rows token rows, fp32 MFMA below (streaming chunks); 2 = gemm_x6 at every size.
+    // AFTER_GEMM_X6 at create, after_denoiser_set_gemm_path at run time.
+    int x6 = 1, x6_min_rows = 192;
+    unsigned short *hb3 = nullptr, *mlp3 = nullptr;  // plane forms of hbuf / mlp
     float *cond_w_all, *cond_b_all, *tc_w_all, *tc_b_all, *freqs, *rope_cos, *rope_sin;
     std::vector<LayerW> layers;
     // workspaces
@@ -668,6 +683,7 @@ struct after_denoiser {
     int last_rows = 0, last_T = 0;
     KernelTimer timer;
     double timer_min_flops = 0;  // after_denoiser_profile_min_flops
+    int timer_kernel = 0;        // after_denoiser_profile_kernel: 0 both GEMM kernels, 1 gemm_x6 only, 2 gemm.hip only
     // hipGraph replay of sample(): the whole Euler loop is captured once per
     // (B, T, nb_steps, cfg_mode, drop_value) on a private stream, operating on
     // handle-owned staging tensors; guidance scalars live in device memory.
@@ -695,17 +711,35 @@ int gemm(after_denoiser* h, hipStream_t s, const float* A, int lda, const float*
          const float* R = nullptr, int ldr = 0) {
     GemmArgs g{A, lda, W, ldw, bias, R, ldr, Cc, ldc, M, N, K, epi};
     const double fl = 2.0 * M * (double)N * K;
-    const bool timed = fl >= h->timer_min_flops;  // the roofline leg looks at the dominant launches only
+    const bool timed = fl >= h->timer_min_flops && h->timer_kernel != 1;  // the roofline leg looks at the dominant launches only
     if (timed) h->timer.begin(s);
-    int rc = AFTER_OK;
-    const unsigned short* w3 = nullptr;
-    if (h->x6 && M >= h->x6_min_rows && (K & 31) == 0 && ldw == K)
-        for (const auto& e : h->x6_w)
-            if (e.first == W) w3 = e.second;
-    if (w3) rc = launch_gemm_x6(g, w3, 0, s);
-    else rc = launch_gemm(g, s);
+    const int rc = launch_gemm(g, s);
     if (timed) h->timer.end(s, fl, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     return rc;
+}
+
+// the same Linear on the bf16-split path: A3 / W3 = three bf16 planes per row, result fp32 (Cc) or planes (C3)
+int gemm_x6(after_denoiser* h, hipStream_t s, const unsigned short* A3, const unsigned short* W3, const float* bias,
+            float* Cc, unsigned short* C3, int ldc, int M, int N, int K, int epi, const float* R = nullptr,
+            int ldr = 0) {
+    X6GemmArgs g{A3, W3, bias, R, ldr, Cc, C3, ldc, M, N, K, epi};
+    const double fl = 2.0 * M * (double)N * K;
+    const bool timed = fl >= h->timer_min_flops && h->timer_kernel != 2;
+    if (timed) h->timer.begin(s);
+    const int rc = launch_gemm_x6(g, 0, s);
+    if (timed) h->timer.end(s, fl, 6.0 * ((double)M * K + (double)N * K) + (C3 ? 6.0 : 4.0) * M * N);
+    return rc;
+}
+
+// Per-Linear dispatch between the two GEMM kernels (mode 1; measured in the sampler, profiles/r3_*): with many
+// token rows gemm_x6 wins every shape (B = 8: 52 - 60 us against 74 - 76); at one clip (768 rows) it wins the
+// wide-N, short-K Linears (qkv 11.3 us, MLP-up 12.8 us against 13.5) and loses MLP-down (N = 512, K = 1536:
+// 48 x 32 tiles pull 737 KB per CU through the L2 -> LDS path, 15.0 us against 14.2), which stays on gemm.hip.
+bool x6_wins(const after_denoiser* h, int M, int N, int K) {
+    if (h->x6 == 0) return false;
+    if (h->x6 == 2) return true;
+    if (M < h->x6_min_rows) return false;
+    return M >= 1536 || N >= 2 * K;
 }
 
 int upload_padded(float* dst, int ldp, const float* src, int rows, int cols) {
@@ -826,21 +860,31 @@ int run_layers(after_denoiser* h, hipStream_t s, int row0, int rows, const int* 
     const bool wide = h->W < 0 || !h->cfg.causal;
     const int nkmax = wide ? 1 : (h->W - 1 + h->cs > h->cs ? h->W - 1 + h->cs : h->cs);
     const size_t lds = attn_lds_bytes(E, h->cs, nkmax);
+    // bf16-split GEMM path, decided per Linear (x6_wins): the producer of a Linear's input then writes bf16 planes
+    // instead of fp32.  (x6 blocks hold 16 rows: a row range must start on a block boundary -- always true for
+    // the single-group call.)
+    const bool x6_ok = (r0 % 16) == 0;
+    const bool x6_qkv = x6_ok && x6_wins(h, M, 3 * E, E), x6_up = x6_ok && x6_wins(h, M, ME, E),
+               x6_dn = x6_up && x6_wins(h, M, E, ME);
+    unsigned short* hb3 = h->hb3 + r0 * 3 * E;    // norm1 output (qkv's input) / norm3 output (MLP-up's input)
+    unsigned short* mlp3 = h->mlp3 + r0 * 3 * ME;
     for (int l = 0; l < L; ++l) {
         const LayerW& w = h->layers[l];
         hipLaunchKernelGGL(ln_mod_ln_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s,
                            l == 0 ? h->pat : xres,
                            l == 0 ? (dev_xmap ? dev_xmap + row0 : (const int*)nullptr) : (const int*)nullptr,
-                           xres, hbuf, h->tc_ab + (size_t)l * 2 * E, L * 2 * E,
+                           xres, hbuf, x6_qkv ? hb3 : nullptr, h->tc_ab + (size_t)l * 2 * E, L * 2 * E,
                            dev_tcmap ? dev_tcmap + row0 : (const int*)nullptr, w.n1w, w.n1b, rows, T, E);
         AFTER_HIP_CHECK(hipGetLastError());
         float* qkv = (h->cache > 0 ? h->qkv_layers + (size_t)l * h->max_rows * h->max_T * 3 * E : h->qkv) +
                      r0 * 3 * E;
-        AFTER_TRY(gemm(h, s, hbuf, E, w.qkv_w, E, nullptr, qkv, 3 * E, M, 3 * E, E, EPI_NONE));
+        if (x6_qkv) AFTER_TRY(gemm_x6(h, s, hb3, w.qkv_w3, nullptr, qkv, nullptr, 3 * E, M, 3 * E, E, EPI_NONE));
+        else AFTER_TRY(gemm(h, s, hbuf, E, w.qkv_w, E, nullptr, qkv, 3 * E, M, 3 * E, E, EPI_NONE));
         AttnArgs a;
         a.qkv = qkv;
         a.xres = xres;
         a.h = hbuf;
+        a.h3 = x6_up ? hb3 : nullptr;
         a.cond_ab = cond_ab_step + (size_t)row0 * L * 2 * E + (size_t)l * 2 * E;
         a.cond_ld = L * 2 * E;
         a.w3 = w.n3w;
@@ -872,8 +916,11 @@ int run_layers(after_denoiser* h, hipStream_t s, int row0, int rows, const int* 
             a.dbg = dbg;
         }
         AFTER_TRY(launch_attn(a, rows, lds, s));
-        AFTER_TRY(gemm(h, s, hbuf, E, w.mlp0_w, E, w.mlp0_b, mlp, ME, M, ME, E, EPI_GELU));
-        AFTER_TRY(gemm(h, s, mlp, ME, w.mlp2_w, ME, w.mlp2_b, xres, E, M, E, ME, EPI_RESIDUAL, xres, E));
+        if (x6_up) AFTER_TRY(gemm_x6(h, s, hb3, w.mlp0_w3, w.mlp0_b, x6_dn ? nullptr : mlp, x6_dn ? mlp3 : nullptr,
+                                     x6_dn ? 0 : ME, M, ME, E, EPI_GELU));
+        else AFTER_TRY(gemm(h, s, hbuf, E, w.mlp0_w, E, w.mlp0_b, mlp, ME, M, ME, E, EPI_GELU));
+        if (x6_dn) AFTER_TRY(gemm_x6(h, s, mlp3, w.mlp2_w3, w.mlp2_b, xres, nullptr, E, M, E, ME, EPI_RESIDUAL, xres, E));
+        else AFTER_TRY(gemm(h, s, mlp, ME, w.mlp2_w, ME, w.mlp2_b, xres, E, M, E, ME, EPI_RESIDUAL, xres, E));
     }
     if (!out_proj) return AFTER_OK;  // fused into the sampler tail (launch_gemm_cfg_euler)
     return gemm(h, s, xres, E, h->out_w, E, h->out_b, h->outp + r0 * C, C, M, C, E, EPI_NONE);
@@ -1003,7 +1050,8 @@ extern "C" int after_denoiser_create(const after_denoiser_cfg* cfg, const float*
                  (size_t)L * 2 * E + (size_t)L * 2 * E * h->ZSp + (size_t)L * 2 * E + h->NE +
                  2 * (size_t)max_pos * 16 +
                  (size_t)L * ((size_t)3 * E * E + 2 * (size_t)ME * E + ME + E + 4 * E);
-    TRY_OR_FAIL(h->wa.init(wfl * sizeof(float) + 256 * (64 + 16 * (size_t)L)));
+    wfl += (size_t)L * ((size_t)3 * E * E + 2 * (size_t)ME * E) * 3 / 2;  // bf16 planes of the big Linears
+    TRY_OR_FAIL(h->wa.init(wfl * sizeof(float) + 256 * (64 + 20 * (size_t)L)));
     TAKE(h->emb0_w, h->wa, (size_t)E * h->K0p);
     TAKE(h->emb0_b, h->wa, E);
     TAKE(h->emb2_w, h->wa, (size_t)E * E);
@@ -1054,6 +1102,16 @@ extern "C" int after_denoiser_create(const after_denoiser_cfg* cfg, const float*
         TRY_OR_FAIL(upload(lw.n1b, w[6], E));
         TRY_OR_FAIL(upload(lw.n3w, w[7], E));
         TRY_OR_FAIL(upload(lw.n3b, w[8], E));
+        lw.qkv_w3 = h->wa.take<unsigned short>(x6_elems(3 * E, E));
+        lw.mlp0_w3 = h->wa.take<unsigned short>(x6_elems(ME, E));
+        lw.mlp2_w3 = h->wa.take<unsigned short>(x6_elems(E, ME));
+        if (!lw.qkv_w3 || !lw.mlp0_w3 || !lw.mlp2_w3) {
+            set_error("arena exhausted at the bf16 weight planes");
+            return fail(AFTER_E_NOMEM);
+        }
+        TRY_OR_FAIL(gemm_x6_split(lw.qkv_w, E, lw.qkv_w3, 3 * E, E, 0));
+        TRY_OR_FAIL(gemm_x6_split(lw.mlp0_w, E, lw.mlp0_w3, ME, E, 0));
+        TRY_OR_FAIL(gemm_x6_split(lw.mlp2_w, ME, lw.mlp2_w3, E, ME, 0));
         // all layers' AdaLN projections concatenated along N -> one GEMM each
         TRY_OR_FAIL(upload(h->cond_w_all + (size_t)l * 2 * E * E, w[9], (size_t)2 * E * E));
         TRY_OR_FAIL(upload(h->cond_b_all + (size_t)l * 2 * E, w[10], (size_t)2 * E));
@@ -1088,7 +1146,8 @@ extern "C" int after_denoiser_create(const after_denoiser_cfg* cfg, const float*
     const size_t SR = (size_t)max_steps * max_rows;
     size_t wsf = MT * h->Cp + MT * E + 2 * MT * h->ZSp + MT * L * 2 * E + SR * h->K0p +
                  2 * SR * E + SR * L * 2 * E + 2 * MT * E + MT * 3 * E + MT * ME + MT * C +
-                 MT * C + 2 * MT * C + (size_t)max_rows * h->ZT + MT * h->ZSp + 1024;
+                 MT * C + 2 * MT * C + (size_t)max_rows * h->ZT + MT * h->ZSp + 1024 +
+                 ((MT + 16) * E + (MT + 16) * ME) * 3 / 2 + 256;
     TRY_OR_FAIL(h->ws.init(wsf * sizeof(float) + 4 * ((size_t)max_rows + 1) * sizeof(int) + 256 * 32));
     TAKE(h->xt, h->ws, MT * h->Cp);
     TAKE(h->pat, h->ws, MT * E);
@@ -1109,6 +1168,12 @@ extern "C" int after_denoiser_create(const after_denoiser_cfg* cfg, const float*
     TAKE(h->sout, h->ws, MT * C);
     TAKE(h->scond, h->ws, (size_t)max_rows * h->ZT);
     TAKE(h->stc, h->ws, MT * h->ZSp);
+    h->hb3 = h->ws.take<unsigned short>((MT + 16) * 3 * E);   // rows padded to whole 16-row blocks
+    h->mlp3 = h->ws.take<unsigned short>((MT + 16) * 3 * ME);
+    if (!h->hb3 || !h->mlp3) {
+        set_error("arena exhausted at the activation planes");
+        return fail(AFTER_E_NOMEM);
+    }
     h->dparams = reinterpret_cast<CfgParams*>(h->ws.take<float>(64));
     if (!h->dparams) return fail(AFTER_E_NOMEM);
     h->ms = max_rows + 1;
@@ -1149,23 +1214,9 @@ extern "C" int after_denoiser_create(const after_denoiser_cfg* cfg, const float*
         const char* f = getenv("AFTER_FUSE_TAIL");
         h->fuse_tail = f ? atoi(f) : 1;
         const char* x6 = getenv("AFTER_GEMM_X6");
-        h->x6 = x6 ? atoi(x6) : 0;
+        if (x6) h->x6 = atoi(x6) < 0 ? 0 : (atoi(x6) > 2 ? 2 : atoi(x6));
         const char* x6r = getenv("AFTER_GEMM_X6_MINROWS");
         if (x6r) h->x6_min_rows = atoi(x6r);
-        if (h->x6) {
-            for (int l = 0; l < h->L; ++l) {
-                const LayerW& w = h->layers[l];
-                const float* ws_[3] = {w.qkv_w, w.mlp0_w, w.mlp2_w};
-                const int ns_[3] = {3 * h->E, h->ME, h->E}, ks_[3] = {h->E, h->E, h->ME};
-                for (int q = 0; q < 3; ++q) {
-                    unsigned short* w3 = nullptr;
-                    if (hipMalloc(reinterpret_cast<void**>(&w3), (size_t)ns_[q] * 3 * ks_[q] * sizeof(unsigned short)) != hipSuccess)
-                        return fail(AFTER_E_NOMEM);
-                    h->x6_w.emplace_back(ws_[q], w3);
-                    if (gemm_x6_split(ws_[q], ks_[q], w3, ns_[q], ks_[q], 0) != AFTER_OK) return fail(AFTER_E_HIP);
-                }
-            }
-        }
         if (h->E % 128 != 0) h->fuse_tail = 0;  // the fused GEMM splits K four ways
     }
     if (hipDeviceSynchronize() != hipSuccess) return fail(AFTER_E_HIP);
@@ -1187,7 +1238,6 @@ extern "C" void after_denoiser_destroy(after_denoiser* h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->ev_out) (void)hipEventDestroy(h->ev_out);
-    for (auto& e : h->x6_w) (void)hipFree(e.second);
     h->timer.destroy();
     h->wa.release();
     h->ws.release();
@@ -1413,6 +1463,23 @@ extern "C" int after_sample(after_denoiser* h, const float* x0, const float* con
     return AFTER_OK;
 }
 
+extern "C" int after_denoiser_set_gemm_path(after_denoiser* h, int mode, int min_rows) {
+    AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
+    AFTER_REQUIRE(mode >= 0 && mode <= 2, AFTER_E_INVALID, "gemm path %d (0 fp32 MFMA, 1 bf16-split above min_rows, 2 always)", mode);
+    h->x6 = mode;
+    if (min_rows > 0) h->x6_min_rows = min_rows;
+    for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.exec);  // captured launches bake the path in
+    h->graphs.clear();
+    return AFTER_OK;
+}
+
+extern "C" int after_denoiser_gemm_path(after_denoiser* h, int* mode, int* min_rows) {
+    AFTER_REQUIRE(h && mode && min_rows, AFTER_E_INVALID, "null argument");
+    *mode = h->x6;
+    *min_rows = h->x6_min_rows;
+    return AFTER_OK;
+}
+
 extern "C" int after_denoiser_set_graph(after_denoiser* h, int enable) {
     AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
     h->use_graph = enable != 0;
@@ -1480,6 +1547,12 @@ extern "C" int after_denoiser_gemm_time2(after_denoiser* h, double* total_ms, lo
                                          double* bytes) {
     AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
     return h->timer.collect(total_ms, launches, flops, bytes);
+}
+
+extern "C" int after_denoiser_profile_kernel(after_denoiser* h, int which) {
+    AFTER_REQUIRE(h && which >= 0 && which <= 2, AFTER_E_INVALID, "profile kernel class 0..2");
+    h->timer_kernel = which;
+    return AFTER_OK;
 }
 
 extern "C" int after_denoiser_profile_min_flops(after_denoiser* h, double min_flops) {

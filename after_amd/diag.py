@@ -22,26 +22,58 @@ def gemm(a, w, bias=None, residual=None, epilogue=0, tile=(0, 0), out=None):
     return out
 
 
+class X6Planes:
+    """The three bf16 planes of an fp32 [rows, K] matrix in gemm_x6's block layout (include/after_hip.h:
+    1-KB blocks [ceil(rows / 16)][K / 32][plane]; int16 storage).  `data` is the flat device buffer."""
+
+    def __init__(self, data, rows, K):
+        self.data, self.rows, self.K = data, rows, K
+
+    @staticmethod
+    def empty(rows, K, device):
+        n = ((rows + 15) // 16) * 16 * 3 * K
+        return X6Planes(torch.zeros(n, device=device, dtype=torch.int16), rows, K)
+
+    def index(self):
+        """int64 [rows, 3, K]: flat element offset of (row, plane, column) -- the layout restated in torch
+        (checked against after_gemm_x6_offset by tests/test_gemm_gpu.py)."""
+        r = torch.arange(self.rows).view(-1, 1, 1)
+        p = torch.arange(3).view(1, -1, 1)
+        k = torch.arange(self.K).view(1, 1, -1)
+        rr, c = r & 15, (k & 31) >> 3
+        f = torch.tensor([0, 2, 3, 1])[(rr >> 2) & 3]
+        slot = c ^ f
+        return (((r >> 4) * (self.K >> 5) + (k >> 5)) * 3 + p) * 512 + rr * 32 + slot * 8 + (k & 7)
+
+    def join(self):
+        """fp32 [rows, K] value of the planes (h + m + l, exact), on the CPU."""
+        d = self.data.cpu()[self.index()]
+        f = (d.to(torch.int32) << 16).view(torch.float32)
+        return (f[:, 0] + f[:, 1]) + f[:, 2]
+
+
 def split_x6(w):
-    """The three bf16 planes [N, 3, K] (int16 storage) of an fp32 weight, for gemm_x6."""
-    w = _lib.require_gpu_tensor(w, "w")
+    """fp32 [rows, K] device matrix -> X6Planes (both operands of gemm_x6)."""
+    w = _lib.require_gpu_tensor(w, "w", allow_row_stride=True)
     N, K = w.shape
-    w3 = torch.empty(N, 3, K, device=w.device, dtype=torch.int16)
-    _lib.check(_lib.lib().after_gemm_x6_split(_lib.ptr(w), w.stride(0), _lib.ptr(w3), N, K,
+    out = X6Planes.empty(N, K, w.device)
+    _lib.check(_lib.lib().after_gemm_x6_split(_lib.ptr(w), w.stride(0), _lib.ptr(out.data), N, K,
                                               _lib.current_stream(w.device)), "after_gemm_x6_split")
-    return w3
+    return out
 
 
-def gemm_x6(a, w3, bias=None, residual=None, epilogue=0, tile=0, out=None):
-    """EXPERIMENTAL: out[M,N] = epi(a @ w^T + bias) with fp32 products formed on the bf16 matrix pipe."""
-    a = _lib.require_gpu_tensor(a, "a", allow_row_stride=True)
-    M, K = a.shape
-    N = w3.shape[0]
+def gemm_x6(a3, w3, bias=None, residual=None, epilogue=0, tile=0, out=None, planes=False):
+    """out[M,N] = epi(a @ w^T + bias) on the bf16-split path (gemm_x6.hip): a3 / w3 = X6Planes; the result is
+    fp32 [M, N], or (planes=True) X6Planes of it."""
+    M, K, N = a3.rows, a3.K, w3.rows
+    assert w3.K == K
     if out is None:
-        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
-    rc = _lib.lib().after_gemm_x6(_lib.ptr(a), a.stride(0), _lib.ptr(w3), _lib.ptr(bias), _lib.ptr(residual),
-                                  residual.stride(0) if residual is not None else 0, _lib.ptr(out), out.stride(0),
-                                  M, N, K, int(epilogue), int(tile), _lib.current_stream(a.device))
+        out = X6Planes.empty(M, N, a3.data.device) if planes else torch.empty(M, N, device=a3.data.device)
+    rc = _lib.lib().after_gemm_x6(_lib.ptr(a3.data), _lib.ptr(w3.data), _lib.ptr(bias), _lib.ptr(residual),
+                                  residual.stride(0) if residual is not None else 0,
+                                  None if planes else _lib.ptr(out), _lib.ptr(out.data) if planes else None,
+                                  0 if planes else out.stride(0), M, N, K, int(epilogue), int(tile),
+                                  _lib.current_stream(a3.data.device))
     _lib.check(rc, "after_gemm_x6")
     return out
 

@@ -209,8 +209,14 @@ class DenoiserV2(nn.Module):
         _lib.check(rc, "after_denoiser_create")
         self._handle = out
         self._cap = cap
-        if self._profile:
+        if self._profile:  # measurement hooks survive a rebuilt handle (.to(), load_state_dict, refresh, growth)
+            _lib.check(L.after_denoiser_profile_min_flops(out, float(getattr(self, "_profile_min_flops", 0.0))),
+                       "after_denoiser_profile_min_flops")
+            _lib.check(L.after_denoiser_profile_kernel(out, int(getattr(self, "_profile_kernel", 0))),
+                       "after_denoiser_profile_kernel")
             _lib.check(L.after_denoiser_profile(out, 1), "after_denoiser_profile")
+        if getattr(self, "_gemm_path", None) is not None:
+            _lib.check(L.after_denoiser_set_gemm_path(out, *self._gemm_path), "after_denoiser_set_gemm_path")
         if self._stream_args is not None and not getattr(self, "_enabling", False):
             # the handle was rebuilt (.to(), load_state_dict, refresh): a Streamer still expects
             # its K/V caches -- re-create them (zeroed = a new stream), as AutoEncoder / Encoder1D do
@@ -348,9 +354,32 @@ class DenoiserV2(nn.Module):
         return out
 
     # ------------------------------------------------------------ measurement hooks
-    def profile(self, enable: bool = True, min_flops: float = 0.0):
-        self._profile = bool(enable)
+    def set_gemm_path(self, mode: int, min_rows: int = 0):
+        """Arithmetic path of the qkv / MLP Linears (include/after_hip.h: after_denoiser_set_gemm_path):
+        0 fp32 MFMA; 1 bf16-split kernel for >= min_rows token rows (the default); 2 bf16-split always."""
+        self._gemm_path = (int(mode), int(min_rows))
         if self._handle is not None:
+            _lib.check(_lib.lib().after_denoiser_set_gemm_path(self._handle, int(mode), int(min_rows)),
+                       "after_denoiser_set_gemm_path")
+
+    def gemm_path(self):
+        """(mode, min_rows) in effect (the handle's, i.e. including the AFTER_GEMM_X6 environment default)."""
+        if self._handle is None:
+            self._ensure(1, 1, 1)
+        m, r = ctypes.c_int(), ctypes.c_int()
+        _lib.check(_lib.lib().after_denoiser_gemm_path(self._handle, ctypes.byref(m), ctypes.byref(r)),
+                   "after_denoiser_gemm_path")
+        return m.value, r.value
+
+    def profile(self, enable: bool = True, min_flops: float = 0.0, kernel: int = 0):
+        """Bracket the GEMM launches with HIP events: only those of >= min_flops, and of kernel class
+        `kernel` (0 both, 1 the bf16-split gemm_x6 kernel, 2 the fp32 MFMA kernel)."""
+        self._profile = bool(enable)
+        self._profile_min_flops = float(min_flops)
+        self._profile_kernel = int(kernel)
+        if self._handle is not None:
+            _lib.check(_lib.lib().after_denoiser_profile_kernel(self._handle, int(kernel)),
+                       "after_denoiser_profile_kernel")
             _lib.check(_lib.lib().after_denoiser_profile_min_flops(self._handle, float(min_flops)),
                        "after_denoiser_profile_min_flops")
             _lib.check(_lib.lib().after_denoiser_profile(self._handle, int(enable)),

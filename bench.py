@@ -11,7 +11,9 @@ init, synthetic latents; one clip = 524288 samples = 11.889 s @ 44.1 kHz).
 Other BASELINE configs: `--batch-per-gpu 8` (configs[2]'s per-GPU shard),
 `--config midi --batch-per-gpu 8` (configs[3]), `--stream` (configs[4]: base + cycle,
 100-step cached sampler, causal cached-conv codec, 8 independent streams; one step =
-one 4-frame chunk of every stream).  Prints ONE JSON line on rank 0.
+one 4-frame chunk of every stream), `--from-audio [--config tiny]` (configs[0]'s chain:
+two audio clips -> AutoEncoder.encode x 2 -> encoders -> sampler -> decode).
+Prints ONE JSON line on rank 0.
 
 `--pmc` (single GPU): re-measures the HBM traffic of the dominant GEMM with two
 rocprofv3 counter passes of this same command and writes profiles/<round>_pmc_hbm_<cfg>.json
@@ -38,10 +40,12 @@ CLIP_SAMPLES = 524288
 CLIP_SECONDS = CLIP_SAMPLES / 44100.0
 T_FRAMES = 256
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_* dense peak
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (the experimental gemm_x6 path only)
-ROUND = "r2"
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak; gemm_x6 spends six bf16 MFMAs per fp32 product block
+PEAK_X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+ROUND = "r3"
 # sources whose change invalidates a committed traffic measurement of the dominant GEMM
-TRAFFIC_SOURCES = ["after_amd/csrc/gemm.hip", "after_amd/csrc/gemm_pipe.h", "after_amd/csrc/denoiser.hip"]
+TRAFFIC_SOURCES = ["after_amd/csrc/gemm.hip", "after_amd/csrc/gemm_x6.hip", "after_amd/csrc/gemm_pipe.h",
+                   "after_amd/csrc/denoiser.hip"]
 
 
 def source_hash():
@@ -88,10 +92,22 @@ def cpu_baseline(nb_steps, state_dicts, dcfg, acfg, tcond=None):
         z = oracle.sample(sd_net, dcfg["net"], x0, cond, tc, nb_steps, 2.0, 1.0)
         y = oracle.ae_decode(sd_ae, z, acfg)
         dt = time.perf_counter() - t0
+        t8 = None
+        if cores > 8:  # comparability with BASELINE.md section 2 (the reference's own numbers: 8 cores)
+            torch.set_num_threads(8)
+            t1 = time.perf_counter()
+            cond = oracle.ecapa_forward(sd_enc, zt[..., :128], dcfg["encoder"])
+            tc = tcond if tcond is not None else oracle.encoder1d_forward(sd_et, zs, dcfg["encoder_time"])
+            oracle.ae_decode(sd_ae, oracle.sample(sd_net, dcfg["net"], x0, cond, tc, nb_steps, 2.0, 1.0), acfg)
+            t8 = time.perf_counter() - t1
+            torch.set_num_threads(cores)
     assert y.shape[-1] == CLIP_SAMPLES
     return {"value": CLIP_SECONDS / dt, "unit": "audio_s_per_wall_s", "cores": cores, "kind": "port",
             "sample": f"1 clip, full path (encoders + {nb_steps}-step sampler + decode), "
-                      f"{dt:.2f} s on {cores} threads, torch {torch.__version__} CPU fp32"}
+                      f"{dt:.2f} s on {cores} threads, torch {torch.__version__} CPU fp32",
+            "threads8": ({"value": round(CLIP_SECONDS / t8, 3), "cores": 8,
+                          "sample": f"the same clip on 8 threads, {t8:.2f} s (BASELINE.md section 2: the reference's "
+                                    "own path on 8 cores of the survey container, 3.6x RT)"} if t8 else None)}
 
 
 def cpu_baseline_stream(model, dcfg, acfg, chunk, nb_steps, nsig):
@@ -117,25 +133,58 @@ def cpu_baseline_stream(model, dcfg, acfg, chunk, nb_steps, nsig):
                       f"codec (oracle.stream_forward), {dt:.2f} s on {cores} threads"}
 
 
-def x6_experiment():
-    return os.environ.get("AFTER_GEMM_X6", "0") not in ("", "0")
+def _trains(dev, M, shapes, x6):
+    """The dominant launches without per-launch event bracketing: trains of 100 back-to-back launches of the
+    given (N, K) shapes, one event pair per train -> TFLOP/s."""
+    from after_amd import diag
+    tot_t, tot_f = 0.0, 0.0
+    for (n_, k_) in shapes:
+        a_ = torch.randn(M, k_, device=dev)
+        w_ = torch.randn(n_, k_, device=dev)
+        o_ = torch.empty(M, n_, device=dev)
+        if x6:
+            a3, w3 = diag.split_x6(a_), diag.split_x6(w_)
+            fn = lambda: diag.gemm_x6(a3, w3, out=o_)
+        else:
+            fn = lambda: diag.gemm(a_, w_, out=o_)
+        for _ in range(5):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(100):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        tot_t += e0.elapsed_time(e1) * 1e-3 / 100
+        tot_f += 2.0 * M * n_ * k_
+    return round(tot_f / tot_t / 1e12, 2)
 
 
 def gemm_roofline(model, run_once, dev, dcfg, B, config, args):
-    """Roofline of the dominant kernel (the fp32 MFMA GEMM behind qkv / MLP), measured live with HIP
-    events on the launch stream in one extra, untimed pass."""
+    """Roofline of the dominant kernel -- the GEMM behind the qkv / MLP Linears -- measured live with HIP events on
+    the launch stream in extra, untimed passes.  On the default path that kernel is gemm_x6 (fp32 products as six
+    exact bf16 MFMAs: priced against the dense bf16 MFMA peak / 6); `fp32_mfma_path` carries the same measurement
+    with every Linear forced onto the fp32 MFMA kernel (the rounds-1/2 path, priced against the fp32 MFMA peak)."""
     # the dominant launches: qkv / MLP-up / MLP-down (1.208 GFLOP each for base at B=1); the patchify /
-    # AdaLN / out_proj launches share the kernel template but are a tenth of the size
+    # AdaLN / out_proj launches share the fp32 kernel template but are a tenth of the size
     E_, ME_ = dcfg["net"]["embed_dim"], dcfg["net"]["embed_dim"] * dcfg["net"]["mlp_multiplier"]
     big = 0.5 * 2.0 * (3 * B * T_FRAMES) * E_ * ME_
-    model.net.profile(True, min_flops=0.0 if args.stream else big)
-    run_once()
-    torch.cuda.synchronize()
-    ms, launches, flops, nbytes = model.net.gemm_time(with_bytes=True)
-    model.net.profile(False)
-    if not launches:
-        return None
+
+    def timed_pass(kernel, min_flops):
+        model.net.profile(True, min_flops=min_flops, kernel=kernel)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_once()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        ms, launches, flops, nbytes = model.net.gemm_time(with_bytes=True)
+        model.net.profile(False)
+        return ms, launches, flops, nbytes, wall
+
     if args.stream:
+        ms, launches, flops, nbytes, _ = timed_pass(0, 0.0)
+        if not launches:
+            return None
         # <= 96 tokens per launch: weight-streaming GEMMs (3 MB of W against 0.2 MB of activations),
         # priced against HBM bandwidth; in practice they sit at the launch / dependency floor
         gbs = nbytes / (ms * 1e-3) / 1e9
@@ -146,61 +195,73 @@ def gemm_roofline(model, run_once, dev, dcfg, B, config, args):
                 "bytes_per_launch": round(nbytes / launches),
                 "note": "algorithmic bytes (A + W + C) / HIP-event launch duration; the launches are 6-9 us each, "
                         "i.e. latency-bound, and the weights are Infinity-Cache resident after the first step"}
-    traffic, traffic_note = None, "no committed PMC profile for this configuration (python bench.py --pmc)"
+
+    prof = None
     pth = pmc_path(config, B)
+    traffic_note = "no committed PMC profile for this configuration (python bench.py --pmc)"
     if os.path.exists(pth):
         prof = json.load(open(pth))
-        if prof.get("source_hash") == source_hash():
-            traffic = prof.get("gemm_big_mean_bytes_per_launch")
+        if prof.get("source_hash") != source_hash():
+            prof, traffic_note = None, f"{os.path.basename(pth)} is stale (kernel sources changed since it was measured)"
+        else:
             traffic_note = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command ({os.path.basename(pth)}, "
                             f"sources {prof.get('source_hash')}): (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, "
                             "Infinity-Cache hits included")
-        else:
-            traffic_note = f"{os.path.basename(pth)} is stale (kernel sources changed since it was measured)"
-    # the same launches without per-launch event bracketing: trains of 100 back-to-back
-    # launches of the two dominant shapes (qkv / MLP-up and MLP-down), one event pair per train
-    b2b = None
-    try:
-        from after_amd import diag
-        M = 3 * B * (T_FRAMES if not args.stream else args.chunk)
-        tot_t, tot_f = 0.0, 0.0
-        for (n_, k_) in ((ME_, E_), (E_, ME_)):
-            a_ = torch.randn(M, k_, device=dev)
-            w_ = torch.randn(n_, k_, device=dev)
-            o_ = torch.empty(M, n_, device=dev)
-            for _ in range(5):
-                diag.gemm(a_, w_, out=o_)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(100):
-                diag.gemm(a_, w_, out=o_)
-            e1.record()
-            torch.cuda.synchronize()
-            tot_t += e0.elapsed_time(e1) * 1e-3 / 100
-            tot_f += 2.0 * M * n_ * k_
-        b2b = round(tot_f / tot_t / 1e12, 2)
-    except Exception:  # diagnostics only
-        b2b = None
-    ach = flops / (ms * 1e-3) / 1e12
-    if x6_experiment():
-        # EXPERIMENT (never the default): the big Linears run on the bf16 matrix pipe, six bf16 MFMAs per
-        # fp32 product block -> priced against the dense bf16 MFMA peak / 6, not the fp32 MFMA peak
-        peak = PEAK_BF16_MFMA_TFLOPS / 6.0
-        return {"bound": "mfma", "kernel": "gemm_x6_kernel (6 x v_mfma_f32_16x16x32_bf16 per 32-deep fp32 block)",
-                "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                "traffic": None, "launches": int(launches), "avg_launch_us": round(ms * 1e3 / launches, 2),
-                "note": "EXPERIMENT AFTER_GEMM_X6=1: algorithmic fp32 flops / HIP-event launch duration against "
-                        "the dense bf16 MFMA peak (2500 TFLOP/s) / 6", "flops_per_launch": round(flops / launches)}
-    return {"bound": "mfma", "kernel": "gemm_f32_bal_kernel (v_mfma_f32_16x16x4_f32): the qkv / MLP-up / MLP-down "
-                                       f"launches (>= {big / 1e9:.2f} GFLOP each)",
-            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes per launch",
-            "traffic_note": traffic_note, "launches": int(launches),
-            "avg_launch_us": round(ms * 1e3 / launches, 2), "achieved_back_to_back": b2b,
-            "note": "achieved = per-launch HIP-event bracketing inside the sampler (launch latency included: the "
-                    "rocprofv3 kernel durations in profiles/ are ~2 us shorter per launch); achieved_back_to_back = "
-                    "same kernels in trains of 100 launches",
-            "flops_per_launch": round(flops / launches)}
+    M = 3 * B * T_FRAMES
+    note = ("achieved = algorithmic fp32 flops / per-launch HIP-event bracketing inside the sampler (launch latency "
+            "included: the rocprofv3 kernel durations in profiles/ are ~2 us shorter per launch); "
+            "achieved_back_to_back = the same kernel in trains of 100 launches of the qkv / MLP-up and MLP-down shapes")
+
+    def fp32_leg(ms, launches, flops, extra=None):
+        ach = flops / (ms * 1e-3) / 1e12
+        d = {"kernel": "gemm_f32_bal_kernel (v_mfma_f32_16x16x4_f32, exact fp32 fma chain)",
+             "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+             "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "launches": int(launches),
+             "avg_launch_us": round(ms * 1e3 / launches, 2), "flops_per_launch": round(flops / launches)}
+        d.update(extra or {})
+        return d
+
+    mode, min_rows = model.net.gemm_path()
+    x_ms, x_n, x_fl, _, _ = timed_pass(1, big) if mode != 0 else (0.0, 0, 0.0, 0.0, 0.0)
+    f_ms, f_n, f_fl, _, _ = timed_pass(2, big)  # big launches the default path leaves on the fp32 MFMA kernel
+    if not x_n:  # fp32 MFMA everywhere (AFTER_GEMM_X6=0, or too few token rows)
+        if not f_n:
+            return None
+        r = fp32_leg(f_ms, f_n, f_fl, {"achieved_back_to_back": _trains(dev, M, ((ME_, E_), (E_, ME_)), False)})
+        r.update({"bound": "mfma", "traffic": prof.get("gemm_big_mean_bytes_per_launch") if prof else None,
+                  "traffic_unit": "bytes per launch", "traffic_note": traffic_note, "note": note,
+                  "kernel": r["kernel"] + f": the qkv / MLP launches (>= {big / 1e9:.2f} GFLOP each)"})
+        return r
+    ach = x_fl / (x_ms * 1e-3) / 1e12
+    roof = {"bound": "mfma",
+            "kernel": "gemm_x6_kernel (fp32 product blocks as 6 x v_mfma_f32_16x16x32_bf16 on exact three-way bf16 "
+                      f"splits, fp32 accumulate): the qkv / MLP launches (>= {big / 1e9:.2f} GFLOP each) it runs",
+            "achieved": round(ach, 2), "peak": round(PEAK_X6_TFLOPS, 1), "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_X6_TFLOPS, 4),
+            "peak_note": "dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMAs per fp32 product block; against the fp32 MFMA peak "
+                         f"(157.3) the same launches are at {ach / PEAK_FP32_MFMA_TFLOPS:.3f}",
+            "traffic": prof.get("gemm_x6_mean_bytes_per_launch") if prof else None, "traffic_unit": "bytes per launch",
+            "traffic_note": traffic_note, "launches": int(x_n), "avg_launch_us": round(x_ms * 1e3 / x_n, 2),
+            "flops_per_launch": round(x_fl / x_n),
+            "achieved_back_to_back": _trains(dev, M, ((ME_, E_), (E_, ME_)) if f_n == 0 else ((ME_, E_), ), True),
+            "gemm_path": {"mode": mode, "min_rows": min_rows},
+            "note": note}
+    if f_n:
+        roof["same_run_fp32_kernel_launches"] = fp32_leg(
+            f_ms, f_n, f_fl, {"what": "launches of the same size class that stay on the fp32 MFMA kernel: at one clip "
+                                      "MLP-down (N = 512, K = 1536: per-shape dispatch, DESIGN.md section 4), at larger "
+                                      "batches only the once-per-sample AdaLN projection of all steps"})
+    # continuity with rounds 1-2: the same step with EVERY Linear on the fp32 MFMA kernel
+    model.net.set_gemm_path(0)
+    run_once()
+    a_ms, a_n, a_fl, _, wall = timed_pass(2, big)
+    model.net.set_gemm_path(mode, min_rows)
+    if a_n:
+        roof["fp32_mfma_path"] = fp32_leg(a_ms, a_n, a_fl, {
+            "ms_per_step": round(wall * 1e3, 3), "achieved_back_to_back": _trains(dev, M, ((ME_, E_), (E_, ME_)), False),
+            "what": "one extra untimed step with after_denoiser_set_gemm_path(0): every Linear on the fp32 MFMA kernel "
+                    "(the rounds-1/2 product path; ms_per_step here includes the event bracketing)"})
+    return roof
 
 
 def run_pmc(args):
@@ -226,7 +287,7 @@ def run_pmc(args):
                 continue
             key = (row["Kernel_Name"], int(row["Grid_Size"]))
             agg.setdefault(key, {}).setdefault(ctr, []).append(float(row["Counter_Value"]))
-    rows, big_bytes, big_n = [], 0.0, 0
+    rows, big_bytes, big_n, x6_bytes, x6_n = [], 0.0, 0, 0.0, 0
     for (name, grid), v in agg.items():
         f, w = v.get("FETCH_SIZE", [0.0]), v.get("WRITE_SIZE", [0.0])
         fm, wm = sum(f) / len(f), sum(w) / len(w)
@@ -239,14 +300,19 @@ def run_pmc(args):
         if m and m.group(1).split(",")[-1].strip() == "0" and total > 5e6:  # MODE 0, not the small launches
             big_bytes += total * len(f)
             big_n += len(f)
+        if "gemm_x6_kernel" in name:
+            x6_bytes += total * len(f)
+            x6_n += len(f)
     rows.sort(key=lambda r: -r["bytes_per_launch_corrected"] * r["launches"])
     prof = {"note": "bytes_per_launch_corrected = (2 * FETCH_SIZE + WRITE_SIZE) * 1024; includes Infinity-Cache hits",
             "command": " ".join(inner[1:]), "source_hash": source_hash(), "sources": TRAFFIC_SOURCES,
             "gemm_big_mean_bytes_per_launch": round(big_bytes / max(1, big_n)), "gemm_big_launches": big_n,
+            "gemm_x6_mean_bytes_per_launch": round(x6_bytes / max(1, x6_n)), "gemm_x6_launches": x6_n,
             "kernels": rows[:24]}
     json.dump(prof, open(pmc_path(args.config, args.batch_per_gpu), "w"), indent=1)
     json.dump(prof, open(os.path.join(out, os.path.basename(pmc_path(args.config, args.batch_per_gpu))), "w"), indent=1)
-    print(json.dumps({k: prof[k] for k in ("gemm_big_mean_bytes_per_launch", "gemm_big_launches", "source_hash")}))
+    print(json.dumps({k: prof[k] for k in ("gemm_x6_mean_bytes_per_launch", "gemm_x6_launches",
+                                           "gemm_big_mean_bytes_per_launch", "gemm_big_launches", "source_hash")}))
 
 
 def main():
@@ -263,6 +329,8 @@ def main():
     ap.add_argument("--stream", action="store_true", help="BASELINE config 5: streaming, 100 cached steps")
     ap.add_argument("--nb-steps", type=int, default=None, help="Euler steps (50; 100 with --stream)")
     ap.add_argument("--chunk", type=int, default=4, help="--stream: latent frames per chunk")
+    ap.add_argument("--from-audio", action="store_true",
+                    help="BASELINE config 1's chain: audio -> AutoEncoder.encode x 2 -> encoders -> sampler -> decode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pmc", action="store_true", help="measure the GEMM's HBM traffic with rocprofv3 and exit")
     args = ap.parse_args()
@@ -305,6 +373,8 @@ def main():
     if world > 1:  # identical models everywhere: one RCCL broadcast at start-up
         parallel.broadcast_module(model)  # net, both encoders and the codec (a registered sub-module)
     n_ranks_seen = parallel.ranks_seen() if world > 1 else 1
+    if n_ranks_seen != world:  # RCCL did not connect every rank: a "scaling" number of this run would be fiction
+        raise SystemExit(f"rank {rank}: {n_ranks_seen} ranks answered the all-reduce, expected {world}")
 
     n_clips = args.global_batch if args.global_batch else args.batch_per_gpu * world
     g = torch.Generator(device="cpu").manual_seed(1000)
@@ -344,6 +414,10 @@ def main():
         x0_all = torch.randn(n_clips, 64, T_FRAMES, generator=g)
         zs, zt, x0 = (t[lo:hi].to(dev) for t in (zs_all, zt_all, x0_all))
         tcond = None
+        audio_s = audio_t = None
+        if args.from_audio:  # two 0.1 N(0,1) clips, encoded by the codec inside the step
+            audio_s = (0.1 * torch.randn(n_clips, 1, CLIP_SAMPLES, generator=g))[lo:hi].to(dev)
+            audio_t = (0.1 * torch.randn(n_clips, 1, CLIP_SAMPLES, generator=g))[lo:hi].to(dev)
         if dcfg["encoder_time"] is None:  # midi: synthetic piano roll
             tcond = piano_roll(n_clips, dcfg["net"]["tcond_dim"], dev)[lo:hi].contiguous()
         unit_seconds = CLIP_SECONDS
@@ -351,13 +425,19 @@ def main():
         gather_buf = torch.empty(out_shape, device=dev) if world > 1 else None
 
         def step(gather=True):
-            audio, z = pipeline.generate_from_latents(model, zs, zt, x0, nb_steps=nb_steps,
-                                                      guidance_timbre=2.0, guidance_structure=1.0,
-                                                      time_cond=tcond)
+            if args.from_audio:
+                audio, z = pipeline.audio_to_audio(model, audio_s, audio_t, x0, nb_steps=nb_steps,
+                                                   guidance_timbre=2.0, guidance_structure=1.0, time_cond=tcond)
+            else:
+                audio, z = pipeline.generate_from_latents(model, zs, zt, x0, nb_steps=nb_steps,
+                                                          guidance_timbre=2.0, guidance_structure=1.0,
+                                                          time_cond=tcond)
             if world > 1 and gather:
                 audio = parallel.gather_clips(audio, n_clips, out=gather_buf)
             return audio
         src = "synthetic piano roll + timbre latents" if tcond is not None else "synthetic latents"
+        if args.from_audio:
+            src = "two synthetic audio clips per item (AutoEncoder.encode x 2 inside the step)"
         workload = (f"{args.config} {'midi' if tcond is not None else 'audio'}-to-audio from {src}, "
                     f"{nb_steps} Euler steps with 3-way CFG (g_t=2, g_s=1), "
                     f"T=256 frames = 11.889 s clips, encoders + sampler + AE decode, random-init weights")
@@ -374,10 +454,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    elapsed_min = elapsed
+    if world > 1:  # the slowest rank is the job's time; the fastest beside it makes a straggler visible
         te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tn = te.clone()
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = te.item()
+        dist.all_reduce(tn, op=dist.ReduceOp.MIN)
+        elapsed, elapsed_min = te.item(), tn.item()
     assert tuple(out.shape) == out_shape and torch.isfinite(out).all()
 
     roof = None
@@ -407,10 +490,14 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "ms_per_step_fastest_rank": round(elapsed_min / args.steps * 1e3, 3),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if not x6_experiment() else "f32 (EXPERIMENT: products as six bf16 MFMAs, fp32 accumulate)",
+            "dtype": ("f32" if not (roof and "gemm_path" in roof) else
+                      "f32 (arithmetic and results fp32 as in the reference; the qkv / MLP Linears form each fp32 product "
+                      "as six exact bf16 MFMAs on exact three-way bf16 splits of both operands, fp32 accumulate -- error "
+                      "vs fp64 <= the fp32 MFMA chain's, tests/test_gemm_gpu.py; AFTER_GEMM_X6=0 = fp32 MFMA everywhere)"),
             "data": "synthetic",
             "config": {"workload": workload,
                        "batch_per_gpu": args.batch_per_gpu if not args.global_batch else None,
@@ -419,9 +506,6 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         }
-        if x6_experiment():
-            line["experiment"] = ("AFTER_GEMM_X6=1: the denoiser's qkv / MLP Linears through after_amd/csrc/gemm_x6.hip "
-                                  "for >= 1536 token rows; not the default path, see DESIGN.md section 10")
         if args.stream:
             line["metric"] = "audio sec generated / wall sec (xRT, all streams), base+cycle 100-step streaming @44.1 kHz"
         print(json.dumps(line))

@@ -119,6 +119,17 @@ int after_sample(after_denoiser* h, const float* x0, const float* cond, const fl
  * enable = 1 or environment AFTER_GRAPH=1 selects the replay. */
 int after_denoiser_set_graph(after_denoiser* h, int enable);
 
+/* Arithmetic path of the qkv / MLP Linears (nn.Linear at transformerv2.py:251, :275-283; every other Linear
+ * always runs on the fp32 MFMA kernel).  The result is fp32 either way:
+ *   0  fp32 MFMA (v_mfma_f32_16x16x4_f32: an exact fp32 fma chain), every size;
+ *   1  (default) the bf16-split kernel -- every fp32 operand carried as three bf16 planes, each product formed
+ *      as six exact bf16 MFMAs, fp32 accumulation; error vs fp64 <= the fp32 chain's -- for calls with
+ *      >= min_rows token rows (rows * T), fp32 MFMA below (streaming chunks);
+ *   2  the bf16-split kernel at every size (parity tests).
+ * min_rows <= 0 keeps the current threshold.  Environment at create: AFTER_GEMM_X6, AFTER_GEMM_X6_MINROWS. */
+int after_denoiser_set_gemm_path(after_denoiser* h, int mode, int min_rows);
+int after_denoiser_gemm_path(after_denoiser* h, int* mode, int* min_rows);
+
 /* Streaming KV caches (transformerv2.py:143-204; enabled in the reference by the
  * gin binding at after_scripts/export.py:77-79).  cache_size frames (a multiple of
  * the attention chunk) per layer, per diffusion step, per network row;
@@ -143,6 +154,9 @@ int after_denoiser_gemm_time_ms(after_denoiser* h, double* total_ms, long long* 
 /* only launches of at least min_flops are bracketed (the dominant qkv / MLP GEMMs: the small
  * patchify / AdaLN projections share the kernel template but not its roofline) */
 int after_denoiser_profile_min_flops(after_denoiser* h, double min_flops);
+/* which GEMM kernel's launches are bracketed: 0 both, 1 the bf16-split kernel (gemm_x6.hip) only, 2 the fp32 MFMA
+ * kernel (gemm.hip) only -- the two have different rooflines */
+int after_denoiser_profile_kernel(after_denoiser* h, int which);
 /* as after_denoiser_gemm_time_ms, plus the algorithmic bytes (A + W + C, fp32) of those launches:
  * the streaming path's GEMMs (<= 96 tokens) are weight-streaming launches priced against HBM */
 int after_denoiser_gemm_time2(after_denoiser* h, double* total_ms, long long* launches, double* flops,
@@ -360,13 +374,21 @@ int after_gemm_f32(const float* A, int lda, const float* W, int ldw, const float
                    const float* R, int ldr, float* C, int ldc, int M, int N, int K, int epilogue,
                    int force_mt, int force_nt, void* stream);
 
-/* EXPERIMENTAL (diagnostics / tests; see after_amd/csrc/gemm_x6.hip): the same GEMM with every fp32 product
- * formed from three-way bf16 splits of its operands on the bf16 matrix pipe (six v_mfma_f32_16x16x32_bf16
- * per 32-deep step, fp32 accumulation).  after_gemm_x6_split writes the [N][3][K] bf16 planes of W once. */
+/* Diagnostics / tests for after_amd/csrc/gemm_x6.hip, the kernel behind the denoiser's qkv / MLP Linears
+ * (reference transformerv2.py:251, :275-283) on the bf16-split path: every fp32 operand is carried as its
+ * three bf16 planes (x = h + m + l exactly), products are six v_mfma_f32_16x16x32_bf16 per 32-deep step with
+ * fp32 accumulation, the result is fp32 (C) or again planes (C3) for a following GEMM.  Plane storage
+ * ("x6 blocks", after_amd/csrc/common.h): for a [R][K] matrix, K % 32 == 0, 1-KB blocks
+ * [ceil(R / 16)][K / 32][plane] of 16 rows x 32 columns, i.e. 16 * ceil(R / 16) * 3 * K unsigned shorts;
+ * after_gemm_x6_offset gives the element offset of (row, plane, column).  after_gemm_x6_split writes the blocks
+ * of an fp32 matrix; tile 0 = chosen by shape (after_gemm_x6_pick_tile), else an id of the tile table in
+ * gemm_x6.hip.  Exactly one of C / C3 (C3 needs N % 32 == 0). */
 int after_gemm_x6_split(const float* W, int ldw, unsigned short* W3, int N, int K, void* stream);
-void after_gemm_x6_set_debug(unsigned long long* dbg); /* per-workgroup cycle counts of the pipeline phases */
-int after_gemm_x6(const float* A, int lda, const unsigned short* W3, const float* bias, const float* R,
-                  int ldr, float* C, int ldc, int M, int N, int K, int epilogue, int tile, void* stream);
+long long after_gemm_x6_offset(int row, int plane, int col, int K);
+void after_gemm_x6_set_debug(unsigned long long* dbg); /* per-workgroup cycle stamps, as after_gemm_set_debug */
+int after_gemm_x6_pick_tile(int M, int N, int K);
+int after_gemm_x6(const unsigned short* A3, const unsigned short* W3, const float* bias, const float* R, int ldr,
+                  float* C, unsigned short* C3, int ldc, int M, int N, int K, int epilogue, int tile, void* stream);
 
 /* One Conv1d layer on the time-major conv path (act(x) into the zero-haloed [B][T][C] buffer, then
  * the conv as a balanced LDS-DMA GEMM) for parity tests against a plain fp32 conv and for the

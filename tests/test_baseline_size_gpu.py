@@ -21,7 +21,7 @@ import oracle
 from after_amd import Streamer, _lib, pipeline
 from fixtures import max_abs, rel_l2
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("both_gemm_paths")]
 torch.set_grad_enabled(False)
 
 
@@ -151,3 +151,25 @@ def test_base_streamer_8_streams_100_steps_vs_oracle(hip_device):
     # conditioning scale, and the audio relative to its range
     assert max_abs(z, want_z) < 5e-4 * max(1.0, want_z.abs().max().item()), (max_abs(z, want_z), rel_l2(z, want_z))
     assert max_abs(y, want_audio) < 2e-3 * want_audio.abs().max().item(), rel_l2(y, want_audio)
+
+
+def test_config1_audio_to_audio_vs_oracle(hip_device):
+    """BASELINE config 1 (tiny audio-to-audio: audio -> AutoEncoder.encode x 2 -> encoder / encoder_time ->
+    RectifiedFlow.sample -> decode, notebooks/audio_to_audio_demo.ipynb cells 5-19) through
+    pipeline.audio_to_audio -- the function INTEGRATION.md shows as the drop-in example -- on whole 524288-sample
+    clips against the same chain of the CPU oracle (10 Euler steps keep the oracle leg at a few seconds)."""
+    model, dcfg, acfg = pipeline.build_models("tiny", "baseAE", hip_device, seed=9)
+    g = torch.Generator().manual_seed(77)
+    a_s, a_t = (0.1 * torch.randn(1, 1, 524288, generator=g) for _ in range(2))
+    x0 = torch.randn(1, 64, 256, generator=g)
+    sd_ae, sd_net, sd_enc, sd_et = (cpu_sd(m) for m in (model.emb_model, model.net, model.encoder, model.encoder_time))
+    zs, zt = oracle.ae_encode(sd_ae, a_s, acfg), oracle.ae_encode(sd_ae, a_t, acfg)
+    cond = oracle.ecapa_forward(sd_enc, zt[..., :128], dcfg["encoder"])
+    tc = oracle.encoder1d_forward(sd_et, zs, dcfg["encoder_time"])
+    zw = oracle.sample(sd_net, dcfg["net"], x0, cond, tc, 10, 2.0, 1.0)
+    yw = oracle.ae_decode(sd_ae, zw, acfg)
+    y, z = pipeline.audio_to_audio(model, a_s.to(hip_device), a_t.to(hip_device), x0.to(hip_device), nb_steps=10,
+                                   guidance_timbre=2.0, guidance_structure=1.0)
+    assert y.shape == (1, 1, 524288) and z.shape == (1, 64, 256)
+    assert max_abs(z.cpu(), zw) < 2e-4, (max_abs(z.cpu(), zw), rel_l2(z.cpu(), zw))
+    assert max_abs(y.cpu(), yw) < 2e-4 * yw.abs().max().item(), (max_abs(y.cpu(), yw), yw.abs().max().item())

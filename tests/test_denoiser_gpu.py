@@ -14,7 +14,7 @@ import oracle
 from after_amd import DenoiserV2, RectifiedFlow, _lib, configs
 from fixtures import Fixture, max_abs, rel_l2
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("both_gemm_paths")]
 torch.set_grad_enabled(False)
 
 

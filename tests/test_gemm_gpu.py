@@ -94,15 +94,15 @@ def test_gemm_strided_operands(hip_device):
     assert (out.double() - ref).abs().max().item() < 1e-4
 
 
-@pytest.mark.parametrize("tile", [0, 332, 312, 322, 314, 431, 421, 631, 1431, 1332, 831, 1831, 861])
-@pytest.mark.parametrize("M,N,K,epi", [(768, 1536, 512, 0), (100, 96, 128, 1), (6144, 512, 1536, 2), (49, 33, 256, 0)])
-def test_gemm_x6_experimental(tile, M, N, K, epi, hip_device):
-    """The experimental bf16-split GEMM (gemm_x6.hip: fp32 products as six bf16 MFMAs, fp32 accumulation)
-    against fp64, every tile, ragged shapes, bias + GELU / residual epilogues: it has to be at least as
-    accurate as the fp32 MFMA kernel up to the spread between summation orders (3 x its error)."""
-    from after_amd import diag
-    g = torch.Generator().manual_seed(M + N + K + tile)
-    a = (1.3 * torch.randn(M, K, generator=g))
+X6_SHAPES = [(768, 1536, 512, 0), (768, 512, 1536, 2), (6144, 1536, 512, 1), (6144, 512, 1536, 2), (100, 96, 128, 1),
+             (49, 33, 256, 0), (1536, 768, 256, 1), (200, 768, 768, 2)]
+
+
+def _x6_case(M, N, K, epi, seed):
+    """Operands in the sampler's regime: LayerNorm-scale activations with outlier rows / columns (x 25), weights
+    ~ N(0, 1/K), bias; fp64 reference of the fp32 operands."""
+    g = torch.Generator().manual_seed(seed)
+    a = 1.3 * torch.randn(M, K, generator=g)
     a[::5, ::11] *= 25.0
     w = torch.randn(N, K, generator=g) / K ** 0.5
     bias = torch.randn(N, generator=g)
@@ -112,11 +112,59 @@ def test_gemm_x6_experimental(tile, M, N, K, epi, hip_device):
         ref = torch.nn.functional.gelu(ref)
     if epi == 2:
         ref = ref + res.double()
-    w3 = diag.split_x6(w.to(hip_device))
-    got = diag.gemm_x6(a.to(hip_device), w3, bias=bias.to(hip_device),
-                       residual=res.to(hip_device) if res is not None else None, epilogue=epi, tile=tile).cpu()
-    base = diag.gemm(a.to(hip_device), w.to(hip_device), bias=bias.to(hip_device),
-                     residual=res.to(hip_device) if res is not None else None, epilogue=epi).cpu()
-    e6 = (got.double() - ref).abs().max().item()
-    e32 = (base.double() - ref).abs().max().item()
-    assert e6 <= max(3.0 * e32, 2e-7 * ref.abs().max().item()), (e6, e32)
+    return a, w, bias, res, ref
+
+
+# k-parts of each gemm_x6 tile (ACC2 tiles count double) and the fp32 MFMA kernel with the same split
+X6_KPARTS = {1: 2, 2: 4, 3: 1, 4: 2, 5: 1, 6: 2, 7: 1, 8: 2, 9: 1}
+F32_TILE_BY_KPARTS = {1: (304, 23), 2: (103, 21), 4: (203, 21)}
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("M,N,K,epi", X6_SHAPES)
+def test_gemm_x6(tile, M, N, K, epi, hip_device):
+    """gemm_x6.hip (the qkv / MLP Linears on the bf16-split path: operands as three bf16 planes, products as six
+    bf16 MFMAs, fp32 accumulation) against fp64 at the sampler's own shapes (M = 768 and 6144 token rows, both
+    GEMM orientations) and on ragged ones, every tile, bias + GELU / residual epilogues, operands with outliers.
+    Bar: its error against fp64 is no larger than that of the fp32 MFMA kernel (an exact fp32 fma chain) with the
+    same number of k-parts: rms <= 1.0 x; max (an extreme-value statistic over up to 9.4 M outputs of two
+    different summation orders: measured spread 0.5 - 1.5 x, scripts/bench_gemm_x6.py) <= 2 x, also against whatever
+    the fp32 dispatch picks for the shape."""
+    from after_amd import _lib, diag
+    a, w, bias, res, ref = _x6_case(M, N, K, epi, M + N + K + tile)
+    dev = hip_device
+    w3, a3 = diag.split_x6(w.to(dev)), diag.split_x6(a.to(dev))
+    assert torch.equal(a3.join(), a), "the bf16 planes must add up to the fp32 operand exactly"
+    kw = dict(bias=bias.to(dev), residual=res.to(dev) if res is not None else None, epilogue=epi)
+    got = diag.gemm_x6(a3, w3, tile=tile, **kw).cpu()
+    t = tile if tile else _lib.lib().after_gemm_x6_pick_tile(M, N, K)
+    same_split = diag.gemm(a.to(dev), w.to(dev), tile=F32_TILE_BY_KPARTS[X6_KPARTS[t]], **kw).cpu()
+    default = diag.gemm(a.to(dev), w.to(dev), **kw).cpu()
+    e6, es, ed = ((x.double() - ref).abs() for x in (got, same_split, default))
+    floor = 1e-7 * ref.abs().max().item()
+    rms = lambda e: e.pow(2).mean().sqrt().item()
+    assert rms(e6) <= max(rms(es), floor), (rms(e6), rms(es))
+    assert e6.max().item() <= max(2.0 * es.max().item(), floor), (e6.max().item(), es.max().item())
+    assert e6.max().item() <= max(2.0 * ed.max().item(), floor), (e6.max().item(), ed.max().item())
+    if epi != 2:  # plane output (the next GEMM's A operand): the same numbers, split exactly
+        got3 = diag.gemm_x6(a3, w3, tile=tile, planes=True, **kw)
+        assert torch.equal(got3.join(), got)
+
+
+def test_gemm_x6_layout_and_determinism(hip_device):
+    from after_amd import _lib, diag
+    from after_amd._lib import AFTERHipError
+    idx = diag.X6Planes(None, 50, 96).index()
+    L = _lib.lib()
+    for (r, p, k) in [(0, 0, 0), (1, 0, 8), (5, 2, 9), (17, 1, 33), (49, 2, 95), (15, 0, 31), (16, 0, 0)]:
+        assert int(idx[r, p, k]) == L.after_gemm_x6_offset(r, p, k, 96)
+    assert idx.unique().numel() == idx.numel() and int(idx.max()) < 64 * 3 * 96
+    a, w, bias, _, _ = _x6_case(768, 1536, 512, 0, 3)
+    a3, w3 = diag.split_x6(a.to(hip_device)), diag.split_x6(w.to(hip_device))
+    outs = [diag.gemm_x6(a3, w3, bias=bias.to(hip_device)).clone() for _ in range(3)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    a96, w96 = diag.split_x6(a[:, :96].contiguous().to(hip_device)), diag.split_x6(w[:, :96].contiguous().to(hip_device))
+    with pytest.raises(AFTERHipError):  # K not a multiple of the tile's k-parts
+        diag.gemm_x6(a96, w96, tile=2)
+    with pytest.raises(AFTERHipError):
+        diag.gemm_x6(a3, w3, tile=77)

@@ -10,7 +10,7 @@ import oracle
 from after_amd import pipeline
 from fixtures import max_abs, rel_l2
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("both_gemm_paths")]
 torch.set_grad_enabled(False)
 
 

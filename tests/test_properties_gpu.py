@@ -5,7 +5,7 @@ import torch
 
 from after_amd import _lib, pipeline
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("both_gemm_paths")]
 torch.set_grad_enabled(False)
 
 

@@ -11,7 +11,7 @@ import oracle
 from after_amd import Streamer, pipeline
 from fixtures import max_abs
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("both_gemm_paths")]
 torch.set_grad_enabled(False)
 
 
