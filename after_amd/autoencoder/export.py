@@ -27,6 +27,14 @@ class ExportedAutoEncoder:
 
     def __init__(self, model: AutoEncoder, stream: bool = False, n_fade: int = 4, max_batch: int = 4,
                  chunk_frames: int = 4, gn_window_samples: int = 131072, gn_window_frames: int = 64):
+        if stream:
+            # The reference builds the streaming graph as SEPARATE twins of the trained codec
+            # (export_autoencoder.py:283-312: new modules under cc.use_cached_conv(True) + load_state_dict), so
+            # the caller's `model` -- the offline export.ts, RectifiedFlow.emb_model, embed_dataset -- stays
+            # stateless.  Streaming state (cached convs, windowed GroupNorm) therefore lives in a private copy.
+            twin = AutoEncoder(**model.cfg_kwargs())
+            twin.load_state_dict(model.state_dict(), strict=False)
+            model = twin.to(next(model.parameters()).device)
         self.model = model
         self.comp_ratio = model.ratio
         self.latent_size = model.z_channels
@@ -80,7 +88,8 @@ class ExportedAutoEncoder:
 
     @torch.no_grad()
     def forward(self, x):
-        """:106-121 / :235-249: the plain decode(encode(x)) (no cross-fade)."""
+        """:106-121 / :235-249: decode(encode(x)) without the cross-fade.  On a streaming export this runs the
+        streaming twin (stateful: cached convs / windowed GroupNorm advance), as export_stream.ts's forward does."""
         return self.model.decode(self.model.encode(x)[0])
 
     __call__ = forward
@@ -91,7 +100,13 @@ def embed_dataset(emb_model, waveforms, batch_size: int = 32):
     """prepare_dataset.py:313-323 / update_dataset.py:52-61: z for every `num_signal`-sample
     chunk, `batch_size` chunks per codec call.  waveforms: [N, L] or [N, 1, L] (any device;
     moved to the codec's device per batch).  Returns [N, Z, L / ratio] on the CPU."""
-    model = emb_model.model if isinstance(emb_model, ExportedAutoEncoder) else emb_model
+    if isinstance(emb_model, ExportedAutoEncoder):
+        if emb_model.stream:
+            raise ValueError("embed_dataset needs the offline codec (export.ts): a streaming export is stateful -- its "
+                             "latents lag by the encoder delay and depend on the history of earlier calls")
+        model = emb_model.model
+    else:
+        model = emb_model
     dev = next(model.parameters()).device
     w = waveforms if waveforms.dim() == 3 else waveforms[:, None, :]
     model.reserve(min(batch_size, w.shape[0]), w.shape[-1])

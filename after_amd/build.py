@@ -76,7 +76,11 @@ def _compile(src, obj, hipcc):
 def build_library(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
-    check_hipcc_version(hipcc)
+    ver = check_hipcc_version(hipcc)
+    # objects of another compiler must not survive an mtime check: the version that built them is recorded
+    stamp = os.path.join(LIBDIR, "hipcc_version.txt")
+    if os.path.exists(stamp) and open(stamp).read().strip() != ver:
+        force = True
     srcs = sources()
     hmt = _deps_mtime()
     objs, todo = [], []
@@ -95,6 +99,9 @@ def build_library(force=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        open(stamp, "w").write(ver + "\n")
+    elif not os.path.exists(stamp):
+        open(stamp, "w").write(ver + "\n")
     return LIB
 
 

@@ -391,6 +391,11 @@ struct after_ae {
     // delay compensation + CachedGroupNorm(stream=True); the PQMF and the decoder stay offline
     bool enc_cached = false;   // mode enabled
     bool pass_stream = false;  // the pass being issued keeps conv state
+    // A pass that keeps host-side stream counters (windowed-GroupNorm ring heads, delay-line flips: advanced at
+    // ENQUEUE time) and fails half way leaves earlier layers advanced and later ones not: `in_pass` stays set and
+    // the next stateful call is refused until after_ae_reset_state.  (For the same reason such passes must not be
+    // captured into a hipGraph: a replay would reuse the baked-in heads.)
+    bool in_pass = false;
     bool pass_cached = false;  // ... and is the cached non-causal encoder
     bool pass_gnwin = false;   // GroupNorm statistics over a sliding window (CachedGroupNorm.stream)
     int dec_gn_frames = 0;     // decoder: CachedGroupNorm window in latent frames (0: plain GroupNorm)
@@ -641,6 +646,11 @@ int run_resblock2(after_ae* h, hipStream_t s, const ResBlockW& rb, const float* 
 }
 
 int begin_pass(after_ae* h, hipStream_t s) {
+    const bool stateful = h->streaming || h->enc_cached || h->dec_gn_frames > 0;
+    AFTER_REQUIRE(!(h->in_pass && stateful), AFTER_E_INVALID,
+                  "autoencoder: an earlier streaming pass failed half way, the stream state is desynchronised: call "
+                  "after_ae_reset_state");
+    h->in_pass = true;
     h->stat_slot = 0;
     h->state_slot = 0;
     h->prepared = nullptr;
@@ -1071,6 +1081,7 @@ int right_pad(int k, int dil) { return k == 1 ? 0 : ((k - 1) * dil + 1) / 2; }  
 extern "C" int after_ae_reset_state(after_ae* h, void* stream) {
     AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
     AFTER_REQUIRE(h->sa.base || h->sn.base || h->sg.base, AFTER_E_INVALID, "autoencoder: streaming was never enabled");
+    h->in_pass = false;
     if (h->sa.base) AFTER_HIP_CHECK(hipMemsetAsync(h->sa.base, 0, h->sa.off, (hipStream_t)stream));
     if (h->sn.base) {
         AFTER_HIP_CHECK(hipMemsetAsync(h->sn.base, 0, h->sn.off, (hipStream_t)stream));
@@ -1319,9 +1330,11 @@ extern "C" int after_ae_encode(after_ae* h, const float* x, float* z, int B, int
         t1 = o;
         T /= d.f;
     }
-    return run_dma(h, s, h->enc_tail.d, cur, nullptr, nullptr, nullptr, h->enc_tail_alpha,
-                   h->enc_tail_invb, ACT_SNAKE, h->enc_tail.bias, nullptr, z, B, T, T, T, false,
-                   nullptr, sb, 0, 1);  // z leaves in the reference's [B][Z][T] layout
+    AFTER_TRY(run_dma(h, s, h->enc_tail.d, cur, nullptr, nullptr, nullptr, h->enc_tail_alpha,
+                      h->enc_tail_invb, ACT_SNAKE, h->enc_tail.bias, nullptr, z, B, T, T, T, false,
+                      nullptr, sb, 0, 1));  // z leaves in the reference's [B][Z][T] layout
+    h->in_pass = false;
+    return AFTER_OK;
 }
 
 // x_multiband of Decoder1d.forward (SimpleNetsStream.py:643-646): y[:, :M] * sigmoid(y[:, M:])
@@ -1386,8 +1399,9 @@ static int decode_impl(after_ae* h, const float* z, float* x, float* mb, int B, 
     AFTER_TRY(run_convblock2(h, s, h->synth1, t1, st1, t2, nullptr, B, T, false, nullptr));
     const int och = c.use_loudness ? 2 * h->M : h->M;
     AFTER_TRY(write_multiband(h, s, t2, mb, B, T, c.use_loudness, och));
-    return pqmf_inverse(h, s, t2, x, B, T, c.use_loudness, och,
-                        h->streaming ? h->pq_istate : nullptr, true);
+    AFTER_TRY(pqmf_inverse(h, s, t2, x, B, T, c.use_loudness, och, h->streaming ? h->pq_istate : nullptr, true));
+    h->in_pass = false;
+    return AFTER_OK;
 }
 
 extern "C" int after_ae_decode(after_ae* h, const float* z, float* x, int B, int T, void* stream) {

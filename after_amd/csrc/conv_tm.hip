@@ -375,8 +375,10 @@ __global__ __launch_bounds__(128 * KS * RS) void conv_tm_kernel(ConvTmArgs g, in
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // statistics scratch behind the ring: zeroed here, long before the epilogue (the main loop's
     // barriers order it); inside the ring (gs_in_ring) it is zeroed after the last ring read
-    float* gs = smem + g.gs_off;  // [2][16] per-group partial sums of this tile
-    if (g.stats && !g.gs_in_ring && tid < 32) gs[tid] = 0.f;
+    // [2][NW][NT][SL] partial sums (SL = 4 channel quads of a 16-column block, or its 16 columns when a quad may
+    // straddle two groups): every (wave, column block) owns its slots, tid < 16 adds them per group in a fixed
+    // order -- no LDS atomics, so the tile's statistics do not depend on the order the waves finish in
+    float* gs = smem + g.gs_off;
 
     unsigned long long ph_fence = 0, ph_vm = 0, ph_bar = 0;  // cycle-stamp sinks of the pipeline macros
     (void)ph_fence;
@@ -432,7 +434,6 @@ __global__ __launch_bounds__(128 * KS * RS) void conv_tm_kernel(ConvTmArgs g, in
             for (int j = 0; j < NT; ++j)
                 *reinterpret_cast<f32x4*>(red + ((wid * MT * NT + i * NT + j) * 64 + lane) * 4) = acc[i][j];
     }
-    if (g.stats && g.gs_in_ring && tid < 32) gs[tid] = 0.f;
     if (KS > 1 || (g.stats && g.gs_in_ring)) __syncthreads();
 
     // accumulator layout (W fragment as srcA): lane l holds C[row = l & 15][col = 4 (l >> 4) + r]
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(128 * KS * RS) void conv_tm_kernel(ConvTmArgs g, in
                     if (g.y2_pb) pb2[r] = g.y2_pb[gn + r];
                 }
             }
-        float ssum = 0.f, qsum = 0.f;
+        f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, qsum = {0.f, 0.f, 0.f, 0.f};  // per column of the lane's quad
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             if ((i * NT + j) % KS != kh) continue;
@@ -531,14 +532,8 @@ __global__ __launch_bounds__(128 * KS * RS) void conv_tm_kernel(ConvTmArgs g, in
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (gn + r < N) {
-                        if (quad) {
-                            ssum += o[r];
-                            qsum += o[r] * o[r];
-                        } else {  // narrow test configurations: one LDS atomic per element
-                            const int gl = (gn + r) / Cg - g0;
-                            atomicAdd(&gs[gl & 15], o[r]);
-                            atomicAdd(&gs[16 + (gl & 15)], o[r] * o[r]);
-                        }
+                        ssum[r] += o[r];
+                        qsum[r] += o[r] * o[r];
                     }
             }
             // the next conv's activated, haloed input
@@ -574,17 +569,35 @@ __global__ __launch_bounds__(128 * KS * RS) void conv_tm_kernel(ConvTmArgs g, in
                 }
             }
         }
-        if (g.stats && quad) {
-            // the 16 lanes l & 15 of a quad share the channel quad: butterfly over the rows
+        if (g.stats) {
+            constexpr int NWV = 2 * KS * RS;
+            if (quad) {  // Cg % 4 == 0: the lane's four columns sit in one group (every shipped width)
+                float s1 = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]), q1 = (qsum[0] + qsum[1]) + (qsum[2] + qsum[3]);
+                // the 16 lanes l & 15 of a quad share the channel quad: butterfly over the rows
 #pragma unroll
-            for (int o2 = 1; o2 < 16; o2 <<= 1) {
-                ssum += __shfl_xor(ssum, o2, 64);
-                qsum += __shfl_xor(qsum, o2, 64);
-            }
-            if (crow == 0 && gn < N) {
-                const int gl = gn / Cg - g0;  // Cg % 4 == 0: the quad sits in one group
-                atomicAdd(&gs[gl & 15], ssum);
-                atomicAdd(&gs[16 + (gl & 15)], qsum);
+                for (int o2 = 1; o2 < 16; o2 <<= 1) {
+                    s1 += __shfl_xor(s1, o2, 64);
+                    q1 += __shfl_xor(q1, o2, 64);
+                }
+                if (crow == 0) {
+                    gs[((0 * NWV + wid) * NT + j) * 4 + (lane >> 4)] = s1;
+                    gs[((1 * NWV + wid) * NT + j) * 4 + (lane >> 4)] = q1;
+                }
+            } else {  // narrow test configurations: one slot per column
+#pragma unroll
+                for (int o2 = 1; o2 < 16; o2 <<= 1)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ssum[r] += __shfl_xor(ssum[r], o2, 64);
+                        qsum[r] += __shfl_xor(qsum[r], o2, 64);
+                    }
+                if (crow == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        gs[((0 * NWV + wid) * NT + j) * 16 + ccol0 + r] = ssum[r];
+                        gs[((1 * NWV + wid) * NT + j) * 16 + ccol0 + r] = qsum[r];
+                    }
+                }
             }
         }
     }
@@ -610,9 +623,28 @@ __global__ __launch_bounds__(128 * KS * RS) void conv_tm_kernel(ConvTmArgs g, in
             const int grp = g0 + tid;
             const int glast = (min(n0 + BN, N) - 1) / Cg;
             if (grp <= glast) {
+                // this group's slots in (wave, column block, slot) order: a fixed summation order.  (Across
+                // workgroups the fp64 atomics below are exact, hence order-independent, unless the partial sums of
+                // one (clip, group) span more than ~2^19 in magnitude; they then differ by <= 1 ulp of fp64.)
+                constexpr int NWV = 2 * KS * RS;
+                const int SL = quad ? 4 : 16, cstep = quad ? 4 : 1;
+                const float inv_cg = 1.0f / (float)Cg;
+                float s1 = 0.f, q1 = 0.f;
+                for (int w = 0; w < NWV; ++w) {
+                    const int cbase = n0 + (w / (KS * RS)) * 16 * NB;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        for (int sl = 0; sl < SL; ++sl) {
+                            const int c = cbase + j * 16 + sl * cstep;
+                            if (c < N && __float2int_rd(((float)c + 0.5f) * inv_cg) == grp) {
+                                s1 += gs[((0 * NWV + w) * NT + j) * SL + sl];
+                                q1 += gs[((1 * NWV + w) * NT + j) * SL + sl];
+                            }
+                        }
+                }
                 double* sp = g.stats + (size_t)(blockIdx.x % kStatSub) * g.sub_stride + ((size_t)b * g.G + grp) * 2;
-                atomicAdd(sp, (double)gs[tid]);
-                atomicAdd(sp + 1, (double)gs[16 + tid]);
+                atomicAdd(sp, (double)s1);
+                atomicAdd(sp + 1, (double)q1);
             }
         }
     }
@@ -638,26 +670,26 @@ __global__ void repack_tm_kernel(const float* __restrict__ w, float* __restrict_
 __global__ __launch_bounds__(256) void stats_accum_tm_kernel(const float* __restrict__ x, int ld,
                                                              double* __restrict__ stats, int C, int T,
                                                              int G, int rows_per_block) {
-    __shared__ float sh[2][16];
+    // per-thread partial sums land in their own LDS slots and thread g < G adds group g's slots in a fixed order
+    // (no LDS atomics: the block's contribution does not depend on thread scheduling)
+    extern __shared__ __attribute__((aligned(16))) float sh[];  // [2][max(256, C)]
     const int b = blockIdx.y;
     const int Cg = C / G;
-    if (threadIdx.x < 32) (&sh[0][0])[threadIdx.x] = 0.f;
-    __syncthreads();
     const int lo = blockIdx.x * rows_per_block, hi = min(lo + rows_per_block, T);
-    if (C <= 128) {  // several rows per pass
+    const int W = C <= 128 ? 256 : C;
+    if (C <= 128) {  // several rows per pass: slot = thread
         const int R = 256 / C;
         const int r = threadIdx.x / C, c = threadIdx.x - r * C;
         float s = 0.f, q = 0.f;
-        if (r < R) {
+        if (r < R)
             for (int t = lo + r; t < hi; t += R) {
                 const float v = x[((size_t)b * T + t) * ld + c];
                 s += v;
                 q += v * v;
             }
-            atomicAdd(&sh[0][c / Cg], s);
-            atomicAdd(&sh[1][c / Cg], q);
-        }
-    } else {
+        sh[threadIdx.x] = s;
+        sh[W + threadIdx.x] = q;
+    } else {  // slot = channel
         for (int c = threadIdx.x; c < C; c += 256) {
             float s = 0.f, q = 0.f;
             for (int t = lo; t < hi; ++t) {
@@ -665,15 +697,30 @@ __global__ __launch_bounds__(256) void stats_accum_tm_kernel(const float* __rest
                 s += v;
                 q += v * v;
             }
-            atomicAdd(&sh[0][c / Cg], s);
-            atomicAdd(&sh[1][c / Cg], q);
+            sh[c] = s;
+            sh[W + c] = q;
         }
     }
     __syncthreads();
     if (threadIdx.x < G) {
+        float s = 0.f, q = 0.f;
+        const int c0 = threadIdx.x * Cg;
+        if (C <= 128) {
+            const int R = 256 / C;
+            for (int r = 0; r < R; ++r)
+                for (int c = c0; c < c0 + Cg; ++c) {
+                    s += sh[r * C + c];
+                    q += sh[W + r * C + c];
+                }
+        } else {
+            for (int c = c0; c < c0 + Cg; ++c) {
+                s += sh[c];
+                q += sh[W + c];
+            }
+        }
         double* sp = stats + ((size_t)b * G + threadIdx.x) * 2;
-        atomicAdd(sp, (double)sh[0][threadIdx.x]);
-        atomicAdd(sp + 1, (double)sh[1][threadIdx.x]);
+        atomicAdd(sp, (double)s);
+        atomicAdd(sp + 1, (double)q);
     }
 }
 
@@ -732,17 +779,19 @@ int launch_tm_cfg(ConvTmArgs a, int B, bool dil, hipStream_t s) {
     const int tiles_m = cdiv(a.Nn, BM), tiles_n = cdiv(a.Cout, BN);
     const size_t ring = size_t(NS) * KS * (BM + BN) * 32 * sizeof(float);
     const size_t red = KS > 1 ? size_t(2 * KS * RS) * (MB / RS) * NB * 256 * sizeof(float) : 0;
-    // the statistics scratch (32 floats) lives behind the reduction slabs inside the ring when it
-    // fits: 128 extra bytes would cost the 80-KiB split-K-4 ring its second workgroup per CU
+    // the statistics scratch ([2][waves][NB][4 or 16] floats, conv_tm_kernel) lives behind the reduction slabs
+    // inside the ring when it fits: extra bytes would cost the 80-KiB split-K-4 ring its second workgroup per CU
+    const bool quad = !a.stats || ((a.Cout / a.G) & 3) == 0;
+    const size_t gsb = a.stats ? (size_t)2 * (2 * KS * RS) * NB * (quad ? 4 : 16) * sizeof(float) : 0;
     size_t lds = ring > red ? ring : red;
     if (KS > 1) {  // the split-K epilogue synchronises anyway; rings of 80 / 120 KiB must not grow
         a.gs_off = (int)(red / sizeof(float));
         a.gs_in_ring = 1;
-        if (red + 128 > lds) lds = red + 128;
+        if (red + gsb > lds) lds = red + gsb;
     } else {
         a.gs_off = (int)(lds / sizeof(float));
         a.gs_in_ring = 0;
-        lds += 128;
+        lds += gsb;
     }
     static_assert(size_t(NS) * KS * (BM + BN) * 32 * sizeof(float) <= 160 * 1024, "ring exceeds the LDS");
     const int nwg = tiles_m * tiles_n, ny = B * a.phases;
@@ -881,7 +930,7 @@ int launch_stats_accum_tm(const float* x, double* stats, int B, int C, int T, in
     AFTER_REQUIRE(G >= 1 && G <= 16 && C % G == 0, AFTER_E_INVALID, "stats_accum_tm: G <= 16, G | C");
     int rpb = C <= 128 ? 64 : 16;
     while ((long long)cdiv(T, rpb) * B > 1024) rpb *= 2;
-    hipLaunchKernelGGL(stats_accum_tm_kernel, dim3(cdiv(T, rpb), B), dim3(256), 0, s, x, ld > 0 ? ld : C, stats, C,
+    hipLaunchKernelGGL(stats_accum_tm_kernel, dim3(cdiv(T, rpb), B), dim3(256), 2 * (size_t)(C <= 128 ? 256 : C) * sizeof(float), s, x, ld > 0 ? ld : C, stats, C,
                        T, G, rpb);
     AFTER_HIP_CHECK(hipGetLastError());
     return AFTER_OK;

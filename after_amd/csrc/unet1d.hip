@@ -676,6 +676,13 @@ int cfg_prepare(after_unet1d* h, hipStream_t s, const float* cond, const float* 
                   B, h->max_batch);
     AFTER_REQUIRE((h->cfg.out_size > 0 ? h->cfg.out_size : h->cfg.in_size) == h->cfg.in_size, AFTER_E_INVALID,
                   "unet1d: the sampler needs out_size == in_size");
+    // before anything is launched: cfg3_cond_kernel / cfg3_x_kernel write workspaces sized for max_T
+    AFTER_REQUIRE(T > 0 && T <= h->max_T, AFTER_E_CAPACITY, "unet1d: T=%d exceeds max_T=%d", T, h->max_T);
+    {
+        int total_ratio = 1;
+        for (int i = 0; i < h->n; ++i) total_ratio *= h->cfg.ratios[i];
+        AFTER_REQUIRE(T % total_ratio == 0, AFTER_E_INVALID, "unet1d: T=%d not a multiple of %d", T, total_ratio);
+    }
     const size_t tc_per = (size_t)h->cfg.time_cond_in_channels * T;
     const size_t n = 3 * (size_t)B * (tc_per > (size_t)h->cfg.cond_channels ? tc_per : h->cfg.cond_channels);
     hipLaunchKernelGGL(cfg3_cond_kernel, dim3((unsigned)cdivll((long long)n, 256)), dim3(256), 0, s, cond, tc,

@@ -24,7 +24,8 @@ class Fixture:
 
     def state_dict(self, shapes_key="shapes", seed_offset=0, dtype=torch.float32):
         shapes = self.meta[shapes_key]
-        sd = detweights.fill(shapes, self.meta["seed"] + seed_offset, keep=self.keep)
+        sd = detweights.fill(shapes, self.meta["seed"] + seed_offset, keep=self.keep,
+                             wg_scale=self.meta.get("wg_scale", 1.0))
         return {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
 
 
@@ -34,3 +35,24 @@ def max_abs(a, b):
 
 def rel_l2(a, b):
     return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+def scale_gains(sd, s=0.5):
+    """state dict with every weight-norm gain (`weight_g`) multiplied by s: keeps the activations of a
+    GroupNorm-free random-weight codec O(1) through its ~80 layers (with gains ~ 1 they grow to ~3e3 and
+    any comparison is limited by the fixture's conditioning, not by the code under test)."""
+    return {k: (v * s if k.endswith("weight_g") else v) for k, v in sd.items()}
+
+
+def to_f64(sd):
+    return {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+
+
+def within_fp64_rule(got, oracle32, oracle64, factor=3.0, floor=2e-6):
+    """|got - fp64| <= factor x |oracle_fp32 - fp64| (max-abs), with a floor relative to the output range
+    for cases where the fp32 oracle happens to be exact: the bar for ill-conditioned fixtures, expressed by
+    the reference arithmetic's own rounding error instead of a hand-picked tolerance."""
+    rng = oracle64.abs().max().item()
+    e_got = (got.double() - oracle64).abs().max().item()
+    e_ref = (oracle32.double() - oracle64).abs().max().item()
+    return e_got <= max(factor * e_ref, floor * rng), (e_got, e_ref, rng)

@@ -29,11 +29,11 @@ torch.set_grad_enabled(False)
 R = refimport.modules()
 
 
-def refill(module, seed):
+def refill(module, seed, wg_scale=1.0):
     """Overwrite the reference module's parameters/buffers with detweights values."""
     sd = module.state_dict()
     shapes = {k: tuple(v.shape) for k, v in sd.items()}
-    new = detweights.fill(shapes, seed)
+    new = detweights.fill(shapes, seed, wg_scale=wg_scale)
     sd.update(new)
     module.load_state_dict(sd)
     module.eval()
@@ -170,10 +170,14 @@ def stream_case(case, cfg_name, seed, n_chunks=10, chunk=4, steps=3):
 
 
 # ---------------------------------------------------------------- autoencoder
-def ae_case(case, cfg_name, B, L, seed):
+def ae_case(case, cfg_name, B, L, seed, wg_scale=1.0):
+    """wg_scale < 1 (the *_wc cases): weight-norm gains scaled so that the activations of the GroupNorm-free
+    causal codec stay O(1) through its ~80 layers -- a well-conditioned fixture whose bar is the codec's, not
+    the fixture's (with gains ~ 1 the norm-free stack amplifies to |y| ~ 3e3 and the reference's own
+    fp32-vs-fp64 error is 2e-3 of the range)."""
     cfg = configs.autoencoder_config(cfg_name)
     ae = build_ae(cfg)
-    shapes, keep = refill(ae, seed)
+    shapes, keep = refill(ae, seed, wg_scale)
     x = detweights.seeded_tensor("audio", (B, 1, L), seed, 0.1)
     z, _ = ae.encode(x)
     zin = detweights.seeded_tensor("z", tuple(z.shape), seed)
@@ -181,6 +185,8 @@ def ae_case(case, cfg_name, B, L, seed):
     mb = ae.pqmf(x)
     xr = ae.pqmf.inverse(mb)
     meta = dict(kind="autoencoder", config=cfg_name, seed=seed, B=B, L=L, shapes=shapes)
+    if wg_scale != 1.0:
+        meta["wg_scale"] = wg_scale
     save(case, meta, x=x, z=z, zin=zin, y=y, multiband=mb, pqmf_roundtrip=xr, **keepdict(keep))
 
 
@@ -433,6 +439,8 @@ CASES = {
     "ae_micro": lambda: ae_case("ae_micro", "microAE", 2, 16384, 41),
     "ae_micro_causal": lambda: ae_case("ae_micro_causal", "microAE_causal", 1, 8192, 42),
     "ae_base": lambda: ae_case("ae_base", "baseAE", 1, 32768, 43),
+    "ae_micro_causal_wc": lambda: ae_case("ae_micro_causal_wc", "microAE_causal", 2, 8192, 44, wg_scale=0.5),
+    "ae_base_causal_wc": lambda: ae_case("ae_base_causal_wc", "baseAE_causal", 1, 16384, 45, wg_scale=0.5),
     "encoders_micro": lambda: encoders_case("encoders_micro", "micro", 2, 64, 51),
     "encoders_tiny": lambda: encoders_case("encoders_tiny", "tiny", 1, 256, 52),
     "encoders_base": lambda: encoders_case("encoders_base", "base", 1, 256, 53),

@@ -11,7 +11,8 @@ on the GPU box's host cores, each case a few seconds):
              (export.py:398-416) against oracle.stream_forward
 
 Tolerances are the ones DESIGN.md states: N-step latents <= 1e-4 abs (sigma ~ 1.4; 2e-4 where
-guidance amplifies, 5e-4 for the 100-step cached sampler), codec <= 1e-4 x max|oracle|."""
+guidance amplifies, 5e-4 for the 100-step cached sampler), codec <= 1e-4 x max|oracle| (2e-4 for the norm-free
+causal codec of config 5, on weights conditioned by fixtures.scale_gains)."""
 import os
 
 import pytest
@@ -19,7 +20,7 @@ import torch
 
 import oracle
 from after_amd import Streamer, _lib, pipeline
-from fixtures import max_abs, rel_l2
+from fixtures import max_abs, rel_l2, scale_gains
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("both_gemm_paths")]
 torch.set_grad_enabled(False)
@@ -117,6 +118,9 @@ def test_base_streamer_8_streams_100_steps_vs_oracle(hip_device):
     8 independent streams, 100-step cached sampler, 8 chunks of 4 frames."""
     model, dcfg, acfg = pipeline.build_models("cycle", "baseAE_causal", hip_device, seed=7)
     ae = model.emb_model
+    # weight-norm gains x 0.5: the GroupNorm-free codec stays O(1) through its ~80 layers, so the audio bar below is
+    # the codec's (2e-4 x max, as every other codec test), not the conditioning of a random-weight fixture
+    ae.load_state_dict(scale_gains(ae.state_dict()))
     sd = cpu_sd(model)
     pick = lambda pre: {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
     sd_net, sd_enc, sd_et = pick("net."), pick("encoder."), pick("encoder_time.")
@@ -146,11 +150,8 @@ def test_base_streamer_8_streams_100_steps_vs_oracle(hip_device):
     z = torch.cat(lats, -1)
     y = torch.cat(outs, -1)
     assert z.shape == want_z.shape and y.shape == want_audio.shape
-    # the structure conditioning goes through the norm-free causal codec (ill-conditioned with
-    # random weights, see test_autoencoder_gpu.py): compare the sampler given the oracle's
-    # conditioning scale, and the audio relative to its range
     assert max_abs(z, want_z) < 5e-4 * max(1.0, want_z.abs().max().item()), (max_abs(z, want_z), rel_l2(z, want_z))
-    assert max_abs(y, want_audio) < 2e-3 * want_audio.abs().max().item(), rel_l2(y, want_audio)
+    assert max_abs(y, want_audio) < 2e-4 * want_audio.abs().max().item(), (max_abs(y, want_audio), rel_l2(y, want_audio))
 
 
 def test_config1_audio_to_audio_vs_oracle(hip_device):

@@ -3,13 +3,13 @@ whole-stream restatement (oracle/streaming.py).  -m gpu.
 
 Random-init micro models (torch default init: well conditioned, unlike the crc-seeded causal
 fixture); tolerances: latents 5e-4 abs on O(1) values after nb_steps cached Euler steps, audio
-1e-3 of the output range through the ~80-layer norm-free codec."""
+2e-4 of the output range through the ~80-layer norm-free codec (weight-norm gains x 0.5: fixtures.scale_gains)."""
 import pytest
 import torch
 
 import oracle
 from after_amd import Streamer, pipeline
-from fixtures import max_abs
+from fixtures import max_abs, scale_gains
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("both_gemm_paths")]
 torch.set_grad_enabled(False)
@@ -25,6 +25,7 @@ def split_sd(model):
 def test_streamer_matches_whole_stream_oracle(n, share, hip_device):
     model, dcfg, acfg = pipeline.build_models("micro", "microAE_causal", hip_device, seed=3)
     ae = model.emb_model
+    ae.load_state_dict(scale_gains(ae.state_dict()))  # well-conditioned norm-free codec: the bar below is the code's
     sd_net, sd_enc, sd_et = split_sd(model)
     sd_ae = {k: v.detach().cpu() for k, v in ae.state_dict().items()}
     chunk, steps, n_chunks, nsig = 4, 3, 5, 16
@@ -55,7 +56,7 @@ def test_streamer_matches_whole_stream_oracle(n, share, hip_device):
         y = torch.cat(outs, -1)
         assert z.shape == want_z.shape and y.shape == want_audio.shape
         assert max_abs(z, want_z) < 5e-4, (rep, max_abs(z, want_z))
-        assert max_abs(y, want_audio) < 1e-3 * want_audio.abs().max().item(), rep
+        assert max_abs(y, want_audio) < 2e-4 * want_audio.abs().max().item(), (rep, max_abs(y, want_audio))
         st.reset()
 
 

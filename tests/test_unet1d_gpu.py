@@ -106,3 +106,29 @@ def test_unet_model_forward_cfg_modes(mode, hip_device):
     got = model.model_forward(x.to(hip_device), t.reshape(B, 1, 1).to(hip_device), cond.to(hip_device),
                               tc.to(hip_device), gt, gs).cpu()
     assert max_abs(got, want) < 5e-4 * max(1.0, want.abs().max().item())
+
+
+def test_unet_sampler_rejects_oversize_T_before_launching(hip_device):
+    """A direct C-ABI caller with T beyond the handle's max_T (or off the down-sampling grid) gets the capacity /
+    argument error BEFORE the CFG assembly kernels write the max_T-sized workspaces (after_unet1d_sample /
+    after_unet1d_model_forward validate T first)."""
+    import ctypes
+    fx = Fixture("unet_micro")
+    net = build("unet_micro", fx.state_dict(), hip_device)
+    h = net._ensure(3, 16)  # handle provisioned for 3 network rows x 16 frames
+    B, T = 1, 64
+    x = torch.zeros(B, 16, T, device=hip_device)
+    tc = torch.zeros(B, 12, T, device=hip_device)
+    cond = torch.zeros(B, 6, device=hip_device)
+    t = torch.zeros(B, device=hip_device)
+    out = torch.empty_like(x)
+    L = _lib.lib()
+    rc = L.after_unet1d_sample(h, _lib.ptr(x), _lib.ptr(cond), _lib.ptr(tc), _lib.ptr(out), B, T, 2,
+                               ctypes.c_float(2.0), ctypes.c_float(1.0), ctypes.c_float(-4.0), 0,
+                               _lib.current_stream(hip_device))
+    assert rc == -3, (rc, L.after_last_error())  # AFTER_E_CAPACITY
+    rc = L.after_unet1d_model_forward(h, _lib.ptr(x), _lib.ptr(t), _lib.ptr(cond), _lib.ptr(tc), _lib.ptr(out), B, T,
+                                      ctypes.c_float(2.0), ctypes.c_float(1.0), ctypes.c_float(-4.0), 0,
+                                      _lib.current_stream(hip_device))
+    assert rc == -3, (rc, L.after_last_error())  # AFTER_E_CAPACITY
+    torch.cuda.synchronize()
