@@ -24,7 +24,8 @@ class AECfg(ctypes.Structure):
                                      "n_dilations", "kernel_size", "use_norm", "use_loudness",
                                      "causal")] + [("multipliers", c_int * 9),
                                                    ("dec_multipliers", c_int * 9),
-                                                   ("factors", c_int * 8), ("dilations", c_int * 8)]
+                                                   ("factors", c_int * 8), ("dilations", c_int * 8),
+                                                   ("encoder_out_channels", c_int)]
 
 
 class Encoder1dCfg(ctypes.Structure):
@@ -88,6 +89,8 @@ SIGNATURES = {
     "after_ae_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "after_ae_decode_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "after_latent_reg": (c_int, [c_void_p, ctypes.c_longlong, ctypes.c_float, c_void_p, c_void_p]),
+    "after_bottleneck_tanh": (c_int, [c_void_p, c_longlong, c_float, c_void_p]),
+    "after_bottleneck_vae": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "after_ae_pqmf_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "after_ae_pqmf_inverse": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "after_ae_enable_streaming": (c_int, [c_void_p, c_int]),

@@ -140,18 +140,36 @@ class ReluBottleneck(nn.Module):
         self.sigma = float(sigma)
 
 
+class TanhBottleneck(nn.Module):
+    """SimpleNetsStream.py:719-740: z = scale * tanh(z) (+ sigma * randn: `AutoEncoder.encode` calls the
+    bottleneck with its default apply_noise=True; sigma defaults to 0), regulariser tensor(0.)."""
+
+    def __init__(self, scale: float = 3, sigma: float = 0.):
+        super().__init__()
+        self.scale = float(scale)
+        self.sigma = float(sigma)
+
+
+class VAEBottleneck(nn.Module):
+    """SimpleNetsStream.py:763-785: the encoder emits 2 x z_channels (mean | scale, :864-867);
+    z = randn * (softplus(scale) + 1e-2) + mean, regulariser = the KL term; `encode(return_mean=True)` also
+    returns the mean."""
+
+
 def _resolve_bottleneck(b):
-    """The bottleneck shapes what `encode` returns, and it has no parameters -- a checkpoint of a
-    codec trained with another one loads cleanly -- so anything but ReluBottleneck (the binding of
-    baseAE.gin:41-43,58) is refused instead of silently returning un-squashed latents."""
+    """The bottleneck shapes what `encode` returns, and it has no parameters -- a checkpoint cannot reveal which one
+    a codec was trained with -- so the binding (baseAE.gin:41-43,48) must be named: None / "relu" ->
+    ReluBottleneck, "tanh" -> TanhBottleneck, "vae" -> VAEBottleneck, or an instance."""
     if b is None or (isinstance(b, str) and b.lower() in ("relu", "relubottleneck")):
         return ReluBottleneck()
-    if isinstance(b, ReluBottleneck):
+    if isinstance(b, str) and b.lower() in ("tanh", "tanhbottleneck"):
+        return TanhBottleneck()
+    if isinstance(b, str) and b.lower() in ("vae", "vaebottleneck"):
+        return VAEBottleneck()
+    if isinstance(b, (ReluBottleneck, TanhBottleneck, VAEBottleneck)):
         return b
     name = b if isinstance(b, str) else type(b).__name__
-    raise NotImplementedError(
-        f"bottleneck {name!r}: after_amd builds ReluBottleneck only (TanhBottleneck would squash z "
-        "to scale*tanh(z), VAEBottleneck doubles the encoder's output channels)")
+    raise NotImplementedError(f"bottleneck {name!r}: SimpleNetsStream.py defines Relu / Tanh / VAE bottlenecks")
 
 
 def _check_activation(a):
@@ -203,8 +221,10 @@ class AutoEncoder(nn.Module):
         nd = len(dilations)
         self.dec_multipliers = [int(m * decoder_ratio) for m in list(multipliers)[::-1]]
         self.pqmf = _PQMF(100, pqmf_bands)
+        # SimpleNetsStream.py:864-867: a VAE codec's encoder emits mean and scale
+        self.encoder_out_channels = 2 * z_channels if isinstance(self.bottleneck, VAEBottleneck) else z_channels
         self.encoder = _Encoder(in_channels, channels, list(multipliers), list(factors), nd,
-                                kernel_size, z_channels, use_norm)
+                                kernel_size, self.encoder_out_channels, use_norm)
         self.decoder = _Decoder(in_channels, channels, self.dec_multipliers, list(factors)[::-1], nd,
                                 kernel_size, z_channels, use_norm, use_loudness)
         self.requires_grad_(False)
@@ -296,6 +316,7 @@ class AutoEncoder(nn.Module):
         cfg.pqmf_bands = c["pqmf_bands"]
         cfg.channels = c["channels"]
         cfg.z_channels = c["z_channels"]
+        cfg.encoder_out_channels = self.encoder_out_channels
         cfg.n_stages = len(c["factors"])
         cfg.n_dilations = len(c["dilations"])
         cfg.kernel_size = c["kernel_size"]
@@ -383,8 +404,9 @@ class AutoEncoder(nn.Module):
     @torch.no_grad()
     def encode(self, x, with_multi: bool = False, return_mean: bool = False):
         """SimpleNetsStream.py:918-941 -> (z, regloss); export: z only."""
-        if return_mean:  # :932-934 is the VAEBottleneck protocol
-            raise NotImplementedError("return_mean=True needs a VAEBottleneck (not built)")
+        vae = isinstance(self.bottleneck, VAEBottleneck)
+        if return_mean and not vae:  # :932-934 is the VAEBottleneck protocol
+            raise TypeError("return_mean=True needs a VAEBottleneck (the other bottlenecks take no such argument)")
         x = _lib.require_gpu_tensor(x, "x")
         if x.dim() != 3 or x.shape[1] != 1:
             raise ValueError(f"encode expects [B, 1, L], got {tuple(x.shape)}")
@@ -392,15 +414,32 @@ class AutoEncoder(nn.Module):
         if L % self.ratio:
             raise ValueError(f"length {L} is not a multiple of the codec ratio {self.ratio}")
         h = self._ensure(B, L)
-        z = torch.empty(B, self.z_channels, L // self.ratio, device=x.device, dtype=torch.float32)
+        T = L // self.ratio
+        z = torch.empty(B, self.encoder_out_channels, T, device=x.device, dtype=torch.float32)
+        L_ = _lib.lib()
+        mean = None
         with torch.cuda.device(x.device):
-            _lib.check(_lib.lib().after_ae_encode(h, _lib.ptr(x), _lib.ptr(z), B, L,
-                                                  _lib.current_stream(x.device)), "after_ae_encode")
-            # ReluBottleneck: z unchanged, reg = mean(ELU(|z| - scale)) + 1 (:753-760)
-            reg = torch.empty((), device=x.device, dtype=torch.float32)
-            _lib.check(_lib.lib().after_latent_reg(_lib.ptr(z), z.numel(), self.bottleneck.scale,
-                                                   _lib.ptr(reg), _lib.current_stream(x.device)),
-                       "after_latent_reg")
+            st = _lib.current_stream(x.device)
+            _lib.check(L_.after_ae_encode(h, _lib.ptr(x), _lib.ptr(z), B, L, st), "after_ae_encode")
+            reg = torch.zeros((), device=x.device, dtype=torch.float32)
+            if isinstance(self.bottleneck, ReluBottleneck):
+                # z unchanged, reg = mean(ELU(|z| - scale)) + 1 (:753-760)
+                _lib.check(L_.after_latent_reg(_lib.ptr(z), z.numel(), self.bottleneck.scale, _lib.ptr(reg), st),
+                           "after_latent_reg")
+            elif isinstance(self.bottleneck, TanhBottleneck):
+                _lib.check(L_.after_bottleneck_tanh(_lib.ptr(z), z.numel(), self.bottleneck.scale, st),
+                           "after_bottleneck_tanh")
+                if self.bottleneck.sigma > 0:  # :733-735 (apply_noise defaults to True)
+                    z.add_(self.bottleneck.sigma * torch.randn_like(z))
+            else:  # VAE: z = randn * std + mean, reg = KL (:770-785)
+                zraw, Z = z, self.z_channels
+                z = torch.empty(B, Z, T, device=x.device, dtype=torch.float32)
+                mean = torch.empty_like(z)
+                noise = torch.randn(B, Z, T, device=x.device, dtype=torch.float32)
+                _lib.check(L_.after_bottleneck_vae(_lib.ptr(zraw), _lib.ptr(noise), _lib.ptr(z), _lib.ptr(mean),
+                                                   _lib.ptr(reg), B, Z, T, st), "after_bottleneck_vae")
+        if return_mean:
+            return z, reg, mean
         if with_multi:
             return z, self.pqmf_forward(x), reg
         return z, reg

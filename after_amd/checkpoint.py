@@ -17,7 +17,7 @@ from typing import Optional
 
 import torch
 
-from .autoencoder.model import AutoEncoder, ReluBottleneck
+from .autoencoder.model import AutoEncoder, ReluBottleneck, TanhBottleneck, VAEBottleneck
 from .diffusion.model import RectifiedFlow
 from .diffusion.networks.ecapa_encoder import ECAPATDNN
 from .diffusion.networks.encoder import Encoder1D
@@ -117,11 +117,15 @@ def autoencoder_from_config(cfg: GinConfig, device="cuda:0") -> AutoEncoder:
         name = b.selector.split(".")[-1]
         if name == "ReluBottleneck":
             b = ReluBottleneck(**cfg.kwargs(b.selector, b.scope))
+        elif name == "TanhBottleneck":
+            b = TanhBottleneck(**cfg.kwargs(b.selector, b.scope))
+        elif name == "VAEBottleneck":
+            b = VAEBottleneck()
         elif name == "Identity":
             raise NotImplementedError("bottleneck = nn.Identity is not callable as a bottleneck in the "
                                       "reference either (encode unpacks `z, regloss`)")
         else:
-            b = name  # TanhBottleneck / VAEBottleneck -> refused by AutoEncoder with the reason
+            b = name  # anything else -> refused by AutoEncoder with the reason
     a = kw.pop("activation", None)
     if isinstance(a, Ref):
         a = a.selector

@@ -785,7 +785,7 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
             const int cn = C0 * cfg->multipliers[i + 1];
             wf += nd * (cbsz(c, c, k) + cbsz(c, c, 1)) + cbsz(c, cn, 2 * cfg->factors[i]);
         }
-        wf += cbsz(C0 * cfg->multipliers[n], cfg->z_channels, 3);
+        wf += cbsz(C0 * cfg->multipliers[n], cfg->encoder_out_channels > 0 ? cfg->encoder_out_channels : cfg->z_channels, 3);
         c = C0 * cfg->dec_multipliers[0];
         wf += cbsz(cfg->z_channels, c, k);
         for (int i = 0; i < n; ++i) {
@@ -848,9 +848,10 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
         const int c = C0 * cfg->multipliers[n];
         AE_TRY(load_snake(h, cur, &h->enc_tail_alpha, &h->enc_tail_invb, c));
         h->enc_tail.cin = c;
-        h->enc_tail.cout = cfg->z_channels;
+        const int zo = cfg->encoder_out_channels > 0 ? cfg->encoder_out_channels : cfg->z_channels;  // VAE: 2 Z
+        h->enc_tail.cout = zo;
         h->enc_tail.k = 3;
-        AE_TRY(load_wnconv(h, cur, &h->enc_tail.w, &h->enc_tail.bias, cfg->z_channels, c, 3));
+        AE_TRY(load_wnconv(h, cur, &h->enc_tail.w, &h->enc_tail.bias, zo, c, 3));
     }
     // decoder (SimpleNetsStream.py:552-651)
     h->dec_head.cin = cfg->z_channels;
@@ -1001,7 +1002,7 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
             if (i < n) T /= cfg->factors[i];
         }
         T = h->max_samples / h->ratio;
-        upd(cfg->z_channels, T);
+        upd(cfg->encoder_out_channels > cfg->z_channels ? cfg->encoder_out_channels : cfg->z_channels, T);
         for (int i = 0; i <= n; ++i) {
             upd(C0 * cfg->dec_multipliers[i], T);
             if (i < n) {
@@ -1449,6 +1450,62 @@ __global__ __launch_bounds__(1024) void latent_reg_kernel(const float* __restric
 extern "C" int after_latent_reg(const float* z, long long n, float scale, float* out, void* stream) {
     AFTER_REQUIRE(z && out && n > 0, AFTER_E_INVALID, "latent_reg: bad argument");
     hipLaunchKernelGGL(latent_reg_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, z, n, scale, out);
+    AFTER_HIP_CHECK(hipGetLastError());
+    return AFTER_OK;
+}
+
+// ---------------------------------------------------------------- the other bottlenecks of SimpleNetsStream.py
+__global__ __launch_bounds__(256) void bottleneck_tanh_kernel(float* __restrict__ z, long long n, float scale) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) z[i] = scale * tanhf(z[i]);
+}
+
+extern "C" int after_bottleneck_tanh(float* z, long long n, float scale, void* stream) {
+    AFTER_REQUIRE(z && n > 0, AFTER_E_INVALID, "bottleneck_tanh: bad argument");
+    hipLaunchKernelGGL(bottleneck_tanh_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, (hipStream_t)stream, z, n,
+                       scale);
+    AFTER_HIP_CHECK(hipGetLastError());
+    return AFTER_OK;
+}
+
+// one workgroup: thread t walks the (b, time) columns t, t + 1024, ...; per column the KL channel sum in fp64
+__global__ __launch_bounds__(1024) void bottleneck_vae_kernel(const float* __restrict__ zraw,
+                                                              const float* __restrict__ noise, float* __restrict__ z,
+                                                              float* __restrict__ mean_out, float* __restrict__ kl,
+                                                              int B, int Z, int T) {
+    __shared__ double red[1024];
+    double acc = 0.0;
+    const long long cols = (long long)B * T;
+    for (long long col = threadIdx.x; col < cols; col += 1024) {
+        const int b = (int)(col / T), t = (int)(col - (long long)b * T);
+        double ks = 0.0;
+        for (int c = 0; c < Z; ++c) {
+            const float m = zraw[((size_t)b * 2 * Z + c) * T + t];
+            const float sc = zraw[((size_t)b * 2 * Z + Z + c) * T + t];
+            // torch softplus (beta 1, threshold 20): x for x > 20, else log1p(exp(x))
+            const float std = (sc > 20.f ? sc : log1pf(expf(sc))) + 1e-2f;
+            const float var = std * std;
+            const size_t o = ((size_t)b * Z + c) * T + t;
+            z[o] = noise ? noise[o] * std + m : m;
+            if (mean_out) mean_out[o] = m;
+            ks += (double)(m * m + var - logf(var) - 1.0f);
+        }
+        acc += ks;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) kl[0] = (float)(red[0] / (double)cols);
+}
+
+extern "C" int after_bottleneck_vae(const float* zraw, const float* noise, float* z, float* mean_out, float* kl, int B,
+                                    int Z, int T, void* stream) {
+    AFTER_REQUIRE(zraw && z && kl && B > 0 && Z > 0 && T > 0, AFTER_E_INVALID, "bottleneck_vae: bad argument");
+    hipLaunchKernelGGL(bottleneck_vae_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, zraw, noise, z, mean_out, kl,
+                       B, Z, T);
     AFTER_HIP_CHECK(hipGetLastError());
     return AFTER_OK;
 }

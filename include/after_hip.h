@@ -181,6 +181,8 @@ typedef struct after_ae_cfg {
     int dec_multipliers[AFTER_AE_MAX_STAGES + 1]; /* int(m * decoder_ratio), reversed */
     int factors[AFTER_AE_MAX_STAGES];             /* encoder order                    */
     int dilations[AFTER_AE_MAX_STAGES];
+    int encoder_out_channels; /* 0 = z_channels; 2 * z_channels with a VAEBottleneck (SimpleNetsStream.py:864-867):
+                               * after_ae_encode then writes [B, encoder_out_channels, T]          */
 } after_ae_cfg;
 
 /* Order of the `weights` array (reference state-dict keys).
@@ -224,6 +226,15 @@ int after_ae_decode_multi(after_ae* h, const float* z, float* x, float* multiban
  * ReluBottleneck.forward returns beside z (SimpleNetsStream.py:742-760 -> SimpleLatentReg,
  * after/autoencoder/core.py:189-198).  Deterministic (one workgroup, fixed order). */
 int after_latent_reg(const float* z, long long n, float scale, float* out, void* stream);
+/* TanhBottleneck.forward (SimpleNetsStream.py:719-740): z <- scale * tanh(z), in place (its noise term
+ * sigma * randn and its zero regulariser are the caller's). */
+int after_bottleneck_tanh(float* z, long long n, float scale, void* stream);
+/* VAEBottleneck.forward (SimpleNetsStream.py:763-785) on the encoder output zraw [B, 2Z, T] (mean | scale along
+ * the channels): std = softplus(scale) + 1e-2; z = noise * std + mean (noise [B, Z, T] ~ N(0, 1) from the caller;
+ * NULL = the mean itself); mean_out [B, Z, T] (may be NULL); kl[0] = mean over (b, t) of the channel sums of
+ * mean^2 + var - log var - 1.  Deterministic (one workgroup reduces in a fixed order). */
+int after_bottleneck_vae(const float* zraw, const float* noise, float* z, float* mean_out, float* kl, int B, int Z,
+                         int T, void* stream);
 /* multiband[B, M, L/M] = pqmf(x) / x = pqmf.inverse(multiband) (pqmf.py:286-301) */
 int after_ae_pqmf_forward(after_ae* h, const float* x, float* mb, int B, int L, void* stream);
 int after_ae_pqmf_inverse(after_ae* h, const float* mb, float* x, int B, int Tm, void* stream);

@@ -34,7 +34,7 @@ from .denoiser import (denoiser_forward, band_bounds, rope_tables,  # noqa: F401
                        banded_attention_loop)
 from .sampler import model_forward, sample  # noqa: F401
 from .autoencoder import (ae_encode, ae_decode, pqmf_forward, pqmf_inverse,  # noqa: F401
-                          fold_weight_norm)
+                          fold_weight_norm, tanh_bottleneck, vae_bottleneck, ae_encode_raw)
 from .encoders import encoder1d_forward, ecapa_forward  # noqa: F401
 from .streaming import stream_forward  # noqa: F401
 from .cached import NonCausalStreamEncoder, StreamGroupNorm, StreamNormDecoder  # noqa: F401

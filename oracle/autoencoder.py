@@ -161,3 +161,23 @@ def ae_encode(sd, x, cfg):
 def ae_decode(sd, z, cfg):
     """SimpleNetsStream.py:943-954."""
     return pqmf_inverse(sd, decoder_forward(sd, z, cfg), cfg["padding_mode"])
+
+
+def tanh_bottleneck(z, scale=3.0):
+    """TanhBottleneck.forward without its noise term (SimpleNetsStream.py:719-740): scale * tanh(z)."""
+    return scale * torch.tanh(z)
+
+
+def vae_bottleneck(zraw):
+    """VAEBottleneck.forward (SimpleNetsStream.py:763-785) up to the sampling: (mean, std, kl) of the encoder
+    output [B, 2Z, T]; the reference draws z = randn * std + mean."""
+    mean, scale = zraw.chunk(2, 1)
+    std = torch.nn.functional.softplus(scale) + 1e-2
+    var = std * std
+    kl = (mean * mean + var - torch.log(var) - 1).sum(1).mean()
+    return mean, std, kl
+
+
+def ae_encode_raw(sd, x, cfg):
+    """The encoder's output before the bottleneck (for VAE codecs: 2 x z_channels)."""
+    return encoder_forward(sd, pqmf_forward(sd, x, cfg["padding_mode"]), cfg)

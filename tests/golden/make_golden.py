@@ -75,11 +75,11 @@ def build_ecapa(cfg):
     return R.ecapa.ECAPATDNN(**cfg)
 
 
-def build_ae(cfg):
+def build_ae(cfg, bottleneck=None):
     kw = {k: v for k, v in cfg.items() if k not in ("padding_mode", "bottleneck")}
     R.cc.set_padding_mode(cfg["padding_mode"])
     try:
-        return R.ae.AutoEncoder(bottleneck=R.ae.ReluBottleneck(sigma=0.01, scale=3), **kw)
+        return R.ae.AutoEncoder(bottleneck=bottleneck or R.ae.ReluBottleneck(sigma=0.01, scale=3), **kw)
     finally:
         R.cc.set_padding_mode("centered")
 
@@ -188,6 +188,23 @@ def ae_case(case, cfg_name, B, L, seed, wg_scale=1.0):
     if wg_scale != 1.0:
         meta["wg_scale"] = wg_scale
     save(case, meta, x=x, z=z, zin=zin, y=y, multiband=mb, pqmf_roundtrip=xr, **keepdict(keep))
+
+
+def bottleneck_case(case="ae_micro_bottlenecks", seed=46):
+    """The two other bottlenecks of SimpleNetsStream.py:719-785 on the micro codec: TanhBottleneck (sigma = 0:
+    deterministic) through AutoEncoder.encode, and VAEBottleneck through encode(return_mean=True) -- mean and KL
+    are deterministic, the drawn z is checked through its moments by the tests."""
+    cfg = configs.autoencoder_config("microAE")
+    x = detweights.seeded_tensor("audio", (2, 1, 8192), seed, 0.1)
+    ae_t = build_ae(cfg, R.ae.TanhBottleneck(scale=3, sigma=0.))
+    shapes_t, keep = refill(ae_t, seed)
+    z_t, reg_t = ae_t.encode(x)
+    ae_v = build_ae(cfg, R.ae.VAEBottleneck())
+    shapes_v, _ = refill(ae_v, seed + 1)
+    torch.manual_seed(0)
+    z_v, kl, mean = ae_v.encode(x, return_mean=True)
+    meta = dict(kind="bottlenecks", config="microAE", seed=seed, shapes=shapes_t, shapes_vae=shapes_v)
+    save(case, meta, x=x, z_tanh=z_t, reg_tanh=reg_t, vae_mean=mean, vae_kl=kl, vae_z=z_v, **keepdict(keep))
 
 
 def cached_gn_case():
@@ -439,6 +456,7 @@ CASES = {
     "ae_micro": lambda: ae_case("ae_micro", "microAE", 2, 16384, 41),
     "ae_micro_causal": lambda: ae_case("ae_micro_causal", "microAE_causal", 1, 8192, 42),
     "ae_base": lambda: ae_case("ae_base", "baseAE", 1, 32768, 43),
+    "ae_micro_bottlenecks": bottleneck_case,
     "ae_micro_causal_wc": lambda: ae_case("ae_micro_causal_wc", "microAE_causal", 2, 8192, 44, wg_scale=0.5),
     "ae_base_causal_wc": lambda: ae_case("ae_base_causal_wc", "baseAE_causal", 1, 16384, 45, wg_scale=0.5),
     "encoders_micro": lambda: encoders_case("encoders_micro", "micro", 2, 64, 51),

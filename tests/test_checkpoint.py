@@ -195,13 +195,18 @@ def test_load_diffusion_and_autoencoder_from_run_folders(tmp_path):
     assert all(torch.equal(got[k], v) for k, v in ae_sd.items())
 
 
-def test_unsupported_bottleneck_and_activation_are_refused(tmp_path):
+def test_bottleneck_binding_decides_and_unsupported_activation_is_refused(tmp_path):
     """The bottleneck has no parameters, so a checkpoint cannot reveal that the codec was trained with
     TanhBottleneck (z = scale * tanh(z)) or VAEBottleneck (2x encoder channels): the config decides."""
-    for bn in ("TanhBottleneck", "VAEBottleneck"):
+    from after_amd.autoencoder import TanhBottleneck, VAEBottleneck
+    for bn, cls in (("TanhBottleneck", TanhBottleneck), ("VAEBottleneck", VAEBottleneck)):
         cfg = GinConfig.parse_string(BLOCK_AE.replace("@SimpleNetsStream.ReluBottleneck()", f"@SimpleNetsStream.{bn}()"))
-        with pytest.raises(NotImplementedError):
-            checkpoint.autoencoder_from_config(cfg, device="cpu")
+        ae_b = checkpoint.autoencoder_from_config(cfg, device="cpu")
+        assert isinstance(ae_b.bottleneck, cls)
+        assert ae_b.encoder_out_channels == (2 if cls is VAEBottleneck else 1) * ae_b.z_channels
+    cfg = GinConfig.parse_string(BLOCK_AE.replace("@SimpleNetsStream.ReluBottleneck()", "@SimpleNetsStream.FSQ()"))
+    with pytest.raises(NotImplementedError):
+        checkpoint.autoencoder_from_config(cfg, device="cpu")
     cfg = GinConfig.parse_string(BLOCK_AE + "\nSimpleNetsStream.AutoEncoder.activation = @torch.nn.ReLU\n")
     with pytest.raises(NotImplementedError):
         checkpoint.autoencoder_from_config(cfg, device="cpu")

@@ -135,6 +135,22 @@ def test_autoencoder_matches_reference(case):
     assert max_abs(y, fx.t("y")) < ry * fx.t("y").abs().max().item()
 
 
+def test_other_bottlenecks_match_reference():
+    """TanhBottleneck / VAEBottleneck (SimpleNetsStream.py:719-785) as the reference's AutoEncoder.encode runs them."""
+    fx = Fixture("ae_micro_bottlenecks")
+    cfg = configs.autoencoder_config("microAE")
+    x = fx.t("x")
+    zt = oracle.tanh_bottleneck(oracle.ae_encode_raw(fx.state_dict(), x, cfg), 3.0)
+    assert max_abs(zt, fx.t("z_tanh")) < 5e-5 * fx.t("z_tanh").abs().max().item() and float(fx.t("reg_tanh")) == 0.0
+    sdv = fx.state_dict("shapes_vae", seed_offset=1)
+    mean, std, kl = oracle.vae_bottleneck(oracle.ae_encode_raw(sdv, x, cfg))
+    assert max_abs(mean, fx.t("vae_mean")) < 5e-5 * fx.t("vae_mean").abs().max().item()
+    assert abs(kl.item() - float(fx.t("vae_kl"))) < 1e-4 * abs(float(fx.t("vae_kl")))
+    # the reference's draw is randn * std + mean: its standardised residual is N(0, 1)
+    r = (fx.t("vae_z") - mean) / std
+    assert abs(r.mean().item()) < 0.1 and abs(r.std().item() - 1.0) < 0.1
+
+
 @pytest.mark.parametrize("case", ["encoders_micro", "encoders_tiny", "encoders_base"])
 def test_encoders_match_reference(case):
     fx = Fixture(case)
