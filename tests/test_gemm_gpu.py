@@ -127,9 +127,10 @@ def test_gemm_x6(tile, M, N, K, epi, hip_device):
     bf16 MFMAs, fp32 accumulation) against fp64 at the sampler's own shapes (M = 768 and 6144 token rows, both
     GEMM orientations) and on ragged ones, every tile, bias + GELU / residual epilogues, operands with outliers.
     Bar: its error against fp64 is no larger than that of the fp32 MFMA kernel (an exact fp32 fma chain) with the
-    same number of k-parts: rms <= 1.0 x; max (an extreme-value statistic over up to 9.4 M outputs of two
-    different summation orders: measured spread 0.5 - 1.5 x, scripts/bench_gemm_x6.py) <= 2 x, also against whatever
-    the fp32 dispatch picks for the shape."""
+    same number of k-parts: rms <= 1.0 x (measured 0.79 - 0.82 x on every shape and tile, profiles/r3_gemm_x6_sweep.jsonl);
+    max -- an extreme-value statistic over up to 9.4 M outputs of two different summation orders, measured
+    0.55 - 1.08 x -- <= 1.5 x.  And the tile the dispatch picks (tile 0) against whatever the fp32 dispatch picks for
+    the same shape, i.e. production against production: rms <= 1.0 x, max <= 1.25 x."""
     from after_amd import _lib, diag
     a, w, bias, res, ref = _x6_case(M, N, K, epi, M + N + K + tile)
     dev = hip_device
@@ -144,9 +145,11 @@ def test_gemm_x6(tile, M, N, K, epi, hip_device):
     floor = 1e-7 * ref.abs().max().item()
     rms = lambda e: e.pow(2).mean().sqrt().item()
     assert rms(e6) <= max(rms(es), floor), (rms(e6), rms(es))
-    assert e6.max().item() <= max(2.0 * es.max().item(), floor), (e6.max().item(), es.max().item())
-    assert e6.max().item() <= max(2.0 * ed.max().item(), floor), (e6.max().item(), ed.max().item())
-    if epi != 2:  # plane output (the next GEMM's A operand): the same numbers, split exactly
+    assert e6.max().item() <= max(1.5 * es.max().item(), floor), (e6.max().item(), es.max().item())
+    if tile == 0:
+        assert rms(e6) <= max(rms(ed), floor), (rms(e6), rms(ed))
+        assert e6.max().item() <= max(1.25 * ed.max().item(), floor), (e6.max().item(), ed.max().item())
+    if epi != 2 and N % 32 == 0:  # plane output (the next GEMM's A operand): the same numbers, split exactly
         got3 = diag.gemm_x6(a3, w3, tile=tile, planes=True, **kw)
         assert torch.equal(got3.join(), got)
 
