@@ -732,14 +732,15 @@ int gemm_x6(after_denoiser* h, hipStream_t s, const unsigned short* A3, const un
 }
 
 // Per-Linear dispatch between the two GEMM kernels (mode 1; measured in the sampler, profiles/r3_*): with many
-// token rows gemm_x6 wins every shape (B = 8: 52 - 60 us against 74 - 76); at one clip (768 rows) it wins the
-// wide-N, short-K Linears (qkv 11.3 us, MLP-up 12.8 us against 13.5) and loses MLP-down (N = 512, K = 1536:
-// 48 x 32 tiles pull 737 KB per CU through the L2 -> LDS path, 15.0 us against 14.2), which stays on gemm.hip.
+// token rows gemm_x6 wins every shape (B = 8: 52 - 60 us against 74 - 76 for gemm.hip); at one clip (768 rows) its
+// W-in-register tiles win the wide-N Linears (qkv, MLP-up) and, where K allows their four-slab groups
+// (K % 512 == 0: every shipped width), the long-K MLP-down as well; otherwise MLP-down's 48 x 32 LDS-staged tile
+// pulls 737 KB per CU through the L2 -> LDS path and loses to gemm.hip, which keeps it.
 bool x6_wins(const after_denoiser* h, int M, int N, int K) {
     if (h->x6 == 0) return false;
     if (h->x6 == 2) return true;
     if (M < h->x6_min_rows) return false;
-    return M >= 1536 || N >= 2 * K;
+    return M >= 1536 || N >= 2 * K || (K % 512) == 0;
 }
 
 int upload_padded(float* dst, int ldp, const float* src, int rows, int cols) {

@@ -32,7 +32,8 @@ def timeit(fn, reps=200):
 g = torch.Generator(device="cpu").manual_seed(0)
 rows = []
 SHAPES = [(768, 1536, 512, 0), (768, 1536, 512, 1), (768, 512, 1536, 2), (1536, 1536, 512, 0), (1536, 512, 1536, 2),
-          (3072, 1536, 512, 0), (3072, 512, 1536, 2), (6144, 1536, 512, 0), (6144, 1536, 512, 1), (6144, 512, 1536, 2)]
+          (3072, 1536, 512, 0), (3072, 512, 1536, 2), (6144, 1536, 512, 0), (6144, 1536, 512, 1), (6144, 512, 1536, 2),
+          (12288, 1536, 512, 1)]
 for (M, N, K, epi) in SHAPES:
     a = (1.3 * torch.randn(M, K, generator=g)).to(dev)
     a[::7, ::13] *= 30.0
@@ -60,7 +61,7 @@ for (M, N, K, epi) in SHAPES:
     fl = 2.0 * M * N * K
     auto = _lib.lib().after_gemm_x6_pick_tile(M, N, K)
     line = f"M={M} N={N} K={K} epi={epi}  fp32 {t32:.2f}us ({fl / t32 * 1e-6:.0f} TF) err {e32:.1e} | auto={auto} |"
-    for t in range(1, 10):
+    for t in list(range(1, 10)) + [11, 12, 15]:
         try:
             out.zero_()
             diag.gemm_x6(a3, w3, tile=t, out=out, **kw)
