@@ -36,10 +36,6 @@ namespace {
 template <int BK>
 constexpr int lds_ld() { return BK == 32 ? 40 : BK + 40; }  // (LD/4) == 10 (mod 16): conflict-free b128 fragments
 
-__device__ __forceinline__ float gelu_erf(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-}
-
 template <int NL>
 __device__ __forceinline__ void tile_gload(float4 (&r)[NL], const float* __restrict__ base,
                                            const size_t (&off)[NL], const bool (&ok)[NL], int k0,

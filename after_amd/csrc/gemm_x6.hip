@@ -44,8 +44,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float gelu_erf_x6(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-
 // round-to-nearest-even bf16 of x, as the high half of a dword (low half zero) -> exact float
 __device__ __forceinline__ unsigned bf16_hi(float x) {
     unsigned u = __float_as_uint(x);
@@ -309,7 +307,7 @@ __device__ __forceinline__ void x6_epilogue(const X6Args& g, f32x4 (&acc)[MT][NT
             o += bv;
             if (g.epilogue == EPI_GELU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = gelu_erf_x6(o[r]);
+                for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r]);
             } else if (g.epilogue == EPI_RELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
@@ -504,7 +502,7 @@ __device__ __forceinline__ void x6_epilogue_full(const X6Args& g, f32x4 (&acc)[M
             f32x4 o = acc[i][j] + bias_pre[j];
             if (g.epilogue == EPI_GELU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = gelu_erf_x6(o[r]);
+                for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r]);
             } else if (g.epilogue == EPI_RELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
@@ -904,17 +902,19 @@ __global__ __launch_bounds__(64 * C::NW, C::WPS) void gemm_x6w_kernel(X6Args g, 
         t_start = __builtin_readcyclecounter();
         r_start = wall_clock64();
     }
-    // ---- prologue: A0 W0 A1 W1 A2 W2 A3 (nk >= 4), wait for A0, read its fragments
+    // ---- prologue: A0 W0 A1 W1 (A2 W2 A3 follow behind the first barrier: a wave's A0 piece queues behind whatever
+    // the CU's other eleven waves issued before it, and every wave needs every A0 piece), wait for A0, read its
+    // fragments.  The issue ORDER is the one the step waits count on: A0 W0 A1 W1 A2 W2 A3 | W3 A4 | ...
     x6w_issue_a<C>(c, 0);
     x6w_issue_w<C, 0>(c, 0);
     x6w_issue_a<C>(c, 1);
     x6w_issue_w<C, 1>(c, 1);
+    x6w_wait<C, 1, 1, 0>(c);  // everything but A0: W0, the group A1 + W1
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     x6w_issue_a<C>(c, 2);
     x6w_issue_w<C, 2>(c, 2);
     x6w_issue_a<C>(c, 3);
-    x6w_wait<C, 3, 0, 0>(c);  // everything but A0: three "W + A" groups
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
     if (g.dbg) t_loop = __builtin_readcyclecounter();
     x6w_sides<C, 1, 0, false, false, true, 3 + C::LPA, C::NWORK>(c, 0, c.a_rd);  // slab 0's fragments into set 0
     int kt = 0;
