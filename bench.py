@@ -300,7 +300,7 @@ def run_pmc(args):
         if m and m.group(1).split(",")[-1].strip() == "0" and total > 5e6:  # MODE 0, not the small launches
             big_bytes += total * len(f)
             big_n += len(f)
-        if "gemm_x6_kernel" in name:
+        if "gemm_x6" in name and "_kernel" in name:  # gemm_x6_kernel / gemm_x6w_kernel / gemm_x6p_kernel
             x6_bytes += total * len(f)
             x6_n += len(f)
     rows.sort(key=lambda r: -r["bytes_per_launch_corrected"] * r["launches"])

@@ -1,27 +1,48 @@
 #!/bin/bash
 # Regenerates the per-round measurement artefacts on the GPU box (run through gpurun from the repo root):
-#   bash scripts/round_profiles.sh r2
+#   bash scripts/round_profiles.sh r3
 # Writes into gpurun_out/final_<round>/; the summaries are then copied into profiles/ by hand.
-R=${1:-r2}
+R=${1:-r3}
 O=gpurun_out/final_$R
 mkdir -p $O
 export TMPDIR=/tmp
-python bench.py --pmc > $O/pmc.log 2>&1   # first: the bench line below quotes its traffic figure
+python bench.py --pmc > $O/pmc_b1.log 2>&1   # first: the bench lines below quote their traffic figures
+python bench.py --pmc --batch-per-gpu 8 > $O/pmc_b8.log 2>&1
+cp profiles/${R}_pmc_hbm_base_b1.json profiles/${R}_pmc_hbm_base_b8.json $O/ 2>/dev/null
 python bench.py --steps 20 --warmup 5 > $O/${R}_bench_b1.json 2> $O/bench_b1.err
 python bench.py --steps 6 --warmup 2 --batch-per-gpu 8 --no-cpu-baseline > $O/${R}_bench_b8.json 2> $O/bench_b8.err
 python bench.py --steps 4 --warmup 1 --batch-per-gpu 8 --config midi > $O/${R}_bench_midi_b8.json 2> $O/bench_midi.err
 python bench.py --stream --steps 16 --warmup 4 > $O/${R}_bench_stream.json 2> $O/bench_stream.err
-AFTER_GEMM_X6=1 python bench.py --steps 6 --warmup 2 --batch-per-gpu 8 --no-cpu-baseline > $O/${R}_experiment_x6_bench_b8.json 2> $O/bench_x6.err
+python bench.py --steps 5 --warmup 2 --from-audio --config tiny > $O/${R}_bench_tiny_from_audio.json 2> $O/bench_fa.err
+python bench.py --steps 5 --warmup 2 --from-audio --no-cpu-baseline > $O/${R}_bench_base_from_audio.json 2>> $O/bench_fa.err
+# same-box A/B of the GEMM paths and of the persistent many-row tile
+for c in 0 1; do
+  AFTER_GEMM_X6=$c python bench.py --steps 12 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'leg': 'b1', 'AFTER_GEMM_X6': $c, 'ms_per_step': d['ms_per_step'], 'xrt': d['value']}))" >> $O/${R}_ab_gemm_path.jsonl
+  AFTER_GEMM_X6=$c python bench.py --steps 6 --warmup 2 --batch-per-gpu 8 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'leg': 'b8', 'AFTER_GEMM_X6': $c, 'ms_per_step': d['ms_per_step'], 'xrt': d['value']}))" >> $O/${R}_ab_gemm_path.jsonl
+done
+for p in 1 0; do
+  AFTER_GEMM_X6_PERSIST=$p python bench.py --steps 6 --warmup 2 --batch-per-gpu 8 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'leg': 'b8', 'AFTER_GEMM_X6_PERSIST': $p, 'ms_per_step': d['ms_per_step'], 'xrt': d['value']}))" >> $O/${R}_ab_gemm_path.jsonl
+done
+python scripts/bench_gemm_x6.py $O/${R}_gemm_x6_sweep.jsonl > $O/x6_sweep.log 2>&1
 python scripts/time_codec.py --rounds 30 2>/dev/null | grep workload > $O/${R}_codec.jsonl
 python scripts/time_encoders.py 2>/dev/null | grep workload >> $O/${R}_codec.jsonl
+./scripts/ubench/xcd_barrier.bin > $O/${R}_xcd_barrier.jsonl 2>/dev/null
 for b in 1 8; do
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/st$b -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --batch-per-gpu $b --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/st$b.log 2>&1)
   f=$(find $O/st$b -name "*kernel_stats.csv" | head -1)
   head -41 "$f" | cut -c1-260 > $O/${R}_bench_base_b${b}_kernel_stats.csv
   rm -rf $O/st$b
-  (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/tr -- python $GRAFT_REPO_ROOT/scripts/time_codec.py --rounds 3 --batches $b --only decode > $GRAFT_REPO_ROOT/$O/tr.log 2>&1)
-  python scripts/trace_reduce.py $O/tr --end pqmf_inverse --rows > $O/${R}_decode_trace_b$b.jsonl
-  rm -rf $O/tr
+  # the sampler alone (default GEMM path only: bench.py's roofline legs also run the fp32 MFMA path once)
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/ss$b -- python $GRAFT_REPO_ROOT/scripts/time_sampler.py base $b 50 5 > $GRAFT_REPO_ROOT/$O/ss$b.log 2>&1)
+  f=$(find $O/ss$b -name "*kernel_stats.csv" | head -1)
+  head -21 "$f" | cut -c1-260 > $O/${R}_sampler_b${b}_kernel_stats.csv
+  rm -rf $O/ss$b
+  for w in decode encode; do
+    e=pqmf_inverse; [ $w = encode ] && e=pqmf_forward
+    (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/tr -- python $GRAFT_REPO_ROOT/scripts/time_codec.py --rounds 3 --batches $b --only $w > $GRAFT_REPO_ROOT/$O/tr.log 2>&1)
+    python scripts/trace_reduce.py $O/tr --end $e --rows > $O/${R}_${w}_trace_b$b.jsonl
+    rm -rf $O/tr
+  done
 done
 python scripts/pmc_run.py $O/${R}_pmc_codec_b1.json -- python scripts/time_codec.py --batches 1 --rounds 3 > $O/pmc_codec.log 2>&1
-ls -la $O profiles | head -60
+ls -la $O | head -60

@@ -13,10 +13,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("extra,n_clips", [([], 2), (["--global-batch", "3"], 3)])
+@pytest.mark.parametrize("extra,n_clips", [([], 2), (["--global-batch", "3"], 3), (["--batch-per-gpu", "8"], 16)])
 def test_two_rank_bench_flow(extra, n_clips, hip_device):
-    """Even shards (all_gather_into_tensor on RCCL; the host-staged list form under gloo) and a
-    ragged global batch (3 clips over 2 ranks: shards of 2 and 1)."""
+    """Even shards (all_gather_into_tensor on RCCL; the host-staged list form under gloo), a ragged global batch
+    (3 clips over 2 ranks: shards of 2 and 1) and BASELINE config 3's per-rank shard (8 clips per rank: the
+    many-row GEMM tiles and the large-grid attention under the multi-rank flow)."""
     env = dict(os.environ, AFTER_BENCH_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(29533 + n_clips), os.path.join(ROOT, "bench.py"),
@@ -28,3 +29,4 @@ def test_two_rank_bench_flow(extra, n_clips, hip_device):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["config"]["global_batch"] == n_clips
     assert d["scaling"] == "weak" and d["value"] > 0 and d["roofline"]["frac"] > 0
+    assert 0 < d["ms_per_step_fastest_rank"] <= d["ms_per_step"]  # per-rank spread beside the max
