@@ -29,6 +29,8 @@
 namespace after {
 namespace {
 
+__device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
+
 constexpr int kMaxKeys = 32;   // W - 1 + chunk
 constexpr int kMaxChunk = 8;
 constexpr int kMaxPer = 8;     // E / 64 <= 8  (E <= 512: every shipped config)
@@ -186,19 +188,11 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(float* __restrict__ out
 // CFG sample reads the patchify output of clip r % B for all three CFG rows).
 // h3 != nullptr: h is written as its three bf16 planes (x6 blocks of [rows * T][E], common.h: the A operand of
 // gemm_x6.hip) instead of fp32.
-__global__ __launch_bounds__(256) void ln_mod_ln_kernel(const float* __restrict__ xin,
-                                                        const int* __restrict__ src_map,
-                                                        float* __restrict__ xout,
-                                                        float* __restrict__ h,
-                                                        unsigned short* __restrict__ h3,
-                                                        const float* __restrict__ tc_ab, int tc_ld,
-                                                        const int* __restrict__ tc_map,
-                                                        const float* __restrict__ w1,
-                                                        const float* __restrict__ b1, int rows,
-                                                        int T, int E) {
-    const int lane = threadIdx.x & 63;
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= rows * T) return;
+__device__ __forceinline__ void ln_mod_ln_row(const float* __restrict__ xin, const int* __restrict__ src_map,
+                                              float* __restrict__ xout, float* __restrict__ h,
+                                              unsigned short* __restrict__ h3, const float* __restrict__ tc_ab, int tc_ld,
+                                              const int* __restrict__ tc_map, const float* __restrict__ w1,
+                                              const float* __restrict__ b1, int T, int E, int m, int lane) {
     const int r = m / T, t = m - r * T;
     const int sr = src_map ? src_map[r] : r;
     const float* xi = xin + ((size_t)sr * T + t) * E;
@@ -268,6 +262,21 @@ __global__ __launch_bounds__(256) void ln_mod_ln_kernel(const float* __restrict_
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void ln_mod_ln_kernel(const float* __restrict__ xin,
+                                                        const int* __restrict__ src_map,
+                                                        float* __restrict__ xout,
+                                                        float* __restrict__ h,
+                                                        unsigned short* __restrict__ h3,
+                                                        const float* __restrict__ tc_ab, int tc_ld,
+                                                        const int* __restrict__ tc_map,
+                                                        const float* __restrict__ w1,
+                                                        const float* __restrict__ b1, int rows,
+                                                        int T, int E) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= rows * T) return;
+    ln_mod_ln_row(xin, src_map, xout, h, h3, tc_ab, tc_ld, tc_map, w1, b1, T, E, m, threadIdx.x & 63);
 }
 
 // SelfAttention + second half of DecoderBlock.forward for one chunk of <= 8 query
@@ -344,17 +353,18 @@ constexpr int kAttnKeyBlock = 12;
 // WIDE (no shipped config): the unlimited windows of transformerv2.py:204-220 -- chunk-wise causal
 // over ALL previous chunks (local_attention_size None / negative) or no mask at all (causal=False).
 // Keys start at 0, the RoPE tables are read from global memory per key (no per-chunk slice).
-template <bool CACHE, bool PRELOAD, bool WIDE = false>
-__global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
+// (body shared by attn_block_kernel and the persistent streaming step: bx = chunk, by = network row, smem = the
+// workgroup's dynamic LDS [cs][E + 4] | cos, sin [nkmax][16] | K/V landing zones)
+template <bool CACHE, bool PRELOAD, bool WIDE>
+__device__ __forceinline__ void attn_block_body(const AttnArgs& a, int bx, int by, float* smem) {
     constexpr int NKMAX = kAttnKeyBlock;  // key block
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [cs][E + 4] | cos, sin [nkmax][16]
     const int E = a.E, H = a.H, T = a.T, cs = a.cs, W = a.W;
     const int nc = CACHE ? a.nc : 0;
     const int ld = E + 4;
-    const int r = blockIdx.y, tid = threadIdx.x;
+    const int r = by, tid = threadIdx.x;
     const int lane = tid & 63, hw = tid >> 6;  // head of this wave
     const int grp = lane >> 4, d4 = (lane & 15) * 4;
-    const int i0 = blockIdx.x * cs;  // chunk start within this call's T frames
+    const int i0 = bx * cs;  // chunk start within this call's T frames
     const int e = min(i0 + cs, T);
     const int nq = e - i0;
     const int a0 = nc + i0;          // absolute position of the first query (keys: nc cached frames first)
@@ -580,6 +590,12 @@ __global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
     }
 }
 
+template <bool CACHE, bool PRELOAD, bool WIDE = false>
+__global__ __launch_bounds__(64 * kMaxPer) void attn_block_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    attn_block_body<CACHE, PRELOAD, WIDE>(a, blockIdx.x, blockIdx.y, smem);
+}
+
 __global__ void set_params_kernel(CfgParams* p, float total, float factor, float dt) {
     p->total = total;
     p->factor = factor;
@@ -638,6 +654,328 @@ __global__ __launch_bounds__(256) void roll_cache_kernel(const float* __restrict
     }
     knew[idx] = kv;
     vnew[idx] = vv;
+}
+
+
+// =====================================================================================================
+// Persistent streaming step: ONE launch per cached Euler step instead of 33 (Streamer.sample, export.py:398-416).
+// A chunk of the streaming sampler is 4 frames x 3 CFG rows x B streams = 96 token rows at eight streams: every
+// kernel of the step is ~1 us of work behind ~8 us of launch / dependency latency.  Here 256 workgroups (one per
+// CU, 512 threads) walk the step's phases -- patchify | per layer: ln_mod_ln, qkv GEMM, cached attention, MLP-up
+// GEMM (+ the K/V cache roll on the idle workgroups), MLP-down GEMM | out_proj + CFG + Euler -- separated by the
+// XCD-hierarchical device-wide barrier of the microarchitecture guide (scripts/ubench/xcd_barrier.hip: 4.0-4.3 us
+// measured on this part against ~9 us per dependent launch): per-XCC arrival counter -> the XCC's last arriver
+// writes the XCD's L2 back once and arrives at the top counter -> polls it, acquires, publishes the round in its
+// XCC's generation word -> every other workgroup polls that word and acquires once.  Populations per XCC are
+// counted at kernel start (dispatch placement is observed, not promised); every spin is bounded and raises a
+// timeout word the host checks.  The phase bodies are the launch path's own (ln_mod_ln_row, attn_block_body) or
+// its skinny-GEMM scheme (fragments straight from global memory, k-waves summed through LDS in wave order), so the
+// arithmetic -- and the results, bit for bit -- are those of the launch path with AFTER_GEMM_SKINNY=2.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct StepBarrier {
+    unsigned arrive[8][32];  // [xcc][0]: arrivals (each word on its own 128-byte line)
+    unsigned gen[8][32];     // [xcc][0]: last completed round, published by the XCC's leader
+    unsigned top[32];        // [0]: XCC leaders that arrived
+    unsigned pop[8][32];     // [xcc][0]: workgroups resident on the XCC
+    unsigned census[32];     // [0]: workgroups counted
+    unsigned timeout[32];    // [0]: a spin gave up
+};
+
+struct StepLayer {
+    const float *qkv_w, *mlp0_w, *mlp0_b, *mlp2_w, *mlp2_b, *n1w, *n1b, *n3w, *n3b;
+    float* qkv;                 // this layer's [rows * T][3E] (kept for roll_cache)
+    const float *kold, *vold;   // cache half the step attends over
+    float *knew, *vnew;         // the other half: rolled by T frames
+};
+
+struct StepArgs {
+    int rows, B, T, E, ME, C, Cp, L, H, cs, W, nkmax, causal, cache, cache_rows, last_step;
+    const float* xt;      // token-major latents [B * T][Cp] (this step's input)
+    float *pat, *xres, *hbuf, *mlp;
+    const float *patch_w, *patch_b, *out_w, *out_b;
+    const float* tc_ab;
+    int tc_ld;
+    const int *xmap, *tcmap;
+    const float* cond_ab;  // this step's rows
+    int cond_ld;
+    const float *rope_cos, *rope_sin;
+    const float* xin;      // [B, C, T]
+    float* xout;
+    float* xt_next;        // token-major copy for the next step (nullptr on the last)
+    const float* cfg;      // device CfgParams
+    StepBarrier* bar;
+    StepLayer layer[8];
+};
+
+__device__ __forceinline__ unsigned step_xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 7u;
+}
+
+__device__ __forceinline__ bool step_spin(unsigned* word, unsigned want, unsigned* timeout) {
+    for (unsigned spins = 0;; ++spins) {
+        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if (spins > (1u << 21)) {
+            __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+}
+
+__device__ __forceinline__ void step_barrier(StepBarrier* st, unsigned xcc, unsigned n_xcc, unsigned n_xccs,
+                                             unsigned round) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have reached the XCD's L2
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned ticket = __hip_atomic_fetch_add(&st->arrive[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == round * n_xcc - 1) {  // last arriver of this XCC: the round's leader
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // write the XCD's L2 back once
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(&st->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            step_spin(&st->top[0], round * n_xccs, &st->timeout[0]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(&st->gen[xcc][0], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            step_spin(&st->gen[xcc][0], round, &st->timeout[0]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    }
+    __syncthreads();
+}
+
+// One [16 MB rows] x [16 columns] tile of C = epi(A W^T + bias): the waves split K (nwk = min(8, K / 16) of them take
+// K / nwk each), load their fragments straight from global memory, and the partial tiles are summed through LDS in
+// wave order (gemm.hip's skinny kernel).  BRANCH > 0: the MB = 3 row blocks are the three CFG branches of the same 16
+// tokens (A row = i * BRANCH + row0 + lane % 16) and the results stay in LDS for step_tail_finish.
+template <int MB>
+__device__ __forceinline__ void step_gemm_tile(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
+                                               const float* __restrict__ bias, const float* __restrict__ R, int ldr,
+                                               float* __restrict__ Cc, int ldc, int M, int N, int K, int epi, int row0,
+                                               int n0, int branch, float* red) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row = lane & 15, kq = lane >> 4;
+    const int nwk = K >= 128 ? 8 : K / 16, Kw = K / nwk;
+    f32x4 acc[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (w < nwk) {
+        const float* wp = W + (size_t)min(n0 + row, N - 1) * ldw + w * Kw + kq * 4;
+        const float* ap[MB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const int gm = branch > 0 ? i * branch + min(row0 + row, branch - 1) : min(row0 + i * 16 + row, M - 1);
+            ap[i] = A + (size_t)gm * lda + w * Kw + kq * 4;
+        }
+        constexpr int U = 4;  // 16-deep k-blocks in flight per wave
+        for (int kb = 0; kb < Kw; kb += 16 * U) {
+            f32x4 bw[U], av[U][MB];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = kb + 16 * u;
+                if (k < Kw) {
+                    bw[u] = *reinterpret_cast<const f32x4*>(wp + k);
+#pragma unroll
+                    for (int i = 0; i < MB; ++i) av[u][i] = *reinterpret_cast<const f32x4*>(ap[i] + k);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (kb + 16 * u < Kw) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int i = 0; i < MB; ++i)  // W fragment as srcA: the accumulator holds C^T
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[u][c], av[u][i][c], acc[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();  // the previous item's readers are done with `red`
+#pragma unroll
+    for (int i = 0; i < MB; ++i) *reinterpret_cast<f32x4*>(red + ((w * MB + i) * 64 + lane) * 4) = acc[i];
+    __syncthreads();
+    if (branch > 0) return;
+    // wave w finalises row block w: lane owns row 16 w + lane % 16, columns n0 + 4 (lane / 16) + r
+    const int gn = n0 + 4 * kq;
+    for (int i = w; i < MB; i += 8) {
+        f32x4 o = *reinterpret_cast<const f32x4*>(red + (i * 64 + lane) * 4);
+#pragma unroll
+        for (int q = 1; q < 8; ++q) o += *reinterpret_cast<const f32x4*>(red + ((q * MB + i) * 64 + lane) * 4);
+        const int gm = row0 + i * 16 + row;
+        if (gm >= M) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (gn + r >= N) continue;
+            float v = o[r] + (bias ? bias[gn + r] : 0.f);
+            if (epi == EPI_GELU) v = gelu_erf(v);
+            if (epi == EPI_RESIDUAL) v += R[(size_t)gm * ldr + gn + r];
+            Cc[(size_t)gm * ldc + gn + r] = v;
+        }
+    }
+}
+
+// CFG combine + Euler update + both output layouts for the 16 tokens x 16 channels whose three branch tiles
+// step_gemm_tile<3>(branch = B T) left in LDS (model.py:749-759, 777-783; as gemm.hip's fused tail)
+__device__ __forceinline__ void step_tail_finish(const StepArgs& a, int tok0, int n0, const float* red) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    if ((tid >> 6) != 0) return;
+    const int BT = a.B * a.T, N = a.C;
+    f32x4 d[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        d[i] = *reinterpret_cast<const f32x4*>(red + (i * 64 + lane) * 4);
+#pragma unroll
+        for (int q = 1; q < 8; ++q) d[i] += *reinterpret_cast<const f32x4*>(red + ((q * 3 + i) * 64 + lane) * 4);
+    }
+    const int tok = tok0 + (lane & 15);
+    if (tok >= BT) return;
+    const float total = a.cfg[0], factor = a.cfg[1], dt = a.cfg[2];
+    const int bq = tok / a.T, t = tok - bq * a.T;
+    const int gn = n0 + 4 * (lane >> 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = gn + r;
+        if (n >= N) continue;
+        const float bo = a.out_b ? a.out_b[n] : 0.f;
+        const float dfull = d[0][r] + bo, dmid = d[1][r] + bo, dnone = d[2][r] + bo;
+        const float v = dnone + total * (dmid + factor * (dfull - dmid) - dnone);
+        const size_t o = ((size_t)bq * N + n) * a.T + t;
+        const float xn = a.xin[o] + v * dt;
+        a.xout[o] = xn;
+        if (a.xt_next) a.xt_next[(size_t)tok * a.Cp + n] = xn;
+    }
+}
+
+__global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ unsigned s_n, s_nx;
+    StepBarrier* st = a.bar;
+    const unsigned xcc = step_xcc_id(), nb = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) {  // census: workgroups per XCC
+        __hip_atomic_fetch_add(&st->pop[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&st->census[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        step_spin(&st->census[0], nb, &st->timeout[0]);
+        unsigned nx = 0;
+        for (int x = 0; x < 8; ++x)
+            nx += __hip_atomic_load(&st->pop[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+        s_n = __hip_atomic_load(&st->pop[xcc][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_nx = nx;
+    }
+    __syncthreads();
+    const unsigned n_xcc = s_n, n_xccs = s_nx;
+    unsigned round = 0;
+    const int E = a.E, ME = a.ME, T = a.T, M = a.rows * T, BT = a.B * T;
+    const int bid = blockIdx.x, G = gridDim.x;
+
+    // ---- patchify_and_embed: pat = GELU(xt patch_w^T + b)   (transformerv2.py:387-391)
+    {
+        const int tn = E / 16, nit = cdiv_dev(BT, 48) * tn;
+        for (int it = bid; it < nit; it += G)
+            step_gemm_tile<3>(a.xt, a.Cp, a.patch_w, a.Cp, a.patch_b, nullptr, 0, a.pat, E, BT, E, a.Cp, EPI_GELU,
+                              (it / tn) * 48, (it % tn) * 16, 0, smem);
+    }
+    step_barrier(st, xcc, n_xcc, n_xccs, ++round);
+    const int nchunks = (T + a.cs - 1) / a.cs;
+    for (int l = 0; l < a.L; ++l) {
+        const StepLayer& w = a.layer[l];
+        // ---- norm0 -> AdaLN(tcond) -> norm1: one wave per token row
+        for (int it = bid; it * 8 < M; it += G) {
+            const int m = it * 8 + wv;
+            if (m < M)
+                ln_mod_ln_row(l == 0 ? a.pat : a.xres, l == 0 ? a.xmap : nullptr, a.xres, a.hbuf, nullptr,
+                              a.tc_ab + (size_t)l * 2 * E, a.tc_ld, a.tcmap, w.n1w, w.n1b, T, E, m, lane);
+        }
+        step_barrier(st, xcc, n_xcc, n_xccs, ++round);
+        // ---- qkv
+        {
+            const int tn = 3 * E / 16, nit = cdiv_dev(M, 48) * tn;
+            for (int it = bid; it < nit; it += G)
+                step_gemm_tile<3>(a.hbuf, E, w.qkv_w, E, nullptr, nullptr, 0, w.qkv, 3 * E, M, 3 * E, E, EPI_NONE,
+                                  (it / tn) * 48, (it % tn) * 16, 0, smem);
+        }
+        step_barrier(st, xcc, n_xcc, n_xccs, ++round);
+        // ---- cached attention + residual + AdaLN(cond) + norm3
+        {
+            AttnArgs at;
+            at.qkv = w.qkv;
+            at.xres = a.xres;
+            at.h = a.hbuf;
+            at.h3 = nullptr;
+            at.cond_ab = a.cond_ab + (size_t)l * 2 * E;
+            at.cond_ld = a.cond_ld;
+            at.w3 = w.n3w;
+            at.b3 = w.n3b;
+            at.rope_cos = a.rope_cos;
+            at.rope_sin = a.rope_sin;
+            at.kcache = w.kold;
+            at.vcache = w.vold;
+            at.nc = a.cache;
+            at.T = T;
+            at.E = E;
+            at.H = a.H;
+            at.cs = a.cs;
+            at.W = a.W;
+            at.nkmax = a.nkmax;
+            at.causal = a.causal;
+            at.dbg = 0;
+            for (int it = bid; it < nchunks * a.rows; it += G) {
+                __syncthreads();  // (a second item of this workgroup reuses the LDS rows)
+                attn_block_body<true, true, false>(at, it % nchunks, it / nchunks, smem);
+            }
+        }
+        step_barrier(st, xcc, n_xcc, n_xccs, ++round);
+        // ---- MLP up (+ GELU); the workgroups without a tile roll this layer's K / V cache by T frames
+        {
+            const int tn = ME / 16, nit = cdiv_dev(M, 48) * tn;
+            for (int it = bid; it < nit; it += G)
+                step_gemm_tile<3>(a.hbuf, E, w.mlp0_w, E, w.mlp0_b, nullptr, 0, a.mlp, ME, M, ME, E, EPI_GELU,
+                                  (it / tn) * 48, (it % tn) * 16, 0, smem);
+            const int nroll = nit < G ? G - nit : G, rb = nit < G ? bid - nit : bid;
+            if (rb >= 0) {  // MHAttention.roll_cache (transformerv2.py:171-188): flip-flop halves, out of place
+                const size_t total = (size_t)a.cache_rows * a.cache * E;
+                for (size_t idx = (size_t)rb * 512 + tid; idx < total; idx += (size_t)nroll * 512) {
+                    const int c = idx % E, p = (idx / E) % a.cache, r = idx / ((size_t)E * a.cache);
+                    float kv, vv;
+                    if (r >= a.rows) {
+                        kv = w.kold[idx];
+                        vv = w.vold[idx];
+                    } else if (p + T < a.cache) {
+                        kv = w.kold[((size_t)r * a.cache + p + T) * E + c];
+                        vv = w.vold[((size_t)r * a.cache + p + T) * E + c];
+                    } else {
+                        const int t = p + T - a.cache;
+                        kv = w.qkv[((size_t)r * T + t) * 3 * E + E + c];
+                        vv = w.qkv[((size_t)r * T + t) * 3 * E + 2 * E + c];
+                    }
+                    w.knew[idx] = kv;
+                    w.vnew[idx] = vv;
+                }
+            }
+        }
+        step_barrier(st, xcc, n_xcc, n_xccs, ++round);
+        // ---- MLP down + residual
+        {
+            const int tn = E / 16, nit = cdiv_dev(M, 48) * tn;
+            for (int it = bid; it < nit; it += G)
+                step_gemm_tile<3>(a.mlp, ME, w.mlp2_w, ME, w.mlp2_b, a.xres, E, a.xres, E, M, E, ME, EPI_RESIDUAL,
+                                  (it / tn) * 48, (it % tn) * 16, 0, smem);
+        }
+        step_barrier(st, xcc, n_xcc, n_xccs, ++round);
+    }
+    // ---- out_proj + CFG + Euler (+ the token-major latents of the next step)
+    {
+        const int tn = (a.C + 15) / 16, nit = cdiv_dev(BT, 16) * tn;
+        for (int it = bid; it < nit; it += G) {
+            const int tok0 = (it / tn) * 16, n0 = (it % tn) * 16;
+            step_gemm_tile<3>(a.xres, E, a.out_w, E, nullptr, nullptr, 0, nullptr, 0, M, a.C, E, EPI_NONE, tok0, n0, BT, smem);
+            step_tail_finish(a, tok0, n0, smem);
+        }
+    }
 }
 
 }  // namespace
@@ -702,6 +1040,12 @@ struct after_denoiser {
     };
     std::vector<GraphEntry> graphs;
     int use_graph = 0;
+    // persistent streaming step (stream_step_kernel): one launch per cached Euler step.  AFTER_STREAM_PERSIST=0 /
+    // after_denoiser_set_stream_persist(h, 0) keep the launch-per-kernel path.
+    int persist_step = 1, n_cus = 0;
+    StepBarrier* step_bar = nullptr;     // [max_steps]: one barrier state per step of a sample() call
+    unsigned* step_timeout = nullptr;    // pinned host copy of the last call's timeout words (checked at the next call)
+    int step_timeout_n = 0;
 };
 
 namespace {
@@ -1219,6 +1563,12 @@ extern "C" int after_denoiser_create(const after_denoiser_cfg* cfg, const float*
         const char* x6r = getenv("AFTER_GEMM_X6_MINROWS");
         if (x6r) h->x6_min_rows = atoi(x6r);
         if (h->E % 128 != 0) h->fuse_tail = 0;  // the fused GEMM splits K four ways
+        const char* ps = getenv("AFTER_STREAM_PERSIST");
+        if (ps) h->persist_step = atoi(ps) != 0;
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(AFTER_E_HIP);
+        h->n_cus = prop.multiProcessorCount;
     }
     if (hipDeviceSynchronize() != hipSuccess) return fail(AFTER_E_HIP);
 #undef TAKE
@@ -1240,6 +1590,8 @@ extern "C" void after_denoiser_destroy(after_denoiser* h) {
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->ev_out) (void)hipEventDestroy(h->ev_out);
     h->timer.destroy();
+    if (h->step_bar) (void)hipFree(h->step_bar);
+    if (h->step_timeout) (void)hipHostFree(h->step_timeout);
     h->wa.release();
     h->ws.release();
     h->ca.release();
@@ -1323,6 +1675,83 @@ int roll_cache_step(after_denoiser* h, hipStream_t s, int rows, int T, int size,
     return AFTER_OK;
 }
 
+// Streamer.sample (export.py:398-416) with ONE launch per Euler step (stream_step_kernel).  Eligible: the shipped
+// streaming geometry -- eight heads (512 threads = the attention block), finite causal window, K of every Linear a
+// multiple of 128 (the eight k-waves), at most eight layers (the by-value argument block).
+bool step_persist_ok(const after_denoiser* h) {
+    const bool wide = h->W < 0 || !h->cfg.causal;
+    return h->persist_step && h->cache > 0 && !h->timer.enabled && h->x6 != 2 && h->H == 8 && h->L <= 8 && !wide &&
+           h->ME % 128 == 0 && h->Cp == h->C && h->Cp % 16 == 0 && (h->Cp < 128 || h->Cp % 128 == 0) && h->n_cus > 0;
+}
+
+int sample_persistent(after_denoiser* h, hipStream_t s, const float* x0, float* out, int B, int T, int nb_steps) {
+    const int rows = 3 * B, E = h->E, L = h->L;
+    if (h->step_timeout && h->step_timeout_n > 0) {  // the previous call's barriers (complete by stream order or not yet:
+        for (int i = 0; i < h->step_timeout_n; ++i)  //  a late flag is seen one call later)
+            if (h->step_timeout[i * 32]) {
+                h->persist_step = 0;
+                h->step_timeout_n = 0;
+                set_error("persistent streaming step: a device-wide barrier timed out (workgroups not co-resident?); "
+                          "the launch-per-kernel path is selected from now on -- reset the streamer");
+                return AFTER_E_HIP;
+            }
+    }
+    if (!h->step_bar) {
+        AFTER_HIP_CHECK(hipMalloc(&h->step_bar, (size_t)h->max_steps * sizeof(StepBarrier)));
+        AFTER_HIP_CHECK(hipHostMalloc(&h->step_timeout, (size_t)h->max_steps * 32 * sizeof(unsigned), hipHostMallocDefault));
+    }
+    const int nkmax = h->W - 1 + h->cs > h->cs ? h->W - 1 + h->cs : h->cs;
+    size_t lds = attn_lds_bytes(E, h->cs, nkmax);
+    if (lds < 8 * 3 * 256 * sizeof(float)) lds = 8 * 3 * 256 * sizeof(float);
+    static size_t attr = 0;
+    if (lds > attr) {
+        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stream_step_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = lds;
+    }
+    {
+        dim3 grid(cdiv(T, 32), cdiv(h->Cp, 32), B);
+        hipLaunchKernelGGL(to_token_major_kernel, grid, dim3(256), 0, s, x0, h->xt, (const int*)nullptr, h->C, T, h->Cp, 0.f);
+        AFTER_HIP_CHECK(hipGetLastError());
+    }
+    AFTER_HIP_CHECK(hipMemsetAsync(h->step_bar, 0, (size_t)nb_steps * sizeof(StepBarrier), s));
+    const size_t step_stride = (size_t)rows * L * 2 * E;
+    const size_t per = (size_t)h->cache_rows * h->cache * E;
+    for (int i = 0; i < nb_steps; ++i) {
+        StepArgs a;
+        a.rows = rows, a.B = B, a.T = T, a.E = E, a.ME = h->ME, a.C = h->C, a.Cp = h->Cp, a.L = L, a.H = h->H;
+        a.cs = h->cs, a.W = h->W, a.nkmax = nkmax, a.causal = h->cfg.causal, a.cache = h->cache;
+        a.cache_rows = h->cache_rows, a.last_step = i + 1 == nb_steps;
+        a.xt = h->xt, a.pat = h->pat, a.xres = h->xres, a.hbuf = h->hbuf, a.mlp = h->mlp;
+        a.patch_w = h->patch_w, a.patch_b = h->patch_b, a.out_w = h->out_w, a.out_b = h->out_b;
+        a.tc_ab = h->tc_ab, a.tc_ld = L * 2 * E, a.xmap = h->maps, a.tcmap = h->maps + h->ms;
+        a.cond_ab = h->cond_ab + (size_t)i * step_stride, a.cond_ld = L * 2 * E;
+        a.rope_cos = h->rope_cos, a.rope_sin = h->rope_sin;
+        a.xin = i == 0 ? x0 : out, a.xout = out, a.xt_next = i + 1 < nb_steps ? h->xt : nullptr;
+        a.cfg = reinterpret_cast<const float*>(h->dparams);
+        a.bar = h->step_bar + i;
+        const int cur = h->flip[i];
+        for (int l = 0; l < L; ++l) {
+            const LayerW& w = h->layers[l];
+            StepLayer& sl = a.layer[l];
+            sl.qkv_w = w.qkv_w, sl.mlp0_w = w.mlp0_w, sl.mlp0_b = w.mlp0_b, sl.mlp2_w = w.mlp2_w, sl.mlp2_b = w.mlp2_b;
+            sl.n1w = w.n1w, sl.n1b = w.n1b, sl.n3w = w.n3w, sl.n3b = w.n3b;
+            sl.qkv = h->qkv_layers + (size_t)l * h->max_rows * h->max_T * 3 * E;
+            const size_t slot = ((size_t)l * h->cache_steps + i) * 2 * per;
+            sl.kold = h->kcache + slot + cur * per, sl.vold = h->vcache + slot + cur * per;
+            sl.knew = h->kcache + slot + (cur ^ 1) * per, sl.vnew = h->vcache + slot + (cur ^ 1) * per;
+        }
+        hipLaunchKernelGGL(stream_step_kernel, dim3(h->n_cus), dim3(512), lds, s, a);
+        AFTER_HIP_CHECK(hipGetLastError());
+        h->flip[i] = cur ^ 1;
+    }
+    // timeout words -> pinned host memory, looked at when the next call starts
+    AFTER_HIP_CHECK(hipMemcpy2DAsync(h->step_timeout, 32 * sizeof(unsigned), &h->step_bar[0].timeout[0], sizeof(StepBarrier),
+                                     32 * sizeof(unsigned), nb_steps, hipMemcpyDeviceToHost, s));
+    h->step_timeout_n = nb_steps;
+    return AFTER_OK;
+}
+
 // The whole sampler as a sequence of launches on `s` (eager path and graph capture body).
 // With streaming caches (h->cache > 0) this is Streamer.sample of export.py:398-416: step i
 // attends over its own cache slot i, which is rolled by the chunk length after the step.
@@ -1333,6 +1762,13 @@ int sample_enqueue(after_denoiser* h, hipStream_t s, const float* x0, const floa
     const int rows = 3 * B;
     AFTER_TRY(compute_cond_ab(h, s, nb_steps, rows, nullptr, nullptr, nb_steps, cond,
                               h->maps + 2 * h->ms, drop_value));
+    if (step_persist_ok(h)) {
+        AFTER_TRY(sample_persistent(h, s, x0, out, B, T, nb_steps));
+        h->have_last = true;
+        h->last_rows = rows;
+        h->last_T = T;
+        return AFTER_OK;
+    }
     const size_t step_stride = (size_t)rows * h->L * 2 * h->E;
     // Fused tail: out_proj + CFG + Euler in ONE GEMM launch that also leaves the new latents in
     // token-major form for the next step's patchify (instead of GEMM, cfg_euler, to_token_major).
@@ -1471,6 +1907,18 @@ extern "C" int after_denoiser_set_gemm_path(after_denoiser* h, int mode, int min
     if (min_rows > 0) h->x6_min_rows = min_rows;
     for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.exec);  // captured launches bake the path in
     h->graphs.clear();
+    return AFTER_OK;
+}
+
+extern "C" int after_denoiser_set_stream_persist(after_denoiser* h, int enable) {
+    AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
+    h->persist_step = enable != 0;
+    return AFTER_OK;
+}
+
+extern "C" int after_denoiser_stream_persist(after_denoiser* h, int* active) {
+    AFTER_REQUIRE(h && active, AFTER_E_INVALID, "null argument");
+    *active = step_persist_ok(h) ? 1 : 0;
     return AFTER_OK;
 }
 

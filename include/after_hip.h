@@ -130,6 +130,16 @@ int after_denoiser_set_graph(after_denoiser* h, int enable);
 int after_denoiser_set_gemm_path(after_denoiser* h, int mode, int min_rows);
 int after_denoiser_gemm_path(after_denoiser* h, int* mode, int* min_rows);
 
+/* The streaming sampler (after_sample on a handle with K/V caches: Streamer.sample, after_scripts/export.py:398-416)
+ * runs each cached Euler step as ONE persistent launch -- every phase of the network behind a device-wide
+ * barrier inside the kernel -- when the geometry allows it (eight heads, finite causal window, <= 8 layers, Linear
+ * widths multiples of 128, gemm path != 2); otherwise, or with enable = 0 / AFTER_STREAM_PERSIST=0, as the
+ * launch-per-kernel sequence.  Same arithmetic either way.  A barrier that times out (the workgroups could not
+ * all be resident) is reported by the NEXT after_sample call on the handle, which also selects the launch path.
+ * after_denoiser_stream_persist: *active = 1 when after_sample would take the persistent path now. */
+int after_denoiser_set_stream_persist(after_denoiser* h, int enable);
+int after_denoiser_stream_persist(after_denoiser* h, int* active);
+
 /* Streaming KV caches (transformerv2.py:143-204; enabled in the reference by the
  * gin binding at after_scripts/export.py:77-79).  cache_size frames (a multiple of
  * the attention chunk) per layer, per diffusion step, per network row;
