@@ -658,55 +658,88 @@ __global__ __launch_bounds__(256) void roll_cache_kernel(const float* __restrict
 
 
 // =====================================================================================================
-// Persistent streaming step: ONE launch per cached Euler step instead of 33 (Streamer.sample, export.py:398-416).
-// A chunk of the streaming sampler is 4 frames x 3 CFG rows x B streams = 96 token rows at eight streams: every
-// kernel of the step is ~1 us of work behind ~8 us of launch / dependency latency.  Here 256 workgroups (one per
-// CU, 512 threads) walk the step's phases -- patchify | per layer: ln_mod_ln, qkv GEMM, cached attention, MLP-up
-// GEMM (+ the K/V cache roll on the idle workgroups), MLP-down GEMM | out_proj + CFG + Euler -- separated by the
-// XCD-hierarchical device-wide barrier of the microarchitecture guide (scripts/ubench/xcd_barrier.hip: 4.0-4.3 us
-// measured on this part against ~9 us per dependent launch): per-XCC arrival counter -> the XCC's last arriver
-// writes the XCD's L2 back once and arrives at the top counter -> polls it, acquires, publishes the round in its
-// XCC's generation word -> every other workgroup polls that word and acquires once.  Populations per XCC are
-// counted at kernel start (dispatch placement is observed, not promised); every spin is bounded and raises a
-// timeout word the host checks.  The phase bodies are the launch path's own (ln_mod_ln_row, attn_block_body) or
-// its skinny-GEMM scheme (fragments straight from global memory, k-waves summed through LDS in wave order), so the
-// arithmetic -- and the results, bit for bit -- are those of the launch path with AFTER_GEMM_SKINNY=2.
+// Persistent streaming step: ONE launch per cached Euler step instead of 33 (Streamer.sample, export.py:398-416),
+// organised as EIGHT INDEPENDENT XCD-LOCAL PIPELINES.
+//
+// A streaming chunk is 4 frames x 3 CFG rows x B streams (96 token rows at eight streams): every kernel of the
+// launch path is ~1 us of work behind 6 - 9 us of launch / cross-XCD dependency latency, and a device-wide barrier
+// inside one kernel (scripts/ubench/xcd_barrier.hip: 4.0 us; first version of this kernel: 2.2 us + ~6 us per phase
+// of L2-cold operand fetches) does not beat it.  But the network never mixes streams: a clip's three CFG rows only
+// meet in the sampler tail.  So the clips are dealt to the eight XCDs (clip c -> XCD c / cpg) and each XCD runs
+// the whole step for its own rows on its own 32 workgroups:
+//   - activations live in that XCD's L2 from producer to consumer: stores are written through the CU's vector L1,
+//     consumers read with sc1 (agent-scope) loads, which miss the L1 and hit the L2 (~0.3 us) -- no L2 write-back
+//     or invalidate anywhere inside the kernel (scripts/ubench/xcd_local.hip: visibility checked, 0 errors);
+//   - the phases are separated by an XCD-local barrier (arrival counter + generation word in that L2): 1.5 us
+//     (same ubench), no cross-XCD traffic at all;
+//   - every XCD streams all the weights (8 x 69 MB per step out of the memory-side cache instead of 1 x): each
+//     workgroup requests the next GEMM phase's weight fragments BEFORE the barrier in front of it, so that stream
+//     overlaps the dependency latency instead of following it;
+//   - operands are stored as 16 x 16 tiles in MFMA fragment order (activations between phases, and a tiled copy of
+//     the weights): every fragment load / store of a wave is one contiguous 1-KB block.
+// Phases: patchify | per layer: ln_mod_ln, qkv GEMM, cached attention (+ the K / V cache roll on the idle
+// workgroups), MLP-up GEMM, MLP-down GEMM | out_proj + CFG + Euler.  GEMM tiles: 16 columns x all of the XCD's rows
+// (<= 48) per workgroup, the eight waves split K, partial tiles are summed through LDS in wave order.  The
+// arithmetic is the launch path's (same LayerNorm / attention code shape, fp32 MFMA GEMMs with a different but fixed
+// K split), so the results agree with it to fp32 round-off and with the oracle to the same bars.
+// Dispatch placement (workgroup b on XCD b % 8) is observed by a census at kernel start, not assumed: anything but
+// 8 x 32 raises a flag, the kernel returns, and the host falls back to the launch path.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-struct StepBarrier {
+constexpr int kSE = 512, kSME = 2048, kSH = 8;  // the shipped streaming width (embed 512, mlp x 4, 8 heads)
+constexpr int kSGroupRows = 48;                 // token rows one XCD can own (three 16-row blocks)
+
+struct StepSync {
     unsigned arrive[8][32];  // [xcc][0]: arrivals (each word on its own 128-byte line)
-    unsigned gen[8][32];     // [xcc][0]: last completed round, published by the XCC's leader
-    unsigned top[32];        // [0]: XCC leaders that arrived
+    unsigned gen[8][32];     // [xcc][0]: last completed round
     unsigned pop[8][32];     // [xcc][0]: workgroups resident on the XCC
     unsigned census[32];     // [0]: workgroups counted
-    unsigned timeout[32];    // [0]: a spin gave up
+    unsigned fail[32];       // [0]: a spin gave up; [1]: census is not 8 x 32
 };
 
 struct StepLayer {
-    const float *qkv_w, *mlp0_w, *mlp0_b, *mlp2_w, *mlp2_b, *n1w, *n1b, *n3w, *n3b;
-    float* qkv;                 // this layer's [rows * T][3E] (kept for roll_cache)
-    const float *kold, *vold;   // cache half the step attends over
-    float *knew, *vnew;         // the other half: rolled by T frames
+    const float *qkv_wt, *mlp0_wt, *mlp0_b, *mlp2_wt, *mlp2_b, *n1w, *n1b, *n3w, *n3b;  // *_wt: 16 x 16-tiled copies
+    float* qkv;                // this layer's [rows * T][3E], row-major (attention, roll_cache)
+    const float *kold, *vold;  // cache half the step attends over
+    float *knew, *vnew;        // the other half: rolled by T frames
 };
 
 struct StepArgs {
-    int rows, B, T, E, ME, C, Cp, L, H, cs, W, nkmax, causal, cache, cache_rows, last_step;
-    const float* xt;      // token-major latents [B * T][Cp] (this step's input)
-    float *pat, *xres, *hbuf, *mlp;
-    const float *patch_w, *patch_b, *out_w, *out_b;
+    int rows, B, T, C, Cp, L, cs, W, nkmax, cache, cache_rows, cpg;
+    const float* xt;                       // token-major latents [B * T][Cp] (this step's input)
+    float *pat_t, *xres_t, *h_t, *mlp_t;   // tiled, one slice of kSGroupRows rows per XCD
+    const float *patch_wt, *patch_b, *out_wt, *out_b;
     const float* tc_ab;
     int tc_ld;
-    const int *xmap, *tcmap;
+    const int* tcmap;
     const float* cond_ab;  // this step's rows
     int cond_ld;
     const float *rope_cos, *rope_sin;
-    const float* xin;      // [B, C, T]
+    const float* xin;  // [B, C, T]
     float* xout;
-    float* xt_next;        // token-major copy for the next step (nullptr on the last)
-    const float* cfg;      // device CfgParams
-    StepBarrier* bar;
+    float* xt_next;    // token-major copy for the next step (nullptr on the last)
+    const float* cfg;  // device CfgParams
+    StepSync* sync;
+    unsigned long long* trace;  // AFTER_STEP_TRACE: [gridDim][128] wall-clock stamps (100 MHz) around every barrier
     StepLayer layer[8];
 };
+
+// float offset of the 4 channels starting at c (c % 4 == 0) of row lr in a tiled [rows][16 kblocks] buffer: 16 x 16
+// blocks [row block][k block], inside a block element (r, k) at (k / 4) * 64 + r * 4 + k % 4 -- the MFMA fragment of
+// lane r + 16 (k / 4) is the float4 at lane * 4
+__device__ __forceinline__ unsigned t16_off(int lr, int c, int kblocks) {
+    return (unsigned)((((lr >> 4) * kblocks + (c >> 4)) << 8) + (((c & 15) >> 2) << 6) + ((lr & 15) << 2));
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t step_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+
+// sc1 load of 4 floats at float offset `off`: misses the vector L1, served by the XCD's L2
+__device__ __forceinline__ f32x4 ld_l2(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off * 4u, 0, 16));
+}
 
 __device__ __forceinline__ unsigned step_xcc_id() {
     unsigned v;
@@ -714,268 +747,518 @@ __device__ __forceinline__ unsigned step_xcc_id() {
     return v & 7u;
 }
 
-__device__ __forceinline__ bool step_spin(unsigned* word, unsigned want, unsigned* timeout) {
+__device__ __forceinline__ bool step_spin(unsigned* word, unsigned want, unsigned* fail) {
     for (unsigned spins = 0;; ++spins) {
         if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
         __builtin_amdgcn_s_sleep(1);
         if (spins > (1u << 21)) {
-            __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
     }
 }
 
-__device__ __forceinline__ void step_barrier(StepBarrier* st, unsigned xcc, unsigned n_xcc, unsigned n_xccs,
-                                             unsigned round) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have reached the XCD's L2
+// XCD-local barrier (all threads of the workgroup call it; n = workgroups of this XCC)
+__device__ __forceinline__ void step_barrier(StepSync* st, unsigned xcc, unsigned n, unsigned round,
+                                             unsigned long long* trace) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores are in the XCD's L2 (write-through L1)
     __syncthreads();
     if (threadIdx.x == 0) {
+        if (trace) trace[2 * round - 1] = wall_clock64();
         const unsigned ticket = __hip_atomic_fetch_add(&st->arrive[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ticket == round * n_xcc - 1) {  // last arriver of this XCC: the round's leader
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // write the XCD's L2 back once
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(&st->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            step_spin(&st->top[0], round * n_xccs, &st->timeout[0]);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(&st->gen[xcc][0], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            step_spin(&st->gen[xcc][0], round, &st->timeout[0]);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
+        if (ticket == round * n - 1) __hip_atomic_store(&st->gen[xcc][0], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else step_spin(&st->gen[xcc][0], round, &st->fail[0]);
+        if (trace) trace[2 * round] = wall_clock64();
     }
     __syncthreads();
 }
 
-// One [16 MB rows] x [16 columns] tile of C = epi(A W^T + bias): the waves split K (nwk = min(8, K / 16) of them take
-// K / nwk each), load their fragments straight from global memory, and the partial tiles are summed through LDS in
-// wave order (gemm.hip's skinny kernel).  BRANCH > 0: the MB = 3 row blocks are the three CFG branches of the same 16
-// tokens (A row = i * BRANCH + row0 + lane % 16) and the results stay in LDS for step_tail_finish.
+// the next GEMM phase's weight fragments: NT column tiles (tile0, tile0 + 32, ...) x KB k-blocks starting at kb0 of a
+// tiled [N / 16][kblocks][256] weight copy (plain loads: weights are never written)
+template <int NT, int KB>
+__device__ __forceinline__ void step_w_fetch(f32x4 (&wf)[16], const float* __restrict__ wt, int kblocks, int tile0,
+                                             int kb0, int lane, bool active) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int u = 0; u < KB; ++u)
+            wf[j * KB + u] = active ? *reinterpret_cast<const f32x4*>(wt + ((size_t)((tile0 + 32 * j) * kblocks + kb0 + u) << 8) + lane * 4)
+                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// acc[j * MB + i] = (this wave's K slice of) rows 16 i .. 16 i + 15 of A x column tile j of W.  A: tiled buffer read
+// with sc1 loads (`a_kblocks` k-blocks per row block), or -- AROW -- row-major rows `arow0 + min(lane % 16, arows - 1)`
+// of a matrix written before the kernel (the token-major latents of patchify).
+template <int MB, int NT, int KB, bool AROW>
+__device__ __forceinline__ void step_mma(f32x4 (&acc)[NT * MB], const f32x4 (&wf)[16], __amdgpu_buffer_rsrc_t A,
+                                         int a_kblocks, int kb0, int lane, bool active, const float* arow = nullptr,
+                                         int lda = 0) {
+#pragma unroll
+    for (int p = 0; p < NT * MB; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!active) return;
+    constexpr int CH = KB < 4 ? KB : 4;  // k-blocks of A in flight
+#pragma unroll
+    for (int u0 = 0; u0 < KB; u0 += CH) {
+        f32x4 av[CH][MB];
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                if constexpr (AROW) av[u][i] = *reinterpret_cast<const f32x4*>(arow + (size_t)(kb0 + u0 + u) * 16 + (lane >> 4) * 4);
+                else av[u][i] = ld_l2(A, (unsigned)(((i * a_kblocks + kb0 + u0 + u) << 8) + lane * 4));
+            }
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int i = 0; i < MB; ++i)  // W fragment as srcA: the accumulator holds C^T
+                        acc[j * MB + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j * KB + u0 + u][c], av[u][i][c], acc[j * MB + i], 0, 0, 0);
+    }
+}
+
+// the eight waves' partial tiles -> LDS [wave][P][256]; afterwards step_reduced(p) sums tile p in wave order
+template <int P>
+__device__ __forceinline__ void step_partials(const f32x4 (&acc)[P], float* red, int w, int lane) {
+    __syncthreads();  // the previous readers are done with `red`
+#pragma unroll
+    for (int p = 0; p < P; ++p) *reinterpret_cast<f32x4*>(red + (((w * P + p) << 6) + lane) * 4) = acc[p];
+    __syncthreads();
+}
+
+__device__ __forceinline__ f32x4 step_reduced(const float* red, int P, int p, int lane) {
+    f32x4 o = *reinterpret_cast<const f32x4*>(red + ((p << 6) + lane) * 4);
+#pragma unroll
+    for (int q = 1; q < 8; ++q) o += *reinterpret_cast<const f32x4*>(red + ((((q * P + p)) << 6) + lane) * 4);
+    return o;
+}
+
+// ln_mod_ln_row on tiled buffers (E = 512): x = norm0(xin[src]) * (1 + alpha_t) + beta_t -> xres ; h = norm1(x)
+__device__ __forceinline__ void step_ln_row(__amdgpu_buffer_rsrc_t xin, int src_lr, float* __restrict__ xres,
+                                            float* __restrict__ h, int lr, const float* __restrict__ ab,
+                                            const float* __restrict__ w1, const float* __restrict__ b1, int lane) {
+    constexpr int E = kSE, NV = E / 256, KBt = E / 16;
+    f32x4 v[NV], al[NV], be[NV], ww[NV], bb[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = 4 * lane + 256 * i;
+        v[i] = ld_l2(xin, t16_off(src_lr, c, KBt));
+        al[i] = *reinterpret_cast<const f32x4*>(ab + c);
+        be[i] = *reinterpret_cast<const f32x4*>(ab + E + c);
+        ww[i] = *reinterpret_cast<const f32x4*>(w1 + c);
+        bb[i] = *reinterpret_cast<const f32x4*>(b1 + c);
+    }
+    auto stats = [&](float& mean, float& rstd) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        mean = wave_sum(s) / (float)E;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+        rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + 1e-5f);
+    };
+    float mean, rstd;
+    stats(mean, rstd);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i].x = (v[i].x - mean) * rstd * (1.0f + al[i].x) + be[i].x;
+        v[i].y = (v[i].y - mean) * rstd * (1.0f + al[i].y) + be[i].y;
+        v[i].z = (v[i].z - mean) * rstd * (1.0f + al[i].z) + be[i].z;
+        v[i].w = (v[i].w - mean) * rstd * (1.0f + al[i].w) + be[i].w;
+    }
+    stats(mean, rstd);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const unsigned o = t16_off(lr, 4 * lane + 256 * i, KBt);
+        *reinterpret_cast<f32x4*>(xres + o) = v[i];
+        f32x4 y;
+        y.x = (v[i].x - mean) * rstd * ww[i].x + bb[i].x;
+        y.y = (v[i].y - mean) * rstd * ww[i].y + bb[i].y;
+        y.z = (v[i].z - mean) * rstd * ww[i].z + bb[i].z;
+        y.w = (v[i].w - mean) * rstd * ww[i].w + bb[i].w;
+        *reinterpret_cast<f32x4*>(h + o) = y;
+    }
+}
+
+// attn_block_body<CACHE, PRELOAD> for the persistent step: chunk bx of network row rg (local rows lr0 ..): q / k / v
+// through sc1 loads from this layer's qkv, the cached frames from the K / V ring (written by an earlier launch),
+// residual stream and h in the XCD's tiled buffers.  smem: [cs][E + 4] | per-wave cos, sin [nkmax][16].
+__device__ __forceinline__ void step_attention(const StepArgs& a, const StepLayer& L, const float* __restrict__ cond_ab, int rg,
+                                               int lr0, int bx, float* smem, __amdgpu_buffer_rsrc_t qkvr,
+                                               __amdgpu_buffer_rsrc_t xr, float* __restrict__ xres, float* __restrict__ hout) {
+    constexpr int NKMAX = kAttnKeyBlock, E = kSE, H = kSH, KBt = E / 16, ld = E + 4;
+    const int T = a.T, cs = a.cs, W = a.W, nc = a.cache;
+    const int tid = threadIdx.x, lane = tid & 63, hw = tid >> 6;
+    const int grp = lane >> 4, d4 = (lane & 15) * 4;
+    const int i0 = bx * cs, e = min(i0 + cs, T), nq = e - i0;
+    const int a0 = nc + i0;
+    const int lo_c = min(a0, max(0, a0 - W + 1));
+    const int nk = nc + e - lo_c;
+    const unsigned rowbase = (unsigned)rg * T;
+    float* const rc = smem + cs * ld + hw * (2 * a.nkmax * 16);
+    float* const rs = rc + a.nkmax * 16;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 tc0 = z4, tc1 = z4, ts0 = z4, ts1 = z4;
+    if (lane < nk * 4) {
+        tc0 = *reinterpret_cast<const float4*>(a.rope_cos + (size_t)lo_c * 16 + lane * 4);
+        ts0 = *reinterpret_cast<const float4*>(a.rope_sin + (size_t)lo_c * 16 + lane * 4);
+    }
+    if (lane + 64 < nk * 4) {
+        tc1 = *reinterpret_cast<const float4*>(a.rope_cos + (size_t)lo_c * 16 + (lane + 64) * 4);
+        ts1 = *reinterpret_cast<const float4*>(a.rope_sin + (size_t)lo_c * 16 + (lane + 64) * 4);
+    }
+    const float* abp = cond_ab + (size_t)rg * a.cond_ld;
+    constexpr int NV = E / 256;
+    float4 al[NV], be[NV], ww[NV], bb[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = 4 * lane + 256 * i;
+        al[i] = *reinterpret_cast<const float4*>(abp + c);
+        be[i] = *reinterpret_cast<const float4*>(abp + E + c);
+        ww[i] = *reinterpret_cast<const float4*>(L.n3w + c);
+        bb[i] = *reinterpret_cast<const float4*>(L.n3b + c);
+    }
+    auto as4 = [](f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
+    for (int qb = 0; qb < nq; qb += 4) {
+        const int qi = qb + grp;
+        const bool qok = qi < nq;
+        const int qic = qok ? qi : nq - 1;
+        const int ja = a0 + qic;
+        const int lo_row = min(a0, max(0, ja - W + 1));
+        float4 q4 = as4(ld_l2(qkvr, (rowbase + i0 + qic) * 3u * E + hw * 64 + d4));
+        const float4 x4 = as4(ld_l2(xr, t16_off(lr0 + i0 + qic, hw * 64 + d4, KBt)));
+        float mrun = -INFINITY, sum = 0.f;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+        for (int kb = 0; kb < nk; kb += NKMAX) {
+            float4 k4[NKMAX], v4[NKMAX];
+#pragma unroll
+            for (int j = 0; j < NKMAX; ++j) {  // all K and V rows requested unconditionally (slot clamped, masked later)
+                const int pos = lo_c + min(kb + j, nk - 1);
+                if (pos < nc) {
+                    k4[j] = *reinterpret_cast<const float4*>(L.kold + ((size_t)rg * nc + pos) * E + hw * 64 + d4);
+                    v4[j] = *reinterpret_cast<const float4*>(L.vold + ((size_t)rg * nc + pos) * E + hw * 64 + d4);
+                } else {
+                    const unsigned off = (rowbase + (pos - nc)) * 3u * E + E + hw * 64 + d4;
+                    k4[j] = as4(ld_l2(qkvr, off));
+                    v4[j] = as4(ld_l2(qkvr, off + E));
+                }
+            }
+            if (qb == 0 && kb == 0) {  // K / V requests are in flight: now land the RoPE slice
+                if (lane < nk * 4) {
+                    *reinterpret_cast<float4*>(rc + lane * 4) = tc0;
+                    *reinterpret_cast<float4*>(rs + lane * 4) = ts0;
+                }
+                if (lane + 64 < nk * 4) {
+                    *reinterpret_cast<float4*>(rc + (lane + 64) * 4) = tc1;
+                    *reinterpret_cast<float4*>(rs + (lane + 64) * 4) = ts1;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            if (kb == 0) q4 = rope4(q4, rc, rs, ja - lo_c, d4);
+            float sc[NKMAX];
+            float mx = mrun;
+#pragma unroll
+            for (int j = 0; j < NKMAX; ++j) {
+                const int pos = lo_c + min(kb + j, nk - 1);
+                const float4 kr = rope4(k4[j], rc, rs, pos - lo_c, d4);
+                float dot = q4.x * kr.x + q4.y * kr.y + q4.z * kr.z + q4.w * kr.w;
+                dot = group16_sum(dot);
+                sc[j] = (kb + j < nk && pos >= lo_row) ? dot * 0.125f : -INFINITY;
+                mx = fmaxf(mx, sc[j]);
+            }
+            const float resc = expf(mrun - mx);
+            sum *= resc;
+            o.x *= resc;
+            o.y *= resc;
+            o.z *= resc;
+            o.w *= resc;
+            mrun = mx;
+#pragma unroll
+            for (int j = 0; j < NKMAX; ++j) {
+                const float p = expf(sc[j] - mx);
+                sum += p;
+                o.x += p * v4[j].x;
+                o.y += p * v4[j].y;
+                o.z += p * v4[j].z;
+                o.w += p * v4[j].w;
+            }
+        }
+        const float inv = 1.0f / sum;
+        if (qok) {
+            float4 res;
+            res.x = o.x * inv + x4.x;
+            res.y = o.y * inv + x4.y;
+            res.z = o.z * inv + x4.z;
+            res.w = o.w * inv + x4.w;
+            *reinterpret_cast<float4*>(smem + qi * ld + hw * 64 + d4) = res;
+        }
+    }
+    __syncthreads();
+    // ---- AdaLN(cond) + norm3, one wave per row
+    for (int qi = hw; qi < nq; qi += H) {
+        float4 v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(smem + qi * ld + 4 * lane + 256 * i);
+        auto stats = [&](float& mean, float& rstd) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            mean = wave_sum(s) / (float)E;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+                q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+            rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + 1e-5f);
+        };
+        float mean, rstd;
+        stats(mean, rstd);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i].x = (v[i].x - mean) * rstd * (1.0f + al[i].x) + be[i].x;
+            v[i].y = (v[i].y - mean) * rstd * (1.0f + al[i].y) + be[i].y;
+            v[i].z = (v[i].z - mean) * rstd * (1.0f + al[i].z) + be[i].z;
+            v[i].w = (v[i].w - mean) * rstd * (1.0f + al[i].w) + be[i].w;
+        }
+        stats(mean, rstd);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const unsigned off = t16_off(lr0 + i0 + qi, 4 * lane + 256 * i, KBt);
+            *reinterpret_cast<float4*>(xres + off) = v[i];
+            float4 y;
+            y.x = (v[i].x - mean) * rstd * ww[i].x + bb[i].x;
+            y.y = (v[i].y - mean) * rstd * ww[i].y + bb[i].y;
+            y.z = (v[i].z - mean) * rstd * ww[i].z + bb[i].z;
+            y.w = (v[i].w - mean) * rstd * ww[i].w + bb[i].w;
+            *reinterpret_cast<float4*>(hout + off) = y;
+        }
+    }
+}
+
 template <int MB>
-__device__ __forceinline__ void step_gemm_tile(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
-                                               const float* __restrict__ bias, const float* __restrict__ R, int ldr,
-                                               float* __restrict__ Cc, int ldc, int M, int N, int K, int epi, int row0,
-                                               int n0, int branch, float* red) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row = lane & 15, kq = lane >> 4;
-    const int nwk = K >= 128 ? 8 : K / 16, Kw = K / nwk;
-    f32x4 acc[MB];
-#pragma unroll
-    for (int i = 0; i < MB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (w < nwk) {
-        const float* wp = W + (size_t)min(n0 + row, N - 1) * ldw + w * Kw + kq * 4;
-        const float* ap[MB];
-#pragma unroll
-        for (int i = 0; i < MB; ++i) {
-            const int gm = branch > 0 ? i * branch + min(row0 + row, branch - 1) : min(row0 + i * 16 + row, M - 1);
-            ap[i] = A + (size_t)gm * lda + w * Kw + kq * 4;
-        }
-        constexpr int U = 4;  // 16-deep k-blocks in flight per wave
-        for (int kb = 0; kb < Kw; kb += 16 * U) {
-            f32x4 bw[U], av[U][MB];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int k = kb + 16 * u;
-                if (k < Kw) {
-                    bw[u] = *reinterpret_cast<const f32x4*>(wp + k);
-#pragma unroll
-                    for (int i = 0; i < MB; ++i) av[u][i] = *reinterpret_cast<const f32x4*>(ap[i] + k);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (kb + 16 * u < Kw) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-#pragma unroll
-                        for (int i = 0; i < MB; ++i)  // W fragment as srcA: the accumulator holds C^T
-                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[u][c], av[u][i][c], acc[i], 0, 0, 0);
-                }
-            }
-        }
-    }
-    __syncthreads();  // the previous item's readers are done with `red`
-#pragma unroll
-    for (int i = 0; i < MB; ++i) *reinterpret_cast<f32x4*>(red + ((w * MB + i) * 64 + lane) * 4) = acc[i];
-    __syncthreads();
-    if (branch > 0) return;
-    // wave w finalises row block w: lane owns row 16 w + lane % 16, columns n0 + 4 (lane / 16) + r
-    const int gn = n0 + 4 * kq;
-    for (int i = w; i < MB; i += 8) {
-        f32x4 o = *reinterpret_cast<const f32x4*>(red + (i * 64 + lane) * 4);
-#pragma unroll
-        for (int q = 1; q < 8; ++q) o += *reinterpret_cast<const f32x4*>(red + ((q * MB + i) * 64 + lane) * 4);
-        const int gm = row0 + i * 16 + row;
-        if (gm >= M) continue;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (gn + r >= N) continue;
-            float v = o[r] + (bias ? bias[gn + r] : 0.f);
-            if (epi == EPI_GELU) v = gelu_erf(v);
-            if (epi == EPI_RESIDUAL) v += R[(size_t)gm * ldr + gn + r];
-            Cc[(size_t)gm * ldc + gn + r] = v;
-        }
-    }
-}
-
-// CFG combine + Euler update + both output layouts for the 16 tokens x 16 channels whose three branch tiles
-// step_gemm_tile<3>(branch = B T) left in LDS (model.py:749-759, 777-783; as gemm.hip's fused tail)
-__device__ __forceinline__ void step_tail_finish(const StepArgs& a, int tok0, int n0, const float* red) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    if ((tid >> 6) != 0) return;
-    const int BT = a.B * a.T, N = a.C;
-    f32x4 d[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        d[i] = *reinterpret_cast<const f32x4*>(red + (i * 64 + lane) * 4);
-#pragma unroll
-        for (int q = 1; q < 8; ++q) d[i] += *reinterpret_cast<const f32x4*>(red + ((q * 3 + i) * 64 + lane) * 4);
-    }
-    const int tok = tok0 + (lane & 15);
-    if (tok >= BT) return;
-    const float total = a.cfg[0], factor = a.cfg[1], dt = a.cfg[2];
-    const int bq = tok / a.T, t = tok - bq * a.T;
-    const int gn = n0 + 4 * (lane >> 4);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int n = gn + r;
-        if (n >= N) continue;
-        const float bo = a.out_b ? a.out_b[n] : 0.f;
-        const float dfull = d[0][r] + bo, dmid = d[1][r] + bo, dnone = d[2][r] + bo;
-        const float v = dnone + total * (dmid + factor * (dfull - dmid) - dnone);
-        const size_t o = ((size_t)bq * N + n) * a.T + t;
-        const float xn = a.xin[o] + v * dt;
-        a.xout[o] = xn;
-        if (a.xt_next) a.xt_next[(size_t)tok * a.Cp + n] = xn;
-    }
-}
-
 __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ unsigned s_n, s_nx;
-    StepBarrier* st = a.bar;
+    __shared__ unsigned s_n, s_rank, s_bad;
+    constexpr int E = kSE, ME = kSME, KBE = E / 16, KBM = ME / 16;
+    StepSync* st = a.sync;
     const unsigned xcc = step_xcc_id(), nb = gridDim.x;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) {  // census: workgroups per XCC
-        __hip_atomic_fetch_add(&st->pop[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) {  // census: workgroups per XCC, this workgroup's rank on its XCC
+        s_rank = __hip_atomic_fetch_add(&st->pop[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&st->census[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        step_spin(&st->census[0], nb, &st->timeout[0]);
-        unsigned nx = 0;
+        step_spin(&st->census[0], nb, &st->fail[0]);
+        unsigned bad = 0;
         for (int x = 0; x < 8; ++x)
-            nx += __hip_atomic_load(&st->pop[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
-        s_n = __hip_atomic_load(&st->pop[xcc][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_nx = nx;
+            bad |= __hip_atomic_load(&st->pop[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 32u;
+        if (bad) __hip_atomic_store(&st->fail[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_n = 32;
+        s_bad = bad;
     }
     __syncthreads();
-    const unsigned n_xcc = s_n, n_xccs = s_nx;
+    if (s_bad) return;  // (every workgroup reads the same populations: all of them leave)
+    const unsigned n = s_n;
+    const int rank = __builtin_amdgcn_readfirstlane((int)s_rank), g = (int)xcc;
     unsigned round = 0;
-    const int E = a.E, ME = a.ME, T = a.T, M = a.rows * T, BT = a.B * T;
-    const int bid = blockIdx.x, G = gridDim.x;
+    unsigned long long* trace = a.trace ? a.trace + (size_t)blockIdx.x * 128 : nullptr;
+    if (trace && tid == 0) trace[0] = wall_clock64();
 
-    // ---- patchify_and_embed: pat = GELU(xt patch_w^T + b)   (transformerv2.py:387-391)
-    {
-        const int tn = E / 16, nit = cdiv_dev(BT, 48) * tn;
-        for (int it = bid; it < nit; it += G)
-            step_gemm_tile<3>(a.xt, a.Cp, a.patch_w, a.Cp, a.patch_b, nullptr, 0, a.pat, E, BT, E, a.Cp, EPI_GELU,
-                              (it / tn) * 48, (it % tn) * 16, 0, smem);
+    // this XCD's clips [c0, c0 + nclip), local token rows lm = (branch * cpg + clip) * T + t
+    const int T = a.T, B = a.B, cpg = a.cpg, ct = cpg * T;
+    const int c0 = g * cpg, nclip = min(cpg, B - c0);
+    // MHAttention.roll_cache (transformerv2.py:171-188) for this XCD's `nown` network rows and the provisioned-but-unused
+    // cache rows r = rows + g + 8 q (copied through): flip-flop halves, out of place; workgroup rb of nroll
+    auto roll = [&](const StepLayer& Lw, __amdgpu_buffer_rsrc_t qkv_r, int nown, int rb, int nroll) {
+        const int nc = a.cache, per4 = nc * E / 4;
+        const int nextra = a.cache_rows - a.rows > g ? (a.cache_rows - a.rows - g + 7) / 8 : 0;
+        for (int idx = rb * 512 + tid; idx < (nown + nextra) * per4; idx += nroll * 512) {
+            const int q = idx / per4, e4 = idx - q * per4, p = e4 / (E / 4), c = (e4 - p * (E / 4)) * 4;
+            const bool own = q < nown;
+            int rg;
+            if (own) {
+                const int br = q / nclip;
+                rg = br * B + c0 + (q - br * nclip);
+            } else {
+                rg = a.rows + g + 8 * (q - nown);
+            }
+            const size_t dst = ((size_t)rg * nc + p) * E + c;
+            f32x4 kv, vv;
+            if (!own) {
+                kv = *reinterpret_cast<const f32x4*>(Lw.kold + dst);
+                vv = *reinterpret_cast<const f32x4*>(Lw.vold + dst);
+            } else if (p + T < nc) {
+                kv = *reinterpret_cast<const f32x4*>(Lw.kold + dst + (size_t)T * E);
+                vv = *reinterpret_cast<const f32x4*>(Lw.vold + dst + (size_t)T * E);
+            } else {
+                const unsigned off = ((unsigned)rg * T + (p + T - nc)) * 3u * E + E + c;
+                kv = ld_l2(qkv_r, off);
+                vv = ld_l2(qkv_r, off + E);
+            }
+            *reinterpret_cast<f32x4*>(Lw.knew + dst) = kv;
+            *reinterpret_cast<f32x4*>(Lw.vnew + dst) = vv;
+        }
+    };
+    if (nclip <= 0) {  // an XCD without clips (barriers are per XCD: nothing to wait for) only copies its unused cache rows
+        for (int l = 0; l < a.L; ++l) roll(a.layer[l], step_rsrc(a.layer[l].qkv), 0, rank, (int)n);
+        return;
     }
-    step_barrier(st, xcc, n_xcc, n_xccs, ++round);
+    const int Mg = 3 * ct;
+    float* const pat = a.pat_t + (size_t)g * kSGroupRows * E;
+    float* const xres = a.xres_t + (size_t)g * kSGroupRows * E;
+    float* const hb = a.h_t + (size_t)g * kSGroupRows * E;
+    float* const mlp = a.mlp_t + (size_t)g * kSGroupRows * ME;
+    const __amdgpu_buffer_rsrc_t pat_r = step_rsrc(pat), xres_r = step_rsrc(xres), hb_r = step_rsrc(hb), mlp_r = step_rsrc(mlp);
+    float* const red = smem;
+    f32x4 wf[16];  // weight fragments of the next GEMM phase (requested one barrier early)
+
+    // ---- patchify_and_embed: pat = GELU(xt patch_w^T + b) for the XCD's ct clip tokens (transformerv2.py:387-391)
+    {
+        const int kbp = a.Cp / 16;
+        step_w_fetch<1, 1>(wf, a.patch_wt, kbp, rank, w, lane, w < kbp);
+        f32x4 acc[1];
+        const float* arow = a.xt + (size_t)(c0 * T + min(lane & 15, nclip * T - 1)) * a.Cp;
+        step_mma<1, 1, 1, true>(acc, wf, pat_r, 0, w, lane, w < kbp, arow, a.Cp);
+        step_w_fetch<3, 4>(wf, a.layer[0].qkv_wt, KBE, rank, 4 * w, lane, true);
+        step_partials<1>(acc, red, w, lane);
+        if (w == 0) {
+            f32x4 o = step_reduced(red, 1, 0, lane);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.patch_b + 16 * rank + 4 * (lane >> 4));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r] + bv[r]);
+            *reinterpret_cast<f32x4*>(pat + ((size_t)rank << 8) + lane * 4) = o;
+        }
+    }
+    step_barrier(st, xcc, n, ++round, trace);
     const int nchunks = (T + a.cs - 1) / a.cs;
     for (int l = 0; l < a.L; ++l) {
-        const StepLayer& w = a.layer[l];
-        // ---- norm0 -> AdaLN(tcond) -> norm1: one wave per token row
-        for (int it = bid; it * 8 < M; it += G) {
-            const int m = it * 8 + wv;
-            if (m < M)
-                ln_mod_ln_row(l == 0 ? a.pat : a.xres, l == 0 ? a.xmap : nullptr, a.xres, a.hbuf, nullptr,
-                              a.tc_ab + (size_t)l * 2 * E, a.tc_ld, a.tcmap, w.n1w, w.n1b, T, E, m, lane);
+        const StepLayer& Lw = a.layer[l];
+        const __amdgpu_buffer_rsrc_t qkv_r = step_rsrc(Lw.qkv);
+        // ---- norm0 -> AdaLN(tcond) -> norm1: one wave per token row, rows dealt round-robin to the workgroups
+        for (int lm = rank + (int)n * w; lm < Mg; lm += (int)n * 8) {
+            const int br = lm / ct, rem = lm - br * ct, cl = rem / T, t = rem - cl * T;
+            if (cl < nclip) {
+                const int rg = br * B + c0 + cl;
+                const float* ab = a.tc_ab + ((size_t)a.tcmap[rg] * T + t) * a.tc_ld + (size_t)l * 2 * E;
+                step_ln_row(l == 0 ? pat_r : xres_r, l == 0 ? rem : lm, xres, hb, lm, ab, Lw.n1w, Lw.n1b, lane);
+            }
         }
-        step_barrier(st, xcc, n_xcc, n_xccs, ++round);
-        // ---- qkv
+        step_barrier(st, xcc, n, ++round, trace);
+        // ---- qkv: column tiles rank, rank + 32, rank + 64
         {
-            const int tn = 3 * E / 16, nit = cdiv_dev(M, 48) * tn;
-            for (int it = bid; it < nit; it += G)
-                step_gemm_tile<3>(a.hbuf, E, w.qkv_w, E, nullptr, nullptr, 0, w.qkv, 3 * E, M, 3 * E, E, EPI_NONE,
-                                  (it / tn) * 48, (it % tn) * 16, 0, smem);
+            f32x4 acc[3 * MB];
+            step_mma<MB, 3, 4, false>(acc, wf, hb_r, KBE, 4 * w, lane, true);
+            step_w_fetch<4, 4>(wf, Lw.mlp0_wt, KBE, rank, 4 * w, lane, true);
+            step_partials<3 * MB>(acc, red, w, lane);
+            for (int p = w; p < 3 * MB; p += 8) {
+                const int j = p / MB, i = p - j * MB;
+                const f32x4 o = step_reduced(red, 3 * MB, p, lane);
+                const int lm = 16 * i + (lane & 15);
+                const int br = lm / ct, rem = lm - br * ct, cl = rem / T, t = rem - cl * T;
+                if (lm < Mg && cl < nclip)
+                    *reinterpret_cast<f32x4*>(Lw.qkv + ((size_t)(br * B + c0 + cl) * T + t) * 3 * E + 16 * (rank + 32 * j) + 4 * (lane >> 4)) = o;
+            }
         }
-        step_barrier(st, xcc, n_xcc, n_xccs, ++round);
-        // ---- cached attention + residual + AdaLN(cond) + norm3
+        step_barrier(st, xcc, n, ++round, trace);
+        // ---- cached attention + residual + AdaLN(cond) + norm3 (one workgroup per chunk of a network row); the
+        //      other workgroups roll this layer's K / V ring by T frames (MHAttention.roll_cache,
+        //      transformerv2.py:171-188: flip-flop halves, out of place)
         {
-            AttnArgs at;
-            at.qkv = w.qkv;
-            at.xres = a.xres;
-            at.h = a.hbuf;
-            at.h3 = nullptr;
-            at.cond_ab = a.cond_ab + (size_t)l * 2 * E;
-            at.cond_ld = a.cond_ld;
-            at.w3 = w.n3w;
-            at.b3 = w.n3b;
-            at.rope_cos = a.rope_cos;
-            at.rope_sin = a.rope_sin;
-            at.kcache = w.kold;
-            at.vcache = w.vold;
-            at.nc = a.cache;
-            at.T = T;
-            at.E = E;
-            at.H = a.H;
-            at.cs = a.cs;
-            at.W = a.W;
-            at.nkmax = a.nkmax;
-            at.causal = a.causal;
-            at.dbg = 0;
-            for (int it = bid; it < nchunks * a.rows; it += G) {
+            const int nitems = 3 * nclip * nchunks;
+            for (int it = rank; it < nitems; it += (int)n) {
+                const int q = it / nchunks, bx = it - q * nchunks, br = q / nclip, cl = q - br * nclip;
                 __syncthreads();  // (a second item of this workgroup reuses the LDS rows)
-                attn_block_body<true, true, false>(at, it % nchunks, it / nchunks, smem);
+                step_attention(a, Lw, a.cond_ab + (size_t)l * 2 * E, br * B + c0 + cl, br * ct + cl * T, bx, smem, qkv_r, xres_r,
+                               xres, hb);
+            }
+            const int nroll = nitems < (int)n ? (int)n - nitems : (int)n, rb = nitems < (int)n ? rank - nitems : rank;
+            if (rb >= 0) roll(Lw, qkv_r, 3 * nclip, rb, nroll);
+        }
+        step_barrier(st, xcc, n, ++round, trace);
+        // ---- MLP up + GELU: column tiles rank + 32 j, j < 4
+        {
+            f32x4 acc[4 * MB];
+            step_mma<MB, 4, 4, false>(acc, wf, hb_r, KBE, 4 * w, lane, true);
+            step_w_fetch<1, 16>(wf, Lw.mlp2_wt, KBM, rank, 16 * w, lane, true);
+            step_partials<4 * MB>(acc, red, w, lane);
+            for (int p = w; p < 4 * MB; p += 8) {
+                const int j = p / MB, i = p - j * MB, tile = rank + 32 * j;
+                f32x4 o = step_reduced(red, 4 * MB, p, lane);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(Lw.mlp0_b + 16 * tile + 4 * (lane >> 4));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r] + bv[r]);
+                *reinterpret_cast<f32x4*>(mlp + ((size_t)(i * KBM + tile) << 8) + lane * 4) = o;
             }
         }
-        step_barrier(st, xcc, n_xcc, n_xccs, ++round);
-        // ---- MLP up (+ GELU); the workgroups without a tile roll this layer's K / V cache by T frames
+        step_barrier(st, xcc, n, ++round, trace);
+        // ---- MLP down + residual: column tile rank
         {
-            const int tn = ME / 16, nit = cdiv_dev(M, 48) * tn;
-            for (int it = bid; it < nit; it += G)
-                step_gemm_tile<3>(a.hbuf, E, w.mlp0_w, E, w.mlp0_b, nullptr, 0, a.mlp, ME, M, ME, E, EPI_GELU,
-                                  (it / tn) * 48, (it % tn) * 16, 0, smem);
-            const int nroll = nit < G ? G - nit : G, rb = nit < G ? bid - nit : bid;
-            if (rb >= 0) {  // MHAttention.roll_cache (transformerv2.py:171-188): flip-flop halves, out of place
-                const size_t total = (size_t)a.cache_rows * a.cache * E;
-                for (size_t idx = (size_t)rb * 512 + tid; idx < total; idx += (size_t)nroll * 512) {
-                    const int c = idx % E, p = (idx / E) % a.cache, r = idx / ((size_t)E * a.cache);
-                    float kv, vv;
-                    if (r >= a.rows) {
-                        kv = w.kold[idx];
-                        vv = w.vold[idx];
-                    } else if (p + T < a.cache) {
-                        kv = w.kold[((size_t)r * a.cache + p + T) * E + c];
-                        vv = w.vold[((size_t)r * a.cache + p + T) * E + c];
-                    } else {
-                        const int t = p + T - a.cache;
-                        kv = w.qkv[((size_t)r * T + t) * 3 * E + E + c];
-                        vv = w.qkv[((size_t)r * T + t) * 3 * E + 2 * E + c];
-                    }
-                    w.knew[idx] = kv;
-                    w.vnew[idx] = vv;
-                }
+            f32x4 acc[MB];
+            step_mma<MB, 1, 16, false>(acc, wf, mlp_r, KBM, 16 * w, lane, true);
+            if (l + 1 < a.L) step_w_fetch<3, 4>(wf, a.layer[l + 1].qkv_wt, KBE, rank, 4 * w, lane, true);
+            else step_w_fetch<1, 4>(wf, a.out_wt, KBE, min(rank, a.C / 16 - 1), 4 * w, lane, true);
+            step_partials<MB>(acc, red, w, lane);
+            for (int p = w; p < MB; p += 8) {
+                f32x4 o = step_reduced(red, MB, p, lane);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(Lw.mlp2_b + 16 * rank + 4 * (lane >> 4));
+                const unsigned off = (unsigned)(((p * KBE + rank) << 8) + lane * 4);
+                const f32x4 rv = ld_l2(xres_r, off);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = o[r] + bv[r] + rv[r];
+                *reinterpret_cast<f32x4*>(xres + off) = o;
             }
         }
-        step_barrier(st, xcc, n_xcc, n_xccs, ++round);
-        // ---- MLP down + residual
-        {
-            const int tn = E / 16, nit = cdiv_dev(M, 48) * tn;
-            for (int it = bid; it < nit; it += G)
-                step_gemm_tile<3>(a.mlp, ME, w.mlp2_w, ME, w.mlp2_b, a.xres, E, a.xres, E, M, E, ME, EPI_RESIDUAL,
-                                  (it / tn) * 48, (it % tn) * 16, 0, smem);
-        }
-        step_barrier(st, xcc, n_xcc, n_xccs, ++round);
+        step_barrier(st, xcc, n, ++round, trace);
     }
-    // ---- out_proj + CFG + Euler (+ the token-major latents of the next step)
-    {
-        const int tn = (a.C + 15) / 16, nit = cdiv_dev(BT, 16) * tn;
-        for (int it = bid; it < nit; it += G) {
-            const int tok0 = (it / tn) * 16, n0 = (it % tn) * 16;
-            step_gemm_tile<3>(a.xres, E, a.out_w, E, nullptr, nullptr, 0, nullptr, 0, M, a.C, E, EPI_NONE, tok0, n0, BT, smem);
-            step_tail_finish(a, tok0, n0, smem);
+    // ---- out_proj + CFG + Euler (+ the token-major latents of the next step): column tile rank < C / 16
+    if (rank < a.C / 16) {
+        f32x4 acc[MB];
+        step_mma<MB, 1, 4, false>(acc, wf, xres_r, KBE, 4 * w, lane, true);
+        step_partials<MB>(acc, red, w, lane);
+        float* const outt = red + 8 * MB * 256;  // [MB * 16 rows][16 columns]
+        for (int p = w; p < MB; p += 8) {
+            const f32x4 o = step_reduced(red, MB, p, lane);
+            *reinterpret_cast<f32x4*>(outt + (16 * p + (lane & 15)) * 16 + 4 * (lane >> 4)) = o;
+        }
+        __syncthreads();
+        if (tid < nclip * T * 16) {  // model.py:749-759, 777-783
+            const int tok = tid >> 4, col = tid & 15, nn = 16 * rank + col;
+            const float bo = a.out_b ? a.out_b[nn] : 0.f;
+            const float dfull = outt[tok * 16 + col] + bo, dmid = outt[(ct + tok) * 16 + col] + bo,
+                        dnone = outt[(2 * ct + tok) * 16 + col] + bo;
+            const float total = a.cfg[0], factor = a.cfg[1], dt = a.cfg[2];
+            const float v = dnone + total * (dmid + factor * (dfull - dmid) - dnone);
+            const int cl = tok / T, t = tok - cl * T;
+            const size_t o = ((size_t)(c0 + cl) * a.C + nn) * T + t;
+            const float xn = a.xin[o] + v * dt;
+            a.xout[o] = xn;
+            if (a.xt_next) a.xt_next[((size_t)(c0 + cl) * T + t) * a.Cp + nn] = xn;
         }
     }
+    if (trace && tid == 0) {
+        trace[2 * round + 1] = wall_clock64();
+        trace[127] = xcc;
+    }
+}
+
+// W [N][K] (row stride ldw) -> 16 x 16 tiles [N / 16][K / 16][256] in MFMA fragment order (t16_off)
+__global__ __launch_bounds__(256) void tile16_kernel(const float* __restrict__ W, int ldw, float* __restrict__ out, int N, int K) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // one float4 of the output
+    if (idx >= (size_t)N * K / 4) return;
+    const int l = idx & 63;
+    const size_t blk = idx >> 6;
+    const int kb = blk % (K / 16), tile = blk / (K / 16);
+    const int r = l & 15, kq = l >> 4;
+    *reinterpret_cast<f32x4*>(out + idx * 4) = *reinterpret_cast<const f32x4*>(W + (size_t)(16 * tile + r) * ldw + 16 * kb + 4 * kq);
 }
 
 }  // namespace
@@ -1043,9 +1326,17 @@ struct after_denoiser {
     // persistent streaming step (stream_step_kernel): one launch per cached Euler step.  AFTER_STREAM_PERSIST=0 /
     // after_denoiser_set_stream_persist(h, 0) keep the launch-per-kernel path.
     int persist_step = 1, n_cus = 0;
-    StepBarrier* step_bar = nullptr;     // [max_steps]: one barrier state per step of a sample() call
-    unsigned* step_timeout = nullptr;    // pinned host copy of the last call's timeout words (checked at the next call)
-    int step_timeout_n = 0;
+    StepSync* step_sync = nullptr;       // [max_steps]: one barrier state per step of a sample() call
+    unsigned long long* step_trace = nullptr;  // AFTER_STEP_TRACE=1: stamps of the LAST step launched (diagnostics)
+    unsigned* step_fail = nullptr;       // pinned host copy of the last call's failure words (checked at the next call)
+    int step_fail_n = 0;
+    float *step_wt = nullptr, *step_act = nullptr;  // 16 x 16-tiled weight copies; per-XCD tiled activation slices
+    const float *step_patch_wt = nullptr, *step_out_wt = nullptr;
+    struct StepLayerW {
+        const float *qkv, *mlp0, *mlp2;
+    };
+    std::vector<StepLayerW> step_layers;
+    size_t step_lds[3] = {0, 0, 0};
 };
 
 namespace {
@@ -1590,8 +1881,11 @@ extern "C" void after_denoiser_destroy(after_denoiser* h) {
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->ev_out) (void)hipEventDestroy(h->ev_out);
     h->timer.destroy();
-    if (h->step_bar) (void)hipFree(h->step_bar);
-    if (h->step_timeout) (void)hipHostFree(h->step_timeout);
+    if (h->step_sync) (void)hipFree(h->step_sync);
+    if (h->step_trace) (void)hipFree(h->step_trace);
+    if (h->step_fail) (void)hipHostFree(h->step_fail);
+    if (h->step_wt) (void)hipFree(h->step_wt);
+    if (h->step_act) (void)hipFree(h->step_act);
     h->wa.release();
     h->ws.release();
     h->ca.release();
@@ -1676,79 +1970,120 @@ int roll_cache_step(after_denoiser* h, hipStream_t s, int rows, int T, int size,
 }
 
 // Streamer.sample (export.py:398-416) with ONE launch per Euler step (stream_step_kernel).  Eligible: the shipped
-// streaming geometry -- eight heads (512 threads = the attention block), finite causal window, K of every Linear a
-// multiple of 128 (the eight k-waves), at most eight layers (the by-value argument block).
-bool step_persist_ok(const after_denoiser* h) {
+// streaming geometry -- embed 512 / mlp 2048 / eight heads (the kernel's tile counts: 32 workgroups per XCD own
+// 3 + 4 + 1 column tiles of the three Linears), finite causal window, <= 8 layers (the by-value argument block),
+// 256 CUs, and at most 16 clip tokens per XCD (ceil(B / 8) * T <= 16: eight streams at 4 - 16 frames, 32 at 4).
+bool step_persist_ok(const after_denoiser* h, int B, int T) {
     const bool wide = h->W < 0 || !h->cfg.causal;
-    return h->persist_step && h->cache > 0 && !h->timer.enabled && h->x6 != 2 && h->H == 8 && h->L <= 8 && !wide &&
-           h->ME % 128 == 0 && h->Cp == h->C && h->Cp % 16 == 0 && (h->Cp < 128 || h->Cp % 128 == 0) && h->n_cus > 0;
+    const int cpg = (B + 7) / 8;
+    return h->persist_step && h->cache > 0 && !h->timer.enabled && h->x6 != 2 && h->E == kSE && h->ME == kSME &&
+           h->H == kSH && h->L <= 8 && !wide && h->Cp == h->C && h->C % 16 == 0 && h->C / 16 <= 8 && h->n_cus == 256 &&
+           cpg * T <= 16;
+}
+
+int step_tile_weights(after_denoiser* h, hipStream_t s) {
+    const size_t E = h->E, ME = h->ME, C = h->C;
+    const size_t per_layer = 3 * E * E + ME * E + E * ME;
+    const size_t total = E * C + C * E + per_layer * h->L;
+    AFTER_HIP_CHECK(hipMalloc(&h->step_wt, total * sizeof(float)));
+    float* p = h->step_wt;
+    auto tile = [&](const float* w, int N, int K) -> const float* {
+        float* out = p;
+        hipLaunchKernelGGL(tile16_kernel, dim3((unsigned)cdivll((long long)N * K / 4, 256)), dim3(256), 0, s, w, K, out, N, K);
+        p += (size_t)N * K;
+        return out;
+    };
+    h->step_patch_wt = tile(h->patch_w, (int)E, (int)C);
+    h->step_out_wt = tile(h->out_w, (int)C, (int)E);
+    h->step_layers.resize(h->L);
+    for (int l = 0; l < h->L; ++l) {
+        const LayerW& w = h->layers[l];
+        h->step_layers[l] = {tile(w.qkv_w, 3 * (int)E, (int)E), tile(w.mlp0_w, (int)ME, (int)E), tile(w.mlp2_w, (int)E, (int)ME)};
+    }
+    AFTER_HIP_CHECK(hipGetLastError());
+    // tiled activation slices: 8 XCDs x kSGroupRows rows x (pat, xres, h: E; mlp: ME)
+    AFTER_HIP_CHECK(hipMalloc(&h->step_act, (size_t)8 * kSGroupRows * (3 * E + ME) * sizeof(float)));
+    AFTER_HIP_CHECK(hipMemsetAsync(h->step_act, 0, (size_t)8 * kSGroupRows * (3 * E + ME) * sizeof(float), s));
+    return AFTER_OK;
 }
 
 int sample_persistent(after_denoiser* h, hipStream_t s, const float* x0, float* out, int B, int T, int nb_steps) {
     const int rows = 3 * B, E = h->E, L = h->L;
-    if (h->step_timeout && h->step_timeout_n > 0) {  // the previous call's barriers (complete by stream order or not yet:
-        for (int i = 0; i < h->step_timeout_n; ++i)  //  a late flag is seen one call later)
-            if (h->step_timeout[i * 32]) {
+    if (h->step_fail && h->step_fail_n > 0) {  // the previous call's flags (a late flag is seen one call later)
+        for (int i = 0; i < h->step_fail_n; ++i)
+            if (h->step_fail[i * 32] || h->step_fail[i * 32 + 1]) {
+                const bool census = h->step_fail[i * 32 + 1] != 0;
                 h->persist_step = 0;
-                h->step_timeout_n = 0;
-                set_error("persistent streaming step: a device-wide barrier timed out (workgroups not co-resident?); "
-                          "the launch-per-kernel path is selected from now on -- reset the streamer");
+                h->step_fail_n = 0;
+                set_error("persistent streaming step: %s; the launch-per-kernel path is selected from now on -- reset "
+                          "the streamer (the previous chunk is invalid)",
+                          census ? "the workgroups were not placed 32 per XCD" : "an XCD-local barrier timed out");
                 return AFTER_E_HIP;
             }
     }
-    if (!h->step_bar) {
-        AFTER_HIP_CHECK(hipMalloc(&h->step_bar, (size_t)h->max_steps * sizeof(StepBarrier)));
-        AFTER_HIP_CHECK(hipHostMalloc(&h->step_timeout, (size_t)h->max_steps * 32 * sizeof(unsigned), hipHostMallocDefault));
+    if (!h->step_sync) {
+        AFTER_HIP_CHECK(hipMalloc(&h->step_sync, (size_t)h->max_steps * sizeof(StepSync)));
+        AFTER_HIP_CHECK(hipHostMalloc(&h->step_fail, (size_t)h->max_steps * 32 * sizeof(unsigned), hipHostMallocDefault));
+        memset(h->step_fail, 0, (size_t)h->max_steps * 32 * sizeof(unsigned));
+        const char* tr = getenv("AFTER_STEP_TRACE");
+        if (tr && atoi(tr) != 0) AFTER_HIP_CHECK(hipMalloc(&h->step_trace, (size_t)h->n_cus * 128 * sizeof(unsigned long long)));
+        AFTER_TRY(step_tile_weights(h, s));
     }
+    const int cpg = (B + 7) / 8, MB = (3 * cpg * T + 15) / 16;
     const int nkmax = h->W - 1 + h->cs > h->cs ? h->W - 1 + h->cs : h->cs;
-    size_t lds = attn_lds_bytes(E, h->cs, nkmax);
-    if (lds < 8 * 3 * 256 * sizeof(float)) lds = 8 * 3 * 256 * sizeof(float);
-    static size_t attr = 0;
-    if (lds > attr) {
-        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stream_step_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = lds;
+    size_t lds = ((size_t)h->cs * (E + 4) + (size_t)kSH * 2 * nkmax * 16) * sizeof(float);
+    if (lds < (size_t)MB * 32768 + 4096) lds = (size_t)MB * 32768 + 4096;
+    const void* fn = MB == 1 ? reinterpret_cast<const void*>(stream_step_kernel<1>)
+                             : (MB == 2 ? reinterpret_cast<const void*>(stream_step_kernel<2>)
+                                        : reinterpret_cast<const void*>(stream_step_kernel<3>));
+    if (lds > h->step_lds[MB - 1]) {
+        AFTER_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        h->step_lds[MB - 1] = lds;
     }
     {
         dim3 grid(cdiv(T, 32), cdiv(h->Cp, 32), B);
         hipLaunchKernelGGL(to_token_major_kernel, grid, dim3(256), 0, s, x0, h->xt, (const int*)nullptr, h->C, T, h->Cp, 0.f);
         AFTER_HIP_CHECK(hipGetLastError());
     }
-    AFTER_HIP_CHECK(hipMemsetAsync(h->step_bar, 0, (size_t)nb_steps * sizeof(StepBarrier), s));
+    AFTER_HIP_CHECK(hipMemsetAsync(h->step_sync, 0, (size_t)nb_steps * sizeof(StepSync), s));
     const size_t step_stride = (size_t)rows * L * 2 * E;
     const size_t per = (size_t)h->cache_rows * h->cache * E;
+    const size_t slice = (size_t)8 * kSGroupRows * E;
     for (int i = 0; i < nb_steps; ++i) {
         StepArgs a;
-        a.rows = rows, a.B = B, a.T = T, a.E = E, a.ME = h->ME, a.C = h->C, a.Cp = h->Cp, a.L = L, a.H = h->H;
-        a.cs = h->cs, a.W = h->W, a.nkmax = nkmax, a.causal = h->cfg.causal, a.cache = h->cache;
-        a.cache_rows = h->cache_rows, a.last_step = i + 1 == nb_steps;
-        a.xt = h->xt, a.pat = h->pat, a.xres = h->xres, a.hbuf = h->hbuf, a.mlp = h->mlp;
-        a.patch_w = h->patch_w, a.patch_b = h->patch_b, a.out_w = h->out_w, a.out_b = h->out_b;
-        a.tc_ab = h->tc_ab, a.tc_ld = L * 2 * E, a.xmap = h->maps, a.tcmap = h->maps + h->ms;
+        a.rows = rows, a.B = B, a.T = T, a.C = h->C, a.Cp = h->Cp, a.L = L;
+        a.cs = h->cs, a.W = h->W, a.nkmax = nkmax, a.cache = h->cache, a.cache_rows = h->cache_rows, a.cpg = cpg;
+        a.xt = h->xt;
+        a.pat_t = h->step_act, a.xres_t = h->step_act + slice, a.h_t = h->step_act + 2 * slice, a.mlp_t = h->step_act + 3 * slice;
+        a.patch_wt = h->step_patch_wt, a.patch_b = h->patch_b, a.out_wt = h->step_out_wt, a.out_b = h->out_b;
+        a.tc_ab = h->tc_ab, a.tc_ld = L * 2 * E, a.tcmap = h->maps + h->ms;
         a.cond_ab = h->cond_ab + (size_t)i * step_stride, a.cond_ld = L * 2 * E;
         a.rope_cos = h->rope_cos, a.rope_sin = h->rope_sin;
         a.xin = i == 0 ? x0 : out, a.xout = out, a.xt_next = i + 1 < nb_steps ? h->xt : nullptr;
         a.cfg = reinterpret_cast<const float*>(h->dparams);
-        a.bar = h->step_bar + i;
+        a.sync = h->step_sync + i;
+        a.trace = h->step_trace;
         const int cur = h->flip[i];
         for (int l = 0; l < L; ++l) {
             const LayerW& w = h->layers[l];
             StepLayer& sl = a.layer[l];
-            sl.qkv_w = w.qkv_w, sl.mlp0_w = w.mlp0_w, sl.mlp0_b = w.mlp0_b, sl.mlp2_w = w.mlp2_w, sl.mlp2_b = w.mlp2_b;
-            sl.n1w = w.n1w, sl.n1b = w.n1b, sl.n3w = w.n3w, sl.n3b = w.n3b;
+            sl.qkv_wt = h->step_layers[l].qkv, sl.mlp0_wt = h->step_layers[l].mlp0, sl.mlp2_wt = h->step_layers[l].mlp2;
+            sl.mlp0_b = w.mlp0_b, sl.mlp2_b = w.mlp2_b, sl.n1w = w.n1w, sl.n1b = w.n1b, sl.n3w = w.n3w, sl.n3b = w.n3b;
             sl.qkv = h->qkv_layers + (size_t)l * h->max_rows * h->max_T * 3 * E;
             const size_t slot = ((size_t)l * h->cache_steps + i) * 2 * per;
             sl.kold = h->kcache + slot + cur * per, sl.vold = h->vcache + slot + cur * per;
             sl.knew = h->kcache + slot + (cur ^ 1) * per, sl.vnew = h->vcache + slot + (cur ^ 1) * per;
         }
-        hipLaunchKernelGGL(stream_step_kernel, dim3(h->n_cus), dim3(512), lds, s, a);
+        if (MB == 1) hipLaunchKernelGGL(stream_step_kernel<1>, dim3(h->n_cus), dim3(512), lds, s, a);
+        else if (MB == 2) hipLaunchKernelGGL(stream_step_kernel<2>, dim3(h->n_cus), dim3(512), lds, s, a);
+        else hipLaunchKernelGGL(stream_step_kernel<3>, dim3(h->n_cus), dim3(512), lds, s, a);
         AFTER_HIP_CHECK(hipGetLastError());
         h->flip[i] = cur ^ 1;
     }
-    // timeout words -> pinned host memory, looked at when the next call starts
-    AFTER_HIP_CHECK(hipMemcpy2DAsync(h->step_timeout, 32 * sizeof(unsigned), &h->step_bar[0].timeout[0], sizeof(StepBarrier),
+    // failure words -> pinned host memory, looked at when the next call starts
+    AFTER_HIP_CHECK(hipMemcpy2DAsync(h->step_fail, 32 * sizeof(unsigned), &h->step_sync[0].fail[0], sizeof(StepSync),
                                      32 * sizeof(unsigned), nb_steps, hipMemcpyDeviceToHost, s));
-    h->step_timeout_n = nb_steps;
+    h->step_fail_n = nb_steps;
     return AFTER_OK;
 }
 
@@ -1762,7 +2097,7 @@ int sample_enqueue(after_denoiser* h, hipStream_t s, const float* x0, const floa
     const int rows = 3 * B;
     AFTER_TRY(compute_cond_ab(h, s, nb_steps, rows, nullptr, nullptr, nb_steps, cond,
                               h->maps + 2 * h->ms, drop_value));
-    if (step_persist_ok(h)) {
+    if (step_persist_ok(h, B, T)) {
         AFTER_TRY(sample_persistent(h, s, x0, out, B, T, nb_steps));
         h->have_last = true;
         h->last_rows = rows;
@@ -1916,9 +2251,18 @@ extern "C" int after_denoiser_set_stream_persist(after_denoiser* h, int enable) 
     return AFTER_OK;
 }
 
+extern "C" int after_denoiser_step_trace(after_denoiser* h, unsigned long long* out, int n_workgroups) {
+    AFTER_REQUIRE(h && out, AFTER_E_INVALID, "null argument");
+    AFTER_REQUIRE(h->step_trace, AFTER_E_INVALID, "no trace: AFTER_STEP_TRACE=1 and one streaming after_sample call first");
+    AFTER_REQUIRE(n_workgroups == h->n_cus, AFTER_E_INVALID, "the step kernel runs %d workgroups", h->n_cus);
+    AFTER_HIP_CHECK(hipDeviceSynchronize());
+    AFTER_HIP_CHECK(hipMemcpy(out, h->step_trace, (size_t)h->n_cus * 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return AFTER_OK;
+}
+
 extern "C" int after_denoiser_stream_persist(after_denoiser* h, int* active) {
     AFTER_REQUIRE(h && active, AFTER_E_INVALID, "null argument");
-    *active = step_persist_ok(h) ? 1 : 0;
+    *active = h->have_last && step_persist_ok(h, h->last_rows / 3, h->last_T) ? 1 : 0;
     return AFTER_OK;
 }
 

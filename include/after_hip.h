@@ -139,6 +139,9 @@ int after_denoiser_gemm_path(after_denoiser* h, int* mode, int* min_rows);
  * after_denoiser_stream_persist: *active = 1 when after_sample would take the persistent path now. */
 int after_denoiser_set_stream_persist(after_denoiser* h, int enable);
 int after_denoiser_stream_persist(after_denoiser* h, int* active);
+/* Diagnostics (AFTER_STEP_TRACE=1 at the first streaming call): out[workgroup][128] = 100 MHz wall-clock stamps of
+ * the last persistent step -- [0] start, [2r-1] / [2r] arrival at / exit from barrier r, then the end; [127] = XCC. */
+int after_denoiser_step_trace(after_denoiser* h, unsigned long long* out, int n_workgroups);
 
 /* Streaming KV caches (transformerv2.py:143-204; enabled in the reference by the
  * gin binding at after_scripts/export.py:77-79).  cache_size frames (a multiple of

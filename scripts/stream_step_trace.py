@@ -1,0 +1,60 @@
+"""Per-phase timeline of the persistent streaming step (stream_step_kernel, denoiser.hip) on BASELINE config 5:
+AFTER_STEP_TRACE=1 makes every workgroup stamp the 100 MHz wall clock when it arrives at / leaves each XCD-local
+barrier.  Prints, per phase and for the workgroups of ONE XCD (--xcd): the slowest workgroup's work time, the median, and
+the barrier cost (first exit minus last arrival); then the step time of every XCD.  python scripts/stream_step_trace.py [--streams 8]"""
+import argparse
+import ctypes
+import os
+import sys
+
+os.environ["AFTER_STEP_TRACE"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from after_amd import Streamer, _lib, pipeline
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--streams", type=int, default=8)
+ap.add_argument("--steps", type=int, default=100)
+ap.add_argument("--xcd", type=int, default=0)
+args = ap.parse_args()
+torch.set_grad_enabled(False)
+dev = torch.device("cuda:0")
+model, dcfg, acfg = pipeline.build_models("cycle", "baseAE_causal", dev, seed=7)
+st = Streamer(model, model.emb_model, chunk_size=4, n_signal_timbre=128, max_batch=args.streams, max_nb_steps=args.steps,
+              share_first_stream=False)
+st.set_nb_steps(args.steps)
+x = 0.1 * torch.randn(args.streams, 2, 4 * st.ae_ratio, device=dev)
+for _ in range(3):
+    st(x)
+torch.cuda.synchronize()
+h = model.net._handle
+n = torch.cuda.get_device_properties(0).multi_processor_count
+buf = np.zeros((n, 128), dtype=np.uint64)
+_lib.check(_lib.lib().after_denoiser_step_trace(h, buf.ctypes.data_as(ctypes.c_void_p), n), "step_trace")
+L = dcfg["net"]["n_layers"]
+names = ["patchify"] + sum(([f"L{l} ln", f"L{l} qkv", f"L{l} attn", f"L{l} up+roll", f"L{l} down"] for l in range(L)), []) + ["tail"]
+xcc = buf[:, 127].astype(int)
+t_all = buf[:, :2 * len(names)].astype(np.int64)
+t = t_all[xcc == args.xcd]
+t0 = t[:, 0].min()
+tot_work = tot_bar = 0.0
+print(f"workgroups {n}, XCC populations {np.bincount(buf[:, 127].astype(int), minlength=8).tolist()}")
+print(f"{'phase':>12} {'work max':>9} {'work med':>9} {'barrier':>8}   (us)")
+for p, name in enumerate(names):
+    start = t[:, 2 * p]                      # leaves the previous barrier (or kernel start)
+    end = t[:, 2 * p + 1]                    # arrives at the next barrier (or kernel end)
+    work = (end - start) / 100.0
+    line = f"{name:>12} {work.max():9.2f} {np.median(work):9.2f}"
+    tot_work += (end.max() - start.min()) / 100.0
+    if p + 1 < len(names):
+        bar = (t[:, 2 * p + 2].min() - end.max()) / 100.0
+        tot_bar += (t[:, 2 * p + 2].max() - end.max()) / 100.0
+        line += f" {bar:8.2f}"
+    print(line)
+print("step per XCD (us): " + ", ".join(f"{(t_all[xcc == x][:, 2 * len(names) - 1].max() - t_all[xcc == x][:, 0].min()) / 100.0:.1f}"
+                                         for x in range(8) if (xcc == x).any()))
+print(f"XCD {args.xcd} step: {(t[:, 2 * len(names) - 1].max() - t0) / 100.0:.1f} us; phases (first start -> last arrival) {tot_work:.1f} us; "
+      f"barriers (last arrival -> last exit) {tot_bar:.1f} us")
+

@@ -1,0 +1,132 @@
+// XCD-local barrier + visibility: the 32 workgroups resident on one XCD share that XCD's L2, so data exchanged ONLY
+// between them needs no L2 write-back / invalidate (the cross-XCD cost of an agent-scope release / acquire) -- stores
+// are written through the CU's vector L1 into the L2, a reader drops its L1 (buffer_inv sc0) and reads the L2.
+// Measures, per XCD concurrently (8 independent groups of 32 workgroups):
+//   barrier   us per XCD-local barrier (arrival counter + generation word, relaxed agent-scope atomics on one line each)
+//   record    the same with every workgroup publishing 128 B that a peer ON THE SAME XCD re-reads (visibility check)
+//   tile      the same with a 32-KB tile per workgroup re-read by the peer (a GEMM phase's activation hand-over)
+//   hipcc --offload-arch=gfx950 -O3 xcd_local.hip -o xcd_local.bin && ./xcd_local.bin
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+struct LocalState {
+    unsigned arrive[8][32];  // [xcc][0]
+    unsigned gen[8][32];
+    unsigned pop[8][32];
+    unsigned census[32];
+    unsigned timeout[32];
+};
+
+__device__ __forceinline__ unsigned xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 7u;
+}
+
+__device__ __forceinline__ bool spin_until(unsigned* word, unsigned want, unsigned* timeout) {
+    for (unsigned spins = 0;; ++spins) {
+        if (__hip_atomic_load(word, RLX_AGENT) >= want) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if (spins > (1u << 22)) {
+            __hip_atomic_store(timeout, 1u, RLX_AGENT);
+            return false;
+        }
+    }
+}
+
+// all threads call; n = workgroups of this XCC
+template <int INV>
+__device__ __forceinline__ bool local_barrier(LocalState* st, unsigned xcc, unsigned n, unsigned round) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stores are in the XCD's L2 (the vector L1 is write-through)
+    __syncthreads();
+    bool ok = true;
+    if (threadIdx.x == 0) {
+        const unsigned ticket = __hip_atomic_fetch_add(&st->arrive[xcc][0], 1u, RLX_AGENT);
+        if (ticket == round * n - 1) __hip_atomic_store(&st->gen[xcc][0], round, RLX_AGENT);
+        else ok = spin_until(&st->gen[xcc][0], round, &st->timeout[0]);
+    }
+    __syncthreads();
+    if (INV == 1) asm volatile("buffer_inv sc1" ::: "memory");  // drop this CU's vector L1 (and clean non-coherent L2 lines)
+    return ok;
+}
+
+__device__ __forceinline__ float4 load_sc1(const float4* p) {  // agent-scope load: misses the vector L1, served by the L2
+    float4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+template <int MODE, int INV>  // 0 bare, 1 128-B record, 2 32-KB tile; INV 1: buffer_inv sc1 after the barrier, 0: sc1 loads
+__global__ __launch_bounds__(512) void k_local(LocalState* st, float* buf, int rounds, int* errs) {
+    __shared__ unsigned s_n, s_rank;
+    const unsigned xcc = xcc_id(), nb = gridDim.x;
+    if (threadIdx.x == 0) {
+        s_rank = __hip_atomic_fetch_add(&st->pop[xcc][0], 1u, RLX_AGENT);
+        __hip_atomic_fetch_add(&st->census[0], 1u, RLX_AGENT);
+        spin_until(&st->census[0], nb, &st->timeout[0]);
+        s_n = __hip_atomic_load(&st->pop[xcc][0], RLX_AGENT);
+    }
+    __syncthreads();
+    const unsigned n = s_n, rank = s_rank;
+    constexpr int REC = MODE == 2 ? 8192 : 32;  // floats per workgroup record
+    float* mine = buf + ((size_t)xcc * 64 + rank) * REC;
+    const unsigned peer = (rank + 13) % n;
+    const float* theirs = buf + ((size_t)xcc * 64 + peer) * REC;
+    unsigned round = 0;
+    int bad = 0;
+    for (int r = 0; r < rounds; ++r) {
+        if (MODE == 1 && threadIdx.x < 32) mine[threadIdx.x] = (float)(r * 1000 + rank);
+        if (MODE == 2)
+            for (int i = threadIdx.x; i < REC / 4; i += 512)
+                reinterpret_cast<float4*>(mine)[i] = make_float4((float)(r * 1000 + rank), 1.f, 2.f, 3.f);
+        if (!local_barrier<INV>(st, xcc, n, ++round)) return;
+        if (MODE == 1 && threadIdx.x < 8) bad += (INV ? reinterpret_cast<const float4*>(theirs)[threadIdx.x] : load_sc1(reinterpret_cast<const float4*>(theirs) + threadIdx.x)).x != (float)(r * 1000 + peer);
+        if (MODE == 2)
+            for (int i = threadIdx.x; i < REC / 4; i += 512)
+                bad += (INV ? reinterpret_cast<const float4*>(theirs)[i] : load_sc1(reinterpret_cast<const float4*>(theirs) + i)).x != (float)(r * 1000 + peer);
+        if (!local_barrier<INV>(st, xcc, n, ++round)) return;
+    }
+    if (bad) atomicAdd(errs, bad);
+}
+
+int main() {
+    LocalState* st;
+    float* buf;
+    int* errs;
+    (void)hipMalloc(&st, sizeof(LocalState));
+    (void)hipMalloc(&buf, (size_t)8 * 64 * 8192 * 4);
+    (void)hipMalloc(&errs, 4);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    const int rounds = 2000;
+    for (int mode = 0; mode < 3; ++mode) {
+        for (int inv = 0; inv < 2; ++inv) {
+            (void)hipMemset(st, 0, sizeof(LocalState));
+            (void)hipMemset(errs, 0, 4);
+            (void)hipEventRecord(e0);
+            if (mode == 0 && inv) hipLaunchKernelGGL((k_local<0, 1>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
+            if (mode == 1 && inv) hipLaunchKernelGGL((k_local<1, 1>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
+            if (mode == 2 && inv) hipLaunchKernelGGL((k_local<2, 1>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
+            if (mode == 0 && !inv) hipLaunchKernelGGL((k_local<0, 0>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
+            if (mode == 1 && !inv) hipLaunchKernelGGL((k_local<1, 0>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
+            if (mode == 2 && !inv) hipLaunchKernelGGL((k_local<2, 0>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
+            (void)hipEventRecord(e1);
+            (void)hipEventSynchronize(e1);
+            float ms;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            int h;
+            LocalState hs;
+            (void)hipMemcpy(&h, errs, 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(&hs, st, sizeof(hs), hipMemcpyDeviceToHost);
+            printf("{\"ubench\": \"xcd_local_barrier\", \"mode\": \"%s\", \"reader\": \"%s\", \"us_per_barrier\": %.2f, \"visibility_errors\": %d, "
+                   "\"timeout\": %u, \"pop\": [%u,%u,%u,%u,%u,%u,%u,%u]}\n",
+                   mode == 0 ? "bare" : (mode == 1 ? "record_128B" : "tile_32KB"), inv ? "buffer_inv sc1" : "sc1 loads", ms * 1e3 / (2 * rounds), h, hs.timeout[0],
+                   hs.pop[0][0], hs.pop[1][0], hs.pop[2][0], hs.pop[3][0], hs.pop[4][0], hs.pop[5][0], hs.pop[6][0], hs.pop[7][0]);
+        }
+    }
+    return 0;
+}
