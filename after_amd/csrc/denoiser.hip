@@ -687,7 +687,17 @@ __global__ __launch_bounds__(256) void roll_cache_kernel(const float* __restrict
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kSE = 512, kSME = 2048, kSH = 8;  // the shipped streaming width (embed 512, mlp x 4, 8 heads)
+constexpr int kSE = 512, kSME = 1536, kSH = 8;  // the shipped width (configs: embed 512, mlp x 3, 8 heads)
+constexpr int kSNTU = kSME / 512;   // MLP-up column tiles per workgroup (32 workgroups per XCD)
+constexpr int kSCW = 8;             // compute waves of a GEMM phase (K split kSCW ways).  Measured with 4 compute + 4
+                                    // L2-streaming waves: the streamers' misses clog the CU's one load path -- every phase slower
+constexpr int kSKBQ = kSE / 16 / kSCW;   // qkv / MLP-up k-blocks per compute wave
+constexpr int kSKBD = kSME / 16 / kSCW;  // MLP-down k-blocks per compute wave
+// LDS floats in front of the K / V landing zones: the partial tiles (kSCW compute waves x 3 MB tiles x 256) or the attention rows +
+// RoPE slices (<= 28 KB), whichever is larger
+__host__ __device__ constexpr int kSRedFloats(int MB) { return (MB * 3 * 256 * kSCW > 7168 ? MB * 3 * 256 * kSCW : 7168) + 1024; }
+constexpr int kSWF = 12;            // weight fragments of a compute wave: max(3 x kSKBQ, kSNTU x kSKBQ, kSKBD)
+static_assert(3 * kSKBQ <= kSWF && kSNTU * kSKBQ <= kSWF && kSKBD <= kSWF && kSKBD % 4 == 0 && kSKBQ % 4 == 0, "weight fragment budget");
 constexpr int kSGroupRows = 48;                 // token rows one XCD can own (three 16-row blocks)
 
 struct StepSync {
@@ -706,7 +716,8 @@ struct StepLayer {
 };
 
 struct StepArgs {
-    int rows, B, T, C, Cp, L, cs, W, nkmax, cache, cache_rows, cpg;
+    int rows, B, T, C, Cp, L, cs, W, nkmax, cache, cache_rows, cpg, dbg;
+    int warm[3];  // sixteenths of the qkv / MLP-up / MLP-down weights warmed into the L2 by idle waves (AFTER_STEP_WARM)
     const float* xt;                       // token-major latents [B * T][Cp] (this step's input)
     float *pat_t, *xres_t, *h_t, *mlp_t;   // tiled, one slice of kSGroupRows rows per XCD
     const float *patch_wt, *patch_b, *out_wt, *out_b;
@@ -758,11 +769,14 @@ __device__ __forceinline__ bool step_spin(unsigned* word, unsigned want, unsigne
     }
 }
 
-// XCD-local barrier (all threads of the workgroup call it; n = workgroups of this XCC)
+// XCD-local barrier (all threads of the workgroup call it; n = workgroups of this XCC).  `drain`: this wave stored
+// something in the phase -- wait until it is in the XCD's L2 (write-through L1).  A streaming wave passes false: its
+// L2-warming loads stay in flight across the barrier (raw s_barrier: no memory wait).
 __device__ __forceinline__ void step_barrier(StepSync* st, unsigned xcc, unsigned n, unsigned round,
-                                             unsigned long long* trace) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores are in the XCD's L2 (write-through L1)
-    __syncthreads();
+                                             unsigned long long* trace, bool drain) {
+    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     if (threadIdx.x == 0) {
         if (trace) trace[2 * round - 1] = wall_clock64();
         const unsigned ticket = __hip_atomic_fetch_add(&st->arrive[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -770,36 +784,44 @@ __device__ __forceinline__ void step_barrier(StepSync* st, unsigned xcc, unsigne
         else step_spin(&st->gen[xcc][0], round, &st->fail[0]);
         if (trace) trace[2 * round] = wall_clock64();
     }
-    __syncthreads();
+    __builtin_amdgcn_s_barrier();
 }
 
-// the next GEMM phase's weight fragments: NT column tiles (tile0, tile0 + 32, ...) x KB k-blocks starting at kb0 of a
-// tiled [N / 16][kblocks][256] weight copy (plain loads: weights are never written)
-template <int NT, int KB>
-__device__ __forceinline__ void step_w_fetch(f32x4 (&wf)[16], const float* __restrict__ wt, int kblocks, int tile0,
-                                             int kb0, int lane, bool active) {
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int u = 0; u < KB; ++u)
-            wf[j * KB + u] = active ? *reinterpret_cast<const f32x4*>(wt + ((size_t)((tile0 + 32 * j) * kblocks + kb0 + u) << 8) + lane * 4)
-                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+// L2 warming: touch one dword per 128-byte line of memory the XCD is about to stream (the next GEMM phase's weight tiles,
+// the attention's K / V ring rows), so that the consumers' loads after the barrier hit the XCD's L2 instead of paying
+// the fabric latency -- and, eight XCDs streaming the same 54 MB of weights per step, the fabric bandwidth -- on the
+// critical path.  Wave `wi` of `nw` warms 8-KB
+// chunks wi, wi + nw, ... of [base, base + bytes): one load instruction per chunk, result discarded.
+// (Inline-asm loads: a C++ volatile load is legalised to a cache-bypassing load followed by s_waitcnt vmcnt(0) -- one
+//  fabric round trip per line.  All of them write `sink`, which stays live -- one register the compiler cannot hand to
+//  anything else -- until step_warm_done has waited for the last of them; the data is never read.)
+__device__ __forceinline__ void step_warm(unsigned& sink, const void* base, size_t bytes, int wi, int nw, int lane) {
+    const char* p = static_cast<const char*>(base);
+    for (size_t c = (size_t)wi * 8192; c < bytes; c += (size_t)nw * 8192) {
+        const size_t off = c + (size_t)lane * 128;
+        const char* q = p + (off < bytes ? off : c);
+        asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(q) : "memory");
+    }
 }
 
-// acc[j * MB + i] = (this wave's K slice of) rows 16 i .. 16 i + 15 of A x column tile j of W.  A: tiled buffer read
-// with sc1 loads (`a_kblocks` k-blocks per row block), or -- AROW -- row-major rows `arow0 + min(lane % 16, arows - 1)`
-// of a matrix written before the kernel (the token-major latents of patchify).
+__device__ __forceinline__ void step_warm_done(unsigned& sink) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory"); }
+
+// acc[j * MB + i] = (this wave's K slice: k-blocks kb0 .. kb0 + KB) of rows 16 i .. 16 i + 15 of A x column tile
+// tile0 + 32 j of W.  A: tiled buffer read with sc1 loads (`a_kblocks` k-blocks per row block), or -- AROW -- row-major
+// rows of a matrix written before the kernel (`arow` = this lane's row: the token-major latents of patchify).  W: tiled
+// [N / 16][w_kblocks][256] copy, plain loads (never written).  Loads return in issue order: the first A k-blocks go
+// first (L2 hits), then the weight fragments in the order the MFMAs consume them (k-block-major), so the MFMAs of
+// k-block u run while the fragments of u + 1 .. are still arriving from the fabric.
 template <int MB, int NT, int KB, bool AROW>
-__device__ __forceinline__ void step_mma(f32x4 (&acc)[NT * MB], const f32x4 (&wf)[16], __amdgpu_buffer_rsrc_t A,
-                                         int a_kblocks, int kb0, int lane, bool active, const float* arow = nullptr,
-                                         int lda = 0) {
+__device__ __forceinline__ void step_gemm(f32x4 (&acc)[NT * MB], __amdgpu_buffer_rsrc_t A, int a_kblocks,
+                                          const float* __restrict__ wt, int w_kblocks, int tile0, int kb0, int lane,
+                                          bool active, bool wact, const float* arow = nullptr) {
 #pragma unroll
     for (int p = 0; p < NT * MB; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (!active) return;
-    constexpr int CH = KB < 4 ? KB : 4;  // k-blocks of A in flight
-#pragma unroll
-    for (int u0 = 0; u0 < KB; u0 += CH) {
-        f32x4 av[CH][MB];
+    constexpr int CH = KB * MB <= 12 ? KB : 4;  // k-blocks of A in flight
+    f32x4 wf[NT * KB], av[CH][MB];
+    auto load_a = [&](int u0) {
 #pragma unroll
         for (int u = 0; u < CH; ++u)
 #pragma unroll
@@ -807,6 +829,17 @@ __device__ __forceinline__ void step_mma(f32x4 (&acc)[NT * MB], const f32x4 (&wf
                 if constexpr (AROW) av[u][i] = *reinterpret_cast<const f32x4*>(arow + (size_t)(kb0 + u0 + u) * 16 + (lane >> 4) * 4);
                 else av[u][i] = ld_l2(A, (unsigned)(((i * a_kblocks + kb0 + u0 + u) << 8) + lane * 4));
             }
+    };
+    load_a(0);
+#pragma unroll
+    for (int u = 0; u < KB; ++u)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            wf[j * KB + u] = wact ? *reinterpret_cast<const f32x4*>(wt + ((size_t)((tile0 + 32 * j) * w_kblocks + kb0 + u) << 8) + lane * 4)
+                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u0 = 0; u0 < KB; u0 += CH) {
+        if (u0 > 0) load_a(u0);
 #pragma unroll
         for (int u = 0; u < CH; ++u)
 #pragma unroll
@@ -819,19 +852,22 @@ __device__ __forceinline__ void step_mma(f32x4 (&acc)[NT * MB], const f32x4 (&wf
     }
 }
 
-// the eight waves' partial tiles -> LDS [wave][P][256]; afterwards step_reduced(p) sums tile p in wave order
+// the compute waves' partial tiles -> LDS [wave][P][256] (all eight waves call it: two workgroup barriers);
+// afterwards step_reduced(p) sums tile p in wave order
 template <int P>
 __device__ __forceinline__ void step_partials(const f32x4 (&acc)[P], float* red, int w, int lane) {
     __syncthreads();  // the previous readers are done with `red`
+    if (w < kSCW) {
 #pragma unroll
-    for (int p = 0; p < P; ++p) *reinterpret_cast<f32x4*>(red + (((w * P + p) << 6) + lane) * 4) = acc[p];
+        for (int p = 0; p < P; ++p) *reinterpret_cast<f32x4*>(red + (((w * P + p) << 6) + lane) * 4) = acc[p];
+    }
     __syncthreads();
 }
 
 __device__ __forceinline__ f32x4 step_reduced(const float* red, int P, int p, int lane) {
     f32x4 o = *reinterpret_cast<const f32x4*>(red + ((p << 6) + lane) * 4);
 #pragma unroll
-    for (int q = 1; q < 8; ++q) o += *reinterpret_cast<const f32x4*>(red + ((((q * P + p)) << 6) + lane) * 4);
+    for (int q = 1; q < kSCW; ++q) o += *reinterpret_cast<const f32x4*>(red + ((((q * P + p)) << 6) + lane) * 4);
     return o;
 }
 
@@ -886,11 +922,12 @@ __device__ __forceinline__ void step_ln_row(__amdgpu_buffer_rsrc_t xin, int src_
     }
 }
 
-// attn_block_body<CACHE, PRELOAD> for the persistent step: chunk bx of network row rg (local rows lr0 ..): q / k / v
+// attn_block_body<CACHE, !PRELOAD> for the persistent step: chunk bx of network row rg (local rows lr0 ..): q / k / v
 // through sc1 loads from this layer's qkv, the cached frames from the K / V ring (written by an earlier launch),
-// residual stream and h in the XCD's tiled buffers.  smem: [cs][E + 4] | per-wave cos, sin [nkmax][16].
+// residual stream and h in the XCD's tiled buffers.  smem: [cs][E + 4] | per-wave cos, sin [nkmax][16]; kvlds: K / V
+// landing zones [8 waves][2][12][64].
 __device__ __forceinline__ void step_attention(const StepArgs& a, const StepLayer& L, const float* __restrict__ cond_ab, int rg,
-                                               int lr0, int bx, float* smem, __amdgpu_buffer_rsrc_t qkvr,
+                                               int lr0, int bx, float* smem, float* kvlds, __amdgpu_buffer_rsrc_t qkvr,
                                                __amdgpu_buffer_rsrc_t xr, float* __restrict__ xres, float* __restrict__ hout) {
     constexpr int NKMAX = kAttnKeyBlock, E = kSE, H = kSH, KBt = E / 16, ld = E + 4;
     const int T = a.T, cs = a.cs, W = a.W, nc = a.cache;
@@ -903,6 +940,7 @@ __device__ __forceinline__ void step_attention(const StepArgs& a, const StepLaye
     const unsigned rowbase = (unsigned)rg * T;
     float* const rc = smem + cs * ld + hw * (2 * a.nkmax * 16);
     float* const rs = rc + a.nkmax * 16;
+    float* const kvs = kvlds + hw * (2 * NKMAX * 64);  // per-wave K / V landing zone [2][NKMAX][64]
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 tc0 = z4, tc1 = z4, ts0 = z4, ts1 = z4;
     if (lane < nk * 4) {
@@ -937,18 +975,21 @@ __device__ __forceinline__ void step_attention(const StepArgs& a, const StepLaye
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 1
         for (int kb = 0; kb < nk; kb += NKMAX) {
-            float4 k4[NKMAX], v4[NKMAX];
+            // K / V rows go global -> LDS by DMA (no VGPR landing zone: this kernel's register budget belongs to the
+            // weight fragments).  One instruction moves 4 keys: 16-lane group g fetches the 256-byte head slice of key
+            // 4 u + g, lane-linear into [key][64 dims]; sc1: the new frames were written by this XCD's qkv phase.
+            if (qb > 0 || kb > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous block consumed
 #pragma unroll
-            for (int j = 0; j < NKMAX; ++j) {  // all K and V rows requested unconditionally (slot clamped, masked later)
-                const int pos = lo_c + min(kb + j, nk - 1);
+            for (int u = 0; u < NKMAX / 4; ++u) {
+                const int pos = lo_c + min(kb + 4 * u + grp, nk - 1);
+                const float* ksrc = L.qkv + ((size_t)rowbase + (pos - nc)) * 3 * E + E + hw * 64 + d4;
+                const float* vsrc = ksrc + E;
                 if (pos < nc) {
-                    k4[j] = *reinterpret_cast<const float4*>(L.kold + ((size_t)rg * nc + pos) * E + hw * 64 + d4);
-                    v4[j] = *reinterpret_cast<const float4*>(L.vold + ((size_t)rg * nc + pos) * E + hw * 64 + d4);
-                } else {
-                    const unsigned off = (rowbase + (pos - nc)) * 3u * E + E + hw * 64 + d4;
-                    k4[j] = as4(ld_l2(qkvr, off));
-                    v4[j] = as4(ld_l2(qkvr, off + E));
+                    ksrc = L.kold + ((size_t)rg * nc + pos) * E + hw * 64 + d4;
+                    vsrc = L.vold + ((size_t)rg * nc + pos) * E + hw * 64 + d4;
                 }
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)ksrc, (lds_ptr_t)(kvs + 4 * u * 64), 16, 0, 16);
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)vsrc, (lds_ptr_t)(kvs + (NKMAX + 4 * u) * 64), 16, 0, 16);
             }
             if (qb == 0 && kb == 0) {  // K / V requests are in flight: now land the RoPE slice
                 if (lane < nk * 4) {
@@ -963,13 +1004,15 @@ __device__ __forceinline__ void step_attention(const StepArgs& a, const StepLaye
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the K / V block (and q, x) have landed
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (kb == 0) q4 = rope4(q4, rc, rs, ja - lo_c, d4);
             float sc[NKMAX];
             float mx = mrun;
 #pragma unroll
             for (int j = 0; j < NKMAX; ++j) {
                 const int pos = lo_c + min(kb + j, nk - 1);
-                const float4 kr = rope4(k4[j], rc, rs, pos - lo_c, d4);
+                const float4 kr = rope4(*reinterpret_cast<const float4*>(kvs + j * 64 + d4), rc, rs, pos - lo_c, d4);
                 float dot = q4.x * kr.x + q4.y * kr.y + q4.z * kr.z + q4.w * kr.w;
                 dot = group16_sum(dot);
                 sc[j] = (kb + j < nk && pos >= lo_row) ? dot * 0.125f : -INFINITY;
@@ -986,10 +1029,11 @@ __device__ __forceinline__ void step_attention(const StepArgs& a, const StepLaye
             for (int j = 0; j < NKMAX; ++j) {
                 const float p = expf(sc[j] - mx);
                 sum += p;
-                o.x += p * v4[j].x;
-                o.y += p * v4[j].y;
-                o.z += p * v4[j].z;
-                o.w += p * v4[j].w;
+                const float4 vj = *reinterpret_cast<const float4*>(kvs + (NKMAX + j) * 64 + d4);
+                o.x += p * vj.x;
+                o.y += p * vj.y;
+                o.z += p * vj.z;
+                o.w += p * vj.w;
             }
         }
         const float inv = 1.0f / sum;
@@ -1118,27 +1162,37 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
     float* const hb = a.h_t + (size_t)g * kSGroupRows * E;
     float* const mlp = a.mlp_t + (size_t)g * kSGroupRows * ME;
     const __amdgpu_buffer_rsrc_t pat_r = step_rsrc(pat), xres_r = step_rsrc(xres), hb_r = step_rsrc(hb), mlp_r = step_rsrc(mlp);
-    float* const red = smem;
-    f32x4 wf[16];  // weight fragments of the next GEMM phase (requested one barrier early)
+    float* const red = smem;                    // partial tiles [4 compute waves][<= 3 MB][256] | attention rows + RoPE slices
+    float* const kvl = smem + kSRedFloats(MB);  // attention: K / V landing zones [8 waves][2][12][64]
+    const bool wact = !(a.dbg & 2);  // (AFTER_STEP_DBG=2, timing experiments: no weight traffic, wrong results)
+    const bool cw = w < kSCW;        // compute wave of the GEMM phases
+    // L2 warming (step_warm) by waves that have nothing to do in the ln / attention phases: `sixteenths` / 16 of a
+    // Linear's 3 E^2 weights (ME = 3 E).  A warming wave does not wait for these loads at the barrier (it stored nothing)
+    const size_t wbytes = (size_t)E * ME * sizeof(float);
+    static_assert(kSME == 3 * kSE, "qkv and MLP weights of one size");
+    auto end_phase = [&](bool drain) { step_barrier(st, xcc, n, ++round, trace, drain); };
 
     // ---- patchify_and_embed: pat = GELU(xt patch_w^T + b) for the XCD's ct clip tokens (transformerv2.py:387-391)
     {
-        const int kbp = a.Cp / 16;
-        step_w_fetch<1, 1>(wf, a.patch_wt, kbp, rank, w, lane, w < kbp);
+        const int kbp = a.Cp / 16;  // <= 8: one k-block per wave
         f32x4 acc[1];
         const float* arow = a.xt + (size_t)(c0 * T + min(lane & 15, nclip * T - 1)) * a.Cp;
-        step_mma<1, 1, 1, true>(acc, wf, pat_r, 0, w, lane, w < kbp, arow, a.Cp);
-        step_w_fetch<3, 4>(wf, a.layer[0].qkv_wt, KBE, rank, 4 * w, lane, true);
-        step_partials<1>(acc, red, w, lane);
+        const f32x4 bv = w == 0 ? *reinterpret_cast<const f32x4*>(a.patch_b + 16 * rank + 4 * (lane >> 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        step_gemm<1, 1, 1, true>(acc, pat_r, 0, a.patch_wt, kbp, rank, w, lane, w < kbp, wact, arow);
+        // (all eight waves may carry a k-block here: partial tiles through the full-width LDS exchange)
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(red + ((w << 6) + lane) * 4) = acc[0];
+        __syncthreads();
         if (w == 0) {
-            f32x4 o = step_reduced(red, 1, 0, lane);
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.patch_b + 16 * rank + 4 * (lane >> 4));
+            f32x4 o = *reinterpret_cast<const f32x4*>(red + lane * 4);
+#pragma unroll
+            for (int q = 1; q < 8; ++q) o += *reinterpret_cast<const f32x4*>(red + ((q << 6) + lane) * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r] + bv[r]);
             *reinterpret_cast<f32x4*>(pat + ((size_t)rank << 8) + lane * 4) = o;
         }
     }
-    step_barrier(st, xcc, n, ++round, trace);
+    end_phase(cw);
     const int nchunks = (T + a.cs - 1) / a.cs;
     for (int l = 0; l < a.L; ++l) {
         const StepLayer& Lw = a.layer[l];
@@ -1152,14 +1206,25 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
                 step_ln_row(l == 0 ? pat_r : xres_r, l == 0 ? rem : lm, xres, hb, lm, ab, Lw.n1w, Lw.n1b, lane);
             }
         }
-        step_barrier(st, xcc, n, ++round, trace);
+        if (wact && rank >= Mg) {  // workgroups without a row (a warming wave next to a row's wave delays its loads: one
+                                   // load path per CU): warm the K / V ring rows of this layer, then (part of) the qkv weights
+            const int wi = (rank - Mg) * 8 + w, nw = ((int)n - Mg) * 8;
+            unsigned sink = 0;
+            for (int q = 0; q < 3 * nclip; ++q) {
+                const int br = q / nclip, rg = br * B + c0 + (q - br * nclip);
+                step_warm(sink, Lw.kold + (size_t)rg * a.cache * E, (size_t)a.cache * E * sizeof(float), wi, nw, lane);
+                step_warm(sink, Lw.vold + (size_t)rg * a.cache * E, (size_t)a.cache * E * sizeof(float), wi, nw, lane);
+            }
+            step_warm(sink, Lw.qkv_wt, wbytes * a.warm[0] / 16, wi, nw, lane);
+            step_warm_done(sink);
+        }
+        end_phase(true);
         // ---- qkv: column tiles rank, rank + 32, rank + 64
         {
             f32x4 acc[3 * MB];
-            step_mma<MB, 3, 4, false>(acc, wf, hb_r, KBE, 4 * w, lane, true);
-            step_w_fetch<4, 4>(wf, Lw.mlp0_wt, KBE, rank, 4 * w, lane, true);
+            step_gemm<MB, 3, kSKBQ, false>(acc, hb_r, KBE, Lw.qkv_wt, KBE, rank, kSKBQ * w, lane, cw, wact);
             step_partials<3 * MB>(acc, red, w, lane);
-            for (int p = w; p < 3 * MB; p += 8) {
+            for (int p = w; p < 3 * MB && cw; p += kSCW) {
                 const int j = p / MB, i = p - j * MB;
                 const f32x4 o = step_reduced(red, 3 * MB, p, lane);
                 const int lm = 16 * i + (lane & 15);
@@ -1168,7 +1233,7 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
                     *reinterpret_cast<f32x4*>(Lw.qkv + ((size_t)(br * B + c0 + cl) * T + t) * 3 * E + 16 * (rank + 32 * j) + 4 * (lane >> 4)) = o;
             }
         }
-        step_barrier(st, xcc, n, ++round, trace);
+        end_phase(cw);
         // ---- cached attention + residual + AdaLN(cond) + norm3 (one workgroup per chunk of a network row); the
         //      other workgroups roll this layer's K / V ring by T frames (MHAttention.roll_cache,
         //      transformerv2.py:171-188: flip-flop halves, out of place)
@@ -1177,55 +1242,69 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
             for (int it = rank; it < nitems; it += (int)n) {
                 const int q = it / nchunks, bx = it - q * nchunks, br = q / nclip, cl = q - br * nclip;
                 __syncthreads();  // (a second item of this workgroup reuses the LDS rows)
-                step_attention(a, Lw, a.cond_ab + (size_t)l * 2 * E, br * B + c0 + cl, br * ct + cl * T, bx, smem, qkv_r, xres_r,
+                step_attention(a, Lw, a.cond_ab + (size_t)l * 2 * E, br * B + c0 + cl, br * ct + cl * T, bx, smem, kvl, qkv_r, xres_r,
                                xres, hb);
             }
             const int nroll = nitems < (int)n ? (int)n - nitems : (int)n, rb = nitems < (int)n ? rank - nitems : rank;
-            if (rb >= 0) roll(Lw, qkv_r, 3 * nclip, rb, nroll);
+            bool drain = true;
+            if (rb >= 0) {
+                roll(Lw, qkv_r, 3 * nclip, rb, nroll);
+                if (wact) {  // then warm the MLP weights (MLP-up first: it is needed first)
+                    unsigned sink = 0;
+                    step_warm(sink, Lw.mlp0_wt, wbytes * a.warm[1] / 16, rb * 8 + w, nroll * 8, lane);
+                    step_warm(sink, Lw.mlp2_wt, wbytes * a.warm[2] / 16, rb * 8 + w, nroll * 8, lane);
+                    step_warm_done(sink);
+                }
+            }
+            end_phase(drain);
         }
-        step_barrier(st, xcc, n, ++round, trace);
-        // ---- MLP up + GELU: column tiles rank + 32 j, j < 4
+        // ---- MLP up + GELU: column tiles rank + 32 j, j < kSNTU
         {
-            f32x4 acc[4 * MB];
-            step_mma<MB, 4, 4, false>(acc, wf, hb_r, KBE, 4 * w, lane, true);
-            step_w_fetch<1, 16>(wf, Lw.mlp2_wt, KBM, rank, 16 * w, lane, true);
-            step_partials<4 * MB>(acc, red, w, lane);
-            for (int p = w; p < 4 * MB; p += 8) {
+            f32x4 acc[kSNTU * MB];
+            // (epilogue operands are requested before the GEMM: a load issued after the reduction would put one more
+            //  fabric round trip on the phase's critical path)
+            const int pj = w / MB;
+            const f32x4 bv0 = cw && w < kSNTU * MB ? *reinterpret_cast<const f32x4*>(Lw.mlp0_b + 16 * (rank + 32 * pj) + 4 * (lane >> 4))
+                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+            step_gemm<MB, kSNTU, kSKBQ, false>(acc, hb_r, KBE, Lw.mlp0_wt, KBE, rank, kSKBQ * w, lane, cw, wact);
+            step_partials<kSNTU * MB>(acc, red, w, lane);
+            for (int p = w; p < kSNTU * MB && cw; p += kSCW) {
                 const int j = p / MB, i = p - j * MB, tile = rank + 32 * j;
-                f32x4 o = step_reduced(red, 4 * MB, p, lane);
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(Lw.mlp0_b + 16 * tile + 4 * (lane >> 4));
+                f32x4 o = step_reduced(red, kSNTU * MB, p, lane);
+                const f32x4 bv = p == w ? bv0 : *reinterpret_cast<const f32x4*>(Lw.mlp0_b + 16 * tile + 4 * (lane >> 4));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r] + bv[r]);
                 *reinterpret_cast<f32x4*>(mlp + ((size_t)(i * KBM + tile) << 8) + lane * 4) = o;
             }
         }
-        step_barrier(st, xcc, n, ++round, trace);
+        end_phase(cw);
         // ---- MLP down + residual: column tile rank
         {
             f32x4 acc[MB];
-            step_mma<MB, 1, 16, false>(acc, wf, mlp_r, KBM, 16 * w, lane, true);
-            if (l + 1 < a.L) step_w_fetch<3, 4>(wf, a.layer[l + 1].qkv_wt, KBE, rank, 4 * w, lane, true);
-            else step_w_fetch<1, 4>(wf, a.out_wt, KBE, min(rank, a.C / 16 - 1), 4 * w, lane, true);
+            const unsigned off = (unsigned)(((w * KBE + rank) << 8) + lane * 4);  // wave w finishes row block w
+            f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f}, rv = bv;
+            if (cw && w < MB) {
+                bv = *reinterpret_cast<const f32x4*>(Lw.mlp2_b + 16 * rank + 4 * (lane >> 4));
+                rv = ld_l2(xres_r, off);
+            }
+            step_gemm<MB, 1, kSKBD, false>(acc, mlp_r, KBM, Lw.mlp2_wt, KBM, rank, kSKBD * w, lane, cw, wact);
             step_partials<MB>(acc, red, w, lane);
-            for (int p = w; p < MB; p += 8) {
+            for (int p = w; p < MB && cw; p += kSCW) {
                 f32x4 o = step_reduced(red, MB, p, lane);
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(Lw.mlp2_b + 16 * rank + 4 * (lane >> 4));
-                const unsigned off = (unsigned)(((p * KBE + rank) << 8) + lane * 4);
-                const f32x4 rv = ld_l2(xres_r, off);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = o[r] + bv[r] + rv[r];
                 *reinterpret_cast<f32x4*>(xres + off) = o;
             }
         }
-        step_barrier(st, xcc, n, ++round, trace);
+        end_phase(cw);
     }
     // ---- out_proj + CFG + Euler (+ the token-major latents of the next step): column tile rank < C / 16
     if (rank < a.C / 16) {
         f32x4 acc[MB];
-        step_mma<MB, 1, 4, false>(acc, wf, xres_r, KBE, 4 * w, lane, true);
+        step_gemm<MB, 1, kSKBQ, false>(acc, xres_r, KBE, a.out_wt, KBE, rank, kSKBQ * w, lane, cw, wact);
         step_partials<MB>(acc, red, w, lane);
-        float* const outt = red + 8 * MB * 256;  // [MB * 16 rows][16 columns]
-        for (int p = w; p < MB; p += 8) {
+        float* const outt = red + kSCW * MB * 256;  // [MB * 16 rows][16 columns]
+        for (int p = w; p < MB && cw; p += kSCW) {
             const f32x4 o = step_reduced(red, MB, p, lane);
             *reinterpret_cast<f32x4*>(outt + (16 * p + (lane & 15)) * 16 + 4 * (lane >> 4)) = o;
         }
@@ -1970,15 +2049,16 @@ int roll_cache_step(after_denoiser* h, hipStream_t s, int rows, int T, int size,
 }
 
 // Streamer.sample (export.py:398-416) with ONE launch per Euler step (stream_step_kernel).  Eligible: the shipped
-// streaming geometry -- embed 512 / mlp 2048 / eight heads (the kernel's tile counts: 32 workgroups per XCD own
-// 3 + 4 + 1 column tiles of the three Linears), finite causal window, <= 8 layers (the by-value argument block),
+// streaming geometry -- embed 512 / mlp 1536 / eight heads (the kernel's tile counts: 32 workgroups per XCD own
+// 3 + 3 + 1 column tiles of the three Linears), finite causal window, <= 8 layers (the by-value argument block),
 // 256 CUs, and at most 16 clip tokens per XCD (ceil(B / 8) * T <= 16: eight streams at 4 - 16 frames, 32 at 4).
 bool step_persist_ok(const after_denoiser* h, int B, int T) {
     const bool wide = h->W < 0 || !h->cfg.causal;
     const int cpg = (B + 7) / 8;
     return h->persist_step && h->cache > 0 && !h->timer.enabled && h->x6 != 2 && h->E == kSE && h->ME == kSME &&
            h->H == kSH && h->L <= 8 && !wide && h->Cp == h->C && h->C % 16 == 0 && h->C / 16 <= 8 && h->n_cus == 256 &&
-           cpg * T <= 16;
+           3 * cpg * T <= 32 &&  // (two 16-row blocks: the LDS budget of the partial tiles + the weight slot)
+           ((size_t)h->cs * (h->E + 4) + (size_t)kSH * 2 * (h->W - 1 + h->cs) * 16) <= 7168;
 }
 
 int step_tile_weights(after_denoiser* h, hipStream_t s) {
@@ -2031,8 +2111,9 @@ int sample_persistent(after_denoiser* h, hipStream_t s, const float* x0, float* 
     }
     const int cpg = (B + 7) / 8, MB = (3 * cpg * T + 15) / 16;
     const int nkmax = h->W - 1 + h->cs > h->cs ? h->W - 1 + h->cs : h->cs;
-    size_t lds = ((size_t)h->cs * (E + 4) + (size_t)kSH * 2 * nkmax * 16) * sizeof(float);
-    if (lds < (size_t)MB * 32768 + 4096) lds = (size_t)MB * 32768 + 4096;
+    const size_t attn_lds = ((size_t)h->cs * (E + 4) + (size_t)kSH * 2 * nkmax * 16) * sizeof(float);
+    AFTER_REQUIRE(attn_lds <= 7168 * sizeof(float), AFTER_E_INVALID, "persistent step: attention LDS %zu exceeds the slot", attn_lds);
+    const size_t lds = ((size_t)kSRedFloats(MB) + 8 * 2 * kAttnKeyBlock * 64) * sizeof(float);  // + the K / V landing zones
     const void* fn = MB == 1 ? reinterpret_cast<const void*>(stream_step_kernel<1>)
                              : (MB == 2 ? reinterpret_cast<const void*>(stream_step_kernel<2>)
                                         : reinterpret_cast<const void*>(stream_step_kernel<3>));
@@ -2063,6 +2144,21 @@ int sample_persistent(after_denoiser* h, hipStream_t s, const float* x0, float* 
         a.cfg = reinterpret_cast<const float*>(h->dparams);
         a.sync = h->step_sync + i;
         a.trace = h->step_trace;
+        {
+            static int dbg = -1;
+            if (dbg < 0) {
+                const char* e = getenv("AFTER_STEP_DBG");
+                dbg = e ? atoi(e) : 0;
+            }
+            a.dbg = dbg;
+            static int warm[3] = {-1, 0, 0};
+            if (warm[0] < 0) {
+                warm[0] = 4, warm[1] = 16, warm[2] = 4;
+                const char* e = getenv("AFTER_STEP_WARM");
+                if (e) sscanf(e, "%d,%d,%d", &warm[0], &warm[1], &warm[2]);
+            }
+            a.warm[0] = warm[0], a.warm[1] = warm[1], a.warm[2] = warm[2];
+        }
         const int cur = h->flip[i];
         for (int l = 0; l < L; ++l) {
             const LayerW& w = h->layers[l];

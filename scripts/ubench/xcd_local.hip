@@ -38,8 +38,67 @@ __device__ __forceinline__ bool spin_until(unsigned* word, unsigned want, unsign
 }
 
 // all threads call; n = workgroups of this XCC
+// no-return arrival atomic + SCALAR polling of the counter (s_load_dword glc: misses the scalar cache, served by the L2):
+// no vector-memory result is waited for, so loads a wave issued before the barrier stay in flight across it
+__device__ __forceinline__ bool scalar_barrier(LocalState* st, unsigned xcc, unsigned n, unsigned round) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    bool ok = true;
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(&st->arrive[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned* word = &st->arrive[xcc][0];
+        const unsigned want = round * n;
+        unsigned spins = 0;
+        for (;; ++spins) {
+            unsigned v;
+            asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(word) : "memory");
+            if (v >= want) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (spins > (1u << 22)) {
+                __hip_atomic_store(&st->timeout[0], 1u, RLX_AGENT);
+                ok = false;
+                break;
+            }
+        }
+    }
+    __builtin_amdgcn_s_barrier();
+    return ok;
+}
+
+// flag barrier: every workgroup stores the round into its own word of ONE 128-byte line per XCC (no atomics), and polls
+// the whole line with two scalar 16-dword loads until the minimum reaches the round
+typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ bool flag_barrier(LocalState* st, unsigned xcc, unsigned rank, unsigned round) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    bool ok = true;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&st->gen[xcc][rank], round, RLX_AGENT);
+        const unsigned* line = &st->gen[xcc][0];
+        unsigned spins = 0;
+        for (;; ++spins) {
+            u32x16 a, b;
+            asm volatile("s_load_dwordx16 %0, %2, 0x0 glc\n\ts_load_dwordx16 %1, %2, 0x40 glc\n\ts_waitcnt lgkmcnt(0)"
+                         : "=s"(a), "=s"(b) : "s"(line) : "memory");
+            unsigned m = 0xffffffffu;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) m = min(m, min(a[i], b[i]));
+            if (m >= round) break;
+            if (spins > (1u << 22)) {
+                __hip_atomic_store(&st->timeout[0], 1u, RLX_AGENT);
+                ok = false;
+                break;
+            }
+        }
+    }
+    __builtin_amdgcn_s_barrier();
+    return ok;
+}
+
 template <int INV>
-__device__ __forceinline__ bool local_barrier(LocalState* st, unsigned xcc, unsigned n, unsigned round) {
+__device__ __forceinline__ bool local_barrier(LocalState* st, unsigned xcc, unsigned n, unsigned round, unsigned rank) {
+    if (INV == 3) return flag_barrier(st, xcc, rank, round);
+    if (INV == 2) return scalar_barrier(st, xcc, n, round);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stores are in the XCD's L2 (the vector L1 is write-through)
     __syncthreads();
     bool ok = true;
@@ -82,12 +141,12 @@ __global__ __launch_bounds__(512) void k_local(LocalState* st, float* buf, int r
         if (MODE == 2)
             for (int i = threadIdx.x; i < REC / 4; i += 512)
                 reinterpret_cast<float4*>(mine)[i] = make_float4((float)(r * 1000 + rank), 1.f, 2.f, 3.f);
-        if (!local_barrier<INV>(st, xcc, n, ++round)) return;
-        if (MODE == 1 && threadIdx.x < 8) bad += (INV ? reinterpret_cast<const float4*>(theirs)[threadIdx.x] : load_sc1(reinterpret_cast<const float4*>(theirs) + threadIdx.x)).x != (float)(r * 1000 + peer);
+        if (!local_barrier<INV>(st, xcc, n, ++round, rank)) return;
+        if (MODE == 1 && threadIdx.x < 8) bad += (INV == 1 ? reinterpret_cast<const float4*>(theirs)[threadIdx.x] : load_sc1(reinterpret_cast<const float4*>(theirs) + threadIdx.x)).x != (float)(r * 1000 + peer);
         if (MODE == 2)
             for (int i = threadIdx.x; i < REC / 4; i += 512)
-                bad += (INV ? reinterpret_cast<const float4*>(theirs)[i] : load_sc1(reinterpret_cast<const float4*>(theirs) + i)).x != (float)(r * 1000 + peer);
-        if (!local_barrier<INV>(st, xcc, n, ++round)) return;
+                bad += (INV == 1 ? reinterpret_cast<const float4*>(theirs)[i] : load_sc1(reinterpret_cast<const float4*>(theirs) + i)).x != (float)(r * 1000 + peer);
+        if (!local_barrier<INV>(st, xcc, n, ++round, rank)) return;
     }
     if (bad) atomicAdd(errs, bad);
 }
@@ -104,16 +163,22 @@ int main() {
     (void)hipEventCreate(&e1);
     const int rounds = 2000;
     for (int mode = 0; mode < 3; ++mode) {
-        for (int inv = 0; inv < 2; ++inv) {
+        for (int inv = 0; inv < 4; ++inv) {
             (void)hipMemset(st, 0, sizeof(LocalState));
             (void)hipMemset(errs, 0, 4);
             (void)hipEventRecord(e0);
-            if (mode == 0 && inv) hipLaunchKernelGGL((k_local<0, 1>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
-            if (mode == 1 && inv) hipLaunchKernelGGL((k_local<1, 1>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
-            if (mode == 2 && inv) hipLaunchKernelGGL((k_local<2, 1>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
+            if (mode == 0 && inv == 1) hipLaunchKernelGGL((k_local<0, 1>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
+            if (mode == 1 && inv == 1) hipLaunchKernelGGL((k_local<1, 1>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
+            if (mode == 2 && inv == 1) hipLaunchKernelGGL((k_local<2, 1>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
             if (mode == 0 && !inv) hipLaunchKernelGGL((k_local<0, 0>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
             if (mode == 1 && !inv) hipLaunchKernelGGL((k_local<1, 0>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
             if (mode == 2 && !inv) hipLaunchKernelGGL((k_local<2, 0>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
+            if (mode == 0 && inv == 2) hipLaunchKernelGGL((k_local<0, 2>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
+            if (mode == 1 && inv == 2) hipLaunchKernelGGL((k_local<1, 2>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
+            if (mode == 2 && inv == 2) hipLaunchKernelGGL((k_local<2, 2>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
+            if (mode == 0 && inv == 3) hipLaunchKernelGGL((k_local<0, 3>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
+            if (mode == 1 && inv == 3) hipLaunchKernelGGL((k_local<1, 3>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
+            if (mode == 2 && inv == 3) hipLaunchKernelGGL((k_local<2, 3>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
             (void)hipEventRecord(e1);
             (void)hipEventSynchronize(e1);
             float ms;
@@ -124,7 +189,7 @@ int main() {
             (void)hipMemcpy(&hs, st, sizeof(hs), hipMemcpyDeviceToHost);
             printf("{\"ubench\": \"xcd_local_barrier\", \"mode\": \"%s\", \"reader\": \"%s\", \"us_per_barrier\": %.2f, \"visibility_errors\": %d, "
                    "\"timeout\": %u, \"pop\": [%u,%u,%u,%u,%u,%u,%u,%u]}\n",
-                   mode == 0 ? "bare" : (mode == 1 ? "record_128B" : "tile_32KB"), inv ? "buffer_inv sc1" : "sc1 loads", ms * 1e3 / (2 * rounds), h, hs.timeout[0],
+                   mode == 0 ? "bare" : (mode == 1 ? "record_128B" : "tile_32KB"), inv == 3 ? "sc1 loads, flag-line barrier (scalar polls)" : inv == 2 ? "sc1 loads, scalar-polled barrier" : (inv ? "buffer_inv sc1" : "sc1 loads"), ms * 1e3 / (2 * rounds), h, hs.timeout[0],
                    hs.pop[0][0], hs.pop[1][0], hs.pop[2][0], hs.pop[3][0], hs.pop[4][0], hs.pop[5][0], hs.pop[6][0], hs.pop[7][0]);
         }
     }
