@@ -217,6 +217,8 @@ class DenoiserV2(nn.Module):
             _lib.check(L.after_denoiser_profile(out, 1), "after_denoiser_profile")
         if getattr(self, "_gemm_path", None) is not None:
             _lib.check(L.after_denoiser_set_gemm_path(out, *self._gemm_path), "after_denoiser_set_gemm_path")
+        if getattr(self, "_stream_persist", None) is not None:
+            _lib.check(L.after_denoiser_set_stream_persist(out, int(self._stream_persist)), "after_denoiser_set_stream_persist")
         if self._stream_args is not None and not getattr(self, "_enabling", False):
             # the handle was rebuilt (.to(), load_state_dict, refresh): a Streamer still expects
             # its K/V caches -- re-create them (zeroed = a new stream), as AutoEncoder / Encoder1D do
@@ -361,6 +363,23 @@ class DenoiserV2(nn.Module):
         if self._handle is not None:
             _lib.check(_lib.lib().after_denoiser_set_gemm_path(self._handle, int(mode), int(min_rows)),
                        "after_denoiser_set_gemm_path")
+
+    def set_stream_persist(self, enable: bool):
+        """Streaming sampler (cfg_sample on a handle with K/V caches): one persistent launch per Euler step where the
+        geometry allows it (include/after_hip.h: after_denoiser_set_stream_persist), or the launch-per-kernel path."""
+        self._stream_persist = bool(enable)
+        if self._handle is not None:
+            _lib.check(_lib.lib().after_denoiser_set_stream_persist(self._handle, int(bool(enable))),
+                       "after_denoiser_set_stream_persist")
+
+    def stream_persist(self) -> bool:
+        """True when the last streaming cfg_sample of this handle ran (and the next one of the same shape will run) as
+        persistent launches."""
+        if self._handle is None:
+            return False
+        a = ctypes.c_int()
+        _lib.check(_lib.lib().after_denoiser_stream_persist(self._handle, ctypes.byref(a)), "after_denoiser_stream_persist")
+        return bool(a.value)
 
     def gemm_path(self):
         """(mode, min_rows) in effect (the handle's, i.e. including the AFTER_GEMM_X6 environment default)."""

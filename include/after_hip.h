@@ -131,12 +131,15 @@ int after_denoiser_set_gemm_path(after_denoiser* h, int mode, int min_rows);
 int after_denoiser_gemm_path(after_denoiser* h, int* mode, int* min_rows);
 
 /* The streaming sampler (after_sample on a handle with K/V caches: Streamer.sample, after_scripts/export.py:398-416)
- * runs each cached Euler step as ONE persistent launch -- every phase of the network behind a device-wide
- * barrier inside the kernel -- when the geometry allows it (eight heads, finite causal window, <= 8 layers, Linear
- * widths multiples of 128, gemm path != 2); otherwise, or with enable = 0 / AFTER_STREAM_PERSIST=0, as the
- * launch-per-kernel sequence.  Same arithmetic either way.  A barrier that times out (the workgroups could not
- * all be resident) is reported by the NEXT after_sample call on the handle, which also selects the launch path.
- * after_denoiser_stream_persist: *active = 1 when after_sample would take the persistent path now. */
+ * runs each cached Euler step as ONE persistent launch -- eight independent XCD-local pipelines, clip c on XCD
+ * c / ceil(B / 8), every phase of the network behind an XCD-local barrier inside the kernel -- when the geometry allows
+ * it: embed 512 / mlp x 3 / eight heads, finite causal window, <= 8 layers, 256 CUs, ceil(B / 8) * T * 3 <= 32 token rows
+ * per XCD, gemm path != 2.  Otherwise, or with enable = 0 / AFTER_STREAM_PERSIST=0, as the launch-per-kernel sequence.
+ * Same arithmetic (fp32 MFMA, a different but fixed K split): the two paths agree to fp32 round-off.  A step whose
+ * workgroups were not placed 32 per XCD, or an XCD-local barrier that timed out, is reported by the NEXT after_sample
+ * call on the handle (AFTER_E_HIP; that call also selects the launch path): the chunk before it is invalid, reset the
+ * streamer.  after_denoiser_stream_persist: *active = 1 when the handle's last streaming shape takes the persistent
+ * path. */
 int after_denoiser_set_stream_persist(after_denoiser* h, int enable);
 int after_denoiser_stream_persist(after_denoiser* h, int* active);
 /* Diagnostics (AFTER_STEP_TRACE=1 at the first streaming call): out[workgroup][128] = 100 MHz wall-clock stamps of
