@@ -812,13 +812,18 @@ __device__ __forceinline__ void step_warm_done(unsigned& sink) { asm volatile("s
 // [N / 16][w_kblocks][256] copy, plain loads (never written).  Loads return in issue order: the first A k-blocks go
 // first (L2 hits), then the weight fragments in the order the MFMAs consume them (k-block-major), so the MFMAs of
 // k-block u run while the fragments of u + 1 .. are still arriving from the fabric.
-template <int MB, int NT, int KB, bool AROW>
+// `after_loads()` runs once every operand load of the phase has been issued (before the last A chunk's MFMAs): the place to
+// request the NEXT phase's small operands -- behind this phase's loads in the wave's in-order queue, landing under the MFMAs.
+template <int MB, int NT, int KB, bool AROW, class F>
 __device__ __forceinline__ void step_gemm(f32x4 (&acc)[NT * MB], __amdgpu_buffer_rsrc_t A, int a_kblocks,
                                           const float* __restrict__ wt, int w_kblocks, int tile0, int kb0, int lane,
-                                          bool active, bool wact, const float* arow = nullptr) {
+                                          bool active, bool wact, F&& after_loads, const float* arow = nullptr) {
 #pragma unroll
     for (int p = 0; p < NT * MB; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!active) return;
+    if (!active) {
+        after_loads();
+        return;
+    }
     constexpr int CH = KB * MB <= 12 ? KB : 4;  // k-blocks of A in flight
     f32x4 wf[NT * KB], av[CH][MB];
     auto load_a = [&](int u0) {
@@ -840,6 +845,7 @@ __device__ __forceinline__ void step_gemm(f32x4 (&acc)[NT * MB], __amdgpu_buffer
 #pragma unroll
     for (int u0 = 0; u0 < KB; u0 += CH) {
         if (u0 > 0) load_a(u0);
+        if (u0 + CH >= KB) after_loads();
 #pragma unroll
         for (int u = 0; u < CH; ++u)
 #pragma unroll
@@ -871,21 +877,33 @@ __device__ __forceinline__ f32x4 step_reduced(const float* red, int P, int p, in
     return o;
 }
 
+// The row-wise operands of a LayerNorm phase -- AdaLN alpha / beta of the row, affine weight / bias: 4 x 2 float4 per
+// lane (lane owns channels 4 lane + 256 i) -- come from the memory-side cache (~2 us).  They are requested one GEMM phase
+// EARLY (behind that phase's operand loads, see step_gemm's `after_loads`) and ride through the barrier in registers.
+struct StepLnOps {
+    f32x4 al[kSE / 256], be[kSE / 256], ww[kSE / 256], bb[kSE / 256];
+};
+
+__device__ __forceinline__ void step_ln_ops(StepLnOps& o, const float* __restrict__ ab, const float* __restrict__ w1,
+                                            const float* __restrict__ b1, int lane) {
+#pragma unroll
+    for (int i = 0; i < kSE / 256; ++i) {
+        const int c = 4 * lane + 256 * i;
+        o.al[i] = *reinterpret_cast<const f32x4*>(ab + c);
+        o.be[i] = *reinterpret_cast<const f32x4*>(ab + kSE + c);
+        o.ww[i] = *reinterpret_cast<const f32x4*>(w1 + c);
+        o.bb[i] = *reinterpret_cast<const f32x4*>(b1 + c);
+    }
+}
+
 // ln_mod_ln_row on tiled buffers (E = 512): x = norm0(xin[src]) * (1 + alpha_t) + beta_t -> xres ; h = norm1(x)
 __device__ __forceinline__ void step_ln_row(__amdgpu_buffer_rsrc_t xin, int src_lr, float* __restrict__ xres,
-                                            float* __restrict__ h, int lr, const float* __restrict__ ab,
-                                            const float* __restrict__ w1, const float* __restrict__ b1, int lane) {
+                                            float* __restrict__ h, int lr, const StepLnOps& ops, int lane) {
     constexpr int E = kSE, NV = E / 256, KBt = E / 16;
-    f32x4 v[NV], al[NV], be[NV], ww[NV], bb[NV];
+    f32x4 v[NV];
+    const f32x4 (&al)[NV] = ops.al, (&be)[NV] = ops.be, (&ww)[NV] = ops.ww, (&bb)[NV] = ops.bb;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = 4 * lane + 256 * i;
-        v[i] = ld_l2(xin, t16_off(src_lr, c, KBt));
-        al[i] = *reinterpret_cast<const f32x4*>(ab + c);
-        be[i] = *reinterpret_cast<const f32x4*>(ab + E + c);
-        ww[i] = *reinterpret_cast<const f32x4*>(w1 + c);
-        bb[i] = *reinterpret_cast<const f32x4*>(b1 + c);
-    }
+    for (int i = 0; i < NV; ++i) v[i] = ld_l2(xin, t16_off(src_lr, 4 * lane + 256 * i, KBt));
     auto stats = [&](float& mean, float& rstd) {
         float s = 0.f;
 #pragma unroll
@@ -926,7 +944,7 @@ __device__ __forceinline__ void step_ln_row(__amdgpu_buffer_rsrc_t xin, int src_
 // through sc1 loads from this layer's qkv, the cached frames from the K / V ring (written by an earlier launch),
 // residual stream and h in the XCD's tiled buffers.  smem: [cs][E + 4] | per-wave cos, sin [nkmax][16]; kvlds: K / V
 // landing zones [8 waves][2][12][64].
-__device__ __forceinline__ void step_attention(const StepArgs& a, const StepLayer& L, const float* __restrict__ cond_ab, int rg,
+__device__ __forceinline__ void step_attention(const StepArgs& a, const StepLayer& L, const StepLnOps& ops, int rg,
                                                int lr0, int bx, float* smem, float* kvlds, __amdgpu_buffer_rsrc_t qkvr,
                                                __amdgpu_buffer_rsrc_t xr, float* __restrict__ xres, float* __restrict__ hout) {
     constexpr int NKMAX = kAttnKeyBlock, E = kSE, H = kSH, KBt = E / 16, ld = E + 4;
@@ -951,17 +969,8 @@ __device__ __forceinline__ void step_attention(const StepArgs& a, const StepLaye
         tc1 = *reinterpret_cast<const float4*>(a.rope_cos + (size_t)lo_c * 16 + (lane + 64) * 4);
         ts1 = *reinterpret_cast<const float4*>(a.rope_sin + (size_t)lo_c * 16 + (lane + 64) * 4);
     }
-    const float* abp = cond_ab + (size_t)rg * a.cond_ld;
     constexpr int NV = E / 256;
-    float4 al[NV], be[NV], ww[NV], bb[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = 4 * lane + 256 * i;
-        al[i] = *reinterpret_cast<const float4*>(abp + c);
-        be[i] = *reinterpret_cast<const float4*>(abp + E + c);
-        ww[i] = *reinterpret_cast<const float4*>(L.n3w + c);
-        bb[i] = *reinterpret_cast<const float4*>(L.n3b + c);
-    }
+    const f32x4 (&al)[NV] = ops.al, (&be)[NV] = ops.be, (&ww)[NV] = ops.ww, (&bb)[NV] = ops.bb;
     auto as4 = [](f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
     for (int qb = 0; qb < nq; qb += 4) {
         const int qi = qb + grp;
@@ -1171,6 +1180,21 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
     const size_t wbytes = (size_t)E * ME * sizeof(float);
     static_assert(kSME == 3 * kSE, "qkv and MLP weights of one size");
     auto end_phase = [&](bool drain) { step_barrier(st, xcc, n, ++round, trace, drain); };
+    // the LayerNorm-phase operands of this wave's row (ln phase: row rank + 32 w) / this workgroup's attention item,
+    // requested one GEMM phase early (StepLnOps)
+    StepLnOps lnops, atops;
+    const int ln_lm = rank + (int)n * w;  // this wave's (first) row of the ln phases
+    const bool ln_mine = ln_lm < 3 * cpg * T && (ln_lm % (cpg * T)) / T < nclip;
+    auto ln_prefetch = [&](int l) {
+        if (!ln_mine) return;
+        const int br = ln_lm / ct, rem = ln_lm - br * ct, cl = rem / T, t = rem - cl * T, rg = br * B + c0 + cl;
+        step_ln_ops(lnops, a.tc_ab + ((size_t)a.tcmap[rg] * T + t) * a.tc_ld + (size_t)l * 2 * E, a.layer[l].n1w, a.layer[l].n1b, lane);
+    };
+    const int nchunks = (T + a.cs - 1) / a.cs, nitems = 3 * nclip * nchunks;
+    auto attn_prefetch = [&](int l, int it) {
+        const int q = it / nchunks, br = q / nclip, rg = br * B + c0 + (q - br * nclip);
+        step_ln_ops(atops, a.cond_ab + (size_t)rg * a.cond_ld + (size_t)l * 2 * E, a.layer[l].n3w, a.layer[l].n3b, lane);
+    };
 
     // ---- patchify_and_embed: pat = GELU(xt patch_w^T + b) for the XCD's ct clip tokens (transformerv2.py:387-391)
     {
@@ -1178,7 +1202,7 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
         f32x4 acc[1];
         const float* arow = a.xt + (size_t)(c0 * T + min(lane & 15, nclip * T - 1)) * a.Cp;
         const f32x4 bv = w == 0 ? *reinterpret_cast<const f32x4*>(a.patch_b + 16 * rank + 4 * (lane >> 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
-        step_gemm<1, 1, 1, true>(acc, pat_r, 0, a.patch_wt, kbp, rank, w, lane, w < kbp, wact, arow);
+        step_gemm<1, 1, 1, true>(acc, pat_r, 0, a.patch_wt, kbp, rank, w, lane, w < kbp, wact, [&] { ln_prefetch(0); }, arow);
         // (all eight waves may carry a k-block here: partial tiles through the full-width LDS exchange)
         __syncthreads();
         *reinterpret_cast<f32x4*>(red + ((w << 6) + lane) * 4) = acc[0];
@@ -1193,17 +1217,16 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
         }
     }
     end_phase(cw);
-    const int nchunks = (T + a.cs - 1) / a.cs;
     for (int l = 0; l < a.L; ++l) {
         const StepLayer& Lw = a.layer[l];
         const __amdgpu_buffer_rsrc_t qkv_r = step_rsrc(Lw.qkv);
         // ---- norm0 -> AdaLN(tcond) -> norm1: one wave per token row, rows dealt round-robin to the workgroups
-        for (int lm = rank + (int)n * w; lm < Mg; lm += (int)n * 8) {
+        for (int lm = ln_lm; lm < Mg; lm += (int)n * 8) {
             const int br = lm / ct, rem = lm - br * ct, cl = rem / T, t = rem - cl * T;
             if (cl < nclip) {
-                const int rg = br * B + c0 + cl;
-                const float* ab = a.tc_ab + ((size_t)a.tcmap[rg] * T + t) * a.tc_ld + (size_t)l * 2 * E;
-                step_ln_row(l == 0 ? pat_r : xres_r, l == 0 ? rem : lm, xres, hb, lm, ab, Lw.n1w, Lw.n1b, lane);
+                if (lm != ln_lm)  // (more than 256 rows per XCD: never with the shipped limits)
+                    step_ln_ops(lnops, a.tc_ab + ((size_t)a.tcmap[br * B + c0 + cl] * T + t) * a.tc_ld + (size_t)l * 2 * E, Lw.n1w, Lw.n1b, lane);
+                step_ln_row(l == 0 ? pat_r : xres_r, l == 0 ? rem : lm, xres, hb, lm, lnops, lane);
             }
         }
         if (wact && rank >= Mg) {  // workgroups without a row (a warming wave next to a row's wave delays its loads: one
@@ -1222,7 +1245,8 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
         // ---- qkv: column tiles rank, rank + 32, rank + 64
         {
             f32x4 acc[3 * MB];
-            step_gemm<MB, 3, kSKBQ, false>(acc, hb_r, KBE, Lw.qkv_wt, KBE, rank, kSKBQ * w, lane, cw, wact);
+            step_gemm<MB, 3, kSKBQ, false>(acc, hb_r, KBE, Lw.qkv_wt, KBE, rank, kSKBQ * w, lane, cw, wact,
+                                           [&] { if (rank < nitems) attn_prefetch(l, rank); });
             step_partials<3 * MB>(acc, red, w, lane);
             for (int p = w; p < 3 * MB && cw; p += kSCW) {
                 const int j = p / MB, i = p - j * MB;
@@ -1238,11 +1262,11 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
         //      other workgroups roll this layer's K / V ring by T frames (MHAttention.roll_cache,
         //      transformerv2.py:171-188: flip-flop halves, out of place)
         {
-            const int nitems = 3 * nclip * nchunks;
             for (int it = rank; it < nitems; it += (int)n) {
                 const int q = it / nchunks, bx = it - q * nchunks, br = q / nclip, cl = q - br * nclip;
                 __syncthreads();  // (a second item of this workgroup reuses the LDS rows)
-                step_attention(a, Lw, a.cond_ab + (size_t)l * 2 * E, br * B + c0 + cl, br * ct + cl * T, bx, smem, kvl, qkv_r, xres_r,
+                if (it != rank) attn_prefetch(l, it);
+                step_attention(a, Lw, atops, br * B + c0 + cl, br * ct + cl * T, bx, smem, kvl, qkv_r, xres_r,
                                xres, hb);
             }
             const int nroll = nitems < (int)n ? (int)n - nitems : (int)n, rb = nitems < (int)n ? rank - nitems : rank;
@@ -1266,7 +1290,7 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
             const int pj = w / MB;
             const f32x4 bv0 = cw && w < kSNTU * MB ? *reinterpret_cast<const f32x4*>(Lw.mlp0_b + 16 * (rank + 32 * pj) + 4 * (lane >> 4))
                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
-            step_gemm<MB, kSNTU, kSKBQ, false>(acc, hb_r, KBE, Lw.mlp0_wt, KBE, rank, kSKBQ * w, lane, cw, wact);
+            step_gemm<MB, kSNTU, kSKBQ, false>(acc, hb_r, KBE, Lw.mlp0_wt, KBE, rank, kSKBQ * w, lane, cw, wact, [] {});
             step_partials<kSNTU * MB>(acc, red, w, lane);
             for (int p = w; p < kSNTU * MB && cw; p += kSCW) {
                 const int j = p / MB, i = p - j * MB, tile = rank + 32 * j;
@@ -1287,7 +1311,8 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
                 bv = *reinterpret_cast<const f32x4*>(Lw.mlp2_b + 16 * rank + 4 * (lane >> 4));
                 rv = ld_l2(xres_r, off);
             }
-            step_gemm<MB, 1, kSKBD, false>(acc, mlp_r, KBM, Lw.mlp2_wt, KBM, rank, kSKBD * w, lane, cw, wact);
+            step_gemm<MB, 1, kSKBD, false>(acc, mlp_r, KBM, Lw.mlp2_wt, KBM, rank, kSKBD * w, lane, cw, wact,
+                                           [&] { if (l + 1 < a.L) ln_prefetch(l + 1); });
             step_partials<MB>(acc, red, w, lane);
             for (int p = w; p < MB && cw; p += kSCW) {
                 f32x4 o = step_reduced(red, MB, p, lane);
@@ -1301,7 +1326,7 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
     // ---- out_proj + CFG + Euler (+ the token-major latents of the next step): column tile rank < C / 16
     if (rank < a.C / 16) {
         f32x4 acc[MB];
-        step_gemm<MB, 1, kSKBQ, false>(acc, xres_r, KBE, a.out_wt, KBE, rank, kSKBQ * w, lane, cw, wact);
+        step_gemm<MB, 1, kSKBQ, false>(acc, xres_r, KBE, a.out_wt, KBE, rank, kSKBQ * w, lane, cw, wact, [] {});
         step_partials<MB>(acc, red, w, lane);
         float* const outt = red + kSCW * MB * 256;  // [MB * 16 rows][16 columns]
         for (int p = w; p < MB && cw; p += kSCW) {

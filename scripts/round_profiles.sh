@@ -27,6 +27,16 @@ python scripts/bench_gemm_x6.py $O/${R}_gemm_x6_sweep.jsonl > $O/x6_sweep.log 2>
 python scripts/time_codec.py --rounds 30 2>/dev/null | grep workload > $O/${R}_codec.jsonl
 python scripts/time_encoders.py 2>/dev/null | grep workload >> $O/${R}_codec.jsonl
 ./scripts/ubench/xcd_barrier.bin > $O/${R}_xcd_barrier.jsonl 2>/dev/null
+./scripts/ubench/xcd_local.bin > $O/${R}_xcd_local.jsonl 2>/dev/null
+# the persistent streaming step: same-box A/B against the launch path, per-phase timeline, kernel stats of a chunk
+for p in 1 0 1 0; do
+  AFTER_STREAM_PERSIST=$p python bench.py --stream --steps 24 --warmup 4 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'leg': 'stream 8x100 steps', 'AFTER_STREAM_PERSIST': $p, 'ms_per_chunk': d['ms_per_step'], 'xrt': d['value']}))" >> $O/${R}_ab_stream_persist.jsonl
+done
+python scripts/stream_step_trace.py > $O/${R}_stream_step_trace.txt 2>/dev/null
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/sp -- python $GRAFT_REPO_ROOT/bench.py --stream --steps 6 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/sp.log 2>&1)
+f=$(find $O/sp -name "*kernel_stats.csv" | head -1)
+head -31 "$f" | cut -c1-260 > $O/${R}_bench_stream_kernel_stats.csv
+rm -rf $O/sp
 for b in 1 8; do
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/st$b -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --batch-per-gpu $b --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/st$b.log 2>&1)
   f=$(find $O/st$b -name "*kernel_stats.csv" | head -1)
