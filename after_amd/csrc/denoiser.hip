@@ -711,25 +711,31 @@ struct StepSync {
 struct StepLayer {
     const float *qkv_wt, *mlp0_wt, *mlp0_b, *mlp2_wt, *mlp2_b, *n1w, *n1b, *n3w, *n3b;  // *_wt: 16 x 16-tiled copies
     float* qkv;                // this layer's [rows * T][3E], row-major (attention, roll_cache)
-    const float *kold, *vold;  // cache half the step attends over
-    float *knew, *vnew;        // the other half: rolled by T frames
+};
+
+struct StepKV {
+    const float *kold, *vold;  // K / V ring halves the step attends over
+    float *knew, *vnew;        // the other halves: rolled by T frames
 };
 
 struct StepArgs {
     int rows, B, T, C, Cp, L, cs, W, nkmax, cache, cache_rows, cpg, dbg;
+    int nsteps, cache_steps;  // Euler steps of this launch (ALL of a sample() call); ring slots per layer
+    unsigned flip[4];         // bit i: which half of step i's K / V rings is current
     int warm[3];  // sixteenths of the qkv / MLP-up / MLP-down weights warmed into the L2 by idle waves (AFTER_STEP_WARM)
-    const float* xt;                       // token-major latents [B * T][Cp] (this step's input)
+    float* xt;                             // token-major latents [B * T][Cp]: a step's input, rewritten by its tail
     float *pat_t, *xres_t, *h_t, *mlp_t;   // tiled, one slice of kSGroupRows rows per XCD
     const float *patch_wt, *patch_b, *out_wt, *out_b;
     const float* tc_ab;
     int tc_ld;
     const int* tcmap;
-    const float* cond_ab;  // this step's rows
+    const float* cond_ab;  // [steps][rows][L * 2E]
+    size_t cond_step;      // floats between steps
     int cond_ld;
     const float *rope_cos, *rope_sin;
-    const float* xin;  // [B, C, T]
-    float* xout;
-    float* xt_next;    // token-major copy for the next step (nullptr on the last)
+    const float* x0;   // [B, C, T]: the noise
+    float* xout;       // [B, C, T]: the latents after every step (read back by the next one)
+    float *kcache, *vcache;  // [L][cache_steps][2 halves][cache_rows * cache * E]
     const float* cfg;  // device CfgParams
     StepSync* sync;
     unsigned long long* trace;  // AFTER_STEP_TRACE: [gridDim][128] wall-clock stamps (100 MHz) around every barrier
@@ -772,19 +778,22 @@ __device__ __forceinline__ bool step_spin(unsigned* word, unsigned want, unsigne
 // XCD-local barrier (all threads of the workgroup call it; n = workgroups of this XCC).  `drain`: this wave stored
 // something in the phase -- wait until it is in the XCD's L2 (write-through L1).  A streaming wave passes false: its
 // L2-warming loads stay in flight across the barrier (raw s_barrier: no memory wait).
-__device__ __forceinline__ void step_barrier(StepSync* st, unsigned xcc, unsigned n, unsigned round,
-                                             unsigned long long* trace, bool drain) {
+__device__ __forceinline__ bool step_barrier(StepSync* st, unsigned xcc, unsigned n, unsigned round,
+                                             unsigned long long* trace, unsigned tslot, bool drain, unsigned* s_ok) {
     if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (threadIdx.x == 0) {
-        if (trace) trace[2 * round - 1] = wall_clock64();
+        if (trace) trace[2 * tslot - 1] = wall_clock64();
+        bool ok = true;
         const unsigned ticket = __hip_atomic_fetch_add(&st->arrive[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (ticket == round * n - 1) __hip_atomic_store(&st->gen[xcc][0], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else step_spin(&st->gen[xcc][0], round, &st->fail[0]);
-        if (trace) trace[2 * round] = wall_clock64();
+        else ok = step_spin(&st->gen[xcc][0], round, &st->fail[0]);
+        *s_ok = ok;
+        if (trace) trace[2 * tslot] = wall_clock64();
     }
     __builtin_amdgcn_s_barrier();
+    return *s_ok != 0;  // false: a spin gave up (flag raised) -- the caller leaves the kernel instead of timing out 3000 more times
 }
 
 // L2 warming: touch one dword per 128-byte line of memory the XCD is about to stream (the next GEMM phase's weight tiles,
@@ -808,7 +817,7 @@ __device__ __forceinline__ void step_warm_done(unsigned& sink) { asm volatile("s
 
 // acc[j * MB + i] = (this wave's K slice: k-blocks kb0 .. kb0 + KB) of rows 16 i .. 16 i + 15 of A x column tile
 // tile0 + 32 j of W.  A: tiled buffer read with sc1 loads (`a_kblocks` k-blocks per row block), or -- AROW -- row-major
-// rows of a matrix written before the kernel (`arow` = this lane's row: the token-major latents of patchify).  W: tiled
+// rows of a row-major matrix (`arow_off` = float offset of this lane's row: the token-major latents of patchify).  W: tiled
 // [N / 16][w_kblocks][256] copy, plain loads (never written).  Loads return in issue order: the first A k-blocks go
 // first (L2 hits), then the weight fragments in the order the MFMAs consume them (k-block-major), so the MFMAs of
 // k-block u run while the fragments of u + 1 .. are still arriving from the fabric.
@@ -817,7 +826,7 @@ __device__ __forceinline__ void step_warm_done(unsigned& sink) { asm volatile("s
 template <int MB, int NT, int KB, bool AROW, class F>
 __device__ __forceinline__ void step_gemm(f32x4 (&acc)[NT * MB], __amdgpu_buffer_rsrc_t A, int a_kblocks,
                                           const float* __restrict__ wt, int w_kblocks, int tile0, int kb0, int lane,
-                                          bool active, bool wact, F&& after_loads, const float* arow = nullptr) {
+                                          bool active, bool wact, F&& after_loads, unsigned arow_off = 0) {
 #pragma unroll
     for (int p = 0; p < NT * MB; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (!active) {
@@ -831,7 +840,7 @@ __device__ __forceinline__ void step_gemm(f32x4 (&acc)[NT * MB], __amdgpu_buffer
         for (int u = 0; u < CH; ++u)
 #pragma unroll
             for (int i = 0; i < MB; ++i) {
-                if constexpr (AROW) av[u][i] = *reinterpret_cast<const f32x4*>(arow + (size_t)(kb0 + u0 + u) * 16 + (lane >> 4) * 4);
+                if constexpr (AROW) av[u][i] = ld_l2(A, arow_off + (unsigned)(kb0 + u0 + u) * 16 + (lane >> 4) * 4);
                 else av[u][i] = ld_l2(A, (unsigned)(((i * a_kblocks + kb0 + u0 + u) << 8) + lane * 4));
             }
     };
@@ -944,7 +953,7 @@ __device__ __forceinline__ void step_ln_row(__amdgpu_buffer_rsrc_t xin, int src_
 // through sc1 loads from this layer's qkv, the cached frames from the K / V ring (written by an earlier launch),
 // residual stream and h in the XCD's tiled buffers.  smem: [cs][E + 4] | per-wave cos, sin [nkmax][16]; kvlds: K / V
 // landing zones [8 waves][2][12][64].
-__device__ __forceinline__ void step_attention(const StepArgs& a, const StepLayer& L, const StepLnOps& ops, int rg,
+__device__ __forceinline__ void step_attention(const StepArgs& a, const StepLayer& L, const StepKV& kv, const StepLnOps& ops, int rg,
                                                int lr0, int bx, float* smem, float* kvlds, __amdgpu_buffer_rsrc_t qkvr,
                                                __amdgpu_buffer_rsrc_t xr, float* __restrict__ xres, float* __restrict__ hout) {
     constexpr int NKMAX = kAttnKeyBlock, E = kSE, H = kSH, KBt = E / 16, ld = E + 4;
@@ -994,8 +1003,8 @@ __device__ __forceinline__ void step_attention(const StepArgs& a, const StepLaye
                 const float* ksrc = L.qkv + ((size_t)rowbase + (pos - nc)) * 3 * E + E + hw * 64 + d4;
                 const float* vsrc = ksrc + E;
                 if (pos < nc) {
-                    ksrc = L.kold + ((size_t)rg * nc + pos) * E + hw * 64 + d4;
-                    vsrc = L.vold + ((size_t)rg * nc + pos) * E + hw * 64 + d4;
+                    ksrc = kv.kold + ((size_t)rg * nc + pos) * E + hw * 64 + d4;
+                    vsrc = kv.vold + ((size_t)rg * nc + pos) * E + hw * 64 + d4;
                 }
                 __builtin_amdgcn_global_load_lds((gbl_ptr_t)ksrc, (lds_ptr_t)(kvs + 4 * u * 64), 16, 0, 16);
                 __builtin_amdgcn_global_load_lds((gbl_ptr_t)vsrc, (lds_ptr_t)(kvs + (NKMAX + 4 * u) * 64), 16, 0, 16);
@@ -1101,7 +1110,7 @@ __device__ __forceinline__ void step_attention(const StepArgs& a, const StepLaye
 template <int MB>
 __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ unsigned s_n, s_rank, s_bad;
+    __shared__ unsigned s_n, s_rank, s_bad, s_ok;
     constexpr int E = kSE, ME = kSME, KBE = E / 16, KBM = ME / 16;
     StepSync* st = a.sync;
     const unsigned xcc = step_xcc_id(), nb = gridDim.x;
@@ -1122,16 +1131,23 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
     if (s_bad) return;  // (every workgroup reads the same populations: all of them leave)
     const unsigned n = s_n;
     const int rank = __builtin_amdgcn_readfirstlane((int)s_rank), g = (int)xcc;
-    unsigned round = 0;
+    unsigned round = 0, tslot = 0;  // barrier rounds of the launch / of the current step (trace slots)
     unsigned long long* trace = a.trace ? a.trace + (size_t)blockIdx.x * 128 : nullptr;
-    if (trace && tid == 0) trace[0] = wall_clock64();
 
     // this XCD's clips [c0, c0 + nclip), local token rows lm = (branch * cpg + clip) * T + t
     const int T = a.T, B = a.B, cpg = a.cpg, ct = cpg * T;
     const int c0 = g * cpg, nclip = min(cpg, B - c0);
+    // K / V ring halves of (layer, step): [L][cache_steps][2][cache_rows * cache * E], flip-flop by a.flip
+    const size_t per = (size_t)a.cache_rows * a.cache * E;
+    auto rings = [&](int l, int i) {
+        const size_t slot = ((size_t)l * a.cache_steps + i) * 2;
+        const unsigned cur = (a.flip[i >> 5] >> (i & 31)) & 1u;
+        return StepKV{a.kcache + (slot + cur) * per, a.vcache + (slot + cur) * per, a.kcache + (slot + (cur ^ 1u)) * per,
+                      a.vcache + (slot + (cur ^ 1u)) * per};
+    };
     // MHAttention.roll_cache (transformerv2.py:171-188) for this XCD's `nown` network rows and the provisioned-but-unused
     // cache rows r = rows + g + 8 q (copied through): flip-flop halves, out of place; workgroup rb of nroll
-    auto roll = [&](const StepLayer& Lw, __amdgpu_buffer_rsrc_t qkv_r, int nown, int rb, int nroll) {
+    auto roll = [&](const StepKV& kv, __amdgpu_buffer_rsrc_t qkv_r, int nown, int rb, int nroll) {
         const int nc = a.cache, per4 = nc * E / 4;
         const int nextra = a.cache_rows - a.rows > g ? (a.cache_rows - a.rows - g + 7) / 8 : 0;
         for (int idx = rb * 512 + tid; idx < (nown + nextra) * per4; idx += nroll * 512) {
@@ -1145,24 +1161,25 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
                 rg = a.rows + g + 8 * (q - nown);
             }
             const size_t dst = ((size_t)rg * nc + p) * E + c;
-            f32x4 kv, vv;
+            f32x4 kk, vv;
             if (!own) {
-                kv = *reinterpret_cast<const f32x4*>(Lw.kold + dst);
-                vv = *reinterpret_cast<const f32x4*>(Lw.vold + dst);
+                kk = *reinterpret_cast<const f32x4*>(kv.kold + dst);
+                vv = *reinterpret_cast<const f32x4*>(kv.vold + dst);
             } else if (p + T < nc) {
-                kv = *reinterpret_cast<const f32x4*>(Lw.kold + dst + (size_t)T * E);
-                vv = *reinterpret_cast<const f32x4*>(Lw.vold + dst + (size_t)T * E);
+                kk = *reinterpret_cast<const f32x4*>(kv.kold + dst + (size_t)T * E);
+                vv = *reinterpret_cast<const f32x4*>(kv.vold + dst + (size_t)T * E);
             } else {
                 const unsigned off = ((unsigned)rg * T + (p + T - nc)) * 3u * E + E + c;
-                kv = ld_l2(qkv_r, off);
+                kk = ld_l2(qkv_r, off);
                 vv = ld_l2(qkv_r, off + E);
             }
-            *reinterpret_cast<f32x4*>(Lw.knew + dst) = kv;
-            *reinterpret_cast<f32x4*>(Lw.vnew + dst) = vv;
+            *reinterpret_cast<f32x4*>(kv.knew + dst) = kk;
+            *reinterpret_cast<f32x4*>(kv.vnew + dst) = vv;
         }
     };
     if (nclip <= 0) {  // an XCD without clips (barriers are per XCD: nothing to wait for) only copies its unused cache rows
-        for (int l = 0; l < a.L; ++l) roll(a.layer[l], step_rsrc(a.layer[l].qkv), 0, rank, (int)n);
+        for (int i = 0; i < a.nsteps; ++i)
+            for (int l = 0; l < a.L; ++l) roll(rings(l, i), step_rsrc(a.layer[l].qkv), 0, rank, (int)n);
         return;
     }
     const int Mg = 3 * ct;
@@ -1171,186 +1188,196 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
     float* const hb = a.h_t + (size_t)g * kSGroupRows * E;
     float* const mlp = a.mlp_t + (size_t)g * kSGroupRows * ME;
     const __amdgpu_buffer_rsrc_t pat_r = step_rsrc(pat), xres_r = step_rsrc(xres), hb_r = step_rsrc(hb), mlp_r = step_rsrc(mlp);
-    float* const red = smem;                    // partial tiles [4 compute waves][<= 3 MB][256] | attention rows + RoPE slices
+    const __amdgpu_buffer_rsrc_t xt_r = step_rsrc(a.xt), xout_r = step_rsrc(a.xout);
+    float* const red = smem;                    // partial tiles [kSCW waves][<= 3 MB][256] | attention rows + RoPE slices
     float* const kvl = smem + kSRedFloats(MB);  // attention: K / V landing zones [8 waves][2][12][64]
     const bool wact = !(a.dbg & 2);  // (AFTER_STEP_DBG=2, timing experiments: no weight traffic, wrong results)
     const bool cw = w < kSCW;        // compute wave of the GEMM phases
     // L2 warming (step_warm) by waves that have nothing to do in the ln / attention phases: `sixteenths` / 16 of a
-    // Linear's 3 E^2 weights (ME = 3 E).  A warming wave does not wait for these loads at the barrier (it stored nothing)
+    // Linear's 3 E^2 weights (ME = 3 E)
     const size_t wbytes = (size_t)E * ME * sizeof(float);
     static_assert(kSME == 3 * kSE, "qkv and MLP weights of one size");
-    auto end_phase = [&](bool drain) { step_barrier(st, xcc, n, ++round, trace, drain); };
+    // end of a phase: XCD-local barrier; false = a spin timed out (flag raised): leave the kernel
+    auto end_phase = [&](bool drain) { return step_barrier(st, xcc, n, ++round, trace, ++tslot, drain, &s_ok); };
     // the LayerNorm-phase operands of this wave's row (ln phase: row rank + 32 w) / this workgroup's attention item,
     // requested one GEMM phase early (StepLnOps)
-    StepLnOps lnops, atops;
+    StepLnOps lnops;  // (one register set: the ln row's operands live from MLP-down to ln, the attention item's from qkv to attention)
     const int ln_lm = rank + (int)n * w;  // this wave's (first) row of the ln phases
-    const bool ln_mine = ln_lm < 3 * cpg * T && (ln_lm % (cpg * T)) / T < nclip;
+    const bool ln_mine = ln_lm < Mg && (ln_lm % ct) / T < nclip;
     auto ln_prefetch = [&](int l) {
         if (!ln_mine) return;
         const int br = ln_lm / ct, rem = ln_lm - br * ct, cl = rem / T, t = rem - cl * T, rg = br * B + c0 + cl;
         step_ln_ops(lnops, a.tc_ab + ((size_t)a.tcmap[rg] * T + t) * a.tc_ld + (size_t)l * 2 * E, a.layer[l].n1w, a.layer[l].n1b, lane);
     };
     const int nchunks = (T + a.cs - 1) / a.cs, nitems = 3 * nclip * nchunks;
-    auto attn_prefetch = [&](int l, int it) {
-        const int q = it / nchunks, br = q / nclip, rg = br * B + c0 + (q - br * nclip);
-        step_ln_ops(atops, a.cond_ab + (size_t)rg * a.cond_ld + (size_t)l * 2 * E, a.layer[l].n3w, a.layer[l].n3b, lane);
-    };
 
-    // ---- patchify_and_embed: pat = GELU(xt patch_w^T + b) for the XCD's ct clip tokens (transformerv2.py:387-391)
-    {
-        const int kbp = a.Cp / 16;  // <= 8: one k-block per wave
-        f32x4 acc[1];
-        const float* arow = a.xt + (size_t)(c0 * T + min(lane & 15, nclip * T - 1)) * a.Cp;
-        const f32x4 bv = w == 0 ? *reinterpret_cast<const f32x4*>(a.patch_b + 16 * rank + 4 * (lane >> 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
-        step_gemm<1, 1, 1, true>(acc, pat_r, 0, a.patch_wt, kbp, rank, w, lane, w < kbp, wact, [&] { ln_prefetch(0); }, arow);
-        // (all eight waves may carry a k-block here: partial tiles through the full-width LDS exchange)
-        __syncthreads();
-        *reinterpret_cast<f32x4*>(red + ((w << 6) + lane) * 4) = acc[0];
-        __syncthreads();
-        if (w == 0) {
-            f32x4 o = *reinterpret_cast<const f32x4*>(red + lane * 4);
+    for (int i = 0; i < a.nsteps; ++i) {  // ---- the Euler steps of Streamer.sample (export.py:398-416)
+        const float* cond_ab = a.cond_ab + (size_t)i * a.cond_step;
+        auto attn_prefetch = [&](int l, int it) {
+            const int q = it / nchunks, br = q / nclip, rg = br * B + c0 + (q - br * nclip);
+            step_ln_ops(lnops, cond_ab + (size_t)rg * a.cond_ld + (size_t)l * 2 * E, a.layer[l].n3w, a.layer[l].n3b, lane);
+        };
+        tslot = 0;
+        if (trace && tid == 0) trace[0] = wall_clock64();
+        // ---- patchify_and_embed: pat = GELU(xt patch_w^T + b) for the XCD's ct clip tokens (transformerv2.py:387-391)
+        {
+            const int kbp = a.Cp / 16;  // <= 8: one k-block per wave
+            f32x4 acc[1];
+            const f32x4 bv = w == 0 ? *reinterpret_cast<const f32x4*>(a.patch_b + 16 * rank + 4 * (lane >> 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            step_gemm<1, 1, 1, true>(acc, xt_r, 0, a.patch_wt, kbp, rank, w, lane, w < kbp, wact, [&] { ln_prefetch(0); },
+                                     (unsigned)((c0 * T + min(lane & 15, nclip * T - 1)) * a.Cp));
+            // (all eight waves may carry a k-block here: partial tiles through the full-width LDS exchange)
+            __syncthreads();
+            *reinterpret_cast<f32x4*>(red + ((w << 6) + lane) * 4) = acc[0];
+            __syncthreads();
+            if (w == 0) {
+                f32x4 o = *reinterpret_cast<const f32x4*>(red + lane * 4);
 #pragma unroll
-            for (int q = 1; q < 8; ++q) o += *reinterpret_cast<const f32x4*>(red + ((q << 6) + lane) * 4);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r] + bv[r]);
-            *reinterpret_cast<f32x4*>(pat + ((size_t)rank << 8) + lane * 4) = o;
-        }
-    }
-    end_phase(cw);
-    for (int l = 0; l < a.L; ++l) {
-        const StepLayer& Lw = a.layer[l];
-        const __amdgpu_buffer_rsrc_t qkv_r = step_rsrc(Lw.qkv);
-        // ---- norm0 -> AdaLN(tcond) -> norm1: one wave per token row, rows dealt round-robin to the workgroups
-        for (int lm = ln_lm; lm < Mg; lm += (int)n * 8) {
-            const int br = lm / ct, rem = lm - br * ct, cl = rem / T, t = rem - cl * T;
-            if (cl < nclip) {
-                if (lm != ln_lm)  // (more than 256 rows per XCD: never with the shipped limits)
-                    step_ln_ops(lnops, a.tc_ab + ((size_t)a.tcmap[br * B + c0 + cl] * T + t) * a.tc_ld + (size_t)l * 2 * E, Lw.n1w, Lw.n1b, lane);
-                step_ln_row(l == 0 ? pat_r : xres_r, l == 0 ? rem : lm, xres, hb, lm, lnops, lane);
-            }
-        }
-        if (wact && rank >= Mg) {  // workgroups without a row (a warming wave next to a row's wave delays its loads: one
-                                   // load path per CU): warm the K / V ring rows of this layer, then (part of) the qkv weights
-            const int wi = (rank - Mg) * 8 + w, nw = ((int)n - Mg) * 8;
-            unsigned sink = 0;
-            for (int q = 0; q < 3 * nclip; ++q) {
-                const int br = q / nclip, rg = br * B + c0 + (q - br * nclip);
-                step_warm(sink, Lw.kold + (size_t)rg * a.cache * E, (size_t)a.cache * E * sizeof(float), wi, nw, lane);
-                step_warm(sink, Lw.vold + (size_t)rg * a.cache * E, (size_t)a.cache * E * sizeof(float), wi, nw, lane);
-            }
-            step_warm(sink, Lw.qkv_wt, wbytes * a.warm[0] / 16, wi, nw, lane);
-            step_warm_done(sink);
-        }
-        end_phase(true);
-        // ---- qkv: column tiles rank, rank + 32, rank + 64
-        {
-            f32x4 acc[3 * MB];
-            step_gemm<MB, 3, kSKBQ, false>(acc, hb_r, KBE, Lw.qkv_wt, KBE, rank, kSKBQ * w, lane, cw, wact,
-                                           [&] { if (rank < nitems) attn_prefetch(l, rank); });
-            step_partials<3 * MB>(acc, red, w, lane);
-            for (int p = w; p < 3 * MB && cw; p += kSCW) {
-                const int j = p / MB, i = p - j * MB;
-                const f32x4 o = step_reduced(red, 3 * MB, p, lane);
-                const int lm = 16 * i + (lane & 15);
-                const int br = lm / ct, rem = lm - br * ct, cl = rem / T, t = rem - cl * T;
-                if (lm < Mg && cl < nclip)
-                    *reinterpret_cast<f32x4*>(Lw.qkv + ((size_t)(br * B + c0 + cl) * T + t) * 3 * E + 16 * (rank + 32 * j) + 4 * (lane >> 4)) = o;
-            }
-        }
-        end_phase(cw);
-        // ---- cached attention + residual + AdaLN(cond) + norm3 (one workgroup per chunk of a network row); the
-        //      other workgroups roll this layer's K / V ring by T frames (MHAttention.roll_cache,
-        //      transformerv2.py:171-188: flip-flop halves, out of place)
-        {
-            for (int it = rank; it < nitems; it += (int)n) {
-                const int q = it / nchunks, bx = it - q * nchunks, br = q / nclip, cl = q - br * nclip;
-                __syncthreads();  // (a second item of this workgroup reuses the LDS rows)
-                if (it != rank) attn_prefetch(l, it);
-                step_attention(a, Lw, atops, br * B + c0 + cl, br * ct + cl * T, bx, smem, kvl, qkv_r, xres_r,
-                               xres, hb);
-            }
-            const int nroll = nitems < (int)n ? (int)n - nitems : (int)n, rb = nitems < (int)n ? rank - nitems : rank;
-            bool drain = true;
-            if (rb >= 0) {
-                roll(Lw, qkv_r, 3 * nclip, rb, nroll);
-                if (wact) {  // then warm the MLP weights (MLP-up first: it is needed first)
-                    unsigned sink = 0;
-                    step_warm(sink, Lw.mlp0_wt, wbytes * a.warm[1] / 16, rb * 8 + w, nroll * 8, lane);
-                    step_warm(sink, Lw.mlp2_wt, wbytes * a.warm[2] / 16, rb * 8 + w, nroll * 8, lane);
-                    step_warm_done(sink);
-                }
-            }
-            end_phase(drain);
-        }
-        // ---- MLP up + GELU: column tiles rank + 32 j, j < kSNTU
-        {
-            f32x4 acc[kSNTU * MB];
-            // (epilogue operands are requested before the GEMM: a load issued after the reduction would put one more
-            //  fabric round trip on the phase's critical path)
-            const int pj = w / MB;
-            const f32x4 bv0 = cw && w < kSNTU * MB ? *reinterpret_cast<const f32x4*>(Lw.mlp0_b + 16 * (rank + 32 * pj) + 4 * (lane >> 4))
-                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
-            step_gemm<MB, kSNTU, kSKBQ, false>(acc, hb_r, KBE, Lw.mlp0_wt, KBE, rank, kSKBQ * w, lane, cw, wact, [] {});
-            step_partials<kSNTU * MB>(acc, red, w, lane);
-            for (int p = w; p < kSNTU * MB && cw; p += kSCW) {
-                const int j = p / MB, i = p - j * MB, tile = rank + 32 * j;
-                f32x4 o = step_reduced(red, kSNTU * MB, p, lane);
-                const f32x4 bv = p == w ? bv0 : *reinterpret_cast<const f32x4*>(Lw.mlp0_b + 16 * tile + 4 * (lane >> 4));
+                for (int q = 1; q < 8; ++q) o += *reinterpret_cast<const f32x4*>(red + ((q << 6) + lane) * 4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r] + bv[r]);
-                *reinterpret_cast<f32x4*>(mlp + ((size_t)(i * KBM + tile) << 8) + lane * 4) = o;
+                *reinterpret_cast<f32x4*>(pat + ((size_t)rank << 8) + lane * 4) = o;
             }
         }
-        end_phase(cw);
-        // ---- MLP down + residual: column tile rank
-        {
-            f32x4 acc[MB];
-            const unsigned off = (unsigned)(((w * KBE + rank) << 8) + lane * 4);  // wave w finishes row block w
-            f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f}, rv = bv;
-            if (cw && w < MB) {
-                bv = *reinterpret_cast<const f32x4*>(Lw.mlp2_b + 16 * rank + 4 * (lane >> 4));
-                rv = ld_l2(xres_r, off);
+        if (!end_phase(cw)) return;
+        for (int l = 0; l < a.L; ++l) {
+            const StepLayer& Lw = a.layer[l];
+            const StepKV kv = rings(l, i);
+            const __amdgpu_buffer_rsrc_t qkv_r = step_rsrc(Lw.qkv);
+            // ---- norm0 -> AdaLN(tcond) -> norm1: one wave per token row, rows dealt round-robin to the workgroups
+            for (int lm = ln_lm; lm < Mg; lm += (int)n * 8) {
+                const int br = lm / ct, rem = lm - br * ct, cl = rem / T, t = rem - cl * T;
+                if (cl < nclip) {
+                    if (lm != ln_lm)  // (more than 256 rows per XCD: never with the shipped limits)
+                        step_ln_ops(lnops, a.tc_ab + ((size_t)a.tcmap[br * B + c0 + cl] * T + t) * a.tc_ld + (size_t)l * 2 * E, Lw.n1w, Lw.n1b, lane);
+                    step_ln_row(l == 0 ? pat_r : xres_r, l == 0 ? rem : lm, xres, hb, lm, lnops, lane);
+                }
             }
-            step_gemm<MB, 1, kSKBD, false>(acc, mlp_r, KBM, Lw.mlp2_wt, KBM, rank, kSKBD * w, lane, cw, wact,
-                                           [&] { if (l + 1 < a.L) ln_prefetch(l + 1); });
-            step_partials<MB>(acc, red, w, lane);
-            for (int p = w; p < MB && cw; p += kSCW) {
-                f32x4 o = step_reduced(red, MB, p, lane);
+            if (wact && rank >= Mg) {  // workgroups without a row (a warming wave next to a row's wave delays its loads: one
+                                       // load path per CU): warm the K / V ring rows of this layer, then (part of) the qkv weights
+                const int wi = (rank - Mg) * 8 + w, nw = ((int)n - Mg) * 8;
+                unsigned sink = 0;
+                for (int q = 0; q < 3 * nclip; ++q) {
+                    const int br = q / nclip, rg = br * B + c0 + (q - br * nclip);
+                    step_warm(sink, kv.kold + (size_t)rg * a.cache * E, (size_t)a.cache * E * sizeof(float), wi, nw, lane);
+                    step_warm(sink, kv.vold + (size_t)rg * a.cache * E, (size_t)a.cache * E * sizeof(float), wi, nw, lane);
+                }
+                step_warm(sink, Lw.qkv_wt, wbytes * a.warm[0] / 16, wi, nw, lane);
+                step_warm_done(sink);
+            }
+            if (!end_phase(true)) return;
+            // ---- qkv: column tiles rank, rank + 32, rank + 64
+            {
+                f32x4 acc[3 * MB];
+                step_gemm<MB, 3, kSKBQ, false>(acc, hb_r, KBE, Lw.qkv_wt, KBE, rank, kSKBQ * w, lane, cw, wact,
+                                               [&] { if (rank < nitems) attn_prefetch(l, rank); });
+                step_partials<3 * MB>(acc, red, w, lane);
+                for (int p = w; p < 3 * MB && cw; p += kSCW) {
+                    const int j = p / MB, ib = p - j * MB;
+                    const f32x4 o = step_reduced(red, 3 * MB, p, lane);
+                    const int lm = 16 * ib + (lane & 15);
+                    const int br = lm / ct, rem = lm - br * ct, cl = rem / T, t = rem - cl * T;
+                    if (lm < Mg && cl < nclip)
+                        *reinterpret_cast<f32x4*>(Lw.qkv + ((size_t)(br * B + c0 + cl) * T + t) * 3 * E + 16 * (rank + 32 * j) + 4 * (lane >> 4)) = o;
+                }
+            }
+            if (!end_phase(cw)) return;
+            // ---- cached attention + residual + AdaLN(cond) + norm3 (one workgroup per chunk of a network row); the
+            //      other workgroups roll this layer's K / V ring by T frames (MHAttention.roll_cache,
+            //      transformerv2.py:171-188: flip-flop halves, out of place), then warm the MLP weights
+            {
+                for (int it = rank; it < nitems; it += (int)n) {
+                    const int q = it / nchunks, bx = it - q * nchunks, br = q / nclip, cl = q - br * nclip;
+                    __syncthreads();  // (a second item of this workgroup reuses the LDS rows)
+                    if (it != rank) attn_prefetch(l, it);
+                    step_attention(a, Lw, kv, lnops, br * B + c0 + cl, br * ct + cl * T, bx, smem, kvl, qkv_r, xres_r, xres, hb);
+                }
+                const int nroll = nitems < (int)n ? (int)n - nitems : (int)n, rb = nitems < (int)n ? rank - nitems : rank;
+                if (rb >= 0) {
+                    roll(kv, qkv_r, 3 * nclip, rb, nroll);
+                    if (wact) {  // (MLP-up first: it is needed first)
+                        unsigned sink = 0;
+                        step_warm(sink, Lw.mlp0_wt, wbytes * a.warm[1] / 16, rb * 8 + w, nroll * 8, lane);
+                        step_warm(sink, Lw.mlp2_wt, wbytes * a.warm[2] / 16, rb * 8 + w, nroll * 8, lane);
+                        step_warm_done(sink);
+                    }
+                }
+            }
+            if (!end_phase(true)) return;
+            // ---- MLP up + GELU: column tiles rank + 32 j, j < kSNTU
+            {
+                f32x4 acc[kSNTU * MB];
+                // (epilogue operands are requested before the GEMM: a load issued after the reduction would put one more
+                //  fabric round trip on the phase's critical path)
+                const int pj = w / MB;
+                const f32x4 bv0 = cw && w < kSNTU * MB ? *reinterpret_cast<const f32x4*>(Lw.mlp0_b + 16 * (rank + 32 * pj) + 4 * (lane >> 4))
+                                                       : f32x4{0.f, 0.f, 0.f, 0.f};
+                step_gemm<MB, kSNTU, kSKBQ, false>(acc, hb_r, KBE, Lw.mlp0_wt, KBE, rank, kSKBQ * w, lane, cw, wact, [] {});
+                step_partials<kSNTU * MB>(acc, red, w, lane);
+                for (int p = w; p < kSNTU * MB && cw; p += kSCW) {
+                    const int j = p / MB, ib = p - j * MB, tile = rank + 32 * j;
+                    f32x4 o = step_reduced(red, kSNTU * MB, p, lane);
+                    const f32x4 bv = p == w ? bv0 : *reinterpret_cast<const f32x4*>(Lw.mlp0_b + 16 * tile + 4 * (lane >> 4));
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = o[r] + bv[r] + rv[r];
-                *reinterpret_cast<f32x4*>(xres + off) = o;
+                    for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r] + bv[r]);
+                    *reinterpret_cast<f32x4*>(mlp + ((size_t)(ib * KBM + tile) << 8) + lane * 4) = o;
+                }
+            }
+            if (!end_phase(cw)) return;
+            // ---- MLP down + residual: column tile rank
+            {
+                f32x4 acc[MB];
+                const unsigned off = (unsigned)(((w * KBE + rank) << 8) + lane * 4);  // wave w finishes row block w
+                f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f}, rv = bv;
+                if (cw && w < MB) {
+                    bv = *reinterpret_cast<const f32x4*>(Lw.mlp2_b + 16 * rank + 4 * (lane >> 4));
+                    rv = ld_l2(xres_r, off);
+                }
+                step_gemm<MB, 1, kSKBD, false>(acc, mlp_r, KBM, Lw.mlp2_wt, KBM, rank, kSKBD * w, lane, cw, wact,
+                                               [&] { if (l + 1 < a.L) ln_prefetch(l + 1); });
+                step_partials<MB>(acc, red, w, lane);
+                for (int p = w; p < MB && cw; p += kSCW) {
+                    f32x4 o = step_reduced(red, MB, p, lane);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = o[r] + bv[r] + rv[r];
+                    *reinterpret_cast<f32x4*>(xres + off) = o;
+                }
+            }
+            if (!end_phase(cw)) return;
+        }
+        // ---- out_proj + CFG + Euler (+ the token-major latents of the next step): column tile rank < C / 16
+        if (rank < a.C / 16) {
+            f32x4 acc[MB];
+            step_gemm<MB, 1, kSKBQ, false>(acc, xres_r, KBE, a.out_wt, KBE, rank, kSKBQ * w, lane, cw, wact, [] {});
+            step_partials<MB>(acc, red, w, lane);
+            float* const outt = red + kSCW * MB * 256;  // [MB * 16 rows][16 columns]
+            for (int p = w; p < MB && cw; p += kSCW) {
+                const f32x4 o = step_reduced(red, MB, p, lane);
+                *reinterpret_cast<f32x4*>(outt + (16 * p + (lane & 15)) * 16 + 4 * (lane >> 4)) = o;
+            }
+            __syncthreads();
+            if (tid < nclip * T * 16) {  // model.py:749-759, 777-783
+                const int tok = tid >> 4, col = tid & 15, nn = 16 * rank + col;
+                const float bo = a.out_b ? a.out_b[nn] : 0.f;
+                const float dfull = outt[tok * 16 + col] + bo, dmid = outt[(ct + tok) * 16 + col] + bo,
+                            dnone = outt[(2 * ct + tok) * 16 + col] + bo;
+                const float total = a.cfg[0], factor = a.cfg[1], dt = a.cfg[2];
+                const float v = dnone + total * (dmid + factor * (dfull - dmid) - dnone);
+                const int cl = tok / T, t = tok - cl * T;
+                const size_t o = ((size_t)(c0 + cl) * a.C + nn) * T + t;
+                // (the previous step's latents were written by this very thread, through the L1: read them from the L2)
+                const float xi = i == 0 ? a.x0[o]
+                                        : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xout_r, (unsigned)o * 4u, 0, 16));
+                const float xn = xi + v * dt;
+                a.xout[o] = xn;
+                if (i + 1 < a.nsteps) a.xt[((size_t)(c0 + cl) * T + t) * a.Cp + nn] = xn;
             }
         }
-        end_phase(cw);
-    }
-    // ---- out_proj + CFG + Euler (+ the token-major latents of the next step): column tile rank < C / 16
-    if (rank < a.C / 16) {
-        f32x4 acc[MB];
-        step_gemm<MB, 1, kSKBQ, false>(acc, xres_r, KBE, a.out_wt, KBE, rank, kSKBQ * w, lane, cw, wact, [] {});
-        step_partials<MB>(acc, red, w, lane);
-        float* const outt = red + kSCW * MB * 256;  // [MB * 16 rows][16 columns]
-        for (int p = w; p < MB && cw; p += kSCW) {
-            const f32x4 o = step_reduced(red, MB, p, lane);
-            *reinterpret_cast<f32x4*>(outt + (16 * p + (lane & 15)) * 16 + 4 * (lane >> 4)) = o;
+        if (trace && tid == 0) {
+            trace[2 * tslot + 1] = wall_clock64();
+            trace[127] = xcc;
         }
-        __syncthreads();
-        if (tid < nclip * T * 16) {  // model.py:749-759, 777-783
-            const int tok = tid >> 4, col = tid & 15, nn = 16 * rank + col;
-            const float bo = a.out_b ? a.out_b[nn] : 0.f;
-            const float dfull = outt[tok * 16 + col] + bo, dmid = outt[(ct + tok) * 16 + col] + bo,
-                        dnone = outt[(2 * ct + tok) * 16 + col] + bo;
-            const float total = a.cfg[0], factor = a.cfg[1], dt = a.cfg[2];
-            const float v = dnone + total * (dmid + factor * (dfull - dmid) - dnone);
-            const int cl = tok / T, t = tok - cl * T;
-            const size_t o = ((size_t)(c0 + cl) * a.C + nn) * T + t;
-            const float xn = a.xin[o] + v * dt;
-            a.xout[o] = xn;
-            if (a.xt_next) a.xt_next[((size_t)(c0 + cl) * T + t) * a.Cp + nn] = xn;
-        }
-    }
-    if (trace && tid == 0) {
-        trace[2 * round + 1] = wall_clock64();
-        trace[127] = xcc;
+        if (i + 1 < a.nsteps && !end_phase(true)) return;  // the next step's patchify reads the new latents
     }
 }
 
@@ -2127,9 +2154,9 @@ int sample_persistent(after_denoiser* h, hipStream_t s, const float* x0, float* 
             }
     }
     if (!h->step_sync) {
-        AFTER_HIP_CHECK(hipMalloc(&h->step_sync, (size_t)h->max_steps * sizeof(StepSync)));
-        AFTER_HIP_CHECK(hipHostMalloc(&h->step_fail, (size_t)h->max_steps * 32 * sizeof(unsigned), hipHostMallocDefault));
-        memset(h->step_fail, 0, (size_t)h->max_steps * 32 * sizeof(unsigned));
+        AFTER_HIP_CHECK(hipMalloc(&h->step_sync, sizeof(StepSync)));
+        AFTER_HIP_CHECK(hipHostMalloc(&h->step_fail, 32 * sizeof(unsigned), hipHostMallocDefault));
+        memset(h->step_fail, 0, 32 * sizeof(unsigned));
         const char* tr = getenv("AFTER_STEP_TRACE");
         if (tr && atoi(tr) != 0) AFTER_HIP_CHECK(hipMalloc(&h->step_trace, (size_t)h->n_cus * 128 * sizeof(unsigned long long)));
         AFTER_TRY(step_tile_weights(h, s));
@@ -2151,23 +2178,26 @@ int sample_persistent(after_denoiser* h, hipStream_t s, const float* x0, float* 
         hipLaunchKernelGGL(to_token_major_kernel, grid, dim3(256), 0, s, x0, h->xt, (const int*)nullptr, h->C, T, h->Cp, 0.f);
         AFTER_HIP_CHECK(hipGetLastError());
     }
-    AFTER_HIP_CHECK(hipMemsetAsync(h->step_sync, 0, (size_t)nb_steps * sizeof(StepSync), s));
-    const size_t step_stride = (size_t)rows * L * 2 * E;
-    const size_t per = (size_t)h->cache_rows * h->cache * E;
+    AFTER_HIP_CHECK(hipMemsetAsync(h->step_sync, 0, sizeof(StepSync), s));
+    AFTER_REQUIRE(nb_steps <= 128, AFTER_E_CAPACITY, "persistent step: %d steps exceed the 128 flip bits", nb_steps);
     const size_t slice = (size_t)8 * kSGroupRows * E;
-    for (int i = 0; i < nb_steps; ++i) {
+    {
         StepArgs a;
         a.rows = rows, a.B = B, a.T = T, a.C = h->C, a.Cp = h->Cp, a.L = L;
         a.cs = h->cs, a.W = h->W, a.nkmax = nkmax, a.cache = h->cache, a.cache_rows = h->cache_rows, a.cpg = cpg;
+        a.nsteps = nb_steps, a.cache_steps = h->cache_steps;
+        for (int k = 0; k < 4; ++k) a.flip[k] = 0;
+        for (int i = 0; i < nb_steps; ++i) a.flip[i >> 5] |= (unsigned)(h->flip[i] & 1) << (i & 31);
         a.xt = h->xt;
         a.pat_t = h->step_act, a.xres_t = h->step_act + slice, a.h_t = h->step_act + 2 * slice, a.mlp_t = h->step_act + 3 * slice;
         a.patch_wt = h->step_patch_wt, a.patch_b = h->patch_b, a.out_wt = h->step_out_wt, a.out_b = h->out_b;
         a.tc_ab = h->tc_ab, a.tc_ld = L * 2 * E, a.tcmap = h->maps + h->ms;
-        a.cond_ab = h->cond_ab + (size_t)i * step_stride, a.cond_ld = L * 2 * E;
+        a.cond_ab = h->cond_ab, a.cond_step = (size_t)rows * L * 2 * E, a.cond_ld = L * 2 * E;
         a.rope_cos = h->rope_cos, a.rope_sin = h->rope_sin;
-        a.xin = i == 0 ? x0 : out, a.xout = out, a.xt_next = i + 1 < nb_steps ? h->xt : nullptr;
+        a.x0 = x0, a.xout = out;
+        a.kcache = h->kcache, a.vcache = h->vcache;
         a.cfg = reinterpret_cast<const float*>(h->dparams);
-        a.sync = h->step_sync + i;
+        a.sync = h->step_sync;
         a.trace = h->step_trace;
         {
             static int dbg = -1;
@@ -2184,27 +2214,22 @@ int sample_persistent(after_denoiser* h, hipStream_t s, const float* x0, float* 
             }
             a.warm[0] = warm[0], a.warm[1] = warm[1], a.warm[2] = warm[2];
         }
-        const int cur = h->flip[i];
         for (int l = 0; l < L; ++l) {
             const LayerW& w = h->layers[l];
             StepLayer& sl = a.layer[l];
             sl.qkv_wt = h->step_layers[l].qkv, sl.mlp0_wt = h->step_layers[l].mlp0, sl.mlp2_wt = h->step_layers[l].mlp2;
             sl.mlp0_b = w.mlp0_b, sl.mlp2_b = w.mlp2_b, sl.n1w = w.n1w, sl.n1b = w.n1b, sl.n3w = w.n3w, sl.n3b = w.n3b;
             sl.qkv = h->qkv_layers + (size_t)l * h->max_rows * h->max_T * 3 * E;
-            const size_t slot = ((size_t)l * h->cache_steps + i) * 2 * per;
-            sl.kold = h->kcache + slot + cur * per, sl.vold = h->vcache + slot + cur * per;
-            sl.knew = h->kcache + slot + (cur ^ 1) * per, sl.vnew = h->vcache + slot + (cur ^ 1) * per;
         }
         if (MB == 1) hipLaunchKernelGGL(stream_step_kernel<1>, dim3(h->n_cus), dim3(512), lds, s, a);
         else if (MB == 2) hipLaunchKernelGGL(stream_step_kernel<2>, dim3(h->n_cus), dim3(512), lds, s, a);
         else hipLaunchKernelGGL(stream_step_kernel<3>, dim3(h->n_cus), dim3(512), lds, s, a);
         AFTER_HIP_CHECK(hipGetLastError());
-        h->flip[i] = cur ^ 1;
+        for (int i = 0; i < nb_steps; ++i) h->flip[i] ^= 1;
     }
     // failure words -> pinned host memory, looked at when the next call starts
-    AFTER_HIP_CHECK(hipMemcpy2DAsync(h->step_fail, 32 * sizeof(unsigned), &h->step_sync[0].fail[0], sizeof(StepSync),
-                                     32 * sizeof(unsigned), nb_steps, hipMemcpyDeviceToHost, s));
-    h->step_fail_n = nb_steps;
+    AFTER_HIP_CHECK(hipMemcpyAsync(h->step_fail, &h->step_sync[0].fail[0], 32 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    h->step_fail_n = 1;
     return AFTER_OK;
 }
 
