@@ -1123,6 +1123,7 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
         unsigned bad = 0;
         for (int x = 0; x < 8; ++x)
             bad |= __hip_atomic_load(&st->pop[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 32u;
+        if (a.dbg & 8) bad = 1;  // (AFTER_STEP_DBG=8: pretend the placement census failed -- tests of the failure report)
         if (bad) __hip_atomic_store(&st->fail[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_n = 32;
         s_bad = bad;
@@ -1457,6 +1458,7 @@ struct after_denoiser {
     // persistent streaming step (stream_step_kernel): one launch per cached Euler step.  AFTER_STREAM_PERSIST=0 /
     // after_denoiser_set_stream_persist(h, 0) keep the launch-per-kernel path.
     int persist_step = 1, n_cus = 0;
+    int step_dbg = 0;  // after_denoiser_set_stream_persist(h, 1 | dbg << 8): diagnostics bits OR-ed into AFTER_STEP_DBG
     StepSync* step_sync = nullptr;       // [max_steps]: one barrier state per step of a sample() call
     unsigned long long* step_trace = nullptr;  // AFTER_STEP_TRACE=1: stamps of the LAST step launched (diagnostics)
     unsigned* step_fail = nullptr;       // pinned host copy of the last call's failure words (checked at the next call)
@@ -2205,7 +2207,7 @@ int sample_persistent(after_denoiser* h, hipStream_t s, const float* x0, float* 
                 const char* e = getenv("AFTER_STEP_DBG");
                 dbg = e ? atoi(e) : 0;
             }
-            a.dbg = dbg;
+            a.dbg = dbg | h->step_dbg;
             static int warm[3] = {-1, 0, 0};
             if (warm[0] < 0) {
                 warm[0] = 4, warm[1] = 16, warm[2] = 4;
@@ -2393,7 +2395,8 @@ extern "C" int after_denoiser_set_gemm_path(after_denoiser* h, int mode, int min
 
 extern "C" int after_denoiser_set_stream_persist(after_denoiser* h, int enable) {
     AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
-    h->persist_step = enable != 0;
+    h->persist_step = (enable & 0xff) != 0;
+    h->step_dbg = enable >> 8;  // (diagnostics: bit 3 = report a failed placement census, as tests/test_stream_persist_gpu.py does)
     return AFTER_OK;
 }
 

@@ -10,7 +10,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print(f"total kernel time {tot/1e6:.2f} ms over 8 chunks (2 warm-up + 6 timed), {sum(int(r['Calls']) for r in rows)} launches")
-for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:28]:
+for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:70]:
     print(f"{float(r['TotalDurationNs'])/1e6:9.3f} ms {int(r['Calls']):7d} calls {float(r['AverageNs'])/1e3:9.2f} us avg  {float(r['Percentage']):5.1f}%  {r['Name'][:110]}")
 PY
 grep '^{' /tmp/prof_o.log | cut -c1-200 >> gpurun_out/o/r3_stream_kernel_stats.txt
