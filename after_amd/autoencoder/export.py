@@ -26,7 +26,12 @@ from .model import AutoEncoder
 class ExportedAutoEncoder:
 
     def __init__(self, model: AutoEncoder, stream: bool = False, n_fade: int = 4, max_batch: int = 4,
-                 chunk_frames: int = 4, gn_window_samples: int = 131072, gn_window_frames: int = 64):
+                 chunk_frames: int = 4, gn_window_samples: int = 131072, gn_window_frames: int = 64,
+                 prime_with_silence: bool = False):
+        """prime_with_silence: the reference runs one encode + decode of 131072 zero samples through the streaming twin
+        before scripting it (export_autoencoder.py:296-298, :314-316), so export_stream.ts starts -- and its saved state
+        is -- the codec's response to silence (non-zero: biases, Snake), not zeros.  True reproduces that start (here and
+        after every reset()): `gn_window_samples` of zeros, fed chunk by chunk; False (default) starts from zero history."""
         if stream:
             # The reference builds the streaming graph as SEPARATE twins of the trained codec
             # (export_autoencoder.py:283-312: new modules under cc.use_cached_conv(True) + load_state_dict), so
@@ -57,6 +62,18 @@ class ExportedAutoEncoder:
             self.out_buffer = torch.zeros(self.max_batch, 1, self.comp_ratio * self.n_fade, device=dev)
             self.z_buffer = torch.zeros(self.max_batch, self.latent_size, self.n_fade, device=dev)
             self.alpha = torch.linspace(0, 1, self.n_fade * self.comp_ratio, device=dev)[None, None, :]
+        self.prime_with_silence = bool(prime_with_silence) and self.stream
+        self._chunk_samples = chunk_frames * self.comp_ratio
+        self._prime_chunks = max(1, gn_window_samples // self._chunk_samples)
+        if self.prime_with_silence:
+            self._prime()
+
+    @torch.no_grad()
+    def _prime(self):
+        dev = next(self.model.parameters()).device
+        zeros = torch.zeros(self.max_batch, 1, self._chunk_samples, device=dev)
+        for _ in range(self._prime_chunks):
+            self.decode(self.encode(zeros))
 
     def reset(self):
         if self.stream and self.causal:
@@ -65,6 +82,8 @@ class ExportedAutoEncoder:
             self.model.reset_state()
             self.out_buffer.zero_()
             self.z_buffer.zero_()
+        if self.prime_with_silence:
+            self._prime()
 
     @torch.no_grad()
     def encode(self, x):
