@@ -1436,7 +1436,8 @@ struct after_denoiser {
     int last_rows = 0, last_T = 0;
     KernelTimer timer;
     double timer_min_flops = 0;  // after_denoiser_profile_min_flops
-    int timer_kernel = 0;        // after_denoiser_profile_kernel: 0 both GEMM kernels, 1 gemm_x6 only, 2 gemm.hip only
+    int timer_kernel = 0;        // after_denoiser_profile_kernel: 0 both GEMM kernels, 1 gemm_x6 only, 2 gemm.hip only,
+                                 // 3 the persistent streaming sampler (stream_step_kernel: one launch per sample call)
     // hipGraph replay of sample(): the whole Euler loop is captured once per
     // (B, T, nb_steps, cfg_mode, drop_value) on a private stream, operating on
     // handle-owned staging tensors; guidance scalars live in device memory.
@@ -1479,7 +1480,7 @@ int gemm(after_denoiser* h, hipStream_t s, const float* A, int lda, const float*
          const float* R = nullptr, int ldr = 0) {
     GemmArgs g{A, lda, W, ldw, bias, R, ldr, Cc, ldc, M, N, K, epi};
     const double fl = 2.0 * M * (double)N * K;
-    const bool timed = fl >= h->timer_min_flops && h->timer_kernel != 1;  // the roofline leg looks at the dominant launches only
+    const bool timed = fl >= h->timer_min_flops && h->timer_kernel != 1 && h->timer_kernel != 3;  // the roofline leg looks at the dominant launches only
     if (timed) h->timer.begin(s);
     const int rc = launch_gemm(g, s);
     if (timed) h->timer.end(s, fl, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
@@ -1492,7 +1493,7 @@ int gemm_x6(after_denoiser* h, hipStream_t s, const unsigned short* A3, const un
             int ldr = 0) {
     X6GemmArgs g{A3, W3, bias, R, ldr, Cc, C3, ldc, M, N, K, epi};
     const double fl = 2.0 * M * (double)N * K;
-    const bool timed = fl >= h->timer_min_flops && h->timer_kernel != 2;
+    const bool timed = fl >= h->timer_min_flops && h->timer_kernel != 2 && h->timer_kernel != 3;
     if (timed) h->timer.begin(s);
     const int rc = launch_gemm_x6(g, 0, s);
     if (timed) h->timer.end(s, fl, 6.0 * ((double)M * K + (double)N * K) + (C3 ? 6.0 : 4.0) * M * N);
@@ -2109,7 +2110,7 @@ int roll_cache_step(after_denoiser* h, hipStream_t s, int rows, int T, int size,
 bool step_persist_ok(const after_denoiser* h, int B, int T) {
     const bool wide = h->W < 0 || !h->cfg.causal;
     const int cpg = (B + 7) / 8;
-    return h->persist_step && h->cache > 0 && !h->timer.enabled && h->x6 != 2 && h->E == kSE && h->ME == kSME &&
+    return h->persist_step && h->cache > 0 && (!h->timer.enabled || h->timer_kernel == 3) && h->x6 != 2 && h->E == kSE && h->ME == kSME &&
            h->H == kSH && h->L <= 8 && !wide && h->Cp == h->C && h->C % 16 == 0 && h->C / 16 <= 8 && h->n_cus == 256 &&
            3 * cpg * T <= 32 &&  // (two 16-row blocks: the LDS budget of the partial tiles + the weight slot)
            ((size_t)h->cs * (h->E + 4) + (size_t)kSH * 2 * (h->W - 1 + h->cs) * 16) <= 7168;
@@ -2223,10 +2224,18 @@ int sample_persistent(after_denoiser* h, hipStream_t s, const float* x0, float* 
             sl.mlp0_b = w.mlp0_b, sl.mlp2_b = w.mlp2_b, sl.n1w = w.n1w, sl.n1b = w.n1b, sl.n3w = w.n3w, sl.n3b = w.n3b;
             sl.qkv = h->qkv_layers + (size_t)l * h->max_rows * h->max_T * 3 * E;
         }
+        const bool timed = h->timer.enabled && h->timer_kernel == 3;
+        if (timed) h->timer.begin(s);
         if (MB == 1) hipLaunchKernelGGL(stream_step_kernel<1>, dim3(h->n_cus), dim3(512), lds, s, a);
         else if (MB == 2) hipLaunchKernelGGL(stream_step_kernel<2>, dim3(h->n_cus), dim3(512), lds, s, a);
         else hipLaunchKernelGGL(stream_step_kernel<3>, dim3(h->n_cus), dim3(512), lds, s, a);
         AFTER_HIP_CHECK(hipGetLastError());
+        if (timed) {  // flops of the GEMMs; algorithmic bytes = every weight once per Euler step (the activations are KBs)
+            const double M = (double)rows * T, Ed = E, MEd = h->ME, Cd = h->C;
+            const double wts = Ed * h->Cp + Cd * Ed + L * (3 * Ed * Ed + 2 * Ed * MEd);
+            const double fl = 2.0 * ((double)B * T * Ed * h->Cp + M * (Cd * Ed + L * (3 * Ed * Ed + 2 * Ed * MEd)));
+            h->timer.end(s, nb_steps * fl, nb_steps * 4.0 * wts);
+        }
         for (int i = 0; i < nb_steps; ++i) h->flip[i] ^= 1;
     }
     // failure words -> pinned host memory, looked at when the next call starts
@@ -2492,7 +2501,7 @@ extern "C" int after_denoiser_gemm_time2(after_denoiser* h, double* total_ms, lo
 }
 
 extern "C" int after_denoiser_profile_kernel(after_denoiser* h, int which) {
-    AFTER_REQUIRE(h && which >= 0 && which <= 2, AFTER_E_INVALID, "profile kernel class 0..2");
+    AFTER_REQUIRE(h && which >= 0 && which <= 3, AFTER_E_INVALID, "profile kernel class 0..3");
     h->timer_kernel = which;
     return AFTER_OK;
 }

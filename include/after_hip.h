@@ -170,8 +170,10 @@ int after_denoiser_gemm_time_ms(after_denoiser* h, double* total_ms, long long* 
 /* only launches of at least min_flops are bracketed (the dominant qkv / MLP GEMMs: the small
  * patchify / AdaLN projections share the kernel template but not its roofline) */
 int after_denoiser_profile_min_flops(after_denoiser* h, double min_flops);
-/* which GEMM kernel's launches are bracketed: 0 both, 1 the bf16-split kernel (gemm_x6.hip) only, 2 the fp32 MFMA
- * kernel (gemm.hip) only -- the two have different rooflines */
+/* which kernel's launches are bracketed: 0 both GEMM kernels, 1 the bf16-split kernel (gemm_x6.hip) only, 2 the fp32 MFMA
+ * kernel (gemm.hip) only -- the two have different rooflines -- 3 the persistent streaming sampler (one launch per
+ * after_sample call on a handle with K/V caches; flops = its GEMMs, bytes = every weight once per Euler step).  Classes
+ * 0-2 make the streaming sampler take its launch-per-kernel path while profiling is on. */
 int after_denoiser_profile_kernel(after_denoiser* h, int which);
 /* as after_denoiser_gemm_time_ms, plus the algorithmic bytes (A + W + C, fp32) of those launches:
  * the streaming path's GEMMs (<= 96 tokens) are weight-streaming launches priced against HBM */
