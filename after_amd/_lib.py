@@ -73,6 +73,8 @@ SIGNATURES = {
     "after_denoiser_gemm_path": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     "after_denoiser_set_stream_persist": (c_int, [c_void_p, c_int]),
     "after_denoiser_stream_persist": (c_int, [c_void_p, POINTER(c_int)]),
+    "after_denoiser_set_sample_persist": (c_int, [c_void_p, c_int]),
+    "after_denoiser_sample_persist": (c_int, [c_void_p, POINTER(c_int)]),
     "after_denoiser_step_trace": (c_int, [c_void_p, c_void_p, c_int]),
     "after_denoiser_enable_cache": (c_int, [c_void_p, c_int, c_int, c_int]),
     "after_denoiser_reset_cache": (c_int, [c_void_p, c_void_p]),

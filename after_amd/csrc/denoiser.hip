@@ -698,7 +698,7 @@ constexpr int kSKBD = kSME / 16 / kSCW;  // MLP-down k-blocks per compute wave
 __host__ __device__ constexpr int kSRedFloats(int MB) { return (MB * 3 * 256 * kSCW > 7168 ? MB * 3 * 256 * kSCW : 7168) + 1024; }
 constexpr int kSWF = 12;            // weight fragments of a compute wave: max(3 x kSKBQ, kSNTU x kSKBQ, kSKBD)
 static_assert(3 * kSKBQ <= kSWF && kSNTU * kSKBQ <= kSWF && kSKBD <= kSWF && kSKBD % 4 == 0 && kSKBQ % 4 == 0, "weight fragment budget");
-constexpr int kSGroupRows = 48;                 // token rows one XCD can own (three 16-row blocks)
+constexpr int kSGroupRows = 96;                 // token rows one XCD can own (offline segment sampler: 3 CFG rows x 32 frames)
 
 struct StepSync {
     unsigned arrive[8][32];  // [xcc][0]: arrivals (each word on its own 128-byte line)
@@ -706,6 +706,9 @@ struct StepSync {
     unsigned pop[8][32];     // [xcc][0]: workgroups resident on the XCC
     unsigned census[32];     // [0]: workgroups counted
     unsigned fail[32];       // [0]: a spin gave up; [1]: census is not 8 x 32
+    // offline segment sampler: [xcc][0] = layers completed (step * L + layer + 1), system-scope words
+    unsigned qkv_seq[8][32];  // ... whose qkv rows are in memory (the next XCD's attention reads the last W - 1 frames)
+    unsigned att_seq[8][32];  // ... whose attention has read its keys (the previous XCD may overwrite that layer's rows)
 };
 
 struct StepLayer {
@@ -720,6 +723,7 @@ struct StepKV {
 
 struct StepArgs {
     int rows, B, T, C, Cp, L, cs, W, nkmax, cache, cache_rows, cpg, dbg;
+    int Tseg;                 // offline segment sampler: frames per XCD (T / 8)
     int nsteps, cache_steps;  // Euler steps of this launch (ALL of a sample() call); ring slots per layer
     unsigned flip[4];         // bit i: which half of step i's K / V rings is current
     int warm[3];  // sixteenths of the qkv / MLP-up / MLP-down weights warmed into the L2 by idle waves (AFTER_STEP_WARM)
@@ -953,6 +957,9 @@ __device__ __forceinline__ void step_ln_row(__amdgpu_buffer_rsrc_t xin, int src_
 // through sc1 loads from this layer's qkv, the cached frames from the K / V ring (written by an earlier launch),
 // residual stream and h in the XCD's tiled buffers.  smem: [cs][E + 4] | per-wave cos, sin [nkmax][16]; kvlds: K / V
 // landing zones [8 waves][2][12][64].
+// AUX: cache policy of the q / K / V loads -- 16 (sc1: the XCD's L2) for the streaming sampler, 17 (sc0 sc1: system scope)
+// for the offline segment sampler, whose first chunks read the neighbour XCD's last frames.
+template <int AUX>
 __device__ __forceinline__ void step_attention(const StepArgs& a, const StepLayer& L, const StepKV& kv, const StepLnOps& ops, int rg,
                                                int lr0, int bx, float* smem, float* kvlds, __amdgpu_buffer_rsrc_t qkvr,
                                                __amdgpu_buffer_rsrc_t xr, float* __restrict__ xres, float* __restrict__ hout) {
@@ -987,7 +994,7 @@ __device__ __forceinline__ void step_attention(const StepArgs& a, const StepLaye
         const int qic = qok ? qi : nq - 1;
         const int ja = a0 + qic;
         const int lo_row = min(a0, max(0, ja - W + 1));
-        float4 q4 = as4(ld_l2(qkvr, (rowbase + i0 + qic) * 3u * E + hw * 64 + d4));
+        float4 q4 = as4(__builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qkvr, ((rowbase + i0 + qic) * 3u * E + hw * 64 + d4) * 4u, 0, AUX)));
         const float4 x4 = as4(ld_l2(xr, t16_off(lr0 + i0 + qic, hw * 64 + d4, KBt)));
         float mrun = -INFINITY, sum = 0.f;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1006,8 +1013,8 @@ __device__ __forceinline__ void step_attention(const StepArgs& a, const StepLaye
                     ksrc = kv.kold + ((size_t)rg * nc + pos) * E + hw * 64 + d4;
                     vsrc = kv.vold + ((size_t)rg * nc + pos) * E + hw * 64 + d4;
                 }
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)ksrc, (lds_ptr_t)(kvs + 4 * u * 64), 16, 0, 16);
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)vsrc, (lds_ptr_t)(kvs + (NKMAX + 4 * u) * 64), 16, 0, 16);
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)ksrc, (lds_ptr_t)(kvs + 4 * u * 64), 16, 0, AUX);
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)vsrc, (lds_ptr_t)(kvs + (NKMAX + 4 * u) * 64), 16, 0, AUX);
             }
             if (qb == 0 && kb == 0) {  // K / V requests are in flight: now land the RoPE slice
                 if (lane < nk * 4) {
@@ -1291,7 +1298,7 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
                     const int q = it / nchunks, bx = it - q * nchunks, br = q / nclip, cl = q - br * nclip;
                     __syncthreads();  // (a second item of this workgroup reuses the LDS rows)
                     if (it != rank) attn_prefetch(l, it);
-                    step_attention(a, Lw, kv, lnops, br * B + c0 + cl, br * ct + cl * T, bx, smem, kvl, qkv_r, xres_r, xres, hb);
+                    step_attention<16>(a, Lw, kv, lnops, br * B + c0 + cl, br * ct + cl * T, bx, smem, kvl, qkv_r, xres_r, xres, hb);
                 }
                 const int nroll = nitems < (int)n ? (int)n - nitems : (int)n, rb = nitems < (int)n ? rank - nitems : rank;
                 if (rb >= 0) {
@@ -1382,6 +1389,308 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
     }
 }
 
+// =====================================================================================================
+// Persistent OFFLINE sampler for one clip (RectifiedFlow.sample, model.py:763-785, B = 1): the same eight XCD-local
+// pipelines as the streaming sampler, partitioned over TIME -- XCD g owns frames [g Tseg, (g + 1) Tseg) of the clip's
+// three CFG rows (96 token rows at T = 256) for every layer and every Euler step.  The only thing that crosses an XCD
+// boundary is the attention's left context: the keys / values of the W - 1 frames in front of a segment belong to the
+// previous XCD.  No device-wide barrier for that: the qkv rows are written with system-scope stores (sc0 sc1: through to
+// memory), each XCD publishes "layers whose qkv rows are in memory" in a system-scope word after its XCD-local barrier,
+// and the workgroups whose chunks reach in front of the segment poll the neighbour's word before they load K / V with
+// system-scope loads (scripts/ubench/xcd_halo.hip: 0 errors, ~0.5 us per hand-over when the XCDs run in step).  The
+// reverse hazard -- an XCD a whole step ahead overwriting a layer's rows before its neighbour read them -- is closed by a
+// second word (`att_seq`) checked by an idle wave during the LayerNorm phase.
+// With 96 rows per XCD the Linears are MFMA-bound, not latency-bound: they run as bf16 x 3 split products like
+// gemm_x6.hip (six exact bf16 MFMAs per fp32 product block, fp32 accumulate), the three-way split of BOTH operands done in
+// registers from the fp32 tiles (the 16 x 16 tiles in fp32-MFMA fragment order serve the 16 x 16 x 32 bf16 MFMA as well:
+// a lane's eight k values are its float4 of k-block 2u and of 2u + 1 -- any k order inside the 32 is fine as long as both
+// operands use the same one).
+typedef __bf16 sbf16x8 __attribute__((ext_vector_type(8)));
+constexpr int kSegWP[6] = {2, 0, 1, 1, 0, 0}, kSegAP[6] = {0, 2, 1, 0, 1, 0};  // (W plane, A plane): smallest products first
+
+// eight fp32 values -> their three bf16 planes (h + m + l == x exactly, each a packed bf16 x 8 MFMA operand)
+__device__ __forceinline__ void seg_split8(const f32x4& a, const f32x4& b, u32x4 (&p)[3]) {
+    uint2 h0, m0, l0, h1, m1, l1;
+    x6_split4(a[0], a[1], a[2], a[3], h0, m0, l0);
+    x6_split4(b[0], b[1], b[2], b[3], h1, m1, l1);
+    p[0] = u32x4{h0.x, h0.y, h1.x, h1.y};
+    p[1] = u32x4{m0.x, m0.y, m1.x, m1.y};
+    p[2] = u32x4{l0.x, l0.y, l1.x, l1.y};
+}
+
+// acc[j * MB + i] += (this wave's K slice: 32-deep k-blocks kb0 .. kb0 + KB) of rows 16 i .. of A x column tile tile0 + 32 j
+// of W, both fp32 in 16 x 16 tiles (k-blocks of 16: `a_kblocks` / `w_kblocks` per row block / tile)
+template <int MB, int NT, int KB>
+__device__ __forceinline__ void seg_gemm(f32x4 (&acc)[NT * MB], __amdgpu_buffer_rsrc_t A, int a_kblocks,
+                                         const float* __restrict__ wt, int w_kblocks, int tile0, int kb0, int lane, bool wact) {
+#pragma unroll
+    for (int p = 0; p < NT * MB; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int RH = MB > 3 ? 3 : MB;  // row blocks per pass (register budget)
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+        const int kb = 2 * (kb0 + u);
+        u32x4 wp[NT][3];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const float* q = wt + ((size_t)((tile0 + 32 * j) * w_kblocks + kb) << 8) + lane * 4;
+            const f32x4 w0 = wact ? *reinterpret_cast<const f32x4*>(q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 w1 = wact ? *reinterpret_cast<const f32x4*>(q + 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+            seg_split8(w0, w1, wp[j]);
+        }
+#pragma unroll
+        for (int i0 = 0; i0 < MB; i0 += RH) {
+            u32x4 ap[RH][3];
+#pragma unroll
+            for (int i = 0; i < RH; ++i) {
+                const unsigned off = (unsigned)((((i0 + i) * a_kblocks + kb) << 8) + lane * 4);
+                seg_split8(ld_l2(A, off), ld_l2(A, off + 256), ap[i]);
+            }
+#pragma unroll
+            for (int p = 0; p < 6; ++p)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int i = 0; i < RH; ++i)  // W fragment as srcA: the accumulator holds C^T
+                        acc[j * MB + i0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(sbf16x8, wp[j][kSegWP[p]]), __builtin_bit_cast(sbf16x8, ap[i][kSegAP[p]]),
+                            acc[j * MB + i0 + i], 0, 0, 0);
+        }
+    }
+}
+
+// the eight waves' partials of ONE column tile (MB row blocks) -> LDS -> wave w returns the sum of row block w (wave order)
+template <int MB, int P>
+__device__ __forceinline__ f32x4 seg_reduce(const f32x4 (&acc)[P], int j, float* red, int w, int lane) {
+    __syncthreads();  // the previous readers are done with `red`
+#pragma unroll
+    for (int i = 0; i < MB; ++i) *reinterpret_cast<f32x4*>(red + (((w * MB + i) << 6) + lane) * 4) = acc[j * MB + i];
+    __syncthreads();
+    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (w < MB) {
+        o = *reinterpret_cast<const f32x4*>(red + ((w << 6) + lane) * 4);
+#pragma unroll
+        for (int q = 1; q < 8; ++q) o += *reinterpret_cast<const f32x4*>(red + ((((q * MB + w)) << 6) + lane) * 4);
+    }
+    return o;
+}
+
+__device__ __forceinline__ bool seg_spin_sys(const unsigned* word, unsigned want, unsigned* fail) {
+    const __amdgpu_buffer_rsrc_t r = step_rsrc(word);
+    for (unsigned spins = 0;; ++spins) {
+        if (__builtin_amdgcn_raw_buffer_load_b32(r, 0, 0, 17) >= want) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if (spins > (1u << 21)) {
+            __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+}
+
+// (out of line: with the attention body inlined next to the split-MFMA GEMMs, clang 22's InstCombine crashes on this kernel)
+__device__ __attribute__((noinline)) void seg_attention(const StepArgs& a, const StepLayer& L, const StepLnOps& ops, int rg, int lr0,
+                                                        int bx, float* smem, float* kvlds, float* xres, float* hout) {
+    const StepKV nokv{nullptr, nullptr, nullptr, nullptr};
+    step_attention<17>(a, L, nokv, ops, rg, lr0, bx, smem, kvlds, step_rsrc(L.qkv), step_rsrc(xres), xres, hout);
+}
+
+template <int MB>  // row blocks per XCD: 3 Tseg / 16 (6 at T = 256)
+__global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ unsigned s_rank, s_bad, s_ok;
+    constexpr int E = kSE, ME = kSME, KBE = E / 16, KBM = ME / 16, MBP = (MB + 2) / 3;  // MBP: row blocks of one CFG row
+    StepSync* st = a.sync;
+    const unsigned xcc = step_xcc_id(), nb = gridDim.x, n = 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) {  // census: workgroups per XCC, this workgroup's rank on its XCC
+        s_rank = __hip_atomic_fetch_add(&st->pop[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&st->census[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        step_spin(&st->census[0], nb, &st->fail[0]);
+        unsigned bad = 0;
+        for (int x = 0; x < 8; ++x)
+            bad |= __hip_atomic_load(&st->pop[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 32u;
+        if (a.dbg & 8) bad = 1;
+        if (bad) __hip_atomic_store(&st->fail[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_bad = bad;
+    }
+    __syncthreads();
+    if (s_bad) return;
+    const int rank = __builtin_amdgcn_readfirstlane((int)s_rank), g = (int)xcc;
+    unsigned round = 0, tslot = 0;
+    unsigned long long* trace = a.trace ? a.trace + (size_t)blockIdx.x * 128 : nullptr;
+
+    // this XCD's frames [f0, f0 + Tseg) of the three CFG rows: local token rows lm = branch * Tseg + (frame - f0)
+    const int T = a.T, Tseg = a.Tseg, f0 = g * Tseg, Mg = 3 * Tseg;
+    float* const pat = a.pat_t + (size_t)g * kSGroupRows * E;
+    float* const xres = a.xres_t + (size_t)g * kSGroupRows * E;
+    float* const hb = a.h_t + (size_t)g * kSGroupRows * E;
+    float* const mlp = a.mlp_t + (size_t)g * kSGroupRows * ME;
+    const __amdgpu_buffer_rsrc_t pat_r = step_rsrc(pat), xres_r = step_rsrc(xres), hb_r = step_rsrc(hb), mlp_r = step_rsrc(mlp);
+    const __amdgpu_buffer_rsrc_t xt_r = step_rsrc(a.xt), xout_r = step_rsrc(a.xout);
+    float* const red = smem;                      // partial tiles [8 waves][MB][256] (one column tile at a time) | attention rows
+    float* const kvl = smem + kSRedFloats(2);     // attention: K / V landing zones [8 waves][2][12][64]
+    const bool wact = !(a.dbg & 2);
+    auto end_phase = [&](bool drain) { return step_barrier(st, xcc, n, ++round, trace, ++tslot, drain, &s_ok); };
+    StepLnOps lnops;
+    const int ln_lm = rank + (int)n * w;  // this wave's row of the ln phases (waves 0 .. 2 at 96 rows)
+    const bool ln_mine = ln_lm < Mg;
+    auto ln_prefetch = [&](int l) {
+        if (!ln_mine) return;
+        const int br = ln_lm / Tseg, tl = ln_lm - br * Tseg;
+        step_ln_ops(lnops, a.tc_ab + ((size_t)a.tcmap[br] * T + f0 + tl) * a.tc_ld + (size_t)l * 2 * E, a.layer[l].n1w, a.layer[l].n1b, lane);
+    };
+    const int cps = Tseg / a.cs, nitems = 3 * cps;  // attention items: (CFG row, chunk of the segment)
+
+    for (int i = 0; i < a.nsteps; ++i) {  // ---- the Euler steps of RectifiedFlow.sample (model.py:770-785)
+        const float* cond_ab = a.cond_ab + (size_t)i * a.cond_step;
+        auto attn_prefetch = [&](int l, int it) {
+            step_ln_ops(lnops, cond_ab + (size_t)(it / cps) * a.cond_ld + (size_t)l * 2 * E, a.layer[l].n3w, a.layer[l].n3b, lane);
+        };
+        tslot = 0;
+        if (trace && tid == 0) trace[0] = wall_clock64();
+        // ---- patchify_and_embed for the segment's Tseg frames (shared by the three CFG rows): fp32 MFMA, K = Cp
+        {
+            const int kbp = a.Cp / 16;
+            f32x4 acc[MBP];
+            const f32x4 bv = w < MBP ? *reinterpret_cast<const f32x4*>(a.patch_b + 16 * rank + 4 * (lane >> 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ib = 0; ib < MBP; ++ib) acc[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (w < kbp) {
+                const f32x4 wv = wact ? *reinterpret_cast<const f32x4*>(a.patch_wt + ((size_t)(rank * kbp + w) << 8) + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 av[MBP];
+#pragma unroll
+                for (int ib = 0; ib < MBP; ++ib)
+                    av[ib] = ld_l2(xt_r, (unsigned)((f0 + min(16 * ib + (lane & 15), Tseg - 1)) * a.Cp + 16 * w + 4 * (lane >> 4)));
+                ln_prefetch(0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int ib = 0; ib < MBP; ++ib) acc[ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c], av[ib][c], acc[ib], 0, 0, 0);
+            } else {
+                ln_prefetch(0);
+            }
+            f32x4 o = seg_reduce<MBP>(acc, 0, red, w, lane);
+            if (w < MBP) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r] + bv[r]);
+                *reinterpret_cast<f32x4*>(pat + ((size_t)(w * KBE + rank) << 8) + lane * 4) = o;
+            }
+        }
+        if (!end_phase(w < MBP)) return;
+        for (int l = 0; l < a.L; ++l) {
+            const StepLayer& Lw = a.layer[l];
+            const __amdgpu_buffer_rsrc_t qkv_r = step_rsrc(Lw.qkv);
+            const unsigned seq = (unsigned)(i * a.L + l + 1);
+            // ---- norm0 -> AdaLN(tcond) -> norm1: one wave per token row (three per workgroup)
+            if (ln_mine) {
+                const int br = ln_lm / Tseg, tl = ln_lm - br * Tseg;
+                step_ln_row(l == 0 ? pat_r : xres_r, l == 0 ? tl : ln_lm, xres, hb, ln_lm, lnops, lane);
+            }
+            // (idle wave 7 of workgroup 0: the next XCD has read this layer's keys of the PREVIOUS step -- its last
+            //  frames may be overwritten.  A whole step behind: satisfied long ago, one memory round trip off the path)
+            if (rank == 0 && w == 7 && lane == 0 && g < 7 && i > 0) seg_spin_sys(&st->att_seq[g + 1][0], seq - a.L, &st->fail[0]);
+            if (!end_phase(ln_mine)) return;
+            // ---- qkv: column tiles rank, rank + 32, rank + 64 (bf16 x 3 split MFMAs); rows written through to memory
+            {
+                f32x4 acc[3 * MB];
+                seg_gemm<MB, 3, KBE / 16>(acc, hb_r, KBE, Lw.qkv_wt, KBE, rank, (KBE / 16) * w, lane, wact);
+                if (rank < nitems) attn_prefetch(l, rank);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const f32x4 o = seg_reduce<MB>(acc, j, red, w, lane);
+                    if (w < MB) {
+                        const int lm = 16 * w + (lane & 15), br = lm / Tseg, tl = lm - br * Tseg;
+                        if (lm < Mg)
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), qkv_r,
+                                                                   (unsigned)(((br * T + f0 + tl) * 3 * E + 16 * (rank + 32 * j) + 4 * (lane >> 4)) * 4), 0, 17);
+                    }
+                }
+            }
+            if (!end_phase(w < MB)) return;
+            if (rank == 0 && tid == 0) __builtin_amdgcn_raw_buffer_store_b32(seq, step_rsrc(&st->qkv_seq[g][0]), 0, 0, 17);
+            // ---- attention + residual + AdaLN(cond) + norm3: one workgroup per chunk of a CFG row; a chunk whose window
+            //      starts in front of the segment waits for the previous XCD's rows
+            for (int it = rank; it < nitems; it += (int)n) {
+                const int br = it / cps, ch = it - br * cps, i0f = f0 + ch * a.cs;
+                __syncthreads();  // (a second item of this workgroup reuses the LDS rows)
+                if (it != rank) attn_prefetch(l, it);
+                if (g > 0 && i0f - (a.W - 1) < f0) {
+                    if (tid == 0) s_ok = seg_spin_sys(&st->qkv_seq[g - 1][0], seq, &st->fail[0]);
+                    __syncthreads();
+                    if (!s_ok) return;
+                }
+                seg_attention(a, Lw, lnops, br, br * Tseg - f0, i0f / a.cs, smem, kvl, xres, hb);
+            }
+            if (!end_phase(true)) return;
+            if (rank == 0 && tid == 0) __builtin_amdgcn_raw_buffer_store_b32(seq, step_rsrc(&st->att_seq[g][0]), 0, 0, 17);
+            // ---- MLP up + GELU: column tiles rank + 32 j
+            {
+                f32x4 acc[kSNTU * MB];
+                seg_gemm<MB, kSNTU, KBE / 16>(acc, hb_r, KBE, Lw.mlp0_wt, KBE, rank, (KBE / 16) * w, lane, wact);
+#pragma unroll
+                for (int j = 0; j < kSNTU; ++j) {
+                    const int tile = rank + 32 * j;
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(Lw.mlp0_b + 16 * tile + 4 * (lane >> 4));
+                    f32x4 o = seg_reduce<MB>(acc, j, red, w, lane);
+                    if (w < MB) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r] + bv[r]);
+                        *reinterpret_cast<f32x4*>(mlp + ((size_t)(w * KBM + tile) << 8) + lane * 4) = o;
+                    }
+                }
+            }
+            if (!end_phase(w < MB)) return;
+            // ---- MLP down + residual: column tile rank
+            {
+                f32x4 acc[MB];
+                const unsigned off = (unsigned)(((w * KBE + rank) << 8) + lane * 4);  // wave w finishes row block w
+                f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f}, rv = bv;
+                if (w < MB) {
+                    bv = *reinterpret_cast<const f32x4*>(Lw.mlp2_b + 16 * rank + 4 * (lane >> 4));
+                    rv = ld_l2(xres_r, off);
+                }
+                seg_gemm<MB, 1, KBM / 16>(acc, mlp_r, KBM, Lw.mlp2_wt, KBM, rank, (KBM / 16) * w, lane, wact);
+                if (l + 1 < a.L) ln_prefetch(l + 1);
+                f32x4 o = seg_reduce<MB>(acc, 0, red, w, lane);
+                if (w < MB) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = o[r] + bv[r] + rv[r];
+                    *reinterpret_cast<f32x4*>(xres + off) = o;
+                }
+            }
+            if (!end_phase(w < MB)) return;
+        }
+        // ---- out_proj + CFG + Euler (+ the token-major latents of the next step): column tile rank < C / 16, fp32 MFMA
+        if (rank < a.C / 16) {
+            f32x4 acc[MB];
+            step_gemm<MB, 1, kSKBQ, false>(acc, xres_r, KBE, a.out_wt, KBE, rank, kSKBQ * w, lane, true, wact, [] {});
+            const f32x4 o = seg_reduce<MB>(acc, 0, red, w, lane);
+            float* const outt = red + 8 * MB * 256;  // [MB * 16 rows][16 columns]
+            if (w < MB) *reinterpret_cast<f32x4*>(outt + (16 * w + (lane & 15)) * 16 + 4 * (lane >> 4)) = o;
+            __syncthreads();
+            for (int e = tid; e < Tseg * 16; e += 512) {  // model.py:749-759, 777-783
+                const int tl = e >> 4, col = e & 15, nn = 16 * rank + col;
+                const float bo = a.out_b ? a.out_b[nn] : 0.f;
+                const float dfull = outt[tl * 16 + col] + bo, dmid = outt[(Tseg + tl) * 16 + col] + bo,
+                            dnone = outt[(2 * Tseg + tl) * 16 + col] + bo;
+                const float total = a.cfg[0], factor = a.cfg[1], dt = a.cfg[2];
+                const float v = dnone + total * (dmid + factor * (dfull - dmid) - dnone);
+                const size_t o1 = (size_t)nn * T + f0 + tl;
+                const float xi = i == 0 ? a.x0[o1]
+                                        : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xout_r, (unsigned)o1 * 4u, 0, 16));
+                const float xn = xi + v * dt;
+                a.xout[o1] = xn;
+                if (i + 1 < a.nsteps) a.xt[(size_t)(f0 + tl) * a.Cp + nn] = xn;
+            }
+        }
+        if (trace && tid == 0) {
+            trace[2 * tslot + 1] = wall_clock64();
+            trace[127] = xcc;
+        }
+        if (i + 1 < a.nsteps && !end_phase(true)) return;
+    }
+}
+
 // W [N][K] (row stride ldw) -> 16 x 16 tiles [N / 16][K / 16][256] in MFMA fragment order (t16_off)
 __global__ __launch_bounds__(256) void tile16_kernel(const float* __restrict__ W, int ldw, float* __restrict__ out, int N, int K) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // one float4 of the output
@@ -1459,6 +1768,9 @@ struct after_denoiser {
     // persistent streaming step (stream_step_kernel): one launch per cached Euler step.  AFTER_STREAM_PERSIST=0 /
     // after_denoiser_set_stream_persist(h, 0) keep the launch-per-kernel path.
     int persist_step = 1, n_cus = 0;
+    int persist_offline = 0;  // AFTER_SAMPLE_PERSIST / after_denoiser_set_sample_persist: one clip's offline sampler as sample_seg_kernel
+    float* seg_qkv = nullptr;  // [L][3 max_T][3E]: per-layer qkv rows of the segment sampler
+    bool last_seg = false;     // the last after_sample ran as sample_seg_kernel
     int step_dbg = 0;  // after_denoiser_set_stream_persist(h, 1 | dbg << 8): diagnostics bits OR-ed into AFTER_STEP_DBG
     StepSync* step_sync = nullptr;       // [max_steps]: one barrier state per step of a sample() call
     unsigned long long* step_trace = nullptr;  // AFTER_STEP_TRACE=1: stamps of the LAST step launched (diagnostics)
@@ -1990,6 +2302,8 @@ extern "C" int after_denoiser_create(const after_denoiser_cfg* cfg, const float*
         if (h->E % 128 != 0) h->fuse_tail = 0;  // the fused GEMM splits K four ways
         const char* ps = getenv("AFTER_STREAM_PERSIST");
         if (ps) h->persist_step = atoi(ps) != 0;
+        const char* po = getenv("AFTER_SAMPLE_PERSIST");
+        if (po) h->persist_offline = atoi(po) != 0;
         hipDeviceProp_t prop;
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(AFTER_E_HIP);
@@ -2020,6 +2334,7 @@ extern "C" void after_denoiser_destroy(after_denoiser* h) {
     if (h->step_fail) (void)hipHostFree(h->step_fail);
     if (h->step_wt) (void)hipFree(h->step_wt);
     if (h->step_act) (void)hipFree(h->step_act);
+    if (h->seg_qkv) (void)hipFree(h->seg_qkv);
     h->wa.release();
     h->ws.release();
     h->ca.release();
@@ -2142,28 +2457,35 @@ int step_tile_weights(after_denoiser* h, hipStream_t s) {
     return AFTER_OK;
 }
 
+int step_check_failure(after_denoiser* h) {
+    if (h->step_fail && h->step_fail_n > 0 && (h->step_fail[0] || h->step_fail[1])) {
+        const bool census = h->step_fail[1] != 0;
+        h->persist_step = 0;
+        h->persist_offline = 0;
+        h->step_fail_n = 0;
+        h->step_fail[0] = h->step_fail[1] = 0;
+        set_error("persistent sampler: %s; the launch-per-kernel path is selected from now on (the previous result is "
+                  "invalid: reset the streamer / repeat the call)",
+                  census ? "the workgroups were not placed 32 per XCD" : "a barrier or a neighbour flag timed out");
+        return AFTER_E_HIP;
+    }
+    return AFTER_OK;
+}
+
+int step_alloc(after_denoiser* h, hipStream_t s) {
+    if (h->step_sync) return AFTER_OK;
+    AFTER_HIP_CHECK(hipMalloc(&h->step_sync, sizeof(StepSync)));
+    AFTER_HIP_CHECK(hipHostMalloc(&h->step_fail, 32 * sizeof(unsigned), hipHostMallocDefault));
+    memset(h->step_fail, 0, 32 * sizeof(unsigned));
+    const char* tr = getenv("AFTER_STEP_TRACE");
+    if (tr && atoi(tr) != 0) AFTER_HIP_CHECK(hipMalloc(&h->step_trace, (size_t)h->n_cus * 128 * sizeof(unsigned long long)));
+    return step_tile_weights(h, s);
+}
+
 int sample_persistent(after_denoiser* h, hipStream_t s, const float* x0, float* out, int B, int T, int nb_steps) {
     const int rows = 3 * B, E = h->E, L = h->L;
-    if (h->step_fail && h->step_fail_n > 0) {  // the previous call's flags (a late flag is seen one call later)
-        for (int i = 0; i < h->step_fail_n; ++i)
-            if (h->step_fail[i * 32] || h->step_fail[i * 32 + 1]) {
-                const bool census = h->step_fail[i * 32 + 1] != 0;
-                h->persist_step = 0;
-                h->step_fail_n = 0;
-                set_error("persistent streaming step: %s; the launch-per-kernel path is selected from now on -- reset "
-                          "the streamer (the previous chunk is invalid)",
-                          census ? "the workgroups were not placed 32 per XCD" : "an XCD-local barrier timed out");
-                return AFTER_E_HIP;
-            }
-    }
-    if (!h->step_sync) {
-        AFTER_HIP_CHECK(hipMalloc(&h->step_sync, sizeof(StepSync)));
-        AFTER_HIP_CHECK(hipHostMalloc(&h->step_fail, 32 * sizeof(unsigned), hipHostMallocDefault));
-        memset(h->step_fail, 0, 32 * sizeof(unsigned));
-        const char* tr = getenv("AFTER_STEP_TRACE");
-        if (tr && atoi(tr) != 0) AFTER_HIP_CHECK(hipMalloc(&h->step_trace, (size_t)h->n_cus * 128 * sizeof(unsigned long long)));
-        AFTER_TRY(step_tile_weights(h, s));
-    }
+    AFTER_TRY(step_check_failure(h));  // the previous call's flags (a late flag is seen one call later)
+    AFTER_TRY(step_alloc(h, s));
     const int cpg = (B + 7) / 8, MB = (3 * cpg * T + 15) / 16;
     const int nkmax = h->W - 1 + h->cs > h->cs ? h->W - 1 + h->cs : h->cs;
     const size_t attn_lds = ((size_t)h->cs * (E + 4) + (size_t)kSH * 2 * nkmax * 16) * sizeof(float);
@@ -2244,6 +2566,86 @@ int sample_persistent(after_denoiser* h, hipStream_t s, const float* x0, float* 
     return AFTER_OK;
 }
 
+// RectifiedFlow.sample for ONE clip as one persistent launch (sample_seg_kernel): eligible for the shipped width (embed
+// 512 / mlp x 3 / eight heads: the kernel's tile counts), finite causal window that fits one segment, T = 128 or 256 frames
+// (eight segments of 16 / 32 frames, whole attention chunks), <= 8 layers, 256 CUs, no streaming caches.
+bool sample_seg_ok(const after_denoiser* h, int B, int T, int nb_steps) {
+    const bool wide = h->W < 0 || !h->cfg.causal;
+    const int Tseg = T / 8;
+    return h->persist_offline && h->cache == 0 && B == 1 && (!h->timer.enabled || h->timer_kernel == 3) && !h->use_graph &&
+           h->x6 != 0 && h->E == kSE && h->ME == kSME && h->H == kSH && h->L <= 8 && !wide && h->Cp == h->C && h->C % 16 == 0 &&
+           h->C / 16 <= 4 && h->n_cus == 256 && T % 8 == 0 && (Tseg == 16 || Tseg == 32) && Tseg % h->cs == 0 &&
+           h->W - 1 <= Tseg && nb_steps >= 1 && T <= h->max_T &&
+           ((size_t)h->cs * (h->E + 4) + (size_t)kSH * 2 * (h->W - 1 + h->cs) * 16) <= 7168;
+}
+
+int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, int T, int nb_steps) {
+    const int E = h->E, L = h->L, Tseg = T / 8, MB = 3 * Tseg / 16;
+    AFTER_TRY(step_check_failure(h));
+    AFTER_TRY(step_alloc(h, s));
+    if (!h->seg_qkv) AFTER_HIP_CHECK(hipMalloc(&h->seg_qkv, (size_t)L * 3 * h->max_T * 3 * E * sizeof(float)));
+    const int nkmax = h->W - 1 + h->cs > h->cs ? h->W - 1 + h->cs : h->cs;
+    const size_t lds = ((size_t)kSRedFloats(2) + 8 * 2 * kAttnKeyBlock * 64) * sizeof(float);
+    static size_t attr[2] = {0, 0};
+    if (lds > attr[MB == 6]) {
+        AFTER_HIP_CHECK(hipFuncSetAttribute(MB == 6 ? reinterpret_cast<const void*>(sample_seg_kernel<6>)
+                                                    : reinterpret_cast<const void*>(sample_seg_kernel<3>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr[MB == 6] = lds;
+    }
+    {
+        dim3 grid(cdiv(T, 32), cdiv(h->Cp, 32), 1);
+        hipLaunchKernelGGL(to_token_major_kernel, grid, dim3(256), 0, s, x0, h->xt, (const int*)nullptr, h->C, T, h->Cp, 0.f);
+        AFTER_HIP_CHECK(hipGetLastError());
+    }
+    AFTER_HIP_CHECK(hipMemsetAsync(h->step_sync, 0, sizeof(StepSync), s));
+    const size_t slice = (size_t)8 * kSGroupRows * E;
+    StepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rows = 3, a.B = 1, a.T = T, a.C = h->C, a.Cp = h->Cp, a.L = L;
+    a.cs = h->cs, a.W = h->W, a.nkmax = nkmax, a.cache = 0, a.cache_rows = 0, a.cpg = 1, a.Tseg = Tseg;
+    a.nsteps = nb_steps, a.cache_steps = 0;
+    a.xt = h->xt;
+    a.pat_t = h->step_act, a.xres_t = h->step_act + slice, a.h_t = h->step_act + 2 * slice, a.mlp_t = h->step_act + 3 * slice;
+    a.patch_wt = h->step_patch_wt, a.patch_b = h->patch_b, a.out_wt = h->step_out_wt, a.out_b = h->out_b;
+    a.tc_ab = h->tc_ab, a.tc_ld = L * 2 * E, a.tcmap = h->maps + h->ms;
+    a.cond_ab = h->cond_ab, a.cond_step = (size_t)3 * L * 2 * E, a.cond_ld = L * 2 * E;
+    a.rope_cos = h->rope_cos, a.rope_sin = h->rope_sin;
+    a.x0 = x0, a.xout = out;
+    a.cfg = reinterpret_cast<const float*>(h->dparams);
+    a.sync = h->step_sync;
+    a.trace = h->step_trace;
+    {
+        static int dbg = -1;
+        if (dbg < 0) {
+            const char* e = getenv("AFTER_STEP_DBG");
+            dbg = e ? atoi(e) : 0;
+        }
+        a.dbg = dbg | h->step_dbg;
+    }
+    for (int l = 0; l < L; ++l) {
+        const LayerW& w = h->layers[l];
+        StepLayer& sl = a.layer[l];
+        sl.qkv_wt = h->step_layers[l].qkv, sl.mlp0_wt = h->step_layers[l].mlp0, sl.mlp2_wt = h->step_layers[l].mlp2;
+        sl.mlp0_b = w.mlp0_b, sl.mlp2_b = w.mlp2_b, sl.n1w = w.n1w, sl.n1b = w.n1b, sl.n3w = w.n3w, sl.n3b = w.n3b;
+        sl.qkv = h->seg_qkv + (size_t)l * 3 * h->max_T * 3 * E;
+    }
+    const bool timed = h->timer.enabled && h->timer_kernel == 3;
+    if (timed) h->timer.begin(s);
+    if (MB == 6) hipLaunchKernelGGL(sample_seg_kernel<6>, dim3(h->n_cus), dim3(512), lds, s, a);
+    else hipLaunchKernelGGL(sample_seg_kernel<3>, dim3(h->n_cus), dim3(512), lds, s, a);
+    AFTER_HIP_CHECK(hipGetLastError());
+    if (timed) {
+        const double M = 3.0 * T, Ed = E, MEd = h->ME, Cd = h->C;
+        const double wts = Ed * h->Cp + Cd * Ed + L * (3 * Ed * Ed + 2 * Ed * MEd);
+        const double fl = 2.0 * ((double)T * Ed * h->Cp + M * (Cd * Ed + L * (3 * Ed * Ed + 2 * Ed * MEd)));
+        h->timer.end(s, nb_steps * fl, nb_steps * 4.0 * wts);
+    }
+    AFTER_HIP_CHECK(hipMemcpyAsync(h->step_fail, &h->step_sync[0].fail[0], 32 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    h->step_fail_n = 1;
+    return AFTER_OK;
+}
+
 // The whole sampler as a sequence of launches on `s` (eager path and graph capture body).
 // With streaming caches (h->cache > 0) this is Streamer.sample of export.py:398-416: step i
 // attends over its own cache slot i, which is rolled by the chunk length after the step.
@@ -2254,6 +2656,11 @@ int sample_enqueue(after_denoiser* h, hipStream_t s, const float* x0, const floa
     const int rows = 3 * B;
     AFTER_TRY(compute_cond_ab(h, s, nb_steps, rows, nullptr, nullptr, nb_steps, cond,
                               h->maps + 2 * h->ms, drop_value));
+    h->last_seg = false;
+    if (sample_seg_ok(h, B, T, nb_steps)) {
+        h->last_seg = true;
+        return sample_seg(h, s, x0, out, T, nb_steps);
+    }
     if (step_persist_ok(h, B, T)) {
         AFTER_TRY(sample_persistent(h, s, x0, out, B, T, nb_steps));
         h->have_last = true;
@@ -2406,6 +2813,19 @@ extern "C" int after_denoiser_set_stream_persist(after_denoiser* h, int enable) 
     AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
     h->persist_step = (enable & 0xff) != 0;
     h->step_dbg = enable >> 8;  // (diagnostics: bit 3 = report a failed placement census, as tests/test_stream_persist_gpu.py does)
+    return AFTER_OK;
+}
+
+extern "C" int after_denoiser_set_sample_persist(after_denoiser* h, int enable) {
+    AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
+    h->persist_offline = (enable & 0xff) != 0;
+    h->step_dbg = enable >> 8;
+    return AFTER_OK;
+}
+
+extern "C" int after_denoiser_sample_persist(after_denoiser* h, int* active) {
+    AFTER_REQUIRE(h && active, AFTER_E_INVALID, "null argument");
+    *active = h->last_seg ? 1 : 0;
     return AFTER_OK;
 }
 

@@ -219,6 +219,8 @@ class DenoiserV2(nn.Module):
             _lib.check(L.after_denoiser_set_gemm_path(out, *self._gemm_path), "after_denoiser_set_gemm_path")
         if getattr(self, "_stream_persist", None) is not None:
             _lib.check(L.after_denoiser_set_stream_persist(out, int(self._stream_persist)), "after_denoiser_set_stream_persist")
+        if getattr(self, "_sample_persist", None) is not None:
+            _lib.check(L.after_denoiser_set_sample_persist(out, int(self._sample_persist)), "after_denoiser_set_sample_persist")
         if self._stream_args is not None and not getattr(self, "_enabling", False):
             # the handle was rebuilt (.to(), load_state_dict, refresh): a Streamer still expects
             # its K/V caches -- re-create them (zeroed = a new stream), as AutoEncoder / Encoder1D do
@@ -371,6 +373,22 @@ class DenoiserV2(nn.Module):
         if self._handle is not None:
             _lib.check(_lib.lib().after_denoiser_set_stream_persist(self._handle, int(bool(enable))),
                        "after_denoiser_set_stream_persist")
+
+    def set_sample_persist(self, enable: bool):
+        """Offline cfg_sample of ONE clip as one persistent launch (include/after_hip.h: after_denoiser_set_sample_persist)
+        where the geometry allows it, or the launch-per-kernel path."""
+        self._sample_persist = bool(enable)
+        if self._handle is not None:
+            _lib.check(_lib.lib().after_denoiser_set_sample_persist(self._handle, int(bool(enable))),
+                       "after_denoiser_set_sample_persist")
+
+    def sample_persist(self) -> bool:
+        """True when the last cfg_sample of this handle ran as the persistent offline kernel."""
+        if self._handle is None:
+            return False
+        a = ctypes.c_int()
+        _lib.check(_lib.lib().after_denoiser_sample_persist(self._handle, ctypes.byref(a)), "after_denoiser_sample_persist")
+        return bool(a.value)
 
     def stream_persist(self) -> bool:
         """True when the last streaming cfg_sample of this handle ran (and the next one of the same shape will run) as

@@ -141,6 +141,15 @@ int after_denoiser_gemm_path(after_denoiser* h, int* mode, int* min_rows);
  * streamer.  after_denoiser_stream_persist: *active = 1 when the handle's last streaming shape takes the persistent
  * path. */
 int after_denoiser_set_stream_persist(after_denoiser* h, int enable);
+/* after_sample for ONE clip without K/V caches (RectifiedFlow.sample, model.py:763-785) as one persistent launch: the same
+ * XCD-local pipelines partitioned over time (XCD g owns frames [g T/8, (g+1) T/8) of the three CFG rows; the attention's
+ * left context crosses XCDs through system-scope stores / loads and per-XCD sequence words, no device-wide barrier), the
+ * Linears as bf16 x 3 split MFMAs like gemm_x6.  Eligible: the shipped width (embed 512 / mlp x 3 / eight heads), T = 128 or
+ * 256, window - 1 <= T / 8, gemm path != 0, no graph replay; otherwise, or with enable = 0 / AFTER_SAMPLE_PERSIST=0, the
+ * launch path runs.  Failures are reported as for the streaming sampler.  _sample_persist: *active = 1 when the last
+ * after_sample ran this way. */
+int after_denoiser_set_sample_persist(after_denoiser* h, int enable);
+int after_denoiser_sample_persist(after_denoiser* h, int* active);
 int after_denoiser_stream_persist(after_denoiser* h, int* active);
 /* Diagnostics (AFTER_STEP_TRACE=1 at the first streaming call): out[workgroup][128] = 100 MHz wall-clock stamps of
  * the last persistent step -- [0] start, [2r-1] / [2r] arrival at / exit from barrier r, then the end; [127] = XCC. */

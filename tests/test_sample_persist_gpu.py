@@ -1,0 +1,47 @@
+"""The persistent offline sampler for one clip (denoiser.hip: sample_seg_kernel -- all Euler steps in one launch, the clip's
+frames partitioned over the eight XCDs, the attention's left context handed from XCD to XCD through system-scope stores /
+loads) against the launch-per-kernel path of the same handle and against the CPU oracle.  Both GPU paths form the big
+Linears' fp32 products from exact three-way bf16 splits (gemm_x6 / the in-register split of sample_seg_kernel) with
+different fixed K orders: they agree to fp32 round-off.  -m gpu."""
+import pytest
+import torch
+
+import oracle
+from after_amd import pipeline
+from fixtures import max_abs, rel_l2
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def base(hip_device):
+    model, dcfg, _ = pipeline.build_models("base", "baseAE", hip_device, seed=5)
+    return model, dcfg
+
+
+@pytest.mark.parametrize("T,steps", [(256, 6), (128, 4)])
+def test_persistent_offline_sampler_matches_launch_path_and_oracle(T, steps, base, hip_device):
+    model, dcfg = base
+    net = model.net
+    g = torch.Generator().manual_seed(41 + T)
+    x0 = torch.randn(1, 64, T, generator=g)
+    cond = torch.randn(1, 6, generator=g)
+    tc = torch.randn(1, 12, T, generator=g)
+    args = (x0.to(hip_device), cond.to(hip_device), tc.to(hip_device), steps, 2.0, 1.0, -4.0)
+    net.set_sample_persist(False)
+    ref = net.cfg_sample(*args).cpu()
+    assert not net.sample_persist()
+    net.set_sample_persist(True)
+    got = net.cfg_sample(*args).cpu()
+    assert net.sample_persist(), "the persistent offline sampler refused an eligible shape"
+    again = net.cfg_sample(*args).cpu()
+    assert torch.equal(got, again), "not reproducible"
+    assert max_abs(got, ref) < 5e-5, max_abs(got, ref)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    want = oracle.sample(sd, dcfg["net"], x0, cond, tc, steps, 2.0, 1.0)
+    assert max_abs(got, want) < 1e-4 and rel_l2(got, want) < 2e-5, (max_abs(got, want), rel_l2(got, want))
+    # shapes the kernel does not take fall back silently: two clips
+    x2 = torch.randn(2, 64, T, generator=g).to(hip_device)
+    net.cfg_sample(x2, torch.randn(2, 6, generator=g).to(hip_device), torch.randn(2, 12, T, generator=g).to(hip_device), 2, 2.0, 1.0, -4.0)
+    assert not net.sample_persist()
