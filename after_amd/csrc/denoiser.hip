@@ -729,6 +729,7 @@ struct StepArgs {
     int warm[3];  // sixteenths of the qkv / MLP-up / MLP-down weights warmed into the L2 by idle waves (AFTER_STEP_WARM)
     float* xt;                             // token-major latents [B * T][Cp]: a step's input, rewritten by its tail
     float *pat_t, *xres_t, *h_t, *mlp_t;   // tiled, one slice of kSGroupRows rows per XCD
+    unsigned short *h3_t, *mlp3_t;         // offline segment sampler: bf16 x 3 planes of h / the MLP hidden layer (p32_store4)
     const float *patch_wt, *patch_b, *out_wt, *out_b;
     const float* tc_ab;
     int tc_ld;
@@ -760,6 +761,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t step_rsrc(const void* p) {
 // sc1 load of 4 floats at float offset `off`: misses the vector L1, served by the XCD's L2
 __device__ __forceinline__ f32x4 ld_l2(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off * 4u, 0, 16));
+}
+
+// the same with the offset split into a per-lane part and a wave-uniform part: the uniform part travels in the instruction's
+// scalar offset, so a phase's dozens of fragment loads share ONE address register (precomputed per-load VGPR offsets are
+// loop invariants the compiler keeps live across the whole kernel -- and spills)
+__device__ __forceinline__ f32x4 ld_l2u(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned uniform_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off * 4u, uniform_off * 4u, 16));
 }
 
 __device__ __forceinline__ unsigned step_xcc_id() {
@@ -830,7 +838,7 @@ __device__ __forceinline__ void step_warm_done(unsigned& sink) { asm volatile("s
 template <int MB, int NT, int KB, bool AROW, class F>
 __device__ __forceinline__ void step_gemm(f32x4 (&acc)[NT * MB], __amdgpu_buffer_rsrc_t A, int a_kblocks,
                                           const float* __restrict__ wt, int w_kblocks, int tile0, int kb0, int lane,
-                                          bool active, bool wact, F&& after_loads, unsigned arow_off = 0) {
+                                          bool active, bool wact, F&& after_loads, unsigned arow_off = 0, int rb0 = 0, int rbs = 1) {
 #pragma unroll
     for (int p = 0; p < NT * MB; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (!active) {
@@ -845,7 +853,7 @@ __device__ __forceinline__ void step_gemm(f32x4 (&acc)[NT * MB], __amdgpu_buffer
 #pragma unroll
             for (int i = 0; i < MB; ++i) {
                 if constexpr (AROW) av[u][i] = ld_l2(A, arow_off + (unsigned)(kb0 + u0 + u) * 16 + (lane >> 4) * 4);
-                else av[u][i] = ld_l2(A, (unsigned)(((i * a_kblocks + kb0 + u0 + u) << 8) + lane * 4));
+                else av[u][i] = ld_l2u(A, lane * 4, (unsigned)(((rb0 + rbs * i) * a_kblocks + kb0 + u0 + u) << 8));
             }
     };
     load_a(0);
@@ -909,7 +917,20 @@ __device__ __forceinline__ void step_ln_ops(StepLnOps& o, const float* __restric
     }
 }
 
+// bf16 x 3 planes of an activation for the split-MFMA GEMMs of the offline segment sampler: 1-KB blocks [row block][k / 32][plane]
+// holding, for lane (r, kq), its eight k values of the 16 x 16 x 32 MFMA operand -- columns 32 u + 4 kq + j and 32 u + 16 + 4 kq + j,
+// the same k sets the fp32 weight tiles deliver -- at lane * 16 bytes.  p32_store4: columns c .. c + 3 (c % 4 == 0) of row lr.
+__device__ __forceinline__ void p32_store4(unsigned short* base, int lr, int c, int kb32, float x0, float x1, float x2, float x3) {
+    uint2 h, m, l;
+    x6_split4(x0, x1, x2, x3, h, m, l);
+    unsigned short* q = base + (((size_t)((lr >> 4) * kb32 + (c >> 5)) * 3) << 9) + ((((c & 15) >> 2) * 16 + (lr & 15)) << 3) + ((c & 16) >> 2);
+    *reinterpret_cast<uint2*>(q) = h;
+    *reinterpret_cast<uint2*>(q + 512) = m;
+    *reinterpret_cast<uint2*>(q + 1024) = l;
+}
+
 // ln_mod_ln_row on tiled buffers (E = 512): x = norm0(xin[src]) * (1 + alpha_t) + beta_t -> xres ; h = norm1(x)
+template <bool PLANES = false>  // h: fp32 tiles, or -- PLANES -- bf16 x 3 planes (p32_store4)
 __device__ __forceinline__ void step_ln_row(__amdgpu_buffer_rsrc_t xin, int src_lr, float* __restrict__ xres,
                                             float* __restrict__ h, int lr, const StepLnOps& ops, int lane) {
     constexpr int E = kSE, NV = E / 256, KBt = E / 16;
@@ -949,7 +970,8 @@ __device__ __forceinline__ void step_ln_row(__amdgpu_buffer_rsrc_t xin, int src_
         y.y = (v[i].y - mean) * rstd * ww[i].y + bb[i].y;
         y.z = (v[i].z - mean) * rstd * ww[i].z + bb[i].z;
         y.w = (v[i].w - mean) * rstd * ww[i].w + bb[i].w;
-        *reinterpret_cast<f32x4*>(h + o) = y;
+        if constexpr (PLANES) p32_store4(reinterpret_cast<unsigned short*>(h), lr, 4 * lane + 256 * i, E / 32, y.x, y.y, y.z, y.w);
+        else *reinterpret_cast<f32x4*>(h + o) = y;
     }
 }
 
@@ -959,8 +981,15 @@ __device__ __forceinline__ void step_ln_row(__amdgpu_buffer_rsrc_t xin, int src_
 // landing zones [8 waves][2][12][64].
 // AUX: cache policy of the q / K / V loads -- 16 (sc1: the XCD's L2) for the streaming sampler, 17 (sc0 sc1: system scope)
 // for the offline segment sampler, whose first chunks read the neighbour XCD's last frames.
-template <int AUX>
-__device__ __forceinline__ void step_attention(const StepArgs& a, const StepLayer& L, const StepKV& kv, const StepLnOps& ops, int rg,
+struct StepAttn {  // (by value: the offline kernel calls the attention out of line -- nothing of the kernel's argument block may
+                   //  have its address taken, or every access to it goes through scratch memory and flat loads)
+    int T, cs, W, cache, nkmax;
+    const float *rope_cos, *rope_sin;
+    const float* qkv;  // this layer's rows
+};
+
+template <int AUX, bool PLANES = false>  // hout: fp32 tiles, or -- PLANES -- bf16 x 3 planes (p32_store4)
+__device__ __forceinline__ void step_attention(const StepAttn& a, const StepKV& kv, const StepLnOps& ops, int rg,
                                                int lr0, int bx, float* smem, float* kvlds, __amdgpu_buffer_rsrc_t qkvr,
                                                __amdgpu_buffer_rsrc_t xr, float* __restrict__ xres, float* __restrict__ hout) {
     constexpr int NKMAX = kAttnKeyBlock, E = kSE, H = kSH, KBt = E / 16, ld = E + 4;
@@ -1007,7 +1036,7 @@ __device__ __forceinline__ void step_attention(const StepArgs& a, const StepLaye
 #pragma unroll
             for (int u = 0; u < NKMAX / 4; ++u) {
                 const int pos = lo_c + min(kb + 4 * u + grp, nk - 1);
-                const float* ksrc = L.qkv + ((size_t)rowbase + (pos - nc)) * 3 * E + E + hw * 64 + d4;
+                const float* ksrc = a.qkv + ((size_t)rowbase + (pos - nc)) * 3 * E + E + hw * 64 + d4;
                 const float* vsrc = ksrc + E;
                 if (pos < nc) {
                     ksrc = kv.kold + ((size_t)rg * nc + pos) * E + hw * 64 + d4;
@@ -1109,7 +1138,8 @@ __device__ __forceinline__ void step_attention(const StepArgs& a, const StepLaye
             y.y = (v[i].y - mean) * rstd * ww[i].y + bb[i].y;
             y.z = (v[i].z - mean) * rstd * ww[i].z + bb[i].z;
             y.w = (v[i].w - mean) * rstd * ww[i].w + bb[i].w;
-            *reinterpret_cast<float4*>(hout + off) = y;
+            if constexpr (PLANES) p32_store4(reinterpret_cast<unsigned short*>(hout), lr0 + i0 + qi, 4 * lane + 256 * i, E / 32, y.x, y.y, y.z, y.w);
+            else *reinterpret_cast<float4*>(hout + off) = y;
         }
     }
 }
@@ -1298,7 +1328,8 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
                     const int q = it / nchunks, bx = it - q * nchunks, br = q / nclip, cl = q - br * nclip;
                     __syncthreads();  // (a second item of this workgroup reuses the LDS rows)
                     if (it != rank) attn_prefetch(l, it);
-                    step_attention<16>(a, Lw, kv, lnops, br * B + c0 + cl, br * ct + cl * T, bx, smem, kvl, qkv_r, xres_r, xres, hb);
+                    step_attention<16>(StepAttn{a.T, a.cs, a.W, a.cache, a.nkmax, a.rope_cos, a.rope_sin, Lw.qkv}, kv, lnops,
+                                       br * B + c0 + cl, br * ct + cl * T, bx, smem, kvl, qkv_r, xres_r, xres, hb);
                 }
                 const int nroll = nitems < (int)n ? (int)n - nitems : (int)n, rb = nitems < (int)n ? rank - nitems : rank;
                 if (rb >= 0) {
@@ -1418,47 +1449,58 @@ __device__ __forceinline__ void seg_split8(const f32x4& a, const f32x4& b, u32x4
     p[2] = u32x4{l0.x, l0.y, l1.x, l1.y};
 }
 
-// acc[j * MB + i] += (this wave's K slice: 32-deep k-blocks kb0 .. kb0 + KB) of rows 16 i .. of A x column tile tile0 + 32 j
-// of W, both fp32 in 16 x 16 tiles (k-blocks of 16: `a_kblocks` / `w_kblocks` per row block / tile)
-template <int MB, int NT, int KB>
-__device__ __forceinline__ void seg_gemm(f32x4 (&acc)[NT * MB], __amdgpu_buffer_rsrc_t A, int a_kblocks,
-                                         const float* __restrict__ wt, int w_kblocks, int tile0, int kb0, int lane, bool wact) {
+// acc[j * RB + i] += (this wave's K slice: 32-deep k-blocks kb0 .. kb0 + KB) of row blocks rb0 .. rb0 + RB of A x column tiles
+// tile0 + ts j of W.  A: bf16 x 3 planes written by the producing phase (p32_store4; `a_kb32` k-blocks per row block, sc1
+// loads), W: fp32 16 x 16 tiles, split into its planes in registers (a weight fragment serves all RB row blocks).  Software
+// pipeline over the k-blocks: the operands of k-block u + 1 are requested before the MFMAs of u (loads return in issue
+// order); seg_load(.., 0) of the first k-block is the caller's, so that it can be in flight behind other work.
+template <int RB, int NT>
+struct SegBuf {
+    f32x4 wr[2][NT][2];   // raw fp32 weight fragments of a 32-deep k-block, double-buffered
+    u32x4 ap[2][RB][3];   // activation planes
+};
+
+template <int RB, int NT>
+__device__ __forceinline__ void seg_load(SegBuf<RB, NT>& sb, int slot, __amdgpu_buffer_rsrc_t A3, int a_kb32, int rb0,
+                                         const float* __restrict__ wt, int w_kblocks, int tile0, int ts, int kb, int lane, bool wact) {
+    typedef const __attribute__((address_space(1))) f32x4* gptr;
 #pragma unroll
-    for (int p = 0; p < NT * MB; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int RH = MB > 3 ? 3 : MB;  // row blocks per pass (register budget)
+    for (int i = 0; i < RB; ++i)
 #pragma unroll
-    for (int u = 0; u < KB; ++u) {
-        const int kb = 2 * (kb0 + u);
-        u32x4 wp[NT][3];
+        for (int p = 0; p < 3; ++p)
+            sb.ap[slot][i][p] = __builtin_amdgcn_raw_buffer_load_b128(A3, lane * 16, (unsigned)((((rb0 + i) * a_kb32 + kb) * 3 + p) << 10), 16);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const float* q = wt + ((size_t)((tile0 + 32 * j) * w_kblocks + kb) << 8) + lane * 4;
-            const f32x4 w0 = wact ? *reinterpret_cast<const f32x4*>(q) : f32x4{0.f, 0.f, 0.f, 0.f};
-            const f32x4 w1 = wact ? *reinterpret_cast<const f32x4*>(q + 256) : f32x4{0.f, 0.f, 0.f, 0.f};
-            seg_split8(w0, w1, wp[j]);
-        }
-#pragma unroll
-        for (int i0 = 0; i0 < MB; i0 += RH) {
-            u32x4 ap[RH][3];
-#pragma unroll
-            for (int i = 0; i < RH; ++i) {
-                const unsigned off = (unsigned)((((i0 + i) * a_kblocks + kb) << 8) + lane * 4);
-                seg_split8(ld_l2(A, off), ld_l2(A, off + 256), ap[i]);
-            }
-#pragma unroll
-            for (int p = 0; p < 6; ++p)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int i = 0; i < RH; ++i)  // W fragment as srcA: the accumulator holds C^T
-                        acc[j * MB + i0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(sbf16x8, wp[j][kSegWP[p]]), __builtin_bit_cast(sbf16x8, ap[i][kSegAP[p]]),
-                            acc[j * MB + i0 + i], 0, 0, 0);
-        }
+    for (int j = 0; j < NT; ++j) {
+        const float* q = wt + ((size_t)((tile0 + ts * j) * w_kblocks + 2 * kb) << 8) + lane * 4;
+        sb.wr[slot][j][0] = wact ? *(gptr)(q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        sb.wr[slot][j][1] = wact ? *(gptr)(q + 256) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
-// the eight waves' partials of ONE column tile (MB row blocks) -> LDS -> wave w returns the sum of row block w (wave order)
+template <int RB, int NT, int KB>
+__device__ __forceinline__ void seg_run(f32x4 (&acc)[NT * RB], SegBuf<RB, NT>& sb, __amdgpu_buffer_rsrc_t A3, int a_kb32, int rb0,
+                                        const float* __restrict__ wt, int w_kblocks, int tile0, int ts, int kb0, int lane, bool wact) {
+#pragma unroll
+    for (int p = 0; p < NT * RB; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+        if (u + 1 < KB) seg_load<RB, NT>(sb, (u + 1) & 1, A3, a_kb32, rb0, wt, w_kblocks, tile0, ts, kb0 + u + 1, lane, wact);
+        u32x4 wp[NT][3];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) seg_split8(sb.wr[u & 1][j][0], sb.wr[u & 1][j][1], wp[j]);
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int i = 0; i < RB; ++i)  // W fragment as srcA: the accumulator holds C^T
+                    acc[j * RB + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(sbf16x8, wp[j][kSegWP[p]]), __builtin_bit_cast(sbf16x8, sb.ap[u & 1][i][kSegAP[p]]),
+                        acc[j * RB + i], 0, 0, 0);
+    }
+}
+
+// the eight waves' partials of ONE column tile (RB row blocks) -> LDS -> wave w returns the sum of row block w (wave order)
 template <int MB, int P>
 __device__ __forceinline__ f32x4 seg_reduce(const f32x4 (&acc)[P], int j, float* red, int w, int lane) {
     __syncthreads();  // the previous readers are done with `red`
@@ -1474,6 +1516,23 @@ __device__ __forceinline__ f32x4 seg_reduce(const f32x4 (&acc)[P], int j, float*
     return o;
 }
 
+// all P partial tiles of the eight waves -> LDS [wave][P][256] in ONE exchange; seg_sum(p) then adds tile p in wave order
+template <int P>
+__device__ __forceinline__ void seg_partials(const f32x4 (&acc)[P], float* red, int w, int lane) {
+    __syncthreads();  // the previous readers are done with `red`
+#pragma unroll
+    for (int p = 0; p < P; ++p) *reinterpret_cast<f32x4*>(red + (((w * P + p) << 6) + lane) * 4) = acc[p];
+    __syncthreads();
+}
+
+template <int NQ>  // partials to add (consecutive waves)
+__device__ __forceinline__ f32x4 seg_sum(const float* red, int P, int p, int lane) {
+    f32x4 o = *reinterpret_cast<const f32x4*>(red + ((p << 6) + lane) * 4);
+#pragma unroll
+    for (int q = 1; q < NQ; ++q) o += *reinterpret_cast<const f32x4*>(red + ((((q * P + p)) << 6) + lane) * 4);
+    return o;
+}
+
 __device__ __forceinline__ bool seg_spin_sys(const unsigned* word, unsigned want, unsigned* fail) {
     const __amdgpu_buffer_rsrc_t r = step_rsrc(word);
     for (unsigned spins = 0;; ++spins) {
@@ -1486,11 +1545,14 @@ __device__ __forceinline__ bool seg_spin_sys(const unsigned* word, unsigned want
     }
 }
 
-// (out of line: with the attention body inlined next to the split-MFMA GEMMs, clang 22's InstCombine crashes on this kernel)
-__device__ __attribute__((noinline)) void seg_attention(const StepArgs& a, const StepLayer& L, const StepLnOps& ops, int rg, int lr0,
-                                                        int bx, float* smem, float* kvlds, float* xres, float* hout) {
+// (out of line: with the attention body inlined next to the split-MFMA GEMMs, clang 22's InstCombine crashes on this kernel;
+//  every argument by value -- see StepAttn)
+__device__ __attribute__((noinline)) void seg_attention(StepAttn g, StepLnOps ops, int rg, int lr0, int bx, bool halo, float* smem,
+                                                        float* kvlds, float* xres, float* hout) {
     const StepKV nokv{nullptr, nullptr, nullptr, nullptr};
-    step_attention<17>(a, L, nokv, ops, rg, lr0, bx, smem, kvlds, step_rsrc(L.qkv), step_rsrc(xres), xres, hout);
+    // system-scope q / K / V loads only where keys of the previous XCD are involved; the other chunks read this XCD's L2
+    if (halo) step_attention<17, true>(g, nokv, ops, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout);
+    else step_attention<16, true>(g, nokv, ops, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout);
 }
 
 template <int MB>  // row blocks per XCD: 3 Tseg / 16 (6 at T = 256)
@@ -1523,11 +1585,12 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
     const int T = a.T, Tseg = a.Tseg, f0 = g * Tseg, Mg = 3 * Tseg;
     float* const pat = a.pat_t + (size_t)g * kSGroupRows * E;
     float* const xres = a.xres_t + (size_t)g * kSGroupRows * E;
-    float* const hb = a.h_t + (size_t)g * kSGroupRows * E;
-    float* const mlp = a.mlp_t + (size_t)g * kSGroupRows * ME;
-    const __amdgpu_buffer_rsrc_t pat_r = step_rsrc(pat), xres_r = step_rsrc(xres), hb_r = step_rsrc(hb), mlp_r = step_rsrc(mlp);
+    const __amdgpu_buffer_rsrc_t pat_r = step_rsrc(pat), xres_r = step_rsrc(xres);
+    unsigned short* const hb3 = a.h3_t + (size_t)g * kSGroupRows * E * 3;
+    unsigned short* const mlp3 = a.mlp3_t + (size_t)g * kSGroupRows * ME * 3;
+    const __amdgpu_buffer_rsrc_t hb3_r = step_rsrc(hb3), mlp3_r = step_rsrc(mlp3);
     const __amdgpu_buffer_rsrc_t xt_r = step_rsrc(a.xt), xout_r = step_rsrc(a.xout);
-    float* const red = smem;                      // partial tiles [8 waves][MB][256] (one column tile at a time) | attention rows
+    float* const red = smem;                      // partial tiles [8 waves][3][256] (one column tile at a time) | attention rows
     float* const kvl = smem + kSRedFloats(2);     // attention: K / V landing zones [8 waves][2][12][64]
     const bool wact = !(a.dbg & 2);
     auto end_phase = [&](bool drain) { return step_barrier(st, xcc, n, ++round, trace, ++tslot, drain, &s_ok); };
@@ -1581,32 +1644,37 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
             const StepLayer& Lw = a.layer[l];
             const __amdgpu_buffer_rsrc_t qkv_r = step_rsrc(Lw.qkv);
             const unsigned seq = (unsigned)(i * a.L + l + 1);
-            // ---- norm0 -> AdaLN(tcond) -> norm1: one wave per token row (three per workgroup)
+            // ---- norm0 -> AdaLN(tcond) -> norm1: one wave per token row (three per workgroup); h as bf16 x 3 planes
             if (ln_mine) {
                 const int br = ln_lm / Tseg, tl = ln_lm - br * Tseg;
-                step_ln_row(l == 0 ? pat_r : xres_r, l == 0 ? tl : ln_lm, xres, hb, ln_lm, lnops, lane);
+                step_ln_row<true>(l == 0 ? pat_r : xres_r, l == 0 ? tl : ln_lm, xres, reinterpret_cast<float*>(hb3), ln_lm, lnops, lane);
             }
             // (idle wave 7 of workgroup 0: the next XCD has read this layer's keys of the PREVIOUS step -- its last
             //  frames may be overwritten.  A whole step behind: satisfied long ago, one memory round trip off the path)
             if (rank == 0 && w == 7 && lane == 0 && g < 7 && i > 0) seg_spin_sys(&st->att_seq[g + 1][0], seq - a.L, &st->fail[0]);
             if (!end_phase(ln_mine)) return;
-            // ---- qkv: column tiles rank, rank + 32, rank + 64 (bf16 x 3 split MFMAs); rows written through to memory
+            // ---- qkv: column tiles rank, rank + 32, rank + 64 (bf16 x 3 split MFMAs), three row blocks at a time; the
+            //      rows are written through to memory (the next XCD's attention reads the last W - 1 frames)
             {
-                f32x4 acc[3 * MB];
-                seg_gemm<MB, 3, KBE / 16>(acc, hb_r, KBE, Lw.qkv_wt, KBE, rank, (KBE / 16) * w, lane, wact);
+                // waves = (row half, K slice): with 96 rows both halves run side by side, each wave four k-blocks deep
+                constexpr int NH = MB / 3, KS = 8 / NH, KQ = KBE / 2 / KS;  // row halves, K slices, 32-deep k-blocks per wave
+                const int rh = w / KS, ks = w - rh * KS;
+                SegBuf<3, 3> sb;
+                f32x4 acc[9];
+                seg_load<3, 3>(sb, 0, hb3_r, E / 32, 3 * rh, Lw.qkv_wt, KBE, rank, 32, KQ * ks, lane, wact);
+                seg_run<3, 3, KQ>(acc, sb, hb3_r, E / 32, 3 * rh, Lw.qkv_wt, KBE, rank, 32, KQ * ks, lane, wact);
                 if (rank < nitems) attn_prefetch(l, rank);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const f32x4 o = seg_reduce<MB>(acc, j, red, w, lane);
-                    if (w < MB) {
-                        const int lm = 16 * w + (lane & 15), br = lm / Tseg, tl = lm - br * Tseg;
-                        if (lm < Mg)
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), qkv_r,
-                                                                   (unsigned)(((br * T + f0 + tl) * 3 * E + 16 * (rank + 32 * j) + 4 * (lane >> 4)) * 4), 0, 17);
-                    }
+                seg_partials<9>(acc, red, w, lane);
+                for (int p = w; p < 9 * NH; p += 8) {
+                    const int hh = p / 9, pp = p - 9 * hh, j = pp / 3, ib = pp - 3 * j;
+                    const f32x4 o = seg_sum<KS>(red + (size_t)hh * KS * 9 * 256, 9, pp, lane);
+                    const int lm = 16 * (3 * hh + ib) + (lane & 15), br = lm / Tseg, tl = lm - br * Tseg;
+                    if (lm < Mg)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), qkv_r,
+                                                               (unsigned)(((br * T + f0 + tl) * 3 * E + 16 * (rank + 32 * j) + 4 * (lane >> 4)) * 4), 0, 17);
                 }
             }
-            if (!end_phase(w < MB)) return;
+            if (!end_phase(true)) return;
             if (rank == 0 && tid == 0) __builtin_amdgcn_raw_buffer_store_b32(seq, step_rsrc(&st->qkv_seq[g][0]), 0, 0, 17);
             // ---- attention + residual + AdaLN(cond) + norm3: one workgroup per chunk of a CFG row; a chunk whose window
             //      starts in front of the segment waits for the previous XCD's rows
@@ -1614,65 +1682,90 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 const int br = it / cps, ch = it - br * cps, i0f = f0 + ch * a.cs;
                 __syncthreads();  // (a second item of this workgroup reuses the LDS rows)
                 if (it != rank) attn_prefetch(l, it);
-                if (g > 0 && i0f - (a.W - 1) < f0) {
+                const bool halo = g > 0 && i0f - (a.W - 1) < f0;
+                if (halo) {
                     if (tid == 0) s_ok = seg_spin_sys(&st->qkv_seq[g - 1][0], seq, &st->fail[0]);
                     __syncthreads();
                     if (!s_ok) return;
                 }
-                seg_attention(a, Lw, lnops, br, br * Tseg - f0, i0f / a.cs, smem, kvl, xres, hb);
+                seg_attention(StepAttn{T, a.cs, a.W, 0, a.nkmax, a.rope_cos, a.rope_sin, Lw.qkv}, lnops, br, br * Tseg - f0, i0f / a.cs,
+                              halo, smem, kvl, xres, reinterpret_cast<float*>(hb3));
+            }
+            if (rank >= nitems && wact) {  // workgroups without a chunk: warm the MLP weights into this XCD's L2 (step_warm)
+                const size_t wbytes = (size_t)E * ME * sizeof(float);
+                const int wi = (rank - nitems) * 8 + w, nw = ((int)n - nitems) * 8;
+                unsigned sink = 0;
+                step_warm(sink, Lw.mlp0_wt, wbytes * a.warm[1] / 16, wi, nw, lane);
+                step_warm(sink, Lw.mlp2_wt, wbytes * a.warm[2] / 16, wi, nw, lane);
+                step_warm_done(sink);
             }
             if (!end_phase(true)) return;
             if (rank == 0 && tid == 0) __builtin_amdgcn_raw_buffer_store_b32(seq, step_rsrc(&st->att_seq[g][0]), 0, 0, 17);
-            // ---- MLP up + GELU: column tiles rank + 32 j
+            // ---- MLP up + GELU: column tiles rank + 32 j; the hidden layer as bf16 x 3 planes
             {
-                f32x4 acc[kSNTU * MB];
-                seg_gemm<MB, kSNTU, KBE / 16>(acc, hb_r, KBE, Lw.mlp0_wt, KBE, rank, (KBE / 16) * w, lane, wact);
-#pragma unroll
-                for (int j = 0; j < kSNTU; ++j) {
-                    const int tile = rank + 32 * j;
+                constexpr int NH = MB / 3, KS = 8 / NH, KQ = KBE / 2 / KS;
+                const int rh = w / KS, ks = w - rh * KS;
+                SegBuf<3, kSNTU> sb;
+                f32x4 acc[3 * kSNTU];
+                seg_load<3, kSNTU>(sb, 0, hb3_r, E / 32, 3 * rh, Lw.mlp0_wt, KBE, rank, 32, KQ * ks, lane, wact);
+                seg_run<3, kSNTU, KQ>(acc, sb, hb3_r, E / 32, 3 * rh, Lw.mlp0_wt, KBE, rank, 32, KQ * ks, lane, wact);
+                seg_partials<3 * kSNTU>(acc, red, w, lane);
+                for (int p = w; p < 3 * kSNTU * NH; p += 8) {
+                    const int hh = p / (3 * kSNTU), pp = p - 3 * kSNTU * hh, j = pp / 3, ib = pp - 3 * j, tile = rank + 32 * j;
                     const f32x4 bv = *reinterpret_cast<const f32x4*>(Lw.mlp0_b + 16 * tile + 4 * (lane >> 4));
-                    f32x4 o = seg_reduce<MB>(acc, j, red, w, lane);
-                    if (w < MB) {
+                    const f32x4 o = seg_sum<KS>(red + (size_t)hh * KS * 3 * kSNTU * 256, 3 * kSNTU, pp, lane);
+                    p32_store4(mlp3, 16 * (3 * hh + ib) + (lane & 15), 16 * tile + 4 * (lane >> 4), ME / 32, gelu_erf(o[0] + bv[0]),
+                               gelu_erf(o[1] + bv[1]), gelu_erf(o[2] + bv[2]), gelu_erf(o[3] + bv[3]));
+                }
+            }
+            if (!end_phase(true)) return;
+            // ---- MLP down + residual.  96 rows: 2-D -- workgroup (row half, column-tile pair): half the activation bytes
+            //      per workgroup of the all-rows x one-tile split; 48 rows: column tile rank, all rows
+            {
+                constexpr int NTD = MB == 6 ? 2 : 1;
+                const int rb0 = MB == 6 ? 3 * (rank & 1) : 0, tile0 = MB == 6 ? 2 * (rank >> 1) : rank;
+                f32x4 acc[3 * NTD], bv[NTD], rv[NTD];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r] + bv[r]);
-                        *reinterpret_cast<f32x4*>(mlp + ((size_t)(w * KBM + tile) << 8) + lane * 4) = o;
+                for (int j = 0; j < NTD; ++j) {
+                    bv[j] = rv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (w < 3) {
+                        bv[j] = *reinterpret_cast<const f32x4*>(Lw.mlp2_b + 16 * (tile0 + j) + 4 * (lane >> 4));
+                        rv[j] = ld_l2(xres_r, (unsigned)((((rb0 + w) * KBE + tile0 + j) << 8) + lane * 4));
+                    }
+                }
+                {
+                    SegBuf<3, NTD> sb;
+                    seg_load<3, NTD>(sb, 0, mlp3_r, ME / 32, rb0, Lw.mlp2_wt, KBM, tile0, 1, (KBM / 16) * w, lane, wact);
+                    seg_run<3, NTD, KBM / 16>(acc, sb, mlp3_r, ME / 32, rb0, Lw.mlp2_wt, KBM, tile0, 1, (KBM / 16) * w, lane, wact);
+                }
+                if (l + 1 < a.L) ln_prefetch(l + 1);
+#pragma unroll
+                for (int j = 0; j < NTD; ++j) {
+                    f32x4 o = seg_reduce<3>(acc, j, red, w, lane);
+                    if (w < 3) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = o[r] + bv[j][r] + rv[j][r];
+                        *reinterpret_cast<f32x4*>(xres + ((size_t)((rb0 + w) * KBE + tile0 + j) << 8) + lane * 4) = o;
                     }
                 }
             }
-            if (!end_phase(w < MB)) return;
-            // ---- MLP down + residual: column tile rank
-            {
-                f32x4 acc[MB];
-                const unsigned off = (unsigned)(((w * KBE + rank) << 8) + lane * 4);  // wave w finishes row block w
-                f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f}, rv = bv;
-                if (w < MB) {
-                    bv = *reinterpret_cast<const f32x4*>(Lw.mlp2_b + 16 * rank + 4 * (lane >> 4));
-                    rv = ld_l2(xres_r, off);
-                }
-                seg_gemm<MB, 1, KBM / 16>(acc, mlp_r, KBM, Lw.mlp2_wt, KBM, rank, (KBM / 16) * w, lane, wact);
-                if (l + 1 < a.L) ln_prefetch(l + 1);
-                f32x4 o = seg_reduce<MB>(acc, 0, red, w, lane);
-                if (w < MB) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = o[r] + bv[r] + rv[r];
-                    *reinterpret_cast<f32x4*>(xres + off) = o;
-                }
-            }
-            if (!end_phase(w < MB)) return;
+            if (!end_phase(w < 3)) return;
         }
-        // ---- out_proj + CFG + Euler (+ the token-major latents of the next step): column tile rank < C / 16, fp32 MFMA
-        if (rank < a.C / 16) {
-            f32x4 acc[MB];
-            step_gemm<MB, 1, kSKBQ, false>(acc, xres_r, KBE, a.out_wt, KBE, rank, kSKBQ * w, lane, true, wact, [] {});
-            const f32x4 o = seg_reduce<MB>(acc, 0, red, w, lane);
-            float* const outt = red + 8 * MB * 256;  // [MB * 16 rows][16 columns]
-            if (w < MB) *reinterpret_cast<f32x4*>(outt + (16 * w + (lane & 15)) * 16 + 4 * (lane >> 4)) = o;
+        // ---- out_proj + CFG + Euler (+ the token-major latents of the next step), fp32 MFMA: workgroup (column tile,
+        //      16-frame block) owns the three CFG rows of its frames
+        if (rank < (a.C / 16) * MBP) {
+            const int tile = rank % (a.C / 16), fb = rank / (a.C / 16);
+            f32x4 acc[3];
+            step_gemm<3, 1, kSKBQ, false>(acc, xres_r, KBE, a.out_wt, KBE, tile, kSKBQ * w, lane, true, wact, [] {}, 0, fb, MBP);
+            const f32x4 o = seg_reduce<3>(acc, 0, red, w, lane);
+            float* const outt = red + 8 * 3 * 256;  // [3 branches x 16 frames][16 columns]
+            if (w < 3) *reinterpret_cast<f32x4*>(outt + (16 * w + (lane & 15)) * 16 + 4 * (lane >> 4)) = o;
             __syncthreads();
-            for (int e = tid; e < Tseg * 16; e += 512) {  // model.py:749-759, 777-783
-                const int tl = e >> 4, col = e & 15, nn = 16 * rank + col;
+            if (tid < 256 && 16 * fb + (tid >> 4) < Tseg) {  // model.py:749-759, 777-783
+                const int tq = tid >> 4, col = tid & 15, nn = 16 * tile + col, tl = 16 * fb + tq;
                 const float bo = a.out_b ? a.out_b[nn] : 0.f;
-                const float dfull = outt[tl * 16 + col] + bo, dmid = outt[(Tseg + tl) * 16 + col] + bo,
-                            dnone = outt[(2 * Tseg + tl) * 16 + col] + bo;
+                const float dfull = outt[tq * 16 + col] + bo, dmid = outt[(16 + tq) * 16 + col] + bo,
+                            dnone = outt[(32 + tq) * 16 + col] + bo;
                 const float total = a.cfg[0], factor = a.cfg[1], dt = a.cfg[2];
                 const float v = dnone + total * (dmid + factor * (dfull - dmid) - dnone);
                 const size_t o1 = (size_t)nn * T + f0 + tl;
@@ -1770,6 +1863,7 @@ struct after_denoiser {
     int persist_step = 1, n_cus = 0;
     int persist_offline = 0;  // AFTER_SAMPLE_PERSIST / after_denoiser_set_sample_persist: one clip's offline sampler as sample_seg_kernel
     float* seg_qkv = nullptr;  // [L][3 max_T][3E]: per-layer qkv rows of the segment sampler
+    unsigned short* seg_act3 = nullptr;  // bf16 x 3 planes of h and of the MLP hidden layer, one slice per XCD
     bool last_seg = false;     // the last after_sample ran as sample_seg_kernel
     int step_dbg = 0;  // after_denoiser_set_stream_persist(h, 1 | dbg << 8): diagnostics bits OR-ed into AFTER_STEP_DBG
     StepSync* step_sync = nullptr;       // [max_steps]: one barrier state per step of a sample() call
@@ -2335,6 +2429,7 @@ extern "C" void after_denoiser_destroy(after_denoiser* h) {
     if (h->step_wt) (void)hipFree(h->step_wt);
     if (h->step_act) (void)hipFree(h->step_act);
     if (h->seg_qkv) (void)hipFree(h->seg_qkv);
+    if (h->seg_act3) (void)hipFree(h->seg_act3);
     h->wa.release();
     h->ws.release();
     h->ca.release();
@@ -2584,6 +2679,11 @@ int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, in
     AFTER_TRY(step_check_failure(h));
     AFTER_TRY(step_alloc(h, s));
     if (!h->seg_qkv) AFTER_HIP_CHECK(hipMalloc(&h->seg_qkv, (size_t)L * 3 * h->max_T * 3 * E * sizeof(float)));
+    if (!h->seg_act3) {
+        const size_t n3 = (size_t)8 * kSGroupRows * 3 * (E + h->ME);
+        AFTER_HIP_CHECK(hipMalloc(&h->seg_act3, n3 * sizeof(unsigned short)));
+        AFTER_HIP_CHECK(hipMemsetAsync(h->seg_act3, 0, n3 * sizeof(unsigned short), s));
+    }
     const int nkmax = h->W - 1 + h->cs > h->cs ? h->W - 1 + h->cs : h->cs;
     const size_t lds = ((size_t)kSRedFloats(2) + 8 * 2 * kAttnKeyBlock * 64) * sizeof(float);
     static size_t attr[2] = {0, 0};
@@ -2607,6 +2707,7 @@ int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, in
     a.nsteps = nb_steps, a.cache_steps = 0;
     a.xt = h->xt;
     a.pat_t = h->step_act, a.xres_t = h->step_act + slice, a.h_t = h->step_act + 2 * slice, a.mlp_t = h->step_act + 3 * slice;
+    a.h3_t = h->seg_act3, a.mlp3_t = h->seg_act3 + (size_t)8 * kSGroupRows * 3 * E;
     a.patch_wt = h->step_patch_wt, a.patch_b = h->patch_b, a.out_wt = h->step_out_wt, a.out_b = h->out_b;
     a.tc_ab = h->tc_ab, a.tc_ld = L * 2 * E, a.tcmap = h->maps + h->ms;
     a.cond_ab = h->cond_ab, a.cond_step = (size_t)3 * L * 2 * E, a.cond_ld = L * 2 * E;
@@ -2622,6 +2723,13 @@ int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, in
             dbg = e ? atoi(e) : 0;
         }
         a.dbg = dbg | h->step_dbg;
+        static int warm[3] = {-1, 0, 0};
+        if (warm[0] < 0) {
+            warm[0] = 0, warm[1] = 0, warm[2] = 0;  // (measured: warming during the attention phase does not pay here)
+            const char* e = getenv("AFTER_SEG_WARM");
+            if (e) sscanf(e, "%d,%d,%d", &warm[0], &warm[1], &warm[2]);
+        }
+        a.warm[0] = warm[0], a.warm[1] = warm[1], a.warm[2] = warm[2];
     }
     for (int l = 0; l < L; ++l) {
         const LayerW& w = h->layers[l];

@@ -18,17 +18,29 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--streams", type=int, default=8)
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--xcd", type=int, default=0)
+ap.add_argument("--offline", action="store_true", help="the persistent OFFLINE sampler (one clip, base, 50 steps) instead")
 args = ap.parse_args()
 torch.set_grad_enabled(False)
 dev = torch.device("cuda:0")
-model, dcfg, acfg = pipeline.build_models("cycle", "baseAE_causal", dev, seed=7)
-st = Streamer(model, model.emb_model, chunk_size=4, n_signal_timbre=128, max_batch=args.streams, max_nb_steps=args.steps,
+if args.offline:
+    os.environ.setdefault("AFTER_SAMPLE_PERSIST", "1")
+    model, dcfg, acfg = pipeline.build_models("base", "baseAE", dev, seed=7)
+    x0, cond, tc = torch.randn(1, 64, 256, device=dev), torch.randn(1, 6, device=dev), torch.randn(1, 12, 256, device=dev)
+    model.net.set_sample_persist(True)
+    for _ in range(3):
+        model.net.cfg_sample(x0, cond, tc, 50, 2.0, 1.0, -4.0)
+    torch.cuda.synchronize()
+    assert model.net.sample_persist()
+else:
+    model, dcfg, acfg = pipeline.build_models("cycle", "baseAE_causal", dev, seed=7)
+if not args.offline:
+  st = Streamer(model, model.emb_model, chunk_size=4, n_signal_timbre=128, max_batch=args.streams, max_nb_steps=args.steps,
               share_first_stream=False)
-st.set_nb_steps(args.steps)
-x = 0.1 * torch.randn(args.streams, 2, 4 * st.ae_ratio, device=dev)
-for _ in range(3):
+  st.set_nb_steps(args.steps)
+  x = 0.1 * torch.randn(args.streams, 2, 4 * st.ae_ratio, device=dev)
+  for _ in range(3):
     st(x)
-torch.cuda.synchronize()
+  torch.cuda.synchronize()
 h = model.net._handle
 n = torch.cuda.get_device_properties(0).multi_processor_count
 buf = np.zeros((n, 128), dtype=np.uint64)
