@@ -1477,14 +1477,19 @@ __device__ __forceinline__ void seg_load(SegBuf<RB, NT>& sb, int slot, __amdgpu_
     }
 }
 
-template <int RB, int NT, int KB>
+// `after_loads()` runs once the last k-block's operands are requested: the place for the NEXT phase's operand prefetch (issued
+// any earlier it would sit in front of this phase's operands in the in-order load queue; any later -- after the MFMAs -- the
+// workgroup barrier of the partial-tile exchange waits a full fabric round trip for it)
+template <int RB, int NT, int KB, class F>
 __device__ __forceinline__ void seg_run(f32x4 (&acc)[NT * RB], SegBuf<RB, NT>& sb, __amdgpu_buffer_rsrc_t A3, int a_kb32, int rb0,
-                                        const float* __restrict__ wt, int w_kblocks, int tile0, int ts, int kb0, int lane, bool wact) {
+                                        const float* __restrict__ wt, int w_kblocks, int tile0, int ts, int kb0, int lane, bool wact,
+                                        F&& after_loads) {
 #pragma unroll
     for (int p = 0; p < NT * RB; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < KB; ++u) {
         if (u + 1 < KB) seg_load<RB, NT>(sb, (u + 1) & 1, A3, a_kb32, rb0, wt, w_kblocks, tile0, ts, kb0 + u + 1, lane, wact);
+        if (u + 2 == KB || KB == 1) after_loads();
         u32x4 wp[NT][3];
 #pragma unroll
         for (int j = 0; j < NT; ++j) seg_split8(sb.wr[u & 1][j][0], sb.wr[u & 1][j][1], wp[j]);
@@ -1610,7 +1615,10 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
             step_ln_ops(lnops, cond_ab + (size_t)(it / cps) * a.cond_ld + (size_t)l * 2 * E, a.layer[l].n3w, a.layer[l].n3b, lane);
         };
         tslot = 0;
-        if (trace && tid == 0) trace[0] = wall_clock64();
+        if (trace && tid == 0) {
+            trace[0] = wall_clock64();
+            trace[70] = __builtin_readcyclecounter();  // shader clock (s_memtime): effective clock = cycles / wall time
+        }
         // ---- patchify_and_embed for the segment's Tseg frames (shared by the three CFG rows): fp32 MFMA, K = Cp
         {
             const int kbp = a.Cp / 16;
@@ -1661,10 +1669,22 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 const int rh = w / KS, ks = w - rh * KS;
                 SegBuf<3, 3> sb;
                 f32x4 acc[9];
+                if (trace && tid == 0) trace[64] = wall_clock64();
+                __builtin_amdgcn_sched_barrier(0);
                 seg_load<3, 3>(sb, 0, hb3_r, E / 32, 3 * rh, Lw.qkv_wt, KBE, rank, 32, KQ * ks, lane, wact);
-                seg_run<3, 3, KQ>(acc, sb, hb3_r, E / 32, 3 * rh, Lw.qkv_wt, KBE, rank, 32, KQ * ks, lane, wact);
-                if (rank < nitems) attn_prefetch(l, rank);
+                seg_run<3, 3, KQ>(acc, sb, hb3_r, E / 32, 3 * rh, Lw.qkv_wt, KBE, rank, 32, KQ * ks, lane, wact,
+                                  [&] { if (rank < nitems) attn_prefetch(l, rank); });
+                __builtin_amdgcn_sched_barrier(0);
+                if (trace) {  // (every wave drains its MFMAs first: the stamp is the end of wave 0's arithmetic)
+                    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[8]));
+                    if (tid == 0) trace[65] = wall_clock64();
+                    if (lane == 0) trace[72 + w] = wall_clock64();
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 seg_partials<9>(acc, red, w, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                if (trace && tid == 0) trace[66] = wall_clock64();
+                __builtin_amdgcn_sched_barrier(0);
                 for (int p = w; p < 9 * NH; p += 8) {
                     const int hh = p / 9, pp = p - 9 * hh, j = pp / 3, ib = pp - 3 * j;
                     const f32x4 o = seg_sum<KS>(red + (size_t)hh * KS * 9 * 256, 9, pp, lane);
@@ -1673,6 +1693,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), qkv_r,
                                                                (unsigned)(((br * T + f0 + tl) * 3 * E + 16 * (rank + 32 * j) + 4 * (lane >> 4)) * 4), 0, 17);
                 }
+                if (trace && tid == 0) trace[67] = wall_clock64();
             }
             if (!end_phase(true)) return;
             if (rank == 0 && tid == 0) __builtin_amdgcn_raw_buffer_store_b32(seq, step_rsrc(&st->qkv_seq[g][0]), 0, 0, 17);
@@ -1708,11 +1729,22 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 SegBuf<3, kSNTU> sb;
                 f32x4 acc[3 * kSNTU];
                 seg_load<3, kSNTU>(sb, 0, hb3_r, E / 32, 3 * rh, Lw.mlp0_wt, KBE, rank, 32, KQ * ks, lane, wact);
-                seg_run<3, kSNTU, KQ>(acc, sb, hb3_r, E / 32, 3 * rh, Lw.mlp0_wt, KBE, rank, 32, KQ * ks, lane, wact);
+                // (epilogue operands before the GEMM: wave w finishes tiles p = w, w + 8, w + 16)
+                f32x4 bvs[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int p = w + 8 * q, pp = p % (3 * kSNTU);
+                    bvs[q] = p < 3 * kSNTU * NH ? *reinterpret_cast<const f32x4*>(Lw.mlp0_b + 16 * (rank + 32 * (pp / 3)) + 4 * (lane >> 4))
+                                                : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                seg_run<3, kSNTU, KQ>(acc, sb, hb3_r, E / 32, 3 * rh, Lw.mlp0_wt, KBE, rank, 32, KQ * ks, lane, wact, [] {});
                 seg_partials<3 * kSNTU>(acc, red, w, lane);
-                for (int p = w; p < 3 * kSNTU * NH; p += 8) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int p = w + 8 * q;
+                    if (p >= 3 * kSNTU * NH) break;
                     const int hh = p / (3 * kSNTU), pp = p - 3 * kSNTU * hh, j = pp / 3, ib = pp - 3 * j, tile = rank + 32 * j;
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(Lw.mlp0_b + 16 * tile + 4 * (lane >> 4));
+                    const f32x4 bv = bvs[q];
                     const f32x4 o = seg_sum<KS>(red + (size_t)hh * KS * 3 * kSNTU * 256, 3 * kSNTU, pp, lane);
                     p32_store4(mlp3, 16 * (3 * hh + ib) + (lane & 15), 16 * tile + 4 * (lane >> 4), ME / 32, gelu_erf(o[0] + bv[0]),
                                gelu_erf(o[1] + bv[1]), gelu_erf(o[2] + bv[2]), gelu_erf(o[3] + bv[3]));
@@ -1736,9 +1768,9 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 {
                     SegBuf<3, NTD> sb;
                     seg_load<3, NTD>(sb, 0, mlp3_r, ME / 32, rb0, Lw.mlp2_wt, KBM, tile0, 1, (KBM / 16) * w, lane, wact);
-                    seg_run<3, NTD, KBM / 16>(acc, sb, mlp3_r, ME / 32, rb0, Lw.mlp2_wt, KBM, tile0, 1, (KBM / 16) * w, lane, wact);
+                    seg_run<3, NTD, KBM / 16>(acc, sb, mlp3_r, ME / 32, rb0, Lw.mlp2_wt, KBM, tile0, 1, (KBM / 16) * w, lane, wact,
+                                              [&] { if (l + 1 < a.L) ln_prefetch(l + 1); });
                 }
-                if (l + 1 < a.L) ln_prefetch(l + 1);
 #pragma unroll
                 for (int j = 0; j < NTD; ++j) {
                     f32x4 o = seg_reduce<3>(acc, j, red, w, lane);
@@ -1776,6 +1808,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 if (i + 1 < a.nsteps) a.xt[(size_t)(f0 + tl) * a.Cp + nn] = xn;
             }
         }
+        if (trace && tid == 0) trace[71] = __builtin_readcyclecounter();
         if (trace && tid == 0) {
             trace[2 * tslot + 1] = wall_clock64();
             trace[127] = xcc;

@@ -28,6 +28,8 @@ python scripts/time_codec.py --rounds 30 2>/dev/null | grep workload > $O/${R}_c
 python scripts/time_encoders.py 2>/dev/null | grep workload >> $O/${R}_codec.jsonl
 ./scripts/ubench/xcd_barrier.bin > $O/${R}_xcd_barrier.jsonl 2>/dev/null
 ./scripts/ubench/xcd_local.bin > $O/${R}_xcd_local.jsonl 2>/dev/null
+./scripts/ubench/xcd_halo.bin > $O/${R}_xcd_halo.jsonl 2>/dev/null
+python scripts/stream_step_trace.py --offline > $O/${R}_offline_step_trace.txt 2>/dev/null
 # the persistent streaming step: same-box A/B against the launch path, per-phase timeline, kernel stats of a chunk
 for p in 1 0 1 0; do
   AFTER_STREAM_PERSIST=$p python bench.py --stream --steps 24 --warmup 4 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'leg': 'stream 8x100 steps', 'AFTER_STREAM_PERSIST': $p, 'ms_per_chunk': d['ms_per_step'], 'xrt': d['value']}))" >> $O/${R}_ab_stream_persist.jsonl

@@ -70,3 +70,16 @@ print("step per XCD (us): " + ", ".join(f"{(t_all[xcc == x][:, 2 * len(names) - 
 print(f"XCD {args.xcd} step: {(t[:, 2 * len(names) - 1].max() - t0) / 100.0:.1f} us; phases (first start -> last arrival) {tot_work:.1f} us; "
       f"barriers (last arrival -> last exit) {tot_bar:.1f} us")
 
+
+if args.offline:  # effective shader clock over the step; inside the last layer's qkv phase (workgroup-local stamps of wave 0)
+    cyc = (buf[:, 71].astype(np.int64) - buf[:, 70].astype(np.int64))
+    wall = (t_all[:, 2 * len(names) - 1] - t_all[:, 0]) / 100.0
+    print("effective shader clock over the step: %.0f MHz (median over workgroups)" % np.median(cyc / wall))
+    ph = 2 + 5 * (L - 1)
+    gq = buf[:, 64:68].astype(np.int64)
+    rel = (gq - t_all[:, 2 * ph][:, None]) / 100.0
+    arr = (t_all[:, 2 * ph + 1] - t_all[:, 2 * ph]) / 100.0
+    print("qkv phase, median us after the barrier: start %.2f, MFMAs issued %.2f, partials exchanged %.2f, stores issued %.2f, "
+          "arrival %.2f" % tuple(np.median(rel, 0).tolist() + [np.median(arr)]))
+    gw = buf[:, 72:80].astype(np.int64)
+    print("qkv phase, end of each wave's MFMAs (median us after the barrier): " + " ".join("%.2f" % v for v in np.median((gw - t_all[:, 2 * ph][:, None]) / 100.0, 0)))
