@@ -26,6 +26,7 @@ import hashlib
 import json
 import os
 import re
+import shutil
 import subprocess
 import sys
 import time
@@ -295,6 +296,7 @@ def run_pmc(args):
     agg = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = os.path.join(out, ctr)
+        shutil.rmtree(d, ignore_errors=True)  # (a second --pmc run on the same box must not pick up the first one's CSV)
         env = dict(os.environ, TMPDIR="/tmp")
         r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--"] + inner,
                            cwd="/tmp", env=env, capture_output=True, text=True)
