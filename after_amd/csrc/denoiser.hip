@@ -1437,6 +1437,9 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
 // a lane's eight k values are its float4 of k-block 2u and of 2u + 1 -- any k order inside the 32 is fine as long as both
 // operands use the same one).
 typedef __bf16 sbf16x8 __attribute__((ext_vector_type(8)));
+#ifndef SEG_DIAG
+#define SEG_DIAG 0
+#endif
 constexpr int kSegWP[6] = {2, 0, 1, 1, 0, 0}, kSegAP[6] = {0, 2, 1, 0, 1, 0};  // (W plane, A plane): smallest products first
 
 // eight fp32 values -> their three bf16 planes (h + m + l == x exactly, each a packed bf16 x 8 MFMA operand)
@@ -1480,7 +1483,7 @@ __device__ __forceinline__ void seg_load(SegBuf<RB, NT>& sb, int slot, __amdgpu_
 // `after_loads()` runs once the last k-block's operands are requested: the place for the NEXT phase's operand prefetch (issued
 // any earlier it would sit in front of this phase's operands in the in-order load queue; any later -- after the MFMAs -- the
 // workgroup barrier of the partial-tile exchange waits a full fabric round trip for it)
-template <int RB, int NT, int KB, class F>
+template <int RB, int NT, int KB, int DIAG, class F>  // DIAG (timing experiments, -DSEG_DIAG=n): 1 no MFMAs, 2 no weight split
 __device__ __forceinline__ void seg_run(f32x4 (&acc)[NT * RB], SegBuf<RB, NT>& sb, __amdgpu_buffer_rsrc_t A3, int a_kb32, int rb0,
                                         const float* __restrict__ wt, int w_kblocks, int tile0, int ts, int kb0, int lane, bool wact,
                                         F&& after_loads) {
@@ -1492,16 +1495,28 @@ __device__ __forceinline__ void seg_run(f32x4 (&acc)[NT * RB], SegBuf<RB, NT>& s
         if (u + 2 == KB || KB == 1) after_loads();
         u32x4 wp[NT][3];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) seg_split8(sb.wr[u & 1][j][0], sb.wr[u & 1][j][1], wp[j]);
+        for (int j = 0; j < NT; ++j) {
+            if constexpr (DIAG & 2) {
+                wp[j][0] = __builtin_bit_cast(u32x4, sb.wr[u & 1][j][0]);
+                wp[j][1] = __builtin_bit_cast(u32x4, sb.wr[u & 1][j][1]);
+                wp[j][2] = wp[j][0] ^ wp[j][1];
+            } else {
+                seg_split8(sb.wr[u & 1][j][0], sb.wr[u & 1][j][1], wp[j]);
+            }
+        }
 #pragma unroll
         for (int p = 0; p < 6; ++p)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int i = 0; i < RB; ++i)  // W fragment as srcA: the accumulator holds C^T
-                    acc[j * RB + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(sbf16x8, wp[j][kSegWP[p]]), __builtin_bit_cast(sbf16x8, sb.ap[u & 1][i][kSegAP[p]]),
-                        acc[j * RB + i], 0, 0, 0);
+                for (int i = 0; i < RB; ++i) {  // W fragment as srcA: the accumulator holds C^T
+                    if constexpr (DIAG & 1)
+                        acc[j * RB + i] += __builtin_bit_cast(f32x4, wp[j][kSegWP[p]] ^ sb.ap[u & 1][i][kSegAP[p]]);
+                    else
+                        acc[j * RB + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(sbf16x8, wp[j][kSegWP[p]]), __builtin_bit_cast(sbf16x8, sb.ap[u & 1][i][kSegAP[p]]),
+                            acc[j * RB + i], 0, 0, 0);
+                }
     }
 }
 
@@ -1672,7 +1687,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 if (trace && tid == 0) trace[64] = wall_clock64();
                 __builtin_amdgcn_sched_barrier(0);
                 seg_load<3, 3>(sb, 0, hb3_r, E / 32, 3 * rh, Lw.qkv_wt, KBE, rank, 32, KQ * ks, lane, wact);
-                seg_run<3, 3, KQ>(acc, sb, hb3_r, E / 32, 3 * rh, Lw.qkv_wt, KBE, rank, 32, KQ * ks, lane, wact,
+                seg_run<3, 3, KQ, SEG_DIAG>(acc, sb, hb3_r, E / 32, 3 * rh, Lw.qkv_wt, KBE, rank, 32, KQ * ks, lane, wact,
                                   [&] { if (rank < nitems) attn_prefetch(l, rank); });
                 __builtin_amdgcn_sched_barrier(0);
                 if (trace) {  // (every wave drains its MFMAs first: the stamp is the end of wave 0's arithmetic)
@@ -1737,7 +1752,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                     bvs[q] = p < 3 * kSNTU * NH ? *reinterpret_cast<const f32x4*>(Lw.mlp0_b + 16 * (rank + 32 * (pp / 3)) + 4 * (lane >> 4))
                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                seg_run<3, kSNTU, KQ>(acc, sb, hb3_r, E / 32, 3 * rh, Lw.mlp0_wt, KBE, rank, 32, KQ * ks, lane, wact, [] {});
+                seg_run<3, kSNTU, KQ, SEG_DIAG>(acc, sb, hb3_r, E / 32, 3 * rh, Lw.mlp0_wt, KBE, rank, 32, KQ * ks, lane, wact, [] {});
                 seg_partials<3 * kSNTU>(acc, red, w, lane);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
@@ -1768,7 +1783,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 {
                     SegBuf<3, NTD> sb;
                     seg_load<3, NTD>(sb, 0, mlp3_r, ME / 32, rb0, Lw.mlp2_wt, KBM, tile0, 1, (KBM / 16) * w, lane, wact);
-                    seg_run<3, NTD, KBM / 16>(acc, sb, mlp3_r, ME / 32, rb0, Lw.mlp2_wt, KBM, tile0, 1, (KBM / 16) * w, lane, wact,
+                    seg_run<3, NTD, KBM / 16, SEG_DIAG>(acc, sb, mlp3_r, ME / 32, rb0, Lw.mlp2_wt, KBM, tile0, 1, (KBM / 16) * w, lane, wact,
                                               [&] { if (l + 1 < a.L) ln_prefetch(l + 1); });
                 }
 #pragma unroll
