@@ -1239,6 +1239,7 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
     auto end_phase = [&](bool drain) { return step_barrier(st, xcc, n, ++round, trace, ++tslot, drain, &s_ok); };
     // the LayerNorm-phase operands of this wave's row (ln phase: row rank + 32 w) / this workgroup's attention item,
     // requested one GEMM phase early (StepLnOps)
+    unsigned warm_sink = 0;  // destination of the L2-warming loads in flight across the ln barrier (step_warm)
     StepLnOps lnops;  // (one register set: the ln row's operands live from MLP-down to ln, the attention item's from qkv to attention)
     const int ln_lm = rank + (int)n * w;  // this wave's (first) row of the ln phases
     const bool ln_mine = ln_lm < Mg && (ln_lm % ct) / T < nclip;
@@ -1291,24 +1292,27 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
                     step_ln_row(l == 0 ? pat_r : xres_r, l == 0 ? rem : lm, xres, hb, lm, lnops, lane);
                 }
             }
-            if (wact && rank >= Mg) {  // workgroups without a row (a warming wave next to a row's wave delays its loads: one
-                                       // load path per CU): warm the K / V ring rows of this layer, then (part of) the qkv weights
-                const int wi = (rank - Mg) * 8 + w, nw = ((int)n - Mg) * 8;
-                unsigned sink = 0;
+            // workgroups without a row (a warming wave next to a row's wave delays its loads: one load path per CU): warm the
+            // K / V ring rows of this layer, then (part of) the qkv weights.  Waves 1 - 7 do not wait for these loads (they stored
+            // nothing: no drain at the barrier) -- the short LayerNorm phase is not held up by the warmers; the loads are waited
+            // for after the qkv GEMM (`warm_sink` stays live until then).  Wave 0 carries the barrier's atomics and stays out.
+            const bool warmer = wact && rank >= Mg && w > 0 && a.warm[0] > 0;
+            if (warmer) {
+                const int wi = (rank - Mg) * 7 + w - 1, nw = ((int)n - Mg) * 7;
                 for (int q = 0; q < 3 * nclip; ++q) {
                     const int br = q / nclip, rg = br * B + c0 + (q - br * nclip);
-                    step_warm(sink, kv.kold + (size_t)rg * a.cache * E, (size_t)a.cache * E * sizeof(float), wi, nw, lane);
-                    step_warm(sink, kv.vold + (size_t)rg * a.cache * E, (size_t)a.cache * E * sizeof(float), wi, nw, lane);
+                    step_warm(warm_sink, kv.kold + (size_t)rg * a.cache * E, (size_t)a.cache * E * sizeof(float), wi, nw, lane);
+                    step_warm(warm_sink, kv.vold + (size_t)rg * a.cache * E, (size_t)a.cache * E * sizeof(float), wi, nw, lane);
                 }
-                step_warm(sink, Lw.qkv_wt, wbytes * a.warm[0] / 16, wi, nw, lane);
-                step_warm_done(sink);
+                step_warm(warm_sink, Lw.qkv_wt, wbytes * a.warm[0] / 16, wi, nw, lane);
             }
-            if (!end_phase(true)) return;
+            if (!end_phase(!warmer)) return;
             // ---- qkv: column tiles rank, rank + 32, rank + 64
             {
                 f32x4 acc[3 * MB];
                 step_gemm<MB, 3, kSKBQ, false>(acc, hb_r, KBE, Lw.qkv_wt, KBE, rank, kSKBQ * w, lane, cw, wact,
                                                [&] { if (rank < nitems) attn_prefetch(l, rank); });
+                step_warm_done(warm_sink);  // (older than the GEMM's operand loads: long landed)
                 step_partials<3 * MB>(acc, red, w, lane);
                 for (int p = w; p < 3 * MB && cw; p += kSCW) {
                     const int j = p / MB, ib = p - j * MB;
@@ -2676,7 +2680,7 @@ int sample_persistent(after_denoiser* h, hipStream_t s, const float* x0, float* 
             a.dbg = dbg | h->step_dbg;
             static int warm[3] = {-1, 0, 0};
             if (warm[0] < 0) {
-                warm[0] = 4, warm[1] = 16, warm[2] = 4;
+                warm[0] = 0, warm[1] = 16, warm[2] = 4;  // (same-box A/B: warming in the short LayerNorm phase does not pay)
                 const char* e = getenv("AFTER_STEP_WARM");
                 if (e) sscanf(e, "%d,%d,%d", &warm[0], &warm[1], &warm[2]);
             }
