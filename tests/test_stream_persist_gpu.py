@@ -104,3 +104,30 @@ def test_persistent_step_failure_is_reported_then_falls_back(net, hip_device):
     assert (got - want).abs().max().item() < 5e-5
     _lib.check(_lib.lib().after_denoiser_set_stream_persist(net._handle, 1), "set_stream_persist")
     net.set_stream_persist(True)
+
+
+def test_persistent_step_midi_window_16(hip_device):
+    """The midi denoiser (export_midi.py's Streamer: piano-roll conditioning, window 16 -> 19 keys per chunk: two key blocks
+    of the online softmax, a 16-frame ring) under CFG_MIDI, persistent against launches."""
+    from after_amd import _lib
+    model, dcfg, _ = pipeline.build_models("midi", "baseAE_causal", hip_device, seed=12)
+    net = model.net
+    net.set_gemm_path(0)
+    steps, n_chunks, B, T = 4, 5, 2, 4
+    net.enable_streaming_cache(max_diffusion_steps=steps, max_batch_size=3 * B, max_frames=T)
+    res = {}
+    for persist in (True, False):
+        net.set_stream_persist(persist)
+        net.reset_cache()
+        g = torch.Generator().manual_seed(77)
+        outs = []
+        for _ in range(n_chunks):
+            x0 = torch.randn(B, net.n_channels, T, generator=g).to(hip_device)
+            cond = torch.randn(B, net.cond_dim, generator=g).to(hip_device)
+            tc = torch.rand(B, net.tcond_dim, T, generator=g).to(hip_device)
+            outs.append(net.cfg_sample(x0, cond, tc, steps, 1.5, 2.0, -4.0, cfg_mode=_lib.CFG_MIDI).cpu())
+        assert net.stream_persist() == persist
+        res[persist] = torch.cat(outs, -1)
+    assert torch.isfinite(res[True]).all()
+    d = (res[True] - res[False]).abs().max().item()
+    assert d < 5e-5, d
