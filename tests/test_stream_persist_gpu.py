@@ -6,7 +6,8 @@ tests/test_baseline_size_gpu.py (config 5) and tests/test_streamer_gpu.py.  -m g
 
 Shapes: one stream (one XCD active, seven idle), fewer streams than provisioned cache rows (the unused rows are copied
 through the roll), eight streams (config 5: one clip per XCD), sixteen (two clips per XCD: two 16-row blocks), eight
-frames per chunk (two attention chunks per row), two frames (less than an attention chunk)."""
+frames per chunk (two attention chunks per row), two frames (less than an attention chunk), six and ten frames (a ragged last
+chunk; thirty rows per XCD)."""
 import pytest
 import torch
 
@@ -33,7 +34,7 @@ def run_chunks(net, B, T, steps, n_chunks, seed, dev):
     return torch.cat(outs, -1)
 
 
-@pytest.mark.parametrize("B,T,max_batch", [(1, 4, 1), (3, 4, 4), (8, 4, 8), (16, 4, 16), (8, 8, 8), (2, 2, 2)])
+@pytest.mark.parametrize("B,T,max_batch", [(1, 4, 1), (3, 4, 4), (8, 4, 8), (16, 4, 16), (8, 8, 8), (2, 2, 2), (4, 6, 4), (8, 10, 8)])
 def test_persistent_step_matches_launch_path(B, T, max_batch, net, hip_device, monkeypatch):
     monkeypatch.delenv("AFTER_STREAM_PERSIST", raising=False)
     steps, n_chunks = 6, 5
