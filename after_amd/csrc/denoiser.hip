@@ -1887,7 +1887,7 @@ struct after_denoiser {
     std::vector<unsigned char> flip;             // per diffusion step: which half is current
     Arena ca;
     bool have_last = false;
-    int last_rows = 0, last_T = 0;
+    int last_rows = 0, last_T = 0, last_steps = 1;
     KernelTimer timer;
     double timer_min_flops = 0;  // after_denoiser_profile_min_flops
     int timer_kernel = 0;        // after_denoiser_profile_kernel: 0 both GEMM kernels, 1 gemm_x6 only, 2 gemm.hip only,
@@ -2569,12 +2569,13 @@ int roll_cache_step(after_denoiser* h, hipStream_t s, int rows, int T, int size,
 // streaming geometry -- embed 512 / mlp 1536 / eight heads (the kernel's tile counts: 32 workgroups per XCD own
 // 3 + 3 + 1 column tiles of the three Linears), finite causal window, <= 8 layers (the by-value argument block),
 // 256 CUs, and at most 16 clip tokens per XCD (ceil(B / 8) * T <= 16: eight streams at 4 - 16 frames, 32 at 4).
-bool step_persist_ok(const after_denoiser* h, int B, int T) {
+bool step_persist_ok(const after_denoiser* h, int B, int T, int nb_steps) {
     const bool wide = h->W < 0 || !h->cfg.causal;
     const int cpg = (B + 7) / 8;
     return h->persist_step && h->cache > 0 && (!h->timer.enabled || h->timer_kernel == 3) && h->x6 != 2 && h->E == kSE && h->ME == kSME &&
            h->H == kSH && h->L <= 8 && !wide && h->Cp == h->C && h->C % 16 == 0 && h->C / 16 <= 8 && h->n_cus == 256 &&
-           3 * cpg * T <= 32 &&  // (two 16-row blocks: the LDS budget of the partial tiles + the weight slot)
+           nb_steps <= 128 &&    // (the flip bits of the argument block)
+           3 * cpg * T <= 32 &&  // (two 16-row blocks: the LDS budget of the partial tiles)
            ((size_t)h->cs * (h->E + 4) + (size_t)kSH * 2 * (h->W - 1 + h->cs) * 16) <= 7168;
 }
 
@@ -2651,7 +2652,6 @@ int sample_persistent(after_denoiser* h, hipStream_t s, const float* x0, float* 
         AFTER_HIP_CHECK(hipGetLastError());
     }
     AFTER_HIP_CHECK(hipMemsetAsync(h->step_sync, 0, sizeof(StepSync), s));
-    AFTER_REQUIRE(nb_steps <= 128, AFTER_E_CAPACITY, "persistent step: %d steps exceed the 128 flip bits", nb_steps);
     const size_t slice = (size_t)8 * kSGroupRows * E;
     {
         StepArgs a;
@@ -2821,11 +2821,12 @@ int sample_enqueue(after_denoiser* h, hipStream_t s, const float* x0, const floa
         h->last_seg = true;
         return sample_seg(h, s, x0, out, T, nb_steps);
     }
-    if (step_persist_ok(h, B, T)) {
+    if (step_persist_ok(h, B, T, nb_steps)) {
         AFTER_TRY(sample_persistent(h, s, x0, out, B, T, nb_steps));
         h->have_last = true;
         h->last_rows = rows;
         h->last_T = T;
+        h->last_steps = nb_steps;
         return AFTER_OK;
     }
     const size_t step_stride = (size_t)rows * h->L * 2 * h->E;
@@ -2857,6 +2858,7 @@ int sample_enqueue(after_denoiser* h, hipStream_t s, const float* x0, const floa
         h->have_last = true;
         h->last_rows = rows;
         h->last_T = T;
+        h->last_steps = nb_steps;
     }
     return AFTER_OK;
 }
@@ -3000,7 +3002,7 @@ extern "C" int after_denoiser_step_trace(after_denoiser* h, unsigned long long* 
 
 extern "C" int after_denoiser_stream_persist(after_denoiser* h, int* active) {
     AFTER_REQUIRE(h && active, AFTER_E_INVALID, "null argument");
-    *active = h->have_last && step_persist_ok(h, h->last_rows / 3, h->last_T) ? 1 : 0;
+    *active = h->have_last && step_persist_ok(h, h->last_rows / 3, h->last_T, h->last_steps) ? 1 : 0;
     return AFTER_OK;
 }
 

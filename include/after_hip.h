@@ -134,7 +134,7 @@ int after_denoiser_gemm_path(after_denoiser* h, int* mode, int* min_rows);
  * runs each cached Euler step as ONE persistent launch -- eight independent XCD-local pipelines, clip c on XCD
  * c / ceil(B / 8), every phase of the network behind an XCD-local barrier inside the kernel -- when the geometry allows
  * it: embed 512 / mlp x 3 / eight heads, finite causal window, <= 8 layers, 256 CUs, ceil(B / 8) * T * 3 <= 32 token rows
- * per XCD, gemm path != 2.  Otherwise, or with enable = 0 / AFTER_STREAM_PERSIST=0, as the launch-per-kernel sequence.
+ * per XCD, <= 128 Euler steps, gemm path != 2.  Otherwise, or with enable = 0 / AFTER_STREAM_PERSIST=0, as the launch-per-kernel sequence.
  * Same arithmetic (fp32 MFMA, a different but fixed K split): the two paths agree to fp32 round-off.  A step whose
  * workgroups were not placed 32 per XCD, or an XCD-local barrier that timed out, is reported by the NEXT after_sample
  * call on the handle (AFTER_E_HIP; that call also selects the launch path): the chunk before it is invalid, reset the

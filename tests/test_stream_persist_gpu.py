@@ -77,6 +77,13 @@ def test_persistent_step_refused_shapes_fall_back(net, hip_device):
     net.reset_cache()
     z = run_chunks(net, 32, 4, 2, 2, 7, hip_device)
     assert not net.stream_persist() and torch.isfinite(z).all()
+    # more Euler steps than the kernel's 128 flip bits: launches, no error
+    net.enable_streaming_cache(max_diffusion_steps=130, max_batch_size=3, max_frames=4)
+    net.reset_cache()
+    z = run_chunks(net, 1, 4, 130, 1, 8, hip_device)
+    assert not net.stream_persist() and torch.isfinite(z).all()
+    z = run_chunks(net, 1, 4, 100, 1, 8, hip_device)
+    assert net.stream_persist()
 
 
 def test_persistent_step_failure_is_reported_then_falls_back(net, hip_device):
