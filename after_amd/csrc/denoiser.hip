@@ -1917,6 +1917,7 @@ struct after_denoiser {
     float* seg_qkv = nullptr;  // [L][3 max_T][3E]: per-layer qkv rows of the segment sampler
     unsigned short* seg_act3 = nullptr;  // bf16 x 3 planes of h and of the MLP hidden layer, one slice per XCD
     bool last_seg = false;     // the last after_sample ran as sample_seg_kernel
+    bool step_validated = false;  // the placement census of a persistent launch has been looked at (first use: synchronously)
     int step_dbg = 0;  // after_denoiser_set_stream_persist(h, 1 | dbg << 8): diagnostics bits OR-ed into AFTER_STEP_DBG
     StepSync* step_sync = nullptr;       // [max_steps]: one barrier state per step of a sample() call
     unsigned long long* step_trace = nullptr;  // AFTER_STEP_TRACE=1: stamps of the LAST step launched (diagnostics)
@@ -2620,6 +2621,26 @@ int step_check_failure(after_denoiser* h) {
     return AFTER_OK;
 }
 
+// First persistent launch of a handle: look at the placement census NOW (one stream synchronisation) instead of at the next
+// call.  A kernel that did not find 32 workgroups on each of 8 XCDs returned before touching anything, so the caller can run
+// the same call on the launch path: kStepRetry.  (Placement is a property of the device and the runtime, not of the call:
+// once seen, it is not checked synchronously again; barrier time-outs keep the report-at-the-next-call protocol.)
+constexpr int kStepRetry = 1;
+int step_validate_first(after_denoiser* h, hipStream_t s) {
+    if (h->step_validated) return AFTER_OK;
+    AFTER_HIP_CHECK(hipStreamSynchronize(s));
+    if (h->step_fail[1]) {
+        h->persist_step = 0;
+        h->persist_offline = 0;
+        h->step_fail_n = 0;
+        h->step_fail[0] = h->step_fail[1] = 0;
+        return kStepRetry;
+    }
+    if (h->step_fail[0]) return step_check_failure(h);
+    h->step_validated = true;
+    return AFTER_OK;
+}
+
 int step_alloc(after_denoiser* h, hipStream_t s) {
     if (h->step_sync) return AFTER_OK;
     AFTER_HIP_CHECK(hipMalloc(&h->step_sync, sizeof(StepSync)));
@@ -2710,7 +2731,10 @@ int sample_persistent(after_denoiser* h, hipStream_t s, const float* x0, float* 
     // failure words -> pinned host memory, looked at when the next call starts
     AFTER_HIP_CHECK(hipMemcpyAsync(h->step_fail, &h->step_sync[0].fail[0], 32 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     h->step_fail_n = 1;
-    return AFTER_OK;
+    const int rc = step_validate_first(h, s);
+    if (rc == kStepRetry)
+        for (int i = 0; i < nb_steps; ++i) h->flip[i] ^= 1;  // nothing was rolled
+    return rc;
 }
 
 // RectifiedFlow.sample for ONE clip as one persistent launch (sample_seg_kernel): eligible for the shipped width (embed
@@ -2803,7 +2827,7 @@ int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, in
     }
     AFTER_HIP_CHECK(hipMemcpyAsync(h->step_fail, &h->step_sync[0].fail[0], 32 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     h->step_fail_n = 1;
-    return AFTER_OK;
+    return step_validate_first(h, s);
 }
 
 // The whole sampler as a sequence of launches on `s` (eager path and graph capture body).
@@ -2818,16 +2842,22 @@ int sample_enqueue(after_denoiser* h, hipStream_t s, const float* x0, const floa
                               h->maps + 2 * h->ms, drop_value));
     h->last_seg = false;
     if (sample_seg_ok(h, B, T, nb_steps)) {
-        h->last_seg = true;
-        return sample_seg(h, s, x0, out, T, nb_steps);
+        const int rc = sample_seg(h, s, x0, out, T, nb_steps);
+        if (rc != kStepRetry) {
+            h->last_seg = rc == AFTER_OK;
+            return rc;
+        }
     }
     if (step_persist_ok(h, B, T, nb_steps)) {
-        AFTER_TRY(sample_persistent(h, s, x0, out, B, T, nb_steps));
-        h->have_last = true;
-        h->last_rows = rows;
-        h->last_T = T;
-        h->last_steps = nb_steps;
-        return AFTER_OK;
+        const int rc = sample_persistent(h, s, x0, out, B, T, nb_steps);
+        if (rc != kStepRetry) {
+            AFTER_TRY(rc);
+            h->have_last = true;
+            h->last_rows = rows;
+            h->last_T = T;
+            h->last_steps = nb_steps;
+            return AFTER_OK;
+        }
     }
     const size_t step_stride = (size_t)rows * h->L * 2 * h->E;
     // Fused tail: out_proj + CFG + Euler in ONE GEMM launch that also leaves the new latents in
@@ -2974,13 +3004,15 @@ extern "C" int after_denoiser_set_gemm_path(after_denoiser* h, int mode, int min
 extern "C" int after_denoiser_set_stream_persist(after_denoiser* h, int enable) {
     AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
     h->persist_step = (enable & 0xff) != 0;
-    h->step_dbg = enable >> 8;  // (diagnostics: bit 3 = report a failed placement census, as tests/test_stream_persist_gpu.py does)
+    if (h->step_dbg != (enable >> 8)) h->step_validated = false;
+    h->step_dbg = enable >> 8;  // (diagnostics: bit 3 = a failed placement census, as tests/test_stream_persist_gpu.py simulates)
     return AFTER_OK;
 }
 
 extern "C" int after_denoiser_set_sample_persist(after_denoiser* h, int enable) {
     AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
     h->persist_offline = (enable & 0xff) != 0;
+    if (h->step_dbg != (enable >> 8)) h->step_validated = false;
     h->step_dbg = enable >> 8;
     return AFTER_OK;
 }

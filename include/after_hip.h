@@ -135,9 +135,11 @@ int after_denoiser_gemm_path(after_denoiser* h, int* mode, int* min_rows);
  * c / ceil(B / 8), every phase of the network behind an XCD-local barrier inside the kernel -- when the geometry allows
  * it: embed 512 / mlp x 3 / eight heads, finite causal window, <= 8 layers, 256 CUs, ceil(B / 8) * T * 3 <= 32 token rows
  * per XCD, <= 128 Euler steps, gemm path != 2.  Otherwise, or with enable = 0 / AFTER_STREAM_PERSIST=0, as the launch-per-kernel sequence.
- * Same arithmetic (fp32 MFMA, a different but fixed K split): the two paths agree to fp32 round-off.  A step whose
- * workgroups were not placed 32 per XCD, or an XCD-local barrier that timed out, is reported by the NEXT after_sample
- * call on the handle (AFTER_E_HIP; that call also selects the launch path): the chunk before it is invalid, reset the
+ * Same arithmetic (fp32 MFMA, a different but fixed K split): the two paths agree to fp32 round-off.  The first persistent
+ * launch of a handle is checked synchronously: if its workgroups were not placed 32 per XCD (the kernel then returned before
+ * touching anything) the same call runs on the launch path and the handle stays there -- no invalid chunk, no error.  An
+ * XCD-local barrier that timed out later on is reported by the NEXT after_sample call on the handle (AFTER_E_HIP; that call
+ * also selects the launch path): the chunk before it is invalid, reset the
  * streamer.  after_denoiser_stream_persist: *active = 1 when the handle's last streaming shape takes the persistent
  * path. */
 int after_denoiser_set_stream_persist(after_denoiser* h, int enable);
