@@ -20,6 +20,7 @@
 //     <= W+chunk-1 keys.
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 #include <new>
 #include <utility>
 #include <vector>
@@ -705,10 +706,13 @@ struct StepSync {
     unsigned gen[8][32];     // [xcc][0]: last completed round
     unsigned pop[8][32];     // [xcc][0]: workgroups resident on the XCC
     unsigned census[32];     // [0]: workgroups counted
-    unsigned fail[32];       // [0]: a spin gave up; [1]: census is not 8 x 32
     // offline segment sampler: [xcc][0] = layers completed (step * L + layer + 1), system-scope words
     unsigned qkv_seq[8][32];  // ... whose qkv rows are in memory (the next XCD's attention reads the last W - 1 frames)
     unsigned att_seq[8][32];  // ... whose attention has read its keys (the previous XCD may overwrite that layer's rows)
+    // STICKY failure words -- [0]: a spin gave up; [1]: census is not 8 x 32.  The per-call memset stops in front of them:
+    // once raised they stay raised, every later persistent launch sees them at entry and returns without touching anything,
+    // until the host has reported the failure (persist_poll) and cleared them.
+    unsigned fail[32];
 };
 
 struct StepLayer {
@@ -727,6 +731,7 @@ struct StepArgs {
     int nsteps, cache_steps;  // Euler steps of this launch (ALL of a sample() call); ring slots per layer
     unsigned flip[4];         // bit i: which half of step i's K / V rings is current
     int warm[3];  // sixteenths of the qkv / MLP-up / MLP-down weights warmed into the L2 by idle waves (AFTER_STEP_WARM)
+    int segw;     // offline segment sampler: which phases warm the workgroup's OWN slice of the next GEMM's weights (AFTER_SEG_W)
     float* xt;                             // token-major latents [B * T][Cp]: a step's input, rewritten by its tail
     float *pat_t, *xres_t, *h_t, *mlp_t;   // tiled, one slice of kSGroupRows rows per XCD
     unsigned short *h3_t, *mlp3_t;         // offline segment sampler: bf16 x 3 planes of h / the MLP hidden layer (p32_store4)
@@ -826,6 +831,17 @@ __device__ __forceinline__ void step_warm(unsigned& sink, const void* base, size
 }
 
 __device__ __forceinline__ void step_warm_done(unsigned& sink) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory"); }
+
+// The same for whole 16-column weight tiles of a tiled copy (`kblocks` 1-KB blocks each: tiles tile0 + ts j, j < nt): wave
+// `wi` of `nw` touches 8-KB chunks wi, wi + nw, ... of the nt tiles.  Nobody waits for these loads: the wave's later loads
+// return behind them (in issue order), a later s_waitcnt vmcnt(0) covers them.
+__device__ __forceinline__ void seg_warm_tiles(unsigned& sink, const float* wt, int kblocks, int tile0, int ts, int nt, int wi, int nw, int lane) {
+    const int cpt = kblocks / 8;
+    for (int c = wi; c < nt * cpt; c += nw) {
+        const char* q = reinterpret_cast<const char*>(wt + ((size_t)((tile0 + ts * (c / cpt)) * kblocks) << 8)) + (size_t)(c % cpt) * 8192 + lane * 128;
+        asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(q) : "memory");
+    }
+}
 
 // acc[j * MB + i] = (this wave's K slice: k-blocks kb0 .. kb0 + KB) of rows 16 i .. 16 i + 15 of A x column tile
 // tile0 + 32 j of W.  A: tiled buffer read with sc1 loads (`a_kblocks` k-blocks per row block), or -- AROW -- row-major
@@ -1153,14 +1169,17 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
     const unsigned xcc = step_xcc_id(), nb = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid == 0) {  // census: workgroups per XCC, this workgroup's rank on its XCC
+    if (tid == 0 && (__hip_atomic_load(&st->fail[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) |
+                     __hip_atomic_load(&st->fail[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        s_bad = 1;  // an earlier launch failed (sticky words, raised before this launch began: every workgroup sees them)
+    } else if (tid == 0) {  // census: workgroups per XCC, this workgroup's rank on its XCC
         s_rank = __hip_atomic_fetch_add(&st->pop[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&st->census[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         step_spin(&st->census[0], nb, &st->fail[0]);
         unsigned bad = 0;
         for (int x = 0; x < 8; ++x)
             bad |= __hip_atomic_load(&st->pop[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 32u;
-        if (a.dbg & 8) bad = 1;  // (AFTER_STEP_DBG=8: pretend the placement census failed -- tests of the failure report)
+        if (a.dbg & 24) bad = 1;  // (diagnostics bit 3: pretend the placement census failed, dry census included; bit 4: in real launches only -- tests of the failure report)
         if (bad) __hip_atomic_store(&st->fail[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_n = 32;
         s_bad = bad;
@@ -1467,10 +1486,14 @@ struct SegBuf {
     u32x4 ap[2][RB][3];   // activation planes
 };
 
+constexpr bool kSegW = !(SEG_DIAG & 4);  // -DSEG_DIAG=4 (timing experiments): no weight traffic, wrong results
+
+// (W: buffer resource of the tiled weight copy -- every fragment load of the kernel then shares ONE address register, lane x 16
+//  bytes, and carries its tile / k-block position in the instruction's scalar offset: per-load 64-bit lane addresses are
+//  kernel-lifetime invariants that the register allocator spills, and each reload's s_waitcnt vmcnt(0) drains the operand queue)
 template <int RB, int NT>
 __device__ __forceinline__ void seg_load(SegBuf<RB, NT>& sb, int slot, __amdgpu_buffer_rsrc_t A3, int a_kb32, int rb0,
-                                         const float* __restrict__ wt, int w_kblocks, int tile0, int ts, int kb, int lane, bool wact) {
-    typedef const __attribute__((address_space(1))) f32x4* gptr;
+                                         __amdgpu_buffer_rsrc_t W, int w_kblocks, int tile0, int ts, int kb, int lane) {
 #pragma unroll
     for (int i = 0; i < RB; ++i)
 #pragma unroll
@@ -1478,9 +1501,9 @@ __device__ __forceinline__ void seg_load(SegBuf<RB, NT>& sb, int slot, __amdgpu_
             sb.ap[slot][i][p] = __builtin_amdgcn_raw_buffer_load_b128(A3, lane * 16, (unsigned)((((rb0 + i) * a_kb32 + kb) * 3 + p) << 10), 16);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const float* q = wt + ((size_t)((tile0 + ts * j) * w_kblocks + 2 * kb) << 8) + lane * 4;
-        sb.wr[slot][j][0] = wact ? *(gptr)(q) : f32x4{0.f, 0.f, 0.f, 0.f};
-        sb.wr[slot][j][1] = wact ? *(gptr)(q + 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned so = (unsigned)(((tile0 + ts * j) * w_kblocks + 2 * kb) << 10);
+        sb.wr[slot][j][0] = kSegW ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W, lane * 16, so, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        sb.wr[slot][j][1] = kSegW ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W, lane * 16 + 1024, so, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -1489,13 +1512,12 @@ __device__ __forceinline__ void seg_load(SegBuf<RB, NT>& sb, int slot, __amdgpu_
 // workgroup barrier of the partial-tile exchange waits a full fabric round trip for it)
 template <int RB, int NT, int KB, int DIAG, class F>  // DIAG (timing experiments, -DSEG_DIAG=n): 1 no MFMAs, 2 no weight split
 __device__ __forceinline__ void seg_run(f32x4 (&acc)[NT * RB], SegBuf<RB, NT>& sb, __amdgpu_buffer_rsrc_t A3, int a_kb32, int rb0,
-                                        const float* __restrict__ wt, int w_kblocks, int tile0, int ts, int kb0, int lane, bool wact,
-                                        F&& after_loads) {
+                                        __amdgpu_buffer_rsrc_t W, int w_kblocks, int tile0, int ts, int kb0, int lane, F&& after_loads) {
 #pragma unroll
     for (int p = 0; p < NT * RB; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < KB; ++u) {
-        if (u + 1 < KB) seg_load<RB, NT>(sb, (u + 1) & 1, A3, a_kb32, rb0, wt, w_kblocks, tile0, ts, kb0 + u + 1, lane, wact);
+        if (u + 1 < KB) seg_load<RB, NT>(sb, (u + 1) & 1, A3, a_kb32, rb0, W, w_kblocks, tile0, ts, kb0 + u + 1, lane);
         if (u + 2 == KB || KB == 1) after_loads();
         u32x4 wp[NT][3];
 #pragma unroll
@@ -1522,6 +1544,81 @@ __device__ __forceinline__ void seg_run(f32x4 (&acc)[NT * RB], SegBuf<RB, NT>& s
                             acc[j * RB + i], 0, 0, 0);
                 }
     }
+}
+
+// The qkv / MLP-up GEMM of a 96-row segment with K split EIGHT ways over all six row blocks (K8): wave w owns 32-deep k-blocks
+// 2 w, 2 w + 1 of every row block and of the workgroup's NT column tiles, so no operand is fetched twice by a CU (the row-half
+// x 4-way split fetches and splits every weight fragment in both halves: 480 instead of 384 KB per CU and phase through the
+// one load path, twice the VALU work of the weight split) and the two waves of a SIMD do the same work at the same time.
+// acc[j * 6 + rb].  The weight fragments of both k-blocks are requested first (the longest latency: fabric or L2), then the
+// activation planes in chunks of (k-block, three row blocks) through a ring of NS register slots.
+template <int NT, int NS, int DIAG, class F>
+__device__ __forceinline__ void seg_run_k8(f32x4 (&acc)[NT * 6], __amdgpu_buffer_rsrc_t A3, int a_kb32, __amdgpu_buffer_rsrc_t W,
+                                           int w_kblocks, int tile0, int ts, int kb0, int lane, F&& after_loads) {
+    f32x4 wr[2][NT][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const unsigned so = (unsigned)(((tile0 + ts * j) * w_kblocks + 2 * (kb0 + u)) << 10);
+            wr[u][j][0] = kSegW ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W, lane * 16, so, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            wr[u][j][1] = kSegW ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W, lane * 16 + 1024, so, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    u32x4 ap[NS][3][3];
+    auto load_a = [&](int slot, int c) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                ap[slot][i][p] = __builtin_amdgcn_raw_buffer_load_b128(
+                    A3, lane * 16, (unsigned)((((3 * (c & 1) + i) * a_kb32 + kb0 + (c >> 1)) * 3 + p) << 10), 16);
+    };
+#pragma unroll
+    for (int c = 0; c < NS; ++c) load_a(c, c);
+#pragma unroll
+    for (int p = 0; p < NT * 6; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 wp[NT][3];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if ((c & 1) == 0) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if constexpr (DIAG & 2) {
+                    wp[j][0] = __builtin_bit_cast(u32x4, wr[c >> 1][j][0]);
+                    wp[j][1] = __builtin_bit_cast(u32x4, wr[c >> 1][j][1]);
+                    wp[j][2] = wp[j][0] ^ wp[j][1];
+                } else {
+                    seg_split8(wr[c >> 1][j][0], wr[c >> 1][j][1], wp[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {  // W fragment as srcA: the accumulator holds C^T
+                    const int t = j * 6 + 3 * (c & 1) + i;
+                    if constexpr (DIAG & 1)
+                        acc[t] += __builtin_bit_cast(f32x4, wp[j][kSegWP[p]] ^ ap[c % NS][i][kSegAP[p]]);
+                    else
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sbf16x8, wp[j][kSegWP[p]]),
+                                                                         __builtin_bit_cast(sbf16x8, ap[c % NS][i][kSegAP[p]]), acc[t], 0, 0, 0);
+                }
+        if (c + NS < 4) load_a(c % NS, c + NS);
+        if (c + NS == 3 || (NS >= 4 && c == 0)) after_loads();
+    }
+}
+
+// row half r of the K8 partials (the NT x 3 tiles acc[j * 6 + 3 r + i]) -> LDS [wave][NT * 3][256]
+template <int NT>
+__device__ __forceinline__ void seg_partials_k8(const f32x4 (&acc)[NT * 6], int r, float* red, int w, int lane) {
+    __syncthreads();  // the previous readers are done with `red`
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) *reinterpret_cast<f32x4*>(red + (((w * NT * 3 + j * 3 + i) << 6) + lane) * 4) = acc[j * 6 + 3 * r + i];
+    __syncthreads();
 }
 
 // the eight waves' partials of ONE column tile (RB row blocks) -> LDS -> wave w returns the sum of row block w (wave order)
@@ -1571,31 +1668,44 @@ __device__ __forceinline__ bool seg_spin_sys(const unsigned* word, unsigned want
 
 // (out of line: with the attention body inlined next to the split-MFMA GEMMs, clang 22's InstCombine crashes on this kernel;
 //  every argument by value -- see StepAttn)
-__device__ __attribute__((noinline)) void seg_attention(StepAttn g, StepLnOps ops, int rg, int lr0, int bx, bool halo, float* smem,
-                                                        float* kvlds, float* xres, float* hout) {
+__device__ __attribute__((noinline)) void seg_attention(StepAttn g, const float* ab, const float* w3, const float* b3, int rg, int lr0,
+                                                        int bx, bool halo, float* smem, float* kvlds, float* xres, float* hout) {
     const StepKV nokv{nullptr, nullptr, nullptr, nullptr};
+    // The LayerNorm tail's row operands (AdaLN(cond) alpha / beta of the CFG row, norm3's affine: waves < cs own a row) are
+    // requested HERE, in front of q / K / V -- an earlier phase touched their lines into the XCD's L2 (attn_warm), so they
+    // cost a few hundred cycles of queue, not a fabric round trip -- instead of riding through the qkv GEMM in 32 registers.
+    StepLnOps ops;
+    if ((int)(threadIdx.x >> 6) < g.cs) {
+        step_ln_ops(ops, ab, w3, b3, threadIdx.x & 63);
+    } else {
+#pragma unroll
+        for (int i = 0; i < kSE / 256; ++i) ops.al[i] = ops.be[i] = ops.ww[i] = ops.bb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     // system-scope q / K / V loads only where keys of the previous XCD are involved; the other chunks read this XCD's L2
     if (halo) step_attention<17, true>(g, nokv, ops, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout);
     else step_attention<16, true>(g, nokv, ops, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout);
 }
 
-template <int MB>  // row blocks per XCD: 3 Tseg / 16 (6 at T = 256)
+template <int MB, int K8 = 0>  // row blocks per XCD: 3 Tseg / 16 (6 at T = 256); K8 > 0: qkv / MLP-up by seg_run_k8 with K8 ring slots (MB = 6)
 __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ unsigned s_rank, s_bad, s_ok;
     constexpr int E = kSE, ME = kSME, KBE = E / 16, KBM = ME / 16, MBP = (MB + 2) / 3;  // MBP: row blocks of one CFG row
     StepSync* st = a.sync;
     const unsigned xcc = step_xcc_id(), nb = gridDim.x, n = 32;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane0 = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid == 0) {  // census: workgroups per XCC, this workgroup's rank on its XCC
+    if (tid == 0 && (__hip_atomic_load(&st->fail[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) |
+                     __hip_atomic_load(&st->fail[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        s_bad = 1;  // an earlier launch failed (sticky words, raised before this launch began: every workgroup sees them)
+    } else if (tid == 0) {  // census: workgroups per XCC, this workgroup's rank on its XCC
         s_rank = __hip_atomic_fetch_add(&st->pop[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&st->census[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         step_spin(&st->census[0], nb, &st->fail[0]);
         unsigned bad = 0;
         for (int x = 0; x < 8; ++x)
             bad |= __hip_atomic_load(&st->pop[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 32u;
-        if (a.dbg & 8) bad = 1;
+        if (a.dbg & 24) bad = 1;
         if (bad) __hip_atomic_store(&st->fail[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_bad = bad;
     }
@@ -1616,22 +1726,38 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
     const __amdgpu_buffer_rsrc_t xt_r = step_rsrc(a.xt), xout_r = step_rsrc(a.xout);
     float* const red = smem;                      // partial tiles [8 waves][3][256] (one column tile at a time) | attention rows
     float* const kvl = smem + kSRedFloats(2);     // attention: K / V landing zones [8 waves][2][12][64]
-    const bool wact = !(a.dbg & 2);
+    constexpr bool wact = kSegW;
     auto end_phase = [&](bool drain) { return step_barrier(st, xcc, n, ++round, trace, ++tslot, drain, &s_ok); };
-    StepLnOps lnops;
     const int ln_lm = rank + (int)n * w;  // this wave's row of the ln phases (waves 0 .. 2 at 96 rows)
     const bool ln_mine = ln_lm < Mg;
-    auto ln_prefetch = [&](int l) {
-        if (!ln_mine) return;
+    unsigned wsink = 0;  // destination of the L2-warming loads (seg_warm_tiles, row_warm): never read
+    // The row-wise operands of a LayerNorm (AdaLN alpha | beta of the row: 4 KB; affine weight, bias: 2 KB each) come from the
+    // memory-side cache.  One phase EARLY a wave touches their 64 lines into the XCD's L2 (one load instruction, nobody waits
+    // for it); the phase that needs them then loads them beside its activation row at L2 latency -- carrying them through the
+    // GEMM phase in registers (32 per lane) made the register allocator spill inside the MFMA loops.
+    auto row_warm = [&](const float* ab, const float* wv, const float* bv) {
+        const char* q = lane0 < 32 ? reinterpret_cast<const char*>(ab) + lane0 * 128
+                                   : (lane0 < 48 ? reinterpret_cast<const char*>(wv) + (lane0 - 32) * 128 : reinterpret_cast<const char*>(bv) + (lane0 - 48) * 128);
+        asm volatile("global_load_dword %0, %1, off" : "+v"(wsink) : "v"(q) : "memory");
+    };
+    const float* ln_ab0 = a.tc_ab;  // this wave's tcond AdaLN row (layer 0)
+    if (ln_mine) {
         const int br = ln_lm / Tseg, tl = ln_lm - br * Tseg;
-        step_ln_ops(lnops, a.tc_ab + ((size_t)a.tcmap[br] * T + f0 + tl) * a.tc_ld + (size_t)l * 2 * E, a.layer[l].n1w, a.layer[l].n1b, lane);
+        ln_ab0 += ((size_t)a.tcmap[br] * T + f0 + tl) * a.tc_ld;
+    }
+    auto ln_prefetch = [&](int l) {
+        if (ln_mine) row_warm(ln_ab0 + (size_t)l * 2 * E, a.layer[l].n1w, a.layer[l].n1b);
     };
     const int cps = Tseg / a.cs, nitems = 3 * cps;  // attention items: (CFG row, chunk of the segment)
+    const int segw = wact ? a.segw : 0;
 
     for (int i = 0; i < a.nsteps; ++i) {  // ---- the Euler steps of RectifiedFlow.sample (model.py:770-785)
         const float* cond_ab = a.cond_ab + (size_t)i * a.cond_step;
-        auto attn_prefetch = [&](int l, int it) {
-            step_ln_ops(lnops, cond_ab + (size_t)(it / cps) * a.cond_ld + (size_t)l * 2 * E, a.layer[l].n3w, a.layer[l].n3b, lane);
+        int lane_i = lane0;
+        asm volatile("" : "+v"(lane_i));  // (opaque: per-lane addresses are recomputed here -- hoisted out of the loops they are
+        const int lane = lane_i;         //  kernel-lifetime 64-bit register pairs, and the allocator spills them into the MFMA loops)
+        auto attn_prefetch = [&](int l, int it) {  // (wave 0: one touch per workgroup)
+            if (w == 0) row_warm(cond_ab + (size_t)(it / cps) * a.cond_ld + (size_t)l * 2 * E, a.layer[l].n3w, a.layer[l].n3b);
         };
         tslot = 0;
         if (trace && tid == 0) {
@@ -1670,19 +1796,54 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
         for (int l = 0; l < a.L; ++l) {
             const StepLayer& Lw = a.layer[l];
             const __amdgpu_buffer_rsrc_t qkv_r = step_rsrc(Lw.qkv);
+            int lane_l = lane0;
+            asm volatile("" : "+v"(lane_l));  // (opaque: per-lane addresses are recomputed here -- hoisted out of the loops they are
+            const int lane = lane_l;         //  kernel-lifetime 64-bit register pairs, and the allocator spills them into the MFMA loops)
             const unsigned seq = (unsigned)(i * a.L + l + 1);
             // ---- norm0 -> AdaLN(tcond) -> norm1: one wave per token row (three per workgroup); h as bf16 x 3 planes
             if (ln_mine) {
-                const int br = ln_lm / Tseg, tl = ln_lm - br * Tseg;
-                step_ln_row<true>(l == 0 ? pat_r : xres_r, l == 0 ? tl : ln_lm, xres, reinterpret_cast<float*>(hb3), ln_lm, lnops, lane);
+                StepLnOps lnops;
+                step_ln_ops(lnops, ln_ab0 + (size_t)l * 2 * E, Lw.n1w, Lw.n1b, lane);
+                step_ln_row<true>(l == 0 ? pat_r : xres_r, l == 0 ? ln_lm % Tseg : ln_lm, xres, reinterpret_cast<float*>(hb3), ln_lm, lnops, lane);
             }
             // (idle wave 7 of workgroup 0: the next XCD has read this layer's keys of the PREVIOUS step -- its last
             //  frames may be overwritten.  A whole step behind: satisfied long ago, one memory round trip off the path)
             if (rank == 0 && w == 7 && lane == 0 && g < 7 && i > 0) seg_spin_sys(&st->att_seq[g + 1][0], seq - a.L, &st->fail[0]);
+            // (segw bit 0: the waves without a row request this workgroup's qkv weight tiles into the XCD's L2)
+            if (!ln_mine && (segw & 1)) {
+                const int nbusy = (Mg - rank + (int)n - 1) / (int)n;  // waves of this workgroup with a row
+                seg_warm_tiles(wsink, Lw.qkv_wt, KBE, rank, 32, 3, w - nbusy, 8 - nbusy, lane);
+            }
             if (!end_phase(ln_mine)) return;
             // ---- qkv: column tiles rank, rank + 32, rank + 64 (bf16 x 3 split MFMAs), three row blocks at a time; the
             //      rows are written through to memory (the next XCD's attention reads the last W - 1 frames)
-            {
+            auto qkv_store = [&](const f32x4& o, int rb, int j) {
+                const int lm = 16 * rb + (lane & 15), br = lm / Tseg, tl = lm - br * Tseg;
+                if (lm < Mg)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), qkv_r,
+                                                           (unsigned)(((br * T + f0 + tl) * 3 * E + 16 * (rank + 32 * j) + 4 * (lane >> 4)) * 4), 0, 17);
+            };
+            if constexpr (K8 > 0) {
+                f32x4 acc[18];
+                if (trace && tid == 0) trace[64] = wall_clock64();
+                __builtin_amdgcn_sched_barrier(0);
+                seg_run_k8<3, K8, SEG_DIAG>(acc, hb3_r, E / 32, step_rsrc(Lw.qkv_wt), KBE, rank, 32, 2 * w, lane,
+                                                      [&] { if (rank < nitems) attn_prefetch(l, rank); });
+                __builtin_amdgcn_sched_barrier(0);
+                if (trace) {
+                    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[17]));
+                    if (tid == 0) trace[65] = wall_clock64();
+                    if (lane == 0) trace[72 + w] = wall_clock64();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    seg_partials_k8<3>(acc, r, red, w, lane);
+                    if (r == 0 && trace && tid == 0) trace[66] = wall_clock64();
+                    for (int pp = w; pp < 9; pp += 8) qkv_store(seg_sum<8>(red, 9, pp, lane), 3 * r + pp % 3, pp / 3);
+                }
+                if (trace && tid == 0) trace[67] = wall_clock64();
+            } else {
                 // waves = (row half, K slice): with 96 rows both halves run side by side, each wave four k-blocks deep
                 constexpr int NH = MB / 3, KS = 8 / NH, KQ = KBE / 2 / KS;  // row halves, K slices, 32-deep k-blocks per wave
                 const int rh = w / KS, ks = w - rh * KS;
@@ -1690,8 +1851,8 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 f32x4 acc[9];
                 if (trace && tid == 0) trace[64] = wall_clock64();
                 __builtin_amdgcn_sched_barrier(0);
-                seg_load<3, 3>(sb, 0, hb3_r, E / 32, 3 * rh, Lw.qkv_wt, KBE, rank, 32, KQ * ks, lane, wact);
-                seg_run<3, 3, KQ, SEG_DIAG>(acc, sb, hb3_r, E / 32, 3 * rh, Lw.qkv_wt, KBE, rank, 32, KQ * ks, lane, wact,
+                seg_load<3, 3>(sb, 0, hb3_r, E / 32, 3 * rh, step_rsrc(Lw.qkv_wt), KBE, rank, 32, KQ * ks, lane);
+                seg_run<3, 3, KQ, SEG_DIAG>(acc, sb, hb3_r, E / 32, 3 * rh, step_rsrc(Lw.qkv_wt), KBE, rank, 32, KQ * ks, lane,
                                   [&] { if (rank < nitems) attn_prefetch(l, rank); });
                 __builtin_amdgcn_sched_barrier(0);
                 if (trace) {  // (every wave drains its MFMAs first: the stamp is the end of wave 0's arithmetic)
@@ -1705,12 +1866,8 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 if (trace && tid == 0) trace[66] = wall_clock64();
                 __builtin_amdgcn_sched_barrier(0);
                 for (int p = w; p < 9 * NH; p += 8) {
-                    const int hh = p / 9, pp = p - 9 * hh, j = pp / 3, ib = pp - 3 * j;
-                    const f32x4 o = seg_sum<KS>(red + (size_t)hh * KS * 9 * 256, 9, pp, lane);
-                    const int lm = 16 * (3 * hh + ib) + (lane & 15), br = lm / Tseg, tl = lm - br * Tseg;
-                    if (lm < Mg)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), qkv_r,
-                                                               (unsigned)(((br * T + f0 + tl) * 3 * E + 16 * (rank + 32 * j) + 4 * (lane >> 4)) * 4), 0, 17);
+                    const int hh = p / 9, pp = p - 9 * hh;
+                    qkv_store(seg_sum<KS>(red + (size_t)hh * KS * 9 * 256, 9, pp, lane), 3 * hh + pp % 3, pp / 3);
                 }
                 if (trace && tid == 0) trace[67] = wall_clock64();
             }
@@ -1721,17 +1878,21 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
             for (int it = rank; it < nitems; it += (int)n) {
                 const int br = it / cps, ch = it - br * cps, i0f = f0 + ch * a.cs;
                 __syncthreads();  // (a second item of this workgroup reuses the LDS rows)
-                if (it != rank) attn_prefetch(l, it);
                 const bool halo = g > 0 && i0f - (a.W - 1) < f0;
                 if (halo) {
                     if (tid == 0) s_ok = seg_spin_sys(&st->qkv_seq[g - 1][0], seq, &st->fail[0]);
                     __syncthreads();
                     if (!s_ok) return;
                 }
-                seg_attention(StepAttn{T, a.cs, a.W, 0, a.nkmax, a.rope_cos, a.rope_sin, Lw.qkv}, lnops, br, br * Tseg - f0, i0f / a.cs,
-                              halo, smem, kvl, xres, reinterpret_cast<float*>(hb3));
+                seg_attention(StepAttn{T, a.cs, a.W, 0, a.nkmax, a.rope_cos, a.rope_sin, Lw.qkv}, cond_ab + (size_t)br * a.cond_ld + (size_t)l * 2 * E,
+                              Lw.n3w, Lw.n3b, br, br * Tseg - f0, i0f / a.cs, halo, smem, kvl, xres, reinterpret_cast<float*>(hb3));
             }
-            if (rank >= nitems && wact) {  // workgroups without a chunk: warm the MLP weights into this XCD's L2 (step_warm)
+            // (segw bit 2: every workgroup requests its own MLP-up weight tiles into the L2 -- by the waves that did not store a
+            //  row in the LayerNorm tail (waves >= cs: nothing of theirs has to be in the L2 before the barrier))
+            const bool att_stored = rank < nitems && w < a.cs;
+            if ((segw & 4) && !att_stored)
+                seg_warm_tiles(wsink, Lw.mlp0_wt, KBE, rank, 32, kSNTU, rank < nitems ? w - a.cs : w, rank < nitems ? 8 - a.cs : 8, lane);
+            if (rank >= nitems && wact && (a.warm[1] | a.warm[2])) {  // workgroups without a chunk: warm the MLP weights into this XCD's L2 (step_warm)
                 const size_t wbytes = (size_t)E * ME * sizeof(float);
                 const int wi = (rank - nitems) * 8 + w, nw = ((int)n - nitems) * 8;
                 unsigned sink = 0;
@@ -1739,15 +1900,39 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 step_warm(sink, Lw.mlp2_wt, wbytes * a.warm[2] / 16, wi, nw, lane);
                 step_warm_done(sink);
             }
-            if (!end_phase(true)) return;
+            if (!end_phase((segw & 4) ? att_stored : true)) return;
             if (rank == 0 && tid == 0) __builtin_amdgcn_raw_buffer_store_b32(seq, step_rsrc(&st->att_seq[g][0]), 0, 0, 17);
             // ---- MLP up + GELU: column tiles rank + 32 j; the hidden layer as bf16 x 3 planes
-            {
+            // (segw bit 3: behind the phase's own operand requests every wave asks for a share of the workgroup's MLP-down weight
+            //  tiles -- the tile pair 2 (rank / 2), + 1, half each of the two row-half workgroups -- into the L2)
+            auto warm_down = [&] {
+                if (segw & 8) {
+                    if constexpr (MB == 6) seg_warm_tiles(wsink, Lw.mlp2_wt, KBM, 2 * (rank >> 1), 1, 2, 8 * (rank & 1) + w, 16, lane);
+                    else seg_warm_tiles(wsink, Lw.mlp2_wt, KBM, rank, 1, 1, w, 8, lane);
+                }
+            };
+            auto up_store = [&](const f32x4& o, const f32x4& bv, int rb, int j) {
+                p32_store4(mlp3, 16 * rb + (lane & 15), 16 * (rank + 32 * j) + 4 * (lane >> 4), ME / 32, gelu_erf(o[0] + bv[0]),
+                           gelu_erf(o[1] + bv[1]), gelu_erf(o[2] + bv[2]), gelu_erf(o[3] + bv[3]));
+            };
+            if constexpr (K8 > 0) {
+                f32x4 acc[6 * kSNTU];
+                // (epilogue operands before the GEMM: wave w finishes tile pp = w of either row half, wave 0 also pp = 8)
+                const f32x4 bv0 = *reinterpret_cast<const f32x4*>(Lw.mlp0_b + 16 * (rank + 32 * (w / 3)) + 4 * (lane >> 4));
+                const f32x4 bv1 = *reinterpret_cast<const f32x4*>(Lw.mlp0_b + 16 * (rank + 32 * (kSNTU - 1)) + 4 * (lane >> 4));
+                seg_run_k8<kSNTU, K8, SEG_DIAG>(acc, hb3_r, E / 32, step_rsrc(Lw.mlp0_wt), KBE, rank, 32, 2 * w, lane, warm_down);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    seg_partials_k8<kSNTU>(acc, r, red, w, lane);
+                    for (int pp = w; pp < 3 * kSNTU; pp += 8)
+                        up_store(seg_sum<8>(red, 3 * kSNTU, pp, lane), pp == w ? bv0 : bv1, 3 * r + pp % 3, pp / 3);
+                }
+            } else {
                 constexpr int NH = MB / 3, KS = 8 / NH, KQ = KBE / 2 / KS;
                 const int rh = w / KS, ks = w - rh * KS;
                 SegBuf<3, kSNTU> sb;
                 f32x4 acc[3 * kSNTU];
-                seg_load<3, kSNTU>(sb, 0, hb3_r, E / 32, 3 * rh, Lw.mlp0_wt, KBE, rank, 32, KQ * ks, lane, wact);
+                seg_load<3, kSNTU>(sb, 0, hb3_r, E / 32, 3 * rh, step_rsrc(Lw.mlp0_wt), KBE, rank, 32, KQ * ks, lane);
                 // (epilogue operands before the GEMM: wave w finishes tiles p = w, w + 8, w + 16)
                 f32x4 bvs[3];
 #pragma unroll
@@ -1756,17 +1941,14 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                     bvs[q] = p < 3 * kSNTU * NH ? *reinterpret_cast<const f32x4*>(Lw.mlp0_b + 16 * (rank + 32 * (pp / 3)) + 4 * (lane >> 4))
                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                seg_run<3, kSNTU, KQ, SEG_DIAG>(acc, sb, hb3_r, E / 32, 3 * rh, Lw.mlp0_wt, KBE, rank, 32, KQ * ks, lane, wact, [] {});
+                seg_run<3, kSNTU, KQ, SEG_DIAG>(acc, sb, hb3_r, E / 32, 3 * rh, step_rsrc(Lw.mlp0_wt), KBE, rank, 32, KQ * ks, lane, warm_down);
                 seg_partials<3 * kSNTU>(acc, red, w, lane);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const int p = w + 8 * q;
                     if (p >= 3 * kSNTU * NH) break;
-                    const int hh = p / (3 * kSNTU), pp = p - 3 * kSNTU * hh, j = pp / 3, ib = pp - 3 * j, tile = rank + 32 * j;
-                    const f32x4 bv = bvs[q];
-                    const f32x4 o = seg_sum<KS>(red + (size_t)hh * KS * 3 * kSNTU * 256, 3 * kSNTU, pp, lane);
-                    p32_store4(mlp3, 16 * (3 * hh + ib) + (lane & 15), 16 * tile + 4 * (lane >> 4), ME / 32, gelu_erf(o[0] + bv[0]),
-                               gelu_erf(o[1] + bv[1]), gelu_erf(o[2] + bv[2]), gelu_erf(o[3] + bv[3]));
+                    const int hh = p / (3 * kSNTU), pp = p - 3 * kSNTU * hh;
+                    up_store(seg_sum<KS>(red + (size_t)hh * KS * 3 * kSNTU * 256, 3 * kSNTU, pp, lane), bvs[q], 3 * hh + pp % 3, pp / 3);
                 }
             }
             if (!end_phase(true)) return;
@@ -1786,9 +1968,15 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 }
                 {
                     SegBuf<3, NTD> sb;
-                    seg_load<3, NTD>(sb, 0, mlp3_r, ME / 32, rb0, Lw.mlp2_wt, KBM, tile0, 1, (KBM / 16) * w, lane, wact);
-                    seg_run<3, NTD, KBM / 16, SEG_DIAG>(acc, sb, mlp3_r, ME / 32, rb0, Lw.mlp2_wt, KBM, tile0, 1, (KBM / 16) * w, lane, wact,
-                                              [&] { if (l + 1 < a.L) ln_prefetch(l + 1); });
+                    seg_load<3, NTD>(sb, 0, mlp3_r, ME / 32, rb0, step_rsrc(Lw.mlp2_wt), KBM, tile0, 1, (KBM / 16) * w, lane);
+                    seg_run<3, NTD, KBM / 16, SEG_DIAG>(acc, sb, mlp3_r, ME / 32, rb0, step_rsrc(Lw.mlp2_wt), KBM, tile0, 1, (KBM / 16) * w, lane,
+                                              [&] {
+                                                  if (l + 1 < a.L) ln_prefetch(l + 1);
+                                                  // (segw bit 1: ... and the workgroup's qkv weight tiles of the next layer /
+                                                  //  of the next step's first layer into the L2)
+                                                  if ((segw & 2) && (l + 1 < a.L || i + 1 < a.nsteps))
+                                                      seg_warm_tiles(wsink, a.layer[l + 1 < a.L ? l + 1 : 0].qkv_wt, KBE, rank, 32, 3, w, 8, lane);
+                                              });
                 }
 #pragma unroll
                 for (int j = 0; j < NTD; ++j) {
@@ -1834,6 +2022,22 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
         }
         if (i + 1 < a.nsteps && !end_phase(true)) return;
     }
+}
+
+// The placement census of the persistent samplers on its own (persist_prepare: a dry launch with their grid, block and LDS
+// footprint while the handle is being configured, so that the first real after_sample need not look at it synchronously)
+__global__ __launch_bounds__(512) void persist_census_kernel(StepSync* st, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (threadIdx.x != 0) return;
+    const unsigned xcc = step_xcc_id();
+    __hip_atomic_fetch_add(&st->pop[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&st->census[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    step_spin(&st->census[0], gridDim.x, &st->fail[0]);
+    unsigned bad = 0;
+    for (int x = 0; x < 8; ++x) bad |= __hip_atomic_load(&st->pop[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 32u;
+    if (dbg & 8) bad = 1;
+    if (bad) __hip_atomic_store(&st->fail[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (smem[0] == 12345.f) st->census[1] = 1;  // (keeps the dynamic LDS allocation alive)
 }
 
 // W [N][K] (row stride ldw) -> 16 x 16 tiles [N / 16][K / 16][256] in MFMA fragment order (t16_off)
@@ -1913,23 +2117,27 @@ struct after_denoiser {
     // persistent streaming step (stream_step_kernel): one launch per cached Euler step.  AFTER_STREAM_PERSIST=0 /
     // after_denoiser_set_stream_persist(h, 0) keep the launch-per-kernel path.
     int persist_step = 1, n_cus = 0;
-    int persist_offline = 0;  // AFTER_SAMPLE_PERSIST / after_denoiser_set_sample_persist: one clip's offline sampler as sample_seg_kernel
+    int persist_offline = 1;  // AFTER_SAMPLE_PERSIST=0 / after_denoiser_set_sample_persist(h, 0): one clip's offline sampler by launches instead of sample_seg_kernel
     float* seg_qkv = nullptr;  // [L][3 max_T][3E]: per-layer qkv rows of the segment sampler
     unsigned short* seg_act3 = nullptr;  // bf16 x 3 planes of h and of the MLP hidden layer, one slice per XCD
     bool last_seg = false;     // the last after_sample ran as sample_seg_kernel
-    bool step_validated = false;  // the placement census of a persistent launch has been looked at (first use: synchronously)
+    // persist_prepare (called by create / enable_cache / set_*_persist, never by after_sample) has allocated the persistent
+    // samplers' buffers, re-tiled the weights and seen a clean placement census: only then does a call take those paths
+    bool step_ready = false;
+    int dev = 0;                   // the device the handle lives on
+    hipEvent_t step_ev = nullptr;  // recorded behind the copy of the failure words of the last persistent launch
+    bool step_pending = false;     // ... and not looked at yet
+    int persist_check = 0;         // after_denoiser_set_persist_check: 1 = every persistent call synchronises and reports its own failure
     int step_dbg = 0;  // after_denoiser_set_stream_persist(h, 1 | dbg << 8): diagnostics bits OR-ed into AFTER_STEP_DBG
     StepSync* step_sync = nullptr;       // [max_steps]: one barrier state per step of a sample() call
     unsigned long long* step_trace = nullptr;  // AFTER_STEP_TRACE=1: stamps of the LAST step launched (diagnostics)
-    unsigned* step_fail = nullptr;       // pinned host copy of the last call's failure words (checked at the next call)
-    int step_fail_n = 0;
+    unsigned* step_fail = nullptr;       // pinned host copy of the device's sticky failure words (persist_poll)
     float *step_wt = nullptr, *step_act = nullptr;  // 16 x 16-tiled weight copies; per-XCD tiled activation slices
     const float *step_patch_wt = nullptr, *step_out_wt = nullptr;
     struct StepLayerW {
         const float *qkv, *mlp0, *mlp2;
     };
     std::vector<StepLayerW> step_layers;
-    size_t step_lds[3] = {0, 0, 0};
 };
 
 namespace {
@@ -2207,6 +2415,11 @@ int check_shape(after_denoiser* h, int rows, int T) {
 
 }  // namespace
 
+namespace {
+int persist_prepare(after_denoiser* h, bool offline);
+int persist_poll(after_denoiser* h, hipStream_t s, bool wait);
+}
+
 extern "C" int after_denoiser_create(const after_denoiser_cfg* cfg, const float* const* weights,
                                      int n_weights, int max_rows, int max_T, int max_steps,
                                      after_denoiser** out) {
@@ -2455,10 +2668,15 @@ extern "C" int after_denoiser_create(const after_denoiser_cfg* cfg, const float*
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(AFTER_E_HIP);
         h->n_cus = prop.multiProcessorCount;
+        h->dev = dev;
     }
     if (hipDeviceSynchronize() != hipSuccess) return fail(AFTER_E_HIP);
 #undef TAKE
 #undef TRY_OR_FAIL
+    if (h->persist_offline) {  // the offline persistent sampler's buffers + placement census, now (never in after_sample)
+        const int rc = persist_prepare(h, true);
+        if (rc != AFTER_OK) return fail(rc);
+    }
     *out = h;
     return AFTER_OK;
 }
@@ -2479,6 +2697,7 @@ extern "C" void after_denoiser_destroy(after_denoiser* h) {
     if (h->step_sync) (void)hipFree(h->step_sync);
     if (h->step_trace) (void)hipFree(h->step_trace);
     if (h->step_fail) (void)hipHostFree(h->step_fail);
+    if (h->step_ev) (void)hipEventDestroy(h->step_ev);
     if (h->step_wt) (void)hipFree(h->step_wt);
     if (h->step_act) (void)hipFree(h->step_act);
     if (h->seg_qkv) (void)hipFree(h->seg_qkv);
@@ -2573,106 +2792,229 @@ int roll_cache_step(after_denoiser* h, hipStream_t s, int rows, int T, int size,
 bool step_persist_ok(const after_denoiser* h, int B, int T, int nb_steps) {
     const bool wide = h->W < 0 || !h->cfg.causal;
     const int cpg = (B + 7) / 8;
-    return h->persist_step && h->cache > 0 && (!h->timer.enabled || h->timer_kernel == 3) && h->x6 != 2 && h->E == kSE && h->ME == kSME &&
+    return h->persist_step && h->step_ready && h->cache > 0 && (!h->timer.enabled || h->timer_kernel == 3) && h->x6 != 2 && h->E == kSE && h->ME == kSME &&
            h->H == kSH && h->L <= 8 && !wide && h->Cp == h->C && h->C % 16 == 0 && h->C / 16 <= 8 && h->n_cus == 256 &&
            nb_steps <= 128 &&    // (the flip bits of the argument block)
            3 * cpg * T <= 32 &&  // (two 16-row blocks: the LDS budget of the partial tiles)
            ((size_t)h->cs * (h->E + 4) + (size_t)kSH * 2 * (h->W - 1 + h->cs) * 16) <= 7168;
 }
 
-int step_tile_weights(after_denoiser* h, hipStream_t s) {
-    const size_t E = h->E, ME = h->ME, C = h->C;
-    const size_t per_layer = 3 * E * E + ME * E + E * ME;
-    const size_t total = E * C + C * E + per_layer * h->L;
-    AFTER_HIP_CHECK(hipMalloc(&h->step_wt, total * sizeof(float)));
-    float* p = h->step_wt;
-    auto tile = [&](const float* w, int N, int K) -> const float* {
-        float* out = p;
-        hipLaunchKernelGGL(tile16_kernel, dim3((unsigned)cdivll((long long)N * K / 4, 256)), dim3(256), 0, s, w, K, out, N, K);
-        p += (size_t)N * K;
-        return out;
-    };
-    h->step_patch_wt = tile(h->patch_w, (int)E, (int)C);
-    h->step_out_wt = tile(h->out_w, (int)C, (int)E);
-    h->step_layers.resize(h->L);
-    for (int l = 0; l < h->L; ++l) {
-        const LayerW& w = h->layers[l];
-        h->step_layers[l] = {tile(w.qkv_w, 3 * (int)E, (int)E), tile(w.mlp0_w, (int)ME, (int)E), tile(w.mlp2_w, (int)E, (int)ME)};
+// The geometry a persistent sampler can take at all (call-independent part of step_persist_ok / sample_seg_ok)
+bool persist_geometry_ok(const after_denoiser* h) {
+    const bool wide = h->W < 0 || !h->cfg.causal;
+    return h->E == kSE && h->ME == kSME && h->H == kSH && h->L <= 8 && !wide && h->Cp == h->C && h->C % 16 == 0 &&
+           h->C / 16 <= 8 && h->n_cus == 256;
+}
+
+// One persistent kernel in flight per device and process.  The samplers spin on XCD-local barriers, i.e. they need all 256
+// workgroups resident at once: two of them enqueued on different streams (two handles) could each take part of the CUs and
+// starve each other until the spin limit.  A persistent launch therefore waits (on the device: hipStreamWaitEvent) for the
+// previous persistent launch of ANY stream of this process on the device.  Kernels of other processes sharing the GPU are
+// outside this guard: such deployments select the launch path (AFTER_STREAM_PERSIST=0, AFTER_SAMPLE_PERSIST=0).
+struct PersistGuard {
+    std::mutex mu;
+    hipEvent_t ev[16] = {};
+    hipStream_t last[16] = {};
+    bool have[16] = {};
+};
+PersistGuard g_persist;
+
+struct PersistLaunch {  // brackets one persistent launch on stream s
+    std::unique_lock<std::mutex> lock;
+    int dev;
+    hipStream_t s;
+    PersistLaunch(int dev_, hipStream_t s_) : lock(g_persist.mu), dev(dev_ & 15), s(s_) {
+        if (g_persist.have[dev] && g_persist.last[dev] != s && hipEventQuery(g_persist.ev[dev]) == hipErrorNotReady)
+            (void)hipStreamWaitEvent(s, g_persist.ev[dev], 0);
+        (void)hipGetLastError();
     }
-    AFTER_HIP_CHECK(hipGetLastError());
-    // tiled activation slices: 8 XCDs x kSGroupRows rows x (pat, xres, h: E; mlp: ME)
-    AFTER_HIP_CHECK(hipMalloc(&h->step_act, (size_t)8 * kSGroupRows * (3 * E + ME) * sizeof(float)));
-    AFTER_HIP_CHECK(hipMemsetAsync(h->step_act, 0, (size_t)8 * kSGroupRows * (3 * E + ME) * sizeof(float), s));
+    ~PersistLaunch() {
+        if (!g_persist.ev[dev] && hipEventCreateWithFlags(&g_persist.ev[dev], hipEventDisableTiming) != hipSuccess) return;
+        if (hipEventRecord(g_persist.ev[dev], s) == hipSuccess) {
+            g_persist.last[dev] = s;
+            g_persist.have[dev] = true;
+        }
+    }
+};
+
+bool stream_is_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return st != hipStreamCaptureStatusNone;
+}
+
+void persist_off(after_denoiser* h) {
+    h->persist_step = 0;
+    h->persist_offline = 0;
+    h->step_ready = false;
+}
+
+// Everything the persistent samplers need beyond the launch path's buffers -- barrier state, the pinned failure words and
+// their event, 16 x 16-tiled copies of the weights (+ 54 MB at base width), per-XCD activation slices, and for the offline
+// segment sampler its qkv rows and bf16-plane slices -- plus a DRY placement census, synchronously.  Called while a handle
+// is being configured (after_denoiser_create / _enable_cache / _set_stream_persist / _set_sample_persist), never by
+// after_sample: a call that does the path's work neither allocates nor synchronises.  All-or-nothing: allocations go to
+// locals and are committed together; if anything fails they are released, the persistent paths are switched off and the
+// launch path serves the handle (not an error: the persistent samplers are an acceleration, not a capability).
+int persist_prepare(after_denoiser* h, bool offline) {
+    if (!persist_geometry_ok(h)) return AFTER_OK;
+    AFTER_TRY(persist_poll(h, nullptr, true));  // (a failure nobody has looked at yet is reported, not wiped, by re-enabling)
+    const size_t E = h->E, ME = h->ME, C = h->C;
+    if (!h->step_sync) {
+        StepSync* sync = nullptr;
+        unsigned* failw = nullptr;
+        hipEvent_t ev = nullptr;
+        unsigned long long* trace = nullptr;
+        float *wt = nullptr, *act = nullptr;
+        const size_t per_layer = 3 * E * E + ME * E + E * ME;
+        const size_t total = E * C + C * E + per_layer * h->L;
+        const size_t nact = (size_t)8 * kSGroupRows * (3 * E + ME);
+        const char* tr = getenv("AFTER_STEP_TRACE");
+        bool ok = hipMalloc(&sync, sizeof(StepSync)) == hipSuccess &&
+                  hipHostMalloc(&failw, 32 * sizeof(unsigned), hipHostMallocDefault) == hipSuccess &&
+                  hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess &&
+                  hipMalloc(&wt, total * sizeof(float)) == hipSuccess && hipMalloc(&act, nact * sizeof(float)) == hipSuccess;
+        if (ok && tr && atoi(tr) != 0) ok = hipMalloc(&trace, (size_t)h->n_cus * 128 * sizeof(unsigned long long)) == hipSuccess;
+        if (ok) ok = hipMemset(act, 0, nact * sizeof(float)) == hipSuccess && hipMemset(sync, 0, sizeof(StepSync)) == hipSuccess;
+        std::vector<after_denoiser::StepLayerW> layers;
+        const float *patch_wt = nullptr, *out_wt = nullptr;
+        if (ok) {
+            float* p = wt;
+            auto tile = [&](const float* w, int N, int K) -> const float* {
+                float* out = p;
+                hipLaunchKernelGGL(tile16_kernel, dim3((unsigned)cdivll((long long)N * K / 4, 256)), dim3(256), 0, nullptr, w, K, out, N, K);
+                p += (size_t)N * K;
+                return out;
+            };
+            patch_wt = tile(h->patch_w, (int)E, (int)C);
+            out_wt = tile(h->out_w, (int)C, (int)E);
+            for (int l = 0; l < h->L; ++l) {
+                const LayerW& w = h->layers[l];
+                layers.push_back({tile(w.qkv_w, 3 * (int)E, (int)E), tile(w.mlp0_w, (int)ME, (int)E), tile(w.mlp2_w, (int)E, (int)ME)});
+            }
+            ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+        }
+        if (!ok) {
+            (void)hipGetLastError();
+            if (sync) (void)hipFree(sync);
+            if (failw) (void)hipHostFree(failw);
+            if (ev) (void)hipEventDestroy(ev);
+            if (trace) (void)hipFree(trace);
+            if (wt) (void)hipFree(wt);
+            if (act) (void)hipFree(act);
+            persist_off(h);
+            return AFTER_OK;
+        }
+        memset(failw, 0, 32 * sizeof(unsigned));
+        h->step_sync = sync, h->step_fail = failw, h->step_ev = ev, h->step_trace = trace, h->step_wt = wt, h->step_act = act;
+        h->step_patch_wt = patch_wt, h->step_out_wt = out_wt;
+        h->step_layers = std::move(layers);
+    }
+    if (offline && !h->seg_qkv) {
+        float* q = nullptr;
+        unsigned short* a3 = nullptr;
+        const size_t n3 = (size_t)8 * kSGroupRows * 3 * (E + ME);
+        const bool ok = hipMalloc(&q, (size_t)h->L * 3 * h->max_T * 3 * E * sizeof(float)) == hipSuccess &&
+                        hipMalloc(&a3, n3 * sizeof(unsigned short)) == hipSuccess && hipMemset(a3, 0, n3 * sizeof(unsigned short)) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            if (q) (void)hipFree(q);
+            if (a3) (void)hipFree(a3);
+            h->persist_offline = 0;
+            return AFTER_OK;
+        }
+        h->seg_qkv = q, h->seg_act3 = a3;
+    }
+    // the kernels' dynamic LDS limits (a hipFuncSetAttribute inside after_sample would be one more first-call cost)
+    {
+        const size_t lds_seg = ((size_t)kSRedFloats(2) + 8 * 2 * kAttnKeyBlock * 64) * sizeof(float);
+        const void* fns[] = {reinterpret_cast<const void*>(sample_seg_kernel<6, 0>), reinterpret_cast<const void*>(sample_seg_kernel<6, 2>),
+                             reinterpret_cast<const void*>(sample_seg_kernel<6, 3>), reinterpret_cast<const void*>(sample_seg_kernel<3, 0>),
+                             reinterpret_cast<const void*>(persist_census_kernel)};
+        for (const void* fn : fns) AFTER_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_seg));
+        const void* sf[] = {reinterpret_cast<const void*>(stream_step_kernel<1>), reinterpret_cast<const void*>(stream_step_kernel<2>),
+                            reinterpret_cast<const void*>(stream_step_kernel<3>)};
+        for (int mb = 1; mb <= 3; ++mb) {
+            const size_t lds = ((size_t)kSRedFloats(mb) + 8 * 2 * kAttnKeyBlock * 64) * sizeof(float);
+            AFTER_HIP_CHECK(hipFuncSetAttribute(sf[mb - 1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        // dry census with the samplers' launch geometry
+        AFTER_HIP_CHECK(hipDeviceSynchronize());
+        AFTER_HIP_CHECK(hipMemset(h->step_sync, 0, sizeof(StepSync)));
+        static int dbg_env = -1;
+        if (dbg_env < 0) {
+            const char* e = getenv("AFTER_STEP_DBG");
+            dbg_env = e ? atoi(e) : 0;
+        }
+        {
+            PersistLaunch guard(h->dev, nullptr);
+            hipLaunchKernelGGL(persist_census_kernel, dim3(h->n_cus), dim3(512), lds_seg, nullptr, h->step_sync, dbg_env | h->step_dbg);
+        }
+        AFTER_HIP_CHECK(hipGetLastError());
+        AFTER_HIP_CHECK(hipMemcpy(h->step_fail, &h->step_sync->fail[0], 32 * sizeof(unsigned), hipMemcpyDeviceToHost));
+        h->step_ready = !(h->step_fail[0] | h->step_fail[1]);
+        h->step_pending = false;
+        if (!h->step_ready) {
+            h->step_fail[0] = h->step_fail[1] = 0;
+            AFTER_HIP_CHECK(hipMemset(&h->step_sync->fail[0], 0, 32 * sizeof(unsigned)));
+        }
+    }
     return AFTER_OK;
 }
 
-int step_check_failure(after_denoiser* h) {
-    if (h->step_fail && h->step_fail_n > 0 && (h->step_fail[0] || h->step_fail[1])) {
+// The device's sticky failure words, copied to pinned memory behind every persistent launch.  `wait`: synchronise with that
+// copy (after_denoiser_check, persist_check mode); otherwise look only if it has completed -- the words are sticky and
+// every later launch refuses to run behind them, so a copy that is still in flight is simply seen by a later poll.
+// A failure switches the handle to the launch path, clears the words (on `s`) and is reported as AFTER_E_HIP.
+int persist_poll(after_denoiser* h, hipStream_t s, bool wait) {
+    if (!h->step_pending) return AFTER_OK;
+    if (wait) {
+        AFTER_HIP_CHECK(hipEventSynchronize(h->step_ev));
+    } else {
+        const hipError_t q = hipEventQuery(h->step_ev);
+        if (q == hipErrorNotReady) return AFTER_OK;
+        AFTER_HIP_CHECK(q);
+    }
+    h->step_pending = false;
+    if (h->step_fail[0] | h->step_fail[1]) {
         const bool census = h->step_fail[1] != 0;
-        h->persist_step = 0;
-        h->persist_offline = 0;
-        h->step_fail_n = 0;
+        persist_off(h);
         h->step_fail[0] = h->step_fail[1] = 0;
-        set_error("persistent sampler: %s; the launch-per-kernel path is selected from now on (the previous result is "
-                  "invalid: reset the streamer / repeat the call)",
+        AFTER_HIP_CHECK(hipMemsetAsync(&h->step_sync->fail[0], 0, 32 * sizeof(unsigned), s));
+        set_error("persistent sampler: %s; the launch-per-kernel path is selected from now on (every result since the failing "
+                  "call is invalid: reset the streamer / repeat the calls)",
                   census ? "the workgroups were not placed 32 per XCD" : "a barrier or a neighbour flag timed out");
         return AFTER_E_HIP;
     }
     return AFTER_OK;
 }
 
-// First persistent launch of a handle: look at the placement census NOW (one stream synchronisation) instead of at the next
-// call.  A kernel that did not find 32 workgroups on each of 8 XCDs returned before touching anything, so the caller can run
-// the same call on the launch path: kStepRetry.  (Placement is a property of the device and the runtime, not of the call:
-// once seen, it is not checked synchronously again; barrier time-outs keep the report-at-the-next-call protocol.)
-constexpr int kStepRetry = 1;
-int step_validate_first(after_denoiser* h, hipStream_t s) {
-    if (h->step_validated) return AFTER_OK;
-    AFTER_HIP_CHECK(hipStreamSynchronize(s));
-    if (h->step_fail[1]) {
-        h->persist_step = 0;
-        h->persist_offline = 0;
-        h->step_fail_n = 0;
-        h->step_fail[0] = h->step_fail[1] = 0;
-        return kStepRetry;
-    }
-    if (h->step_fail[0]) return step_check_failure(h);
-    h->step_validated = true;
-    return AFTER_OK;
+// behind a persistent launch on s: failure words -> pinned memory, event
+int persist_published(after_denoiser* h, hipStream_t s) {
+    AFTER_HIP_CHECK(hipMemcpyAsync(h->step_fail, &h->step_sync->fail[0], 32 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    AFTER_HIP_CHECK(hipEventRecord(h->step_ev, s));
+    h->step_pending = true;
+    return h->persist_check ? persist_poll(h, s, true) : AFTER_OK;
 }
 
-int step_alloc(after_denoiser* h, hipStream_t s) {
-    if (h->step_sync) return AFTER_OK;
-    AFTER_HIP_CHECK(hipMalloc(&h->step_sync, sizeof(StepSync)));
-    AFTER_HIP_CHECK(hipHostMalloc(&h->step_fail, 32 * sizeof(unsigned), hipHostMallocDefault));
-    memset(h->step_fail, 0, 32 * sizeof(unsigned));
-    const char* tr = getenv("AFTER_STEP_TRACE");
-    if (tr && atoi(tr) != 0) AFTER_HIP_CHECK(hipMalloc(&h->step_trace, (size_t)h->n_cus * 128 * sizeof(unsigned long long)));
-    return step_tile_weights(h, s);
-}
+constexpr int kStepRetry = 1;  // (sample_seg in persist_check mode: the kernel refused or failed -- rerun the call by launches)
 
 int sample_persistent(after_denoiser* h, hipStream_t s, const float* x0, float* out, int B, int T, int nb_steps) {
     const int rows = 3 * B, E = h->E, L = h->L;
-    AFTER_TRY(step_check_failure(h));  // the previous call's flags (a late flag is seen one call later)
-    AFTER_TRY(step_alloc(h, s));
     const int cpg = (B + 7) / 8, MB = (3 * cpg * T + 15) / 16;
     const int nkmax = h->W - 1 + h->cs > h->cs ? h->W - 1 + h->cs : h->cs;
     const size_t attn_lds = ((size_t)h->cs * (E + 4) + (size_t)kSH * 2 * nkmax * 16) * sizeof(float);
     AFTER_REQUIRE(attn_lds <= 7168 * sizeof(float), AFTER_E_INVALID, "persistent step: attention LDS %zu exceeds the slot", attn_lds);
     const size_t lds = ((size_t)kSRedFloats(MB) + 8 * 2 * kAttnKeyBlock * 64) * sizeof(float);  // + the K / V landing zones
-    const void* fn = MB == 1 ? reinterpret_cast<const void*>(stream_step_kernel<1>)
-                             : (MB == 2 ? reinterpret_cast<const void*>(stream_step_kernel<2>)
-                                        : reinterpret_cast<const void*>(stream_step_kernel<3>));
-    if (lds > h->step_lds[MB - 1]) {
-        AFTER_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        h->step_lds[MB - 1] = lds;
-    }
     {
         dim3 grid(cdiv(T, 32), cdiv(h->Cp, 32), B);
         hipLaunchKernelGGL(to_token_major_kernel, grid, dim3(256), 0, s, x0, h->xt, (const int*)nullptr, h->C, T, h->Cp, 0.f);
         AFTER_HIP_CHECK(hipGetLastError());
     }
-    AFTER_HIP_CHECK(hipMemsetAsync(h->step_sync, 0, sizeof(StepSync), s));
+    AFTER_HIP_CHECK(hipMemsetAsync(h->step_sync, 0, offsetof(StepSync, fail), s));  // (not the sticky failure words)
     const size_t slice = (size_t)8 * kSGroupRows * E;
     {
         StepArgs a;
@@ -2716,9 +3058,12 @@ int sample_persistent(after_denoiser* h, hipStream_t s, const float* x0, float* 
         }
         const bool timed = h->timer.enabled && h->timer_kernel == 3;
         if (timed) h->timer.begin(s);
-        if (MB == 1) hipLaunchKernelGGL(stream_step_kernel<1>, dim3(h->n_cus), dim3(512), lds, s, a);
-        else if (MB == 2) hipLaunchKernelGGL(stream_step_kernel<2>, dim3(h->n_cus), dim3(512), lds, s, a);
-        else hipLaunchKernelGGL(stream_step_kernel<3>, dim3(h->n_cus), dim3(512), lds, s, a);
+        {
+            PersistLaunch guard(h->dev, s);
+            if (MB == 1) hipLaunchKernelGGL(stream_step_kernel<1>, dim3(h->n_cus), dim3(512), lds, s, a);
+            else if (MB == 2) hipLaunchKernelGGL(stream_step_kernel<2>, dim3(h->n_cus), dim3(512), lds, s, a);
+            else hipLaunchKernelGGL(stream_step_kernel<3>, dim3(h->n_cus), dim3(512), lds, s, a);
+        }
         AFTER_HIP_CHECK(hipGetLastError());
         if (timed) {  // flops of the GEMMs; algorithmic bytes = every weight once per Euler step (the activations are KBs)
             const double M = (double)rows * T, Ed = E, MEd = h->ME, Cd = h->C;
@@ -2728,13 +3073,8 @@ int sample_persistent(after_denoiser* h, hipStream_t s, const float* x0, float* 
         }
         for (int i = 0; i < nb_steps; ++i) h->flip[i] ^= 1;
     }
-    // failure words -> pinned host memory, looked at when the next call starts
-    AFTER_HIP_CHECK(hipMemcpyAsync(h->step_fail, &h->step_sync[0].fail[0], 32 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
-    h->step_fail_n = 1;
-    const int rc = step_validate_first(h, s);
-    if (rc == kStepRetry)
-        for (int i = 0; i < nb_steps; ++i) h->flip[i] ^= 1;  // nothing was rolled
-    return rc;
+    // failure words -> pinned host memory, looked at by the next call (or by this one: after_denoiser_set_persist_check)
+    return persist_published(h, s);
 }
 
 // RectifiedFlow.sample for ONE clip as one persistent launch (sample_seg_kernel): eligible for the shipped width (embed
@@ -2743,7 +3083,7 @@ int sample_persistent(after_denoiser* h, hipStream_t s, const float* x0, float* 
 bool sample_seg_ok(const after_denoiser* h, int B, int T, int nb_steps) {
     const bool wide = h->W < 0 || !h->cfg.causal;
     const int Tseg = T / 8;
-    return h->persist_offline && h->cache == 0 && B == 1 && (!h->timer.enabled || h->timer_kernel == 3) && !h->use_graph &&
+    return h->persist_offline && h->step_ready && h->seg_qkv && h->cache == 0 && B == 1 && (!h->timer.enabled || h->timer_kernel == 3) && !h->use_graph &&
            h->x6 != 0 && h->E == kSE && h->ME == kSME && h->H == kSH && h->L <= 8 && !wide && h->Cp == h->C && h->C % 16 == 0 &&
            h->C / 16 <= 4 && h->n_cus == 256 && T % 8 == 0 && (Tseg == 16 || Tseg == 32) && Tseg % h->cs == 0 &&
            h->W - 1 <= Tseg && nb_steps >= 1 && T <= h->max_T &&
@@ -2752,29 +3092,14 @@ bool sample_seg_ok(const after_denoiser* h, int B, int T, int nb_steps) {
 
 int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, int T, int nb_steps) {
     const int E = h->E, L = h->L, Tseg = T / 8, MB = 3 * Tseg / 16;
-    AFTER_TRY(step_check_failure(h));
-    AFTER_TRY(step_alloc(h, s));
-    if (!h->seg_qkv) AFTER_HIP_CHECK(hipMalloc(&h->seg_qkv, (size_t)L * 3 * h->max_T * 3 * E * sizeof(float)));
-    if (!h->seg_act3) {
-        const size_t n3 = (size_t)8 * kSGroupRows * 3 * (E + h->ME);
-        AFTER_HIP_CHECK(hipMalloc(&h->seg_act3, n3 * sizeof(unsigned short)));
-        AFTER_HIP_CHECK(hipMemsetAsync(h->seg_act3, 0, n3 * sizeof(unsigned short), s));
-    }
     const int nkmax = h->W - 1 + h->cs > h->cs ? h->W - 1 + h->cs : h->cs;
     const size_t lds = ((size_t)kSRedFloats(2) + 8 * 2 * kAttnKeyBlock * 64) * sizeof(float);
-    static size_t attr[2] = {0, 0};
-    if (lds > attr[MB == 6]) {
-        AFTER_HIP_CHECK(hipFuncSetAttribute(MB == 6 ? reinterpret_cast<const void*>(sample_seg_kernel<6>)
-                                                    : reinterpret_cast<const void*>(sample_seg_kernel<3>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr[MB == 6] = lds;
-    }
     {
         dim3 grid(cdiv(T, 32), cdiv(h->Cp, 32), 1);
         hipLaunchKernelGGL(to_token_major_kernel, grid, dim3(256), 0, s, x0, h->xt, (const int*)nullptr, h->C, T, h->Cp, 0.f);
         AFTER_HIP_CHECK(hipGetLastError());
     }
-    AFTER_HIP_CHECK(hipMemsetAsync(h->step_sync, 0, sizeof(StepSync), s));
+    AFTER_HIP_CHECK(hipMemsetAsync(h->step_sync, 0, offsetof(StepSync, fail), s));  // (not the sticky failure words)
     const size_t slice = (size_t)8 * kSGroupRows * E;
     StepArgs a;
     memset(&a, 0, sizeof(a));
@@ -2816,8 +3141,21 @@ int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, in
     }
     const bool timed = h->timer.enabled && h->timer_kernel == 3;
     if (timed) h->timer.begin(s);
-    if (MB == 6) hipLaunchKernelGGL(sample_seg_kernel<6>, dim3(h->n_cus), dim3(512), lds, s, a);
-    else hipLaunchKernelGGL(sample_seg_kernel<3>, dim3(h->n_cus), dim3(512), lds, s, a);
+    static int k8 = -1, segw = -1;
+    if (k8 < 0) {
+        const char* e = getenv("AFTER_SEG_K8");
+        k8 = e ? atoi(e) : 0;
+        e = getenv("AFTER_SEG_W");
+        segw = e ? atoi(e) : 0;
+    }
+    a.segw = segw;
+    {
+        PersistLaunch guard(h->dev, s);
+        if (MB == 6 && k8 == 2) hipLaunchKernelGGL((sample_seg_kernel<6, 2>), dim3(h->n_cus), dim3(512), lds, s, a);
+        else if (MB == 6 && k8) hipLaunchKernelGGL((sample_seg_kernel<6, 3>), dim3(h->n_cus), dim3(512), lds, s, a);
+        else if (MB == 6) hipLaunchKernelGGL((sample_seg_kernel<6, 0>), dim3(h->n_cus), dim3(512), lds, s, a);
+        else hipLaunchKernelGGL((sample_seg_kernel<3, 0>), dim3(h->n_cus), dim3(512), lds, s, a);
+    }
     AFTER_HIP_CHECK(hipGetLastError());
     if (timed) {
         const double M = 3.0 * T, Ed = E, MEd = h->ME, Cd = h->C;
@@ -2825,9 +3163,10 @@ int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, in
         const double fl = 2.0 * ((double)T * Ed * h->Cp + M * (Cd * Ed + L * (3 * Ed * Ed + 2 * Ed * MEd)));
         h->timer.end(s, nb_steps * fl, nb_steps * 4.0 * wts);
     }
-    AFTER_HIP_CHECK(hipMemcpyAsync(h->step_fail, &h->step_sync[0].fail[0], 32 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
-    h->step_fail_n = 1;
-    return step_validate_first(h, s);
+    const int rc = persist_published(h, s);
+    // (persist_check mode: the failing call itself is seen -- the offline sampler has no state, so the same call can be
+    //  served by launches; the handle stays on the launch path and the error text is kept for after_last_error)
+    return rc == AFTER_E_HIP && h->persist_check ? kStepRetry : rc;
 }
 
 // The whole sampler as a sequence of launches on `s` (eager path and graph capture body).
@@ -2841,23 +3180,23 @@ int sample_enqueue(after_denoiser* h, hipStream_t s, const float* x0, const floa
     AFTER_TRY(compute_cond_ab(h, s, nb_steps, rows, nullptr, nullptr, nb_steps, cond,
                               h->maps + 2 * h->ms, drop_value));
     h->last_seg = false;
-    if (sample_seg_ok(h, B, T, nb_steps)) {
+    // the sticky failure words of earlier persistent launches, if their copy has landed (AFTER_E_HIP once, then launches)
+    AFTER_TRY(persist_poll(h, s, false));
+    // (a persistent kernel cannot be a captured graph node of somebody else's graph: no event protocol, no co-residency guard)
+    const bool capturing = (h->persist_step || h->persist_offline) && h->step_ready && stream_is_capturing(s);
+    if (!capturing && sample_seg_ok(h, B, T, nb_steps)) {
         const int rc = sample_seg(h, s, x0, out, T, nb_steps);
         if (rc != kStepRetry) {
             h->last_seg = rc == AFTER_OK;
             return rc;
         }
     }
-    if (step_persist_ok(h, B, T, nb_steps)) {
-        const int rc = sample_persistent(h, s, x0, out, B, T, nb_steps);
-        if (rc != kStepRetry) {
-            AFTER_TRY(rc);
-            h->have_last = true;
-            h->last_rows = rows;
-            h->last_T = T;
-            h->last_steps = nb_steps;
-            return AFTER_OK;
-        }
+    if (!capturing && step_persist_ok(h, B, T, nb_steps)) {
+        h->have_last = true;
+        h->last_rows = rows;
+        h->last_T = T;
+        h->last_steps = nb_steps;
+        return sample_persistent(h, s, x0, out, B, T, nb_steps);
     }
     const size_t step_stride = (size_t)rows * h->L * 2 * h->E;
     // Fused tail: out_proj + CFG + Euler in ONE GEMM launch that also leaves the new latents in
@@ -3004,17 +3343,29 @@ extern "C" int after_denoiser_set_gemm_path(after_denoiser* h, int mode, int min
 extern "C" int after_denoiser_set_stream_persist(after_denoiser* h, int enable) {
     AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
     h->persist_step = (enable & 0xff) != 0;
-    if (h->step_dbg != (enable >> 8)) h->step_validated = false;
     h->step_dbg = enable >> 8;  // (diagnostics: bit 3 = a failed placement census, as tests/test_stream_persist_gpu.py simulates)
+    // enabling (re-)prepares: buffers on first use, and always a fresh placement census (also after a reported failure)
+    if (h->persist_step && h->cache > 0) return persist_prepare(h, false);
     return AFTER_OK;
 }
 
 extern "C" int after_denoiser_set_sample_persist(after_denoiser* h, int enable) {
     AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
     h->persist_offline = (enable & 0xff) != 0;
-    if (h->step_dbg != (enable >> 8)) h->step_validated = false;
     h->step_dbg = enable >> 8;
+    if (h->persist_offline) return persist_prepare(h, true);
     return AFTER_OK;
+}
+
+extern "C" int after_denoiser_set_persist_check(after_denoiser* h, int mode) {
+    AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
+    h->persist_check = mode != 0;
+    return AFTER_OK;
+}
+
+extern "C" int after_denoiser_check(after_denoiser* h, void* stream) {
+    AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
+    return persist_poll(h, (hipStream_t)stream, true);
 }
 
 extern "C" int after_denoiser_sample_persist(after_denoiser* h, int* active) {
@@ -3081,6 +3432,7 @@ extern "C" int after_denoiser_enable_cache(after_denoiser* h, int cache_size, in
     h->cache_rows = max_rows;
     h->flip.assign(max_steps, 0);
     h->have_last = false;
+    if (h->persist_step) AFTER_TRY(persist_prepare(h, false));  // (here, not in the first after_sample: see persist_prepare)
     return AFTER_OK;
 }
 

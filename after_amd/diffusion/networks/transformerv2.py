@@ -221,6 +221,8 @@ class DenoiserV2(nn.Module):
             _lib.check(L.after_denoiser_set_stream_persist(out, int(self._stream_persist)), "after_denoiser_set_stream_persist")
         if getattr(self, "_sample_persist", None) is not None:
             _lib.check(L.after_denoiser_set_sample_persist(out, int(self._sample_persist)), "after_denoiser_set_sample_persist")
+        if getattr(self, "_persist_check", None) is not None:
+            _lib.check(L.after_denoiser_set_persist_check(out, int(self._persist_check)), "after_denoiser_set_persist_check")
         if self._stream_args is not None and not getattr(self, "_enabling", False):
             # the handle was rebuilt (.to(), load_state_dict, refresh): a Streamer still expects
             # its K/V caches -- re-create them (zeroed = a new stream), as AutoEncoder / Encoder1D do
@@ -381,6 +383,20 @@ class DenoiserV2(nn.Module):
         if self._handle is not None:
             _lib.check(_lib.lib().after_denoiser_set_sample_persist(self._handle, int(bool(enable))),
                        "after_denoiser_set_sample_persist")
+
+    def set_persist_check(self, enable: bool):
+        """Persistent samplers: True = every call synchronises its stream and reports its own failure (a barrier time-out:
+        AFTERHipError from that very call; the offline sampler reruns the call by launches instead); False (default) = the
+        failure words are looked at by the next call or by check() (include/after_hip.h: after_denoiser_set_persist_check)."""
+        self._persist_check = bool(enable)
+        if self._handle is not None:
+            _lib.check(_lib.lib().after_denoiser_set_persist_check(self._handle, int(bool(enable))), "after_denoiser_set_persist_check")
+
+    def check(self):
+        """Waits for the last persistent launch's failure words and raises if a persistent sampler failed since the last look
+        (include/after_hip.h: after_denoiser_check): the way to validate the LAST chunk of a stream."""
+        if self._handle is not None:
+            _lib.check(_lib.lib().after_denoiser_check(self._handle, _lib.current_stream(None)), "after_denoiser_check")
 
     def sample_persist(self) -> bool:
         """True when the last cfg_sample of this handle ran as the persistent offline kernel."""

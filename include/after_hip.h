@@ -12,9 +12,13 @@
  *     owned by the caller, unless the parameter is documented as host memory;
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all
  *     work is enqueued on it and nothing synchronises the device;
- *   - functions return 0 on success or a negative AFTER_E_* code; they never
- *     throw and never allocate after *_create; after_last_error() returns a
- *     thread-local description of the last failure;
+ *   - functions return 0 on success or a negative AFTER_E_* code and never throw;
+ *     after_last_error() returns a thread-local description of the last failure;
+ *   - the calls that do the path's work (forward / model_forward / sample / encode /
+ *     decode / roll / reset ...) never allocate and never synchronise: everything is
+ *     provisioned by the CONFIGURATION calls -- *_create, *_enable_*, *_set_* --
+ *     which may allocate and synchronise the device (they also run the persistent
+ *     samplers' placement census, see after_denoiser_set_stream_persist);
  *   - a handle is not re-entrant (it owns workspaces and streaming state): use
  *     one handle per stream / per concurrent caller.  Different handles are
  *     independent.
@@ -135,24 +139,46 @@ int after_denoiser_gemm_path(after_denoiser* h, int* mode, int* min_rows);
  * c / ceil(B / 8), every phase of the network behind an XCD-local barrier inside the kernel -- when the geometry allows
  * it: embed 512 / mlp x 3 / eight heads, finite causal window, <= 8 layers, 256 CUs, ceil(B / 8) * T * 3 <= 32 token rows
  * per XCD, <= 128 Euler steps, gemm path != 2.  Otherwise, or with enable = 0 / AFTER_STREAM_PERSIST=0, as the launch-per-kernel sequence.
- * Same arithmetic (fp32 MFMA, a different but fixed K split): the two paths agree to fp32 round-off.  The first persistent
- * launch of a handle is checked synchronously: if its workgroups were not placed 32 per XCD (the kernel then returned before
- * touching anything) the same call runs on the launch path and the handle stays there -- no invalid chunk, no error.  An
- * XCD-local barrier that timed out later on is reported by the NEXT after_sample call on the handle (AFTER_E_HIP; that call
- * also selects the launch path): the chunk before it is invalid, reset the
- * streamer.  after_denoiser_stream_persist: *active = 1 when the handle's last streaming shape takes the persistent
- * path. */
+ * Same arithmetic (fp32 MFMA, a different but fixed K split): the two paths agree to fp32 round-off.
+ *
+ * Provisioning.  The persistent samplers' buffers (barrier state, 16 x 16-tiled weight copies: + 54 MB at base width,
+ * per-XCD activation slices) are allocated, and a dry placement census (are the 256 workgroups placed 32 per XCD?) is run
+ * synchronously, by the configuration calls: after_denoiser_enable_cache and after_denoiser_set_stream_persist(h, 1) for
+ * the streaming sampler, after_denoiser_create and after_denoiser_set_sample_persist(h, 1) for the offline one.  If the
+ * census fails, or memory is short, the handle silently stays on the launch path.  after_sample itself never allocates
+ * and never synchronises.
+ *
+ * Co-residency.  The kernels spin on barriers among their 256 workgroups x 512 threads (80 - 125 KB of LDS each): all of
+ * them must be resident at once, i.e. they need the whole device.  Inside one process the library serialises persistent
+ * launches of different streams / handles on a device (the later launch waits, on the device, for the earlier one), and a
+ * stream under capture takes the launch path.  Kernels of OTHER processes sharing the GPU are outside that guard and can
+ * starve the barriers into their ~2-s spin limit: such deployments select the launch path (AFTER_STREAM_PERSIST=0,
+ * AFTER_SAMPLE_PERSIST=0).
+ *
+ * Failures (a barrier or neighbour flag that timed out, a bad placement seen by a real launch) raise STICKY words on the
+ * device: every later persistent launch of the handle returns at entry without touching anything.  The host looks at a
+ * copy of the words at the start of the next after_sample whose predecessor's copy has landed, and in after_denoiser_check
+ * (which waits for it: the way to validate the last chunk of a stream): AFTER_E_HIP once, the handle then runs on the
+ * launch path; every result since the failing call is invalid (reset the streamer / repeat the calls).  With
+ * after_denoiser_set_persist_check(h, 1) every persistent after_sample synchronises its stream and reports its own failure
+ * (the offline sampler, which has no state, serves that very call by launches instead and returns AFTER_OK).
+ * after_denoiser_stream_persist: *active = 1 when the handle's last streaming shape takes the persistent path. */
 int after_denoiser_set_stream_persist(after_denoiser* h, int enable);
 /* after_sample for ONE clip without K/V caches (RectifiedFlow.sample, model.py:763-785) as one persistent launch: the same
  * XCD-local pipelines partitioned over time (XCD g owns frames [g T/8, (g+1) T/8) of the three CFG rows; the attention's
  * left context crosses XCDs through system-scope stores / loads and per-XCD sequence words, no device-wide barrier), the
- * Linears as bf16 x 3 split MFMAs like gemm_x6.  Eligible: the shipped width (embed 512 / mlp x 3 / eight heads), T = 128 or
- * 256, window - 1 <= T / 8, gemm path != 0, no graph replay; otherwise, or with enable = 0 / AFTER_SAMPLE_PERSIST=0, the
- * launch path runs.  Failures are reported as for the streaming sampler.  _sample_persist: *active = 1 when the last
- * after_sample ran this way. */
+ * Linears as bf16 x 3 split MFMAs like gemm_x6.  The DEFAULT where eligible: the shipped width (embed 512 / mlp x 3 / eight
+ * heads), B = 1, T = 128 or 256, window - 1 <= T / 8, gemm path != 0, no graph replay; otherwise, or with enable = 0 /
+ * AFTER_SAMPLE_PERSIST=0, the launch path runs.  Provisioning, co-residency and failures as above.  _sample_persist:
+ * *active = 1 when the last after_sample ran this way. */
 int after_denoiser_set_sample_persist(after_denoiser* h, int enable);
 int after_denoiser_sample_persist(after_denoiser* h, int* active);
 int after_denoiser_stream_persist(after_denoiser* h, int* active);
+/* mode 1: every persistent after_sample synchronises `stream` and reports its own failure; 0 (default): deferred. */
+int after_denoiser_set_persist_check(after_denoiser* h, int mode);
+/* Waits for the failure words of the handle's last persistent launch (if not yet looked at) and reports them:
+ * AFTER_E_HIP if a persistent sampler failed since the last look, AFTER_OK otherwise (also without persistent launches). */
+int after_denoiser_check(after_denoiser* h, void* stream);
 /* Diagnostics (AFTER_STEP_TRACE=1 at the first streaming call): out[workgroup][128] = 100 MHz wall-clock stamps of
  * the last persistent step -- [0] start, [2r-1] / [2r] arrival at / exit from barrier r, then the end; [127] = XCC. */
 int after_denoiser_step_trace(after_denoiser* h, unsigned long long* out, int n_workgroups);

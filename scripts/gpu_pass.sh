@@ -1,0 +1,52 @@
+#!/bin/bash
+# The GPU passes of a round as they were run through `gpurun -- bash scripts/gpu_pass.sh <pass>` (one lease each).
+# Output goes to gpurun_out/<pass>/ (merged back by gpurun); summaries worth keeping are copied to profiles/ by hand.
+set -u
+pass=${1:?pass name}
+out=gpurun_out/$pass
+mkdir -p "$out"
+export TMPDIR=/tmp
+ts() { # ts <label> <env...> : 50-step base B=1 sampler time under an environment
+    local label=$1; shift
+    env "$@" timeout 300 python scripts/time_sampler.py base 1 50 7 2>&1 | grep "sample " | sed "s/^/$label: /" >> "$out/times.log"
+}
+case "$pass" in
+seg_a)  # round 4: persistent offline sampler after the de-spill pass -- K split variants x L2 warming variants
+    timeout 900 python -m pytest tests/test_sample_persist_gpu.py -x -q > "$out/test_k0.log" 2>&1
+    AFTER_SEG_K8=2 AFTER_SEG_W=15 timeout 900 python -m pytest tests/test_sample_persist_gpu.py -x -q > "$out/test_k2w15.log" 2>&1
+    AFTER_SEG_K8=3 AFTER_SEG_W=10 timeout 900 python -m pytest tests/test_sample_persist_gpu.py -x -q > "$out/test_k3w10.log" 2>&1
+    tail -3 "$out"/test_*.log
+    ts launch AFTER_SAMPLE_PERSIST=0
+    for k in 0 2 3; do
+        for w in 0 1 2 4 8 10 15; do
+            ts "persist k8=$k w=$w" AFTER_SAMPLE_PERSIST=1 AFTER_SEG_K8=$k AFTER_SEG_W=$w
+        done
+    done
+    ts "persist k8=0 w=0 warm0,16,4" AFTER_SAMPLE_PERSIST=1 AFTER_SEG_WARM=0,16,4
+    ts "persist k8=0 w=10 warm0,16,0" AFTER_SAMPLE_PERSIST=1 AFTER_SEG_W=10 AFTER_SEG_WARM=0,16,0
+    ts launch AFTER_SAMPLE_PERSIST=0
+    cat "$out/times.log"
+    for k in 0 2; do
+        for w in 0 15; do
+            AFTER_SEG_K8=$k AFTER_SEG_W=$w timeout 300 python scripts/stream_step_trace.py --offline > "$out/trace_k${k}_w${w}.txt" 2>&1
+        done
+    done
+    tail -12 "$out/trace_k0_w0.txt"
+    ;;
+persist_tests)  # round 4: the persistent samplers' host protocol + every test that touches them
+    timeout 1700 python -m pytest tests/test_persist_protocol_gpu.py tests/test_stream_persist_gpu.py tests/test_sample_persist_gpu.py \
+        tests/test_baseline_size_gpu.py tests/test_denoiser_gpu.py tests/test_streamer_gpu.py -x -q > "$out/tests.log" 2>&1
+    tail -30 "$out/tests.log"
+    ts launch AFTER_SAMPLE_PERSIST=0
+    ts persist_default
+    cat "$out/times.log"
+    ;;
+tests)  # the whole -m gpu suite + smoke
+    timeout 3000 python -m pytest tests -m gpu -x -q > "$out/tests.log" 2>&1
+    tail -15 "$out/tests.log"
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.log" 2>&1
+    tail -3 "$out/smoke.log"
+    ;;
+*)
+    echo "unknown pass $pass"; exit 2;;
+esac

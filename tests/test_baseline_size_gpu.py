@@ -113,9 +113,11 @@ def test_midi_b8_t256_50steps_vs_oracle(mode, gt, gs, hip_device):
         assert rel_l2(got[s], want) < 4e-5
 
 
-def test_base_streamer_8_streams_100_steps_vs_oracle(hip_device):
+def test_base_streamer_8_streams_100_steps_vs_oracle(hip_device, both_gemm_paths):
     """Config 5: base + cycle dims (cycle.gin only changes training), causal GroupNorm-free codec,
-    8 independent streams, 100-step cached sampler, 8 chunks of 4 frames."""
+    8 independent streams, 100-step cached sampler, 8 chunks of 4 frames.  Under `fp32mfma` this IS the persistent
+    streaming sampler (stream_step_kernel, the default path of this shape) against the oracle -- asserted, because a
+    refused placement falls back to launches silently; under `bf16x6` (gemm path 2) the launch path."""
     model, dcfg, acfg = pipeline.build_models("cycle", "baseAE_causal", hip_device, seed=7)
     ae = model.emb_model
     # weight-norm gains x 0.5: the GroupNorm-free codec stays O(1) through its ~80 layers, so the audio bar below is
@@ -145,13 +147,57 @@ def test_base_streamer_8_streams_100_steps_vs_oracle(hip_device):
         cond = torch.cat((st.structure(xs[..., a].contiguous().to(hip_device)),
                           st.timbre(xt[..., a].contiguous().to(hip_device))), 1)
         z = st.diffuse(cond, nz)
+        assert model.net.stream_persist() == (both_gemm_paths == "fp32mfma"), (c, both_gemm_paths)
         lats.append(z.cpu())
         outs.append(st.decode(z).cpu())
+    model.net.check()  # the last chunk's persistent launch did not time out either
     z = torch.cat(lats, -1)
     y = torch.cat(outs, -1)
     assert z.shape == want_z.shape and y.shape == want_audio.shape
     assert max_abs(z, want_z) < 5e-4 * max(1.0, want_z.abs().max().item()), (max_abs(z, want_z), rel_l2(z, want_z))
     assert max_abs(y, want_audio) < 2e-4 * want_audio.abs().max().item(), (max_abs(y, want_audio), rel_l2(y, want_audio))
+
+
+def test_midi_streamer_base_dims_persistent_vs_oracle(hip_device, both_gemm_paths):
+    """export_midi.py's Streamer at the midi config's real width (embed 512, window 16 -> 19 keys per chunk: two key blocks
+    of the online softmax, a 16-frame K / V ring; piano-roll conditioning, CFG_MIDI): two streams, 8 cached steps, 4 chunks
+    against the oracle's K / V-cache sampler.  Under `fp32mfma` on the persistent streaming sampler -- asserted."""
+    from after_amd import MidiStreamer
+    from oracle.sampler import CFG_MIDI
+    model, dcfg, acfg = pipeline.build_models("midi", "baseAE_causal", hip_device, seed=13)
+    sd = cpu_sd(model)
+    sd_net = {k[4:]: v for k, v in sd.items() if k.startswith("net.")}
+    ncfg = dcfg["net"]
+    chunk, steps, n_chunks, nsig, n_poly, n = 4, 8, 4, 128, 4, 2
+    st = MidiStreamer(model, model.emb_model, n_poly=n_poly, chunk_size=chunk, n_signal_timbre=nsig, max_batch=n,
+                      max_nb_steps=steps)
+    st.set_nb_steps(steps)
+    st.set_guidance_timbre(1.5)
+    st.set_guidance_structure(2.0)
+    g = torch.Generator().manual_seed(23)
+    H = ncfg["embed_dim"] // 64
+    caches = [oracle.DenoiserCache(ncfg["n_layers"], 3, steps, H, ncfg["local_attention_size"], 64) for _ in range(n)]
+    tvals = torch.linspace(0, 1, steps + 1)[:-1]
+    for c in range(n_chunks):
+        notes = torch.zeros(n, 2 * n_poly, chunk)
+        for b in range(n):
+            for v in range(n_poly):
+                notes[b, 2 * v] = float(torch.randint(20, 110, (1, ), generator=g))
+                notes[b, 2 * v + 1] = torch.randint(0, 128, (chunk, ), generator=g).float() * (torch.rand(chunk, generator=g) > 0.3)
+        zsem = torch.randn(n, st.zt_channels, generator=g)
+        x = torch.cat((notes, zsem.unsqueeze(-1).repeat(1, 1, chunk)), 1)
+        noise = torch.randn(n, st.ae_latents, chunk, generator=g)
+        tc = st.piano_roll(notes.to(hip_device)).cpu()  # (pinned against the reference recipe in test_streamer_gpu.py)
+        got = st.diffuse(x.to(hip_device), noise.to(hip_device)).cpu()
+        assert model.net.stream_persist() == (both_gemm_paths == "fp32mfma"), (c, both_gemm_paths)
+        for b in range(n):
+            want = noise[b:b + 1]
+            for i, t in enumerate(tvals):
+                want = want + oracle.model_forward(sd_net, ncfg, want, t.reshape(1, 1, 1), zsem[b:b + 1], tc[b:b + 1], 1.5, 2.0, -4.0,
+                                                   CFG_MIDI, cache=caches[b], cache_index=i) * (1 / steps)
+                caches[b].roll(chunk, i)
+            assert max_abs(got[b:b + 1], want) < 5e-4, (c, b, max_abs(got[b:b + 1], want))
+    model.net.check()
 
 
 def test_config1_audio_to_audio_vs_oracle(hip_device):

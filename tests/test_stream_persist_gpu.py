@@ -87,10 +87,10 @@ def test_persistent_step_refused_shapes_fall_back(net, hip_device):
 
 
 def test_persistent_step_bad_placement_falls_back_at_first_use(net, hip_device):
-    """A persistent launch whose workgroups are not placed 32 per XCD raises a flag and returns without touching anything.  The
-    first persistent launch of a handle is checked synchronously: the same call then runs on the launch path -- no invalid
-    chunk, no error -- and the handle stays there.  The census failure is simulated (diagnostics bit 3 of
-    after_denoiser_set_stream_persist, which also re-arms the first-use check)."""
+    """The placement census (are the 256 workgroups placed 32 per XCD?) runs as a dry launch when the persistent path is
+    configured (after_denoiser_enable_cache / _set_stream_persist), not in the first after_sample: a handle whose census fails
+    serves every chunk by launches -- no invalid chunk, no error -- until it is re-enabled (which repeats the census).  The
+    census failure is simulated (diagnostics bit 3 of after_denoiser_set_stream_persist)."""
     from after_amd import _lib
     net.set_gemm_path(0)
     net.enable_streaming_cache(max_diffusion_steps=3, max_batch_size=6, max_frames=4)
