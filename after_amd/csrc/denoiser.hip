@@ -731,7 +731,6 @@ struct StepArgs {
     int nsteps, cache_steps;  // Euler steps of this launch (ALL of a sample() call); ring slots per layer
     unsigned flip[4];         // bit i: which half of step i's K / V rings is current
     int warm[3];  // sixteenths of the qkv / MLP-up / MLP-down weights warmed into the L2 by idle waves (AFTER_STEP_WARM)
-    int segw;     // offline segment sampler: which phases warm the workgroup's OWN slice of the next GEMM's weights (AFTER_SEG_W)
     float* xt;                             // token-major latents [B * T][Cp]: a step's input, rewritten by its tail
     float *pat_t, *xres_t, *h_t, *mlp_t;   // tiled, one slice of kSGroupRows rows per XCD
     unsigned short *h3_t, *mlp3_t;         // offline segment sampler: bf16 x 3 planes of h / the MLP hidden layer (p32_store4)
@@ -795,8 +794,12 @@ __device__ __forceinline__ bool step_spin(unsigned* word, unsigned want, unsigne
 // XCD-local barrier (all threads of the workgroup call it; n = workgroups of this XCC).  `drain`: this wave stored
 // something in the phase -- wait until it is in the XCD's L2 (write-through L1).  A streaming wave passes false: its
 // L2-warming loads stay in flight across the barrier (raw s_barrier: no memory wait).
+// `pub`: a system-scope word the LAST arriver sets to `pubval` (the offline sampler's "this layer's qkv rows are in memory":
+// every workgroup has drained its stores when the last ticket is drawn -- half a round trip earlier than a store behind the
+// barrier's exit).
 __device__ __forceinline__ bool step_barrier(StepSync* st, unsigned xcc, unsigned n, unsigned round,
-                                             unsigned long long* trace, unsigned tslot, bool drain, unsigned* s_ok) {
+                                             unsigned long long* trace, unsigned tslot, bool drain, unsigned* s_ok,
+                                             unsigned* pub = nullptr, unsigned pubval = 0) {
     if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -804,8 +807,12 @@ __device__ __forceinline__ bool step_barrier(StepSync* st, unsigned xcc, unsigne
         if (trace) trace[2 * tslot - 1] = wall_clock64();
         bool ok = true;
         const unsigned ticket = __hip_atomic_fetch_add(&st->arrive[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ticket == round * n - 1) __hip_atomic_store(&st->gen[xcc][0], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else ok = step_spin(&st->gen[xcc][0], round, &st->fail[0]);
+        if (ticket == round * n - 1) {
+            if (pub) __builtin_amdgcn_raw_buffer_store_b32(pubval, step_rsrc(pub), 0, 0, 17);
+            __hip_atomic_store(&st->gen[xcc][0], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            ok = step_spin(&st->gen[xcc][0], round, &st->fail[0]);
+        }
         *s_ok = ok;
         if (trace) trace[2 * tslot] = wall_clock64();
     }
@@ -1004,10 +1011,30 @@ struct StepAttn {  // (by value: the offline kernel calls the attention out of l
     const float* qkv;  // this layer's rows
 };
 
-template <int AUX, bool PLANES = false>  // hout: fp32 tiles, or -- PLANES -- bf16 x 3 planes (p32_store4)
+__device__ __forceinline__ bool seg_spin_sys(const unsigned* word, unsigned want, unsigned* fail) {
+    const __amdgpu_buffer_rsrc_t r = step_rsrc(word);
+    for (unsigned spins = 0;; ++spins) {
+        if (__builtin_amdgcn_raw_buffer_load_b32(r, 0, 0, 17) >= want) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if (spins > (1u << 21)) {
+            __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+}
+
+// LATE (the offline segment sampler): nothing is requested in front of the key loop -- the RoPE slice, q, the residual row and
+// the LayerNorm tail's row operands (`lab`: AdaLN alpha | beta of the CFG row, `lw3` / `lb3`: norm3's affine; `ops` unused) go
+// out BEHIND the first K / V block's DMA and land with it: one round trip for the whole item.  (hipcc waits for every
+// outstanding load at a loop header: requested in front of the loops, each group cost a round trip of its own.)
+// (Tried on top, LATE only: a chunk whose window reaches into the previous XCD's segment runs its OWN keys first and fetches
+//  the neighbour's -- after the sequence-word wait -- in a second pass of the online softmax.  The second pass (a
+//  system-scope round trip + a 12-key block) costs more than the wait it hides: 285 vs 270 us per Euler step.)
+template <int AUX, bool PLANES = false, bool LATE = false>  // hout: fp32 tiles, or -- PLANES -- bf16 x 3 planes (p32_store4)
 __device__ __forceinline__ void step_attention(const StepAttn& a, const StepKV& kv, const StepLnOps& ops, int rg,
                                                int lr0, int bx, float* smem, float* kvlds, __amdgpu_buffer_rsrc_t qkvr,
-                                               __amdgpu_buffer_rsrc_t xr, float* __restrict__ xres, float* __restrict__ hout) {
+                                               __amdgpu_buffer_rsrc_t xr, float* __restrict__ xres, float* __restrict__ hout,
+                                               const float* lab = nullptr, const float* lw3 = nullptr, const float* lb3 = nullptr) {
     constexpr int NKMAX = kAttnKeyBlock, E = kSE, H = kSH, KBt = E / 16, ld = E + 4;
     const int T = a.T, cs = a.cs, W = a.W, nc = a.cache;
     const int tid = threadIdx.x, lane = tid & 63, hw = tid >> 6;
@@ -1022,46 +1049,69 @@ __device__ __forceinline__ void step_attention(const StepAttn& a, const StepKV& 
     float* const kvs = kvlds + hw * (2 * NKMAX * 64);  // per-wave K / V landing zone [2][NKMAX][64]
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 tc0 = z4, tc1 = z4, ts0 = z4, ts1 = z4;
-    if (lane < nk * 4) {
-        tc0 = *reinterpret_cast<const float4*>(a.rope_cos + (size_t)lo_c * 16 + lane * 4);
-        ts0 = *reinterpret_cast<const float4*>(a.rope_sin + (size_t)lo_c * 16 + lane * 4);
-    }
-    if (lane + 64 < nk * 4) {
-        tc1 = *reinterpret_cast<const float4*>(a.rope_cos + (size_t)lo_c * 16 + (lane + 64) * 4);
-        ts1 = *reinterpret_cast<const float4*>(a.rope_sin + (size_t)lo_c * 16 + (lane + 64) * 4);
-    }
+    auto rope_loads = [&] {
+        if (lane < nk * 4) {
+            tc0 = *reinterpret_cast<const float4*>(a.rope_cos + (size_t)lo_c * 16 + lane * 4);
+            ts0 = *reinterpret_cast<const float4*>(a.rope_sin + (size_t)lo_c * 16 + lane * 4);
+        }
+        if (lane + 64 < nk * 4) {
+            tc1 = *reinterpret_cast<const float4*>(a.rope_cos + (size_t)lo_c * 16 + (lane + 64) * 4);
+            ts1 = *reinterpret_cast<const float4*>(a.rope_sin + (size_t)lo_c * 16 + (lane + 64) * 4);
+        }
+    };
+    if constexpr (!LATE) rope_loads();
     constexpr int NV = E / 256;
-    const f32x4 (&al)[NV] = ops.al, (&be)[NV] = ops.be, (&ww)[NV] = ops.ww, (&bb)[NV] = ops.bb;
+    StepLnOps late;
+    const StepLnOps& lo = LATE ? late : ops;
+    const f32x4 (&al)[NV] = lo.al, (&be)[NV] = lo.be, (&ww)[NV] = lo.ww, (&bb)[NV] = lo.bb;
     auto as4 = [](f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
+    // K / V rows go global -> LDS by DMA (no VGPR landing zone: this kernel's register budget belongs to the weight
+    // fragments).  One instruction moves 4 keys: 16-lane group g fetches the 256-byte head slice of key 4 u + g,
+    // lane-linear into [key][64 dims]; sc1: the new frames were written by this XCD's qkv phase.
+    auto kv_dma = [&](int kb) {
+#pragma unroll
+        for (int u = 0; u < NKMAX / 4; ++u) {
+            const int pos = lo_c + min(kb + 4 * u + grp, nk - 1);
+            const float* ksrc = a.qkv + ((size_t)rowbase + (pos - nc)) * 3 * E + E + hw * 64 + d4;
+            const float* vsrc = ksrc + E;
+            if (pos < nc) {
+                ksrc = kv.kold + ((size_t)rg * nc + pos) * E + hw * 64 + d4;
+                vsrc = kv.vold + ((size_t)rg * nc + pos) * E + hw * 64 + d4;
+            }
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)ksrc, (lds_ptr_t)(kvs + 4 * u * 64), 16, 0, AUX);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)vsrc, (lds_ptr_t)(kvs + (NKMAX + 4 * u) * 64), 16, 0, AUX);
+        }
+    };
+    auto q_load = [&](int qb) {
+        const int qic = min(qb + grp, nq - 1);
+        return as4(__builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qkvr, ((rowbase + i0 + qic) * 3u * E + hw * 64 + d4) * 4u, 0, AUX)));
+    };
+    auto x_load = [&](int qb) { return as4(ld_l2(xr, t16_off(lr0 + i0 + min(qb + grp, nq - 1), hw * 64 + d4, KBt))); };
+    float4 q4n = z4, x4n = z4;
+    if constexpr (LATE) {  // every request of the item's first pass, K / V first, in front of the loops (one round trip)
+        kv_dma(0);
+        rope_loads();
+        if (hw < nq) step_ln_ops(late, lab, lw3, lb3, lane);
+        q4n = q_load(0), x4n = x_load(0);
+    }
     for (int qb = 0; qb < nq; qb += 4) {
         const int qi = qb + grp;
         const bool qok = qi < nq;
         const int qic = qok ? qi : nq - 1;
         const int ja = a0 + qic;
         const int lo_row = min(a0, max(0, ja - W + 1));
-        float4 q4 = as4(__builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qkvr, ((rowbase + i0 + qic) * 3u * E + hw * 64 + d4) * 4u, 0, AUX)));
-        const float4 x4 = as4(ld_l2(xr, t16_off(lr0 + i0 + qic, hw * 64 + d4, KBt)));
+        float4 q4, x4;
+        if constexpr (LATE) q4 = q4n, x4 = x4n;
+        else q4 = q_load(qb), x4 = x_load(qb);
         float mrun = -INFINITY, sum = 0.f;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 1
         for (int kb = 0; kb < nk; kb += NKMAX) {
-            // K / V rows go global -> LDS by DMA (no VGPR landing zone: this kernel's register budget belongs to the
-            // weight fragments).  One instruction moves 4 keys: 16-lane group g fetches the 256-byte head slice of key
-            // 4 u + g, lane-linear into [key][64 dims]; sc1: the new frames were written by this XCD's qkv phase.
-            if (qb > 0 || kb > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous block consumed
-#pragma unroll
-            for (int u = 0; u < NKMAX / 4; ++u) {
-                const int pos = lo_c + min(kb + 4 * u + grp, nk - 1);
-                const float* ksrc = a.qkv + ((size_t)rowbase + (pos - nc)) * 3 * E + E + hw * 64 + d4;
-                const float* vsrc = ksrc + E;
-                if (pos < nc) {
-                    ksrc = kv.kold + ((size_t)rg * nc + pos) * E + hw * 64 + d4;
-                    vsrc = kv.vold + ((size_t)rg * nc + pos) * E + hw * 64 + d4;
-                }
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)ksrc, (lds_ptr_t)(kvs + 4 * u * 64), 16, 0, AUX);
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)vsrc, (lds_ptr_t)(kvs + (NKMAX + 4 * u) * 64), 16, 0, AUX);
-            }
-            if (qb == 0 && kb == 0) {  // K / V requests are in flight: now land the RoPE slice
+            const bool first = kb == 0;
+            if (qb > 0 || !first) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous block consumed
+            if (!LATE || qb > 0 || !first) kv_dma(kb);
+            if (LATE && first && qb + 4 < nq) q4n = q_load(qb + 4), x4n = x_load(qb + 4);  // (the next pass's, a pass early)
+            if (qb == 0 && first) {  // K / V requests are in flight: now land the RoPE slice
                 if (lane < nk * 4) {
                     *reinterpret_cast<float4*>(rc + lane * 4) = tc0;
                     *reinterpret_cast<float4*>(rs + lane * 4) = ts0;
@@ -1076,7 +1126,7 @@ __device__ __forceinline__ void step_attention(const StepAttn& a, const StepKV& 
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the K / V block (and q, x) have landed
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (kb == 0) q4 = rope4(q4, rc, rs, ja - lo_c, d4);
+            if (first) q4 = rope4(q4, rc, rs, ja - lo_c, d4);
             float sc[NKMAX];
             float mx = mrun;
 #pragma unroll
@@ -1492,13 +1542,16 @@ constexpr bool kSegW = !(SEG_DIAG & 4);  // -DSEG_DIAG=4 (timing experiments): n
 //  bytes, and carries its tile / k-block position in the instruction's scalar offset: per-load 64-bit lane addresses are
 //  kernel-lifetime invariants that the register allocator spills, and each reload's s_waitcnt vmcnt(0) drains the operand queue)
 template <int RB, int NT>
-__device__ __forceinline__ void seg_load(SegBuf<RB, NT>& sb, int slot, __amdgpu_buffer_rsrc_t A3, int a_kb32, int rb0,
-                                         __amdgpu_buffer_rsrc_t W, int w_kblocks, int tile0, int ts, int kb, int lane) {
+__device__ __forceinline__ void seg_load_a(SegBuf<RB, NT>& sb, int slot, __amdgpu_buffer_rsrc_t A3, int a_kb32, int rb0, int kb, int lane) {
 #pragma unroll
     for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int p = 0; p < 3; ++p)
             sb.ap[slot][i][p] = __builtin_amdgcn_raw_buffer_load_b128(A3, lane * 16, (unsigned)((((rb0 + i) * a_kb32 + kb) * 3 + p) << 10), 16);
+}
+
+template <int RB, int NT>
+__device__ __forceinline__ void seg_load_w(SegBuf<RB, NT>& sb, int slot, __amdgpu_buffer_rsrc_t W, int w_kblocks, int tile0, int ts, int kb, int lane) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const unsigned so = (unsigned)(((tile0 + ts * j) * w_kblocks + 2 * kb) << 10);
@@ -1509,7 +1562,9 @@ __device__ __forceinline__ void seg_load(SegBuf<RB, NT>& sb, int slot, __amdgpu_
 
 // `after_loads()` runs once the last k-block's operands are requested: the place for the NEXT phase's operand prefetch (issued
 // any earlier it would sit in front of this phase's operands in the in-order load queue; any later -- after the MFMAs -- the
-// workgroup barrier of the partial-tile exchange waits a full fabric round trip for it)
+// workgroup barrier of the partial-tile exchange waits a full fabric round trip for it).
+// On entry the caller has requested k-block 0 (seg_load_a, then seg_load_w: activations first -- they come from the L2, the
+// weights from the fabric, and loads return in issue order; weights first measured + 0.6 us per phase).
 template <int RB, int NT, int KB, int DIAG, class F>  // DIAG (timing experiments, -DSEG_DIAG=n): 1 no MFMAs, 2 no weight split
 __device__ __forceinline__ void seg_run(f32x4 (&acc)[NT * RB], SegBuf<RB, NT>& sb, __amdgpu_buffer_rsrc_t A3, int a_kb32, int rb0,
                                         __amdgpu_buffer_rsrc_t W, int w_kblocks, int tile0, int ts, int kb0, int lane, F&& after_loads) {
@@ -1517,7 +1572,10 @@ __device__ __forceinline__ void seg_run(f32x4 (&acc)[NT * RB], SegBuf<RB, NT>& s
     for (int p = 0; p < NT * RB; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < KB; ++u) {
-        if (u + 1 < KB) seg_load<RB, NT>(sb, (u + 1) & 1, A3, a_kb32, rb0, W, w_kblocks, tile0, ts, kb0 + u + 1, lane);
+        if (u + 1 < KB) {
+            seg_load_a<RB, NT>(sb, (u + 1) & 1, A3, a_kb32, rb0, kb0 + u + 1, lane);
+            seg_load_w<RB, NT>(sb, (u + 1) & 1, W, w_kblocks, tile0, ts, kb0 + u + 1, lane);
+        }
         if (u + 2 == KB || KB == 1) after_loads();
         u32x4 wp[NT][3];
 #pragma unroll
@@ -1544,81 +1602,6 @@ __device__ __forceinline__ void seg_run(f32x4 (&acc)[NT * RB], SegBuf<RB, NT>& s
                             acc[j * RB + i], 0, 0, 0);
                 }
     }
-}
-
-// The qkv / MLP-up GEMM of a 96-row segment with K split EIGHT ways over all six row blocks (K8): wave w owns 32-deep k-blocks
-// 2 w, 2 w + 1 of every row block and of the workgroup's NT column tiles, so no operand is fetched twice by a CU (the row-half
-// x 4-way split fetches and splits every weight fragment in both halves: 480 instead of 384 KB per CU and phase through the
-// one load path, twice the VALU work of the weight split) and the two waves of a SIMD do the same work at the same time.
-// acc[j * 6 + rb].  The weight fragments of both k-blocks are requested first (the longest latency: fabric or L2), then the
-// activation planes in chunks of (k-block, three row blocks) through a ring of NS register slots.
-template <int NT, int NS, int DIAG, class F>
-__device__ __forceinline__ void seg_run_k8(f32x4 (&acc)[NT * 6], __amdgpu_buffer_rsrc_t A3, int a_kb32, __amdgpu_buffer_rsrc_t W,
-                                           int w_kblocks, int tile0, int ts, int kb0, int lane, F&& after_loads) {
-    f32x4 wr[2][NT][2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const unsigned so = (unsigned)(((tile0 + ts * j) * w_kblocks + 2 * (kb0 + u)) << 10);
-            wr[u][j][0] = kSegW ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W, lane * 16, so, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
-            wr[u][j][1] = kSegW ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W, lane * 16 + 1024, so, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    u32x4 ap[NS][3][3];
-    auto load_a = [&](int slot, int c) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-                ap[slot][i][p] = __builtin_amdgcn_raw_buffer_load_b128(
-                    A3, lane * 16, (unsigned)((((3 * (c & 1) + i) * a_kb32 + kb0 + (c >> 1)) * 3 + p) << 10), 16);
-    };
-#pragma unroll
-    for (int c = 0; c < NS; ++c) load_a(c, c);
-#pragma unroll
-    for (int p = 0; p < NT * 6; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-    u32x4 wp[NT][3];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        if ((c & 1) == 0) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if constexpr (DIAG & 2) {
-                    wp[j][0] = __builtin_bit_cast(u32x4, wr[c >> 1][j][0]);
-                    wp[j][1] = __builtin_bit_cast(u32x4, wr[c >> 1][j][1]);
-                    wp[j][2] = wp[j][0] ^ wp[j][1];
-                } else {
-                    seg_split8(wr[c >> 1][j][0], wr[c >> 1][j][1], wp[j]);
-                }
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < 6; ++p)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {  // W fragment as srcA: the accumulator holds C^T
-                    const int t = j * 6 + 3 * (c & 1) + i;
-                    if constexpr (DIAG & 1)
-                        acc[t] += __builtin_bit_cast(f32x4, wp[j][kSegWP[p]] ^ ap[c % NS][i][kSegAP[p]]);
-                    else
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sbf16x8, wp[j][kSegWP[p]]),
-                                                                         __builtin_bit_cast(sbf16x8, ap[c % NS][i][kSegAP[p]]), acc[t], 0, 0, 0);
-                }
-        if (c + NS < 4) load_a(c % NS, c + NS);
-        if (c + NS == 3 || (NS >= 4 && c == 0)) after_loads();
-    }
-}
-
-// row half r of the K8 partials (the NT x 3 tiles acc[j * 6 + 3 r + i]) -> LDS [wave][NT * 3][256]
-template <int NT>
-__device__ __forceinline__ void seg_partials_k8(const f32x4 (&acc)[NT * 6], int r, float* red, int w, int lane) {
-    __syncthreads();  // the previous readers are done with `red`
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) *reinterpret_cast<f32x4*>(red + (((w * NT * 3 + j * 3 + i) << 6) + lane) * 4) = acc[j * 6 + 3 * r + i];
-    __syncthreads();
 }
 
 // the eight waves' partials of ONE column tile (RB row blocks) -> LDS -> wave w returns the sum of row block w (wave order)
@@ -1654,39 +1637,39 @@ __device__ __forceinline__ f32x4 seg_sum(const float* red, int P, int p, int lan
     return o;
 }
 
-__device__ __forceinline__ bool seg_spin_sys(const unsigned* word, unsigned want, unsigned* fail) {
-    const __amdgpu_buffer_rsrc_t r = step_rsrc(word);
-    for (unsigned spins = 0;; ++spins) {
-        if (__builtin_amdgcn_raw_buffer_load_b32(r, 0, 0, 17) >= want) return true;
-        __builtin_amdgcn_s_sleep(1);
-        if (spins > (1u << 21)) {
-            __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
-        }
-    }
-}
-
 // (out of line: with the attention body inlined next to the split-MFMA GEMMs, clang 22's InstCombine crashes on this kernel;
 //  every argument by value -- see StepAttn)
+// wave-uniform values that arrive in vector registers (the arguments of an out-of-line function do): back into scalar ones
+template <class T>
+__device__ __forceinline__ T* seg_uniform(T* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int seg_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 __device__ __attribute__((noinline)) void seg_attention(StepAttn g, const float* ab, const float* w3, const float* b3, int rg, int lr0,
                                                         int bx, bool halo, float* smem, float* kvlds, float* xres, float* hout) {
+    // (every argument is wave-uniform, but the calling convention hands it over in vector registers: a buffer resource built
+    //  from those is "divergent" to the compiler, and every buffer load through it becomes a waterfall loop with a full
+    //  s_waitcnt in front -- q, x and the K / V rows were fetched one round trip after the other)
+    g.T = seg_uniform(g.T), g.cs = seg_uniform(g.cs), g.W = seg_uniform(g.W), g.cache = seg_uniform(g.cache), g.nkmax = seg_uniform(g.nkmax);
+    g.rope_cos = seg_uniform(g.rope_cos), g.rope_sin = seg_uniform(g.rope_sin), g.qkv = seg_uniform(g.qkv);
+    ab = seg_uniform(ab), w3 = seg_uniform(w3), b3 = seg_uniform(b3);
+    rg = seg_uniform(rg), lr0 = seg_uniform(lr0), bx = seg_uniform(bx), halo = seg_uniform((int)halo) != 0;
+    smem = seg_uniform(smem), kvlds = seg_uniform(kvlds), xres = seg_uniform(xres), hout = seg_uniform(hout);
     const StepKV nokv{nullptr, nullptr, nullptr, nullptr};
-    // The LayerNorm tail's row operands (AdaLN(cond) alpha / beta of the CFG row, norm3's affine: waves < cs own a row) are
-    // requested HERE, in front of q / K / V -- an earlier phase touched their lines into the XCD's L2 (attn_warm), so they
-    // cost a few hundred cycles of queue, not a fabric round trip -- instead of riding through the qkv GEMM in 32 registers.
-    StepLnOps ops;
-    if ((int)(threadIdx.x >> 6) < g.cs) {
-        step_ln_ops(ops, ab, w3, b3, threadIdx.x & 63);
-    } else {
+    // (the LayerNorm tail's row operands -- AdaLN(cond) alpha / beta of the CFG row, norm3's affine -- are requested inside,
+    //  behind the K / V rows: an earlier phase touched their lines into the XCD's L2, attn_prefetch)
+    StepLnOps none;
 #pragma unroll
-        for (int i = 0; i < kSE / 256; ++i) ops.al[i] = ops.be[i] = ops.ww[i] = ops.bb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int i = 0; i < kSE / 256; ++i) none.al[i] = none.be[i] = none.ww[i] = none.bb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     // system-scope q / K / V loads only where keys of the previous XCD are involved; the other chunks read this XCD's L2
-    if (halo) step_attention<17, true>(g, nokv, ops, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout);
-    else step_attention<16, true>(g, nokv, ops, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout);
+    if (halo) step_attention<17, true, true>(g, nokv, none, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout, ab, w3, b3);
+    else step_attention<16, true, true>(g, nokv, none, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout, ab, w3, b3);
 }
 
-template <int MB, int K8 = 0>  // row blocks per XCD: 3 Tseg / 16 (6 at T = 256); K8 > 0: qkv / MLP-up by seg_run_k8 with K8 ring slots (MB = 6)
+template <int MB>  // row blocks per XCD: 3 Tseg / 16 (6 at T = 256)
 __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ unsigned s_rank, s_bad, s_ok;
@@ -1727,7 +1710,9 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
     float* const red = smem;                      // partial tiles [8 waves][3][256] (one column tile at a time) | attention rows
     float* const kvl = smem + kSRedFloats(2);     // attention: K / V landing zones [8 waves][2][12][64]
     constexpr bool wact = kSegW;
-    auto end_phase = [&](bool drain) { return step_barrier(st, xcc, n, ++round, trace, ++tslot, drain, &s_ok); };
+    auto end_phase = [&](bool drain, unsigned* pub = nullptr, unsigned pubval = 0) {
+        return step_barrier(st, xcc, n, ++round, trace, ++tslot, drain, &s_ok, pub, pubval);
+    };
     const int ln_lm = rank + (int)n * w;  // this wave's row of the ln phases (waves 0 .. 2 at 96 rows)
     const bool ln_mine = ln_lm < Mg;
     unsigned wsink = 0;  // destination of the L2-warming loads (seg_warm_tiles, row_warm): never read
@@ -1749,7 +1734,6 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
         if (ln_mine) row_warm(ln_ab0 + (size_t)l * 2 * E, a.layer[l].n1w, a.layer[l].n1b);
     };
     const int cps = Tseg / a.cs, nitems = 3 * cps;  // attention items: (CFG row, chunk of the segment)
-    const int segw = wact ? a.segw : 0;
 
     for (int i = 0; i < a.nsteps; ++i) {  // ---- the Euler steps of RectifiedFlow.sample (model.py:770-785)
         const float* cond_ab = a.cond_ab + (size_t)i * a.cond_step;
@@ -1809,51 +1793,27 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
             // (idle wave 7 of workgroup 0: the next XCD has read this layer's keys of the PREVIOUS step -- its last
             //  frames may be overwritten.  A whole step behind: satisfied long ago, one memory round trip off the path)
             if (rank == 0 && w == 7 && lane == 0 && g < 7 && i > 0) seg_spin_sys(&st->att_seq[g + 1][0], seq - a.L, &st->fail[0]);
-            // (segw bit 0: the waves without a row request this workgroup's qkv weight tiles into the XCD's L2)
-            if (!ln_mine && (segw & 1)) {
-                const int nbusy = (Mg - rank + (int)n - 1) / (int)n;  // waves of this workgroup with a row
-                seg_warm_tiles(wsink, Lw.qkv_wt, KBE, rank, 32, 3, w - nbusy, 8 - nbusy, lane);
-            }
-            if (!end_phase(ln_mine)) return;
-            // ---- qkv: column tiles rank, rank + 32, rank + 64 (bf16 x 3 split MFMAs), three row blocks at a time; the
-            //      rows are written through to memory (the next XCD's attention reads the last W - 1 frames)
-            auto qkv_store = [&](const f32x4& o, int rb, int j) {
-                const int lm = 16 * rb + (lane & 15), br = lm / Tseg, tl = lm - br * Tseg;
-                if (lm < Mg)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), qkv_r,
-                                                           (unsigned)(((br * T + f0 + tl) * 3 * E + 16 * (rank + 32 * j) + 4 * (lane >> 4)) * 4), 0, 17);
-            };
-            if constexpr (K8 > 0) {
-                f32x4 acc[18];
-                if (trace && tid == 0) trace[64] = wall_clock64();
-                __builtin_amdgcn_sched_barrier(0);
-                seg_run_k8<3, K8, SEG_DIAG>(acc, hb3_r, E / 32, step_rsrc(Lw.qkv_wt), KBE, rank, 32, 2 * w, lane,
-                                                      [&] { if (rank < nitems) attn_prefetch(l, rank); });
-                __builtin_amdgcn_sched_barrier(0);
-                if (trace) {
-                    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[17]));
-                    if (tid == 0) trace[65] = wall_clock64();
-                    if (lane == 0) trace[72 + w] = wall_clock64();
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    seg_partials_k8<3>(acc, r, red, w, lane);
-                    if (r == 0 && trace && tid == 0) trace[66] = wall_clock64();
-                    for (int pp = w; pp < 9; pp += 8) qkv_store(seg_sum<8>(red, 9, pp, lane), 3 * r + pp % 3, pp / 3);
-                }
-                if (trace && tid == 0) trace[67] = wall_clock64();
-            } else {
-                // waves = (row half, K slice): with 96 rows both halves run side by side, each wave four k-blocks deep
-                constexpr int NH = MB / 3, KS = 8 / NH, KQ = KBE / 2 / KS;  // row halves, K slices, 32-deep k-blocks per wave
-                const int rh = w / KS, ks = w - rh * KS;
-                SegBuf<3, 3> sb;
+            // Geometry of the qkv / MLP-up GEMMs -- waves = (row half, K slice): with 96 rows both halves run side by side, each
+            // wave four k-blocks deep; column tiles rank, rank + 32, rank + 64 -- and of MLP-down: 96 rows 2-D, workgroup (row
+            // half, column-tile pair): half the activation bytes per workgroup of the all-rows x one-tile split; 48 rows:
+            // column tile rank, all rows
+            constexpr int NH = MB / 3, KS = 8 / NH, KQ = KBE / 2 / KS;  // row halves, K slices, 32-deep k-blocks per wave
+            const int rh = w / KS, ks = w - rh * KS;
+            constexpr int NTD = MB == 6 ? 2 : 1, KD = KBM / 16;
+            const int rb0d = MB == 6 ? 3 * (rank & 1) : 0, tile0d = MB == 6 ? 2 * (rank >> 1) : rank;
+            SegBuf<3, 3> sbq;
+            {
+                const __amdgpu_buffer_rsrc_t Wq = step_rsrc(Lw.qkv_wt);
+                if (!end_phase(ln_mine)) return;
+                // ---- qkv (bf16 x 3 split MFMAs), three row blocks at a time; the rows are written through to memory (the next
+                //      XCD's attention reads the last W - 1 frames)
                 f32x4 acc[9];
                 if (trace && tid == 0) trace[64] = wall_clock64();
                 __builtin_amdgcn_sched_barrier(0);
-                seg_load<3, 3>(sb, 0, hb3_r, E / 32, 3 * rh, step_rsrc(Lw.qkv_wt), KBE, rank, 32, KQ * ks, lane);
-                seg_run<3, 3, KQ, SEG_DIAG>(acc, sb, hb3_r, E / 32, 3 * rh, step_rsrc(Lw.qkv_wt), KBE, rank, 32, KQ * ks, lane,
-                                  [&] { if (rank < nitems) attn_prefetch(l, rank); });
+                seg_load_a<3, 3>(sbq, 0, hb3_r, E / 32, 3 * rh, KQ * ks, lane);
+                seg_load_w<3, 3>(sbq, 0, Wq, KBE, rank, 32, KQ * ks, lane);
+                seg_run<3, 3, KQ, SEG_DIAG>(acc, sbq, hb3_r, E / 32, 3 * rh, Wq, KBE, rank, 32, KQ * ks, lane,
+                                            [&] { if (rank < nitems) attn_prefetch(l, rank); });
                 __builtin_amdgcn_sched_barrier(0);
                 if (trace) {  // (every wave drains its MFMAs first: the stamp is the end of wave 0's arithmetic)
                     asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[8]));
@@ -1866,13 +1826,16 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 if (trace && tid == 0) trace[66] = wall_clock64();
                 __builtin_amdgcn_sched_barrier(0);
                 for (int p = w; p < 9 * NH; p += 8) {
-                    const int hh = p / 9, pp = p - 9 * hh;
-                    qkv_store(seg_sum<KS>(red + (size_t)hh * KS * 9 * 256, 9, pp, lane), 3 * hh + pp % 3, pp / 3);
+                    const int hh = p / 9, pp = p - 9 * hh, j = pp / 3;
+                    const f32x4 o = seg_sum<KS>(red + (size_t)hh * KS * 9 * 256, 9, pp, lane);
+                    const int lm = 16 * (3 * hh + pp % 3) + (lane & 15), br = lm / Tseg, tl = lm - br * Tseg;
+                    if (lm < Mg)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), qkv_r,
+                                                               (unsigned)(((br * T + f0 + tl) * 3 * E + 16 * (rank + 32 * j) + 4 * (lane >> 4)) * 4), 0, 17);
                 }
                 if (trace && tid == 0) trace[67] = wall_clock64();
             }
-            if (!end_phase(true)) return;
-            if (rank == 0 && tid == 0) __builtin_amdgcn_raw_buffer_store_b32(seq, step_rsrc(&st->qkv_seq[g][0]), 0, 0, 17);
+            if (!end_phase(true, &st->qkv_seq[g][0], seq)) return;
             // ---- attention + residual + AdaLN(cond) + norm3: one workgroup per chunk of a CFG row; a chunk whose window
             //      starts in front of the segment waits for the previous XCD's rows
             for (int it = rank; it < nitems; it += (int)n) {
@@ -1887,52 +1850,14 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 seg_attention(StepAttn{T, a.cs, a.W, 0, a.nkmax, a.rope_cos, a.rope_sin, Lw.qkv}, cond_ab + (size_t)br * a.cond_ld + (size_t)l * 2 * E,
                               Lw.n3w, Lw.n3b, br, br * Tseg - f0, i0f / a.cs, halo, smem, kvl, xres, reinterpret_cast<float*>(hb3));
             }
-            // (segw bit 2: every workgroup requests its own MLP-up weight tiles into the L2 -- by the waves that did not store a
-            //  row in the LayerNorm tail (waves >= cs: nothing of theirs has to be in the L2 before the barrier))
-            const bool att_stored = rank < nitems && w < a.cs;
-            if ((segw & 4) && !att_stored)
-                seg_warm_tiles(wsink, Lw.mlp0_wt, KBE, rank, 32, kSNTU, rank < nitems ? w - a.cs : w, rank < nitems ? 8 - a.cs : 8, lane);
-            if (rank >= nitems && wact && (a.warm[1] | a.warm[2])) {  // workgroups without a chunk: warm the MLP weights into this XCD's L2 (step_warm)
-                const size_t wbytes = (size_t)E * ME * sizeof(float);
-                const int wi = (rank - nitems) * 8 + w, nw = ((int)n - nitems) * 8;
-                unsigned sink = 0;
-                step_warm(sink, Lw.mlp0_wt, wbytes * a.warm[1] / 16, wi, nw, lane);
-                step_warm(sink, Lw.mlp2_wt, wbytes * a.warm[2] / 16, wi, nw, lane);
-                step_warm_done(sink);
-            }
-            if (!end_phase((segw & 4) ? att_stored : true)) return;
-            if (rank == 0 && tid == 0) __builtin_amdgcn_raw_buffer_store_b32(seq, step_rsrc(&st->att_seq[g][0]), 0, 0, 17);
-            // ---- MLP up + GELU: column tiles rank + 32 j; the hidden layer as bf16 x 3 planes
-            // (segw bit 3: behind the phase's own operand requests every wave asks for a share of the workgroup's MLP-down weight
-            //  tiles -- the tile pair 2 (rank / 2), + 1, half each of the two row-half workgroups -- into the L2)
-            auto warm_down = [&] {
-                if (segw & 8) {
-                    if constexpr (MB == 6) seg_warm_tiles(wsink, Lw.mlp2_wt, KBM, 2 * (rank >> 1), 1, 2, 8 * (rank & 1) + w, 16, lane);
-                    else seg_warm_tiles(wsink, Lw.mlp2_wt, KBM, rank, 1, 1, w, 8, lane);
-                }
-            };
-            auto up_store = [&](const f32x4& o, const f32x4& bv, int rb, int j) {
-                p32_store4(mlp3, 16 * rb + (lane & 15), 16 * (rank + 32 * j) + 4 * (lane >> 4), ME / 32, gelu_erf(o[0] + bv[0]),
-                           gelu_erf(o[1] + bv[1]), gelu_erf(o[2] + bv[2]), gelu_erf(o[3] + bv[3]));
-            };
-            if constexpr (K8 > 0) {
-                f32x4 acc[6 * kSNTU];
-                // (epilogue operands before the GEMM: wave w finishes tile pp = w of either row half, wave 0 also pp = 8)
-                const f32x4 bv0 = *reinterpret_cast<const f32x4*>(Lw.mlp0_b + 16 * (rank + 32 * (w / 3)) + 4 * (lane >> 4));
-                const f32x4 bv1 = *reinterpret_cast<const f32x4*>(Lw.mlp0_b + 16 * (rank + 32 * (kSNTU - 1)) + 4 * (lane >> 4));
-                seg_run_k8<kSNTU, K8, SEG_DIAG>(acc, hb3_r, E / 32, step_rsrc(Lw.mlp0_wt), KBE, rank, 32, 2 * w, lane, warm_down);
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    seg_partials_k8<kSNTU>(acc, r, red, w, lane);
-                    for (int pp = w; pp < 3 * kSNTU; pp += 8)
-                        up_store(seg_sum<8>(red, 3 * kSNTU, pp, lane), pp == w ? bv0 : bv1, 3 * r + pp % 3, pp / 3);
-                }
-            } else {
-                constexpr int NH = MB / 3, KS = 8 / NH, KQ = KBE / 2 / KS;
-                const int rh = w / KS, ks = w - rh * KS;
-                SegBuf<3, kSNTU> sb;
+            SegBuf<3, kSNTU> sbu;
+            {
+                const __amdgpu_buffer_rsrc_t Wu = step_rsrc(Lw.mlp0_wt);
+                if (!end_phase(true, &st->att_seq[g][0], seq)) return;
+                // ---- MLP up + GELU: column tiles rank + 32 j; the hidden layer as bf16 x 3 planes
                 f32x4 acc[3 * kSNTU];
-                seg_load<3, kSNTU>(sb, 0, hb3_r, E / 32, 3 * rh, step_rsrc(Lw.mlp0_wt), KBE, rank, 32, KQ * ks, lane);
+                seg_load_a<3, kSNTU>(sbu, 0, hb3_r, E / 32, 3 * rh, KQ * ks, lane);
+                seg_load_w<3, kSNTU>(sbu, 0, Wu, KBE, rank, 32, KQ * ks, lane);
                 // (epilogue operands before the GEMM: wave w finishes tiles p = w, w + 8, w + 16)
                 f32x4 bvs[3];
 #pragma unroll
@@ -1941,50 +1866,44 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                     bvs[q] = p < 3 * kSNTU * NH ? *reinterpret_cast<const f32x4*>(Lw.mlp0_b + 16 * (rank + 32 * (pp / 3)) + 4 * (lane >> 4))
                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                seg_run<3, kSNTU, KQ, SEG_DIAG>(acc, sb, hb3_r, E / 32, 3 * rh, step_rsrc(Lw.mlp0_wt), KBE, rank, 32, KQ * ks, lane, warm_down);
+                seg_run<3, kSNTU, KQ, SEG_DIAG>(acc, sbu, hb3_r, E / 32, 3 * rh, Wu, KBE, rank, 32, KQ * ks, lane, [] {});
                 seg_partials<3 * kSNTU>(acc, red, w, lane);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const int p = w + 8 * q;
                     if (p >= 3 * kSNTU * NH) break;
-                    const int hh = p / (3 * kSNTU), pp = p - 3 * kSNTU * hh;
-                    up_store(seg_sum<KS>(red + (size_t)hh * KS * 3 * kSNTU * 256, 3 * kSNTU, pp, lane), bvs[q], 3 * hh + pp % 3, pp / 3);
+                    const int hh = p / (3 * kSNTU), pp = p - 3 * kSNTU * hh, j = pp / 3, ib = pp - 3 * j, tile = rank + 32 * j;
+                    const f32x4 bv = bvs[q];
+                    const f32x4 o = seg_sum<KS>(red + (size_t)hh * KS * 3 * kSNTU * 256, 3 * kSNTU, pp, lane);
+                    p32_store4(mlp3, 16 * (3 * hh + ib) + (lane & 15), 16 * tile + 4 * (lane >> 4), ME / 32, gelu_erf(o[0] + bv[0]),
+                               gelu_erf(o[1] + bv[1]), gelu_erf(o[2] + bv[2]), gelu_erf(o[3] + bv[3]));
                 }
             }
-            if (!end_phase(true)) return;
-            // ---- MLP down + residual.  96 rows: 2-D -- workgroup (row half, column-tile pair): half the activation bytes
-            //      per workgroup of the all-rows x one-tile split; 48 rows: column tile rank, all rows
+            SegBuf<3, NTD> sbd;
             {
-                constexpr int NTD = MB == 6 ? 2 : 1;
-                const int rb0 = MB == 6 ? 3 * (rank & 1) : 0, tile0 = MB == 6 ? 2 * (rank >> 1) : rank;
+                const __amdgpu_buffer_rsrc_t Wd = step_rsrc(Lw.mlp2_wt);
+                if (!end_phase(true)) return;
+                // ---- MLP down + residual
                 f32x4 acc[3 * NTD], bv[NTD], rv[NTD];
+                seg_load_a<3, NTD>(sbd, 0, mlp3_r, ME / 32, rb0d, KD * w, lane);
+                seg_load_w<3, NTD>(sbd, 0, Wd, KBM, tile0d, 1, KD * w, lane);
 #pragma unroll
                 for (int j = 0; j < NTD; ++j) {
                     bv[j] = rv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (w < 3) {
-                        bv[j] = *reinterpret_cast<const f32x4*>(Lw.mlp2_b + 16 * (tile0 + j) + 4 * (lane >> 4));
-                        rv[j] = ld_l2(xres_r, (unsigned)((((rb0 + w) * KBE + tile0 + j) << 8) + lane * 4));
+                        bv[j] = *reinterpret_cast<const f32x4*>(Lw.mlp2_b + 16 * (tile0d + j) + 4 * (lane >> 4));
+                        rv[j] = ld_l2(xres_r, (unsigned)((((rb0d + w) * KBE + tile0d + j) << 8) + lane * 4));
                     }
                 }
-                {
-                    SegBuf<3, NTD> sb;
-                    seg_load<3, NTD>(sb, 0, mlp3_r, ME / 32, rb0, step_rsrc(Lw.mlp2_wt), KBM, tile0, 1, (KBM / 16) * w, lane);
-                    seg_run<3, NTD, KBM / 16, SEG_DIAG>(acc, sb, mlp3_r, ME / 32, rb0, step_rsrc(Lw.mlp2_wt), KBM, tile0, 1, (KBM / 16) * w, lane,
-                                              [&] {
-                                                  if (l + 1 < a.L) ln_prefetch(l + 1);
-                                                  // (segw bit 1: ... and the workgroup's qkv weight tiles of the next layer /
-                                                  //  of the next step's first layer into the L2)
-                                                  if ((segw & 2) && (l + 1 < a.L || i + 1 < a.nsteps))
-                                                      seg_warm_tiles(wsink, a.layer[l + 1 < a.L ? l + 1 : 0].qkv_wt, KBE, rank, 32, 3, w, 8, lane);
-                                              });
-                }
+                seg_run<3, NTD, KD, SEG_DIAG>(acc, sbd, mlp3_r, ME / 32, rb0d, Wd, KBM, tile0d, 1, KD * w, lane,
+                                              [&] { if (l + 1 < a.L) ln_prefetch(l + 1); });
 #pragma unroll
                 for (int j = 0; j < NTD; ++j) {
                     f32x4 o = seg_reduce<3>(acc, j, red, w, lane);
                     if (w < 3) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) o[r] = o[r] + bv[j][r] + rv[j][r];
-                        *reinterpret_cast<f32x4*>(xres + ((size_t)((rb0 + w) * KBE + tile0 + j) << 8) + lane * 4) = o;
+                        *reinterpret_cast<f32x4*>(xres + ((size_t)((rb0d + w) * KBE + tile0d + j) << 8) + lane * 4) = o;
                     }
                 }
             }
@@ -2050,6 +1969,14 @@ __global__ __launch_bounds__(256) void tile16_kernel(const float* __restrict__ W
     const int r = l & 15, kq = l >> 4;
     *reinterpret_cast<f32x4*>(out + idx * 4) = *reinterpret_cast<const f32x4*>(W + (size_t)(16 * tile + r) * ldw + 16 * kb + 4 * kq);
 }
+
+// (explicit: with the generic lambdas of step_attention in the tree, hipcc 7.2 drops the implicit instantiations that the host
+//  code below asks for -- the objects then carry undefined kernel handles)
+template __global__ void stream_step_kernel<1>(StepArgs);
+template __global__ void stream_step_kernel<2>(StepArgs);
+template __global__ void stream_step_kernel<3>(StepArgs);
+template __global__ void sample_seg_kernel<3>(StepArgs);
+template __global__ void sample_seg_kernel<6>(StepArgs);
 
 }  // namespace
 }  // namespace after
@@ -2130,7 +2057,8 @@ struct after_denoiser {
     int persist_check = 0;         // after_denoiser_set_persist_check: 1 = every persistent call synchronises and reports its own failure
     int step_dbg = 0;  // after_denoiser_set_stream_persist(h, 1 | dbg << 8): diagnostics bits OR-ed into AFTER_STEP_DBG
     StepSync* step_sync = nullptr;       // [max_steps]: one barrier state per step of a sample() call
-    unsigned long long* step_trace = nullptr;  // AFTER_STEP_TRACE=1: stamps of the LAST step launched (diagnostics)
+    unsigned long long* step_trace = nullptr;  // stamps of the LAST step launched (diagnostics: AFTER_STEP_TRACE=1 / after_denoiser_set_step_trace)
+    bool step_trace_on = false;
     unsigned* step_fail = nullptr;       // pinned host copy of the device's sticky failure words (persist_poll)
     float *step_wt = nullptr, *step_act = nullptr;  // 16 x 16-tiled weight copies; per-XCD tiled activation slices
     const float *step_patch_wt = nullptr, *step_out_wt = nullptr;
@@ -2910,6 +2838,7 @@ int persist_prepare(after_denoiser* h, bool offline) {
         }
         memset(failw, 0, 32 * sizeof(unsigned));
         h->step_sync = sync, h->step_fail = failw, h->step_ev = ev, h->step_trace = trace, h->step_wt = wt, h->step_act = act;
+        h->step_trace_on = trace != nullptr;
         h->step_patch_wt = patch_wt, h->step_out_wt = out_wt;
         h->step_layers = std::move(layers);
     }
@@ -2931,8 +2860,7 @@ int persist_prepare(after_denoiser* h, bool offline) {
     // the kernels' dynamic LDS limits (a hipFuncSetAttribute inside after_sample would be one more first-call cost)
     {
         const size_t lds_seg = ((size_t)kSRedFloats(2) + 8 * 2 * kAttnKeyBlock * 64) * sizeof(float);
-        const void* fns[] = {reinterpret_cast<const void*>(sample_seg_kernel<6, 0>), reinterpret_cast<const void*>(sample_seg_kernel<6, 2>),
-                             reinterpret_cast<const void*>(sample_seg_kernel<6, 3>), reinterpret_cast<const void*>(sample_seg_kernel<3, 0>),
+        const void* fns[] = {reinterpret_cast<const void*>(sample_seg_kernel<6>), reinterpret_cast<const void*>(sample_seg_kernel<3>),
                              reinterpret_cast<const void*>(persist_census_kernel)};
         for (const void* fn : fns) AFTER_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_seg));
         const void* sf[] = {reinterpret_cast<const void*>(stream_step_kernel<1>), reinterpret_cast<const void*>(stream_step_kernel<2>),
@@ -3033,7 +2961,7 @@ int sample_persistent(after_denoiser* h, hipStream_t s, const float* x0, float* 
         a.kcache = h->kcache, a.vcache = h->vcache;
         a.cfg = reinterpret_cast<const float*>(h->dparams);
         a.sync = h->step_sync;
-        a.trace = h->step_trace;
+        a.trace = h->step_trace_on ? h->step_trace : nullptr;
         {
             static int dbg = -1;
             if (dbg < 0) {
@@ -3116,7 +3044,7 @@ int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, in
     a.x0 = x0, a.xout = out;
     a.cfg = reinterpret_cast<const float*>(h->dparams);
     a.sync = h->step_sync;
-    a.trace = h->step_trace;
+    a.trace = h->step_trace_on ? h->step_trace : nullptr;
     {
         static int dbg = -1;
         if (dbg < 0) {
@@ -3124,13 +3052,7 @@ int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, in
             dbg = e ? atoi(e) : 0;
         }
         a.dbg = dbg | h->step_dbg;
-        static int warm[3] = {-1, 0, 0};
-        if (warm[0] < 0) {
-            warm[0] = 0, warm[1] = 0, warm[2] = 0;  // (measured: warming during the attention phase does not pay here)
-            const char* e = getenv("AFTER_SEG_WARM");
-            if (e) sscanf(e, "%d,%d,%d", &warm[0], &warm[1], &warm[2]);
-        }
-        a.warm[0] = warm[0], a.warm[1] = warm[1], a.warm[2] = warm[2];
+        a.warm[0] = a.warm[1] = a.warm[2] = 0;
     }
     for (int l = 0; l < L; ++l) {
         const LayerW& w = h->layers[l];
@@ -3141,20 +3063,10 @@ int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, in
     }
     const bool timed = h->timer.enabled && h->timer_kernel == 3;
     if (timed) h->timer.begin(s);
-    static int k8 = -1, segw = -1;
-    if (k8 < 0) {
-        const char* e = getenv("AFTER_SEG_K8");
-        k8 = e ? atoi(e) : 0;
-        e = getenv("AFTER_SEG_W");
-        segw = e ? atoi(e) : 0;
-    }
-    a.segw = segw;
     {
         PersistLaunch guard(h->dev, s);
-        if (MB == 6 && k8 == 2) hipLaunchKernelGGL((sample_seg_kernel<6, 2>), dim3(h->n_cus), dim3(512), lds, s, a);
-        else if (MB == 6 && k8) hipLaunchKernelGGL((sample_seg_kernel<6, 3>), dim3(h->n_cus), dim3(512), lds, s, a);
-        else if (MB == 6) hipLaunchKernelGGL((sample_seg_kernel<6, 0>), dim3(h->n_cus), dim3(512), lds, s, a);
-        else hipLaunchKernelGGL((sample_seg_kernel<3, 0>), dim3(h->n_cus), dim3(512), lds, s, a);
+        if (MB == 6) hipLaunchKernelGGL(sample_seg_kernel<6>, dim3(h->n_cus), dim3(512), lds, s, a);
+        else hipLaunchKernelGGL(sample_seg_kernel<3>, dim3(h->n_cus), dim3(512), lds, s, a);
     }
     AFTER_HIP_CHECK(hipGetLastError());
     if (timed) {
@@ -3374,9 +3286,20 @@ extern "C" int after_denoiser_sample_persist(after_denoiser* h, int* active) {
     return AFTER_OK;
 }
 
+extern "C" int after_denoiser_set_step_trace(after_denoiser* h, int enable) {
+    AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
+    if (enable && !h->step_trace) {
+        AFTER_REQUIRE(h->step_sync, AFTER_E_INVALID, "no persistent sampler is provisioned on this handle");
+        AFTER_HIP_CHECK(hipMalloc(&h->step_trace, (size_t)h->n_cus * 128 * sizeof(unsigned long long)));
+        AFTER_HIP_CHECK(hipMemset(h->step_trace, 0, (size_t)h->n_cus * 128 * sizeof(unsigned long long)));
+    }
+    h->step_trace_on = enable != 0;
+    return AFTER_OK;
+}
+
 extern "C" int after_denoiser_step_trace(after_denoiser* h, unsigned long long* out, int n_workgroups) {
     AFTER_REQUIRE(h && out, AFTER_E_INVALID, "null argument");
-    AFTER_REQUIRE(h->step_trace, AFTER_E_INVALID, "no trace: AFTER_STEP_TRACE=1 and one streaming after_sample call first");
+    AFTER_REQUIRE(h->step_trace, AFTER_E_INVALID, "no trace: after_denoiser_set_step_trace(h, 1) (or AFTER_STEP_TRACE=1) and one persistent after_sample call first");
     AFTER_REQUIRE(n_workgroups == h->n_cus, AFTER_E_INVALID, "the step kernel runs %d workgroups", h->n_cus);
     AFTER_HIP_CHECK(hipDeviceSynchronize());
     AFTER_HIP_CHECK(hipMemcpy(out, h->step_trace, (size_t)h->n_cus * 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost));

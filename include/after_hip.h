@@ -179,8 +179,12 @@ int after_denoiser_set_persist_check(after_denoiser* h, int mode);
 /* Waits for the failure words of the handle's last persistent launch (if not yet looked at) and reports them:
  * AFTER_E_HIP if a persistent sampler failed since the last look, AFTER_OK otherwise (also without persistent launches). */
 int after_denoiser_check(after_denoiser* h, void* stream);
-/* Diagnostics (AFTER_STEP_TRACE=1 at the first streaming call): out[workgroup][128] = 100 MHz wall-clock stamps of
- * the last persistent step -- [0] start, [2r-1] / [2r] arrival at / exit from barrier r, then the end; [127] = XCC. */
+/* Diagnostics / bench.py's per-phase roofline.  _set_step_trace(h, 1) (a configuration call: allocates the stamp buffer; also
+ * AFTER_STEP_TRACE=1 in the environment when the persistent samplers are provisioned) makes every workgroup of a persistent
+ * launch stamp the 100 MHz wall clock around each XCD-local barrier; _step_trace synchronises the device and returns
+ * out[workgroup][128] of the LAST Euler step launched -- [0] start, [2r-1] / [2r] arrival at / exit from barrier r, then the
+ * end; [127] = XCC. */
+int after_denoiser_set_step_trace(after_denoiser* h, int enable);
 int after_denoiser_step_trace(after_denoiser* h, unsigned long long* out, int n_workgroups);
 
 /* Streaming KV caches (transformerv2.py:143-204; enabled in the reference by the

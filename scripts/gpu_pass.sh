@@ -33,6 +33,26 @@ seg_a)  # round 4: persistent offline sampler after the de-spill pass -- K split
     done
     tail -12 "$out/trace_k0_w0.txt"
     ;;
+seg_c)  # round 4: halo keys last in the offline persistent sampler's attention
+    timeout 900 python -m pytest tests/test_sample_persist_gpu.py tests/test_persist_protocol_gpu.py -x -q > "$out/test.log" 2>&1
+    tail -n 3 "$out"/test.log
+    ts launch AFTER_SAMPLE_PERSIST=0
+    ts persist; ts persist
+    cat "$out/times.log"
+    timeout 300 python scripts/stream_step_trace.py --offline > "$out/trace.txt" 2>&1
+    timeout 300 python scripts/stream_step_trace.py --offline --xcd 3 > "$out/trace_xcd3.txt" 2>&1
+    head -12 "$out/trace_xcd3.txt"; tail -5 "$out/trace.txt"
+    ;;
+seg_b)  # round 4: attention of the offline persistent sampler with one round trip per item; weight prefetch across the barriers
+    timeout 900 python -m pytest tests/test_sample_persist_gpu.py -x -q > "$out/test_pre0.log" 2>&1
+    AFTER_SEG_PRE=7 timeout 900 python -m pytest tests/test_sample_persist_gpu.py -x -q > "$out/test_pre7.log" 2>&1
+    tail -n 3 "$out"/test_*.log
+    ts launch AFTER_SAMPLE_PERSIST=0
+    for p in 0 1 6 7 14 15 0; do ts "persist pre=$p" AFTER_SEG_PRE=$p; done
+    cat "$out/times.log"
+    for p in 0 7; do AFTER_SEG_PRE=$p timeout 300 python scripts/stream_step_trace.py --offline > "$out/trace_pre$p.txt" 2>&1; done
+    head -12 "$out/trace_pre0.txt"; tail -5 "$out/trace_pre0.txt"
+    ;;
 persist_tests)  # round 4: the persistent samplers' host protocol + every test that touches them
     timeout 1700 python -m pytest tests/test_persist_protocol_gpu.py tests/test_stream_persist_gpu.py tests/test_sample_persist_gpu.py \
         tests/test_baseline_size_gpu.py tests/test_denoiser_gpu.py tests/test_streamer_gpu.py -x -q > "$out/tests.log" 2>&1

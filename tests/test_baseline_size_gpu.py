@@ -160,15 +160,16 @@ def test_base_streamer_8_streams_100_steps_vs_oracle(hip_device, both_gemm_paths
 
 def test_midi_streamer_base_dims_persistent_vs_oracle(hip_device, both_gemm_paths):
     """export_midi.py's Streamer at the midi config's real width (embed 512, window 16 -> 19 keys per chunk: two key blocks
-    of the online softmax, a 16-frame K / V ring; piano-roll conditioning, CFG_MIDI): two streams, 8 cached steps, 4 chunks
-    against the oracle's K / V-cache sampler.  Under `fp32mfma` on the persistent streaming sampler -- asserted."""
+    of the online softmax, a 16-frame K / V ring; piano-roll conditioning, CFG_MIDI): 8 cached steps, 4 chunks
+    against the oracle's K / V-cache sampler (one stream: the reference's MIDI Streamer diffuses x[:1]).  Under `fp32mfma`
+    on the persistent streaming sampler -- asserted."""
     from after_amd import MidiStreamer
     from oracle.sampler import CFG_MIDI
     model, dcfg, acfg = pipeline.build_models("midi", "baseAE_causal", hip_device, seed=13)
     sd = cpu_sd(model)
     sd_net = {k[4:]: v for k, v in sd.items() if k.startswith("net.")}
     ncfg = dcfg["net"]
-    chunk, steps, n_chunks, nsig, n_poly, n = 4, 8, 4, 128, 4, 2
+    chunk, steps, n_chunks, nsig, n_poly, n = 4, 8, 4, 128, 4, 1
     st = MidiStreamer(model, model.emb_model, n_poly=n_poly, chunk_size=chunk, n_signal_timbre=nsig, max_batch=n,
                       max_nb_steps=steps)
     st.set_nb_steps(steps)
