@@ -271,9 +271,10 @@ __global__ __launch_bounds__(256) void gn_window_kernel(const float* __restrict_
         }
         __syncthreads();
     }
-    if (tid == 0) {
-        stats[((size_t)b * G + g) * 2] = red[0][0];
-        stats[((size_t)b * G + g) * 2 + 1] = red[1][0];
+    if (tid == 0) {  // (the act_pad consumer reads binned integer words: conv.h, stat_bins)
+        long long* sp = reinterpret_cast<long long*>(stats) + ((size_t)b * G + g) * kStatWords;
+        stat_bins_set(sp, red[0][0]);
+        stat_bins_set(sp + kStatBins, red[1][0]);
     }
 }
 
@@ -376,7 +377,7 @@ struct after_ae {
     const float* next_alpha = nullptr;  // Snake of the following resampling conv: request to the next
     const float* next_invb = nullptr;   //   run_dma to emit that conv's activated input itself
     size_t xp_elems = 0;
-    double* stats_ring = nullptr; // [kStatSlots][stat_sub][max_batch][8][2]
+    double* stats_ring = nullptr; // [kStatSlots][stat_sub][max_batch][8][2][kStatBins] 64-bit words (conv.h: stat_bins)
     int stat_sub = 1;             // accumulator pairs per (clip, group): conv_tm_stat_sub() on the time-major path
     int stat_slot = 0;
     Arena wd;                     // repacked weights
@@ -506,7 +507,7 @@ int make_dma(after_ae* h, DmaConv& d, const float* packed, int cin, int cout, in
 }
 
 double* next_stats(after_ae* h, int B) {
-    double* p = h->stats_ring + (size_t)(h->stat_slot % kStatSlots) * h->stat_sub * h->max_batch * 16;
+    double* p = h->stats_ring + (size_t)(h->stat_slot % kStatSlots) * h->stat_sub * h->max_batch * 8 * kStatWords;
     ++h->stat_slot;
     (void)B;
     return p;
@@ -547,7 +548,7 @@ int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const 
         p.G = cin < 8 ? cin : 8;
         p.x_cm = x_cm;
         p.stat_T = stat_T;
-        p.sub_stride = h->max_batch * 16;
+        p.sub_stride = h->max_batch * 8 * kStatWords;
         AFTER_TRY(launch_act_pad_tm(p, s));
         xin = h->xp;
     }
@@ -568,7 +569,7 @@ int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const 
     r.Tout = Tout;
     r.Nn = Nn;
     r.y_cm = y_cm;
-    r.sub_stride = h->max_batch * 16;
+    r.sub_stride = h->max_batch * 8 * kStatWords;
     static int fuse_snake = -1;  // AFTER_AE_FUSE_SNAKE=0: A/B switch (separate act_pad launches)
     if (fuse_snake < 0) {
         const char* e = getenv("AFTER_AE_FUSE_SNAKE");
@@ -657,7 +658,7 @@ int begin_pass(after_ae* h, hipStream_t s) {
     h->next_alpha = h->next_invb = nullptr;
     if (h->norm)
         AFTER_HIP_CHECK(hipMemsetAsync(h->stats_ring, 0,
-                                       (size_t)kStatSlots * h->stat_sub * h->max_batch * 16 * sizeof(double), s));
+                                       (size_t)kStatSlots * h->stat_sub * h->max_batch * 8 * kStatWords * sizeof(double), s));
     return AFTER_OK;
 }
 
@@ -1012,12 +1013,12 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
         }
     }
     h->xp_elems = xpe * max_batch + 4096;
-    rc = h->ws.init(3 * h->buf_elems * sizeof(float) + 8192 + 2 * h->xp_elems * sizeof(float) + (size_t)kStatSlots * h->stat_sub * max_batch * 16 * sizeof(double));
+    rc = h->ws.init(3 * h->buf_elems * sizeof(float) + 8192 + 2 * h->xp_elems * sizeof(float) + (size_t)kStatSlots * h->stat_sub * max_batch * 8 * kStatWords * sizeof(double));
     if (rc != AFTER_OK) return fail(rc);
     for (int i = 0; i < 3; ++i) h->buf[i] = h->ws.take<float>(h->buf_elems);
     h->xp = h->ws.take<float>(h->xp_elems);
     h->xp2 = h->ws.take<float>(h->xp_elems);
-    h->stats_ring = h->ws.take<double>((size_t)kStatSlots * h->stat_sub * max_batch * 16);
+    h->stats_ring = h->ws.take<double>((size_t)kStatSlots * h->stat_sub * max_batch * 8 * kStatWords);
     if (!h->buf[2] || !h->xp || !h->xp2 || !h->stats_ring) return fail(AFTER_E_NOMEM);
     if (hipDeviceSynchronize() != hipSuccess) {
         set_error("autoencoder: device initialisation failed");

@@ -10,6 +10,57 @@ enum ConvPad { PAD_ZERO = 0, PAD_REFLECT = 1 };
 constexpr int kMaxTaps = 8;
 constexpr int kMaxPhases = 4;
 
+// ---- GroupNorm statistics, accumulated across workgroups EXACTLY (round 4; before: fp64 atomicAdd of fp32 partial sums --
+// exact, hence order-independent, only while the partials of one (clip, group) span < 2^19 in magnitude).
+// A quantity (sum, sum of squares) of one (clip, group) is kStatBins signed 64-bit words: word k accumulates the bits of
+// weight 2^(40 k - 64) .. 2^(40 k - 25) of every addend, as an integer.  An fp32 partial sum has a 24-bit significand: it is
+// split over at most two adjacent words and added with INTEGER atomics -- associative and commutative, so the result does
+// not depend on the order in which the workgroups arrive, by construction, whatever the magnitudes (no rounding happens
+// before the words are folded, top word first, into one fp64 by the consumer).  A word holds 2^40 x 2^23 addends before it
+// could overflow; addends below 2^-41 in magnitude lose bits at the bottom (flushed toward minus infinity by < 2^-64),
+// above 2^95 saturate -- neither occurs for sums of O(1 .. 1e4) activations.
+// Layout of a statistics buffer: [sub-slot][clip][group][2 quantities][kStatBins] 64-bit words (`double*` in the host-side
+// structs only names an 8-byte word).
+constexpr int kStatBins = 4;
+constexpr int kStatWords = 2 * kStatBins;  // words per (clip, group)
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ void stat_bins_add(long long* bins, float p) {
+    if (p == 0.f || !(fabsf(p) < 3.0e28f)) return;  // (NaN / inf / > 2^95: nothing sensible to accumulate)
+    int e;
+    const float f = frexpf(p, &e);                       // p = f x 2^e, 0.5 <= |f| < 1
+    const long long m = (long long)(f * 16777216.0f);    // 24-bit signed significand: p = m x 2^(e - 24), exactly
+    int pos = e - 24 + 64;                                // weight of m's least significant bit: 2^(pos - 64)
+    long long v = m;
+    if (pos < 0) {
+        v >>= min(-pos, 63);
+        pos = 0;
+    }
+    const int k = pos / 40, sh = pos - 40 * k;
+    v <<= sh;                                             // |v| < 2^63
+    const long long lo = v & ((1ll << 40) - 1), hi = v >> 40;  // v = hi x 2^40 + lo, 0 <= lo < 2^40 (floor semantics)
+    if (lo) atomicAdd(reinterpret_cast<unsigned long long*>(bins + k), (unsigned long long)lo);
+    if (hi && k + 1 < kStatBins) atomicAdd(reinterpret_cast<unsigned long long*>(bins + k + 1), (unsigned long long)hi);
+}
+// the words of one quantity, already summed over the sub-slots -> fp64 (top word first: a fixed order)
+__device__ __forceinline__ double stat_bins_total(const long long (&w)[kStatBins]) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = kStatBins - 1; k >= 0; --k) t += (double)w[k] * __builtin_ldexp(1.0, 40 * k - 64);
+    return t;
+}
+// a value computed elsewhere (the windowed GroupNorm of the streaming twin) stored in the same format, exactly
+__device__ __forceinline__ void stat_bins_set(long long* bins, double v) {
+#pragma unroll
+    for (int k = kStatBins - 1; k >= 0; --k) {
+        const double scale = __builtin_ldexp(1.0, 40 * k - 64);
+        const double q = trunc(v / scale);
+        bins[k] = (long long)q;
+        v -= q * scale;
+    }
+}
+#endif
+
 // BatchNorm1d (eval) -> per-channel affine, replicated over B (done once at create)
 int launch_bn_affine(const float* w, const float* b, const float* rm, const float* rv, float* scale,
                      float* shift, int C, int B, float eps, hipStream_t s);
@@ -49,7 +100,7 @@ struct ConvTmRun {
     const float* bias;
     const float* res;  // [B][Tout][Cout] time-major, or nullptr
     float* y;          // [B][Tout][Cout] time-major ([B][Cout][Tout] when y_cm)
-    double* stats;     // [conv_tm_stat_sub()][sub_stride] doubles, [B][G][2] in each: accumulators of y, or nullptr
+    double* stats;     // [conv_tm_stat_sub()][sub_stride] words, [B][G][2][kStatBins] in each: accumulators of y (stat_bins_add), or nullptr
     int B, Tp, Tout, Nn, G, y_cm, sub_stride;
     const float* post_scale;  // y = out_act(acc + bias) * post_scale[b * post_bstride + co] + post_shift[...]
     const float* post_shift;

@@ -80,7 +80,7 @@ __device__ __forceinline__ float act_apply(float v, int act, float pa, float pb)
 struct ActTmArgs {
     const float* x;       // [B][T][ldx] time-major, or [B][C][T] when x_cm
     float* y;             // [B][Tp][Cp]
-    const double* stats;  // [B][G][2] or nullptr
+    const double* stats;  // [sub-slot][B][G][2][kStatBins] 64-bit words (conv.h: stat_bins) or nullptr
     const float* gamma;   // with stats: GroupNorm weight; without: per-channel scale (or nullptr)
     const float* beta;
     const float* act_a;
@@ -175,18 +175,19 @@ __global__ __launch_bounds__(256) void act_pad_tm_kernel(ActTmArgs a) {
         if (threadIdx.x < a.G) {
             const int gI = threadIdx.x;
             const double n = (double)(a.C / a.G) * a.stat_T;
-            double sv[kStatSub], qv[kStatSub];
+            // the sub-slots' words add as integers (exact), then each quantity folds into one fp64 (conv.h: stat_bins)
+            const long long* sw = reinterpret_cast<const long long*>(a.stats) + ((size_t)b * a.G + gI) * kStatWords;
+            long long ws[kStatBins], wq[kStatBins];
 #pragma unroll
-            for (int u = 0; u < kStatSub; ++u) {
-                sv[u] = a.stats[(size_t)u * a.sub_stride + ((size_t)b * a.G + gI) * 2];
-                qv[u] = a.stats[(size_t)u * a.sub_stride + ((size_t)b * a.G + gI) * 2 + 1];
-            }
-            double s = 0, qq = 0;
+            for (int k = 0; k < kStatBins; ++k) ws[k] = wq[k] = 0;
 #pragma unroll
-            for (int u = 0; u < kStatSub; ++u) {
-                s += sv[u];
-                qq += qv[u];
-            }
+            for (int u = 0; u < kStatSub; ++u)
+#pragma unroll
+                for (int k = 0; k < kStatBins; ++k) {
+                    ws[k] += sw[(size_t)u * a.sub_stride + k];
+                    wq[k] += sw[(size_t)u * a.sub_stride + kStatBins + k];
+                }
+            const double s = stat_bins_total(ws), qq = stat_bins_total(wq);
             const double mean = s / n;
             double var = qq / n - mean * mean;
             var = var < 0 ? 0 : var;
@@ -249,7 +250,7 @@ struct ConvTmArgs {
     const float* bias;  // [Cout] or nullptr
     const float* res;   // [B][Tout][Cout] or nullptr
     float* y;           // [B][Tout][Cout]  (y_cm: [B][Cout][Tout])
-    double* stats;      // [kStatSub][sub_stride] with [B][G][2] inside: accumulators of y, or nullptr
+    double* stats;      // [kStatSub][sub_stride] words with [B][G][2][kStatBins] inside: accumulators of y, or nullptr
     int Cp, Cout, Tp, Tout, K, phases, lda, ostride, Nn, G, y_cm, sub_stride;
     int magic, extra;   // tap(s) = (s * magic) >> 16,  extra = (dil - 1) * Cp
     int abase[kMaxPhases];  // (HALO + toff[ph][0]) * Cp
@@ -623,9 +624,8 @@ __global__ __launch_bounds__(128 * KS * RS) void conv_tm_kernel(ConvTmArgs g, in
             const int grp = g0 + tid;
             const int glast = (min(n0 + BN, N) - 1) / Cg;
             if (grp <= glast) {
-                // this group's slots in (wave, column block, slot) order: a fixed summation order.  (Across
-                // workgroups the fp64 atomics below are exact, hence order-independent, unless the partial sums of
-                // one (clip, group) span more than ~2^19 in magnitude; they then differ by <= 1 ulp of fp64.)
+                // this group's slots in (wave, column block, slot) order: a fixed summation order.  Across workgroups
+                // the partial sums are added as integers (conv.h: stat_bins_add): exact and order-independent.
                 constexpr int NWV = 2 * KS * RS;
                 const int SL = quad ? 4 : 16, cstep = quad ? 4 : 1;
                 const float inv_cg = 1.0f / (float)Cg;
@@ -642,9 +642,10 @@ __global__ __launch_bounds__(128 * KS * RS) void conv_tm_kernel(ConvTmArgs g, in
                             }
                         }
                 }
-                double* sp = g.stats + (size_t)(blockIdx.x % kStatSub) * g.sub_stride + ((size_t)b * g.G + grp) * 2;
-                atomicAdd(sp, (double)s1);
-                atomicAdd(sp + 1, (double)q1);
+                long long* sp = reinterpret_cast<long long*>(g.stats) + (size_t)(blockIdx.x % kStatSub) * g.sub_stride +
+                                ((size_t)b * g.G + grp) * kStatWords;
+                stat_bins_add(sp, s1);
+                stat_bins_add(sp + kStatBins, q1);
             }
         }
     }
@@ -718,9 +719,9 @@ __global__ __launch_bounds__(256) void stats_accum_tm_kernel(const float* __rest
                 q += sh[W + c];
             }
         }
-        double* sp = stats + ((size_t)b * G + threadIdx.x) * 2;
-        atomicAdd(sp, (double)s);
-        atomicAdd(sp + 1, (double)q);
+        long long* sp = reinterpret_cast<long long*>(stats) + ((size_t)b * G + threadIdx.x) * kStatWords;
+        stat_bins_add(sp, s);
+        stat_bins_add(sp + kStatBins, q);
     }
 }
 
@@ -1167,7 +1168,7 @@ extern "C" int after_convtm_create(const float* w, const float* bias, int B, int
     const size_t xpn = (size_t)B * conv_tm_rows(T) * h->plan.Cp, yn = (size_t)B * Tout * Cout;
     const size_t packed = (size_t)Cout * k * pad16(Cin);
     int rc = h->ar.init((h->plan.w_floats + packed + Cout + xpn + (size_t)B * T * Cin + 2 * yn) * sizeof(float) +
-                        (size_t)conv_tm_stat_sub() * B * 16 * sizeof(double) + (1 << 16));
+                        (size_t)conv_tm_stat_sub() * B * 8 * kStatWords * sizeof(double) + (1 << 16));
     auto fail = [&](int code) {
         after_convtm_destroy(h);
         return code;
@@ -1180,7 +1181,7 @@ extern "C" int after_convtm_create(const float* w, const float* bias, int B, int
     h->xtm = h->ar.take<float>((size_t)B * T * Cin);
     h->ytm = h->ar.take<float>(yn);
     h->res = h->ar.take<float>(yn);
-    h->stats = h->ar.take<double>((size_t)conv_tm_stat_sub() * B * 16);
+    h->stats = h->ar.take<double>((size_t)conv_tm_stat_sub() * B * 8 * kStatWords);
     if (!h->stats || !h->plan.ok) {
         set_error("convtm: allocation failed or unsupported tap pattern");
         return fail(AFTER_E_INVALID);
@@ -1230,9 +1231,9 @@ extern "C" int after_convtm_run(after_convtm* h, const float* x, float* y, int m
         r.Tout = h->Tout;
         r.Nn = h->Tout;
         r.G = h->Cout < 8 ? h->Cout : 8;
-        r.sub_stride = h->B * 16;
+        r.sub_stride = h->B * 8 * kStatWords;
         if ((mode & 4) && h->Cout % r.G == 0) {
-            AFTER_HIP_CHECK(hipMemsetAsync(h->stats, 0, (size_t)conv_tm_stat_sub() * h->B * 16 * sizeof(double), s));
+            AFTER_HIP_CHECK(hipMemsetAsync(h->stats, 0, (size_t)conv_tm_stat_sub() * h->B * 8 * kStatWords * sizeof(double), s));
             r.stats = h->stats;
         }
         AFTER_TRY(launch_conv_tm(r, h->in, h->plan, s));

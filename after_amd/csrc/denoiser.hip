@@ -1530,10 +1530,17 @@ __device__ __forceinline__ void seg_split8(const f32x4& a, const f32x4& b, u32x4
 // loads), W: fp32 16 x 16 tiles, split into its planes in registers (a weight fragment serves all RB row blocks).  Software
 // pipeline over the k-blocks: the operands of k-block u + 1 are requested before the MFMAs of u (loads return in issue
 // order); seg_load(.., 0) of the first k-block is the caller's, so that it can be in flight behind other work.
+#ifndef SEG_SLOTS_A
+#define SEG_SLOTS_A 2
+#endif
+#ifndef SEG_SLOTS_W
+#define SEG_SLOTS_W 2
+#endif
+constexpr int kSegSlotsA = SEG_SLOTS_A, kSegSlotsW = SEG_SLOTS_W;  // k-blocks of a wave in flight or in use (rings of register slots)
 template <int RB, int NT>
 struct SegBuf {
-    f32x4 wr[2][NT][2];   // raw fp32 weight fragments of a 32-deep k-block, double-buffered
-    u32x4 ap[2][RB][3];   // activation planes
+    f32x4 wr[kSegSlotsW][NT][2];   // raw fp32 weight fragments of a 32-deep k-block
+    u32x4 ap[kSegSlotsA][RB][3];   // activation planes
 };
 
 constexpr bool kSegW = !(SEG_DIAG & 4);  // -DSEG_DIAG=4 (timing experiments): no weight traffic, wrong results
@@ -1568,39 +1575,45 @@ __device__ __forceinline__ void seg_load_w(SegBuf<RB, NT>& sb, int slot, __amdgp
 template <int RB, int NT, int KB, int DIAG, class F>  // DIAG (timing experiments, -DSEG_DIAG=n): 1 no MFMAs, 2 no weight split
 __device__ __forceinline__ void seg_run(f32x4 (&acc)[NT * RB], SegBuf<RB, NT>& sb, __amdgpu_buffer_rsrc_t A3, int a_kb32, int rb0,
                                         __amdgpu_buffer_rsrc_t W, int w_kblocks, int tile0, int ts, int kb0, int lane, F&& after_loads) {
+    constexpr int NA = kSegSlotsA, NW = kSegSlotsW, NX = NA > NW ? NA : NW;
+    // the rings: activation k-blocks u .. u + NA - 1 and weight k-blocks u .. u + NW - 1 are in flight or in use while u is
+    // multiplied (the loop is latency-bound: bytes in flight per CU are what it runs on)
+#pragma unroll
+    for (int v = 1; v < NX - 1 && v < KB; ++v) {
+        if (v < NA - 1) seg_load_a<RB, NT>(sb, v % NA, A3, a_kb32, rb0, kb0 + v, lane);
+        if (v < NW - 1) seg_load_w<RB, NT>(sb, v % NW, W, w_kblocks, tile0, ts, kb0 + v, lane);
+    }
 #pragma unroll
     for (int p = 0; p < NT * RB; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < KB; ++u) {
-        if (u + 1 < KB) {
-            seg_load_a<RB, NT>(sb, (u + 1) & 1, A3, a_kb32, rb0, kb0 + u + 1, lane);
-            seg_load_w<RB, NT>(sb, (u + 1) & 1, W, w_kblocks, tile0, ts, kb0 + u + 1, lane);
-        }
+        if (u + NA - 1 < KB) seg_load_a<RB, NT>(sb, (u + NA - 1) % NA, A3, a_kb32, rb0, kb0 + u + NA - 1, lane);
+        if (u + NW - 1 < KB) seg_load_w<RB, NT>(sb, (u + NW - 1) % NW, W, w_kblocks, tile0, ts, kb0 + u + NW - 1, lane);
         if (u + 2 == KB || KB == 1) after_loads();
-        u32x4 wp[NT][3];
+        // one column tile at a time: its weight fragment is split into the three bf16 planes (12 registers, not 12 NT) and
+        // multiplied with every row block -- smallest products first
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
+            u32x4 wp[3];
             if constexpr (DIAG & 2) {
-                wp[j][0] = __builtin_bit_cast(u32x4, sb.wr[u & 1][j][0]);
-                wp[j][1] = __builtin_bit_cast(u32x4, sb.wr[u & 1][j][1]);
-                wp[j][2] = wp[j][0] ^ wp[j][1];
+                wp[0] = __builtin_bit_cast(u32x4, sb.wr[u % NW][j][0]);
+                wp[1] = __builtin_bit_cast(u32x4, sb.wr[u % NW][j][1]);
+                wp[2] = wp[0] ^ wp[1];
             } else {
-                seg_split8(sb.wr[u & 1][j][0], sb.wr[u & 1][j][1], wp[j]);
+                seg_split8(sb.wr[u % NW][j][0], sb.wr[u % NW][j][1], wp);
             }
-        }
 #pragma unroll
-        for (int p = 0; p < 6; ++p)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
+            for (int p = 0; p < 6; ++p)
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {  // W fragment as srcA: the accumulator holds C^T
                     if constexpr (DIAG & 1)
-                        acc[j * RB + i] += __builtin_bit_cast(f32x4, wp[j][kSegWP[p]] ^ sb.ap[u & 1][i][kSegAP[p]]);
+                        acc[j * RB + i] += __builtin_bit_cast(f32x4, wp[kSegWP[p]] ^ sb.ap[u % NA][i][kSegAP[p]]);
                     else
                         acc[j * RB + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(sbf16x8, wp[j][kSegWP[p]]), __builtin_bit_cast(sbf16x8, sb.ap[u & 1][i][kSegAP[p]]),
+                            __builtin_bit_cast(sbf16x8, wp[kSegWP[p]]), __builtin_bit_cast(sbf16x8, sb.ap[u % NA][i][kSegAP[p]]),
                             acc[j * RB + i], 0, 0, 0);
                 }
+        }
     }
 }
 
@@ -1710,6 +1723,9 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
     float* const red = smem;                      // partial tiles [8 waves][3][256] (one column tile at a time) | attention rows
     float* const kvl = smem + kSRedFloats(2);     // attention: K / V landing zones [8 waves][2][12][64]
     constexpr bool wact = kSegW;
+#ifdef SEG_PRIO
+    if (w >= 4) __builtin_amdgcn_s_setprio(SEG_PRIO);  // (the younger half of the workgroup loses every arbitration at equal priority)
+#endif
     auto end_phase = [&](bool drain, unsigned* pub = nullptr, unsigned pubval = 0) {
         return step_barrier(st, xcc, n, ++round, trace, ++tslot, drain, &s_ok, pub, pubval);
     };

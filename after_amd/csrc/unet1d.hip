@@ -172,7 +172,7 @@ struct after_unet1d {
     BlockW mid;
     // workspaces
     float *emb = nullptr, *ps = nullptr, *pt = nullptr;
-    double* stats = nullptr;  // [kSlots][conv_tm_stat_sub()][max_batch][16][2] GroupNorm accumulators
+    double* stats = nullptr;  // [kSlots][conv_tm_stat_sub()][max_batch][16][2][kStatBins] GroupNorm accumulators (conv.h: stat_bins)
     int stat_slot = 0;
     float *cat = nullptr, *tmp = nullptr, *resb = nullptr, *xa = nullptr, *xb = nullptr, *ups = nullptr;
     float *xtm = nullptr;     // the network input in time-major form
@@ -279,7 +279,7 @@ size_t block_fl(int in_c, int out_c, int skip_c, int tc_c, int k, int TC, int CC
 constexpr int kSlots = 48;  // GroupNorm statistics slots per forward: 2 per ConvBlock1D, 2 n + 1 blocks
 
 double* next_slot(after_unet1d* h) {
-    double* p = h->stats + (size_t)(h->stat_slot % kSlots) * conv_tm_stat_sub() * h->max_batch * 32;
+    double* p = h->stats + (size_t)(h->stat_slot % kSlots) * conv_tm_stat_sub() * h->max_batch * 16 * kStatWords;
     ++h->stat_slot;
     return p;
 }
@@ -318,7 +318,7 @@ int conv_tm_run(after_unet1d* h, hipStream_t s, const PackedConv& p, const ConvI
     a.C = p.cin;
     a.T = Tin;
     a.G = io.G;
-    a.sub_stride = h->max_batch * 32;
+    a.sub_stride = h->max_batch * 16 * kStatWords;
     AFTER_TRY(launch_act_pad_tm(a, s));
     ConvTmRun r;
     memset(&r, 0, sizeof(r));
@@ -336,7 +336,7 @@ int conv_tm_run(after_unet1d* h, hipStream_t s, const PackedConv& p, const ConvI
     r.post_bstride = io.ps ? p.cout : 0;
     r.stats = io.stats_out;
     r.G = io.G_out;
-    r.sub_stride = h->max_batch * 32;
+    r.sub_stride = h->max_batch * 16 * kStatWords;
     r.B = B;
     r.Tp = conv_tm_rows(Tin);
     r.Tout = Tout;
@@ -511,7 +511,7 @@ extern "C" int after_unet1d_create(const after_unet1d_cfg* cfg, const float* con
     int cin_max = ccat_max > cmax ? ccat_max : cmax;
     cin_max = cfg->time_cond_in_channels > cin_max ? cfg->time_cond_in_channels : cin_max;
     h->xp_elems = Bm * (size_t)conv_tm_cp(cin_max) * conv_tm_rows((int)T);
-    const size_t stat_d = (size_t)kSlots * conv_tm_stat_sub() * Bm * 32;
+    const size_t stat_d = (size_t)kSlots * conv_tm_stat_sub() * Bm * 16 * kStatWords;
     size_t bytes = (Bm * TC + 2 * Bm * cmax) * sizeof(float) + stat_d * sizeof(double) +
                    (catn + 5 * act + (size_t)n * act + (size_t)(n + 2) * tcn + h->xp_elems) * sizeof(float) +
                    (1 << 16) +
@@ -574,7 +574,7 @@ extern "C" int after_unet1d_forward(after_unet1d* h, const float* x, const float
     AFTER_HIP_CHECK(hipGetLastError());
     // GroupNorm accumulators of this forward: one slot per normalisation, zeroed together
     h->stat_slot = 0;
-    AFTER_HIP_CHECK(hipMemsetAsync(h->stats, 0, (size_t)kSlots * conv_tm_stat_sub() * h->max_batch * 32 * sizeof(double), s));
+    AFTER_HIP_CHECK(hipMemsetAsync(h->stats, 0, (size_t)kSlots * conv_tm_stat_sub() * h->max_batch * 16 * kStatWords * sizeof(double), s));
     AFTER_REQUIRE(2 * (2 * n + 1) <= kSlots, AFTER_E_INVALID, "unet1d: statistics slots");
     // the network input is read twice (concatenation, shortcut): one transpose
     AFTER_TRY(launch_cm_to_tm(x, h->xtm, B, c.in_size, T, c.in_size, s));

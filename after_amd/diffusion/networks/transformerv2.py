@@ -438,6 +438,18 @@ class DenoiserV2(nn.Module):
             _lib.check(_lib.lib().after_denoiser_profile(self._handle, int(enable)),
                        "after_denoiser_profile")
 
+    def set_step_trace(self, enable: bool):
+        """Persistent samplers: per-phase wall-clock stamps of every workgroup (include/after_hip.h: after_denoiser_set_step_trace)."""
+        _lib.check(_lib.lib().after_denoiser_set_step_trace(self._handle, int(bool(enable))), "after_denoiser_set_step_trace")
+
+    def step_trace(self):
+        """numpy [workgroups, 128] uint64: the stamps of the last persistent Euler step (after_denoiser_step_trace)."""
+        import numpy as np
+        n = torch.cuda.get_device_properties(0).multi_processor_count
+        buf = np.zeros((n, 128), dtype=np.uint64)
+        _lib.check(_lib.lib().after_denoiser_step_trace(self._handle, buf.ctypes.data_as(ctypes.c_void_p), n), "after_denoiser_step_trace")
+        return buf
+
     def gemm_time(self, with_bytes: bool = False):
         """(total_ms, launches, flops[, algorithmic bytes]) of the bracketed GEMM launches since the
         last call; synchronise the stream first."""

@@ -43,7 +43,7 @@ T_FRAMES = 256
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak; gemm_x6 spends six bf16 MFMAs per fp32 product block
 PEAK_X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
-ROUND = "r3"
+ROUND = "r4"
 # sources whose change invalidates a committed traffic measurement of the dominant GEMM
 TRAFFIC_SOURCES = ["after_amd/csrc/gemm.hip", "after_amd/csrc/gemm_x6.hip", "after_amd/csrc/gemm_pipe.h",
                    "after_amd/csrc/denoiser.hip"]
@@ -218,6 +218,9 @@ def gemm_roofline(model, run_once, dev, dcfg, B, config, args):
                 "note": "algorithmic bytes (A + W + C) / HIP-event launch duration; the launches are 6-9 us each, "
                         "i.e. latency-bound, and the weights are Infinity-Cache resident after the first step"}
 
+    seg = None
+    if model.net.sample_persist():
+        seg = seg_roofline(model, run_once, dcfg, B, config)
     prof = None
     pth = pmc_path(config, B)
     traffic_note = "no committed PMC profile for this configuration (python bench.py --pmc)"
@@ -243,6 +246,8 @@ def gemm_roofline(model, run_once, dev, dcfg, B, config, args):
         d.update(extra or {})
         return d
 
+    if seg is not None:
+        note = "the launch-per-kernel path of the same sampler (AFTER_SAMPLE_PERSIST=0), one extra untimed pass: " + note
     mode, min_rows = model.net.gemm_path()
     x_ms, x_n, x_fl, _, _ = timed_pass(1, big) if mode != 0 else (0.0, 0, 0.0, 0.0, 0.0)
     f_ms, f_n, f_fl, _, _ = timed_pass(2, big)  # big launches the default path leaves on the fp32 MFMA kernel
@@ -283,7 +288,146 @@ def gemm_roofline(model, run_once, dev, dcfg, B, config, args):
             "ms_per_step": round(wall * 1e3, 3), "achieved_back_to_back": _trains(dev, M, ((ME_, E_), (E_, ME_)), False),
             "what": "one extra untimed step with after_denoiser_set_gemm_path(0): every Linear on the fp32 MFMA kernel "
                     "(the rounds-1/2 product path; ms_per_step here includes the event bracketing)"})
+    mf = mfma_profile(config, B)
+    if seg is not None:  # the dominant kernel of this leg is the persistent one; the launch path rides along for continuity
+        if prof and prof.get("seg_bytes_per_launch"):
+            seg["traffic"] = prof["seg_bytes_per_launch"]
+            seg["traffic_unit"] = "bytes per launch (one launch = all Euler steps of a clip)"
+            seg["traffic_note"] = traffic_note
+        if mf:
+            seg["mfma_busy"] = mf
+        seg["launch_path"] = roof
+        return seg
+    if mf:
+        roof["mfma_busy"] = mf
     return roof
+
+
+def mfma_path(config, batch):
+    return os.path.join(ROOT, "profiles", f"{ROUND}_pmc_mfma_{config}_b{batch}.json")
+
+
+def mfma_profile(config, B):
+    """MFMA-busy counters of the committed rocprofv3 --pmc pass (profiles/<round>_pmc_mfma_<cfg>_b<B>.json, regenerated by
+    `python bench.py --pmc-mfma`), if its source hash matches this tree."""
+    pth = mfma_path(config, B)
+    if not os.path.exists(pth):
+        return None
+    p = json.load(open(pth))
+    if p.get("source_hash") != source_hash():
+        return {"stale": os.path.basename(pth)}
+    return {"file": os.path.basename(pth), "dominant": p.get("dominant"), "what": p.get("what")}
+
+
+def seg_roofline(model, run_once, dcfg, B, config):
+    """The persistent offline sampler (sample_seg_kernel: ONE launch per clip runs every Euler step): the rate of
+    its qkv / MLP GEMM phases from the kernel's own per-phase stamps (every workgroup stamps the 100 MHz wall clock around each
+    XCD-local barrier; last Euler step of an extra untimed pass), and the whole launch by HIP events."""
+    import numpy as np
+    net = model.net
+    E_, L_ = dcfg["net"]["embed_dim"], dcfg["net"]["n_layers"]
+    ME_ = E_ * dcfg["net"]["mlp_multiplier"]
+    M = 3 * B * T_FRAMES
+    gemm_fl = 2.0 * M * E_ * ME_  # one qkv / MLP-up / MLP-down GEMM (3E = ME at mlp x 3)
+    net.profile(True, min_flops=0.0, kernel=3)
+    torch.cuda.synchronize()
+    run_once()
+    torch.cuda.synchronize()
+    ms, launches, flops, nbytes = net.gemm_time(with_bytes=True)
+    net.profile(False)
+    if not launches:
+        return None
+    net.set_step_trace(True)
+    run_once()
+    torch.cuda.synchronize()
+    buf = net.step_trace()
+    net.set_step_trace(False)
+    names = ["patchify"] + sum(([f"ln{l}", f"qkv{l}", f"attn{l}", f"up{l}", f"down{l}"] for l in range(L_)), []) + ["tail"]
+    xcc = buf[:, 127].astype(int)
+    t = buf[:, :2 * len(names)].astype(np.int64)
+    dur = {}  # phase -> us, per XCD: first start -> last arrival at the closing barrier
+    for x in range(8):
+        tx = t[xcc == x]
+        if not len(tx):
+            continue
+        for p, nme in enumerate(names):
+            dur.setdefault(nme, []).append((tx[:, 2 * p + 1].max() - tx[:, 2 * p].min()) / 100.0)
+    med = {k: float(np.median(v)) for k, v in dur.items()}
+    kinds = {k: float(np.mean([med[f"{k}{l}"] for l in range(L_)])) for k in ("ln", "qkv", "attn", "up", "down")}
+    gemm_us = sum(med[f"{k}{l}"] for k in ("qkv", "up", "down") for l in range(L_))
+    step_us = float(np.median([(t[xcc == x][:, 2 * len(names) - 1].max() - t[xcc == x][:, 0].min()) / 100.0
+                               for x in range(8) if (xcc == x).any()]))
+    ach = 3 * L_ * gemm_fl / (gemm_us * 1e-6) / 1e12
+    whole = flops / (ms * 1e-3) / 1e12
+    steps = 50
+    return {"bound": "mfma",
+            "kernel": "sample_seg_kernel (persistent offline sampler: one launch per clip, eight XCD-local pipelines over time "
+                      "segments; fp32 product blocks as 6 x v_mfma_f32_16x16x32_bf16 on exact three-way bf16 splits): its qkv / "
+                      "MLP-up / MLP-down GEMM phases",
+            "achieved": round(ach, 2), "peak": round(PEAK_X6_TFLOPS, 1), "unit": "TFLOP/s", "frac": round(ach / PEAK_X6_TFLOPS, 4),
+            "peak_note": "dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMAs per fp32 product block; against the fp32 MFMA peak "
+                         f"(157.3) the GEMM phases are at {ach / PEAK_FP32_MFMA_TFLOPS:.3f}",
+            "phase_us": {k: round(v, 2) for k, v in kinds.items()}, "patchify_us": round(med["patchify"], 2),
+            "tail_us": round(med["tail"], 2), "us_per_euler_step_in_kernel": round(step_us, 1),
+            "flops_per_gemm_phase": round(gemm_fl),
+            "whole_kernel": {"achieved": round(whole, 2), "frac": round(whole / PEAK_X6_TFLOPS, 4), "launches": int(launches),
+                             "avg_launch_us": round(ms * 1e3 / launches, 1),
+                             "us_per_euler_step": round(ms * 1e3 / launches / steps, 2),
+                             "what": "GEMM flops of all Euler steps / HIP-event duration of the launch (launch-inclusive = "
+                                     "kernel-only to 0.1 %: one launch of ~13 ms)"},
+            "traffic": None,
+            "note": "achieved = algorithmic fp32 flops of the 18 GEMM phases of one Euler step / the sum of their durations "
+                    "(first workgroup's start to last workgroup's arrival at the closing XCD-local barrier, median over the "
+                    "eight XCDs; stamps of the last Euler step of an extra untimed pass).  Phases in between (LayerNorm, banded "
+                    "attention, barriers: phase_us) are not GEMMs and not priced here; whole_kernel prices the entire launch"}
+
+
+def run_pmc_mfma(args):
+    """One rocprofv3 counter pass (--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE; kernel trace only) of this
+    very command: per kernel, the fraction of its SIMD-cycles in which the matrix pipe was busy (rocprofv3's MfmaUtil
+    expression: MFMA_BUSY summed over the SIMDs / (GRBM_GUI_ACTIVE x SIMDs)), summarised into profiles/."""
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out", f"{ROUND}_pmc_mfma")
+    os.makedirs(out, exist_ok=True)
+    inner = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+             "--batch-per-gpu", str(args.batch_per_gpu), "--config", args.config]
+    d = os.path.join(out, "pass")
+    shutil.rmtree(d, ignore_errors=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+    ctrs = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]
+    r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "--"] + inner,
+                       cwd="/tmp", env=env, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise SystemExit(f"rocprofv3 --pmc {ctrs} failed:\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}")
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        raise SystemExit(f"no counter_collection.csv under {d}")
+    agg = {}
+    for row in csv.DictReader(open(files[0])):
+        key = (row["Kernel_Name"], int(row["Grid_Size"]))
+        agg.setdefault(key, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    n_simd, n_xcc = 256 * 4, 8  # (GRBM_GUI_ACTIVE comes summed over its 8 XCC instances: / 8 = the launch's active cycles)
+    rows = []
+    for (name, grid), v in agg.items():
+        mb, gui = v.get("SQ_VALU_MFMA_BUSY_CYCLES", [0.0]), v.get("GRBM_GUI_ACTIVE", [0.0])
+        sb = v.get("SQ_BUSY_CYCLES", [0.0])
+        mbm, guim, sbm = sum(mb) / len(mb), sum(gui) / max(1, len(gui)), sum(sb) / max(1, len(sb))
+        short = name.replace("void ", "").replace("(anonymous namespace)::", "").replace("after::", "")[:100]
+        rows.append({"kernel": short, "grid_threads": grid, "launches": len(mb), "SQ_VALU_MFMA_BUSY_CYCLES_mean": round(mbm),
+                     "GRBM_GUI_ACTIVE_mean": round(guim), "SQ_BUSY_CYCLES_mean": round(sbm),
+                     "mfma_busy_frac": round(mbm / (guim / n_xcc * n_simd), 4) if guim else None,
+                     "mfma_busy_total": mbm * len(mb)})
+    rows.sort(key=lambda r_: -r_["mfma_busy_total"])
+    for r_ in rows:
+        del r_["mfma_busy_total"]
+    dom = next((r_ for r_ in rows if "sample_seg_kernel" in r_["kernel"] or "gemm_x6" in r_["kernel"]), rows[0] if rows else None)
+    prof = {"what": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES (summed over the SIMDs) / (GRBM_GUI_ACTIVE / 8 XCC instances x 1024 "
+                    "SIMDs), per launch, mean over the launches of a kernel -- rocprofv3's MfmaUtil expression (it takes the max "
+                    "over the XCC instances of GRBM_GUI_ACTIVE; the CSV carries their sum): the fraction of SIMD-cycles in which "
+                    "the matrix pipe was busy",
+            "command": " ".join(inner[1:]), "counters": ctrs, "source_hash": source_hash(), "sources": TRAFFIC_SOURCES,
+            "dominant": dom, "kernels": rows[:24]}
+    json.dump(prof, open(mfma_path(args.config, args.batch_per_gpu), "w"), indent=1)
+    print(json.dumps({"dominant": dom}))
 
 
 def run_pmc(args):
@@ -310,7 +454,7 @@ def run_pmc(args):
                 continue
             key = (row["Kernel_Name"], int(row["Grid_Size"]))
             agg.setdefault(key, {}).setdefault(ctr, []).append(float(row["Counter_Value"]))
-    rows, big_bytes, big_n, x6_bytes, x6_n = [], 0.0, 0, 0.0, 0
+    rows, big_bytes, big_n, x6_bytes, x6_n, seg_bytes, seg_n = [], 0.0, 0, 0.0, 0, 0.0, 0
     for (name, grid), v in agg.items():
         f, w = v.get("FETCH_SIZE", [0.0]), v.get("WRITE_SIZE", [0.0])
         fm, wm = sum(f) / len(f), sum(w) / len(w)
@@ -326,15 +470,19 @@ def run_pmc(args):
         if "gemm_x6" in name and "_kernel" in name:  # gemm_x6_kernel / gemm_x6w_kernel / gemm_x6p_kernel
             x6_bytes += total * len(f)
             x6_n += len(f)
+        if "sample_seg_kernel" in name:  # the persistent offline sampler: one launch per clip
+            seg_bytes += total * len(f)
+            seg_n += len(f)
     rows.sort(key=lambda r: -r["bytes_per_launch_corrected"] * r["launches"])
     prof = {"note": "bytes_per_launch_corrected = (2 * FETCH_SIZE + WRITE_SIZE) * 1024; includes Infinity-Cache hits",
             "command": " ".join(inner[1:]), "source_hash": source_hash(), "sources": TRAFFIC_SOURCES,
             "gemm_big_mean_bytes_per_launch": round(big_bytes / max(1, big_n)), "gemm_big_launches": big_n,
             "gemm_x6_mean_bytes_per_launch": round(x6_bytes / max(1, x6_n)), "gemm_x6_launches": x6_n,
+            "seg_bytes_per_launch": round(seg_bytes / max(1, seg_n)), "seg_launches": seg_n,
             "kernels": rows[:24]}
     json.dump(prof, open(pmc_path(args.config, args.batch_per_gpu), "w"), indent=1)
     json.dump(prof, open(os.path.join(out, os.path.basename(pmc_path(args.config, args.batch_per_gpu))), "w"), indent=1)
-    print(json.dumps({k: prof[k] for k in ("gemm_x6_mean_bytes_per_launch", "gemm_x6_launches",
+    print(json.dumps({k: prof[k] for k in ("gemm_x6_mean_bytes_per_launch", "gemm_x6_launches", "seg_bytes_per_launch", "seg_launches",
                                            "gemm_big_mean_bytes_per_launch", "gemm_big_launches", "source_hash")}))
 
 
@@ -356,6 +504,7 @@ def main():
                     help="BASELINE config 1's chain: audio -> AutoEncoder.encode x 2 -> encoders -> sampler -> decode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pmc", action="store_true", help="measure the GEMM's HBM traffic with rocprofv3 and exit")
+    ap.add_argument("--pmc-mfma", action="store_true", help="measure the kernels' matrix-pipe busy fraction with rocprofv3 and exit")
     args = ap.parse_args()
     if args.batch_per_gpu is None:
         args.batch_per_gpu = 8 if args.stream else 1
@@ -375,6 +524,10 @@ def main():
         if world != 1:
             raise SystemExit("--pmc is a single-GPU measurement")
         return run_pmc(args)
+    if args.pmc_mfma:
+        if world != 1:
+            raise SystemExit("--pmc-mfma is a single-GPU measurement")
+        return run_pmc_mfma(args)
     # test hook: AFTER_BENCH_SHARE_GPU=1 runs all ranks on cuda:0 over gloo, to exercise the
     # multi-rank flow on a single-GPU box (the numbers of such a run mean nothing)
     share = os.environ.get("AFTER_BENCH_SHARE_GPU") == "1"

@@ -33,6 +33,17 @@ seg_a)  # round 4: persistent offline sampler after the de-spill pass -- K split
     done
     tail -12 "$out/trace_k0_w0.txt"
     ;;
+variants)  # A/B of the kernel variants built by scripts/build_variant.sh (each a complete libafter_hip.so), same box, interleaved
+    cp after_amd/lib/libafter_hip.so "$out/default.so"
+    for rep in 1 2; do
+        for v in default $(ls scripts/variants); do
+            if [ "$v" = default ]; then cp "$out/default.so" after_amd/lib/libafter_hip.so; else cp "scripts/variants/$v/libafter_hip.so" after_amd/lib/libafter_hip.so; fi
+            ts "$v" AFTER_X=1
+        done
+    done
+    cp "$out/default.so" after_amd/lib/libafter_hip.so; rm "$out/default.so"
+    sort "$out/times.log"
+    ;;
 seg_c)  # round 4: halo keys last in the offline persistent sampler's attention
     timeout 900 python -m pytest tests/test_sample_persist_gpu.py tests/test_persist_protocol_gpu.py -x -q > "$out/test.log" 2>&1
     tail -n 3 "$out"/test.log
@@ -60,6 +71,21 @@ persist_tests)  # round 4: the persistent samplers' host protocol + every test t
     ts launch AFTER_SAMPLE_PERSIST=0
     ts persist_default
     cat "$out/times.log"
+    ;;
+counters)  # which MFMA / busy counters this rocprofv3 knows on gfx950
+    cd /tmp; rocprofv3 --list-avail 2>&1 | grep -i -B1 -A3 "mfma\|SQ_BUSY_CY\|SQ_WAVES \|GRBM_GUI_ACTIVE\|SQ_WAVE_CYCLES\|VALUBusy\|MfmaUtil" | head -150 > "$GRAFT_REPO_ROOT/$out/avail.txt" 2>&1
+    cd "$GRAFT_REPO_ROOT"; head -150 "$out/avail.txt"
+    ;;
+pmc)  # HBM traffic + MFMA-busy counter passes of the bench command at B = 1 and B = 8 (written into profiles/ -> copied to $out)
+    for b in 1 8; do
+        timeout 900 python bench.py --pmc --batch-per-gpu $b > "$out/pmc_b$b.log" 2>&1; tail -2 "$out/pmc_b$b.log"
+        timeout 900 python bench.py --pmc-mfma --batch-per-gpu $b > "$out/mfma_b$b.log" 2>&1; tail -2 "$out/mfma_b$b.log"
+    done
+    cp profiles/r4_pmc_* "$out/" 2>/dev/null
+    ;;
+bench)  # the default bench line (B = 1) + B = 8
+    timeout 900 python bench.py > "$out/b1.json" 2> "$out/b1.err"; tail -c 6000 "$out/b1.json"
+    timeout 900 python bench.py --batch-per-gpu 8 --steps 5 > "$out/b8.json" 2> "$out/b8.err"; tail -c 1500 "$out/b8.json"
     ;;
 tests)  # the whole -m gpu suite + smoke
     timeout 3000 python -m pytest tests -m gpu -x -q > "$out/tests.log" 2>&1
