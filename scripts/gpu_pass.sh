@@ -39,6 +39,7 @@ variants)  # A/B of the kernel variants built by scripts/build_variant.sh (each 
         for v in default $(ls scripts/variants); do
             if [ "$v" = default ]; then cp "$out/default.so" after_amd/lib/libafter_hip.so; else cp "scripts/variants/$v/libafter_hip.so" after_amd/lib/libafter_hip.so; fi
             ts "$v" AFTER_X=1
+            if [ $rep = 1 ] && [ "${VARIANT_TESTS:-1}" = 1 ]; then timeout 600 python -m pytest tests/test_sample_persist_gpu.py -x -q 2>&1 | tail -1 | sed "s/^/$v tests: /" >> "$out/times.log"; fi
         done
     done
     cp "$out/default.so" after_amd/lib/libafter_hip.so; rm "$out/default.so"
