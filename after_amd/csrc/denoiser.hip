@@ -703,7 +703,8 @@ constexpr int kSGroupRows = 96;                 // token rows one XCD can own (o
 
 struct StepSync {
     unsigned arrive[8][32];  // [xcc][0]: arrivals (each word on its own 128-byte line)
-    unsigned gen[8][32];     // [xcc][0]: last completed round
+    unsigned gen[8][32];     // (unused since round 4b)
+    unsigned flag[8][32][32];  // [xcc][rank][0]: the last round workgroup `rank` of the XCC has arrived at (one line each)
     unsigned pop[8][32];     // [xcc][0]: workgroups resident on the XCC
     unsigned census[32];     // [0]: workgroups counted
     // offline segment sampler: [xcc][0] = layers completed (step * L + layer + 1), system-scope words
@@ -791,30 +792,44 @@ __device__ __forceinline__ bool step_spin(unsigned* word, unsigned want, unsigne
     }
 }
 
-// XCD-local barrier (all threads of the workgroup call it; n = workgroups of this XCC).  `drain`: this wave stored
-// something in the phase -- wait until it is in the XCD's L2 (write-through L1).  A streaming wave passes false: its
+// XCD-local barrier (all threads of the workgroup call it; n <= 32 = workgroups of this XCC, rank = this one's).  `drain`: this
+// wave stored something in the phase -- wait until it is in the XCD's L2 (write-through L1).  A streaming wave passes false: its
 // L2-warming loads stay in flight across the barrier (raw s_barrier: no memory wait).
-// `pub`: a system-scope word the LAST arriver sets to `pubval` (the offline sampler's "this layer's qkv rows are in memory":
-// every workgroup has drained its stores when the last ticket is drawn -- half a round trip earlier than a store behind the
-// barrier's exit).
-__device__ __forceinline__ bool step_barrier(StepSync* st, unsigned xcc, unsigned n, unsigned round,
+// Flags, not a counter (scripts/ubench/xcd_barrier2.hip + l2_rtt.hip, round 4): a returning atomic costs ~0.38 us, a store ~0.4 us
+// to land, an sc1 load 0.1 us -- and the samplers' arrivals are spread over ~0.5 us, where early arrivers poll while the late
+// ones still arrive.  Ticket + generation word (rounds 3 - 4a): atomic round trip, then store + poll: 0.85 us from the last
+// arrival to the last exit.  Polling the arrival counter itself: 0.45 us when everybody arrives at once, 1.5 us when not (the
+// atomics queue behind the polls of their line).  Here every workgroup STORES the round into a word on its own 128-byte line
+// and wave 0 polls the lines of all n workgroups with one load per poll (a lane stops asking once its workgroup has arrived):
+// one store + one poll on the critical path, nothing serialises on a line: 0.66 - 0.72 us.
+// `pub`: a system-scope word that workgroup 0 sets to `pubval` when it has seen everybody (the offline sampler's "this layer's qkv
+// rows are in memory": every workgroup drains its stores before it raises its flag).
+__device__ __forceinline__ bool step_barrier(StepSync* st, unsigned xcc, unsigned n, unsigned rank, unsigned round,
                                              unsigned long long* trace, unsigned tslot, bool drain, unsigned* s_ok,
                                              unsigned* pub = nullptr, unsigned pubval = 0) {
     if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (threadIdx.x == 0) {
-        if (trace) trace[2 * tslot - 1] = wall_clock64();
-        bool ok = true;
-        const unsigned ticket = __hip_atomic_fetch_add(&st->arrive[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ticket == round * n - 1) {
-            if (pub) __builtin_amdgcn_raw_buffer_store_b32(pubval, step_rsrc(pub), 0, 0, 17);
-            __hip_atomic_store(&st->gen[xcc][0], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            ok = step_spin(&st->gen[xcc][0], round, &st->fail[0]);
+    if (threadIdx.x < 64) {
+        const unsigned lane = threadIdx.x;
+        if (trace && lane == 0) trace[2 * tslot - 1] = wall_clock64();
+        if (lane == 0) __hip_atomic_store(&st->flag[xcc][rank][0], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = true, pending = lane < n;
+        for (unsigned spins = 0;; ++spins) {
+            if (pending) pending = __hip_atomic_load(&st->flag[xcc][lane][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < round;
+            if (__builtin_amdgcn_ballot_w64(pending) == 0) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (spins > (1u << 21)) {
+                if (lane == 0) __hip_atomic_store(&st->fail[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = false;
+                break;
+            }
         }
-        *s_ok = ok;
-        if (trace) trace[2 * tslot] = wall_clock64();
+        if (lane == 0) {
+            if (pub && rank == 0 && ok) __builtin_amdgcn_raw_buffer_store_b32(pubval, step_rsrc(pub), 0, 0, 17);
+            *s_ok = ok;
+            if (trace) trace[2 * tslot] = wall_clock64();
+        }
     }
     __builtin_amdgcn_s_barrier();
     return *s_ok != 0;  // false: a spin gave up (flag raised) -- the caller leaves the kernel instead of timing out 3000 more times
@@ -1034,10 +1049,12 @@ template <int AUX, bool PLANES = false, bool LATE = false>  // hout: fp32 tiles,
 __device__ __forceinline__ void step_attention(const StepAttn& a, const StepKV& kv, const StepLnOps& ops, int rg,
                                                int lr0, int bx, float* smem, float* kvlds, __amdgpu_buffer_rsrc_t qkvr,
                                                __amdgpu_buffer_rsrc_t xr, float* __restrict__ xres, float* __restrict__ hout,
-                                               const float* lab = nullptr, const float* lw3 = nullptr, const float* lb3 = nullptr) {
+                                               const float* lab = nullptr, const float* lw3 = nullptr, const float* lb3 = nullptr,
+                                               unsigned long long* tr = nullptr) {  // tr: AFTER_STEP_TRACE stamps [80 ..]
     constexpr int NKMAX = kAttnKeyBlock, E = kSE, H = kSH, KBt = E / 16, ld = E + 4;
     const int T = a.T, cs = a.cs, W = a.W, nc = a.cache;
     const int tid = threadIdx.x, lane = tid & 63, hw = tid >> 6;
+    if (tr && tid == 0) tr[80] = wall_clock64();
     const int grp = lane >> 4, d4 = (lane & 15) * 4;
     const int i0 = bx * cs, e = min(i0 + cs, T), nq = e - i0;
     const int a0 = nc + i0;
@@ -1125,6 +1142,7 @@ __device__ __forceinline__ void step_attention(const StepAttn& a, const StepKV& 
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the K / V block (and q, x) have landed
+            if (tr && tid == 0 && first && qb == 0) tr[81] = wall_clock64();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (first) q4 = rope4(q4, rc, rs, ja - lo_c, d4);
             float sc[NKMAX];
@@ -1166,7 +1184,9 @@ __device__ __forceinline__ void step_attention(const StepAttn& a, const StepKV& 
             *reinterpret_cast<float4*>(smem + qi * ld + hw * 64 + d4) = res;
         }
     }
+    if (tr && tid == 0) tr[82] = wall_clock64();
     __syncthreads();
+    if (tr && tid == 0) tr[83] = wall_clock64();
     // ---- AdaLN(cond) + norm3, one wave per row
     for (int qi = hw; qi < nq; qi += H) {
         float4 v[NV];
@@ -1208,6 +1228,7 @@ __device__ __forceinline__ void step_attention(const StepAttn& a, const StepKV& 
             else *reinterpret_cast<float4*>(hout + off) = y;
         }
     }
+    if (tr && tid == 0) tr[84] = wall_clock64();
 }
 
 template <int MB>
@@ -1305,7 +1326,7 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
     const size_t wbytes = (size_t)E * ME * sizeof(float);
     static_assert(kSME == 3 * kSE, "qkv and MLP weights of one size");
     // end of a phase: XCD-local barrier; false = a spin timed out (flag raised): leave the kernel
-    auto end_phase = [&](bool drain) { return step_barrier(st, xcc, n, ++round, trace, ++tslot, drain, &s_ok); };
+    auto end_phase = [&](bool drain) { return step_barrier(st, xcc, n, (unsigned)rank, ++round, trace, ++tslot, drain, &s_ok); };
     // the LayerNorm-phase operands of this wave's row (ln phase: row rank + 32 w) / this workgroup's attention item,
     // requested one GEMM phase early (StepLnOps)
     unsigned warm_sink = 0;  // destination of the L2-warming loads in flight across the ln barrier (step_warm)
@@ -1561,7 +1582,9 @@ template <int RB, int NT>
 __device__ __forceinline__ void seg_load_w(SegBuf<RB, NT>& sb, int slot, __amdgpu_buffer_rsrc_t W, int w_kblocks, int tile0, int ts, int kb, int lane) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const unsigned so = (unsigned)(((tile0 + ts * j) * w_kblocks + 2 * kb) << 10);
+        // (-DSEG_DIAG=8, timing experiments: every workgroup reads one of 8 tile sets -- with the layer-0 weights for every layer the
+        //  whole weight traffic of a step is 2.3 MB and stays in the XCD's L2: the phase time with L2-hot weights; wrong results)
+        const unsigned so = (unsigned)((((SEG_DIAG & 8 ? tile0 & 7 : tile0) + ts * j) * w_kblocks + 2 * kb) << 10);
         sb.wr[slot][j][0] = kSegW ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W, lane * 16, so, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
         sb.wr[slot][j][1] = kSegW ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W, lane * 16 + 1024, so, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -1665,7 +1688,8 @@ __device__ __forceinline__ T* seg_uniform(T* p) {
 __device__ __forceinline__ int seg_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ __attribute__((noinline)) void seg_attention(StepAttn g, const float* ab, const float* w3, const float* b3, int rg, int lr0,
-                                                        int bx, bool halo, float* smem, float* kvlds, float* xres, float* hout) {
+                                                        int bx, bool halo, float* smem, float* kvlds, float* xres, float* hout,
+                                                        unsigned long long* tr) {
     // (every argument is wave-uniform, but the calling convention hands it over in vector registers: a buffer resource built
     //  from those is "divergent" to the compiler, and every buffer load through it becomes a waterfall loop with a full
     //  s_waitcnt in front -- q, x and the K / V rows were fetched one round trip after the other)
@@ -1673,7 +1697,7 @@ __device__ __attribute__((noinline)) void seg_attention(StepAttn g, const float*
     g.rope_cos = seg_uniform(g.rope_cos), g.rope_sin = seg_uniform(g.rope_sin), g.qkv = seg_uniform(g.qkv);
     ab = seg_uniform(ab), w3 = seg_uniform(w3), b3 = seg_uniform(b3);
     rg = seg_uniform(rg), lr0 = seg_uniform(lr0), bx = seg_uniform(bx), halo = seg_uniform((int)halo) != 0;
-    smem = seg_uniform(smem), kvlds = seg_uniform(kvlds), xres = seg_uniform(xres), hout = seg_uniform(hout);
+    smem = seg_uniform(smem), kvlds = seg_uniform(kvlds), xres = seg_uniform(xres), hout = seg_uniform(hout), tr = seg_uniform(tr);
     const StepKV nokv{nullptr, nullptr, nullptr, nullptr};
     // (the LayerNorm tail's row operands -- AdaLN(cond) alpha / beta of the CFG row, norm3's affine -- are requested inside,
     //  behind the K / V rows: an earlier phase touched their lines into the XCD's L2, attn_prefetch)
@@ -1681,8 +1705,8 @@ __device__ __attribute__((noinline)) void seg_attention(StepAttn g, const float*
 #pragma unroll
     for (int i = 0; i < kSE / 256; ++i) none.al[i] = none.be[i] = none.ww[i] = none.bb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     // system-scope q / K / V loads only where keys of the previous XCD are involved; the other chunks read this XCD's L2
-    if (halo) step_attention<17, true, true>(g, nokv, none, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout, ab, w3, b3);
-    else step_attention<16, true, true>(g, nokv, none, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout, ab, w3, b3);
+    if (halo) step_attention<17, true, true>(g, nokv, none, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout, ab, w3, b3, tr);
+    else step_attention<16, true, true>(g, nokv, none, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout, ab, w3, b3, tr);
 }
 
 template <int MB>  // row blocks per XCD: 3 Tseg / 16 (6 at T = 256)
@@ -1730,7 +1754,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
     if (w >= 4) __builtin_amdgcn_s_setprio(SEG_PRIO);  // (the younger half of the workgroup loses every arbitration at equal priority)
 #endif
     auto end_phase = [&](bool drain, unsigned* pub = nullptr, unsigned pubval = 0) {
-        return step_barrier(st, xcc, n, ++round, trace, ++tslot, drain, &s_ok, pub, pubval);
+        return step_barrier(st, xcc, n, (unsigned)rank, ++round, trace, ++tslot, drain, &s_ok, pub, pubval);
     };
     const int ln_lm = rank + (int)n * w;  // this wave's row of the ln phases (waves 0 .. 2 at 96 rows)
     const bool ln_mine = ln_lm < Mg;
@@ -1798,6 +1822,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
         if (!end_phase(w < MBP)) return;
         for (int l = 0; l < a.L; ++l) {
             const StepLayer& Lw = a.layer[l];
+            const StepLayer& Lww = a.layer[SEG_DIAG & 8 ? 0 : l];  // (the layer whose Linear weights are read: see seg_load_w)
             const __amdgpu_buffer_rsrc_t qkv_r = step_rsrc(Lw.qkv);
             int lane_l = lane0;
             asm volatile("" : "+v"(lane_l));  // (opaque: per-lane addresses are recomputed here -- hoisted out of the loops they are
@@ -1822,7 +1847,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
             const int rb0d = MB == 6 ? 3 * (rank & 1) : 0, tile0d = MB == 6 ? 2 * (rank >> 1) : rank;
             SegBuf<3, 3> sbq;
             {
-                const __amdgpu_buffer_rsrc_t Wq = step_rsrc(Lw.qkv_wt);
+                const __amdgpu_buffer_rsrc_t Wq = step_rsrc(Lww.qkv_wt);
                 if (!end_phase(ln_mine)) return;
                 // ---- qkv (bf16 x 3 split MFMAs), three row blocks at a time; the rows are written through to memory (the next
                 //      XCD's attention reads the last W - 1 frames)
@@ -1867,11 +1892,11 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                     if (!s_ok) return;
                 }
                 seg_attention(StepAttn{T, a.cs, a.W, 0, a.nkmax, a.rope_cos, a.rope_sin, Lw.qkv}, cond_ab + (size_t)br * a.cond_ld + (size_t)l * 2 * E,
-                              Lw.n3w, Lw.n3b, br, br * Tseg - f0, i0f / a.cs, halo, smem, kvl, xres, reinterpret_cast<float*>(hb3));
+                              Lw.n3w, Lw.n3b, br, br * Tseg - f0, i0f / a.cs, halo, smem, kvl, xres, reinterpret_cast<float*>(hb3), trace);
             }
             SegBuf<3, kSNTU> sbu;
             {
-                const __amdgpu_buffer_rsrc_t Wu = step_rsrc(Lw.mlp0_wt);
+                const __amdgpu_buffer_rsrc_t Wu = step_rsrc(Lww.mlp0_wt);
                 if (!end_phase(true, &st->att_seq[g][0], seq)) return;
                 // ---- MLP up + GELU: column tiles rank + 32 j; the hidden layer as bf16 x 3 planes
                 f32x4 acc[3 * kSNTU];
@@ -1900,7 +1925,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
             }
             SegBuf<3, NTD> sbd;
             {
-                const __amdgpu_buffer_rsrc_t Wd = step_rsrc(Lw.mlp2_wt);
+                const __amdgpu_buffer_rsrc_t Wd = step_rsrc(Lww.mlp2_wt);
                 if (!end_phase(true)) return;
                 // ---- MLP down + residual
                 f32x4 acc[3 * NTD], bv[NTD], rv[NTD];

@@ -33,6 +33,15 @@ seg_a)  # round 4: persistent offline sampler after the de-spill pass -- K split
     done
     tail -12 "$out/trace_k0_w0.txt"
     ;;
+vtrace)  # per-phase traces of the kernel variants
+    cp after_amd/lib/libafter_hip.so "$out/default.so"
+    for v in default $(ls scripts/variants); do
+        if [ "$v" = default ]; then cp "$out/default.so" after_amd/lib/libafter_hip.so; else cp "scripts/variants/$v/libafter_hip.so" after_amd/lib/libafter_hip.so; fi
+        timeout 300 python scripts/stream_step_trace.py --offline --xcd 3 > "$out/trace_$v.txt" 2>&1
+        echo "== $v"; sed -n 4,9p "$out/trace_$v.txt"; tail -4 "$out/trace_$v.txt"
+    done
+    cp "$out/default.so" after_amd/lib/libafter_hip.so; rm "$out/default.so"
+    ;;
 variants)  # A/B of the kernel variants built by scripts/build_variant.sh (each a complete libafter_hip.so), same box, interleaved
     cp after_amd/lib/libafter_hip.so "$out/default.so"
     for rep in 1 2; do
@@ -93,6 +102,15 @@ tests)  # the whole -m gpu suite + smoke
     tail -15 "$out/tests.log"
     timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.log" 2>&1
     tail -3 "$out/smoke.log"
+    ;;
+quick)  # the persistent samplers' own tests + sampler time + per-phase trace (the inner loop of a kernel change)
+    timeout 900 python -m pytest tests/test_sample_persist_gpu.py tests/test_stream_persist_gpu.py tests/test_persist_protocol_gpu.py -x -q > "$out/test.log" 2>&1
+    tail -n 3 "$out"/test.log
+    ts persist; ts persist
+    cat "$out/times.log"
+    timeout 300 python scripts/stream_step_trace.py --offline --xcd 3 --detail > "$out/trace_xcd3.txt" 2>&1
+    grep -v amdgpu.ids "$out/trace_xcd3.txt" | cut -c1-48 | sed -n 2,14p; tail -6 "$out/trace_xcd3.txt"
+    timeout 300 python bench.py --stream --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('stream', d['value'], d['ms_per_step'], d['config'].get('sampler_path'))"
     ;;
 *)
     echo "unknown pass $pass"; exit 2;;

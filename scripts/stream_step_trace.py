@@ -18,6 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--streams", type=int, default=8)
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--xcd", type=int, default=0)
+ap.add_argument("--detail", action="store_true", help="per phase: the five slowest workgroups (index in the XCD: work us)")
 ap.add_argument("--offline", action="store_true", help="the persistent OFFLINE sampler (one clip, base, 50 steps) instead")
 args = ap.parse_args()
 torch.set_grad_enabled(False)
@@ -64,6 +65,9 @@ for p, name in enumerate(names):
         bar = (t[:, 2 * p + 2].min() - end.max()) / 100.0
         tot_bar += (t[:, 2 * p + 2].max() - end.max()) / 100.0
         line += f" {bar:8.2f}"
+    if args.detail:
+        o = np.argsort(-work)[:5]
+        line += "   slowest: " + " ".join(f"{i}:{work[i]:.2f}(+{(start[i] - start.min()) / 100.0:.2f})" for i in o)
     print(line)
 print("step per XCD (us): " + ", ".join(f"{(t_all[xcc == x][:, 2 * len(names) - 1].max() - t_all[xcc == x][:, 0].min()) / 100.0:.1f}"
                                          for x in range(8) if (xcc == x).any()))
@@ -81,5 +85,14 @@ if args.offline:  # effective shader clock over the step; inside the last layer'
     arr = (t_all[:, 2 * ph + 1] - t_all[:, 2 * ph]) / 100.0
     print("qkv phase, median us after the barrier: start %.2f, MFMAs issued %.2f, partials exchanged %.2f, stores issued %.2f, "
           "arrival %.2f" % tuple(np.median(rel, 0).tolist() + [np.median(arr)]))
+    pa = 3 + 5 * (L - 1)  # the last layer's attention phase: stamps of thread 0 inside the item (workgroups with an item)
+    ga = buf[:, 80:85].astype(np.int64)
+    has = ga[:, 0] > 0
+    if has.any():
+        rela = (ga[has] - t_all[has][:, 2 * pa][:, None]) / 100.0
+        arra = (t_all[has][:, 2 * pa + 1] - t_all[has][:, 2 * pa]) / 100.0
+        print("attention phase, median / max us after the barrier: entry %.2f / %.2f, first pass landed %.2f / %.2f, keys done %.2f / %.2f, "
+              "rows exchanged %.2f / %.2f, LayerNorm tail stored %.2f / %.2f, arrival %.2f / %.2f" % (tuple(
+                  v for k in range(5) for v in (np.median(rela[:, k]), rela[:, k].max())) + (np.median(arra), arra.max())))
     gw = buf[:, 72:80].astype(np.int64)
     print("qkv phase, end of each wave's MFMAs (median us after the barrier): " + " ".join("%.2f" % v for v in np.median((gw - t_all[:, 2 * ph][:, None]) / 100.0, 0)))

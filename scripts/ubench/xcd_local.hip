@@ -95,8 +95,64 @@ __device__ __forceinline__ bool flag_barrier(LocalState* st, unsigned xcc, unsig
     return ok;
 }
 
+// INV 4: ticket + every non-last workgroup polls the ARRIVAL counter itself (no generation word: one hop less after the last ticket)
+__device__ __forceinline__ bool ticket_barrier(LocalState* st, unsigned xcc, unsigned n, unsigned round) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    bool ok = true;
+    if (threadIdx.x == 0) {
+        const unsigned ticket = __hip_atomic_fetch_add(&st->arrive[xcc][0], 1u, RLX_AGENT);
+        if (ticket != round * n - 1) ok = spin_until(&st->arrive[xcc][0], round * n, &st->timeout[0]);
+    }
+    __builtin_amdgcn_s_barrier();
+    return ok;
+}
+
+// INV 5: no-return arrival atomic, vector polls of the counter
+__device__ __forceinline__ bool noret_barrier(LocalState* st, unsigned xcc, unsigned n, unsigned round) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    bool ok = true;
+    if (threadIdx.x == 0) {
+        unsigned* w = &st->arrive[xcc][0];
+        unsigned one = 1u;
+        asm volatile("global_atomic_add %0, %1, off" : : "v"(w), "v"(one) : "memory");
+        ok = spin_until(w, round * n, &st->timeout[0]);
+    }
+    __builtin_amdgcn_s_barrier();
+    return ok;
+}
+
+// INV 6: flag line, vector polled: workgroup `rank` stores the round into word rank of ONE 128-byte line per XCC (sc1 store,
+// no read-modify-write), lanes 0 .. n - 1 of wave 0 poll the line with ONE sc1 load per poll
+__device__ __forceinline__ bool vflag_barrier(LocalState* st, unsigned xcc, unsigned n, unsigned rank, unsigned round) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    bool ok = true;
+    if (threadIdx.x < 64) {
+        const unsigned lane = threadIdx.x;
+        if (lane == 0) __hip_atomic_store(&st->gen[xcc][rank], round, RLX_AGENT);
+        unsigned spins = 0;
+        for (;; ++spins) {
+            const unsigned v = lane < n ? __hip_atomic_load(&st->gen[xcc][lane], RLX_AGENT) : round;
+            if (__builtin_amdgcn_ballot_w64(v < round) == 0) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (spins > (1u << 22)) {
+                if (lane == 0) __hip_atomic_store(&st->timeout[0], 1u, RLX_AGENT);
+                ok = false;
+                break;
+            }
+        }
+    }
+    __builtin_amdgcn_s_barrier();
+    return ok;
+}
+
 template <int INV>
 __device__ __forceinline__ bool local_barrier(LocalState* st, unsigned xcc, unsigned n, unsigned round, unsigned rank) {
+    if (INV == 6) return vflag_barrier(st, xcc, n, rank, round);
+    if (INV == 5) return noret_barrier(st, xcc, n, round);
+    if (INV == 4) return ticket_barrier(st, xcc, n, round);
     if (INV == 3) return flag_barrier(st, xcc, rank, round);
     if (INV == 2) return scalar_barrier(st, xcc, n, round);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stores are in the XCD's L2 (the vector L1 is write-through)
@@ -163,7 +219,7 @@ int main() {
     (void)hipEventCreate(&e1);
     const int rounds = 2000;
     for (int mode = 0; mode < 3; ++mode) {
-        for (int inv = 0; inv < 4; ++inv) {
+        for (int inv = 0; inv < 7; ++inv) {
             (void)hipMemset(st, 0, sizeof(LocalState));
             (void)hipMemset(errs, 0, 4);
             (void)hipEventRecord(e0);
@@ -179,6 +235,15 @@ int main() {
             if (mode == 0 && inv == 3) hipLaunchKernelGGL((k_local<0, 3>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
             if (mode == 1 && inv == 3) hipLaunchKernelGGL((k_local<1, 3>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
             if (mode == 2 && inv == 3) hipLaunchKernelGGL((k_local<2, 3>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
+            if (mode == 0 && inv == 4) hipLaunchKernelGGL((k_local<0, 4>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
+            if (mode == 1 && inv == 4) hipLaunchKernelGGL((k_local<1, 4>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
+            if (mode == 2 && inv == 4) hipLaunchKernelGGL((k_local<2, 4>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
+            if (mode == 0 && inv == 5) hipLaunchKernelGGL((k_local<0, 5>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
+            if (mode == 1 && inv == 5) hipLaunchKernelGGL((k_local<1, 5>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
+            if (mode == 2 && inv == 5) hipLaunchKernelGGL((k_local<2, 5>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
+            if (mode == 0 && inv == 6) hipLaunchKernelGGL((k_local<0, 6>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
+            if (mode == 1 && inv == 6) hipLaunchKernelGGL((k_local<1, 6>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
+            if (mode == 2 && inv == 6) hipLaunchKernelGGL((k_local<2, 6>), dim3(256), dim3(512), 0, 0, st, buf, rounds, errs);
             (void)hipEventRecord(e1);
             (void)hipEventSynchronize(e1);
             float ms;
@@ -189,7 +254,7 @@ int main() {
             (void)hipMemcpy(&hs, st, sizeof(hs), hipMemcpyDeviceToHost);
             printf("{\"ubench\": \"xcd_local_barrier\", \"mode\": \"%s\", \"reader\": \"%s\", \"us_per_barrier\": %.2f, \"visibility_errors\": %d, "
                    "\"timeout\": %u, \"pop\": [%u,%u,%u,%u,%u,%u,%u,%u]}\n",
-                   mode == 0 ? "bare" : (mode == 1 ? "record_128B" : "tile_32KB"), inv == 3 ? "sc1 loads, flag-line barrier (scalar polls)" : inv == 2 ? "sc1 loads, scalar-polled barrier" : (inv ? "buffer_inv sc1" : "sc1 loads"), ms * 1e3 / (2 * rounds), h, hs.timeout[0],
+                   mode == 0 ? "bare" : (mode == 1 ? "record_128B" : "tile_32KB"), inv == 6 ? "sc1 loads, flag-line barrier (one vector poll)" : inv == 5 ? "sc1 loads, no-return arrival + counter polls" : inv == 4 ? "sc1 loads, ticket + counter polls" : inv == 3 ? "sc1 loads, flag-line barrier (scalar polls)" : inv == 2 ? "sc1 loads, scalar-polled barrier" : (inv ? "buffer_inv sc1" : "sc1 loads"), ms * 1e3 / (2 * rounds), h, hs.timeout[0],
                    hs.pop[0][0], hs.pop[1][0], hs.pop[2][0], hs.pop[3][0], hs.pop[4][0], hs.pop[5][0], hs.pop[6][0], hs.pop[7][0]);
         }
     }
