@@ -1834,9 +1834,12 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 step_ln_ops(lnops, ln_ab0 + (size_t)l * 2 * E, Lw.n1w, Lw.n1b, lane);
                 step_ln_row<true>(l == 0 ? pat_r : xres_r, l == 0 ? ln_lm % Tseg : ln_lm, xres, reinterpret_cast<float*>(hb3), ln_lm, lnops, lane);
             }
-            // (idle wave 7 of workgroup 0: the next XCD has read this layer's keys of the PREVIOUS step -- its last
-            //  frames may be overwritten.  A whole step behind: satisfied long ago, one memory round trip off the path)
-            if (rank == 0 && w == 7 && lane == 0 && g < 7 && i > 0) seg_spin_sys(&st->att_seq[g + 1][0], seq - a.L, &st->fail[0]);
+            // (the reverse hazard -- the next XCD must have read this layer's keys of the PREVIOUS step before the qkv phase below
+            //  overwrites the segment's last frames -- is checked one layer early, by a workgroup without an attention item during
+            //  the attention phase: in this phase the memory round trip of the check sat on the critical path of a 2.2-us phase
+            //  whenever the fabric was busy.  Only when every workgroup has an item does the check stay here)
+            if (nitems >= (int)n && rank == 0 && w == 7 && lane == 0 && g < 7 && i > 0)
+                seg_spin_sys(&st->att_seq[g + 1][0], seq - a.L, &st->fail[0]);
             // Geometry of the qkv / MLP-up GEMMs -- waves = (row half, K slice): with 96 rows both halves run side by side, each
             // wave four k-blocks deep; column tiles rank, rank + 32, rank + 64 -- and of MLP-down: 96 rows 2-D, workgroup (row
             // half, column-tile pair): half the activation bytes per workgroup of the all-rows x one-tile split; 48 rows:
@@ -1882,6 +1885,10 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
             if (!end_phase(true, &st->qkv_seq[g][0], seq)) return;
             // ---- attention + residual + AdaLN(cond) + norm3: one workgroup per chunk of a CFG row; a chunk whose window
             //      starts in front of the segment waits for the previous XCD's rows
+            // (the last workgroup has no item: before the NEXT qkv phase -- sequence number seq + 1, this layer's successor or layer 0
+            //  of the next step -- overwrites its rows of the previous step, the next XCD must have read them: att_seq >= seq + 1 - L)
+            if (nitems < (int)n && rank == (int)n - 1 && w == 0 && lane == 0 && g < 7 && seq + 1 > (unsigned)a.L)
+                seg_spin_sys(&st->att_seq[g + 1][0], seq + 1 - a.L, &st->fail[0]);
             for (int it = rank; it < nitems; it += (int)n) {
                 const int br = it / cps, ch = it - br * cps, i0f = f0 + ch * a.cs;
                 __syncthreads();  // (a second item of this workgroup reuses the LDS rows)

@@ -103,6 +103,22 @@ tests)  # the whole -m gpu suite + smoke
     timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.log" 2>&1
     tail -3 "$out/smoke.log"
     ;;
+vq)  # variants: sampler time only, interleaved (no tests) + traces
+    cp after_amd/lib/libafter_hip.so "$out/default.so"
+    for rep in 1 2; do
+        for v in default $(ls scripts/variants); do
+            if [ "$v" = default ]; then cp "$out/default.so" after_amd/lib/libafter_hip.so; else cp "scripts/variants/$v/libafter_hip.so" after_amd/lib/libafter_hip.so; fi
+            ts "$v" AFTER_X=1
+        done
+    done
+    for v in default $(ls scripts/variants); do
+        if [ "$v" = default ]; then cp "$out/default.so" after_amd/lib/libafter_hip.so; else cp "scripts/variants/$v/libafter_hip.so" after_amd/lib/libafter_hip.so; fi
+        timeout 300 python scripts/stream_step_trace.py --offline --xcd 3 > "$out/trace_$v.txt" 2>&1
+        echo "== $v"; sed -n 4,9p "$out/trace_$v.txt" | cut -c1-48; tail -5 "$out/trace_$v.txt" | head -3
+    done
+    cp "$out/default.so" after_amd/lib/libafter_hip.so; rm "$out/default.so"
+    sort "$out/times.log" | cut -c1-80
+    ;;
 quick)  # the persistent samplers' own tests + sampler time + per-phase trace (the inner loop of a kernel change)
     timeout 900 python -m pytest tests/test_sample_persist_gpu.py tests/test_stream_persist_gpu.py tests/test_persist_protocol_gpu.py -x -q > "$out/test.log" 2>&1
     tail -n 3 "$out"/test.log
