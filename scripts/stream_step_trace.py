@@ -26,7 +26,8 @@ dev = torch.device("cuda:0")
 if args.offline:
     os.environ.setdefault("AFTER_SAMPLE_PERSIST", "1")
     model, dcfg, acfg = pipeline.build_models("base", "baseAE", dev, seed=7)
-    x0, cond, tc = torch.randn(1, 64, 256, device=dev), torch.randn(1, 6, device=dev), torch.randn(1, 12, 256, device=dev)
+    TT = int(os.environ.get("AFTER_T", "256"))
+    x0, cond, tc = torch.randn(1, 64, TT, device=dev), torch.randn(1, 6, device=dev), torch.randn(1, 12, TT, device=dev)
     model.net.set_sample_persist(True)
     for _ in range(3):
         model.net.cfg_sample(x0, cond, tc, 50, 2.0, 1.0, -4.0)

@@ -13,7 +13,7 @@ torch.manual_seed(0)
 dcfg = configs.diffusion_config(cfgname)
 net = DenoiserV2(**dcfg["net"])
 model = RectifiedFlow(net=net, sr=44100, device=dev)
-T = 256
+T = int(os.environ.get("AFTER_T", "256"))
 x0 = torch.randn(B, 64, T, device=dev)
 cond = torch.randn(B, 6, device=dev)
 tc = torch.randn(B, dcfg["net"]["tcond_dim"], T, device=dev)
