@@ -31,14 +31,17 @@ class ExportedAutoEncoder:
         """prime_with_silence: the reference runs one encode + decode of 131072 zero samples through the streaming twin
         before scripting it (export_autoencoder.py:296-298, :314-316), so export_stream.ts starts -- and its saved state
         is -- the codec's response to silence (non-zero: biases, Snake), not zeros.  True reproduces that start (here and
-        after every reset()): `gn_window_samples` of zeros, fed chunk by chunk; False (default) starts from zero history."""
+        after every reset()): `gn_window_samples` of zeros, fed chunk by chunk; False (default) starts from zero history.
+        The reference feeds the silence as ONE 131072-sample call: for the causal codec the two are the same stream, for the
+        non-causal twin (windowed GroupNorm, cross-fade buffers) the chunked priming is an approximation of that start, not
+        a bit-equal copy -- and costs one encode + decode per chunk on every reset()."""
         if stream:
             # The reference builds the streaming graph as SEPARATE twins of the trained codec
             # (export_autoencoder.py:283-312: new modules under cc.use_cached_conv(True) + load_state_dict), so
             # the caller's `model` -- the offline export.ts, RectifiedFlow.emb_model, embed_dataset -- stays
             # stateless.  Streaming state (cached convs, windowed GroupNorm) therefore lives in a private copy.
             twin = AutoEncoder(**model.cfg_kwargs())
-            twin.load_state_dict(model.state_dict(), strict=False)
+            twin.load_state_dict(model.state_dict(), strict=True)  # (built from the same cfg: a missing or extra key is a bug)
             model = twin.to(next(model.parameters()).device)
         self.model = model
         self.comp_ratio = model.ratio

@@ -651,7 +651,7 @@ int begin_pass(after_ae* h, hipStream_t s) {
     AFTER_REQUIRE(!(h->in_pass && stateful), AFTER_E_INVALID,
                   "autoencoder: an earlier streaming pass failed half way, the stream state is desynchronised: call "
                   "after_ae_reset_state");
-    h->in_pass = true;
+    h->in_pass = stateful;  // (a stateless pass that fails half way leaves nothing behind)
     h->stat_slot = 0;
     h->state_slot = 0;
     h->prepared = nullptr;
@@ -1299,8 +1299,8 @@ extern "C" int after_ae_encode(after_ae* h, const float* x, float* z, int B, int
     float *b0 = h->buf[0], *b1 = h->buf[1], *b2 = h->buf[2];
     // (cached non-causal encoder: the PQMF analysis stays the offline, zero-padded one per chunk, as in the
     // reference's export_stream.ts, where only `model.encoder` is the cached twin)
+    AFTER_TRY(begin_pass(h, s));  // (in front of the streaming PQMF: a desynchronised stream must not advance its filter state)
     AFTER_TRY(pqmf_forward(h, s, x, b0, B, L, h->streaming ? h->pq_fstate : nullptr, true));
-    AFTER_TRY(begin_pass(h, s));
     h->pass_cached = h->pass_gnwin = h->enc_cached;
     h->pass_stream = h->streaming || h->enc_cached;
     float* sb = h->streaming ? h->enc_state : (h->enc_cached ? h->nc_state : nullptr);

@@ -1872,12 +1872,20 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (trace && tid == 0) trace[66] = wall_clock64();
                 __builtin_amdgcn_sched_barrier(0);
-                for (int p = w; p < 9 * NH; p += 8) {
-                    const int hh = p / 9, pp = p - 9 * hh, j = pp / 3;
-                    const f32x4 o = seg_sum<KS>(red + (size_t)hh * KS * 9 * 256, 9, pp, lane);
+                // (wave w finishes tiles w, w + 8, w + 16: every partial is requested before the first sum -- in a loop over p each
+                //  tile paid its own LDS round trip in front of its store)
+                f32x4 os[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int p = w + 8 * q, hh = p / 9, pp = p - 9 * hh;
+                    os[q] = p < 9 * NH ? seg_sum<KS>(red + (size_t)hh * KS * 9 * 256, 9, pp, lane) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int p = w + 8 * q, hh = p / 9, pp = p - 9 * hh, j = pp / 3;
                     const int lm = 16 * (3 * hh + pp % 3) + (lane & 15), br = lm / Tseg, tl = lm - br * Tseg;
-                    if (lm < Mg)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), qkv_r,
+                    if (p < 9 * NH && lm < Mg)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, os[q]), qkv_r,
                                                                (unsigned)(((br * T + f0 + tl) * 3 * E + 16 * (rank + 32 * j) + 4 * (lane >> 4)) * 4), 0, 17);
                 }
                 if (trace && tid == 0) trace[67] = wall_clock64();
@@ -1935,30 +1943,29 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 const __amdgpu_buffer_rsrc_t Wd = step_rsrc(Lww.mlp2_wt);
                 if (!end_phase(true)) return;
                 // ---- MLP down + residual
-                f32x4 acc[3 * NTD], bv[NTD], rv[NTD];
+                f32x4 acc[3 * NTD], bv[1], rv[1];
                 seg_load_a<3, NTD>(sbd, 0, mlp3_r, ME / 32, rb0d, KD * w, lane);
                 seg_load_w<3, NTD>(sbd, 0, Wd, KBM, tile0d, 1, KD * w, lane);
-#pragma unroll
-                for (int j = 0; j < NTD; ++j) {
-                    bv[j] = rv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (w < 3) {
-                        bv[j] = *reinterpret_cast<const f32x4*>(Lw.mlp2_b + 16 * (tile0d + j) + 4 * (lane >> 4));
-                        rv[j] = ld_l2(xres_r, (unsigned)((((rb0d + w) * KBE + tile0d + j) << 8) + lane * 4));
-                    }
+                // (wave w < 3 NTD finishes column tile w / 3, row block w % 3: one exchange of all partials, six finishing waves at
+                //  96 rows -- not a round of the exchange per column tile with three)
+                const int jd = w / 3, id = w - 3 * jd;
+                const unsigned offd = (unsigned)((((rb0d + id) * KBE + tile0d + jd) << 8) + lane * 4);
+                bv[0] = rv[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (w < 3 * NTD) {
+                    bv[0] = *reinterpret_cast<const f32x4*>(Lw.mlp2_b + 16 * (tile0d + jd) + 4 * (lane >> 4));
+                    rv[0] = ld_l2(xres_r, offd);
                 }
                 seg_run<3, NTD, KD, SEG_DIAG>(acc, sbd, mlp3_r, ME / 32, rb0d, Wd, KBM, tile0d, 1, KD * w, lane,
                                               [&] { if (l + 1 < a.L) ln_prefetch(l + 1); });
+                seg_partials<3 * NTD>(acc, red, w, lane);
+                if (w < 3 * NTD) {
+                    f32x4 o = seg_sum<8>(red, 3 * NTD, w, lane);  // (acc index = column tile x 3 + row block = w)
 #pragma unroll
-                for (int j = 0; j < NTD; ++j) {
-                    f32x4 o = seg_reduce<3>(acc, j, red, w, lane);
-                    if (w < 3) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = o[r] + bv[j][r] + rv[j][r];
-                        *reinterpret_cast<f32x4*>(xres + ((size_t)((rb0d + w) * KBE + tile0d + j) << 8) + lane * 4) = o;
-                    }
+                    for (int r = 0; r < 4; ++r) o[r] = o[r] + bv[0][r] + rv[0][r];
+                    *reinterpret_cast<f32x4*>(xres + offd) = o;
                 }
             }
-            if (!end_phase(w < 3)) return;
+            if (!end_phase(w < 3 * NTD)) return;
         }
         // ---- out_proj + CFG + Euler (+ the token-major latents of the next step), fp32 MFMA: workgroup (column tile,
         //      16-frame block) owns the three CFG rows of its frames
