@@ -202,8 +202,12 @@ class AutoEncoder(nn.Module):
                  use_noise: bool = False,
                  padding_mode: str = "centered"):
         super().__init__()
-        if pqmf_bands <= 1 or in_channels != pqmf_bands:
-            raise NotImplementedError("after_amd builds the shipped codec: pqmf_bands = in_channels > 1")
+        # SimpleNetsStream.py:853-859: pqmf_bands > 1 -> CachedPQMF, the codec's input channels are the bands; otherwise
+        # DummyIdentity -- the codec runs on the (mono) audio itself (baseAE.gin:15: "Set to 1 if no pqmf")
+        if pqmf_bands > 1 and in_channels != pqmf_bands:
+            raise NotImplementedError("a PQMF codec has in_channels = pqmf_bands")
+        if pqmf_bands <= 1 and in_channels != 1:
+            raise NotImplementedError("without PQMF (pqmf_bands <= 1) after_amd builds the mono codec: in_channels = 1")
         if use_noise:
             raise NotImplementedError("use_noise=True (NoiseGenerator) is not built (baseAE.gin: False)")
         if resnet_groups != 8:
@@ -216,11 +220,13 @@ class AutoEncoder(nn.Module):
                         decoder_ratio=decoder_ratio, pqmf_bands=pqmf_bands,
                         use_loudness=use_loudness, padding_mode=padding_mode)
         self.pqmf_bands = pqmf_bands
+        self._bands = max(1, pqmf_bands)  # what the C side calls pqmf_bands: 1 = the identity bank
         self.z_channels = z_channels
-        self.ratio = pqmf_bands * math.prod(factors)
+        self.ratio = self._bands * math.prod(factors)
         nd = len(dilations)
         self.dec_multipliers = [int(m * decoder_ratio) for m in list(multipliers)[::-1]]
-        self.pqmf = _PQMF(100, pqmf_bands)
+        # (no parameters without PQMF, like the reference's DummyIdentity: the state dicts stay interchangeable)
+        self.pqmf = _PQMF(100, pqmf_bands) if pqmf_bands > 1 else nn.Identity()
         # SimpleNetsStream.py:864-867: a VAE codec's encoder emits mean and scale
         self.encoder_out_channels = 2 * z_channels if isinstance(self.bottleneck, VAEBottleneck) else z_channels
         self.encoder = _Encoder(in_channels, channels, list(multipliers), list(factors), nd,
@@ -275,7 +281,7 @@ class AutoEncoder(nn.Module):
         def SN(p):
             return [p + "alpha", p + "beta"]
 
-        names = ["pqmf.forward_conv.weight", "pqmf.inverse_conv.weight"]
+        names = ["pqmf.forward_conv.weight", "pqmf.inverse_conv.weight"]  # (identity bank: replaced by the unit tap in _ensure)
         e = "encoder.net."
         names += CB(e + "0.net.branches.0.0.") + CB(e + "0.net.branches.0.1.")
         if c["in_channels"] != c["channels"] * c["multipliers"][0]:
@@ -305,15 +311,19 @@ class AutoEncoder(nn.Module):
         cap = (max(batch, cb), max(samples, cs))
         sd = self.state_dict()
         ws = []
+        if self._bands == 1:
+            self._unit_tap = torch.ones(1, device=next(self.parameters()).device)
         for name in self._weight_names():
-            if name.endswith("gn.weight") or name.endswith("gn.bias"):
+            if self._bands == 1 and name.startswith("pqmf."):
+                ws.append(self._unit_tap)
+            elif name.endswith("gn.weight") or name.endswith("gn.bias"):
                 ws.append(_lib.require_gpu_tensor(sd[name], name) if name in sd else None)
             else:
                 ws.append(_lib.require_gpu_tensor(sd[name], name))
         arr = (ctypes.c_void_p * len(ws))(*[w.data_ptr() if w is not None else None for w in ws])
         c = self.cfg
         cfg = _lib.AECfg()
-        cfg.pqmf_bands = c["pqmf_bands"]
+        cfg.pqmf_bands = self._bands
         cfg.channels = c["channels"]
         cfg.z_channels = c["z_channels"]
         cfg.encoder_out_channels = self.encoder_out_channels
@@ -456,7 +466,7 @@ class AutoEncoder(nn.Module):
         x = torch.empty(B, 1, T * self.ratio, device=z.device, dtype=torch.float32)
         with torch.cuda.device(z.device):
             if with_multi:
-                mb = torch.empty(B, self.pqmf_bands, T * self.ratio // self.pqmf_bands, device=z.device,
+                mb = torch.empty(B, self._bands, T * self.ratio // self._bands, device=z.device,
                                  dtype=torch.float32)
                 _lib.check(_lib.lib().after_ae_decode_multi(h, _lib.ptr(z), _lib.ptr(x), _lib.ptr(mb), B, T,
                                                             _lib.current_stream(z.device)),
@@ -475,7 +485,7 @@ class AutoEncoder(nn.Module):
         x = _lib.require_gpu_tensor(x, "x")
         B, _, L = x.shape
         h = self._ensure(B, max(L, self.ratio))
-        mb = torch.empty(B, self.pqmf_bands, L // self.pqmf_bands, device=x.device)
+        mb = torch.empty(B, self._bands, L // self._bands, device=x.device)
         _lib.check(_lib.lib().after_ae_pqmf_forward(h, _lib.ptr(x), _lib.ptr(mb), B, L,
                                                     _lib.current_stream(x.device)),
                    "after_ae_pqmf_forward")

@@ -95,8 +95,9 @@ def diffusion_from_config(cfg: GinConfig, device="cuda:0", in_size: Optional[int
         base = cfg.kwargs("RectifiedFlow")
     if "net" not in base:
         raise GinError("config has no Base.net binding")
-    if base.get("time_transform") is not None:
-        raise NotImplementedError("time_transform is not built (every shipped config: None)")
+    # Base.time_transform (model.py:136-137) is applied by prep_data, i.e. to TRAINING batches only; Base.post_encoder is
+    # stored and never called (model.py:38).  Neither is on the sampling path: a config that binds them loads, the bindings
+    # are not built (their state-dict entries are in the allowed-unexpected list of load_diffusion).
     net = _build(cfg, base["net"])
     enc = _build(cfg, base.get("encoder"))
     enc_t = _build(cfg, base.get("encoder_time"))

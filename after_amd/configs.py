@@ -88,6 +88,9 @@ AUTOENCODER["baseAE_causal"] = dict(AUTOENCODER["baseAE"], use_norm=False,
                                     padding_mode="causal")
 AUTOENCODER["microAE_causal"] = dict(AUTOENCODER["microAE"], use_norm=False,
                                      padding_mode="causal")
+# no filter bank (SimpleNetsStream.py:853-859, baseAE.gin:15 "Set to 1 if no pqmf"): the codec runs on the mono samples
+AUTOENCODER["microAE_nopqmf"] = dict(AUTOENCODER["microAE"], in_channels=1, pqmf_bands=1, multipliers=[1, 2, 4, 4],
+                                     factors=[2, 4, 4])
 
 
 def diffusion_config(name: str) -> dict:

@@ -695,7 +695,7 @@ int pqmf_forward(after_ae* h, hipStream_t s, const float* x, float* mb, int B, i
                            dim3(256), 0, s, x, h->pq_fw, mb, L, M, K, pl, state, cs, ts);
     }
     AFTER_HIP_CHECK(hipGetLastError());
-    if (state) {  // keep the last K - 1 input samples of every clip
+    if (state && K > 1) {  // keep the last K - 1 input samples of every clip
         const int S = K - 1;
         AFTER_REQUIRE(L >= S && (L / M) % 2 == 0, AFTER_E_INVALID,
                       "pqmf streaming: chunk of %d samples too short / odd frame count", L);
@@ -726,7 +726,7 @@ int pqmf_inverse(after_ae* h, hipStream_t s, const float* y, float* audio, int B
                            dim3(256), 0, s, y, h->pq_iw, audio, Tm, M, K, pl, gated, ychan, zstate, cs, ts);
     }
     AFTER_HIP_CHECK(hipGetLastError());
-    if (zstate) {
+    if (zstate && K > 1) {
         const int S = K - 1;
         AFTER_REQUIRE(Tm >= S && Tm % 2 == 0, AFTER_E_INVALID,
                       "pqmf streaming: chunk of %d frames too short / odd", Tm);
@@ -747,8 +747,10 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
     AFTER_REQUIRE(cfg->n_stages >= 1 && cfg->n_stages <= AFTER_AE_MAX_STAGES &&
                       cfg->n_dilations >= 1 && cfg->n_dilations <= AFTER_AE_MAX_STAGES,
                   AFTER_E_INVALID, "autoencoder: bad stage / dilation count");
-    AFTER_REQUIRE(cfg->pqmf_bands >= 2 && cfg->kernel_size % 2 == 1 && cfg->kernel_size <= 7,
-                  AFTER_E_INVALID, "autoencoder: pqmf_bands >= 2 and odd kernel_size <= 7 required");
+    // (pqmf_bands = 1: no filter bank -- the reference's DummyIdentity, SimpleNetsStream.py:854-858: the codec runs on the audio
+    //  samples themselves; here the one-band bank with the single tap 1.0 on the generic PQMF kernels)
+    AFTER_REQUIRE(cfg->pqmf_bands >= 1 && cfg->kernel_size % 2 == 1 && cfg->kernel_size <= 7,
+                  AFTER_E_INVALID, "autoencoder: pqmf_bands >= 1 and odd kernel_size <= 7 required");
     AFTER_REQUIRE(max_batch > 0 && max_samples > 0, AFTER_E_INVALID, "bad capacities");
     // one statistics slot per normalised conv of a pass (the larger of encode / decode):
     // 2 per ResnetBlock + 1 per resampling conv + stem / synth
@@ -809,8 +811,8 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
     } while (0)
     // PQMF banks (pqmf.py:258-280): forward [M,1,Kf], inverse [M,M,Ki]; the kernel sizes
     // follow from the arena request below (Kf = 32 M + 1, Ki = 2 M + 1 for hk of 32 M taps)
-    h->pq_fk = 32 * h->M + 1;
-    h->pq_ik = 2 * h->M + 1;
+    h->pq_fk = h->M > 1 ? 32 * h->M + 1 : 1;
+    h->pq_ik = h->M > 1 ? 2 * h->M + 1 : 1;
     {
         const float* fw = cur.next();
         const float* iw = cur.next();
@@ -1262,8 +1264,8 @@ extern "C" int after_ae_enable_streaming(after_ae* h, int enable) {
         const int n = c.n_stages, nd = c.n_dilations;
         const int enc_slots = 1 + n * nd + n + 1, dec_slots = 1 + n + n * nd + 1;
         h->slot_elems = (size_t)h->max_batch * conv_tm_cp(h->cmax) * conv_tm_halo();
-        const size_t fs = (size_t)h->max_batch * (h->pq_fk - 1);
-        const size_t is = (size_t)h->max_batch * h->M * (h->pq_ik - 1);
+        const size_t fs = (size_t)h->max_batch * (h->pq_fk > 1 ? h->pq_fk - 1 : 1);  // (one-band identity bank: no history, one unused word)
+        const size_t is = (size_t)h->max_batch * h->M * (h->pq_ik > 1 ? h->pq_ik - 1 : 1);
         AFTER_TRY(h->sa.init(((enc_slots + dec_slots) * h->slot_elems + fs + is) * sizeof(float) + 8192));
         h->enc_state = h->sa.take<float>(enc_slots * h->slot_elems);
         h->dec_state = h->sa.take<float>(dec_slots * h->slot_elems);

@@ -225,8 +225,7 @@ class MidiStreamer(Streamer):
             raise ValueError("MidiStreamer is for MIDI-structure models (encoder_time = None, midi.gin:66)")
         self.n_poly = int(n_poly)
         super().__init__(blender, emb_model, **kw)
-        if getattr(blender, "post_encoder", None) is not None:
-            raise NotImplementedError("post_encoder is not built (every shipped config: None)")
+        # (blender.post_encoder: stored by Base.__init__ and never called on the reference's sampling path either, model.py:38)
 
     def structure(self, x):
         raise AttributeError("the MIDI streamer has no structure encoder (export_midi.py)")

@@ -49,20 +49,20 @@ def pqmf_forward(sd, x, mode="centered"):
     """pqmf.py:286-290 (CachedPQMF.forward): Conv1d(1->M, k=513, stride M,
     pad get_padding(513) = (256,256) centred / (512,0) under the causal gin
     switch, pqmf.py:263-270) then reverse_half."""
-    w = sd["pqmf.forward_conv.weight"]
-    M = w.shape[0]
-    if M == 1:
+    w = sd.get("pqmf.forward_conv.weight")
+    if w is None or w.shape[0] == 1:  # pqmf_bands <= 1: DummyIdentity, SimpleNetsStream.py:853-859, 925-928
         return x
+    M = w.shape[0]
     x = F.pad(x, get_padding(w.shape[-1], mode=mode))
     return reverse_half(F.conv1d(x, w, stride=M))
 
 
 def pqmf_inverse(sd, x, mode="centered"):
     """pqmf.py:292-301 (CachedPQMF.inverse); conv pad get_padding(33) (pqmf.py:272-280)."""
-    w = sd["pqmf.inverse_conv.weight"]
-    m = w.shape[0]
-    if m == 1:
+    w = sd.get("pqmf.inverse_conv.weight")
+    if w is None or w.shape[0] == 1:  # (SimpleNetsStream.py:946-949)
         return x
+    m = w.shape[0]
     x = reverse_half(x)
     x = F.conv1d(F.pad(x, get_padding(w.shape[-1], mode=mode)), w) * m
     x = x.flip(1)

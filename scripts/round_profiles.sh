@@ -8,7 +8,9 @@ mkdir -p $O
 export TMPDIR=/tmp
 python bench.py --pmc > $O/pmc_b1.log 2>&1   # first: the bench lines below quote their traffic figures
 python bench.py --pmc --batch-per-gpu 8 > $O/pmc_b8.log 2>&1
-cp profiles/${R}_pmc_hbm_base_b1.json profiles/${R}_pmc_hbm_base_b8.json $O/ 2>/dev/null
+python bench.py --pmc-mfma > $O/mfma_b1.log 2>&1   # matrix-pipe busy fraction per kernel (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE)
+python bench.py --pmc-mfma --batch-per-gpu 8 > $O/mfma_b8.log 2>&1
+cp profiles/${R}_pmc_hbm_base_b1.json profiles/${R}_pmc_hbm_base_b8.json profiles/${R}_pmc_mfma_base_b1.json profiles/${R}_pmc_mfma_base_b8.json $O/ 2>/dev/null
 python bench.py --steps 20 --warmup 5 > $O/${R}_bench_b1.json 2> $O/bench_b1.err
 python bench.py --steps 6 --warmup 2 --batch-per-gpu 8 --no-cpu-baseline > $O/${R}_bench_b8.json 2> $O/bench_b8.err
 python bench.py --steps 4 --warmup 1 --batch-per-gpu 8 --config midi > $O/${R}_bench_midi_b8.json 2> $O/bench_midi.err
@@ -29,6 +31,15 @@ python scripts/time_encoders.py 2>/dev/null | grep workload >> $O/${R}_codec.jso
 ./scripts/ubench/xcd_barrier.bin > $O/${R}_xcd_barrier.jsonl 2>/dev/null
 ./scripts/ubench/xcd_local.bin > $O/${R}_xcd_local.jsonl 2>/dev/null
 ./scripts/ubench/xcd_halo.bin > $O/${R}_xcd_halo.jsonl 2>/dev/null
+./scripts/ubench/xcd_barrier2.bin > $O/${R}_xcd_barrier2.jsonl 2>/dev/null   # round 4: the barrier under spread arrivals, the L2 round trips, the DMA issue rate
+./scripts/ubench/l2_rtt.bin > $O/${R}_l2_rtt.jsonl 2>/dev/null
+./scripts/ubench/dma_issue.bin > $O/${R}_dma_issue.jsonl 2>/dev/null
+AFTER_SAMPLE_PERSIST=0 python scripts/time_graph.py > $O/${R}_graph_vs_eager.jsonl 2>/dev/null   # (launch path: eager launches vs hipGraph replay)
+AFTER_SAMPLE_PERSIST=0 python scripts/time_sampler.py base 1 50 7 2>/dev/null | tail -1 > $O/${R}_ab_sample_persist.txt
+python scripts/time_sampler.py base 1 50 7 2>/dev/null | tail -1 >> $O/${R}_ab_sample_persist.txt
+AFTER_SAMPLE_PERSIST=0 python scripts/time_sampler.py base 1 50 7 2>/dev/null | tail -1 >> $O/${R}_ab_sample_persist.txt
+python scripts/time_sampler.py base 1 50 7 2>/dev/null | tail -1 >> $O/${R}_ab_sample_persist.txt
+python scripts/seg_context.py 2>/dev/null | tail -9 > $O/${R}_clip_breakdown_b1.txt
 python scripts/stream_step_trace.py --offline > $O/${R}_offline_step_trace.txt 2>/dev/null
 # the persistent streaming step: same-box A/B against the launch path, per-phase timeline, kernel stats of a chunk
 for p in 1 0 1 0; do

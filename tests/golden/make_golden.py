@@ -182,8 +182,11 @@ def ae_case(case, cfg_name, B, L, seed, wg_scale=1.0):
     z, _ = ae.encode(x)
     zin = detweights.seeded_tensor("z", tuple(z.shape), seed)
     y = ae.decode(zin)
-    mb = ae.pqmf(x)
-    xr = ae.pqmf.inverse(mb)
+    if cfg["pqmf_bands"] > 1:
+        mb = ae.pqmf(x)
+        xr = ae.pqmf.inverse(mb)
+    else:  # DummyIdentity: the "multiband" signal is the audio
+        mb, xr = x, x
     meta = dict(kind="autoencoder", config=cfg_name, seed=seed, B=B, L=L, shapes=shapes)
     if wg_scale != 1.0:
         meta["wg_scale"] = wg_scale
@@ -457,6 +460,7 @@ CASES = {
     "ae_micro_causal": lambda: ae_case("ae_micro_causal", "microAE_causal", 1, 8192, 42),
     "ae_base": lambda: ae_case("ae_base", "baseAE", 1, 32768, 43),
     "ae_micro_bottlenecks": bottleneck_case,
+    "ae_micro_nopqmf": lambda: ae_case("ae_micro_nopqmf", "microAE_nopqmf", 2, 4096, 47),
     "ae_micro_causal_wc": lambda: ae_case("ae_micro_causal_wc", "microAE_causal", 2, 8192, 44, wg_scale=0.5),
     "ae_base_causal_wc": lambda: ae_case("ae_base_causal_wc", "baseAE_causal", 1, 16384, 45, wg_scale=0.5),
     "encoders_micro": lambda: encoders_case("encoders_micro", "micro", 2, 64, 51),

@@ -184,6 +184,18 @@ def test_load_diffusion_and_autoencoder_from_run_folders(tmp_path):
     with pytest.raises(RuntimeError):
         checkpoint.load_diffusion(str(run), device="cpu")
 
+    # training-only hooks (Base.time_transform: applied by prep_data to training batches, model.py:136-137; Base.post_encoder:
+    # stored, never called, model.py:38): a run that bound them loads, the sampling path ignores them as the reference's does
+    hooks = tmp_path / "hooks"
+    hooks.mkdir()
+    (hooks / "config.gin").write_text(OPERATIVE.replace("Base.time_transform = None",
+                                                        "Base.time_transform = @some_training_transform\nBase.post_encoder = @post/Encoder1D()"))
+    sdh = dict(sd)
+    sdh["post_encoder.net.0.weight"] = torch.zeros(3)
+    torch.save({"model_state": sdh, "opt_state": {}}, hooks / "checkpoint10_EMA.pt")
+    mh = checkpoint.load_diffusion(str(hooks), device="cpu")
+    assert all(torch.equal(mh.state_dict()[k], want[k]) for k in want)
+
     ae_run = tmp_path / "codec"
     ae_run.mkdir()
     (ae_run / "config.gin").write_text(BLOCK_AE)

@@ -109,7 +109,8 @@ def test_streaming_cache_matches_reference():
             assert max_abs(got, want[c, i]) < 2e-5, (c, i)
 
 
-@pytest.mark.parametrize("case", ["ae_micro", "ae_micro_causal", "ae_base", "ae_micro_causal_wc", "ae_base_causal_wc"])
+@pytest.mark.parametrize("case", ["ae_micro", "ae_micro_causal", "ae_base", "ae_micro_causal_wc", "ae_base_causal_wc",
+                                  "ae_micro_nopqmf"])
 def test_autoencoder_matches_reference(case):
     fx = Fixture(case)
     cfg = configs.autoencoder_config(fx.meta["config"])
