@@ -38,7 +38,7 @@ class Unet1dCfg(ctypes.Structure):
     _fields_ = [("in_size", c_int), ("out_size", c_int), ("n_blocks", c_int), ("channels", c_int * 8),
                 ("ratios", c_int * 8), ("kernel_size", c_int), ("time_channels", c_int),
                 ("time_cond_in_channels", c_int), ("time_cond_channels", c_int),
-                ("cond_channels", c_int), ("use_res_last", c_int)]
+                ("cond_channels", c_int), ("use_res_last", c_int), ("n_attn_layers", c_int)]
 
 
 class EcapaCfg(ctypes.Structure):

@@ -108,6 +108,10 @@ UNET = {
     "unet_micro": dict(in_size=16, channels=[32, 32, 64, 64], ratios=[2, 2, 2, 2, 2], kernel_size=5,
                        time_channels=64, time_cond_in_channels=12, time_cond_channels=16, cond_channels=6,
                        n_attn_layers=0, use_res_last=False),
+    # two self-attention levels (unet1d.py:339, 350, 372: down_layers 2, 3; up_layers 0, 1; the middle block with 64 // 32 heads)
+    "unet_micro_attn": dict(in_size=16, channels=[32, 32, 64, 64], ratios=[2, 2, 2, 2, 2], kernel_size=5,
+                            time_channels=64, time_cond_in_channels=12, time_cond_channels=16, cond_channels=6,
+                            n_attn_layers=2, use_res_last=False),
     "unet_micro_flat": dict(in_size=16, out_size=16, channels=[32, 64], ratios=[1, 2], kernel_size=3,
                             time_channels=32, time_cond_in_channels=12, time_cond_channels=16,
                             cond_channels=6, n_attn_layers=0, use_res_last=True),

@@ -8,7 +8,9 @@
 // conv as the balanced LDS-DMA GEMM, FiLM (time and cond modulation, unet1d.py:100-110) as a
 // per-(clip, channel) affine in the conv epilogue, strided pools via the row stride of the A
 // operand, nearest upsampling as a row copy.
-// Supported: time_cond_channels > 0, cond_channels > 0, n_attn_layers = 0 (the defaults).
+// Supported: time_cond_channels > 0, cond_channels > 0; n_attn_layers > 0 (round 4): SelfAttention1d (blocks.py:201-243) as
+// GroupNorm(1, C) statistics pass -> 1 x 1 qkv conv (the same conv path) -> unet_attn_kernel (full softmax attention per
+// head, one lane per query, keys staged through LDS) -> 1 x 1 out_proj conv with the block output as residual.
 #include <new>
 #include <vector>
 
@@ -62,6 +64,55 @@ __global__ __launch_bounds__(256) void film_kernel(FilmArgs a) {
         }
         a.ps[(size_t)b * a.C + c] = tm * cm;
         a.pt[(size_t)b * a.C + c] = ta * cm + ca;
+    }
+}
+
+// ---- SelfAttention1d's core (blocks.py:231-241): qkv [B][T][3 C] time-major, head h = channels [h D, (h + 1) D) of each third;
+// att = softmax((q s) (k s)^T), s = D^-1/4 on both operands as in the reference; y [B][T][C].  One lane per query row (online
+// softmax over key tiles of 64 staged in LDS, q and the output row in registers); grid (T / 64, heads, B).  Not a hot kernel:
+// no shipped config selects UNET1D, and its attention runs at 1/4 .. 1/32 of the clip's frames.
+template <int D>
+__global__ __launch_bounds__(64) void unet_attn_kernel(const float* __restrict__ qkv, float* __restrict__ y, int T, int C) {
+    __shared__ float ks[64][D + 1], vs[64][D + 1];
+    const int t = blockIdx.x * 64 + threadIdx.x, hd = blockIdx.y, b = blockIdx.z;
+    const float scale = powf((float)D, -0.25f);
+    const float* base = qkv + (size_t)b * T * 3 * C;
+    float q[D], o[D];
+    const int tq = t < T ? t : T - 1;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        q[j] = base[(size_t)tq * 3 * C + hd * D + j] * scale;
+        o[j] = 0.f;
+    }
+    float m = -INFINITY, l = 0.f;
+    for (int k0 = 0; k0 < T; k0 += 64) {
+        const int kr = k0 + threadIdx.x;
+        __syncthreads();
+        if (kr < T) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                ks[threadIdx.x][j] = base[(size_t)kr * 3 * C + C + hd * D + j] * scale;
+                vs[threadIdx.x][j] = base[(size_t)kr * 3 * C + 2 * C + hd * D + j];
+            }
+        }
+        __syncthreads();
+        const int nk = min(64, T - k0);
+        for (int kk = 0; kk < nk; ++kk) {
+            float sc = 0.f;
+#pragma unroll
+            for (int j = 0; j < D; ++j) sc += q[j] * ks[kk][j];
+            const float mn = fmaxf(m, sc);
+            const float corr = expf(m - mn), pw = expf(sc - mn);
+            l = l * corr + pw;
+#pragma unroll
+            for (int j = 0; j < D; ++j) o[j] = o[j] * corr + pw * vs[kk][j];
+            m = mn;
+        }
+    }
+    if (t < T) {
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int j = 0; j < D; ++j) y[((size_t)b * T + t) * C + hd * D + j] = o[j] * inv;
     }
 }
 
@@ -148,6 +199,12 @@ struct PackedConv {
     ConvTmPlan plan;
     float* wd = nullptr;
 };
+struct AttnW {  // SelfAttention1d (blocks.py:201-243)
+    PackedConv qkv, out;
+    float *nw = nullptr, *nb = nullptr;  // GroupNorm(1, C) affine
+    int C = 0, nh = 0;
+    bool on = false;
+};
 struct BlockW {  // ConvBlock1D
     PackedConv c1, c2, to_out;
     float *gn1_w = nullptr, *gn1_b = nullptr, *gn2_w = nullptr, *gn2_b = nullptr;
@@ -170,6 +227,9 @@ struct after_unet1d {
     std::vector<PackedConv> pool, upconv;
     std::vector<char> up_has_conv;
     BlockW mid;
+    std::vector<AttnW> down_attn, up_attn;  // n each (`on` where unet1d.py:339 / :350 switch them on)
+    AttnW mid_attn;
+    float *attx = nullptr, *qkvb = nullptr, *attb = nullptr;  // a block's output in front of its attention, qkv [B][T][3C], att @ v
     // workspaces
     float *emb = nullptr, *ps = nullptr, *pt = nullptr;
     double* stats = nullptr;  // [kSlots][conv_tm_stat_sub()][max_batch][16][2][kStatBins] GroupNorm accumulators (conv.h: stat_bins)
@@ -267,6 +327,22 @@ int load_block(Arena& a, WCur& c, BlockW& b, int in_c, int out_c, int skip_c, in
     return AFTER_OK;
 }
 
+int load_attn(Arena& a, WCur& c, AttnW& w, int C, int nh) {
+    AFTER_REQUIRE(nh >= 1 && C % nh == 0, AFTER_E_INVALID, "unet1d: self-attention over %d channels with %d heads", C, nh);
+    const int D = C / nh;
+    AFTER_REQUIRE(D == 4 || D == 8 || D == 16 || D == 32 || D == 64, AFTER_E_INVALID,
+                  "unet1d: self-attention head size %d (built: 4, 8, 16, 32, 64)", D);
+    w.C = C;
+    w.nh = nh;
+    w.on = true;
+    const float *nw = c.next(), *nb = c.next();
+    AFTER_REQUIRE(c.ok, AFTER_E_INVALID, "unet1d: missing self_attn.norm");
+    AFTER_TRY(dev_copy(a, &w.nw, nw, C));
+    AFTER_TRY(dev_copy(a, &w.nb, nb, C));
+    AFTER_TRY(load_pconv(a, c, w.qkv, C, 3 * C, 1));
+    return load_pconv(a, c, w.out, C, C, 1);
+}
+
 size_t conv_fl(int cin, int cout, int k) {  // staging copy + GEMM operand + bias
     return (size_t)cout * k * (pad16(cin) + conv_tm_cp(cin)) + cout + 256;
 }
@@ -276,7 +352,7 @@ size_t block_fl(int in_c, int out_c, int skip_c, int tc_c, int k, int TC, int CC
            2 * (size_t)out_c + 128 * (size_t)(TC + CC) + 256 + 4 * (size_t)out_c * 128 + 4 * (size_t)out_c + 2048;
 }
 
-constexpr int kSlots = 48;  // GroupNorm statistics slots per forward: 2 per ConvBlock1D, 2 n + 1 blocks
+constexpr int kSlots = 64;  // GroupNorm statistics slots per forward: 2 per ConvBlock1D (2 n + 1 blocks), 1 per self-attention
 
 double* next_slot(after_unet1d* h) {
     double* p = h->stats + (size_t)(h->stat_slot % kSlots) * conv_tm_stat_sub() * h->max_batch * 16 * kStatWords;
@@ -412,6 +488,40 @@ int run_block(after_unet1d* h, hipStream_t s, const BlockW& b, const float* x, i
     return conv_tm_run(h, s, b.c2, io, B, T);
 }
 
+// SelfAttention1d.forward (blocks.py:231-243) on the block output x [B][T][C]: y = x + out_proj(attention(qkv_proj(norm(x))))
+int run_attn(after_unet1d* h, hipStream_t s, const AttnW& w, const float* x, float* y, int B, int T) {
+    const int C = w.C, D = C / w.nh;
+    double* st = next_slot(h);
+    AFTER_TRY(launch_stats_accum_tm(x, st, B, C, T, 1, s, C));
+    {
+        ConvIo io;
+        io.x = x;
+        io.x_ld = C;
+        io.stats = st;
+        io.gamma = w.nw;
+        io.beta = w.nb;
+        io.G = 1;
+        io.y = h->qkvb;
+        AFTER_TRY(conv_tm_run(h, s, w.qkv, io, B, T));
+    }
+    const dim3 grid(cdiv(T, 64), w.nh, B);
+    switch (D) {
+        case 4: hipLaunchKernelGGL(unet_attn_kernel<4>, grid, dim3(64), 0, s, h->qkvb, h->attb, T, C); break;
+        case 8: hipLaunchKernelGGL(unet_attn_kernel<8>, grid, dim3(64), 0, s, h->qkvb, h->attb, T, C); break;
+        case 16: hipLaunchKernelGGL(unet_attn_kernel<16>, grid, dim3(64), 0, s, h->qkvb, h->attb, T, C); break;
+        case 32: hipLaunchKernelGGL(unet_attn_kernel<32>, grid, dim3(64), 0, s, h->qkvb, h->attb, T, C); break;
+        default: hipLaunchKernelGGL(unet_attn_kernel<64>, grid, dim3(64), 0, s, h->qkvb, h->attb, T, C); break;
+    }
+    AFTER_HIP_CHECK(hipGetLastError());
+    ConvIo io;
+    io.x = h->attb;
+    io.x_ld = C;
+    io.y = y;
+    io.res = x;
+    io.res_ld = C;
+    return conv_tm_run(h, s, w.out, io, B, T);
+}
+
 }  // namespace
 
 extern "C" int after_unet1d_create(const after_unet1d_cfg* cfg, const float* const* weights,
@@ -452,6 +562,16 @@ extern "C" int after_unet1d_create(const after_unet1d_cfg* cfg, const float* con
     }
     wf += block_fl(ch[n - 1], ch[n - 1], 0, tcc, k, TC, CC);
     ccat_max = ch[n - 1] + tcc > ccat_max ? ch[n - 1] + tcc : ccat_max;
+    // self-attention layers (unet1d.py:339, 350, 372): down_layers i >= n - n_attn (i >= 1), up_layers i <= n_attn (loop index
+    // 1 .. n - 1), the middle block when n_attn > 0
+    const int na = cfg->n_attn_layers;
+    AFTER_REQUIRE(na >= 0 && na <= n, AFTER_E_INVALID, "unet1d: n_attn_layers = %d", na);
+    auto attn_fl = [&](int C) { return conv_fl(C, 3 * C, 1) + conv_fl(C, C, 1) + 2 * (size_t)C + 64; };
+    for (int i = 1; i < n; ++i) {
+        if (i >= n - na) wf += attn_fl(in_of(i));
+        if (i <= na) wf += attn_fl(ch[n - i - 1]);
+    }
+    if (na > 0) wf += attn_fl(ch[n - 1]);
     for (int i = 1; i <= n; ++i) {
         const int ic = ch[n - i], oc = i < n ? ch[n - i - 1] : outsz;
         const int sk = i < n ? oc : in0;
@@ -476,11 +596,21 @@ extern "C" int after_unet1d_create(const after_unet1d_cfg* cfg, const float* con
     // down layers (:318-340): ConvBlock(in -> in) then pool(in -> channels[i], stride ratios[i])
     h->down.resize(n);
     h->pool.resize(n);
+    h->down_attn.resize(n);
+    h->up_attn.resize(n);
     for (int i = 0; i < n; ++i) {
         U_TRY(load_block(h->wa, cur, h->down[i], in_of(i), in_of(i), 0, tcc, k, TC, CC, true));
+        if (i >= 1 && i >= n - na) U_TRY(load_attn(h->wa, cur, h->down_attn[i], in_of(i), 4));
         U_TRY(load_pconv(h->wa, cur, h->pool[i], in_of(i), ch[i], k, cfg->ratios[i]));
     }
     U_TRY(load_block(h->wa, cur, h->mid, ch[n - 1], ch[n - 1], 0, tcc, k, TC, CC, true));
+    if (na > 0) {
+        if (ch[n - 1] < 32) {
+            set_error("unet1d: the middle block's self-attention has in_c // 32 heads: %d channels", ch[n - 1]);
+            return fail(AFTER_E_INVALID);
+        }
+        U_TRY(load_attn(h->wa, cur, h->mid_attn, ch[n - 1], ch[n - 1] / 32));
+    }
     // up layers (:341-372): i = 1..n-1: channels[n-i] -> channels[n-i-1], ratio ratios[n-i];
     // last: channels[0] -> out_size, ratio ratios[0], skip = in_size, res = use_res_last
     h->up.resize(n);
@@ -499,6 +629,7 @@ extern "C" int after_unet1d_create(const after_unet1d_cfg* cfg, const float* con
             (void)cur.opt();
         }
         U_TRY(load_block(h->wa, cur, h->up[i - 1], oc, oc, sk, tcc, k, TC, CC, i < n ? true : cfg->use_res_last != 0));
+        if (i < n && i <= na) U_TRY(load_attn(h->wa, cur, h->up_attn[i - 1], oc, 4));
     }
 #undef U_TRY
     if (!cur.ok || cur.i != n_weights) {
@@ -513,7 +644,7 @@ extern "C" int after_unet1d_create(const after_unet1d_cfg* cfg, const float* con
     h->xp_elems = Bm * (size_t)conv_tm_cp(cin_max) * conv_tm_rows((int)T);
     const size_t stat_d = (size_t)kSlots * conv_tm_stat_sub() * Bm * 16 * kStatWords;
     size_t bytes = (Bm * TC + 2 * Bm * cmax) * sizeof(float) + stat_d * sizeof(double) +
-                   (catn + 5 * act + (size_t)n * act + (size_t)(n + 2) * tcn + h->xp_elems) * sizeof(float) +
+                   (catn + (na > 0 ? 10 : 5) * act + (size_t)n * act + (size_t)(n + 2) * tcn + h->xp_elems) * sizeof(float) +
                    (1 << 16) +
                    (Bm * T * (size_t)(3 * in0 + outsz + cfg->time_cond_in_channels) + Bm * (CC + 1)) * sizeof(float) +
                    8192;
@@ -528,6 +659,12 @@ extern "C" int after_unet1d_create(const after_unet1d_cfg* cfg, const float* con
     h->xa = h->ws.take<float>(act);
     h->xb = h->ws.take<float>(act);
     h->ups = h->ws.take<float>(act);
+    if (na > 0) {
+        h->attx = h->ws.take<float>(act);
+        h->qkvb = h->ws.take<float>(3 * act);
+        h->attb = h->ws.take<float>(act);
+        if (!h->attb) return fail(AFTER_E_NOMEM);
+    }
     h->xp = h->ws.take<float>(h->xp_elems);
     h->skips.resize(n);
     h->tconds.resize(n + 2);
@@ -575,7 +712,7 @@ extern "C" int after_unet1d_forward(after_unet1d* h, const float* x, const float
     // GroupNorm accumulators of this forward: one slot per normalisation, zeroed together
     h->stat_slot = 0;
     AFTER_HIP_CHECK(hipMemsetAsync(h->stats, 0, (size_t)kSlots * conv_tm_stat_sub() * h->max_batch * 16 * kStatWords * sizeof(double), s));
-    AFTER_REQUIRE(2 * (2 * n + 1) <= kSlots, AFTER_E_INVALID, "unet1d: statistics slots");
+    AFTER_REQUIRE(2 * (2 * n + 1) + 2 * n <= kSlots, AFTER_E_INVALID, "unet1d: statistics slots");
     // the network input is read twice (concatenation, shortcut): one transpose
     AFTER_TRY(launch_cm_to_tm(x, h->xtm, B, c.in_size, T, c.in_size, s));
     // ---- encoder: time_cond is re-embedded (conv + SiLU) at every scale
@@ -592,7 +729,12 @@ extern "C" int after_unet1d_forward(after_unet1d* h, const float* x, const float
         io.out_act = ACT_SILU;
         AFTER_TRY(conv_tm_run(h, s, h->cond_emb[i], io, B, i == 0 ? T : Ts[i - 1]));
         Ts[i] = Tc;
-        AFTER_TRY(run_block(h, s, h->down[i], cur, cur_c, nullptr, h->tconds[i], cond, h->skips[i], 0, B, Tc));
+        if (h->down_attn[i].on) {  // skip = self_attn(conv(x)), unet1d.py:162-163
+            AFTER_TRY(run_block(h, s, h->down[i], cur, cur_c, nullptr, h->tconds[i], cond, h->attx, 0, B, Tc));
+            AFTER_TRY(run_attn(h, s, h->down_attn[i], h->attx, h->skips[i], B, Tc));
+        } else {
+            AFTER_TRY(run_block(h, s, h->down[i], cur, cur_c, nullptr, h->tconds[i], cond, h->skips[i], 0, B, Tc));
+        }
         float* nx = (cur == h->xa) ? h->xb : h->xa;
         ConvIo pl;
         pl.x = h->skips[i];
@@ -611,7 +753,12 @@ extern "C" int after_unet1d_forward(after_unet1d* h, const float* x, const float
         io.out_act = ACT_SILU;
         AFTER_TRY(conv_tm_run(h, s, h->cond_emb[n], io, B, Ts[n - 1]));
         float* nx = (cur == h->xa) ? h->xb : h->xa;
-        AFTER_TRY(run_block(h, s, h->mid, cur, cur_c, nullptr, h->tconds[n], cond, nx, 0, B, Tc));
+        if (h->mid_attn.on) {
+            AFTER_TRY(run_block(h, s, h->mid, cur, cur_c, nullptr, h->tconds[n], cond, h->attx, 0, B, Tc));
+            AFTER_TRY(run_attn(h, s, h->mid_attn, h->attx, nx, B, Tc));
+        } else {
+            AFTER_TRY(run_block(h, s, h->mid, cur, cur_c, nullptr, h->tconds[n], cond, nx, 0, B, Tc));
+        }
         cur = nx;
     }
     // ---- decoder
@@ -636,7 +783,12 @@ extern "C" int after_unet1d_forward(after_unet1d* h, const float* x, const float
         }
         float* y = i == n ? out : ((bx == h->xa) ? h->xb : h->xa);
         if (i < n && y == bx) y = h->ups;  // (identity `up`: keep input and output apart)
-        AFTER_TRY(run_block(h, s, h->up[i - 1], bx, cur_c, h->skips[n - i], h->tconds[n - i], cond, y, i == n, B, Tc));
+        if (h->up_attn[i - 1].on) {  // (never the last block: y is time-major here)
+            AFTER_TRY(run_block(h, s, h->up[i - 1], bx, cur_c, h->skips[n - i], h->tconds[n - i], cond, h->attx, 0, B, Tc));
+            AFTER_TRY(run_attn(h, s, h->up_attn[i - 1], h->attx, y, B, Tc));
+        } else {
+            AFTER_TRY(run_block(h, s, h->up[i - 1], bx, cur_c, h->skips[n - i], h->tconds[n - i], cond, y, i == n, B, Tc));
+        }
         cur = y;
         cur_c = h->up[i - 1].out_c;
     }

@@ -1,7 +1,7 @@
 """UNET1D: drop-in container for the reference's Conv1d / GroupNorm / SiLU / FiLM denoiser
 (after/diffusion/networks/unet1d.py:254-429).  Same constructor arguments and state-dict keys;
-`forward` runs in libafter_hip (after_unet1d_*).  Built for the default topology
-(time_cond_channels > 0, cond_channels > 0, n_attn_layers = 0); no shipped gin config selects
+`forward` runs in libafter_hip (after_unet1d_*).  Built for time_cond_channels > 0, cond_channels > 0, with or
+without the self-attention layers of n_attn_layers > 0 (blocks.py:201-243); no shipped gin config selects
 this network -- it is SURVEY 8(f)-4."""
 import ctypes
 
@@ -30,27 +30,39 @@ class _ConvBlock(nn.Module):  # ConvBlock1D, unet1d.py:29-118
         self.to_out = nn.Conv1d(in_c, out_c, 1, padding="same") if skip_c else nn.Identity()
 
 
+class _SelfAttn(nn.Module):  # SelfAttention1d, blocks.py:201-243 (parameters only: the arithmetic is after_unet1d_forward's)
+
+    def __init__(self, c, n_head):
+        super().__init__()
+        if n_head < 1 or c % n_head:
+            raise ValueError(f"SelfAttention1d({c}, {n_head}): heads must divide the channels")
+        self.n_head = n_head
+        self.norm = nn.GroupNorm(1, c)
+        self.qkv_proj = nn.Conv1d(c, 3 * c, 1)
+        self.out_proj = nn.Conv1d(c, c, 1)
+
+
 class _EncBlock(nn.Module):  # EncoderBlock1D, :121-165
 
-    def __init__(self, in_c, out_c, tc_c, time_c, cond_c, k, ratio):
+    def __init__(self, in_c, out_c, tc_c, time_c, cond_c, k, ratio, use_self_attn=False):
         super().__init__()
         self.conv = _ConvBlock(in_c, in_c, 0, tc_c, time_c, cond_c, k)
-        self.self_attn = nn.Identity()
+        self.self_attn = _SelfAttn(in_c, 4) if use_self_attn else nn.Identity()
         self.pool = nn.Conv1d(in_c, out_c, k, padding="same") if ratio == 1 else \
             nn.Conv1d(in_c, out_c, k, stride=ratio, padding=k // 2)
 
 
 class _MidBlock(nn.Module):  # MiddleBlock1D, :168-197
 
-    def __init__(self, in_c, tc_c, time_c, cond_c, k):
+    def __init__(self, in_c, tc_c, time_c, cond_c, k, use_self_attn=False):
         super().__init__()
         self.conv = _ConvBlock(in_c, in_c, 0, tc_c, time_c, cond_c, k)
-        self.self_attn = nn.Identity()
+        self.self_attn = _SelfAttn(in_c, in_c // 32) if use_self_attn else nn.Identity()
 
 
 class _DecBlock(nn.Module):  # DecoderBlock1D, :200-251
 
-    def __init__(self, in_c, out_c, tc_c, time_c, cond_c, k, ratio, skip_size=None):
+    def __init__(self, in_c, out_c, tc_c, time_c, cond_c, k, ratio, skip_size=None, use_self_attn=False):
         super().__init__()
         if ratio == 1:
             self.up = nn.Identity() if in_c == out_c else nn.Conv1d(in_c, out_c, 3, padding="same")
@@ -59,7 +71,7 @@ class _DecBlock(nn.Module):  # DecoderBlock1D, :200-251
                                     nn.Conv1d(in_c, out_c, 3, padding="same"))
         self.conv = _ConvBlock(out_c, out_c, skip_size if skip_size is not None else out_c, tc_c, time_c,
                                cond_c, k)
-        self.self_attn = nn.Identity()
+        self.self_attn = _SelfAttn(out_c, 4) if use_self_attn else nn.Identity()
 
 
 class UNET1D(nn.Module):
@@ -68,9 +80,11 @@ class UNET1D(nn.Module):
                  kernel_size=5, time_channels=64, time_cond_in_channels=1, time_cond_channels=64,
                  cond_channels=32, n_attn_layers=0, use_res_last=False):
         super().__init__()
-        if n_attn_layers or not time_cond_channels or not cond_channels or not time_channels:
-            raise NotImplementedError("after_amd builds UNET1D in its default topology: n_attn_layers = 0, "
-                                      "time_cond_channels > 0, cond_channels > 0, time_channels > 0")
+        if not time_cond_channels or not cond_channels or not time_channels:
+            raise NotImplementedError("after_amd builds UNET1D with time_cond_channels > 0, cond_channels > 0, "
+                                      "time_channels > 0")
+        if not 0 <= n_attn_layers <= len(channels):
+            raise ValueError(f"n_attn_layers = {n_attn_layers} with {len(channels)} levels")
         if kernel_size % 2 == 0:
             raise NotImplementedError("odd kernel_size only (padding='same')")
         channels = list(channels)
@@ -81,6 +95,7 @@ class UNET1D(nn.Module):
         self.time_channels, self.time_cond_in_channels = time_channels, time_cond_in_channels
         self.time_cond_channels, self.cond_channels = time_cond_channels, cond_channels
         self.use_res_last = bool(use_res_last)
+        self.n_attn_layers = na = int(n_attn_layers)
         n = len(channels)
         R = [1] + list(ratios)
         self.ratios = R[:n]
@@ -93,10 +108,12 @@ class UNET1D(nn.Module):
         self.up_layers = nn.ModuleList()
         self.down_layers = nn.ModuleList([_EncBlock(in_size, channels[0], tcc, tc, cc, k, R[0])])
         for i in range(1, n):
-            self.down_layers.append(_EncBlock(channels[i - 1], channels[i], tcc, tc, cc, k, R[i]))
-            self.up_layers.append(_DecBlock(channels[n - i], channels[n - i - 1], tcc, tc, cc, k, R[n - i]))
+            self.down_layers.append(_EncBlock(channels[i - 1], channels[i], tcc, tc, cc, k, R[i],
+                                              use_self_attn=i >= n - na))  # unet1d.py:339
+            self.up_layers.append(_DecBlock(channels[n - i], channels[n - i - 1], tcc, tc, cc, k, R[n - i],
+                                            use_self_attn=i <= na))  # :350
         self.up_layers.append(_DecBlock(channels[0], self.out_size, tcc, tc, cc, k, R[0], skip_size=in_size))
-        self.middle_block = _MidBlock(channels[-1], tcc, tc, cc, k)
+        self.middle_block = _MidBlock(channels[-1], tcc, tc, cc, k, use_self_attn=na > 0)  # :372
         self.total_ratio = 1
         for r in self.ratios:
             self.total_ratio *= r
@@ -141,11 +158,17 @@ class UNET1D(nn.Module):
             names += [f"{p}.{m}.{i}.{t}" for m in ("time_mlp", "cond_mlp") for i in (0, 2) for t in ("weight", "bias")]
             return names + ([f"{p}.to_out.weight", f"{p}.to_out.bias"] if skip else [])
 
+        def SA(p, layer):
+            if isinstance(layer.self_attn, nn.Identity):
+                return []
+            return [f"{p}.self_attn.{m}.{t}" for m in ("norm", "qkv_proj", "out_proj") for t in ("weight", "bias")]
+
         n = len(self.channels)
         names = [f"cond_emb_time.{i}.0.{t}" for i in range(n + 1) for t in ("weight", "bias")]
         for i in range(n):
-            names += CB(f"down_layers.{i}.conv", False) + [f"down_layers.{i}.pool.weight", f"down_layers.{i}.pool.bias"]
-        names += CB("middle_block.conv", False)
+            names += CB(f"down_layers.{i}.conv", False) + SA(f"down_layers.{i}", self.down_layers[i])
+            names += [f"down_layers.{i}.pool.weight", f"down_layers.{i}.pool.bias"]
+        names += CB("middle_block.conv", False) + SA("middle_block", self.middle_block)
         for j, layer in enumerate(self.up_layers):
             if isinstance(layer.up, nn.Identity):
                 names += [None, None]
@@ -153,7 +176,7 @@ class UNET1D(nn.Module):
                 names += [f"up_layers.{j}.up.1.weight", f"up_layers.{j}.up.1.bias"]
             else:
                 names += [f"up_layers.{j}.up.weight", f"up_layers.{j}.up.bias"]
-            names += CB(f"up_layers.{j}.conv", True)
+            names += CB(f"up_layers.{j}.conv", True) + SA(f"up_layers.{j}", layer)
         return names
 
     def _ensure(self, B, T):
@@ -176,6 +199,7 @@ class UNET1D(nn.Module):
         cfg.time_channels, cfg.time_cond_in_channels = self.time_channels, self.time_cond_in_channels
         cfg.time_cond_channels, cfg.cond_channels = self.time_cond_channels, self.cond_channels
         cfg.use_res_last = int(self.use_res_last)
+        cfg.n_attn_layers = self.n_attn_layers
         out = ctypes.c_void_p()
         dev = next(w for w in ws if w is not None).device
         with torch.cuda.device(dev):

@@ -394,8 +394,10 @@ int after_ecapa_forward(after_ecapa* h, const float* z, float* out, int B, int T
 /* ---------------------------------------------------------------- UNET1D denoiser
  * The Conv1d / GroupNorm / SiLU / FiLM alternative to DenoiserV2
  * (after/diffusion/networks/unet1d.py:254-429; no shipped gin config selects it).
- * Built for the default topology: time_cond_channels > 0, cond_channels > 0,
- * n_attn_layers = 0; GroupNorm(min(16, C/4), C) must be well defined for every block. */
+ * Built for time_cond_channels > 0, cond_channels > 0; GroupNorm(min(16, C/4), C) must be well defined for
+ * every block.  n_attn_layers > 0 (unet1d.py:339, 350, 372): SelfAttention1d (blocks.py:201-243) behind the conv block of
+ * down_layers i >= n - n_attn_layers (i >= 1; 4 heads), of up_layers j < n_attn_layers (j < n - 1; 4 heads) and of the
+ * middle block (in_c // 32 heads); head sizes 4 .. 64 (powers of two). */
 typedef struct after_unet1d_cfg {
     int in_size, out_size;   /* out_size <= 0: = in_size                                  */
     int n_blocks;            /* len(channels)                                             */
@@ -404,14 +406,17 @@ typedef struct after_unet1d_cfg {
     int kernel_size;         /* odd                                                       */
     int time_channels, time_cond_in_channels, time_cond_channels, cond_channels;
     int use_res_last;
+    int n_attn_layers;       /* 0 .. n_blocks                                             */
 } after_unet1d_cfg;
 /* weights (reference state_dict keys), CB(p) = p.conv1.{weight,bias} p.gn1.{weight,bias}
  * p.conv2.{weight,bias} p.gn2.{weight,bias} p.time_mlp.{0,2}.{weight,bias}
  * p.cond_mlp.{0,2}.{weight,bias} [p.to_out.{weight,bias} when the block takes a skip]:
  *   cond_emb_time.i.0.{weight,bias}, i = 0..n
- *   for i < n: CB(down_layers.i.conv) down_layers.i.pool.{weight,bias}
- *   CB(middle_block.conv)
- *   for j < n: up_layers.j.up[.1].{weight,bias} (NULL, NULL when `up` is Identity) CB(up_layers.j.conv) */
+ * SA(p) = p.self_attn.norm.{weight,bias} p.self_attn.qkv_proj.{weight,bias} p.self_attn.out_proj.{weight,bias},
+ * present only where the block has a self-attention layer:
+ *   for i < n: CB(down_layers.i.conv) [SA(down_layers.i)] down_layers.i.pool.{weight,bias}
+ *   CB(middle_block.conv) [SA(middle_block)]
+ *   for j < n: up_layers.j.up[.1].{weight,bias} (NULL, NULL when `up` is Identity) CB(up_layers.j.conv) [SA(up_layers.j)] */
 typedef struct after_unet1d after_unet1d;
 int after_unet1d_create(const after_unet1d_cfg* cfg, const float* const* weights, int n_weights,
                         int max_batch, int max_T, after_unet1d** out);

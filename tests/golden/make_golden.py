@@ -468,6 +468,7 @@ CASES = {
     "encoders_base": lambda: encoders_case("encoders_base", "base", 1, 256, 53),
     "unet_micro": lambda: unet_case("unet_micro", "unet_micro", 2, 64, 61),
     "unet_micro_flat": lambda: unet_case("unet_micro_flat", "unet_micro_flat", 3, 24, 62),
+    "unet_micro_attn": lambda: unet_case("unet_micro_attn", "unet_micro_attn", 2, 64, 63),
     "ckpt_nano": checkpoint_case,
 }
 

@@ -171,7 +171,7 @@ def test_encoders_match_reference(case):
     assert max_abs(got, fx.t("cond")) < 5e-5
 
 
-@pytest.mark.parametrize("case", ["unet_micro", "unet_micro_flat"])
+@pytest.mark.parametrize("case", ["unet_micro", "unet_micro_flat", "unet_micro_attn"])
 def test_unet1d_matches_reference(case):
     fx = Fixture(case)
     cfg = configs.unet_config(fx.meta["config"])

@@ -19,7 +19,7 @@ def build(cfg_name, sd, dev):
     return net.to(dev)
 
 
-@pytest.mark.parametrize("case", ["unet_micro", "unet_micro_flat"])
+@pytest.mark.parametrize("case", ["unet_micro", "unet_micro_flat", "unet_micro_attn"])
 def test_unet1d_golden(case, hip_device):
     fx = Fixture(case)
     net = build(fx.meta["config"], fx.state_dict(), hip_device)
@@ -30,7 +30,8 @@ def test_unet1d_golden(case, hip_device):
     assert max_abs(got, want) < 2e-4 * max(1.0, want.abs().max().item())
 
 
-@pytest.mark.parametrize("cfg_name,B,T", [("unet_micro", 1, 8), ("unet_micro", 3, 40), ("unet_micro_flat", 2, 6)])
+@pytest.mark.parametrize("cfg_name,B,T", [("unet_micro", 1, 8), ("unet_micro", 3, 40), ("unet_micro_flat", 2, 6),
+                                          ("unet_micro_attn", 2, 8), ("unet_micro_attn", 1, 200)])
 def test_unet1d_vs_oracle_shapes(cfg_name, B, T, hip_device):
     fx = Fixture(cfg_name)
     sd = fx.state_dict()
