@@ -45,3 +45,44 @@ def test_persistent_offline_sampler_matches_launch_path_and_oracle(T, steps, bas
     x2 = torch.randn(2, 64, T, generator=g).to(hip_device)
     net.cfg_sample(x2, torch.randn(2, 6, generator=g).to(hip_device), torch.randn(2, 12, T, generator=g).to(hip_device), 2, 2.0, 1.0, -4.0)
     assert not net.sample_persist()
+
+
+def test_midi_cfg_arrangement_on_the_persistent_sampler(hip_device):
+    """The midi denoiser (base width, piano-roll time conditioning, CFG_MIDI: rows (c, tc) / (c, -4) / (-4, -4), export_midi.py:329-358)
+    is eligible too: the persistent kernel reads the CFG maps of the call.  Against the launch path of the same handle."""
+    from after_amd import _lib
+    model, dcfg, _ = pipeline.build_models("midi", "baseAE", hip_device, seed=9)
+    net = model.net
+    g = torch.Generator().manual_seed(77)
+    x0 = torch.randn(1, net.n_channels, 256, generator=g).to(hip_device)
+    cond = torch.randn(1, net.cond_dim, generator=g).to(hip_device)
+    tc = torch.rand(1, net.tcond_dim, 256, generator=g).to(hip_device)
+    for mode in (_lib.CFG_MIDI, _lib.CFG_API):
+        net.set_sample_persist(False)
+        ref = net.cfg_sample(x0, cond, tc, 5, 1.5, 2.0, -4.0, cfg_mode=mode).cpu()
+        net.set_sample_persist(True)
+        got = net.cfg_sample(x0, cond, tc, 5, 1.5, 2.0, -4.0, cfg_mode=mode).cpu()
+        assert net.sample_persist(), mode
+        assert torch.isfinite(got).all() and max_abs(got, ref) < 5e-5, (mode, max_abs(got, ref))
+
+
+def test_geometries_the_kernel_does_not_take_run_by_launches(base, hip_device):
+    """Explicit refusals: another width (tiny: embed 256 -- the kernel's tile counts are the base width's), clip lengths other than
+    128 / 256 frames.  after_sample serves them by launches, silently (the persistent sampler is an acceleration, not a capability),
+    and the results are the launch path's, held to the oracle."""
+    tiny, tcfg, _ = pipeline.build_models("tiny", "baseAE", hip_device, seed=3)
+    g = torch.Generator().manual_seed(5)
+    x0, cond, tc = torch.randn(1, 64, 256, generator=g), torch.randn(1, 6, generator=g), torch.randn(1, 12, 256, generator=g)
+    tiny.net.set_sample_persist(True)
+    got = tiny.net.cfg_sample(x0.to(hip_device), cond.to(hip_device), tc.to(hip_device), 3, 2.0, 1.0, -4.0).cpu()
+    assert not tiny.net.sample_persist()
+    sd = {k: v.detach().cpu() for k, v in tiny.net.state_dict().items()}
+    want = oracle.sample(sd, tcfg["net"], x0, cond, tc, 3, 2.0, 1.0)
+    assert max_abs(got, want) < 1e-4, max_abs(got, want)
+    model, _ = base
+    model.net.set_sample_persist(True)
+    for T in (64, 192, 512):
+        xt = torch.randn(1, 64, T, generator=g).to(hip_device)
+        out = model.net.cfg_sample(xt, cond.to(hip_device), torch.randn(1, 12, T, generator=g).to(hip_device), 2, 2.0, 1.0, -4.0)
+        assert not model.net.sample_persist(), T
+        assert torch.isfinite(out).all()
