@@ -61,6 +61,33 @@ def test_denoiser_state_dict_matches_reference_layout(case):
     net.load_state_dict(fx.state_dict(), strict=True)
 
 
+@pytest.mark.parametrize("case", ["unet_micro", "unet_micro_flat", "unet_micro_attn"])
+def test_unet1d_state_dict_matches_reference_layout(case):
+    """UNET1D (with and without the self-attention layers of n_attn_layers > 0): the keys and shapes the REFERENCE module had when
+    the fixture was generated (meta["shapes"]) are exactly the container's."""
+    from after_amd.diffusion.networks.unet1d import UNET1D
+    fx = Fixture(case)
+    net = UNET1D(**configs.unet_config(fx.meta["config"]))
+    sd, ref = net.state_dict(), fx.meta["shapes"]
+    assert set(sd) == set(ref)
+    assert all(tuple(v.shape) == tuple(ref[k]) for k, v in sd.items())
+    net.load_state_dict(fx.state_dict(), strict=True)
+
+
+@pytest.mark.parametrize("case", ["ae_micro", "ae_micro_nopqmf"])
+def test_autoencoder_state_dict_matches_reference_layout(case):
+    """The codec with and without a filter bank (pqmf_bands = 1: the reference's DummyIdentity has no parameters, neither has ours):
+    every key of the reference module exists with its shape; the container adds nothing but the reference's own streaming buffers."""
+    from after_amd.autoencoder import AutoEncoder
+    fx = Fixture(case)
+    cfg = configs.autoencoder_config(fx.meta["config"])
+    cfg.pop("bottleneck", None)
+    sd, ref = AutoEncoder(**cfg).state_dict(), fx.meta["shapes"]
+    assert set(sd) <= set(ref), sorted(set(sd) - set(ref))[:5]
+    assert all(k.endswith(".pad") for k in set(ref) - set(sd)), sorted(set(ref) - set(sd))[:5]  # CachedGroupNorm's stream buffers
+    assert all(tuple(v.shape) == tuple(ref[k]) for k, v in sd.items())
+
+
 def test_product_path_refuses_cpu_tensors():
     net = DenoiserV2(**configs.diffusion_config("micro")["net"])
     model = RectifiedFlow(net=net, sr=44100)
