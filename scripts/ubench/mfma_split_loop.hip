@@ -27,20 +27,23 @@ __device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, u
     l.y = __builtin_bit_cast(unsigned, __builtin_convertvector(t1, bf2));
 }
 
-template <int SPLIT>
+// RB: row blocks a weight fragment serves (3: one row half per wave, the shipped kernel; 6: both halves in ONE wave per SIMD --
+// the "fat wave" layout: every fragment fetched and split once, 108 MFMAs per k-block behind one split)
+template <int SPLIT, int RB = 3>
 __global__ __launch_bounds__(512) void k(float* out, long long* cyc, float seed, int iters) {
     constexpr int WP[6] = {2, 0, 1, 1, 0, 0}, AP[6] = {0, 2, 1, 0, 1, 0};
-    f32x4 acc[9];
+    f32x4 acc[3 * RB];
 #pragma unroll
-    for (int p = 0; p < 9; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-    u32x4 ap[3][3], wp[3][3];
+    for (int p = 0; p < 3 * RB; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 ap[RB][3], wp[3][3];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) ap[i][p] = u32x4{threadIdx.x + i, 0x3f803f80u, 0x3f803f80u + p, 0x3f803f80u};
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            ap[i][p] = u32x4{threadIdx.x + i, 0x3f803f80u, 0x3f803f80u + p, 0x3f803f80u};
-            wp[i][p] = u32x4{0x3f803f80u, threadIdx.x + p, 0x3f803f80u, 0x3f803f80u + i};
-        }
+        for (int p = 0; p < 3; ++p) wp[i][p] = u32x4{0x3f803f80u, threadIdx.x + p, 0x3f803f80u, 0x3f803f80u + i};
     f32x4 wr[3][2];
 #pragma unroll
     for (int j = 0; j < 3; ++j) wr[j][0] = wr[j][1] = f32x4{seed + j, seed * 2.f, seed * 3.f, (float)threadIdx.x};
@@ -65,14 +68,14 @@ __global__ __launch_bounds__(512) void k(float* out, long long* cyc, float seed,
 #pragma unroll
             for (int j = 0; j < 3; ++j)
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
-                    acc[j * 3 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wp[j][WP[p]]),
-                                                                             __builtin_bit_cast(bf16x8, ap[i][AP[p]]), acc[j * 3 + i], 0, 0, 0);
+                for (int i = 0; i < RB; ++i)
+                    acc[j * RB + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wp[j][WP[p]]),
+                                                                              __builtin_bit_cast(bf16x8, ap[i][AP[p]]), acc[j * RB + i], 0, 0, 0);
     }
     const long long t1 = __builtin_readcyclecounter();
     f32x4 s = acc[0];
 #pragma unroll
-    for (int p = 1; p < 9; ++p) s += acc[p];
+    for (int p = 1; p < 3 * RB; ++p) s += acc[p];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
@@ -96,5 +99,13 @@ int main() {
             printf("{\"ubench\": \"mfma_split_loop\", \"weight_split\": %d, \"waves_per_simd\": %d, \"cycles_per_mfma_per_wave\": %.1f, "
                    "\"cycles_per_mfma_per_simd\": %.1f}\n", split, wps, (double)c / (iters * 54), (double)c / (iters * 54 * wps));
         }
+    for (int rep = 0; rep < 2; ++rep) {  // the fat wave: one wave per SIMD, six row blocks behind one split
+        hipLaunchKernelGGL((k<1, 6>), dim3(256), dim3(256), 0, 0, out, cyc, 1.f, iters);
+        (void)hipDeviceSynchronize();
+    }
+    long long c;
+    (void)hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+    printf("{\"ubench\": \"mfma_split_loop\", \"weight_split\": 1, \"waves_per_simd\": 1, \"row_blocks\": 6, \"cycles_per_mfma_per_simd\": %.1f}\n",
+           (double)c / (iters * 108));
     return 0;
 }
