@@ -387,6 +387,12 @@ struct after_ae {
     float *enc_state = nullptr, *dec_state = nullptr;  // [slot][max_batch][cmax][HALO]
     float *pq_fstate = nullptr, *pq_istate = nullptr;  // [B][Kf-1] audio, [B][M][Ki-1] bands
     int state_slot = 0;
+    // every conv's context exists twice: a pass reads half `flip` and writes half `flip ^ 1` (act_pad_tm writes the new context
+    // itself: no second launch per conv), and a pass that completed flips.  pass_*: the area of the pass being issued.
+    int enc_slots = 0, dec_slots = 0, nc_slots = 0;
+    int enc_flip = 0, dec_flip = 0, nc_flip = 0;
+    int pass_slots = 0;
+    int* pass_flip = nullptr;
     size_t slot_elems = 0;
     // streaming NON-causal encoder (export_autoencoder.py:305-312): cached centred-padding convs with
     // delay compensation + CachedGroupNorm(stream=True); the PQMF and the decoder stay offline
@@ -522,7 +528,12 @@ int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const 
             int stat_T = 0) {
     const int cin = d.in.Cin, cout = d.in.Cout;
     float* state = nullptr;
-    if (h->pass_stream && state_base) state = state_base + (size_t)(h->state_slot++) * h->slot_elems;
+    float* state_out = nullptr;
+    if (h->pass_stream && state_base) {
+        const int f = *h->pass_flip, slot = h->state_slot++;
+        state = state_base + ((size_t)f * h->pass_slots + slot) * h->slot_elems;
+        state_out = state_base + ((size_t)(f ^ 1) * h->pass_slots + slot) * h->slot_elems;
+    }
     // x, res, y time-major [B][T][C] (x_cm / y_cm: the reference's [B][C][T] at the API edges)
     AFTER_REQUIRE((size_t)B * conv_tm_cp(cin) * conv_tm_rows(Tin) <= h->xp_elems, AFTER_E_CAPACITY,
                   "autoencoder: activation scratch too small");
@@ -541,6 +552,7 @@ int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const 
         p.act_a = alpha;
         p.act_b = invb;
         p.state = state;
+        p.state_out = state_out;
         p.act = act;
         p.B = B;
         p.C = cin;
@@ -1086,6 +1098,7 @@ extern "C" int after_ae_reset_state(after_ae* h, void* stream) {
     AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
     AFTER_REQUIRE(h->sa.base || h->sn.base || h->sg.base, AFTER_E_INVALID, "autoencoder: streaming was never enabled");
     h->in_pass = false;
+    h->enc_flip = h->dec_flip = h->nc_flip = 0;
     if (h->sa.base) AFTER_HIP_CHECK(hipMemsetAsync(h->sa.base, 0, h->sa.off, (hipStream_t)stream));
     if (h->sn.base) {
         AFTER_HIP_CHECK(hipMemsetAsync(h->sn.base, 0, h->sn.off, (hipStream_t)stream));
@@ -1163,9 +1176,10 @@ extern "C" int after_ae_enable_encoder_streaming(after_ae* h, int enable, int gn
     // ---- state: activated conv contexts, delay lines, GroupNorm rings
     const int nd = c.n_dilations;
     const int enc_slots = 1 + n * nd + n + 1;
+    h->nc_slots = enc_slots;
     h->slot_elems = (size_t)h->max_batch * conv_tm_cp(h->cmax) * conv_tm_halo();
     auto pad64 = [](size_t v) { return (v + 63) & ~(size_t)63; };
-    fl = pad64(enc_slots * h->slot_elems);
+    fl = pad64(2 * enc_slots * h->slot_elems);
     for_each_enc_resblock(h, [&](ResBlockW& rb, int stage) {
         fl += 2 * pad64((size_t)h->max_batch * rb.delay * rb.cb0.cin);
         if (h->norm) {
@@ -1177,7 +1191,7 @@ extern "C" int after_ae_enable_encoder_streaming(after_ae* h, int enable, int gn
         }
     });
     AFTER_TRY(h->sn.init(fl * sizeof(float) + (64 << 10)));
-    h->nc_state = h->sn.take<float>(enc_slots * h->slot_elems);
+    h->nc_state = h->sn.take<float>(2 * enc_slots * h->slot_elems);
     bool ok = h->nc_state != nullptr;
     for_each_enc_resblock(h, [&](ResBlockW& rb, int) {
         for (int q = 0; q < 2; ++q) {
@@ -1266,9 +1280,11 @@ extern "C" int after_ae_enable_streaming(after_ae* h, int enable) {
         h->slot_elems = (size_t)h->max_batch * conv_tm_cp(h->cmax) * conv_tm_halo();
         const size_t fs = (size_t)h->max_batch * (h->pq_fk > 1 ? h->pq_fk - 1 : 1);  // (one-band identity bank: no history, one unused word)
         const size_t is = (size_t)h->max_batch * h->M * (h->pq_ik > 1 ? h->pq_ik - 1 : 1);
-        AFTER_TRY(h->sa.init(((enc_slots + dec_slots) * h->slot_elems + fs + is) * sizeof(float) + 8192));
-        h->enc_state = h->sa.take<float>(enc_slots * h->slot_elems);
-        h->dec_state = h->sa.take<float>(dec_slots * h->slot_elems);
+        h->enc_slots = enc_slots;
+        h->dec_slots = dec_slots;
+        AFTER_TRY(h->sa.init((2 * (size_t)(enc_slots + dec_slots) * h->slot_elems + fs + is) * sizeof(float) + 8192));
+        h->enc_state = h->sa.take<float>(2 * (size_t)enc_slots * h->slot_elems);
+        h->dec_state = h->sa.take<float>(2 * (size_t)dec_slots * h->slot_elems);
         h->pq_fstate = h->sa.take<float>(fs);
         h->pq_istate = h->sa.take<float>(is);
         AFTER_REQUIRE(h->pq_istate, AFTER_E_NOMEM, "autoencoder: streaming state allocation failed");
@@ -1306,6 +1322,8 @@ extern "C" int after_ae_encode(after_ae* h, const float* x, float* z, int B, int
     h->pass_cached = h->pass_gnwin = h->enc_cached;
     h->pass_stream = h->streaming || h->enc_cached;
     float* sb = h->streaming ? h->enc_state : (h->enc_cached ? h->nc_state : nullptr);
+    h->pass_slots = h->streaming ? h->enc_slots : h->nc_slots;
+    h->pass_flip = h->streaming ? &h->enc_flip : &h->nc_flip;
     double* st = nullptr;
     if (h->norm && !h->pass_gnwin) {  // the first GroupNorm sees the PQMF output: its producer is not a conv
         st = next_stats(h, B);
@@ -1337,6 +1355,7 @@ extern "C" int after_ae_encode(after_ae* h, const float* x, float* z, int B, int
     AFTER_TRY(run_dma(h, s, h->enc_tail.d, cur, nullptr, nullptr, nullptr, h->enc_tail_alpha,
                       h->enc_tail_invb, ACT_SNAKE, h->enc_tail.bias, nullptr, z, B, T, T, T, false,
                       nullptr, sb, 0, 1));  // z leaves in the reference's [B][Z][T] layout
+    if (sb) *h->pass_flip ^= 1;  // the pass is enqueued in full: the next one reads what this one wrote
     h->in_pass = false;
     return AFTER_OK;
 }
@@ -1377,6 +1396,8 @@ static int decode_impl(after_ae* h, const float* z, float* x, float* mb, int B, 
     h->pass_gnwin = h->norm && h->dec_gn_frames > 0;
     h->pass_stream = h->streaming;
     float* sb = h->streaming ? h->dec_state : nullptr;
+    h->pass_slots = h->dec_slots;
+    h->pass_flip = &h->dec_flip;
     double* st = nullptr;
     AFTER_TRY(run_dma(h, s, h->dec_head.d, z, nullptr, nullptr, nullptr, nullptr, nullptr, ACT_NONE,
                       h->dec_head.bias, nullptr, cur, B, T, T, T, false, nullptr, sb, 1, 0));  // z: [B][Z][T]
@@ -1404,6 +1425,7 @@ static int decode_impl(after_ae* h, const float* z, float* x, float* mb, int B, 
     const int och = c.use_loudness ? 2 * h->M : h->M;
     AFTER_TRY(write_multiband(h, s, t2, mb, B, T, c.use_loudness, och));
     AFTER_TRY(pqmf_inverse(h, s, t2, x, B, T, c.use_loudness, och, h->streaming ? h->pq_istate : nullptr, true));
+    if (sb) h->dec_flip ^= 1;
     h->in_pass = false;
     return AFTER_OK;
 }

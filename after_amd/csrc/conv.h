@@ -129,6 +129,8 @@ struct ActPadTm {
     const float* act_a;
     const float* act_b;
     float* state;         // streaming: [B][halo][Cp] left context, used and then replaced; or nullptr
+    float* state_out;     // with `state`: where the NEW context goes (a second buffer: the caller ping-pongs) -- the kernel
+                          // writes it beside the haloed tensor; nullptr: `state` is replaced in place by a second launch
     const float* scale_b; // per-(clip, channel) affine [B][C] (takes the place of gamma / beta), or nullptr
     const float* shift_b;
     int act, B, C, T, G, x_cm, ldx, pad_reflect, sub_stride;

@@ -86,6 +86,8 @@ struct ActTmArgs {
     const float* act_a;
     const float* act_b;
     const float* state;   // streaming: [B][HALO][Cp] activated rows preceding this chunk, or nullptr
+    float* state_out;     // streaming: the context of the NEXT chunk = rows [T, T + HALO) of the padded tensor (another buffer than
+                          // `state`: other workgroups still read that one), or nullptr
     const float* scale_b; // optional per-(b, channel) affine [B][C] applied instead of gamma / beta
     const float* shift_b;
     const float* x2;      // optional second time-major input added to x first (Res2Net: x_i + y_{i-1})
@@ -227,6 +229,8 @@ __global__ __launch_bounds__(256) void act_pad_tm_kernel(ActTmArgs a) {
                     o[u][k] = c0 + k < a.C ? act_apply(o[u][k] * sc[k] + sh[k], a.act, pa[k], pb[k]) : 0.f;
             }
             *reinterpret_cast<f32x4*>(yb + (size_t)p * a.Cp + c0) = o[u];
+            if (a.state_out && p >= a.T && p < a.T + HALO)
+                *reinterpret_cast<f32x4*>(a.state_out + ((size_t)b * HALO + (p - a.T)) * a.Cp + c0) = o[u];
         }
     }
 }
@@ -882,6 +886,7 @@ int launch_act_pad_tm(const ActPadTm& p, hipStream_t s) {
     a.act_a = p.act_a;
     a.act_b = p.act_b;
     a.state = p.state;
+    a.state_out = p.state ? p.state_out : nullptr;
     a.scale_b = p.scale_b;
     a.shift_b = p.shift_b;
     a.act = snake_variant(p.act);
@@ -918,7 +923,7 @@ int launch_act_pad_tm(const ActPadTm& p, hipStream_t s) {
     if (a.xcd_rows) nb = (nb + 7) & ~7;
     hipLaunchKernelGGL(act_pad_tm_kernel, dim3(nb, p.B), dim3(256), 0, s, a);
     AFTER_HIP_CHECK(hipGetLastError());
-    if (p.state) {
+    if (p.state && !p.state_out) {
         const int total4 = p.B * HALO * a.Cp / 4;
         hipLaunchKernelGGL(state_update_tm_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, s, p.y, p.state, a.Cp,
                            p.T, a.Tp, total4);

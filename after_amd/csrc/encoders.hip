@@ -312,6 +312,7 @@ struct after_encoder1d {
     bool streaming = false;
     float* state = nullptr;
     size_t slot_elems = 0;
+    int n_slots = 0, flip = 0;
     int slot = 0;
 };
 
@@ -365,7 +366,11 @@ int enc_act(after_encoder1d* h, hipStream_t s, const float* x, int x_cm, const A
     p.T = T;
     p.G = 1;
     p.x_cm = x_cm;
-    if (h->streaming && temporal) p.state = h->state + (size_t)(h->slot++) * h->slot_elems;
+    if (h->streaming && temporal) {  // (the context exists twice: read half `flip`, write the other -- one launch per conv)
+        const int slot = h->slot++;
+        p.state = h->state + ((size_t)h->flip * h->n_slots + slot) * h->slot_elems;
+        p.state_out = h->state + ((size_t)(h->flip ^ 1) * h->n_slots + slot) * h->slot_elems;
+    }
     return launch_act_pad_tm(p, s);
 }
 
@@ -498,8 +503,9 @@ extern "C" int after_encoder1d_enable_streaming(after_encoder1d* h, int enable) 
     if (!h->sa.base) {
         const int slots = 3 * h->cfg.n_blocks + 2;
         h->slot_elems = (size_t)h->max_batch * conv_tm_cp(h->cmax) * conv_tm_halo();
-        AFTER_TRY(h->sa.init(slots * h->slot_elems * sizeof(float) + 4096));
-        h->state = h->sa.take<float>(slots * h->slot_elems);
+        h->n_slots = slots;
+        AFTER_TRY(h->sa.init(2 * (size_t)slots * h->slot_elems * sizeof(float) + 4096));
+        h->state = h->sa.take<float>(2 * (size_t)slots * h->slot_elems);
         AFTER_REQUIRE(h->state, AFTER_E_NOMEM, "encoder1d: streaming state allocation failed");
         AFTER_HIP_CHECK(hipMemset(h->sa.base, 0, h->sa.off));
     }
@@ -509,6 +515,7 @@ extern "C" int after_encoder1d_enable_streaming(after_encoder1d* h, int enable) 
 
 extern "C" int after_encoder1d_reset_state(after_encoder1d* h, void* stream) {
     AFTER_REQUIRE(h && h->sa.base, AFTER_E_INVALID, "encoder1d: streaming was never enabled");
+    h->flip = 0;
     AFTER_HIP_CHECK(hipMemsetAsync(h->sa.base, 0, h->sa.off, (hipStream_t)stream));
     return AFTER_OK;
 }
@@ -590,6 +597,7 @@ extern "C" int after_encoder1d_forward(after_encoder1d* h, const float* z, float
         hipLaunchKernelGGL(tanh_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, s, out, tot);
         AFTER_HIP_CHECK(hipGetLastError());
     }
+    if (h->streaming) h->flip ^= 1;  // the chunk is enqueued in full: the next one reads the contexts this one wrote
     return AFTER_OK;
 }
 
