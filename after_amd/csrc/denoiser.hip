@@ -1105,9 +1105,12 @@ __device__ __forceinline__ void step_attention(const StepAttn& a, const StepKV& 
     };
     auto x_load = [&](int qb) { return as4(ld_l2(xr, t16_off(lr0 + i0 + min(qb + grp, nq - 1), hw * 64 + d4, KBt))); };
     float4 q4n = z4, x4n = z4;
+    // ROPED (= LATE, the offline segment sampler): q and k arrive ROTATED -- its qkv phase applies RoPE once per row in the
+    // epilogue (seg kernel), not once per (query, key) here: two LDS reads and eight FMAs per key and lane less in the key loop
+    constexpr bool ROPED = LATE;
     if constexpr (LATE) {  // every request of the item's first pass, K / V first, in front of the loops (one round trip)
         kv_dma(0);
-        rope_loads();
+        if constexpr (!ROPED) rope_loads();
         if (hw < nq) step_ln_ops(late, lab, lw3, lb3, lane);
         q4n = q_load(0), x4n = x_load(0);
     }
@@ -1128,7 +1131,7 @@ __device__ __forceinline__ void step_attention(const StepAttn& a, const StepKV& 
             if (qb > 0 || !first) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous block consumed
             if (!LATE || qb > 0 || !first) kv_dma(kb);
             if (LATE && first && qb + 4 < nq) q4n = q_load(qb + 4), x4n = x_load(qb + 4);  // (the next pass's, a pass early)
-            if (qb == 0 && first) {  // K / V requests are in flight: now land the RoPE slice
+            if (!ROPED && qb == 0 && first) {  // K / V requests are in flight: now land the RoPE slice
                 if (lane < nk * 4) {
                     *reinterpret_cast<float4*>(rc + lane * 4) = tc0;
                     *reinterpret_cast<float4*>(rs + lane * 4) = ts0;
@@ -1144,13 +1147,14 @@ __device__ __forceinline__ void step_attention(const StepAttn& a, const StepKV& 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the K / V block (and q, x) have landed
             if (tr && tid == 0 && first && qb == 0) tr[81] = wall_clock64();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (first) q4 = rope4(q4, rc, rs, ja - lo_c, d4);
+            if (!ROPED && first) q4 = rope4(q4, rc, rs, ja - lo_c, d4);
             float sc[NKMAX];
             float mx = mrun;
 #pragma unroll
             for (int j = 0; j < NKMAX; ++j) {
                 const int pos = lo_c + min(kb + j, nk - 1);
-                const float4 kr = rope4(*reinterpret_cast<const float4*>(kvs + j * 64 + d4), rc, rs, pos - lo_c, d4);
+                const float4 kraw = *reinterpret_cast<const float4*>(kvs + j * 64 + d4);
+                const float4 kr = ROPED ? kraw : rope4(kraw, rc, rs, pos - lo_c, d4);
                 float dot = q4.x * kr.x + q4.y * kr.y + q4.z * kr.z + q4.w * kr.w;
                 dot = group16_sum(dot);
                 sc[j] = (kb + j < nk && pos >= lo_row) ? dot * 0.125f : -INFINITY;
@@ -1855,12 +1859,34 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 // ---- qkv (bf16 x 3 split MFMAs), three row blocks at a time; the rows are written through to memory (the next
                 //      XCD's attention reads the last W - 1 frames)
                 f32x4 acc[9];
+                // RoPE (rotary_embedding.py:132-173: interleaved pairs, the first 32 dims of every head) on the q and k tiles this
+                // wave finishes -- column tiles rank (q) and rank + 32 (k) with rank % 4 < 2 -- at the rows' absolute frames: the cos /
+                // sin pairs are requested behind the last operand requests of the MFMA loop and land long before the epilogue
+                float2 rcs[3][2];
+                const bool roped = (rank & 3) < 2;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) rcs[q][0] = make_float2(1.f, 1.f), rcs[q][1] = make_float2(0.f, 0.f);
+                auto rope_req = [&] {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const int p = w + 8 * q, hh = p / 9, pp = p - 9 * hh;
+                        const int lm = min(16 * (3 * hh + pp % 3) + (lane & 15), Mg - 1), tl = lm % Tseg;
+                        if (roped && p < 9 * NH && pp / 3 < 2) {
+                            const int o = (f0 + tl) * 16 + 8 * (rank & 3) + 2 * (lane >> 4);
+                            rcs[q][0] = *reinterpret_cast<const float2*>(a.rope_cos + o);
+                            rcs[q][1] = *reinterpret_cast<const float2*>(a.rope_sin + o);
+                        }
+                    }
+                };
                 if (trace && tid == 0) trace[64] = wall_clock64();
                 __builtin_amdgcn_sched_barrier(0);
                 seg_load_a<3, 3>(sbq, 0, hb3_r, E / 32, 3 * rh, KQ * ks, lane);
                 seg_load_w<3, 3>(sbq, 0, Wq, KBE, rank, 32, KQ * ks, lane);
                 seg_run<3, 3, KQ, SEG_DIAG>(acc, sbq, hb3_r, E / 32, 3 * rh, Wq, KBE, rank, 32, KQ * ks, lane,
-                                            [&] { if (rank < nitems) attn_prefetch(l, rank); });
+                                            [&] {
+                                                if (rank < nitems) attn_prefetch(l, rank);
+                                                rope_req();
+                                            });
                 __builtin_amdgcn_sched_barrier(0);
                 if (trace) {  // (every wave drains its MFMAs first: the stamp is the end of wave 0's arithmetic)
                     asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[8]));
@@ -1879,6 +1905,12 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 for (int q = 0; q < 3; ++q) {
                     const int p = w + 8 * q, hh = p / 9, pp = p - 9 * hh;
                     os[q] = p < 9 * NH ? seg_sum<KS>(red + (size_t)hh * KS * 9 * 256, 9, pp, lane) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {  // (unconditional: tiles without RoPE carry cos = 1, sin = 0 -- no branch between the sums and the stores)
+                    const float2 c = rcs[q][0], sn = rcs[q][1];
+                    const f32x4 x = os[q];
+                    os[q] = f32x4{x[0] * c.x - x[1] * sn.x, x[1] * c.x + x[0] * sn.x, x[2] * c.y - x[3] * sn.y, x[3] * c.y + x[2] * sn.y};
                 }
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
