@@ -308,6 +308,11 @@ struct AttnArgs {
     int dbg;                // AFTER_ATTN_DBG bitmask (diagnostics): 1 no rope, 2 no reduce, 4 no LN tail, 8 no KV loads
 };
 
+// exp of a non-positive argument (softmax against the running maximum) on the hardware exponential: v_exp_f32 of x log2 e --
+// relative error <= ~2e-6 for the |x| <= 30 that matter, -inf -> 0 -- instead of libm's expf (13 calls per lane and key
+// block, in the dependent chain of every attention item)
+__device__ __forceinline__ float attn_exp(float v) { return __builtin_amdgcn_exp2f(v * 1.44269504088896341f); }
+
 __device__ __forceinline__ float group16_sum(float v) {
     // all-reduce over the 16 lanes of a query group with DPP row operations (VALU, no LDS round
     // trip): quad xor 1, quad xor 2, then the mirrored half / row partner -- once the quads are
@@ -502,7 +507,7 @@ __device__ __forceinline__ void attn_block_body(const AttnArgs& a, int bx, int b
                 sc[j] = (kb + j < nk && pos >= lo_row) ? dot * 0.125f : -INFINITY;
                 mx = fmaxf(mx, sc[j]);
             }
-            const float resc = expf(mrun - mx);  // 0 on the first block (mrun = -inf)
+            const float resc = attn_exp(mrun - mx);  // 0 on the first block (mrun = -inf)
             sum *= resc;
             o.x *= resc;
             o.y *= resc;
@@ -511,7 +516,7 @@ __device__ __forceinline__ void attn_block_body(const AttnArgs& a, int bx, int b
             mrun = mx;
 #pragma unroll
             for (int j = 0; j < NKMAX; ++j) {
-                const float p = expf(sc[j] - mx);  // exp(-inf) = 0 for masked / padded slots
+                const float p = attn_exp(sc[j] - mx);  // exp(-inf) = 0 for masked / padded slots
                 sum += p;
                 float4 vj;
                 if constexpr (PRELOAD) vj = v4[j];
@@ -1108,10 +1113,7 @@ __device__ __forceinline__ void step_attention(const StepAttn& a, const StepKV& 
     // ROPED (= LATE, the offline segment sampler): q and k arrive ROTATED -- its qkv phase applies RoPE once per row in the
     // epilogue (seg kernel), not once per (query, key) here: two LDS reads and eight FMAs per key and lane less in the key loop
     constexpr bool ROPED = LATE;
-    // exp of a non-positive argument (softmax against the running maximum): LATE on the hardware exponential (v_exp_f32 of
-    // x log2 e: relative error <= ~2e-6 for the |x| <= 30 that matter, -inf -> 0) instead of libm's expf (13 calls per lane and
-    // key block in the item's dependent chain)
-    auto ex = [](float v) { return LATE ? __builtin_amdgcn_exp2f(v * 1.44269504088896341f) : expf(v); };
+    auto ex = [](float v) { return attn_exp(v); };
     if constexpr (LATE) {  // every request of the item's first pass, K / V first, in front of the loops (one round trip)
         kv_dma(0);
         if constexpr (!ROPED) rope_loads();
