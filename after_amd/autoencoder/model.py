@@ -172,11 +172,27 @@ def _resolve_bottleneck(b):
     raise NotImplementedError(f"bottleneck {name!r}: SimpleNetsStream.py defines Relu / Tanh / VAE bottlenecks")
 
 
-def _check_activation(a):
-    name = None if a is None else (a if isinstance(a, str) else getattr(a, "__name__", type(a).__name__))
-    if name is not None and name.split(".")[-1] not in ("Snake", "SnakeBeta"):
-        raise NotImplementedError(f"activation {name!r}: after_amd builds SnakeBeta only "
-                                  "(SimpleNetsStream.py:15, core.py:217-260)")
+def _resolve_activation(a):
+    """The codec's `activation` class (SimpleNetsStream.py:161,169: built as `activation(dim=channels)`) -> "beta" for
+    SnakeBeta (core.py:227-268; imported AS `Snake` by SimpleNetsStream.py:15, the default everywhere) or "alpha" for
+    the one-parameter core.Snake (core.py:201-209: x + sin^2(alpha x) / (alpha + 1e-9), alpha of shape [dim, 1]).
+    A bare "Snake" means what it means inside SimpleNetsStream -- SnakeBeta; the one-parameter class is named by its
+    module ("core.Snake", "after.autoencoder.core.Snake") or passed as the class itself."""
+    if a is None:
+        return "beta"
+    if isinstance(a, str):
+        parts = a.lstrip("@").split(".")
+        name, mod = parts[-1], parts[:-1]
+    else:
+        name = getattr(a, "__name__", type(a).__name__)
+        mod = str(getattr(a, "__module__", "")).split(".")
+    if name == "SnakeBeta" or (name == "Snake" and (not mod or mod[-1] != "core")):
+        return "beta"
+    if name == "Snake":
+        return "alpha"
+    raise NotImplementedError(f"activation {name!r}: after_amd builds the reference's two snake activations "
+                              "(core.py:201-209 Snake, :227-268 SnakeBeta); no other class in the reference takes "
+                              "the `dim=` argument ConvBlock1d passes")
 
 
 class AutoEncoder(nn.Module):
@@ -212,7 +228,7 @@ class AutoEncoder(nn.Module):
             raise NotImplementedError("use_noise=True (NoiseGenerator) is not built (baseAE.gin: False)")
         if resnet_groups != 8:
             raise NotImplementedError("resnet_groups must be 8 (every shipped config)")
-        _check_activation(activation)
+        self.snake = _resolve_activation(activation)
         self.bottleneck = _resolve_bottleneck(bottleneck)
         self.cfg = dict(in_channels=in_channels, channels=channels, z_channels=z_channels,
                         multipliers=list(multipliers), factors=list(factors),
@@ -233,13 +249,18 @@ class AutoEncoder(nn.Module):
                                 kernel_size, self.encoder_out_channels, use_norm)
         self.decoder = _Decoder(in_channels, channels, self.dec_multipliers, list(factors)[::-1], nd,
                                 kernel_size, z_channels, use_norm, use_loudness)
+        if self.snake == "alpha":  # core.Snake: one parameter of shape [dim, 1] where SnakeBeta has two of [dim]
+            for m in self.modules():
+                if isinstance(m, _Snake):
+                    del m.beta
+                    m.alpha = nn.Parameter(torch.ones(m.alpha.shape[0], 1))
         self.requires_grad_(False)
         self._handle = None
         self._cap = (0, 0)
 
     def cfg_kwargs(self):
         """Constructor arguments of an identical codec (streaming twin, after_amd.streaming)."""
-        return dict(self.cfg, bottleneck=self.bottleneck)
+        return dict(self.cfg, bottleneck=self.bottleneck, activation="core.Snake" if self.snake == "alpha" else None)
 
     # ------------------------------------------------------------ handle management
     def _apply(self, fn, *a, **k):
@@ -271,15 +292,18 @@ class AutoEncoder(nn.Module):
         c = self.cfg
         nd, n = len(c["dilations"]), len(c["factors"])
 
+        # the C side takes (alpha, beta) per activation and computes 1 / (beta + 1e-9): core.Snake is beta = alpha
+        bk = "beta" if self.snake == "beta" else "alpha"
+
         def CB(p):
-            return [p + "net.0.gn.weight", p + "net.0.gn.bias", p + "net.1.alpha", p + "net.1.beta",
+            return [p + "net.0.gn.weight", p + "net.0.gn.bias", p + "net.1.alpha", p + "net.1." + bk,
                     p + "net.2.weight_g", p + "net.2.weight_v", p + "net.2.bias"]
 
         def WN(p):
             return [p + "weight_g", p + "weight_v", p + "bias"]
 
         def SN(p):
-            return [p + "alpha", p + "beta"]
+            return [p + "alpha", p + bk]
 
         names = ["pqmf.forward_conv.weight", "pqmf.inverse_conv.weight"]  # (identity bank: replaced by the unit tap in _ensure)
         e = "encoder.net."

@@ -1327,7 +1327,7 @@ extern "C" int after_ae_encode(after_ae* h, const float* x, float* z, int B, int
     double* st = nullptr;
     if (h->norm && !h->pass_gnwin) {  // the first GroupNorm sees the PQMF output: its producer is not a conv
         st = next_stats(h, B);
-        AFTER_TRY(launch_stats_accum_tm(b0, st, B, h->M, T, h->M < 8 ? h->M : 8, s));
+        AFTER_TRY(launch_stats_accum_tm(b0, st, B, h->M, T, h->M < 8 ? h->M : 8, s, 0, h->max_batch * 8 * kStatWords));
     }
     AFTER_TRY(run_resblock2(h, s, h->enc_stem, b0, b1, b2, B, T, &st, sb));
     float *cur = b2, *t1 = b0, *t2 = b1;

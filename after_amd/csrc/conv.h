@@ -146,7 +146,8 @@ void conv_tm_plan(const ConvDmaPlanIn& in, ConvTmPlan* p);
 int conv_tm_repack(const float* packed, float* out, const ConvDmaPlanIn& in, const ConvTmPlan& p, hipStream_t s);
 int launch_conv_tm(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan& p, hipStream_t s);
 int launch_act_pad_tm(const ActPadTm& p, hipStream_t s);
-int launch_stats_accum_tm(const float* x, double* stats, int B, int C, int T, int G, hipStream_t s, int ld = 0);
+// sub_stride > 0: stats is a [conv_tm_stat_sub()][sub_stride] accumulator (ConvTmRun) and the blocks spread over its sub-slots
+int launch_stats_accum_tm(const float* x, double* stats, int B, int C, int T, int G, hipStream_t s, int ld = 0, int sub_stride = 0);
 // small layout helpers on time-major tensors
 int launch_copy_cols_tm(const float* src, int ld_src, float* dst, int ld_dst, int C, size_t rows, hipStream_t s);
 int launch_cm_to_tm(const float* x, float* y, int B, int C, int T, int ld, hipStream_t s);

@@ -171,14 +171,26 @@ __global__ __launch_bounds__(256) void act_pad_tm_kernel(ActTmArgs a) {
         if (a.act_a) pa[k] = a.act_a[c];
         if (a.act_b) pb[k] = a.act_b[c];
     }
-    // GroupNorm statistics -> (mean, rstd) per group: one lane per group adds the sub-slots (fixed
-    // order) and does the fp64 arithmetic once per block
+    // GroupNorm statistics -> (mean, rstd) per group.  The words of the (sub-slot, group) pairs -- 64 contiguous bytes each --
+    // are fetched ONCE per block, 16 bytes per thread, into LDS; one lane per group then adds the sub-slots (integers:
+    // exact) and does the fp64 arithmetic.  (Round 4's first form had every group lane issue its 64 eight-byte loads
+    // itself: 512 line requests per block on the same few lines of the same L2 channels -- with several hundred blocks
+    // per launch those channels were the bottleneck: +3-6 us per 12-MB launch, profiles/r4_decode_trace_b1.jsonl.)
     if (a.stats) {
+        __shared__ __attribute__((aligned(16))) long long swl[16 * kStatSub * kStatWords];
+        static_assert(kStatWords % 2 == 0, "16-byte pieces");
+        constexpr int PPG = kStatWords / 2;  // 16-byte pieces per (sub-slot, group)
+        const long long* sbase = reinterpret_cast<const long long*>(a.stats) + (size_t)b * a.G * kStatWords;
+        for (int i = threadIdx.x; i < a.G * kStatSub * PPG; i += 256) {
+            const int piece = i % PPG, u = (i / PPG) % kStatSub, gI = i / (PPG * kStatSub);
+            const longlong2 w2 = *reinterpret_cast<const longlong2*>(sbase + (size_t)u * a.sub_stride + gI * kStatWords + 2 * piece);
+            *reinterpret_cast<longlong2*>(&swl[(gI * kStatSub + u) * kStatWords + 2 * piece]) = w2;
+        }
+        __syncthreads();
         if (threadIdx.x < a.G) {
             const int gI = threadIdx.x;
             const double n = (double)(a.C / a.G) * a.stat_T;
             // the sub-slots' words add as integers (exact), then each quantity folds into one fp64 (conv.h: stat_bins)
-            const long long* sw = reinterpret_cast<const long long*>(a.stats) + ((size_t)b * a.G + gI) * kStatWords;
             long long ws[kStatBins], wq[kStatBins];
 #pragma unroll
             for (int k = 0; k < kStatBins; ++k) ws[k] = wq[k] = 0;
@@ -186,8 +198,8 @@ __global__ __launch_bounds__(256) void act_pad_tm_kernel(ActTmArgs a) {
             for (int u = 0; u < kStatSub; ++u)
 #pragma unroll
                 for (int k = 0; k < kStatBins; ++k) {
-                    ws[k] += sw[(size_t)u * a.sub_stride + k];
-                    wq[k] += sw[(size_t)u * a.sub_stride + kStatBins + k];
+                    ws[k] += swl[(gI * kStatSub + u) * kStatWords + k];
+                    wq[k] += swl[(gI * kStatSub + u) * kStatWords + kStatBins + k];
                 }
             const double s = stat_bins_total(ws), qq = stat_bins_total(wq);
             const double mean = s / n;
@@ -674,7 +686,7 @@ __global__ void repack_tm_kernel(const float* __restrict__ w, float* __restrict_
 // its channels (tid, tid + 256, ...) across the block's rows and adds its sums to LDS once.
 __global__ __launch_bounds__(256) void stats_accum_tm_kernel(const float* __restrict__ x, int ld,
                                                              double* __restrict__ stats, int C, int T,
-                                                             int G, int rows_per_block) {
+                                                             int G, int rows_per_block, int sub_stride) {
     // per-thread partial sums land in their own LDS slots and thread g < G adds group g's slots in a fixed order
     // (no LDS atomics: the block's contribution does not depend on thread scheduling)
     extern __shared__ __attribute__((aligned(16))) float sh[];  // [2][max(256, C)]
@@ -723,7 +735,10 @@ __global__ __launch_bounds__(256) void stats_accum_tm_kernel(const float* __rest
                 q += sh[W + c];
             }
         }
-        long long* sp = reinterpret_cast<long long*>(stats) + ((size_t)b * G + threadIdx.x) * kStatWords;
+        // sub_stride > 0: the blocks spread over the sub-slots the consumer adds anyway (several hundred blocks'
+        // atomics on the 16 words of one clip serialise otherwise: 43 us for the codec's 2-MB input)
+        long long* sp = reinterpret_cast<long long*>(stats) + (size_t)(blockIdx.x % kStatSub) * sub_stride +
+                        ((size_t)b * G + threadIdx.x) * kStatWords;
         stat_bins_add(sp, s);
         stat_bins_add(sp + kStatBins, q);
     }
@@ -932,12 +947,12 @@ int launch_act_pad_tm(const ActPadTm& p, hipStream_t s) {
     return AFTER_OK;
 }
 
-int launch_stats_accum_tm(const float* x, double* stats, int B, int C, int T, int G, hipStream_t s, int ld) {
+int launch_stats_accum_tm(const float* x, double* stats, int B, int C, int T, int G, hipStream_t s, int ld, int sub_stride) {
     AFTER_REQUIRE(G >= 1 && G <= 16 && C % G == 0, AFTER_E_INVALID, "stats_accum_tm: G <= 16, G | C");
     int rpb = C <= 128 ? 64 : 16;
     while ((long long)cdiv(T, rpb) * B > 1024) rpb *= 2;
     hipLaunchKernelGGL(stats_accum_tm_kernel, dim3(cdiv(T, rpb), B), dim3(256), 2 * (size_t)(C <= 128 ? 256 : C) * sizeof(float), s, x, ld > 0 ? ld : C, stats, C,
-                       T, G, rpb);
+                       T, G, rpb, sub_stride);
     AFTER_HIP_CHECK(hipGetLastError());
     return AFTER_OK;
 }

@@ -440,7 +440,7 @@ int run_block(after_unet1d* h, hipStream_t s, const BlockW& b, const float* x, i
     AFTER_HIP_CHECK(hipGetLastError());
     // GroupNorm 1 over the concatenation: its parts have three different producers -> one pass
     double* st1 = next_slot(h);
-    AFTER_TRY(launch_stats_accum_tm(in, st1, B, ccat, T, gn_groups(ccat), s, in_ld));
+    AFTER_TRY(launch_stats_accum_tm(in, st1, B, ccat, T, gn_groups(ccat), s, in_ld, h->max_batch * 16 * kStatWords));
     double* st2 = next_slot(h);
     {
         ConvIo io;
@@ -492,7 +492,7 @@ int run_block(after_unet1d* h, hipStream_t s, const BlockW& b, const float* x, i
 int run_attn(after_unet1d* h, hipStream_t s, const AttnW& w, const float* x, float* y, int B, int T) {
     const int C = w.C, D = C / w.nh;
     double* st = next_slot(h);
-    AFTER_TRY(launch_stats_accum_tm(x, st, B, C, T, 1, s, C));
+    AFTER_TRY(launch_stats_accum_tm(x, st, B, C, T, 1, s, C, h->max_batch * 16 * kStatWords));
     {
         ConvIo io;
         io.x = x;

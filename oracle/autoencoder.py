@@ -38,6 +38,13 @@ def snake_beta(x, alpha, beta):
     return x + (1.0 / (b + 0.000000001)) * torch.sin(x * a).pow(2)
 
 
+def snake(sd, pre, x):
+    """The codec's activation by the state dict's own keys: SnakeBeta (alpha, beta of [dim]) or the one-parameter
+    core.py:201-209 Snake (alpha of [dim, 1]): x + (alpha + 1e-9).reciprocal() * sin(alpha x)^2."""
+    alpha = sd[pre + "alpha"]
+    return snake_beta(x, alpha, sd.get(pre + "beta", alpha))
+
+
 def reverse_half(x):
     """pqmf.py:16-20: negate odd bands at even time indices."""
     m = torch.ones_like(x)
@@ -82,7 +89,7 @@ def conv_block(sd, pre, x, cfg, kernel_size=3, dilation=1, norm=None):
     elif cfg["use_norm"]:
         x = F.group_norm(x, min(c, 8), sd[pre + "net.0.gn.weight"], sd[pre + "net.0.gn.bias"],
                          1e-5)
-    x = snake_beta(x, sd[pre + "net.1.alpha"], sd[pre + "net.1.beta"])
+    x = snake(sd, pre + "net.1.", x)
     w, b = _wn(sd, pre + "net.2.")
     x = F.pad(x, get_padding(kernel_size, dilation=dilation, mode=cfg["padding_mode"]))
     return F.conv1d(x, w, b, dilation=dilation)
@@ -114,12 +121,12 @@ def encoder_forward(sd, x, cfg):
         for j, d in enumerate(cfg["dilations"]):
             x = resnet_block(sd, f"{bp}{j}.", x, cfg, d)
         nb = len(cfg["dilations"])
-        x = snake_beta(x, sd[f"{bp}{nb}.alpha"], sd[f"{bp}{nb}.beta"])
+        x = snake(sd, f"{bp}{nb}.", x)
         f = cfg["factors"][i]
         w, b = _wn(sd, f"{bp}{nb + 1}.")
         x = F.pad(x, get_padding(2 * f, f, mode=cfg["padding_mode"]))
         x = F.conv1d(x, w, b, stride=f)
-    x = snake_beta(x, sd[f"{pre}{n + 1}.alpha"], sd[f"{pre}{n + 1}.beta"])
+    x = snake(sd, f"{pre}{n + 1}.", x)
     w, b = _wn(sd, f"{pre}{n + 2}.")
     x = F.pad(x, get_padding(3, mode=cfg["padding_mode"]))
     return F.conv1d(x, w, b)
@@ -133,7 +140,7 @@ def decoder_forward(sd, z, cfg, norm=None):
     factors = cfg["factors"][::-1]
     for i, f in enumerate(factors):
         bp = f"{pre}{i + 1}.net."
-        x = snake_beta(x, sd[bp + "0.alpha"], sd[bp + "0.beta"])
+        x = snake(sd, bp + "0.", x)
         w, b = _wn(sd, bp + "1.")
         if cfg.get("stream_convT"):
             # cached_conv.CachedConvTranspose1d (third-party, absent here): conv_transpose1d with

@@ -87,7 +87,8 @@ class _ConvBlock:
         if cfg["use_norm"]:
             self.norm = StreamGroupNorm(min(cin, 8), sd[pre + "net.0.gn.weight"], sd[pre + "net.0.gn.bias"],
                                         gn_stream)
-        self.alpha, self.beta = sd[pre + "net.1.alpha"], sd[pre + "net.1.beta"]
+        self.alpha = sd[pre + "net.1.alpha"]
+        self.beta = sd.get(pre + "net.1.beta", self.alpha)  # (core.Snake: one parameter)
         w, b = _wn(sd, pre + "net.2.")
         self.conv = CachedConv(w, b, k, 1, dilation, 0)
         self.cumulative_delay = self.conv.cumulative_delay
@@ -147,9 +148,9 @@ class NonCausalStreamEncoder:
             w, b = _wn(sd, f"{bp}{nb + 1}.")
             down = CachedConv(w, b, 2 * f, f, 1, cd, pad_stride_arg=f)  # Downsample1d :32-48
             cd = down.cumulative_delay
-            self.stages.append((blocks, (sd[f"{bp}{nb}.alpha"], sd[f"{bp}{nb}.beta"]), down))
+            self.stages.append((blocks, (sd[f"{bp}{nb}.alpha"], sd.get(f"{bp}{nb}.beta", sd[f"{bp}{nb}.alpha"])), down))
             c = w.shape[0]
-        self.tail_act = (sd[f"{pre}{n + 1}.alpha"], sd[f"{pre}{n + 1}.beta"])
+        self.tail_act = (sd[f"{pre}{n + 1}.alpha"], sd.get(f"{pre}{n + 1}.beta", sd[f"{pre}{n + 1}.alpha"]))
         w, b = _wn(sd, f"{pre}{n + 2}.")
         self.tail = CachedConv(w, b, 3, 1, 1, cd)
         self.delay = self.tail.cumulative_delay

@@ -77,6 +77,9 @@ def build_ecapa(cfg):
 
 def build_ae(cfg, bottleneck=None):
     kw = {k: v for k, v in cfg.items() if k not in ("padding_mode", "bottleneck")}
+    if kw.get("activation") == "core.Snake":  # the reference takes the class itself
+        import importlib
+        kw["activation"] = importlib.import_module("after.autoencoder.core").Snake
     R.cc.set_padding_mode(cfg["padding_mode"])
     try:
         return R.ae.AutoEncoder(bottleneck=bottleneck or R.ae.ReluBottleneck(sigma=0.01, scale=3), **kw)
@@ -461,6 +464,7 @@ CASES = {
     "ae_base": lambda: ae_case("ae_base", "baseAE", 1, 32768, 43),
     "ae_micro_bottlenecks": bottleneck_case,
     "ae_micro_nopqmf": lambda: ae_case("ae_micro_nopqmf", "microAE_nopqmf", 2, 4096, 47),
+    "ae_micro_snake1": lambda: ae_case("ae_micro_snake1", "microAE_snake1", 2, 8192, 48),
     "ae_micro_causal_wc": lambda: ae_case("ae_micro_causal_wc", "microAE_causal", 2, 8192, 44, wg_scale=0.5),
     "ae_base_causal_wc": lambda: ae_case("ae_base_causal_wc", "baseAE_causal", 1, 16384, 45, wg_scale=0.5),
     "encoders_micro": lambda: encoders_case("encoders_micro", "micro", 2, 64, 51),

@@ -110,7 +110,7 @@ def test_streaming_cache_matches_reference():
 
 
 @pytest.mark.parametrize("case", ["ae_micro", "ae_micro_causal", "ae_base", "ae_micro_causal_wc", "ae_base_causal_wc",
-                                  "ae_micro_nopqmf"])
+                                  "ae_micro_nopqmf", "ae_micro_snake1"])
 def test_autoencoder_matches_reference(case):
     fx = Fixture(case)
     cfg = configs.autoencoder_config(fx.meta["config"])
