@@ -311,6 +311,7 @@ struct DmaConv {
     ConvDmaPlanIn in;
     ConvTmPlan tplan;
     float* w = nullptr;
+    unsigned short* w3 = nullptr;     // the same weights as bf16 planes (conv_x6.hip), where the layer has a bf16-pipe form
     int toff_offline[kMaxTaps] = {};  // phase-0 taps of the offline plan while a cached (streaming) form is active
 };
 struct ConvBlockW {
@@ -372,6 +373,8 @@ struct after_ae {
     int cmax = 0;
     // conv path (conv_tm.hip): activations time-major [B][T][C] between the API edges
     float* xp = nullptr;          // activated + haloed scratch tensor
+    unsigned short* xp3 = nullptr;  // the same, as bf16 planes: input of the convs that run on the bf16 pipe (conv_x6.hip)
+    size_t xp3_elems = 0;
     float* xp2 = nullptr;         // second one: a conv epilogue prepares the NEXT conv's input there
     const float* prepared = nullptr;  // haloed input already laid out by the producer (time-major path)
     const float* next_alpha = nullptr;  // Snake of the following resampling conv: request to the next
@@ -509,7 +512,14 @@ int make_dma(after_ae* h, DmaConv& d, const float* packed, int cin, int cout, in
     AFTER_REQUIRE(d.tplan.ok, AFTER_E_INVALID, "autoencoder: tap pattern outside the time-major conv path");
     d.w = h->wd.take<float>(d.tplan.w_floats);
     AFTER_REQUIRE(d.w, AFTER_E_NOMEM, "autoencoder: conv weight arena exhausted");
-    return conv_tm_repack(packed, d.w, d.in, d.tplan, 0);
+    AFTER_TRY(conv_tm_repack(packed, d.w, d.in, d.tplan, 0));
+    d.w3 = nullptr;
+    if (conv_x6_mode() && conv_x6_eligible(d.in, d.tplan) && cout >= 64 && d.tplan.K >= 256) {
+        d.w3 = h->wd.take<unsigned short>(conv_x6_weight_elems(d.in, d.tplan));
+        AFTER_REQUIRE(d.w3, AFTER_E_NOMEM, "autoencoder: conv weight arena exhausted");
+        AFTER_TRY(conv_x6_split(d.w, d.w3, d.in, d.tplan, 0));
+    }
+    return AFTER_OK;
 }
 
 double* next_stats(after_ae* h, int B) {
@@ -541,32 +551,8 @@ int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const 
     // offline their producer's epilogue has already written the activated, haloed tensor
     const float* xin = h->prepared;
     h->prepared = nullptr;
-    if (!xin) {
-        ActPadTm p;
-        memset(&p, 0, sizeof(p));
-        p.x = x;
-        p.y = h->xp;
-        p.stats = stats_in;
-        p.gamma = gamma;
-        p.beta = beta;
-        p.act_a = alpha;
-        p.act_b = invb;
-        p.state = state;
-        p.state_out = state_out;
-        p.act = act;
-        p.B = B;
-        p.C = cin;
-        p.T = Tin;
-        p.G = cin < 8 ? cin : 8;
-        p.x_cm = x_cm;
-        p.stat_T = stat_T;
-        p.sub_stride = h->max_batch * 8 * kStatWords;
-        AFTER_TRY(launch_act_pad_tm(p, s));
-        xin = h->xp;
-    }
     ConvTmRun r;
     memset(&r, 0, sizeof(r));
-    r.xp = xin;
     r.w = d.w;
     r.bias = bias;
     r.res = res;
@@ -597,6 +583,39 @@ int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const 
         h->prepared = r.y2;
     }
     h->next_alpha = h->next_invb = nullptr;
+    // MFMA-bound whole-clip launches run on the bf16 pipe (conv_x6.hip): their input is written as bf16 planes
+    const bool x6 = !xin && d.w3 && !h->pass_stream && !x_cm && conv_x6_wins(r, d.in, d.tplan) &&
+                    conv_x6_plane_elems(B, Tin, cin) <= h->xp3_elems;
+    if (!xin) {
+        ActPadTm p;
+        memset(&p, 0, sizeof(p));
+        p.x = x;
+        p.y = h->xp;
+        p.y3 = x6 ? h->xp3 : nullptr;
+        p.stats = stats_in;
+        p.gamma = gamma;
+        p.beta = beta;
+        p.act_a = alpha;
+        p.act_b = invb;
+        p.state = state;
+        p.state_out = state_out;
+        p.act = act;
+        p.B = B;
+        p.C = cin;
+        p.T = Tin;
+        p.G = cin < 8 ? cin : 8;
+        p.x_cm = x_cm;
+        p.stat_T = stat_T;
+        p.sub_stride = h->max_batch * 8 * kStatWords;
+        AFTER_TRY(launch_act_pad_tm(p, s));
+        xin = h->xp;
+    }
+    r.xp = xin;
+    if (x6) {
+        r.xp3 = h->xp3;
+        r.w3 = d.w3;
+        return launch_conv_x6(r, d.in, d.tplan, s);
+    }
     return launch_conv_tm(r, d.in, d.tplan, s);
 }
 
@@ -920,7 +939,7 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
     // ---- per-conv geometry + GEMM-operand weights
     h->stat_sub = conv_tm_stat_sub();
     {
-        AE_TRY(h->wd.init((size_t)(wf * 2.0) * sizeof(float) + (8 << 20)));
+        AE_TRY(h->wd.init((size_t)(wf * 2.0) * sizeof(float) + (size_t)(wf * 2.0) * 3 * sizeof(unsigned short) + (16 << 20)));
         const size_t Tm = h->max_samples / h->M;
         auto plan_conv = [&](DmaConv& d, const float* packed, int cin, int cout, int kk, int dil,
                              size_t T) -> int {
@@ -1027,13 +1046,15 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
         }
     }
     h->xp_elems = xpe * max_batch + 4096;
-    rc = h->ws.init(3 * h->buf_elems * sizeof(float) + 8192 + 2 * h->xp_elems * sizeof(float) + (size_t)kStatSlots * h->stat_sub * max_batch * 8 * kStatWords * sizeof(double));
+    h->xp3_elems = 3 * (h->xp_elems + (size_t)max_batch * 16 * conv_tm_cp(h->cmax));
+    rc = h->ws.init(3 * h->buf_elems * sizeof(float) + 16384 + 2 * h->xp_elems * sizeof(float) + h->xp3_elems * sizeof(unsigned short) + (size_t)kStatSlots * h->stat_sub * max_batch * 8 * kStatWords * sizeof(double));
     if (rc != AFTER_OK) return fail(rc);
     for (int i = 0; i < 3; ++i) h->buf[i] = h->ws.take<float>(h->buf_elems);
     h->xp = h->ws.take<float>(h->xp_elems);
     h->xp2 = h->ws.take<float>(h->xp_elems);
+    h->xp3 = h->ws.take<unsigned short>(h->xp3_elems);
     h->stats_ring = h->ws.take<double>((size_t)kStatSlots * h->stat_sub * max_batch * 8 * kStatWords);
-    if (!h->buf[2] || !h->xp || !h->xp2 || !h->stats_ring) return fail(AFTER_E_NOMEM);
+    if (!h->buf[2] || !h->xp || !h->xp2 || !h->xp3 || !h->stats_ring) return fail(AFTER_E_NOMEM);
     if (hipDeviceSynchronize() != hipSuccess) {
         set_error("autoencoder: device initialisation failed");
         return fail(AFTER_E_HIP);

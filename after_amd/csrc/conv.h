@@ -97,6 +97,8 @@ struct ConvTmPlan {
 struct ConvTmRun {
     const float* xp;   // [B][Tp][Cp] activated, haloed input (launch_act_pad_tm)
     const float* w;    // conv_tm_repack output
+    const unsigned short* xp3;  // launch_conv_x6: the same input as bf16 planes (ActPadTm::y3)
+    const unsigned short* w3;   //                 conv_x6_split output
     const float* bias;
     const float* res;  // [B][Tout][Cout] time-major, or nullptr
     float* y;          // [B][Tout][Cout] time-major ([B][Cout][Tout] when y_cm)
@@ -123,6 +125,7 @@ struct ConvTmRun {
 struct ActPadTm {
     const float* x;       // [B][T][ldx] time-major ([B][C][T] when x_cm)
     float* y;             // [B][conv_tm_rows(T)][conv_tm_cp(C)]
+    unsigned short* y3;   // instead of y: three bf16 planes in x6 blocks of [B x conv_x6_rows(T)][conv_tm_cp(C)] (conv_x6.hip)
     const double* stats;  // producer's accumulators ([sub][sub_stride], see ConvTmRun) -> GroupNorm, or nullptr
     const float* gamma;   // with stats: GroupNorm weight; without: per-channel scale (BatchNorm eval) or nullptr
     const float* beta;
@@ -146,6 +149,16 @@ void conv_tm_plan(const ConvDmaPlanIn& in, ConvTmPlan* p);
 int conv_tm_repack(const float* packed, float* out, const ConvDmaPlanIn& in, const ConvTmPlan& p, hipStream_t s);
 int launch_conv_tm(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan& p, hipStream_t s);
 int launch_act_pad_tm(const ActPadTm& p, hipStream_t s);
+// ---- the same convs through the bf16 matrix pipe (conv_x6.hip): stride-1 convs of <= 3 taps, operands as bf16 planes
+constexpr int kConvTmHalo = 32;  // == conv_tm_halo()
+int conv_x6_rows(int T);                          // plane rows per clip: conv_tm_rows(T) rounded up to 16
+size_t conv_x6_plane_elems(int B, int T, int C);  // unsigned shorts of the plane tensor act_pad_tm writes
+size_t conv_x6_weight_elems(const ConvDmaPlanIn& in, const ConvTmPlan& p);
+bool conv_x6_eligible(const ConvDmaPlanIn& in, const ConvTmPlan& p);
+int conv_x6_split(const float* w_tm, unsigned short* w3, const ConvDmaPlanIn& in, const ConvTmPlan& p, hipStream_t s);
+int conv_x6_mode();  // AFTER_CONV_X6: 0 never, 1 by size (default), 2 wherever eligible
+bool conv_x6_wins(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan& p);
+int launch_conv_x6(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan& p, hipStream_t s);
 // sub_stride > 0: stats is a [conv_tm_stat_sub()][sub_stride] accumulator (ConvTmRun) and the blocks spread over its sub-slots
 int launch_stats_accum_tm(const float* x, double* stats, int B, int C, int T, int G, hipStream_t s, int ld = 0, int sub_stride = 0);
 // small layout helpers on time-major tensors

@@ -35,6 +35,7 @@ namespace after {
 namespace {
 
 constexpr int HALO = 32;  // zero rows on both sides of every clip
+static_assert(HALO == kConvTmHalo, "conv.h");
 // The statistics of one (clip, group) are spread over kStatSub accumulator pairs (workgroup id
 // mod kStatSub) so that the fp64 atomics of several hundred workgroups do not serialise on 16
 // addresses; the consumer adds the sub-slots in a fixed order.
@@ -76,10 +77,53 @@ __device__ __forceinline__ float act_apply(float v, int act, float pa, float pb)
     }
 }
 
+// GroupNorm statistics -> (mean, rstd) per group, once per block.  The words of the (sub-slot, group) pairs -- 64
+// contiguous bytes each -- are fetched ONCE per block, 16 bytes per thread, into LDS; one lane per group then adds the
+// sub-slots (integers: exact) and does the fp64 arithmetic.  (Round 4's first form had every group lane issue its 64
+// eight-byte loads itself: 512 line requests per block on the same few lines of the same L2 channels -- with several
+// hundred blocks per launch those channels were the bottleneck: +3-6 us per 12-MB launch.)  Ends with a barrier.
+__device__ __forceinline__ void gn_mean_rstd(const double* stats, int b, int G, int sub_stride, int C, int stat_T, float eps,
+                                             long long* swl /* [16 * kStatSub * kStatWords] LDS */, float* gmean,
+                                             float* grstd, int nthreads) {
+    static_assert(kStatWords % 2 == 0, "16-byte pieces");
+    constexpr int PPG = kStatWords / 2;  // 16-byte pieces per (sub-slot, group)
+    const long long* sbase = reinterpret_cast<const long long*>(stats) + (size_t)b * G * kStatWords;
+    for (int i = threadIdx.x; i < G * kStatSub * PPG; i += nthreads) {
+        const int piece = i % PPG, u = (i / PPG) % kStatSub, gI = i / (PPG * kStatSub);
+        const longlong2 w2 = *reinterpret_cast<const longlong2*>(sbase + (size_t)u * sub_stride + gI * kStatWords + 2 * piece);
+        *reinterpret_cast<longlong2*>(&swl[(gI * kStatSub + u) * kStatWords + 2 * piece]) = w2;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < G) {
+        const int gI = threadIdx.x;
+        const double n = (double)(C / G) * stat_T;
+        // the sub-slots' words add as integers (exact), then each quantity folds into one fp64 (conv.h: stat_bins)
+        long long ws[kStatBins], wq[kStatBins];
+#pragma unroll
+        for (int k = 0; k < kStatBins; ++k) ws[k] = wq[k] = 0;
+#pragma unroll
+        for (int u = 0; u < kStatSub; ++u)
+#pragma unroll
+            for (int k = 0; k < kStatBins; ++k) {
+                ws[k] += swl[(gI * kStatSub + u) * kStatWords + k];
+                wq[k] += swl[(gI * kStatSub + u) * kStatWords + kStatBins + k];
+            }
+        const double sm = stat_bins_total(ws), qq = stat_bins_total(wq);
+        const double mean = sm / n;
+        double var = qq / n - mean * mean;
+        var = var < 0 ? 0 : var;
+        gmean[gI] = (float)mean;
+        grstd[gI] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------ activate + halo
 struct ActTmArgs {
     const float* x;       // [B][T][ldx] time-major, or [B][C][T] when x_cm
     float* y;             // [B][Tp][Cp]
+    unsigned short* y3;   // instead of y: bf16 planes, x6 blocks of [B x rows16][Cp] (conv_x6.hip)
+    int rows16;
     const double* stats;  // [sub-slot][B][G][2][kStatBins] 64-bit words (conv.h: stat_bins) or nullptr
     const float* gamma;   // with stats: GroupNorm weight; without: per-channel scale (or nullptr)
     const float* beta;
@@ -171,44 +215,9 @@ __global__ __launch_bounds__(256) void act_pad_tm_kernel(ActTmArgs a) {
         if (a.act_a) pa[k] = a.act_a[c];
         if (a.act_b) pb[k] = a.act_b[c];
     }
-    // GroupNorm statistics -> (mean, rstd) per group.  The words of the (sub-slot, group) pairs -- 64 contiguous bytes each --
-    // are fetched ONCE per block, 16 bytes per thread, into LDS; one lane per group then adds the sub-slots (integers:
-    // exact) and does the fp64 arithmetic.  (Round 4's first form had every group lane issue its 64 eight-byte loads
-    // itself: 512 line requests per block on the same few lines of the same L2 channels -- with several hundred blocks
-    // per launch those channels were the bottleneck: +3-6 us per 12-MB launch, profiles/r4_decode_trace_b1.jsonl.)
     if (a.stats) {
         __shared__ __attribute__((aligned(16))) long long swl[16 * kStatSub * kStatWords];
-        static_assert(kStatWords % 2 == 0, "16-byte pieces");
-        constexpr int PPG = kStatWords / 2;  // 16-byte pieces per (sub-slot, group)
-        const long long* sbase = reinterpret_cast<const long long*>(a.stats) + (size_t)b * a.G * kStatWords;
-        for (int i = threadIdx.x; i < a.G * kStatSub * PPG; i += 256) {
-            const int piece = i % PPG, u = (i / PPG) % kStatSub, gI = i / (PPG * kStatSub);
-            const longlong2 w2 = *reinterpret_cast<const longlong2*>(sbase + (size_t)u * a.sub_stride + gI * kStatWords + 2 * piece);
-            *reinterpret_cast<longlong2*>(&swl[(gI * kStatSub + u) * kStatWords + 2 * piece]) = w2;
-        }
-        __syncthreads();
-        if (threadIdx.x < a.G) {
-            const int gI = threadIdx.x;
-            const double n = (double)(a.C / a.G) * a.stat_T;
-            // the sub-slots' words add as integers (exact), then each quantity folds into one fp64 (conv.h: stat_bins)
-            long long ws[kStatBins], wq[kStatBins];
-#pragma unroll
-            for (int k = 0; k < kStatBins; ++k) ws[k] = wq[k] = 0;
-#pragma unroll
-            for (int u = 0; u < kStatSub; ++u)
-#pragma unroll
-                for (int k = 0; k < kStatBins; ++k) {
-                    ws[k] += swl[(gI * kStatSub + u) * kStatWords + k];
-                    wq[k] += swl[(gI * kStatSub + u) * kStatWords + kStatBins + k];
-                }
-            const double s = stat_bins_total(ws), qq = stat_bins_total(wq);
-            const double mean = s / n;
-            double var = qq / n - mean * mean;
-            var = var < 0 ? 0 : var;
-            gmean[gI] = (float)mean;
-            grstd[gI] = (float)(1.0 / sqrt(var + (double)a.eps));
-        }
-        __syncthreads();
+        gn_mean_rstd(a.stats, b, a.G, a.sub_stride, a.C, a.stat_T, a.eps, swl, gmean, grstd, 256);
     }
     if (!active) return;
     float sc[4], sh[4];
@@ -257,6 +266,89 @@ __global__ void state_update_tm_kernel(const float* __restrict__ yp, float* __re
     const int b = idx / per, e = idx - b * per;
     reinterpret_cast<f32x4*>(state)[idx] =
         reinterpret_cast<const f32x4*>(yp + ((size_t)b * Tp + T) * Cp)[e];
+}
+
+// The same pass with the output as bf16 planes in x6 blocks (common.h) of [B x rows16][Cp] -- the A operand of
+// conv_x6.hip.  One wave = one (16-row, 32-channel) block at a time: lane l holds row l / 4, channels 8 (l % 4) .. + 7
+// of it, so each of the three planes of the block leaves as ONE 1-KB contiguous store instruction (16 bytes per lane at
+// the block's own chunk permutation); a wave walks RB consecutive row blocks of its channel block, all of their rows
+// requested up front.  Whole-clip passes of time-major tensors only (no streaming context, no second input).
+__global__ __launch_bounds__(256) void act_pad_x6_kernel(ActTmArgs a, int nkb, int RB) {
+    __shared__ float gmean[16], grstd[16];
+    __shared__ __attribute__((aligned(16))) long long swl[16 * kStatSub * kStatWords];
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // waves are dealt over (row group, channel block) pairs, channel blocks fastest: no idle waves whatever Cp / 32 is
+    const int nrb = a.rows16 >> 4;
+    const int wv = blockIdx.x * 4 + w;
+    const int kb = wv % nkb, rg = wv / nkb;
+    const int r = lane >> 2, c0 = kb * 32 + 8 * (lane & 3);
+    constexpr int MAXRB = 4;
+    f32x4 v[MAXRB][2];
+    const bool kvalid = rg * RB < nrb;
+#pragma unroll
+    for (int u = 0; u < MAXRB; ++u) {
+        v[u][0] = v[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int rbI = rg * RB + u, t = rbI * 16 + r - HALO;
+        if (u < RB && kvalid && rbI < nrb && t >= 0 && t < a.T) {
+            const float* xr = a.x + ((size_t)b * a.T + t) * a.ldx + c0;
+            if (c0 + 7 < a.C) {
+                v[u][0] = *reinterpret_cast<const f32x4*>(xr);
+                v[u][1] = *reinterpret_cast<const f32x4*>(xr + 4);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (c0 + k < a.C) v[u][k >> 2][k & 3] = xr[k];
+            }
+        }
+    }
+    float ga[8], be[8], pa[8], pb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = c0 + k;
+        ga[k] = 1.f;
+        be[k] = 0.f;
+        pa[k] = pb[k] = 0.f;
+        if (!kvalid || c >= a.C) continue;
+        if (a.gamma) {
+            ga[k] = a.gamma[c];
+            be[k] = a.beta[c];
+        }
+        if (a.act_a) pa[k] = a.act_a[c];
+        if (a.act_b) pb[k] = a.act_b[c];
+    }
+    if (a.stats) gn_mean_rstd(a.stats, b, a.G, a.sub_stride, a.C, a.stat_T, a.eps, swl, gmean, grstd, 256);
+    if (!kvalid) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sc[k] = ga[k];
+        sh[k] = be[k];
+        if (a.stats && c0 + k < a.C) {
+            const int g = (c0 + k) / (a.C / a.G);
+            sc[k] = grstd[g] * ga[k];
+            sh[k] = be[k] - gmean[g] * sc[k];
+        }
+    }
+    const int slot = (lane & 3) ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3);  // x6 chunk permutation (common.h: x6_offset)
+#pragma unroll
+    for (int u = 0; u < MAXRB; ++u) {
+        const int rbI = rg * RB + u, t = rbI * 16 + r - HALO;
+        if (u >= RB || rbI >= nrb) continue;
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float xv = v[u][k >> 2][k & 3];
+            o[k] = (t >= 0 && t < a.T && c0 + k < a.C) ? act_apply(xv * sc[k] + sh[k], a.act, pa[k], pb[k]) : 0.f;
+        }
+        uint2 h0, m0, l0, h1, m1, l1;
+        x6_split4(o[0], o[1], o[2], o[3], h0, m0, l0);
+        x6_split4(o[4], o[5], o[6], o[7], h1, m1, l1);
+        unsigned short* bp = a.y3 + ((((size_t)b * nrb + rbI) * nkb + kb) * 3) * 512 + r * 32 + slot * 8;
+        *reinterpret_cast<uint4*>(bp) = uint4{h0.x, h0.y, h1.x, h1.y};
+        *reinterpret_cast<uint4*>(bp + 512) = uint4{m0.x, m0.y, m1.x, m1.y};
+        *reinterpret_cast<uint4*>(bp + 1024) = uint4{l0.x, l0.y, l1.x, l1.y};
+    }
 }
 
 // ------------------------------------------------------------------ the conv GEMM
@@ -395,7 +487,16 @@ __global__ __launch_bounds__(128 * KS * RS) void conv_tm_kernel(ConvTmArgs g, in
     // [2][NW][NT][SL] partial sums (SL = 4 channel quads of a 16-column block, or its 16 columns when a quad may
     // straddle two groups): every (wave, column block) owns its slots, tid < 16 adds them per group in a fixed
     // order -- no LDS atomics, so the tile's statistics do not depend on the order the waves finish in
-    float* gs = smem + g.gs_off;
+    // round 4: the per-wave float slots and the one-lane-per-group serial loop over them (96 dependent LDS reads:
+    // 6-11 us per tile, measured on conv_x6's copy of it) became binned INTEGER accumulators in LDS -- every lane quad's
+    // partial sum goes in with ds_add_u64 (exact, order-independent: conv.h stat_bins_add), the non-zero words go on to
+    // the global accumulators
+    long long* lbins = reinterpret_cast<long long*>(smem + g.gs_off);  // [groups of this tile <= 16][kStatWords]
+    const int Cg_ = g.stats ? g.Cout / g.G : 1;
+    const int sg0 = g.stats ? n0 / Cg_ : 0;
+    const int sng = g.stats ? (min(n0 + BN, g.Cout) - 1) / Cg_ - sg0 + 1 : 0;
+    if (g.stats && !g.gs_in_ring)
+        for (int i = tid; i < sng * kStatWords; i += 128 * KS * RS) lbins[i] = 0;
 
     unsigned long long ph_fence = 0, ph_vm = 0, ph_bar = 0;  // cycle-stamp sinks of the pipeline macros
     (void)ph_fence;
@@ -444,6 +545,8 @@ __global__ __launch_bounds__(128 * KS * RS) void conv_tm_kernel(ConvTmArgs g, in
     // ---- split-K reduction through LDS in k-part order (bit-deterministic), as in gemm.hip
     float* red = smem;
     if (KS > 1 || (g.stats && g.gs_in_ring)) __syncthreads();  // every wave is past its last ring read
+    if (g.stats && g.gs_in_ring)
+        for (int i = tid; i < sng * kStatWords; i += 128 * KS * RS) lbins[i] = 0;
     if constexpr (KS > 1) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -456,7 +559,6 @@ __global__ __launch_bounds__(128 * KS * RS) void conv_tm_kernel(ConvTmArgs g, in
     // accumulator layout (W fragment as srcA): lane l holds C[row = l & 15][col = 4 (l >> 4) + r]
     const int crow = lane & 15, ccol0 = 4 * (lane >> 4);
     const int Cg = g.stats ? g.Cout / g.G : 1;
-    const int g0 = n0 / Cg;
     const bool quad = (Cg & 3) == 0;  // a lane's four channels sit in one group (every shipped width)
     float* yb = g.y ? g.y + (size_t)b * g.y_bs + g.y_coff : nullptr;
     const float* rb = g.res ? g.res + (size_t)b * g.res_bs + g.res_coff : nullptr;
@@ -587,7 +689,6 @@ __global__ __launch_bounds__(128 * KS * RS) void conv_tm_kernel(ConvTmArgs g, in
             }
         }
         if (g.stats) {
-            constexpr int NWV = 2 * KS * RS;
             if (quad) {  // Cg % 4 == 0: the lane's four columns sit in one group (every shipped width)
                 float s1 = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]), q1 = (qsum[0] + qsum[1]) + (qsum[2] + qsum[3]);
                 // the 16 lanes l & 15 of a quad share the channel quad: butterfly over the rows
@@ -596,11 +697,12 @@ __global__ __launch_bounds__(128 * KS * RS) void conv_tm_kernel(ConvTmArgs g, in
                     s1 += __shfl_xor(s1, o2, 64);
                     q1 += __shfl_xor(q1, o2, 64);
                 }
-                if (crow == 0) {
-                    gs[((0 * NWV + wid) * NT + j) * 4 + (lane >> 4)] = s1;
-                    gs[((1 * NWV + wid) * NT + j) * 4 + (lane >> 4)] = q1;
+                if (crow == 0 && gn < N) {
+                    long long* bp = lbins + (gn / Cg - sg0) * kStatWords;
+                    stat_bins_add(bp, s1);
+                    stat_bins_add(bp + kStatBins, q1);
                 }
-            } else {  // narrow test configurations: one slot per column
+            } else {  // narrow test configurations: per column
 #pragma unroll
                 for (int o2 = 1; o2 < 16; o2 <<= 1)
 #pragma unroll
@@ -610,10 +712,12 @@ __global__ __launch_bounds__(128 * KS * RS) void conv_tm_kernel(ConvTmArgs g, in
                     }
                 if (crow == 0) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        gs[((0 * NWV + wid) * NT + j) * 16 + ccol0 + r] = ssum[r];
-                        gs[((1 * NWV + wid) * NT + j) * 16 + ccol0 + r] = qsum[r];
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        if (gn + r < N) {
+                            long long* bp = lbins + ((gn + r) / Cg - sg0) * kStatWords;
+                            stat_bins_add(bp, ssum[r]);
+                            stat_bins_add(bp + kStatBins, qsum[r]);
+                        }
                 }
             }
         }
@@ -636,32 +740,13 @@ __global__ __launch_bounds__(128 * KS * RS) void conv_tm_kernel(ConvTmArgs g, in
     }
     if (g.stats) {
         __syncthreads();
-        if (tid < 16) {
-            const int grp = g0 + tid;
-            const int glast = (min(n0 + BN, N) - 1) / Cg;
-            if (grp <= glast) {
-                // this group's slots in (wave, column block, slot) order: a fixed summation order.  Across workgroups
-                // the partial sums are added as integers (conv.h: stat_bins_add): exact and order-independent.
-                constexpr int NWV = 2 * KS * RS;
-                const int SL = quad ? 4 : 16, cstep = quad ? 4 : 1;
-                const float inv_cg = 1.0f / (float)Cg;
-                float s1 = 0.f, q1 = 0.f;
-                for (int w = 0; w < NWV; ++w) {
-                    const int cbase = n0 + (w / (KS * RS)) * 16 * NB;
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        for (int sl = 0; sl < SL; ++sl) {
-                            const int c = cbase + j * 16 + sl * cstep;
-                            if (c < N && __float2int_rd(((float)c + 0.5f) * inv_cg) == grp) {
-                                s1 += gs[((0 * NWV + w) * NT + j) * SL + sl];
-                                q1 += gs[((1 * NWV + w) * NT + j) * SL + sl];
-                            }
-                        }
-                }
+        if (tid < sng * kStatWords) {
+            const long long v = lbins[tid];
+            if (v) {
+                const int grp = sg0 + tid / kStatWords, k = tid % kStatWords;
                 long long* sp = reinterpret_cast<long long*>(g.stats) + (size_t)(blockIdx.x % kStatSub) * g.sub_stride +
-                                ((size_t)b * g.G + grp) * kStatWords;
-                stat_bins_add(sp, s1);
-                stat_bins_add(sp + kStatBins, q1);
+                                ((size_t)b * g.G + grp) * kStatWords + k;
+                atomicAdd(reinterpret_cast<unsigned long long*>(sp), (unsigned long long)v);
             }
         }
     }
@@ -780,6 +865,16 @@ __global__ __launch_bounds__(256) void cm_to_tm_kernel(const float* __restrict__
     }
 }
 
+// y[b][c][t] = x[b][t][c] (diagnostic entry only: the bf16-pipe conv writes time-major)
+__global__ __launch_bounds__(256) void tm_to_cm_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int T,
+                                                       size_t total) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const size_t b = idx / ((size_t)C * T), rem = idx - b * (size_t)C * T;
+    const int cc = (int)(rem / T), t = (int)(rem - (size_t)cc * T);
+    y[idx] = x[(b * T + t) * C + cc];
+}
+
 // nn.Upsample(mode='nearest', scale_factor=r) on time-major rows: y[b][t][:] = x[b][t / r][:]
 __global__ __launch_bounds__(256) void upsample_rows_tm_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                int C, int T, int r, size_t total4) {
@@ -801,8 +896,7 @@ int launch_tm_cfg(ConvTmArgs a, int B, bool dil, hipStream_t s) {
     const size_t red = KS > 1 ? size_t(2 * KS * RS) * (MB / RS) * NB * 256 * sizeof(float) : 0;
     // the statistics scratch ([2][waves][NB][4 or 16] floats, conv_tm_kernel) lives behind the reduction slabs
     // inside the ring when it fits: extra bytes would cost the 80-KiB split-K-4 ring its second workgroup per CU
-    const bool quad = !a.stats || ((a.Cout / a.G) & 3) == 0;
-    const size_t gsb = a.stats ? (size_t)2 * (2 * KS * RS) * NB * (quad ? 4 : 16) * sizeof(float) : 0;
+    const size_t gsb = a.stats ? (size_t)16 * kStatWords * sizeof(long long) : 0;  // binned accumulators of <= 16 groups
     size_t lds = ring > red ? ring : red;
     if (KS > 1) {  // the split-K epilogue synchronises anyway; rings of 80 / 120 KiB must not grow
         a.gs_off = (int)(red / sizeof(float));
@@ -895,6 +989,9 @@ int launch_act_pad_tm(const ActPadTm& p, hipStream_t s) {
     memset(&a, 0, sizeof(a));
     a.x = p.x;
     a.y = p.y;
+    a.y3 = p.y3;
+    a.rows16 = conv_x6_rows(p.T);
+    AFTER_REQUIRE(!p.y3 || !p.state, AFTER_E_INVALID, "act_pad_tm: plane output is for whole-clip passes");
     a.stats = p.stats;
     a.gamma = p.gamma;
     a.beta = p.beta;
@@ -932,6 +1029,16 @@ int launch_act_pad_tm(const ActPadTm& p, hipStream_t s) {
     if (xcd_rows < 0) {
         const char* e = getenv("AFTER_ACT_XCD");
         xcd_rows = e ? atoi(e) : 1;
+    }
+    if (p.y3) {
+        AFTER_REQUIRE(!p.x_cm && !p.x2 && !p.scale_b && !p.pad_reflect && (a.ldx & 3) == 0 && ((uintptr_t)p.x & 15) == 0,
+                      AFTER_E_INVALID, "act_pad_tm: plane output takes plain time-major inputs");
+        const int nkb = a.Cp / 32, nrb = a.rows16 / 16;
+        int RB = 4;
+        while (RB > 1 && (long long)cdiv(nrb, RB) * nkb * p.B < 4 * 768) RB >>= 1;  // >= 3 blocks per CU where the tensor allows
+        hipLaunchKernelGGL(act_pad_x6_kernel, dim3(cdiv(cdiv(nrb, RB) * nkb, 4), p.B), dim3(256), 0, s, a, nkb, RB);
+        AFTER_HIP_CHECK(hipGetLastError());
+        return AFTER_OK;
     }
     int nb = cdiv(a.Tp, rpb);
     a.xcd_rows = xcd_rows && nb >= 64 && p.B == 1;  // measured: +1.5 % decode at one clip, -0.6 % at eight
@@ -1149,6 +1256,7 @@ struct after_convtm {
     after::ConvTmPlan plan;
     after::Arena ar;
     float *w = nullptr, *bias = nullptr, *xp = nullptr, *xtm = nullptr, *ytm = nullptr, *res = nullptr;
+    unsigned short *xp3 = nullptr, *w3 = nullptr;  // bf16-plane operands of the same layer (conv_x6.hip), where eligible
     double* stats = nullptr;
     int B, Cin, Cout, T, Tout, act;
 };
@@ -1187,7 +1295,10 @@ extern "C" int after_convtm_create(const float* w, const float* bias, int B, int
     h->act = act;
     const size_t xpn = (size_t)B * conv_tm_rows(T) * h->plan.Cp, yn = (size_t)B * Tout * Cout;
     const size_t packed = (size_t)Cout * k * pad16(Cin);
+    const bool x6 = conv_x6_eligible(h->in, h->plan);
+    const size_t xp3n = x6 ? conv_x6_plane_elems(B, T, Cin) : 0, w3n = x6 ? conv_x6_weight_elems(h->in, h->plan) : 0;
     int rc = h->ar.init((h->plan.w_floats + packed + Cout + xpn + (size_t)B * T * Cin + 2 * yn) * sizeof(float) +
+                        (xp3n + w3n) * sizeof(unsigned short) +
                         (size_t)conv_tm_stat_sub() * B * 8 * kStatWords * sizeof(double) + (1 << 16));
     auto fail = [&](int code) {
         after_convtm_destroy(h);
@@ -1202,12 +1313,17 @@ extern "C" int after_convtm_create(const float* w, const float* bias, int B, int
     h->ytm = h->ar.take<float>(yn);
     h->res = h->ar.take<float>(yn);
     h->stats = h->ar.take<double>((size_t)conv_tm_stat_sub() * B * 8 * kStatWords);
-    if (!h->stats || !h->plan.ok) {
+    if (x6) {
+        h->xp3 = h->ar.take<unsigned short>(xp3n);
+        h->w3 = h->ar.take<unsigned short>(w3n);
+    }
+    if (!h->stats || !h->plan.ok || (x6 && !h->w3)) {
         set_error("convtm: allocation failed or unsupported tap pattern");
         return fail(AFTER_E_INVALID);
     }
     if ((rc = pack_conv_weight(w, nullptr, pk, Cout, Cin, k, pad16(Cin), 0)) != AFTER_OK) return fail(rc);
     if ((rc = conv_tm_repack(pk, h->w, h->in, h->plan, 0)) != AFTER_OK) return fail(rc);
+    if (x6 && (rc = conv_x6_split(h->w, h->w3, h->in, h->plan, 0)) != AFTER_OK) return fail(rc);
     if (bias) (void)hipMemcpy(h->bias, bias, Cout * sizeof(float), hipMemcpyDeviceToDevice);
     else (void)hipMemset(h->bias, 0, Cout * sizeof(float));
     (void)hipMemset(h->res, 0, yn * sizeof(float));
@@ -1219,22 +1335,31 @@ extern "C" int after_convtm_create(const float* w, const float* bias, int B, int
 
 // mode bit 0: act_pad (x: [B][Cin][T] when given, else the handle's time-major scratch);
 // bit 1: conv (y: [B][Cout][Tout] when given, else time-major into the handle's scratch);
-// bit 2: accumulate GroupNorm statistics in the conv epilogue; bit 3: add a (zero) residual.
+// bit 2: accumulate GroupNorm statistics in the conv epilogue; bit 3: add a (zero) residual;
+// bit 4: the bf16-pipe path (conv_x6.hip: act_pad writes planes, the conv runs as split-bf16 MFMAs) -- refused
+// where the layer is not eligible.
 extern "C" int after_convtm_run(after_convtm* h, const float* x, float* y, int mode, void* stream) {
     using namespace after;
     AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
     hipStream_t s = (hipStream_t)stream;
+    const bool x6 = (mode & 16) != 0;
+    AFTER_REQUIRE(!x6 || h->w3, AFTER_E_INVALID, "convtm: this layer has no bf16-pipe form (stride 1, <= 3 taps, Cout %% 4 == 0)");
     if (mode & 1) {
         ActPadTm p;
         memset(&p, 0, sizeof(p));
         p.x = x ? x : h->xtm;
         p.y = h->xp;
+        p.y3 = x6 ? h->xp3 : nullptr;
+        if (x6 && x) {  // the plane writer takes time-major inputs
+            AFTER_TRY(launch_cm_to_tm(x, h->xtm, h->B, h->Cin, h->T, h->Cin, s));
+            p.x = h->xtm;
+        }
         p.act = h->act;
         p.B = h->B;
         p.C = h->Cin;
         p.T = h->T;
         p.G = h->Cin < 8 ? h->Cin : 8;
-        p.x_cm = x ? 1 : 0;
+        p.x_cm = (x && !x6) ? 1 : 0;
         AFTER_TRY(launch_act_pad_tm(p, s));
     }
     if (mode & 2) {
@@ -1255,6 +1380,20 @@ extern "C" int after_convtm_run(after_convtm* h, const float* x, float* y, int m
         if ((mode & 4) && h->Cout % r.G == 0) {
             AFTER_HIP_CHECK(hipMemsetAsync(h->stats, 0, (size_t)conv_tm_stat_sub() * h->B * 8 * kStatWords * sizeof(double), s));
             r.stats = h->stats;
+        }
+        if (x6) {
+            r.xp3 = h->xp3;
+            r.w3 = h->w3;
+            r.y = h->ytm;
+            r.y_cm = 0;
+            AFTER_TRY(launch_conv_x6(r, h->in, h->plan, s));
+            if (y) {
+                const size_t total = (size_t)h->B * h->Tout * h->Cout;
+                hipLaunchKernelGGL(tm_to_cm_kernel, dim3((unsigned)cdivll((long long)total, 256)), dim3(256), 0, s, h->ytm, y, h->Cout,
+                                   h->Tout, total);
+                AFTER_HIP_CHECK(hipGetLastError());
+            }
+            return AFTER_OK;
         }
         AFTER_TRY(launch_conv_tm(r, h->in, h->plan, s));
     }

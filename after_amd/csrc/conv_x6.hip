@@ -1,0 +1,405 @@
+// Stride-1 convolutions of the codec through the bf16 matrix pipe: the conv GEMM of conv_tm.hip
+//
+//   y[b, n * ostride + ooff, co] = bias[co] + res[...] + sum_{tap, ci} xp[b, HALO + n + toff0 + tap * dil, ci] * w[co, tap * Cp + ci]
+//
+// with every fp32 product formed by six exact bf16 MFMAs on three-way bf16 splits of both operands (gemm_x6.hip: fp32
+// accumulation, error vs fp64 <= the fp32 MFMA chain's; 2.67x its issue rate).  The dilated k = 3 convs, the k = 1 convs
+// and the two-tap phases of the transposed convs (reference SimpleNetsStream.py:150-194 ConvBlock1d, :51-70 Upsample1d)
+// are MFMA-bound at the sizes of the decoder's upper stages: those launches run here, the others stay on conv_tm.
+//
+// Operands: the activated, haloed input arrives as bf16 planes in x6 blocks (common.h) of a [B x rows16][Cp] matrix,
+// written by act_pad_tm (ActPadTm::y3) instead of its fp32 tensor; the weights are split once at create
+// (conv_x6_split).  A tile's A rows for tap t are the plane rows m0 + shift_t .. m0 + shift_t + BM - 1: the stage holds
+// the MB + 1 ALIGNED 16-row blocks that contain them (whole 1-KB LDS-DMA pieces whatever the shift; the x6 chunk
+// permutation depends on row % 16 only, and 16 consecutive rows from any start are bank-conflict free) and the
+// fragment reads start shift_t % 16 rows into it (gemm_x6_pipe.h, C::CONV).  Everything else -- ring, counted vmcnt,
+// one barrier per slab, side work behind individual MFMAs -- is the pipeline of gemm_x6.
+//
+// Epilogue = conv_tm's for the features these launches use: bias, residual, fp32 time-major output (strided rows for the
+// transposed-conv phases), statistics of the next GroupNorm (per-wave LDS slots added in a fixed order, binned integer
+// atomics across workgroups: conv.h).
+#include <cstdint>
+#include <cstdlib>
+
+#include "conv.h"
+#include "gemm_x6_pipe.h"
+
+namespace after {
+namespace {
+
+constexpr int kStatSubX6 = 8;  // == conv_tm_stat_sub() (checked by the launcher)
+
+struct ConvX6Args {
+    const unsigned short* A3;  // planes of [B x rows16][Cp]
+    const unsigned short* W3;  // [phases] x planes of [Cout][K]
+    const float* bias;
+    const float* res;
+    float* y;
+    double* stats;
+    int Cp, Cout, K, Tout, Nn, phases, ostride, G, sub_stride;
+    int blocks_per_clip, total_blocks, cpb, magic;
+    int y_ld, y_coff, res_ld, res_coff;
+    long long y_bs, res_bs;
+    size_t w3_phase;            // elements between the phases of W3
+    int blk0[kMaxPhases];       // first 16-row block of tap 0, relative to the tile's own block
+    int sh[kMaxPhases][3];      // row shift inside the first block, per tap
+    int dblk[kMaxPhases][3];    // blocks between tap t's and tap 0's first block
+    int ooff[kMaxPhases];
+};
+
+template <class C>
+__global__ __launch_bounds__(64 * C::NW, C::WPS) void conv_x6_kernel(ConvX6Args g, int tiles_m, int tiles_n, int xcd_pm,
+                                                                     int ny) {
+    static_assert(C::CONV == 1 && C::KS == 1 && C::OUT3 == 0 && C::ACC2 == 0, "conv tiles: one k-part, fp32 output");
+    constexpr int BM = C::BM, BN = C::BN, MT = C::MT, NT = C::NT, RS = C::RS, NW = C::NW, NS = C::NS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+    // ---- workgroup -> (clip / phase, tile): conv_tm's XCD-aware map
+    const int nwg = tiles_m * tiles_n;
+    int tm, tn, yi;
+    if (xcd_pm > 0) {
+        const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+        const int per = nwg >> 3;
+        yi = li / per;
+        const int l2 = li - yi * per;
+        const int pn = 8 / xcd_pm;
+        const int cm = tiles_m / xcd_pm, cn = tiles_n / pn;
+        const int xi = xcd % xcd_pm, xj = xcd / xcd_pm;
+        tm = xi * cm + l2 % cm;
+        tn = xj * cn + l2 / cm;
+    } else {
+        const int total = nwg * ny;
+        int bid = blockIdx.x;
+        const int xcd = bid & 7, q = total >> 3, r = total & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        yi = bid / nwg;
+        const int t = bid - yi * nwg;
+        tn = t / tiles_m;
+        tm = t - tn * tiles_m;
+    }
+    const int b = yi / g.phases, ph = yi - b * g.phases;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rp = wid % RS, cp = wid / RS;  // row part, column part (KS == 1)
+    const int M = g.Nn, N = g.Cout;
+    const int nk = g.K >> 5;
+
+    X6State<C> c;
+    c.wid = wid;
+    c.lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem_raw;
+    c.full = !C::RAGGED || (wid + NW * (C::LPS - 1) < C::P);
+    c.voff = (unsigned)lane * 16u;
+    c.magic = g.magic;
+    // tap t's A pieces: slab S = t * cpb + cb sits at K block cb of the row blocks dblk[t] further on
+    {
+        int d[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) d[t] = (g.dblk[ph][t] - t) * g.cpb * 3072;
+        c.doff[0] = __builtin_amdgcn_readfirstlane(d[0]);
+        c.doff[1] = __builtin_amdgcn_readfirstlane(d[1] - d[0]);
+        c.doff[2] = __builtin_amdgcn_readfirstlane(d[2] - d[1]);
+    }
+    {
+        const int kbw = g.K >> 5;
+        const unsigned short* w3 = g.W3 + (size_t)ph * g.w3_phase;
+        const int ablk = b * g.blocks_per_clip + (m0 >> 4) + g.blk0[ph];
+#pragma unroll
+        for (int i = 0; i < C::LPS; ++i) {
+            int p = wid + NW * i;
+            if (p >= C::P) p = C::P - 1;  // never issued (c.full == false)
+            const unsigned short* base;
+            int am;
+            if (p < C::GA) {
+                const int plane = p / C::AB, grp = p - plane * C::AB;
+                const int rb = min(ablk + grp, g.total_blocks - 1);  // past the tensor: a clamped block, rows unused
+                base = g.A3 + (((size_t)rb * g.cpb) * 3 + plane) * 512;
+                am = -1;
+            } else {
+                const int qq = p - C::GA;
+                const int plane = qq / C::NBK, grp = qq - plane * C::NBK;
+                const int rb = min((n0 >> 4) + grp, (N - 1) >> 4);
+                base = w3 + (((size_t)rb * kbw) * 3 + plane) * 512;
+                am = 0;
+            }
+            const unsigned long long v = (unsigned long long)(uintptr_t)base;
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+            c.sb[i] = ((unsigned long long)hi << 32) | lo;
+            c.amask[i] = __builtin_amdgcn_readfirstlane(am);
+        }
+    }
+    // ---- fragment addresses: lane l -> row l & 15 of a 16-row block, 16-byte chunk l >> 4 of its 64-byte row; A per
+    // tap: the window starts sh rows into the stage's first block
+    {
+        const int frow = lane & 15, kq = lane >> 4;
+        unsigned ar[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int row = rp * (BM / RS) + frow + g.sh[ph][t];
+            ar[t] = c.lds0 + (unsigned)(row * 64) + (unsigned)((kq ^ swz4((row >> 2) & 3)) * 16);
+        }
+        c.a_rd = c.a_rd3[0] = ar[0];
+        c.a_rd3[1] = ar[1] - ar[0];
+        c.a_rd3[2] = ar[2] - ar[1];
+        c.w_rd = c.lds0 + (unsigned)(C::GA * 1024 + (cp * (BN / C::CP) + frow) * 64) +
+                 (unsigned)((kq ^ swz4((frow >> 2) & 3)) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) c.acc[0][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- the residual tile is requested BEFORE the ring fill: it lands with slab 0 (vmcnt retires in order) and waits
+    // in registers, instead of an exposed round trip in the epilogue of the CU's only workgroup (measured, 384 -> 384
+    // k = 1 at eight clips: 181 us with the loads in the epilogue against 110 us without a residual)
+    const int crow = lane & 15, ccol0 = 4 * (lane >> 4);
+    const int row0 = m0 + rp * (BM / RS), col0 = n0 + cp * (BN / C::CP);
+    const float* rb = g.res ? g.res + (size_t)b * g.res_bs + g.res_coff : nullptr;
+    f32x4 rv[MT][NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            rv[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int gm = row0 + i * 16 + crow, gn = col0 + j * 16 + ccol0;
+            const int trow = gm * g.ostride + g.ooff[ph];
+            if (rb && gm < M && gn < N && trow < g.Tout) rv[i][j] = *reinterpret_cast<const f32x4*>(rb + (size_t)trow * g.res_ld + gn);
+        }
+
+    // ---- prologue: fill the ring, wait for slab 0, read its fragments; then the slab steps
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        if (s < nk) x6_issue_slab<C>(c, s, s);
+    x6_wait<C>(c, (nk < NS ? nk : NS) - 1);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    x6_sides<C, 0, C::LPS, C::NWORK, true>(c, false, true, 0, 0, c.a_rd3[0], c.w_rd);
+    int kt = 0;
+    for (; kt + 1 + NS < nk; kt += 2) {
+        x6_step<C, 0, true>(c, kt, nk);
+        x6_step<C, 1, true>(c, kt + 1, nk);
+    }
+    for (; kt < nk; kt += 2) {
+        x6_step<C, 0, false>(c, kt, nk);
+        if (kt + 1 < nk) x6_step<C, 1, false>(c, kt + 1, nk);
+    }
+
+    // ---- epilogue.  accumulator layout (W fragment as srcA): lane l holds C[row = l & 15][col = 4 (l >> 4) + r]
+    // Statistics of the next GroupNorm: every lane's partial sums go through a 16-row butterfly, then into the
+    // workgroup's binned INTEGER accumulators in LDS (ds_add_u64: exact, order-independent), whose non-zero words are
+    // added to the global accumulators (conv.h: stat_bins_add).  (conv_tm's first form -- per-wave float slots added by
+    // one lane per group in a serial loop of dependent LDS reads -- cost 8-11 us per tile.)
+    long long* lbins = reinterpret_cast<long long*>(smem_raw);  // [groups of this tile][kStatWords], over the idle ring
+    const int Cg = g.stats ? N / g.G : 4;
+    const int g0 = n0 / Cg;
+    const int ng = g.stats ? (min(n0 + BN, N) - 1) / Cg - g0 + 1 : 0;
+    if (g.stats) {
+        __syncthreads();  // every wave is past its last ring read
+        for (int i = tid; i < ng * kStatWords; i += 64 * NW) lbins[i] = 0;
+    }
+    float* yb = g.y + (size_t)b * g.y_bs + g.y_coff;
+    float ssum[NT], qsum[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int gn = col0 + j * 16 + ccol0;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias && gn < N) bv = *reinterpret_cast<const f32x4*>(g.bias + gn);  // (Cout % 4 == 0: launcher)
+        ssum[j] = qsum[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int gm = row0 + i * 16 + crow;
+            if (gm >= M || gn >= N) continue;
+            const int trow = gm * g.ostride + g.ooff[ph];
+            if (trow >= g.Tout) continue;
+            const f32x4 o = (c.acc[0][i][j] + bv) + rv[i][j];
+            *reinterpret_cast<f32x4*>(yb + (size_t)trow * g.y_ld + gn) = o;
+            ssum[j] += (o[0] + o[1]) + (o[2] + o[3]);
+            qsum[j] += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+        }
+    }
+    if (g.stats) {
+        // the 16 lanes l & 15 of a quad share the channel quad (one group: Cg % 4 == 0): butterfly over the rows
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int o2 = 1; o2 < 16; o2 <<= 1) {
+                ssum[j] += __shfl_xor(ssum[j], o2, 64);
+                qsum[j] += __shfl_xor(qsum[j], o2, 64);
+            }
+        __syncthreads();  // the bins are zero
+        if (crow == 0) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int gn = col0 + j * 16 + ccol0;
+                if (gn < N) {
+                    long long* bp = lbins + (gn / Cg - g0) * kStatWords;
+                    stat_bins_add(bp, ssum[j]);
+                    stat_bins_add(bp + kStatBins, qsum[j]);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < ng * kStatWords) {
+            const long long v = lbins[tid];
+            if (v) {
+                const int grp = g0 + tid / kStatWords, k = tid % kStatWords;
+                long long* sp = reinterpret_cast<long long*>(g.stats) + (size_t)(blockIdx.x % kStatSubX6) * g.sub_stride +
+                                ((size_t)b * g.G + grp) * kStatWords + k;
+                atomicAdd(reinterpret_cast<unsigned long long*>(sp), (unsigned long long)v);
+            }
+        }
+    }
+}
+
+// tile configurations: rows x 96 columns, eight waves (4 row parts x 2 column parts), two-stage ring
+using CfgX6_128 = X6Cfg<8, 6, 1, 4, 2, 2, 0, 1, 0, 0, 1>;   // 128 x 96: 256 workgroups for 8192 x 384 (one clip's 384-channel stage)
+using CfgX6_192 = X6Cfg<12, 6, 1, 4, 2, 2, 0, 1, 0, 0, 1>;  // 192 x 96: the many-row tile of gemm_x6 (9 accumulators per wave)
+using CfgX6_128n = X6Cfg<8, 4, 1, 4, 2, 2, 0, 1, 0, 0, 1>;  // 128 x 64: 64- and 192-channel outputs
+using CfgX6_96 = X6Cfg<6, 6, 1, 2, 2, 2, 0, 2, 0, 0, 1>;    // 96 x 96, four waves, two workgroups per CU
+using CfgX6_128s3 = X6Cfg<8, 6, 1, 4, 2, 3, 0, 1, 0, 0, 1>; // 128 x 96 with a three-stage ring
+
+template <class C>
+int launch_x6_cfg(const ConvX6Args& a, int B, hipStream_t s) {
+    const int tiles_m = cdiv(a.Nn, C::BM), tiles_n = cdiv(a.Cout, C::BN);
+    const int nwg = tiles_m * tiles_n, ny = B * a.phases;
+    size_t lds = (size_t)C::NS * C::STAGE;
+    int pm = 0;
+    if ((nwg & 7) == 0) {
+        double best = 0;
+        for (int cdv = 1; cdv <= 8; cdv *= 2) {
+            if (tiles_m % cdv || tiles_n % (8 / cdv)) continue;
+            const double cost = (double)a.Nn * a.Cp / cdv + (double)a.Cout * a.K / (8 / cdv);
+            if (pm == 0 || cost < best) {
+                pm = cdv;
+                best = cost;
+            }
+        }
+    }
+    static bool attr = false;
+    if (!attr) {
+        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x6_kernel<C>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL(conv_x6_kernel<C>, dim3(nwg * ny), dim3(64 * C::NW), lds, s, a, tiles_m, tiles_n, pm, ny);
+    AFTER_HIP_CHECK(hipGetLastError());
+    return AFTER_OK;
+}
+
+int g_x6_force = -1;  // AFTER_CONV_X6: 0 = never, 1 = by size (default), 2 = wherever eligible
+int g_x6_tile = -1;   // AFTER_CONV_X6_TILE / after_convtm_set_x6_tile: 0 = by shape, 1 = 128 x 96, 2 = 192 x 96, 3 = 128 x 64
+
+}  // namespace
+
+int conv_x6_rows(int T) { return (conv_tm_rows(T) + 15) & ~15; }
+size_t conv_x6_plane_elems(int B, int T, int C) { return (size_t)B * conv_x6_rows(T) * 3 * conv_tm_cp(C); }
+size_t conv_x6_weight_elems(const ConvDmaPlanIn& in, const ConvTmPlan& p) { return (size_t)in.phases * x6_elems(in.Cout, p.K); }
+
+bool conv_x6_eligible(const ConvDmaPlanIn& in, const ConvTmPlan& p) {
+    return p.ok && in.istride == 1 && in.taps <= 3 && (in.Cout & 3) == 0 && in.phases <= kMaxPhases;
+}
+
+int conv_x6_split(const float* w_tm, unsigned short* w3, const ConvDmaPlanIn& in, const ConvTmPlan& p, hipStream_t s) {
+    for (int ph = 0; ph < in.phases; ++ph)
+        AFTER_TRY(gemm_x6_split(w_tm + (size_t)ph * in.Cout * p.K, p.K, w3 + (size_t)ph * x6_elems(in.Cout, p.K), in.Cout, p.K, s));
+    return AFTER_OK;
+}
+
+int conv_x6_mode() {
+    if (g_x6_force < 0) {
+        const char* e = getenv("AFTER_CONV_X6");
+        g_x6_force = e ? atoi(e) : 1;
+    }
+    return g_x6_force;
+}
+
+// does this launch run on the bf16 pipe?  (the caller then hands act_pad_tm a plane buffer instead of the fp32 one)
+bool conv_x6_wins(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan& p) {
+    const int mode = conv_x6_mode();
+    if (mode == 0 || !conv_x6_eligible(in, p)) return false;
+    if (r.y2 || r.y_cm || r.res_cm || r.post_scale || r.out_act || r.bias_bstride || r.x_ld || r.x_bs) return false;
+    if (r.stats && (in.Cout % r.G || ((in.Cout / r.G) & 3) || r.G > 16)) return false;
+    if ((r.y_ld & 3) || (r.y_coff & 3) || (r.res_ld & 3) || (r.res_coff & 3)) return false;
+    if (mode >= 2) return true;
+    // MFMA-bound launches only: enough 128 x 96 tiles to fill the chip, enough K for the ring to run
+    const double wgs = (double)cdiv(r.Nn, 128) * cdiv(in.Cout, 96) * r.B * in.phases;
+    if (in.Cout % 96 && in.taps == 1) return false;  // (128 x 64 tile: no gain on the k = 1 convs of those widths)
+    return wgs >= 200 && p.K >= 256 && in.Cout >= 64;
+}
+
+int launch_conv_x6(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan& p, hipStream_t s) {
+    AFTER_REQUIRE(conv_x6_eligible(in, p) && r.xp3 && r.w3, AFTER_E_INVALID, "conv_x6: not an x6 launch");
+    AFTER_REQUIRE(conv_tm_stat_sub() == kStatSubX6, AFTER_E_INVALID, "conv_x6: statistics sub-slot count");
+    ConvX6Args a;
+    memset(&a, 0, sizeof(a));
+    a.A3 = r.xp3;
+    a.W3 = r.w3;
+    a.bias = r.bias;
+    a.res = r.res;
+    a.y = r.y;
+    a.stats = r.stats;
+    a.Cp = p.Cp;
+    a.Cout = in.Cout;
+    a.K = p.K;
+    a.Tout = r.Tout;
+    a.Nn = r.Nn;
+    a.phases = in.phases;
+    a.ostride = in.ostride;
+    a.G = r.G;
+    a.sub_stride = r.sub_stride;
+    a.cpb = p.Cp / 32;
+    a.magic = (65536 + a.cpb - 1) / a.cpb;
+    const int rows16 = (r.Tp + 15) & ~15;
+    a.blocks_per_clip = rows16 / 16;
+    a.total_blocks = r.B * a.blocks_per_clip;
+    a.y_ld = r.y_ld > 0 ? r.y_ld : in.Cout;
+    a.y_coff = r.y_coff;
+    a.y_bs = r.y_bs > 0 ? r.y_bs : (long long)r.Tout * in.Cout;
+    a.res_ld = r.res_ld > 0 ? r.res_ld : in.Cout;
+    a.res_coff = r.res_coff;
+    a.res_bs = r.res_bs > 0 ? r.res_bs : (long long)r.Tout * in.Cout;
+    a.w3_phase = x6_elems(in.Cout, p.K);
+    const int halo = conv_tm_halo();
+    for (int ph = 0; ph < in.phases; ++ph) {
+        const int s0 = halo + in.toff[ph][0];
+        a.blk0[ph] = s0 >> 4;
+        for (int t = 0; t < 3; ++t) {
+            const int st = halo + in.toff[ph][t < in.taps ? t : in.taps - 1];
+            a.sh[ph][t] = st & 15;
+            a.dblk[ph][t] = (st >> 4) - (s0 >> 4);
+        }
+        a.ooff[ph] = in.ooff[ph];
+    }
+    AFTER_REQUIRE(((uintptr_t)r.y & 15) == 0 && (!r.res || ((uintptr_t)r.res & 15) == 0) && (!r.bias || ((uintptr_t)r.bias & 15) == 0),
+                  AFTER_E_INVALID, "conv_x6: operand alignment");
+    if (g_x6_tile < 0) {
+        const char* e = getenv("AFTER_CONV_X6_TILE");
+        g_x6_tile = e ? atoi(e) : 0;
+    }
+    int t = g_x6_tile;
+    if (t == 0) {
+        // measured per layer (scripts/bench_conv.py --x6, profiles/r4_bench_conv_x6_b{1,8}.jsonl): the three-stage 128 x 96
+        // ring wins the k = 3 / two-tap launches at every size; the k = 1 convs (12-24 slabs, residual + statistics
+        // epilogue) run best as two 96 x 96 workgroups per CU once those fill the chip twice over; widths that are
+        // multiples of 64 but not of 96 take the 128 x 64 tile; 192 x 96 never won
+        const long long ny = (long long)r.B * in.phases;
+        if (in.Cout % 96 && in.Cout % 64 == 0) t = 3;
+        else if (in.taps == 1 && (double)cdiv(r.Nn, 96) * cdiv(in.Cout, 96) * ny >= 1024) t = 4;
+        else t = 5;
+    }
+    switch (t) {
+        case 1: return launch_x6_cfg<CfgX6_128>(a, r.B, s);
+        case 2: return launch_x6_cfg<CfgX6_192>(a, r.B, s);
+        case 3: return launch_x6_cfg<CfgX6_128n>(a, r.B, s);
+        case 4: return launch_x6_cfg<CfgX6_96>(a, r.B, s);
+        case 5: return launch_x6_cfg<CfgX6_128s3>(a, r.B, s);
+        default: break;
+    }
+    set_error("conv_x6: no tile configuration %d", t);
+    return AFTER_E_INVALID;
+}
+
+}  // namespace after
+
+extern "C" void after_convtm_set_x6_tile(int id) { after::g_x6_tile = id; }

@@ -100,10 +100,11 @@ class ConvTm:
         _lib.check(_lib.lib().after_convtm_run(self._h, _lib.ptr(x), _lib.ptr(y), int(mode),
                                                _lib.current_stream(dev)), "after_convtm_run")
 
-    def __call__(self, x, stats=False, residual=False):
+    def __call__(self, x, stats=False, residual=False, x6=False):
+        """x6: the bf16-pipe form of the layer (conv_x6.hip; stride-1 layers of <= 3 taps)."""
         x = _lib.require_gpu_tensor(x, "x")
         y = torch.empty(self.B, self.Cout, self.Tout, device=x.device, dtype=torch.float32)
-        self.run(x, y, 3 | (4 if stats else 0) | (8 if residual else 0))
+        self.run(x, y, 3 | (4 if stats else 0) | (8 if residual else 0) | (16 if x6 else 0))
         return y
 
     def close(self):
@@ -120,3 +121,8 @@ class ConvTm:
 
 def set_conv_tile(tile_id: int):
     _lib.lib().after_convtm_set_tile(int(tile_id))
+
+
+def set_conv_x6_tile(tile_id: int):
+    """Tile of the bf16-pipe convs: 0 = by shape, 1 = 128 x 96, 2 = 192 x 96, 3 = 128 x 64."""
+    _lib.lib().after_convtm_set_x6_tile(int(tile_id))

@@ -471,7 +471,8 @@ int after_gemm_x6(const unsigned short* A3, const unsigned short* W3, const floa
  * y[b, co, n] = bias[co] + sum_{t, ci} w[co, ci, t] act(x)[b, ci, n*stride + t*dil - left_pad] (0 outside).
  * act: 0 none, 1 snake(alpha = beta = 1), 2 SiLU, 3 ReLU, 4 tanh.
  * run mode bits: 1 activate + halo (x [B][Cin][T] or NULL = internal buffer), 2 conv (y [B][Cout][Tout]
- * or NULL = internal time-major buffer), 4 fused GroupNorm statistics, 8 residual add. */
+ * or NULL = internal time-major buffer), 4 fused GroupNorm statistics, 8 residual add, 16 the bf16-pipe form of the
+ * layer (conv_x6.hip: stride 1, <= 3 taps, Cout % 4 == 0; refused otherwise). */
 typedef struct after_convtm after_convtm;
 int after_convtm_create(const float* w, const float* bias, int B, int Cin, int Cout, int T, int Tout,
                         int k, int dil, int stride, int left_pad, int act, after_convtm** out);
@@ -479,6 +480,9 @@ int after_convtm_run(after_convtm* h, const float* x, float* y, int mode, void* 
 void after_convtm_destroy(after_convtm* h);
 /* 0 = heuristic; 1..11 pin a tile configuration (conv_tm.hip: launch_tm_id) */
 void after_convtm_set_tile(int id);
+/* tile of the bf16-pipe form of the layer (after_convtm_run mode bit 4; conv_x6.hip): 0 = by shape, 1 = 128 x 96,
+   2 = 192 x 96, 3 = 128 x 64 */
+void after_convtm_set_x6_tile(int id);
 
 #ifdef __cplusplus
 }

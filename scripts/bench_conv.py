@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--tiles", default="0,1,2,3,4,5,6,9,15,16")
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--layers", default="")
+    ap.add_argument("--x6", action="store_true", help="also time the bf16-pipe form (conv_x6.hip) of the stride-1 layers of <= 3 taps, per x6 tile")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.set_grad_enabled(False)
@@ -88,6 +89,21 @@ def main():
             if best:
                 line[f"{tag}_best"] = best[0]
                 line[f"{tag}_best_frac"] = round(c.flops / best[1] / PEAK, 3)
+        if a.x6 and stride == 1 and k <= 3 and cout % 4 == 0:
+            t_act6 = timeit(lambda: c.run(None, None, 1 | 16), a.reps)  # activate + halo into bf16 planes
+            line["x6_act_us"] = round(t_act6 * 1e6, 1)
+            for mode, tag in ((2 | 4 | 8 | 16, "x6_full"), (2 | 16, "x6_bare"), (2 | 4 | 16, "x6_stats"), (2 | 8 | 16, "x6_res")):
+                for t in (1, 2, 3, 4, 5):
+                    diag.set_conv_x6_tile(t)
+                    try:
+                        dt = timeit(lambda: c.run(None, None, mode), a.reps)
+                        line[f"{tag}_t{t}_us"] = round(dt * 1e6, 1)
+                    except Exception:
+                        pass
+                diag.set_conv_x6_tile(0)
+            v = [line[k2] for k2 in line if k2.startswith("x6_full_t")]
+            if v:
+                line["x6_full_TF"] = round(c.flops / (min(v) * 1e-6) / 1e12, 1)
         print(json.dumps(line), flush=True)
         c.close()
 

@@ -74,3 +74,56 @@ def test_conv_tm_every_tile_configuration(tile, hip_device):
             assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item()), (tile, dil)
     finally:
         diag.set_conv_tile(0)
+
+
+X6_CASES = [
+    # B, Cin, Cout, T, k, dil, lp, rp, act      (stride 1, <= 3 taps: the layers conv_x6.hip takes)
+    (1, 384, 384, 2048, 3, 1, 1, 1, 0),
+    (2, 384, 384, 1000, 3, 3, 3, 3, 0),      # ragged length: rows past the clip in the last tile
+    (1, 384, 384, 1024, 3, 9, 9, 9, 2),
+    (2, 192, 192, 777, 3, 9, 18, 0, 2),      # causal dilated, 2 clips
+    (1, 384, 384, 512, 1, 1, 0, 0, 0),       # 1 x 1
+    (1, 768, 384, 640, 2, 1, 1, 0, 0),       # two taps (a transposed-conv phase)
+    (3, 96, 64, 300, 3, 3, 3, 3, 3),         # 64-column tile, ragged K blocks (Cin = 96 = 3 blocks)
+    (1, 40, 72, 130, 3, 1, 1, 1, 3),         # ragged everything
+]
+
+
+@pytest.mark.parametrize("case", X6_CASES)
+def test_conv_x6_matches_torch(case, hip_device):
+    """The same layers through the bf16 matrix pipe (six exact bf16 MFMAs per fp32 product on three-way bf16 splits,
+    conv_x6.hip) against the fp64 conv: same bar as the fp32 MFMA path, and at least as close to fp64 as it on the
+    MFMA-bound shapes."""
+    B, Cin, Cout, T, k, dil, lp, rp, act = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, k, generator=g) / (Cin * k) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    want = ref_conv(x, w, b, dil, 1, lp, rp, act)
+    c = diag.ConvTm(w.to(hip_device), b.to(hip_device), B, T, dil, 1, lp, rp, act)
+    assert c.Tout == want.shape[-1]
+    scale = max(1.0, want.abs().max().item())
+    got = c(x.to(hip_device), x6=True).cpu().double()
+    assert (got - want).abs().max().item() < 2e-5 * scale
+    got2 = c(x.to(hip_device), stats=Cout % min(Cout, 8) == 0 and (Cout // min(Cout, 8)) % 4 == 0, residual=True, x6=True).cpu().double()
+    assert (got2 - want).abs().max().item() < 2e-5 * scale
+    ref32 = c(x.to(hip_device)).cpu().double()
+    e6, e32 = (got - want).abs().max().item(), (ref32 - want).abs().max().item()
+    assert e6 <= 3 * e32 + 1e-6 * scale, (e6, e32)  # (one accumulation chain here, two k-parts there on some shapes)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3])
+def test_conv_x6_every_tile(tile, hip_device, monkeypatch):
+    g = torch.Generator().manual_seed(tile)
+    B, Cin, Cout, T = 2, 128, 192, 700
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, 3, generator=g) / (Cin * 3) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    want = ref_conv(x, w, b, 3, 1, 3, 3, 0)
+    c = diag.ConvTm(w.to(hip_device), b.to(hip_device), B, T, 3, 1, 3, 3, 0)
+    try:
+        diag.set_conv_x6_tile(tile)
+        got = c(x.to(hip_device), stats=True, x6=True).cpu().double()
+    finally:
+        diag.set_conv_x6_tile(0)
+    assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
