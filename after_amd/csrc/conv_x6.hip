@@ -50,8 +50,8 @@ struct ConvX6Args {
 template <class C>
 __global__ __launch_bounds__(64 * C::NW, C::WPS) void conv_x6_kernel(ConvX6Args g, int tiles_m, int tiles_n, int xcd_pm,
                                                                      int ny) {
-    static_assert(C::CONV == 1 && C::KS == 1 && C::OUT3 == 0 && C::ACC2 == 0, "conv tiles: one k-part, fp32 output");
-    constexpr int BM = C::BM, BN = C::BN, MT = C::MT, NT = C::NT, RS = C::RS, NW = C::NW, NS = C::NS;
+    static_assert(C::CONV == 1 && C::OUT3 == 0 && C::ACC2 == 0, "conv tiles: fp32 output");
+    constexpr int BM = C::BM, BN = C::BN, MT = C::MT, NT = C::NT, KS = C::KS, RS = C::RS, NW = C::NW, NS = C::NS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
     // ---- workgroup -> (clip / phase, tile): conv_tm's XCD-aware map
@@ -81,9 +81,9 @@ __global__ __launch_bounds__(64 * C::NW, C::WPS) void conv_x6_kernel(ConvX6Args 
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rp = wid % RS, cp = wid / RS;  // row part, column part (KS == 1)
+    const int kh = wid % KS, rp = (wid / KS) % RS, cp = wid / (KS * RS);  // k-part, row part, column part
     const int M = g.Nn, N = g.Cout;
-    const int nk = g.K >> 5;
+    const int nk = (g.K >> 5) / KS;  // slabs per k-part
 
     X6State<C> c;
     c.wid = wid;
@@ -100,6 +100,7 @@ __global__ __launch_bounds__(64 * C::NW, C::WPS) void conv_x6_kernel(ConvX6Args 
         c.doff[1] = __builtin_amdgcn_readfirstlane(d[1] - d[0]);
         c.doff[2] = __builtin_amdgcn_readfirstlane(d[2] - d[1]);
     }
+    c.kslab_w = kh * nk;
     {
         const int kbw = g.K >> 5;
         const unsigned short* w3 = g.W3 + (size_t)ph * g.w3_phase;
@@ -108,20 +109,22 @@ __global__ __launch_bounds__(64 * C::NW, C::WPS) void conv_x6_kernel(ConvX6Args 
         for (int i = 0; i < C::LPS; ++i) {
             int p = wid + NW * i;
             if (p >= C::P) p = C::P - 1;  // never issued (c.full == false)
+            const int kp = p / C::PPK, q = p - kp * C::PPK;
             const unsigned short* base;
             int am;
-            if (p < C::GA) {
-                const int plane = p / C::AB, grp = p - plane * C::AB;
+            if (q < C::GA) {
+                const int plane = q / C::AB, grp = q - plane * C::AB;
                 const int rb = min(ablk + grp, g.total_blocks - 1);  // past the tensor: a clamped block, rows unused
-                base = g.A3 + (((size_t)rb * g.cpb) * 3 + plane) * 512;
+                base = g.A3 + (((size_t)rb * g.cpb) * 3 + plane) * 512 + (size_t)kp * nk * 1536;
                 am = -1;
             } else {
-                const int qq = p - C::GA;
+                const int qq = q - C::GA;
                 const int plane = qq / C::NBK, grp = qq - plane * C::NBK;
                 const int rb = min((n0 >> 4) + grp, (N - 1) >> 4);
-                base = w3 + (((size_t)rb * kbw) * 3 + plane) * 512;
+                base = w3 + (((size_t)rb * kbw + (size_t)kp * nk) * 3 + plane) * 512;
                 am = 0;
             }
+            c.kslab[i] = __builtin_amdgcn_readfirstlane(kp * nk);
             const unsigned long long v = (unsigned long long)(uintptr_t)base;
             const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
             const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
@@ -137,12 +140,12 @@ __global__ __launch_bounds__(64 * C::NW, C::WPS) void conv_x6_kernel(ConvX6Args 
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const int row = rp * (BM / RS) + frow + g.sh[ph][t];
-            ar[t] = c.lds0 + (unsigned)(row * 64) + (unsigned)((kq ^ swz4((row >> 2) & 3)) * 16);
+            ar[t] = c.lds0 + (unsigned)(kh * C::PART + row * 64) + (unsigned)((kq ^ swz4((row >> 2) & 3)) * 16);
         }
         c.a_rd = c.a_rd3[0] = ar[0];
         c.a_rd3[1] = ar[1] - ar[0];
         c.a_rd3[2] = ar[2] - ar[1];
-        c.w_rd = c.lds0 + (unsigned)(C::GA * 1024 + (cp * (BN / C::CP) + frow) * 64) +
+        c.w_rd = c.lds0 + (unsigned)(kh * C::PART + C::GA * 1024 + (cp * (BN / C::CP) + frow) * 64) +
                  (unsigned)((kq ^ swz4((frow >> 2) & 3)) * 16);
     }
 #pragma unroll
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(64 * C::NW, C::WPS) void conv_x6_kernel(ConvX6Args 
             rv[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int gm = row0 + i * 16 + crow, gn = col0 + j * 16 + ccol0;
             const int trow = gm * g.ostride + g.ooff[ph];
-            if (rb && gm < M && gn < N && trow < g.Tout) rv[i][j] = *reinterpret_cast<const f32x4*>(rb + (size_t)trow * g.res_ld + gn);
+            if (rb && (i * NT + j) % KS == kh && gm < M && gn < N && trow < g.Tout) rv[i][j] = *reinterpret_cast<const f32x4*>(rb + (size_t)trow * g.res_ld + gn);
         }
 
     // ---- prologue: fill the ring, wait for slab 0, read its fragments; then the slab steps
@@ -174,7 +177,11 @@ __global__ __launch_bounds__(64 * C::NW, C::WPS) void conv_x6_kernel(ConvX6Args 
     x6_wait<C>(c, (nk < NS ? nk : NS) - 1);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    x6_sides<C, 0, C::LPS, C::NWORK, true>(c, false, true, 0, 0, c.a_rd3[0], c.w_rd);
+    {
+        const int t0 = x6_tap<C>(c, c.kslab_w);
+        const unsigned a0 = c.a_rd3[0] + (c.a_rd3[1] & (unsigned)((0 - t0) >> 31)) + (c.a_rd3[2] & (unsigned)((1 - t0) >> 31));
+        x6_sides<C, 0, C::LPS, C::NWORK, true>(c, false, true, 0, 0, a0, c.w_rd);
+    }
     int kt = 0;
     for (; kt + 1 + NS < nk; kt += 2) {
         x6_step<C, 0, true>(c, kt, nk);
@@ -190,14 +197,26 @@ __global__ __launch_bounds__(64 * C::NW, C::WPS) void conv_x6_kernel(ConvX6Args 
     // workgroup's binned INTEGER accumulators in LDS (ds_add_u64: exact, order-independent), whose non-zero words are
     // added to the global accumulators (conv.h: stat_bins_add).  (conv_tm's first form -- per-wave float slots added by
     // one lane per group in a serial loop of dependent LDS reads -- cost 8-11 us per tile.)
-    long long* lbins = reinterpret_cast<long long*>(smem_raw);  // [groups of this tile][kStatWords], over the idle ring
+    // k-parts are summed through LDS in k-part order (bit-deterministic), as in gemm_x6
+    constexpr size_t kRedBytes = KS > 1 ? (size_t)NW * MT * NT * 1024 : 0;
+    static_assert(kRedBytes + 24 * kStatWords * 8 <= (size_t)NS * C::STAGE, "epilogue scratch exceeds the ring");
+    float* red = reinterpret_cast<float*>(smem_raw);
+    long long* lbins = reinterpret_cast<long long*>(smem_raw + kRedBytes);  // [groups of this tile][kStatWords], over the idle ring
     const int Cg = g.stats ? N / g.G : 4;
     const int g0 = n0 / Cg;
     const int ng = g.stats ? (min(n0 + BN, N) - 1) / Cg - g0 + 1 : 0;
-    if (g.stats) {
-        __syncthreads();  // every wave is past its last ring read
+    if (g.stats || KS > 1) __syncthreads();  // every wave is past its last ring read
+    if (g.stats)
         for (int i = tid; i < ng * kStatWords; i += 64 * NW) lbins[i] = 0;
+    if constexpr (KS > 1) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                *reinterpret_cast<f32x4*>(red + ((wid * MT * NT + i * NT + j) * 64 + lane) * 4) = c.acc[0][i][j];
+        __syncthreads();
     }
+    const int w0 = (cp * RS + rp) * KS;  // first wave of the k-parts of this wave's blocks
     float* yb = g.y + (size_t)b * g.y_bs + g.y_coff;
     float ssum[NT], qsum[NT];
 #pragma unroll
@@ -208,11 +227,19 @@ __global__ __launch_bounds__(64 * C::NW, C::WPS) void conv_x6_kernel(ConvX6Args 
         ssum[j] = qsum[j] = 0.f;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
+            if ((i * NT + j) % KS != kh) continue;  // the blocks' k-parts are finished by one of their waves each
             const int gm = row0 + i * 16 + crow;
             if (gm >= M || gn >= N) continue;
             const int trow = gm * g.ostride + g.ooff[ph];
             if (trow >= g.Tout) continue;
-            const f32x4 o = (c.acc[0][i][j] + bv) + rv[i][j];
+            f32x4 a4 = c.acc[0][i][j];
+            if constexpr (KS > 1) {
+                a4 = *reinterpret_cast<const f32x4*>(red + ((w0 * MT * NT + i * NT + j) * 64 + lane) * 4);
+#pragma unroll
+                for (int q = 1; q < KS; ++q)
+                    a4 += *reinterpret_cast<const f32x4*>(red + (((w0 + q) * MT * NT + i * NT + j) * 64 + lane) * 4);
+            }
+            const f32x4 o = (a4 + bv) + rv[i][j];
             *reinterpret_cast<f32x4*>(yb + (size_t)trow * g.y_ld + gn) = o;
             ssum[j] += (o[0] + o[1]) + (o[2] + o[3]);
             qsum[j] += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
@@ -258,6 +285,9 @@ using CfgX6_192 = X6Cfg<12, 6, 1, 4, 2, 2, 0, 1, 0, 0, 1>;  // 192 x 96: the man
 using CfgX6_128n = X6Cfg<8, 4, 1, 4, 2, 2, 0, 1, 0, 0, 1>;  // 128 x 64: 64- and 192-channel outputs
 using CfgX6_96 = X6Cfg<6, 6, 1, 2, 2, 2, 0, 2, 0, 0, 1>;    // 96 x 96, four waves, two workgroups per CU
 using CfgX6_128s3 = X6Cfg<8, 6, 1, 4, 2, 3, 0, 1, 0, 0, 1>; // 128 x 96 with a three-stage ring
+// (32 x 96 with two k-parts -- 256 workgroups for the 768-channel stage at T = 1024 -- measured 37 us against 39 for conv_tm's
+//  split-K tile: not worth its operand conversion; dropped)
+using CfgX6_64k2 = X6Cfg<4, 6, 2, 1, 6, 2, 0, 1, 0, 0, 1>;  // 64 x 96, two k-parts, twelve waves: 256 workgroups for 4096 x 384
 
 template <class C>
 int launch_x6_cfg(const ConvX6Args& a, int B, hipStream_t s) {
@@ -324,7 +354,14 @@ bool conv_x6_wins(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan&
     if (mode >= 2) return true;
     // MFMA-bound launches only: enough 128 x 96 tiles to fill the chip, enough K for the ring to run
     const double wgs = (double)cdiv(r.Nn, 128) * cdiv(in.Cout, 96) * r.B * in.phases;
-    if (in.Cout % 96 && in.taps == 1) return false;  // (128 x 64 tile: no gain on the k = 1 convs of those widths)
+    // half-filled launches of the 128-row tile: the 64 x 96 tile with two k-parts wins the k = 3 convs (384 channels at
+    // T = 4096: 28 against 39 us), not the k = 1 ones
+    if (wgs < 200 && in.taps >= 2 && (p.K & 63) == 0 && in.Cout % 96 == 0 &&
+        (double)cdiv(r.Nn, 64) * cdiv(in.Cout, 96) * r.B * in.phases >= 200)
+        return true;
+    // widths that are not multiples of 96 (the encoder's 64 / 128 / 256 / 512) would run on the 128 x 64 tile: measured
+    // same-box, encode 1.16 -> 1.18 ms at one clip and 4.61 -> 4.71 at eight with them on this path -- they stay on conv_tm
+    if (in.Cout % 96) return false;
     return wgs >= 200 && p.K >= 256 && in.Cout >= 64;
 }
 
@@ -385,15 +422,18 @@ int launch_conv_x6(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan
         // multiples of 64 but not of 96 take the 128 x 64 tile; 192 x 96 never won
         const long long ny = (long long)r.B * in.phases;
         if (in.Cout % 96 && in.Cout % 64 == 0) t = 3;
+        else if ((double)cdiv(r.Nn, 128) * cdiv(in.Cout, 96) * ny < 200) t = 6;  // (conv_x6_wins: taps >= 2, K % 64 == 0)
         else if (in.taps == 1 && (double)cdiv(r.Nn, 96) * cdiv(in.Cout, 96) * ny >= 1024) t = 4;
         else t = 5;
     }
+    if (t == 6 && (p.K & 63)) t = 5;  // two k-parts need an even slab count
     switch (t) {
         case 1: return launch_x6_cfg<CfgX6_128>(a, r.B, s);
         case 2: return launch_x6_cfg<CfgX6_192>(a, r.B, s);
         case 3: return launch_x6_cfg<CfgX6_128n>(a, r.B, s);
         case 4: return launch_x6_cfg<CfgX6_96>(a, r.B, s);
         case 5: return launch_x6_cfg<CfgX6_128s3>(a, r.B, s);
+        case 6: return launch_x6_cfg<CfgX6_64k2>(a, r.B, s);
         default: break;
     }
     set_error("conv_x6: no tile configuration %d", t);

@@ -70,6 +70,8 @@ struct X6State {
     unsigned a_rd3[3];       // tap 0's fragment address, then the increments tap 0 -> 1, 1 -> 2
     int doff[3];             // byte offset of tap 0's A pieces relative to slab x 3072, then the increments tap 0 -> 1, 1 -> 2
     int amask[C::LPS];       // -1: piece i is an A piece, 0: a W piece
+    int kslab[C::LPS];       // first slab of piece i's k-part on the whole K axis (taps are a function of the global slab)
+    int kslab_w;             // the same for the k-part this wave computes
     int magic;
 };
 
@@ -88,7 +90,7 @@ constexpr int kAP[6] = {0, 2, 1, 0, 1, 0};
 template <class C>
 __device__ __forceinline__ unsigned long long x6_src(const X6State<C>& c, int i, int slab) {
     if constexpr (C::CONV) {
-        const int t = x6_tap<C>(c, slab);
+        const int t = x6_tap<C>(c, slab + c.kslab[i]);
         // (sign masks instead of selects: the address must stay in scalar registers)
         const int d = (c.doff[0] + (c.doff[1] & ((0 - t) >> 31)) + (c.doff[2] & ((1 - t) >> 31))) & c.amask[i];
         return c.sb[i] + (unsigned long long)(long long)(slab * 3072 + d);
@@ -223,7 +225,7 @@ __device__ __forceinline__ void x6_step(X6State<C>& c, int kt, int nk) {
     if constexpr (C::CONV) {
         // (sign masks, not selects between fields: a select of two loads becomes a load through a selected address and
         // pins the whole state in scratch memory)
-        const int t = x6_tap<C>(c, kt + 1);
+        const int t = x6_tap<C>(c, kt + 1 + c.kslab_w);
         a_base = c.a_rd3[0] + (c.a_rd3[1] & (unsigned)((0 - t) >> 31)) + (c.a_rd3[2] & (unsigned)((1 - t) >> 31));
     }
     const unsigned a_next = a_base + (unsigned)(sn * C::STAGE), w_next = c.w_rd + (unsigned)(sn * C::STAGE);

@@ -124,5 +124,5 @@ def set_conv_tile(tile_id: int):
 
 
 def set_conv_x6_tile(tile_id: int):
-    """Tile of the bf16-pipe convs: 0 = by shape, 1 = 128 x 96, 2 = 192 x 96, 3 = 128 x 64."""
+    """Tile of the bf16-pipe convs: 0 = by shape, 1..6 pin one (conv_x6.hip: launch_conv_x6)."""
     _lib.lib().after_convtm_set_x6_tile(int(tile_id))
