@@ -25,7 +25,7 @@ class AECfg(ctypes.Structure):
                                      "causal")] + [("multipliers", c_int * 9),
                                                    ("dec_multipliers", c_int * 9),
                                                    ("factors", c_int * 8), ("dilations", c_int * 8),
-                                                   ("encoder_out_channels", c_int)]
+                                                   ("encoder_out_channels", c_int), ("use_noise", c_int)]
 
 
 class Encoder1dCfg(ctypes.Structure):
@@ -95,6 +95,7 @@ SIGNATURES = {
     "after_ae_ratio": (c_int, [c_void_p]),
     "after_ae_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "after_ae_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "after_ae_set_noise": (c_int, [c_void_p, c_void_p]),
     "after_ae_decode_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "after_latent_reg": (c_int, [c_void_p, ctypes.c_longlong, ctypes.c_float, c_void_p, c_void_p]),
     "after_bottleneck_tanh": (c_int, [c_void_p, c_longlong, c_float, c_void_p]),

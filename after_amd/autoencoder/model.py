@@ -107,14 +107,29 @@ class _Encoder(nn.Module):
 
 class _Decoder(nn.Module):
 
-    def __init__(self, cout, channels, mult, factors, nd, k, zc, use_norm, use_loudness):
+    def __init__(self, cout, channels, mult, factors, nd, k, zc, use_norm, use_loudness, use_noise=False):
         super().__init__()
         mods = [_WNConv(zc, channels * mult[0], k)]
         for i, f in enumerate(factors):
             mods.append(_Up(channels * mult[i], channels * mult[i + 1], f, nd, k, use_norm))
         self.net = nn.Sequential(*mods)
-        self.synth = _Branches(_NoRes(channels * mult[-1], cout * 2 if use_loudness else cout, k,
-                                      use_norm))
+        branches = [_NoRes(channels * mult[-1], cout * 2 if use_loudness else cout, k, use_norm)]
+        if use_noise:  # SimpleNetsStream.py:622-627: NoiseGenerator(in_size, data_size=out_channels, ratios=[2,2,2], noise_bands=5)
+            self.noise_module = _NoiseGenerator(channels * mult[-1], cout)
+            branches.append(self.noise_module)
+        self.synth = _Branches(*branches)
+
+
+class _NoiseGenerator(nn.Module):
+    """Parameters of SimpleNetsStream.py:499-535 (hidden 128, ratios [2, 2, 2], 5 noise bands): plain Conv1d k = 3 at
+    `net.0 / .2 / .4` (LeakyReLU(0.2) in between) and the `target_size` buffer."""
+
+    def __init__(self, in_size, data_size, hidden=128, noise_bands=5):
+        super().__init__()
+        ch = [in_size, hidden, hidden, data_size * noise_bands]
+        self.net = nn.Sequential(nn.Conv1d(ch[0], ch[1], 3), nn.Identity(), nn.Conv1d(ch[1], ch[2], 3), nn.Identity(),
+                                 nn.Conv1d(ch[2], ch[3], 3))
+        self.register_buffer("target_size", torch.tensor(8).long())
 
 
 class _PQMF(nn.Module):
@@ -224,8 +239,8 @@ class AutoEncoder(nn.Module):
             raise NotImplementedError("a PQMF codec has in_channels = pqmf_bands")
         if pqmf_bands <= 1 and in_channels != 1:
             raise NotImplementedError("without PQMF (pqmf_bands <= 1) after_amd builds the mono codec: in_channels = 1")
-        if use_noise:
-            raise NotImplementedError("use_noise=True (NoiseGenerator) is not built (baseAE.gin: False)")
+        if use_noise and padding_mode != "centered":
+            raise NotImplementedError("use_noise=True (NoiseGenerator) is built for centred padding (whole-clip decoding)")
         if resnet_groups != 8:
             raise NotImplementedError("resnet_groups must be 8 (every shipped config)")
         self.snake = _resolve_activation(activation)
@@ -234,7 +249,7 @@ class AutoEncoder(nn.Module):
                         multipliers=list(multipliers), factors=list(factors),
                         dilations=list(dilations), kernel_size=kernel_size, use_norm=use_norm,
                         decoder_ratio=decoder_ratio, pqmf_bands=pqmf_bands,
-                        use_loudness=use_loudness, padding_mode=padding_mode)
+                        use_loudness=use_loudness, use_noise=use_noise, padding_mode=padding_mode)
         self.pqmf_bands = pqmf_bands
         self._bands = max(1, pqmf_bands)  # what the C side calls pqmf_bands: 1 = the identity bank
         self.z_channels = z_channels
@@ -248,7 +263,7 @@ class AutoEncoder(nn.Module):
         self.encoder = _Encoder(in_channels, channels, list(multipliers), list(factors), nd,
                                 kernel_size, self.encoder_out_channels, use_norm)
         self.decoder = _Decoder(in_channels, channels, self.dec_multipliers, list(factors)[::-1], nd,
-                                kernel_size, z_channels, use_norm, use_loudness)
+                                kernel_size, z_channels, use_norm, use_loudness, use_noise)
         if self.snake == "alpha":  # core.Snake: one parameter of shape [dim, 1] where SnakeBeta has two of [dim]
             for m in self.modules():
                 if isinstance(m, _Snake):
@@ -324,6 +339,9 @@ class AutoEncoder(nn.Module):
             for j in range(nd):
                 names += CB(f"{s}{j + 2}.net.branches.0.0.") + CB(f"{s}{j + 2}.net.branches.0.1.")
         names += CB("decoder.synth.branches.0.net.0.") + CB("decoder.synth.branches.0.net.1.")
+        if c["use_noise"]:  # (the module is registered twice, as in the reference: decoder.noise_module and decoder.synth.branches.1)
+            for i in (0, 2, 4):
+                names += [f"decoder.noise_module.net.{i}.weight", f"decoder.noise_module.net.{i}.bias"]
         return names
 
     def _ensure(self, batch: int, samples: int):
@@ -356,6 +374,7 @@ class AutoEncoder(nn.Module):
         cfg.kernel_size = c["kernel_size"]
         cfg.use_norm = int(c["use_norm"])
         cfg.use_loudness = int(c["use_loudness"])
+        cfg.use_noise = int(c["use_noise"])
         cfg.causal = int(c["padding_mode"] == "causal")
         for i, m in enumerate(c["multipliers"]):
             cfg.multipliers[i] = m
@@ -479,15 +498,24 @@ class AutoEncoder(nn.Module):
         return z, reg
 
     @torch.no_grad()
-    def decode(self, z, with_multi: bool = False):
+    def decode(self, z, with_multi: bool = False, noise_u=None):
         """SimpleNetsStream.py:943-954; with_multi=True also returns x_multiband, the decoder
-        output before the PQMF synthesis bank."""
+        output before the PQMF synthesis bank.  use_noise codecs: `noise_u` = the uniform [0, 1) draws of the
+        NoiseGenerator ([B, T_band / 8, bands, 8]: the reference's torch.rand_like(ir), :545); drawn here when None."""
         z = _lib.require_gpu_tensor(z, "z")
         if z.dim() != 3 or z.shape[1] != self.z_channels:
             raise ValueError(f"decode expects [B, {self.z_channels}, T], got {tuple(z.shape)}")
         B, _, T = z.shape
         h = self._ensure(B, T * self.ratio)
         x = torch.empty(B, 1, T * self.ratio, device=z.device, dtype=torch.float32)
+        if self.cfg["use_noise"]:
+            shape = (B, T * self.ratio // self._bands // 8, self._bands, 8)
+            if noise_u is None:
+                noise_u = torch.rand(shape, device=z.device, dtype=torch.float32)
+            noise_u = _lib.require_gpu_tensor(noise_u, "noise_u")
+            if tuple(noise_u.shape) != shape:
+                raise ValueError(f"noise_u must be {shape}, got {tuple(noise_u.shape)}")
+            _lib.check(_lib.lib().after_ae_set_noise(h, _lib.ptr(noise_u)), "after_ae_set_noise")
         with torch.cuda.device(z.device):
             if with_multi:
                 mb = torch.empty(B, self._bands, T * self.ratio // self._bands, device=z.device,

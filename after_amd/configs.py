@@ -91,6 +91,8 @@ AUTOENCODER["microAE_causal"] = dict(AUTOENCODER["microAE"], use_norm=False,
 # no filter bank (SimpleNetsStream.py:853-859, baseAE.gin:15 "Set to 1 if no pqmf"): the codec runs on the mono samples
 AUTOENCODER["microAE_nopqmf"] = dict(AUTOENCODER["microAE"], in_channels=1, pqmf_bands=1, multipliers=[1, 2, 4, 4],
                                      factors=[2, 4, 4])
+# the decoder's NoiseGenerator branch (SimpleNetsStream.py:499-550, :622-650; baseAE.gin binds use_noise = False)
+AUTOENCODER["microAE_noise"] = dict(AUTOENCODER["microAE"], use_noise=True)
 # the one-parameter snake of core.py:201-209 as the codec's `activation` (SimpleNetsStream.py:161,169; default: SnakeBeta)
 AUTOENCODER["microAE_snake1"] = dict(AUTOENCODER["microAE"], activation="core.Snake")
 

@@ -367,6 +367,15 @@ struct after_ae {
     std::vector<ResampleW> dec_up;
     std::vector<std::vector<ResBlockW>> dec_res;
     ConvBlockW synth0, synth1;
+    // NoiseGenerator (SimpleNetsStream.py:499-550; use_noise): three plain k = 3, stride-2 convs with LeakyReLU(0.2)
+    // between them, then filtered uniform noise added to the band signal
+    struct NoiseW {
+        float *w[3] = {nullptr, nullptr, nullptr}, *bias[3] = {nullptr, nullptr, nullptr};
+        int cin[3] = {0, 0, 0}, cout[3] = {0, 0, 0};
+        DmaConv d[3];
+    } noise;
+    float *nz[3] = {nullptr, nullptr, nullptr}, *nadd = nullptr;  // conv outputs [B][T / 2^i][C]; gated bands + noise [B][T][M]
+    const float* noise_u = nullptr;  // after_ae_set_noise: uniform [0, 1) draws [B][T / 8][M][8] for the next decode
     // workspaces
     float *buf[3] = {nullptr, nullptr, nullptr};
     size_t buf_elems = 0;
@@ -829,6 +838,7 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
         }
         c = C0 * cfg->dec_multipliers[n];
         wf += cbsz(c, out_ch, k) + cbsz(out_ch, out_ch, 1);
+        if (cfg->use_noise) wf += cbsz(c, 128, 3) + cbsz(128, 128, 3) + cbsz(128, h->M * 5, 3);
         wf += (size_t)h->M * 1024 + (size_t)h->M * h->M * 64;
     }
     int rc = h->wa.init(wf * sizeof(float) + (1 << 20));
@@ -931,6 +941,23 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
         const int c = C0 * cfg->dec_multipliers[n];
         AE_TRY(load_convblock(h, cur, h->synth0, c, out_ch, k, 1));
         AE_TRY(load_convblock(h, cur, h->synth1, out_ch, out_ch, 1, 1));
+        if (cfg->use_noise) {  // NoiseGenerator(in_size = c, data_size = M, ratios = [2, 2, 2], noise_bands = 5, hidden 128)
+            const int ch[4] = {c, 128, 128, h->M * 5};
+            for (int i = 0; i < 3; ++i) {
+                const float* w = cur.next();
+                const float* b = cur.next();
+                if (!cur.ok) break;
+                h->noise.cin[i] = ch[i];
+                h->noise.cout[i] = ch[i + 1];
+                h->noise.w[i] = h->wa.take<float>((size_t)ch[i + 1] * 3 * pad16(ch[i]));
+                if (!h->noise.w[i]) {
+                    set_error("autoencoder: weight arena exhausted");
+                    return fail(AFTER_E_NOMEM);
+                }
+                AE_TRY(pack_conv_weight(w, nullptr, h->noise.w[i], ch[i + 1], ch[i], 3, pad16(ch[i]), 0));
+                AE_TRY(copy_vec(h, &h->noise.bias[i], b, ch[i + 1]));
+            }
+        }
     }
     if (!cur.ok || cur.i != n_weights) {
         set_error("autoencoder: expected %d weight tensors, got %d", cur.i, n_weights);
@@ -991,6 +1018,17 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
         }
         AE_TRY(plan_conv(h->synth0.d, h->synth0.w, h->synth0.cin, h->synth0.cout, h->synth0.k, 1, T));
         AE_TRY(plan_conv(h->synth1.d, h->synth1.w, h->synth1.cin, h->synth1.cout, 1, 1, T));
+        if (cfg->use_noise) {  // cc.Conv1d(k = 3, stride = 2, padding = get_padding(3, 2) = (1, 1)): y[n] = sum_t w[t] x[2 n + t - 1]
+            AFTER_REQUIRE(!h->causal, AFTER_E_INVALID, "autoencoder: use_noise with causal padding is not built");
+            size_t Tn = T;
+            for (int i = 0; i < 3; ++i) {
+                int toff[kMaxPhases][kMaxTaps] = {};
+                for (int t = 0; t < 3; ++t) toff[0][t] = t - 1;
+                AE_TRY(make_dma(h, h->noise.d[i], h->noise.w[i], h->noise.cin[i], h->noise.cout[i], 3, 1, 2, 1, toff, nullptr,
+                                (int)(Tn / 2)));
+                Tn /= 2;
+            }
+        }
     }
 #undef AE_TRY
 
@@ -1031,6 +1069,10 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
         };
         upd(h->M, Tm);
         upd(out_ch, Tm);
+        if (cfg->use_noise) {
+            upd(128, Tm / 2);
+            upd(128, Tm / 4);
+        }
         for (int i = 0; i <= n; ++i) {
             upd(C0 * cfg->multipliers[i], T);
             if (i < n) T /= cfg->factors[i];
@@ -1047,12 +1089,20 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
     }
     h->xp_elems = xpe * max_batch + 4096;
     h->xp3_elems = 3 * (h->xp_elems + (size_t)max_batch * 16 * conv_tm_cp(h->cmax));
-    rc = h->ws.init(3 * h->buf_elems * sizeof(float) + 16384 + 2 * h->xp_elems * sizeof(float) + h->xp3_elems * sizeof(unsigned short) + (size_t)kStatSlots * h->stat_sub * max_batch * 8 * kStatWords * sizeof(double));
+    const size_t TmN = h->max_samples / h->M;
+    const size_t nz_elems[4] = {cfg->use_noise ? (size_t)max_batch * (TmN / 2) * 128 : 0, cfg->use_noise ? (size_t)max_batch * (TmN / 4) * 128 : 0,
+                                cfg->use_noise ? (size_t)max_batch * (TmN / 8) * h->M * 5 : 0, cfg->use_noise ? (size_t)max_batch * TmN * h->M : 0};
+    rc = h->ws.init(3 * h->buf_elems * sizeof(float) + 16384 + 2 * h->xp_elems * sizeof(float) + h->xp3_elems * sizeof(unsigned short) + (nz_elems[0] + nz_elems[1] + nz_elems[2] + nz_elems[3] + 1024) * sizeof(float) + (size_t)kStatSlots * h->stat_sub * max_batch * 8 * kStatWords * sizeof(double));
     if (rc != AFTER_OK) return fail(rc);
     for (int i = 0; i < 3; ++i) h->buf[i] = h->ws.take<float>(h->buf_elems);
     h->xp = h->ws.take<float>(h->xp_elems);
     h->xp2 = h->ws.take<float>(h->xp_elems);
     h->xp3 = h->ws.take<unsigned short>(h->xp3_elems);
+    if (cfg->use_noise) {
+        for (int i = 0; i < 3; ++i) h->nz[i] = h->ws.take<float>(nz_elems[i]);
+        h->nadd = h->ws.take<float>(nz_elems[3]);
+        if (!h->nadd) return fail(AFTER_E_NOMEM);
+    }
     h->stats_ring = h->ws.take<double>((size_t)kStatSlots * h->stat_sub * max_batch * 8 * kStatWords);
     if (!h->buf[2] || !h->xp || !h->xp2 || !h->xp3 || !h->stats_ring) return fail(AFTER_E_NOMEM);
     if (hipDeviceSynchronize() != hipSuccess) {
@@ -1405,6 +1455,56 @@ static int write_multiband(after_ae* h, hipStream_t s, const float* y, float* mb
     return AFTER_OK;
 }
 
+// NoiseGenerator.forward after its conv stack (SimpleNetsStream.py:537-550, :462-495) fused with the decoder's tail
+// (:643-650): per (clip, frame f of 8 band samples, band d)
+//   amp[k] = mod_sigmoid(a[f][5 d + k] - 5) = 2 sigmoid(.)^2.3 + 1e-7                 (core.py:7-8), k < 5
+//   h = irfft(amp) (8 samples), rolled by 4, times the periodic Hann window, rolled back = h[n] w[(n + 4) % 8]
+//   noise[n] = sum_{i <= n} (2 u[n - i] - 1) ir[i]   (fft_convolve of 8 + 8 zero-padded samples, second half kept)
+//   out[f * 8 + n][d] = y[.][d] * sigmoid(y[.][M + d]) (use_loudness; else y[.][d]) + noise[n]
+// a: [B][F][5 M] time-major conv output, u: [B][F][M][8] uniform [0, 1) draws, y: [B][8 F][ychan], out: [B][8 F][M].
+__global__ __launch_bounds__(256) void noise_synth_kernel(const float* __restrict__ a, const float* __restrict__ u,
+                                                          const float* __restrict__ y, float* __restrict__ out, int F, int M,
+                                                          int gated, int ychan) {
+    const int b = blockIdx.y;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)F * M) return;
+    const int f = (int)(idx / M), d = (int)(idx - (size_t)f * M);
+    const float* ap = a + ((size_t)b * F + f) * (5 * M) + 5 * d;
+    float amp[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const float sg = 1.0f / (1.0f + expf(-(ap[k] - 5.0f)));
+        amp[k] = 2.0f * powf(sg, 2.3f) + 1e-7f;
+    }
+    // cos(2 pi k n / 8) for k n mod 8: 1, r, 0, -r, -1, -r, 0, r with r = sqrt(1/2)
+    const float r = 0.70710678118654752f;
+    const float ct[8] = {1.f, r, 0.f, -r, -1.f, -r, 0.f, r};
+    float ir[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        float hv = amp[0] + ((n & 1) ? -amp[4] : amp[4]);
+#pragma unroll
+        for (int k = 1; k < 4; ++k) hv += 2.0f * amp[k] * ct[(k * n) & 7];
+        hv *= 0.125f;
+        const float w = 0.5f - 0.5f * ct[(n + 4) & 7];  // hann_window(8, periodic)[(n + 4) % 8]
+        ir[n] = hv * w;
+    }
+    const float4* up = reinterpret_cast<const float4*>(u + (((size_t)b * F + f) * M + d) * 8);
+    const float4 u0 = up[0], u1 = up[1];
+    const float nz[8] = {2.f * u0.x - 1.f, 2.f * u0.y - 1.f, 2.f * u0.z - 1.f, 2.f * u0.w - 1.f,
+                         2.f * u1.x - 1.f, 2.f * u1.y - 1.f, 2.f * u1.z - 1.f, 2.f * u1.w - 1.f};
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i <= n; ++i) acc += nz[n - i] * ir[i];
+        const size_t row = (size_t)b * 8 * F + (size_t)f * 8 + n;
+        float v = y[row * ychan + d];
+        if (gated) v *= 1.0f / (1.0f + expf(-y[row * ychan + M + d]));
+        out[row * M + d] = v + acc;
+    }
+}
+
 static int decode_impl(after_ae* h, const float* z, float* x, float* mb, int B, int T, void* stream) {
     AFTER_TRY(check_ae(h, B, (long long)T * (h ? h->ratio : 1)));
     AFTER_REQUIRE(z && x, AFTER_E_INVALID, "null tensor");
@@ -1440,14 +1540,45 @@ static int decode_impl(after_ae* h, const float* z, float* x, float* mb, int B, 
             t2 = o;
         }
     }
+    if (c.use_noise) {  // the noise branch reads the same tensor as the synthesis block (cc.AlignBranches, offline: no delay)
+        AFTER_REQUIRE(!h->streaming, AFTER_E_INVALID, "autoencoder: use_noise is built for whole-clip decoding");
+        AFTER_REQUIRE(h->noise_u, AFTER_E_INVALID, "autoencoder: use_noise needs the uniform draws of this call (after_ae_set_noise)");
+        AFTER_REQUIRE(T % 8 == 0, AFTER_E_INVALID, "autoencoder: use_noise needs a multiple of 8 band samples");
+        const float* src = cur;
+        int Tn = T;
+        for (int i = 0; i < 3; ++i) {
+            AFTER_TRY(run_dma(h, s, h->noise.d[i], src, nullptr, nullptr, nullptr, nullptr, nullptr, i ? ACT_LRELU : ACT_NONE,
+                              h->noise.bias[i], nullptr, h->nz[i], B, Tn, Tn / 2, Tn / 2, false, nullptr));
+            src = h->nz[i];
+            Tn /= 2;
+        }
+    }
     double* st1 = nullptr;
     AFTER_TRY(run_convblock2(h, s, h->synth0, cur, st, t1, nullptr, B, T, true, &st1, sb));
     AFTER_TRY(run_convblock2(h, s, h->synth1, t1, st1, t2, nullptr, B, T, false, nullptr));
+    if (c.use_noise) {
+        const int F = T / 8, ych = c.use_loudness ? 2 * h->M : h->M;
+        hipLaunchKernelGGL(noise_synth_kernel, dim3((unsigned)cdivll((long long)F * h->M, 256), B), dim3(256), 0, s, h->nz[2],
+                           h->noise_u, t2, h->nadd, F, h->M, c.use_loudness, ych);
+        AFTER_HIP_CHECK(hipGetLastError());
+        h->noise_u = nullptr;  // one set of draws per decode
+        AFTER_TRY(write_multiband(h, s, h->nadd, mb, B, T, 0, h->M));
+        AFTER_TRY(pqmf_inverse(h, s, h->nadd, x, B, T, 0, h->M, nullptr, true));
+        h->in_pass = false;
+        return AFTER_OK;
+    }
     const int och = c.use_loudness ? 2 * h->M : h->M;
     AFTER_TRY(write_multiband(h, s, t2, mb, B, T, c.use_loudness, och));
     AFTER_TRY(pqmf_inverse(h, s, t2, x, B, T, c.use_loudness, och, h->streaming ? h->pq_istate : nullptr, true));
     if (sb) h->dec_flip ^= 1;
     h->in_pass = false;
+    return AFTER_OK;
+}
+
+extern "C" int after_ae_set_noise(after_ae* h, const float* u) {
+    AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
+    AFTER_REQUIRE(h->cfg.use_noise, AFTER_E_INVALID, "autoencoder: this codec has no noise branch (use_noise = 0)");
+    h->noise_u = u;
     return AFTER_OK;
 }
 

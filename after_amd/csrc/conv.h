@@ -4,7 +4,7 @@
 
 namespace after {
 
-enum ConvAct { ACT_NONE = 0, ACT_SNAKE = 1, ACT_SILU = 2, ACT_RELU = 3, ACT_TANH = 4 };
+enum ConvAct { ACT_NONE = 0, ACT_SNAKE = 1, ACT_SILU = 2, ACT_RELU = 3, ACT_TANH = 4, ACT_LRELU = 5 /* LeakyReLU(0.2) */ };
 enum ConvPad { PAD_ZERO = 0, PAD_REFLECT = 1 };
 
 constexpr int kMaxTaps = 8;

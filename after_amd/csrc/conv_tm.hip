@@ -72,6 +72,8 @@ __device__ __forceinline__ float act_apply(float v, int act, float pa, float pb)
             return fmaxf(v, 0.f);
         case ACT_TANH:
             return tanhf(v);
+        case ACT_LRELU:
+            return v > 0.f ? v : 0.2f * v;
         default:
             return v;
     }

@@ -242,6 +242,10 @@ typedef struct after_ae_cfg {
     int dilations[AFTER_AE_MAX_STAGES];
     int encoder_out_channels; /* 0 = z_channels; 2 * z_channels with a VAEBottleneck (SimpleNetsStream.py:864-867):
                                * after_ae_encode then writes [B, encoder_out_channels, T]          */
+    int use_noise;            /* Decoder1d's NoiseGenerator branch (SimpleNetsStream.py:499-550, :622-650): three plain
+                               * k = 3 stride-2 convs (in -> 128 -> 128 -> 5 * pqmf_bands) on the last decoder stage's
+                               * output, filtered uniform noise added to the band signal; whole-clip decoding only,
+                               * centred padding only; every decode takes its draws from after_ae_set_noise          */
 } after_ae_cfg;
 
 /* Order of the `weights` array (reference state-dict keys).
@@ -259,6 +263,7 @@ typedef struct after_ae_cfg {
  *   decoder.net.{1+i}: SN(.net.0) WN(.net.1) then for j: CB(.net.{2+j}.net.branches.0.0)
  *                   CB(.net.{2+j}.net.branches.0.1)
  *   CB(decoder.synth.branches.0.net.0) CB(decoder.synth.branches.0.net.1)
+ *   use_noise: decoder.noise_module.net.{0,2,4}.weight [Cout, Cin, 3] and .bias, in that order (plain Conv1d, no weight norm)
  */
 typedef struct after_ae after_ae;
 
@@ -277,6 +282,10 @@ int after_ae_ratio(const after_ae* h);
 int after_ae_encode(after_ae* h, const float* x, float* z, int B, int L, void* stream);
 /* x[B, 1, T*ratio] = decode(z[B, Z, T]).  Replaces: AutoEncoder.decode (:943-954). */
 int after_ae_decode(after_ae* h, const float* z, float* x, int B, int T, void* stream);
+/* use_noise codecs: the uniform [0, 1) draws of the NEXT decode, u[B, T * ratio / (8 * pqmf_bands), pqmf_bands, 8] on
+ * the device (the reference's torch.rand_like(ir), SimpleNetsStream.py:545; the kernel forms 2 u - 1).  The pointer is
+ * consumed by that decode; a decode without it fails with AFTER_E_INVALID. */
+int after_ae_set_noise(after_ae* h, const float* u);
 /* decode(z, with_multi=True) (:943-954): additionally writes x_multiband[B, M, T*ratio/M], the
  * decoder output after the loudness gate and before the PQMF synthesis bank (:643-646). */
 int after_ae_decode_multi(after_ae* h, const float* z, float* x, float* multiband, int B, int T,

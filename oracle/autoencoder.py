@@ -132,7 +132,40 @@ def encoder_forward(sd, x, cfg):
     return F.conv1d(x, w, b)
 
 
-def decoder_forward(sd, z, cfg, norm=None):
+def mod_sigmoid(x):
+    """core.py:7-8."""
+    return 2 * torch.sigmoid(x)**2.3 + 1e-7
+
+
+def noise_generator(sd, pre, x, noise_u):
+    """SimpleNetsStream.py:499-550 (NoiseGenerator, ratios [2, 2, 2]) with :462-495 (amp_to_impulse_response,
+    fft_convolve).  noise_u: the uniform [0, 1) draws the reference takes from torch.rand_like(ir) (:545),
+    [B, T / 8, data, 8] -- an input here, so that the branch is deterministic."""
+    h = x
+    for i in (0, 2, 4):
+        h = F.conv1d(F.pad(h, get_padding(3, 2)), sd[f"{pre}net.{i}.weight"], sd[f"{pre}net.{i}.bias"], stride=2)
+        if i != 4:
+            h = F.leaky_relu(h, 0.2)
+    amp = mod_sigmoid(h - 5).permute(0, 2, 1)
+    data = noise_u.shape[2]
+    amp = amp.reshape(amp.shape[0], amp.shape[1], data, -1)
+    # amp_to_impulse_response(amp, target_size = 8)
+    a = torch.fft.irfft(torch.view_as_complex(torch.stack([amp, torch.zeros_like(amp)], -1)))
+    n = a.shape[-1]
+    a = torch.roll(a, n // 2, -1) * torch.hann_window(n, dtype=a.dtype)
+    a = F.pad(a, (0, 8 - n))
+    ir = torch.roll(a, -n // 2, -1)
+    noise = noise_u.to(ir.dtype) * 2 - 1
+    # fft_convolve(noise, ir)
+    sig = F.pad(noise, (0, noise.shape[-1]))
+    ker = F.pad(ir, (ir.shape[-1], 0))
+    out = torch.fft.irfft(torch.fft.rfft(sig) * torch.fft.rfft(ker))
+    out = out[..., out.shape[-1] // 2:]
+    out = out.permute(0, 2, 1, 3)
+    return out.reshape(out.shape[0], out.shape[1], -1)
+
+
+def decoder_forward(sd, z, cfg, norm=None, noise_u=None):
     """SimpleNetsStream.py:552-651 (Decoder1d) with UpsampleBlock1d :344-384."""
     pre = "decoder.net."
     w, b = _wn(sd, pre + "0.")
@@ -152,10 +185,19 @@ def decoder_forward(sd, z, cfg, norm=None):
             x = F.conv_transpose1d(x, w, b, stride=f, padding=f // 2)
         for j, d in enumerate(cfg["dilations"]):
             x = resnet_block(sd, f"{bp}{j + 2}.", x, cfg, d, norm=norm)
+    noise = None
+    if cfg.get("use_noise"):  # SimpleNetsStream.py:635-650: both branches read the last stage's output
+        if noise_u is None:
+            raise ValueError("use_noise: pass the uniform draws (noise_u)")
+        # the module is registered twice (decoder.noise_module, decoder.synth.branches.1: same tensors in a real
+        # checkpoint); load_state_dict leaves the later key's values in it
+        noise = noise_generator(sd, "decoder.synth.branches.1.", x, noise_u)
     x = resnet_block(sd, "decoder.synth.branches.0.", x, cfg, 1, use_res=False, norm=norm)
     if cfg["use_loudness"]:
         x, amp = x.split(x.shape[1] // 2, 1)
         x = x * torch.sigmoid(amp)
+    if noise is not None:
+        x = x + noise
     return x
 
 
@@ -165,9 +207,9 @@ def ae_encode(sd, x, cfg):
     return encoder_forward(sd, pqmf_forward(sd, x, cfg["padding_mode"]), cfg)
 
 
-def ae_decode(sd, z, cfg):
+def ae_decode(sd, z, cfg, noise_u=None):
     """SimpleNetsStream.py:943-954."""
-    return pqmf_inverse(sd, decoder_forward(sd, z, cfg), cfg["padding_mode"])
+    return pqmf_inverse(sd, decoder_forward(sd, z, cfg, noise_u=noise_u), cfg["padding_mode"])
 
 
 def tanh_bottleneck(z, scale=3.0):

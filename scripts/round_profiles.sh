@@ -28,6 +28,15 @@ done
 python scripts/bench_gemm_x6.py $O/${R}_gemm_x6_sweep.jsonl > $O/x6_sweep.log 2>&1
 python scripts/time_codec.py --rounds 30 2>/dev/null | grep workload > $O/${R}_codec.jsonl
 python scripts/time_encoders.py 2>/dev/null | grep workload >> $O/${R}_codec.jsonl
+# round 4: the bf16-pipe convs of the decoder (conv_x6.hip): same-box A/B of the codec, per-layer sweep against the fp32 kernel
+for m in 0 1 0 1; do
+  AFTER_CONV_X6=$m python scripts/time_codec.py --rounds 30 2>/dev/null | grep workload | python -c "import json,sys
+for l in sys.stdin:
+    d=json.loads(l); d['AFTER_CONV_X6']=$m; print(json.dumps(d))" >> $O/${R}_ab_conv_x6.jsonl
+done
+X6L="dec0 k3 ,dec1 k3,dec1 k1,dec2 k3 ,dec2 k1,dec3 k3,dec3 k1,up2"
+python scripts/bench_conv.py --x6 --tiles 0 --layers "$X6L" 2>/dev/null | grep layer > $O/${R}_bench_conv_x6_b1.jsonl
+python scripts/bench_conv.py --batch 8 --x6 --tiles 0 --layers "$X6L" 2>/dev/null | grep layer > $O/${R}_bench_conv_x6_b8.jsonl
 ./scripts/ubench/xcd_barrier.bin > $O/${R}_xcd_barrier.jsonl 2>/dev/null
 ./scripts/ubench/xcd_local.bin > $O/${R}_xcd_local.jsonl 2>/dev/null
 ./scripts/ubench/xcd_halo.bin > $O/${R}_xcd_halo.jsonl 2>/dev/null

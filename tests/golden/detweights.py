@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 # buffers that carry real values (filters, frequency tables, caches): never refilled
-KEEP = re.compile(r"(rotary_emb\.freqs|precomputed_pos_enc|^pqmf\.|\.pad$|k_cache$|v_cache$)")
+KEEP = re.compile(r"(rotary_emb\.freqs|precomputed_pos_enc|^pqmf\.|\.pad$|k_cache$|v_cache$|target_size$)")
 
 
 def canonical(key: str) -> str:
@@ -56,9 +56,10 @@ def fill(shapes: dict, seed: int, keep: dict = None, wg_scale: float = 1.0) -> d
     for the KEEP buffers (taken from the fixture)."""
     out = {}
     for k, s in shapes.items():
+        if keep is not None and k in keep:  # buffers the fixture stores (KEEP), and any tensor a case pinned by hand
+            out[k] = torch.as_tensor(keep[k])
+            continue
         if KEEP.search(k):
-            if keep is not None and k in keep:
-                out[k] = torch.as_tensor(keep[k])
             continue
         out[k] = fill_one(k, s, seed, wg_scale)
     return out

@@ -196,6 +196,39 @@ def ae_case(case, cfg_name, B, L, seed, wg_scale=1.0):
     save(case, meta, x=x, z=z, zin=zin, y=y, multiband=mb, pqmf_roundtrip=xr, **keepdict(keep))
 
 
+def noise_case(case="ae_micro_noise", seed=49):
+    """Decoder1d with its NoiseGenerator branch (use_noise=True, SimpleNetsStream.py:499-550, :622-650).  The branch
+    draws torch.rand_like(ir) inside forward: the draws are recorded here and stored, so that oracle and kernels are
+    compared on the reference's own noise.  The last conv's bias is pinned at +5 (stored): with the random-weight
+    default the amplitudes are mod_sigmoid(~N(0, 1) - 5) ~ 2e-5 and the branch would vanish below the test's bar."""
+    cfg = configs.autoencoder_config("microAE_noise")
+    ae = build_ae(cfg)
+    shapes, keep = refill(ae, seed)
+    sd = ae.state_dict()
+    for k in ("decoder.noise_module.net.4.bias", "decoder.synth.branches.1.net.4.bias"):
+        sd[k] = sd[k] + 5.0
+        keep[k] = sd[k].numpy().copy()
+    ae.load_state_dict(sd)
+    zin = detweights.seeded_tensor("z", (2, cfg["z_channels"], 8), seed)
+    drawn = []
+    orig = torch.rand_like
+
+    def recording(t, *a, **k):
+        u = orig(t, *a, **k)
+        drawn.append(u.clone())
+        return u
+
+    torch.rand_like = recording
+    try:
+        torch.manual_seed(seed)
+        y = ae.decode(zin)
+    finally:
+        torch.rand_like = orig
+    assert len(drawn) == 1
+    meta = dict(kind="autoencoder_noise", config="microAE_noise", seed=seed, shapes=shapes)
+    save(case, meta, zin=zin, y=y, noise_u=drawn[0], **keepdict(keep))
+
+
 def bottleneck_case(case="ae_micro_bottlenecks", seed=46):
     """The two other bottlenecks of SimpleNetsStream.py:719-785 on the micro codec: TanhBottleneck (sigma = 0:
     deterministic) through AutoEncoder.encode, and VAEBottleneck through encode(return_mean=True) -- mean and KL
@@ -463,6 +496,7 @@ CASES = {
     "ae_micro_causal": lambda: ae_case("ae_micro_causal", "microAE_causal", 1, 8192, 42),
     "ae_base": lambda: ae_case("ae_base", "baseAE", 1, 32768, 43),
     "ae_micro_bottlenecks": bottleneck_case,
+    "ae_micro_noise": noise_case,
     "ae_micro_nopqmf": lambda: ae_case("ae_micro_nopqmf", "microAE_nopqmf", 2, 4096, 47),
     "ae_micro_snake1": lambda: ae_case("ae_micro_snake1", "microAE_snake1", 2, 8192, 48),
     "ae_micro_causal_wc": lambda: ae_case("ae_micro_causal_wc", "microAE_causal", 2, 8192, 44, wg_scale=0.5),

@@ -74,7 +74,7 @@ def test_unet1d_state_dict_matches_reference_layout(case):
     net.load_state_dict(fx.state_dict(), strict=True)
 
 
-@pytest.mark.parametrize("case", ["ae_micro", "ae_micro_nopqmf", "ae_micro_snake1"])
+@pytest.mark.parametrize("case", ["ae_micro", "ae_micro_nopqmf", "ae_micro_snake1", "ae_micro_noise"])
 def test_autoencoder_state_dict_matches_reference_layout(case):
     """The codec with and without a filter bank (pqmf_bands = 1: the reference's DummyIdentity has no parameters, neither has ours):
     every key of the reference module exists with its shape; the container adds nothing but the reference's own streaming buffers."""

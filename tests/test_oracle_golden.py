@@ -180,3 +180,19 @@ def test_unet1d_matches_reference(case):
     want = fx.t("y")
     assert got.shape == want.shape
     assert max_abs(got, want) < 2e-5 * max(1.0, want.abs().max().item())
+
+
+def test_decoder_noise_branch_matches_reference():
+    """Decoder1d with use_noise=True (NoiseGenerator, SimpleNetsStream.py:499-550) on the reference's own uniform
+    draws (recorded when the fixture was generated): the oracle's branch -- convs, mod_sigmoid, irfft + window,
+    fft convolution -- against the reference's output.  The fixture pins the last conv's bias at +5 so that the
+    noise is O(0.1) of the signal, and the test checks that it is."""
+    fx = Fixture("ae_micro_noise")
+    cfg = configs.autoencoder_config(fx.meta["config"])
+    sd = fx.state_dict()
+    y = oracle.ae_decode(sd, fx.t("zin"), cfg, noise_u=fx.t("noise_u"))
+    want = fx.t("y")
+    assert y.shape == want.shape
+    assert max_abs(y, want) < 5e-5 * want.abs().max().item()
+    silent = oracle.ae_decode(sd, fx.t("zin"), dict(cfg, use_noise=False))
+    assert max_abs(silent, want) > 0.02 * want.abs().max().item()  # the branch is audible in this fixture
