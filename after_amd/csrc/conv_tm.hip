@@ -282,7 +282,11 @@ __global__ __launch_bounds__(256) void act_pad_x6_kernel(ActTmArgs a, int nkb, i
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     // waves are dealt over (row group, channel block) pairs, channel blocks fastest: no idle waves whatever Cp / 32 is
     const int nrb = a.rows16 >> 4;
-    const int wv = blockIdx.x * 4 + w;
+    // block id i runs on XCD i % 8: with xcd_rows XCD j takes the j-th eighth of the (row group, channel block) pairs --
+    // the rows XCD j's conv tiles wrote and will read (act_pad_tm_kernel, conv_x6's pm = 8 tile map)
+    int bid = blockIdx.x;
+    if (a.xcd_rows) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int wv = bid * 4 + w;
     const int kb = wv % nkb, rg = wv / nkb;
     const int r = lane >> 2, c0 = kb * 32 + 8 * (lane & 3);
     constexpr int MAXRB = 4;
@@ -1038,7 +1042,10 @@ int launch_act_pad_tm(const ActPadTm& p, hipStream_t s) {
         const int nkb = a.Cp / 32, nrb = a.rows16 / 16;
         int RB = 4;
         while (RB > 1 && (long long)cdiv(nrb, RB) * nkb * p.B < 4 * 768) RB >>= 1;  // >= 3 blocks per CU where the tensor allows
-        hipLaunchKernelGGL(act_pad_x6_kernel, dim3(cdiv(cdiv(nrb, RB) * nkb, 4), p.B), dim3(256), 0, s, a, nkb, RB);
+        int nwg = cdiv(cdiv(nrb, RB) * nkb, 4);
+        a.xcd_rows = xcd_rows && nwg >= 64 && p.B == 1;
+        if (a.xcd_rows) nwg = (nwg + 7) & ~7;
+        hipLaunchKernelGGL(act_pad_x6_kernel, dim3(nwg, p.B), dim3(256), 0, s, a, nkb, RB);
         AFTER_HIP_CHECK(hipGetLastError());
         return AFTER_OK;
     }
