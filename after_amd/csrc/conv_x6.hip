@@ -318,6 +318,7 @@ int launch_x6_cfg(const ConvX6Args& a, int B, hipStream_t s) {
 }
 
 int g_x6_force = -1;  // AFTER_CONV_X6: 0 = never, 1 = by size (default), 2 = wherever eligible
+long long g_x6_launches = 0;  // after_conv_x6_launches(): the tests check that the default path really takes this kernel
 int g_x6_tile = -1;   // AFTER_CONV_X6_TILE / after_convtm_set_x6_tile: 0 = by shape, 1 = 128 x 96, 2 = 192 x 96, 3 = 128 x 64
 
 }  // namespace
@@ -427,6 +428,7 @@ int launch_conv_x6(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan
         else t = 5;
     }
     if (t == 6 && (p.K & 63)) t = 5;  // two k-parts need an even slab count
+    ++g_x6_launches;
     switch (t) {
         case 1: return launch_x6_cfg<CfgX6_128>(a, r.B, s);
         case 2: return launch_x6_cfg<CfgX6_192>(a, r.B, s);
@@ -443,3 +445,4 @@ int launch_conv_x6(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan
 }  // namespace after
 
 extern "C" void after_convtm_set_x6_tile(int id) { after::g_x6_tile = id; }
+extern "C" long long after_conv_x6_launches(void) { return after::g_x6_launches; }

@@ -123,6 +123,11 @@ def set_conv_tile(tile_id: int):
     _lib.lib().after_convtm_set_tile(int(tile_id))
 
 
+def conv_x6_launches() -> int:
+    """Conv launches this process has sent down the bf16-pipe path (conv_x6.hip) so far."""
+    return int(_lib.lib().after_conv_x6_launches())
+
+
 def set_conv_x6_tile(tile_id: int):
     """Tile of the bf16-pipe convs: 0 = by shape, 1..6 pin one (conv_x6.hip: launch_conv_x6)."""
     _lib.lib().after_convtm_set_x6_tile(int(tile_id))

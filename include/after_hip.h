@@ -492,6 +492,9 @@ void after_convtm_set_tile(int id);
 /* tile of the bf16-pipe form of the layer (after_convtm_run mode bit 4; conv_x6.hip): 0 = by shape, 1..6 pin a tile
    (conv_x6.hip: launch_conv_x6) */
 void after_convtm_set_x6_tile(int id);
+/* number of conv launches this process has sent down the bf16-pipe path so far (diagnostic: the tests check that the
+   decoder's MFMA-bound convs take it by default and that AFTER_CONV_X6=0 keeps them off it) */
+long long after_conv_x6_launches(void);
 
 #ifdef __cplusplus
 }
