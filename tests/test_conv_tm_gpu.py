@@ -127,3 +127,17 @@ def test_conv_x6_every_tile(tile, hip_device, monkeypatch):
     finally:
         diag.set_conv_x6_tile(0)
     assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+
+
+def test_conv_x6_refuses_layers_without_a_bf16_pipe_form(hip_device):
+    """Strided convs (their rows are not contiguous in the plane layout) and k > 3 stay on conv_tm: the diagnostic entry
+    refuses mode bit 4 for them instead of silently running the fp32 kernel."""
+    from after_amd import _lib
+    g = torch.Generator().manual_seed(3)
+    for (cin, cout, k, stride) in ((64, 128, 8, 4), (64, 64, 5, 1)):
+        w = torch.randn(cout, cin, k, generator=g).to(hip_device)
+        c = diag.ConvTm(w, None, 1, 256, 1, stride, k - 1, 0, 0)
+        x = torch.randn(1, cin, 256, generator=g).to(hip_device)
+        c(x)  # the fp32 form runs
+        with pytest.raises(_lib.AFTERHipError):
+            c(x, x6=True)
