@@ -287,6 +287,8 @@ using CfgX6_96 = X6Cfg<6, 6, 1, 2, 2, 2, 0, 2, 0, 0, 1>;    // 96 x 96, four wav
 using CfgX6_128s3 = X6Cfg<8, 6, 1, 4, 2, 3, 0, 1, 0, 0, 1>; // 128 x 96 with a three-stage ring
 // (32 x 96 with two k-parts -- 256 workgroups for the 768-channel stage at T = 1024 -- measured 37 us against 39 for conv_tm's
 //  split-K tile: not worth its operand conversion; dropped)
+using CfgX6_128w = X6Cfg<8, 8, 1, 4, 2, 2, 0, 1, 0, 0, 1>;   // 128 x 128: the encoder's widths (128 / 256 / 512 channels)
+using CfgX6_128w3 = X6Cfg<8, 8, 1, 4, 2, 3, 0, 1, 0, 0, 1>;  // the same with a three-stage ring (153 KB)
 using CfgX6_64k2 = X6Cfg<4, 6, 2, 1, 6, 2, 0, 1, 0, 0, 1>;  // 64 x 96, two k-parts, twelve waves: 256 workgroups for 4096 x 384
 
 template <class C>
@@ -360,9 +362,12 @@ bool conv_x6_wins(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan&
     if (wgs < 200 && in.taps >= 2 && (p.K & 63) == 0 && in.Cout % 96 == 0 &&
         (double)cdiv(r.Nn, 64) * cdiv(in.Cout, 96) * r.B * in.phases >= 200)
         return true;
-    // widths that are not multiples of 96 (the encoder's 64 / 128 / 256 / 512) would run on the 128 x 64 tile: measured
-    // same-box, encode 1.16 -> 1.18 ms at one clip and 4.61 -> 4.71 at eight with them on this path -- they stay on conv_tm
-    if (in.Cout % 96) return false;
+    // widths that are not multiples of 96 (the encoder's 64 / 128 / 256 / 512): on the 128 x 64 tile they LOST 2 % end to
+    // end; the 128 x 128 tile wins their k = 3 convs once it fills the chip, i.e. from two clips on (eight clips: 128
+    // channels at T = 16384 129 -> 98 us, 256 at 8192 199 -> 134, 512 at 1024 97 -> 60)
+    if (in.Cout % 96)
+        return (in.Cout & 127) == 0 && in.taps >= 2 && p.K >= 256 &&
+               (double)cdiv(r.Nn, 128) * (in.Cout / 128) * r.B * in.phases >= 200;
     return wgs >= 200 && p.K >= 256 && in.Cout >= 64;
 }
 
@@ -422,7 +427,8 @@ int launch_conv_x6(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan
         // epilogue) run best as two 96 x 96 workgroups per CU once those fill the chip twice over; widths that are
         // multiples of 64 but not of 96 take the 128 x 64 tile; 192 x 96 never won
         const long long ny = (long long)r.B * in.phases;
-        if (in.Cout % 96 && in.Cout % 64 == 0) t = 3;
+        if (in.Cout % 96 && (in.Cout & 127) == 0) t = p.K >= 1536 ? 8 : 7;
+        else if (in.Cout % 96 && in.Cout % 64 == 0) t = 3;
         else if ((double)cdiv(r.Nn, 128) * cdiv(in.Cout, 96) * ny < 200) t = 6;  // (conv_x6_wins: taps >= 2, K % 64 == 0)
         else if (in.taps == 1 && (double)cdiv(r.Nn, 96) * cdiv(in.Cout, 96) * ny >= 1024) t = 4;
         else t = 5;
@@ -436,6 +442,8 @@ int launch_conv_x6(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan
         case 4: return launch_x6_cfg<CfgX6_96>(a, r.B, s);
         case 5: return launch_x6_cfg<CfgX6_128s3>(a, r.B, s);
         case 6: return launch_x6_cfg<CfgX6_64k2>(a, r.B, s);
+        case 7: return launch_x6_cfg<CfgX6_128w>(a, r.B, s);
+        case 8: return launch_x6_cfg<CfgX6_128w3>(a, r.B, s);
         default: break;
     }
     set_error("conv_x6: no tile configuration %d", t);

@@ -129,5 +129,5 @@ def conv_x6_launches() -> int:
 
 
 def set_conv_x6_tile(tile_id: int):
-    """Tile of the bf16-pipe convs: 0 = by shape, 1..6 pin one (conv_x6.hip: launch_conv_x6)."""
+    """Tile of the bf16-pipe convs: 0 = by shape, 1..8 pin one (conv_x6.hip: launch_conv_x6)."""
     _lib.lib().after_convtm_set_x6_tile(int(tile_id))

@@ -489,7 +489,7 @@ int after_convtm_run(after_convtm* h, const float* x, float* y, int mode, void* 
 void after_convtm_destroy(after_convtm* h);
 /* 0 = heuristic; 1..11 pin a tile configuration (conv_tm.hip: launch_tm_id) */
 void after_convtm_set_tile(int id);
-/* tile of the bf16-pipe form of the layer (after_convtm_run mode bit 4; conv_x6.hip): 0 = by shape, 1..6 pin a tile
+/* tile of the bf16-pipe form of the layer (after_convtm_run mode bit 4; conv_x6.hip): 0 = by shape, 1..8 pin a tile
    (conv_x6.hip: launch_conv_x6) */
 void after_convtm_set_x6_tile(int id);
 /* number of conv launches this process has sent down the bf16-pipe path so far (diagnostic: the tests check that the

@@ -93,7 +93,7 @@ def main():
             t_act6 = timeit(lambda: c.run(None, None, 1 | 16), a.reps)  # activate + halo into bf16 planes
             line["x6_act_us"] = round(t_act6 * 1e6, 1)
             for mode, tag in ((2 | 4 | 8 | 16, "x6_full"), (2 | 16, "x6_bare"), (2 | 4 | 16, "x6_stats"), (2 | 8 | 16, "x6_res")):
-                for t in (1, 2, 3, 4, 5, 6):
+                for t in (1, 2, 3, 4, 5, 6, 7, 8):
                     diag.set_conv_x6_tile(t)
                     try:
                         dt = timeit(lambda: c.run(None, None, mode), a.reps)

@@ -112,7 +112,7 @@ def test_conv_x6_matches_torch(case, hip_device):
     assert e6 <= 3 * e32 + 1e-6 * scale, (e6, e32)  # (one accumulation chain here, two k-parts there on some shapes)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_conv_x6_every_tile(tile, hip_device, monkeypatch):
     g = torch.Generator().manual_seed(tile)
     B, Cin, Cout, T = 2, 128, 192, 700
