@@ -362,12 +362,12 @@ bool conv_x6_wins(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan&
     if (wgs < 200 && in.taps >= 2 && (p.K & 63) == 0 && in.Cout % 96 == 0 &&
         (double)cdiv(r.Nn, 64) * cdiv(in.Cout, 96) * r.B * in.phases >= 200)
         return true;
-    // widths that are not multiples of 96 (the encoder's 64 / 128 / 256 / 512): on the 128 x 64 tile they LOST 2 % end to
-    // end; the 128 x 128 tile wins their k = 3 convs once it fills the chip, i.e. from two clips on (eight clips: 128
-    // channels at T = 16384 129 -> 98 us, 256 at 8192 199 -> 134, 512 at 1024 97 -> 60)
-    if (in.Cout % 96)
-        return (in.Cout & 127) == 0 && in.taps >= 2 && p.K >= 256 &&
-               (double)cdiv(r.Nn, 128) * (in.Cout / 128) * r.B * in.phases >= 200;
+    // widths that are not multiples of 96 (the encoder's 64 / 128 / 256 / 512) stay on conv_tm.  Isolated, the 128 x 128
+    // tile wins their k = 3 convs from two clips on (eight clips: 256 channels at T = 8192 199 -> 134 us, 512 at 1024
+    // 97 -> 60, on every lease); inside the encoder the gain did not reproduce from lease to lease (encode at eight clips
+    // 4.61 -> 4.41 ms on one box, 4.61 -> 4.71 on two others, the fp32 path within 0.3 % on all of them: the 1.5x
+    // larger plane tensors push the pass's working set past the 256-MB Infinity Cache).  AFTER_CONV_X6=2 runs them here.
+    if (in.Cout % 96) return false;
     return wgs >= 200 && p.K >= 256 && in.Cout >= 64;
 }
 

@@ -29,6 +29,8 @@ LAYERS = [
     ("up4 phase 192->64 @16384", 192, 64, 16384, 2, 1, 1),
     ("enc1 k3 128@16384", 128, 128, 16384, 3, 1, 1), ("enc2 k3 256@8192", 256, 256, 8192, 3, 1, 1),
     ("enc4 k3 512@1024", 512, 512, 1024, 3, 1, 1), ("enc5 k3 512@256", 512, 512, 256, 3, 1, 1),
+    ("enc1 k1 128@16384", 128, 128, 16384, 1, 1, 1), ("enc2 k1 256@8192", 256, 256, 8192, 1, 1, 1),
+    ("enc4 k1 512@1024", 512, 512, 1024, 1, 1, 1),
     ("down 256->512 f4 @4096", 256, 512, 4096, 8, 1, 4),
     ("enct k5 512@256", 512, 512, 256, 5, 1, 1), ("enct k5 256@256", 256, 256, 256, 5, 1, 1),
     ("enct k5 64@256", 64, 64, 256, 5, 1, 1), ("ecapa k3 512@128", 512, 512, 128, 3, 1, 1),
