@@ -431,7 +431,16 @@ int launch_conv_x6(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan
         else if (in.Cout % 96 && in.Cout % 64 == 0) t = 3;
         else if ((double)cdiv(r.Nn, 128) * cdiv(in.Cout, 96) * ny < 200) t = 6;  // (conv_x6_wins: taps >= 2, K % 64 == 0)
         else if (in.taps == 1 && (double)cdiv(r.Nn, 96) * cdiv(in.Cout, 96) * ny >= 1024) t = 4;
-        else t = 5;
+        else {
+            t = 5;
+            // widths that both tiles divide (384, 768): rounds of 256 workgroups x tile area, the 128 x 128 tile moving 7 %
+            // fewer operand bytes per MFMA (eight clips: 384 channels at T = 8192 300 -> 273 us, 768 at 1024 stays: 127 vs 144)
+            if ((in.Cout & 127) == 0) {
+                const double w5 = (double)cdiv(r.Nn, 128) * (in.Cout / 96) * ny, w7 = (double)cdiv(r.Nn, 128) * (in.Cout / 128) * ny;
+                const double c5 = (double)cdivll((long long)w5, 256) * 96, c7 = (double)cdivll((long long)w7, 256) * 128 * 0.93;
+                if (c7 < c5) t = 7;
+            }
+        }
     }
     if (t == 6 && (p.K & 63)) t = 5;  // two k-parts need an even slab count
     ++g_x6_launches;
