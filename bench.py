@@ -46,7 +46,7 @@ PEAK_X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 ROUND = "r4"
 # sources whose change invalidates a committed traffic measurement of the dominant GEMM
 TRAFFIC_SOURCES = ["after_amd/csrc/gemm.hip", "after_amd/csrc/gemm_x6.hip", "after_amd/csrc/gemm_pipe.h",
-                   "after_amd/csrc/denoiser.hip"]
+                   "after_amd/csrc/gemm_x6_pipe.h", "after_amd/csrc/denoiser.hip"]
 
 
 def source_hash():
