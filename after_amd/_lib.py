@@ -96,6 +96,8 @@ SIGNATURES = {
     "after_ae_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "after_ae_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "after_ae_set_noise": (c_int, [c_void_p, c_void_p]),
+    "after_ae_set_stream_lanes": (c_int, [c_void_p, c_int]),
+    "after_ae_encode_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "after_ae_decode_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "after_latent_reg": (c_int, [c_void_p, ctypes.c_longlong, ctypes.c_float, c_void_p, c_void_p]),
     "after_bottleneck_tanh": (c_int, [c_void_p, c_longlong, c_float, c_void_p]),

@@ -455,8 +455,17 @@ class AutoEncoder(nn.Module):
 
     # ------------------------------------------------------------ reference surface
     @torch.no_grad()
-    def encode(self, x, with_multi: bool = False, return_mean: bool = False):
-        """SimpleNetsStream.py:918-941 -> (z, regloss); export: z only."""
+    def set_stream_lanes(self, lane_rows: int):
+        """Two independent groups of `lane_rows` streams in this streaming encoder (see `encode(row0=...)`); call on a
+        freshly enabled / reset stream."""
+        if self._handle is None:
+            raise RuntimeError("enable_streaming first")
+        _lib.check(_lib.lib().after_ae_set_stream_lanes(self._handle, int(lane_rows)), "after_ae_set_stream_lanes")
+        self._lane_rows = int(lane_rows)
+
+    def encode(self, x, with_multi: bool = False, return_mean: bool = False, row0=None):
+        """SimpleNetsStream.py:918-941 -> (z, regloss); export: z only.  row0 (streaming codecs with lanes): the first
+        context row of this batch -- 0 or `lane_rows` for one lane, 0 with a batch of 2 x lane_rows for both."""
         vae = isinstance(self.bottleneck, VAEBottleneck)
         if return_mean and not vae:  # :932-934 is the VAEBottleneck protocol
             raise TypeError("return_mean=True needs a VAEBottleneck (the other bottlenecks take no such argument)")
@@ -473,7 +482,10 @@ class AutoEncoder(nn.Module):
         mean = None
         with torch.cuda.device(x.device):
             st = _lib.current_stream(x.device)
-            _lib.check(L_.after_ae_encode(h, _lib.ptr(x), _lib.ptr(z), B, L, st), "after_ae_encode")
+            if row0 is None:
+                _lib.check(L_.after_ae_encode(h, _lib.ptr(x), _lib.ptr(z), B, L, st), "after_ae_encode")
+            else:
+                _lib.check(L_.after_ae_encode_rows(h, _lib.ptr(x), _lib.ptr(z), B, L, int(row0), st), "after_ae_encode_rows")
             reg = torch.zeros((), device=x.device, dtype=torch.float32)
             if isinstance(self.bottleneck, ReluBottleneck):
                 # z unchanged, reg = mean(ELU(|z| - scale)) + 1 (:753-760)

@@ -404,6 +404,11 @@ struct after_ae {
     // itself: no second launch per conv), and a pass that completed flips.  pass_*: the area of the pass being issued.
     int enc_slots = 0, dec_slots = 0, nc_slots = 0;
     int enc_flip = 0, dec_flip = 0, nc_flip = 0;
+    // after_ae_set_stream_lanes: the streaming encoder's batch rows are two independent groups of `lane_rows` streams
+    // each (Streamer: structure audio, timbre audio) with their own context parity, so that ONE pass can encode both
+    // groups (rows [0, 2 lane_rows)) or either alone (rows [row0, row0 + B)); 0 = one group
+    int lane_rows = 0, enc_flip1 = 0;
+    int pass_row0 = 0;  // first state row of the pass in flight
     int pass_slots = 0;
     int* pass_flip = nullptr;
     size_t slot_elems = 0;
@@ -551,8 +556,9 @@ int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const 
     float* state_out = nullptr;
     if (h->pass_stream && state_base) {
         const int f = *h->pass_flip, slot = h->state_slot++;
-        state = state_base + ((size_t)f * h->pass_slots + slot) * h->slot_elems;
-        state_out = state_base + ((size_t)(f ^ 1) * h->pass_slots + slot) * h->slot_elems;
+        const size_t roff = (size_t)h->pass_row0 * conv_tm_halo() * conv_tm_cp(cin);  // a slot is [row][HALO][Cp] of this conv
+        state = state_base + ((size_t)f * h->pass_slots + slot) * h->slot_elems + roff;
+        state_out = state_base + ((size_t)(f ^ 1) * h->pass_slots + slot) * h->slot_elems + roff;
     }
     // x, res, y time-major [B][T][C] (x_cm / y_cm: the reference's [B][C][T] at the API edges)
     AFTER_REQUIRE((size_t)B * conv_tm_cp(cin) * conv_tm_rows(Tin) <= h->xp_elems, AFTER_E_CAPACITY,
@@ -705,6 +711,7 @@ int begin_pass(after_ae* h, hipStream_t s) {
     h->in_pass = stateful;  // (a stateless pass that fails half way leaves nothing behind)
     h->stat_slot = 0;
     h->state_slot = 0;
+    h->pass_row0 = 0;
     h->prepared = nullptr;
     h->next_alpha = h->next_invb = nullptr;
     h->next_k1 = false;
@@ -1182,6 +1189,7 @@ extern "C" int after_ae_reset_state(after_ae* h, void* stream) {
     AFTER_REQUIRE(h->sa.base || h->sn.base || h->sg.base, AFTER_E_INVALID, "autoencoder: streaming was never enabled");
     h->in_pass = false;
     h->enc_flip = h->dec_flip = h->nc_flip = 0;
+    h->enc_flip1 = 0;
     if (h->sa.base) AFTER_HIP_CHECK(hipMemsetAsync(h->sa.base, 0, h->sa.off, (hipStream_t)stream));
     if (h->sn.base) {
         AFTER_HIP_CHECK(hipMemsetAsync(h->sn.base, 0, h->sn.off, (hipStream_t)stream));
@@ -1390,10 +1398,40 @@ extern "C" int after_ae_pqmf_inverse(after_ae* h, const float* mb, float* x, int
     return pqmf_inverse(h, (hipStream_t)stream, mb, x, B, Tm, 0, h->M);
 }
 
+static int encode_impl(after_ae* h, const float* x, float* z, int B, int L, int row0, void* stream);
+
 extern "C" int after_ae_encode(after_ae* h, const float* x, float* z, int B, int L, void* stream) {
+    return encode_impl(h, x, z, B, L, 0, stream);
+}
+
+extern "C" int after_ae_set_stream_lanes(after_ae* h, int lane_rows) {
+    AFTER_REQUIRE(h && h->streaming, AFTER_E_INVALID, "autoencoder: lanes are a property of the streaming encoder (enable streaming first)");
+    AFTER_REQUIRE(lane_rows >= 0 && 2 * lane_rows <= h->max_batch, AFTER_E_CAPACITY,
+                  "autoencoder: two lanes of %d streams exceed max_batch=%d", lane_rows, h->max_batch);
+    AFTER_REQUIRE(h->enc_flip == h->enc_flip1, AFTER_E_INVALID, "autoencoder: lanes can be set on a reset stream only");
+    h->lane_rows = lane_rows;
+    return AFTER_OK;
+}
+
+extern "C" int after_ae_encode_rows(after_ae* h, const float* x, float* z, int B, int L, int row0, void* stream) {
+    AFTER_REQUIRE(h && h->streaming && h->lane_rows > 0, AFTER_E_INVALID, "autoencoder: encode_rows needs after_ae_set_stream_lanes");
+    AFTER_REQUIRE((row0 == 0 && (B <= h->lane_rows || B == 2 * h->lane_rows)) || (row0 == h->lane_rows && B <= h->lane_rows),
+                  AFTER_E_INVALID, "autoencoder: a pass covers streams of one lane (rows [0, n) or [lane, lane + n)) or both lanes in full");
+    AFTER_REQUIRE(B <= h->lane_rows || h->enc_flip == h->enc_flip1, AFTER_E_INVALID,
+                  "autoencoder: the two lanes are a chunk apart: encode them separately");
+    return encode_impl(h, x, z, B, L, row0, stream);
+}
+
+static int encode_impl(after_ae* h, const float* x, float* z, int B, int L, int row0, void* stream) {
     AFTER_TRY(check_ae(h, B, L));
     AFTER_REQUIRE(x && z, AFTER_E_INVALID, "null tensor");
+    AFTER_REQUIRE(row0 == 0 || (h->streaming && h->lane_rows > 0), AFTER_E_INVALID, "autoencoder: row offset without lanes");
+    AFTER_REQUIRE(!(h->streaming && h->lane_rows > 0) || row0 > 0 || B <= h->lane_rows || B == 2 * h->lane_rows, AFTER_E_INVALID,
+                  "autoencoder: with lanes set a pass covers one lane or both in full");
     hipStream_t s = (hipStream_t)stream;
+    const bool lane1 = h->streaming && h->lane_rows > 0 && row0 > 0;
+    const bool both = h->streaming && h->lane_rows > 0 && row0 == 0 && B == 2 * h->lane_rows;
+    AFTER_REQUIRE(!both || h->enc_flip == h->enc_flip1, AFTER_E_INVALID, "autoencoder: the two lanes are a chunk apart: encode them separately");
     const after_ae_cfg& c = h->cfg;
     const int n = c.n_stages, nd = c.n_dilations;
     int T = L / h->M;
@@ -1401,12 +1439,13 @@ extern "C" int after_ae_encode(after_ae* h, const float* x, float* z, int B, int
     // (cached non-causal encoder: the PQMF analysis stays the offline, zero-padded one per chunk, as in the
     // reference's export_stream.ts, where only `model.encoder` is the cached twin)
     AFTER_TRY(begin_pass(h, s));  // (in front of the streaming PQMF: a desynchronised stream must not advance its filter state)
-    AFTER_TRY(pqmf_forward(h, s, x, b0, B, L, h->streaming ? h->pq_fstate : nullptr, true));
+    h->pass_row0 = row0;
+    AFTER_TRY(pqmf_forward(h, s, x, b0, B, L, h->streaming ? h->pq_fstate + (size_t)row0 * (h->pq_fk > 1 ? h->pq_fk - 1 : 1) : nullptr, true));
     h->pass_cached = h->pass_gnwin = h->enc_cached;
     h->pass_stream = h->streaming || h->enc_cached;
     float* sb = h->streaming ? h->enc_state : (h->enc_cached ? h->nc_state : nullptr);
     h->pass_slots = h->streaming ? h->enc_slots : h->nc_slots;
-    h->pass_flip = h->streaming ? &h->enc_flip : &h->nc_flip;
+    h->pass_flip = h->streaming ? (lane1 ? &h->enc_flip1 : &h->enc_flip) : &h->nc_flip;
     double* st = nullptr;
     if (h->norm && !h->pass_gnwin) {  // the first GroupNorm sees the PQMF output: its producer is not a conv
         st = next_stats(h, B);
@@ -1439,6 +1478,8 @@ extern "C" int after_ae_encode(after_ae* h, const float* x, float* z, int B, int
                       h->enc_tail_invb, ACT_SNAKE, h->enc_tail.bias, nullptr, z, B, T, T, T, false,
                       nullptr, sb, 0, 1));  // z leaves in the reference's [B][Z][T] layout
     if (sb) *h->pass_flip ^= 1;  // the pass is enqueued in full: the next one reads what this one wrote
+    if (sb && both) h->enc_flip1 ^= 1;
+    h->pass_row0 = 0;
     h->in_pass = false;
     return AFTER_OK;
 }

@@ -48,10 +48,16 @@ class Streamer:
         self.encoder = blender.encoder
         self.encoder_time = blender.encoder_time
         self.emb_model_structure = emb_model
-        if not self.uses_structure_encoder:  # export_midi.py: ONE codec instance (timbre encode + decode)
+        # The reference loads the codec twice (emb_model_structure / emb_model_timbre, export.py:161-166): two streaming
+        # states of the same weights.  Here they are two LANES of one streaming encoder (after_ae_set_stream_lanes):
+        # `structure` / `timbre` encode their own lane, and `forward` encodes both in ONE pass of the codec -- its ~120
+        # launches per chunk are latency chains whose cost does not depend on the batch.  A caller-supplied second
+        # codec (other weights) keeps its own handle.
+        self._lanes = self.uses_structure_encoder and emb_model_timbre is None
+        if not self.uses_structure_encoder or self._lanes:  # (export_midi.py: ONE codec instance, timbre encode + decode)
             self.emb_model_timbre = emb_model
         else:
-            self.emb_model_timbre = emb_model_timbre if emb_model_timbre is not None else clone_codec(emb_model)
+            self.emb_model_timbre = emb_model_timbre
         self.chunk_size = int(chunk_size)
         self.n_signal_timbre = int(n_signal_timbre)
         self.latent_range = float(latent_range)
@@ -74,9 +80,13 @@ class Streamer:
                                            device=dev)
         # ---- streaming state in the handles
         chunk_samples = self.chunk_size * self.ae_ratio
-        self.emb_model_structure.enable_streaming(self.max_batch, chunk_samples)
+        self.emb_model_structure.enable_streaming((2 if self._lanes else 1) * self.max_batch, chunk_samples)
+        self.emb_model_structure.reset_state()  # (the modules may have streamed before: a Streamer starts from silence)
+        self.emb_model_structure.set_stream_lanes(self.max_batch if self._lanes else 0)
         if self.emb_model_timbre is not self.emb_model_structure:
             self.emb_model_timbre.enable_streaming(self.max_batch, chunk_samples)
+            self.emb_model_timbre.reset_state()
+        self._lane_passes = [0, 0]  # chunks each lane has seen (one pass over both needs them at the same parity)
         if self.encoder_time is not None:
             self.encoder_time.enable_streaming(self.max_batch, self.chunk_size)
         rows = 3 * (1 if share_first_stream else self.max_batch)
@@ -85,6 +95,9 @@ class Streamer:
                                         max_frames=self.chunk_size)
         self.max_nb_steps = int(max_nb_steps)
         self.blender.cfg_mode = self.cfg_mode
+        if self.encoder_time is not None:
+            self.encoder_time.reset_state()
+        self.net.reset_cache()
 
     # ------------------------------------------------------------ nn~ attribute accessors
     def get_guidance_timbre(self):
@@ -119,6 +132,7 @@ class Streamer:
             self.encoder_time.reset_state()
         self.net.reset_cache()
         self.previous_timbre.zero_()
+        self._lane_passes = [0, 0]
 
     # ------------------------------------------------------------ export.py:398-416
     @torch.no_grad()
@@ -129,7 +143,14 @@ class Streamer:
     # ------------------------------------------------------------ export.py:418-441
     @torch.no_grad()
     def timbre(self, x):
-        z = self.emb_model_timbre.encode(x)[0]
+        if self._lanes:
+            z = self.emb_model_timbre.encode(x, row0=self.max_batch)[0]
+            self._lane_passes[1] += 1
+        else:
+            z = self.emb_model_timbre.encode(x)[0]
+        return self._timbre_from_latents(z)
+
+    def _timbre_from_latents(self, z):
         n = z.shape[0]
         self.previous_timbre[:n] = torch.cat((self.previous_timbre[:n], z), -1)[..., z.shape[-1]:]
         zsem = self.encoder.forward_stream(self.previous_timbre[:n].contiguous())
@@ -138,7 +159,11 @@ class Streamer:
 
     @torch.no_grad()
     def structure(self, x):
-        z = self.emb_model_structure.encode(x)[0]
+        if self._lanes:
+            z = self.emb_model_structure.encode(x, row0=0)[0]
+            self._lane_passes[0] += 1
+        else:
+            z = self.emb_model_structure.encode(x)[0]
         return self.encoder_time.forward_stream(z)
 
     # ------------------------------------------------------------ export.py:443-455
@@ -205,8 +230,17 @@ class Streamer:
         x = _lib.require_gpu_tensor(x, "x")
         if x.dim() != 3 or x.shape[1] != 2 or x.shape[-1] != self.chunk_size * self.ae_ratio:
             raise ValueError(f"forward expects [n, 2, {self.chunk_size * self.ae_ratio}], got {tuple(x.shape)}")
-        structure = self.structure(x[:, :1].contiguous())
-        timbre = self.timbre(x[:, 1:].contiguous())
+        n = x.shape[0]
+        if self._lanes and n == self.max_batch and (self._lane_passes[0] - self._lane_passes[1]) % 2 == 0:
+            # both lanes in one pass of the codec: rows [0, n) the structure inputs, [n, 2 n) the timbre inputs
+            z2 = self.emb_model_structure.encode(x.transpose(0, 1).reshape(2 * n, 1, x.shape[-1]).contiguous(), row0=0)[0]
+            self._lane_passes[0] += 1
+            self._lane_passes[1] += 1
+            structure = self.encoder_time.forward_stream(z2[:n].contiguous())
+            timbre = self._timbre_from_latents(z2[n:].contiguous())
+        else:
+            structure = self.structure(x[:, :1].contiguous())
+            timbre = self.timbre(x[:, 1:].contiguous())
         return self.generate(torch.cat((structure, timbre), 1), noise)
 
     __call__ = forward

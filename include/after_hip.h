@@ -280,6 +280,13 @@ int after_ae_ratio(const after_ae* h);
  * Replaces: AutoEncoder.encode (SimpleNetsStream.py:918-941; the bottleneck is the
  * identity on z at inference, :753-760). */
 int after_ae_encode(after_ae* h, const float* x, float* z, int B, int L, void* stream);
+/* Two lanes of streams in ONE streaming encoder (the Streamer's structure and timbre inputs go through the same codec,
+ * export.py:161-166 loads it twice): after after_ae_set_stream_lanes(h, n) -- on a freshly enabled / reset stream,
+ * 2 n <= max_batch -- the encoder's context rows [0, n) and [n, 2 n) are independent streams groups with their own chunk
+ * parity.  after_ae_encode_rows encodes x[B, 1, L] against the context rows [row0, row0 + B): one lane (row0 = 0 or n,
+ * B <= n) or both in one pass (row0 = 0, B = 2 n; refused with AFTER_E_INVALID while the lanes are a chunk apart). */
+int after_ae_set_stream_lanes(after_ae* h, int lane_rows);
+int after_ae_encode_rows(after_ae* h, const float* x, float* z, int B, int L, int row0, void* stream);
 /* x[B, 1, T*ratio] = decode(z[B, Z, T]).  Replaces: AutoEncoder.decode (:943-954). */
 int after_ae_decode(after_ae* h, const float* z, float* x, int B, int T, void* stream);
 /* use_noise codecs: the uniform [0, 1) draws of the NEXT decode, u[B, T * ratio / (8 * pqmf_bands), pqmf_bands, 8] on

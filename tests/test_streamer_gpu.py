@@ -60,6 +60,60 @@ def test_streamer_matches_whole_stream_oracle(n, share, hip_device):
         st.reset()
 
 
+def test_streamer_forward_one_codec_pass_for_both_inputs(hip_device):
+    """`forward` encodes the structure and the timbre input in ONE pass of the codec (two lanes of one streaming encoder,
+    after_ae_set_stream_lanes) where the reference runs two copies of it; `structure` / `timbre` called on their own
+    advance their lane alone.  Any interleaving of the two ways must give the whole-stream oracle's audio -- including
+    chunks where the lanes are a call apart (then `forward` falls back to two passes) -- and a caller-supplied second
+    codec (two handles, the reference's arrangement) the same."""
+    from after_amd.streaming import clone_codec
+    model, dcfg, acfg = pipeline.build_models("micro", "microAE_causal", hip_device, seed=3)
+    ae = model.emb_model
+    ae.load_state_dict(scale_gains(ae.state_dict()))
+    sd_net, sd_enc, sd_et = split_sd(model)
+    sd_ae = {k: v.detach().cpu() for k, v in ae.state_dict().items()}
+    n, chunk, steps, n_chunks, nsig = 2, 4, 2, 6, 16
+    g = torch.Generator().manual_seed(12)
+    L = n_chunks * chunk * ae.ratio
+    xs = 0.3 * torch.randn(n, 1, L, generator=g)
+    xt = 0.3 * torch.randn(n, 1, L, generator=g)
+    noise = torch.randn(n, ae.z_channels, n_chunks * chunk, generator=g)
+    want_audio, _, _ = oracle.stream_forward(sd_net, sd_enc, sd_et, sd_ae, dcfg, acfg, xs, xt, noise, chunk, steps, 2.0, 1.5, nsig)
+    for second in (None, "clone"):
+        st = Streamer(model, ae, chunk_size=chunk, n_signal_timbre=nsig, max_batch=n, max_nb_steps=steps, share_first_stream=False,
+                      emb_model_timbre=clone_codec(ae) if second else None)
+        assert st._lanes == (second is None)
+        st.set_nb_steps(steps)
+        st.set_guidance_timbre(2.0)
+        st.set_guidance_structure(1.5)
+        outs = []
+        for c in range(n_chunks):
+            a = slice(c * chunk * ae.ratio, (c + 1) * chunk * ae.ratio)
+            x = torch.cat((xs[..., a], xt[..., a]), 1).to(hip_device)
+            nz = noise[..., c * chunk:(c + 1) * chunk].contiguous().to(hip_device)
+            if c in (0, 1, 4):
+                outs.append(st.forward(x, nz).cpu())
+            elif c == 2:  # timbre first, then structure: lanes advance one at a time
+                t = st.timbre(x[:, 1:].contiguous())
+                s_ = st.structure(x[:, :1].contiguous())
+                outs.append(st.generate(torch.cat((s_, t), 1), nz).cpu())
+            else:
+                s_ = st.structure(x[:, :1].contiguous())
+                t = st.timbre(x[:, 1:].contiguous())
+                outs.append(st.generate(torch.cat((s_, t), 1), nz).cpu())
+        y = torch.cat(outs, -1)
+        assert max_abs(y, want_audio) < 2e-4 * want_audio.abs().max().item(), (second, max_abs(y, want_audio))
+    # the C ABI refuses a pass over both lanes while they are a chunk apart
+    st = Streamer(model, ae, chunk_size=chunk, n_signal_timbre=nsig, max_batch=n, max_nb_steps=steps, share_first_stream=False)
+    x = torch.cat((xs[..., :chunk * ae.ratio], xt[..., :chunk * ae.ratio]), 1).to(hip_device)
+    st.structure(x[:, :1].contiguous())
+    from after_amd import _lib
+    with pytest.raises(_lib.AFTERHipError):
+        ae.encode(x.transpose(0, 1).reshape(2 * n, 1, -1).contiguous(), row0=0)
+    st.timbre(x[:, 1:].contiguous())
+    assert st.forward(x).shape == (n, 1, chunk * ae.ratio)
+
+
 def test_streamer_forward_shapes_and_limits(hip_device):
     model, dcfg, acfg = pipeline.build_models("micro", "microAE_causal", hip_device, seed=4)
     st = Streamer(model, model.emb_model, chunk_size=4, n_signal_timbre=16, max_batch=2, max_nb_steps=2)
