@@ -386,7 +386,6 @@ struct after_ae {
     size_t xp3_elems = 0;
     float* xp2 = nullptr;         // second one: a conv epilogue prepares the NEXT conv's input there
     const float* prepared = nullptr;  // haloed input already laid out by the producer (time-major path)
-    bool next_k1 = false;             // next_alpha belongs to a k = 1 conv (no temporal context: allowed while streaming)
     const float* next_alpha = nullptr;  // Snake of the following resampling conv: request to the next
     const float* next_invb = nullptr;   //   run_dma to emit that conv's activated input itself
     size_t xp_elems = 0;
@@ -589,7 +588,7 @@ int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const 
         const char* e = getenv("AFTER_AE_FUSE_SNAKE");
         fuse_snake = e ? atoi(e) : 1;
     }
-    if (fuse_snake && h->next_alpha && (!h->pass_stream || h->next_k1) && (cout & 31) == 0 && d.in.ostride == 1 &&
+    if (fuse_snake && h->next_alpha && !h->pass_stream && (cout & 31) == 0 && d.in.ostride == 1 &&
         (size_t)B * cout * conv_tm_rows(Tout) <= h->xp_elems) {
         r.y2 = xin == h->xp2 ? h->xp : h->xp2;
         r.y2_act = ACT_SNAKE;
@@ -599,7 +598,6 @@ int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const 
         h->prepared = r.y2;
     }
     h->next_alpha = h->next_invb = nullptr;
-    h->next_k1 = false;
     // MFMA-bound whole-clip launches run on the bf16 pipe (conv_x6.hip): their input is written as bf16 planes
     const bool x6 = !xin && d.w3 && !h->pass_stream && !x_cm && conv_x6_wins(r, d.in, d.tplan) &&
                     conv_x6_plane_elems(B, Tin, cin) <= h->xp3_elems;
@@ -684,15 +682,6 @@ int run_resblock2(after_ae* h, hipStream_t s, const ResBlockW& rb, const float* 
                           rb.to_b, nullptr, by, B, T, T, T, false, nullptr));
         res = by;
     }
-    // GroupNorm-free codecs (the causal streaming codec, baseAE.gin:32-33,49): the second ConvBlock1d's activation is a
-    // function of the first conv's output alone and its k = 1 conv keeps no temporal context, so the first conv's epilogue
-    // writes the activated tensor itself -- one act_pad launch less per ResnetBlock1d, offline and while streaming (the
-    // second haloed scratch is the delay line's while a cached non-causal pass delays the shortcut: not then)
-    if (!h->norm && !(h->pass_cached && rb.delay > 0) && !h->pass_gnwin) {
-        h->next_alpha = rb.cb1.alpha;
-        h->next_invb = rb.cb1.invb;
-        h->next_k1 = true;
-    }
     double* st1 = nullptr;
     AFTER_TRY(run_convblock2(h, s, rb.cb0, bx, *stats, bt, nullptr, B, T, true, &st1, sb));
     double* st2 = nullptr;
@@ -714,7 +703,6 @@ int begin_pass(after_ae* h, hipStream_t s) {
     h->pass_row0 = 0;
     h->prepared = nullptr;
     h->next_alpha = h->next_invb = nullptr;
-    h->next_k1 = false;
     if (h->norm)
         AFTER_HIP_CHECK(hipMemsetAsync(h->stats_ring, 0,
                                        (size_t)kStatSlots * h->stat_sub * h->max_batch * 8 * kStatWords * sizeof(double), s));
@@ -1605,11 +1593,6 @@ static int decode_impl(after_ae* h, const float* z, float* x, float* mb, int B, 
             src = h->nz[i];
             Tn /= 2;
         }
-    }
-    if (!h->norm && !h->pass_gnwin) {  // ResnetBlock1dNoRes: same pair as in run_resblock2
-        h->next_alpha = h->synth1.alpha;
-        h->next_invb = h->synth1.invb;
-        h->next_k1 = true;
     }
     double* st1 = nullptr;
     AFTER_TRY(run_convblock2(h, s, h->synth0, cur, st, t1, nullptr, B, T, true, &st1, sb));
