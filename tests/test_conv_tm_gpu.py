@@ -141,3 +141,42 @@ def test_conv_x6_refuses_layers_without_a_bf16_pipe_form(hip_device):
         c(x)  # the fp32 form runs
         with pytest.raises(_lib.AFTERHipError):
             c(x, x6=True)
+
+
+def test_conv_x6_random_shapes(hip_device):
+    """Forty seeded random stride-1 layers (taps 1-3, dilation 1-9, centred / causal / lopsided padding, channel counts
+    that are not multiples of the 32-deep K slab or of the column tiles, lengths that are not multiples of the 16-row
+    plane blocks or of the row tiles, 1-3 clips, every tile configuration in turn) through the bf16-pipe form against
+    the fp64 conv -- the row windows shifted by (tap x dilation) across 16-row plane blocks, the clamped blocks past a
+    clip's end and the masked tile edges are where this kernel could go wrong."""
+    import random
+    rnd = random.Random(1234)
+    g = torch.Generator().manual_seed(99)
+    try:
+        for it in range(40):
+            k = rnd.choice((1, 2, 3, 3))
+            dil = rnd.choice((1, 1, 2, 3, 5, 9)) if k > 1 else 1
+            span = (k - 1) * dil
+            lp = rnd.choice((span // 2, span, 0)) if span else 0
+            rp = span - lp
+            B = rnd.choice((1, 2, 3))
+            Cin = rnd.choice((24, 32, 40, 64, 96, 136, 192))
+            Cout = 4 * rnd.randint(3, 60)
+            T = rnd.choice((17, 63, 64, 100, 129, 255, 400, 513))
+            act = rnd.choice((0, 2, 3))
+            x = torch.randn(B, Cin, T, generator=g)
+            w = torch.randn(Cout, Cin, k, generator=g) / (Cin * k) ** 0.5
+            b = torch.randn(Cout, generator=g)
+            want = ref_conv(x, w, b, dil, 1, lp, rp, act)
+            c = diag.ConvTm(w.to(hip_device), b.to(hip_device), B, T, dil, 1, lp, rp, act)
+            tile = it % 9  # 0 = by shape, 1..8
+            if tile == 6 and (k * ((Cin + 31) // 32 * 32)) % 64:
+                tile = 0  # (two k-parts need an even slab count)
+            diag.set_conv_x6_tile(tile)
+            stats = Cout % min(Cout, 8) == 0 and (Cout // min(Cout, 8)) % 4 == 0
+            got = c(x.to(hip_device), stats=stats, residual=bool(it & 1), x6=True).cpu().double()
+            err = (got - want).abs().max().item()
+            assert err < 2e-5 * max(1.0, want.abs().max().item()), (it, tile, (B, Cin, Cout, T, k, dil, lp, rp, act), err)
+            c.close()
+    finally:
+        diag.set_conv_x6_tile(0)
