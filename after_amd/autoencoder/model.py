@@ -394,6 +394,8 @@ class AutoEncoder(nn.Module):
         self._cap = cap
         if getattr(self, "_streaming", False):  # a re-created handle starts a fresh stream
             _lib.check(L.after_ae_enable_streaming(out, 1), "after_ae_enable_streaming")
+            if getattr(self, "_lane_rows", 0) and 2 * self._lane_rows <= cap[0]:
+                _lib.check(L.after_ae_set_stream_lanes(out, self._lane_rows), "after_ae_set_stream_lanes")
         if getattr(self, "_dec_gn_window", None):
             _lib.check(L.after_ae_set_decoder_gn_window(out, int(self._dec_gn_window)),
                        "after_ae_set_decoder_gn_window")
