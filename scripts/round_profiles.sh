@@ -77,4 +77,5 @@ for b in 1 8; do
   done
 done
 python scripts/pmc_run.py $O/${R}_pmc_codec_b1.json -- python scripts/time_codec.py --batches 1 --rounds 3 > $O/pmc_codec.log 2>&1
+for b in 1 8; do python scripts/pmc_run.py --mfma $O/${R}_pmc_mfma_codec_b$b.json -- python scripts/time_codec.py --batches $b --rounds 3 >> $O/pmc_codec.log 2>&1; done   # matrix-pipe busy fraction of the conv kernels
 ls -la $O | head -60
