@@ -200,22 +200,35 @@ __global__ __launch_bounds__(256) void act_pad_tm_kernel(ActTmArgs a) {
     if (active) load_rows(p_lo + r);
     // raw per-channel parameters (independent of the statistics)
     float ga[4], be[4], pa[4], pb[4];
+    if (active && c0 + 3 < a.C && (a.C & 3) == 0) {  // four whole channels: one 16-byte request per parameter instead of four scalar ones
+        auto ld4 = [&](const float* p, float (&o)[4], float dflt) {
+            const f32x4 v4 = p ? *reinterpret_cast<const f32x4*>(p + c0) : f32x4{dflt, dflt, dflt, dflt};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = c0 + k;
-        ga[k] = 1.f;
-        be[k] = 0.f;
-        pa[k] = pb[k] = 0.f;
-        if (!active || c >= a.C) continue;
-        if (a.scale_b && !a.stats) {
-            ga[k] = a.scale_b[(size_t)b * a.C + c];
-            be[k] = a.shift_b[(size_t)b * a.C + c];
-        } else if (a.gamma) {
-            ga[k] = a.gamma[c];
-            be[k] = a.beta[c];
+            for (int k = 0; k < 4; ++k) o[k] = v4[k];
+        };
+        const bool per_clip = a.scale_b && !a.stats;
+        ld4(per_clip ? a.scale_b + (size_t)b * a.C : a.gamma, ga, 1.f);
+        ld4(per_clip ? a.shift_b + (size_t)b * a.C : (a.gamma ? a.beta : nullptr), be, 0.f);
+        ld4(a.act_a, pa, 0.f);
+        ld4(a.act_b, pb, 0.f);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + k;
+            ga[k] = 1.f;
+            be[k] = 0.f;
+            pa[k] = pb[k] = 0.f;
+            if (!active || c >= a.C) continue;
+            if (a.scale_b && !a.stats) {
+                ga[k] = a.scale_b[(size_t)b * a.C + c];
+                be[k] = a.shift_b[(size_t)b * a.C + c];
+            } else if (a.gamma) {
+                ga[k] = a.gamma[c];
+                be[k] = a.beta[c];
+            }
+            if (a.act_a) pa[k] = a.act_a[c];
+            if (a.act_b) pb[k] = a.act_b[c];
         }
-        if (a.act_a) pa[k] = a.act_a[c];
-        if (a.act_b) pb[k] = a.act_b[c];
     }
     if (a.stats) {
         __shared__ __attribute__((aligned(16))) long long swl[16 * kStatSub * kStatWords];
@@ -309,19 +322,39 @@ __global__ __launch_bounds__(256) void act_pad_x6_kernel(ActTmArgs a, int nkb, i
         }
     }
     float ga[8], be[8], pa[8], pb[8];
+    if (kvalid && c0 + 7 < a.C && ((a.C | c0) & 3) == 0) {  // eight whole channels: four 32-byte requests instead of 32 scalar ones
+        auto ld8 = [&](const float* p, float (&o)[8], float dflt) {
+            if (p) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + c0), v1 = *reinterpret_cast<const f32x4*>(p + c0 + 4);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int c = c0 + k;
-        ga[k] = 1.f;
-        be[k] = 0.f;
-        pa[k] = pb[k] = 0.f;
-        if (!kvalid || c >= a.C) continue;
-        if (a.gamma) {
-            ga[k] = a.gamma[c];
-            be[k] = a.beta[c];
+                for (int k = 0; k < 4; ++k) {
+                    o[k] = v0[k];
+                    o[4 + k] = v1[k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = dflt;
+            }
+        };
+        ld8(a.gamma, ga, 1.f);
+        ld8(a.gamma ? a.beta : nullptr, be, 0.f);
+        ld8(a.act_a, pa, 0.f);
+        ld8(a.act_b, pb, 0.f);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = c0 + k;
+            ga[k] = 1.f;
+            be[k] = 0.f;
+            pa[k] = pb[k] = 0.f;
+            if (!kvalid || c >= a.C) continue;
+            if (a.gamma) {
+                ga[k] = a.gamma[c];
+                be[k] = a.beta[c];
+            }
+            if (a.act_a) pa[k] = a.act_a[c];
+            if (a.act_b) pb[k] = a.act_b[c];
         }
-        if (a.act_a) pa[k] = a.act_a[c];
-        if (a.act_b) pb[k] = a.act_b[c];
     }
     if (a.stats) gn_mean_rstd(a.stats, b, a.G, a.sub_stride, a.C, a.stat_T, a.eps, swl, gmean, grstd, 256);
     if (!kvalid) return;
