@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "common.h"
+#include "gemm_x6_pipe.h"
 
 namespace after {
 namespace {
@@ -973,7 +974,7 @@ __device__ __forceinline__ void p32_store4(unsigned short* base, int lr, int c, 
 }
 
 // ln_mod_ln_row on tiled buffers (E = 512): x = norm0(xin[src]) * (1 + alpha_t) + beta_t -> xres ; h = norm1(x)
-template <bool PLANES = false>  // h: fp32 tiles, or -- PLANES -- bf16 x 3 planes (p32_store4)
+template <int PLANES = 0>  // h: fp32 tiles (0), bf16 x 3 planes in fragment order (1: p32_store4) or in x6 blocks (2: x6_store4, common.h)
 __device__ __forceinline__ void step_ln_row(__amdgpu_buffer_rsrc_t xin, int src_lr, float* __restrict__ xres,
                                             float* __restrict__ h, int lr, const StepLnOps& ops, int lane) {
     constexpr int E = kSE, NV = E / 256, KBt = E / 16;
@@ -1013,7 +1014,8 @@ __device__ __forceinline__ void step_ln_row(__amdgpu_buffer_rsrc_t xin, int src_
         y.y = (v[i].y - mean) * rstd * ww[i].y + bb[i].y;
         y.z = (v[i].z - mean) * rstd * ww[i].z + bb[i].z;
         y.w = (v[i].w - mean) * rstd * ww[i].w + bb[i].w;
-        if constexpr (PLANES) p32_store4(reinterpret_cast<unsigned short*>(h), lr, 4 * lane + 256 * i, E / 32, y.x, y.y, y.z, y.w);
+        if constexpr (PLANES == 2) x6_store4(reinterpret_cast<unsigned short*>(h), lr, 4 * lane + 256 * i, E, y.x, y.y, y.z, y.w);
+        else if constexpr (PLANES == 1) p32_store4(reinterpret_cast<unsigned short*>(h), lr, 4 * lane + 256 * i, E / 32, y.x, y.y, y.z, y.w);
         else *reinterpret_cast<f32x4*>(h + o) = y;
     }
 }
@@ -1050,7 +1052,7 @@ __device__ __forceinline__ bool seg_spin_sys(const unsigned* word, unsigned want
 // (Tried on top, LATE only: a chunk whose window reaches into the previous XCD's segment runs its OWN keys first and fetches
 //  the neighbour's -- after the sequence-word wait -- in a second pass of the online softmax.  The second pass (a
 //  system-scope round trip + a 12-key block) costs more than the wait it hides: 285 vs 270 us per Euler step.)
-template <int AUX, bool PLANES = false, bool LATE = false>  // hout: fp32 tiles, or -- PLANES -- bf16 x 3 planes (p32_store4)
+template <int AUX, int PLANES = 0, bool LATE = false>  // hout: fp32 tiles (0), bf16 x 3 planes: p32_store4 (1) / x6 blocks (2)
 __device__ __forceinline__ void step_attention(const StepAttn& a, const StepKV& kv, const StepLnOps& ops, int rg,
                                                int lr0, int bx, float* smem, float* kvlds, __amdgpu_buffer_rsrc_t qkvr,
                                                __amdgpu_buffer_rsrc_t xr, float* __restrict__ xres, float* __restrict__ hout,
@@ -1234,7 +1236,8 @@ __device__ __forceinline__ void step_attention(const StepAttn& a, const StepKV& 
             y.y = (v[i].y - mean) * rstd * ww[i].y + bb[i].y;
             y.z = (v[i].z - mean) * rstd * ww[i].z + bb[i].z;
             y.w = (v[i].w - mean) * rstd * ww[i].w + bb[i].w;
-            if constexpr (PLANES) p32_store4(reinterpret_cast<unsigned short*>(hout), lr0 + i0 + qi, 4 * lane + 256 * i, E / 32, y.x, y.y, y.z, y.w);
+            if constexpr (PLANES == 2) x6_store4(reinterpret_cast<unsigned short*>(hout), lr0 + i0 + qi, 4 * lane + 256 * i, E, y.x, y.y, y.z, y.w);
+            else if constexpr (PLANES == 1) p32_store4(reinterpret_cast<unsigned short*>(hout), lr0 + i0 + qi, 4 * lane + 256 * i, E / 32, y.x, y.y, y.z, y.w);
             else *reinterpret_cast<float4*>(hout + off) = y;
         }
     }
@@ -1715,8 +1718,8 @@ __device__ __attribute__((noinline)) void seg_attention(StepAttn g, const float*
 #pragma unroll
     for (int i = 0; i < kSE / 256; ++i) none.al[i] = none.be[i] = none.ww[i] = none.bb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     // system-scope q / K / V loads only where keys of the previous XCD are involved; the other chunks read this XCD's L2
-    if (halo) step_attention<17, true, true>(g, nokv, none, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout, ab, w3, b3, tr);
-    else step_attention<16, true, true>(g, nokv, none, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout, ab, w3, b3, tr);
+    if (halo) step_attention<17, 1, true>(g, nokv, none, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout, ab, w3, b3, tr);
+    else step_attention<16, 1, true>(g, nokv, none, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout, ab, w3, b3, tr);
 }
 
 template <int MB>  // row blocks per XCD: 3 Tseg / 16 (6 at T = 256)
@@ -1842,7 +1845,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
             if (ln_mine) {
                 StepLnOps lnops;
                 step_ln_ops(lnops, ln_ab0 + (size_t)l * 2 * E, Lw.n1w, Lw.n1b, lane);
-                step_ln_row<true>(l == 0 ? pat_r : xres_r, l == 0 ? ln_lm % Tseg : ln_lm, xres, reinterpret_cast<float*>(hb3), ln_lm, lnops, lane);
+                step_ln_row<1>(l == 0 ? pat_r : xres_r, l == 0 ? ln_lm % Tseg : ln_lm, xres, reinterpret_cast<float*>(hb3), ln_lm, lnops, lane);
             }
             // (the reverse hazard -- the next XCD must have read this layer's keys of the PREVIOUS step before the qkv phase below
             //  overwrites the segment's last frames -- is checked one layer early, by a workgroup without an attention item during
@@ -2039,6 +2042,425 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
     }
 }
 
+// =====================================================================================================
+// Persistent OFFLINE sampler for a BATCH of clips, ONE CLIP PER XCD (RectifiedFlow.sample, model.py:763-785; BASELINE config
+// 3's per-GPU shard and config 4): clip c runs on XCD c % 8 -- its three CFG rows x T frames (768 token rows at T = 256) for
+// every layer and every Euler step on that XCD's 32 workgroups.  The network never mixes clips (the three CFG rows of a clip
+// only meet in the sampler tail), so the eight pipelines share nothing but the weights: no cross-XCD word inside the kernel,
+// no halo, XCD-local barriers only (step_barrier).  With 768 rows per XCD the Linears are MFMA-bound, so they run on the
+// LDS-staged pipeline of gemm_x6.hip (gemm_x6_pipe.h: operands as bf16 x 3 planes in x6 blocks, six exact bf16 MFMAs per fp32
+// product block, fp32 accumulate) as tiles walked by the XCD's workgroups: qkv / MLP-up 192 x 96 (4 x 16 tiles: two per
+// workgroup, same row tile), MLP-down 96 x 128 (8 x 4 tiles: one per workgroup; even / odd slabs in separate accumulators).
+// The weights are the x6 planes split at create (the launch path's); activations between phases are written by their
+// producers as x6 planes (LayerNorm rows, the attention's LayerNorm tail, the GELU epilogue) through the L1 into the XCD's L2
+// and fetched by sc1 LDS-DMA (X6Cfg::SC1).  The residual stream and the patchify output stay in the 16 x 16-tiled fp32 form
+// of the other persistent samplers (step_ln_row / step_attention / the out_proj tail are theirs); qkv is a per-XCD row-major
+// [3 T][3 E] buffer with RoPE applied to q and k in the epilogue.  More than eight clips: XCD g runs clips g, g + 8, ... one
+// after the other (the samples are independent).  Rows are provisioned in whole tiles: a clip length that does not fill
+// the last row tile computes padding rows nobody reads.
+using ClipQU = X6RCfg<12, 12, 4, 2, 1>;                     // qkv / MLP-up: 192 x 192, waves = 4 row parts x 2 column parts, rolling fragments
+using ClipDn = X6RCfg<6, 16, 2, 4, 1>;                      // MLP-down: 96 x 256 x two K halves (32 work items), waves = 2 row parts x 4 column parts
+#ifndef CLIP_LOADERS
+#define CLIP_LOADERS 4
+#endif
+#ifndef CLIP_TRACE_DOWN
+#define CLIP_TRACE_DOWN 0
+#endif
+#ifndef CLIP_DIAG
+#define CLIP_DIAG 0
+#endif
+constexpr int kClipLoaders = CLIP_LOADERS;  // loader waves of a GEMM phase (waves 0 .. : one per SIMD)
+constexpr int kClipRowTile = 192;  // rows of an XCD's slices are provisioned in multiples of it (both tile heights divide it)
+constexpr int kClipMaxT = 1024;    // longest clip the slices are provisioned for (15.5 MB per XCD at T = 256)
+// dynamic LDS: the GEMM ring of the larger tile | attention rows + K / V landing zones | the tail's partial tiles
+constexpr int kClipDnParts = 2;  // K parts of the MLP-down work items (clip_gemm_r, EPI 2)
+constexpr size_t kClipLds = (size_t)ClipQU::NS * ClipQU::STAGE > (size_t)ClipDn::NS * ClipDn::STAGE ? (size_t)ClipQU::NS * ClipQU::STAGE
+                                                                                                    : (size_t)ClipDn::NS * ClipDn::STAGE;
+static_assert(kClipLds >= (8192 + 8 * 2 * kAttnKeyBlock * 64) * sizeof(float), "attention landing zones beyond the ring");
+
+struct ClipLayer {
+    const unsigned short *qkv_w3, *mlp0_w3, *mlp2_w3;  // x6 planes of the three big Linears (after_denoiser_create)
+    const float *mlp0_b, *mlp2_b, *n1w, *n1b, *n3w, *n3b;
+};
+
+struct ClipArgs {
+    int B, T, C, Cp, L, cs, W, nkmax, nsteps, dbg;
+    int stagger;              // start offset between consecutive XCDs, wall-clock ticks of 10 ns (AFTER_CLIP_STAGGER)
+    int rows_pad;             // token rows provisioned per XCD (3 T rounded up to kClipRowTile)
+    int pat_rows;             // rows of an XCD's patchify slice (T rounded up to 16)
+    float* xt;                // token-major latents [B * T][Cp]: a step's input, rewritten by its tail
+    float *pat_t, *xres_t;    // per-XCD slices, 16 x 16-tiled fp32: [8][pat_rows][E], [8][rows_pad][E]
+    float* qkv;               // [8][rows_pad][3E] row-major, RoPE applied to q and k
+    float* dnp;               // [8][rows_pad][E]: K part 0's partial sums of MLP-down, tiled
+    unsigned short *h3, *mlp3;  // [8] x6 planes of [rows_pad][E] / [rows_pad][ME]
+    const float *patch_wt, *patch_b, *out_wt, *out_b;
+    const float* tc_ab;
+    int tc_ld;
+    const int* tcmap;
+    const float* cond_ab;  // [steps][3 B][L * 2E]
+    size_t cond_step;
+    int cond_ld;
+    const float *rope_cos, *rope_sin;
+    const float* x0;
+    float* xout;
+    const float* cfg;
+    StepSync* sync;
+    unsigned long long* trace;
+    ClipLayer layer[8];
+};
+
+struct ClipGemm {
+    const unsigned short *A3, *W3;
+    int M, N, K;            // M: provisioned rows (a multiple of the tile height)
+    const float* bias;
+    float* out;             // EPI 0: fp32 [M][N]
+    unsigned short* out3;   // EPI 1: x6 planes of [M][N]
+    const float *rope_cos, *rope_sin;
+    int T;
+    float* xres;            // EPI 2: residual in / out, 16 x 16 tiles [M / 16][N / 16][256]
+    int kparts;             // K parts of a work item (EPI 2: item = (tile, K part); 1 otherwise)
+    float* part;            // EPI 2: K part 0's (sums + bias) + xres, tiled like xres
+    unsigned* flags;        // EPI 2: [tile] -- the round in which K part 0's partial sums of the tile were last written (XCD-local)
+    unsigned round;         // EPI 2: this phase's round (monotonic over the launch)
+    unsigned* fail;         // spin time-outs
+    unsigned long long* tr; // AFTER_STEP_TRACE stamps of the workgroup's first tile: [64] entry, [65] (unused), [66] K loop done, [67] epilogue issued
+};
+
+// role dispatch of the loader-wave ring (wave-uniform switch: every role has its own instruction stream)
+#define CLIP_ROLE(wid_, CALL)                                                    \
+    switch ((wid_) < kClipLoaders ? (wid_) : -1) {                               \
+        case 0: { constexpr int LID = 0; CALL; } break;                          \
+        case 1: { constexpr int LID = kClipLoaders > 1 ? 1 : -1; CALL; } break;  \
+        case 2: { constexpr int LID = kClipLoaders > 2 ? 2 : -1; CALL; } break;  \
+        case 3: { constexpr int LID = kClipLoaders > 3 ? 3 : -1; CALL; } break;  \
+        case 4: { constexpr int LID = kClipLoaders > 4 ? 4 : -1; CALL; } break;  \
+        case 5: { constexpr int LID = kClipLoaders > 5 ? 5 : -1; CALL; } break;  \
+        case 6: { constexpr int LID = kClipLoaders > 6 ? 6 : -1; CALL; } break;  \
+        case 7: { constexpr int LID = kClipLoaders > 7 ? 7 : -1; CALL; } break;  \
+        default: { constexpr int LID = -1; CALL; } break;                        \
+    }
+
+// One GEMM phase of an XCD on the ROLLING-fragment ring of gemm_x6_pipe.h (192 x 192 tiles: one per workgroup at T = 256): C =
+// epi(A3 W3^T) over the tiles rank, rank + 32, ... of the XCD's tile grid (row tile fastest)
+template <class C, int EPI>
+__device__ __forceinline__ void clip_gemm_r(const ClipGemm& g, unsigned char* smem_raw, int rank, int wid, int lane_in) {
+    constexpr int BM = C::BM, BN = C::BN, MT = C::MT, NT = C::NT, RS = C::RS;
+    static_assert(C::SC1 == 1, "sc1 operand loads");  // EPI 0: qkv -- rotated fp32 rows; 1: MLP-up -- bias, exact GELU, x6 planes;
+                                                       // 2: MLP-down -- the K part's partial sums, tiled fp32
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));  // (opaque: everything derived from the lane is this phase's own -- shared with the other phases
+                                    //  it is a kernel-lifetime register that the allocator spills into the MFMA loops)
+    const int tiles_m = g.M / BM, tiles_n = g.N / BN, ntiles = tiles_m * tiles_n * g.kparts;  // (work items: K part slowest)
+    const int rp = wid % RS, cp = wid / RS;
+    const int nk = g.K / 32 / g.kparts;  // slabs of a work item (even)
+    X6RState<C> c;
+    c.lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem_raw;
+    c.voff = (unsigned)lane * 16u;
+    c.rgs = (unsigned)(g.K / 32) * 3072u;
+    {
+        const int frow = lane & 15, kq = lane >> 4;
+        const unsigned sw = (unsigned)((kq ^ swz4((frow >> 2) & 3)) * 16);
+        c.a_rd = c.lds0 + (unsigned)((rp * (BM / RS) + frow) * 64) + sw;
+        c.w_rd = c.lds0 + (unsigned)(C::GA * 1024 + (cp * (BN / C::CP) + frow) * 64) + sw;
+    }
+    unsigned long long* const tr = threadIdx.x == 0 ? g.tr : nullptr;
+    c.prof[0] = c.prof[1] = c.prof[2] = c.prof[3] = c.tprev = 0;
+    for (int t = rank; t < ntiles; t += 32) {
+        const int tm = t % tiles_m, tn = (t / tiles_m) % tiles_n, kp = t / (tiles_m * tiles_n);
+        if (tr && t == rank) tr[64] = wall_clock64(), tr[68] = __builtin_readcyclecounter();
+        c.a_src = (unsigned long long)(uintptr_t)g.A3 + (unsigned long long)(tm * (BM >> 4)) * c.rgs + (unsigned long long)(kp * nk) * 3072u;
+        c.w_src = (unsigned long long)(uintptr_t)g.W3 + (unsigned long long)(tn * (BN >> 4)) * c.rgs + (unsigned long long)(kp * nk) * 3072u;
+#if CLIP_DIAG & 1  // (timing experiments, wrong results: MLP-down's activations from an L2-resident footprint)
+        if (EPI == 2) c.a_src = (unsigned long long)(uintptr_t)g.A3 + (unsigned long long)((tm & 1) * (BM >> 4)) * c.rgs;
+#endif
+#if CLIP_DIAG & 2  // (... and its weights)
+        if (EPI == 2) c.w_src = (unsigned long long)(uintptr_t)g.W3;
+#endif
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) c.acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t != rank) {  // every wave is past its last read of the ring (and its stores are out)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        CLIP_ROLE(wid, (x6r_tile<C, kClipLoaders, LID>(c, nk)));
+        if (tr && t == rank) {
+            asm volatile("s_nop 15\n\ts_nop 15" : "+v"(c.acc[MT - 1][NT - 1]));
+            tr[66] = wall_clock64(), tr[69] = __builtin_readcyclecounter();
+        }
+        // (the lane again opaque: the epilogue's index arithmetic depends on the tile only, and hoisted above the K loop it is
+        //  two dozen registers that are spilled there -- every reload down here then waits, with vmcnt(0), for the stores so far)
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int row0 = tm * BM + rp * (BM / RS), col0 = tn * BN + cp * (BN / C::CP);
+        const int crow = lane_e & 15, cq = lane_e >> 4;
+        // every operand of the epilogue is requested before the first store: vmcnt counts loads and stores alike, so a load
+        // behind a store is waited for together with that store's round trip -- block by block that was 6 us of a 41-us phase
+        f32x4 bv[NT], ov[EPI == 2 ? MT : 1][EPI == 2 ? NT : 1];
+        float2 rcs[EPI == 0 ? MT : 1][EPI == 0 ? NT : 1], rsn[EPI == 0 ? MT : 1][EPI == 0 ? NT : 1];
+        if constexpr (EPI == 2) {
+            // MLP-down: K part 0 leaves part = (its sums + bias) + xres and raises the tile's flag; K part 1 (a workgroup of the same
+            // XCD that finishes at about the same time) waits for the flag and writes xres = its sums + part: the residual stream
+            // is complete when the phase ends, in one fixed order of additions (K part 0 has read xres before it raises the flag)
+            if (kp != 0) {
+                if (threadIdx.x == 0) seg_spin_sys(g.flags + tm * tiles_n + tn, g.round, g.fail);
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int cb = col0 + 16 * j, gn = cb + 4 * cq;
+            bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI == 1) bv[j] = *reinterpret_cast<const f32x4*>(g.bias + gn);
+            if constexpr (EPI == 2) {
+                if (kp == 0) bv[j] = *reinterpret_cast<const f32x4*>(g.bias + gn);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    ov[i][j] = ld_l2(step_rsrc(kp == 0 ? g.xres : g.part), (unsigned)(((((row0 >> 4) + i) * (g.N >> 4) + (cb >> 4)) << 8) + lane_e * 4));
+            }
+            if constexpr (EPI == 0) {
+                const bool roped = cb < 2 * kSE && (cb & 63) < 32;  // (wave-uniform; RoPE: rotary_embedding.py:132-173)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    int tf = row0 + 16 * i + crow;
+                    tf -= tf >= g.T ? g.T : 0;
+                    tf -= tf >= g.T ? g.T : 0;
+                    tf = min(tf, g.T - 1);  // (padding rows: any valid table row)
+                    const int ro = tf * 16 + (((cb & 63) + 4 * cq) >> 1);
+                    rcs[i][j] = make_float2(1.f, 1.f), rsn[i][j] = make_float2(0.f, 0.f);
+                    if (roped) {
+                        rcs[i][j] = *reinterpret_cast<const float2*>(g.rope_cos + ro);
+                        rsn[i][j] = *reinterpret_cast<const float2*>(g.rope_sin + ro);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            asm volatile("" : "+v"(bv[j]));
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                if constexpr (EPI == 0) asm volatile("" : "+v"(rcs[i][j]), "+v"(rsn[i][j]));
+                if constexpr (EPI == 2) asm volatile("" : "+v"(ov[i][j]));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int cb = col0 + 16 * j, gn = cb + 4 * cq;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int gm = row0 + 16 * i + crow;
+                const f32x4 o = c.acc[i][j];
+                if constexpr (EPI == 0) {
+                    const float2 cs = rcs[i][j], sn = rsn[i][j];  // (blocks that are not rotated: cos = 1, sin = 0 -- exact)
+                    *reinterpret_cast<f32x4*>(g.out + (size_t)gm * g.N + gn) =
+                        f32x4{o[0] * cs.x - o[1] * sn.x, o[1] * cs.x + o[0] * sn.x, o[2] * cs.y - o[3] * sn.y, o[3] * cs.y + o[2] * sn.y};
+                } else if constexpr (EPI == 1) {
+                    const f32x4 v = o + bv[j];
+                    x6_store4(g.out3, gm, gn, g.N, gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
+                } else {  // (a block is one contiguous KB of the tiled tensors)
+                    const unsigned off = (unsigned)(((((row0 >> 4) + i) * (g.N >> 4) + (cb >> 4)) << 8) + lane_e * 4);
+                    *reinterpret_cast<f32x4*>((kp == 0 ? g.part : g.xres) + off) = (o + bv[j]) + ov[i][j];  // (K part 1: bv = 0)
+                }
+            }
+        }
+        if constexpr (EPI == 2) {
+            if (kp == 0) {  // the partial sums are in the XCD's L2 (write-through L1): raise the tile's flag
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (threadIdx.x == 0) __builtin_amdgcn_raw_buffer_store_b32(g.round, step_rsrc(g.flags + tm * tiles_n + tn), 0, 0, 17);
+            }
+        }
+        if (tr && t == rank) tr[67] = wall_clock64();
+    }
+    if (X6R_PROF && g.tr && (threadIdx.x & 63) == 0) {  // (per wave: [88 + 4 w ..] of the workgroup's stamps)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g.tr[88 + 4 * wid + k] = c.prof[k];
+    }
+}
+
+// (out of line, every argument by value and re-uniformed: see seg_attention)
+__device__ __attribute__((noinline)) void clip_attention(StepAttn g, const float* ab, const float* w3, const float* b3, int rg, int lr0,
+                                                         int bx, float* smem, float* kvlds, float* xres, float* hout,
+                                                         unsigned long long* tr) {
+    g.T = seg_uniform(g.T), g.cs = seg_uniform(g.cs), g.W = seg_uniform(g.W), g.cache = seg_uniform(g.cache), g.nkmax = seg_uniform(g.nkmax);
+    g.rope_cos = seg_uniform(g.rope_cos), g.rope_sin = seg_uniform(g.rope_sin), g.qkv = seg_uniform(g.qkv);
+    ab = seg_uniform(ab), w3 = seg_uniform(w3), b3 = seg_uniform(b3);
+    rg = seg_uniform(rg), lr0 = seg_uniform(lr0), bx = seg_uniform(bx);
+    smem = seg_uniform(smem), kvlds = seg_uniform(kvlds), xres = seg_uniform(xres), hout = seg_uniform(hout), tr = seg_uniform(tr);
+    const StepKV nokv{nullptr, nullptr, nullptr, nullptr};
+    StepLnOps none;
+#pragma unroll
+    for (int i = 0; i < kSE / 256; ++i) none.al[i] = none.be[i] = none.ww[i] = none.bb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    step_attention<16, 2, true>(g, nokv, none, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout, ab, w3, b3, tr);
+}
+
+__global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ unsigned s_rank, s_bad, s_ok;
+    constexpr int E = kSE, ME = kSME, KBE = E / 16;
+    float* const smem = reinterpret_cast<float*>(smem_raw);
+    StepSync* st = a.sync;
+    const unsigned xcc = step_xcc_id(), nb = gridDim.x, n = 32;
+    const int tid = threadIdx.x, lane0 = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0 && (__hip_atomic_load(&st->fail[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) |
+                     __hip_atomic_load(&st->fail[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        s_bad = 1;  // an earlier launch failed (sticky words, raised before this launch began: every workgroup sees them)
+    } else if (tid == 0) {  // census: workgroups per XCC, this workgroup's rank on its XCC
+        s_rank = __hip_atomic_fetch_add(&st->pop[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&st->census[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        step_spin(&st->census[0], nb, &st->fail[0]);
+        unsigned bad = 0;
+        for (int x = 0; x < 8; ++x)
+            bad |= __hip_atomic_load(&st->pop[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 32u;
+        if (a.dbg & 24) bad = 1;
+        if (bad) __hip_atomic_store(&st->fail[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_bad = bad;
+    }
+    __syncthreads();
+    if (s_bad) return;
+    const int rank = __builtin_amdgcn_readfirstlane((int)s_rank), g = (int)xcc;
+    if (g >= a.B) return;  // (barriers are per XCD: an XCD without a clip has nothing to wait for)
+    unsigned round = 0, tslot = 0;
+    unsigned long long* trace = a.trace ? a.trace + (size_t)blockIdx.x * 128 : nullptr;
+    if (a.stagger > 0) {  // XCD g starts g x stagger wall-clock ticks (10 ns) late: the eight pipelines' store bursts out of phase
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (unsigned long long)(g * a.stagger)) __builtin_amdgcn_s_sleep(8);
+    }
+
+    const int T = a.T, B = a.B, Mg = 3 * T;
+    float* const pat = a.pat_t + (size_t)g * a.pat_rows * E;
+    float* const xres = a.xres_t + (size_t)g * a.rows_pad * E;
+    float* const qkv = a.qkv + (size_t)g * a.rows_pad * 3 * E;
+    float* const dnp = a.dnp + (size_t)g * a.rows_pad * E;  // MLP-down: K part 0's partial sums [rows_pad][E], tiled
+    unsigned short* const h3 = a.h3 + (size_t)g * a.rows_pad * E * 3;
+    unsigned short* const mlp3 = a.mlp3 + (size_t)g * a.rows_pad * ME * 3;
+    const __amdgpu_buffer_rsrc_t pat_r = step_rsrc(pat), xres_r = step_rsrc(xres);
+    const __amdgpu_buffer_rsrc_t xt_r = step_rsrc(a.xt), xout_r = step_rsrc(a.xout);
+    float* const red = smem;          // tail: partial tiles [8 waves][3][256] | attention rows
+    float* const kvl = smem + 8192;   // attention: K / V landing zones [8 waves][2][12][64]
+    auto end_phase = [&](bool drain) { return step_barrier(st, xcc, n, (unsigned)rank, ++round, trace, ++tslot, drain, &s_ok); };
+    const int cps = (T + a.cs - 1) / a.cs, nitems = 3 * cps;  // attention items: (CFG row, chunk)
+    const int nfb = T / 16, ntail = (a.C / 16) * nfb;         // tail items: (column tile, 16-frame block)
+
+    for (int c = g; c < B; c += 8) {  // ---- this XCD's clips, one after the other
+        for (int i = 0; i < a.nsteps; ++i) {  // ---- the Euler steps of RectifiedFlow.sample (model.py:770-785)
+            const float* cond_ab = a.cond_ab + (size_t)i * a.cond_step;
+            tslot = 0;
+            if (trace && tid == 0) trace[0] = wall_clock64(), trace[70] = __builtin_readcyclecounter();
+            int lane_i = lane0;
+            asm volatile("" : "+v"(lane_i));  // (opaque: see clip_gemm)
+            const int lane = lane_i;
+            // ---- patchify_and_embed (transformerv2.py:387-391) for the clip's T frames (shared by the three CFG rows):
+            //      workgroup = column tile, wave = row blocks w, w + 8, ..; fp32 MFMA over K = Cp
+            {
+                const int kbp = a.Cp / 16;  // <= 4
+                f32x4 wv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    wv[u] = u < kbp ? *reinterpret_cast<const f32x4*>(a.patch_wt + ((size_t)(rank * kbp + u) << 8) + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(a.patch_b + 16 * rank + 4 * (lane >> 4));
+                for (int rb = w; rb < nfb; rb += 8) {
+                    f32x4 av[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        av[u] = u < kbp ? ld_l2(xt_r, (unsigned)((c * T + 16 * rb + (lane & 15)) * a.Cp + 16 * u + 4 * (lane >> 4))) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][q], av[u][q], acc, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = gelu_erf(acc[r] + bv[r]);
+                    *reinterpret_cast<f32x4*>(pat + ((size_t)(rb * KBE + rank) << 8) + lane * 4) = acc;
+                }
+            }
+            if (!end_phase(true)) return;
+            for (int l = 0; l < a.L; ++l) {
+                const ClipLayer& Lw = a.layer[l];
+                int lane_l = lane0;
+                asm volatile("" : "+v"(lane_l));
+                const int lane = lane_l;
+                // ---- norm0 -> AdaLN(tcond) -> norm1 (transformerv2.py:345-351): one wave per token row; h as x6 planes
+                for (int lm = rank + 32 * w; lm < Mg; lm += 256) {
+                    const int br = lm / T, t = lm - br * T;
+                    StepLnOps lnops;
+                    step_ln_ops(lnops, a.tc_ab + ((size_t)a.tcmap[br * B + c] * T + t) * a.tc_ld + (size_t)l * 2 * E, Lw.n1w, Lw.n1b, lane);
+                    step_ln_row<2>(l == 0 ? pat_r : xres_r, l == 0 ? t : lm, xres, reinterpret_cast<float*>(h3), lm, lnops, lane);
+                }
+                if (!end_phase(true)) return;
+                // ---- qkv
+                {
+                    const ClipGemm gq{h3, Lw.qkv_w3, a.rows_pad, 3 * E, E, nullptr, qkv, nullptr, a.rope_cos, a.rope_sin, T, nullptr, 1, nullptr, nullptr, 0, nullptr, CLIP_TRACE_DOWN ? nullptr : trace};
+                    clip_gemm_r<ClipQU, 0>(gq, smem_raw, rank, w, lane);
+                }
+                if (!end_phase(true)) return;
+                // ---- attention + residual + AdaLN(cond) + norm3 (transformerv2.py:190-236, :351-361): one workgroup per chunk
+                //      of a CFG row; h as x6 planes
+                for (int it = rank; it < nitems; it += (int)n) {
+                    const int br = it / cps, ch = it - br * cps;
+                    __syncthreads();  // (a second item of this workgroup reuses the LDS rows)
+                    clip_attention(StepAttn{T, a.cs, a.W, 0, a.nkmax, a.rope_cos, a.rope_sin, qkv},
+                                   cond_ab + (size_t)(br * B + c) * a.cond_ld + (size_t)l * 2 * E, Lw.n3w, Lw.n3b, br, br * T, ch, smem, kvl,
+                                   xres, reinterpret_cast<float*>(h3), trace);
+                }
+                if (!end_phase(true)) return;
+                // ---- MLP up + GELU
+                {
+                    const ClipGemm gu{h3, Lw.mlp0_w3, a.rows_pad, ME, E, Lw.mlp0_b, nullptr, mlp3, nullptr, nullptr, T, nullptr, 1, nullptr, nullptr, 0, nullptr, nullptr};
+                    clip_gemm_r<ClipQU, 1>(gu, smem_raw, rank, w, lane);
+                }
+                if (!end_phase(true)) return;
+                // ---- MLP down + residual
+                {
+                    const ClipGemm gd{mlp3, Lw.mlp2_w3, a.rows_pad, E, ME, Lw.mlp2_b, nullptr, nullptr, nullptr, nullptr, T, xres, kClipDnParts, dnp,
+                                      &st->gen[xcc][0], round + 1, &st->fail[0], CLIP_TRACE_DOWN ? trace : nullptr};
+                    clip_gemm_r<ClipDn, 2>(gd, smem_raw, rank, w, lane);
+                }
+                if (!end_phase(true)) return;
+            }
+            // ---- out_proj + CFG + Euler (+ the token-major latents of the next step), fp32 MFMA: item (column tile,
+            //      16-frame block) owns the three CFG rows of its frames (model.py:749-759, 777-783)
+            int lane_t = lane0;
+            asm volatile("" : "+v"(lane_t));
+            for (int it = rank; it < ntail; it += (int)n) {
+                const int lane = lane_t;
+                const int tile = it % (a.C / 16), fb = it / (a.C / 16);
+                f32x4 acc[3];
+                step_gemm<3, 1, kSKBQ, false>(acc, xres_r, KBE, a.out_wt, KBE, tile, kSKBQ * w, lane, true, true, [] {}, 0, fb, nfb);
+                const f32x4 o = seg_reduce<3>(acc, 0, red, w, lane);
+                float* const outt = red + 8 * 3 * 256;  // [3 branches x 16 frames][16 columns]
+                if (w < 3) *reinterpret_cast<f32x4*>(outt + (16 * w + (lane & 15)) * 16 + 4 * (lane >> 4)) = o;
+                __syncthreads();
+                if (tid < 256) {
+                    const int tq = tid >> 4, col = tid & 15, nn = 16 * tile + col, tl = 16 * fb + tq;
+                    const float bo = a.out_b ? a.out_b[nn] : 0.f;
+                    const float dfull = outt[tq * 16 + col] + bo, dmid = outt[(16 + tq) * 16 + col] + bo,
+                                dnone = outt[(32 + tq) * 16 + col] + bo;
+                    const float total = a.cfg[0], factor = a.cfg[1], dt = a.cfg[2];
+                    const float v = dnone + total * (dmid + factor * (dfull - dmid) - dnone);
+                    const size_t o1 = ((size_t)c * a.C + nn) * T + tl;
+                    const float xi = i == 0 ? a.x0[o1]
+                                            : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xout_r, (unsigned)o1 * 4u, 0, 16));
+                    const float xn = xi + v * dt;
+                    a.xout[o1] = xn;
+                    if (i + 1 < a.nsteps) a.xt[((size_t)c * T + tl) * a.Cp + nn] = xn;
+                }
+                __syncthreads();  // (a second item of this workgroup reuses the LDS tiles)
+            }
+            if (trace && tid == 0) {
+                trace[2 * tslot + 1] = wall_clock64();
+                trace[71] = __builtin_readcyclecounter();
+                trace[127] = xcc;
+            }
+            if ((i + 1 < a.nsteps || c + 8 < B) && !end_phase(true)) return;  // the next step's patchify reads the new latents
+        }
+    }
+}
+
 // The placement census of the persistent samplers on its own (persist_prepare: a dry launch with their grid, block and LDS
 // footprint while the handle is being configured, so that the first real after_sample need not look at it synchronously)
 __global__ __launch_bounds__(512) void persist_census_kernel(StepSync* st, int dbg) {
@@ -2144,6 +2566,14 @@ struct after_denoiser {
     float* seg_qkv = nullptr;  // [L][3 max_T][3E]: per-layer qkv rows of the segment sampler
     unsigned short* seg_act3 = nullptr;  // bf16 x 3 planes of h and of the MLP hidden layer, one slice per XCD
     bool last_seg = false;     // the last after_sample ran as sample_seg_kernel
+    // clip-per-XCD offline sampler (sample_clip_kernel): per-XCD slices of the residual stream / patchify output (tiled fp32),
+    // qkv rows (fp32) and the x6 planes of h and of the MLP hidden layer; rows provisioned per XCD
+    float* clip_act = nullptr;
+    unsigned short* clip_act3 = nullptr;
+    int clip_rows = 0, clip_pat_rows = 0;
+    int clip_min_b = 5;        // AFTER_SAMPLE_CLIP_MINB: fewest clips of a call that take the kernel (below: seg kernel / launches)
+    int persist_clip = 1;      // AFTER_SAMPLE_CLIP=0: batches by launches
+    bool last_clip = false;    // the last after_sample ran as sample_clip_kernel
     // persist_prepare (called by create / enable_cache / set_*_persist, never by after_sample) has allocated the persistent
     // samplers' buffers, re-tiled the weights and seen a clean placement census: only then does a call take those paths
     bool step_ready = false;
@@ -2688,6 +3118,10 @@ extern "C" int after_denoiser_create(const after_denoiser_cfg* cfg, const float*
         if (ps) h->persist_step = atoi(ps) != 0;
         const char* po = getenv("AFTER_SAMPLE_PERSIST");
         if (po) h->persist_offline = atoi(po) != 0;
+        const char* pc = getenv("AFTER_SAMPLE_CLIP");
+        if (pc) h->persist_clip = atoi(pc) != 0;
+        const char* pcb = getenv("AFTER_SAMPLE_CLIP_MINB");
+        if (pcb && atoi(pcb) > 0) h->clip_min_b = atoi(pcb);
         hipDeviceProp_t prop;
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(AFTER_E_HIP);
@@ -2726,6 +3160,8 @@ extern "C" void after_denoiser_destroy(after_denoiser* h) {
     if (h->step_act) (void)hipFree(h->step_act);
     if (h->seg_qkv) (void)hipFree(h->seg_qkv);
     if (h->seg_act3) (void)hipFree(h->seg_act3);
+    if (h->clip_act) (void)hipFree(h->clip_act);
+    if (h->clip_act3) (void)hipFree(h->clip_act3);
     h->wa.release();
     h->ws.release();
     h->ca.release();
@@ -2953,8 +3389,26 @@ int persist_prepare(after_denoiser* h, bool offline) {
         }
         h->seg_qkv = q, h->seg_act3 = a3;
     }
+    // the clip-per-XCD sampler's slices: for handles provisioned for a batch of clips of moderate length
+    if (offline && h->persist_clip && !h->clip_act && h->max_rows >= 3 * h->clip_min_b && h->max_T <= kClipMaxT) {
+        const size_t rows = (size_t)cdiv(3 * h->max_T, kClipRowTile) * kClipRowTile, prow = (size_t)cdiv(h->max_T, 16) * 16;
+        const size_t nf = 8 * (prow * E + rows * E + rows * 3 * E + rows * E), n3 = 8 * rows * 3 * (E + ME);
+        float* f = nullptr;
+        unsigned short* a3 = nullptr;
+        const bool ok = hipMalloc(&f, nf * sizeof(float)) == hipSuccess && hipMalloc(&a3, n3 * sizeof(unsigned short)) == hipSuccess &&
+                        hipMemset(f, 0, nf * sizeof(float)) == hipSuccess && hipMemset(a3, 0, n3 * sizeof(unsigned short)) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            if (f) (void)hipFree(f);
+            if (a3) (void)hipFree(a3);
+            h->persist_clip = 0;  // (the other offline paths serve the handle)
+        } else {
+            h->clip_act = f, h->clip_act3 = a3, h->clip_rows = (int)rows, h->clip_pat_rows = (int)prow;
+        }
+    }
     // the kernels' dynamic LDS limits (a hipFuncSetAttribute inside after_sample would be one more first-call cost)
     {
+        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sample_clip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClipLds));
         const size_t lds_seg = ((size_t)kSRedFloats(2) + 8 * 2 * kAttnKeyBlock * 64) * sizeof(float);
         const void* fns[] = {reinterpret_cast<const void*>(sample_seg_kernel<6>), reinterpret_cast<const void*>(sample_seg_kernel<3>),
                              reinterpret_cast<const void*>(persist_census_kernel)};
@@ -3177,6 +3631,86 @@ int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, in
     return rc == AFTER_E_HIP && h->persist_check ? kStepRetry : rc;
 }
 
+// RectifiedFlow.sample for a batch of clips as one persistent launch, one clip per XCD (sample_clip_kernel): eligible for the
+// shipped width (embed 512 / mlp x 3 / eight heads: the kernel's tile grid), finite causal window, clip_min_b <= B clips of
+// T % 16 == 0 frames within the provisioned slices, <= 8 layers, 256 CUs, no streaming caches, gemm path != 0.
+bool sample_clip_ok(const after_denoiser* h, int B, int T, int nb_steps) {
+    const bool wide = h->W < 0 || !h->cfg.causal;
+    return h->persist_offline && h->persist_clip && h->step_ready && h->clip_act && h->cache == 0 && B >= h->clip_min_b &&
+           (!h->timer.enabled || h->timer_kernel == 3) && !h->use_graph && h->x6 != 0 && h->E == kSE && h->ME == kSME && h->H == kSH &&
+           h->L <= 8 && !wide && h->Cp == h->C && h->C % 16 == 0 && h->C / 16 <= 4 && h->n_cus == 256 && T % 16 == 0 &&
+           cdiv(3 * T, kClipRowTile) * kClipRowTile <= h->clip_rows && nb_steps >= 1 && T <= h->max_T &&
+           ((size_t)h->cs * (h->E + 4) + (size_t)kSH * 2 * (h->W - 1 + h->cs) * 16) <= 7168;
+}
+
+int sample_clip(after_denoiser* h, hipStream_t s, const float* x0, float* out, int B, int T, int nb_steps) {
+    const int E = h->E, ME = h->ME, L = h->L;
+    const int nkmax = h->W - 1 + h->cs > h->cs ? h->W - 1 + h->cs : h->cs;
+    {
+        dim3 grid(cdiv(T, 32), cdiv(h->Cp, 32), B);
+        hipLaunchKernelGGL(to_token_major_kernel, grid, dim3(256), 0, s, x0, h->xt, (const int*)nullptr, h->C, T, h->Cp, 0.f);
+        AFTER_HIP_CHECK(hipGetLastError());
+    }
+    AFTER_HIP_CHECK(hipMemsetAsync(h->step_sync, 0, offsetof(StepSync, fail), s));  // (not the sticky failure words)
+    ClipArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = B, a.T = T, a.C = h->C, a.Cp = h->Cp, a.L = L, a.cs = h->cs, a.W = h->W, a.nkmax = nkmax, a.nsteps = nb_steps;
+    a.rows_pad = cdiv(3 * T, kClipRowTile) * kClipRowTile;  // (slices are addressed with the CALL's row count: dense in the L2)
+    a.pat_rows = cdiv(T, 16) * 16;
+    {
+        static int dbg = -1;
+        if (dbg < 0) {
+            const char* e = getenv("AFTER_STEP_DBG");
+            dbg = e ? atoi(e) : 0;
+        }
+        a.dbg = dbg | h->step_dbg;
+        static int stagger = -1;
+        if (stagger < 0) {
+            const char* e = getenv("AFTER_CLIP_STAGGER");
+            stagger = e ? atoi(e) : 0;
+        }
+        a.stagger = stagger;
+    }
+    a.xt = h->xt;
+    {
+        float* p = h->clip_act;
+        a.pat_t = p, p += (size_t)8 * h->clip_pat_rows * E;
+        a.xres_t = p, p += (size_t)8 * h->clip_rows * E;
+        a.qkv = p, p += (size_t)8 * h->clip_rows * 3 * E;
+        a.dnp = p;
+        a.h3 = h->clip_act3, a.mlp3 = h->clip_act3 + (size_t)8 * h->clip_rows * 3 * E;
+    }
+    a.patch_wt = h->step_patch_wt, a.patch_b = h->patch_b, a.out_wt = h->step_out_wt, a.out_b = h->out_b;
+    a.tc_ab = h->tc_ab, a.tc_ld = L * 2 * E, a.tcmap = h->maps + h->ms;
+    a.cond_ab = h->cond_ab, a.cond_step = (size_t)3 * B * L * 2 * E, a.cond_ld = L * 2 * E;
+    a.rope_cos = h->rope_cos, a.rope_sin = h->rope_sin;
+    a.x0 = x0, a.xout = out;
+    a.cfg = reinterpret_cast<const float*>(h->dparams);
+    a.sync = h->step_sync;
+    a.trace = h->step_trace_on ? h->step_trace : nullptr;
+    for (int l = 0; l < L; ++l) {
+        const LayerW& w = h->layers[l];
+        ClipLayer& cl = a.layer[l];
+        cl.qkv_w3 = w.qkv_w3, cl.mlp0_w3 = w.mlp0_w3, cl.mlp2_w3 = w.mlp2_w3;
+        cl.mlp0_b = w.mlp0_b, cl.mlp2_b = w.mlp2_b, cl.n1w = w.n1w, cl.n1b = w.n1b, cl.n3w = w.n3w, cl.n3b = w.n3b;
+    }
+    const bool timed = h->timer.enabled && h->timer_kernel == 3;
+    if (timed) h->timer.begin(s);
+    {
+        PersistLaunch guard(h->dev, s);
+        hipLaunchKernelGGL(sample_clip_kernel, dim3(h->n_cus), dim3(512), kClipLds, s, a);
+    }
+    AFTER_HIP_CHECK(hipGetLastError());
+    if (timed) {
+        const double M = 3.0 * B * T, Ed = E, MEd = ME, Cd = h->C;
+        const double wts = Ed * h->Cp + Cd * Ed + L * (3 * Ed * Ed + 2 * Ed * MEd);
+        const double fl = 2.0 * ((double)B * T * Ed * h->Cp + M * (Cd * Ed + L * (3 * Ed * Ed + 2 * Ed * MEd)));
+        h->timer.end(s, nb_steps * fl, nb_steps * 6.0 * wts);
+    }
+    const int rc = persist_published(h, s);
+    return rc == AFTER_E_HIP && h->persist_check ? kStepRetry : rc;
+}
+
 // The whole sampler as a sequence of launches on `s` (eager path and graph capture body).
 // With streaming caches (h->cache > 0) this is Streamer.sample of export.py:398-416: step i
 // attends over its own cache slot i, which is rolled by the chunk length after the step.
@@ -3187,7 +3721,7 @@ int sample_enqueue(after_denoiser* h, hipStream_t s, const float* x0, const floa
     const int rows = 3 * B;
     AFTER_TRY(compute_cond_ab(h, s, nb_steps, rows, nullptr, nullptr, nb_steps, cond,
                               h->maps + 2 * h->ms, drop_value));
-    h->last_seg = false;
+    h->last_seg = h->last_clip = false;
     // the sticky failure words of earlier persistent launches, if their copy has landed (AFTER_E_HIP once, then launches)
     AFTER_TRY(persist_poll(h, s, false));
     // (a persistent kernel cannot be a captured graph node of somebody else's graph: no event protocol, no co-residency guard)
@@ -3196,6 +3730,13 @@ int sample_enqueue(after_denoiser* h, hipStream_t s, const float* x0, const floa
         const int rc = sample_seg(h, s, x0, out, T, nb_steps);
         if (rc != kStepRetry) {
             h->last_seg = rc == AFTER_OK;
+            return rc;
+        }
+    }
+    if (!capturing && sample_clip_ok(h, B, T, nb_steps)) {
+        const int rc = sample_clip(h, s, x0, out, B, T, nb_steps);
+        if (rc != kStepRetry) {
+            h->last_clip = rc == AFTER_OK;
             return rc;
         }
     }
@@ -3378,7 +3919,7 @@ extern "C" int after_denoiser_check(after_denoiser* h, void* stream) {
 
 extern "C" int after_denoiser_sample_persist(after_denoiser* h, int* active) {
     AFTER_REQUIRE(h && active, AFTER_E_INVALID, "null argument");
-    *active = h->last_seg ? 1 : 0;
+    *active = h->last_seg ? 1 : (h->last_clip ? 2 : 0);
     return AFTER_OK;
 }
 

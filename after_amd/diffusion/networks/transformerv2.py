@@ -406,6 +406,15 @@ class DenoiserV2(nn.Module):
         _lib.check(_lib.lib().after_denoiser_sample_persist(self._handle, ctypes.byref(a)), "after_denoiser_sample_persist")
         return bool(a.value)
 
+    def sample_path(self) -> int:
+        """How the last cfg_sample of this handle ran: 0 by launches, 1 the one-clip persistent kernel (time segments over the
+        XCDs), 2 the batch persistent kernel (one clip per XCD)."""
+        if self._handle is None:
+            return 0
+        a = ctypes.c_int()
+        _lib.check(_lib.lib().after_denoiser_sample_persist(self._handle, ctypes.byref(a)), "after_denoiser_sample_persist")
+        return int(a.value)
+
     def stream_persist(self) -> bool:
         """True when the last streaming cfg_sample of this handle ran (and the next one of the same shape will run) as
         persistent launches."""

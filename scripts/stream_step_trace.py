@@ -20,6 +20,7 @@ ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--xcd", type=int, default=0)
 ap.add_argument("--detail", action="store_true", help="per phase: the five slowest workgroups (index in the XCD: work us)")
 ap.add_argument("--offline", action="store_true", help="the persistent OFFLINE sampler (one clip, base, 50 steps) instead")
+ap.add_argument("--clips", type=int, default=1, help="with --offline: clips of the call (>= 5: the clip-per-XCD kernel)")
 args = ap.parse_args()
 torch.set_grad_enabled(False)
 dev = torch.device("cuda:0")
@@ -27,7 +28,8 @@ if args.offline:
     os.environ.setdefault("AFTER_SAMPLE_PERSIST", "1")
     model, dcfg, acfg = pipeline.build_models("base", "baseAE", dev, seed=7)
     TT = int(os.environ.get("AFTER_T", "256"))
-    x0, cond, tc = torch.randn(1, 64, TT, device=dev), torch.randn(1, 6, device=dev), torch.randn(1, 12, TT, device=dev)
+    NB = args.clips
+    x0, cond, tc = torch.randn(NB, 64, TT, device=dev), torch.randn(NB, 6, device=dev), torch.randn(NB, 12, TT, device=dev)
     model.net.set_sample_persist(True)
     for _ in range(3):
         model.net.cfg_sample(x0, cond, tc, 50, 2.0, 1.0, -4.0)
@@ -76,7 +78,7 @@ print(f"XCD {args.xcd} step: {(t[:, 2 * len(names) - 1].max() - t0) / 100.0:.1f}
       f"barriers (last arrival -> last exit) {tot_bar:.1f} us")
 
 
-if args.offline:  # effective shader clock over the step; inside the last layer's qkv phase (workgroup-local stamps of wave 0)
+if args.offline and args.clips == 1:  # effective shader clock over the step; inside the last layer's qkv phase (workgroup-local stamps of wave 0)
     cyc = (buf[:, 71].astype(np.int64) - buf[:, 70].astype(np.int64))
     wall = (t_all[:, 2 * len(names) - 1] - t_all[:, 0]) / 100.0
     print("effective shader clock over the step: %.0f MHz (median over workgroups)" % np.median(cyc / wall))
@@ -97,3 +99,22 @@ if args.offline:  # effective shader clock over the step; inside the last layer'
                   v for k in range(5) for v in (np.median(rela[:, k]), rela[:, k].max())) + (np.median(arra), arra.max())))
     gw = buf[:, 72:80].astype(np.int64)
     print("qkv phase, end of each wave's MFMAs (median us after the barrier): " + " ".join("%.2f" % v for v in np.median((gw - t_all[:, 2 * ph][:, None]) / 100.0, 0)))
+
+if args.offline and args.clips > 1:  # the clip-per-XCD kernel: effective shader clock, anatomy of the last layer's qkv phase (first tile of a workgroup)
+    cyc = (buf[:, 71].astype(np.int64) - buf[:, 70].astype(np.int64))
+    wall = (t_all[:, 2 * len(names) - 1] - t_all[:, 0]) / 100.0
+    okw = wall > 0
+    print("effective shader clock over the step: %.0f MHz (median over workgroups)" % np.median(cyc[okw] / wall[okw]))
+    ph = 2 + 5 * (L - 1)
+    gq = buf[okw][:, 64:68].astype(np.int64)
+    rel = (gq - t_all[okw][:, 2 * ph][:, None]) / 100.0
+    arr = (t_all[okw][:, 2 * ph + 1] - t_all[okw][:, 2 * ph]) / 100.0
+    lc = (buf[okw][:, 69].astype(np.int64) - buf[okw][:, 68].astype(np.int64))
+    print("qkv phase, first tile, median us after the barrier: entry %.2f, slab 0 published %.2f, K loop done %.2f, epilogue issued %.2f; "
+          "phase %.2f; shader cycles entry -> loop done %.0f (%.0f MHz)" % (tuple(np.median(rel, 0).tolist()) + (np.median(arr), np.median(lc), np.median(lc / ((gq[:, 2] - gq[:, 0]) / 100.0)))))
+    pr = buf[okw][:, 88:120].astype(np.int64).reshape(-1, 8, 4)
+    if pr.any():  # -DX6R_PROF=1 builds: per-wave cycle counters of the traced GEMM phase's K loop
+        med = np.median(pr, 0)
+        print("traced GEMM phase, per wave, median shader cycles [fragment wait, DMA wait, barrier, MFMA stream]:")
+        for w in range(8):
+            print("  wave %d: %s  (sum %d)" % (w, " ".join("%7d" % v for v in med[w]), med[w].sum()))

@@ -1,0 +1,96 @@
+"""The persistent offline sampler for a BATCH of clips (denoiser.hip: sample_clip_kernel -- all Euler steps of every clip in
+one launch, one clip per XCD, the Linears on the LDS-staged bf16 x 3 pipeline of gemm_x6) against the launch-per-kernel path of
+the same handle and against the CPU oracle.  Both GPU paths form the big Linears' fp32 products from the same exact three-way
+bf16 splits with different fixed tile shapes / K orders: they agree to fp32 round-off.  -m gpu."""
+import pytest
+import torch
+
+import oracle
+from after_amd import _lib, pipeline
+from fixtures import max_abs, rel_l2
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def base(hip_device):
+    model, dcfg, _ = pipeline.build_models("base", "baseAE", hip_device, seed=5)
+    return model, dcfg
+
+
+def _inputs(B, T, seed, net, uniform_tc=False):
+    g = torch.Generator().manual_seed(seed)
+    x0 = torch.randn(B, net.n_channels, T, generator=g)
+    cond = torch.randn(B, net.cond_dim, generator=g)
+    tc = (torch.rand if uniform_tc else torch.randn)(B, net.tcond_dim, T, generator=g)
+    return x0, cond, tc
+
+
+@pytest.mark.parametrize("B,T,steps", [(8, 256, 4), (5, 128, 3), (8, 64, 3), (6, 192, 2), (16, 64, 2), (11, 48, 2)])
+def test_clip_sampler_matches_launch_path_and_oracle(B, T, steps, base, hip_device):
+    model, dcfg = base
+    net = model.net
+    x0, cond, tc = _inputs(B, T, 100 + B + T, net)
+    args = (x0.to(hip_device), cond.to(hip_device), tc.to(hip_device), steps, 2.0, 1.0, -4.0)
+    net.set_sample_persist(False)
+    ref = net.cfg_sample(*args).cpu()
+    assert net.sample_path() == 0
+    net.set_sample_persist(True)
+    got = net.cfg_sample(*args).cpu()
+    assert net.sample_path() == 2, "the clip-per-XCD sampler refused an eligible shape"
+    again = net.cfg_sample(*args).cpu()
+    assert torch.equal(got, again), "not reproducible"
+    assert torch.isfinite(got).all()
+    assert max_abs(got, ref) < 5e-5, max_abs(got, ref)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    for c in sorted({0, B // 2, B - 1}):  # the oracle on single clips (a few seconds each at T = 256)
+        want = oracle.sample(sd, dcfg["net"], x0[c:c + 1], cond[c:c + 1], tc[c:c + 1], steps, 2.0, 1.0)
+        assert max_abs(got[c:c + 1], want) < 1e-4 and rel_l2(got[c:c + 1], want) < 2e-5, (c, max_abs(got[c:c + 1], want))
+
+
+def test_clip_sampler_clips_are_independent(base, hip_device):
+    """Clip c of a batch == the same clip sampled alone (launch path / segment kernel): nothing leaks between the XCDs."""
+    model, _ = base
+    net = model.net
+    x0, cond, tc = _inputs(8, 256, 9, net)
+    net.set_sample_persist(True)
+    got = net.cfg_sample(x0.to(hip_device), cond.to(hip_device), tc.to(hip_device), 3, 1.5, 2.5, -4.0).cpu()
+    assert net.sample_path() == 2
+    net.set_sample_persist(False)
+    for c in (0, 3, 7):
+        one = net.cfg_sample(x0[c:c + 1].to(hip_device), cond[c:c + 1].to(hip_device), tc[c:c + 1].to(hip_device), 3, 1.5, 2.5, -4.0).cpu()
+        assert max_abs(got[c:c + 1], one) < 5e-5, (c, max_abs(got[c:c + 1], one))
+    net.set_sample_persist(True)
+
+
+def test_small_batches_and_other_lengths_take_the_other_paths(base, hip_device):
+    """Below the clip threshold the one-clip segment kernel (B = 1) or the launch path serve the call; a length that is not a
+    multiple of 16 frames runs by launches.  Results held to the launch path."""
+    model, _ = base
+    net = model.net
+    net.set_sample_persist(True)
+    for B, T, want_path in ((1, 256, 1), (2, 256, 0), (8, 250, 0)):
+        x0, cond, tc = _inputs(B, T, 31 + B, net)
+        args = (x0.to(hip_device), cond.to(hip_device), tc.to(hip_device), 2, 2.0, 1.0, -4.0)
+        got = net.cfg_sample(*args).cpu()
+        assert net.sample_path() == want_path, (B, T, net.sample_path())
+        net.set_sample_persist(False)
+        ref = net.cfg_sample(*args).cpu()
+        net.set_sample_persist(True)
+        assert max_abs(got, ref) < 5e-5
+
+
+def test_midi_cfg_arrangement_on_the_clip_sampler(hip_device):
+    """BASELINE config 4's denoiser (base width, piano-roll time conditioning): CFG_MIDI and CFG_API row arrangements."""
+    model, dcfg, _ = pipeline.build_models("midi", "baseAE", hip_device, seed=9)
+    net = model.net
+    x0, cond, tc = _inputs(8, 256, 77, net, uniform_tc=True)
+    x0, cond, tc = x0.to(hip_device), cond.to(hip_device), tc.to(hip_device)
+    for mode in (_lib.CFG_MIDI, _lib.CFG_API):
+        net.set_sample_persist(False)
+        ref = net.cfg_sample(x0, cond, tc, 4, 1.5, 2.0, -4.0, cfg_mode=mode).cpu()
+        net.set_sample_persist(True)
+        got = net.cfg_sample(x0, cond, tc, 4, 1.5, 2.0, -4.0, cfg_mode=mode).cpu()
+        assert net.sample_path() == 2, mode
+        assert torch.isfinite(got).all() and max_abs(got, ref) < 5e-5, (mode, max_abs(got, ref))
