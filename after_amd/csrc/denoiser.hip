@@ -2059,21 +2059,15 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
 // after the other (the samples are independent).  Rows are provisioned in whole tiles: a clip length that does not fill
 // the last row tile computes padding rows nobody reads.
 using ClipQU = X6RCfg<12, 12, 4, 2, 1>;                     // qkv / MLP-up: 192 x 192, waves = 4 row parts x 2 column parts, rolling fragments
-using ClipDn = X6RCfg<6, 16, 2, 4, 1>;                      // MLP-down: 96 x 256 x two K halves (32 work items), waves = 2 row parts x 4 column parts
+using ClipDn = X6Cfg<6, 8, 1, 2, 4, 2, 0, 1, 1, 0, 0, 1>;  // MLP-down: 96 x 128 (32 tiles), waves = 2 row parts x 4 column parts, even / odd slabs in separate accumulators
 #ifndef CLIP_LOADERS
 #define CLIP_LOADERS 4
 #endif
-#ifndef CLIP_TRACE_DOWN
-#define CLIP_TRACE_DOWN 0
-#endif
-#ifndef CLIP_DIAG
-#define CLIP_DIAG 0
-#endif
+
 constexpr int kClipLoaders = CLIP_LOADERS;  // loader waves of a GEMM phase (waves 0 .. : one per SIMD)
 constexpr int kClipRowTile = 192;  // rows of an XCD's slices are provisioned in multiples of it (both tile heights divide it)
 constexpr int kClipMaxT = 1024;    // longest clip the slices are provisioned for (15.5 MB per XCD at T = 256)
 // dynamic LDS: the GEMM ring of the larger tile | attention rows + K / V landing zones | the tail's partial tiles
-constexpr int kClipDnParts = 2;  // K parts of the MLP-down work items (clip_gemm_r, EPI 2)
 constexpr size_t kClipLds = (size_t)ClipQU::NS * ClipQU::STAGE > (size_t)ClipDn::NS * ClipDn::STAGE ? (size_t)ClipQU::NS * ClipQU::STAGE
                                                                                                     : (size_t)ClipDn::NS * ClipDn::STAGE;
 static_assert(kClipLds >= (8192 + 8 * 2 * kAttnKeyBlock * 64) * sizeof(float), "attention landing zones beyond the ring");
@@ -2091,7 +2085,6 @@ struct ClipArgs {
     float* xt;                // token-major latents [B * T][Cp]: a step's input, rewritten by its tail
     float *pat_t, *xres_t;    // per-XCD slices, 16 x 16-tiled fp32: [8][pat_rows][E], [8][rows_pad][E]
     float* qkv;               // [8][rows_pad][3E] row-major, RoPE applied to q and k
-    float* dnp;               // [8][rows_pad][E]: K part 0's partial sums of MLP-down, tiled
     unsigned short *h3, *mlp3;  // [8] x6 planes of [rows_pad][E] / [rows_pad][ME]
     const float *patch_wt, *patch_b, *out_wt, *out_b;
     const float* tc_ab;
@@ -2118,11 +2111,6 @@ struct ClipGemm {
     const float *rope_cos, *rope_sin;
     int T;
     float* xres;            // EPI 2: residual in / out, 16 x 16 tiles [M / 16][N / 16][256]
-    int kparts;             // K parts of a work item (EPI 2: item = (tile, K part); 1 otherwise)
-    float* part;            // EPI 2: K part 0's (sums + bias) + xres, tiled like xres
-    unsigned* flags;        // EPI 2: [tile] -- the round in which K part 0's partial sums of the tile were last written (XCD-local)
-    unsigned round;         // EPI 2: this phase's round (monotonic over the launch)
-    unsigned* fail;         // spin time-outs
     unsigned long long* tr; // AFTER_STEP_TRACE stamps of the workgroup's first tile: [64] entry, [65] (unused), [66] K loop done, [67] epilogue issued
 };
 
@@ -2145,14 +2133,13 @@ struct ClipGemm {
 template <class C, int EPI>
 __device__ __forceinline__ void clip_gemm_r(const ClipGemm& g, unsigned char* smem_raw, int rank, int wid, int lane_in) {
     constexpr int BM = C::BM, BN = C::BN, MT = C::MT, NT = C::NT, RS = C::RS;
-    static_assert(C::SC1 == 1, "sc1 operand loads");  // EPI 0: qkv -- rotated fp32 rows; 1: MLP-up -- bias, exact GELU, x6 planes;
-                                                       // 2: MLP-down -- the K part's partial sums, tiled fp32
+    static_assert(C::SC1 == 1 && EPI != 2, "sc1 operand loads");  // EPI 0: qkv -- rotated fp32 rows; 1: MLP-up -- bias, exact GELU, x6 planes
     int lane = lane_in;
     asm volatile("" : "+v"(lane));  // (opaque: everything derived from the lane is this phase's own -- shared with the other phases
                                     //  it is a kernel-lifetime register that the allocator spills into the MFMA loops)
-    const int tiles_m = g.M / BM, tiles_n = g.N / BN, ntiles = tiles_m * tiles_n * g.kparts;  // (work items: K part slowest)
+    const int tiles_m = g.M / BM, tiles_n = g.N / BN, ntiles = tiles_m * tiles_n;
     const int rp = wid % RS, cp = wid / RS;
-    const int nk = g.K / 32 / g.kparts;  // slabs of a work item (even)
+    const int nk = g.K / 32;  // (even)
     X6RState<C> c;
     c.lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem_raw;
     c.voff = (unsigned)lane * 16u;
@@ -2166,16 +2153,10 @@ __device__ __forceinline__ void clip_gemm_r(const ClipGemm& g, unsigned char* sm
     unsigned long long* const tr = threadIdx.x == 0 ? g.tr : nullptr;
     c.prof[0] = c.prof[1] = c.prof[2] = c.prof[3] = c.tprev = 0;
     for (int t = rank; t < ntiles; t += 32) {
-        const int tm = t % tiles_m, tn = (t / tiles_m) % tiles_n, kp = t / (tiles_m * tiles_n);
+        const int tm = t % tiles_m, tn = t / tiles_m;
         if (tr && t == rank) tr[64] = wall_clock64(), tr[68] = __builtin_readcyclecounter();
-        c.a_src = (unsigned long long)(uintptr_t)g.A3 + (unsigned long long)(tm * (BM >> 4)) * c.rgs + (unsigned long long)(kp * nk) * 3072u;
-        c.w_src = (unsigned long long)(uintptr_t)g.W3 + (unsigned long long)(tn * (BN >> 4)) * c.rgs + (unsigned long long)(kp * nk) * 3072u;
-#if CLIP_DIAG & 1  // (timing experiments, wrong results: MLP-down's activations from an L2-resident footprint)
-        if (EPI == 2) c.a_src = (unsigned long long)(uintptr_t)g.A3 + (unsigned long long)((tm & 1) * (BM >> 4)) * c.rgs;
-#endif
-#if CLIP_DIAG & 2  // (... and its weights)
-        if (EPI == 2) c.w_src = (unsigned long long)(uintptr_t)g.W3;
-#endif
+        c.a_src = (unsigned long long)(uintptr_t)g.A3 + (unsigned long long)(tm * (BM >> 4)) * c.rgs;
+        c.w_src = (unsigned long long)(uintptr_t)g.W3 + (unsigned long long)(tn * (BN >> 4)) * c.rgs;
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -2198,28 +2179,16 @@ __device__ __forceinline__ void clip_gemm_r(const ClipGemm& g, unsigned char* sm
         const int crow = lane_e & 15, cq = lane_e >> 4;
         // every operand of the epilogue is requested before the first store: vmcnt counts loads and stores alike, so a load
         // behind a store is waited for together with that store's round trip -- block by block that was 6 us of a 41-us phase
-        f32x4 bv[NT], ov[EPI == 2 ? MT : 1][EPI == 2 ? NT : 1];
+        // (buffer resources + 32-bit byte offsets: 64-bit lane addresses for the loads and stores below were forty spilled pairs)
+        const __amdgpu_buffer_rsrc_t out_r = step_rsrc(EPI == 0 ? static_cast<const void*>(g.out) : static_cast<const void*>(g.out3));
+        const __amdgpu_buffer_rsrc_t cos_r = step_rsrc(g.rope_cos), sin_r = step_rsrc(g.rope_sin), bias_r = step_rsrc(g.bias);
+        f32x4 bv[NT];
         float2 rcs[EPI == 0 ? MT : 1][EPI == 0 ? NT : 1], rsn[EPI == 0 ? MT : 1][EPI == 0 ? NT : 1];
-        if constexpr (EPI == 2) {
-            // MLP-down: K part 0 leaves part = (its sums + bias) + xres and raises the tile's flag; K part 1 (a workgroup of the same
-            // XCD that finishes at about the same time) waits for the flag and writes xres = its sums + part: the residual stream
-            // is complete when the phase ends, in one fixed order of additions (K part 0 has read xres before it raises the flag)
-            if (kp != 0) {
-                if (threadIdx.x == 0) seg_spin_sys(g.flags + tm * tiles_n + tn, g.round, g.fail);
-                __syncthreads();
-            }
-        }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int cb = col0 + 16 * j, gn = cb + 4 * cq;
             bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (EPI == 1) bv[j] = *reinterpret_cast<const f32x4*>(g.bias + gn);
-            if constexpr (EPI == 2) {
-                if (kp == 0) bv[j] = *reinterpret_cast<const f32x4*>(g.bias + gn);
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    ov[i][j] = ld_l2(step_rsrc(kp == 0 ? g.xres : g.part), (unsigned)(((((row0 >> 4) + i) * (g.N >> 4) + (cb >> 4)) << 8) + lane_e * 4));
-            }
+            if constexpr (EPI == 1) bv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bias_r, (unsigned)gn * 4u, 0, 0));
             if constexpr (EPI == 0) {
                 const bool roped = cb < 2 * kSE && (cb & 63) < 32;  // (wave-uniform; RoPE: rotary_embedding.py:132-173)
 #pragma unroll
@@ -2231,8 +2200,8 @@ __device__ __forceinline__ void clip_gemm_r(const ClipGemm& g, unsigned char* sm
                     const int ro = tf * 16 + (((cb & 63) + 4 * cq) >> 1);
                     rcs[i][j] = make_float2(1.f, 1.f), rsn[i][j] = make_float2(0.f, 0.f);
                     if (roped) {
-                        rcs[i][j] = *reinterpret_cast<const float2*>(g.rope_cos + ro);
-                        rsn[i][j] = *reinterpret_cast<const float2*>(g.rope_sin + ro);
+                        rcs[i][j] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(cos_r, (unsigned)ro * 4u, 0, 0));
+                        rsn[i][j] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(sin_r, (unsigned)ro * 4u, 0, 0));
                     }
                 }
             }
@@ -2243,7 +2212,6 @@ __device__ __forceinline__ void clip_gemm_r(const ClipGemm& g, unsigned char* sm
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 if constexpr (EPI == 0) asm volatile("" : "+v"(rcs[i][j]), "+v"(rsn[i][j]));
-                if constexpr (EPI == 2) asm volatile("" : "+v"(ov[i][j]));
             }
         }
 #pragma unroll
@@ -2255,22 +2223,17 @@ __device__ __forceinline__ void clip_gemm_r(const ClipGemm& g, unsigned char* sm
                 const f32x4 o = c.acc[i][j];
                 if constexpr (EPI == 0) {
                     const float2 cs = rcs[i][j], sn = rsn[i][j];  // (blocks that are not rotated: cos = 1, sin = 0 -- exact)
-                    *reinterpret_cast<f32x4*>(g.out + (size_t)gm * g.N + gn) =
-                        f32x4{o[0] * cs.x - o[1] * sn.x, o[1] * cs.x + o[0] * sn.x, o[2] * cs.y - o[3] * sn.y, o[3] * cs.y + o[2] * sn.y};
-                } else if constexpr (EPI == 1) {
+                    const f32x4 r = f32x4{o[0] * cs.x - o[1] * sn.x, o[1] * cs.x + o[0] * sn.x, o[2] * cs.y - o[3] * sn.y, o[3] * cs.y + o[2] * sn.y};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r), out_r, (unsigned)(gm * g.N + gn) * 4u, 0, 0);
+                } else {  // (x6_store4 with a 32-bit offset: the three planes of the four values, 1 KB apart)
                     const f32x4 v = o + bv[j];
-                    x6_store4(g.out3, gm, gn, g.N, gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
-                } else {  // (a block is one contiguous KB of the tiled tensors)
-                    const unsigned off = (unsigned)(((((row0 >> 4) + i) * (g.N >> 4) + (cb >> 4)) << 8) + lane_e * 4);
-                    *reinterpret_cast<f32x4*>((kp == 0 ? g.part : g.xres) + off) = (o + bv[j]) + ov[i][j];  // (K part 1: bv = 0)
+                    uint2 ph, pm, pl;
+                    x6_split4(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]), ph, pm, pl);
+                    const unsigned off = (unsigned)x6_offset(gm, 0, gn, g.N) * 2u;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ph), out_r, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pm), out_r, off + 1024u, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pl), out_r, off + 2048u, 0, 0);
                 }
-            }
-        }
-        if constexpr (EPI == 2) {
-            if (kp == 0) {  // the partial sums are in the XCD's L2 (write-through L1): raise the tile's flag
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (threadIdx.x == 0) __builtin_amdgcn_raw_buffer_store_b32(g.round, step_rsrc(g.flags + tm * tiles_n + tn), 0, 0, 17);
             }
         }
         if (tr && t == rank) tr[67] = wall_clock64();
@@ -2278,6 +2241,90 @@ __device__ __forceinline__ void clip_gemm_r(const ClipGemm& g, unsigned char* sm
     if (X6R_PROF && g.tr && (threadIdx.x & 63) == 0) {  // (per wave: [88 + 4 w ..] of the workgroup's stamps)
 #pragma unroll
         for (int k = 0; k < 4; ++k) g.tr[88 + 4 * wid + k] = c.prof[k];
+    }
+}
+
+// MLP-down of an XCD on the loader-wave ring with double-buffered fragments (x6l_*: 96 x 128 tiles, one per workgroup at T = 256,
+// K = 1536 with even / odd slabs in separate accumulators): xres = (A3 W3^T + bias) + xres, in place on the tiled residual stream.
+// With several tiles per workgroup the next tile's ring fill is issued BEFORE the finished tile's stores (the epilogue's operands --
+// bias, residual tile -- are fetched and waited for first: a compiler-placed wait behind the fill would wait for the fill).
+template <class C>
+__device__ __forceinline__ void clip_gemm_l(const ClipGemm& g, unsigned char* smem_raw, int rank, int wid, int lane_in) {
+    constexpr int BM = C::BM, BN = C::BN, MT = C::MT, NT = C::NT, RS = C::RS;
+    constexpr int STORES = MT * NT;  // vector-memory instructions of a tile's epilogue behind the fill
+    static_assert(C::KS == 1 && C::SC1 == 1 && C::NS == 2, "clip tiles: no k-parts, sc1 operand loads");
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));  // (opaque: see clip_gemm_r)
+    const int tiles_m = g.M / BM, tiles_n = g.N / BN, ntiles = tiles_m * tiles_n;
+    const int rp = wid % RS, cp = wid / RS;
+    const int nk = g.K / 32;  // (>= 4)
+    int t = rank;
+    if (t >= ntiles) return;
+    X6LState<C> c;
+    c.lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem_raw;
+    c.voff = (unsigned)lane * 16u;
+    c.rgs = (unsigned)nk * 3072u;
+    {
+        const int frow = lane & 15, kq = lane >> 4;
+        const unsigned sw = (unsigned)((kq ^ swz4((frow >> 2) & 3)) * 16);
+        c.a_rd = c.lds0 + (unsigned)((rp * (BM / RS) + frow) * 64) + sw;
+        c.w_rd = c.lds0 + (unsigned)(C::GA * 1024 + (cp * (BN / C::CP) + frow) * 64) + sw;
+    }
+    c.a_src = (unsigned long long)(uintptr_t)g.A3 + (unsigned long long)((t % tiles_m) * (BM >> 4)) * c.rgs;
+    c.w_src = (unsigned long long)(uintptr_t)g.W3 + (unsigned long long)((t / tiles_m) * (BN >> 4)) * c.rgs;
+    CLIP_ROLE(wid, (x6l_fill<C, kClipLoaders, LID>(c)));
+    for (bool first = true;; first = false) {
+        const int tm = t % tiles_m, tn = t / tiles_m;
+#pragma unroll
+        for (int q = 0; q <= C::ACC2; ++q)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) c.acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (first) {
+            CLIP_ROLE(wid, (x6l_main<C, kClipLoaders, LID, 0>(c, nk)));
+        } else {
+            CLIP_ROLE(wid, (x6l_main<C, kClipLoaders, LID, STORES>(c, nk)));
+        }
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));  // (the epilogue's index arithmetic stays behind the K loop: see clip_gemm_r)
+        const int row0 = tm * BM + rp * (BM / RS), col0 = tn * BN + cp * (BN / C::CP);
+        f32x4 bv[NT], rv[MT][NT];
+        const __amdgpu_buffer_rsrc_t xr = step_rsrc(g.xres);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int cb = col0 + 16 * j;
+            bv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(step_rsrc(g.bias), (unsigned)(cb + 4 * (lane_e >> 4)) * 4u, 0, 0));
+#pragma unroll
+            for (int i = 0; i < MT; ++i) rv[i][j] = ld_l2(xr, (unsigned)(((((row0 >> 4) + i) * (g.N >> 4) + (cb >> 4)) << 8) + lane_e * 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            asm volatile("" : "+v"(bv[j]));
+#pragma unroll
+            for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(rv[i][j]));
+        }
+        const int t_next = t + 32;
+        const bool has_next = t_next < ntiles;
+        if (has_next) {
+            __builtin_amdgcn_s_barrier();  // every wave is past its last read of the ring
+            asm volatile("" ::: "memory");
+            c.a_src = (unsigned long long)(uintptr_t)g.A3 + (unsigned long long)((t_next % tiles_m) * (BM >> 4)) * c.rgs;
+            c.w_src = (unsigned long long)(uintptr_t)g.W3 + (unsigned long long)((t_next / tiles_m) * (BN >> 4)) * c.rgs;
+            CLIP_ROLE(wid, (x6l_fill<C, kClipLoaders, LID>(c)));
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int cb = col0 + 16 * j;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const unsigned off = (unsigned)(((((row0 >> 4) + i) * (g.N >> 4) + (cb >> 4)) << 8) + lane_e * 4);
+                const f32x4 o = C::ACC2 ? c.acc[0][i][j] + c.acc[C::ACC2][i][j] : c.acc[0][i][j];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (o + bv[j]) + rv[i][j]), xr, off * 4u, 0, 0);
+            }
+        }
+        if (!has_next) break;
+        t = t_next;
     }
 }
 
@@ -2335,7 +2382,6 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
     float* const pat = a.pat_t + (size_t)g * a.pat_rows * E;
     float* const xres = a.xres_t + (size_t)g * a.rows_pad * E;
     float* const qkv = a.qkv + (size_t)g * a.rows_pad * 3 * E;
-    float* const dnp = a.dnp + (size_t)g * a.rows_pad * E;  // MLP-down: K part 0's partial sums [rows_pad][E], tiled
     unsigned short* const h3 = a.h3 + (size_t)g * a.rows_pad * E * 3;
     unsigned short* const mlp3 = a.mlp3 + (size_t)g * a.rows_pad * ME * 3;
     const __amdgpu_buffer_rsrc_t pat_r = step_rsrc(pat), xres_r = step_rsrc(xres);
@@ -2394,7 +2440,7 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
                 if (!end_phase(true)) return;
                 // ---- qkv
                 {
-                    const ClipGemm gq{h3, Lw.qkv_w3, a.rows_pad, 3 * E, E, nullptr, qkv, nullptr, a.rope_cos, a.rope_sin, T, nullptr, 1, nullptr, nullptr, 0, nullptr, CLIP_TRACE_DOWN ? nullptr : trace};
+                    const ClipGemm gq{h3, Lw.qkv_w3, a.rows_pad, 3 * E, E, nullptr, qkv, nullptr, a.rope_cos, a.rope_sin, T, nullptr, trace};
                     clip_gemm_r<ClipQU, 0>(gq, smem_raw, rank, w, lane);
                 }
                 if (!end_phase(true)) return;
@@ -2410,15 +2456,14 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
                 if (!end_phase(true)) return;
                 // ---- MLP up + GELU
                 {
-                    const ClipGemm gu{h3, Lw.mlp0_w3, a.rows_pad, ME, E, Lw.mlp0_b, nullptr, mlp3, nullptr, nullptr, T, nullptr, 1, nullptr, nullptr, 0, nullptr, nullptr};
+                    const ClipGemm gu{h3, Lw.mlp0_w3, a.rows_pad, ME, E, Lw.mlp0_b, nullptr, mlp3, nullptr, nullptr, T, nullptr, nullptr};
                     clip_gemm_r<ClipQU, 1>(gu, smem_raw, rank, w, lane);
                 }
                 if (!end_phase(true)) return;
                 // ---- MLP down + residual
                 {
-                    const ClipGemm gd{mlp3, Lw.mlp2_w3, a.rows_pad, E, ME, Lw.mlp2_b, nullptr, nullptr, nullptr, nullptr, T, xres, kClipDnParts, dnp,
-                                      &st->gen[xcc][0], round + 1, &st->fail[0], CLIP_TRACE_DOWN ? trace : nullptr};
-                    clip_gemm_r<ClipDn, 2>(gd, smem_raw, rank, w, lane);
+                    const ClipGemm gd{mlp3, Lw.mlp2_w3, a.rows_pad, E, ME, Lw.mlp2_b, nullptr, nullptr, nullptr, nullptr, T, xres, nullptr};
+                    clip_gemm_l<ClipDn>(gd, smem_raw, rank, w, lane);
                 }
                 if (!end_phase(true)) return;
             }
@@ -3392,7 +3437,7 @@ int persist_prepare(after_denoiser* h, bool offline) {
     // the clip-per-XCD sampler's slices: for handles provisioned for a batch of clips of moderate length
     if (offline && h->persist_clip && !h->clip_act && h->max_rows >= 3 * h->clip_min_b && h->max_T <= kClipMaxT) {
         const size_t rows = (size_t)cdiv(3 * h->max_T, kClipRowTile) * kClipRowTile, prow = (size_t)cdiv(h->max_T, 16) * 16;
-        const size_t nf = 8 * (prow * E + rows * E + rows * 3 * E + rows * E), n3 = 8 * rows * 3 * (E + ME);
+        const size_t nf = 8 * (prow * E + rows * E + rows * 3 * E), n3 = 8 * rows * 3 * (E + ME);
         float* f = nullptr;
         unsigned short* a3 = nullptr;
         const bool ok = hipMalloc(&f, nf * sizeof(float)) == hipSuccess && hipMalloc(&a3, n3 * sizeof(unsigned short)) == hipSuccess &&
@@ -3676,8 +3721,7 @@ int sample_clip(after_denoiser* h, hipStream_t s, const float* x0, float* out, i
         float* p = h->clip_act;
         a.pat_t = p, p += (size_t)8 * h->clip_pat_rows * E;
         a.xres_t = p, p += (size_t)8 * h->clip_rows * E;
-        a.qkv = p, p += (size_t)8 * h->clip_rows * 3 * E;
-        a.dnp = p;
+        a.qkv = p;
         a.h3 = h->clip_act3, a.mlp3 = h->clip_act3 + (size_t)8 * h->clip_rows * 3 * E;
     }
     a.patch_wt = h->step_patch_wt, a.patch_b = h->patch_b, a.out_wt = h->step_out_wt, a.out_b = h->out_b;
