@@ -2344,6 +2344,126 @@ __device__ __attribute__((noinline)) void clip_attention(StepAttn g, const float
     step_attention<16, 2, true>(g, nokv, none, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout, ab, w3, b3, tr);
 }
 
+// Attention + residual + AdaLN(cond) + norm3 for a PAIR of consecutive chunks of one CFG row (transformerv2.py:190-236, :351-361;
+// mask: combined_sliding_chunkwise_mask, :62-96): the pair's 2 cs queries share their K / V rows -- frames [i0 - W + 1, e), fetched
+// once by LDS-DMA (one round trip for the item: K / V, q, the residual rows and the LayerNorm operands go out together) -- and
+// every query keeps its own chunk's bounds: keys [min(chunk start, j - W + 1), chunk end).  Two passes of four queries per wave
+// (wave = head, 16-lane group = query, lane = 4 dims); then all eight waves have a row of the LayerNorm tail (a single chunk
+// leaves four of them idle).  q and k arrive rotated (the qkv epilogue applies RoPE); h leaves as x6 planes.  W - 1 + 2 cs <= 16.
+// (out of line, every argument by value and re-uniformed: see seg_attention)
+__device__ __attribute__((noinline)) void clip_attention_pair(StepAttn g, const float* lab, const float* lw3, const float* lb3, int rg, int lr0,
+                                                              int px, float* smem, float* kvlds, float* xres, unsigned short* h3) {
+    g.T = seg_uniform(g.T), g.cs = seg_uniform(g.cs), g.W = seg_uniform(g.W);
+    g.qkv = seg_uniform(g.qkv);
+    lab = seg_uniform(lab), lw3 = seg_uniform(lw3), lb3 = seg_uniform(lb3);
+    rg = seg_uniform(rg), lr0 = seg_uniform(lr0), px = seg_uniform(px);
+    smem = seg_uniform(smem), kvlds = seg_uniform(kvlds), xres = seg_uniform(xres), h3 = seg_uniform(h3);
+    constexpr int NKB = 16, E = kSE, H = kSH, KBt = E / 16, ld = E + 4, NV = E / 256;
+    const int T = g.T, cs = g.cs, W = g.W;
+    const int tid = threadIdx.x, lane = tid & 63, hw = tid >> 6;
+    const int grp = lane >> 4, d4 = (lane & 15) * 4;
+    const int i0 = px * 2 * cs, e = min(i0 + 2 * cs, T), nq = e - i0;
+    const int lo_c = max(0, i0 - W + 1), nk = e - lo_c;  // (<= 16: one key block)
+    const unsigned rowbase = (unsigned)rg * T;
+    const __amdgpu_buffer_rsrc_t qkvr = step_rsrc(g.qkv), xr = step_rsrc(xres);
+    float* const kvs = kvlds + hw * (2 * NKB * 64);  // per-wave K / V landing zone [2][NKB][64]
+    auto as4 = [](f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
+    // one instruction moves 4 keys: 16-lane group gq fetches the 256-byte head slice of key 4 u + gq (sc1: written by this XCD)
+#pragma unroll
+    for (int u = 0; u < NKB / 4; ++u) {
+        const int pos = lo_c + min(4 * u + grp, nk - 1);
+        const float* ksrc = g.qkv + ((size_t)rowbase + pos) * 3 * E + E + hw * 64 + d4;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)ksrc, (lds_ptr_t)(kvs + 4 * u * 64), 16, 0, 16);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ksrc + E), (lds_ptr_t)(kvs + (NKB + 4 * u) * 64), 16, 0, 16);
+    }
+    StepLnOps ops;
+    if (hw < nq) step_ln_ops(ops, lab, lw3, lb3, lane);
+    float4 q4[2], x4[2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int qic = min(4 * ps + grp, nq - 1);
+        q4[ps] = as4(__builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qkvr, ((rowbase + i0 + qic) * 3u * E + hw * 64 + d4) * 4u, 0, 16)));
+        x4[ps] = as4(ld_l2(xr, t16_off(lr0 + i0 + qic, hw * 64 + d4, KBt)));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the K / V block (and everything else) has landed
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int qi = 4 * ps + grp;
+        if (4 * ps >= nq) break;
+        const bool qok = qi < nq;
+        const int ja = i0 + (qok ? qi : nq - 1);
+        const int cstart = ja - (ja - i0) % cs;                   // the query's chunk [cstart, cend)
+        const int lo_row = min(cstart, max(0, ja - W + 1)), cend = min(cstart + cs, T);
+        float sc[NKB];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NKB; ++j) {
+            const int pos = lo_c + min(j, nk - 1);
+            const float4 kr = *reinterpret_cast<const float4*>(kvs + j * 64 + d4);
+            float dot = q4[ps].x * kr.x + q4[ps].y * kr.y + q4[ps].z * kr.z + q4[ps].w * kr.w;
+            dot = group16_sum(dot);
+            sc[j] = (j < nk && pos >= lo_row && pos < cend) ? dot * 0.125f : -INFINITY;
+            mx = fmaxf(mx, sc[j]);
+        }
+        float sum = 0.f;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < NKB; ++j) {
+            const float p = attn_exp(sc[j] - mx);  // exp(-inf) = 0 for masked / padded slots
+            sum += p;
+            const float4 vj = *reinterpret_cast<const float4*>(kvs + (NKB + j) * 64 + d4);
+            o.x += p * vj.x, o.y += p * vj.y, o.z += p * vj.z, o.w += p * vj.w;
+        }
+        const float inv = 1.0f / sum;
+        if (qok) {
+            float4 res;
+            res.x = o.x * inv + x4[ps].x, res.y = o.y * inv + x4[ps].y, res.z = o.z * inv + x4[ps].z, res.w = o.w * inv + x4[ps].w;
+            *reinterpret_cast<float4*>(smem + qi * ld + hw * 64 + d4) = res;
+        }
+    }
+    __syncthreads();
+    // ---- AdaLN(cond) + norm3, one wave per row
+    for (int qi = hw; qi < nq; qi += H) {
+        float4 v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(smem + qi * ld + 4 * lane + 256 * i);
+        auto stats = [&](float& mean, float& rstd) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            mean = wave_sum(s) / (float)E;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+                q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+            rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + 1e-5f);
+        };
+        float mean, rstd;
+        stats(mean, rstd);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i].x = (v[i].x - mean) * rstd * (1.0f + ops.al[i].x) + ops.be[i].x;
+            v[i].y = (v[i].y - mean) * rstd * (1.0f + ops.al[i].y) + ops.be[i].y;
+            v[i].z = (v[i].z - mean) * rstd * (1.0f + ops.al[i].z) + ops.be[i].z;
+            v[i].w = (v[i].w - mean) * rstd * (1.0f + ops.al[i].w) + ops.be[i].w;
+        }
+        stats(mean, rstd);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            *reinterpret_cast<float4*>(xres + t16_off(lr0 + i0 + qi, 4 * lane + 256 * i, KBt)) = v[i];
+            float4 y;
+            y.x = (v[i].x - mean) * rstd * ops.ww[i].x + ops.bb[i].x;
+            y.y = (v[i].y - mean) * rstd * ops.ww[i].y + ops.bb[i].y;
+            y.z = (v[i].z - mean) * rstd * ops.ww[i].z + ops.bb[i].z;
+            y.w = (v[i].w - mean) * rstd * ops.ww[i].w + ops.bb[i].w;
+            x6_store4(h3, lr0 + i0 + qi, 4 * lane + 256 * i, E, y.x, y.y, y.z, y.w);
+        }
+    }
+}
+
 __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ unsigned s_rank, s_bad, s_ok;
@@ -2389,7 +2509,9 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
     float* const red = smem;          // tail: partial tiles [8 waves][3][256] | attention rows
     float* const kvl = smem + 8192;   // attention: K / V landing zones [8 waves][2][12][64]
     auto end_phase = [&](bool drain) { return step_barrier(st, xcc, n, (unsigned)rank, ++round, trace, ++tslot, drain, &s_ok); };
-    const int cps = (T + a.cs - 1) / a.cs, nitems = 3 * cps;  // attention items: (CFG row, chunk)
+    const int cps = (T + a.cs - 1) / a.cs, nitems = 3 * cps;  // attention items: (CFG row, chunk) ...
+    const bool pairs = a.W - 1 + 2 * a.cs <= 16 && T % a.cs == 0 && 2 * a.cs <= 8 && !(a.dbg & 64);  // ... or (CFG row, pair of chunks)
+    const int npair = (cps + 1) / 2;
     const int nfb = T / 16, ntail = (a.C / 16) * nfb;         // tail items: (column tile, 16-frame block)
 
     for (int c = g; c < B; c += 8) {  // ---- this XCD's clips, one after the other
@@ -2446,12 +2568,22 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
                 if (!end_phase(true)) return;
                 // ---- attention + residual + AdaLN(cond) + norm3 (transformerv2.py:190-236, :351-361): one workgroup per chunk
                 //      of a CFG row; h as x6 planes
-                for (int it = rank; it < nitems; it += (int)n) {
-                    const int br = it / cps, ch = it - br * cps;
-                    __syncthreads();  // (a second item of this workgroup reuses the LDS rows)
-                    clip_attention(StepAttn{T, a.cs, a.W, 0, a.nkmax, a.rope_cos, a.rope_sin, qkv},
-                                   cond_ab + (size_t)(br * B + c) * a.cond_ld + (size_t)l * 2 * E, Lw.n3w, Lw.n3b, br, br * T, ch, smem, kvl,
-                                   xres, reinterpret_cast<float*>(h3), trace);
+                if (pairs) {  // items = pairs of chunks: shared K / V rows, a LayerNorm row for each of the eight waves
+                    for (int it = rank; it < 3 * npair; it += (int)n) {
+                        const int br = it / npair, px = it - br * npair;
+                        __syncthreads();  // (a second item of this workgroup reuses the LDS rows)
+                        clip_attention_pair(StepAttn{T, a.cs, a.W, 0, a.nkmax, a.rope_cos, a.rope_sin, qkv},
+                                            cond_ab + (size_t)(br * B + c) * a.cond_ld + (size_t)l * 2 * E, Lw.n3w, Lw.n3b, br, br * T, px, smem, kvl,
+                                            xres, h3);
+                    }
+                } else {
+                    for (int it = rank; it < nitems; it += (int)n) {
+                        const int br = it / cps, ch = it - br * cps;
+                        __syncthreads();  // (a second item of this workgroup reuses the LDS rows)
+                        clip_attention(StepAttn{T, a.cs, a.W, 0, a.nkmax, a.rope_cos, a.rope_sin, qkv},
+                                       cond_ab + (size_t)(br * B + c) * a.cond_ld + (size_t)l * 2 * E, Lw.n3w, Lw.n3b, br, br * T, ch, smem, kvl,
+                                       xres, reinterpret_cast<float*>(h3), trace);
+                    }
                 }
                 if (!end_phase(true)) return;
                 // ---- MLP up + GELU
