@@ -2395,25 +2395,35 @@ __device__ __attribute__((noinline)) void clip_attention_pair(StepAttn g, const 
         const int ja = i0 + (qok ? qi : nq - 1);
         const int cstart = ja - (ja - i0) % cs;                   // the query's chunk [cstart, cend)
         const int lo_row = min(cstart, max(0, ja - W + 1)), cend = min(cstart + cs, T);
+        // a pass = the four queries of ONE chunk when cs = 4: its keys are the NKP slots from the chunk's first visible frame on
+        // (W - 1 + cs <= 12 of the block's 16: a quarter of the key loop's arithmetic less); other chunk sizes walk all 16
+        constexpr int NKP = 12;
+        const bool chunk_pass = cs == 4 && W - 1 + cs <= NKP;
+        const int j0 = chunk_pass ? max(0, cstart - (W - 1) - lo_c) : 0, jn = chunk_pass ? NKP : NKB;
         float sc[NKB];
         float mx = -INFINITY;
 #pragma unroll
         for (int j = 0; j < NKB; ++j) {
-            const int pos = lo_c + min(j, nk - 1);
-            const float4 kr = *reinterpret_cast<const float4*>(kvs + j * 64 + d4);
-            float dot = q4[ps].x * kr.x + q4[ps].y * kr.y + q4[ps].z * kr.z + q4[ps].w * kr.w;
-            dot = group16_sum(dot);
-            sc[j] = (j < nk && pos >= lo_row && pos < cend) ? dot * 0.125f : -INFINITY;
-            mx = fmaxf(mx, sc[j]);
+            sc[j] = -INFINITY;
+            if (j < NKP || jn > NKP) {  // (wave-uniform)
+                const int js = j0 + j, pos = lo_c + min(js, nk - 1);
+                const float4 kr = *reinterpret_cast<const float4*>(kvs + min(js, NKB - 1) * 64 + d4);
+                float dot = q4[ps].x * kr.x + q4[ps].y * kr.y + q4[ps].z * kr.z + q4[ps].w * kr.w;
+                dot = group16_sum(dot);
+                sc[j] = (js < nk && pos >= lo_row && pos < cend) ? dot * 0.125f : -INFINITY;
+                mx = fmaxf(mx, sc[j]);
+            }
         }
         float sum = 0.f;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < NKB; ++j) {
-            const float p = attn_exp(sc[j] - mx);  // exp(-inf) = 0 for masked / padded slots
-            sum += p;
-            const float4 vj = *reinterpret_cast<const float4*>(kvs + (NKB + j) * 64 + d4);
-            o.x += p * vj.x, o.y += p * vj.y, o.z += p * vj.z, o.w += p * vj.w;
+            if (j < NKP || jn > NKP) {
+                const float p = attn_exp(sc[j] - mx);  // exp(-inf) = 0 for masked / padded slots
+                sum += p;
+                const float4 vj = *reinterpret_cast<const float4*>(kvs + (NKB + min(j0 + j, NKB - 1)) * 64 + d4);
+                o.x += p * vj.x, o.y += p * vj.y, o.z += p * vj.z, o.w += p * vj.w;
+            }
         }
         const float inv = 1.0f / sum;
         if (qok) {

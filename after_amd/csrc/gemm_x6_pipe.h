@@ -551,7 +551,7 @@ __device__ __forceinline__ void x6r_mma(X6RState<C>& c, bool refill, bool more, 
             if (more) x6r_reads<C, CUR ^ 1, R, r1>(c, a_next, w_next);
         }
         __builtin_amdgcn_sched_barrier(0);
-        x6r_mma<C, NL, LID, CUR, S + 1, r1, dma_here ? D + 1 : D>(c, refill, more, slab_new, stage_new, a_next, w_next);
+        x6r_mma<C, NL, LID, CUR, S + 1, r1, (dma_here ? D + 1 : D)>(c, refill, more, slab_new, stage_new, a_next, w_next);
     }
 }
 
