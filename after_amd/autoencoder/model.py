@@ -455,8 +455,6 @@ class AutoEncoder(nn.Module):
             _lib.check(_lib.lib().after_ae_reset_state(self._handle, _lib.current_stream(dev)),
                        "after_ae_reset_state")
 
-    # ------------------------------------------------------------ reference surface
-    @torch.no_grad()
     def set_stream_lanes(self, lane_rows: int):
         """Two independent groups of `lane_rows` streams in this streaming encoder (see `encode(row0=...)`); call on a
         freshly enabled / reset stream."""
@@ -465,6 +463,8 @@ class AutoEncoder(nn.Module):
         _lib.check(_lib.lib().after_ae_set_stream_lanes(self._handle, int(lane_rows)), "after_ae_set_stream_lanes")
         self._lane_rows = int(lane_rows)
 
+    # ------------------------------------------------------------ reference surface
+    @torch.no_grad()
     def encode(self, x, with_multi: bool = False, return_mean: bool = False, row0=None):
         """SimpleNetsStream.py:918-941 -> (z, regloss); export: z only.  row0 (streaming codecs with lanes): the first
         context row of this batch -- 0 or `lane_rows` for one lane, 0 with a batch of 2 x lane_rows for both."""

@@ -403,6 +403,9 @@ struct after_ae {
     // itself: no second launch per conv), and a pass that completed flips.  pass_*: the area of the pass being issued.
     int enc_slots = 0, dec_slots = 0, nc_slots = 0;
     int enc_flip = 0, dec_flip = 0, nc_flip = 0;
+    // rows of the streams that a flip belongs to, fixed by the first pass after a reset (0 = none yet): a pass updates the
+    // contexts of ITS rows only, so a later pass with other rows would read two-chunk-old contexts for the rest -- refused
+    int enc_rows = 0, enc_rows1 = 0, dec_rows = 0, nc_rows = 0;
     // after_ae_set_stream_lanes: the streaming encoder's batch rows are two independent groups of `lane_rows` streams
     // each (Streamer: structure audio, timbre audio) with their own context parity, so that ONE pass can encode both
     // groups (rows [0, 2 lane_rows)) or either alone (rows [row0, row0 + B)); 0 = one group
@@ -729,12 +732,8 @@ int pqmf_forward(after_ae* h, hipStream_t s, const float* x, float* mb, int B, i
     const int pl = h->causal ? K - 1 : (K - 1) / 2;
     if (M == 16) {
         const size_t lds = ((size_t)M * Q * M + (size_t)M * (PQ_BT + Q + 1)) * sizeof(float);
-        static bool attr = false;
-        if (!attr) {
-            AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pqmf_forward_kernel<16>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr = true;
-        }
+        static LdsAttr attr;
+        AFTER_TRY(ensure_lds_attr(attr, reinterpret_cast<const void*>(pqmf_forward_kernel<16>), lds));
         hipLaunchKernelGGL(pqmf_forward_kernel<16>, dim3(cdiv(L / M, PQ_BT), B), dim3(256), lds, s, x,
                            h->pq_fwp, mb, L, Q, pl, state, cs, ts);
     } else {
@@ -760,12 +759,8 @@ int pqmf_inverse(after_ae* h, hipStream_t s, const float* y, float* audio, int B
     const int pl = h->causal ? K - 1 : (K - 1) / 2;
     if (M == 16) {
         const size_t lds = ((size_t)M * K * M + (size_t)M * (256 + K)) * sizeof(float);
-        static bool attr = false;
-        if (!attr) {
-            AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pqmf_inverse_kernel<16>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr = true;
-        }
+        static LdsAttr attr;
+        AFTER_TRY(ensure_lds_attr(attr, reinterpret_cast<const void*>(pqmf_inverse_kernel<16>), lds));
         hipLaunchKernelGGL(pqmf_inverse_kernel<16>, dim3(cdiv(Tm, 256), B), dim3(256), lds, s, y, h->pq_iwp,
                            audio, Tm, K, pl, gated, ychan, zstate, cs, ts);
     } else {
@@ -1178,6 +1173,7 @@ extern "C" int after_ae_reset_state(after_ae* h, void* stream) {
     h->in_pass = false;
     h->enc_flip = h->dec_flip = h->nc_flip = 0;
     h->enc_flip1 = 0;
+    h->enc_rows = h->enc_rows1 = h->dec_rows = h->nc_rows = 0;
     if (h->sa.base) AFTER_HIP_CHECK(hipMemsetAsync(h->sa.base, 0, h->sa.off, (hipStream_t)stream));
     if (h->sn.base) {
         AFTER_HIP_CHECK(hipMemsetAsync(h->sn.base, 0, h->sn.off, (hipStream_t)stream));
@@ -1370,6 +1366,7 @@ extern "C" int after_ae_enable_streaming(after_ae* h, int enable) {
         AFTER_HIP_CHECK(hipMemset(h->sa.base, 0, h->sa.off));
     }
     h->streaming = true;
+    h->enc_rows = h->enc_rows1 = h->dec_rows = 0;
     return AFTER_OK;
 }
 
@@ -1434,6 +1431,17 @@ static int encode_impl(after_ae* h, const float* x, float* z, int B, int L, int 
     float* sb = h->streaming ? h->enc_state : (h->enc_cached ? h->nc_state : nullptr);
     h->pass_slots = h->streaming ? h->enc_slots : h->nc_slots;
     h->pass_flip = h->streaming ? (lane1 ? &h->enc_flip1 : &h->enc_flip) : &h->nc_flip;
+    if (sb) {  // the streams of a context set are the rows of its first pass (until after_ae_reset_state)
+        const int rows = both ? h->lane_rows : B;
+        int* const seen[2] = {h->streaming ? (lane1 ? &h->enc_rows1 : &h->enc_rows) : &h->nc_rows, both ? &h->enc_rows1 : nullptr};
+        for (int* p : seen) {
+            if (!p) continue;
+            AFTER_REQUIRE(*p == 0 || *p == rows, AFTER_E_INVALID,
+                          "autoencoder: this stream set was started with %d rows, the pass has %d: the conv contexts ping-pong per pass, "
+                          "rows outside a pass would keep a two-chunk-old context -- after_ae_reset_state first", *p, rows);
+            *p = rows;
+        }
+    }
     double* st = nullptr;
     if (h->norm && !h->pass_gnwin) {  // the first GroupNorm sees the PQMF output: its producer is not a conv
         st = next_stats(h, B);
@@ -1560,6 +1568,12 @@ static int decode_impl(after_ae* h, const float* z, float* x, float* mb, int B, 
     float* sb = h->streaming ? h->dec_state : nullptr;
     h->pass_slots = h->dec_slots;
     h->pass_flip = &h->dec_flip;
+    if (sb) {
+        AFTER_REQUIRE(h->dec_rows == 0 || h->dec_rows == B, AFTER_E_INVALID,
+                      "autoencoder: the decoder's streams were started with %d rows, the pass has %d: after_ae_reset_state first "
+                      "(the conv contexts ping-pong per pass)", h->dec_rows, B);
+        h->dec_rows = B;
+    }
     double* st = nullptr;
     AFTER_TRY(run_dma(h, s, h->dec_head.d, z, nullptr, nullptr, nullptr, nullptr, nullptr, ACT_NONE,
                       h->dec_head.bias, nullptr, cur, B, T, T, T, false, nullptr, sb, 1, 0));  // z: [B][Z][T]

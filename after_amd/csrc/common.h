@@ -56,6 +56,22 @@ struct Arena {
     }
 };
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the function ON A DEVICE: a launcher remembers what it has
+// set per device (a process that moves a handle to a second GPU would otherwise launch > 64 KB of dynamic LDS without it)
+struct LdsAttr {
+    size_t set[16] = {};
+};
+inline int ensure_lds_attr(LdsAttr& st, const void* fn, size_t lds) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    dev &= 15;
+    if (lds > st.set[dev]) {
+        AFTER_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        st.set[dev] = lds;
+    }
+    return AFTER_OK;
+}
+
 // Optional per-kernel-family timing with HIP events on the launch stream.
 struct KernelTimer {
     bool enabled = false;

@@ -25,8 +25,14 @@ constexpr int kStatBins = 4;
 constexpr int kStatWords = 2 * kStatBins;  // words per (clip, group)
 
 #if defined(__HIPCC__)
+// NaN / Inf / |p| >= 2^80 saturate to +-2^80 (NaN: +): finite words that add without overflow (< 2^26 in the top word per addend)
+// and that no sum of real activations reaches -- the consumer (gn_scale_shift: kStatBlown) turns a quantity of that size into NaN
+// statistics, so a non-finite element poisons its whole (clip, group) like torch's group_norm instead of vanishing from the sums
+constexpr float kStatSat = 1.2089258196146292e24f;  // 2^80
+constexpr double kStatBlown = 6.0e23;               // |sum| or sum of squares of a (clip, group) at or above this: NaN
 __device__ __forceinline__ void stat_bins_add(long long* bins, float p) {
-    if (p == 0.f || !(fabsf(p) < 3.0e28f)) return;  // (NaN / inf / > 2^95: nothing sensible to accumulate)
+    if (p == 0.f) return;
+    if (!(fabsf(p) < kStatSat)) p = p < 0.f ? -kStatSat : kStatSat;
     int e;
     const float f = frexpf(p, &e);                       // p = f x 2^e, 0.5 <= |f| < 1
     const long long m = (long long)(f * 16777216.0f);    // 24-bit signed significand: p = m x 2^(e - 24), exactly

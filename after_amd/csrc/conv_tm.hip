@@ -114,8 +114,9 @@ __device__ __forceinline__ void gn_mean_rstd(const double* stats, int b, int G, 
         const double mean = sm / n;
         double var = qq / n - mean * mean;
         var = var < 0 ? 0 : var;
-        gmean[gI] = (float)mean;
-        grstd[gI] = (float)(1.0 / sqrt(var + (double)eps));
+        const bool blown = !(fabs(sm) < kStatBlown) || !(qq < kStatBlown);  // a non-finite (saturated) partial sum went in: conv.h
+        gmean[gI] = blown ? __builtin_nanf("") : (float)mean;
+        grstd[gI] = blown ? __builtin_nanf("") : (float)(1.0 / sqrt(var + (double)eps));
     }
     __syncthreads();
 }
@@ -963,13 +964,9 @@ int launch_tm_cfg(ConvTmArgs a, int B, bool dil, hipStream_t s) {
             }
         }
     }
-    static size_t attr[4] = {0, 0, 0, 0};  // per (DIL, Y2) variant of this configuration
+    static LdsAttr attr[4];  // per (DIL, Y2) variant of this configuration
     auto go = [&](auto kern, int v) -> int {
-        if (lds > attr[v]) {
-            AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr[v] = lds;
-        }
+        AFTER_TRY(ensure_lds_attr(attr[v], reinterpret_cast<const void*>(kern), lds));
         hipLaunchKernelGGL(kern, dim3(nwg * ny), dim3(128 * KS * RS), lds, s, a, tiles_m, tiles_n, pm, ny);
         AFTER_HIP_CHECK(hipGetLastError());
         return AFTER_OK;

@@ -308,12 +308,8 @@ int launch_x6_cfg(const ConvX6Args& a, int B, hipStream_t s) {
             }
         }
     }
-    static bool attr = false;
-    if (!attr) {
-        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x6_kernel<C>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
+    static LdsAttr attr;
+    AFTER_TRY(ensure_lds_attr(attr, reinterpret_cast<const void*>(conv_x6_kernel<C>), lds));
     hipLaunchKernelGGL(conv_x6_kernel<C>, dim3(nwg * ny), dim3(64 * C::NW), lds, s, a, tiles_m, tiles_n, pm, ny);
     AFTER_HIP_CHECK(hipGetLastError());
     return AFTER_OK;

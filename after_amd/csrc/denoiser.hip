@@ -2767,7 +2767,11 @@ struct after_denoiser {
     int dev = 0;                   // the device the handle lives on
     hipEvent_t step_ev = nullptr;  // recorded behind the copy of the failure words of the last persistent launch
     bool step_pending = false;     // ... and not looked at yet
-    int persist_check = 0;         // after_denoiser_set_persist_check: 1 = every persistent call synchronises and reports its own failure
+    // after_denoiser_set_persist_check: -1 (default) = the stateless OFFLINE persistent samplers synchronise and look at their own
+    // failure words -- a refused or failed launch is served by launches within the same call: after_sample never returns an
+    // untouched tensor -- and the streaming sampler defers (its state is invalid after a failure either way); 1 = every persistent
+    // call synchronises; 0 = every persistent call defers
+    int persist_check = -1;
     int step_dbg = 0;  // after_denoiser_set_stream_persist(h, 1 | dbg << 8): diagnostics bits OR-ed into AFTER_STEP_DBG
     StepSync* step_sync = nullptr;       // [max_steps]: one barrier state per step of a sample() call
     unsigned long long* step_trace = nullptr;  // stamps of the LAST step launched (diagnostics: AFTER_STEP_TRACE=1 / after_denoiser_set_step_trace)
@@ -2878,16 +2882,14 @@ size_t attn_lds_bytes(int E, int cs, int nkmax) {  // residual rows + per-wave R
 
 int launch_attn(const AttnArgs& a, int rows, size_t lds, hipStream_t s) {
     const dim3 grid(cdiv(a.T, a.cs), rows), block(64 * a.H);
-    static size_t attr = 0;
-    if (lds > attr) {  // > 64 KiB of dynamic LDS needs the opt-in
+    static LdsAttr attr[5];  // (> 64 KiB of dynamic LDS needs the opt-in, per device)
+    {
         const void* fns[5] = {reinterpret_cast<const void*>(attn_block_kernel<true, true>),
                               reinterpret_cast<const void*>(attn_block_kernel<true, false>),
                               reinterpret_cast<const void*>(attn_block_kernel<false, true>),
                               reinterpret_cast<const void*>(attn_block_kernel<false, false>),
                               reinterpret_cast<const void*>(attn_block_kernel<false, false, true>)};
-        for (const void* f : fns)
-            AFTER_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = lds;
+        for (int k = 0; k < 5; ++k) AFTER_TRY(ensure_lds_attr(attr[k], fns[k], lds));
     }
     const bool preload = (long long)grid.x * grid.y <= 256;
     if (a.W < 0 || !a.causal) {  // unlimited window / no mask: the general (slow) instantiation
@@ -3658,14 +3660,14 @@ int persist_poll(after_denoiser* h, hipStream_t s, bool wait) {
 }
 
 // behind a persistent launch on s: failure words -> pinned memory, event
-int persist_published(after_denoiser* h, hipStream_t s) {
+int persist_published(after_denoiser* h, hipStream_t s, bool check) {
     AFTER_HIP_CHECK(hipMemcpyAsync(h->step_fail, &h->step_sync->fail[0], 32 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     AFTER_HIP_CHECK(hipEventRecord(h->step_ev, s));
     h->step_pending = true;
-    return h->persist_check ? persist_poll(h, s, true) : AFTER_OK;
+    return check ? persist_poll(h, s, true) : AFTER_OK;
 }
 
-constexpr int kStepRetry = 1;  // (sample_seg in persist_check mode: the kernel refused or failed -- rerun the call by launches)
+constexpr int kStepRetry = 1;  // (an offline persistent sampler, checked: the kernel refused or failed -- rerun the call by launches)
 
 int sample_persistent(after_denoiser* h, hipStream_t s, const float* x0, float* out, int B, int T, int nb_steps) {
     const int rows = 3 * B, E = h->E, L = h->L;
@@ -3738,8 +3740,8 @@ int sample_persistent(after_denoiser* h, hipStream_t s, const float* x0, float* 
         }
         for (int i = 0; i < nb_steps; ++i) h->flip[i] ^= 1;
     }
-    // failure words -> pinned host memory, looked at by the next call (or by this one: after_denoiser_set_persist_check)
-    return persist_published(h, s);
+    // failure words -> pinned host memory, looked at by the next call (or by this one: after_denoiser_set_persist_check(h, 1))
+    return persist_published(h, s, h->persist_check == 1);
 }
 
 // RectifiedFlow.sample for ONE clip as one persistent launch (sample_seg_kernel): eligible for the shipped width (embed
@@ -3812,10 +3814,11 @@ int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, in
         const double fl = 2.0 * ((double)T * Ed * h->Cp + M * (Cd * Ed + L * (3 * Ed * Ed + 2 * Ed * MEd)));
         h->timer.end(s, nb_steps * fl, nb_steps * 4.0 * wts);
     }
-    const int rc = persist_published(h, s);
-    // (persist_check mode: the failing call itself is seen -- the offline sampler has no state, so the same call can be
+    const bool check = h->persist_check != 0;
+    const int rc = persist_published(h, s, check);
+    // (checked -- the default: the failing call itself is seen -- the offline sampler has no state, so the same call is
     //  served by launches; the handle stays on the launch path and the error text is kept for after_last_error)
-    return rc == AFTER_E_HIP && h->persist_check ? kStepRetry : rc;
+    return rc == AFTER_E_HIP && check ? kStepRetry : rc;
 }
 
 // RectifiedFlow.sample for a batch of clips as one persistent launch, one clip per XCD (sample_clip_kernel): eligible for the
@@ -3893,8 +3896,9 @@ int sample_clip(after_denoiser* h, hipStream_t s, const float* x0, float* out, i
         const double fl = 2.0 * ((double)B * T * Ed * h->Cp + M * (Cd * Ed + L * (3 * Ed * Ed + 2 * Ed * MEd)));
         h->timer.end(s, nb_steps * fl, nb_steps * 6.0 * wts);
     }
-    const int rc = persist_published(h, s);
-    return rc == AFTER_E_HIP && h->persist_check ? kStepRetry : rc;
+    const bool check = h->persist_check != 0;
+    const int rc = persist_published(h, s, check);
+    return rc == AFTER_E_HIP && check ? kStepRetry : rc;
 }
 
 // The whole sampler as a sequence of launches on `s` (eager path and graph capture body).
@@ -4094,7 +4098,7 @@ extern "C" int after_denoiser_set_sample_persist(after_denoiser* h, int enable) 
 
 extern "C" int after_denoiser_set_persist_check(after_denoiser* h, int mode) {
     AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
-    h->persist_check = mode != 0;
+    h->persist_check = mode < 0 ? -1 : (mode != 0);
     return AFTER_OK;
 }
 

@@ -313,6 +313,7 @@ struct after_encoder1d {
     float* state = nullptr;
     size_t slot_elems = 0;
     int n_slots = 0, flip = 0;
+    int stream_rows = 0;  // rows of the streams, fixed by the first chunk after a reset (a pass updates ITS rows' contexts only)
     int slot = 0;
 };
 
@@ -510,12 +511,14 @@ extern "C" int after_encoder1d_enable_streaming(after_encoder1d* h, int enable) 
         AFTER_HIP_CHECK(hipMemset(h->sa.base, 0, h->sa.off));
     }
     h->streaming = true;
+    h->stream_rows = 0;
     return AFTER_OK;
 }
 
 extern "C" int after_encoder1d_reset_state(after_encoder1d* h, void* stream) {
     AFTER_REQUIRE(h && h->sa.base, AFTER_E_INVALID, "encoder1d: streaming was never enabled");
     h->flip = 0;
+    h->stream_rows = 0;
     AFTER_HIP_CHECK(hipMemsetAsync(h->sa.base, 0, h->sa.off, (hipStream_t)stream));
     return AFTER_OK;
 }
@@ -526,6 +529,12 @@ extern "C" int after_encoder1d_forward(after_encoder1d* h, const float* z, float
     AFTER_REQUIRE(B > 0 && T > 0, AFTER_E_INVALID, "empty batch");
     AFTER_REQUIRE(B <= h->max_batch && T <= h->max_T, AFTER_E_CAPACITY,
                   "B=%d T=%d exceed max_batch=%d max_T=%d", B, T, h->max_batch, h->max_T);
+    if (h->streaming) {
+        AFTER_REQUIRE(h->stream_rows == 0 || h->stream_rows == B, AFTER_E_INVALID,
+                      "encoder1d: the streams were started with %d rows, the chunk has %d: the conv contexts ping-pong per pass, rows "
+                      "outside a pass would keep a two-chunk-old context -- after_encoder1d_reset_state first", h->stream_rows, B);
+        h->stream_rows = B;
+    }
     hipStream_t s = (hipStream_t)stream;
     const after_encoder1d_cfg& c = h->cfg;
     const int n = c.n_blocks;

@@ -712,12 +712,8 @@ int launch_bal(const GemmArgs& g, hipStream_t stream) {
     const size_t red = KS > 1 ? size_t(2 * KS) * MB * NB * 256 * sizeof(float) : 0;
     const size_t lds = ring > red ? ring : red;
     static_assert(size_t(NS) * KS * (BM + BN) * 32 * sizeof(float) <= 160 * 1024, "ring exceeds the LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_bal_kernel<MB, NB, KS, NS, RS>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static LdsAttr attr_set;
+    AFTER_TRY(ensure_lds_attr(attr_set, reinterpret_cast<const void*>(gemm_f32_bal_kernel<MB, NB, KS, NS, RS>), lds));
     // XCD grid pm x (8 / pm): minimise the per-XCD operand footprint A / pm + W / pn
     static int xcd2d = -1;
     if (xcd2d < 0) {
@@ -825,13 +821,8 @@ int launch_dma(const GemmArgs& g, hipStream_t stream) {
     constexpr int BM = 32 * MT, BN = 32 * NT;
     const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
     const size_t lds = size_t(NS) * (BM + BN) * BK * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        AFTER_HIP_CHECK(hipFuncSetAttribute(
-            reinterpret_cast<const void*>(gemm_f32_dma_kernel<MT, NT, NS, BK>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static LdsAttr attr_set;
+    AFTER_TRY(ensure_lds_attr(attr_set, reinterpret_cast<const void*>(gemm_f32_dma_kernel<MT, NT, NS, BK>), lds));
     hipLaunchKernelGGL((gemm_f32_dma_kernel<MT, NT, NS, BK>), dim3(tiles_m * tiles_n), dim3(256), lds,
                        stream, g, tiles_m, tiles_n);
     AFTER_HIP_CHECK(hipGetLastError());
@@ -850,12 +841,8 @@ int launch_cfg_bk(const GemmArgs& g, hipStream_t stream) {
         g_lds_min = e ? atoi(e) : 0;
     }
     if ((size_t)g_lds_min > lds) lds = g_lds_min;
-    static size_t attr = 0;
-    if (lds > attr) {
-        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<MT, NT, BK>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = lds;
-    }
+    static LdsAttr attr;
+    AFTER_TRY(ensure_lds_attr(attr, reinterpret_cast<const void*>(gemm_f32_kernel<MT, NT, BK>), lds));
     hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, BK>), dim3(tiles_m * tiles_n), dim3(256), lds, stream, g,
                        tiles_m, tiles_n);
     AFTER_HIP_CHECK(hipGetLastError());
@@ -910,13 +897,8 @@ int launch_gemm_cfg_euler(const GemmArgs& g, hipStream_t stream) {
     const size_t ring = size_t(NS) * KS * (16 * MB + 32 * NB) * 32 * sizeof(float);
     const size_t red = size_t(2 * KS) * MB * NB * 256 * sizeof(float);
     const size_t lds = ring > red ? ring : red;
-    static bool attr_set = false;
-    if (!attr_set) {
-        AFTER_HIP_CHECK(hipFuncSetAttribute(
-            reinterpret_cast<const void*>(gemm_f32_bal_kernel<MB, NB, KS, NS, 1, 1>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static LdsAttr attr_set;
+    AFTER_TRY(ensure_lds_attr(attr_set, reinterpret_cast<const void*>(gemm_f32_bal_kernel<MB, NB, KS, NS, 1, 1>), lds));
     hipLaunchKernelGGL((gemm_f32_bal_kernel<MB, NB, KS, NS, 1, 1>), dim3(tiles_m * tiles_n), dim3(128 * KS), lds,
                        stream, g, tiles_m, tiles_n, 0);
     AFTER_HIP_CHECK(hipGetLastError());

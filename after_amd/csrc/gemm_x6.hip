@@ -502,12 +502,8 @@ int launch_x6p(const X6Args& g, hipStream_t stream) {
     }
     if (!ok) return launch_x6<CPlain>(g, stream);
     const size_t lds = (size_t)C::NS * C::STAGE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6p_kernel<C>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static LdsAttr attr_set;
+    AFTER_TRY(ensure_lds_attr(attr_set, reinterpret_cast<const void*>(gemm_x6p_kernel<C>), lds));
     hipLaunchKernelGGL((gemm_x6p_kernel<C>), dim3(8 * nwx), dim3(64 * C::NW), lds, stream, g, tiles_m, tiles_n, pm, nwx);
     AFTER_HIP_CHECK(hipGetLastError());
     return AFTER_OK;
@@ -775,12 +771,8 @@ int launch_x6w(const X6Args& g, hipStream_t stream) {
     const size_t ring = (size_t)C::D * C::STAGE;
     const size_t red = C::KS > 1 ? (size_t)C::NW * C::MT * 1024 : 0;
     const size_t lds = ring > red ? ring : red;
-    static bool attr_set = false;
-    if (!attr_set) {
-        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6w_kernel<C>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static LdsAttr attr_set;
+    AFTER_TRY(ensure_lds_attr(attr_set, reinterpret_cast<const void*>(gemm_x6w_kernel<C>), lds));
     int pm = 0;
     double best = 0;
     for (int cdv = 1; cdv <= 8; cdv *= 2) {
@@ -803,12 +795,8 @@ int launch_x6(const X6Args& g, hipStream_t stream) {
     const size_t ring = (size_t)C::NS * C::STAGE;
     const size_t red = C::KS > 1 ? (size_t)C::NW * C::MT * C::NT * 1024 : 0;
     const size_t lds = ring > red ? ring : red;
-    static bool attr_set = false;
-    if (!attr_set) {
-        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6_kernel<C>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static LdsAttr attr_set;
+    AFTER_TRY(ensure_lds_attr(attr_set, reinterpret_cast<const void*>(gemm_x6_kernel<C>), lds));
     // XCD grid pm x (8 / pm): minimise the per-XCD operand footprint A / pm + W / pn
     int pm = 0;
     double best = 0;

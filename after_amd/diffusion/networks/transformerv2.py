@@ -384,19 +384,27 @@ class DenoiserV2(nn.Module):
             _lib.check(_lib.lib().after_denoiser_set_sample_persist(self._handle, int(bool(enable))),
                        "after_denoiser_set_sample_persist")
 
-    def set_persist_check(self, enable: bool):
-        """Persistent samplers: True = every call synchronises its stream and reports its own failure (a barrier time-out:
-        AFTERHipError from that very call; the offline sampler reruns the call by launches instead); False (default) = the
-        failure words are looked at by the next call or by check() (include/after_hip.h: after_denoiser_set_persist_check)."""
-        self._persist_check = bool(enable)
+    def set_persist_check(self, enable):
+        """Persistent samplers, when a launch's failure words are looked at (include/after_hip.h: after_denoiser_set_persist_check).
+        None (the default): the stateless offline samplers synchronise their stream and look at once -- a refused or failed launch
+        is served by launches within the same cfg_sample call, which therefore never returns an untouched tensor -- and the
+        streaming sampler defers to the next call / check().  True: every persistent call synchronises and reports its own
+        failure (streaming: AFTERHipError from that very call).  False: every persistent call defers (no host synchronisation in
+        cfg_sample; a failure surfaces in the next call or in check())."""
+        self._persist_check = -1 if enable is None else int(bool(enable))
         if self._handle is not None:
-            _lib.check(_lib.lib().after_denoiser_set_persist_check(self._handle, int(bool(enable))), "after_denoiser_set_persist_check")
+            _lib.check(_lib.lib().after_denoiser_set_persist_check(self._handle, self._persist_check), "after_denoiser_set_persist_check")
+
+    def _device(self):
+        return next(self.parameters()).device
 
     def check(self):
         """Waits for the last persistent launch's failure words and raises if a persistent sampler failed since the last look
         (include/after_hip.h: after_denoiser_check): the way to validate the LAST chunk of a stream."""
         if self._handle is not None:
-            _lib.check(_lib.lib().after_denoiser_check(self._handle, _lib.current_stream(None)), "after_denoiser_check")
+            dev = self._device()
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().after_denoiser_check(self._handle, _lib.current_stream(dev)), "after_denoiser_check")
 
     def sample_persist(self) -> bool:
         """True when the last cfg_sample of this handle ran as the persistent offline kernel."""
@@ -449,12 +457,16 @@ class DenoiserV2(nn.Module):
 
     def set_step_trace(self, enable: bool):
         """Persistent samplers: per-phase wall-clock stamps of every workgroup (include/after_hip.h: after_denoiser_set_step_trace)."""
+        if self._handle is None:
+            raise _lib.AFTERHipError("set_step_trace: no handle yet (reserve() or one forward first)")
         _lib.check(_lib.lib().after_denoiser_set_step_trace(self._handle, int(bool(enable))), "after_denoiser_set_step_trace")
 
     def step_trace(self):
         """numpy [workgroups, 128] uint64: the stamps of the last persistent Euler step (after_denoiser_step_trace)."""
         import numpy as np
-        n = torch.cuda.get_device_properties(0).multi_processor_count
+        if self._handle is None:
+            raise _lib.AFTERHipError("step_trace: no handle yet")
+        n = torch.cuda.get_device_properties(self._device()).multi_processor_count
         buf = np.zeros((n, 128), dtype=np.uint64)
         _lib.check(_lib.lib().after_denoiser_step_trace(self._handle, buf.ctypes.data_as(ctypes.c_void_p), n), "after_denoiser_step_trace")
         return buf

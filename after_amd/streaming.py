@@ -257,9 +257,15 @@ class MidiStreamer(Streamer):
     def __init__(self, blender: RectifiedFlow, emb_model: AutoEncoder, n_poly: int = 4, **kw):
         if blender.encoder_time is not None:
             raise ValueError("MidiStreamer is for MIDI-structure models (encoder_time = None, midi.gin:66)")
+        if getattr(blender, "post_encoder", None) is not None:
+            # export_midi.py:393-394 applies `post_encoder.forward_stream(zsem)` behind the timbre encoder when the model has
+            # one (and :109-110 chains it for the embedding plot).  No shipped configuration binds a post_encoder and its
+            # network class is not part of this build: refuse instead of silently conditioning on different timbre vectors.
+            raise NotImplementedError(
+                "MidiStreamer: the model has a post_encoder, which export_midi.py:393-394 applies to the timbre embedding "
+                "(post_encoder.forward_stream); it is not built here -- pass a model without it")
         self.n_poly = int(n_poly)
         super().__init__(blender, emb_model, **kw)
-        # (blender.post_encoder: stored by Base.__init__ and never called on the reference's sampling path either, model.py:38)
 
     def structure(self, x):
         raise AttributeError("the MIDI streamer has no structure encoder (export_midi.py)")

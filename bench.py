@@ -43,7 +43,7 @@ T_FRAMES = 256
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak; gemm_x6 spends six bf16 MFMAs per fp32 product block
 PEAK_X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
-ROUND = "r4"
+ROUND = "r5"
 # sources whose change invalidates a committed traffic measurement of the dominant GEMM
 TRAFFIC_SOURCES = ["after_amd/csrc/gemm.hip", "after_amd/csrc/gemm_x6.hip", "after_amd/csrc/gemm_pipe.h",
                    "after_amd/csrc/gemm_x6_pipe.h", "after_amd/csrc/denoiser.hip"]
@@ -220,7 +220,7 @@ def gemm_roofline(model, run_once, dev, dcfg, B, config, args):
 
     seg = None
     if model.net.sample_persist():
-        seg = seg_roofline(model, run_once, dcfg, B, config)
+        seg = persist_roofline(model, run_once, dcfg, B, config, args.nb_steps or 50)
     prof = None
     pth = pmc_path(config, B)
     traffic_note = "no committed PMC profile for this configuration (python bench.py --pmc)"
@@ -291,9 +291,24 @@ def gemm_roofline(model, run_once, dev, dcfg, B, config, args):
     mf = mfma_profile(config, B)
     if seg is not None:  # the dominant kernel of this leg is the persistent one; the launch path rides along for continuity
         if prof and prof.get("seg_bytes_per_launch"):
+            nb = args.nb_steps or 50
             seg["traffic"] = prof["seg_bytes_per_launch"]
-            seg["traffic_unit"] = "bytes per launch (one launch = all Euler steps of a clip)"
+            seg["traffic_unit"] = "bytes per launch (one launch = all Euler steps of all clips)"
             seg["traffic_note"] = traffic_note
+            # algorithmic bytes of one Euler step: every Linear weight once in the form the kernel reads it (fp32 tiles at one
+            # clip, bf16 x 3 planes for a batch) + every activation tensor between two phases written once and read once
+            E2, L2 = dcfg["net"]["embed_dim"], dcfg["net"]["n_layers"]
+            ME2 = E2 * dcfg["net"]["mlp_multiplier"]
+            wel = L2 * (3 * E2 * E2 + 2 * E2 * ME2)
+            rows = 3 * B * T_FRAMES
+            wbytes = wel * (4 if model.net.sample_path() == 1 else 6)
+            # per layer and row: xres (4 B x E) x 3 writers, h planes (6 B x E) x 2, qkv (4 B x 3E), MLP hidden planes (6 B x ME)
+            abytes = L2 * rows * (3 * 4 * E2 + 2 * 6 * E2 + 4 * 3 * E2 + 6 * ME2) * 2
+            seg["algorithmic_bytes_per_euler_step"] = {"weights": wbytes, "activations_written_and_read_once": abytes}
+            seg["traffic_ratio"] = round(prof["seg_bytes_per_launch"] / nb / (wbytes + abytes), 2)
+            seg["traffic_ratio_note"] = ("counted bytes per Euler step / algorithmic bytes per Euler step; at one clip the eight XCDs "
+                                         "each stream the weights (8 x by construction), for a batch they stream them once each too "
+                                         "but amortised over 768 rows per XCD")
         if mf:
             seg["mfma_busy"] = mf
         seg["launch_path"] = roof
@@ -319,16 +334,20 @@ def mfma_profile(config, B):
     return {"file": os.path.basename(pth), "dominant": p.get("dominant"), "what": p.get("what")}
 
 
-def seg_roofline(model, run_once, dcfg, B, config):
-    """The persistent offline sampler (sample_seg_kernel: ONE launch per clip runs every Euler step): the rate of
-    its qkv / MLP GEMM phases from the kernel's own per-phase stamps (every workgroup stamps the 100 MHz wall clock around each
-    XCD-local barrier; last Euler step of an extra untimed pass), and the whole launch by HIP events."""
+def persist_roofline(model, run_once, dcfg, B, config, nb_steps):
+    """The persistent offline samplers -- sample_seg_kernel (one clip: time segments over the XCDs) and
+    sample_clip_kernel (a batch: one clip per XCD): ONE launch runs every Euler step of every clip.  The launch
+    is priced as a whole by HIP events on the launch stream (`achieved` / `frac`: algorithmic fp32 flops of all Euler steps /
+    launch duration / the split-bf16 ceiling); `gemm_phases` carries the rate of its qkv / MLP GEMM phases alone, from the
+    kernel's own per-phase stamps (every workgroup stamps the 100 MHz wall clock around each XCD-local barrier; last Euler step
+    of an extra untimed pass)."""
     import numpy as np
     net = model.net
+    path = net.sample_path()
     E_, L_ = dcfg["net"]["embed_dim"], dcfg["net"]["n_layers"]
     ME_ = E_ * dcfg["net"]["mlp_multiplier"]
     M = 3 * B * T_FRAMES
-    gemm_fl = 2.0 * M * E_ * ME_  # one qkv / MLP-up / MLP-down GEMM (3E = ME at mlp x 3)
+    gemm_fl = 2.0 * M * E_ * ME_  # one qkv / MLP-up / MLP-down GEMM over all clips (3E = ME at mlp x 3)
     net.profile(True, min_flops=0.0, kernel=3)
     torch.cuda.synchronize()
     run_once()
@@ -345,41 +364,66 @@ def seg_roofline(model, run_once, dcfg, B, config):
     names = ["patchify"] + sum(([f"ln{l}", f"qkv{l}", f"attn{l}", f"up{l}", f"down{l}"] for l in range(L_)), []) + ["tail"]
     xcc = buf[:, 127].astype(int)
     t = buf[:, :2 * len(names)].astype(np.int64)
+    live = [x for x in range(8) if (xcc == x).any() and t[xcc == x][:, 1].max() > 0]  # (XCDs that ran a clip)
     dur = {}  # phase -> us, per XCD: first start -> last arrival at the closing barrier
-    for x in range(8):
+    for x in live:
         tx = t[xcc == x]
-        if not len(tx):
-            continue
         for p, nme in enumerate(names):
             dur.setdefault(nme, []).append((tx[:, 2 * p + 1].max() - tx[:, 2 * p].min()) / 100.0)
     med = {k: float(np.median(v)) for k, v in dur.items()}
     kinds = {k: float(np.mean([med[f"{k}{l}"] for l in range(L_)])) for k in ("ln", "qkv", "attn", "up", "down")}
     gemm_us = sum(med[f"{k}{l}"] for k in ("qkv", "up", "down") for l in range(L_))
-    step_us = float(np.median([(t[xcc == x][:, 2 * len(names) - 1].max() - t[xcc == x][:, 0].min()) / 100.0
-                               for x in range(8) if (xcc == x).any()]))
-    ach = 3 * L_ * gemm_fl / (gemm_us * 1e-6) / 1e12
+    step_us = float(np.median([(t[xcc == x][:, 2 * len(names) - 1].max() - t[xcc == x][:, 0].min()) / 100.0 for x in live]))
+    # (the phases of the eight XCDs run side by side: all clips' flops in one XCD's phase time)
+    ach_gemm = 3 * L_ * gemm_fl / (gemm_us * 1e-6) / 1e12
     whole = flops / (ms * 1e-3) / 1e12
-    steps = 50
+    kname = ("sample_seg_kernel (persistent offline sampler: one launch per clip, eight XCD-local pipelines over time segments"
+             if path == 1 else
+             "sample_clip_kernel (persistent offline sampler: one launch per batch, one clip per XCD, LDS-staged tiles fed by loader waves")
     return {"bound": "mfma",
-            "kernel": "sample_seg_kernel (persistent offline sampler: one launch per clip, eight XCD-local pipelines over time "
-                      "segments; fp32 product blocks as 6 x v_mfma_f32_16x16x32_bf16 on exact three-way bf16 splits): its qkv / "
-                      "MLP-up / MLP-down GEMM phases",
-            "achieved": round(ach, 2), "peak": round(PEAK_X6_TFLOPS, 1), "unit": "TFLOP/s", "frac": round(ach / PEAK_X6_TFLOPS, 4),
+            "kernel": kname + "; fp32 product blocks as 6 x v_mfma_f32_16x16x32_bf16 on exact three-way bf16 splits): the whole launch",
+            "achieved": round(whole, 2), "peak": round(PEAK_X6_TFLOPS, 1), "unit": "TFLOP/s", "frac": round(whole / PEAK_X6_TFLOPS, 4),
             "peak_note": "dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMAs per fp32 product block; against the fp32 MFMA peak "
-                         f"(157.3) the GEMM phases are at {ach / PEAK_FP32_MFMA_TFLOPS:.3f}",
+                         f"(157.3) the launch is at {whole / PEAK_FP32_MFMA_TFLOPS:.3f}",
+            "launches": int(launches), "avg_launch_us": round(ms * 1e3 / launches, 1),
+            "us_per_euler_step": round(ms * 1e3 / launches / nb_steps, 2),
+            "flops_per_launch": round(flops / launches),
+            "gemm_phases": {"achieved": round(ach_gemm, 2), "frac": round(ach_gemm / PEAK_X6_TFLOPS, 4),
+                            "what": "algorithmic fp32 flops of the 18 GEMM phases of one Euler step / the sum of their durations "
+                                    "(first workgroup's start to last workgroup's arrival at the closing XCD-local barrier, median "
+                                    "over the XCDs at work; stamps of the last Euler step of an extra untimed pass)",
+                            "flops_per_gemm_phase": round(gemm_fl)},
             "phase_us": {k: round(v, 2) for k, v in kinds.items()}, "patchify_us": round(med["patchify"], 2),
             "tail_us": round(med["tail"], 2), "us_per_euler_step_in_kernel": round(step_us, 1),
-            "flops_per_gemm_phase": round(gemm_fl),
-            "whole_kernel": {"achieved": round(whole, 2), "frac": round(whole / PEAK_X6_TFLOPS, 4), "launches": int(launches),
-                             "avg_launch_us": round(ms * 1e3 / launches, 1),
-                             "us_per_euler_step": round(ms * 1e3 / launches / steps, 2),
-                             "what": "GEMM flops of all Euler steps / HIP-event duration of the launch (launch-inclusive = "
-                                     "kernel-only to 0.1 %: one launch of ~13 ms)"},
             "traffic": None,
-            "note": "achieved = algorithmic fp32 flops of the 18 GEMM phases of one Euler step / the sum of their durations "
-                    "(first workgroup's start to last workgroup's arrival at the closing XCD-local barrier, median over the "
-                    "eight XCDs; stamps of the last Euler step of an extra untimed pass).  Phases in between (LayerNorm, banded "
-                    "attention, barriers: phase_us) are not GEMMs and not priced here; whole_kernel prices the entire launch"}
+            "note": "achieved = algorithmic fp32 flops of every Euler step of the launch (GEMMs of the denoiser) / HIP-event duration of "
+                    "the launch on the launch stream (launch-inclusive = kernel-only to 0.1 %: one launch of 13 - 55 ms); LayerNorm, "
+                    "banded attention and the barriers between the phases (phase_us) are inside that time"}
+
+
+def codec_record(model, dev, B):
+    """The other ~14 % of a clip: AutoEncoder.decode / .encode on B clips, HIP-event timed in untimed extra passes, priced
+    against both matrix peaks (95.3 / 45.2 GFLOP per clip; the decoder's stride-1 convs run on the split-bf16 pipe
+    (conv_x6.hip), everything else on fp32 MFMA: neither ceiling applies to the whole pass, both are given)."""
+    ae = model.emb_model
+    z = torch.randn(B, 64, T_FRAMES, device=dev)
+    x = 0.1 * torch.randn(B, 1, CLIP_SAMPLES, device=dev)
+    out = {}
+    for name, fn, gf in (("decode", lambda: ae.decode(z), 95.3), ("encode", lambda: ae.encode(x), 45.2)):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        tf = B * gf * 1e9 / (ms * 1e-3) / 1e12
+        out[name] = {"ms": round(ms, 3), "tflops": round(tf, 1), "frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 3),
+                     "frac_of_split_bf16_ceiling": round(tf / PEAK_X6_TFLOPS, 3)}
+    out["what"] = f"{B} clip(s) per pass, mean of 5 passes behind 2 warm-up passes, torch.cuda.Event on the launch stream"
+    return out
 
 
 def run_pmc_mfma(args):
@@ -419,7 +463,8 @@ def run_pmc_mfma(args):
     rows.sort(key=lambda r_: -r_["mfma_busy_total"])
     for r_ in rows:
         del r_["mfma_busy_total"]
-    dom = next((r_ for r_ in rows if "sample_seg_kernel" in r_["kernel"] or "gemm_x6" in r_["kernel"]), rows[0] if rows else None)
+    dom = next((r_ for r_ in rows if "sample_seg_kernel" in r_["kernel"] or "sample_clip_kernel" in r_["kernel"] or "gemm_x6" in r_["kernel"]),
+               rows[0] if rows else None)
     prof = {"what": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES (summed over the SIMDs) / (GRBM_GUI_ACTIVE / 8 XCC instances x 1024 "
                     "SIMDs), per launch, mean over the launches of a kernel -- rocprofv3's MfmaUtil expression (it takes the max "
                     "over the XCC instances of GRBM_GUI_ACTIVE; the CSV carries their sum): the fraction of SIMD-cycles in which "
@@ -470,7 +515,7 @@ def run_pmc(args):
         if "gemm_x6" in name and "_kernel" in name:  # gemm_x6_kernel / gemm_x6w_kernel / gemm_x6p_kernel
             x6_bytes += total * len(f)
             x6_n += len(f)
-        if "sample_seg_kernel" in name:  # the persistent offline sampler: one launch per clip
+        if "sample_seg_kernel" in name or "sample_clip_kernel" in name:  # the persistent offline samplers: one launch per call
             seg_bytes += total * len(f)
             seg_n += len(f)
     rows.sort(key=lambda r: -r["bytes_per_launch_corrected"] * r["launches"])
@@ -640,8 +685,14 @@ def main():
     assert tuple(out.shape) == out_shape and torch.isfinite(out).all()
 
     roof = None
+    sampler_path = None
     if rank == 0:  # rank 0 only: no collective in this pass
+        if not args.stream:
+            sampler_path = {0: "one launch per kernel (33 per Euler step)", 1: "persistent, one clip (sample_seg_kernel)",
+                            2: "persistent, one clip per XCD (sample_clip_kernel)"}[model.net.sample_path()]
         roof = gemm_roofline(model, lambda: step(gather=False), dev, dcfg, B, args.config, args)
+        if roof is not None and not args.stream and model.emb_model is not None:
+            roof["codec"] = codec_record(model, dev, B)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -670,7 +721,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("f32" if not (roof and "gemm_path" in roof) else
+            # (the disclosure holds whenever the sampler's Linears run on bf16 MFMAs: the launch path's gemm_x6 and both
+            #  persistent kernels; streaming chunks (<= 96 token rows) and AFTER_GEMM_X6=0 are fp32 MFMA throughout)
+            "dtype": ("f32" if (args.stream or model.net.gemm_path()[0] == 0) else
                       "f32 (arithmetic and results fp32 as in the reference; the qkv / MLP Linears form each fp32 product "
                       "as six exact bf16 MFMAs on exact three-way bf16 splits of both operands, fp32 accumulate -- error "
                       "vs fp64 <= the fp32 MFMA chain's, tests/test_gemm_gpu.py; AFTER_GEMM_X6=0 = fp32 MFMA everywhere)"),
@@ -682,6 +735,8 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         }
+        if sampler_path:
+            line["config"]["sampler_path"] = sampler_path
         if args.stream:
             line["metric"] = "audio sec generated / wall sec (xRT, all streams), base+cycle 100-step streaming @44.1 kHz"
             line["config"]["sampler_path"] = ("persistent (one launch per chunk: stream_step_kernel)" if model.net.stream_persist()

@@ -156,12 +156,21 @@ int after_denoiser_gemm_path(after_denoiser* h, int* mode, int* min_rows);
  * AFTER_SAMPLE_PERSIST=0).
  *
  * Failures (a barrier or neighbour flag that timed out, a bad placement seen by a real launch) raise STICKY words on the
- * device: every later persistent launch of the handle returns at entry without touching anything.  The host looks at a
- * copy of the words at the start of the next after_sample whose predecessor's copy has landed, and in after_denoiser_check
- * (which waits for it: the way to validate the last chunk of a stream): AFTER_E_HIP once, the handle then runs on the
- * launch path; every result since the failing call is invalid (reset the streamer / repeat the calls).  With
- * after_denoiser_set_persist_check(h, 1) every persistent after_sample synchronises its stream and reports its own failure
- * (the offline sampler, which has no state, serves that very call by launches instead and returns AFTER_OK).
+ * device: every later persistent launch of the handle returns at entry without touching anything.
+ *   - The OFFLINE samplers (no K/V caches: RectifiedFlow.sample, which returns a valid tensor or raises, model.py:763-785)
+ *     look at a copy of the words before after_sample returns: the call synchronises `stream` once behind its persistent
+ *     launch, and a launch that refused or failed is served by the launch-per-kernel path WITHIN THE SAME CALL (AFTER_OK;
+ *     the text is kept for after_last_error; the handle stays on the launch path until after_denoiser_set_sample_persist(h, 1)
+ *     prepares it again).  after_sample therefore never returns an untouched tensor.  Cost of the synchronisation: one
+ *     event wait per call of 13 - 50 ms (measured: DESIGN.md section 7.3).
+ *   - The STREAMING sampler defers: the host looks at the words at the start of the next after_sample whose predecessor's
+ *     copy has landed, and in after_denoiser_check (which waits for it: the way to validate the last chunk of a stream):
+ *     AFTER_E_HIP once, the handle then runs on the launch path; every result since the failing call is invalid (reset the
+ *     streamer / repeat the calls).
+ * after_denoiser_set_persist_check(h, mode) overrides both: 1 = every persistent after_sample synchronises and reports its
+ * own failure (streaming: AFTER_E_HIP from that very call), 0 = every persistent after_sample defers (no host
+ * synchronisation inside after_sample; a failed offline call then returns AFTER_OK with an untouched `out`, reported by the
+ * next call or after_denoiser_check), -1 = the default above.
  * after_denoiser_stream_persist: *active = 1 when the handle's last streaming shape takes the persistent path. */
 int after_denoiser_set_stream_persist(after_denoiser* h, int enable);
 /* after_sample for ONE clip without K/V caches (RectifiedFlow.sample, model.py:763-785) as one persistent launch: the same
@@ -169,12 +178,20 @@ int after_denoiser_set_stream_persist(after_denoiser* h, int enable);
  * left context crosses XCDs through system-scope stores / loads and per-XCD sequence words, no device-wide barrier), the
  * Linears as bf16 x 3 split MFMAs like gemm_x6.  The DEFAULT where eligible: the shipped width (embed 512 / mlp x 3 / eight
  * heads), B = 1, T = 128 or 256, window - 1 <= T / 8, gemm path != 0, no graph replay; otherwise, or with enable = 0 /
- * AFTER_SAMPLE_PERSIST=0, the launch path runs.  Provisioning, co-residency and failures as above.  _sample_persist:
- * *active = 1 when the last after_sample ran this way. */
+ * AFTER_SAMPLE_PERSIST=0, the launch path runs.  Provisioning, co-residency and failures as above.
+ *
+ * BATCHES (B >= 5 clips; BASELINE config 3's per-GPU shard, config 4): one persistent launch with ONE CLIP PER XCD (clips 8 .. on
+ * the same XCDs, one after the other) -- no cross-XCD word at all; the Linears on LDS-staged bf16 x 3 tiles (192 x 192 /
+ * 96 x 128) fed by four loader waves per workgroup.  Eligible: the shipped width, T % 16 == 0 and T <= 1024 frames within
+ * the handle's capacity, finite causal window, gemm path != 0, no graph replay; provisioned (+ 15.5 MB per XCD at T = 256)
+ * when the handle is created with max_rows >= 15.  AFTER_SAMPLE_CLIP=0 keeps batches on the launch path,
+ * AFTER_SAMPLE_CLIP_MINB=n moves the threshold.
+ * _sample_persist: *active = how the last after_sample ran -- 0 by launches, 1 the one-clip kernel, 2 the batch kernel. */
 int after_denoiser_set_sample_persist(after_denoiser* h, int enable);
 int after_denoiser_sample_persist(after_denoiser* h, int* active);
 int after_denoiser_stream_persist(after_denoiser* h, int* active);
-/* mode 1: every persistent after_sample synchronises `stream` and reports its own failure; 0 (default): deferred. */
+/* mode -1 (default): the offline samplers look at their own launch (never an untouched tensor), the streaming sampler defers;
+ * 1: every persistent after_sample synchronises `stream` and reports its own failure; 0: every one defers. */
 int after_denoiser_set_persist_check(after_denoiser* h, int mode);
 /* Waits for the failure words of the handle's last persistent launch (if not yet looked at) and reports them:
  * AFTER_E_HIP if a persistent sampler failed since the last look, AFTER_OK otherwise (also without persistent launches). */

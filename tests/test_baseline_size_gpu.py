@@ -83,6 +83,9 @@ def test_base_sampler_b8_shard_vs_oracle(base, hip_device):
     cond = torch.randn(B, 6, generator=g)
     tc = torch.randn(B, 12, 256, generator=g)
     got = model.sample(x0.to(hip_device), cond.to(hip_device), tc.to(hip_device), N, 2.0, 1.0).cpu()
+    # the shard runs on the path bench.py --batch-per-gpu 8 times: the clip-per-XCD persistent kernel wherever the Linears are on
+    # the bf16 pipe (with AFTER_GEMM_X6=0 -- the fixture's fp32 leg -- the launch path)
+    assert model.net.sample_path() == (2 if model.net.gemm_path()[0] != 0 else 0), model.net.sample_path()
     for i in (0, 7):
         s = slice(i, i + 1)
         want = oracle.sample(sd_net, ncfg, x0[s], cond[s], tc[s], N, 2.0, 1.0)
@@ -113,6 +116,7 @@ def test_midi_b8_t256_50steps_vs_oracle(mode, gt, gs, hip_device):
             roll[b, p, a:a + 32] = 0.3 + 0.7 * float(torch.rand((), generator=g))
     model.cfg_mode = mode
     got = model.sample(x0.to(hip_device), cond.to(hip_device), roll.to(hip_device), N, gt, gs).cpu()
+    assert model.net.sample_path() == (2 if model.net.gemm_path()[0] != 0 else 0), model.net.sample_path()
     for i in (1, 6):
         s = slice(i, i + 1)
         want = oracle.sample(sd_net, ncfg, x0[s], cond[s], roll[s], N, gt, gs, cfg_mode=mode)

@@ -119,3 +119,18 @@ def test_linspace_formula_matches_torch():
                 got.append(np.float32(1.0 - float(step) * (pts - s - 1)))
         want = torch.linspace(0, 1, n + 1)[:-1].numpy()
         assert np.array_equal(np.asarray(got, dtype=np.float32), want), n
+
+
+def test_midi_streamer_refuses_a_post_encoder():
+    """export_midi.py:393-394 applies `post_encoder.forward_stream` to the timbre embedding when the model has one; the
+    network is not part of this build, so MidiStreamer must refuse such a model (an error, not a silent skip) -- before it
+    touches the device."""
+    import pytest as _pytest
+    from after_amd import MidiStreamer
+
+    class _Blender:  # the attributes MidiStreamer reads before anything else
+        encoder_time = None
+        post_encoder = torch.nn.Identity()
+
+    with _pytest.raises(NotImplementedError, match="post_encoder"):
+        MidiStreamer(_Blender(), emb_model=None)

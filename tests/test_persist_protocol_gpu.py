@@ -73,6 +73,7 @@ def test_first_offline_persistent_sample_neither_allocates_nor_synchronises(hip_
     net = model.net
     x0, cond, tc = _inputs(net, 1, 256, 2, hip_device)
     net.reserve(3, 256, 4)  # capacity (re-creates the handle: a configuration step)
+    net.set_persist_check(False)  # the deferred protocol (the default looks at the launch's failure words before it returns)
     keep = torch.empty_like(x0)
     del keep
     _busy(hip_device, 0.01)  # (its own first launch loads a code object)
@@ -125,7 +126,7 @@ def test_streaming_failure_is_sticky_and_reported_once(stream_net, hip_device):
     net.reset_cache()
     with pytest.raises(_lib.AFTERHipError, match="persistent sampler"):
         net.cfg_sample(*ins[0], 3, 2.0, 1.0, -4.0)
-    net.set_persist_check(False)
+    net.set_persist_check(None)
     _lib.check(_lib.lib().after_denoiser_set_stream_persist(net._handle, 1), "set_stream_persist")
     net.reset_cache()
     got = [net.cfg_sample(*i, 3, 2.0, 1.0, -4.0).cpu() for i in ins]
@@ -133,19 +134,35 @@ def test_streaming_failure_is_sticky_and_reported_once(stream_net, hip_device):
     assert max((a - b).abs().max().item() for a, b in zip(got, want)) < 5e-5
 
 
-def test_offline_failure_in_check_mode_is_served_by_launches(hip_device):
-    model, _, _ = pipeline.build_models("base", "baseAE", hip_device, seed=4)
+@pytest.mark.parametrize("B", [1, 8])
+def test_offline_failure_is_served_by_launches_within_the_call(B, hip_device):
+    """RectifiedFlow.sample returns a valid tensor or raises (model.py:763-785).  DEFAULT mode: a persistent launch that refuses
+    (injected: its placement census fails -- it raises the sticky word and returns without touching anything) is seen by the very
+    after_sample call, which then runs by launches: the latents it returns are the launch path's, held to the oracle."""
+    import oracle
+    from fixtures import max_abs
+    model, dcfg, _ = pipeline.build_models("base", "baseAE", hip_device, seed=4)
     net = model.net
-    x0, cond, tc = _inputs(net, 1, 256, 2, hip_device)
+    x0, cond, tc = _inputs(net, B, 256, 2, hip_device)
     net.set_sample_persist(False)
     want = net.cfg_sample(x0, cond, tc, 3, 2.0, 1.0, -4.0).cpu()
     assert not net.sample_persist()
     _lib.check(_lib.lib().after_denoiser_set_sample_persist(net._handle, 1 | INJECT), "set_sample_persist")
-    net.set_persist_check(True)
-    got = net.cfg_sample(x0, cond, tc, 3, 2.0, 1.0, -4.0).cpu()
+    out = torch.full_like(x0, float("nan"))  # (an untouched output would be seen)
+    got = net.cfg_sample(x0, cond, tc, 3, 2.0, 1.0, -4.0, out=out).cpu()
     assert not net.sample_persist()
     assert torch.equal(got, want)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    ref = oracle.sample(sd, dcfg["net"], x0[:1].cpu(), cond[:1].cpu(), tc[:1].cpu(), 3, 2.0, 1.0)
+    assert max_abs(got[:1], ref) < 1e-4
+    # the deferred protocol (set_persist_check(False)): the failing call returns without looking; the next one reports
+    _lib.check(_lib.lib().after_denoiser_set_sample_persist(net._handle, 1 | INJECT), "set_sample_persist")
     net.set_persist_check(False)
+    net.cfg_sample(x0, cond, tc, 3, 2.0, 1.0, -4.0)
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.AFTERHipError, match="persistent sampler"):
+        net.cfg_sample(x0, cond, tc, 3, 2.0, 1.0, -4.0)
+    net.set_persist_check(None)
     net.set_sample_persist(True)
     got = net.cfg_sample(x0, cond, tc, 3, 2.0, 1.0, -4.0).cpu()
     assert net.sample_persist()
