@@ -2058,13 +2058,22 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
 // [3 T][3 E] buffer with RoPE applied to q and k in the epilogue.  More than eight clips: XCD g runs clips g, g + 8, ... one
 // after the other (the samples are independent).  Rows are provisioned in whole tiles: a clip length that does not fill
 // the last row tile computes padding rows nobody reads.
-using ClipQU = X6RCfg<12, 12, 4, 2, 1>;                     // qkv / MLP-up: 192 x 192, waves = 4 row parts x 2 column parts, rolling fragments
-using ClipDn = X6Cfg<6, 8, 1, 2, 4, 2, 0, 1, 1, 0, 0, 1>;  // MLP-down: 96 x 128 (32 tiles), waves = 2 row parts x 4 column parts, even / odd slabs in separate accumulators
 #ifndef CLIP_LOADERS
 #define CLIP_LOADERS 4
 #endif
 
 constexpr int kClipLoaders = CLIP_LOADERS;  // loader waves of a GEMM phase (waves 0 .. : one per SIMD)
+// MLP-down: a THREE-stage ring (its A operand, the 7-MB MLP hidden layer, does not fit the XCD's 4-MB L2 and comes through the
+// fabric: one slab of look-ahead left the loaders waiting for their pieces) fed by all eight waves -- 52 -> 40 us per phase
+#ifndef CLIP_DN_NS
+#define CLIP_DN_NS 3
+#endif
+#ifndef CLIP_DN_LOADERS
+#define CLIP_DN_LOADERS 8
+#endif
+constexpr int kClipDnLoaders = CLIP_DN_LOADERS;
+using ClipQU = X6RCfg<12, 12, 4, 2, 1>;                     // qkv / MLP-up: 192 x 192, waves = 4 row parts x 2 column parts, rolling fragments
+using ClipDn = X6Cfg<6, 8, 1, 2, 4, CLIP_DN_NS, 0, 1, 1, 0, 0, 1>;  // MLP-down: 96 x 128 (32 tiles), waves = 2 row parts x 4 column parts, even / odd slabs in separate accumulators
 constexpr int kClipRowTile = 192;  // rows of an XCD's slices are provisioned in multiples of it (both tile heights divide it)
 constexpr int kClipMaxT = 1024;    // longest clip the slices are provisioned for (15.5 MB per XCD at T = 256)
 // dynamic LDS: the GEMM ring of the larger tile | attention rows + K / V landing zones | the tail's partial tiles
@@ -2115,18 +2124,19 @@ struct ClipGemm {
 };
 
 // role dispatch of the loader-wave ring (wave-uniform switch: every role has its own instruction stream)
-#define CLIP_ROLE(wid_, CALL)                                                    \
-    switch ((wid_) < kClipLoaders ? (wid_) : -1) {                               \
-        case 0: { constexpr int LID = 0; CALL; } break;                          \
-        case 1: { constexpr int LID = kClipLoaders > 1 ? 1 : -1; CALL; } break;  \
-        case 2: { constexpr int LID = kClipLoaders > 2 ? 2 : -1; CALL; } break;  \
-        case 3: { constexpr int LID = kClipLoaders > 3 ? 3 : -1; CALL; } break;  \
-        case 4: { constexpr int LID = kClipLoaders > 4 ? 4 : -1; CALL; } break;  \
-        case 5: { constexpr int LID = kClipLoaders > 5 ? 5 : -1; CALL; } break;  \
-        case 6: { constexpr int LID = kClipLoaders > 6 ? 6 : -1; CALL; } break;  \
-        case 7: { constexpr int LID = kClipLoaders > 7 ? 7 : -1; CALL; } break;  \
-        default: { constexpr int LID = -1; CALL; } break;                        \
+#define CLIP_ROLE_N(wid_, NLD, CALL)                                        \
+    switch ((wid_) < (NLD) ? (wid_) : -1) {                                 \
+        case 0: { constexpr int LID = 0; CALL; } break;                     \
+        case 1: { constexpr int LID = (NLD) > 1 ? 1 : -1; CALL; } break;    \
+        case 2: { constexpr int LID = (NLD) > 2 ? 2 : -1; CALL; } break;    \
+        case 3: { constexpr int LID = (NLD) > 3 ? 3 : -1; CALL; } break;    \
+        case 4: { constexpr int LID = (NLD) > 4 ? 4 : -1; CALL; } break;    \
+        case 5: { constexpr int LID = (NLD) > 5 ? 5 : -1; CALL; } break;    \
+        case 6: { constexpr int LID = (NLD) > 6 ? 6 : -1; CALL; } break;    \
+        case 7: { constexpr int LID = (NLD) > 7 ? 7 : -1; CALL; } break;    \
+        default: { constexpr int LID = -1; CALL; } break;                   \
     }
+#define CLIP_ROLE(wid_, CALL) CLIP_ROLE_N(wid_, kClipLoaders, CALL)
 
 // One GEMM phase of an XCD on the ROLLING-fragment ring of gemm_x6_pipe.h (192 x 192 tiles: one per workgroup at T = 256): C =
 // epi(A3 W3^T) over the tiles rank, rank + 32, ... of the XCD's tile grid (row tile fastest)
@@ -2252,7 +2262,7 @@ template <class C>
 __device__ __forceinline__ void clip_gemm_l(const ClipGemm& g, unsigned char* smem_raw, int rank, int wid, int lane_in) {
     constexpr int BM = C::BM, BN = C::BN, MT = C::MT, NT = C::NT, RS = C::RS;
     constexpr int STORES = MT * NT;  // vector-memory instructions of a tile's epilogue behind the fill
-    static_assert(C::KS == 1 && C::SC1 == 1 && C::NS == 2, "clip tiles: no k-parts, sc1 operand loads");
+    static_assert(C::KS == 1 && C::SC1 == 1, "clip tiles: no k-parts, sc1 operand loads");
     int lane = lane_in;
     asm volatile("" : "+v"(lane));  // (opaque: see clip_gemm_r)
     const int tiles_m = g.M / BM, tiles_n = g.N / BN, ntiles = tiles_m * tiles_n;
@@ -2272,7 +2282,7 @@ __device__ __forceinline__ void clip_gemm_l(const ClipGemm& g, unsigned char* sm
     }
     c.a_src = (unsigned long long)(uintptr_t)g.A3 + (unsigned long long)((t % tiles_m) * (BM >> 4)) * c.rgs;
     c.w_src = (unsigned long long)(uintptr_t)g.W3 + (unsigned long long)((t / tiles_m) * (BN >> 4)) * c.rgs;
-    CLIP_ROLE(wid, (x6l_fill<C, kClipLoaders, LID>(c)));
+    CLIP_ROLE_N(wid, kClipDnLoaders, (x6l_fill<C, kClipDnLoaders, LID>(c)));
     for (bool first = true;; first = false) {
         const int tm = t % tiles_m, tn = t / tiles_m;
 #pragma unroll
@@ -2282,9 +2292,9 @@ __device__ __forceinline__ void clip_gemm_l(const ClipGemm& g, unsigned char* sm
 #pragma unroll
                 for (int j = 0; j < NT; ++j) c.acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (first) {
-            CLIP_ROLE(wid, (x6l_main<C, kClipLoaders, LID, 0>(c, nk)));
+            CLIP_ROLE_N(wid, kClipDnLoaders, (x6l_main<C, kClipDnLoaders, LID, 0>(c, nk)));
         } else {
-            CLIP_ROLE(wid, (x6l_main<C, kClipLoaders, LID, STORES>(c, nk)));
+            CLIP_ROLE_N(wid, kClipDnLoaders, (x6l_main<C, kClipDnLoaders, LID, STORES>(c, nk)));
         }
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));  // (the epilogue's index arithmetic stays behind the K loop: see clip_gemm_r)
@@ -2311,7 +2321,7 @@ __device__ __forceinline__ void clip_gemm_l(const ClipGemm& g, unsigned char* sm
             asm volatile("" ::: "memory");
             c.a_src = (unsigned long long)(uintptr_t)g.A3 + (unsigned long long)((t_next % tiles_m) * (BM >> 4)) * c.rgs;
             c.w_src = (unsigned long long)(uintptr_t)g.W3 + (unsigned long long)((t_next / tiles_m) * (BN >> 4)) * c.rgs;
-            CLIP_ROLE(wid, (x6l_fill<C, kClipLoaders, LID>(c)));
+            CLIP_ROLE_N(wid, kClipDnLoaders, (x6l_fill<C, kClipDnLoaders, LID>(c)));
         }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -2474,6 +2484,68 @@ __device__ __attribute__((noinline)) void clip_attention_pair(StepAttn g, const 
     }
 }
 
+// norm0 -> AdaLN(tcond) -> xres ; norm1 -> h (x6 planes) for three token rows of a wave (step_ln_row<2> three times, with every
+// operand of the three rows -- the rows, their AdaLN alpha | beta, the shared affine -- requested before the first reduction).
+// lr[k] < 0: no such row (its loads repeat a valid row, nothing is stored)
+__device__ __forceinline__ void clip_ln_rows(__amdgpu_buffer_rsrc_t xin, const int (&src_lr)[3], const float* const (&ab)[3],
+                                             const float* __restrict__ w1, const float* __restrict__ b1, float* __restrict__ xres,
+                                             unsigned short* __restrict__ h3, const int (&lr)[3], int lane) {
+    constexpr int E = kSE, NV = E / 256, KBt = E / 16;
+    f32x4 v[3][NV], al[3][NV], be[3][NV], ww[NV], bb[NV];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int ch = 4 * lane + 256 * i;
+            v[k][i] = ld_l2(xin, t16_off(src_lr[k], ch, KBt));
+            al[k][i] = *reinterpret_cast<const f32x4*>(ab[k] + ch);
+            be[k][i] = *reinterpret_cast<const f32x4*>(ab[k] + E + ch);
+        }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        ww[i] = *reinterpret_cast<const f32x4*>(w1 + 4 * lane + 256 * i);
+        bb[i] = *reinterpret_cast<const f32x4*>(b1 + 4 * lane + 256 * i);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        auto stats = [&](float& mean, float& rstd) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) s += (v[k][i].x + v[k][i].y) + (v[k][i].z + v[k][i].w);
+            mean = wave_sum(s) / (float)E;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const float d0 = v[k][i].x - mean, d1 = v[k][i].y - mean, d2 = v[k][i].z - mean, d3 = v[k][i].w - mean;
+                q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+            rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + 1e-5f);
+        };
+        float mean, rstd;
+        stats(mean, rstd);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[k][i].x = (v[k][i].x - mean) * rstd * (1.0f + al[k][i].x) + be[k][i].x;
+            v[k][i].y = (v[k][i].y - mean) * rstd * (1.0f + al[k][i].y) + be[k][i].y;
+            v[k][i].z = (v[k][i].z - mean) * rstd * (1.0f + al[k][i].z) + be[k][i].z;
+            v[k][i].w = (v[k][i].w - mean) * rstd * (1.0f + al[k][i].w) + be[k][i].w;
+        }
+        stats(mean, rstd);
+        if (lr[k] >= 0) {  // (wave-uniform)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                *reinterpret_cast<f32x4*>(xres + t16_off(lr[k], 4 * lane + 256 * i, KBt)) = v[k][i];
+                f32x4 y;
+                y.x = (v[k][i].x - mean) * rstd * ww[i].x + bb[i].x;
+                y.y = (v[k][i].y - mean) * rstd * ww[i].y + bb[i].y;
+                y.z = (v[k][i].z - mean) * rstd * ww[i].z + bb[i].z;
+                y.w = (v[k][i].w - mean) * rstd * ww[i].w + bb[i].w;
+                x6_store4(h3, lr[k], 4 * lane + 256 * i, E, y.x, y.y, y.z, y.w);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ unsigned s_rank, s_bad, s_ok;
@@ -2563,11 +2635,19 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
                 asm volatile("" : "+v"(lane_l));
                 const int lane = lane_l;
                 // ---- norm0 -> AdaLN(tcond) -> norm1 (transformerv2.py:345-351): one wave per token row; h as x6 planes
-                for (int lm = rank + 32 * w; lm < Mg; lm += 256) {
-                    const int br = lm / T, t = lm - br * T;
-                    StepLnOps lnops;
-                    step_ln_ops(lnops, a.tc_ab + ((size_t)a.tcmap[br * B + c] * T + t) * a.tc_ld + (size_t)l * 2 * E, Lw.n1w, Lw.n1b, lane);
-                    step_ln_row<2>(l == 0 ? pat_r : xres_r, l == 0 ? t : lm, xres, reinterpret_cast<float*>(h3), lm, lnops, lane);
+                //      (three rows per wave at T = 256: requested together -- one memory latency, not three in a row)
+                for (int lm0 = rank + 32 * w; lm0 < Mg; lm0 += 3 * 256) {
+                    const float* ab[3];
+                    int lms[3], srcs[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int lm = min(lm0 + 256 * k, Mg - 1);  // (a missing row repeats the last one: loaded, not stored)
+                        const int br = lm / T, t = lm - br * T;
+                        lms[k] = lm0 + 256 * k < Mg ? lm : -1;
+                        srcs[k] = l == 0 ? t : lm;
+                        ab[k] = a.tc_ab + ((size_t)a.tcmap[br * B + c] * T + t) * a.tc_ld + (size_t)l * 2 * E;
+                    }
+                    clip_ln_rows(l == 0 ? pat_r : xres_r, srcs, ab, Lw.n1w, Lw.n1b, xres, h3, lms, lane);
                 }
                 if (!end_phase(true)) return;
                 // ---- qkv
