@@ -48,6 +48,18 @@ AFTER_SAMPLE_PERSIST=0 python scripts/time_sampler.py base 1 50 7 2>/dev/null | 
 python scripts/time_sampler.py base 1 50 7 2>/dev/null | tail -1 >> $O/${R}_ab_sample_persist.txt
 AFTER_SAMPLE_PERSIST=0 python scripts/time_sampler.py base 1 50 7 2>/dev/null | tail -1 >> $O/${R}_ab_sample_persist.txt
 python scripts/time_sampler.py base 1 50 7 2>/dev/null | tail -1 >> $O/${R}_ab_sample_persist.txt
+# round 5: the clip-per-XCD persistent sampler at 8 clips -- same-box A/B against the launch path, per-phase timeline; cost of the
+# default checked mode of the offline persistent samplers (one event wait per call)
+for rep in 1 2; do
+  AFTER_SAMPLE_CLIP=0 python scripts/time_sampler.py base 8 50 5 2>/dev/null | tail -1 | sed 's/^/launch path:      /' >> $O/${R}_ab_sample_clip.txt
+  python scripts/time_sampler.py base 8 50 5 2>/dev/null | tail -1 | sed 's/^/clip-per-XCD:     /' >> $O/${R}_ab_sample_clip.txt
+done
+for cfgb in "midi 8" "base 6" "base 16"; do set -- $cfgb
+  AFTER_SAMPLE_CLIP=0 python scripts/time_sampler.py $1 $2 50 3 2>/dev/null | tail -1 | sed 's/^/launch path:      /' >> $O/${R}_ab_sample_clip.txt
+  python scripts/time_sampler.py $1 $2 50 3 2>/dev/null | tail -1 | sed 's/^/clip-per-XCD:     /' >> $O/${R}_ab_sample_clip.txt
+done
+python scripts/stream_step_trace.py --offline --clips 8 --xcd 3 2>/dev/null | grep -v amdgpu.ids > $O/${R}_clip_step_trace.txt
+python scripts/persist_check_cost.py > $O/${R}_persist_check_cost.jsonl 2>/dev/null
 python scripts/seg_context.py 2>/dev/null | tail -9 > $O/${R}_clip_breakdown_b1.txt
 python scripts/stream_step_trace.py --offline > $O/${R}_offline_step_trace.txt 2>/dev/null
 # the persistent streaming step: same-box A/B against the launch path, per-phase timeline, kernel stats of a chunk
