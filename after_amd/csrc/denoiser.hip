@@ -4100,8 +4100,24 @@ extern "C" int after_sample(after_denoiser* h, const float* x0, const float* con
     // model.py:771: dt = 1 / nb_steps (python float -> the product dx * dt is fp32)
     AFTER_TRY(cfg_params(guidance_timbre, guidance_structure, cfg_mode, (float)(1.0 / nb_steps), &p));
     AFTER_TRY(set_params(h, s, p));
-    if (!h->use_graph || h->timer.enabled || h->cache > 0)
+    if (!h->use_graph || h->timer.enabled || h->cache > 0) {
+        // More than eight clips with a short remainder (B % 8 in 1 .. clip_min_b - 1): the full groups of eight on the
+        // clip-per-XCD kernel, the remainder as a call of its own on ITS best path (one clip: the segment kernel; 2 - 4: launches) --
+        // as one batch the remainder would cost a whole second round of the kernel (9 clips: 96 ms against 51 + 13;
+        // profiles/r5_clip_threshold.txt).  The samples are independent: the split is a pointer offset.
+        const int rem = B % 8, n8 = B - rem;
+        if (n8 > 0 && rem > 0 && rem < h->clip_min_b && sample_clip_ok(h, n8, T, nb_steps) && !stream_is_capturing(s)) {
+            AFTER_TRY(sample_enqueue(h, s, x0, cond, time_cond, out, n8, T, nb_steps, drop_value, cfg_mode));
+            const bool clip_ran = h->last_clip;
+            const size_t xo = (size_t)n8 * h->C * T;
+            AFTER_TRY(sample_enqueue(h, s, x0 + xo, cond + (size_t)n8 * h->ZT, time_cond + (size_t)n8 * h->ZS * T, out + xo, rem, T, nb_steps,
+                                     drop_value, cfg_mode));
+            h->last_clip = clip_ran;
+            h->last_seg = false;
+            return AFTER_OK;
+        }
         return sample_enqueue(h, s, x0, cond, time_cond, out, B, T, nb_steps, drop_value, cfg_mode);
+    }
 
     // ---- graph path: stage the (small) inputs, replay the captured loop, copy the result out
     const size_t nx = (size_t)B * h->C * T;

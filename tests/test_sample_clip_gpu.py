@@ -27,7 +27,8 @@ def _inputs(B, T, seed, net, uniform_tc=False):
     return x0, cond, tc
 
 
-@pytest.mark.parametrize("B,T,steps", [(8, 256, 4), (5, 128, 3), (8, 64, 3), (6, 192, 2), (16, 64, 2), (11, 48, 2)])
+@pytest.mark.parametrize("B,T,steps", [(8, 256, 4), (5, 128, 3), (8, 64, 3), (6, 192, 2), (16, 64, 2), (11, 48, 2), (9, 256, 2), (17, 64, 2),
+                                       (13, 32, 2)])  # (11, 9, 17: eight clips on the kernel + a remainder of 3 / 1 / 1 on its own path; 13: two rounds)
 def test_clip_sampler_matches_launch_path_and_oracle(B, T, steps, base, hip_device):
     model, dcfg = base
     net = model.net
