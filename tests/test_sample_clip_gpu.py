@@ -95,3 +95,26 @@ def test_midi_cfg_arrangement_on_the_clip_sampler(hip_device):
         got = net.cfg_sample(x0, cond, tc, 4, 1.5, 2.0, -4.0, cfg_mode=mode).cpu()
         assert net.sample_path() == 2, mode
         assert torch.isfinite(got).all() and max_abs(got, ref) < 5e-5, (mode, max_abs(got, ref))
+
+
+@pytest.mark.parametrize("B,T,steps", [(5, 512, 2), (6, 1024, 1), (8, 320, 2)])
+def test_clip_sampler_long_clips_walk_several_tiles(B, T, steps, hip_device):
+    """T > 256: a workgroup walks several tiles per GEMM phase (512 frames: two 192 x 192 tiles and two 96 x 128 tiles each; 1024: four),
+    several attention items and tail blocks, and 320 frames leave padding rows in the last row tile.  Against the launch path of
+    the same handle and, on one clip, the oracle."""
+    model, dcfg, _ = pipeline.build_models("base", "baseAE", hip_device, seed=11)
+    net = model.net
+    net.reserve(3 * B, T, steps)
+    x0, cond, tc = _inputs(B, T, 7 + T, net)
+    args = (x0.to(hip_device), cond.to(hip_device), tc.to(hip_device), steps, 2.0, 1.0, -4.0)
+    net.set_sample_persist(False)
+    ref = net.cfg_sample(*args).cpu()
+    net.set_sample_persist(True)
+    got = net.cfg_sample(*args).cpu()
+    assert net.sample_path() == 2, (B, T)
+    assert torch.equal(got, net.cfg_sample(*args).cpu()), "not reproducible"
+    assert max_abs(got, ref) < 5e-5, max_abs(got, ref)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    c = B - 1
+    want = oracle.sample(sd, dcfg["net"], x0[c:c + 1], cond[c:c + 1], tc[c:c + 1], steps, 2.0, 1.0)
+    assert max_abs(got[c:c + 1], want) < 1e-4, max_abs(got[c:c + 1], want)
