@@ -1052,7 +1052,8 @@ __device__ __forceinline__ bool seg_spin_sys(const unsigned* word, unsigned want
 // (Tried on top, LATE only: a chunk whose window reaches into the previous XCD's segment runs its OWN keys first and fetches
 //  the neighbour's -- after the sequence-word wait -- in a second pass of the online softmax.  The second pass (a
 //  system-scope round trip + a 12-key block) costs more than the wait it hides: 285 vs 270 us per Euler step.)
-template <int AUX, int PLANES = 0, bool LATE = false>  // hout: fp32 tiles (0), bf16 x 3 planes: p32_store4 (1) / x6 blocks (2)
+template <int AUX, int PLANES = 0, bool LATE = false, bool XROW = false>  // hout: fp32 tiles (0), bf16 x 3 planes: p32_store4 (1) / x6 blocks (2);
+                                                                           // XROW: the residual stream row-major [rows][E] instead of 16 x 16 tiles
 __device__ __forceinline__ void step_attention(const StepAttn& a, const StepKV& kv, const StepLnOps& ops, int rg,
                                                int lr0, int bx, float* smem, float* kvlds, __amdgpu_buffer_rsrc_t qkvr,
                                                __amdgpu_buffer_rsrc_t xr, float* __restrict__ xres, float* __restrict__ hout,
@@ -1110,7 +1111,8 @@ __device__ __forceinline__ void step_attention(const StepAttn& a, const StepKV& 
         const int qic = min(qb + grp, nq - 1);
         return as4(__builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qkvr, ((rowbase + i0 + qic) * 3u * E + hw * 64 + d4) * 4u, 0, AUX)));
     };
-    auto x_load = [&](int qb) { return as4(ld_l2(xr, t16_off(lr0 + i0 + min(qb + grp, nq - 1), hw * 64 + d4, KBt))); };
+    auto xoff = [&](int lr, int ch) { return XROW ? (unsigned)(lr * E + ch) : t16_off(lr, ch, KBt); };
+    auto x_load = [&](int qb) { return as4(ld_l2(xr, xoff(lr0 + i0 + min(qb + grp, nq - 1), hw * 64 + d4))); };
     float4 q4n = z4, x4n = z4;
     // ROPED (= LATE, the offline segment sampler): q and k arrive ROTATED -- its qkv phase applies RoPE once per row in the
     // epilogue (seg kernel), not once per (query, key) here: two LDS reads and eight FMAs per key and lane less in the key loop
@@ -1229,7 +1231,7 @@ __device__ __forceinline__ void step_attention(const StepAttn& a, const StepKV& 
         stats(mean, rstd);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const unsigned off = t16_off(lr0 + i0 + qi, 4 * lane + 256 * i, KBt);
+            const unsigned off = xoff(lr0 + i0 + qi, 4 * lane + 256 * i);
             *reinterpret_cast<float4*>(xres + off) = v[i];
             float4 y;
             y.x = (v[i].x - mean) * rstd * ww[i].x + bb[i].x;
@@ -2092,7 +2094,7 @@ struct ClipArgs {
     int rows_pad;             // token rows provisioned per XCD (3 T rounded up to kClipRowTile)
     int pat_rows;             // rows of an XCD's patchify slice (T rounded up to 16)
     float* xt;                // token-major latents [B * T][Cp]: a step's input, rewritten by its tail
-    float *pat_t, *xres_t;    // per-XCD slices, 16 x 16-tiled fp32: [8][pat_rows][E], [8][rows_pad][E]
+    float *pat_t, *xres_t;    // per-XCD slices: patchify output [8][pat_rows][E] (16 x 16 tiles), residual stream [8][rows_pad][E] (row-major)
     float* qkv;               // [8][rows_pad][3E] row-major, RoPE applied to q and k
     unsigned short *h3, *mlp3;  // [8] x6 planes of [rows_pad][E] / [rows_pad][ME]
     const float *patch_wt, *patch_b, *out_wt, *out_b;
@@ -2119,7 +2121,7 @@ struct ClipGemm {
     unsigned short* out3;   // EPI 1: x6 planes of [M][N]
     const float *rope_cos, *rope_sin;
     int T;
-    float* xres;            // EPI 2: residual in / out, 16 x 16 tiles [M / 16][N / 16][256]
+    float* xres;            // MLP-down: residual in / out, row-major [M][N]
     unsigned long long* tr; // AFTER_STEP_TRACE stamps of the workgroup's first tile: [64] entry, [65] (unused), [66] K loop done, [67] epilogue issued
 };
 
@@ -2255,7 +2257,7 @@ __device__ __forceinline__ void clip_gemm_r(const ClipGemm& g, unsigned char* sm
 }
 
 // MLP-down of an XCD on the loader-wave ring with double-buffered fragments (x6l_*: 96 x 128 tiles, one per workgroup at T = 256,
-// K = 1536 with even / odd slabs in separate accumulators): xres = (A3 W3^T + bias) + xres, in place on the tiled residual stream.
+// K = 1536 with even / odd slabs in separate accumulators): xres = (A3 W3^T + bias) + xres, in place on the row-major residual stream.
 // With several tiles per workgroup the next tile's ring fill is issued BEFORE the finished tile's stores (the epilogue's operands --
 // bias, residual tile -- are fetched and waited for first: a compiler-placed wait behind the fill would wait for the fill).
 template <class C>
@@ -2306,7 +2308,7 @@ __device__ __forceinline__ void clip_gemm_l(const ClipGemm& g, unsigned char* sm
             const int cb = col0 + 16 * j;
             bv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(step_rsrc(g.bias), (unsigned)(cb + 4 * (lane_e >> 4)) * 4u, 0, 0));
 #pragma unroll
-            for (int i = 0; i < MT; ++i) rv[i][j] = ld_l2(xr, (unsigned)(((((row0 >> 4) + i) * (g.N >> 4) + (cb >> 4)) << 8) + lane_e * 4));
+            for (int i = 0; i < MT; ++i) rv[i][j] = ld_l2(xr, (unsigned)((row0 + 16 * i + (lane_e & 15)) * g.N + cb + 4 * (lane_e >> 4)));
         }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -2328,7 +2330,7 @@ __device__ __forceinline__ void clip_gemm_l(const ClipGemm& g, unsigned char* sm
             const int cb = col0 + 16 * j;
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const unsigned off = (unsigned)(((((row0 >> 4) + i) * (g.N >> 4) + (cb >> 4)) << 8) + lane_e * 4);
+                const unsigned off = (unsigned)((row0 + 16 * i + (lane_e & 15)) * g.N + cb + 4 * (lane_e >> 4));  // (row-major residual stream)
                 const f32x4 o = C::ACC2 ? c.acc[0][i][j] + c.acc[C::ACC2][i][j] : c.acc[0][i][j];
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (o + bv[j]) + rv[i][j]), xr, off * 4u, 0, 0);
             }
@@ -2351,7 +2353,7 @@ __device__ __attribute__((noinline)) void clip_attention(StepAttn g, const float
     StepLnOps none;
 #pragma unroll
     for (int i = 0; i < kSE / 256; ++i) none.al[i] = none.be[i] = none.ww[i] = none.bb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    step_attention<16, 2, true>(g, nokv, none, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout, ab, w3, b3, tr);
+    step_attention<16, 2, true, true>(g, nokv, none, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout, ab, w3, b3, tr);
 }
 
 // Attention + residual + AdaLN(cond) + norm3 for a PAIR of consecutive chunks of one CFG row (transformerv2.py:190-236, :351-361;
@@ -2368,7 +2370,7 @@ __device__ __attribute__((noinline)) void clip_attention_pair(StepAttn g, const 
     lab = seg_uniform(lab), lw3 = seg_uniform(lw3), lb3 = seg_uniform(lb3);
     rg = seg_uniform(rg), lr0 = seg_uniform(lr0), px = seg_uniform(px);
     smem = seg_uniform(smem), kvlds = seg_uniform(kvlds), xres = seg_uniform(xres), h3 = seg_uniform(h3);
-    constexpr int NKB = 16, E = kSE, H = kSH, KBt = E / 16, ld = E + 4, NV = E / 256;
+    constexpr int NKB = 16, E = kSE, H = kSH, ld = E + 4, NV = E / 256;
     const int T = g.T, cs = g.cs, W = g.W;
     const int tid = threadIdx.x, lane = tid & 63, hw = tid >> 6;
     const int grp = lane >> 4, d4 = (lane & 15) * 4;
@@ -2393,7 +2395,7 @@ __device__ __attribute__((noinline)) void clip_attention_pair(StepAttn g, const 
     for (int ps = 0; ps < 2; ++ps) {
         const int qic = min(4 * ps + grp, nq - 1);
         q4[ps] = as4(__builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qkvr, ((rowbase + i0 + qic) * 3u * E + hw * 64 + d4) * 4u, 0, 16)));
-        x4[ps] = as4(ld_l2(xr, t16_off(lr0 + i0 + qic, hw * 64 + d4, KBt)));
+        x4[ps] = as4(ld_l2(xr, (unsigned)((lr0 + i0 + qic) * E + hw * 64 + d4)));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the K / V block (and everything else) has landed
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -2473,7 +2475,7 @@ __device__ __attribute__((noinline)) void clip_attention_pair(StepAttn g, const 
         stats(mean, rstd);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            *reinterpret_cast<float4*>(xres + t16_off(lr0 + i0 + qi, 4 * lane + 256 * i, KBt)) = v[i];
+            *reinterpret_cast<float4*>(xres + (size_t)(lr0 + i0 + qi) * E + 4 * lane + 256 * i) = v[i];
             float4 y;
             y.x = (v[i].x - mean) * rstd * ops.ww[i].x + ops.bb[i].x;
             y.y = (v[i].y - mean) * rstd * ops.ww[i].y + ops.bb[i].y;
@@ -2484,10 +2486,12 @@ __device__ __attribute__((noinline)) void clip_attention_pair(StepAttn g, const 
     }
 }
 
-// norm0 -> AdaLN(tcond) -> xres ; norm1 -> h (x6 planes) for three token rows of a wave (step_ln_row<2> three times, with every
-// operand of the three rows -- the rows, their AdaLN alpha | beta, the shared affine -- requested before the first reduction).
+// norm0 -> AdaLN(tcond) -> xres ; norm1 -> h (x6 planes) for three token rows of a wave (step_ln_row three times, with every
+// operand of the three rows -- the rows, their AdaLN alpha | beta, the shared affine -- requested before the first reduction).  The
+// residual stream is ROW-MAJOR [rows][E] in this kernel (a row is 2 KB of contiguous memory for the row-wise phases; in the 16 x 16
+// tiles of the other persistent samplers it is 128 pieces of 16 bytes); src_tiled: the source is the tiled patchify output.
 // lr[k] < 0: no such row (its loads repeat a valid row, nothing is stored)
-__device__ __forceinline__ void clip_ln_rows(__amdgpu_buffer_rsrc_t xin, const int (&src_lr)[3], const float* const (&ab)[3],
+__device__ __forceinline__ void clip_ln_rows(__amdgpu_buffer_rsrc_t xin, bool src_tiled, const int (&src_lr)[3], const float* const (&ab)[3],
                                              const float* __restrict__ w1, const float* __restrict__ b1, float* __restrict__ xres,
                                              unsigned short* __restrict__ h3, const int (&lr)[3], int lane) {
     constexpr int E = kSE, NV = E / 256, KBt = E / 16;
@@ -2497,7 +2501,7 @@ __device__ __forceinline__ void clip_ln_rows(__amdgpu_buffer_rsrc_t xin, const i
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int ch = 4 * lane + 256 * i;
-            v[k][i] = ld_l2(xin, t16_off(src_lr[k], ch, KBt));
+            v[k][i] = ld_l2(xin, src_tiled ? t16_off(src_lr[k], ch, KBt) : (unsigned)(src_lr[k] * E + ch));
             al[k][i] = *reinterpret_cast<const f32x4*>(ab[k] + ch);
             be[k][i] = *reinterpret_cast<const f32x4*>(ab[k] + E + ch);
         }
@@ -2534,7 +2538,7 @@ __device__ __forceinline__ void clip_ln_rows(__amdgpu_buffer_rsrc_t xin, const i
         if (lr[k] >= 0) {  // (wave-uniform)
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                *reinterpret_cast<f32x4*>(xres + t16_off(lr[k], 4 * lane + 256 * i, KBt)) = v[k][i];
+                *reinterpret_cast<f32x4*>(xres + (size_t)lr[k] * E + 4 * lane + 256 * i) = v[k][i];
                 f32x4 y;
                 y.x = (v[k][i].x - mean) * rstd * ww[i].x + bb[i].x;
                 y.y = (v[k][i].y - mean) * rstd * ww[i].y + bb[i].y;
@@ -2647,7 +2651,7 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
                         srcs[k] = l == 0 ? t : lm;
                         ab[k] = a.tc_ab + ((size_t)a.tcmap[br * B + c] * T + t) * a.tc_ld + (size_t)l * 2 * E;
                     }
-                    clip_ln_rows(l == 0 ? pat_r : xres_r, srcs, ab, Lw.n1w, Lw.n1b, xres, h3, lms, lane);
+                    clip_ln_rows(l == 0 ? pat_r : xres_r, l == 0, srcs, ab, Lw.n1w, Lw.n1b, xres, h3, lms, lane);
                 }
                 if (!end_phase(true)) return;
                 // ---- qkv
@@ -2697,7 +2701,25 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
                 const int lane = lane_t;
                 const int tile = it % (a.C / 16), fb = it / (a.C / 16);
                 f32x4 acc[3];
-                step_gemm<3, 1, kSKBQ, false>(acc, xres_r, KBE, a.out_wt, KBE, tile, kSKBQ * w, lane, true, true, [] {}, 0, fb, nfb);
+                {  // (step_gemm<3, 1, kSKBQ> with A = the row-major residual stream: wave w's K slice, the three CFG rows of the block)
+                    f32x4 wf[kSKBQ], av[kSKBQ][3];
+#pragma unroll
+                    for (int u = 0; u < kSKBQ; ++u) {
+                        const int kb = kSKBQ * w + u;
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+                            av[u][q] = ld_l2(xres_r, (unsigned)((16 * (fb + nfb * q) + (lane & 15)) * E + 16 * kb + 4 * (lane >> 4)));
+                        wf[u] = *reinterpret_cast<const f32x4*>(a.out_wt + ((size_t)(tile * KBE + kb) << 8) + lane * 4);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int u = 0; u < kSKBQ; ++u)
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                            for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][cc], av[u][q][cc], acc[q], 0, 0, 0);
+                }
                 const f32x4 o = seg_reduce<3>(acc, 0, red, w, lane);
                 float* const outt = red + 8 * 3 * 256;  // [3 branches x 16 frames][16 columns]
                 if (w < 3) *reinterpret_cast<f32x4*>(outt + (16 * w + (lane & 15)) * 16 + 4 * (lane >> 4)) = o;
