@@ -2358,93 +2358,101 @@ __device__ __attribute__((noinline)) void clip_attention(StepAttn g, const float
 
 // Attention + residual + AdaLN(cond) + norm3 for a PAIR of consecutive chunks of one CFG row (transformerv2.py:190-236, :351-361;
 // mask: combined_sliding_chunkwise_mask, :62-96): the pair's 2 cs queries share their K / V rows -- frames [i0 - W + 1, e), fetched
-// once by LDS-DMA (one round trip for the item: K / V, q, the residual rows and the LayerNorm operands go out together) -- and
-// every query keeps its own chunk's bounds: keys [min(chunk start, j - W + 1), chunk end).  Two passes of four queries per wave
-// (wave = head, 16-lane group = query, lane = 4 dims); then all eight waves have a row of the LayerNorm tail (a single chunk
-// leaves four of them idle).  q and k arrive rotated (the qkv epilogue applies RoPE); h leaves as x6 planes.  W - 1 + 2 cs <= 16.
+// once (one round trip for the item: K / V, q, the residual rows and the LayerNorm operands go out together) -- and every query
+// keeps its own chunk's bounds: keys [min(chunk start, j - W + 1), chunk end).  Wave = head: the head's 16 x 16 score tile and its
+// 16 x 64 output are 32 v_mfma_f32_16x16x4_f32 (fp32 products, fp32 accumulate) on operands loaded in fragment order -- no LDS
+// landing zone, no cross-lane dot products; the softmax in between is four values per lane and two 4-lane reductions.  Then all
+// eight waves have a row of the LayerNorm tail (a single chunk leaves four of them idle).  q and k arrive rotated (the qkv
+// epilogue applies RoPE); h leaves as x6 planes.  W - 1 + 2 cs <= 16, 2 cs <= 8.
+// (Tried: the workgroup's three items inside one call, the next item's operands requested as soon as the matrix pipe has consumed
+//  this one's.  The round trip it hides (2.6 us) comes back as issue time -- an item is > 100 KB through the CU's 64-byte-a-clock
+//  vector memory path -- and the larger function is fetched cold every phase: 21 - 24 us per phase against 20.)
 // (out of line, every argument by value and re-uniformed: see seg_attention)
 __device__ __attribute__((noinline)) void clip_attention_pair(StepAttn g, const float* lab, const float* lw3, const float* lb3, int rg, int lr0,
-                                                              int px, float* smem, float* kvlds, float* xres, unsigned short* h3) {
+                                                              int px, float* smem, float* kvlds, float* xres, unsigned short* h3,
+                                                              unsigned long long* tr, int ord) {  // tr: AFTER_STEP_TRACE stamps [80 ..] (item `ord` of the workgroup)
+    tr = seg_uniform(tr), ord = seg_uniform(ord);
+    if (tr && threadIdx.x == 0 && ord < 3) tr[ord == 0 ? 80 : 84 + ord] = wall_clock64();
     g.T = seg_uniform(g.T), g.cs = seg_uniform(g.cs), g.W = seg_uniform(g.W);
     g.qkv = seg_uniform(g.qkv);
     lab = seg_uniform(lab), lw3 = seg_uniform(lw3), lb3 = seg_uniform(lb3);
     rg = seg_uniform(rg), lr0 = seg_uniform(lr0), px = seg_uniform(px);
     smem = seg_uniform(smem), kvlds = seg_uniform(kvlds), xres = seg_uniform(xres), h3 = seg_uniform(h3);
-    constexpr int NKB = 16, E = kSE, H = kSH, ld = E + 4, NV = E / 256;
+    constexpr int E = kSE, H = kSH, ld = E + 4, NV = E / 256;
     const int T = g.T, cs = g.cs, W = g.W;
     const int tid = threadIdx.x, lane = tid & 63, hw = tid >> 6;
-    const int grp = lane >> 4, d4 = (lane & 15) * 4;
+    const int n = lane & 15, gq = lane >> 4;
     const int i0 = px * 2 * cs, e = min(i0 + 2 * cs, T), nq = e - i0;
     const int lo_c = max(0, i0 - W + 1), nk = e - lo_c;  // (<= 16: one key block)
     const unsigned rowbase = (unsigned)rg * T;
     const __amdgpu_buffer_rsrc_t qkvr = step_rsrc(g.qkv), xr = step_rsrc(xres);
-    float* const kvs = kvlds + hw * (2 * NKB * 64);  // per-wave K / V landing zone [2][NKB][64]
-    auto as4 = [](f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
-    // one instruction moves 4 keys: 16-lane group gq fetches the 256-byte head slice of key 4 u + gq (sc1: written by this XCD)
+    // Everything of the item goes out together, in MFMA operand order, straight into registers (no LDS landing zone): lane (n, gq)
+    // holds of key n / query n the dims 16 u + 4 gq .. + 3 (u < 4: the contraction order of S^T = K Q^T, the same for both operands),
+    // of key 4 gq + s (s < 4) the dims 4 n .. + 3 (V: the contraction index of P V is the key, its order (gq, s) is the order the
+    // S^T accumulator leaves the probabilities in), and of query 4 gq + i the residual's dims 4 n .. + 3 (the order P V's
+    // accumulators leave the output in: column n of tile c = dim 4 n + c).
+    f32x4 kf[4], qf[4], vf[4], xf[4];
+    {
+        const unsigned krow = (rowbase + lo_c + min(n, nk - 1)) * 3u * E + E + hw * 64 + 4 * gq;
+        const unsigned qrow = (rowbase + i0 + min(n, nq - 1)) * 3u * E + hw * 64 + 4 * gq;
 #pragma unroll
-    for (int u = 0; u < NKB / 4; ++u) {
-        const int pos = lo_c + min(4 * u + grp, nk - 1);
-        const float* ksrc = g.qkv + ((size_t)rowbase + pos) * 3 * E + E + hw * 64 + d4;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)ksrc, (lds_ptr_t)(kvs + 4 * u * 64), 16, 0, 16);
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ksrc + E), (lds_ptr_t)(kvs + (NKB + 4 * u) * 64), 16, 0, 16);
+        for (int u = 0; u < 4; ++u) kf[u] = ld_l2(qkvr, krow + 16 * u), qf[u] = ld_l2(qkvr, qrow + 16 * u);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) vf[s4] = ld_l2(qkvr, (rowbase + lo_c + min(4 * gq + s4, nk - 1)) * 3u * E + 2 * E + hw * 64 + 4 * n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xf[i] = ld_l2(xr, (unsigned)((lr0 + i0 + min(4 * gq + i, nq - 1)) * E + hw * 64 + 4 * n));
     }
     StepLnOps ops;
     if (hw < nq) step_ln_ops(ops, lab, lw3, lb3, lane);
-    float4 q4[2], x4[2];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tr && tid == 0 && ord == 0) tr[81] = wall_clock64();
+    // ---- S^T = K Q^T on the fp32 matrix pipe: lane (n, gq) gets the scores of query n against keys 4 gq + i
+    f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-        const int qic = min(4 * ps + grp, nq - 1);
-        q4[ps] = as4(__builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qkvr, ((rowbase + i0 + qic) * 3u * E + hw * 64 + d4) * 4u, 0, 16)));
-        x4[ps] = as4(ld_l2(xr, (unsigned)((lr0 + i0 + qic) * E + hw * 64 + d4)));
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) st = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u][cc], qf[u][cc], st, 0, 0, 0);
+    // every query keeps its own chunk's bounds (combined_sliding_chunkwise_mask): keys [min(chunk start, j - W + 1), chunk end)
+    const int ja = i0 + min(n, nq - 1);
+    const int cstart = ja - (ja - i0) % cs;
+    const int lo_row = min(cstart, max(0, ja - W + 1)), cend = min(cstart + cs, T);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pos = lo_c + 4 * gq + i;
+        st[i] = (4 * gq + i < nk && pos >= lo_row && pos < cend) ? st[i] * 0.125f : -INFINITY;
+        mx = fmaxf(mx, st[i]);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the K / V block (and everything else) has landed
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));  // (the query's own frame is always visible: finite)
+    float sum = 0.f;
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-        const int qi = 4 * ps + grp;
-        if (4 * ps >= nq) break;
-        const bool qok = qi < nq;
-        const int ja = i0 + (qok ? qi : nq - 1);
-        const int cstart = ja - (ja - i0) % cs;                   // the query's chunk [cstart, cend)
-        const int lo_row = min(cstart, max(0, ja - W + 1)), cend = min(cstart + cs, T);
-        // a pass = the four queries of ONE chunk when cs = 4: its keys are the NKP slots from the chunk's first visible frame on
-        // (W - 1 + cs <= 12 of the block's 16: a quarter of the key loop's arithmetic less); other chunk sizes walk all 16
-        constexpr int NKP = 12;
-        const bool chunk_pass = cs == 4 && W - 1 + cs <= NKP;
-        const int j0 = chunk_pass ? max(0, cstart - (W - 1) - lo_c) : 0, jn = chunk_pass ? NKP : NKB;
-        float sc[NKB];
-        float mx = -INFINITY;
+    for (int i = 0; i < 4; ++i) st[i] = attn_exp(st[i] - mx), sum += st[i];  // exp(-inf) = 0 for masked / padded slots
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    // ---- O = P V: P's fragment is the S^T accumulator as it stands (row = query n, contraction slot (gq, s) = key 4 gq + s)
+    f32x4 ot[4];
 #pragma unroll
-        for (int j = 0; j < NKB; ++j) {
-            sc[j] = -INFINITY;
-            if (j < NKP || jn > NKP) {  // (wave-uniform)
-                const int js = j0 + j, pos = lo_c + min(js, nk - 1);
-                const float4 kr = *reinterpret_cast<const float4*>(kvs + min(js, NKB - 1) * 64 + d4);
-                float dot = q4[ps].x * kr.x + q4[ps].y * kr.y + q4[ps].z * kr.z + q4[ps].w * kr.w;
-                dot = group16_sum(dot);
-                sc[j] = (js < nk && pos >= lo_row && pos < cend) ? dot * 0.125f : -INFINITY;
-                mx = fmaxf(mx, sc[j]);
-            }
-        }
-        float sum = 0.f;
-        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int cc = 0; cc < 4; ++cc) ot[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < NKB; ++j) {
-            if (j < NKP || jn > NKP) {
-                const float p = attn_exp(sc[j] - mx);  // exp(-inf) = 0 for masked / padded slots
-                sum += p;
-                const float4 vj = *reinterpret_cast<const float4*>(kvs + (NKB + min(j0 + j, NKB - 1)) * 64 + d4);
-                o.x += p * vj.x, o.y += p * vj.y, o.z += p * vj.z, o.w += p * vj.w;
-            }
-        }
-        const float inv = 1.0f / sum;
-        if (qok) {
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const float pn = st[s4] * inv;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) ot[cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(pn, vf[s4][cc], ot[cc], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // lane (n, gq): query 4 gq + i, dims 4 n .. + 3 of the head
+        const int qi = 4 * gq + i;
+        if (qi < nq) {
             float4 res;
-            res.x = o.x * inv + x4[ps].x, res.y = o.y * inv + x4[ps].y, res.z = o.z * inv + x4[ps].z, res.w = o.w * inv + x4[ps].w;
-            *reinterpret_cast<float4*>(smem + qi * ld + hw * 64 + d4) = res;
+            res.x = ot[0][i] + xf[i][0], res.y = ot[1][i] + xf[i][1], res.z = ot[2][i] + xf[i][2], res.w = ot[3][i] + xf[i][3];
+            *reinterpret_cast<float4*>(smem + qi * ld + hw * 64 + 4 * n) = res;
         }
     }
+    if (tr && tid == 0 && ord == 0) tr[82] = wall_clock64();
     __syncthreads();
+    if (tr && tid == 0 && ord == 0) tr[83] = wall_clock64();
     // ---- AdaLN(cond) + norm3, one wave per row
     for (int qi = hw; qi < nq; qi += H) {
         float4 v[NV];
@@ -2484,6 +2492,7 @@ __device__ __attribute__((noinline)) void clip_attention_pair(StepAttn g, const 
             x6_store4(h3, lr0 + i0 + qi, 4 * lane + 256 * i, E, y.x, y.y, y.z, y.w);
         }
     }
+    if (tr && tid == 0 && (ord == 0 || ord == 2)) tr[ord == 0 ? 84 : 87] = wall_clock64();
 }
 
 // norm0 -> AdaLN(tcond) -> xres ; norm1 -> h (x6 planes) for three token rows of a wave (step_ln_row three times, with every
@@ -2668,7 +2677,7 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
                         __syncthreads();  // (a second item of this workgroup reuses the LDS rows)
                         clip_attention_pair(StepAttn{T, a.cs, a.W, 0, a.nkmax, a.rope_cos, a.rope_sin, qkv},
                                             cond_ab + (size_t)(br * B + c) * a.cond_ld + (size_t)l * 2 * E, Lw.n3w, Lw.n3b, br, br * T, px, smem, kvl,
-                                            xres, h3);
+                                            xres, h3, trace, (it - rank) / (int)n);
                     }
                 } else {
                     for (int it = rank; it < nitems; it += (int)n) {

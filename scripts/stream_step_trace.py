@@ -112,6 +112,13 @@ if args.offline and args.clips > 1:  # the clip-per-XCD kernel: effective shader
     lc = (buf[okw][:, 69].astype(np.int64) - buf[okw][:, 68].astype(np.int64))
     print("qkv phase, first tile, median us after the barrier: entry %.2f, slab 0 published %.2f, K loop done %.2f, epilogue issued %.2f; "
           "phase %.2f; shader cycles entry -> loop done %.0f (%.0f MHz)" % (tuple(np.median(rel, 0).tolist()) + (np.median(arr), np.median(lc), np.median(lc / ((gq[:, 2] - gq[:, 0]) / 100.0)))))
+    pa = 3 + 5 * (L - 1)  # the last layer's attention phase: thread 0's stamps inside the workgroup's items (pairs of chunks)
+    ga = buf[okw][:, 80:88].astype(np.int64)
+    if (ga[:, 0] > 0).all():
+        rela = np.median((ga - t_all[okw][:, 2 * pa][:, None]) / 100.0, 0)
+        print("attention phase, median us after the barrier: item 0 entry %.2f, operands landed %.2f, keys done %.2f, rows exchanged %.2f, "
+              "LayerNorm tail issued %.2f; item 1 entry %.2f; item 2 entry %.2f, end %.2f; arrival %.2f"
+              % (tuple(rela.tolist()) + (np.median((t_all[okw][:, 2 * pa + 1] - t_all[okw][:, 2 * pa]) / 100.0),)))
     pr = buf[okw][:, 88:120].astype(np.int64).reshape(-1, 8, 4)
     if pr.any():  # -DX6R_PROF=1 builds: per-wave cycle counters of the traced GEMM phase's K loop
         med = np.median(pr, 0)
