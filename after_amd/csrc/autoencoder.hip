@@ -9,6 +9,7 @@
 // conv that feeds a Snake-only consumer writes that consumer's activated input itself.
 // The two PQMF filter banks are HBM-bound polyphase FIRs on the vector ALUs with their
 // taps in scalar registers.
+#include <cstdio>
 #include <cstdlib>
 #include <new>
 #include <vector>
@@ -629,6 +630,10 @@ int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const 
         xin = h->xp;
     }
     r.xp = xin;
+    static const bool trace_layers = getenv("AFTER_AE_TRACE") != nullptr;  // one line per conv launch: shape and path
+    if (trace_layers)
+        fprintf(stderr, "ae conv: B %d Tin %d Tout %d Nn %d Cin %d Cout %d taps %d phases %d K %d res %d stats %d y2 %d -> %s\n", B, Tin, Tout, Nn, cin,
+                cout, d.in.taps, d.in.phases, d.tplan.K, res != nullptr, r.stats != nullptr, r.y2 != nullptr, x6 ? "conv_x6" : "conv_tm");
     if (x6) {
         r.xp3 = h->xp3;
         r.w3 = d.w3;

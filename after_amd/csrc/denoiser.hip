@@ -1438,7 +1438,7 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
                     __syncthreads();  // (a second item of this workgroup reuses the LDS rows)
                     if (it != rank) attn_prefetch(l, it);
                     step_attention<16>(StepAttn{a.T, a.cs, a.W, a.cache, a.nkmax, a.rope_cos, a.rope_sin, Lw.qkv}, kv, lnops,
-                                       br * B + c0 + cl, br * ct + cl * T, bx, smem, kvl, qkv_r, xres_r, xres, hb);
+                                       br * B + c0 + cl, br * ct + cl * T, bx, smem, kvl, qkv_r, xres_r, xres, hb, nullptr, nullptr, nullptr, trace);
                 }
                 const int nroll = nitems < (int)n ? (int)n - nitems : (int)n, rb = nitems < (int)n ? rank - nitems : rank;
                 if (rb >= 0) {

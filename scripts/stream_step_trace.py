@@ -78,6 +78,17 @@ print(f"XCD {args.xcd} step: {(t[:, 2 * len(names) - 1].max() - t0) / 100.0:.1f}
       f"barriers (last arrival -> last exit) {tot_bar:.1f} us")
 
 
+if not args.offline:  # the last layer's attention phase: stamps of thread 0 inside the item (workgroups with an item)
+    pa = 3 + 5 * (L - 1)
+    ga = buf[:, 80:85].astype(np.int64)
+    has = ga[:, 0] > 0
+    if has.any():
+        rela = (ga[has] - t_all[has][:, 2 * pa][:, None]) / 100.0
+        arra = (t_all[has][:, 2 * pa + 1] - t_all[has][:, 2 * pa]) / 100.0
+        print("attention phase, %d workgroups with an item, median / max us after the barrier: entry %.2f / %.2f, first pass landed %.2f / %.2f, keys done %.2f / %.2f, "
+              "rows exchanged %.2f / %.2f, LayerNorm tail stored %.2f / %.2f, arrival %.2f / %.2f" % ((int(has.sum()),) + tuple(
+                  v for k in range(5) for v in (np.median(rela[:, k]), rela[:, k].max())) + (np.median(arra), arra.max())))
+
 if args.offline and args.clips == 1:  # effective shader clock over the step; inside the last layer's qkv phase (workgroup-local stamps of wave 0)
     cyc = (buf[:, 71].astype(np.int64) - buf[:, 70].astype(np.int64))
     wall = (t_all[:, 2 * len(names) - 1] - t_all[:, 0]) / 100.0

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=20)
     ap.add_argument("--chunk-size", type=int, default=4)
     ap.add_argument("--shared", action="store_true", help="export.py behaviour: one diffusion, repeated")
+    ap.add_argument("--no-parts", action="store_true", help="whole chunks only (for a kernel trace of one chunk)")
     a = ap.parse_args()
     torch.set_grad_enabled(False)
     dev = "cuda:0"
@@ -44,6 +45,9 @@ def main():
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / a.chunks * 1e3
     parts = {}
+    if a.no_parts:
+        print(json.dumps({"ms_per_chunk": round(ms, 3)}))
+        return
     xs, xt = x[:, :1].contiguous(), x[:, 1:].contiguous()
     cond = torch.cat((st.structure(xs), st.timbre(xt)), 1)
     z = st.diffuse(cond)
