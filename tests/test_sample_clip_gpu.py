@@ -118,3 +118,32 @@ def test_clip_sampler_long_clips_walk_several_tiles(B, T, steps, hip_device):
     c = B - 1
     want = oracle.sample(sd, dcfg["net"], x0[c:c + 1], cond[c:c + 1], tc[c:c + 1], steps, 2.0, 1.0)
     assert max_abs(got[c:c + 1], want) < 1e-4, max_abs(got[c:c + 1], want)
+
+
+@pytest.mark.parametrize("cs,window,T", [(4, 16, 64), (2, 8, 64), (4, 4, 48), (2, 16, 32), (1, 8, 32)])
+def test_clip_sampler_other_windows_and_chunk_sizes(cs, window, T, hip_device):
+    """Base width with attention geometries no shipped config uses (transformerv2.py:62-96: any chunk size / window): W - 1 + 2 cs
+    <= 16 runs the paired-chunk attention with other chunk bounds, a wider window (W = 16) the single-chunk item over two key
+    blocks on the row-major residual stream.  Against the launch path of the same handle and the oracle."""
+    from after_amd import configs
+    from after_amd.diffusion.model import RectifiedFlow
+    from after_amd.diffusion.networks.transformerv2 import DenoiserV2
+    dcfg = configs.diffusion_config("base")
+    ncfg = dict(dcfg["net"], attention_chunk_size=cs, local_attention_size=window)
+    torch.manual_seed(3 + cs + window)
+    net = DenoiserV2(**ncfg)
+    model = RectifiedFlow(net=net, sr=dcfg["sr"], drop_value=dcfg["drop_value"], device=hip_device)
+    net = model.net
+    B, steps = 5, 2
+    x0, cond, tc = _inputs(B, T, 11 * cs + window, net)
+    args = (x0.to(hip_device), cond.to(hip_device), tc.to(hip_device), steps, 2.0, 1.0, -4.0)
+    net.set_sample_persist(False)
+    ref = net.cfg_sample(*args).cpu()
+    assert net.sample_path() == 0
+    net.set_sample_persist(True)
+    got = net.cfg_sample(*args).cpu()
+    assert net.sample_path() == 2, (cs, window, net.sample_path())
+    assert torch.isfinite(got).all() and max_abs(got, ref) < 5e-5, max_abs(got, ref)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    want = oracle.sample(sd, ncfg, x0[1:2], cond[1:2], tc[1:2], steps, 2.0, 1.0)
+    assert max_abs(got[1:2], want) < 1e-4, max_abs(got[1:2], want)
