@@ -391,6 +391,121 @@ __global__ __launch_bounds__(256) void act_pad_x6_kernel(ActTmArgs a, int nkb, i
     }
 }
 
+// The same pass for LARGE tensors (a batch of clips): a wave walks RBL row blocks of its channel block two at a time, the next pair's rows
+// requested before the current pair is activated, split and stored.  In act_pad_x6_kernel every wave of the launch requests its rows,
+// then activates (SnakeBeta + the three-way split: ~40 VALU operations per element), then stores -- all at the same time: the memory
+// system idles while the VALUs work and vice versa (384 channels x 4096 frames x 8 clips: 126 MB in 76 us = 1.7 TB/s).  Waves that
+// loop drift apart, and loads, arithmetic and stores of different waves overlap.
+__global__ __launch_bounds__(256) void act_pad_x6_loop_kernel(ActTmArgs a, int nkb, int RBL) {
+    __shared__ float gmean[16], grstd[16];
+    __shared__ __attribute__((aligned(16))) long long swl[16 * kStatSub * kStatWords];
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nrb = a.rows16 >> 4;
+    const int wv = blockIdx.x * 4 + w;
+    const int kb = wv % nkb, rg = wv / nkb;
+    const int r = lane >> 2, c0 = kb * 32 + 8 * (lane & 3);
+    const int rb_lo = rg * RBL, rb_hi = min(rb_lo + RBL, nrb);
+    const bool kvalid = rb_lo < nrb;
+    const bool whole = c0 + 7 < a.C;
+    auto load2 = [&](f32x4 (&v)[2][2], int rb0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            v[u][0] = v[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int rbI = rb0 + u, t = rbI * 16 + r - HALO;
+            if (rbI < rb_hi && t >= 0 && t < a.T) {
+                const float* xr = a.x + ((size_t)b * a.T + t) * a.ldx + c0;
+                if (whole) {
+                    v[u][0] = *reinterpret_cast<const f32x4*>(xr);
+                    v[u][1] = *reinterpret_cast<const f32x4*>(xr + 4);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (c0 + k < a.C) v[u][k >> 2][k & 3] = xr[k];
+                }
+            }
+        }
+    };
+    f32x4 va[2][2], vb[2][2];
+    if (kvalid) load2(va, rb_lo);
+    float ga[8], be[8], pa[8], pb[8];
+    if (kvalid && whole && ((a.C | c0) & 3) == 0) {
+        auto ld8 = [&](const float* p, float (&o)[8], float dflt) {
+            if (p) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + c0), v1 = *reinterpret_cast<const f32x4*>(p + c0 + 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    o[k] = v0[k];
+                    o[4 + k] = v1[k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = dflt;
+            }
+        };
+        ld8(a.gamma, ga, 1.f);
+        ld8(a.gamma ? a.beta : nullptr, be, 0.f);
+        ld8(a.act_a, pa, 0.f);
+        ld8(a.act_b, pb, 0.f);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = c0 + k;
+            ga[k] = 1.f;
+            be[k] = 0.f;
+            pa[k] = pb[k] = 0.f;
+            if (!kvalid || c >= a.C) continue;
+            if (a.gamma) {
+                ga[k] = a.gamma[c];
+                be[k] = a.beta[c];
+            }
+            if (a.act_a) pa[k] = a.act_a[c];
+            if (a.act_b) pb[k] = a.act_b[c];
+        }
+    }
+    if (a.stats) gn_mean_rstd(a.stats, b, a.G, a.sub_stride, a.C, a.stat_T, a.eps, swl, gmean, grstd, 256);
+    if (!kvalid) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sc[k] = ga[k];
+        sh[k] = be[k];
+        if (a.stats && c0 + k < a.C) {
+            const int g = (c0 + k) / (a.C / a.G);
+            sc[k] = grstd[g] * ga[k];
+            sh[k] = be[k] - gmean[g] * sc[k];
+        }
+    }
+    const int slot = (lane & 3) ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3);  // x6 chunk permutation (common.h: x6_offset)
+    auto emit2 = [&](const f32x4 (&v)[2][2], int rb0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int rbI = rb0 + u, t = rbI * 16 + r - HALO;
+            if (rbI >= rb_hi) continue;
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float xv = v[u][k >> 2][k & 3];
+                o[k] = (t >= 0 && t < a.T && c0 + k < a.C) ? act_apply(xv * sc[k] + sh[k], a.act, pa[k], pb[k]) : 0.f;
+            }
+            uint2 h0, m0, l0, h1, m1, l1;
+            x6_split4(o[0], o[1], o[2], o[3], h0, m0, l0);
+            x6_split4(o[4], o[5], o[6], o[7], h1, m1, l1);
+            unsigned short* bp = a.y3 + ((((size_t)b * nrb + rbI) * nkb + kb) * 3) * 512 + r * 32 + slot * 8;
+            *reinterpret_cast<uint4*>(bp) = uint4{h0.x, h0.y, h1.x, h1.y};
+            *reinterpret_cast<uint4*>(bp + 512) = uint4{m0.x, m0.y, m1.x, m1.y};
+            *reinterpret_cast<uint4*>(bp + 1024) = uint4{l0.x, l0.y, l1.x, l1.y};
+        }
+    };
+    for (int rb0 = rb_lo; rb0 < rb_hi; rb0 += 4) {
+        if (rb0 + 2 < rb_hi) load2(vb, rb0 + 2);
+        emit2(va, rb0);
+        if (rb0 + 2 >= rb_hi) break;
+        if (rb0 + 4 < rb_hi) load2(va, rb0 + 4);
+        emit2(vb, rb0 + 2);
+    }
+}
+
 // ------------------------------------------------------------------ the conv GEMM
 struct ConvTmArgs {
     const float* xp;    // [B][Tp][Cp]
@@ -1070,6 +1185,17 @@ int launch_act_pad_tm(const ActPadTm& p, hipStream_t s) {
         AFTER_REQUIRE(!p.x_cm && !p.x2 && !p.scale_b && !p.pad_reflect && (a.ldx & 3) == 0 && ((uintptr_t)p.x & 15) == 0,
                       AFTER_E_INVALID, "act_pad_tm: plane output takes plain time-major inputs");
         const int nkb = a.Cp / 32, nrb = a.rows16 / 16;
+        static int loop_rb = -1;  // AFTER_ACT_LOOP=0: A/B switch; n: row blocks a wave of the looping kernel walks
+        if (loop_rb < 0) {
+            const char* e = getenv("AFTER_ACT_LOOP");
+            loop_rb = e ? atoi(e) : 8;
+        }
+        if (loop_rb >= 4 && (long long)cdiv(nrb, loop_rb) * nkb * p.B >= 1024) {  // large tensors: waves that loop (>= one wave per SIMD)
+            a.xcd_rows = 0;
+            hipLaunchKernelGGL(act_pad_x6_loop_kernel, dim3(cdiv(cdiv(nrb, loop_rb) * nkb, 4), p.B), dim3(256), 0, s, a, nkb, loop_rb);
+            AFTER_HIP_CHECK(hipGetLastError());
+            return AFTER_OK;
+        }
         int RB = 4;
         while (RB > 1 && (long long)cdiv(nrb, RB) * nkb * p.B < 4 * 768) RB >>= 1;  // >= 3 blocks per CU where the tensor allows
         int nwg = cdiv(cdiv(nrb, RB) * nkb, 4);

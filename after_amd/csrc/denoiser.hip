@@ -2363,11 +2363,12 @@ __device__ __attribute__((noinline)) void clip_attention(StepAttn g, const float
 // 16 x 64 output are 32 v_mfma_f32_16x16x4_f32 (fp32 products, fp32 accumulate) on operands loaded in fragment order -- no LDS
 // landing zone, no cross-lane dot products; the softmax in between is four values per lane and two 4-lane reductions.  Then all
 // eight waves have a row of the LayerNorm tail (a single chunk leaves four of them idle).  q and k arrive rotated (the qkv
-// epilogue applies RoPE); h leaves as x6 planes.  W - 1 + 2 cs <= 16, 2 cs <= 8.
+// epilogue applies RoPE); h leaves as x6 planes.  W - 1 + 2 cs <= 16 NKT (NKT = 2: the midi config's window of 16), 2 cs <= 8.
 // (Tried: the workgroup's three items inside one call, the next item's operands requested as soon as the matrix pipe has consumed
 //  this one's.  The round trip it hides (2.6 us) comes back as issue time -- an item is > 100 KB through the CU's 64-byte-a-clock
 //  vector memory path -- and the larger function is fetched cold every phase: 21 - 24 us per phase against 20.)
 // (out of line, every argument by value and re-uniformed: see seg_attention)
+template <int NKT>  // 16-key tiles of the item: W - 1 + 2 cs <= 16 NKT
 __device__ __attribute__((noinline)) void clip_attention_pair(StepAttn g, const float* lab, const float* lw3, const float* lb3, int rg, int lr0,
                                                               int px, float* smem, float* kvlds, float* xres, unsigned short* h3,
                                                               unsigned long long* tr, int ord) {  // tr: AFTER_STEP_TRACE stamps [80 ..] (item `ord` of the workgroup)
@@ -2383,22 +2384,30 @@ __device__ __attribute__((noinline)) void clip_attention_pair(StepAttn g, const 
     const int tid = threadIdx.x, lane = tid & 63, hw = tid >> 6;
     const int n = lane & 15, gq = lane >> 4;
     const int i0 = px * 2 * cs, e = min(i0 + 2 * cs, T), nq = e - i0;
-    const int lo_c = max(0, i0 - W + 1), nk = e - lo_c;  // (<= 16: one key block)
+    const int lo_c = max(0, i0 - W + 1), nk = e - lo_c;  // (<= 16 NKT)
     const unsigned rowbase = (unsigned)rg * T;
     const __amdgpu_buffer_rsrc_t qkvr = step_rsrc(g.qkv), xr = step_rsrc(xres);
     // Everything of the item goes out together, in MFMA operand order, straight into registers (no LDS landing zone): lane (n, gq)
-    // holds of key n / query n the dims 16 u + 4 gq .. + 3 (u < 4: the contraction order of S^T = K Q^T, the same for both operands),
-    // of key 4 gq + s (s < 4) the dims 4 n .. + 3 (V: the contraction index of P V is the key, its order (gq, s) is the order the
-    // S^T accumulator leaves the probabilities in), and of query 4 gq + i the residual's dims 4 n .. + 3 (the order P V's
-    // accumulators leave the output in: column n of tile c = dim 4 n + c).
-    f32x4 kf[4], qf[4], vf[4], xf[4];
+    // holds of key 16 kt + n / query n the dims 16 u + 4 gq .. + 3 (u < 4: the contraction order of S^T = K Q^T, the same for both
+    // operands), of key 16 kt + 4 gq + s (s < 4) the dims 4 n .. + 3 (V: the contraction index of P V is the key, its order
+    // (kt, gq, s) is the order the S^T accumulators leave the probabilities in), and of query 4 gq + i the residual's dims
+    // 4 n .. + 3 (the order P V's accumulators leave the output in: column n of tile c = dim 4 n + c).
+    f32x4 kf[NKT][4], qf[4], vf[NKT][4], xf[4];
     {
-        const unsigned krow = (rowbase + lo_c + min(n, nk - 1)) * 3u * E + E + hw * 64 + 4 * gq;
         const unsigned qrow = (rowbase + i0 + min(n, nq - 1)) * 3u * E + hw * 64 + 4 * gq;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) kf[u] = ld_l2(qkvr, krow + 16 * u), qf[u] = ld_l2(qkvr, qrow + 16 * u);
+        for (int kt = 0; kt < NKT; ++kt) {
+            const unsigned krow = (rowbase + lo_c + min(16 * kt + n, nk - 1)) * 3u * E + E + hw * 64 + 4 * gq;
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) vf[s4] = ld_l2(qkvr, (rowbase + lo_c + min(4 * gq + s4, nk - 1)) * 3u * E + 2 * E + hw * 64 + 4 * n);
+            for (int u = 0; u < 4; ++u) kf[kt][u] = ld_l2(qkvr, krow + 16 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) qf[u] = ld_l2(qkvr, qrow + 16 * u);
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+                vf[kt][s4] = ld_l2(qkvr, (rowbase + lo_c + min(16 * kt + 4 * gq + s4, nk - 1)) * 3u * E + 2 * E + hw * 64 + 4 * n);
 #pragma unroll
         for (int i = 0; i < 4; ++i) xf[i] = ld_l2(xr, (unsigned)((lr0 + i0 + min(4 * gq + i, nq - 1)) * E + hw * 64 + 4 * n));
     }
@@ -2406,41 +2415,51 @@ __device__ __attribute__((noinline)) void clip_attention_pair(StepAttn g, const 
     if (hw < nq) step_ln_ops(ops, lab, lw3, lb3, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tr && tid == 0 && ord == 0) tr[81] = wall_clock64();
-    // ---- S^T = K Q^T on the fp32 matrix pipe: lane (n, gq) gets the scores of query n against keys 4 gq + i
-    f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ---- S^T = K Q^T on the fp32 matrix pipe: lane (n, gq) gets the scores of query n against keys 16 kt + 4 gq + i
+    f32x4 st[NKT];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int kt = 0; kt < NKT; ++kt) {
+        st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) st = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u][cc], qf[u][cc], st, 0, 0, 0);
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][u][cc], qf[u][cc], st[kt], 0, 0, 0);
+    }
     // every query keeps its own chunk's bounds (combined_sliding_chunkwise_mask): keys [min(chunk start, j - W + 1), chunk end)
     const int ja = i0 + min(n, nq - 1);
     const int cstart = ja - (ja - i0) % cs;
     const int lo_row = min(cstart, max(0, ja - W + 1)), cend = min(cstart + cs, T);
     float mx = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int pos = lo_c + 4 * gq + i;
-        st[i] = (4 * gq + i < nk && pos >= lo_row && pos < cend) ? st[i] * 0.125f : -INFINITY;
-        mx = fmaxf(mx, st[i]);
-    }
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = 16 * kt + 4 * gq + i, pos = lo_c + j;
+            st[kt][i] = (j < nk && pos >= lo_row && pos < cend) ? st[kt][i] * 0.125f : -INFINITY;
+            mx = fmaxf(mx, st[kt][i]);
+        }
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));  // (the query's own frame is always visible: finite)
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) st[i] = attn_exp(st[i] - mx), sum += st[i];  // exp(-inf) = 0 for masked / padded slots
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st[kt][i] = attn_exp(st[kt][i] - mx), sum += st[kt][i];  // exp(-inf) = 0 for masked / padded slots
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
-    // ---- O = P V: P's fragment is the S^T accumulator as it stands (row = query n, contraction slot (gq, s) = key 4 gq + s)
+    // ---- O = P V: P's fragments are the S^T accumulators as they stand (row = query n, contraction slot (kt, gq, s) = key 16 kt + 4 gq + s)
     f32x4 ot[4];
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) ot[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-        const float pn = st[s4] * inv;
+    for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) ot[cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(pn, vf[s4][cc], ot[cc], 0, 0, 0);
-    }
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const float pn = st[kt][s4] * inv;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) ot[cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(pn, vf[kt][s4][cc], ot[cc], 0, 0, 0);
+        }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {  // lane (n, gq): query 4 gq + i, dims 4 n .. + 3 of the head
         const int qi = 4 * gq + i;
@@ -2605,7 +2624,8 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
     float* const kvl = smem + 8192;   // attention: K / V landing zones [8 waves][2][12][64]
     auto end_phase = [&](bool drain) { return step_barrier(st, xcc, n, (unsigned)rank, ++round, trace, ++tslot, drain, &s_ok); };
     const int cps = (T + a.cs - 1) / a.cs, nitems = 3 * cps;  // attention items: (CFG row, chunk) ...
-    const bool pairs = a.W - 1 + 2 * a.cs <= 16 && T % a.cs == 0 && 2 * a.cs <= 8 && !(a.dbg & 64);  // ... or (CFG row, pair of chunks)
+    const bool pairs = a.W - 1 + 2 * a.cs <= 32 && T % a.cs == 0 && 2 * a.cs <= 8 && !(a.dbg & 64);  // ... or (CFG row, pair of chunks)
+    const bool pairs2 = a.W - 1 + 2 * a.cs > 16;  // a pair's keys are two 16-key tiles (midi: W = 16)
     const int npair = (cps + 1) / 2;
     const int nfb = T / 16, ntail = (a.C / 16) * nfb;         // tail items: (column tile, 16-frame block)
 
@@ -2675,9 +2695,14 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
                     for (int it = rank; it < 3 * npair; it += (int)n) {
                         const int br = it / npair, px = it - br * npair;
                         __syncthreads();  // (a second item of this workgroup reuses the LDS rows)
-                        clip_attention_pair(StepAttn{T, a.cs, a.W, 0, a.nkmax, a.rope_cos, a.rope_sin, qkv},
-                                            cond_ab + (size_t)(br * B + c) * a.cond_ld + (size_t)l * 2 * E, Lw.n3w, Lw.n3b, br, br * T, px, smem, kvl,
-                                            xres, h3, trace, (it - rank) / (int)n);
+                        if (pairs2)
+                            clip_attention_pair<2>(StepAttn{T, a.cs, a.W, 0, a.nkmax, a.rope_cos, a.rope_sin, qkv},
+                                                   cond_ab + (size_t)(br * B + c) * a.cond_ld + (size_t)l * 2 * E, Lw.n3w, Lw.n3b, br, br * T, px, smem,
+                                                   kvl, xres, h3, trace, (it - rank) / (int)n);
+                        else
+                            clip_attention_pair<1>(StepAttn{T, a.cs, a.W, 0, a.nkmax, a.rope_cos, a.rope_sin, qkv},
+                                                   cond_ab + (size_t)(br * B + c) * a.cond_ld + (size_t)l * 2 * E, Lw.n3w, Lw.n3b, br, br * T, px, smem,
+                                                   kvl, xres, h3, trace, (it - rank) / (int)n);
                     }
                 } else {
                     for (int it = rank; it < nitems; it += (int)n) {

@@ -90,4 +90,6 @@ for b in 1 8; do
 done
 python scripts/pmc_run.py $O/${R}_pmc_codec_b1.json -- python scripts/time_codec.py --batches 1 --rounds 3 > $O/pmc_codec.log 2>&1
 for b in 1 8; do python scripts/pmc_run.py --mfma $O/${R}_pmc_mfma_codec_b$b.json -- python scripts/time_codec.py --batches $b --rounds 3 >> $O/pmc_codec.log 2>&1; done   # matrix-pipe busy fraction of the conv kernels
+# one whole chunk of the streaming path, launch by launch (everything between two launches of the persistent sampler)
+bash scripts/stream_chunk_trace.sh > $O/stream_chunk.log 2>&1; cp gpurun_out/stream_chunk/chunk_trace.jsonl $O/${R}_stream_chunk_trace.jsonl; cp gpurun_out/stream_chunk/time_stream.json $O/${R}_time_stream.json
 ls -la $O | head -60
