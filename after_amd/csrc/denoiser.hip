@@ -734,7 +734,7 @@ struct StepKV {
 
 struct StepArgs {
     int rows, B, T, C, Cp, L, cs, W, nkmax, cache, cache_rows, cpg, dbg;
-    int Tseg;                 // offline segment sampler: frames per XCD (T / 8)
+    int Tseg, nseg;           // offline segment sampler: frames per XCD (16 or 32), XCDs at work (T / Tseg <= 8)
     int nsteps, cache_steps;  // Euler steps of this launch (ALL of a sample() call); ring slots per layer
     unsigned flip[4];         // bit i: which half of step i's K / V rings is current
     int warm[3];  // sixteenths of the qkv / MLP-up / MLP-down weights warmed into the L2 by idle waves (AFTER_STEP_WARM)
@@ -945,17 +945,20 @@ __device__ __forceinline__ f32x4 step_reduced(const float* red, int P, int p, in
 // The row-wise operands of a LayerNorm phase -- AdaLN alpha / beta of the row, affine weight / bias: 4 x 2 float4 per
 // lane (lane owns channels 4 lane + 256 i) -- come from the memory-side cache (~2 us).  They are requested one GEMM phase
 // EARLY (behind that phase's operand loads, see step_gemm's `after_loads`) and ride through the barrier in registers.
-struct StepLnOps {
-    f32x4 al[kSE / 256], be[kSE / 256], ww[kSE / 256], bb[kSE / 256];
+template <int E>  // embed width: 512 (base, midi) or 256 (tiny: the offline segment sampler only)
+struct StepLnOpsT {
+    f32x4 al[E / 256], be[E / 256], ww[E / 256], bb[E / 256];
 };
+using StepLnOps = StepLnOpsT<kSE>;
 
-__device__ __forceinline__ void step_ln_ops(StepLnOps& o, const float* __restrict__ ab, const float* __restrict__ w1,
+template <int E>
+__device__ __forceinline__ void step_ln_ops(StepLnOpsT<E>& o, const float* __restrict__ ab, const float* __restrict__ w1,
                                             const float* __restrict__ b1, int lane) {
 #pragma unroll
-    for (int i = 0; i < kSE / 256; ++i) {
+    for (int i = 0; i < E / 256; ++i) {
         const int c = 4 * lane + 256 * i;
         o.al[i] = *reinterpret_cast<const f32x4*>(ab + c);
-        o.be[i] = *reinterpret_cast<const f32x4*>(ab + kSE + c);
+        o.be[i] = *reinterpret_cast<const f32x4*>(ab + E + c);
         o.ww[i] = *reinterpret_cast<const f32x4*>(w1 + c);
         o.bb[i] = *reinterpret_cast<const f32x4*>(b1 + c);
     }
@@ -974,10 +977,10 @@ __device__ __forceinline__ void p32_store4(unsigned short* base, int lr, int c, 
 }
 
 // ln_mod_ln_row on tiled buffers (E = 512): x = norm0(xin[src]) * (1 + alpha_t) + beta_t -> xres ; h = norm1(x)
-template <int PLANES = 0>  // h: fp32 tiles (0), bf16 x 3 planes in fragment order (1: p32_store4) or in x6 blocks (2: x6_store4, common.h)
+template <int PLANES = 0, int E = kSE>  // h: fp32 tiles (0), bf16 x 3 planes in fragment order (1: p32_store4) or in x6 blocks (2: x6_store4, common.h)
 __device__ __forceinline__ void step_ln_row(__amdgpu_buffer_rsrc_t xin, int src_lr, float* __restrict__ xres,
-                                            float* __restrict__ h, int lr, const StepLnOps& ops, int lane) {
-    constexpr int E = kSE, NV = E / 256, KBt = E / 16;
+                                            float* __restrict__ h, int lr, const StepLnOpsT<E>& ops, int lane) {
+    constexpr int NV = E / 256, KBt = E / 16;
     f32x4 v[NV];
     const f32x4 (&al)[NV] = ops.al, (&be)[NV] = ops.be, (&ww)[NV] = ops.ww, (&bb)[NV] = ops.bb;
 #pragma unroll
@@ -1052,14 +1055,16 @@ __device__ __forceinline__ bool seg_spin_sys(const unsigned* word, unsigned want
 // (Tried on top, LATE only: a chunk whose window reaches into the previous XCD's segment runs its OWN keys first and fetches
 //  the neighbour's -- after the sequence-word wait -- in a second pass of the online softmax.  The second pass (a
 //  system-scope round trip + a 12-key block) costs more than the wait it hides: 285 vs 270 us per Euler step.)
-template <int AUX, int PLANES = 0, bool LATE = false, bool XROW = false>  // hout: fp32 tiles (0), bf16 x 3 planes: p32_store4 (1) / x6 blocks (2);
+template <int AUX, int PLANES = 0, bool LATE = false, bool XROW = false, int E = kSE>  // hout: fp32 tiles (0), bf16 x 3 planes: p32_store4 (1) / x6 blocks (2);
                                                                            // XROW: the residual stream row-major [rows][E] instead of 16 x 16 tiles
-__device__ __forceinline__ void step_attention(const StepAttn& a, const StepKV& kv, const StepLnOps& ops, int rg,
+                                                                           // E: embed width, E / 64 heads on waves 0 .. E / 64 - 1 (256: the tiny config, LATE only)
+__device__ __forceinline__ void step_attention(const StepAttn& a, const StepKV& kv, const StepLnOpsT<E>& ops, int rg,
                                                int lr0, int bx, float* smem, float* kvlds, __amdgpu_buffer_rsrc_t qkvr,
                                                __amdgpu_buffer_rsrc_t xr, float* __restrict__ xres, float* __restrict__ hout,
                                                const float* lab = nullptr, const float* lw3 = nullptr, const float* lb3 = nullptr,
                                                unsigned long long* tr = nullptr) {  // tr: AFTER_STEP_TRACE stamps [80 ..]
-    constexpr int NKMAX = kAttnKeyBlock, E = kSE, H = kSH, KBt = E / 16, ld = E + 4;
+    constexpr int NKMAX = kAttnKeyBlock, H = E / 64, NW = 8, KBt = E / 16, ld = E + 4;  // NW: waves of the workgroup
+    static_assert(H == NW || LATE, "fewer heads than waves: the offline segment sampler only");
     const int T = a.T, cs = a.cs, W = a.W, nc = a.cache;
     const int tid = threadIdx.x, lane = tid & 63, hw = tid >> 6;
     if (tr && tid == 0) tr[80] = wall_clock64();
@@ -1086,8 +1091,8 @@ __device__ __forceinline__ void step_attention(const StepAttn& a, const StepKV& 
     };
     if constexpr (!LATE) rope_loads();
     constexpr int NV = E / 256;
-    StepLnOps late;
-    const StepLnOps& lo = LATE ? late : ops;
+    StepLnOpsT<E> late;
+    const StepLnOpsT<E>& lo = LATE ? late : ops;
     const f32x4 (&al)[NV] = lo.al, (&be)[NV] = lo.be, (&ww)[NV] = lo.ww, (&bb)[NV] = lo.bb;
     auto as4 = [](f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
     // K / V rows go global -> LDS by DMA (no VGPR landing zone: this kernel's register budget belongs to the weight
@@ -1118,13 +1123,14 @@ __device__ __forceinline__ void step_attention(const StepAttn& a, const StepKV& 
     // epilogue (seg kernel), not once per (query, key) here: two LDS reads and eight FMAs per key and lane less in the key loop
     constexpr bool ROPED = LATE;
     auto ex = [](float v) { return attn_exp(v); };
+    const bool head = H == NW || hw < H;  // (a wave without a head still has rows of the LayerNorm tail)
     if constexpr (LATE) {  // every request of the item's first pass, K / V first, in front of the loops (one round trip)
-        kv_dma(0);
+        if (head) kv_dma(0);
         if constexpr (!ROPED) rope_loads();
         if (hw < nq) step_ln_ops(late, lab, lw3, lb3, lane);
-        q4n = q_load(0), x4n = x_load(0);
+        if (head) q4n = q_load(0), x4n = x_load(0);
     }
-    for (int qb = 0; qb < nq; qb += 4) {
+    for (int qb = 0; head && qb < nq; qb += 4) {
         const int qi = qb + grp;
         const bool qok = qi < nq;
         const int qic = qok ? qi : nq - 1;
@@ -1202,7 +1208,7 @@ __device__ __forceinline__ void step_attention(const StepAttn& a, const StepKV& 
     __syncthreads();
     if (tr && tid == 0) tr[83] = wall_clock64();
     // ---- AdaLN(cond) + norm3, one wave per row
-    for (int qi = hw; qi < nq; qi += H) {
+    for (int qi = hw; qi < nq; qi += NW) {
         float4 v[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(smem + qi * ld + 4 * lane + 256 * i);
@@ -1702,6 +1708,7 @@ __device__ __forceinline__ T* seg_uniform(T* p) {
 }
 __device__ __forceinline__ int seg_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+template <int E>
 __device__ __attribute__((noinline)) void seg_attention(StepAttn g, const float* ab, const float* w3, const float* b3, int rg, int lr0,
                                                         int bx, bool halo, float* smem, float* kvlds, float* xres, float* hout,
                                                         unsigned long long* tr) {
@@ -1716,19 +1723,26 @@ __device__ __attribute__((noinline)) void seg_attention(StepAttn g, const float*
     const StepKV nokv{nullptr, nullptr, nullptr, nullptr};
     // (the LayerNorm tail's row operands -- AdaLN(cond) alpha / beta of the CFG row, norm3's affine -- are requested inside,
     //  behind the K / V rows: an earlier phase touched their lines into the XCD's L2, attn_prefetch)
-    StepLnOps none;
+    StepLnOpsT<E> none;
 #pragma unroll
-    for (int i = 0; i < kSE / 256; ++i) none.al[i] = none.be[i] = none.ww[i] = none.bb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < E / 256; ++i) none.al[i] = none.be[i] = none.ww[i] = none.bb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     // system-scope q / K / V loads only where keys of the previous XCD are involved; the other chunks read this XCD's L2
-    if (halo) step_attention<17, 1, true>(g, nokv, none, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout, ab, w3, b3, tr);
-    else step_attention<16, 1, true>(g, nokv, none, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout, ab, w3, b3, tr);
+    if (halo) step_attention<17, 1, true, false, E>(g, nokv, none, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout, ab, w3, b3, tr);
+    else step_attention<16, 1, true, false, E>(g, nokv, none, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout, ab, w3, b3, tr);
 }
 
-template <int MB>  // row blocks per XCD: 3 Tseg / 16 (6 at T = 256)
+// Width: E = 512 (base, midi: 32 column tiles per q / k / v block -- one per workgroup of the XCD) or 256 (tiny.gin:65-83: 16 column
+// tiles -- the XCD's two row halves are dealt over the workgroups instead, workgroup = (column tile rank % 16, row half rank / 16),
+// and its eight waves split K eight ways; four heads on waves 0 .. 3 of an attention item).  MLP width 3 E, heads E / 64.
+// Length: nseg <= 8 segments of Tseg = 16 or 32 frames on XCDs 0 .. nseg - 1; the other XCDs leave after the census.
+template <int MB, int E>  // MB: row blocks per XCD, 3 Tseg / 16 (6 at T = 256)
 __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ unsigned s_rank, s_bad, s_ok;
-    constexpr int E = kSE, ME = kSME, KBE = E / 16, KBM = ME / 16, MBP = (MB + 2) / 3;  // MBP: row blocks of one CFG row
+    constexpr int ME = 3 * E, KBE = E / 16, KBM = ME / 16, MBP = (MB + 2) / 3;  // MBP: row blocks of one CFG row
+    constexpr int TPW = KBE;       // column tiles of a q / k / v block (and of a third of the MLP hidden layer): 32 or 16
+    constexpr int WGH = 32 / TPW;  // row halves dealt over the XCD's workgroups: 1 (every workgroup has all rows) or 2
+    static_assert(E == 512 || E == 256, "embed width");
     StepSync* st = a.sync;
     const unsigned xcc = step_xcc_id(), nb = gridDim.x, n = 32;
     const int tid = threadIdx.x, lane0 = tid & 63;
@@ -1752,6 +1766,8 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
     const int rank = __builtin_amdgcn_readfirstlane((int)s_rank), g = (int)xcc;
     unsigned round = 0, tslot = 0;
     unsigned long long* trace = a.trace ? a.trace + (size_t)blockIdx.x * 128 : nullptr;
+    const int nseg = a.nseg;
+    if (g >= nseg) return;  // (a clip of fewer than eight segments: nothing in the kernel crosses to or from this XCD)
 
     // this XCD's frames [f0, f0 + Tseg) of the three CFG rows: local token rows lm = branch * Tseg + (frame - f0)
     const int T = a.T, Tseg = a.Tseg, f0 = g * Tseg, Mg = 3 * Tseg;
@@ -1779,8 +1795,10 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
     // for it); the phase that needs them then loads them beside its activation row at L2 latency -- carrying them through the
     // GEMM phase in registers (32 per lane) made the register allocator spill inside the MFMA loops.
     auto row_warm = [&](const float* ab, const float* wv, const float* bv) {
-        const char* q = lane0 < 32 ? reinterpret_cast<const char*>(ab) + lane0 * 128
-                                   : (lane0 < 48 ? reinterpret_cast<const char*>(wv) + (lane0 - 32) * 128 : reinterpret_cast<const char*>(bv) + (lane0 - 48) * 128);
+        constexpr int LA = E / 16, LW = E / 32;  // 128-byte lines of the alpha | beta row and of a weight / bias row
+        const char* q = lane0 < LA ? reinterpret_cast<const char*>(ab) + lane0 * 128
+                                   : (lane0 < LA + LW ? reinterpret_cast<const char*>(wv) + (lane0 - LA) * 128
+                                                      : reinterpret_cast<const char*>(bv) + ((lane0 - LA - LW) & (LW - 1)) * 128);
         asm volatile("global_load_dword %0, %1, off" : "+v"(wsink) : "v"(q) : "memory");
     };
     const float* ln_ab0 = a.tc_ab;  // this wave's tcond AdaLN row (layer 0)
@@ -1810,10 +1828,11 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
         {
             const int kbp = a.Cp / 16;
             f32x4 acc[MBP];
-            const f32x4 bv = w < MBP ? *reinterpret_cast<const f32x4*>(a.patch_b + 16 * rank + 4 * (lane >> 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool pact = WGH == 1 || rank < TPW;  // (column tile `rank` of the E / 16)
+            const f32x4 bv = w < MBP && pact ? *reinterpret_cast<const f32x4*>(a.patch_b + 16 * rank + 4 * (lane >> 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ib = 0; ib < MBP; ++ib) acc[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (w < kbp) {
+            if (w < kbp && pact) {
                 const f32x4 wv = wact ? *reinterpret_cast<const f32x4*>(a.patch_wt + ((size_t)(rank * kbp + w) << 8) + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
                 f32x4 av[MBP];
 #pragma unroll
@@ -1828,7 +1847,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 ln_prefetch(0);
             }
             f32x4 o = seg_reduce<MBP>(acc, 0, red, w, lane);
-            if (w < MBP) {
+            if (w < MBP && pact) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r] + bv[r]);
                 *reinterpret_cast<f32x4*>(pat + ((size_t)(w * KBE + rank) << 8) + lane * 4) = o;
@@ -1845,24 +1864,30 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
             const unsigned seq = (unsigned)(i * a.L + l + 1);
             // ---- norm0 -> AdaLN(tcond) -> norm1: one wave per token row (three per workgroup); h as bf16 x 3 planes
             if (ln_mine) {
-                StepLnOps lnops;
+                StepLnOpsT<E> lnops;
                 step_ln_ops(lnops, ln_ab0 + (size_t)l * 2 * E, Lw.n1w, Lw.n1b, lane);
-                step_ln_row<1>(l == 0 ? pat_r : xres_r, l == 0 ? ln_lm % Tseg : ln_lm, xres, reinterpret_cast<float*>(hb3), ln_lm, lnops, lane);
+                step_ln_row<1, E>(l == 0 ? pat_r : xres_r, l == 0 ? ln_lm % Tseg : ln_lm, xres, reinterpret_cast<float*>(hb3), ln_lm, lnops, lane);
             }
             // (the reverse hazard -- the next XCD must have read this layer's keys of the PREVIOUS step before the qkv phase below
             //  overwrites the segment's last frames -- is checked one layer early, by a workgroup without an attention item during
             //  the attention phase: in this phase the memory round trip of the check sat on the critical path of a 2.2-us phase
             //  whenever the fabric was busy.  Only when every workgroup has an item does the check stay here)
-            if (nitems >= (int)n && rank == 0 && w == 7 && lane == 0 && g < 7 && i > 0)
+            if (nitems >= (int)n && rank == 0 && w == 7 && lane == 0 && g < nseg - 1 && i > 0)
                 seg_spin_sys(&st->att_seq[g + 1][0], seq - a.L, &st->fail[0]);
             // Geometry of the qkv / MLP-up GEMMs -- waves = (row half, K slice): with 96 rows both halves run side by side, each
-            // wave four k-blocks deep; column tiles rank, rank + 32, rank + 64 -- and of MLP-down: 96 rows 2-D, workgroup (row
-            // half, column-tile pair): half the activation bytes per workgroup of the all-rows x one-tile split; 48 rows:
-            // column tile rank, all rows
-            constexpr int NH = MB / 3, KS = 8 / NH, KQ = KBE / 2 / KS;  // row halves, K slices, 32-deep k-blocks per wave
-            const int rh = w / KS, ks = w - rh * KS;
-            constexpr int NTD = MB == 6 ? 2 : 1, KD = KBM / 16;
-            const int rb0d = MB == 6 ? 3 * (rank & 1) : 0, tile0d = MB == 6 ? 2 * (rank >> 1) : rank;
+            // wave four k-blocks deep; column tiles rank, rank + 32, rank + 64 (E = 256: the workgroup has ONE row half, rank / 16,
+            // its waves are eight K slices one k-block deep, column tiles rank % 16 + 16 j; with 48 rows the workgroups of
+            // the second half have nothing) -- and of MLP-down: 96 rows 2-D, workgroup (row half, NTD column tiles): half the
+            // activation bytes per workgroup of the all-rows x one-tile split; 48 rows: column tile rank, all rows
+            constexpr int NH = MB / 3;                     // row halves of the XCD
+            constexpr int NHW = WGH == 1 ? NH : 1;         // ... of a workgroup
+            constexpr int KS = 8 / NHW, KQ = KBE / 2 / KS; // K slices, 32-deep k-blocks per wave
+            const int ct = WGH == 1 ? rank : rank % TPW, h0 = WGH == 1 ? 0 : rank / TPW;  // first column tile, first row half
+            const bool gact = WGH == 1 || h0 < NH;         // (qkv / MLP-up: this workgroup has tiles -- a constant but for E = 256 at 48 rows)
+            const int rh = w / KS + h0, ks = w % KS;
+            constexpr int NTD = NH * KBE >= 32 ? NH * KBE / 32 : 1, KD = KBM / 16;
+            const int rb0d = NH == 2 ? 3 * (rank & 1) : 0, tile0d = NH == 2 ? NTD * (rank >> 1) : rank;
+            const bool dact = NH * KBE >= 32 || tile0d < KBE;  // (MLP-down: this workgroup has tiles -- the same)
             SegBuf<3, 3> sbq;
             {
                 const __amdgpu_buffer_rsrc_t Wq = step_rsrc(Lww.qkv_wt);
@@ -1874,16 +1899,16 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 // wave finishes -- column tiles rank (q) and rank + 32 (k) with rank % 4 < 2 -- at the rows' absolute frames: the cos /
                 // sin pairs are requested behind the last operand requests of the MFMA loop and land long before the epilogue
                 float2 rcs[3][2];
-                const bool roped = (rank & 3) < 2;
+                const bool roped = (ct & 3) < 2;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) rcs[q][0] = make_float2(1.f, 1.f), rcs[q][1] = make_float2(0.f, 0.f);
                 auto rope_req = [&] {
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
                         const int p = w + 8 * q, hh = p / 9, pp = p - 9 * hh;
-                        const int lm = min(16 * (3 * hh + pp % 3) + (lane & 15), Mg - 1), tl = lm % Tseg;
-                        if (roped && p < 9 * NH && pp / 3 < 2) {
-                            const int o = (f0 + tl) * 16 + 8 * (rank & 3) + 2 * (lane >> 4);
+                        const int lm = min(16 * (3 * (hh + h0) + pp % 3) + (lane & 15), Mg - 1), tl = lm % Tseg;
+                        if (roped && gact && p < 9 * NHW && pp / 3 < 2) {
+                            const int o = (f0 + tl) * 16 + 8 * (ct & 3) + 2 * (lane >> 4);
                             rcs[q][0] = *reinterpret_cast<const float2*>(a.rope_cos + o);
                             rcs[q][1] = *reinterpret_cast<const float2*>(a.rope_sin + o);
                         }
@@ -1891,13 +1916,19 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 };
                 if (trace && tid == 0) trace[64] = wall_clock64();
                 __builtin_amdgcn_sched_barrier(0);
-                seg_load_a<3, 3>(sbq, 0, hb3_r, E / 32, 3 * rh, KQ * ks, lane);
-                seg_load_w<3, 3>(sbq, 0, Wq, KBE, rank, 32, KQ * ks, lane);
-                seg_run<3, 3, KQ, SEG_DIAG>(acc, sbq, hb3_r, E / 32, 3 * rh, Wq, KBE, rank, 32, KQ * ks, lane,
-                                            [&] {
-                                                if (rank < nitems) attn_prefetch(l, rank);
-                                                rope_req();
-                                            });
+                auto qkv_next = [&] {
+                    if (rank < nitems) attn_prefetch(l, rank);
+                    rope_req();
+                };
+                if (gact) {
+                    seg_load_a<3, 3>(sbq, 0, hb3_r, E / 32, 3 * rh, KQ * ks, lane);
+                    seg_load_w<3, 3>(sbq, 0, Wq, KBE, ct, TPW, KQ * ks, lane);
+                    seg_run<3, 3, KQ, SEG_DIAG>(acc, sbq, hb3_r, E / 32, 3 * rh, Wq, KBE, ct, TPW, KQ * ks, lane, qkv_next);
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 9; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    qkv_next();
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (trace) {  // (every wave drains its MFMAs first: the stamp is the end of wave 0's arithmetic)
                     asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[8]));
@@ -1915,7 +1946,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const int p = w + 8 * q, hh = p / 9, pp = p - 9 * hh;
-                    os[q] = p < 9 * NH ? seg_sum<KS>(red + (size_t)hh * KS * 9 * 256, 9, pp, lane) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    os[q] = p < 9 * NHW ? seg_sum<KS>(red + (size_t)hh * KS * 9 * 256, 9, pp, lane) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {  // (unconditional: tiles without RoPE carry cos = 1, sin = 0 -- no branch between the sums and the stores)
@@ -1926,10 +1957,10 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const int p = w + 8 * q, hh = p / 9, pp = p - 9 * hh, j = pp / 3;
-                    const int lm = 16 * (3 * hh + pp % 3) + (lane & 15), br = lm / Tseg, tl = lm - br * Tseg;
-                    if (p < 9 * NH && lm < Mg)
+                    const int lm = 16 * (3 * (hh + h0) + pp % 3) + (lane & 15), br = lm / Tseg, tl = lm - br * Tseg;
+                    if (gact && p < 9 * NHW && lm < Mg)
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, os[q]), qkv_r,
-                                                               (unsigned)(((br * T + f0 + tl) * 3 * E + 16 * (rank + 32 * j) + 4 * (lane >> 4)) * 4), 0, 17);
+                                                               (unsigned)(((br * T + f0 + tl) * 3 * E + 16 * (ct + TPW * j) + 4 * (lane >> 4)) * 4), 0, 17);
                 }
                 if (trace && tid == 0) trace[67] = wall_clock64();
             }
@@ -1938,7 +1969,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
             //      starts in front of the segment waits for the previous XCD's rows
             // (the last workgroup has no item: before the NEXT qkv phase -- sequence number seq + 1, this layer's successor or layer 0
             //  of the next step -- overwrites its rows of the previous step, the next XCD must have read them: att_seq >= seq + 1 - L)
-            if (nitems < (int)n && rank == (int)n - 1 && w == 0 && lane == 0 && g < 7 && seq + 1 > (unsigned)a.L)
+            if (nitems < (int)n && rank == (int)n - 1 && w == 0 && lane == 0 && g < nseg - 1 && seq + 1 > (unsigned)a.L)
                 seg_spin_sys(&st->att_seq[g + 1][0], seq + 1 - a.L, &st->fail[0]);
             for (int it = rank; it < nitems; it += (int)n) {
                 const int br = it / cps, ch = it - br * cps, i0f = f0 + ch * a.cs;
@@ -1949,35 +1980,43 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                     __syncthreads();
                     if (!s_ok) return;
                 }
-                seg_attention(StepAttn{T, a.cs, a.W, 0, a.nkmax, a.rope_cos, a.rope_sin, Lw.qkv}, cond_ab + (size_t)br * a.cond_ld + (size_t)l * 2 * E,
+                seg_attention<E>(StepAttn{T, a.cs, a.W, 0, a.nkmax, a.rope_cos, a.rope_sin, Lw.qkv}, cond_ab + (size_t)br * a.cond_ld + (size_t)l * 2 * E,
                               Lw.n3w, Lw.n3b, br, br * Tseg - f0, i0f / a.cs, halo, smem, kvl, xres, reinterpret_cast<float*>(hb3), trace);
             }
-            SegBuf<3, kSNTU> sbu;
+            constexpr int NTU = KBM / TPW;  // MLP-up column tiles of a workgroup (3: the hidden layer is 3 E wide)
+            SegBuf<3, NTU> sbu;
             {
                 const __amdgpu_buffer_rsrc_t Wu = step_rsrc(Lww.mlp0_wt);
                 if (!end_phase(true, &st->att_seq[g][0], seq)) return;
                 // ---- MLP up + GELU: column tiles rank + 32 j; the hidden layer as bf16 x 3 planes
-                f32x4 acc[3 * kSNTU];
-                seg_load_a<3, kSNTU>(sbu, 0, hb3_r, E / 32, 3 * rh, KQ * ks, lane);
-                seg_load_w<3, kSNTU>(sbu, 0, Wu, KBE, rank, 32, KQ * ks, lane);
+                f32x4 acc[3 * NTU];
+                if (gact) {
+                    seg_load_a<3, NTU>(sbu, 0, hb3_r, E / 32, 3 * rh, KQ * ks, lane);
+                    seg_load_w<3, NTU>(sbu, 0, Wu, KBE, ct, TPW, KQ * ks, lane);
+                }
                 // (epilogue operands before the GEMM: wave w finishes tiles p = w, w + 8, w + 16)
                 f32x4 bvs[3];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    const int p = w + 8 * q, pp = p % (3 * kSNTU);
-                    bvs[q] = p < 3 * kSNTU * NH ? *reinterpret_cast<const f32x4*>(Lw.mlp0_b + 16 * (rank + 32 * (pp / 3)) + 4 * (lane >> 4))
-                                                : f32x4{0.f, 0.f, 0.f, 0.f};
+                    const int p = w + 8 * q, pp = p % (3 * NTU);
+                    bvs[q] = gact && p < 3 * NTU * NHW ? *reinterpret_cast<const f32x4*>(Lw.mlp0_b + 16 * (ct + TPW * (pp / 3)) + 4 * (lane >> 4))
+                                                       : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                seg_run<3, kSNTU, KQ, SEG_DIAG>(acc, sbu, hb3_r, E / 32, 3 * rh, Wu, KBE, rank, 32, KQ * ks, lane, [] {});
-                seg_partials<3 * kSNTU>(acc, red, w, lane);
+                if (gact) {
+                    seg_run<3, NTU, KQ, SEG_DIAG>(acc, sbu, hb3_r, E / 32, 3 * rh, Wu, KBE, ct, TPW, KQ * ks, lane, [] {});
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 3 * NTU; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                seg_partials<3 * NTU>(acc, red, w, lane);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const int p = w + 8 * q;
-                    if (p >= 3 * kSNTU * NH) break;
-                    const int hh = p / (3 * kSNTU), pp = p - 3 * kSNTU * hh, j = pp / 3, ib = pp - 3 * j, tile = rank + 32 * j;
+                    if (p >= 3 * NTU * NHW || !gact) break;
+                    const int hh = p / (3 * NTU), pp = p - 3 * NTU * hh, j = pp / 3, ib = pp - 3 * j, tile = ct + TPW * j;
                     const f32x4 bv = bvs[q];
-                    const f32x4 o = seg_sum<KS>(red + (size_t)hh * KS * 3 * kSNTU * 256, 3 * kSNTU, pp, lane);
-                    p32_store4(mlp3, 16 * (3 * hh + ib) + (lane & 15), 16 * tile + 4 * (lane >> 4), ME / 32, gelu_erf(o[0] + bv[0]),
+                    const f32x4 o = seg_sum<KS>(red + (size_t)hh * KS * 3 * NTU * 256, 3 * NTU, pp, lane);
+                    p32_store4(mlp3, 16 * (3 * (hh + h0) + ib) + (lane & 15), 16 * tile + 4 * (lane >> 4), ME / 32, gelu_erf(o[0] + bv[0]),
                                gelu_erf(o[1] + bv[1]), gelu_erf(o[2] + bv[2]), gelu_erf(o[3] + bv[3]));
                 }
             }
@@ -1987,21 +2026,29 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 if (!end_phase(true)) return;
                 // ---- MLP down + residual
                 f32x4 acc[3 * NTD], bv[1], rv[1];
-                seg_load_a<3, NTD>(sbd, 0, mlp3_r, ME / 32, rb0d, KD * w, lane);
-                seg_load_w<3, NTD>(sbd, 0, Wd, KBM, tile0d, 1, KD * w, lane);
+                if (dact) {
+                    seg_load_a<3, NTD>(sbd, 0, mlp3_r, ME / 32, rb0d, KD * w, lane);
+                    seg_load_w<3, NTD>(sbd, 0, Wd, KBM, tile0d, 1, KD * w, lane);
+                }
                 // (wave w < 3 NTD finishes column tile w / 3, row block w % 3: one exchange of all partials, six finishing waves at
                 //  96 rows -- not a round of the exchange per column tile with three)
                 const int jd = w / 3, id = w - 3 * jd;
                 const unsigned offd = (unsigned)((((rb0d + id) * KBE + tile0d + jd) << 8) + lane * 4);
                 bv[0] = rv[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (w < 3 * NTD) {
+                if (w < 3 * NTD && dact) {
                     bv[0] = *reinterpret_cast<const f32x4*>(Lw.mlp2_b + 16 * (tile0d + jd) + 4 * (lane >> 4));
                     rv[0] = ld_l2(xres_r, offd);
                 }
-                seg_run<3, NTD, KD, SEG_DIAG>(acc, sbd, mlp3_r, ME / 32, rb0d, Wd, KBM, tile0d, 1, KD * w, lane,
-                                              [&] { if (l + 1 < a.L) ln_prefetch(l + 1); });
+                auto down_next = [&] { if (l + 1 < a.L) ln_prefetch(l + 1); };
+                if (dact) {
+                    seg_run<3, NTD, KD, SEG_DIAG>(acc, sbd, mlp3_r, ME / 32, rb0d, Wd, KBM, tile0d, 1, KD * w, lane, down_next);
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 3 * NTD; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    down_next();
+                }
                 seg_partials<3 * NTD>(acc, red, w, lane);
-                if (w < 3 * NTD) {
+                if (w < 3 * NTD && dact) {
                     f32x4 o = seg_sum<8>(red, 3 * NTD, w, lane);  // (acc index = column tile x 3 + row block = w)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = o[r] + bv[0][r] + rv[0][r];
@@ -2015,7 +2062,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
         if (rank < (a.C / 16) * MBP) {
             const int tile = rank % (a.C / 16), fb = rank / (a.C / 16);
             f32x4 acc[3];
-            step_gemm<3, 1, kSKBQ, false>(acc, xres_r, KBE, a.out_wt, KBE, tile, kSKBQ * w, lane, true, wact, [] {}, 0, fb, MBP);
+            step_gemm<3, 1, KBE / 8, false>(acc, xres_r, KBE, a.out_wt, KBE, tile, KBE / 8 * w, lane, true, wact, [] {}, 0, fb, MBP);
             const f32x4 o = seg_reduce<3>(acc, 0, red, w, lane);
             float* const outt = red + 8 * 3 * 256;  // [3 branches x 16 frames][16 columns]
             if (w < 3) *reinterpret_cast<f32x4*>(outt + (16 * w + (lane & 15)) * 16 + 4 * (lane >> 4)) = o;
@@ -2816,8 +2863,10 @@ __global__ __launch_bounds__(256) void tile16_kernel(const float* __restrict__ W
 template __global__ void stream_step_kernel<1>(StepArgs);
 template __global__ void stream_step_kernel<2>(StepArgs);
 template __global__ void stream_step_kernel<3>(StepArgs);
-template __global__ void sample_seg_kernel<3>(StepArgs);
-template __global__ void sample_seg_kernel<6>(StepArgs);
+template __global__ void sample_seg_kernel<3, 512>(StepArgs);
+template __global__ void sample_seg_kernel<6, 512>(StepArgs);
+template __global__ void sample_seg_kernel<3, 256>(StepArgs);
+template __global__ void sample_seg_kernel<6, 256>(StepArgs);
 
 }  // namespace
 }  // namespace after
@@ -3587,8 +3636,19 @@ bool step_persist_ok(const after_denoiser* h, int B, int T, int nb_steps) {
 // The geometry a persistent sampler can take at all (call-independent part of step_persist_ok / sample_seg_ok)
 bool persist_geometry_ok(const after_denoiser* h) {
     const bool wide = h->W < 0 || !h->cfg.causal;
-    return h->E == kSE && h->ME == kSME && h->H == kSH && h->L <= 8 && !wide && h->Cp == h->C && h->C % 16 == 0 &&
+    return (h->E == kSE || h->E == 256) && h->ME == 3 * h->E && h->H == h->E / 64 && h->L <= 8 && !wide && h->Cp == h->C && h->C % 16 == 0 &&
            h->C / 16 <= 8 && h->n_cus == 256;
+}
+
+// The offline segment sampler's split of a clip: nseg <= 8 segments of Tseg = 16 or 32 frames (whole attention chunks, the window's
+// left context inside ONE neighbour segment); the shorter segment first -- more XCDs at work
+bool seg_split(const after_denoiser* h, int T, int* Tseg, int* nseg) {
+    for (int ts = 16; ts <= 32; ts += 16)
+        if (T % ts == 0 && T / ts <= 8 && ts % h->cs == 0 && h->W - 1 <= ts) {
+            *Tseg = ts, *nseg = T / ts;
+            return true;
+        }
+    return false;
 }
 
 // One persistent kernel in flight per device and process.  The samplers spin on XCD-local barriers, i.e. they need all 256
@@ -3715,7 +3775,7 @@ int persist_prepare(after_denoiser* h, bool offline) {
         h->seg_qkv = q, h->seg_act3 = a3;
     }
     // the clip-per-XCD sampler's slices: for handles provisioned for a batch of clips of moderate length
-    if (offline && h->persist_clip && !h->clip_act && h->max_rows >= 3 * h->clip_min_b && h->max_T <= kClipMaxT) {
+    if (offline && h->persist_clip && !h->clip_act && h->E == kSE && h->max_rows >= 3 * h->clip_min_b && h->max_T <= kClipMaxT) {
         const size_t rows = (size_t)cdiv(3 * h->max_T, kClipRowTile) * kClipRowTile, prow = (size_t)cdiv(h->max_T, 16) * 16;
         const size_t nf = 8 * (prow * E + rows * E + rows * 3 * E), n3 = 8 * rows * 3 * (E + ME);
         float* f = nullptr;
@@ -3735,7 +3795,8 @@ int persist_prepare(after_denoiser* h, bool offline) {
     {
         AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sample_clip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClipLds));
         const size_t lds_seg = ((size_t)kSRedFloats(2) + 8 * 2 * kAttnKeyBlock * 64) * sizeof(float);
-        const void* fns[] = {reinterpret_cast<const void*>(sample_seg_kernel<6>), reinterpret_cast<const void*>(sample_seg_kernel<3>),
+        const void* fns[] = {reinterpret_cast<const void*>(sample_seg_kernel<6, 512>), reinterpret_cast<const void*>(sample_seg_kernel<3, 512>),
+                             reinterpret_cast<const void*>(sample_seg_kernel<6, 256>), reinterpret_cast<const void*>(sample_seg_kernel<3, 256>),
                              reinterpret_cast<const void*>(persist_census_kernel)};
         for (const void* fn : fns) AFTER_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_seg));
         const void* sf[] = {reinterpret_cast<const void*>(stream_step_kernel<1>), reinterpret_cast<const void*>(stream_step_kernel<2>),
@@ -3880,21 +3941,21 @@ int sample_persistent(after_denoiser* h, hipStream_t s, const float* x0, float* 
     return persist_published(h, s, h->persist_check == 1);
 }
 
-// RectifiedFlow.sample for ONE clip as one persistent launch (sample_seg_kernel): eligible for the shipped width (embed
-// 512 / mlp x 3 / eight heads: the kernel's tile counts), finite causal window that fits one segment, T = 128 or 256 frames
-// (eight segments of 16 / 32 frames, whole attention chunks), <= 8 layers, 256 CUs, no streaming caches.
+// RectifiedFlow.sample for ONE clip as one persistent launch (sample_seg_kernel): eligible for the shipped widths (embed
+// 512 or 256 / mlp x 3 / heads of 64: the kernel's tile counts), finite causal window that fits one segment, T = up to eight
+// segments of 16 or 32 frames (T = 16 .. 128 in steps of 16, 160, 192, 224, 256; whole attention chunks), <= 8 layers, 256 CUs,
+// no streaming caches.
 bool sample_seg_ok(const after_denoiser* h, int B, int T, int nb_steps) {
-    const bool wide = h->W < 0 || !h->cfg.causal;
-    const int Tseg = T / 8;
+    int Tseg = 0, nseg = 0;
     return h->persist_offline && h->step_ready && h->seg_qkv && h->cache == 0 && B == 1 && (!h->timer.enabled || h->timer_kernel == 3) && !h->use_graph &&
-           h->x6 != 0 && h->E == kSE && h->ME == kSME && h->H == kSH && h->L <= 8 && !wide && h->Cp == h->C && h->C % 16 == 0 &&
-           h->C / 16 <= 4 && h->n_cus == 256 && T % 8 == 0 && (Tseg == 16 || Tseg == 32) && Tseg % h->cs == 0 &&
-           h->W - 1 <= Tseg && nb_steps >= 1 && T <= h->max_T &&
-           ((size_t)h->cs * (h->E + 4) + (size_t)kSH * 2 * (h->W - 1 + h->cs) * 16) <= 7168;
+           h->x6 != 0 && persist_geometry_ok(h) && h->C / 16 <= 4 && seg_split(h, T, &Tseg, &nseg) && nb_steps >= 1 && T <= h->max_T &&
+           ((size_t)h->cs * (h->E + 4) + (size_t)h->H * 2 * (h->W - 1 + h->cs) * 16) <= 7168;
 }
 
 int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, int T, int nb_steps) {
-    const int E = h->E, L = h->L, Tseg = T / 8, MB = 3 * Tseg / 16;
+    int Tseg = 0, nseg = 0;
+    if (!seg_split(h, T, &Tseg, &nseg)) return AFTER_E_INVALID;
+    const int E = h->E, L = h->L, MB = 3 * Tseg / 16;
     const int nkmax = h->W - 1 + h->cs > h->cs ? h->W - 1 + h->cs : h->cs;
     const size_t lds = ((size_t)kSRedFloats(2) + 8 * 2 * kAttnKeyBlock * 64) * sizeof(float);
     {
@@ -3907,7 +3968,7 @@ int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, in
     StepArgs a;
     memset(&a, 0, sizeof(a));
     a.rows = 3, a.B = 1, a.T = T, a.C = h->C, a.Cp = h->Cp, a.L = L;
-    a.cs = h->cs, a.W = h->W, a.nkmax = nkmax, a.cache = 0, a.cache_rows = 0, a.cpg = 1, a.Tseg = Tseg;
+    a.cs = h->cs, a.W = h->W, a.nkmax = nkmax, a.cache = 0, a.cache_rows = 0, a.cpg = 1, a.Tseg = Tseg, a.nseg = nseg;
     a.nsteps = nb_steps, a.cache_steps = 0;
     a.xt = h->xt;
     a.pat_t = h->step_act, a.xres_t = h->step_act + slice, a.h_t = h->step_act + 2 * slice, a.mlp_t = h->step_act + 3 * slice;
@@ -3940,8 +4001,13 @@ int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, in
     if (timed) h->timer.begin(s);
     {
         PersistLaunch guard(h->dev, s);
-        if (MB == 6) hipLaunchKernelGGL(sample_seg_kernel<6>, dim3(h->n_cus), dim3(512), lds, s, a);
-        else hipLaunchKernelGGL(sample_seg_kernel<3>, dim3(h->n_cus), dim3(512), lds, s, a);
+        if (E == kSE) {
+            if (MB == 6) hipLaunchKernelGGL((sample_seg_kernel<6, 512>), dim3(h->n_cus), dim3(512), lds, s, a);
+            else hipLaunchKernelGGL((sample_seg_kernel<3, 512>), dim3(h->n_cus), dim3(512), lds, s, a);
+        } else {
+            if (MB == 6) hipLaunchKernelGGL((sample_seg_kernel<6, 256>), dim3(h->n_cus), dim3(512), lds, s, a);
+            else hipLaunchKernelGGL((sample_seg_kernel<3, 256>), dim3(h->n_cus), dim3(512), lds, s, a);
+        }
     }
     AFTER_HIP_CHECK(hipGetLastError());
     if (timed) {

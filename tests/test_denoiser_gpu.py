@@ -42,10 +42,11 @@ def test_denoiser_golden(case, hip_device):
     assert max_abs(model.model_forward(x, t03, cond, tc, 1.0, 3.0).cpu(), fx.t("mf_1_3")) < 2e-4
     for n in fx.meta["steps"]:
         got = model.sample(x, cond, tc, n, 2.0, 1.0).cpu()
-        if case == "denoiser_base" and model.net.gemm_path()[0] != 0:
-            # the one full-length (50-step) comparison with the reference's own output runs on the path bench.py times: the
-            # persistent one-clip kernel (a placement refusal on this box must not turn it into a launch-path test silently)
-            assert model.net.sample_path() == 1, "the 50-step base golden did not run on the persistent sampler"
+        if case in ("denoiser_base", "denoiser_tiny") and model.net.gemm_path()[0] != 0:
+            # the full-length (50-step) comparisons with the reference's own output run on the path bench.py times: the
+            # persistent one-clip kernel, at both shipped widths (a placement refusal on this box must not turn them into
+            # launch-path tests silently)
+            assert model.net.sample_path() == 1, f"the {n}-step {case} golden did not run on the persistent sampler"
         want = fx.t(f"sample_{n}_2_1")
         assert max_abs(got, want) < 1e-4, (n, max_abs(got, want))
         assert rel_l2(got, want) < 2e-5

@@ -66,23 +66,62 @@ def test_midi_cfg_arrangement_on_the_persistent_sampler(hip_device):
         assert torch.isfinite(got).all() and max_abs(got, ref) < 5e-5, (mode, max_abs(got, ref))
 
 
-def test_geometries_the_kernel_does_not_take_run_by_launches(base, hip_device):
-    """Explicit refusals: another width (tiny: embed 256 -- the kernel's tile counts are the base width's), clip lengths other than
-    128 / 256 frames.  after_sample serves them by launches, silently (the persistent sampler is an acceleration, not a capability),
-    and the results are the launch path's, held to the oracle."""
-    tiny, tcfg, _ = pipeline.build_models("tiny", "baseAE", hip_device, seed=3)
+@pytest.fixture(scope="module")
+def tiny(hip_device):
+    model, dcfg, _ = pipeline.build_models("tiny", "baseAE", hip_device, seed=3)
+    return model, dcfg
+
+
+def _persist_vs_launch_vs_oracle(model, dcfg, T, steps, hip_device, seed):
+    net = model.net
+    g = torch.Generator().manual_seed(seed)
+    x0 = torch.randn(1, 64, T, generator=g)
+    cond = torch.randn(1, 6, generator=g)
+    tc = torch.randn(1, 12, T, generator=g)
+    args = (x0.to(hip_device), cond.to(hip_device), tc.to(hip_device), steps, 2.0, 1.0, -4.0)
+    net.set_sample_persist(False)
+    ref = net.cfg_sample(*args).cpu()
+    assert not net.sample_persist()
+    net.set_sample_persist(True)
+    got = net.cfg_sample(*args).cpu()
+    assert net.sample_persist(), f"the persistent offline sampler refused T = {T}"
+    assert torch.equal(got, net.cfg_sample(*args).cpu()), "not reproducible"
+    assert max_abs(got, ref) < 5e-5, max_abs(got, ref)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    want = oracle.sample(sd, dcfg["net"], x0, cond, tc, steps, 2.0, 1.0)
+    assert max_abs(got, want) < 1e-4 and rel_l2(got, want) < 2e-5, (T, max_abs(got, want), rel_l2(got, want))
+
+
+@pytest.mark.parametrize("T,steps", [(256, 6), (128, 4), (192, 3), (64, 3)])
+def test_tiny_width_on_the_persistent_sampler(T, steps, tiny, hip_device):
+    """tiny.gin:65-83 (embed 256, four heads, mlp 768): sample_seg_kernel<., 256> -- the XCD's two row halves dealt over its
+    workgroups, four heads on four waves of an attention item."""
+    model, dcfg = tiny
+    _persist_vs_launch_vs_oracle(model, dcfg, T, steps, hip_device, 300 + T)
+
+
+@pytest.mark.parametrize("T", [16, 32, 48, 64, 96, 160, 192, 224])
+def test_clip_lengths_of_fewer_than_eight_segments(T, base, hip_device):
+    """nseg < 8 segments of 16 or 32 frames: XCDs nseg .. 7 leave the kernel after the census; the last segment's XCD has no
+    right neighbour to wait for."""
+    model, dcfg = base
+    _persist_vs_launch_vs_oracle(model, dcfg, T, 3, hip_device, 500 + T)
+
+
+def test_geometries_the_kernel_does_not_take_run_by_launches(base, tiny, hip_device):
+    """Explicit refusals: clip lengths that are not up to eight segments of 16 / 32 frames (512: longer; 40: no whole 16-frame
+    segment; 144 = nine segments of 16 and not a multiple of 32).  after_sample serves them by launches, silently (the persistent
+    sampler is an acceleration, not a capability), and the results are the launch path's, held to the oracle."""
     g = torch.Generator().manual_seed(5)
-    x0, cond, tc = torch.randn(1, 64, 256, generator=g), torch.randn(1, 6, generator=g), torch.randn(1, 12, 256, generator=g)
-    tiny.net.set_sample_persist(True)
-    got = tiny.net.cfg_sample(x0.to(hip_device), cond.to(hip_device), tc.to(hip_device), 3, 2.0, 1.0, -4.0).cpu()
-    assert not tiny.net.sample_persist()
-    sd = {k: v.detach().cpu() for k, v in tiny.net.state_dict().items()}
-    want = oracle.sample(sd, tcfg["net"], x0, cond, tc, 3, 2.0, 1.0)
-    assert max_abs(got, want) < 1e-4, max_abs(got, want)
-    model, _ = base
-    model.net.set_sample_persist(True)
-    for T in (64, 192, 512):
-        xt = torch.randn(1, 64, T, generator=g).to(hip_device)
-        out = model.net.cfg_sample(xt, cond.to(hip_device), torch.randn(1, 12, T, generator=g).to(hip_device), 2, 2.0, 1.0, -4.0)
-        assert not model.net.sample_persist(), T
-        assert torch.isfinite(out).all()
+    cond = torch.randn(1, 6, generator=g)
+    for model, dcfg in (base, tiny):
+        model.net.set_sample_persist(True)
+        for T in (40, 144, 512):
+            x0, tc = torch.randn(1, 64, T, generator=g), torch.randn(1, 12, T, generator=g)
+            got = model.net.cfg_sample(x0.to(hip_device), cond.to(hip_device), tc.to(hip_device), 2, 2.0, 1.0, -4.0).cpu()
+            assert not model.net.sample_persist(), T
+            if T == 40:
+                sd = {k: v.detach().cpu() for k, v in model.net.state_dict().items()}
+                want = oracle.sample(sd, dcfg["net"], x0, cond, tc, 2, 2.0, 1.0)
+                assert max_abs(got, want) < 1e-4, max_abs(got, want)
+            assert torch.isfinite(got).all()
