@@ -2132,6 +2132,7 @@ static_assert(kClipLds >= (8192 + 8 * 2 * kAttnKeyBlock * 64) * sizeof(float), "
 
 struct ClipLayer {
     const unsigned short *qkv_w3, *mlp0_w3, *mlp2_w3;  // x6 planes of the three big Linears (after_denoiser_create)
+    const unsigned short* qkv_w3h;  // qkv with its output columns regrouped by HEAD: 192-column tile h = q_h | k_h | v_h (persist_prepare)
     const float *mlp0_b, *mlp2_b, *n1w, *n1b, *n3w, *n3b;
 };
 
@@ -2143,6 +2144,8 @@ struct ClipArgs {
     float* xt;                // token-major latents [B * T][Cp]: a step's input, rewritten by its tail
     float *pat_t, *xres_t;    // per-XCD slices: patchify output [8][pat_rows][E] (16 x 16 tiles), residual stream [8][rows_pad][E] (row-major)
     float* qkv;               // [8][rows_pad][3E] row-major, RoPE applied to q and k
+    float* halo;              // [8][rows_pad / 192][8 heads][16 rows][k 64 | v 64]: the last 16 rows of every (row tile, head) tile
+    int fuse;                 // qkv tiles are heads and run their own attention (clip_tile_attention); else qkv rows + attention items
     unsigned short *h3, *mlp3;  // [8] x6 planes of [rows_pad][E] / [rows_pad][ME]
     const float *patch_wt, *patch_b, *out_wt, *out_b;
     const float* tc_ab;
@@ -2170,6 +2173,12 @@ struct ClipGemm {
     int T;
     float* xres;            // MLP-down: residual in / out, row-major [M][N]
     unsigned long long* tr; // AFTER_STEP_TRACE stamps of the workgroup's first tile: [64] entry, [65] (unused), [66] K loop done, [67] epilogue issued
+    // EPI 2 (qkv tile = head, attention in the epilogue: clip_tile_attention)
+    float* halo;            // this XCD's [row tile][head][16][128]
+    unsigned* hflag;        // this XCD's [32]: per workgroup, the last sequence number whose halo rows it has published (+ 1)
+    unsigned* fail;         // a spin that gave up raises it
+    unsigned sq0;           // sequence number of this call's first round of tiles
+    int cs, W, Mg;          // attention chunk, window, valid token rows (3 T)
 };
 
 // role dispatch of the loader-wave ring (wave-uniform switch: every role has its own instruction stream)
@@ -2187,12 +2196,174 @@ struct ClipGemm {
     }
 #define CLIP_ROLE(wid_, CALL) CLIP_ROLE_N(wid_, kClipLoaders, CALL)
 
+// The qkv tile of ONE HEAD (192 token rows x [q 64 | k 64 | v 64], RoPE applied, in LDS) attends in place: attention + residual
+// for the tile's rows without a qkv round trip through memory (transformerv2.py:190-236; mask: combined_sliding_chunkwise_mask,
+// :62-96).  LDS image: row r at 192 r floats, its 48 16-byte chunks XOR-permuted with r & 7 (the fragment reads below take 16 rows
+// of one chunk column: two-way instead of sixteen-way bank conflicts, no padding).  A 16-query block's keys are its own 16 rows
+// and the 16 in front of them (W - 1 <= 16, whole chunks inside a block: 16 % cs == 0, T % 16 == 0); the rows in front of the
+// TILE belong to the workgroup with the previous row tile of the same head: every workgroup writes the k | v of its last 16 rows
+// to `halo_out` and publishes a sequence number, the wave with block 0 takes its first key tile from `halo_in` once the
+// neighbour's number is there (XCD-local: agent-scope word, sc1 loads; it runs block 0 last).  Arithmetic of
+// clip_attention_pair: S^T = K Q^T and P V as fp32 MFMAs on operands read in fragment order, softmax on four values per lane.
+// Output: xres[row][head] += attention -- the LayerNorm tail is the next phase's (clip_ln_rows on the cond operands).
+// (out of line, every argument by value and re-uniformed: see seg_attention)
+typedef __attribute__((address_space(3))) const float* lds_cf32_t;
+__device__ __forceinline__ f32x4 tile_ld4(unsigned tile, int row, int chunk) {
+    return *reinterpret_cast<__attribute__((address_space(3))) const f32x4*>((uintptr_t)(tile + (unsigned)(row * 768 + ((chunk ^ (row & 7)) << 4))));
+}
+__device__ __attribute__((noinline)) void clip_tile_attention(int T, int cs, int W, int Mg, int R0, int head, unsigned tile, float* halo_out,
+                                                              const float* halo_in, unsigned* flag_mine, unsigned pub,
+                                                              unsigned* flag_in, unsigned want, unsigned* fail, float* xres,
+                                                              const float* rope_cos, const float* rope_sin) {
+    T = seg_uniform(T), cs = seg_uniform(cs), W = seg_uniform(W), Mg = seg_uniform(Mg), R0 = seg_uniform(R0), head = seg_uniform(head);
+    tile = (unsigned)seg_uniform((int)tile), pub = (unsigned)seg_uniform((int)pub), want = (unsigned)seg_uniform((int)want);
+    halo_out = seg_uniform(halo_out), halo_in = seg_uniform(halo_in), flag_mine = seg_uniform(flag_mine), flag_in = seg_uniform(flag_in);
+    fail = seg_uniform(fail), xres = seg_uniform(xres), rope_cos = seg_uniform(rope_cos), rope_sin = seg_uniform(rope_sin);
+    constexpr int E = kSE;
+    const int tid = threadIdx.x, lane = tid & 63, hw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, gq = lane >> 4;
+    if (hw == 7) {  // the tile's last 16 rows, k | v as they stand (32 chunks a row), by the wave with the least to do; then the sequence number
+        const __amdgpu_buffer_rsrc_t ho = step_rsrc(halo_out);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int p = 64 * q + lane, r = 176 + (p >> 5), ch = 16 + (p & 31);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tile_ld4(tile, r, ch)), ho, (unsigned)(((p >> 5) * 128 + 4 * (p & 31)) * 4), 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(flag_mine, pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const __amdgpu_buffer_rsrc_t xr = step_rsrc(xres), hin = step_rsrc(halo_in), cos_r = step_rsrc(rope_cos), sin_r = step_rsrc(rope_sin);
+    // Per 16-query block, from memory: the residual's 16 bytes of query 4 gq + i (dims 4 n .. + 3 of the head: the order P V's
+    // accumulators leave the output in) and the RoPE pairs (rotary_embedding.py:132-173: interleaved pairs, the first 32 dims of
+    // the head) of the fragments of rows q0 + n (q and the block's own keys) and q0 - 16 + n (the keys in front), dims
+    // 16 u + 4 gq .. + 3, u < 2, at the rows' frames (rows of another CFG row or in front of the clip are masked: any table row).
+    // Both blocks of a wave request theirs before the first block's arithmetic: one memory latency per call, not two.
+    struct Ops {
+        f32x4 xf[4];
+        float2 c1[2], s1[2], c0[2], s0[2];
+    };
+    auto request_rope = [&](Ops& o, int q0) {
+        const int t1 = (R0 + q0 + n) % T, t0r = (R0 + q0 - 16 + n) % T, t0 = t0r < 0 ? 0 : t0r;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const unsigned o1 = (unsigned)(t1 * 16 + 8 * u + 2 * gq) * 4u, o0 = (unsigned)(t0 * 16 + 8 * u + 2 * gq) * 4u;
+            o.c1[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(cos_r, o1, 0, 0));
+            o.s1[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(sin_r, o1, 0, 0));
+            o.c0[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(cos_r, o0, 0, 0));
+            o.s0[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(sin_r, o0, 0, 0));
+        }
+    };
+    auto request_x = [&](Ops& o, int q0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o.xf[i] = ld_l2(xr, (unsigned)((R0 + q0 + 4 * gq + i) * E + head * 64 + 4 * n));
+    };
+    auto rot = [](f32x4& x, float2 cs2, float2 sn) {
+        x = f32x4{x[0] * cs2.x - x[1] * sn.x, x[1] * cs2.x + x[0] * sn.x, x[2] * cs2.y - x[3] * sn.y, x[3] * cs2.y + x[2] * sn.y};
+    };
+    auto block = [&](const Ops& o, int q0) {
+        f32x4 kf[2][4], qf[4], vf[2][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) qf[u] = tile_ld4(tile, q0 + n, 4 * u + gq);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) kf[1][u] = tile_ld4(tile, q0 + n, 16 + 4 * u + gq);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) vf[1][s4] = tile_ld4(tile, q0 + 4 * gq + s4, 32 + n);
+        if (q0 > 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) kf[0][u] = tile_ld4(tile, q0 - 16 + n, 16 + 4 * u + gq);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) vf[0][s4] = tile_ld4(tile, q0 - 16 + 4 * gq + s4, 32 + n);
+        } else if (halo_in) {
+            step_spin(flag_in, want, fail);  // (a spin that gives up raises the failure word: the host discards the launch)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) kf[0][u] = ld_l2(hin, (unsigned)(n * 128 + 16 * u + 4 * gq));
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) vf[0][s4] = ld_l2(hin, (unsigned)((4 * gq + s4) * 128 + 64 + 4 * n));
+        } else {  // (the clip's first rows: nothing in front of them -- the slots are masked below)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) kf[0][u] = vf[0][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            rot(qf[u], o.c1[u], o.s1[u]);
+            rot(kf[1][u], o.c1[u], o.s1[u]);
+            rot(kf[0][u], o.c0[u], o.s0[u]);
+        }
+        // ---- S^T = K Q^T: lane (n, gq) gets the scores of query n against keys 16 kt + 4 gq + i (kt 0: the 16 rows in front)
+        f32x4 st[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][u][cc], qf[u][cc], st[kt], 0, 0, 0);
+        }
+        // every query keeps its own chunk's bounds: keys [min(chunk start, j - W + 1), chunk end) of its own CFG row
+        const int rq = R0 + q0 + n, br = rq / T, ja = rq - br * T;
+        const int cstart = ja - ja % cs;
+        const int lo_row = min(cstart, max(0, ja - W + 1)), cend = min(cstart + cs, T);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int pos = R0 + q0 - 16 + 16 * kt + 4 * gq + i - br * T;  // the key's frame in the query's CFG row (outside [0, T): another row's)
+                st[kt][i] = (pos >= lo_row && pos < cend) ? st[kt][i] * 0.125f : -INFINITY;
+                mx = fmaxf(mx, st[kt][i]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));  // (the query's own frame is always visible: finite)
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st[kt][i] = attn_exp(st[kt][i] - mx), sum += st[kt][i];
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        // ---- O = P V: P's fragments are the S^T accumulators as they stand
+        f32x4 ot[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) ot[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const float pn = st[kt][s4] * inv;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) ot[cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(pn, vf[kt][s4][cc], ot[cc], 0, 0, 0);
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // lane (n, gq): query 4 gq + i, dims 4 n .. + 3 of the head
+            const int row = R0 + q0 + 4 * gq + i;
+            if (row < Mg) {
+                const f32x4 res = f32x4{ot[0][i] + o.xf[i][0], ot[1][i] + o.xf[i][1], ot[2][i] + o.xf[i][2], ot[3][i] + o.xf[i][3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, res), xr, (unsigned)((row * E + head * 64 + 4 * n) * 4), 0, 0);
+            }
+        }
+    };
+    // 16-query blocks hw + 8 (waves 0 .. 3), then hw: block 0 -- the one with foreign keys -- runs last
+    const bool two = hw < 4;
+    Ops oa, ob;
+    // (the table pairs -- L2 hits, needed first -- in front of the residual rows, which come from the memory-side cache and are
+    //  needed last: loads return in issue order)
+    request_rope(oa, two ? 16 * (hw + 8) : 16 * hw);
+    if (two) request_rope(ob, 16 * hw);
+    request_x(oa, two ? 16 * (hw + 8) : 16 * hw);
+    if (two) request_x(ob, 16 * hw);
+    block(oa, two ? 16 * (hw + 8) : 16 * hw);
+    if (two) block(ob, 16 * hw);
+}
+
 // One GEMM phase of an XCD on the ROLLING-fragment ring of gemm_x6_pipe.h (192 x 192 tiles: one per workgroup at T = 256): C =
 // epi(A3 W3^T) over the tiles rank, rank + 32, ... of the XCD's tile grid (row tile fastest)
 template <class C, int EPI>
 __device__ __forceinline__ void clip_gemm_r(const ClipGemm& g, unsigned char* smem_raw, int rank, int wid, int lane_in) {
     constexpr int BM = C::BM, BN = C::BN, MT = C::MT, NT = C::NT, RS = C::RS;
-    static_assert(C::SC1 == 1 && EPI != 2, "sc1 operand loads");  // EPI 0: qkv -- rotated fp32 rows; 1: MLP-up -- bias, exact GELU, x6 planes
+    static_assert(C::SC1 == 1, "sc1 operand loads");  // EPI 0: qkv -- rotated fp32 rows; 1: MLP-up -- bias, exact GELU, x6 planes;
+                                                      // 2: qkv, the tile is a head and attends in place (clip_tile_attention)
+    static_assert(EPI != 2 || (BM == 192 && BN == 192), "a head's tile: 192 rows x (q | k | v)");
     int lane = lane_in;
     asm volatile("" : "+v"(lane));  // (opaque: everything derived from the lane is this phase's own -- shared with the other phases
                                     //  it is a kernel-lifetime register that the allocator spills into the MFMA loops)
@@ -2242,13 +2413,14 @@ __device__ __forceinline__ void clip_gemm_r(const ClipGemm& g, unsigned char* sm
         const __amdgpu_buffer_rsrc_t out_r = step_rsrc(EPI == 0 ? static_cast<const void*>(g.out) : static_cast<const void*>(g.out3));
         const __amdgpu_buffer_rsrc_t cos_r = step_rsrc(g.rope_cos), sin_r = step_rsrc(g.rope_sin), bias_r = step_rsrc(g.bias);
         f32x4 bv[NT];
-        float2 rcs[EPI == 0 ? MT : 1][EPI == 0 ? NT : 1], rsn[EPI == 0 ? MT : 1][EPI == 0 ? NT : 1];
+        constexpr bool ROT = EPI == 0;  // (EPI 2 rotates q and k where it reads them: clip_tile_attention)
+        float2 rcs[ROT ? MT : 1][ROT ? NT : 1], rsn[ROT ? MT : 1][ROT ? NT : 1];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int cb = col0 + 16 * j, gn = cb + 4 * cq;
             bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (EPI == 1) bv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bias_r, (unsigned)gn * 4u, 0, 0));
-            if constexpr (EPI == 0) {
+            if constexpr (ROT) {
                 const bool roped = cb < 2 * kSE && (cb & 63) < 32;  // (wave-uniform; RoPE: rotary_embedding.py:132-173)
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
@@ -2270,8 +2442,31 @@ __device__ __forceinline__ void clip_gemm_r(const ClipGemm& g, unsigned char* sm
             asm volatile("" : "+v"(bv[j]));
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                if constexpr (EPI == 0) asm volatile("" : "+v"(rcs[i][j]), "+v"(rsn[i][j]));
+                if constexpr (ROT) asm volatile("" : "+v"(rcs[i][j]), "+v"(rsn[i][j]));
             }
+        }
+        if constexpr (EPI == 2) {
+            // ---- the tile -> LDS as it stands (over the ring: every wave is past its last fragment read), then the head attends in place
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int lr = rp * (BM / RS) + 16 * i + crow, lch = (cp * (BN / C::CP) + 16 * j) / 4 + cq;
+                    *reinterpret_cast<__attribute__((address_space(3))) f32x4*>((uintptr_t)(c.lds0 + (unsigned)(lr * 768 + ((lch ^ (lr & 7)) << 4)))) = c.acc[i][j];
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (tr && t == rank) tr[67] = wall_clock64();
+            // the workgroup with the previous row tile of this head: tile t - 1 (rank - 1 in this round, or rank 31 in the round before)
+            const unsigned sq = g.sq0 + (unsigned)((t - rank) / 32);
+            const int prank = rank > 0 ? rank - 1 : 31;
+            clip_tile_attention(g.T, g.cs, g.W, g.Mg, tm * BM, tn, c.lds0, g.halo + ((size_t)t << 11), tm > 0 ? g.halo + ((size_t)(t - 1) << 11) : nullptr,
+                                g.hflag + rank, sq + 1, g.hflag + prank, rank > 0 ? sq + 1 : sq, g.fail, g.xres, g.rope_cos, g.rope_sin);
+            continue;
         }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -2280,7 +2475,7 @@ __device__ __forceinline__ void clip_gemm_r(const ClipGemm& g, unsigned char* sm
             for (int i = 0; i < MT; ++i) {
                 const int gm = row0 + 16 * i + crow;
                 const f32x4 o = c.acc[i][j];
-                if constexpr (EPI == 0) {
+                if constexpr (ROT) {
                     const float2 cs = rcs[i][j], sn = rsn[i][j];  // (blocks that are not rotated: cos = 1, sin = 0 -- exact)
                     const f32x4 r = f32x4{o[0] * cs.x - o[1] * sn.x, o[1] * cs.x + o[0] * sn.x, o[2] * cs.y - o[3] * sn.y, o[3] * cs.y + o[2] * sn.y};
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r), out_r, (unsigned)(gm * g.N + gn) * 4u, 0, 0);
@@ -2675,6 +2870,11 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
     const bool pairs2 = a.W - 1 + 2 * a.cs > 16;  // a pair's keys are two 16-key tiles (midi: W = 16)
     const int npair = (cps + 1) / 2;
     const int nfb = T / 16, ntail = (a.C / 16) * nfb;         // tail items: (column tile, 16-frame block)
+    // qkv tiles = heads that attend in place (clip_tile_attention): the window reaches at most 16 rows back, whole chunks per 16 rows
+    const bool fuse = a.fuse != 0;
+    float* const halo = a.halo + (size_t)g * (a.rows_pad / 192) * 8 * 2048;
+    const unsigned qrounds = (unsigned)((a.rows_pad / 192) * 8 + 31) / 32;  // rounds of tiles of a qkv phase
+    unsigned qcalls = 0;
 
     for (int c = g; c < B; c += 8) {  // ---- this XCD's clips, one after the other
         for (int i = 0; i < a.nsteps; ++i) {  // ---- the Euler steps of RectifiedFlow.sample (model.py:770-785)
@@ -2730,15 +2930,34 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
                     clip_ln_rows(l == 0 ? pat_r : xres_r, l == 0, srcs, ab, Lw.n1w, Lw.n1b, xres, h3, lms, lane);
                 }
                 if (!end_phase(true)) return;
-                // ---- qkv
-                {
-                    const ClipGemm gq{h3, Lw.qkv_w3, a.rows_pad, 3 * E, E, nullptr, qkv, nullptr, a.rope_cos, a.rope_sin, T, nullptr, trace};
+                // ---- qkv (+ attention + residual where a tile is a head: clip_tile_attention)
+                if (fuse) {
+                    const ClipGemm gq{h3,  Lw.qkv_w3h, a.rows_pad, 3 * E, E, nullptr, nullptr, nullptr, a.rope_cos, a.rope_sin, T, xres, trace,
+                                      halo, &st->gen[xcc][0], &st->fail[0], qcalls * qrounds, a.cs, a.W, Mg};
+                    clip_gemm_r<ClipQU, 2>(gq, smem_raw, rank, w, lane);
+                    ++qcalls;
+                } else {
+                    const ClipGemm gq{h3, Lw.qkv_w3, a.rows_pad, 3 * E, E, nullptr, qkv, nullptr, a.rope_cos, a.rope_sin, T, nullptr, trace,
+                                      nullptr, nullptr, nullptr, 0, 0, 0, 0};
                     clip_gemm_r<ClipQU, 0>(gq, smem_raw, rank, w, lane);
                 }
                 if (!end_phase(true)) return;
                 // ---- attention + residual + AdaLN(cond) + norm3 (transformerv2.py:190-236, :351-361): one workgroup per chunk
                 //      of a CFG row; h as x6 planes
-                if (pairs) {  // items = pairs of chunks: shared K / V rows, a LayerNorm row for each of the eight waves
+                if (fuse) {  // the attention has been added to the residual stream: AdaLN(cond) + norm3, one wave per token row
+                    for (int lm0 = rank + 32 * w; lm0 < Mg; lm0 += 3 * 256) {
+                        const float* ab[3];
+                        int lms[3], srcs[3];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const int lm = min(lm0 + 256 * k, Mg - 1);
+                            lms[k] = lm0 + 256 * k < Mg ? lm : -1;
+                            srcs[k] = lm;
+                            ab[k] = cond_ab + (size_t)((lm / T) * B + c) * a.cond_ld + (size_t)l * 2 * E;
+                        }
+                        clip_ln_rows(xres_r, false, srcs, ab, Lw.n3w, Lw.n3b, xres, h3, lms, lane);
+                    }
+                } else if (pairs) {  // items = pairs of chunks: shared K / V rows, a LayerNorm row for each of the eight waves
                     for (int it = rank; it < 3 * npair; it += (int)n) {
                         const int br = it / npair, px = it - br * npair;
                         __syncthreads();  // (a second item of this workgroup reuses the LDS rows)
@@ -2763,13 +2982,15 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
                 if (!end_phase(true)) return;
                 // ---- MLP up + GELU
                 {
-                    const ClipGemm gu{h3, Lw.mlp0_w3, a.rows_pad, ME, E, Lw.mlp0_b, nullptr, mlp3, nullptr, nullptr, T, nullptr, nullptr};
+                    const ClipGemm gu{h3, Lw.mlp0_w3, a.rows_pad, ME, E, Lw.mlp0_b, nullptr, mlp3, nullptr, nullptr, T, nullptr, nullptr,
+                                      nullptr, nullptr, nullptr, 0, 0, 0, 0};
                     clip_gemm_r<ClipQU, 1>(gu, smem_raw, rank, w, lane);
                 }
                 if (!end_phase(true)) return;
                 // ---- MLP down + residual
                 {
-                    const ClipGemm gd{mlp3, Lw.mlp2_w3, a.rows_pad, E, ME, Lw.mlp2_b, nullptr, nullptr, nullptr, nullptr, T, xres, nullptr};
+                    const ClipGemm gd{mlp3, Lw.mlp2_w3, a.rows_pad, E, ME, Lw.mlp2_b, nullptr, nullptr, nullptr, nullptr, T, xres, nullptr,
+                                      nullptr, nullptr, nullptr, 0, 0, 0, 0};
                     clip_gemm_l<ClipDn>(gd, smem_raw, rank, w, lane);
                 }
                 if (!end_phase(true)) return;
@@ -2848,6 +3069,14 @@ __global__ __launch_bounds__(512) void persist_census_kernel(StepSync* st, int d
 }
 
 // W [N][K] (row stride ldw) -> 16 x 16 tiles [N / 16][K / 16][256] in MFMA fragment order (t16_off)
+// qkv weight rows regrouped by head for the batch sampler's fused attention: row 192 h + 64 p + d <- row p E + 64 h + d
+// (p: q / k / v) -- a 192-column output tile is then q_h | k_h | v_h of ONE head
+__global__ __launch_bounds__(256) void qkv_by_head_kernel(const float* __restrict__ w, float* __restrict__ out, int E) {
+    const int r = blockIdx.x, h = r / 192, p = (r % 192) / 64, d = r % 64;
+    const float* src = w + (size_t)(p * E + 64 * h + d) * E;
+    for (int k = threadIdx.x; k < E; k += 256) out[(size_t)r * E + k] = src[k];
+}
+
 __global__ __launch_bounds__(256) void tile16_kernel(const float* __restrict__ W, int ldw, float* __restrict__ out, int N, int K) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // one float4 of the output
     if (idx >= (size_t)N * K / 4) return;
@@ -2942,6 +3171,9 @@ struct after_denoiser {
     // qkv rows (fp32) and the x6 planes of h and of the MLP hidden layer; rows provisioned per XCD
     float* clip_act = nullptr;
     unsigned short* clip_act3 = nullptr;
+    float* clip_halo = nullptr;            // [8][clip_rows / 192][8 heads][16][128]: clip_tile_attention's hand-over rows
+    unsigned short* clip_qkv_w3h = nullptr;  // [L] x6 planes of the qkv weights with the output columns regrouped by head
+    int clip_fuse = 1;         // AFTER_CLIP_FUSE=0: qkv rows through memory + attention items (A/B switch)
     int clip_rows = 0, clip_pat_rows = 0;
     int clip_min_b = 5;        // AFTER_SAMPLE_CLIP_MINB: fewest clips of a call that take the kernel (below: seg kernel / launches)
     int persist_clip = 1;      // AFTER_SAMPLE_CLIP=0: batches by launches
@@ -3536,6 +3768,8 @@ extern "C" void after_denoiser_destroy(after_denoiser* h) {
     if (h->seg_act3) (void)hipFree(h->seg_act3);
     if (h->clip_act) (void)hipFree(h->clip_act);
     if (h->clip_act3) (void)hipFree(h->clip_act3);
+    if (h->clip_halo) (void)hipFree(h->clip_halo);
+    if (h->clip_qkv_w3h) (void)hipFree(h->clip_qkv_w3h);
     h->wa.release();
     h->ws.release();
     h->ca.release();
@@ -3780,15 +4014,35 @@ int persist_prepare(after_denoiser* h, bool offline) {
         const size_t nf = 8 * (prow * E + rows * E + rows * 3 * E), n3 = 8 * rows * 3 * (E + ME);
         float* f = nullptr;
         unsigned short* a3 = nullptr;
-        const bool ok = hipMalloc(&f, nf * sizeof(float)) == hipSuccess && hipMalloc(&a3, n3 * sizeof(unsigned short)) == hipSuccess &&
-                        hipMemset(f, 0, nf * sizeof(float)) == hipSuccess && hipMemset(a3, 0, n3 * sizeof(unsigned short)) == hipSuccess;
+        bool ok = hipMalloc(&f, nf * sizeof(float)) == hipSuccess && hipMalloc(&a3, n3 * sizeof(unsigned short)) == hipSuccess &&
+                  hipMemset(f, 0, nf * sizeof(float)) == hipSuccess && hipMemset(a3, 0, n3 * sizeof(unsigned short)) == hipSuccess;
+        // the fused attention's hand-over rows and the qkv weights regrouped by head (+ 4.7 MB of planes per layer)
+        float *halo = nullptr, *tmp = nullptr;
+        unsigned short* w3h = nullptr;
+        const size_t nh = 8 * (rows / 192) * 8 * 2048, per = x6_elems(3 * (int)E, (int)E);
+        if (ok) {
+            const char* e = getenv("AFTER_CLIP_FUSE");
+            if (e) h->clip_fuse = atoi(e) != 0;
+            ok = hipMalloc(&halo, nh * sizeof(float)) == hipSuccess && hipMemset(halo, 0, nh * sizeof(float)) == hipSuccess &&
+                 hipMalloc(&w3h, per * h->L * sizeof(unsigned short)) == hipSuccess &&
+                 hipMemset(w3h, 0, per * h->L * sizeof(unsigned short)) == hipSuccess && hipMalloc(&tmp, 3 * E * E * sizeof(float)) == hipSuccess;
+            for (int l = 0; ok && l < h->L; ++l) {
+                hipLaunchKernelGGL(qkv_by_head_kernel, dim3(3 * (unsigned)E), dim3(256), 0, nullptr, h->layers[l].qkv_w, tmp, (int)E);
+                ok = hipGetLastError() == hipSuccess && gemm_x6_split(tmp, (int)E, w3h + per * l, 3 * (int)E, (int)E, nullptr) == AFTER_OK &&
+                     hipDeviceSynchronize() == hipSuccess;
+            }
+            if (tmp) (void)hipFree(tmp);
+        }
         if (!ok) {
             (void)hipGetLastError();
             if (f) (void)hipFree(f);
             if (a3) (void)hipFree(a3);
+            if (halo) (void)hipFree(halo);
+            if (w3h) (void)hipFree(w3h);
             h->persist_clip = 0;  // (the other offline paths serve the handle)
         } else {
             h->clip_act = f, h->clip_act3 = a3, h->clip_rows = (int)rows, h->clip_pat_rows = (int)prow;
+            h->clip_halo = halo, h->clip_qkv_w3h = w3h;
         }
     }
     // the kernels' dynamic LDS limits (a hipFuncSetAttribute inside after_sample would be one more first-call cost)
@@ -4070,6 +4324,9 @@ int sample_clip(after_denoiser* h, hipStream_t s, const float* x0, float* out, i
         a.xres_t = p, p += (size_t)8 * h->clip_rows * E;
         a.qkv = p;
         a.h3 = h->clip_act3, a.mlp3 = h->clip_act3 + (size_t)8 * h->clip_rows * 3 * E;
+        a.halo = h->clip_halo;
+        // a tile attends in place when a 16-row block sees its keys in itself and the 16 rows in front of it
+        a.fuse = h->clip_fuse && h->W - 1 <= 16 && 16 % h->cs == 0 && h->H == 8;
     }
     a.patch_wt = h->step_patch_wt, a.patch_b = h->patch_b, a.out_wt = h->step_out_wt, a.out_b = h->out_b;
     a.tc_ab = h->tc_ab, a.tc_ld = L * 2 * E, a.tcmap = h->maps + h->ms;
@@ -4083,6 +4340,7 @@ int sample_clip(after_denoiser* h, hipStream_t s, const float* x0, float* out, i
         const LayerW& w = h->layers[l];
         ClipLayer& cl = a.layer[l];
         cl.qkv_w3 = w.qkv_w3, cl.mlp0_w3 = w.mlp0_w3, cl.mlp2_w3 = w.mlp2_w3;
+        cl.qkv_w3h = h->clip_qkv_w3h + x6_elems(3 * E, E) * l;
         cl.mlp0_b = w.mlp0_b, cl.mlp2_b = w.mlp2_b, cl.n1w = w.n1w, cl.n1b = w.n1b, cl.n3w = w.n3w, cl.n3b = w.n3b;
     }
     const bool timed = h->timer.enabled && h->timer_kernel == 3;

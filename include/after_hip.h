@@ -174,11 +174,13 @@ int after_denoiser_gemm_path(after_denoiser* h, int* mode, int* min_rows);
  * after_denoiser_stream_persist: *active = 1 when the handle's last streaming shape takes the persistent path. */
 int after_denoiser_set_stream_persist(after_denoiser* h, int enable);
 /* after_sample for ONE clip without K/V caches (RectifiedFlow.sample, model.py:763-785) as one persistent launch: the same
- * XCD-local pipelines partitioned over time (XCD g owns frames [g T/8, (g+1) T/8) of the three CFG rows; the attention's
- * left context crosses XCDs through system-scope stores / loads and per-XCD sequence words, no device-wide barrier), the
- * Linears as bf16 x 3 split MFMAs like gemm_x6.  The DEFAULT where eligible: the shipped width (embed 512 / mlp x 3 / eight
- * heads), B = 1, T = 128 or 256, window - 1 <= T / 8, gemm path != 0, no graph replay; otherwise, or with enable = 0 /
- * AFTER_SAMPLE_PERSIST=0, the launch path runs.  Provisioning, co-residency and failures as above.
+ * XCD-local pipelines partitioned over time (XCD g owns segment g -- Tseg = 16 or 32 frames -- of the three CFG rows; the
+ * attention's left context crosses XCDs through system-scope stores / loads and per-XCD sequence words, no device-wide
+ * barrier), the Linears as bf16 x 3 split MFMAs like gemm_x6.  The DEFAULT where eligible: the shipped widths (embed 512 --
+ * base, midi -- or 256 -- tiny; mlp x 3, heads of 64), B = 1, T = up to eight segments of 16 or 32 frames (16 .. 128 in steps
+ * of 16, 160, 192, 224, 256: XCDs without a segment leave the kernel at once), whole attention chunks per segment,
+ * window - 1 <= Tseg, gemm path != 0, no graph replay; otherwise, or with enable = 0 / AFTER_SAMPLE_PERSIST=0, the launch
+ * path runs.  Provisioning, co-residency and failures as above.
  *
  * BATCHES (B >= 5 clips; BASELINE config 3's per-GPU shard, config 4): one persistent launch with ONE CLIP PER XCD (clips 8 .. on
  * the same XCDs, one after the other) -- no cross-XCD word at all; the Linears on LDS-staged bf16 x 3 tiles (192 x 192 /
