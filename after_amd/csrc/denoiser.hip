@@ -1590,12 +1590,12 @@ constexpr bool kSegW = !(SEG_DIAG & 4);  // -DSEG_DIAG=4 (timing experiments): n
 // (W: buffer resource of the tiled weight copy -- every fragment load of the kernel then shares ONE address register, lane x 16
 //  bytes, and carries its tile / k-block position in the instruction's scalar offset: per-load 64-bit lane addresses are
 //  kernel-lifetime invariants that the register allocator spills, and each reload's s_waitcnt vmcnt(0) drains the operand queue)
-template <int RB, int NT>
+template <int RB, int NT, int NP = 3>  // NP: planes fetched (1: the bf16 tolerance tier reads the h plane only)
 __device__ __forceinline__ void seg_load_a(SegBuf<RB, NT>& sb, int slot, __amdgpu_buffer_rsrc_t A3, int a_kb32, int rb0, int kb, int lane) {
 #pragma unroll
     for (int i = 0; i < RB; ++i)
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NP; ++p)
             sb.ap[slot][i][p] = __builtin_amdgcn_raw_buffer_load_b128(A3, lane * 16, (unsigned)((((rb0 + i) * a_kb32 + kb) * 3 + p) << 10), 16);
 }
 
@@ -1616,7 +1616,8 @@ __device__ __forceinline__ void seg_load_w(SegBuf<RB, NT>& sb, int slot, __amdgp
 // workgroup barrier of the partial-tile exchange waits a full fabric round trip for it).
 // On entry the caller has requested k-block 0 (seg_load_a, then seg_load_w: activations first -- they come from the L2, the
 // weights from the fabric, and loads return in issue order; weights first measured + 0.6 us per phase).
-template <int RB, int NT, int KB, int DIAG, class F>  // DIAG (timing experiments, -DSEG_DIAG=n): 1 no MFMAs, 2 no weight split
+template <int RB, int NT, int KB, int DIAG, int TIER, class F>  // DIAG (timing experiments, -DSEG_DIAG=n): 1 no MFMAs, 2 no weight split
+                                                                   // TIER 1: the h x h product only (the opt-in bf16 tolerance tier)
 __device__ __forceinline__ void seg_run(f32x4 (&acc)[NT * RB], SegBuf<RB, NT>& sb, __amdgpu_buffer_rsrc_t A3, int a_kb32, int rb0,
                                         __amdgpu_buffer_rsrc_t W, int w_kblocks, int tile0, int ts, int kb0, int lane, F&& after_loads) {
     constexpr int NA = kSegSlotsA, NW = kSegSlotsW, NX = NA > NW ? NA : NW;
@@ -1624,14 +1625,14 @@ __device__ __forceinline__ void seg_run(f32x4 (&acc)[NT * RB], SegBuf<RB, NT>& s
     // multiplied (the loop is latency-bound: bytes in flight per CU are what it runs on)
 #pragma unroll
     for (int v = 1; v < NX - 1 && v < KB; ++v) {
-        if (v < NA - 1) seg_load_a<RB, NT>(sb, v % NA, A3, a_kb32, rb0, kb0 + v, lane);
+        if (v < NA - 1) seg_load_a<RB, NT, TIER ? 1 : 3>(sb, v % NA, A3, a_kb32, rb0, kb0 + v, lane);
         if (v < NW - 1) seg_load_w<RB, NT>(sb, v % NW, W, w_kblocks, tile0, ts, kb0 + v, lane);
     }
 #pragma unroll
     for (int p = 0; p < NT * RB; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < KB; ++u) {
-        if (u + NA - 1 < KB) seg_load_a<RB, NT>(sb, (u + NA - 1) % NA, A3, a_kb32, rb0, kb0 + u + NA - 1, lane);
+        if (u + NA - 1 < KB) seg_load_a<RB, NT, TIER ? 1 : 3>(sb, (u + NA - 1) % NA, A3, a_kb32, rb0, kb0 + u + NA - 1, lane);
         if (u + NW - 1 < KB) seg_load_w<RB, NT>(sb, (u + NW - 1) % NW, W, w_kblocks, tile0, ts, kb0 + u + NW - 1, lane);
         if (u + 2 == KB || KB == 1) after_loads();
         // all weight fragments of the k-block are split first, then the MFMAs run product by product over every (tile, row
@@ -1649,7 +1650,7 @@ __device__ __forceinline__ void seg_run(f32x4 (&acc)[NT * RB], SegBuf<RB, NT>& s
             }
         }
 #pragma unroll
-        for (int p = 0; p < 6; ++p)
+        for (int p = TIER ? 5 : 0; p < 6; ++p)  // (kSegWP / kSegAP: product 5 is h x h)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -1735,8 +1736,9 @@ __device__ __attribute__((noinline)) void seg_attention(StepAttn g, const float*
 // tiles -- the XCD's two row halves are dealt over the workgroups instead, workgroup = (column tile rank % 16, row half rank / 16),
 // and its eight waves split K eight ways; four heads on waves 0 .. 3 of an attention item).  MLP width 3 E, heads E / 64.
 // Length: nseg <= 8 segments of Tseg = 16 or 32 frames on XCDs 0 .. nseg - 1; the other XCDs leave after the census.
-template <int MB, int E>  // MB: row blocks per XCD, 3 Tseg / 16 (6 at T = 256)
+template <int MB, int E, int TIER = 0>  // MB: row blocks per XCD, 3 Tseg / 16 (6 at T = 256); TIER 1: the opt-in bf16 tolerance tier
 __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
+    constexpr int NPL = TIER ? 1 : 3;  // activation planes a GEMM phase fetches
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ unsigned s_rank, s_bad, s_ok;
     constexpr int ME = 3 * E, KBE = E / 16, KBM = ME / 16, MBP = (MB + 2) / 3;  // MBP: row blocks of one CFG row
@@ -1921,9 +1923,9 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                     rope_req();
                 };
                 if (gact) {
-                    seg_load_a<3, 3>(sbq, 0, hb3_r, E / 32, 3 * rh, KQ * ks, lane);
+                    seg_load_a<3, 3, NPL>(sbq, 0, hb3_r, E / 32, 3 * rh, KQ * ks, lane);
                     seg_load_w<3, 3>(sbq, 0, Wq, KBE, ct, TPW, KQ * ks, lane);
-                    seg_run<3, 3, KQ, SEG_DIAG>(acc, sbq, hb3_r, E / 32, 3 * rh, Wq, KBE, ct, TPW, KQ * ks, lane, qkv_next);
+                    seg_run<3, 3, KQ, SEG_DIAG, TIER>(acc, sbq, hb3_r, E / 32, 3 * rh, Wq, KBE, ct, TPW, KQ * ks, lane, qkv_next);
                 } else {
 #pragma unroll
                     for (int p = 0; p < 9; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1991,7 +1993,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 // ---- MLP up + GELU: column tiles rank + 32 j; the hidden layer as bf16 x 3 planes
                 f32x4 acc[3 * NTU];
                 if (gact) {
-                    seg_load_a<3, NTU>(sbu, 0, hb3_r, E / 32, 3 * rh, KQ * ks, lane);
+                    seg_load_a<3, NTU, NPL>(sbu, 0, hb3_r, E / 32, 3 * rh, KQ * ks, lane);
                     seg_load_w<3, NTU>(sbu, 0, Wu, KBE, ct, TPW, KQ * ks, lane);
                 }
                 // (epilogue operands before the GEMM: wave w finishes tiles p = w, w + 8, w + 16)
@@ -2003,7 +2005,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                                                        : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
                 if (gact) {
-                    seg_run<3, NTU, KQ, SEG_DIAG>(acc, sbu, hb3_r, E / 32, 3 * rh, Wu, KBE, ct, TPW, KQ * ks, lane, [] {});
+                    seg_run<3, NTU, KQ, SEG_DIAG, TIER>(acc, sbu, hb3_r, E / 32, 3 * rh, Wu, KBE, ct, TPW, KQ * ks, lane, [] {});
                 } else {
 #pragma unroll
                     for (int p = 0; p < 3 * NTU; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -2027,7 +2029,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 // ---- MLP down + residual
                 f32x4 acc[3 * NTD], bv[1], rv[1];
                 if (dact) {
-                    seg_load_a<3, NTD>(sbd, 0, mlp3_r, ME / 32, rb0d, KD * w, lane);
+                    seg_load_a<3, NTD, NPL>(sbd, 0, mlp3_r, ME / 32, rb0d, KD * w, lane);
                     seg_load_w<3, NTD>(sbd, 0, Wd, KBM, tile0d, 1, KD * w, lane);
                 }
                 // (wave w < 3 NTD finishes column tile w / 3, row block w % 3: one exchange of all partials, six finishing waves at
@@ -2041,7 +2043,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 }
                 auto down_next = [&] { if (l + 1 < a.L) ln_prefetch(l + 1); };
                 if (dact) {
-                    seg_run<3, NTD, KD, SEG_DIAG>(acc, sbd, mlp3_r, ME / 32, rb0d, Wd, KBM, tile0d, 1, KD * w, lane, down_next);
+                    seg_run<3, NTD, KD, SEG_DIAG, TIER>(acc, sbd, mlp3_r, ME / 32, rb0d, Wd, KBM, tile0d, 1, KD * w, lane, down_next);
                 } else {
 #pragma unroll
                     for (int p = 0; p < 3 * NTD; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -2121,8 +2123,12 @@ constexpr int kClipLoaders = CLIP_LOADERS;  // loader waves of a GEMM phase (wav
 #define CLIP_DN_LOADERS 8
 #endif
 constexpr int kClipDnLoaders = CLIP_DN_LOADERS;
-using ClipQU = X6RCfg<12, 12, 4, 2, 1>;                     // qkv / MLP-up: 192 x 192, waves = 4 row parts x 2 column parts, rolling fragments
-using ClipDn = X6Cfg<6, 8, 1, 2, 4, CLIP_DN_NS, 0, 1, 1, 0, 0, 1>;  // MLP-down: 96 x 128 (32 tiles), waves = 2 row parts x 4 column parts, even / odd slabs in separate accumulators
+template <int TIER>  // TIER 1: the opt-in bf16 tolerance tier (one MFMA per product block: X6Cfg::TIER)
+using ClipQUT = X6RCfg<12, 12, 4, 2, 1, TIER>;               // qkv / MLP-up: 192 x 192, waves = 4 row parts x 2 column parts, rolling fragments
+template <int TIER>
+using ClipDnT = X6Cfg<6, 8, 1, 2, 4, CLIP_DN_NS, 0, 1, 1, 0, 0, 1, TIER>;  // MLP-down: 96 x 128 (32 tiles), waves = 2 row parts x 4 column parts, even / odd slabs in separate accumulators
+using ClipQU = ClipQUT<0>;
+using ClipDn = ClipDnT<0>;
 constexpr int kClipRowTile = 192;  // rows of an XCD's slices are provisioned in multiples of it (both tile heights divide it)
 constexpr int kClipMaxT = 1024;    // longest clip the slices are provisioned for (15.5 MB per XCD at T = 256)
 // dynamic LDS: the GEMM ring of the larger tile | attention rows + K / V landing zones | the tail's partial tiles
@@ -2820,6 +2826,7 @@ __device__ __forceinline__ void clip_ln_rows(__amdgpu_buffer_rsrc_t xin, bool sr
     }
 }
 
+template <int TIER>
 __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ unsigned s_rank, s_bad, s_ok;
@@ -2934,12 +2941,12 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
                 if (fuse) {
                     const ClipGemm gq{h3,  Lw.qkv_w3h, a.rows_pad, 3 * E, E, nullptr, nullptr, nullptr, a.rope_cos, a.rope_sin, T, xres, trace,
                                       halo, &st->gen[xcc][0], &st->fail[0], qcalls * qrounds, a.cs, a.W, Mg};
-                    clip_gemm_r<ClipQU, 2>(gq, smem_raw, rank, w, lane);
+                    clip_gemm_r<ClipQUT<TIER>, 2>(gq, smem_raw, rank, w, lane);
                     ++qcalls;
                 } else {
                     const ClipGemm gq{h3, Lw.qkv_w3, a.rows_pad, 3 * E, E, nullptr, qkv, nullptr, a.rope_cos, a.rope_sin, T, nullptr, trace,
                                       nullptr, nullptr, nullptr, 0, 0, 0, 0};
-                    clip_gemm_r<ClipQU, 0>(gq, smem_raw, rank, w, lane);
+                    clip_gemm_r<ClipQUT<TIER>, 0>(gq, smem_raw, rank, w, lane);
                 }
                 if (!end_phase(true)) return;
                 // ---- attention + residual + AdaLN(cond) + norm3 (transformerv2.py:190-236, :351-361): one workgroup per chunk
@@ -2984,14 +2991,14 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
                 {
                     const ClipGemm gu{h3, Lw.mlp0_w3, a.rows_pad, ME, E, Lw.mlp0_b, nullptr, mlp3, nullptr, nullptr, T, nullptr, nullptr,
                                       nullptr, nullptr, nullptr, 0, 0, 0, 0};
-                    clip_gemm_r<ClipQU, 1>(gu, smem_raw, rank, w, lane);
+                    clip_gemm_r<ClipQUT<TIER>, 1>(gu, smem_raw, rank, w, lane);
                 }
                 if (!end_phase(true)) return;
                 // ---- MLP down + residual
                 {
                     const ClipGemm gd{mlp3, Lw.mlp2_w3, a.rows_pad, E, ME, Lw.mlp2_b, nullptr, nullptr, nullptr, nullptr, T, xres, nullptr,
                                       nullptr, nullptr, nullptr, 0, 0, 0, 0};
-                    clip_gemm_l<ClipDn>(gd, smem_raw, rank, w, lane);
+                    clip_gemm_l<ClipDnT<TIER>>(gd, smem_raw, rank, w, lane);
                 }
                 if (!end_phase(true)) return;
             }
@@ -3096,6 +3103,10 @@ template __global__ void sample_seg_kernel<3, 512>(StepArgs);
 template __global__ void sample_seg_kernel<6, 512>(StepArgs);
 template __global__ void sample_seg_kernel<3, 256>(StepArgs);
 template __global__ void sample_seg_kernel<6, 256>(StepArgs);
+template __global__ void sample_seg_kernel<3, 512, 1>(StepArgs);
+template __global__ void sample_seg_kernel<6, 512, 1>(StepArgs);
+template __global__ void sample_clip_kernel<0>(ClipArgs);
+template __global__ void sample_clip_kernel<1>(ClipArgs);
 
 }  // namespace
 }  // namespace after
@@ -3174,6 +3185,7 @@ struct after_denoiser {
     float* clip_halo = nullptr;            // [8][clip_rows / 192][8 heads][16][128]: clip_tile_attention's hand-over rows
     unsigned short* clip_qkv_w3h = nullptr;  // [L] x6 planes of the qkv weights with the output columns regrouped by head
     int clip_fuse = 1;         // AFTER_CLIP_FUSE=0: qkv rows through memory + attention items (A/B switch)
+    int tier = 0;              // after_denoiser_set_gemm_path(h, 3): the persistent offline samplers' Linears with bf16 operands (h planes only)
     int clip_rows = 0, clip_pat_rows = 0;
     int clip_min_b = 5;        // AFTER_SAMPLE_CLIP_MINB: fewest clips of a call that take the kernel (below: seg kernel / launches)
     int persist_clip = 1;      // AFTER_SAMPLE_CLIP=0: batches by launches
@@ -4047,10 +4059,12 @@ int persist_prepare(after_denoiser* h, bool offline) {
     }
     // the kernels' dynamic LDS limits (a hipFuncSetAttribute inside after_sample would be one more first-call cost)
     {
-        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sample_clip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClipLds));
+        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sample_clip_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClipLds));
+        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sample_clip_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClipLds));
         const size_t lds_seg = ((size_t)kSRedFloats(2) + 8 * 2 * kAttnKeyBlock * 64) * sizeof(float);
         const void* fns[] = {reinterpret_cast<const void*>(sample_seg_kernel<6, 512>), reinterpret_cast<const void*>(sample_seg_kernel<3, 512>),
                              reinterpret_cast<const void*>(sample_seg_kernel<6, 256>), reinterpret_cast<const void*>(sample_seg_kernel<3, 256>),
+                             reinterpret_cast<const void*>(sample_seg_kernel<6, 512, 1>), reinterpret_cast<const void*>(sample_seg_kernel<3, 512, 1>),
                              reinterpret_cast<const void*>(persist_census_kernel)};
         for (const void* fn : fns) AFTER_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_seg));
         const void* sf[] = {reinterpret_cast<const void*>(stream_step_kernel<1>), reinterpret_cast<const void*>(stream_step_kernel<2>),
@@ -4255,7 +4269,10 @@ int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, in
     if (timed) h->timer.begin(s);
     {
         PersistLaunch guard(h->dev, s);
-        if (E == kSE) {
+        if (E == kSE && h->tier) {
+            if (MB == 6) hipLaunchKernelGGL((sample_seg_kernel<6, 512, 1>), dim3(h->n_cus), dim3(512), lds, s, a);
+            else hipLaunchKernelGGL((sample_seg_kernel<3, 512, 1>), dim3(h->n_cus), dim3(512), lds, s, a);
+        } else if (E == kSE) {
             if (MB == 6) hipLaunchKernelGGL((sample_seg_kernel<6, 512>), dim3(h->n_cus), dim3(512), lds, s, a);
             else hipLaunchKernelGGL((sample_seg_kernel<3, 512>), dim3(h->n_cus), dim3(512), lds, s, a);
         } else {
@@ -4326,7 +4343,7 @@ int sample_clip(after_denoiser* h, hipStream_t s, const float* x0, float* out, i
         a.h3 = h->clip_act3, a.mlp3 = h->clip_act3 + (size_t)8 * h->clip_rows * 3 * E;
         a.halo = h->clip_halo;
         // a tile attends in place when a 16-row block sees its keys in itself and the 16 rows in front of it
-        a.fuse = h->clip_fuse && h->W - 1 <= 16 && 16 % h->cs == 0 && h->H == 8;
+        a.fuse = h->clip_fuse && !(a.dbg & 128) && h->W - 1 <= 16 && 16 % h->cs == 0 && h->H == 8;  // (diagnostics bit 7: the item form)
     }
     a.patch_wt = h->step_patch_wt, a.patch_b = h->patch_b, a.out_wt = h->step_out_wt, a.out_b = h->out_b;
     a.tc_ab = h->tc_ab, a.tc_ld = L * 2 * E, a.tcmap = h->maps + h->ms;
@@ -4347,7 +4364,8 @@ int sample_clip(after_denoiser* h, hipStream_t s, const float* x0, float* out, i
     if (timed) h->timer.begin(s);
     {
         PersistLaunch guard(h->dev, s);
-        hipLaunchKernelGGL(sample_clip_kernel, dim3(h->n_cus), dim3(512), kClipLds, s, a);
+        if (h->tier) hipLaunchKernelGGL(sample_clip_kernel<1>, dim3(h->n_cus), dim3(512), kClipLds, s, a);
+        else hipLaunchKernelGGL(sample_clip_kernel<0>, dim3(h->n_cus), dim3(512), kClipLds, s, a);
     }
     AFTER_HIP_CHECK(hipGetLastError());
     if (timed) {
@@ -4547,8 +4565,10 @@ extern "C" int after_sample(after_denoiser* h, const float* x0, const float* con
 
 extern "C" int after_denoiser_set_gemm_path(after_denoiser* h, int mode, int min_rows) {
     AFTER_REQUIRE(h, AFTER_E_INVALID, "null handle");
-    AFTER_REQUIRE(mode >= 0 && mode <= 2, AFTER_E_INVALID, "gemm path %d (0 fp32 MFMA, 1 bf16-split above min_rows, 2 always)", mode);
-    h->x6 = mode;
+    AFTER_REQUIRE(mode >= 0 && mode <= 3, AFTER_E_INVALID,
+                  "gemm path %d (0 fp32 MFMA, 1 bf16-split above min_rows, 2 always, 3 the bf16 tolerance tier of the persistent offline samplers)", mode);
+    h->x6 = mode == 3 ? 1 : mode;
+    h->tier = mode == 3;
     if (min_rows > 0) h->x6_min_rows = min_rows;
     for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.exec);  // captured launches bake the path in
     h->graphs.clear();
@@ -4617,7 +4637,7 @@ extern "C" int after_denoiser_stream_persist(after_denoiser* h, int* active) {
 
 extern "C" int after_denoiser_gemm_path(after_denoiser* h, int* mode, int* min_rows) {
     AFTER_REQUIRE(h && mode && min_rows, AFTER_E_INVALID, "null argument");
-    *mode = h->x6;
+    *mode = h->tier ? 3 : h->x6;
     *min_rows = h->x6_min_rows;
     return AFTER_OK;
 }

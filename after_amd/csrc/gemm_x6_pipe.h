@@ -21,8 +21,11 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int swz4(int q) { return (0x78 >> (2 * q)) & 3; }
 
 template <int MB_, int NBK_, int KS_, int RS_, int CP_, int NS_, int OUT3_, int RES_, int ACC2_ = 0, int PERSIST_ = 0,
-          int CONV_ = 0, int SC1_ = 0>
+          int CONV_ = 0, int SC1_ = 0, int TIER_ = 0>
 struct X6Cfg {
+    // TIER 1 (the opt-in bf16 tolerance tier of the batch sampler, after_denoiser_set_gemm_path(h, 3)): only the h x h product of
+    // every block is issued -- bf16 operands (the top planes of the exact splits), fp32 accumulate
+    static constexpr int TIER = TIER_;
     // SC1: the DMA pieces are sc1 loads -- they miss the CU's vector L1 and are served by the XCD's L2: for operands that
     // another workgroup of the same XCD wrote earlier in the SAME kernel (the clip-per-XCD sampler of denoiser.hip)
     static constexpr int SC1 = SC1_;
@@ -43,6 +46,7 @@ struct X6Cfg {
     static constexpr int AB = MB + CONV;                 // 16-row A blocks per plane in a stage
     static constexpr int GA = 3 * AB, GW = 3 * NBK;     // 1-KB pieces (16 rows of one plane) per k-part: A, W
     static constexpr int PPK = GA + GW;
+    static constexpr int PPKI = TIER ? AB + NBK : PPK;  // pieces a slab's loaders ISSUE (TIER 1: the h planes only; the stage keeps its layout)
     static constexpr int PART = PPK * 1024;             // bytes of one k-part of a stage
     static constexpr int STAGE = KS * PART;
     static constexpr int P = KS * PPK;                  // pieces per stage
@@ -169,9 +173,10 @@ __device__ __forceinline__ void x6_mma(X6State<C>& c, bool refill, bool more, in
         constexpr int p = S / (C::MT * C::NT), i = (S / C::NT) % C::MT, j = S % C::NT;
         // W fragment as srcA: the accumulator holds C^T (four consecutive columns of one row per lane)
         constexpr int AS = C::ACC2 ? CUR : 0;
-        c.acc[AS][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, c.fw[CUR][kWP[p]][j]),
-                                                                  __builtin_bit_cast(bf16x8, c.fa[CUR][kAP[p]][i]),
-                                                                  c.acc[AS][i][j], 0, 0, 0);
+        if constexpr (!C::TIER || (kWP[p] == 0 && kAP[p] == 0))
+            c.acc[AS][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, c.fw[CUR][kWP[p]][j]),
+                                                                      __builtin_bit_cast(bf16x8, c.fa[CUR][kAP[p]][i]),
+                                                                      c.acc[AS][i][j], 0, 0, 0);
         constexpr int w0 = (S * C::NWORK) / C::NMMA, w1 = ((S + 1) * C::NWORK) / C::NMMA;
         x6_sides<C, CUR ^ 1, w0, w1, STEADY>(c, refill, more, slab_new, stage_new, a_next, w_next);
         __builtin_amdgcn_sched_barrier(0);
@@ -266,8 +271,9 @@ struct X6LState {
 template <class C, int W>
 __device__ __forceinline__ void x6l_dma(const X6LState<C>& c, int slab, int stage) {
     static_assert(C::KS == 1 && C::CONV == 0, "loader-wave ring: plain tiles without k-parts");
-    constexpr bool isW = W < C::GW;
-    constexpr int q = isW ? W : W - C::GW;
+    constexpr int GWI = C::TIER ? C::NBK : C::GW;  // (TIER 1: the issue-order list holds the h-plane pieces only)
+    constexpr bool isW = W < GWI;
+    constexpr int q = isW ? W : W - GWI;
     constexpr int plane = isW ? q / C::NBK : q / C::MB, grp = isW ? q % C::NBK : q % C::MB;
     constexpr int piece = isW ? C::GA + q : q;  // position inside the stage (1-KB units)
     const unsigned long long src = (isW ? c.w_src : c.a_src) + (unsigned long long)((unsigned)grp * c.rgs + (unsigned)plane * 1024u + (unsigned)slab * 3072u);
@@ -284,7 +290,7 @@ __device__ __forceinline__ void x6l_dma(const X6LState<C>& c, int slab, int stag
 // wave is in the memory path's queue at the same time.
 template <class C, int NL, int LID>
 struct X6LRole {
-    static constexpr int ND = LID < 0 ? 0 : (C::PPK - LID + NL - 1) / NL;  // DMA items of this wave per slab
+    static constexpr int ND = LID < 0 ? 0 : (C::PPKI - LID + NL - 1) / NL;  // DMA items of this wave per slab
     static constexpr int NWK = ND + C::NREAD;
 };
 
@@ -301,11 +307,13 @@ __device__ __forceinline__ void x6l_side(X6LState<C>& c, bool refill, bool more,
         if (STEADY || more) {
             if constexpr (R < 3 * C::MT) {
                 constexpr int pl = R / C::MT, i = R % C::MT;
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c.fa[NXT][pl][i]) : "v"(a_next), "i"((pl * C::AB * 16 + i * 16) * 64));
+                if constexpr (!C::TIER || pl == 0)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c.fa[NXT][pl][i]) : "v"(a_next), "i"((pl * C::AB * 16 + i * 16) * 64));
             } else {
                 constexpr int R2 = R - 3 * C::MT;
                 constexpr int pl = R2 / C::NT, j = R2 % C::NT;
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c.fw[NXT][pl][j]) : "v"(w_next), "i"((pl * C::BN + j * 16) * 64));
+                if constexpr (!C::TIER || pl == 0)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c.fw[NXT][pl][j]) : "v"(w_next), "i"((pl * C::BN + j * 16) * 64));
             }
         }
     }
@@ -326,8 +334,9 @@ __device__ __forceinline__ void x6l_mma(X6LState<C>& c, bool refill, bool more, 
     if constexpr (S < C::NMMA) {
         constexpr int p = S / (C::MT * C::NT), i = (S / C::NT) % C::MT, j = S % C::NT;
         constexpr int AS = C::ACC2 ? CUR : 0;
-        c.acc[AS][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, c.fw[CUR][kWP[p]][j]),
-                                                                  __builtin_bit_cast(bf16x8, c.fa[CUR][kAP[p]][i]), c.acc[AS][i][j], 0, 0, 0);
+        if constexpr (!C::TIER || (kWP[p] == 0 && kAP[p] == 0))
+            c.acc[AS][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, c.fw[CUR][kWP[p]][j]),
+                                                                      __builtin_bit_cast(bf16x8, c.fa[CUR][kAP[p]][i]), c.acc[AS][i][j], 0, 0, 0);
         constexpr int NWK = X6LRole<C, NL, LID>::NWK;
         constexpr int w0 = (S * NWK) / C::NMMA, w1 = ((S + 1) * NWK) / C::NMMA;
         x6l_sides<C, NL, LID, CUR ^ 1, w0, w1, STEADY>(c, refill, more, slab_new, stage_new, a_next, w_next);
@@ -431,11 +440,12 @@ __device__ __forceinline__ void x6l_main(X6LState<C>& c, int nk) {
 #ifndef X6R_PROF
 #define X6R_PROF 0
 #endif
-template <int MB_, int NBK_, int RS_, int CP_, int SC1_ = 0>
+template <int MB_, int NBK_, int RS_, int CP_, int SC1_ = 0, int TIER_ = 0>
 struct X6RCfg {
-    static constexpr int MB = MB_, NBK = NBK_, RS = RS_, CP = CP_, SC1 = SC1_, NS = 2, KS = 1, CONV = 0, ACC2 = 0;
+    static constexpr int MB = MB_, NBK = NBK_, RS = RS_, CP = CP_, SC1 = SC1_, NS = 2, KS = 1, CONV = 0, ACC2 = 0, TIER = TIER_;
     static constexpr int BM = 16 * MB, BN = 16 * NBK, MT = MB / RS, NT = NBK / CP, NW = RS * CP, AB = MB;
     static constexpr int GA = 3 * MB, GW = 3 * NBK, PPK = GA + GW, STAGE = PPK * 1024;
+    static constexpr int PPKI = TIER ? MB + NBK : PPK;  // pieces ISSUED per slab (TIER 1: the h planes only; the stage keeps its layout)
     static constexpr int PN = MT * NT, NMMA = 6 * PN, NREAD = 3 * (MT + NT);
     static_assert(MB % RS == 0 && NBK % CP == 0 && NW == 8, "tile shape (eight waves)");
     static_assert(NS * STAGE <= 160 * 1024, "ring exceeds the LDS");
@@ -456,8 +466,9 @@ struct X6RState {
 
 template <class C, int I>
 __device__ __forceinline__ void x6r_dma(const X6RState<C>& c, int slab, int stage) {  // issue-order item I: W pieces first
-    constexpr bool isW = I < C::GW;
-    constexpr int q = isW ? I : I - C::GW;
+    constexpr int GWI = C::TIER ? C::NBK : C::GW;
+    constexpr bool isW = I < GWI;
+    constexpr int q = isW ? I : I - GWI;
     constexpr int plane = isW ? q / C::NBK : q / C::MB, grp = isW ? q % C::NBK : q % C::MB;
     constexpr int piece = isW ? C::GA + q : q;
     const unsigned long long src = (isW ? c.w_src : c.a_src) + (unsigned long long)((unsigned)grp * c.rgs + (unsigned)plane * 1024u + (unsigned)slab * 3072u);
@@ -469,7 +480,7 @@ __device__ __forceinline__ void x6r_dma(const X6RState<C>& c, int slab, int stag
 }
 template <class C, int NL, int LID, int W = 0>
 __device__ __forceinline__ void x6r_issue_mine(const X6RState<C>& c, int slab, int stage) {
-    if constexpr (LID >= 0 && LID + NL * W < C::PPK) {
+    if constexpr (LID >= 0 && LID + NL * W < C::PPKI) {
         x6r_dma<C, LID + NL * W>(c, slab, stage);
         x6r_issue_mine<C, NL, LID, W + 1>(c, slab, stage);
     }
@@ -484,6 +495,8 @@ __device__ __forceinline__ void x6r_read(X6RState<C>& c, unsigned a_base, unsign
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c.ah[NXT][R]) : "v"(a_base), "i"((0 * C::BM + R * 16) * 64));
     } else if constexpr (R < MT + NT) {
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c.w[0][R - MT]) : "v"(w_base), "i"((0 * C::BN + (R - MT) * 16) * 64));
+    } else if constexpr (C::TIER) {
+        // (the m and l planes are neither fetched nor read)
     } else if constexpr (R < 2 * MT + NT) {
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c.al[R - MT - NT]) : "v"(a_base), "i"((2 * C::BM + (R - MT - NT) * 16) * 64));
     } else if constexpr (R < 3 * MT + NT) {
@@ -533,9 +546,10 @@ __device__ __forceinline__ void x6r_mma(X6RState<C>& c, bool refill, bool more, 
         constexpr int PN = C::PN, p = S / PN, i = (S % PN) / C::NT, j = S % C::NT;
         constexpr int WP[6] = {0, 0, 0, 1, 1, 2}, AP[6] = {0, 1, 2, 1, 0, 0};  // (W plane, A plane) of product p; 0 = h, 1 = m, 2 = l
         const u32x4& af = AP[p] == 0 ? c.ah[CUR][i] : (AP[p] == 1 ? c.am[i] : c.al[i]);
-        c.acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, c.w[WP[p]][j]), __builtin_bit_cast(bf16x8, af), c.acc[i][j], 0, 0, 0);
+        if constexpr (!C::TIER || p == 0)  // (TIER 1: the h x h product only -- X6Cfg::TIER)
+            c.acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, c.w[WP[p]][j]), __builtin_bit_cast(bf16x8, af), c.acc[i][j], 0, 0, 0);
         // side work behind this MFMA: DMA items (loaders: one per DSP MFMAs), then the reads whose slot this is
-        constexpr int ND = LID < 0 ? 0 : (C::PPK - LID + NL - 1) / NL;
+        constexpr int ND = LID < 0 ? 0 : (C::PPKI - LID + NL - 1) / NL;
         constexpr int DSP = ND > 0 ? (C::NMMA / 2) / ND > 0 ? (C::NMMA / 2) / ND : 1 : 1;
         constexpr bool dma_here = D < ND && S == D * DSP;
         if constexpr (dma_here) {
@@ -602,7 +616,7 @@ __device__ __forceinline__ void x6r_step(X6RState<C>& c, int kt, int nk) {
 // one tile for this wave's role: ring fill, slab 0 published and read, the K loop (nk >= 2, even)
 template <class C, int NL, int LID>
 __device__ __forceinline__ void x6r_tile(X6RState<C>& c, int nk) {
-    constexpr int ND = LID < 0 ? 0 : (C::PPK - LID + NL - 1) / NL;
+    constexpr int ND = LID < 0 ? 0 : (C::PPKI - LID + NL - 1) / NL;
     static_assert(ND < 64, "vmcnt is a 6-bit counter");
     x6r_issue_mine<C, NL, LID>(c, 0, 0);
     x6r_issue_mine<C, NL, LID>(c, 1, 1);

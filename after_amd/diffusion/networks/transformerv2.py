@@ -362,7 +362,10 @@ class DenoiserV2(nn.Module):
     # ------------------------------------------------------------ measurement hooks
     def set_gemm_path(self, mode: int, min_rows: int = 0):
         """Arithmetic path of the qkv / MLP Linears (include/after_hip.h: after_denoiser_set_gemm_path):
-        0 fp32 MFMA; 1 bf16-split kernel for >= min_rows token rows (the default); 2 bf16-split always."""
+        0 fp32 MFMA; 1 bf16-split kernel for >= min_rows token rows (the default); 2 bf16-split always; 3 the OPT-IN bf16
+        tolerance tier (latents within 5e-2 abs / 1e-2 rel-L2 of the fp32 reference): path selection
+        as 1, and the persistent offline samplers issue ONE bf16 MFMA per product block -- the operands' top bf16 planes, fp32
+        accumulate; everything else (LayerNorm, attention, RoPE, GELU, the sampler tail) stays fp32.  Never the default."""
         self._gemm_path = (int(mode), int(min_rows))
         if self._handle is not None:
             _lib.check(_lib.lib().after_denoiser_set_gemm_path(self._handle, int(mode), int(min_rows)),

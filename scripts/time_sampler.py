@@ -17,6 +17,8 @@ T = int(os.environ.get("AFTER_T", "256"))
 x0 = torch.randn(B, 64, T, device=dev)
 cond = torch.randn(B, 6, device=dev)
 tc = torch.randn(B, dcfg["net"]["tcond_dim"], T, device=dev)
+if os.environ.get("AFTER_TIME_GEMM_PATH"):  # 3: the opt-in bf16 tolerance tier
+    net.set_gemm_path(int(os.environ["AFTER_TIME_GEMM_PATH"]))
 out = model.sample(x0, cond, tc, steps, 2.0, 1.0)
 torch.cuda.synchronize()
 if os.environ.get("AFTER_PROFILE_GEMM"):

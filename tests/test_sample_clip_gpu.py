@@ -147,3 +147,28 @@ def test_clip_sampler_other_windows_and_chunk_sizes(cs, window, T, hip_device):
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     want = oracle.sample(sd, ncfg, x0[1:2], cond[1:2], tc[1:2], steps, 2.0, 1.0)
     assert max_abs(got[1:2], want) < 1e-4, max_abs(got[1:2], want)
+
+
+@pytest.mark.parametrize("cfg,B,T", [("base", 8, 256), ("midi", 8, 256), ("base", 5, 320), ("base", 6, 48)])
+def test_clip_sampler_tile_attention_against_the_item_form(cfg, B, T, hip_device):
+    """The two forms of the kernel's attention -- qkv tiles that are heads and attend in place (the default: no qkv rows in
+    memory, the previous row tile's last rows handed over behind a sequence word) and qkv rows + (CFG row, chunk pair) items
+    (diagnostics bit 7, AFTER_CLIP_FUSE=0) -- compute the same fp32 products in the same order up to the softmax's
+    block layout: they agree to round-off, and both with the launch path.  320 frames: five row tiles, CFG-row boundaries inside
+    tiles, two rounds of tiles; 48: one row tile holds the three CFG rows; midi: a window of 16 (every slot of the key tile in front)."""
+    model, _, _ = pipeline.build_models(cfg, "baseAE", hip_device, seed=12)
+    net = model.net
+    x0, cond, tc = _inputs(B, T, 900 + T, net, uniform_tc=cfg == "midi")
+    args = (x0.to(hip_device), cond.to(hip_device), tc.to(hip_device), 3, 2.0, 1.0, -4.0)
+    net.set_sample_persist(False)
+    ref = net.cfg_sample(*args).cpu()
+    net.set_sample_persist(True)
+    fused = net.cfg_sample(*args).cpu()
+    assert net.sample_path() == 2
+    _lib.check(_lib.lib().after_denoiser_set_sample_persist(net._handle, 1 | (128 << 8)), "set_sample_persist")
+    items = net.cfg_sample(*args).cpu()
+    assert net.sample_path() == 2
+    _lib.check(_lib.lib().after_denoiser_set_sample_persist(net._handle, 1), "set_sample_persist")
+    assert torch.isfinite(fused).all()
+    assert max_abs(fused, items) < 2e-5, max_abs(fused, items)
+    assert max_abs(fused, ref) < 5e-5 and max_abs(items, ref) < 5e-5, (max_abs(fused, ref), max_abs(items, ref))
