@@ -129,8 +129,15 @@ int after_denoiser_set_graph(after_denoiser* h, int enable);
  *   1  (default) the bf16-split kernel -- every fp32 operand carried as three bf16 planes, each product formed
  *      as six exact bf16 MFMAs, fp32 accumulation; error vs fp64 <= the fp32 chain's -- for calls with
  *      >= min_rows token rows (rows * T), fp32 MFMA below (streaming chunks);
- *   2  the bf16-split kernel at every size (parity tests).
- * min_rows <= 0 keeps the current threshold.  Environment at create: AFTER_GEMM_X6, AFTER_GEMM_X6_MINROWS. */
+ *   2  the bf16-split kernel at every size (parity tests);
+ *   3  OPT-IN, never a default: the bf16 TOLERANCE TIER (latents within 5e-2 abs / 1e-2 rel-L2 of
+ *      the fp32 result over 50 steps, against 1e-4 for modes 0 - 2).  Path selection as mode 1; the persistent offline
+ *      samplers (one clip at base width, batches of >= 5 clips) then issue ONE bf16 MFMA per product block -- the operands'
+ *      top bf16 planes, i.e. round-to-nearest bf16 of weights and activations, fp32 accumulate -- and fetch only those
+ *      planes; LayerNorm, attention, RoPE, GELU and the sampler tail stay fp32.  Calls that run by launches keep mode 1's
+ *      arithmetic (at least as accurate).  after_denoiser_gemm_path reports 3 while the tier is on; any other mode
+ *      switches it off (bit-identical results to before).
+ * min_rows <= 0 keeps the current threshold.  Environment at create: AFTER_GEMM_X6 (0 - 2), AFTER_GEMM_X6_MINROWS. */
 int after_denoiser_set_gemm_path(after_denoiser* h, int mode, int min_rows);
 int after_denoiser_gemm_path(after_denoiser* h, int* mode, int* min_rows);
 
@@ -184,7 +191,9 @@ int after_denoiser_set_stream_persist(after_denoiser* h, int enable);
  *
  * BATCHES (B >= 5 clips; BASELINE config 3's per-GPU shard, config 4): one persistent launch with ONE CLIP PER XCD (clips 8 .. on
  * the same XCDs, one after the other) -- no cross-XCD word at all; the Linears on LDS-staged bf16 x 3 tiles (192 x 192 /
- * 96 x 128) fed by four loader waves per workgroup.  Eligible: the shipped width, T % 16 == 0 and T <= 1024 frames within
+ * 96 x 128) fed by four loader waves per workgroup; a qkv tile is one head of 192 token rows and attends in place (no qkv
+ * rows in memory; window - 1 <= 16 and 16 % chunk == 0, else qkv rows + attention items: also AFTER_CLIP_FUSE=0).
+ * Eligible: base width (embed 512), T % 16 == 0 and T <= 1024 frames within
  * the handle's capacity, finite causal window, gemm path != 0, no graph replay; provisioned (+ 15.5 MB per XCD at T = 256)
  * when the handle is created with max_rows >= 15.  AFTER_SAMPLE_CLIP=0 keeps batches on the launch path,
  * AFTER_SAMPLE_CLIP_MINB=n moves the threshold.

@@ -58,6 +58,28 @@ for cfgb in "midi 8" "base 6" "base 16"; do set -- $cfgb
   AFTER_SAMPLE_CLIP=0 python scripts/time_sampler.py $1 $2 50 3 2>/dev/null | tail -1 | sed 's/^/launch path:      /' >> $O/${R}_ab_sample_clip.txt
   python scripts/time_sampler.py $1 $2 50 3 2>/dev/null | tail -1 | sed 's/^/clip-per-XCD:     /' >> $O/${R}_ab_sample_clip.txt
 done
+# round 5b: the attention inside the qkv tiles against the item form (AFTER_CLIP_FUSE), same box, interleaved; the opt-in bf16
+# tolerance tier against the default arithmetic (sampler alone + the separate bench legs); tiny on the persistent one-clip sampler
+for rep in 1 2; do
+  for cfg in base midi; do
+    AFTER_CLIP_FUSE=0 python scripts/time_sampler.py $cfg 8 50 3 2>/dev/null | tail -1 | cut -c1-90 | sed 's/^/qkv rows + items:      /' >> $O/${R}_ab_clip_fuse.txt
+    python scripts/time_sampler.py $cfg 8 50 3 2>/dev/null | tail -1 | cut -c1-90 | sed 's/^/tiles attend in place: /' >> $O/${R}_ab_clip_fuse.txt
+  done
+done
+for b in 1 8; do
+  for m in 1 3 1 3; do
+    AFTER_TIME_GEMM_PATH=$m python scripts/time_sampler.py base $b 50 5 2>/dev/null | tail -1 | cut -c1-90 | sed "s/^/gemm path $m: /" >> $O/${R}_ab_bf16_tier.txt
+  done
+done
+python bench.py --bf16-tier --steps 20 --warmup 5 --no-cpu-baseline > $O/${R}_bench_bf16_tier_b1.json 2> $O/bench_tier.err
+python bench.py --bf16-tier --steps 6 --warmup 2 --batch-per-gpu 8 --no-cpu-baseline > $O/${R}_bench_bf16_tier_b8.json 2>> $O/bench_tier.err
+for p in 0 1 0 1; do
+  AFTER_SAMPLE_PERSIST=$p python scripts/time_sampler.py tiny 1 50 7 2>/dev/null | tail -1 | cut -c1-90 | sed "s/^/AFTER_SAMPLE_PERSIST=$p: /" >> $O/${R}_ab_tiny_persist.txt
+done
+AFTER_T=192 python scripts/time_sampler.py base 1 50 5 2>/dev/null | tail -1 | cut -c1-90 | sed 's/^/T=192 persistent (6 segments): /' >> $O/${R}_ab_tiny_persist.txt
+AFTER_T=192 AFTER_SAMPLE_PERSIST=0 python scripts/time_sampler.py base 1 50 5 2>/dev/null | tail -1 | cut -c1-90 | sed 's/^/T=192 launches:                /' >> $O/${R}_ab_tiny_persist.txt
+AFTER_T=64 python scripts/time_sampler.py base 1 50 5 2>/dev/null | tail -1 | cut -c1-90 | sed 's/^/T=64 persistent (4 segments):  /' >> $O/${R}_ab_tiny_persist.txt
+AFTER_T=64 AFTER_SAMPLE_PERSIST=0 python scripts/time_sampler.py base 1 50 5 2>/dev/null | tail -1 | cut -c1-90 | sed 's/^/T=64 launches:                 /' >> $O/${R}_ab_tiny_persist.txt
 python scripts/stream_step_trace.py --offline --clips 8 --xcd 3 2>/dev/null | grep -v amdgpu.ids > $O/${R}_clip_step_trace.txt
 python scripts/persist_check_cost.py > $O/${R}_persist_check_cost.jsonl 2>/dev/null
 python scripts/seg_context.py 2>/dev/null | tail -9 > $O/${R}_clip_breakdown_b1.txt
