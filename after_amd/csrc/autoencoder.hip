@@ -602,6 +602,20 @@ int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const 
         h->prepared = r.y2;
     }
     h->next_alpha = h->next_invb = nullptr;
+    // GroupNorm -> Snake -> Conv1d(k = 1) + residual (the second conv of a ResnetBlock1d) as ONE launch where the tensor fills
+    // the chip with row tiles of all channels: no activated tensor, no act_pad launch (conv_tm.hip: conv1_act_kernel)
+    if (!xin && !r.y2 && d.in.taps == 1 && d.in.phases == 1 && d.in.istride == 1 && d.in.ostride == 1 && d.in.toff[0][0] == 0 &&
+        cin == cout && !x_cm && !y_cm && !state && !h->pass_stream && !h->pass_gnwin && act == ACT_SNAKE && Tin == Tout && Nn == Tout &&
+        stat_T == 0 && conv1_act_eligible(B, Tin, cin, cin < 8 ? cin : 8, stats_in || r.stats)) {
+        Conv1ActRun c;
+        memset(&c, 0, sizeof(c));
+        c.x = x, c.stats_in = stats_in, c.gamma = gamma, c.beta = beta, c.act_a = alpha, c.act_b = invb;
+        c.w = d.w, c.ldw = d.tplan.K, c.bias = bias, c.res = res, c.y = y, c.stats_out = r.stats;
+        c.B = B, c.T = Tin, c.C = cin, c.G = cin < 8 ? cin : 8, c.act = act, c.sub_stride = r.sub_stride;
+        static const bool trace_k1 = getenv("AFTER_AE_TRACE") != nullptr;
+        if (trace_k1) fprintf(stderr, "ae conv: B %d T %d C %d k 1 res %d stats %d -> conv1_act (fused GroupNorm + Snake + conv)\n", B, Tin, cin, res != nullptr, r.stats != nullptr);
+        return launch_conv1_act(c, s);
+    }
     // MFMA-bound whole-clip launches run on the bf16 pipe (conv_x6.hip): their input is written as bf16 planes
     const bool x6 = !xin && d.w3 && !h->pass_stream && !x_cm && conv_x6_wins(r, d.in, d.tplan) &&
                     conv_x6_plane_elems(B, Tin, cin) <= h->xp3_elems;

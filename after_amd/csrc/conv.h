@@ -155,6 +155,21 @@ void conv_tm_plan(const ConvDmaPlanIn& in, ConvTmPlan* p);
 int conv_tm_repack(const float* packed, float* out, const ConvDmaPlanIn& in, const ConvTmPlan& p, hipStream_t s);
 int launch_conv_tm(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan& p, hipStream_t s);
 int launch_act_pad_tm(const ActPadTm& p, hipStream_t s);
+// ---- GroupNorm -> activation -> Conv1d(k = 1) (+ residual) as ONE launch (conv_tm.hip: conv1_act_kernel): no activated tensor
+struct Conv1ActRun {
+    const float* x;          // [B][T][ldx] time-major raw input
+    const double* stats_in;  // the producer's accumulators of x (GroupNorm), or nullptr
+    const float *gamma, *beta, *act_a, *act_b;
+    const float* w;          // conv_tm_repack output of the k = 1 conv: [C][ldw]
+    const float* bias;
+    const float* res;        // [B][T][res_ld] or nullptr (may alias y)
+    float* y;                // [B][T][y_ld]
+    double* stats_out;       // accumulators of y (ConvTmRun::stats) or nullptr
+    int B, T, C, G, act, ldx, ldw, res_ld, y_ld, sub_stride;
+};
+bool conv1_act_eligible(int B, int T, int C, int G, bool stats);
+int launch_conv1_act(const Conv1ActRun& r, hipStream_t s);
+long long conv1_act_launches();
 // ---- the same convs through the bf16 matrix pipe (conv_x6.hip): stride-1 convs of <= 3 taps, operands as bf16 planes
 constexpr int kConvTmHalo = 32;  // == conv_tm_halo()
 int conv_x6_rows(int T);                          // plane rows per clip: conv_tm_rows(T) rounded up to 16

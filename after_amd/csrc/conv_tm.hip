@@ -1119,6 +1119,199 @@ int launch_tm_id(int id, const ConvTmArgs& a, int B, bool dil, hipStream_t s) {
     return AFTER_E_INVALID;
 }
 
+
+// =====================================================================================================
+// ConvBlock1d with a k = 1 conv in ONE launch (the second conv of every ResnetBlock1d: GroupNorm -> SnakeBeta -> Conv1d(k = 1)
+// + residual, SimpleNetsStream.py:150-194, :196-254): the activated tensor never exists in memory.  A k = 1 conv needs no
+// halo and no neighbour rows, so a workgroup that owns BM rows of ALL output channels activates its input rows exactly once:
+// raw rows -> registers (requested first, beside the first weight fragments), the producer's GroupNorm statistics -> per-channel
+// scale / shift (gn_mean_rstd), act(x * sc + sh) -> an fp32 tile in LDS, then Y^T = W A^T as v_mfma_f32_16x16x4_f32 (the exact
+// fp32 fma chain of conv_tm's own MFMAs) with the weight fragments streamed from the L2 through a four-deep register ring -- wave w
+// owns the column blocks [w NBW, (w + 1) NBW) for all BM rows -- and conv_x6's epilogue: bias, residual, fp32 rows, the NEXT
+// GroupNorm's statistics through binned integer accumulators.  Against act_pad + conv it saves a launch, the activated tensor's
+// write (fp32, or 1.5 x that as bf16 planes) and its read.
+struct Conv1ActArgs {
+    const float* x;        // [B * T][ldx] time-major raw input
+    const double* stats_in;  // accumulators of x (GroupNorm) or nullptr
+    const float *gamma, *beta, *act_a, *act_b;
+    const float* w;        // [C][ldw]: conv_tm's GEMM operand of a k = 1 conv
+    const float* bias;
+    const float* res;      // [B * T][res_ld] or nullptr (may alias y)
+    float* y;              // [B * T][y_ld]
+    double* stats_out;     // accumulators of y or nullptr
+    int ldx, ldw, res_ld, y_ld, T, C, G, sub_stride, act;
+    float eps;
+};
+
+template <int NW, int NBW, int MB>  // waves, 16-column blocks per wave (C = 16 NBW NW), 16-row blocks per workgroup
+__global__ __launch_bounds__(64 * NW) void conv1_act_kernel(Conv1ActArgs a) {
+    constexpr int NT = 64 * NW, BM = 16 * MB, C = 16 * NBW * NW, LDA = C + 4, Q = C / 4, PD = 4;
+    constexpr int NLD = BM * Q / NT;  // 16-byte pieces of the raw tile per thread
+    static_assert((BM * Q) % NT == 0, "raw tile pieces per thread");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const At = smem;                 // [BM][LDA]
+    float* const prm = smem + BM * LDA;     // sc | sh | pa | pb, [4][C]
+    __shared__ float gmean[16], grstd[16];
+    __shared__ __attribute__((aligned(16))) long long swl[16 * kStatSub * kStatWords];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * BM, b = m0 / a.T;
+    const int n0 = w * NBW * 16, fr = lane & 15, fq = lane >> 4;
+    // ---- requests first: the raw rows and the first weight fragments (one exposed memory latency for the whole prologue)
+    f32x4 xv[NLD];
+#pragma clang loop unroll(full)
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + NT * i, r = idx / Q, q = idx - r * Q;
+        xv[i] = *reinterpret_cast<const f32x4*>(a.x + (size_t)(m0 + r) * a.ldx + 4 * q);
+    }
+    f32x4 wf[PD][NBW];
+    const float* wl = a.w + (size_t)(n0 + fr) * a.ldw + 4 * fq;  // lane (fr, fq): row n0 + 16 j + fr, k = 16 kb + 4 fq .. + 3
+    constexpr int NKB = C / 16;
+#pragma unroll
+    for (int u = 0; u < PD - 1; ++u)
+#pragma unroll
+        for (int j = 0; j < NBW; ++j)
+            wf[u][j] = u < NKB ? *reinterpret_cast<const f32x4*>(wl + (size_t)16 * j * a.ldw + 16 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // ---- per-channel scale / shift of the GroupNorm (or none), Snake parameters -> LDS.  Every parameter of this thread's
+    //      channels is requested before the statistics are waited for: one memory latency, not one per parameter
+    constexpr int PK = (C + NT - 1) / NT;
+    float pg[PK], pbe[PK], ppa[PK], ppb[PK];
+#pragma unroll
+    for (int k = 0; k < PK; ++k) {
+        const int c = min(tid + NT * k, C - 1);
+        pg[k] = a.gamma ? a.gamma[c] : 1.f;
+        pbe[k] = a.gamma ? a.beta[c] : 0.f;
+        ppa[k] = a.act_a ? a.act_a[c] : 0.f;
+        ppb[k] = a.act_b ? a.act_b[c] : 0.f;
+    }
+    if (a.stats_in) gn_mean_rstd(a.stats_in, b, a.G, a.sub_stride, C, a.T, a.eps, swl, gmean, grstd, NT);
+#pragma unroll
+    for (int k = 0; k < PK; ++k) {
+        const int c = tid + NT * k;
+        if (c < C) {
+            float sc = pg[k], sh = pbe[k];
+            if (a.stats_in) {
+                const int g = c / (C / a.G);
+                sc = grstd[g] * sc;
+                sh = sh - gmean[g] * sc;
+            }
+            prm[c] = sc;
+            prm[C + c] = sh;
+            prm[2 * C + c] = ppa[k];
+            prm[3 * C + c] = ppb[k];
+        }
+    }
+    __syncthreads();
+    // ---- activate the tile into LDS
+#pragma clang loop unroll(full)
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + NT * i, r = idx / Q, q = idx - r * Q;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(prm + 4 * q), sh = *reinterpret_cast<const f32x4*>(prm + C + 4 * q);
+        const f32x4 pa = *reinterpret_cast<const f32x4*>(prm + 2 * C + 4 * q), pb = *reinterpret_cast<const f32x4*>(prm + 3 * C + 4 * q);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = act_apply(xv[i][k] * sc[k] + sh[k], a.act, pa[k], pb[k]);
+        *reinterpret_cast<f32x4*>(At + r * LDA + 4 * q) = o;
+    }
+    __syncthreads();
+    // ---- Y^T = W A^T: the W fragment as srcA (the accumulator holds four consecutive columns of one row per lane)
+    f32x4 acc[MB][NBW];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (the epilogue's operands -- bias, the residual tile -- are requested in front of the K loop and land under its MFMAs)
+    f32x4 bvv[NBW], rvv[MB][NBW];
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+        const int gn = n0 + 16 * j + 4 * fq;
+        bvv[j] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + gn) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+            rvv[i][j] = a.res ? *reinterpret_cast<const f32x4*>(a.res + (size_t)(m0 + 16 * i + fr) * a.res_ld + gn) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float* al = At + fr * LDA + 4 * fq;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {  // (fully unrolled: the ring slot of a k-block is a compile-time register set)
+        if (kb + PD - 1 < NKB) {
+#pragma unroll
+            for (int j = 0; j < NBW; ++j)
+                wf[(kb + PD - 1) % PD][j] = *reinterpret_cast<const f32x4*>(wl + (size_t)16 * j * a.ldw + 16 * (kb + PD - 1));
+        }
+        f32x4 af[MB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) af[i] = *reinterpret_cast<const f32x4*>(al + 16 * i * LDA + 16 * kb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < NBW; ++j)
+#pragma unroll
+                for (int i = 0; i < MB; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kb % PD][j][r], af[i][r], acc[i][j], 0, 0, 0);
+    }
+    // ---- epilogue: bias, residual, rows; statistics of the next GroupNorm (conv_x6's: butterfly over the 16 rows of a lane
+    //      quad, binned integer accumulators in LDS, the non-zero words on to the global ones)
+    long long* const lbins = swl;  // [G][kStatWords] (the input statistics' staging area is done with)
+    if (a.stats_out) {
+        __syncthreads();
+        for (int i = tid; i < a.G * kStatWords; i += NT) lbins[i] = 0;
+    }
+    const int Cg = C / (a.G > 0 ? a.G : 1);
+    float ssum[NBW], qsum[NBW];
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+        const int gn = n0 + 16 * j + 4 * fq;
+        ssum[j] = qsum[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const size_t row = (size_t)(m0 + 16 * i + fr);
+            const f32x4 o = (acc[i][j] + bvv[j]) + rvv[i][j];
+            *reinterpret_cast<f32x4*>(a.y + row * a.y_ld + gn) = o;
+            ssum[j] += (o[0] + o[1]) + (o[2] + o[3]);
+            qsum[j] += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+        }
+    }
+    if (a.stats_out) {
+#pragma unroll
+        for (int j = 0; j < NBW; ++j)
+#pragma unroll
+            for (int o2 = 1; o2 < 16; o2 <<= 1) {
+                ssum[j] += __shfl_xor(ssum[j], o2, 64);
+                qsum[j] += __shfl_xor(qsum[j], o2, 64);
+            }
+        __syncthreads();  // the bins are zero
+        if (fr == 0) {
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) {
+                long long* bp = lbins + ((n0 + 16 * j + 4 * fq) / Cg) * kStatWords;
+                stat_bins_add(bp, ssum[j]);
+                stat_bins_add(bp + kStatBins, qsum[j]);
+            }
+        }
+        __syncthreads();
+        if (tid < a.G * kStatWords) {
+            const long long v = lbins[tid];
+            if (v) {
+                long long* sp = reinterpret_cast<long long*>(a.stats_out) + (size_t)(blockIdx.x % kStatSub) * a.sub_stride +
+                                (size_t)b * a.G * kStatWords + tid;
+                atomicAdd(reinterpret_cast<unsigned long long*>(sp), (unsigned long long)v);
+            }
+        }
+    }
+}
+
+template <int NW, int NBW, int MB>
+int launch_conv1_act_cfg(const Conv1ActArgs& a, long long rows, hipStream_t s) {
+    constexpr int BM = 16 * MB, C = 16 * NBW * NW;
+    const size_t lds = ((size_t)BM * (C + 4) + 4 * C) * sizeof(float);
+    static LdsAttr attr;
+    AFTER_TRY(ensure_lds_attr(attr, reinterpret_cast<const void*>(conv1_act_kernel<NW, NBW, MB>), lds));
+    hipLaunchKernelGGL((conv1_act_kernel<NW, NBW, MB>), dim3((unsigned)(rows / BM)), dim3(64 * NW), lds, s, a);
+    AFTER_HIP_CHECK(hipGetLastError());
+    return AFTER_OK;
+}
+
+long long g_conv1_act_launches = 0;
+
 }  // namespace
 
 int conv_tm_halo() { return HALO; }
@@ -1133,6 +1326,51 @@ int snake_variant(int act) {
         libm = e ? atoi(e) : 0;
     }
     return act == ACT_SNAKE && libm ? ACT_SNAKE_LIBM : act;
+}
+
+// Is GroupNorm -> Snake -> Conv1d(k = 1) (+ residual) of this size one launch of conv1_act_kernel?  The narrow, long stages
+// (64 / 96 / 128 channels at T >= 12288: the decoder's last stage, the encoder's first two), where act_pad + conv are two
+// bandwidth- and latency-bound launches: 14.7 us against 11 + 16 at one clip, 52.7 against 31 + 33 at eight (64 channels at
+// T = 32768).  Measured and left on the two launches: 192 channels (37.6 us against 11 + 16 / 190 against 33 + 77) and 384
+// (41.9 against 19 + 22 / 185 against 42 + 123) -- there the conv is MFMA-bound, and the fp32 MFMAs of this kernel lose to the
+// bf16-pipe conv by more than the activated tensor's round trip costs.
+bool conv1_act_eligible(int B, int T, int C, int G, bool stats) {
+    static int on = -1;  // AFTER_AE_FUSE_K1=0: A/B switch (act_pad + conv launches)
+    if (on < 0) {
+        const char* e = getenv("AFTER_AE_FUSE_K1");
+        on = e ? atoi(e) : 1;
+    }
+    if (!on) return false;
+    if (C != 64 && C != 96 && C != 128) return false;
+    const int BM = 64;
+    if (T % BM) return false;
+    if (stats && (G < 1 || G > 16 || C % G || ((C / G) & 3))) return false;
+    return (long long)B * T / BM >= 192;
+}
+
+long long conv1_act_launches() { return g_conv1_act_launches; }
+
+int launch_conv1_act(const Conv1ActRun& r, hipStream_t s) {
+    AFTER_REQUIRE(conv1_act_eligible(r.B, r.T, r.C, r.G, r.stats_in || r.stats_out), AFTER_E_INVALID, "conv1_act: not a fused launch");
+    Conv1ActArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = r.x, a.stats_in = r.stats_in, a.gamma = r.gamma, a.beta = r.beta, a.act_a = r.act_a, a.act_b = r.act_b;
+    a.w = r.w, a.bias = r.bias, a.res = r.res, a.y = r.y, a.stats_out = r.stats_out;
+    a.ldx = r.ldx > 0 ? r.ldx : r.C, a.ldw = r.ldw, a.res_ld = r.res_ld > 0 ? r.res_ld : r.C, a.y_ld = r.y_ld > 0 ? r.y_ld : r.C;
+    a.T = r.T, a.C = r.C, a.G = r.G, a.sub_stride = r.sub_stride, a.act = snake_variant(r.act), a.eps = 1e-5f;
+    AFTER_REQUIRE((a.ldx & 3) == 0 && (a.ldw & 3) == 0 && (a.res_ld & 3) == 0 && (a.y_ld & 3) == 0 && ((uintptr_t)r.x & 15) == 0 &&
+                      ((uintptr_t)r.w & 15) == 0 && ((uintptr_t)r.y & 15) == 0 && (!r.res || ((uintptr_t)r.res & 15) == 0) &&
+                      (!r.bias || ((uintptr_t)r.bias & 15) == 0),
+                  AFTER_E_INVALID, "conv1_act: operand alignment");
+    const long long rows = (long long)r.B * r.T;
+    ++g_conv1_act_launches;
+    switch (r.C) {
+        case 64: return launch_conv1_act_cfg<4, 1, 4>(a, rows, s);
+        case 96: return launch_conv1_act_cfg<2, 3, 4>(a, rows, s);
+        case 128: return launch_conv1_act_cfg<4, 2, 4>(a, rows, s);
+        default: break;
+    }
+    return AFTER_E_INVALID;
 }
 
 int launch_act_pad_tm(const ActPadTm& p, hipStream_t s) {
@@ -1564,4 +1802,4 @@ extern "C" int after_convtm_run(after_convtm* h, const float* x, float* y, int m
     }
     return AFTER_OK;
 }
-
+extern "C" long long after_conv1_act_launches(void) { return after::conv1_act_launches(); }

@@ -128,6 +128,11 @@ def conv_x6_launches() -> int:
     return int(_lib.lib().after_conv_x6_launches())
 
 
+def conv1_act_launches() -> int:
+    """GroupNorm -> Snake -> Conv1d(k = 1) blocks this process has run as one launch (conv_tm.hip: conv1_act_kernel)."""
+    return int(_lib.lib().after_conv1_act_launches())
+
+
 def set_conv_x6_tile(tile_id: int):
     """Tile of the bf16-pipe convs: 0 = by shape, 1..8 pin one (conv_x6.hip: launch_conv_x6)."""
     _lib.lib().after_convtm_set_x6_tile(int(tile_id))

@@ -530,6 +530,10 @@ void after_convtm_set_x6_tile(int id);
 /* number of conv launches this process has sent down the bf16-pipe path so far (diagnostic: the tests check that the
    decoder's MFMA-bound convs take it by default and that AFTER_CONV_X6=0 keeps them off it) */
 long long after_conv_x6_launches(void);
+/* number of GroupNorm -> Snake -> Conv1d(k = 1) blocks (the second conv of a ResnetBlock1d, SimpleNetsStream.py:196-254) this
+   process has run as ONE launch (conv_tm.hip: conv1_act_kernel -- no activated tensor in memory) instead of act_pad + conv;
+   AFTER_AE_FUSE_K1=0 keeps them on the two launches (A/B switch) */
+long long after_conv1_act_launches(void);
 
 #ifdef __cplusplus
 }

@@ -54,13 +54,16 @@ def test_base_codec_full_clip_vs_oracle(base, hip_device):
     yw = oracle.ae_decode(sd, z, acfg)
     zw = oracle.ae_encode(sd, audio, acfg)
     from after_amd import diag
-    n0 = diag.conv_x6_launches()
+    n0, m0 = diag.conv_x6_launches(), diag.conv1_act_launches()
     y = ae.decode(z.to(hip_device)).cpu()
     # the decoder's MFMA-bound convs (384 / 192 channels at T >= 4096) run on the bf16 pipe by default (conv_x6.hip):
     # the oracle comparison below is a comparison of THAT path, not of a silent fallback to the fp32 kernel
     import os
     if os.environ.get("AFTER_CONV_X6", "1") != "0":
         assert diag.conv_x6_launches() - n0 >= 8, diag.conv_x6_launches() - n0
+    # ... and the GroupNorm -> Snake -> k = 1 convs of the last stage's ResnetBlock1ds as ONE launch each (conv1_act_kernel)
+    if os.environ.get("AFTER_AE_FUSE_K1", "1") != "0":
+        assert diag.conv1_act_launches() - m0 >= 3, diag.conv1_act_launches() - m0
     zg, reg = ae.encode(audio.to(hip_device))
     assert y.shape == yw.shape == (1, 1, 524288) and zg.shape == zw.shape == (1, 64, 256)
     assert max_abs(y, yw) < 1e-4 * yw.abs().max().item(), (max_abs(y, yw), yw.abs().max().item(), rel_l2(y, yw))
