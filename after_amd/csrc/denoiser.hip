@@ -709,7 +709,8 @@ constexpr int kSGroupRows = 96;                 // token rows one XCD can own (o
 
 struct StepSync {
     unsigned arrive[8][32];  // [xcc][0]: arrivals (each word on its own 128-byte line)
-    unsigned gen[8][32];     // (unused since round 4b)
+    unsigned gen[8][32];     // [xcc][rank]: batch sampler -- the last qkv round whose hand-over rows workgroup `rank` has published, + 1
+                             // (clip_tile_attention; zeroed per launch with the words above.  The barrier's generation word until round 4b)
     unsigned flag[8][32][32];  // [xcc][rank][0]: the last round workgroup `rank` of the XCC has arrived at (one line each)
     unsigned pop[8][32];     // [xcc][0]: workgroups resident on the XCC
     unsigned census[32];     // [0]: workgroups counted
