@@ -656,6 +656,22 @@ int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const 
     return launch_conv_tm(r, d.in, d.tplan, s);
 }
 
+// Would run_dma send this conv down the bf16 pipe (conv_x6.hip) if its input came through act_pad?  Decides whether a producer
+// hands it the activated tensor as its own second output (fp32: the consumer then stays on the fp32 conv) or leaves the
+// activation to an act_pad launch that writes bf16 planes.  Measured on the decoder's ConvTranspose phases at eight clips:
+// 244 us per launch on the fp32 conv against ~130 + an act_pad of 42 -- decode 6.86 -> 6.51 ms (one clip: 1.45 -> 1.43).
+bool dma_takes_x6(const after_ae* h, const DmaConv& d, int B, int Tin, int Nn, int Tout) {
+    if (!d.w3 || h->pass_stream) return false;
+    static const int always = [] { const char* e = getenv("AFTER_AE_FUSE_SNAKE"); return e && atoi(e) == 2; }();  // A/B: round 4's rule
+    if (always) return false;
+    ConvTmRun r;
+    memset(&r, 0, sizeof(r));
+    r.B = B, r.Tp = conv_tm_rows(Tin), r.Tout = Tout, r.Nn = Nn;
+    r.G = d.in.Cout < 8 ? d.in.Cout : 8;
+    if (h->norm && !h->pass_gnwin) r.stats = reinterpret_cast<double*>(h->stats_ring);  // (a non-null marker: the resampling convs accumulate statistics)
+    return conv_x6_wins(r, d.in, d.tplan) && conv_x6_plane_elems(B, Tin, d.in.Cin) <= h->xp3_elems;
+}
+
 // ConvBlock1d on the DMA path
 int run_convblock2(after_ae* h, hipStream_t s, const ConvBlockW& cb, const float* x,
                    const double* stats_x, float* y, const float* res, int B, int T, bool want_stats,
@@ -1605,7 +1621,10 @@ static int decode_impl(after_ae* h, const float* z, float* x, float* mb, int B, 
         t1 = o;
         T *= u.f;
         for (int j = 0; j < nd; ++j) {
-            const bool feed = j == nd - 1 && i + 1 < n;  // the next stage starts with Snake -> ConvTranspose
+            // the next stage starts with Snake -> ConvTranspose: its activated input is this block's second output -- unless
+            // that conv is worth the bf16 pipe, whose bf16-plane input an act_pad launch writes (dma_takes_x6)
+            const bool feed = j == nd - 1 && i + 1 < n &&
+                              !dma_takes_x6(h, h->streaming ? h->dec_up[i + 1].d_stream : h->dec_up[i + 1].d, B, T, T, T * h->dec_up[i + 1].f);
             AFTER_TRY(run_resblock2(h, s, h->dec_res[i][j], cur, t1, t2, B, T, &st, sb,
                                     feed ? h->dec_up[i + 1].alpha : nullptr,
                                     feed ? h->dec_up[i + 1].invb : nullptr));
