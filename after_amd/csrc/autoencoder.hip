@@ -532,7 +532,7 @@ int make_dma(after_ae* h, DmaConv& d, const float* packed, int cin, int cout, in
     AFTER_REQUIRE(d.w, AFTER_E_NOMEM, "autoencoder: conv weight arena exhausted");
     AFTER_TRY(conv_tm_repack(packed, d.w, d.in, d.tplan, 0));
     d.w3 = nullptr;
-    if (conv_x6_mode() && conv_x6_eligible(d.in, d.tplan) && cout >= 64 && d.tplan.K >= 256) {
+    if (conv_x6_mode() && conv_x6_eligible(d.in, d.tplan) && cout >= 64 && d.tplan.K >= 192) {
         d.w3 = h->wd.take<unsigned short>(conv_x6_weight_elems(d.in, d.tplan));
         AFTER_REQUIRE(d.w3, AFTER_E_NOMEM, "autoencoder: conv weight arena exhausted");
         AFTER_TRY(conv_x6_split(d.w, d.w3, d.in, d.tplan, 0));

@@ -364,7 +364,9 @@ bool conv_x6_wins(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan&
     // 4.61 -> 4.41 ms on one box, 4.61 -> 4.71 on two others, the fp32 path within 0.3 % on all of them: the 1.5x
     // larger plane tensors push the pass's working set past the 256-MB Infinity Cache).  AFTER_CONV_X6=2 runs them here.
     if (in.Cout % 96) return false;
-    return wgs >= 200 && p.K >= 256 && in.Cout >= 64;
+    // (K = 192 -- the 192-channel k = 1 convs, six slabs -- only where the launch is several rounds of tiles: eight clips at
+    //  T = 16384 act_pad 52 + conv 137 us on the fp32 path; decode 6.60 -> 6.42 ms; at one clip the fp32 conv's 16 us stand)
+    return wgs >= 200 && (p.K >= 256 || (p.K >= 192 && wgs >= 1024)) && in.Cout >= 64;
 }
 
 int launch_conv_x6(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan& p, hipStream_t s) {
