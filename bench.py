@@ -352,7 +352,8 @@ def persist_roofline(model, run_once, dcfg, B, config, nb_steps):
     gemm_fl = 2.0 * M * E_ * ME_  # one qkv / MLP-up / MLP-down GEMM over all clips (3E = ME at mlp x 3)
     net.profile(True, min_flops=0.0, kernel=3)
     torch.cuda.synchronize()
-    run_once()
+    for _ in range(4):  # (back to back like the timed region: a single step behind a synchronisation starts at idle clocks -- its
+        run_once()      #  launch measured 5 % longer than the same launch inside a train of steps)
     torch.cuda.synchronize()
     ms, launches, flops, nbytes = net.gemm_time(with_bytes=True)
     net.profile(False)
