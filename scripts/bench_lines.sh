@@ -10,3 +10,9 @@ python bench.py --steps 5 --warmup 2 --from-audio --no-cpu-baseline > $O/${R}_be
 python bench.py --bf16-tier --steps 20 --warmup 5 --no-cpu-baseline > $O/${R}_bench_bf16_tier_b1.json 2> $O/tier.err
 python bench.py --bf16-tier --steps 6 --warmup 2 --batch-per-gpu 8 --no-cpu-baseline > $O/${R}_bench_bf16_tier_b8.json 2>> $O/tier.err
 ls -la $O | head -20
+# same-box A/B of the two conditioning encoders side by side (default) against one after the other
+for m in 0 1 0 1; do
+  AFTER_ENCODERS_CONCURRENT=$m python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'leg': 'b1', 'AFTER_ENCODERS_CONCURRENT': $m, 'ms_per_step': d['ms_per_step'], 'xrt': d['value']}))" >> $O/${R}_ab_encoders_concurrent.jsonl
+  AFTER_ENCODERS_CONCURRENT=$m python bench.py --steps 6 --warmup 2 --batch-per-gpu 8 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'leg': 'b8', 'AFTER_ENCODERS_CONCURRENT': $m, 'ms_per_step': d['ms_per_step'], 'xrt': d['value']}))" >> $O/${R}_ab_encoders_concurrent.jsonl
+done
+cat $O/${R}_ab_encoders_concurrent.jsonl
