@@ -1,11 +1,9 @@
 """Convenience bundle of the hot path as the reference's notebooks drive it
 (notebooks/audio_to_audio_demo.ipynb cells 5, 19): conditioning encoders ->
 RectifiedFlow.sample -> AutoEncoder.decode.  Only composes the drop-in classes."""
-import os
-
 import torch
 
-from . import configs
+from . import _streams, configs
 from .autoencoder import AutoEncoder
 from .diffusion import DenoiserV2, ECAPATDNN, Encoder1D, RectifiedFlow
 
@@ -35,28 +33,17 @@ def build_models(diffusion: str = "base", autoencoder: str = "baseAE", device="c
     return model, dcfg, acfg
 
 
-_CONCURRENT_ENCODERS = os.environ.get("AFTER_ENCODERS_CONCURRENT", "1") != "0"  # A/B switch: 0 = one after the other
-_SIDE_STREAMS = {}
-
-
-def _side_stream(device):
-    key = torch.device(device).index
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-    return _SIDE_STREAMS[key]
-
-
 @torch.no_grad()
 def generate_from_latents(model: RectifiedFlow, z_structure, z_timbre, x0, nb_steps=50,
                           guidance_timbre=2.0, guidance_structure=1.0, n_signal_timbre=128,
                           time_cond=None):
     """latents -> audio.  cond = encoder(z_timbre[..., :n_signal]); time_cond =
     encoder_time(z_structure) (or the given piano-roll for MIDI models)."""
-    if time_cond is None and z_structure.is_cuda and _CONCURRENT_ENCODERS:
+    if time_cond is None and z_structure.is_cuda and _streams.CONCURRENT:
         # the two conditioning encoders are independent, ~40 launches of a few microseconds each (latency chains: 0.26 + 0.20 ms
         # at one clip): the structure encoder runs on a side stream beside the timbre encoder, the sampler waits for both
         cur = torch.cuda.current_stream(z_structure.device)
-        side = _side_stream(z_structure.device)
+        side = _streams.side_stream(z_structure.device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             time_cond = model.encoder_time(z_structure)
