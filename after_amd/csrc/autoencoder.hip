@@ -1245,6 +1245,7 @@ extern "C" int after_ae_enable_encoder_streaming(after_ae* h, int enable, int gn
             (void)set_taps(h->enc_tail.d, h->enc_tail.d.toff_offline, false);
         }
         h->enc_cached = false;
+        h->nc_rows = 0;  // (the stream set ends with the cached encoder: a later enable starts from zeroed contexts)
         return AFTER_OK;
     }
     AFTER_REQUIRE(!h->causal, AFTER_E_INVALID,
@@ -1320,6 +1321,7 @@ extern "C" int after_ae_enable_encoder_streaming(after_ae* h, int enable, int gn
     AFTER_HIP_CHECK(hipMemset(h->sn.base, 0, h->sn.off));
     h->gn_window = gn_window_samples;
     h->enc_cached = true;
+    h->nc_rows = 0;  // fresh zeroed contexts: the first encode fixes the streams of this set again
     return AFTER_OK;
 }
 

@@ -2146,6 +2146,8 @@ struct ClipLayer {
 struct ClipArgs {
     int B, T, C, Cp, L, cs, W, nkmax, nsteps, dbg;
     int stagger;              // start offset between consecutive XCDs, wall-clock ticks of 10 ns (AFTER_CLIP_STAGGER)
+    int gstag;                // experiment (AFTER_CLIP_GSTAG): the MLP-up phase of row tile tm starts tm x gstag ticks late, and the
+                              // phase's stamps [64..67] are MLP-up's instead of qkv's (-1: stamps only)
     int rows_pad;             // token rows provisioned per XCD (3 T rounded up to kClipRowTile)
     int pat_rows;             // rows of an XCD's patchify slice (T rounded up to 16)
     float* xt;                // token-major latents [B * T][Cp]: a step's input, rewritten by its tail
@@ -2940,7 +2942,7 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
                 if (!end_phase(true)) return;
                 // ---- qkv (+ attention + residual where a tile is a head: clip_tile_attention)
                 if (fuse) {
-                    const ClipGemm gq{h3,  Lw.qkv_w3h, a.rows_pad, 3 * E, E, nullptr, nullptr, nullptr, a.rope_cos, a.rope_sin, T, xres, trace,
+                    const ClipGemm gq{h3,  Lw.qkv_w3h, a.rows_pad, 3 * E, E, nullptr, nullptr, nullptr, a.rope_cos, a.rope_sin, T, xres, a.gstag ? nullptr : trace,
                                       halo, &st->gen[xcc][0], &st->fail[0], qcalls * qrounds, a.cs, a.W, Mg};
                     clip_gemm_r<ClipQUT<TIER>, 2>(gq, smem_raw, rank, w, lane);
                     ++qcalls;
@@ -2990,7 +2992,11 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
                 if (!end_phase(true)) return;
                 // ---- MLP up + GELU
                 {
-                    const ClipGemm gu{h3, Lw.mlp0_w3, a.rows_pad, ME, E, Lw.mlp0_b, nullptr, mlp3, nullptr, nullptr, T, nullptr, nullptr,
+                    if (a.gstag > 0) {
+                        const unsigned long long t0 = wall_clock64();
+                        while (wall_clock64() - t0 < (unsigned long long)((rank & 3) * a.gstag)) __builtin_amdgcn_s_sleep(8);
+                    }
+                    const ClipGemm gu{h3, Lw.mlp0_w3, a.rows_pad, ME, E, Lw.mlp0_b, nullptr, mlp3, nullptr, nullptr, T, nullptr, a.gstag ? trace : nullptr,
                                       nullptr, nullptr, nullptr, 0, 0, 0, 0};
                     clip_gemm_r<ClipQUT<TIER>, 1>(gu, smem_raw, rank, w, lane);
                 }
@@ -3948,7 +3954,10 @@ void persist_off(after_denoiser* h) {
 // their event, 16 x 16-tiled copies of the weights (+ 54 MB at base width), per-XCD activation slices, and for the offline
 // segment sampler its qkv rows and bf16-plane slices -- plus a DRY placement census, synchronously.  Called while a handle
 // is being configured (after_denoiser_create / _enable_cache / _set_stream_persist / _set_sample_persist), never by
-// after_sample: a call that does the path's work neither allocates nor synchronises.  All-or-nothing: allocations go to
+// after_sample: a call that does the path's work never allocates.  (It does synchronise in one documented case: an OFFLINE
+// persistent launch in the default checked mode waits on the host for its own failure words -- persist_poll(wait = true) in
+// after_sample -- so that a refused launch is served by launches within the same call; after_denoiser_set_persist_check(h, 0)
+// restores fully asynchronous enqueue.)  All-or-nothing: allocations go to
 // locals and are committed together; if anything fails they are released, the persistent paths are switched off and the
 // launch path serves the handle (not an error: the persistent samplers are an acceleration, not a capability).
 int persist_prepare(after_denoiser* h, bool offline) {
@@ -4334,6 +4343,12 @@ int sample_clip(after_denoiser* h, hipStream_t s, const float* x0, float* out, i
             stagger = e ? atoi(e) : 0;
         }
         a.stagger = stagger;
+        static int gstag = -2;
+        if (gstag == -2) {
+            const char* e = getenv("AFTER_CLIP_GSTAG");
+            gstag = e ? atoi(e) : 0;
+        }
+        a.gstag = gstag;
     }
     a.xt = h->xt;
     {

@@ -264,18 +264,24 @@ class DenoiserV2(nn.Module):
         self._stream_args = (int(cache), int(max_diffusion_steps), int(max_batch_size), int(max_frames))
 
     def reset_cache(self):
-        _lib.check(_lib.lib().after_denoiser_reset_cache(self._handle, _lib.current_stream(None)),
-                   "after_denoiser_reset_cache")
+        if self._handle is None:
+            raise _lib.AFTERHipError("reset_cache before enable_streaming_cache")
+        dev = self._device()  # the HANDLE's device and its current stream, not the process's current device
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().after_denoiser_reset_cache(self._handle, _lib.current_stream(dev)),
+                       "after_denoiser_reset_cache")
 
     # ------------------------------------------------------------ reference surface
     def roll_cache(self, size: int, cache_index: int):
         """transformerv2.py:514-515."""
         if self._handle is None:
             raise _lib.AFTERHipError("roll_cache before any forward")
-        _lib.check(
-            _lib.lib().after_denoiser_roll_cache(self._handle, int(size), int(cache_index),
-                                                 _lib.current_stream(None)),
-            "after_denoiser_roll_cache")
+        dev = self._device()
+        with torch.cuda.device(dev):
+            _lib.check(
+                _lib.lib().after_denoiser_roll_cache(self._handle, int(size), int(cache_index),
+                                                     _lib.current_stream(dev)),
+                "after_denoiser_roll_cache")
 
     @torch.no_grad()
     def forward(self,
@@ -346,6 +352,13 @@ class DenoiserV2(nn.Module):
     @torch.no_grad()
     def cfg_sample(self, x0, cond, time_cond, nb_steps, guidance_timbre, guidance_structure,
                    drop_value, cfg_mode=_lib.CFG_API, out=None):
+        """RectifiedFlow.sample (model.py:763-785) as one call of after_sample on x0's current stream.
+
+        Host synchronisation: when the call is served by a persistent kernel (one base / tiny clip, or >= 5 base clips) and the
+        handle is in its default checked mode (`set_persist_check(None)`), after_sample waits on the host for that launch's failure
+        words (one event wait behind the kernel) so that a refused / failed launch is served by the launch path within this call:
+        the call returns with the sampler finished on the device.  `set_persist_check(False)` restores fully asynchronous
+        enqueue (a failure then surfaces at the next call or in `check()`); calls served by launches never synchronise."""
         x0, cond, time_cond, B, T = self._check_cfg_inputs(x0, cond, time_cond)
         h = self._ensure(3 * B, T, int(nb_steps))
         if out is None:

@@ -43,7 +43,7 @@ T_FRAMES = 256
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak; gemm_x6 spends six bf16 MFMAs per fp32 product block
 PEAK_X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
-ROUND = "r5"
+ROUND = "r6"
 # sources whose change invalidates a committed traffic measurement of the dominant GEMM
 TRAFFIC_SOURCES = ["after_amd/csrc/gemm.hip", "after_amd/csrc/gemm_x6.hip", "after_amd/csrc/gemm_pipe.h",
                    "after_amd/csrc/gemm_x6_pipe.h", "after_amd/csrc/denoiser.hip"]
@@ -295,22 +295,36 @@ def gemm_roofline(model, run_once, dev, dcfg, B, config, args):
             seg["traffic"] = prof["seg_bytes_per_launch"]
             seg["traffic_unit"] = "bytes per launch (one launch = all Euler steps of all clips)"
             seg["traffic_note"] = traffic_note
-            # algorithmic bytes of one Euler step: every Linear weight once in the form the kernel reads it (fp32 tiles at one
-            # clip, bf16 x 3 planes for a batch) + every activation tensor between two phases written once and read once
+            # algorithmic bytes of one Euler step as SURVEY.md 8(d) counts them: the denoiser's weights ONCE in fp32 (all CFG rows
+            # and clips share them) + every tensor that crosses a phase boundary of a layer written once and read once in fp32
+            # (3 x B x 256 rows x 512 x 4 B = 1.6 MB per E-wide tensor and clip): norm1 output (E), qkv (3E), the residual stream
+            # after attention (E), norm3 output (E), the MLP hidden layer (ME), the residual stream after the MLP (E)
             E2, L2 = dcfg["net"]["embed_dim"], dcfg["net"]["n_layers"]
             ME2 = E2 * dcfg["net"]["mlp_multiplier"]
-            wel = L2 * (3 * E2 * E2 + 2 * E2 * ME2)
             rows = 3 * B * T_FRAMES
-            wbytes = wel * (4 if model.net.sample_path() == 1 else 6)
-            # per layer and row: xres (4 B x E) x 3 writers, h planes (6 B x E) x 2, qkv (4 B x 3E), MLP hidden planes (6 B x ME)
-            abytes = L2 * rows * (3 * 4 * E2 + 2 * 6 * E2 + 4 * 3 * E2 + 6 * ME2) * 2
-            seg["algorithmic_bytes_per_euler_step"] = {"weights": wbytes, "activations_written_and_read_once": abytes}
-            seg["traffic_ratio"] = round(prof["seg_bytes_per_launch"] / nb / (wbytes + abytes), 2)
-            seg["traffic_ratio_note"] = ("counted bytes per Euler step / algorithmic bytes per Euler step; at one clip the eight XCDs "
-                                         "each stream the weights (8 x by construction), for a batch they stream them once each too "
-                                         "but amortised over 768 rows per XCD.  The algorithmic figure still counts the qkv tensor "
-                                         "written and read once (the phase-by-phase form); the batch kernel's qkv tiles attend in "
-                                         "place since round 5b, so its counted bytes can fall below it")
+            wbytes = 4 * sum(p_.numel() for p_ in model.net.parameters())
+            abytes = L2 * rows * 4 * (E2 + 3 * E2 + E2 + E2 + ME2 + E2) * 2
+            counted = prof["seg_bytes_per_launch"] / nb
+            one_clip = model.net.sample_path() == 1
+            seg["algorithmic_bytes_per_euler_step"] = {"weights_fp32_once": wbytes, "activations_fp32_written_and_read_once": abytes,
+                                                       "rows": rows}
+            seg["traffic_ratio"] = round(counted / (wbytes + abytes), 2)
+            seg["traffic_over_weights_once"] = round(counted / wbytes, 2)
+            # what the DESIGN adds on top of that by construction (not waste inside the kernel: the price of XCD-local pipelines)
+            lin = 4 * L2 * (3 * E2 * E2 + 2 * E2 * ME2)  # the qkv / MLP Linears' weights, fp32 bytes
+            seg["replication_by_construction"] = {
+                "xcds_streaming_the_linear_weights_each_step": 8,
+                "bytes_per_weight_element_as_read": 4 if one_clip else 6,
+                "linear_weight_bytes_per_euler_step": (8 * lin) if one_clip else (8 * lin * 6 // 4),
+                "activation_bytes_per_element_between_gemm_phases": 6,
+                "what": ("each of the eight XCDs streams every Linear weight once per Euler step (one clip: its time segment needs all "
+                         "of them; a batch: its clip does), served by the memory-side cache, not HBM; one clip reads fp32 tiles and "
+                         "splits them in registers, a batch reads the bf16 x 3 planes split at create (6 B per element); GEMM inputs "
+                         "travel as bf16 x 3 planes (6 B per element) written by their producers")}
+            seg["traffic_ratio_note"] = ("counted bytes ((2 x FETCH_SIZE + WRITE_SIZE) KiB, Infinity-Cache hits included) per Euler step "
+                                         "/ SURVEY 8(d)'s algorithmic bytes per Euler step (weights once in fp32 + phase-crossing "
+                                         "activations once each way in fp32); replication_by_construction itemises the part of the excess "
+                                         "that is the design's (8 XCD-local weight streams, 6-byte planes)")
         if mf:
             seg["mfma_busy"] = mf
         seg["launch_path"] = roof
@@ -435,7 +449,7 @@ def run_pmc_mfma(args):
     expression: MFMA_BUSY summed over the SIMDs / (GRBM_GUI_ACTIVE x SIMDs)), summarised into profiles/."""
     out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out", f"{ROUND}_pmc_mfma")
     os.makedirs(out, exist_ok=True)
-    inner = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+    inner = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-legs",
              "--batch-per-gpu", str(args.batch_per_gpu), "--config", args.config]
     d = os.path.join(out, "pass")
     shutil.rmtree(d, ignore_errors=True)
@@ -483,7 +497,7 @@ def run_pmc(args):
     very command; kernel trace only, no other trace domain."""
     out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out", f"{ROUND}_pmc")
     os.makedirs(out, exist_ok=True)
-    inner = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+    inner = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-legs",
              "--batch-per-gpu", str(args.batch_per_gpu), "--config", args.config]
     agg = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -534,79 +548,40 @@ def run_pmc(args):
                                            "gemm_big_mean_bytes_per_launch", "gemm_big_launches", "source_hash")}))
 
 
-def main():
-    import faulthandler
-    faulthandler.dump_traceback_later(900, exit=True)  # never hang a GPU box silently
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch-per-gpu", type=int, default=None)
-    ap.add_argument("--global-batch", type=int, default=None,
-                    help="total clips over all ranks (default batch-per-gpu x ranks); ragged shards allowed")
-    ap.add_argument("--config", default="base")
-    ap.add_argument("--stream", action="store_true", help="BASELINE config 5: streaming, 100 cached steps")
-    ap.add_argument("--nb-steps", type=int, default=None, help="Euler steps (50; 100 with --stream)")
-    ap.add_argument("--chunk", type=int, default=4, help="--stream: latent frames per chunk")
-    ap.add_argument("--from-audio", action="store_true",
-                    help="BASELINE config 1's chain: audio -> AutoEncoder.encode x 2 -> encoders -> sampler -> decode")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--bf16-tier", action="store_true",
-                    help="a SEPARATE leg, never the default: the opt-in bf16 tolerance tier of the persistent offline samplers "
-                         "(after_denoiser_set_gemm_path(h, 3); latents within 5e-2 abs / 1e-2 rel-L2 of the fp32 reference)")
-    ap.add_argument("--pmc", action="store_true", help="measure the GEMM's HBM traffic with rocprofv3 and exit")
-    ap.add_argument("--pmc-mfma", action="store_true", help="measure the kernels' matrix-pipe busy fraction with rocprofv3 and exit")
-    args = ap.parse_args()
-    if args.batch_per_gpu is None:
-        args.batch_per_gpu = 8 if args.stream else 1
-    if args.stream and args.config == "base":
-        args.config = "cycle"
-    nb_steps = args.nb_steps or (100 if args.stream else 50)
+class Leg:
+    """One workload of the benchmark: models of a config, this rank's synthetic inputs, and `step()` = one pass of the hot path."""
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
-    if args.pmc:
-        if world != 1:
-            raise SystemExit("--pmc is a single-GPU measurement")
-        return run_pmc(args)
-    if args.pmc_mfma:
-        if world != 1:
-            raise SystemExit("--pmc-mfma is a single-GPU measurement")
-        return run_pmc_mfma(args)
-    # test hook: AFTER_BENCH_SHARE_GPU=1 runs all ranks on cuda:0 over gloo, to exercise the
-    # multi-rank flow on a single-GPU box (the numbers of such a run mean nothing)
-    share = os.environ.get("AFTER_BENCH_SHARE_GPU") == "1"
-    if share:
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+    def sampler_path(self):
+        if self.stream:
+            return ("persistent (one launch per chunk: stream_step_kernel)" if self.model.net.stream_persist()
+                    else "one launch per kernel (33 per Euler step)")
+        return {0: "one launch per kernel (33 per Euler step)", 1: "persistent, one clip (sample_seg_kernel)",
+                2: "persistent, one clip per XCD (sample_clip_kernel)"}[self.model.net.sample_path()]
 
+    def persistent(self):
+        return bool(self.model.net.stream_persist()) if self.stream else self.model.net.sample_path() in (1, 2)
+
+
+def build_leg(args, dev, world, rank, reuse=None):
+    """Models + inputs + step() of the workload `args` names (config, stream, from_audio, batch_per_gpu, global_batch, nb_steps,
+    chunk, bf16_tier).  `reuse`: a Leg whose models serve this one too (same config and codec)."""
     from after_amd import parallel, pipeline
-    torch.set_grad_enabled(False)
+    leg = Leg()
+    leg.stream = bool(args.stream)
+    nb_steps = args.nb_steps or (100 if args.stream else 50)
     codec = "baseAE_causal" if args.stream else "baseAE"
-    model, dcfg, acfg = pipeline.build_models(args.config, codec, dev, seed=0)
-    if world > 1:  # identical models everywhere: one RCCL broadcast at start-up
-        parallel.broadcast_module(model)  # net, both encoders and the codec (a registered sub-module)
+    if reuse is not None:
+        model, dcfg, acfg = reuse.model, reuse.dcfg, reuse.acfg
+    else:
+        model, dcfg, acfg = pipeline.build_models(args.config, codec, dev, seed=0)
+        if world > 1:  # identical models everywhere: one RCCL broadcast at start-up
+            parallel.broadcast_module(model)  # net, both encoders and the codec (a registered sub-module)
     if args.bf16_tier:
         if args.stream:
             raise SystemExit("--bf16-tier: the tier exists in the offline persistent samplers only")
+        if dcfg["net"]["embed_dim"] != 512:
+            raise SystemExit("--bf16-tier: the tier exists at the base width (embed_dim 512) only")
         model.net.set_gemm_path(3)
-    n_ranks_seen = parallel.ranks_seen() if world > 1 else 1
-    if n_ranks_seen != world:  # RCCL did not connect every rank: a "scaling" number of this run would be fiction
-        raise SystemExit(f"rank {rank}: {n_ranks_seen} ranks answered the all-reduce, expected {world}")
-
     n_clips = args.global_batch if args.global_batch else args.batch_per_gpu * world
     g = torch.Generator(device="cpu").manual_seed(1000)
     lo, hi = parallel.shard_bounds(n_clips, rank, world)
@@ -672,15 +647,22 @@ def main():
         workload = (f"{args.config} {'midi' if tcond is not None else 'audio'}-to-audio from {src}, "
                     f"{nb_steps} Euler steps with 3-way CFG (g_t=2, g_s=1), "
                     f"T=256 frames = 11.889 s clips, encoders + sampler + AE decode, random-init weights")
+    leg.model, leg.dcfg, leg.acfg, leg.B, leg.n_clips, leg.nb_steps = model, dcfg, acfg, B, n_clips, nb_steps
+    leg.step, leg.unit_seconds, leg.out_shape, leg.workload = step, unit_seconds, out_shape, workload
+    return leg
 
-    for _ in range(args.warmup):
-        out = step()
+
+def time_leg(leg, warmup, steps, world, dev):
+    """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize on both sides; the slowest rank's time."""
+    out = None
+    for _ in range(warmup):
+        out = leg.step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    for _ in range(steps):
+        out = leg.step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -692,15 +674,176 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         dist.all_reduce(tn, op=dist.ReduceOp.MIN)
         elapsed, elapsed_min = te.item(), tn.item()
-    assert tuple(out.shape) == out_shape and torch.isfinite(out).all()
+    assert tuple(out.shape) == leg.out_shape and torch.isfinite(out).all()
+    return elapsed, elapsed_min
+
+
+LAUNCH_PATH_SWITCHES = ("AFTER_SAMPLE_PERSIST", "AFTER_SAMPLE_CLIP", "AFTER_STREAM_PERSIST", "AFTER_GEMM_X6")
+
+
+def expects_persistent(leg, args):
+    """Shapes the persistent samplers take by design: base / midi width at one clip or >= 5 clips (tiny: one clip),
+    T = 256; the streaming sampler always.  2-4 clips per GPU run by launches by design."""
+    if leg.stream:
+        return True
+    if args.bf16_tier:
+        return True  # (the tier exists in the persistent kernels only: a launch-path run would publish the wrong dtype)
+    e = leg.dcfg["net"]["embed_dim"]
+    return leg.B == 1 or (leg.B >= 5 and e == 512)
+
+
+def require_persistent(leg, args):
+    """A box in another partition mode (CPX / NPS) or with a co-tenant silently serves every call by launches (the fallback is
+    correct, and 10-30 % slower): such a run must not produce a quietly different benchmark line."""
+    if leg.persistent() or not expects_persistent(leg, args):
+        return
+    if args.allow_launch_path or any(os.environ.get(k) == "0" for k in LAUNCH_PATH_SWITCHES):
+        return  # an explicit A/B run of the launch path
+    raise SystemExit(f"bench.py: the sampler ran as '{leg.sampler_path()}', not on the persistent kernel this workload is quoted on "
+                     "(device partitioned, busy, or not 256 CUs?); --allow-launch-path prints the line anyway")
+
+
+def leg_roofline(leg):
+    """The dominant kernel of a short leg, HIP-event timed in two extra untimed passes: the persistent sampler's launch priced as a
+    whole (offline: algorithmic fp32 flops / duration / the split-bf16 ceiling; streaming: weight bytes per Euler step / duration / HBM)."""
+    net = leg.model.net
+    if not leg.persistent():
+        return None
+    net.profile(True, min_flops=0.0, kernel=3)
+    torch.cuda.synchronize()
+    for _ in range(2):
+        leg.step(gather=False)
+    torch.cuda.synchronize()
+    ms, launches, flops, nbytes = net.gemm_time(with_bytes=True)
+    net.profile(False)
+    if not launches:
+        return None
+    if leg.stream:
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": "stream_step_kernel", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(gbs / 8000.0, 4), "avg_launch_us": round(ms * 1e3 / launches, 1)}
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "sample_seg_kernel" if net.sample_path() == 1 else "sample_clip_kernel",
+            "achieved": round(tf, 2), "peak": round(PEAK_X6_TFLOPS, 1), "unit": "TFLOP/s", "frac": round(tf / PEAK_X6_TFLOPS, 4),
+            "avg_launch_us": round(ms * 1e3 / launches, 1)}
+
+
+def extra_legs(args, dev, head):
+    """BASELINE.json's other configs as short legs of the SAME process (the driver runs `bench.py --gpus 1` only): configs[2]'s per-GPU
+    shard (base, 8 clips), configs[3] (midi, 8 clips), configs[4] (base + cycle streaming, 8 streams x 100 steps, one step = one
+    chunk), configs[0]'s chain (tiny, from audio).  Same timing rule as the headline (warm-up, then K steps between synchronisations);
+    no CPU baseline, no counter files."""
+    specs = [("b8", dict(batch_per_gpu=8), 1, 3, "BASELINE configs[2]: the per-GPU shard (8 clips) of base B=64 over 8 GPUs"),
+             ("midi_b8", dict(config="midi", batch_per_gpu=8), 1, 3, "BASELINE configs[3]: midi, 8 clips"),
+             ("stream", dict(config="cycle", stream=True, batch_per_gpu=8), 4, 12,
+              "BASELINE configs[4]: base + cycle streaming, 8 streams, 100 cached steps; one step = one 4-frame chunk of every stream"),
+             ("tiny_from_audio", dict(config="tiny", from_audio=True, batch_per_gpu=1), 2, 5,
+              "BASELINE configs[0]'s chain on the GPU: tiny, two audio clips -> encode x 2 -> encoders -> sampler -> decode")]
+    out = {}
+    t_all = time.perf_counter()
+    for name, over, warm, steps, what in specs:
+        a = argparse.Namespace(**vars(args))
+        a.stream, a.from_audio, a.global_batch, a.nb_steps, a.bf16_tier = False, False, None, None, False
+        for k, v in over.items():
+            setattr(a, k, v)
+        try:
+            leg = build_leg(a, dev, 1, 0, reuse=head if (a.config == args.config and not a.stream) else None)
+            el, _ = time_leg(leg, warm, steps, 1, dev)
+            require_persistent(leg, a)
+            ms = el / steps * 1e3
+            out[name] = {"what": what, "ms_per_step": round(ms, 3), "steps": steps, "warmup": warm,
+                         "value": round(leg.n_clips * leg.unit_seconds / (ms * 1e-3), 2), "unit": "audio_s_per_wall_s",
+                         "clips_per_s": None if a.stream else round(leg.n_clips / (ms * 1e-3), 2),
+                         "sampler_path": leg.sampler_path(), "roofline": leg_roofline(leg), "workload": leg.workload}
+            del leg
+        except SystemExit:
+            raise
+        except Exception as e:  # a leg must not take the headline line with it
+            out[name] = {"what": what, "error": f"{type(e).__name__}: {e}"[:300]}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    out["seconds_for_all_legs"] = round(time.perf_counter() - t_all, 2)
+    return out
+
+
+def main():
+    import faulthandler
+    faulthandler.dump_traceback_later(900, exit=True)  # never hang a GPU box silently
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch-per-gpu", type=int, default=None)
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="total clips over all ranks (default batch-per-gpu x ranks); ragged shards allowed")
+    ap.add_argument("--config", default="base")
+    ap.add_argument("--stream", action="store_true", help="BASELINE config 5: streaming, 100 cached steps")
+    ap.add_argument("--nb-steps", type=int, default=None, help="Euler steps (50; 100 with --stream)")
+    ap.add_argument("--chunk", type=int, default=4, help="--stream: latent frames per chunk")
+    ap.add_argument("--from-audio", action="store_true",
+                    help="BASELINE config 1's chain: audio -> AutoEncoder.encode x 2 -> encoders -> sampler -> decode")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="default headline run only: skip the short legs of the other BASELINE configs (`legs` of the line)")
+    ap.add_argument("--allow-launch-path", action="store_true",
+                    help="print the line even if the sampler did not run on the persistent kernel the workload is quoted on")
+    ap.add_argument("--bf16-tier", action="store_true",
+                    help="a SEPARATE leg, never the default: the opt-in bf16 tolerance tier of the persistent offline samplers "
+                         "(after_denoiser_set_gemm_path(h, 3); latents within 5e-2 abs / 1e-2 rel-L2 of the fp32 reference)")
+    ap.add_argument("--pmc", action="store_true", help="measure the GEMM's HBM traffic with rocprofv3 and exit")
+    ap.add_argument("--pmc-mfma", action="store_true", help="measure the kernels' matrix-pipe busy fraction with rocprofv3 and exit")
+    args = ap.parse_args()
+    if args.batch_per_gpu is None:
+        args.batch_per_gpu = 8 if args.stream else 1
+    if args.stream and args.config == "base":
+        args.config = "cycle"
+    nb_steps = args.nb_steps or (100 if args.stream else 50)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    if args.pmc:
+        if world != 1:
+            raise SystemExit("--pmc is a single-GPU measurement")
+        return run_pmc(args)
+    if args.pmc_mfma:
+        if world != 1:
+            raise SystemExit("--pmc-mfma is a single-GPU measurement")
+        return run_pmc_mfma(args)
+    # test hook: AFTER_BENCH_SHARE_GPU=1 runs all ranks on cuda:0 over gloo, to exercise the
+    # multi-rank flow on a single-GPU box (the numbers of such a run mean nothing)
+    share = os.environ.get("AFTER_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    from after_amd import parallel
+    torch.set_grad_enabled(False)
+    leg = build_leg(args, dev, world, rank)
+    n_ranks_seen = parallel.ranks_seen() if world > 1 else 1
+    if n_ranks_seen != world:  # RCCL did not connect every rank: a "scaling" number of this run would be fiction
+        raise SystemExit(f"rank {rank}: {n_ranks_seen} ranks answered the all-reduce, expected {world}")
+    model, dcfg, acfg, B, n_clips, nb_steps = leg.model, leg.dcfg, leg.acfg, leg.B, leg.n_clips, leg.nb_steps
+
+    elapsed, elapsed_min = time_leg(leg, args.warmup, args.steps, world, dev)
+    require_persistent(leg, args)
+    head_path = leg.sampler_path()  # (now: a later leg on the same models changes what "the last call" was)
 
     roof = None
-    sampler_path = None
     if rank == 0:  # rank 0 only: no collective in this pass
-        if not args.stream:
-            sampler_path = {0: "one launch per kernel (33 per Euler step)", 1: "persistent, one clip (sample_seg_kernel)",
-                            2: "persistent, one clip per XCD (sample_clip_kernel)"}[model.net.sample_path()]
-        roof = gemm_roofline(model, lambda: step(gather=False), dev, dcfg, B, args.config, args)
+        roof = gemm_roofline(model, lambda: leg.step(gather=False), dev, dcfg, B, args.config, args)
         if roof is not None and not args.stream and model.emb_model is not None:
             roof["codec"] = codec_record(model, dev, B)
 
@@ -714,14 +857,21 @@ def main():
             tc_cpu = piano_roll(1, dcfg["net"]["tcond_dim"], "cpu") if dcfg["encoder_time"] is None else None
             cpu = cpu_baseline(nb_steps, sds, dcfg, acfg, tc_cpu)
 
+    # the other BASELINE configs in the same process (single GPU, the default headline leg only): short timed legs behind the headline
+    legs = None
+    headline = (world == 1 and not (args.stream or args.from_audio or args.bf16_tier or args.global_batch)
+                and args.config == "base" and args.batch_per_gpu == 1 and args.nb_steps is None)
+    if rank == 0 and headline and not args.no_legs:
+        legs = extra_legs(args, dev, leg)
+
     if rank == 0:
-        audio_s = args.steps * n_clips * unit_seconds
+        audio_s = args.steps * n_clips * leg.unit_seconds
         line = {
             "metric": "audio sec generated / wall sec (xRT), base 50-step @44.1 kHz",
             "value": round(audio_s / elapsed, 2),
             "unit": "audio_s_per_wall_s",
             "clips_per_s": round(args.steps * n_clips / elapsed, 3) if not args.stream else None,
-            "xrt_per_stream": round(unit_seconds / (elapsed / args.steps), 3) if args.stream else None,
+            "xrt_per_stream": round(leg.unit_seconds / (elapsed / args.steps), 3) if args.stream else None,
             "n_gpus": world,
             "n_ranks_seen": n_ranks_seen,
             "steps": args.steps,
@@ -738,15 +888,16 @@ def main():
                       "as six exact bf16 MFMAs on exact three-way bf16 splits of both operands, fp32 accumulate -- error "
                       "vs fp64 <= the fp32 MFMA chain's, tests/test_gemm_gpu.py; AFTER_GEMM_X6=0 = fp32 MFMA everywhere)"),
             "data": "synthetic",
-            "config": {"workload": workload,
+            "config": {"workload": leg.workload,
                        "batch_per_gpu": args.batch_per_gpu if not args.global_batch else None,
                        "global_batch": n_clips, "nb_steps": nb_steps,
-                       "parallelism": f"clip-sharded x{world}" if not args.stream else f"stream-sharded x{world}"},
+                       "parallelism": f"clip-sharded x{world}" if not args.stream else f"stream-sharded x{world}",
+                       "sampler_path": head_path},
             "roofline": roof,
             "cpu_baseline": cpu,
         }
-        if sampler_path:
-            line["config"]["sampler_path"] = sampler_path
+        if legs is not None:
+            line["legs"] = legs
         if args.bf16_tier:  # a different arithmetic: said in the metric, the dtype and the roofline's peak -- this line is never the headline
             line["metric"] += " -- OPT-IN bf16 tolerance tier (NOT the default arithmetic, not comparable with the fp32 line)"
             line["dtype"] = ("bf16 operands (the top planes of the exact three-way splits: round-to-nearest bf16 of weights and "
@@ -758,12 +909,11 @@ def main():
                 roof["peak"] = PEAK_BF16_MFMA_TFLOPS
                 roof["frac"] = round(roof["achieved"] / PEAK_BF16_MFMA_TFLOPS, 4)
                 roof["peak_note"] = "dense bf16 MFMA peak 2500 TFLOP/s, one MFMA per product block in this tier"
-                for k in ("mfma_busy", "traffic", "traffic_ratio", "traffic_note", "traffic_ratio_note"):
+                for k in ("mfma_busy", "traffic", "traffic_ratio", "traffic_note", "traffic_ratio_note", "algorithmic_bytes_per_euler_step",
+                          "replication_by_construction"):
                     roof.pop(k, None)  # (the committed counter passes are the default arithmetic's)
         if args.stream:
             line["metric"] = "audio sec generated / wall sec (xRT, all streams), base+cycle 100-step streaming @44.1 kHz"
-            line["config"]["sampler_path"] = ("persistent (one launch per chunk: stream_step_kernel)" if model.net.stream_persist()
-                                              else "one launch per kernel (33 per Euler step)")
         print(json.dumps(line))
     if world > 1:
         dist.barrier()  # rank 0's roofline pass is done: leave together

@@ -194,8 +194,10 @@ int after_denoiser_set_stream_persist(after_denoiser* h, int enable);
  * 96 x 128) fed by four loader waves per workgroup; a qkv tile is one head of 192 token rows and attends in place (no qkv
  * rows in memory; window - 1 <= 16 and 16 % chunk == 0, else qkv rows + attention items: also AFTER_CLIP_FUSE=0).
  * Eligible: base width (embed 512), T % 16 == 0 and T <= 1024 frames within
- * the handle's capacity, finite causal window, gemm path != 0, no graph replay; provisioned (+ 15.5 MB per XCD at T = 256)
- * when the handle is created with max_rows >= 15.  AFTER_SAMPLE_CLIP=0 keeps batches on the launch path,
+ * the handle's capacity, finite causal window, gemm path != 0, no graph replay; provisioned when the handle is created (or
+ * grown) with max_rows >= 15 (five clips), sized from the handle's max_T, not from the clips later sampled: 15.5 MB per XCD
+ * = 124 MB at max_T = 256, ~ 4x that (~ 520 MB: activation slices and their bf16 planes) at max_T = 1024, + 4.7 MB of regrouped
+ * qkv weight planes per layer.  Handles reserved for fewer than five clips never allocate these.  AFTER_SAMPLE_CLIP=0 keeps batches on the launch path,
  * AFTER_SAMPLE_CLIP_MINB=n moves the threshold.
  * _sample_persist: *active = how the last after_sample ran -- 0 by launches, 1 the one-clip kernel, 2 the batch kernel. */
 int after_denoiser_set_sample_persist(after_denoiser* h, int enable);

@@ -1,0 +1,23 @@
+#!/bin/bash
+# GPU passes of round 6 (gpurun -- bash scripts/r6_pass.sh <name>); output under gpurun_out/r6_<name>/
+set -u
+pass=${1:?pass}
+O=gpurun_out/r6_$pass
+mkdir -p $O
+export TMPDIR=/tmp
+case "$pass" in
+first)  # the bench line with all BASELINE configs as legs, the dataset-embedding test, codec at 16 / 32 clips
+    timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_b1.json 2> $O/bench_b1.err; echo "bench rc $?"
+    python -c "
+import json; d=json.load(open('$O/bench_b1.json')); print(d['ms_per_step'], d['value'], d['config']['sampler_path']); print(json.dumps(d.get('legs'), indent=1)[:3000])"
+    timeout 900 python -m pytest tests/test_dataset_embed_gpu.py tests/test_denoiser_gpu.py tests/test_autoencoder_gpu.py -x -q 2>&1 | tail -5
+    timeout 600 python scripts/time_codec.py --rounds 20 --batches 1,8,16,32 2>/dev/null | grep workload | tee $O/codec.jsonl
+    ;;
+gstag)  # experiment: row-tile groups of an XCD out of phase in the MLP-up phase -- do the output bursts shorten?
+    for gs in -1 300 600 1000 1500; do
+        echo "== AFTER_CLIP_GSTAG=$gs" >> $O/gstag.txt
+        AFTER_CLIP_GSTAG=$gs timeout 300 python scripts/stream_step_trace.py --offline --clips 8 --xcd 3 2>/dev/null | grep -v amdgpu.ids | grep "MLP-up\|L5 up\|L5 down\|step per" >> $O/gstag.txt
+    done
+    cat $O/gstag.txt
+    ;;
+esac

@@ -121,8 +121,23 @@ if args.offline and args.clips > 1:  # the clip-per-XCD kernel: effective shader
     rel = (gq - t_all[okw][:, 2 * ph][:, None]) / 100.0
     arr = (t_all[okw][:, 2 * ph + 1] - t_all[okw][:, 2 * ph]) / 100.0
     lc = (buf[okw][:, 69].astype(np.int64) - buf[okw][:, 68].astype(np.int64))
-    print("qkv phase, first tile, median us after the barrier: entry %.2f, slab 0 published %.2f, K loop done %.2f, epilogue issued %.2f; "
-          "phase %.2f; shader cycles entry -> loop done %.0f (%.0f MHz)" % (tuple(np.median(rel, 0).tolist()) + (np.median(arr), np.median(lc), np.median(lc / ((gq[:, 2] - gq[:, 0]) / 100.0)))))
+    m = np.median(rel, 0).tolist()
+    slab0 = "%.2f" % m[1] if (gq[:, 1] > 0).all() else "n/a (not stamped by this kernel form)"
+    print("qkv phase, first tile, median us after the barrier: entry %.2f, slab 0 published %s, K loop done %.2f, epilogue issued %.2f; "
+          "phase %.2f; shader cycles entry -> loop done %.0f (%.0f MHz)" % (m[0], slab0, m[2], m[3], np.median(arr), np.median(lc),
+                                                                          np.median(lc / ((gq[:, 2] - gq[:, 0]) / 100.0))))
+    if os.environ.get("AFTER_CLIP_GSTAG"):  # experiment: the stamps are MLP-up's; per row tile (rank & 3 -- the census rank is not in the
+        pu = 4 + 5 * (L - 1)                # stamps: group by the delay seen = entry - barrier exit)
+        x = xcc == args.xcd
+        g4 = buf[x][:, 64:68].astype(np.int64)
+        ex, ar = t_all[x][:, 2 * pu], t_all[x][:, 2 * pu + 1]
+        delay = (g4[:, 0] - ex) / 100.0
+        order = np.argsort(delay)
+        for q in range(4):
+            sel = order[8 * q:8 * q + 8]
+            print("MLP-up, delay group %d (entry %.1f us after the barrier): K loop %.2f, epilogue issue %.2f, drain to arrival %.2f, entry -> arrival %.2f us (medians of 8 workgroups)"
+                  % (q, np.median(delay[sel]), np.median((g4[sel, 2] - g4[sel, 0]) / 100.0), np.median((g4[sel, 3] - g4[sel, 2]) / 100.0),
+                     np.median((ar[sel] - g4[sel, 3]) / 100.0), np.median((ar[sel] - g4[sel, 0]) / 100.0)))
     pa = 3 + 5 * (L - 1)  # the last layer's attention phase: thread 0's stamps inside the workgroup's items (pairs of chunks)
     ga = buf[okw][:, 80:88].astype(np.int64)
     if (ga[:, 0] > 0).all():

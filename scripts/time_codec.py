@@ -48,6 +48,7 @@ def main():
             ms = statistics.median(ts)
             res[name + "_ms"] = round(ms, 3)
             res[name + "_ms_min"] = round(min(ts), 3)
+            res[name + "_clips_per_s"] = round(B / (ms * 1e-3), 1)
             res[name + "_frac_of_fp32_mfma_peak"] = round(gflop * 1e9 * B / (ms * 1e-3) / PEAK, 3)
         print(json.dumps(res), flush=True)
 
