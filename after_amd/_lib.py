@@ -142,6 +142,7 @@ SIGNATURES = {
     "after_gemm_x6_set_debug": (None, [c_void_p]),
     "after_gemm_x6_split": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "after_gemm_x6_pick_tile": (c_int, [c_int, c_int, c_int]),
+    "after_diag_split_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]),
     "after_gemm_x6_offset": (ctypes.c_longlong, [c_int, c_int, c_int, c_int]),
     "after_gemm_x6": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                               c_int, c_int, c_int, c_int, c_void_p]),

@@ -22,11 +22,13 @@
 #include <cstdlib>
 #include <mutex>
 #include <new>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
 #include "common.h"
 #include "gemm_x6_pipe.h"
+#include "gemm_h3_pipe.h"
 
 namespace after {
 namespace {
@@ -2130,6 +2132,14 @@ template <int TIER>
 using ClipDnT = X6Cfg<6, 8, 1, 2, 4, CLIP_DN_NS, 0, 1, 1, 0, 0, 1, TIER>;  // MLP-down: 96 x 128 (32 tiles), waves = 2 row parts x 4 column parts, even / odd slabs in separate accumulators
 using ClipQU = ClipQUT<0>;
 using ClipDn = ClipDnT<0>;
+// the two-piece fp16 form of the same tiles (gemm_h3_pipe.h: three MFMAs per product block; three-stage rings of 48 / 28 KB)
+using ClipQUH = H3RCfg<12, 12, 4, 2, 3, 1>;
+using ClipDnH = H3LCfg<6, 8, 2, 4, 3, 1, 1>;
+template <int TIER, int H3>
+using ClipQUS = std::conditional_t<H3 != 0, ClipQUH, ClipQUT<TIER>>;
+template <int TIER, int H3>
+using ClipDnS = std::conditional_t<H3 != 0, ClipDnH, ClipDnT<TIER>>;
+static_assert((size_t)ClipQUH::NS * ClipQUH::STAGE <= (size_t)ClipQU::NS * ClipQU::STAGE, "the fp16 ring fits the LDS the bf16 ring provisions");
 constexpr int kClipRowTile = 192;  // rows of an XCD's slices are provisioned in multiples of it (both tile heights divide it)
 constexpr int kClipMaxT = 1024;    // longest clip the slices are provisioned for (15.5 MB per XCD at T = 256)
 // dynamic LDS: the GEMM ring of the larger tile | attention rows + K / V landing zones | the tail's partial tiles
@@ -2140,6 +2150,10 @@ static_assert(kClipLds >= (8192 + 8 * 2 * kAttnKeyBlock * 64) * sizeof(float), "
 struct ClipLayer {
     const unsigned short *qkv_w3, *mlp0_w3, *mlp2_w3;  // x6 planes of the three big Linears (after_denoiser_create)
     const unsigned short* qkv_w3h;  // qkv with its output columns regrouped by HEAD: 192-column tile h = q_h | k_h | v_h (persist_prepare)
+    // the two-piece fp16 form (H3): h3 blocks of the same three weights (qkv by head) and the exact power-of-two scales -- of the
+    // norm1 / norm3 outputs and the MLP hidden layer as their producers write them, and 1 / (activation scale x weight scale) per Linear
+    const unsigned short *qkv_h3, *mlp0_h3, *mlp2_h3;
+    float s_h1, s_h3, s_m, o_qkv, o_up, o_dn;
     const float *mlp0_b, *mlp2_b, *n1w, *n1b, *n3w, *n3b;
 };
 
@@ -2188,6 +2202,7 @@ struct ClipGemm {
     unsigned* fail;         // a spin that gave up raises it
     unsigned sq0;           // sequence number of this call's first round of tiles
     int cs, W, Mg;          // attention chunk, window, valid token rows (3 T)
+    float oscale, pscale;   // H3: the accumulators' scale back (1 / (activation scale x weight scale)); the scale of the planes EPI 1 writes
 };
 
 // role dispatch of the loader-wave ring (wave-uniform switch: every role has its own instruction stream)
@@ -2379,10 +2394,11 @@ __device__ __forceinline__ void clip_gemm_r(const ClipGemm& g, unsigned char* sm
     const int tiles_m = g.M / BM, tiles_n = g.N / BN, ntiles = tiles_m * tiles_n;
     const int rp = wid % RS, cp = wid / RS;
     const int nk = g.K / 32;  // (even)
-    X6RState<C> c;
+    constexpr bool H3 = C::SPLIT != 0;
+    std::conditional_t<H3, H3RState<C>, X6RState<C>> c;
     c.lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem_raw;
     c.voff = (unsigned)lane * 16u;
-    c.rgs = (unsigned)(g.K / 32) * 3072u;
+    c.rgs = (unsigned)(g.K / 32) * (unsigned)(C::NPL * 1024);
     {
         const int frow = lane & 15, kq = lane >> 4;
         const unsigned sw = (unsigned)((kq ^ swz4((frow >> 2) & 3)) * 16);
@@ -2405,7 +2421,15 @@ __device__ __forceinline__ void clip_gemm_r(const ClipGemm& g, unsigned char* sm
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
-        CLIP_ROLE(wid, (x6r_tile<C, kClipLoaders, LID>(c, nk)));
+        if constexpr (H3) {
+            CLIP_ROLE(wid, (h3r_tile<C, kClipLoaders, LID>(c, nk)));
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) c.acc[i][j] = c.acc[i][j] * g.oscale;  // (an exact power of two)
+        } else {
+            CLIP_ROLE(wid, (x6r_tile<C, kClipLoaders, LID>(c, nk)));
+        }
         if (tr && t == rank) {
             asm volatile("s_nop 15\n\ts_nop 15" : "+v"(c.acc[MT - 1][NT - 1]));
             tr[66] = wall_clock64(), tr[69] = __builtin_readcyclecounter();
@@ -2490,12 +2514,20 @@ __device__ __forceinline__ void clip_gemm_r(const ClipGemm& g, unsigned char* sm
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r), out_r, (unsigned)(gm * g.N + gn) * 4u, 0, 0);
                 } else {  // (x6_store4 with a 32-bit offset: the three planes of the four values, 1 KB apart)
                     const f32x4 v = o + bv[j];
-                    uint2 ph, pm, pl;
-                    x6_split4(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]), ph, pm, pl);
-                    const unsigned off = (unsigned)x6_offset(gm, 0, gn, g.N) * 2u;
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ph), out_r, off, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pm), out_r, off + 1024u, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pl), out_r, off + 2048u, 0, 0);
+                    if constexpr (H3) {  // (the hidden layer's two fp16 pieces, scaled by its bound's power of two)
+                        uint2 ph, pl;
+                        h3_split4(gelu_erf(v[0]) * g.pscale, gelu_erf(v[1]) * g.pscale, gelu_erf(v[2]) * g.pscale, gelu_erf(v[3]) * g.pscale, ph, pl);
+                        const unsigned off = (unsigned)h3_offset(gm, 0, gn, g.N) * 2u;
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ph), out_r, off, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pl), out_r, off + 1024u, 0, 0);
+                    } else {
+                        uint2 ph, pm, pl;
+                        x6_split4(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]), ph, pm, pl);
+                        const unsigned off = (unsigned)x6_offset(gm, 0, gn, g.N) * 2u;
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ph), out_r, off, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pm), out_r, off + 1024u, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pl), out_r, off + 2048u, 0, 0);
+                    }
                 }
             }
         }
@@ -2516,6 +2548,7 @@ __device__ __forceinline__ void clip_gemm_l(const ClipGemm& g, unsigned char* sm
     constexpr int BM = C::BM, BN = C::BN, MT = C::MT, NT = C::NT, RS = C::RS;
     constexpr int STORES = MT * NT;  // vector-memory instructions of a tile's epilogue behind the fill
     static_assert(C::KS == 1 && C::SC1 == 1, "clip tiles: no k-parts, sc1 operand loads");
+    constexpr bool H3 = C::SPLIT != 0;
     int lane = lane_in;
     asm volatile("" : "+v"(lane));  // (opaque: see clip_gemm_r)
     const int tiles_m = g.M / BM, tiles_n = g.N / BN, ntiles = tiles_m * tiles_n;
@@ -2523,10 +2556,10 @@ __device__ __forceinline__ void clip_gemm_l(const ClipGemm& g, unsigned char* sm
     const int nk = g.K / 32;  // (>= 4)
     int t = rank;
     if (t >= ntiles) return;
-    X6LState<C> c;
+    std::conditional_t<H3, H3LState<C>, X6LState<C>> c;
     c.lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem_raw;
     c.voff = (unsigned)lane * 16u;
-    c.rgs = (unsigned)nk * 3072u;
+    c.rgs = (unsigned)nk * (unsigned)(C::NPL * 1024);
     {
         const int frow = lane & 15, kq = lane >> 4;
         const unsigned sw = (unsigned)((kq ^ swz4((frow >> 2) & 3)) * 16);
@@ -2535,7 +2568,11 @@ __device__ __forceinline__ void clip_gemm_l(const ClipGemm& g, unsigned char* sm
     }
     c.a_src = (unsigned long long)(uintptr_t)g.A3 + (unsigned long long)((t % tiles_m) * (BM >> 4)) * c.rgs;
     c.w_src = (unsigned long long)(uintptr_t)g.W3 + (unsigned long long)((t / tiles_m) * (BN >> 4)) * c.rgs;
-    CLIP_ROLE_N(wid, kClipDnLoaders, (x6l_fill<C, kClipDnLoaders, LID>(c)));
+    if constexpr (H3) {
+        CLIP_ROLE_N(wid, kClipDnLoaders, (h3l_fill<C, kClipDnLoaders, LID>(c)));
+    } else {
+        CLIP_ROLE_N(wid, kClipDnLoaders, (x6l_fill<C, kClipDnLoaders, LID>(c)));
+    }
     for (bool first = true;; first = false) {
         const int tm = t % tiles_m, tn = t / tiles_m;
 #pragma unroll
@@ -2544,7 +2581,13 @@ __device__ __forceinline__ void clip_gemm_l(const ClipGemm& g, unsigned char* sm
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) c.acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (first) {
+        if constexpr (H3) {
+            if (first) {
+                CLIP_ROLE_N(wid, kClipDnLoaders, (h3l_main<C, kClipDnLoaders, LID, 0>(c, nk)));
+            } else {
+                CLIP_ROLE_N(wid, kClipDnLoaders, (h3l_main<C, kClipDnLoaders, LID, STORES>(c, nk)));
+            }
+        } else if (first) {
             CLIP_ROLE_N(wid, kClipDnLoaders, (x6l_main<C, kClipDnLoaders, LID, 0>(c, nk)));
         } else {
             CLIP_ROLE_N(wid, kClipDnLoaders, (x6l_main<C, kClipDnLoaders, LID, STORES>(c, nk)));
@@ -2574,7 +2617,11 @@ __device__ __forceinline__ void clip_gemm_l(const ClipGemm& g, unsigned char* sm
             asm volatile("" ::: "memory");
             c.a_src = (unsigned long long)(uintptr_t)g.A3 + (unsigned long long)((t_next % tiles_m) * (BM >> 4)) * c.rgs;
             c.w_src = (unsigned long long)(uintptr_t)g.W3 + (unsigned long long)((t_next / tiles_m) * (BN >> 4)) * c.rgs;
-            CLIP_ROLE_N(wid, kClipDnLoaders, (x6l_fill<C, kClipDnLoaders, LID>(c)));
+            if constexpr (H3) {
+                CLIP_ROLE_N(wid, kClipDnLoaders, (h3l_fill<C, kClipDnLoaders, LID>(c)));
+            } else {
+                CLIP_ROLE_N(wid, kClipDnLoaders, (x6l_fill<C, kClipDnLoaders, LID>(c)));
+            }
         }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -2582,7 +2629,8 @@ __device__ __forceinline__ void clip_gemm_l(const ClipGemm& g, unsigned char* sm
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const unsigned off = (unsigned)((row0 + 16 * i + (lane_e & 15)) * g.N + cb + 4 * (lane_e >> 4));  // (row-major residual stream)
-                const f32x4 o = C::ACC2 ? c.acc[0][i][j] + c.acc[C::ACC2][i][j] : c.acc[0][i][j];
+                f32x4 o = C::ACC2 ? c.acc[0][i][j] + c.acc[C::ACC2][i][j] : c.acc[0][i][j];
+                if constexpr (H3) o = o * g.oscale;  // (an exact power of two)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (o + bv[j]) + rv[i][j]), xr, off * 4u, 0, 0);
             }
         }
@@ -2770,9 +2818,10 @@ __device__ __attribute__((noinline)) void clip_attention_pair(StepAttn g, const 
 // residual stream is ROW-MAJOR [rows][E] in this kernel (a row is 2 KB of contiguous memory for the row-wise phases; in the 16 x 16
 // tiles of the other persistent samplers it is 128 pieces of 16 bytes); src_tiled: the source is the tiled patchify output.
 // lr[k] < 0: no such row (its loads repeat a valid row, nothing is stored)
+template <bool H3>  // h as x6 planes (bf16 x 3) or as h3 blocks (fp16 x 2, scaled by `hs`)
 __device__ __forceinline__ void clip_ln_rows(__amdgpu_buffer_rsrc_t xin, bool src_tiled, const int (&src_lr)[3], const float* const (&ab)[3],
                                              const float* __restrict__ w1, const float* __restrict__ b1, float* __restrict__ xres,
-                                             unsigned short* __restrict__ h3, const int (&lr)[3], int lane) {
+                                             unsigned short* __restrict__ h3, const int (&lr)[3], int lane, float hs) {
     constexpr int E = kSE, NV = E / 256, KBt = E / 16;
     f32x4 v[3][NV], al[3][NV], be[3][NV], ww[NV], bb[NV];
 #pragma unroll
@@ -2823,13 +2872,14 @@ __device__ __forceinline__ void clip_ln_rows(__amdgpu_buffer_rsrc_t xin, bool sr
                 y.y = (v[k][i].y - mean) * rstd * ww[i].y + bb[i].y;
                 y.z = (v[k][i].z - mean) * rstd * ww[i].z + bb[i].z;
                 y.w = (v[k][i].w - mean) * rstd * ww[i].w + bb[i].w;
-                x6_store4(h3, lr[k], 4 * lane + 256 * i, E, y.x, y.y, y.z, y.w);
+                if constexpr (H3) h3_store4(h3, lr[k], 4 * lane + 256 * i, E, y.x * hs, y.y * hs, y.z * hs, y.w * hs);
+                else x6_store4(h3, lr[k], 4 * lane + 256 * i, E, y.x, y.y, y.z, y.w);
             }
         }
     }
 }
 
-template <int TIER>
+template <int TIER, int H3 = 0>  // H3 1: the Linears on two-piece fp16 operands (gemm_h3_pipe.h; qkv tiles attend in place: a.fuse)
 __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ unsigned s_rank, s_bad, s_ok;
@@ -2937,15 +2987,17 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
                         srcs[k] = l == 0 ? t : lm;
                         ab[k] = a.tc_ab + ((size_t)a.tcmap[br * B + c] * T + t) * a.tc_ld + (size_t)l * 2 * E;
                     }
-                    clip_ln_rows(l == 0 ? pat_r : xres_r, l == 0, srcs, ab, Lw.n1w, Lw.n1b, xres, h3, lms, lane);
+                    clip_ln_rows<H3 != 0>(l == 0 ? pat_r : xres_r, l == 0, srcs, ab, Lw.n1w, Lw.n1b, xres, h3, lms, lane, Lw.s_h1);
                 }
                 if (!end_phase(true)) return;
                 // ---- qkv (+ attention + residual where a tile is a head: clip_tile_attention)
                 if (fuse) {
-                    const ClipGemm gq{h3,  Lw.qkv_w3h, a.rows_pad, 3 * E, E, nullptr, nullptr, nullptr, a.rope_cos, a.rope_sin, T, xres, a.gstag ? nullptr : trace,
-                                      halo, &st->gen[xcc][0], &st->fail[0], qcalls * qrounds, a.cs, a.W, Mg};
-                    clip_gemm_r<ClipQUT<TIER>, 2>(gq, smem_raw, rank, w, lane);
+                    const ClipGemm gq{h3,  H3 ? Lw.qkv_h3 : Lw.qkv_w3h, a.rows_pad, 3 * E, E, nullptr, nullptr, nullptr, a.rope_cos, a.rope_sin, T, xres, a.gstag ? nullptr : trace,
+                                      halo, &st->gen[xcc][0], &st->fail[0], qcalls * qrounds, a.cs, a.W, Mg, Lw.o_qkv, 0.f};
+                    clip_gemm_r<ClipQUS<TIER, H3>, 2>(gq, smem_raw, rank, w, lane);
                     ++qcalls;
+                } else if constexpr (H3 != 0) {
+                    return;  // (the host launches this instantiation only when the tiles attend in place)
                 } else {
                     const ClipGemm gq{h3, Lw.qkv_w3, a.rows_pad, 3 * E, E, nullptr, qkv, nullptr, a.rope_cos, a.rope_sin, T, nullptr, trace,
                                       nullptr, nullptr, nullptr, 0, 0, 0, 0};
@@ -2965,8 +3017,10 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
                             srcs[k] = lm;
                             ab[k] = cond_ab + (size_t)((lm / T) * B + c) * a.cond_ld + (size_t)l * 2 * E;
                         }
-                        clip_ln_rows(xres_r, false, srcs, ab, Lw.n3w, Lw.n3b, xres, h3, lms, lane);
+                        clip_ln_rows<H3 != 0>(xres_r, false, srcs, ab, Lw.n3w, Lw.n3b, xres, h3, lms, lane, Lw.s_h3);
                     }
+                } else if constexpr (H3 != 0) {
+                    return;
                 } else if (pairs) {  // items = pairs of chunks: shared K / V rows, a LayerNorm row for each of the eight waves
                     for (int it = rank; it < 3 * npair; it += (int)n) {
                         const int br = it / npair, px = it - br * npair;
@@ -2996,16 +3050,16 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
                         const unsigned long long t0 = wall_clock64();
                         while (wall_clock64() - t0 < (unsigned long long)((rank & 3) * a.gstag)) __builtin_amdgcn_s_sleep(8);
                     }
-                    const ClipGemm gu{h3, Lw.mlp0_w3, a.rows_pad, ME, E, Lw.mlp0_b, nullptr, mlp3, nullptr, nullptr, T, nullptr, a.gstag ? trace : nullptr,
-                                      nullptr, nullptr, nullptr, 0, 0, 0, 0};
-                    clip_gemm_r<ClipQUT<TIER>, 1>(gu, smem_raw, rank, w, lane);
+                    const ClipGemm gu{h3, H3 ? Lw.mlp0_h3 : Lw.mlp0_w3, a.rows_pad, ME, E, Lw.mlp0_b, nullptr, mlp3, nullptr, nullptr, T, nullptr, a.gstag ? trace : nullptr,
+                                      nullptr, nullptr, nullptr, 0, 0, 0, 0, Lw.o_up, Lw.s_m};
+                    clip_gemm_r<ClipQUS<TIER, H3>, 1>(gu, smem_raw, rank, w, lane);
                 }
                 if (!end_phase(true)) return;
                 // ---- MLP down + residual
                 {
-                    const ClipGemm gd{mlp3, Lw.mlp2_w3, a.rows_pad, E, ME, Lw.mlp2_b, nullptr, nullptr, nullptr, nullptr, T, xres, nullptr,
-                                      nullptr, nullptr, nullptr, 0, 0, 0, 0};
-                    clip_gemm_l<ClipDnT<TIER>>(gd, smem_raw, rank, w, lane);
+                    const ClipGemm gd{mlp3, H3 ? Lw.mlp2_h3 : Lw.mlp2_w3, a.rows_pad, E, ME, Lw.mlp2_b, nullptr, nullptr, nullptr, nullptr, T, xres, nullptr,
+                                      nullptr, nullptr, nullptr, 0, 0, 0, 0, Lw.o_dn, 0.f};
+                    clip_gemm_l<ClipDnS<TIER, H3>>(gd, smem_raw, rank, w, lane);
                 }
                 if (!end_phase(true)) return;
             }
@@ -3091,6 +3145,38 @@ __global__ __launch_bounds__(256) void qkv_by_head_kernel(const float* __restric
     for (int k = threadIdx.x; k < E; k += 256) out[(size_t)r * E + k] = src[k];
 }
 
+// H3 provisioning: out[0] = max |w| over the matrix, out[1] = the largest row L1 norm (bit patterns of non-negative floats order like
+// unsigned integers: atomicMax on the words; out zeroed by the caller); one workgroup per row
+__global__ __launch_bounds__(256) void absmax_rows_kernel(const float* __restrict__ w, int ld, int cols, unsigned* __restrict__ out) {
+    __shared__ float s_mx[4], s_l1[4];
+    const float* row = w + (size_t)blockIdx.x * ld;
+    float mx = 0.f, l1 = 0.f;
+    for (int k = threadIdx.x; k < cols; k += 256) {
+        const float v = fabsf(row[k]);
+        mx = fmaxf(mx, v), l1 += v;
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o)), l1 += __shfl_xor(l1, o);
+    if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = mx, s_l1[threadIdx.x >> 6] = l1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+        l1 = (s_l1[0] + s_l1[1]) + (s_l1[2] + s_l1[3]);
+        atomicMax(out, __float_as_uint(mx));
+        atomicMax(out + 1, __float_as_uint(l1 * 1.0001f));  // (the sum's own rounding: the bound stays a bound)
+    }
+}
+// W [N][K] (row stride ldw) x scale -> h3 blocks (gemm_h3_pipe.h: two fp16 pieces per element; rows padded to 16 with zeros)
+__global__ __launch_bounds__(256) void h3_split_kernel(const float* __restrict__ W, int ldw, unsigned short* __restrict__ out, int N, int K, float scale) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // four consecutive k of one row
+    const int k4 = K / 4;
+    const size_t rows = x6_rows_padded(N);
+    if (idx >= rows * k4) return;
+    const int r = (int)(idx / k4), k = 4 * (int)(idx % k4);
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (r < N) v = *reinterpret_cast<const f32x4*>(W + (size_t)r * ldw + k);
+    h3_store4(out, r, k, K, v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale);
+}
+
 __global__ __launch_bounds__(256) void tile16_kernel(const float* __restrict__ W, int ldw, float* __restrict__ out, int N, int K) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // one float4 of the output
     if (idx >= (size_t)N * K / 4) return;
@@ -3112,8 +3198,9 @@ template __global__ void sample_seg_kernel<3, 256>(StepArgs);
 template __global__ void sample_seg_kernel<6, 256>(StepArgs);
 template __global__ void sample_seg_kernel<3, 512, 1>(StepArgs);
 template __global__ void sample_seg_kernel<6, 512, 1>(StepArgs);
-template __global__ void sample_clip_kernel<0>(ClipArgs);
-template __global__ void sample_clip_kernel<1>(ClipArgs);
+template __global__ void sample_clip_kernel<0, 0>(ClipArgs);
+template __global__ void sample_clip_kernel<1, 0>(ClipArgs);
+template __global__ void sample_clip_kernel<0, 1>(ClipArgs);
 
 }  // namespace
 }  // namespace after
@@ -3191,6 +3278,11 @@ struct after_denoiser {
     unsigned short* clip_act3 = nullptr;
     float* clip_halo = nullptr;            // [8][clip_rows / 192][8 heads][16][128]: clip_tile_attention's hand-over rows
     unsigned short* clip_qkv_w3h = nullptr;  // [L] x6 planes of the qkv weights with the output columns regrouped by head
+    // the two-piece fp16 form of the batch sampler's Linears (gemm_h3_pipe.h; AFTER_CLIP_SPLIT=bf16 keeps the three bf16 planes):
+    // [L] h3 blocks of qkv (by head) | mlp0 | mlp2, the per-layer scales (ClipLayer)
+    unsigned short* clip_h3_w = nullptr;
+    int clip_h3 = 1;
+    float clip_sc[8][6] = {};  // per layer: s_h1, s_h3, s_m, o_qkv, o_up, o_dn
     int clip_fuse = 1;         // AFTER_CLIP_FUSE=0: qkv rows through memory + attention items (A/B switch)
     int tier = 0;              // after_denoiser_set_gemm_path(h, 3): the persistent offline samplers' Linears with bf16 operands (h planes only)
     int clip_rows = 0, clip_pat_rows = 0;
@@ -3789,6 +3881,7 @@ extern "C" void after_denoiser_destroy(after_denoiser* h) {
     if (h->clip_act3) (void)hipFree(h->clip_act3);
     if (h->clip_halo) (void)hipFree(h->clip_halo);
     if (h->clip_qkv_w3h) (void)hipFree(h->clip_qkv_w3h);
+    if (h->clip_h3_w) (void)hipFree(h->clip_h3_w);
     h->wa.release();
     h->ws.release();
     h->ca.release();
@@ -4053,7 +4146,65 @@ int persist_prepare(after_denoiser* h, bool offline) {
                 ok = hipGetLastError() == hipSuccess && gemm_x6_split(tmp, (int)E, w3h + per * l, 3 * (int)E, (int)E, nullptr) == AFTER_OK &&
                      hipDeviceSynchronize() == hipSuccess;
             }
+            // ---- the two-piece fp16 form (gemm_h3_pipe.h): per-tensor power-of-two scales from guaranteed bounds, then the pieces
+            unsigned short* wh3 = nullptr;
+            {
+                const char* e2 = getenv("AFTER_CLIP_SPLIT");
+                if (e2) h->clip_h3 = strcmp(e2, "bf16") != 0;
+            }
+            const size_t pq = h3_elems(3 * (int)E, (int)E), pu = h3_elems((int)ME, (int)E), pd = h3_elems((int)E, (int)ME);
+            if (ok && h->clip_h3) {
+                unsigned* stats = nullptr;  // per layer: [w][max, L1] of qkv, mlp0, mlp2, mlp0_b, n1w, n1b, n3w, n3b
+                unsigned hs[8 * 16];
+                bool ok3 = hipMalloc(&wh3, (pq + pu + pd) * h->L * sizeof(unsigned short)) == hipSuccess &&
+                           hipMalloc(&stats, sizeof(hs)) == hipSuccess && hipMemset(stats, 0, sizeof(hs)) == hipSuccess;
+                for (int l = 0; ok3 && l < h->L; ++l) {
+                    const LayerW& w = h->layers[l];
+                    const struct { const float* p; int rows, cols; } m[8] = {{w.qkv_w, 3 * (int)E, (int)E}, {w.mlp0_w, (int)ME, (int)E}, {w.mlp2_w, (int)E, (int)ME},
+                                                                              {w.mlp0_b, 1, (int)ME}, {w.n1w, 1, (int)E}, {w.n1b, 1, (int)E},
+                                                                              {w.n3w, 1, (int)E}, {w.n3b, 1, (int)E}};
+                    for (int q = 0; q < 8; ++q)
+                        hipLaunchKernelGGL(absmax_rows_kernel, dim3((unsigned)m[q].rows), dim3(256), 0, nullptr, m[q].p, m[q].cols, m[q].cols, stats + 16 * l + 2 * q);
+                    ok3 = hipGetLastError() == hipSuccess;
+                }
+                ok3 = ok3 && hipMemcpy(hs, stats, sizeof(hs), hipMemcpyDeviceToHost) == hipSuccess;
+                for (int l = 0; ok3 && l < h->L; ++l) {
+                    auto f32 = [&](int q, int which) {
+                        float v;
+                        memcpy(&v, &hs[16 * l + 2 * q + which], sizeof(float));
+                        return v;
+                    };
+                    const float rootE = sqrtf((float)E);  // |LayerNorm(x)_i| <= sqrt(E - 1)
+                    const float b_h1 = rootE * f32(4, 0) + f32(5, 0), b_h3 = rootE * f32(6, 0) + f32(7, 0);
+                    const float b_m = f32(1, 1) * b_h3 + f32(3, 0);  // |GELU(v)| <= |v| <= ||W_row||_1 max|h| + |bias|
+                    const float s_h1 = h3_scale_for(b_h1), s_h3 = h3_scale_for(b_h3), s_m = h3_scale_for(b_m);
+                    const float sw_q = h3_scale_for(f32(0, 0)), sw_u = h3_scale_for(f32(1, 0)), sw_d = h3_scale_for(f32(2, 0));
+                    ok3 = std::isfinite(b_h1) && std::isfinite(b_h3) && std::isfinite(b_m) && b_m * s_m <= 32768.0f && b_h1 * s_h1 <= 32768.0f &&
+                          b_h3 * s_h3 <= 32768.0f;  // (bounds beyond fp16's range even at the smallest scale: the bf16 form serves the handle)
+                    float* sc = h->clip_sc[l];
+                    sc[0] = s_h1, sc[1] = s_h3, sc[2] = s_m, sc[3] = 1.0f / (s_h1 * sw_q), sc[4] = 1.0f / (s_h3 * sw_u), sc[5] = 1.0f / (s_m * sw_d);
+                    if (!ok3) break;
+                    const LayerW& w = h->layers[l];
+                    unsigned short* base = wh3 + (pq + pu + pd) * l;
+                    hipLaunchKernelGGL(qkv_by_head_kernel, dim3(3 * (unsigned)E), dim3(256), 0, nullptr, w.qkv_w, tmp, (int)E);
+                    hipLaunchKernelGGL(h3_split_kernel, dim3((unsigned)cdivll((long long)x6_rows_padded(3 * (int)E) * E / 4, 256)), dim3(256), 0, nullptr,
+                                       tmp, (int)E, base, 3 * (int)E, (int)E, sw_q);
+                    hipLaunchKernelGGL(h3_split_kernel, dim3((unsigned)cdivll((long long)x6_rows_padded((int)ME) * E / 4, 256)), dim3(256), 0, nullptr,
+                                       w.mlp0_w, (int)E, base + pq, (int)ME, (int)E, sw_u);
+                    hipLaunchKernelGGL(h3_split_kernel, dim3((unsigned)cdivll((long long)x6_rows_padded((int)E) * ME / 4, 256)), dim3(256), 0, nullptr,
+                                       w.mlp2_w, (int)ME, base + pq + pu, (int)E, (int)ME, sw_d);
+                    ok3 = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+                }
+                if (stats) (void)hipFree(stats);
+                if (!ok3) {  // (not an error: the three-plane bf16 form serves the handle)
+                    (void)hipGetLastError();
+                    if (wh3) (void)hipFree(wh3);
+                    wh3 = nullptr;
+                }
+            }
             if (tmp) (void)hipFree(tmp);
+            if (ok) h->clip_h3_w = wh3;
+            else if (wh3) (void)hipFree(wh3);
         }
         if (!ok) {
             (void)hipGetLastError();
@@ -4069,8 +4220,9 @@ int persist_prepare(after_denoiser* h, bool offline) {
     }
     // the kernels' dynamic LDS limits (a hipFuncSetAttribute inside after_sample would be one more first-call cost)
     {
-        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sample_clip_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClipLds));
-        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sample_clip_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClipLds));
+        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sample_clip_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClipLds));
+        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sample_clip_kernel<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClipLds));
+        AFTER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sample_clip_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClipLds));
         const size_t lds_seg = ((size_t)kSRedFloats(2) + 8 * 2 * kAttnKeyBlock * 64) * sizeof(float);
         const void* fns[] = {reinterpret_cast<const void*>(sample_seg_kernel<6, 512>), reinterpret_cast<const void*>(sample_seg_kernel<3, 512>),
                              reinterpret_cast<const void*>(sample_seg_kernel<6, 256>), reinterpret_cast<const void*>(sample_seg_kernel<3, 256>),
@@ -4374,14 +4526,23 @@ int sample_clip(after_denoiser* h, hipStream_t s, const float* x0, float* out, i
         ClipLayer& cl = a.layer[l];
         cl.qkv_w3 = w.qkv_w3, cl.mlp0_w3 = w.mlp0_w3, cl.mlp2_w3 = w.mlp2_w3;
         cl.qkv_w3h = h->clip_qkv_w3h + x6_elems(3 * E, E) * l;
+        if (h->clip_h3_w) {
+            const size_t pq = h3_elems(3 * E, E), pu = h3_elems(ME, E), pd = h3_elems(E, ME);
+            cl.qkv_h3 = h->clip_h3_w + (pq + pu + pd) * l, cl.mlp0_h3 = cl.qkv_h3 + pq, cl.mlp2_h3 = cl.mlp0_h3 + pu;
+            const float* sc = h->clip_sc[l];
+            cl.s_h1 = sc[0], cl.s_h3 = sc[1], cl.s_m = sc[2], cl.o_qkv = sc[3], cl.o_up = sc[4], cl.o_dn = sc[5];
+        }
         cl.mlp0_b = w.mlp0_b, cl.mlp2_b = w.mlp2_b, cl.n1w = w.n1w, cl.n1b = w.n1b, cl.n3w = w.n3w, cl.n3b = w.n3b;
     }
     const bool timed = h->timer.enabled && h->timer_kernel == 3;
     if (timed) h->timer.begin(s);
     {
         PersistLaunch guard(h->dev, s);
-        if (h->tier) hipLaunchKernelGGL(sample_clip_kernel<1>, dim3(h->n_cus), dim3(512), kClipLds, s, a);
-        else hipLaunchKernelGGL(sample_clip_kernel<0>, dim3(h->n_cus), dim3(512), kClipLds, s, a);
+        // the default arithmetic: two-piece fp16 operands where the tiles attend in place (the shipped attention geometries), else
+        // three bf16 planes; the opt-in bf16 tolerance tier is its own instantiation
+        if (h->tier) hipLaunchKernelGGL((sample_clip_kernel<1, 0>), dim3(h->n_cus), dim3(512), kClipLds, s, a);
+        else if (h->clip_h3_w && a.fuse) hipLaunchKernelGGL((sample_clip_kernel<0, 1>), dim3(h->n_cus), dim3(512), kClipLds, s, a);
+        else hipLaunchKernelGGL((sample_clip_kernel<0, 0>), dim3(h->n_cus), dim3(512), kClipLds, s, a);
     }
     AFTER_HIP_CHECK(hipGetLastError());
     if (timed) {

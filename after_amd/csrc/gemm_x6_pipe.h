@@ -26,6 +26,7 @@ struct X6Cfg {
     // TIER 1 (the opt-in bf16 tolerance tier of the batch sampler, after_denoiser_set_gemm_path(h, 3)): only the h x h product of
     // every block is issued -- bf16 operands (the top planes of the exact splits), fp32 accumulate
     static constexpr int TIER = TIER_;
+    static constexpr int SPLIT = 0, NPL = 3;  // three bf16 planes, six products (gemm_h3_pipe.h: SPLIT 1 = two fp16 pieces, three products)
     // SC1: the DMA pieces are sc1 loads -- they miss the CU's vector L1 and are served by the XCD's L2: for operands that
     // another workgroup of the same XCD wrote earlier in the SAME kernel (the clip-per-XCD sampler of denoiser.hip)
     static constexpr int SC1 = SC1_;
@@ -443,6 +444,7 @@ __device__ __forceinline__ void x6l_main(X6LState<C>& c, int nk) {
 template <int MB_, int NBK_, int RS_, int CP_, int SC1_ = 0, int TIER_ = 0>
 struct X6RCfg {
     static constexpr int MB = MB_, NBK = NBK_, RS = RS_, CP = CP_, SC1 = SC1_, NS = 2, KS = 1, CONV = 0, ACC2 = 0, TIER = TIER_;
+    static constexpr int SPLIT = 0, NPL = 3;
     static constexpr int BM = 16 * MB, BN = 16 * NBK, MT = MB / RS, NT = NBK / CP, NW = RS * CP, AB = MB;
     static constexpr int GA = 3 * MB, GW = 3 * NBK, PPK = GA + GW, STAGE = PPK * 1024;
     static constexpr int PPKI = TIER ? MB + NBK : PPK;  // pieces ISSUED per slab (TIER 1: the h planes only; the stage keeps its layout)

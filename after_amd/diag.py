@@ -62,6 +62,19 @@ def split_x6(w):
     return out
 
 
+def split_gemm(a, w, mode):
+    """a [M, K] @ w [N, K]^T in one of the Linears' arithmetics (include/after_hip.h: after_diag_split_gemm) -- 0: the fp32 MFMA
+    chain, 1: three bf16 planes x six products, 2: two fp16 pieces x three products (scales from the operands' maxima)."""
+    a = _lib.require_gpu_tensor(a, "a")
+    w = _lib.require_gpu_tensor(w, "w")
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, device=a.device)
+    _lib.check(_lib.lib().after_diag_split_gemm(_lib.ptr(a), _lib.ptr(w), _lib.ptr(out), M, N, K, int(mode), float(a.abs().max()),
+                                                float(w.abs().max()), _lib.current_stream(a.device)), "after_diag_split_gemm")
+    return out
+
+
 def gemm_x6(a3, w3, bias=None, residual=None, epilogue=0, tile=0, out=None, planes=False):
     """out[M,N] = epi(a @ w^T + bias) on the bf16-split path (gemm_x6.hip): a3 / w3 = X6Planes; the result is
     fp32 [M, N], or (planes=True) X6Planes of it."""

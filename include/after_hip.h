@@ -511,6 +511,16 @@ int after_gemm_x6_pick_tile(int M, int N, int K);
 int after_gemm_x6(const unsigned short* A3, const unsigned short* W3, const float* bias, const float* R, int ldr,
                   float* C, unsigned short* C3, int ldc, int M, int N, int K, int epilogue, int tile, void* stream);
 
+/* Test / measurement entry (after_amd/csrc/split_diag.hip; no product path calls it): C [M][N] = A [M][K] W[N][K]^T in ONE of the
+ * arithmetics the denoiser's Linears run in, one wave per 16 x 16 block, operands split on the fly --
+ * mode 0: v_mfma_f32_16x16x4_f32, the exact fp32 fma chain (reference: F.linear in fp32, transformerv2.py:251, :275-283);
+ * mode 1: three bf16 planes per operand, six bf16 MFMAs per 32-deep block (gemm_x6.hip, the launch path and sample_seg_kernel);
+ * mode 2: two fp16 pieces per operand (a 22-bit significand) under exact power-of-two scales derived from the bounds
+ *         a_bound >= max|A|, w_bound >= max|W|, three f16 MFMAs per block (gemm_h3_pipe.h, the batch sampler's Linears).
+ * M, N multiples of 16, K of 32.  tests/test_gemm_gpu.py holds the split forms' error vs fp64 to the fp32 chain's. */
+int after_diag_split_gemm(const float* A, const float* W, float* C, int M, int N, int K, int mode, float a_bound, float w_bound,
+                          void* stream);
+
 /* One Conv1d layer on the time-major conv path (act(x) into the zero-haloed [B][T][C] buffer, then
  * the conv as a balanced LDS-DMA GEMM) for parity tests against a plain fp32 conv and for the
  * per-layer tile sweeps (scripts/bench_conv.py).  w [Cout, Cin, k] (torch.nn.Conv1d layout),

@@ -20,4 +20,14 @@ gstag)  # experiment: row-tile groups of an XCD out of phase in the MLP-up phase
     done
     cat $O/gstag.txt
     ;;
+h3)  # the two-piece fp16 form of the batch sampler's Linears: parity, same-box A/B against the three bf16 planes, per-phase trace
+    timeout 1200 python -m pytest tests/test_sample_clip_gpu.py -x -q 2>&1 | tail -15
+    for rep in 1 2; do
+      for cfg in "base 8" "midi 8"; do set -- $cfg
+        AFTER_CLIP_SPLIT=bf16 python scripts/time_sampler.py $1 $2 50 3 2>/dev/null | tail -1 | cut -c1-100 | sed "s/^/bf16 x 3 planes: /" | tee -a $O/ab_split.txt
+        python scripts/time_sampler.py $1 $2 50 3 2>/dev/null | tail -1 | cut -c1-100 | sed "s/^/fp16 x 2 pieces: /" | tee -a $O/ab_split.txt
+      done
+    done
+    python scripts/stream_step_trace.py --offline --clips 8 --xcd 3 2>/dev/null | grep -v amdgpu.ids | tee $O/clip_step_trace.txt | tail -12
+    ;;
 esac

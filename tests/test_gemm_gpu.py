@@ -175,3 +175,32 @@ def test_gemm_x6_layout_and_determinism(hip_device):
         diag.gemm_x6(a96, w96, tile=2)
     with pytest.raises(AFTERHipError):
         diag.gemm_x6(a3, w3, tile=77)
+
+
+@pytest.mark.parametrize("M,N,K", [(768, 1536, 512), (768, 512, 1536), (192, 192, 512)])
+@pytest.mark.parametrize("regime", ["sampler", "tiny_weights", "wide_range"])
+def test_h3_two_piece_fp16_products_against_the_fp32_chain(M, N, K, regime, hip_device):
+    """The batch sampler's Linears (gemm_h3_pipe.h): every operand as TWO fp16 pieces under an exact power-of-two scale, three
+    f16 MFMAs per product block (Wh Al + Wh Ah + Wl Ah), fp32 accumulate -- on the sampler's shapes, operands with outliers
+    (x 25), weights of trained-model scale and tiny ones, and activations spanning eight decades.  One wave per 16 x 16 block
+    (after_diag_split_gemm), the SAME summation order in all three arithmetics, so the comparison isolates the operand form:
+    bar: error vs fp64 -- rms <= 1.0 x and max <= 1.25 x that of the exact fp32 fma chain (v_mfma_f32_16x16x4_f32: the reference's
+    own arithmetic); the three-plane bf16 form under the same bar beside it."""
+    from after_amd import diag
+    a, w, _, _, _ = _x6_case(M, N, K, 0, M + N + K)
+    if regime == "tiny_weights":
+        w = w * 1e-3
+    if regime == "wide_range":  # magnitudes from 1e-6 to 1e2 side by side in every row: the pieces' absolute-error floor
+        g = torch.Generator().manual_seed(9)
+        a = a * torch.pow(10.0, torch.randint(-6, 2, a.shape, generator=g).float())
+    ref = a.double() @ w.double().T
+    dev = hip_device
+    c32, c6, c3 = (diag.split_gemm(a.to(dev), w.to(dev), m).cpu() for m in (0, 1, 2))
+    e32, e6, e3 = ((x.double() - ref).abs() for x in (c32, c6, c3))
+    rms = lambda e: e.pow(2).mean().sqrt().item()
+    floor = 1e-7 * ref.abs().max().item()
+    assert rms(e6) <= max(rms(e32), floor), (rms(e6), rms(e32))
+    assert rms(e3) <= max(rms(e32), floor), (rms(e3), rms(e32), rms(e6))
+    assert e3.max().item() <= max(1.25 * e32.max().item(), floor), (e3.max().item(), e32.max().item())
+    print(f"h3 {M}x{N}x{K} {regime}: rms vs fp64 -- fp32 chain {rms(e32):.3e}, bf16 x 6 {rms(e6):.3e} ({rms(e6) / rms(e32):.2f} x), "
+          f"fp16 x 3 {rms(e3):.3e} ({rms(e3) / rms(e32):.2f} x); max {e32.max().item():.3e} / {e6.max().item():.3e} / {e3.max().item():.3e}")
