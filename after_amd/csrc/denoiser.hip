@@ -728,6 +728,10 @@ struct StepSync {
 struct StepLayer {
     const float *qkv_wt, *mlp0_wt, *mlp0_b, *mlp2_wt, *mlp2_b, *n1w, *n1b, *n3w, *n3b;  // *_wt: 16 x 16-tiled copies
     float* qkv;                // this layer's [rows * T][3E], row-major (attention, roll_cache)
+    // offline segment sampler, two-piece fp16 form (TIER 2; gemm_h3_pipe.h): the tiled copies as fp16 pieces (tile16_h3_kernel), the
+    // power-of-two scales of norm1 / norm3 outputs and of the MLP hidden layer, and 1 / (activation scale x weight scale) per Linear
+    const float *qkv_ht, *mlp0_ht, *mlp2_ht;
+    float s_h1, s_h3, s_m, o_qkv, o_up, o_dn;
 };
 
 struct StepKV {
@@ -951,6 +955,7 @@ __device__ __forceinline__ f32x4 step_reduced(const float* red, int P, int p, in
 template <int E>  // embed width: 512 (base, midi) or 256 (tiny: the offline segment sampler only)
 struct StepLnOpsT {
     f32x4 al[E / 256], be[E / 256], ww[E / 256], bb[E / 256];
+    float hs;  // PLANES 3: the power-of-two scale of the fp16 pieces of h
 };
 using StepLnOps = StepLnOpsT<kSE>;
 
@@ -979,8 +984,18 @@ __device__ __forceinline__ void p32_store4(unsigned short* base, int lr, int c, 
     *reinterpret_cast<uint2*>(q + 1024) = l;
 }
 
+// the same block positions with TWO fp16 pieces of the (scaled) values -- gemm_h3_pipe.h -- in planes 0 and 1 (the third stays unused)
+__device__ __forceinline__ void p32h_store4(unsigned short* base, int lr, int c, int kb32, float x0, float x1, float x2, float x3) {
+    uint2 h, l;
+    h3_split4(x0, x1, x2, x3, h, l);
+    unsigned short* q = base + (((size_t)((lr >> 4) * kb32 + (c >> 5)) * 3) << 9) + ((((c & 15) >> 2) * 16 + (lr & 15)) << 3) + ((c & 16) >> 2);
+    *reinterpret_cast<uint2*>(q) = h;
+    *reinterpret_cast<uint2*>(q + 512) = l;
+}
+
 // ln_mod_ln_row on tiled buffers (E = 512): x = norm0(xin[src]) * (1 + alpha_t) + beta_t -> xres ; h = norm1(x)
-template <int PLANES = 0, int E = kSE>  // h: fp32 tiles (0), bf16 x 3 planes in fragment order (1: p32_store4) or in x6 blocks (2: x6_store4, common.h)
+template <int PLANES = 0, int E = kSE>  // h: fp32 tiles (0), bf16 x 3 planes in fragment order (1: p32_store4) or in x6 blocks (2: x6_store4, common.h),
+                                        // two fp16 pieces of h x ops.hs in fragment order (3: p32h_store4)
 __device__ __forceinline__ void step_ln_row(__amdgpu_buffer_rsrc_t xin, int src_lr, float* __restrict__ xres,
                                             float* __restrict__ h, int lr, const StepLnOpsT<E>& ops, int lane) {
     constexpr int NV = E / 256, KBt = E / 16;
@@ -1022,6 +1037,7 @@ __device__ __forceinline__ void step_ln_row(__amdgpu_buffer_rsrc_t xin, int src_
         y.w = (v[i].w - mean) * rstd * ww[i].w + bb[i].w;
         if constexpr (PLANES == 2) x6_store4(reinterpret_cast<unsigned short*>(h), lr, 4 * lane + 256 * i, E, y.x, y.y, y.z, y.w);
         else if constexpr (PLANES == 1) p32_store4(reinterpret_cast<unsigned short*>(h), lr, 4 * lane + 256 * i, E / 32, y.x, y.y, y.z, y.w);
+        else if constexpr (PLANES == 3) p32h_store4(reinterpret_cast<unsigned short*>(h), lr, 4 * lane + 256 * i, E / 32, y.x * ops.hs, y.y * ops.hs, y.z * ops.hs, y.w * ops.hs);
         else *reinterpret_cast<f32x4*>(h + o) = y;
     }
 }
@@ -1037,6 +1053,7 @@ struct StepAttn {  // (by value: the offline kernel calls the attention out of l
     int T, cs, W, cache, nkmax;
     const float *rope_cos, *rope_sin;
     const float* qkv;  // this layer's rows
+    float hs = 1.0f;   // PLANES 3: the power-of-two scale of the fp16 pieces of the LayerNorm tail's output
 };
 
 __device__ __forceinline__ bool seg_spin_sys(const unsigned* word, unsigned want, unsigned* fail) {
@@ -1249,6 +1266,7 @@ __device__ __forceinline__ void step_attention(const StepAttn& a, const StepKV& 
             y.w = (v[i].w - mean) * rstd * ww[i].w + bb[i].w;
             if constexpr (PLANES == 2) x6_store4(reinterpret_cast<unsigned short*>(hout), lr0 + i0 + qi, 4 * lane + 256 * i, E, y.x, y.y, y.z, y.w);
             else if constexpr (PLANES == 1) p32_store4(reinterpret_cast<unsigned short*>(hout), lr0 + i0 + qi, 4 * lane + 256 * i, E / 32, y.x, y.y, y.z, y.w);
+            else if constexpr (PLANES == 3) p32h_store4(reinterpret_cast<unsigned short*>(hout), lr0 + i0 + qi, 4 * lane + 256 * i, E / 32, y.x * a.hs, y.y * a.hs, y.z * a.hs, y.w * a.hs);
             else *reinterpret_cast<float4*>(hout + off) = y;
         }
     }
@@ -1582,6 +1600,7 @@ __device__ __forceinline__ void seg_split8(const f32x4& a, const f32x4& b, u32x4
 #define SEG_SLOTS_W 2
 #endif
 constexpr int kSegSlotsA = SEG_SLOTS_A, kSegSlotsW = SEG_SLOTS_W;  // k-blocks of a wave in flight or in use (rings of register slots)
+constexpr int kSegNP[3] = {3, 1, 2};  // activation planes a GEMM phase fetches, by TIER: three bf16 planes | the h plane | two fp16 pieces
 template <int RB, int NT>
 struct SegBuf {
     f32x4 wr[kSegSlotsW][NT][2];   // raw fp32 weight fragments of a 32-deep k-block
@@ -1621,6 +1640,8 @@ __device__ __forceinline__ void seg_load_w(SegBuf<RB, NT>& sb, int slot, __amdgp
 // weights from the fabric, and loads return in issue order; weights first measured + 0.6 us per phase).
 template <int RB, int NT, int KB, int DIAG, int TIER, class F>  // DIAG (timing experiments, -DSEG_DIAG=n): 1 no MFMAs, 2 no weight split
                                                                    // TIER 1: the h x h product only (the opt-in bf16 tolerance tier)
+                                                                   // TIER 2: two fp16 pieces per operand, three products (gemm_h3_pipe.h):
+                                                                   //         the weight fragments arrive split (tile16_h3_kernel)
 __device__ __forceinline__ void seg_run(f32x4 (&acc)[NT * RB], SegBuf<RB, NT>& sb, __amdgpu_buffer_rsrc_t A3, int a_kb32, int rb0,
                                         __amdgpu_buffer_rsrc_t W, int w_kblocks, int tile0, int ts, int kb0, int lane, F&& after_loads) {
     constexpr int NA = kSegSlotsA, NW = kSegSlotsW, NX = NA > NW ? NA : NW;
@@ -1628,19 +1649,31 @@ __device__ __forceinline__ void seg_run(f32x4 (&acc)[NT * RB], SegBuf<RB, NT>& s
     // multiplied (the loop is latency-bound: bytes in flight per CU are what it runs on)
 #pragma unroll
     for (int v = 1; v < NX - 1 && v < KB; ++v) {
-        if (v < NA - 1) seg_load_a<RB, NT, TIER ? 1 : 3>(sb, v % NA, A3, a_kb32, rb0, kb0 + v, lane);
+        if (v < NA - 1) seg_load_a<RB, NT, kSegNP[TIER]>(sb, v % NA, A3, a_kb32, rb0, kb0 + v, lane);
         if (v < NW - 1) seg_load_w<RB, NT>(sb, v % NW, W, w_kblocks, tile0, ts, kb0 + v, lane);
     }
 #pragma unroll
     for (int p = 0; p < NT * RB; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < KB; ++u) {
-        if (u + NA - 1 < KB) seg_load_a<RB, NT, TIER ? 1 : 3>(sb, (u + NA - 1) % NA, A3, a_kb32, rb0, kb0 + u + NA - 1, lane);
+        if (u + NA - 1 < KB) seg_load_a<RB, NT, kSegNP[TIER]>(sb, (u + NA - 1) % NA, A3, a_kb32, rb0, kb0 + u + NA - 1, lane);
         if (u + NW - 1 < KB) seg_load_w<RB, NT>(sb, (u + NW - 1) % NW, W, w_kblocks, tile0, ts, kb0 + u + NW - 1, lane);
         if (u + 2 == KB || KB == 1) after_loads();
         // all weight fragments of the k-block are split first, then the MFMAs run product by product over every (tile, row
         // block) -- nine independent accumulators between two uses of the same one.  (One tile at a time -- split, 18 MFMAs,
         // next tile: 24 registers less -- measured + 10 % per Euler step: the split's latency is exposed in front of every tile.)
+        if constexpr (TIER == 2) {  // (Wh, Al) (Wh, Ah) (Wl, Ah): smallest product first; planes 0 = h, 1 = l on both sides
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int i = 0; i < RB; ++i)
+                        acc[j * RB + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                            __builtin_bit_cast(f16x8, sb.wr[u % NW][j][p == 2 ? 1 : 0]), __builtin_bit_cast(f16x8, sb.ap[u % NA][i][p == 0 ? 1 : 0]),
+                            acc[j * RB + i], 0, 0, 0);
+            continue;
+        }
         u32x4 wp[NT][3];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -1712,7 +1745,7 @@ __device__ __forceinline__ T* seg_uniform(T* p) {
 }
 __device__ __forceinline__ int seg_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-template <int E>
+template <int E, int PL = 1>  // PL: the form of the LayerNorm tail's output (step_ln_row: 1 bf16 x 3 planes, 3 two fp16 pieces x g.hs)
 __device__ __attribute__((noinline)) void seg_attention(StepAttn g, const float* ab, const float* w3, const float* b3, int rg, int lr0,
                                                         int bx, bool halo, float* smem, float* kvlds, float* xres, float* hout,
                                                         unsigned long long* tr) {
@@ -1731,17 +1764,21 @@ __device__ __attribute__((noinline)) void seg_attention(StepAttn g, const float*
 #pragma unroll
     for (int i = 0; i < E / 256; ++i) none.al[i] = none.be[i] = none.ww[i] = none.bb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     // system-scope q / K / V loads only where keys of the previous XCD are involved; the other chunks read this XCD's L2
-    if (halo) step_attention<17, 1, true, false, E>(g, nokv, none, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout, ab, w3, b3, tr);
-    else step_attention<16, 1, true, false, E>(g, nokv, none, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout, ab, w3, b3, tr);
+    none.hs = 1.0f;
+    if (halo) step_attention<17, PL, true, false, E>(g, nokv, none, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout, ab, w3, b3, tr);
+    else step_attention<16, PL, true, false, E>(g, nokv, none, rg, lr0, bx, smem, kvlds, step_rsrc(g.qkv), step_rsrc(xres), xres, hout, ab, w3, b3, tr);
 }
 
 // Width: E = 512 (base, midi: 32 column tiles per q / k / v block -- one per workgroup of the XCD) or 256 (tiny.gin:65-83: 16 column
 // tiles -- the XCD's two row halves are dealt over the workgroups instead, workgroup = (column tile rank % 16, row half rank / 16),
 // and its eight waves split K eight ways; four heads on waves 0 .. 3 of an attention item).  MLP width 3 E, heads E / 64.
 // Length: nseg <= 8 segments of Tseg = 16 or 32 frames on XCDs 0 .. nseg - 1; the other XCDs leave after the census.
-template <int MB, int E, int TIER = 0>  // MB: row blocks per XCD, 3 Tseg / 16 (6 at T = 256); TIER 1: the opt-in bf16 tolerance tier
+template <int MB, int E, int TIER = 0>  // MB: row blocks per XCD, 3 Tseg / 16 (6 at T = 256); TIER 1: the opt-in bf16 tolerance tier;
+                                        // TIER 2: the Linears on two-piece fp16 operands (gemm_h3_pipe.h)
 __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
-    constexpr int NPL = TIER ? 1 : 3;  // activation planes a GEMM phase fetches
+    constexpr int NPL = kSegNP[TIER];  // activation planes a GEMM phase fetches
+    constexpr bool H3 = TIER == 2;
+    constexpr int PLN = H3 ? 3 : 1;    // producers' plane form (step_ln_row)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ unsigned s_rank, s_bad, s_ok;
     constexpr int ME = 3 * E, KBE = E / 16, KBM = ME / 16, MBP = (MB + 2) / 3;  // MBP: row blocks of one CFG row
@@ -1871,7 +1908,8 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
             if (ln_mine) {
                 StepLnOpsT<E> lnops;
                 step_ln_ops(lnops, ln_ab0 + (size_t)l * 2 * E, Lw.n1w, Lw.n1b, lane);
-                step_ln_row<1, E>(l == 0 ? pat_r : xres_r, l == 0 ? ln_lm % Tseg : ln_lm, xres, reinterpret_cast<float*>(hb3), ln_lm, lnops, lane);
+                lnops.hs = Lw.s_h1;
+                step_ln_row<PLN, E>(l == 0 ? pat_r : xres_r, l == 0 ? ln_lm % Tseg : ln_lm, xres, reinterpret_cast<float*>(hb3), ln_lm, lnops, lane);
             }
             // (the reverse hazard -- the next XCD must have read this layer's keys of the PREVIOUS step before the qkv phase below
             //  overwrites the segment's last frames -- is checked one layer early, by a workgroup without an attention item during
@@ -1895,7 +1933,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
             const bool dact = NH * KBE >= 32 || tile0d < KBE;  // (MLP-down: this workgroup has tiles -- the same)
             SegBuf<3, 3> sbq;
             {
-                const __amdgpu_buffer_rsrc_t Wq = step_rsrc(Lww.qkv_wt);
+                const __amdgpu_buffer_rsrc_t Wq = step_rsrc(H3 ? Lww.qkv_ht : Lww.qkv_wt);
                 if (!end_phase(ln_mine)) return;
                 // ---- qkv (bf16 x 3 split MFMAs), three row blocks at a time; the rows are written through to memory (the next
                 //      XCD's attention reads the last W - 1 frames)
@@ -1952,6 +1990,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 for (int q = 0; q < 3; ++q) {
                     const int p = w + 8 * q, hh = p / 9, pp = p - 9 * hh;
                     os[q] = p < 9 * NHW ? seg_sum<KS>(red + (size_t)hh * KS * 9 * 256, 9, pp, lane) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (H3) os[q] = os[q] * Lw.o_qkv;  // (an exact power of two)
                 }
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {  // (unconditional: tiles without RoPE carry cos = 1, sin = 0 -- no branch between the sums and the stores)
@@ -1985,13 +2024,13 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                     __syncthreads();
                     if (!s_ok) return;
                 }
-                seg_attention<E>(StepAttn{T, a.cs, a.W, 0, a.nkmax, a.rope_cos, a.rope_sin, Lw.qkv}, cond_ab + (size_t)br * a.cond_ld + (size_t)l * 2 * E,
+                seg_attention<E, PLN>(StepAttn{T, a.cs, a.W, 0, a.nkmax, a.rope_cos, a.rope_sin, Lw.qkv, Lw.s_h3}, cond_ab + (size_t)br * a.cond_ld + (size_t)l * 2 * E,
                               Lw.n3w, Lw.n3b, br, br * Tseg - f0, i0f / a.cs, halo, smem, kvl, xres, reinterpret_cast<float*>(hb3), trace);
             }
             constexpr int NTU = KBM / TPW;  // MLP-up column tiles of a workgroup (3: the hidden layer is 3 E wide)
             SegBuf<3, NTU> sbu;
             {
-                const __amdgpu_buffer_rsrc_t Wu = step_rsrc(Lww.mlp0_wt);
+                const __amdgpu_buffer_rsrc_t Wu = step_rsrc(H3 ? Lww.mlp0_ht : Lww.mlp0_wt);
                 if (!end_phase(true, &st->att_seq[g][0], seq)) return;
                 // ---- MLP up + GELU: column tiles rank + 32 j; the hidden layer as bf16 x 3 planes
                 f32x4 acc[3 * NTU];
@@ -2020,14 +2059,20 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                     if (p >= 3 * NTU * NHW || !gact) break;
                     const int hh = p / (3 * NTU), pp = p - 3 * NTU * hh, j = pp / 3, ib = pp - 3 * j, tile = ct + TPW * j;
                     const f32x4 bv = bvs[q];
-                    const f32x4 o = seg_sum<KS>(red + (size_t)hh * KS * 3 * NTU * 256, 3 * NTU, pp, lane);
-                    p32_store4(mlp3, 16 * (3 * (hh + h0) + ib) + (lane & 15), 16 * tile + 4 * (lane >> 4), ME / 32, gelu_erf(o[0] + bv[0]),
-                               gelu_erf(o[1] + bv[1]), gelu_erf(o[2] + bv[2]), gelu_erf(o[3] + bv[3]));
+                    f32x4 o = seg_sum<KS>(red + (size_t)hh * KS * 3 * NTU * 256, 3 * NTU, pp, lane);
+                    if constexpr (H3) {
+                        o = o * Lw.o_up;
+                        p32h_store4(mlp3, 16 * (3 * (hh + h0) + ib) + (lane & 15), 16 * tile + 4 * (lane >> 4), ME / 32, gelu_erf(o[0] + bv[0]) * Lw.s_m,
+                                    gelu_erf(o[1] + bv[1]) * Lw.s_m, gelu_erf(o[2] + bv[2]) * Lw.s_m, gelu_erf(o[3] + bv[3]) * Lw.s_m);
+                    } else {
+                        p32_store4(mlp3, 16 * (3 * (hh + h0) + ib) + (lane & 15), 16 * tile + 4 * (lane >> 4), ME / 32, gelu_erf(o[0] + bv[0]),
+                                   gelu_erf(o[1] + bv[1]), gelu_erf(o[2] + bv[2]), gelu_erf(o[3] + bv[3]));
+                    }
                 }
             }
             SegBuf<3, NTD> sbd;
             {
-                const __amdgpu_buffer_rsrc_t Wd = step_rsrc(Lww.mlp2_wt);
+                const __amdgpu_buffer_rsrc_t Wd = step_rsrc(H3 ? Lww.mlp2_ht : Lww.mlp2_wt);
                 if (!end_phase(true)) return;
                 // ---- MLP down + residual
                 f32x4 acc[3 * NTD], bv[1], rv[1];
@@ -2055,6 +2100,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 seg_partials<3 * NTD>(acc, red, w, lane);
                 if (w < 3 * NTD && dact) {
                     f32x4 o = seg_sum<8>(red, 3 * NTD, w, lane);  // (acc index = column tile x 3 + row block = w)
+                    if constexpr (H3) o = o * Lw.o_dn;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = o[r] + bv[0][r] + rv[0][r];
                     *reinterpret_cast<f32x4*>(xres + offd) = o;
@@ -2134,7 +2180,10 @@ using ClipQU = ClipQUT<0>;
 using ClipDn = ClipDnT<0>;
 // the two-piece fp16 form of the same tiles (gemm_h3_pipe.h: three MFMAs per product block; three-stage rings of 48 / 28 KB)
 using ClipQUH = H3RCfg<12, 12, 4, 2, 3, 1>;
-using ClipDnH = H3LCfg<6, 8, 2, 4, 3, 1, 1>;
+#ifndef CLIP_DNH_NS
+#define CLIP_DNH_NS 3
+#endif
+using ClipDnH = H3LCfg<6, 8, 2, 4, CLIP_DNH_NS, 1, 1>;
 template <int TIER, int H3>
 using ClipQUS = std::conditional_t<H3 != 0, ClipQUH, ClipQUT<TIER>>;
 template <int TIER, int H3>
@@ -3187,6 +3236,26 @@ __global__ __launch_bounds__(256) void tile16_kernel(const float* __restrict__ W
     *reinterpret_cast<f32x4*>(out + idx * 4) = *reinterpret_cast<const f32x4*>(W + (size_t)(16 * tile + r) * ldw + 16 * kb + 4 * kq);
 }
 
+// the same tiles as TWO fp16 pieces of W x scale (gemm_h3_pipe.h), in the operand order of the 16 x 16 x 32 MFMA: per (tile, 32-deep
+// k-block) 1 KB of h pieces then 1 KB of l pieces; lane (r, kq) holds columns 32 b + 4 kq + j and 32 b + 16 + 4 kq + j of row 16 tile + r
+// at lane x 16 bytes -- the k sets the fp32 tiles deliver (2 KB per k-block either way: seg_load_w reads both forms alike)
+__global__ __launch_bounds__(256) void tile16_h3_kernel(const float* __restrict__ W, int ldw, unsigned short* __restrict__ out, int N, int K, float scale) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // one lane's eight values of one (tile, k-block)
+    if (idx >= (size_t)N * K / 8) return;
+    const int l = idx & 63;
+    const size_t blk = idx >> 6;
+    const int kb = blk % (K / 32), tile = blk / (K / 32);
+    const int r = l & 15, kq = l >> 4;
+    const float* src = W + (size_t)(16 * tile + r) * ldw + 32 * kb + 4 * kq;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 16);
+    uint2 h0, l0, h1, l1;
+    h3_split4(v0[0] * scale, v0[1] * scale, v0[2] * scale, v0[3] * scale, h0, l0);
+    h3_split4(v1[0] * scale, v1[1] * scale, v1[2] * scale, v1[3] * scale, h1, l1);
+    unsigned short* o = out + (blk << 10) + l * 8;  // (1024 unsigned shorts = 2 KB per (tile, k-block))
+    *reinterpret_cast<u32x4*>(o) = u32x4{h0.x, h0.y, h1.x, h1.y};
+    *reinterpret_cast<u32x4*>(o + 512) = u32x4{l0.x, l0.y, l1.x, l1.y};
+}
+
 // (explicit: with the generic lambdas of step_attention in the tree, hipcc 7.2 drops the implicit instantiations that the host
 //  code below asks for -- the objects then carry undefined kernel handles)
 template __global__ void stream_step_kernel<1>(StepArgs);
@@ -3198,6 +3267,10 @@ template __global__ void sample_seg_kernel<3, 256>(StepArgs);
 template __global__ void sample_seg_kernel<6, 256>(StepArgs);
 template __global__ void sample_seg_kernel<3, 512, 1>(StepArgs);
 template __global__ void sample_seg_kernel<6, 512, 1>(StepArgs);
+template __global__ void sample_seg_kernel<3, 512, 2>(StepArgs);
+template __global__ void sample_seg_kernel<6, 512, 2>(StepArgs);
+template __global__ void sample_seg_kernel<3, 256, 2>(StepArgs);
+template __global__ void sample_seg_kernel<6, 256, 2>(StepArgs);
 template __global__ void sample_clip_kernel<0, 0>(ClipArgs);
 template __global__ void sample_clip_kernel<1, 0>(ClipArgs);
 template __global__ void sample_clip_kernel<0, 1>(ClipArgs);
@@ -3281,8 +3354,12 @@ struct after_denoiser {
     // the two-piece fp16 form of the batch sampler's Linears (gemm_h3_pipe.h; AFTER_CLIP_SPLIT=bf16 keeps the three bf16 planes):
     // [L] h3 blocks of qkv (by head) | mlp0 | mlp2, the per-layer scales (ClipLayer)
     unsigned short* clip_h3_w = nullptr;
-    int clip_h3 = 1;
+    int clip_h3 = 1;           // AFTER_CLIP_SPLIT=bf16 / AFTER_SEG_SPLIT=bf16: the persistent offline samplers on three bf16 planes (A/B)
+    int seg_h3 = 1;
+    int h3_state = 0;          // 0 not computed, 1 scales valid, -1 a bound beyond fp16's range (the bf16 form serves the handle)
     float clip_sc[8][6] = {};  // per layer: s_h1, s_h3, s_m, o_qkv, o_up, o_dn
+    float h3_sw[8][3] = {};    // per layer: the weights' scales (qkv, mlp0, mlp2)
+    unsigned short* seg_h3_w = nullptr;  // [L] tile16_h3_kernel copies of qkv | mlp0 | mlp2 (the one-clip sampler)
     int clip_fuse = 1;         // AFTER_CLIP_FUSE=0: qkv rows through memory + attention items (A/B switch)
     int tier = 0;              // after_denoiser_set_gemm_path(h, 3): the persistent offline samplers' Linears with bf16 operands (h planes only)
     int clip_rows = 0, clip_pat_rows = 0;
@@ -3882,6 +3959,7 @@ extern "C" void after_denoiser_destroy(after_denoiser* h) {
     if (h->clip_halo) (void)hipFree(h->clip_halo);
     if (h->clip_qkv_w3h) (void)hipFree(h->clip_qkv_w3h);
     if (h->clip_h3_w) (void)hipFree(h->clip_h3_w);
+    if (h->seg_h3_w) (void)hipFree(h->seg_h3_w);
     h->wa.release();
     h->ws.release();
     h->ca.release();
@@ -4053,6 +4131,52 @@ void persist_off(after_denoiser* h) {
 // restores fully asynchronous enqueue.)  All-or-nothing: allocations go to
 // locals and are committed together; if anything fails they are released, the persistent paths are switched off and the
 // launch path serves the handle (not an error: the persistent samplers are an acceleration, not a capability).
+// The power-of-two scales of the two-piece fp16 form (gemm_h3_pipe.h) from GUARANTEED bounds of this handle's tensors, once per
+// handle (synchronous: configuration time).  Weights: their max.  norm1 / norm3 outputs: |LayerNorm(x)_i| <= sqrt(E - 1), so
+// sqrt(E) max|w| + max|b|.  The MLP hidden layer: |GELU(v)| <= |v| <= (largest row L1 norm of the up-projection) x the norm3 bound +
+// max|bias|.  A bound beyond fp16's range even at the smallest scale (or a non-finite one) keeps the handle on the bf16 form.
+bool h3_scales(after_denoiser* h) {
+    if (h->h3_state) return h->h3_state > 0;
+    h->h3_state = -1;
+    const int E = h->E, ME = h->ME;
+    unsigned* stats = nullptr;  // per layer: [max |.|, max row L1] of qkv, mlp0, mlp2, mlp0_b, n1w, n1b, n3w, n3b
+    unsigned hs[8 * 16];
+    if (h->L > 8 || hipMalloc(&stats, sizeof(hs)) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    bool ok = hipMemset(stats, 0, sizeof(hs)) == hipSuccess;
+    for (int l = 0; ok && l < h->L; ++l) {
+        const LayerW& w = h->layers[l];
+        const struct { const float* p; int rows, cols; } m[8] = {{w.qkv_w, 3 * E, E}, {w.mlp0_w, ME, E}, {w.mlp2_w, E, ME}, {w.mlp0_b, 1, ME},
+                                                                  {w.n1w, 1, E},       {w.n1b, 1, E},     {w.n3w, 1, E},      {w.n3b, 1, E}};
+        for (int q = 0; q < 8; ++q)
+            hipLaunchKernelGGL(absmax_rows_kernel, dim3((unsigned)m[q].rows), dim3(256), 0, nullptr, m[q].p, m[q].cols, m[q].cols, stats + 16 * l + 2 * q);
+        ok = hipGetLastError() == hipSuccess;
+    }
+    ok = ok && hipMemcpy(hs, stats, sizeof(hs), hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(stats);
+    for (int l = 0; ok && l < h->L; ++l) {
+        auto f32 = [&](int q, int which) {
+            float v;
+            memcpy(&v, &hs[16 * l + 2 * q + which], sizeof(float));
+            return v;
+        };
+        const float rootE = sqrtf((float)E);
+        const float b_h1 = rootE * f32(4, 0) + f32(5, 0), b_h3 = rootE * f32(6, 0) + f32(7, 0), b_m = f32(1, 1) * b_h3 + f32(3, 0);
+        const float s_h1 = h3_scale_for(b_h1), s_h3 = h3_scale_for(b_h3), s_m = h3_scale_for(b_m);
+        const float sw_q = h3_scale_for(f32(0, 0)), sw_u = h3_scale_for(f32(1, 0)), sw_d = h3_scale_for(f32(2, 0));
+        ok = std::isfinite(b_h1) && std::isfinite(b_h3) && std::isfinite(b_m) && b_h1 * s_h1 <= 32768.0f && b_h3 * s_h3 <= 32768.0f &&
+             b_m * s_m <= 32768.0f && f32(0, 0) * sw_q <= 32768.0f && f32(1, 0) * sw_u <= 32768.0f && f32(2, 0) * sw_d <= 32768.0f;
+        float* sc = h->clip_sc[l];
+        sc[0] = s_h1, sc[1] = s_h3, sc[2] = s_m, sc[3] = 1.0f / (s_h1 * sw_q), sc[4] = 1.0f / (s_h3 * sw_u), sc[5] = 1.0f / (s_m * sw_d);
+        h->h3_sw[l][0] = sw_q, h->h3_sw[l][1] = sw_u, h->h3_sw[l][2] = sw_d;
+    }
+    if (!ok) (void)hipGetLastError();
+    h->h3_state = ok ? 1 : -1;
+    return ok;
+}
+
 int persist_prepare(after_denoiser* h, bool offline) {
     if (!persist_geometry_ok(h)) return AFTER_OK;
     AFTER_TRY(persist_poll(h, nullptr, true));  // (a failure nobody has looked at yet is reported, not wiped, by re-enabling)
@@ -4123,6 +4247,32 @@ int persist_prepare(after_denoiser* h, bool offline) {
         }
         h->seg_qkv = q, h->seg_act3 = a3;
     }
+    if (offline && h->seg_qkv && !h->seg_h3_w) {  // the two-piece fp16 copies of the tiled weights (the default arithmetic of the one-clip sampler)
+        const char* e = getenv("AFTER_SEG_SPLIT");
+        if (e) h->seg_h3 = strcmp(e, "bf16") != 0;
+        if (h->seg_h3 && h3_scales(h)) {
+            const size_t per = (3 * E * E + 2 * E * ME) * 2;  // unsigned shorts per layer
+            unsigned short* w3 = nullptr;
+            bool ok = hipMalloc(&w3, per * h->L * sizeof(unsigned short)) == hipSuccess;
+            for (int l = 0; ok && l < h->L; ++l) {
+                const LayerW& w = h->layers[l];
+                unsigned short* b = w3 + per * l;
+                hipLaunchKernelGGL(tile16_h3_kernel, dim3((unsigned)cdivll((long long)3 * E * E / 8, 256)), dim3(256), 0, nullptr, w.qkv_w, (int)E, b,
+                                   3 * (int)E, (int)E, h->h3_sw[l][0]);
+                hipLaunchKernelGGL(tile16_h3_kernel, dim3((unsigned)cdivll((long long)ME * E / 8, 256)), dim3(256), 0, nullptr, w.mlp0_w, (int)E,
+                                   b + 3 * E * E * 2, (int)ME, (int)E, h->h3_sw[l][1]);
+                hipLaunchKernelGGL(tile16_h3_kernel, dim3((unsigned)cdivll((long long)E * ME / 8, 256)), dim3(256), 0, nullptr, w.mlp2_w, (int)ME,
+                                   b + (3 * E * E + ME * E) * 2, (int)E, (int)ME, h->h3_sw[l][2]);
+                ok = hipGetLastError() == hipSuccess;
+            }
+            ok = ok && hipDeviceSynchronize() == hipSuccess;
+            if (ok) h->seg_h3_w = w3;
+            else {
+                (void)hipGetLastError();
+                if (w3) (void)hipFree(w3);
+            }
+        }
+    }
     // the clip-per-XCD sampler's slices: for handles provisioned for a batch of clips of moderate length
     if (offline && h->persist_clip && !h->clip_act && h->E == kSE && h->max_rows >= 3 * h->clip_min_b && h->max_T <= kClipMaxT) {
         const size_t rows = (size_t)cdiv(3 * h->max_T, kClipRowTile) * kClipRowTile, prow = (size_t)cdiv(h->max_T, 16) * 16;
@@ -4153,49 +4303,20 @@ int persist_prepare(after_denoiser* h, bool offline) {
                 if (e2) h->clip_h3 = strcmp(e2, "bf16") != 0;
             }
             const size_t pq = h3_elems(3 * (int)E, (int)E), pu = h3_elems((int)ME, (int)E), pd = h3_elems((int)E, (int)ME);
-            if (ok && h->clip_h3) {
-                unsigned* stats = nullptr;  // per layer: [w][max, L1] of qkv, mlp0, mlp2, mlp0_b, n1w, n1b, n3w, n3b
-                unsigned hs[8 * 16];
-                bool ok3 = hipMalloc(&wh3, (pq + pu + pd) * h->L * sizeof(unsigned short)) == hipSuccess &&
-                           hipMalloc(&stats, sizeof(hs)) == hipSuccess && hipMemset(stats, 0, sizeof(hs)) == hipSuccess;
+            if (ok && h->clip_h3 && h3_scales(h)) {
+                bool ok3 = hipMalloc(&wh3, (pq + pu + pd) * h->L * sizeof(unsigned short)) == hipSuccess;
                 for (int l = 0; ok3 && l < h->L; ++l) {
-                    const LayerW& w = h->layers[l];
-                    const struct { const float* p; int rows, cols; } m[8] = {{w.qkv_w, 3 * (int)E, (int)E}, {w.mlp0_w, (int)ME, (int)E}, {w.mlp2_w, (int)E, (int)ME},
-                                                                              {w.mlp0_b, 1, (int)ME}, {w.n1w, 1, (int)E}, {w.n1b, 1, (int)E},
-                                                                              {w.n3w, 1, (int)E}, {w.n3b, 1, (int)E}};
-                    for (int q = 0; q < 8; ++q)
-                        hipLaunchKernelGGL(absmax_rows_kernel, dim3((unsigned)m[q].rows), dim3(256), 0, nullptr, m[q].p, m[q].cols, m[q].cols, stats + 16 * l + 2 * q);
-                    ok3 = hipGetLastError() == hipSuccess;
-                }
-                ok3 = ok3 && hipMemcpy(hs, stats, sizeof(hs), hipMemcpyDeviceToHost) == hipSuccess;
-                for (int l = 0; ok3 && l < h->L; ++l) {
-                    auto f32 = [&](int q, int which) {
-                        float v;
-                        memcpy(&v, &hs[16 * l + 2 * q + which], sizeof(float));
-                        return v;
-                    };
-                    const float rootE = sqrtf((float)E);  // |LayerNorm(x)_i| <= sqrt(E - 1)
-                    const float b_h1 = rootE * f32(4, 0) + f32(5, 0), b_h3 = rootE * f32(6, 0) + f32(7, 0);
-                    const float b_m = f32(1, 1) * b_h3 + f32(3, 0);  // |GELU(v)| <= |v| <= ||W_row||_1 max|h| + |bias|
-                    const float s_h1 = h3_scale_for(b_h1), s_h3 = h3_scale_for(b_h3), s_m = h3_scale_for(b_m);
-                    const float sw_q = h3_scale_for(f32(0, 0)), sw_u = h3_scale_for(f32(1, 0)), sw_d = h3_scale_for(f32(2, 0));
-                    ok3 = std::isfinite(b_h1) && std::isfinite(b_h3) && std::isfinite(b_m) && b_m * s_m <= 32768.0f && b_h1 * s_h1 <= 32768.0f &&
-                          b_h3 * s_h3 <= 32768.0f;  // (bounds beyond fp16's range even at the smallest scale: the bf16 form serves the handle)
-                    float* sc = h->clip_sc[l];
-                    sc[0] = s_h1, sc[1] = s_h3, sc[2] = s_m, sc[3] = 1.0f / (s_h1 * sw_q), sc[4] = 1.0f / (s_h3 * sw_u), sc[5] = 1.0f / (s_m * sw_d);
-                    if (!ok3) break;
                     const LayerW& w = h->layers[l];
                     unsigned short* base = wh3 + (pq + pu + pd) * l;
                     hipLaunchKernelGGL(qkv_by_head_kernel, dim3(3 * (unsigned)E), dim3(256), 0, nullptr, w.qkv_w, tmp, (int)E);
                     hipLaunchKernelGGL(h3_split_kernel, dim3((unsigned)cdivll((long long)x6_rows_padded(3 * (int)E) * E / 4, 256)), dim3(256), 0, nullptr,
-                                       tmp, (int)E, base, 3 * (int)E, (int)E, sw_q);
+                                       tmp, (int)E, base, 3 * (int)E, (int)E, h->h3_sw[l][0]);
                     hipLaunchKernelGGL(h3_split_kernel, dim3((unsigned)cdivll((long long)x6_rows_padded((int)ME) * E / 4, 256)), dim3(256), 0, nullptr,
-                                       w.mlp0_w, (int)E, base + pq, (int)ME, (int)E, sw_u);
+                                       w.mlp0_w, (int)E, base + pq, (int)ME, (int)E, h->h3_sw[l][1]);
                     hipLaunchKernelGGL(h3_split_kernel, dim3((unsigned)cdivll((long long)x6_rows_padded((int)E) * ME / 4, 256)), dim3(256), 0, nullptr,
-                                       w.mlp2_w, (int)ME, base + pq + pu, (int)E, (int)ME, sw_d);
+                                       w.mlp2_w, (int)ME, base + pq + pu, (int)E, (int)ME, h->h3_sw[l][2]);
                     ok3 = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
                 }
-                if (stats) (void)hipFree(stats);
                 if (!ok3) {  // (not an error: the three-plane bf16 form serves the handle)
                     (void)hipGetLastError();
                     if (wh3) (void)hipFree(wh3);
@@ -4227,6 +4348,8 @@ int persist_prepare(after_denoiser* h, bool offline) {
         const void* fns[] = {reinterpret_cast<const void*>(sample_seg_kernel<6, 512>), reinterpret_cast<const void*>(sample_seg_kernel<3, 512>),
                              reinterpret_cast<const void*>(sample_seg_kernel<6, 256>), reinterpret_cast<const void*>(sample_seg_kernel<3, 256>),
                              reinterpret_cast<const void*>(sample_seg_kernel<6, 512, 1>), reinterpret_cast<const void*>(sample_seg_kernel<3, 512, 1>),
+                             reinterpret_cast<const void*>(sample_seg_kernel<6, 512, 2>), reinterpret_cast<const void*>(sample_seg_kernel<3, 512, 2>),
+                             reinterpret_cast<const void*>(sample_seg_kernel<6, 256, 2>), reinterpret_cast<const void*>(sample_seg_kernel<3, 256, 2>),
                              reinterpret_cast<const void*>(persist_census_kernel)};
         for (const void* fn : fns) AFTER_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_seg));
         const void* sf[] = {reinterpret_cast<const void*>(stream_step_kernel<1>), reinterpret_cast<const void*>(stream_step_kernel<2>),
@@ -4426,6 +4549,14 @@ int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, in
         sl.qkv_wt = h->step_layers[l].qkv, sl.mlp0_wt = h->step_layers[l].mlp0, sl.mlp2_wt = h->step_layers[l].mlp2;
         sl.mlp0_b = w.mlp0_b, sl.mlp2_b = w.mlp2_b, sl.n1w = w.n1w, sl.n1b = w.n1b, sl.n3w = w.n3w, sl.n3b = w.n3b;
         sl.qkv = h->seg_qkv + (size_t)l * 3 * h->max_T * 3 * E;
+        if (h->seg_h3_w) {
+            const size_t ME_ = h->ME, per = (3 * (size_t)E * E + 2 * (size_t)E * ME_) * 2;
+            const unsigned short* b = h->seg_h3_w + per * l;
+            sl.qkv_ht = reinterpret_cast<const float*>(b), sl.mlp0_ht = reinterpret_cast<const float*>(b + 3 * (size_t)E * E * 2);
+            sl.mlp2_ht = reinterpret_cast<const float*>(b + (3 * (size_t)E * E + ME_ * E) * 2);
+            const float* sc = h->clip_sc[l];
+            sl.s_h1 = sc[0], sl.s_h3 = sc[1], sl.s_m = sc[2], sl.o_qkv = sc[3], sl.o_up = sc[4], sl.o_dn = sc[5];
+        }
     }
     const bool timed = h->timer.enabled && h->timer_kernel == 3;
     if (timed) h->timer.begin(s);
@@ -4434,6 +4565,12 @@ int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, in
         if (E == kSE && h->tier) {
             if (MB == 6) hipLaunchKernelGGL((sample_seg_kernel<6, 512, 1>), dim3(h->n_cus), dim3(512), lds, s, a);
             else hipLaunchKernelGGL((sample_seg_kernel<3, 512, 1>), dim3(h->n_cus), dim3(512), lds, s, a);
+        } else if (h->seg_h3_w && E == kSE) {  // the default arithmetic: two-piece fp16 operands (gemm_h3_pipe.h)
+            if (MB == 6) hipLaunchKernelGGL((sample_seg_kernel<6, 512, 2>), dim3(h->n_cus), dim3(512), lds, s, a);
+            else hipLaunchKernelGGL((sample_seg_kernel<3, 512, 2>), dim3(h->n_cus), dim3(512), lds, s, a);
+        } else if (h->seg_h3_w) {
+            if (MB == 6) hipLaunchKernelGGL((sample_seg_kernel<6, 256, 2>), dim3(h->n_cus), dim3(512), lds, s, a);
+            else hipLaunchKernelGGL((sample_seg_kernel<3, 256, 2>), dim3(h->n_cus), dim3(512), lds, s, a);
         } else if (E == kSE) {
             if (MB == 6) hipLaunchKernelGGL((sample_seg_kernel<6, 512>), dim3(h->n_cus), dim3(512), lds, s, a);
             else hipLaunchKernelGGL((sample_seg_kernel<3, 512>), dim3(h->n_cus), dim3(512), lds, s, a);

@@ -181,7 +181,9 @@ __device__ __forceinline__ void h3l_step(H3LState<C>& c, int kt, int nk) {
     const bool more = STEADY || kt + 1 < nk, refill = STEADY || kt + C::NS < nk;
     if (more) {
         if constexpr (LID >= 0) {
-            if (C::NS >= 3 && (STEADY || kt + 2 < nk)) wait_vmcnt_imm<(C::NS >= 3 ? ND : 0) + EXTRA>();
+            // in flight behind slab kt + 1: slabs kt + 2 .. min(kt + NS - 1, nk - 1), ND pieces of this wave each
+            if (C::NS >= 4 && (STEADY || kt + 3 < nk)) wait_vmcnt_imm<(C::NS >= 4 ? 2 * ND : 0) + EXTRA>();
+            else if (C::NS >= 3 && (STEADY || kt + 2 < nk)) wait_vmcnt_imm<(C::NS >= 3 ? ND : 0) + EXTRA>();
             else wait_vmcnt_imm<EXTRA>();
         }
         __builtin_amdgcn_s_barrier();
@@ -193,10 +195,11 @@ __device__ __forceinline__ void h3l_step(H3LState<C>& c, int kt, int nk) {
 }
 template <class C, int NL, int LID>
 __device__ __forceinline__ void h3l_fill(const H3LState<C>& c) {
-    static_assert(C::NS == 2 || C::NS == 3, "ring depth");
+    static_assert(C::NS >= 2 && C::NS <= 4, "ring depth");
     h3_issue_mine<C, H3LState<C>, NL, LID>(c, 0, 0);
     h3_issue_mine<C, H3LState<C>, NL, LID>(c, 1, 1);
-    if constexpr (C::NS == 3) h3_issue_mine<C, H3LState<C>, NL, LID>(c, 2, 2);
+    if constexpr (C::NS >= 3) h3_issue_mine<C, H3LState<C>, NL, LID>(c, 2, 2);
+    if constexpr (C::NS >= 4) h3_issue_mine<C, H3LState<C>, NL, LID>(c, 3, 3);
 }
 // the K loop of a tile whose ring fill has been issued (nk >= NS + 2, even).  EXTRA: see x6l_main
 template <class C, int NL, int LID, int EXTRA = 0>
@@ -210,7 +213,7 @@ __device__ __forceinline__ void h3l_main(H3LState<C>& c, int nk) {
     int kt = 0;
     if constexpr (EXTRA > 0) {
         h3l_step<C, NL, LID, 0, true, EXTRA>(c, 0, nk);
-        h3l_step<C, NL, LID, 1, true, (C::NS == 3 ? EXTRA : 0)>(c, 1, nk);
+        h3l_step<C, NL, LID, 1, true, (C::NS >= 3 ? EXTRA : 0)>(c, 1, nk);
         kt = 2;
     }
     for (; kt + 1 + C::NS < nk; kt += 2) {
@@ -245,7 +248,7 @@ struct H3RState {
     unsigned long long a_src, w_src;
     unsigned rgs;
     unsigned a_rd, w_rd, lds0;
-    unsigned prof[4], tprev;  // (kept for the shape of X6RState: unused)
+    unsigned prof[4], tprev;  // (X6R_PROF)
 };
 // fragment read R of the next slab, in issue order: [0, MT) A h (other set) | [MT, MT + NT) W l (other set) | [.., + MT) A l |
 // [.., + NT) W h
@@ -327,17 +330,33 @@ __device__ __forceinline__ void h3r_fence(H3RState<C>& c) {
 template <class C, int NL, int LID, int CUR>
 __device__ __forceinline__ void h3r_step(H3RState<C>& c, int kt, int nk) {
     constexpr int ND = H3Role<C, NL, LID>::ND;
+    // (-DX6R_PROF=1, timing experiments: shader-cycle counters of a wave's steps -- [0] waiting for its fragment reads, [1] for its
+    //  DMA pieces, [2] in the barrier, [3] in the MFMA stream: see x6r_step)
+    unsigned t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    if (X6R_PROF) {
+        t0 = (unsigned)__builtin_readcyclecounter();
+        if (c.tprev) c.prof[3] += t0 - c.tprev;
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     h3r_fence<C, CUR>(c);
     __builtin_amdgcn_sched_barrier(0);
+    if (X6R_PROF) t1 = (unsigned)__builtin_readcyclecounter();
     const bool more = kt + 1 < nk, refill = kt + C::NS < nk;
     if (more) {
         if constexpr (LID >= 0) {
             if (C::NS >= 3 && kt + 2 < nk) wait_vmcnt_imm<(C::NS >= 3 ? ND : 0)>();
             else wait_vmcnt_imm<0>();
         }
+        if (X6R_PROF) t2 = (unsigned)__builtin_readcyclecounter();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+    } else if (X6R_PROF) {
+        t2 = t1;
+    }
+    if (X6R_PROF) {
+        t3 = (unsigned)__builtin_readcyclecounter();
+        c.prof[0] += t1 - t0, c.prof[1] += t2 - t1, c.prof[2] += t3 - t2;
+        c.tprev = t3;
     }
     const int sn = (kt + 1) % C::NS;
     const unsigned a_next = c.a_rd + (unsigned)(sn * C::STAGE), w_next = c.w_rd + (unsigned)(sn * C::STAGE);

@@ -30,4 +30,23 @@ h3)  # the two-piece fp16 form of the batch sampler's Linears: parity, same-box 
     done
     python scripts/stream_step_trace.py --offline --clips 8 --xcd 3 2>/dev/null | grep -v amdgpu.ids | tee $O/clip_step_trace.txt | tail -12
     ;;
+h3acc)  # accuracy of the two-piece form vs fp64, the tests that run the batch sampler at BASELINE's sizes, the whole GPU suite
+    timeout 900 python -m pytest tests/test_gemm_gpu.py -x -q -s -k "h3_two_piece" 2>&1 | grep "h3 \|passed\|failed\|Error" | tee $O/h3_accuracy.txt
+    timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -8 | tee $O/gpu_suite.txt
+    ;;
+seg3)  # the two-piece fp16 form in the one-clip sampler: parity, same-box A/B (base and tiny), the bench line
+    timeout 1200 python -m pytest tests/test_sample_persist_gpu.py tests/test_denoiser_gpu.py tests/test_persist_protocol_gpu.py -x -q 2>&1 | tail -6
+    for rep in 1 2; do
+      for cfg in base tiny; do
+        AFTER_SEG_SPLIT=bf16 python scripts/time_sampler.py $cfg 1 50 7 2>/dev/null | tail -1 | cut -c1-100 | sed "s/^/bf16 x 3 planes: /" | tee -a $O/ab_split.txt
+        python scripts/time_sampler.py $cfg 1 50 7 2>/dev/null | tail -1 | cut -c1-100 | sed "s/^/fp16 x 2 pieces: /" | tee -a $O/ab_split.txt
+      done
+    done
+    python scripts/stream_step_trace.py --offline 2>/dev/null | grep -v amdgpu.ids | tee $O/offline_step_trace.txt | tail -8
+    timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_b1.json 2> $O/bench_b1.err; echo "bench rc $?"
+    python -c "
+import json; d=json.load(open('$O/bench_b1.json')); print(d['ms_per_step'], d['value'], d['config']['sampler_path'])
+for k,v in d['legs'].items():
+    if isinstance(v,dict): print(k, v.get('ms_per_step'), v.get('value'), v.get('sampler_path'), (v.get('roofline') or {}).get('frac'), v.get('error'))"
+    ;;
 esac
