@@ -742,6 +742,7 @@ struct StepKV {
 struct StepArgs {
     int rows, B, T, C, Cp, L, cs, W, nkmax, cache, cache_rows, cpg, dbg;
     int Tseg, nseg;           // offline segment sampler: frames per XCD (16 or 32), XCDs at work (T / Tseg <= 8)
+    int clip;                 // ... the clip of the call's B this launch samples (conditioning rows br * B + clip; x0 / xout / xt offset by the host)
     int nsteps, cache_steps;  // Euler steps of this launch (ALL of a sample() call); ring slots per layer
     unsigned flip[4];         // bit i: which half of step i's K / V rings is current
     int warm[3];  // sixteenths of the qkv / MLP-up / MLP-down weights warmed into the L2 by idle waves (AFTER_STEP_WARM)
@@ -930,6 +931,56 @@ __device__ __forceinline__ void step_gemm(f32x4 (&acc)[NT * MB], __amdgpu_buffer
     }
 }
 
+// The same on two-piece fp16 operands (gemm_h3_pipe.h): A = p32h_store4<2> blocks [row block][k / 32][h | l] written by the producing
+// phase (sc1 loads), W = the tile16_h3_kernel copy ([tile][k / 32][h | l]); KB32 32-deep k-blocks from kb0 on; three MFMAs per
+// (column tile, row block, k-block): (Wh, Al) (Wh, Ah) (Wl, Ah).  The caller scales the finished sums back (an exact power of two).
+template <int MB, int NT, int KB32, class F>
+__device__ __forceinline__ void step_gemm_h3(f32x4 (&acc)[NT * MB], __amdgpu_buffer_rsrc_t A, int a_kb32, const float* __restrict__ wt, int w_kb32,
+                                             int tile0, int kb0, int lane, bool active, bool wact, F&& after_loads) {
+#pragma unroll
+    for (int p = 0; p < NT * MB; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!active) {
+        after_loads();
+        return;
+    }
+    constexpr int CH = KB32 * MB <= 6 ? KB32 : 2;  // k-blocks of A in flight
+    static_assert(KB32 % CH == 0, "A chunks");
+    u32x4 wf[NT * KB32][2], av[CH][MB][2];
+    auto load_a = [&](int u0) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    av[u][i][p] = __builtin_amdgcn_raw_buffer_load_b128(A, lane * 16, (unsigned)(((i * a_kb32 + kb0 + u0 + u) * 2 + p) << 10), 16);
+    };
+    load_a(0);
+#pragma unroll
+    for (int u = 0; u < KB32; ++u)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                wf[j * KB32 + u][p] = wact ? *reinterpret_cast<const u32x4*>(wt + ((size_t)(((tile0 + 32 * j) * w_kb32 + kb0 + u) * 2 + p) << 8) + lane * 4)
+                                           : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int u0 = 0; u0 < KB32; u0 += CH) {
+        if (u0 > 0) load_a(u0);
+        if (u0 + CH >= KB32) after_loads();
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int i = 0; i < MB; ++i)  // W fragment as srcA: the accumulator holds C^T
+                        acc[j * MB + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[j * KB32 + u0 + u][p == 2 ? 1 : 0]),
+                                                                                 __builtin_bit_cast(f16x8, av[u][i][p == 0 ? 1 : 0]), acc[j * MB + i], 0, 0, 0);
+    }
+}
+
 // the compute waves' partial tiles -> LDS [wave][P][256] (all eight waves call it: two workgroup barriers);
 // afterwards step_reduced(p) sums tile p in wave order
 template <int P>
@@ -984,11 +1035,13 @@ __device__ __forceinline__ void p32_store4(unsigned short* base, int lr, int c, 
     *reinterpret_cast<uint2*>(q + 1024) = l;
 }
 
-// the same block positions with TWO fp16 pieces of the (scaled) values -- gemm_h3_pipe.h -- in planes 0 and 1 (the third stays unused)
+// the same block positions with TWO fp16 pieces of the (scaled) values -- gemm_h3_pipe.h -- in planes 0 and 1 of NPS planes per block (3: the
+// segment sampler's slices, provisioned for three bf16 planes; 2: the streaming sampler's fp32-sized slices, 4 bytes per element)
+template <int NPS = 3>
 __device__ __forceinline__ void p32h_store4(unsigned short* base, int lr, int c, int kb32, float x0, float x1, float x2, float x3) {
     uint2 h, l;
     h3_split4(x0, x1, x2, x3, h, l);
-    unsigned short* q = base + (((size_t)((lr >> 4) * kb32 + (c >> 5)) * 3) << 9) + ((((c & 15) >> 2) * 16 + (lr & 15)) << 3) + ((c & 16) >> 2);
+    unsigned short* q = base + (((size_t)((lr >> 4) * kb32 + (c >> 5)) * NPS) << 9) + ((((c & 15) >> 2) * 16 + (lr & 15)) << 3) + ((c & 16) >> 2);
     *reinterpret_cast<uint2*>(q) = h;
     *reinterpret_cast<uint2*>(q + 512) = l;
 }
@@ -1037,7 +1090,8 @@ __device__ __forceinline__ void step_ln_row(__amdgpu_buffer_rsrc_t xin, int src_
         y.w = (v[i].w - mean) * rstd * ww[i].w + bb[i].w;
         if constexpr (PLANES == 2) x6_store4(reinterpret_cast<unsigned short*>(h), lr, 4 * lane + 256 * i, E, y.x, y.y, y.z, y.w);
         else if constexpr (PLANES == 1) p32_store4(reinterpret_cast<unsigned short*>(h), lr, 4 * lane + 256 * i, E / 32, y.x, y.y, y.z, y.w);
-        else if constexpr (PLANES == 3) p32h_store4(reinterpret_cast<unsigned short*>(h), lr, 4 * lane + 256 * i, E / 32, y.x * ops.hs, y.y * ops.hs, y.z * ops.hs, y.w * ops.hs);
+        else if constexpr (PLANES == 3 || PLANES == 4)  // (4: two planes per block)
+            p32h_store4<PLANES == 4 ? 2 : 3>(reinterpret_cast<unsigned short*>(h), lr, 4 * lane + 256 * i, E / 32, y.x * ops.hs, y.y * ops.hs, y.z * ops.hs, y.w * ops.hs);
         else *reinterpret_cast<f32x4*>(h + o) = y;
     }
 }
@@ -1266,18 +1320,20 @@ __device__ __forceinline__ void step_attention(const StepAttn& a, const StepKV& 
             y.w = (v[i].w - mean) * rstd * ww[i].w + bb[i].w;
             if constexpr (PLANES == 2) x6_store4(reinterpret_cast<unsigned short*>(hout), lr0 + i0 + qi, 4 * lane + 256 * i, E, y.x, y.y, y.z, y.w);
             else if constexpr (PLANES == 1) p32_store4(reinterpret_cast<unsigned short*>(hout), lr0 + i0 + qi, 4 * lane + 256 * i, E / 32, y.x, y.y, y.z, y.w);
-            else if constexpr (PLANES == 3) p32h_store4(reinterpret_cast<unsigned short*>(hout), lr0 + i0 + qi, 4 * lane + 256 * i, E / 32, y.x * a.hs, y.y * a.hs, y.z * a.hs, y.w * a.hs);
+            else if constexpr (PLANES == 3 || PLANES == 4)
+                p32h_store4<PLANES == 4 ? 2 : 3>(reinterpret_cast<unsigned short*>(hout), lr0 + i0 + qi, 4 * lane + 256 * i, E / 32, y.x * a.hs, y.y * a.hs, y.z * a.hs, y.w * a.hs);
             else *reinterpret_cast<float4*>(hout + off) = y;
         }
     }
     if (tr && tid == 0) tr[84] = wall_clock64();
 }
 
-template <int MB>
+template <int MB, int H3 = 0>  // H3 1: the qkv / MLP Linears on two-piece fp16 operands (gemm_h3_pipe.h: step_gemm_h3; weights: StepLayer::*_ht)
 __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ unsigned s_n, s_rank, s_bad, s_ok;
     constexpr int E = kSE, ME = kSME, KBE = E / 16, KBM = ME / 16;
+    constexpr int PLN = H3 ? 4 : 0;  // the producers' form of h / the MLP hidden layer (step_ln_row: 4 = two fp16 pieces, two planes per block)
     StepSync* st = a.sync;
     const unsigned xcc = step_xcc_id(), nb = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1421,7 +1477,8 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
                 if (cl < nclip) {
                     if (lm != ln_lm)  // (more than 256 rows per XCD: never with the shipped limits)
                         step_ln_ops(lnops, a.tc_ab + ((size_t)a.tcmap[br * B + c0 + cl] * T + t) * a.tc_ld + (size_t)l * 2 * E, Lw.n1w, Lw.n1b, lane);
-                    step_ln_row(l == 0 ? pat_r : xres_r, l == 0 ? rem : lm, xres, hb, lm, lnops, lane);
+                    lnops.hs = Lw.s_h1;
+                    step_ln_row<PLN>(l == 0 ? pat_r : xres_r, l == 0 ? rem : lm, xres, hb, lm, lnops, lane);
                 }
             }
             // workgroups without a row (a warming wave next to a row's wave delays its loads: one load path per CU): warm the
@@ -1442,13 +1499,19 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
             // ---- qkv: column tiles rank, rank + 32, rank + 64
             {
                 f32x4 acc[3 * MB];
-                step_gemm<MB, 3, kSKBQ, false>(acc, hb_r, KBE, Lw.qkv_wt, KBE, rank, kSKBQ * w, lane, cw, wact,
-                                               [&] { if (rank < nitems) attn_prefetch(l, rank); });
+                if constexpr (H3) {
+                    step_gemm_h3<MB, 3, kSKBQ / 2>(acc, hb_r, E / 32, Lw.qkv_ht, E / 32, rank, kSKBQ / 2 * w, lane, cw, wact,
+                                                   [&] { if (rank < nitems) attn_prefetch(l, rank); });
+                } else {
+                    step_gemm<MB, 3, kSKBQ, false>(acc, hb_r, KBE, Lw.qkv_wt, KBE, rank, kSKBQ * w, lane, cw, wact,
+                                                   [&] { if (rank < nitems) attn_prefetch(l, rank); });
+                }
                 step_warm_done(warm_sink);  // (older than the GEMM's operand loads: long landed)
                 step_partials<3 * MB>(acc, red, w, lane);
                 for (int p = w; p < 3 * MB && cw; p += kSCW) {
                     const int j = p / MB, ib = p - j * MB;
-                    const f32x4 o = step_reduced(red, 3 * MB, p, lane);
+                    f32x4 o = step_reduced(red, 3 * MB, p, lane);
+                    if constexpr (H3) o = o * Lw.o_qkv;  // (an exact power of two)
                     const int lm = 16 * ib + (lane & 15);
                     const int br = lm / ct, rem = lm - br * ct, cl = rem / T, t = rem - cl * T;
                     if (lm < Mg && cl < nclip)
@@ -1464,8 +1527,8 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
                     const int q = it / nchunks, bx = it - q * nchunks, br = q / nclip, cl = q - br * nclip;
                     __syncthreads();  // (a second item of this workgroup reuses the LDS rows)
                     if (it != rank) attn_prefetch(l, it);
-                    step_attention<16>(StepAttn{a.T, a.cs, a.W, a.cache, a.nkmax, a.rope_cos, a.rope_sin, Lw.qkv}, kv, lnops,
-                                       br * B + c0 + cl, br * ct + cl * T, bx, smem, kvl, qkv_r, xres_r, xres, hb, nullptr, nullptr, nullptr, trace);
+                    step_attention<16, PLN>(StepAttn{a.T, a.cs, a.W, a.cache, a.nkmax, a.rope_cos, a.rope_sin, Lw.qkv, Lw.s_h3}, kv, lnops,
+                                            br * B + c0 + cl, br * ct + cl * T, bx, smem, kvl, qkv_r, xres_r, xres, hb, nullptr, nullptr, nullptr, trace);
                 }
                 const int nroll = nitems < (int)n ? (int)n - nitems : (int)n, rb = nitems < (int)n ? rank - nitems : rank;
                 if (rb >= 0) {
@@ -1487,15 +1550,20 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
                 const int pj = w / MB;
                 const f32x4 bv0 = cw && w < kSNTU * MB ? *reinterpret_cast<const f32x4*>(Lw.mlp0_b + 16 * (rank + 32 * pj) + 4 * (lane >> 4))
                                                        : f32x4{0.f, 0.f, 0.f, 0.f};
-                step_gemm<MB, kSNTU, kSKBQ, false>(acc, hb_r, KBE, Lw.mlp0_wt, KBE, rank, kSKBQ * w, lane, cw, wact, [] {});
+                if constexpr (H3) step_gemm_h3<MB, kSNTU, kSKBQ / 2>(acc, hb_r, E / 32, Lw.mlp0_ht, E / 32, rank, kSKBQ / 2 * w, lane, cw, wact, [] {});
+                else step_gemm<MB, kSNTU, kSKBQ, false>(acc, hb_r, KBE, Lw.mlp0_wt, KBE, rank, kSKBQ * w, lane, cw, wact, [] {});
                 step_partials<kSNTU * MB>(acc, red, w, lane);
                 for (int p = w; p < kSNTU * MB && cw; p += kSCW) {
                     const int j = p / MB, ib = p - j * MB, tile = rank + 32 * j;
                     f32x4 o = step_reduced(red, kSNTU * MB, p, lane);
+                    if constexpr (H3) o = o * Lw.o_up;
                     const f32x4 bv = p == w ? bv0 : *reinterpret_cast<const f32x4*>(Lw.mlp0_b + 16 * tile + 4 * (lane >> 4));
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r] + bv[r]);
-                    *reinterpret_cast<f32x4*>(mlp + ((size_t)(ib * KBM + tile) << 8) + lane * 4) = o;
+                    if constexpr (H3)
+                        p32h_store4<2>(reinterpret_cast<unsigned short*>(mlp), 16 * ib + (lane & 15), 16 * tile + 4 * (lane >> 4), ME / 32, o[0] * Lw.s_m,
+                                       o[1] * Lw.s_m, o[2] * Lw.s_m, o[3] * Lw.s_m);
+                    else *reinterpret_cast<f32x4*>(mlp + ((size_t)(ib * KBM + tile) << 8) + lane * 4) = o;
                 }
             }
             if (!end_phase(cw)) return;
@@ -1508,11 +1576,16 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
                     bv = *reinterpret_cast<const f32x4*>(Lw.mlp2_b + 16 * rank + 4 * (lane >> 4));
                     rv = ld_l2(xres_r, off);
                 }
-                step_gemm<MB, 1, kSKBD, false>(acc, mlp_r, KBM, Lw.mlp2_wt, KBM, rank, kSKBD * w, lane, cw, wact,
-                                               [&] { if (l + 1 < a.L) ln_prefetch(l + 1); });
+                if constexpr (H3)
+                    step_gemm_h3<MB, 1, kSKBD / 2>(acc, mlp_r, ME / 32, Lw.mlp2_ht, ME / 32, rank, kSKBD / 2 * w, lane, cw, wact,
+                                                   [&] { if (l + 1 < a.L) ln_prefetch(l + 1); });
+                else
+                    step_gemm<MB, 1, kSKBD, false>(acc, mlp_r, KBM, Lw.mlp2_wt, KBM, rank, kSKBD * w, lane, cw, wact,
+                                                   [&] { if (l + 1 < a.L) ln_prefetch(l + 1); });
                 step_partials<MB>(acc, red, w, lane);
                 for (int p = w; p < MB && cw; p += kSCW) {
                     f32x4 o = step_reduced(red, MB, p, lane);
+                    if constexpr (H3) o = o * Lw.o_dn;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = o[r] + bv[r] + rv[r];
                     *reinterpret_cast<f32x4*>(xres + off) = o;
@@ -1846,7 +1919,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
     const float* ln_ab0 = a.tc_ab;  // this wave's tcond AdaLN row (layer 0)
     if (ln_mine) {
         const int br = ln_lm / Tseg, tl = ln_lm - br * Tseg;
-        ln_ab0 += ((size_t)a.tcmap[br] * T + f0 + tl) * a.tc_ld;
+        ln_ab0 += ((size_t)a.tcmap[br * a.B + a.clip] * T + f0 + tl) * a.tc_ld;
     }
     auto ln_prefetch = [&](int l) {
         if (ln_mine) row_warm(ln_ab0 + (size_t)l * 2 * E, a.layer[l].n1w, a.layer[l].n1b);
@@ -1859,7 +1932,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
         asm volatile("" : "+v"(lane_i));  // (opaque: per-lane addresses are recomputed here -- hoisted out of the loops they are
         const int lane = lane_i;         //  kernel-lifetime 64-bit register pairs, and the allocator spills them into the MFMA loops)
         auto attn_prefetch = [&](int l, int it) {  // (wave 0: one touch per workgroup)
-            if (w == 0) row_warm(cond_ab + (size_t)(it / cps) * a.cond_ld + (size_t)l * 2 * E, a.layer[l].n3w, a.layer[l].n3b);
+            if (w == 0) row_warm(cond_ab + (size_t)((it / cps) * a.B + a.clip) * a.cond_ld + (size_t)l * 2 * E, a.layer[l].n3w, a.layer[l].n3b);
         };
         tslot = 0;
         if (trace && tid == 0) {
@@ -2024,7 +2097,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                     __syncthreads();
                     if (!s_ok) return;
                 }
-                seg_attention<E, PLN>(StepAttn{T, a.cs, a.W, 0, a.nkmax, a.rope_cos, a.rope_sin, Lw.qkv, Lw.s_h3}, cond_ab + (size_t)br * a.cond_ld + (size_t)l * 2 * E,
+                seg_attention<E, PLN>(StepAttn{T, a.cs, a.W, 0, a.nkmax, a.rope_cos, a.rope_sin, Lw.qkv, Lw.s_h3}, cond_ab + (size_t)(br * a.B + a.clip) * a.cond_ld + (size_t)l * 2 * E,
                               Lw.n3w, Lw.n3b, br, br * Tseg - f0, i0f / a.cs, halo, smem, kvl, xres, reinterpret_cast<float*>(hb3), trace);
             }
             constexpr int NTU = KBM / TPW;  // MLP-up column tiles of a workgroup (3: the hidden layer is 3 E wide)
@@ -3261,6 +3334,9 @@ __global__ __launch_bounds__(256) void tile16_h3_kernel(const float* __restrict_
 template __global__ void stream_step_kernel<1>(StepArgs);
 template __global__ void stream_step_kernel<2>(StepArgs);
 template __global__ void stream_step_kernel<3>(StepArgs);
+template __global__ void stream_step_kernel<1, 1>(StepArgs);
+template __global__ void stream_step_kernel<2, 1>(StepArgs);
+template __global__ void stream_step_kernel<3, 1>(StepArgs);
 template __global__ void sample_seg_kernel<3, 512>(StepArgs);
 template __global__ void sample_seg_kernel<6, 512>(StepArgs);
 template __global__ void sample_seg_kernel<3, 256>(StepArgs);
@@ -3356,6 +3432,8 @@ struct after_denoiser {
     unsigned short* clip_h3_w = nullptr;
     int clip_h3 = 1;           // AFTER_CLIP_SPLIT=bf16 / AFTER_SEG_SPLIT=bf16: the persistent offline samplers on three bf16 planes (A/B)
     int seg_h3 = 1;
+    int stream_h3 = 1;         // AFTER_STREAM_SPLIT=fp32: the persistent streaming sampler's Linears on the fp32 MFMA chain (A/B)
+    int seg_max_b = 2;         // clips of a call the one-clip sampler serves (one launch each); AFTER_SAMPLE_SEG_MAXB
     int h3_state = 0;          // 0 not computed, 1 scales valid, -1 a bound beyond fp16's range (the bf16 form serves the handle)
     float clip_sc[8][6] = {};  // per layer: s_h1, s_h3, s_m, o_qkv, o_up, o_dn
     float h3_sw[8][3] = {};    // per layer: the weights' scales (qkv, mlp0, mlp2)
@@ -3363,9 +3441,10 @@ struct after_denoiser {
     int clip_fuse = 1;         // AFTER_CLIP_FUSE=0: qkv rows through memory + attention items (A/B switch)
     int tier = 0;              // after_denoiser_set_gemm_path(h, 3): the persistent offline samplers' Linears with bf16 operands (h planes only)
     int clip_rows = 0, clip_pat_rows = 0;
-    int clip_min_b = 5;        // AFTER_SAMPLE_CLIP_MINB: fewest clips of a call that take the kernel (below: seg kernel / launches)
+    int clip_min_b = 3;        // AFTER_SAMPLE_CLIP_MINB: fewest clips of a call that take the kernel (below: the one-clip kernel, a launch per clip)
     int persist_clip = 1;      // AFTER_SAMPLE_CLIP=0: batches by launches
     bool last_clip = false;    // the last after_sample ran as sample_clip_kernel
+    bool last_h3 = false;      // ... with its Linears on two-piece fp16 operands (gemm_h3_pipe.h)
     // persist_prepare (called by create / enable_cache / set_*_persist, never by after_sample) has allocated the persistent
     // samplers' buffers, re-tiled the weights and seen a clean placement census: only then does a call take those paths
     bool step_ready = false;
@@ -3916,6 +3995,8 @@ extern "C" int after_denoiser_create(const after_denoiser_cfg* cfg, const float*
         if (pc) h->persist_clip = atoi(pc) != 0;
         const char* pcb = getenv("AFTER_SAMPLE_CLIP_MINB");
         if (pcb && atoi(pcb) > 0) h->clip_min_b = atoi(pcb);
+        const char* psb = getenv("AFTER_SAMPLE_SEG_MAXB");
+        if (psb && atoi(psb) > 0) h->seg_max_b = atoi(psb);
         hipDeviceProp_t prop;
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(AFTER_E_HIP);
@@ -4247,10 +4328,12 @@ int persist_prepare(after_denoiser* h, bool offline) {
         }
         h->seg_qkv = q, h->seg_act3 = a3;
     }
-    if (offline && h->seg_qkv && !h->seg_h3_w) {  // the two-piece fp16 copies of the tiled weights (the default arithmetic of the one-clip sampler)
+    if (h->step_sync && !h->seg_h3_w) {  // the two-piece fp16 copies of the tiled weights (the default arithmetic of the one-clip and the streaming sampler)
         const char* e = getenv("AFTER_SEG_SPLIT");
         if (e) h->seg_h3 = strcmp(e, "bf16") != 0;
-        if (h->seg_h3 && h3_scales(h)) {
+        const char* e2 = getenv("AFTER_STREAM_SPLIT");
+        if (e2) h->stream_h3 = strcmp(e2, "fp32") != 0;
+        if ((h->seg_h3 || h->stream_h3) && h3_scales(h)) {
             const size_t per = (3 * E * E + 2 * E * ME) * 2;  // unsigned shorts per layer
             unsigned short* w3 = nullptr;
             bool ok = hipMalloc(&w3, per * h->L * sizeof(unsigned short)) == hipSuccess;
@@ -4354,9 +4437,12 @@ int persist_prepare(after_denoiser* h, bool offline) {
         for (const void* fn : fns) AFTER_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_seg));
         const void* sf[] = {reinterpret_cast<const void*>(stream_step_kernel<1>), reinterpret_cast<const void*>(stream_step_kernel<2>),
                             reinterpret_cast<const void*>(stream_step_kernel<3>)};
+        const void* sf3[] = {reinterpret_cast<const void*>(stream_step_kernel<1, 1>), reinterpret_cast<const void*>(stream_step_kernel<2, 1>),
+                             reinterpret_cast<const void*>(stream_step_kernel<3, 1>)};
         for (int mb = 1; mb <= 3; ++mb) {
             const size_t lds = ((size_t)kSRedFloats(mb) + 8 * 2 * kAttnKeyBlock * 64) * sizeof(float);
             AFTER_HIP_CHECK(hipFuncSetAttribute(sf[mb - 1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            AFTER_HIP_CHECK(hipFuncSetAttribute(sf3[mb - 1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
         // dry census with the samplers' launch geometry
         AFTER_HIP_CHECK(hipDeviceSynchronize());
@@ -4472,12 +4558,24 @@ int sample_persistent(after_denoiser* h, hipStream_t s, const float* x0, float* 
             sl.qkv_wt = h->step_layers[l].qkv, sl.mlp0_wt = h->step_layers[l].mlp0, sl.mlp2_wt = h->step_layers[l].mlp2;
             sl.mlp0_b = w.mlp0_b, sl.mlp2_b = w.mlp2_b, sl.n1w = w.n1w, sl.n1b = w.n1b, sl.n3w = w.n3w, sl.n3b = w.n3b;
             sl.qkv = h->qkv_layers + (size_t)l * h->max_rows * h->max_T * 3 * E;
+            if (h->seg_h3_w) {
+                const size_t ME_ = h->ME, per = (3 * (size_t)E * E + 2 * (size_t)E * ME_) * 2;
+                const unsigned short* b = h->seg_h3_w + per * l;
+                sl.qkv_ht = reinterpret_cast<const float*>(b), sl.mlp0_ht = reinterpret_cast<const float*>(b + 3 * (size_t)E * E * 2);
+                sl.mlp2_ht = reinterpret_cast<const float*>(b + (3 * (size_t)E * E + ME_ * E) * 2);
+                const float* sc = h->clip_sc[l];
+                sl.s_h1 = sc[0], sl.s_h3 = sc[1], sl.s_m = sc[2], sl.o_qkv = sc[3], sl.o_up = sc[4], sl.o_dn = sc[5];
+            }
         }
         const bool timed = h->timer.enabled && h->timer_kernel == 3;
         if (timed) h->timer.begin(s);
         {
             PersistLaunch guard(h->dev, s);
-            if (MB == 1) hipLaunchKernelGGL(stream_step_kernel<1>, dim3(h->n_cus), dim3(512), lds, s, a);
+            if (h->seg_h3_w && h->stream_h3) {  // the default arithmetic: two-piece fp16 operands (gemm_h3_pipe.h: step_gemm_h3)
+                if (MB == 1) hipLaunchKernelGGL((stream_step_kernel<1, 1>), dim3(h->n_cus), dim3(512), lds, s, a);
+                else if (MB == 2) hipLaunchKernelGGL((stream_step_kernel<2, 1>), dim3(h->n_cus), dim3(512), lds, s, a);
+                else hipLaunchKernelGGL((stream_step_kernel<3, 1>), dim3(h->n_cus), dim3(512), lds, s, a);
+            } else if (MB == 1) hipLaunchKernelGGL(stream_step_kernel<1>, dim3(h->n_cus), dim3(512), lds, s, a);
             else if (MB == 2) hipLaunchKernelGGL(stream_step_kernel<2>, dim3(h->n_cus), dim3(512), lds, s, a);
             else hipLaunchKernelGGL(stream_step_kernel<3>, dim3(h->n_cus), dim3(512), lds, s, a);
         }
@@ -4500,12 +4598,14 @@ int sample_persistent(after_denoiser* h, hipStream_t s, const float* x0, float* 
 // no streaming caches.
 bool sample_seg_ok(const after_denoiser* h, int B, int T, int nb_steps) {
     int Tseg = 0, nseg = 0;
-    return h->persist_offline && h->step_ready && h->seg_qkv && h->cache == 0 && B == 1 && (!h->timer.enabled || h->timer_kernel == 3) && !h->use_graph &&
+    return h->persist_offline && h->step_ready && h->seg_qkv && h->cache == 0 && B >= 1 && B <= h->seg_max_b && (!h->timer.enabled || h->timer_kernel == 3) && !h->use_graph &&
            h->x6 != 0 && persist_geometry_ok(h) && h->C / 16 <= 4 && seg_split(h, T, &Tseg, &nseg) && nb_steps >= 1 && T <= h->max_T &&
            ((size_t)h->cs * (h->E + 4) + (size_t)h->H * 2 * (h->W - 1 + h->cs) * 16) <= 7168;
 }
 
-int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, int T, int nb_steps) {
+// (clip c of the call's B clips: the kernel samples ONE clip per launch; 2 clips = two launches back to back -- 2 x 10.7 ms against
+//  25.0 by launches and 27.4 on the batch kernel with six idle XCDs, profiles/r6_clip_threshold.txt)
+int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, int T, int nb_steps, int c = 0, int B = 1) {
     int Tseg = 0, nseg = 0;
     if (!seg_split(h, T, &Tseg, &nseg)) return AFTER_E_INVALID;
     const int E = h->E, L = h->L, MB = 3 * Tseg / 16;
@@ -4513,24 +4613,25 @@ int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, in
     const size_t lds = ((size_t)kSRedFloats(2) + 8 * 2 * kAttnKeyBlock * 64) * sizeof(float);
     {
         dim3 grid(cdiv(T, 32), cdiv(h->Cp, 32), 1);
-        hipLaunchKernelGGL(to_token_major_kernel, grid, dim3(256), 0, s, x0, h->xt, (const int*)nullptr, h->C, T, h->Cp, 0.f);
+        hipLaunchKernelGGL(to_token_major_kernel, grid, dim3(256), 0, s, x0 + (size_t)c * h->C * T, h->xt + (size_t)c * T * h->Cp, (const int*)nullptr,
+                           h->C, T, h->Cp, 0.f);
         AFTER_HIP_CHECK(hipGetLastError());
     }
     AFTER_HIP_CHECK(hipMemsetAsync(h->step_sync, 0, offsetof(StepSync, fail), s));  // (not the sticky failure words)
     const size_t slice = (size_t)8 * kSGroupRows * E;
     StepArgs a;
     memset(&a, 0, sizeof(a));
-    a.rows = 3, a.B = 1, a.T = T, a.C = h->C, a.Cp = h->Cp, a.L = L;
+    a.rows = 3, a.B = B, a.clip = c, a.T = T, a.C = h->C, a.Cp = h->Cp, a.L = L;
     a.cs = h->cs, a.W = h->W, a.nkmax = nkmax, a.cache = 0, a.cache_rows = 0, a.cpg = 1, a.Tseg = Tseg, a.nseg = nseg;
     a.nsteps = nb_steps, a.cache_steps = 0;
-    a.xt = h->xt;
+    a.xt = h->xt + (size_t)c * T * h->Cp;
     a.pat_t = h->step_act, a.xres_t = h->step_act + slice, a.h_t = h->step_act + 2 * slice, a.mlp_t = h->step_act + 3 * slice;
     a.h3_t = h->seg_act3, a.mlp3_t = h->seg_act3 + (size_t)8 * kSGroupRows * 3 * E;
     a.patch_wt = h->step_patch_wt, a.patch_b = h->patch_b, a.out_wt = h->step_out_wt, a.out_b = h->out_b;
     a.tc_ab = h->tc_ab, a.tc_ld = L * 2 * E, a.tcmap = h->maps + h->ms;
-    a.cond_ab = h->cond_ab, a.cond_step = (size_t)3 * L * 2 * E, a.cond_ld = L * 2 * E;
+    a.cond_ab = h->cond_ab, a.cond_step = (size_t)3 * B * L * 2 * E, a.cond_ld = L * 2 * E;
     a.rope_cos = h->rope_cos, a.rope_sin = h->rope_sin;
-    a.x0 = x0, a.xout = out;
+    a.x0 = x0 + (size_t)c * h->C * T, a.xout = out + (size_t)c * h->C * T;
     a.cfg = reinterpret_cast<const float*>(h->dparams);
     a.sync = h->step_sync;
     a.trace = h->step_trace_on ? h->step_trace : nullptr;
@@ -4562,13 +4663,15 @@ int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, in
     if (timed) h->timer.begin(s);
     {
         PersistLaunch guard(h->dev, s);
+        const bool seg3 = h->seg_h3_w && h->seg_h3;
+        h->last_h3 = seg3 && !(E == kSE && h->tier);
         if (E == kSE && h->tier) {
             if (MB == 6) hipLaunchKernelGGL((sample_seg_kernel<6, 512, 1>), dim3(h->n_cus), dim3(512), lds, s, a);
             else hipLaunchKernelGGL((sample_seg_kernel<3, 512, 1>), dim3(h->n_cus), dim3(512), lds, s, a);
-        } else if (h->seg_h3_w && E == kSE) {  // the default arithmetic: two-piece fp16 operands (gemm_h3_pipe.h)
+        } else if (seg3 && E == kSE) {  // the default arithmetic: two-piece fp16 operands (gemm_h3_pipe.h)
             if (MB == 6) hipLaunchKernelGGL((sample_seg_kernel<6, 512, 2>), dim3(h->n_cus), dim3(512), lds, s, a);
             else hipLaunchKernelGGL((sample_seg_kernel<3, 512, 2>), dim3(h->n_cus), dim3(512), lds, s, a);
-        } else if (h->seg_h3_w) {
+        } else if (seg3) {
             if (MB == 6) hipLaunchKernelGGL((sample_seg_kernel<6, 256, 2>), dim3(h->n_cus), dim3(512), lds, s, a);
             else hipLaunchKernelGGL((sample_seg_kernel<3, 256, 2>), dim3(h->n_cus), dim3(512), lds, s, a);
         } else if (E == kSE) {
@@ -4677,6 +4780,7 @@ int sample_clip(after_denoiser* h, hipStream_t s, const float* x0, float* out, i
         PersistLaunch guard(h->dev, s);
         // the default arithmetic: two-piece fp16 operands where the tiles attend in place (the shipped attention geometries), else
         // three bf16 planes; the opt-in bf16 tolerance tier is its own instantiation
+        h->last_h3 = !h->tier && h->clip_h3_w && a.fuse;
         if (h->tier) hipLaunchKernelGGL((sample_clip_kernel<1, 0>), dim3(h->n_cus), dim3(512), kClipLds, s, a);
         else if (h->clip_h3_w && a.fuse) hipLaunchKernelGGL((sample_clip_kernel<0, 1>), dim3(h->n_cus), dim3(512), kClipLds, s, a);
         else hipLaunchKernelGGL((sample_clip_kernel<0, 0>), dim3(h->n_cus), dim3(512), kClipLds, s, a);
@@ -4703,14 +4807,15 @@ int sample_enqueue(after_denoiser* h, hipStream_t s, const float* x0, const floa
     const int rows = 3 * B;
     AFTER_TRY(compute_cond_ab(h, s, nb_steps, rows, nullptr, nullptr, nb_steps, cond,
                               h->maps + 2 * h->ms, drop_value));
-    h->last_seg = h->last_clip = false;
+    h->last_seg = h->last_clip = h->last_h3 = false;
     // the sticky failure words of earlier persistent launches, if their copy has landed (AFTER_E_HIP once, then launches)
     AFTER_TRY(persist_poll(h, s, false));
     // (a persistent kernel cannot be a captured graph node of somebody else's graph: no event protocol, no co-residency guard)
     const bool capturing = (h->persist_step || h->persist_offline) && h->step_ready && stream_is_capturing(s);
     if (!capturing && sample_seg_ok(h, B, T, nb_steps)) {
-        const int rc = sample_seg(h, s, x0, out, T, nb_steps);
-        if (rc != kStepRetry) {
+        int rc = AFTER_OK;
+        for (int c = 0; c < B && rc == AFTER_OK; ++c) rc = sample_seg(h, s, x0, out, T, nb_steps, c, B);
+        if (rc != kStepRetry) {  // (a refused / failed launch: every clip again on the next path -- the samples are stateless)
             h->last_seg = rc == AFTER_OK;
             return rc;
         }
@@ -4820,11 +4925,11 @@ extern "C" int after_sample(after_denoiser* h, const float* x0, const float* con
         const int rem = B % 8, n8 = B - rem;
         if (n8 > 0 && rem > 0 && rem < h->clip_min_b && sample_clip_ok(h, n8, T, nb_steps) && !stream_is_capturing(s)) {
             AFTER_TRY(sample_enqueue(h, s, x0, cond, time_cond, out, n8, T, nb_steps, drop_value, cfg_mode));
-            const bool clip_ran = h->last_clip;
+            const bool clip_ran = h->last_clip, h3_ran = h->last_h3;
             const size_t xo = (size_t)n8 * h->C * T;
             AFTER_TRY(sample_enqueue(h, s, x0 + xo, cond + (size_t)n8 * h->ZT, time_cond + (size_t)n8 * h->ZS * T, out + xo, rem, T, nb_steps,
                                      drop_value, cfg_mode));
-            h->last_clip = clip_ran;
+            h->last_clip = clip_ran, h->last_h3 = h3_ran;
             h->last_seg = false;
             return AFTER_OK;
         }
@@ -4920,6 +5025,12 @@ extern "C" int after_denoiser_check(after_denoiser* h, void* stream) {
 extern "C" int after_denoiser_sample_persist(after_denoiser* h, int* active) {
     AFTER_REQUIRE(h && active, AFTER_E_INVALID, "null argument");
     *active = h->last_seg ? 1 : (h->last_clip ? 2 : 0);
+    return AFTER_OK;
+}
+
+extern "C" int after_denoiser_sample_arith(after_denoiser* h, int* form) {
+    AFTER_REQUIRE(h && form, AFTER_E_INVALID, "null argument");
+    *form = (h->last_seg || h->last_clip) ? (h->last_h3 ? 2 : (h->tier ? 3 : 1)) : (h->x6 ? 1 : 0);
     return AFTER_OK;
 }
 

@@ -439,6 +439,16 @@ class DenoiserV2(nn.Module):
         _lib.check(_lib.lib().after_denoiser_sample_persist(self._handle, ctypes.byref(a)), "after_denoiser_sample_persist")
         return int(a.value)
 
+    def sample_arith(self) -> int:
+        """The arithmetic of the qkv / MLP Linears in the last cfg_sample (include/after_hip.h: after_denoiser_sample_arith): 0 the fp32
+        MFMA chain, 1 three bf16 planes x six products, 2 two fp16 pieces x three products (the persistent samplers' default),
+        3 the opt-in bf16 tolerance tier."""
+        if self._handle is None:
+            return 0
+        a = ctypes.c_int()
+        _lib.check(_lib.lib().after_denoiser_sample_arith(self._handle, ctypes.byref(a)), "after_denoiser_sample_arith")
+        return int(a.value)
+
     def stream_persist(self) -> bool:
         """True when the last streaming cfg_sample of this handle ran (and the next one of the same shape will run) as
         persistent launches."""

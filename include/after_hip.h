@@ -202,6 +202,12 @@ int after_denoiser_set_stream_persist(after_denoiser* h, int enable);
  * _sample_persist: *active = how the last after_sample ran -- 0 by launches, 1 the one-clip kernel, 2 the batch kernel. */
 int after_denoiser_set_sample_persist(after_denoiser* h, int enable);
 int after_denoiser_sample_persist(after_denoiser* h, int* active);
+/* The arithmetic of the qkv / MLP Linears in the last after_sample -- *form = 0: v_mfma_f32_* (the exact fp32 fma chain: gemm path 0),
+ * 1: three bf16 planes per operand, six exact MFMAs per product block (gemm_x6.hip: the launch path, and the persistent samplers under
+ * AFTER_SEG_SPLIT=bf16 / AFTER_CLIP_SPLIT=bf16), 2: two fp16 pieces per operand under exact power-of-two scales, three exact MFMAs per
+ * block (gemm_h3_pipe.h: the DEFAULT of both persistent offline samplers; measured error vs fp64 0.63 - 0.72 x the fp32 chain's,
+ * tests/test_gemm_gpu.py), 3: the opt-in bf16 tolerance tier (gemm path 3).  Results are fp32 in every form. */
+int after_denoiser_sample_arith(after_denoiser* h, int* form);
 int after_denoiser_stream_persist(after_denoiser* h, int* active);
 /* mode -1 (default): the offline samplers look at their own launch (never an untouched tensor), the streaming sampler defers;
  * 1: every persistent after_sample synchronises `stream` and reports its own failure; 0: every one defers. */

@@ -49,4 +49,48 @@ import json; d=json.load(open('$O/bench_b1.json')); print(d['ms_per_step'], d['v
 for k,v in d['legs'].items():
     if isinstance(v,dict): print(k, v.get('ms_per_step'), v.get('value'), v.get('sampler_path'), (v.get('roofline') or {}).get('frac'), v.get('error'))"
     ;;
+tune1)  # small batches on the batch kernel vs launches; per-wave cycle counters of the fp16 K loops; MLP-down ring depth 4
+    for b in 2 3 4; do
+      AFTER_SAMPLE_CLIP=0 timeout 300 python scripts/time_sampler.py base $b 50 3 2>&1 | grep "sample " | cut -c1-70 | sed "s/^/launch /" | tee -a $O/clip_threshold.txt
+      AFTER_SAMPLE_CLIP_MINB=2 timeout 300 python scripts/time_sampler.py base $b 50 3 2>&1 | grep "sample " | cut -c1-70 | sed "s/^/clip   /" | tee -a $O/clip_threshold.txt
+    done
+    cp after_amd/lib/libafter_hip.so $O/default.so
+    cp scripts/variants/prof/libafter_hip.so after_amd/lib/libafter_hip.so
+    python scripts/stream_step_trace.py --offline --clips 8 --xcd 3 2>/dev/null | grep -v amdgpu.ids | tail -12 | tee $O/prof_qkv.txt
+    AFTER_CLIP_GSTAG=-1 python scripts/stream_step_trace.py --offline --clips 8 --xcd 3 2>/dev/null | grep -v amdgpu.ids | tail -12 | tee $O/prof_up.txt
+    cp scripts/variants/dn4/libafter_hip.so after_amd/lib/libafter_hip.so
+    python scripts/time_sampler.py base 8 50 3 2>/dev/null | tail -1 | cut -c1-100 | sed "s/^/dn4: /" | tee -a $O/variants.txt
+    python scripts/stream_step_trace.py --offline --clips 8 --xcd 3 2>/dev/null | grep -v amdgpu.ids | grep "L5\|step per" | tee -a $O/variants.txt
+    cp $O/default.so after_amd/lib/libafter_hip.so; rm $O/default.so
+    python scripts/time_sampler.py base 8 50 3 2>/dev/null | tail -1 | cut -c1-100 | sed "s/^/default: /" | tee -a $O/variants.txt
+    ;;
+suite)  # the whole GPU suite, the bench line with its legs, small-batch timings
+    timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | tail -8 | tee $O/gpu_suite.txt
+    timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_b1.json 2> $O/bench_b1.err; echo "bench rc $?"; tail -3 $O/bench_b1.err
+    python -c "
+import json; d=json.load(open('$O/bench_b1.json')); print(d['ms_per_step'], d['value'], d['config']['sampler_path'], d['roofline']['frac'], d['roofline']['peak']); print(d['dtype'][:300])
+for k,v in d['legs'].items():
+    if isinstance(v,dict): print(k, v.get('ms_per_step'), v.get('value'), v.get('sampler_path'), (v.get('roofline') or {}).get('frac'), v.get('error'))"
+    for b in 1 2 3 4 5 8; do
+      timeout 300 python scripts/time_sampler.py base $b 50 3 2>&1 | grep "sample " | cut -c1-70 | tee -a $O/clip_threshold.txt
+    done
+    ;;
+wpre)  # the next GEMM phase's first weight slabs requested inside the barrier: parity, same-box A/B (AFTER_STEP_DBG bit 9 = off), trace; the rest of the suite
+    timeout 1500 python -m pytest tests/test_sample_clip_gpu.py tests/test_sample_persist_gpu.py -x -q 2>&1 | tail -5
+    for rep in 1 2; do
+      AFTER_STEP_DBG=512 python scripts/time_sampler.py base 8 50 3 2>/dev/null | tail -1 | cut -c1-100 | sed "s/^/no prefetch: /" | tee -a $O/ab_wpre.txt
+      python scripts/time_sampler.py base 8 50 3 2>/dev/null | tail -1 | cut -c1-100 | sed "s/^/prefetch:    /" | tee -a $O/ab_wpre.txt
+    done
+    python scripts/stream_step_trace.py --offline --clips 8 --xcd 3 2>/dev/null | grep -v amdgpu.ids | tee $O/clip_step_trace.txt | tail -12
+    timeout 2400 python -m pytest tests -x -q -m gpu --deselect tests/test_sample_clip_gpu.py --deselect tests/test_gemm_gpu.py --deselect tests/test_conv_tm_gpu.py 2>&1 | tail -6 | tee $O/gpu_suite.txt
+    ;;
+stream3)  # the streaming sampler's Linears on two-piece fp16 operands: parity, same-box A/B (AFTER_STREAM_SPLIT=fp32), per-phase trace
+    timeout 1800 python -m pytest tests/test_stream_persist_gpu.py tests/test_streamer_gpu.py tests/test_persist_protocol_gpu.py tests/test_sample_clip_gpu.py tests/test_sample_persist_gpu.py -x -q 2>&1 | tail -5
+    timeout 900 python -m pytest tests/test_baseline_size_gpu.py -x -q -k "streamer" 2>&1 | tail -3
+    for rep in 1 2; do
+      AFTER_STREAM_SPLIT=fp32 python bench.py --stream --steps 24 --warmup 4 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('fp32 MFMA chain:  ', d['ms_per_step'], 'ms per chunk', d['value'], 'xRT')" | tee -a $O/ab_stream_split.txt
+      python bench.py --stream --steps 24 --warmup 4 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('fp16 x 2 pieces:  ', d['ms_per_step'], 'ms per chunk', d['value'], 'xRT')" | tee -a $O/ab_stream_split.txt
+    done
+    python scripts/stream_step_trace.py 2>/dev/null | grep -v amdgpu.ids | tee $O/stream_step_trace.txt | tail -14
+    ;;
 esac

@@ -1,7 +1,7 @@
 """The persistent offline sampler for a BATCH of clips (denoiser.hip: sample_clip_kernel -- all Euler steps of every clip in
-one launch, one clip per XCD, the Linears on the LDS-staged bf16 x 3 pipeline of gemm_x6) against the launch-per-kernel path of
-the same handle and against the CPU oracle.  Both GPU paths form the big Linears' fp32 products from the same exact three-way
-bf16 splits with different fixed tile shapes / K orders: they agree to fp32 round-off.  -m gpu."""
+one launch, one clip per XCD, the Linears on LDS-staged tiles of two-piece fp16 operands, gemm_h3_pipe.h) against the
+launch-per-kernel path of the same handle (its Linears: three bf16 planes, gemm_x6.hip) and against the CPU oracle.  Both split forms
+reproduce the fp32 products to below the fp32 accumulation error (tests/test_gemm_gpu.py): the paths agree to fp32 round-off.  -m gpu."""
 import pytest
 import torch
 
@@ -65,21 +65,30 @@ def test_clip_sampler_clips_are_independent(base, hip_device):
     net.set_sample_persist(True)
 
 
-def test_small_batches_and_other_lengths_take_the_other_paths(base, hip_device):
-    """Below the clip threshold the one-clip segment kernel (B = 1) or the launch path serve the call; a length that is not a
-    multiple of 16 frames runs by launches.  Results held to the launch path."""
-    model, _ = base
+def test_small_batches_and_other_lengths(base, hip_device):
+    """RectifiedFlow.sample takes any batch (model.py:763-785).  One and two clips: the one-clip segment kernel, a launch per clip
+    (round 6: two clips were ~1650 launches); three and four: the batch kernel with idle XCDs (round 6: launches through round 5);
+    a length that is not a multiple of 16 frames runs by launches.  Every case against the launch path of the same handle and every
+    clip of the small batches against the oracle."""
+    model, dcfg = base
     net = model.net
     net.set_sample_persist(True)
-    for B, T, want_path in ((1, 256, 1), (2, 256, 0), (8, 250, 0)):
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    for B, T, want_path in ((1, 256, 1), (2, 256, 1), (2, 128, 1), (3, 256, 2), (4, 256, 2), (4, 64, 2), (2, 250, 0), (8, 250, 0)):
         x0, cond, tc = _inputs(B, T, 31 + B, net)
         args = (x0.to(hip_device), cond.to(hip_device), tc.to(hip_device), 2, 2.0, 1.0, -4.0)
         got = net.cfg_sample(*args).cpu()
         assert net.sample_path() == want_path, (B, T, net.sample_path())
+        assert torch.equal(got, net.cfg_sample(*args).cpu()), "not reproducible"
         net.set_sample_persist(False)
         ref = net.cfg_sample(*args).cpu()
+        assert net.sample_path() == 0
         net.set_sample_persist(True)
-        assert max_abs(got, ref) < 5e-5
+        assert max_abs(got, ref) < 5e-5, (B, T, max_abs(got, ref))
+        if want_path and B > 1:
+            for c in range(B):
+                want = oracle.sample(sd, dcfg["net"], x0[c:c + 1], cond[c:c + 1], tc[c:c + 1], 2, 2.0, 1.0)
+                assert max_abs(got[c:c + 1], want) < 1e-4 and rel_l2(got[c:c + 1], want) < 2e-5, (B, T, c, max_abs(got[c:c + 1], want))
 
 
 def test_midi_cfg_arrangement_on_the_clip_sampler(hip_device):

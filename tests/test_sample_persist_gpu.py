@@ -41,9 +41,16 @@ def test_persistent_offline_sampler_matches_launch_path_and_oracle(T, steps, bas
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     want = oracle.sample(sd, dcfg["net"], x0, cond, tc, steps, 2.0, 1.0)
     assert max_abs(got, want) < 1e-4 and rel_l2(got, want) < 2e-5, (max_abs(got, want), rel_l2(got, want))
-    # shapes the kernel does not take fall back silently: two clips
-    x2 = torch.randn(2, 64, T, generator=g).to(hip_device)
-    net.cfg_sample(x2, torch.randn(2, 6, generator=g).to(hip_device), torch.randn(2, 12, T, generator=g).to(hip_device), 2, 2.0, 1.0, -4.0)
+    # two clips: one launch of the kernel per clip (round 6; ~1650 launches through round 5) -- each clip as if sampled alone
+    x2, c2, t2 = torch.randn(2, 64, T, generator=g).to(hip_device), torch.randn(2, 6, generator=g).to(hip_device), torch.randn(2, 12, T, generator=g).to(hip_device)
+    both = net.cfg_sample(x2, c2, t2, 2, 2.0, 1.0, -4.0)
+    assert net.sample_path() == 1
+    for c in range(2):
+        alone = net.cfg_sample(x2[c:c + 1].contiguous(), c2[c:c + 1].contiguous(), t2[c:c + 1].contiguous(), 2, 2.0, 1.0, -4.0)
+        assert max_abs(both[c:c + 1].cpu(), alone.cpu()) < 2e-5, c  # (the conditioning GEMMs of a 2-clip call pick other tiles)
+    # shapes the kernel does not take fall back silently: a length that is not whole 16-frame segments
+    x3 = torch.randn(1, 64, T - 6, generator=g).to(hip_device)
+    net.cfg_sample(x3, c2[:1].contiguous(), t2[:1, :, :T - 6].contiguous(), 2, 2.0, 1.0, -4.0)
     assert not net.sample_persist()
 
 
