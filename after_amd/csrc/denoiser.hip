@@ -3357,6 +3357,72 @@ template __global__ void sample_clip_kernel<0, 1>(ClipArgs);
 // =====================================================================================
 using namespace after;
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Every environment switch of this file, read in ONE place, env() (A/B and diagnostics: production needs none of them; DESIGN.md
+// section 11 says what each one measured) -- when a handle is created or its persistent samplers are provisioned, and per
+// persistent launch for the diagnostics masks (the tests switch AFTER_GEMM_X6 between handles of one process: no caching).
+// Run-time counterparts, where they exist: after_denoiser_set_*.
+//   variable                     default   effect
+//   AFTER_ATTN_DBG               0         attention diagnostics mask of the launch path (1 no RoPE, 2 no reduce, 4 no LN tail, 8 no K / V loads)
+//   AFTER_ROW_GROUPS             1         launch path: 3 = the CFG branches on three streams
+//   AFTER_GRAPH                  0         launch path: hipGraph replay of the Euler loop
+//   AFTER_FUSE_TAIL              1         launch path: out_proj + CFG + Euler as one launch
+//   AFTER_GEMM_X6                1         qkv / MLP Linears of the launch path: 0 fp32 MFMA, 1 gemm_x6 from AFTER_GEMM_X6_MINROWS rows on, 2 gemm_x6 always
+//   AFTER_GEMM_X6_MINROWS        192
+//   AFTER_STREAM_PERSIST         1         streaming sampler as one persistent launch per chunk (stream_step_kernel)
+//   AFTER_SAMPLE_PERSIST         1         offline sampler on the persistent kernels (sample_seg_kernel / sample_clip_kernel)
+//   AFTER_SAMPLE_CLIP            1         ... batches on sample_clip_kernel; AFTER_SAMPLE_CLIP_MINB (3): fewest clips that take it
+//   AFTER_SAMPLE_SEG_MAXB        2         clips of a call served by sample_seg_kernel, one launch each
+//   AFTER_SEG_SPLIT              fp16      "bf16": the one-clip sampler's Linears on three bf16 planes instead of two fp16 pieces
+//   AFTER_CLIP_SPLIT             fp16      "bf16": the same for the batch sampler
+//   AFTER_STREAM_SPLIT           fp16      "fp32": the streaming sampler's Linears on the fp32 MFMA chain
+//   AFTER_CLIP_FUSE              1         batch sampler: qkv tiles attend in place (0: qkv rows through memory + attention items)
+//   AFTER_CLIP_STAGGER           0         batch sampler: XCD g starts g x n x 10 ns late (experiment: no effect)
+//   AFTER_CLIP_GSTAG             0         batch sampler: MLP-up of row tile tm starts tm x n x 10 ns late (experiment; -1: stamps only)
+//   AFTER_STEP_TRACE             0         persistent samplers stamp the wall clock around every XCD-local barrier
+//   AFTER_STEP_DBG               0         persistent samplers' diagnostics mask (2 no weight traffic, 8 / 16 pretend the census failed, 64 / 128 attention forms)
+//   AFTER_STEP_WARM              0,16,4    streaming sampler: sixteenths of the qkv / MLP-up / MLP-down weights warmed into the L2 by idle waves
+struct Env {
+    int attn_dbg = 0, row_groups = 0, graph = 0, fuse_tail = 1, x6 = -1, x6_minrows = -1;
+    int stream_persist = -1, sample_persist = -1, sample_clip = -1, clip_minb = 0, seg_maxb = 0;
+    int seg_h3 = -1, clip_h3 = -1, stream_h3 = -1, clip_fuse = -1, clip_stagger = 0, clip_gstag = 0, step_trace = 0, step_dbg = 0;
+    int warm[3] = {0, 16, 4};
+};
+Env env() {
+    {
+        Env v;
+        auto geti = [](const char* name, int dflt) {
+            const char* s = getenv(name);
+            return s ? atoi(s) : dflt;
+        };
+        auto is = [](const char* name, const char* what) {  // -1: unset, else whether the variable names the OLD form `what`
+            const char* s = getenv(name);
+            return s ? (strcmp(s, what) != 0 ? 1 : 0) : -1;
+        };
+        v.attn_dbg = geti("AFTER_ATTN_DBG", 0);
+        v.row_groups = geti("AFTER_ROW_GROUPS", 0);
+        v.graph = geti("AFTER_GRAPH", 0) != 0;
+        v.fuse_tail = geti("AFTER_FUSE_TAIL", 1);
+        v.x6 = geti("AFTER_GEMM_X6", -1);
+        v.x6_minrows = geti("AFTER_GEMM_X6_MINROWS", -1);
+        v.stream_persist = geti("AFTER_STREAM_PERSIST", -1);
+        v.sample_persist = geti("AFTER_SAMPLE_PERSIST", -1);
+        v.sample_clip = geti("AFTER_SAMPLE_CLIP", -1);
+        v.clip_minb = geti("AFTER_SAMPLE_CLIP_MINB", 0);
+        v.seg_maxb = geti("AFTER_SAMPLE_SEG_MAXB", 0);
+        v.seg_h3 = is("AFTER_SEG_SPLIT", "bf16");
+        v.clip_h3 = is("AFTER_CLIP_SPLIT", "bf16");
+        v.stream_h3 = is("AFTER_STREAM_SPLIT", "fp32");
+        v.clip_fuse = geti("AFTER_CLIP_FUSE", -1);
+        v.clip_stagger = geti("AFTER_CLIP_STAGGER", 0);
+        v.clip_gstag = geti("AFTER_CLIP_GSTAG", 0);
+        v.step_trace = geti("AFTER_STEP_TRACE", 0);
+        v.step_dbg = geti("AFTER_STEP_DBG", 0);
+        if (const char* w = getenv("AFTER_STEP_WARM")) sscanf(w, "%d,%d,%d", &v.warm[0], &v.warm[1], &v.warm[2]);
+        return v;
+    }
+}
+
 struct LayerW {
     float *qkv_w, *mlp0_w, *mlp0_b, *mlp2_w, *mlp2_b, *n1w, *n1b, *n3w, *n3b;
     unsigned short *qkv_w3, *mlp0_w3, *mlp2_w3;  // bf16 planes (x6 blocks) of the three big Linears (gemm_x6.hip)
@@ -3672,12 +3738,7 @@ int run_layers(after_denoiser* h, hipStream_t s, int row0, int rows, const int* 
         a.nkmax = nkmax;
         a.causal = h->cfg.causal;
         {
-            static int dbg = -1;
-            if (dbg < 0) {
-                const char* e = getenv("AFTER_ATTN_DBG");
-                dbg = e ? atoi(e) : 0;
-            }
-            a.dbg = dbg;
+            a.dbg = env().attn_dbg;
         }
         AFTER_TRY(launch_attn(a, rows, lds, s));
         if (x6_up) AFTER_TRY(gemm_x6(h, s, hb3, w.mlp0_w3, w.mlp0_b, x6_dn ? nullptr : mlp, x6_dn ? mlp3 : nullptr,
@@ -3967,9 +4028,8 @@ extern "C" int after_denoiser_create(const after_denoiser_cfg* cfg, const float*
         // Three concurrent CFG-branch streams helped the classic GEMM tiles at large batch
         // (B=8: 108.9 vs 112.3 ms); with the balanced split-K GEMMs one stream is faster
         // (107.4 vs 111.1 ms), so a single stream is the default and 3 is opt-in.
-        const char* e = getenv("AFTER_ROW_GROUPS");
-        if (e) {
-            h->row_groups = atoi(e) == 3 ? 3 : 1;
+        if (const int rgs = env().row_groups) {
+            h->row_groups = rgs == 3 ? 3 : 1;
             h->row_groups_forced = 1;
         }
     }
@@ -3978,25 +4038,17 @@ extern "C" int after_denoiser_create(const after_denoiser_cfg* cfg, const float*
         // replay 25.3 ms vs 23.7 ms for plain launches -- the path is GPU-bound, the host
         // keeps the queue full, and replay adds ~1 us per node.  Plain launches are therefore
         // the default; AFTER_GRAPH=1 / after_denoiser_set_graph(h, 1) selects the replay.
-        const char* e = getenv("AFTER_GRAPH");
-        h->use_graph = (e && atoi(e) != 0);
-        const char* f = getenv("AFTER_FUSE_TAIL");
-        h->fuse_tail = f ? atoi(f) : 1;
-        const char* x6 = getenv("AFTER_GEMM_X6");
-        if (x6) h->x6 = atoi(x6) < 0 ? 0 : (atoi(x6) > 2 ? 2 : atoi(x6));
-        const char* x6r = getenv("AFTER_GEMM_X6_MINROWS");
-        if (x6r) h->x6_min_rows = atoi(x6r);
+        const Env ev = env();
+        h->use_graph = ev.graph != 0;
+        h->fuse_tail = ev.fuse_tail;
+        if (ev.x6 != -1) h->x6 = ev.x6 < 0 ? 0 : (ev.x6 > 2 ? 2 : ev.x6);
+        if (ev.x6_minrows != -1) h->x6_min_rows = ev.x6_minrows;
         if (h->E % 128 != 0) h->fuse_tail = 0;  // the fused GEMM splits K four ways
-        const char* ps = getenv("AFTER_STREAM_PERSIST");
-        if (ps) h->persist_step = atoi(ps) != 0;
-        const char* po = getenv("AFTER_SAMPLE_PERSIST");
-        if (po) h->persist_offline = atoi(po) != 0;
-        const char* pc = getenv("AFTER_SAMPLE_CLIP");
-        if (pc) h->persist_clip = atoi(pc) != 0;
-        const char* pcb = getenv("AFTER_SAMPLE_CLIP_MINB");
-        if (pcb && atoi(pcb) > 0) h->clip_min_b = atoi(pcb);
-        const char* psb = getenv("AFTER_SAMPLE_SEG_MAXB");
-        if (psb && atoi(psb) > 0) h->seg_max_b = atoi(psb);
+        if (ev.stream_persist != -1) h->persist_step = ev.stream_persist != 0;
+        if (ev.sample_persist != -1) h->persist_offline = ev.sample_persist != 0;
+        if (ev.sample_clip != -1) h->persist_clip = ev.sample_clip != 0;
+        if (ev.clip_minb > 0) h->clip_min_b = ev.clip_minb;
+        if (ev.seg_maxb > 0) h->seg_max_b = ev.seg_maxb;
         hipDeviceProp_t prop;
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(AFTER_E_HIP);
@@ -4271,12 +4323,11 @@ int persist_prepare(after_denoiser* h, bool offline) {
         const size_t per_layer = 3 * E * E + ME * E + E * ME;
         const size_t total = E * C + C * E + per_layer * h->L;
         const size_t nact = (size_t)8 * kSGroupRows * (3 * E + ME);
-        const char* tr = getenv("AFTER_STEP_TRACE");
         bool ok = hipMalloc(&sync, sizeof(StepSync)) == hipSuccess &&
                   hipHostMalloc(&failw, 32 * sizeof(unsigned), hipHostMallocDefault) == hipSuccess &&
                   hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess &&
                   hipMalloc(&wt, total * sizeof(float)) == hipSuccess && hipMalloc(&act, nact * sizeof(float)) == hipSuccess;
-        if (ok && tr && atoi(tr) != 0) ok = hipMalloc(&trace, (size_t)h->n_cus * 128 * sizeof(unsigned long long)) == hipSuccess;
+        if (ok && env().step_trace != 0) ok = hipMalloc(&trace, (size_t)h->n_cus * 128 * sizeof(unsigned long long)) == hipSuccess;
         if (ok) ok = hipMemset(act, 0, nact * sizeof(float)) == hipSuccess && hipMemset(sync, 0, sizeof(StepSync)) == hipSuccess;
         std::vector<after_denoiser::StepLayerW> layers;
         const float *patch_wt = nullptr, *out_wt = nullptr;
@@ -4329,10 +4380,9 @@ int persist_prepare(after_denoiser* h, bool offline) {
         h->seg_qkv = q, h->seg_act3 = a3;
     }
     if (h->step_sync && !h->seg_h3_w) {  // the two-piece fp16 copies of the tiled weights (the default arithmetic of the one-clip and the streaming sampler)
-        const char* e = getenv("AFTER_SEG_SPLIT");
-        if (e) h->seg_h3 = strcmp(e, "bf16") != 0;
-        const char* e2 = getenv("AFTER_STREAM_SPLIT");
-        if (e2) h->stream_h3 = strcmp(e2, "fp32") != 0;
+        const Env ev = env();
+        if (ev.seg_h3 != -1) h->seg_h3 = ev.seg_h3;
+        if (ev.stream_h3 != -1) h->stream_h3 = ev.stream_h3;
         if ((h->seg_h3 || h->stream_h3) && h3_scales(h)) {
             const size_t per = (3 * E * E + 2 * E * ME) * 2;  // unsigned shorts per layer
             unsigned short* w3 = nullptr;
@@ -4369,8 +4419,8 @@ int persist_prepare(after_denoiser* h, bool offline) {
         unsigned short* w3h = nullptr;
         const size_t nh = 8 * (rows / 192) * 8 * 2048, per = x6_elems(3 * (int)E, (int)E);
         if (ok) {
-            const char* e = getenv("AFTER_CLIP_FUSE");
-            if (e) h->clip_fuse = atoi(e) != 0;
+            const Env ev = env();
+            if (ev.clip_fuse != -1) h->clip_fuse = ev.clip_fuse != 0;
             ok = hipMalloc(&halo, nh * sizeof(float)) == hipSuccess && hipMemset(halo, 0, nh * sizeof(float)) == hipSuccess &&
                  hipMalloc(&w3h, per * h->L * sizeof(unsigned short)) == hipSuccess &&
                  hipMemset(w3h, 0, per * h->L * sizeof(unsigned short)) == hipSuccess && hipMalloc(&tmp, 3 * E * E * sizeof(float)) == hipSuccess;
@@ -4381,10 +4431,7 @@ int persist_prepare(after_denoiser* h, bool offline) {
             }
             // ---- the two-piece fp16 form (gemm_h3_pipe.h): per-tensor power-of-two scales from guaranteed bounds, then the pieces
             unsigned short* wh3 = nullptr;
-            {
-                const char* e2 = getenv("AFTER_CLIP_SPLIT");
-                if (e2) h->clip_h3 = strcmp(e2, "bf16") != 0;
-            }
+            if (ev.clip_h3 != -1) h->clip_h3 = ev.clip_h3;
             const size_t pq = h3_elems(3 * (int)E, (int)E), pu = h3_elems((int)ME, (int)E), pd = h3_elems((int)E, (int)ME);
             if (ok && h->clip_h3 && h3_scales(h)) {
                 bool ok3 = hipMalloc(&wh3, (pq + pu + pd) * h->L * sizeof(unsigned short)) == hipSuccess;
@@ -4447,11 +4494,7 @@ int persist_prepare(after_denoiser* h, bool offline) {
         // dry census with the samplers' launch geometry
         AFTER_HIP_CHECK(hipDeviceSynchronize());
         AFTER_HIP_CHECK(hipMemset(h->step_sync, 0, sizeof(StepSync)));
-        static int dbg_env = -1;
-        if (dbg_env < 0) {
-            const char* e = getenv("AFTER_STEP_DBG");
-            dbg_env = e ? atoi(e) : 0;
-        }
+        const int dbg_env = env().step_dbg;
         {
             PersistLaunch guard(h->dev, nullptr);
             hipLaunchKernelGGL(persist_census_kernel, dim3(h->n_cus), dim3(512), lds_seg, nullptr, h->step_sync, dbg_env | h->step_dbg);
@@ -4538,19 +4581,10 @@ int sample_persistent(after_denoiser* h, hipStream_t s, const float* x0, float* 
         a.sync = h->step_sync;
         a.trace = h->step_trace_on ? h->step_trace : nullptr;
         {
-            static int dbg = -1;
-            if (dbg < 0) {
-                const char* e = getenv("AFTER_STEP_DBG");
-                dbg = e ? atoi(e) : 0;
-            }
-            a.dbg = dbg | h->step_dbg;
-            static int warm[3] = {-1, 0, 0};
-            if (warm[0] < 0) {
-                warm[0] = 0, warm[1] = 16, warm[2] = 4;  // (same-box A/B: warming in the short LayerNorm phase does not pay)
-                const char* e = getenv("AFTER_STEP_WARM");
-                if (e) sscanf(e, "%d,%d,%d", &warm[0], &warm[1], &warm[2]);
-            }
-            a.warm[0] = warm[0], a.warm[1] = warm[1], a.warm[2] = warm[2];
+            const Env ev = env();
+            a.dbg = ev.step_dbg | h->step_dbg;
+            // (warming in the short LayerNorm phase does not pay: 0 sixteenths of qkv, 16 of MLP-up, 4 of MLP-down -- same-box A/B)
+            a.warm[0] = ev.warm[0], a.warm[1] = ev.warm[1], a.warm[2] = ev.warm[2];
         }
         for (int l = 0; l < L; ++l) {
             const LayerW& w = h->layers[l];
@@ -4636,12 +4670,7 @@ int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, in
     a.sync = h->step_sync;
     a.trace = h->step_trace_on ? h->step_trace : nullptr;
     {
-        static int dbg = -1;
-        if (dbg < 0) {
-            const char* e = getenv("AFTER_STEP_DBG");
-            dbg = e ? atoi(e) : 0;
-        }
-        a.dbg = dbg | h->step_dbg;
+        a.dbg = env().step_dbg | h->step_dbg;
         a.warm[0] = a.warm[1] = a.warm[2] = 0;
     }
     for (int l = 0; l < L; ++l) {
@@ -4723,24 +4752,10 @@ int sample_clip(after_denoiser* h, hipStream_t s, const float* x0, float* out, i
     a.rows_pad = cdiv(3 * T, kClipRowTile) * kClipRowTile;  // (slices are addressed with the CALL's row count: dense in the L2)
     a.pat_rows = cdiv(T, 16) * 16;
     {
-        static int dbg = -1;
-        if (dbg < 0) {
-            const char* e = getenv("AFTER_STEP_DBG");
-            dbg = e ? atoi(e) : 0;
-        }
-        a.dbg = dbg | h->step_dbg;
-        static int stagger = -1;
-        if (stagger < 0) {
-            const char* e = getenv("AFTER_CLIP_STAGGER");
-            stagger = e ? atoi(e) : 0;
-        }
-        a.stagger = stagger;
-        static int gstag = -2;
-        if (gstag == -2) {
-            const char* e = getenv("AFTER_CLIP_GSTAG");
-            gstag = e ? atoi(e) : 0;
-        }
-        a.gstag = gstag;
+        const Env ev = env();
+        a.dbg = ev.step_dbg | h->step_dbg;
+        a.stagger = ev.clip_stagger;
+        a.gstag = ev.clip_gstag;
     }
     a.xt = h->xt;
     {

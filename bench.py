@@ -57,7 +57,7 @@ def split_ceiling(arith):
 ROUND = "r6"
 # sources whose change invalidates a committed traffic measurement of the dominant GEMM
 TRAFFIC_SOURCES = ["after_amd/csrc/gemm.hip", "after_amd/csrc/gemm_x6.hip", "after_amd/csrc/gemm_pipe.h",
-                   "after_amd/csrc/gemm_x6_pipe.h", "after_amd/csrc/denoiser.hip"]
+                   "after_amd/csrc/gemm_x6_pipe.h", "after_amd/csrc/gemm_h3_pipe.h", "after_amd/csrc/denoiser.hip"]
 
 
 def source_hash():

@@ -93,4 +93,19 @@ stream3)  # the streaming sampler's Linears on two-piece fp16 operands: parity, 
     done
     python scripts/stream_step_trace.py 2>/dev/null | grep -v amdgpu.ids | tee $O/stream_step_trace.txt | tail -14
     ;;
+scales)  # the two-piece form's scales on weights far from the random-init scale; the fall-back to three bf16 planes
+    timeout 900 python -m pytest tests/test_sample_persist_gpu.py -x -q -k "two_piece" 2>&1 | tail -15
+    ;;
+segslots)  # register-slot depth of the one-clip kernel's operand rings (k-blocks of a wave in flight), two-piece form
+    cp after_amd/lib/libafter_hip.so $O/default.so
+    for rep in 1 2; do
+      for v in default s32 s23 s33 s44; do
+        if [ $v = default ]; then cp $O/default.so after_amd/lib/libafter_hip.so; else cp scripts/variants/$v/libafter_hip.so after_amd/lib/libafter_hip.so; fi
+        for cfg in base tiny; do
+          python scripts/time_sampler.py $cfg 1 50 7 2>/dev/null | tail -1 | cut -c1-80 | sed "s/^/$v: /" | tee -a $O/seg_slots.txt
+        done
+      done
+    done
+    cp $O/default.so after_amd/lib/libafter_hip.so; rm $O/default.so
+    ;;
 esac

@@ -11,7 +11,7 @@ python bench.py --pmc --batch-per-gpu 8 > $O/pmc_b8.log 2>&1
 python bench.py --pmc-mfma > $O/mfma_b1.log 2>&1   # matrix-pipe busy fraction per kernel (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE)
 python bench.py --pmc-mfma --batch-per-gpu 8 > $O/mfma_b8.log 2>&1
 cp profiles/${R}_pmc_hbm_base_b1.json profiles/${R}_pmc_hbm_base_b8.json profiles/${R}_pmc_mfma_base_b1.json profiles/${R}_pmc_mfma_base_b8.json $O/ 2>/dev/null
-python bench.py --steps 20 --warmup 5 > $O/${R}_bench_b1.json 2> $O/bench_b1.err
+python bench.py --steps 20 --warmup 5 > $O/${R}_bench_b1.json 2> $O/bench_b1.err   # (the driver's line: the headline + `legs` = the other BASELINE configs)
 python bench.py --steps 6 --warmup 2 --batch-per-gpu 8 --no-cpu-baseline > $O/${R}_bench_b8.json 2> $O/bench_b8.err
 python bench.py --steps 4 --warmup 1 --batch-per-gpu 8 --config midi > $O/${R}_bench_midi_b8.json 2> $O/bench_midi.err
 python bench.py --stream --steps 16 --warmup 4 > $O/${R}_bench_stream.json 2> $O/bench_stream.err
@@ -26,7 +26,7 @@ for p in 1 0; do
   AFTER_GEMM_X6_PERSIST=$p python bench.py --steps 6 --warmup 2 --batch-per-gpu 8 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'leg': 'b8', 'AFTER_GEMM_X6_PERSIST': $p, 'ms_per_step': d['ms_per_step'], 'xrt': d['value']}))" >> $O/${R}_ab_gemm_path.jsonl
 done
 python scripts/bench_gemm_x6.py $O/${R}_gemm_x6_sweep.jsonl > $O/x6_sweep.log 2>&1
-python scripts/time_codec.py --rounds 30 2>/dev/null | grep workload > $O/${R}_codec.jsonl
+python scripts/time_codec.py --rounds 30 --batches 1,8,16,32 2>/dev/null | grep workload > $O/${R}_codec.jsonl   # (16 / 32: the dataset scripts' batches)
 python scripts/time_encoders.py 2>/dev/null | grep workload >> $O/${R}_codec.jsonl
 # round 4: the bf16-pipe convs of the decoder (conv_x6.hip): same-box A/B of the codec, per-layer sweep against the fp32 kernel
 for m in 0 1 0 1; do
@@ -71,6 +71,17 @@ for b in 1 8; do
     AFTER_TIME_GEMM_PATH=$m python scripts/time_sampler.py base $b 50 5 2>/dev/null | tail -1 | cut -c1-90 | sed "s/^/gemm path $m: /" >> $O/${R}_ab_bf16_tier.txt
   done
 done
+# round 6: the Linears' arithmetic in the three persistent samplers -- two fp16 pieces (default) against three bf16 planes / the fp32 chain
+for rep in 1 2; do
+  for cfgb in "base 1" "tiny 1" "base 8" "midi 8"; do set -- $cfgb
+    AFTER_SEG_SPLIT=bf16 AFTER_CLIP_SPLIT=bf16 python scripts/time_sampler.py $1 $2 50 5 2>/dev/null | tail -1 | cut -c1-90 | sed "s/^/bf16 x 3 planes: /" >> $O/${R}_ab_split.txt
+    python scripts/time_sampler.py $1 $2 50 5 2>/dev/null | tail -1 | cut -c1-90 | sed "s/^/fp16 x 2 pieces: /" >> $O/${R}_ab_split.txt
+  done
+  AFTER_STREAM_SPLIT=fp32 python bench.py --stream --steps 24 --warmup 4 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('fp32 MFMA chain:  ', d['ms_per_step'], 'ms per chunk', d['value'], 'xRT')" >> $O/${R}_ab_stream_split.txt
+  python bench.py --stream --steps 24 --warmup 4 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('fp16 x 2 pieces:  ', d['ms_per_step'], 'ms per chunk', d['value'], 'xRT')" >> $O/${R}_ab_stream_split.txt
+done
+for b in 1 2 3 4 5 8; do timeout 300 python scripts/time_sampler.py base $b 50 3 2>&1 | grep "sample " | cut -c1-70 >> $O/${R}_clip_threshold_shipped.txt; done
+timeout 900 python -m pytest tests/test_gemm_gpu.py -x -q -s -k "h3_two_piece" 2>&1 | grep "h3 \|passed\|failed" > $O/${R}_h3_accuracy.txt
 python bench.py --bf16-tier --steps 20 --warmup 5 --no-cpu-baseline > $O/${R}_bench_bf16_tier_b1.json 2> $O/bench_tier.err
 python bench.py --bf16-tier --steps 6 --warmup 2 --batch-per-gpu 8 --no-cpu-baseline > $O/${R}_bench_bf16_tier_b8.json 2>> $O/bench_tier.err
 for p in 0 1 0 1; do

@@ -132,3 +132,58 @@ def test_geometries_the_kernel_does_not_take_run_by_launches(base, tiny, hip_dev
                 want = oracle.sample(sd, dcfg["net"], x0, cond, tc, 2, 2.0, 1.0)
                 assert max_abs(got, want) < 1e-4, max_abs(got, want)
             assert torch.isfinite(got).all()
+
+
+@pytest.mark.parametrize("B", [1, 8])
+def test_two_piece_fp16_scales_follow_the_weights(B, hip_device):
+    """The persistent samplers' Linears carry every operand as two fp16 pieces under a power-of-two scale chosen from GUARANTEED
+    bounds of the handle's own weights (denoiser.hip: h3_scales -- LayerNorm outputs <= sqrt(E) max|w| + max|b|, the MLP hidden
+    layer <= the largest row L1 norm of the up-projection x that bound + max|bias|).  A checkpoint far from the random-init scale
+    -- LayerNorm gains x 40, an up-projection x 25 with biases of +-30, qkv / down-projection x 1 / 64 -- moves the scales by
+    many powers of two; the result must stay on the two-piece form and within the usual bars of the launch path (three bf16
+    planes) and the oracle.  Bounds beyond fp16's range at the smallest scale: the handle falls back to the three-plane form."""
+    model, dcfg, _ = pipeline.build_models("base", "baseAE", hip_device, seed=21)
+    net = model.net
+    torch.manual_seed(3)
+    sd = net.state_dict()
+    for k, v in sd.items():
+        if ".norm1.weight" in k or ".norm3.weight" in k:
+            v.mul_(40.0)
+        if ".mlp.mlp.0.weight" in k:
+            v.mul_(25.0)
+        if ".mlp.mlp.0.bias" in k:
+            v.uniform_(-30.0, 30.0)
+        if ".mlp.mlp.2.weight" in k or "qkv_linear.weight" in k:
+            v.mul_(1.0 / 64.0)
+    net.load_state_dict(sd)
+    g = torch.Generator().manual_seed(5 + B)
+    T, steps = 128, 3
+    x0, cond, tc = torch.randn(B, 64, T, generator=g), torch.randn(B, 6, generator=g), torch.randn(B, 12, T, generator=g)
+    args = (x0.to(hip_device), cond.to(hip_device), tc.to(hip_device), steps, 2.0, 1.0, -4.0)
+    net.set_sample_persist(True)
+    got = net.cfg_sample(*args).cpu()
+    assert net.sample_path() == (1 if B == 1 else 2) and net.sample_arith() == 2, (net.sample_path(), net.sample_arith())
+    net.set_sample_persist(False)
+    ref = net.cfg_sample(*args).cpu()
+    assert net.sample_path() == 0
+    scale = max(1.0, ref.abs().max().item())
+    assert torch.isfinite(got).all() and max_abs(got, ref) < 5e-5 * scale, (max_abs(got, ref), scale)
+    sdc = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    want = oracle.sample(sdc, dcfg["net"], x0[:1], cond[:1], tc[:1], steps, 2.0, 1.0)
+    assert max_abs(got[:1], want) < 1e-4 * scale and rel_l2(got[:1], want) < 2e-5, (max_abs(got[:1], want), rel_l2(got[:1], want))
+    # a hidden-layer bound beyond fp16's range even at the smallest scale (2^-12): the three-plane bf16 form serves the handle
+    sd = net.state_dict()
+    for k, v in sd.items():
+        if ".norm3.weight" in k:
+            v.mul_(1e3)
+        if ".mlp.mlp.0.weight" in k:
+            v.mul_(1e2)
+    net.load_state_dict(sd)
+    net.set_sample_persist(True)
+    got2 = net.cfg_sample(*args).cpu()
+    assert net.sample_path() in (1, 2) and net.sample_arith() == 1, (net.sample_path(), net.sample_arith())
+    net.set_sample_persist(False)
+    ref2 = net.cfg_sample(*args).cpu()
+    assert torch.isfinite(got2).all() == torch.isfinite(ref2).all()
+    if torch.isfinite(ref2).all():
+        assert max_abs(got2, ref2) < 5e-5 * max(1.0, ref2.abs().max().item())
