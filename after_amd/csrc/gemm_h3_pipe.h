@@ -9,7 +9,7 @@
 // i.e. the fp32 product of the operands up to the dropped Wl Al term (<= 2^-22 relative) and the pieces' representation error
 // (<= 2^-22 relative each): per-term errors 4 - 8x BELOW what the fp32 accumulation of a K = 512 .. 1536 dot product commits in the
 // reference's own arithmetic, and uncorrelated.  Measured against fp64 the result is as close as the fp32 MFMA chain's
-// (tests/test_gemm_gpu.py::test_h3_*; DESIGN.md section 4.4).  Half the MFMAs and two thirds of the operand bytes of the
+// (tests/test_gemm_gpu.py::test_h3_*; DESIGN.md section 4.1).  Half the MFMAs and two thirds of the operand bytes of the
 // three-plane bf16 form of gemm_x6_pipe.h -- whose K loops ran at the matrix pipes' issue limit AND at the clock the chip sustains
 // under them (profiles/r6_gstag.txt): fewer instructions per flop is the only way down.
 //

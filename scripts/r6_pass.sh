@@ -108,4 +108,8 @@ segslots)  # register-slot depth of the one-clip kernel's operand rings (k-block
     done
     cp $O/default.so after_amd/lib/libafter_hip.so; rm $O/default.so
     ;;
+final)  # the whole GPU suite on the final sources
+    timeout 3400 python -m pytest tests -x -q -m gpu 2>&1 | tail -8 | tee $O/gpu_suite.txt
+    python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $O/smoke.txt
+    ;;
 esac

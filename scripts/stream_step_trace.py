@@ -74,6 +74,18 @@ for p, name in enumerate(names):
     print(line)
 print("step per XCD (us): " + ", ".join(f"{(t_all[xcc == x][:, 2 * len(names) - 1].max() - t_all[xcc == x][:, 0].min()) / 100.0:.1f}"
                                          for x in range(8) if (xcc == x).any()))
+if args.offline:  # per XCD: the step's time by kind of phase (sum over the layers; first start -> last arrival of each phase)
+    kinds = ["ln", "qkv", "attn", "up+roll", "down"]
+    for x in range(8):
+        tx = t_all[xcc == x]
+        if not len(tx) or tx[:, 1].max() == 0:
+            continue
+        tot = {k: 0.0 for k in kinds}
+        for p_, nm in enumerate(names):
+            for k in kinds:
+                if nm.endswith(" " + k):
+                    tot[k] += (tx[:, 2 * p_ + 1].max() - tx[:, 2 * p_].min()) / 100.0
+        print(f"XCD {x}: " + "  ".join(f"{k} {v:.1f}" for k, v in tot.items()))
 print(f"XCD {args.xcd} step: {(t[:, 2 * len(names) - 1].max() - t0) / 100.0:.1f} us; phases (first start -> last arrival) {tot_work:.1f} us; "
       f"barriers (last arrival -> last exit) {tot_bar:.1f} us")
 
