@@ -112,4 +112,23 @@ final)  # the whole GPU suite on the final sources
     timeout 3400 python -m pytest tests -x -q -m gpu 2>&1 | tail -8 | tee $O/gpu_suite.txt
     python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $O/smoke.txt
     ;;
+grp)  # row-tile groups of the batch kernel free-running inside a layer (8-way barriers, per-layer hand-over rows, start delay): parity, A/B, trace
+    cp after_amd/lib/libafter_hip.so $O/default.so
+    cp scripts/variants/grp/libafter_hip.so after_amd/lib/libafter_hip.so
+    timeout 1500 python -m pytest tests/test_sample_clip_gpu.py -x -q 2>&1 | tail -4
+    timeout 900 python -m pytest tests/test_baseline_size_gpu.py -x -q -k "b8 or midi_b8" 2>&1 | tail -3
+    for rep in 1 2; do
+      cp $O/default.so after_amd/lib/libafter_hip.so
+      python scripts/time_sampler.py base 8 50 3 2>/dev/null | tail -1 | cut -c1-80 | sed "s/^/HEAD (XCD-wide barriers, shared hand-over line):   /" | tee -a $O/ab_grouped.txt
+      cp scripts/variants/grp/libafter_hip.so after_amd/lib/libafter_hip.so
+      AFTER_CLIP_GROUPED=0 python scripts/time_sampler.py base 8 50 3 2>/dev/null | tail -1 | cut -c1-80 | sed "s/^/XCD-wide barriers, hand-over words on own lines:   /" | tee -a $O/ab_grouped.txt
+      for d in 0 100 200 300 500 800; do
+        AFTER_CLIP_GDELAY=$d python scripts/time_sampler.py base 8 50 3 2>/dev/null | tail -1 | cut -c1-80 | sed "s/^/group barriers, start delay $d x 10 ns per group:   /" | tee -a $O/ab_grouped.txt
+      done
+    done
+    AFTER_CLIP_GDELAY=300 python scripts/time_sampler.py midi 8 50 3 2>/dev/null | tail -1 | cut -c1-80 | sed "s/^/midi, group barriers, delay 300: /" | tee -a $O/ab_grouped.txt
+    AFTER_CLIP_GDELAY=300 python scripts/time_sampler.py base 4 50 3 2>/dev/null | tail -1 | cut -c1-80 | sed "s/^/4 clips, group barriers, delay 300: /" | tee -a $O/ab_grouped.txt
+    python scripts/stream_step_trace.py --offline --clips 8 --xcd 3 2>/dev/null | grep -v amdgpu.ids | tee $O/clip_step_trace_grouped.txt | tail -22
+    cp $O/default.so after_amd/lib/libafter_hip.so; rm $O/default.so
+    ;;
 esac
