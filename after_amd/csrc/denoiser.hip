@@ -711,8 +711,10 @@ constexpr int kSGroupRows = 96;                 // token rows one XCD can own (o
 
 struct StepSync {
     unsigned arrive[8][32];  // [xcc][0]: arrivals (each word on its own 128-byte line)
-    unsigned gen[8][32];     // [xcc][rank]: batch sampler -- the last qkv round whose hand-over rows workgroup `rank` has published, + 1
-                             // (clip_tile_attention; zeroed per launch with the words above.  The barrier's generation word until round 4b)
+    unsigned gen[8][32];     // (the barrier's generation word until round 4b; unused)
+    unsigned hand[8][32][32];  // [xcc][rank][0]: batch sampler -- the last qkv round whose hand-over rows workgroup `rank` has published, + 1
+                               // (clip_tile_attention; zeroed per launch with the words above; one 128-byte line per workgroup like `flag`:
+                               // a neighbour's poll and this workgroup's store do not meet on a line)
     unsigned flag[8][32][32];  // [xcc][rank][0]: the last round workgroup `rank` of the XCC has arrived at (one line each)
     unsigned pop[8][32];     // [xcc][0]: workgroups resident on the XCC
     unsigned census[32];     // [0]: workgroups counted
@@ -818,9 +820,11 @@ __device__ __forceinline__ bool step_spin(unsigned* word, unsigned want, unsigne
 // one store + one poll on the critical path, nothing serialises on a line: 0.66 - 0.72 us.
 // `pub`: a system-scope word that workgroup 0 sets to `pubval` when it has seen everybody (the offline sampler's "this layer's qkv
 // rows are in memory": every workgroup drains its stores before it raises its flag).
+// `first` / `stride`: the barrier's members are the n workgroups first + stride x i of the XCC (all of them: 0 / 1; the batch sampler's
+// row-tile GROUPS: workgroups g, g + 4, .. -- a group's phases depend on its own rows only, so its barriers need not wait for the others).
 __device__ __forceinline__ bool step_barrier(StepSync* st, unsigned xcc, unsigned n, unsigned rank, unsigned round,
                                              unsigned long long* trace, unsigned tslot, bool drain, unsigned* s_ok,
-                                             unsigned* pub = nullptr, unsigned pubval = 0) {
+                                             unsigned* pub = nullptr, unsigned pubval = 0, unsigned first = 0, unsigned stride = 1) {
     if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -830,7 +834,7 @@ __device__ __forceinline__ bool step_barrier(StepSync* st, unsigned xcc, unsigne
         if (lane == 0) __hip_atomic_store(&st->flag[xcc][rank][0], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bool ok = true, pending = lane < n;
         for (unsigned spins = 0;; ++spins) {
-            if (pending) pending = __hip_atomic_load(&st->flag[xcc][lane][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < round;
+            if (pending) pending = __hip_atomic_load(&st->flag[xcc][first + stride * lane][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < round;
             if (__builtin_amdgcn_ballot_w64(pending) == 0) break;
             __builtin_amdgcn_s_sleep(1);
             if (spins > (1u << 21)) {
@@ -2282,6 +2286,9 @@ struct ClipLayer {
 struct ClipArgs {
     int B, T, C, Cp, L, cs, W, nkmax, nsteps, dbg;
     int stagger;              // start offset between consecutive XCDs, wall-clock ticks of 10 ns (AFTER_CLIP_STAGGER)
+    int grouped;              // row-tile groups free-running between the sampler's XCD-wide points (rows_pad == 4 x 192, tiles attend in place):
+                              // workgroup rank = 4 j + g belongs to group g (its qkv / MLP-up tile's row tile), a layer's barriers are 8-way
+    int gdelay;               // ... group g starts every Euler step g x gdelay ticks of 10 ns late (the groups' K loops and bursts out of phase)
     int gstag;                // experiment (AFTER_CLIP_GSTAG): the MLP-up phase of row tile tm starts tm x gstag ticks late, and the
                               // phase's stamps [64..67] are MLP-up's instead of qkv's (-1: stamps only)
     int rows_pad;             // token rows provisioned per XCD (3 T rounded up to kClipRowTile)
@@ -2320,7 +2327,7 @@ struct ClipGemm {
     unsigned long long* tr; // AFTER_STEP_TRACE stamps of the workgroup's first tile: [64] entry, [65] (unused), [66] K loop done, [67] epilogue issued
     // EPI 2 (qkv tile = head, attention in the epilogue: clip_tile_attention)
     float* halo;            // this XCD's [row tile][head][16][128]
-    unsigned* hflag;        // this XCD's [32]: per workgroup, the last sequence number whose halo rows it has published (+ 1)
+    unsigned* hflag;        // this XCD's [32][32]: word [rank][0] = the last sequence number whose halo rows workgroup `rank` has published (+ 1)
     unsigned* fail;         // a spin that gave up raises it
     unsigned sq0;           // sequence number of this call's first round of tiles
     int cs, W, Mg;          // attention chunk, window, valid token rows (3 T)
@@ -2620,7 +2627,7 @@ __device__ __forceinline__ void clip_gemm_r(const ClipGemm& g, unsigned char* sm
             const unsigned sq = g.sq0 + (unsigned)((t - rank) / 32);
             const int prank = rank > 0 ? rank - 1 : 31;
             clip_tile_attention(g.T, g.cs, g.W, g.Mg, tm * BM, tn, c.lds0, g.halo + ((size_t)t << 11), tm > 0 ? g.halo + ((size_t)(t - 1) << 11) : nullptr,
-                                g.hflag + rank, sq + 1, g.hflag + prank, rank > 0 ? sq + 1 : sq, g.fail, g.xres, g.rope_cos, g.rope_sin);
+                                g.hflag + 32 * rank, sq + 1, g.hflag + 32 * prank, rank > 0 ? sq + 1 : sq, g.fail, g.xres, g.rope_cos, g.rope_sin);
             continue;
         }
 #pragma unroll
@@ -2666,7 +2673,7 @@ __device__ __forceinline__ void clip_gemm_r(const ClipGemm& g, unsigned char* sm
 // With several tiles per workgroup the next tile's ring fill is issued BEFORE the finished tile's stores (the epilogue's operands --
 // bias, residual tile -- are fetched and waited for first: a compiler-placed wait behind the fill would wait for the fill).
 template <class C>
-__device__ __forceinline__ void clip_gemm_l(const ClipGemm& g, unsigned char* smem_raw, int rank, int wid, int lane_in) {
+__device__ __forceinline__ void clip_gemm_l(const ClipGemm& g, unsigned char* smem_raw, int rank, int wid, int lane_in, int t_first = -1) {
     constexpr int BM = C::BM, BN = C::BN, MT = C::MT, NT = C::NT, RS = C::RS;
     constexpr int STORES = MT * NT;  // vector-memory instructions of a tile's epilogue behind the fill
     static_assert(C::KS == 1 && C::SC1 == 1, "clip tiles: no k-parts, sc1 operand loads");
@@ -2676,7 +2683,7 @@ __device__ __forceinline__ void clip_gemm_l(const ClipGemm& g, unsigned char* sm
     const int tiles_m = g.M / BM, tiles_n = g.N / BN, ntiles = tiles_m * tiles_n;
     const int rp = wid % RS, cp = wid / RS;
     const int nk = g.K / 32;  // (>= 4)
-    int t = rank;
+    int t = t_first >= 0 ? t_first : rank;  // (grouped: the workgroup's tile lies in its own row-tile group -- exactly 32 tiles then)
     if (t >= ntiles) return;
     std::conditional_t<H3, H3LState<C>, X6LState<C>> c;
     c.lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem_raw;
@@ -3047,6 +3054,18 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
     float* const red = smem;          // tail: partial tiles [8 waves][3][256] | attention rows
     float* const kvl = smem + 8192;   // attention: K / V landing zones [8 waves][2][12][64]
     auto end_phase = [&](bool drain) { return step_barrier(st, xcc, n, (unsigned)rank, ++round, trace, ++tslot, drain, &s_ok); };
+    // Row-tile groups: between patchify and the sampler tail every phase of a layer reads and writes the rows of ONE 192-row tile
+    // (LayerNorm rows, the head tiles of qkv, MLP-up's column tiles, MLP-down's two 96-row tiles of it) -- only the in-tile attention
+    // looks at the tile in front (hand-over rows behind a sequence word: no barrier).  With four row tiles the workgroups 4 j + g form
+    // group g, whose barriers wait for its own eight members only -- an 8-way instead of a 32-way wait, 30 times per Euler step
+    // (profiles/r6_ab_grouped.txt: 30.3 -> 30.1 ms per 8 clips; a start delay between the groups, gdelay, buys nothing on top: what
+    // the groups gain out of phase, r6_gstag.txt, they lose again at the step's XCD-wide tail).
+    const bool grouped = a.grouped != 0;
+    const int grp = rank & 3, gj = rank >> 2;
+    auto end_group = [&](bool drain) {
+        return grouped ? step_barrier(st, xcc, 8, (unsigned)rank, ++round, trace, ++tslot, drain, &s_ok, nullptr, 0u, (unsigned)grp, 4u)
+                       : step_barrier(st, xcc, n, (unsigned)rank, ++round, trace, ++tslot, drain, &s_ok);
+    };
     const int cps = (T + a.cs - 1) / a.cs, nitems = 3 * cps;  // attention items: (CFG row, chunk) ...
     const bool pairs = a.W - 1 + 2 * a.cs <= 32 && T % a.cs == 0 && 2 * a.cs <= 8 && !(a.dbg & 64);  // ... or (CFG row, pair of chunks)
     const bool pairs2 = a.W - 1 + 2 * a.cs > 16;  // a pair's keys are two 16-key tiles (midi: W = 16)
@@ -3054,7 +3073,10 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
     const int nfb = T / 16, ntail = (a.C / 16) * nfb;         // tail items: (column tile, 16-frame block)
     // qkv tiles = heads that attend in place (clip_tile_attention): the window reaches at most 16 rows back, whole chunks per 16 rows
     const bool fuse = a.fuse != 0;
-    float* const halo = a.halo + (size_t)g * (a.rows_pad / 192) * 8 * 2048;
+    // (one set of hand-over rows per LAYER: a group that runs ahead must not overwrite what the group behind it has not read -- the
+    //  same layer of the NEXT step is behind an XCD-wide barrier)
+    const size_t halo_l = (size_t)(a.rows_pad / 192) * 8 * 2048;
+    float* const halo = a.halo + (size_t)g * a.L * halo_l;
     const unsigned qrounds = (unsigned)((a.rows_pad / 192) * 8 + 31) / 32;  // rounds of tiles of a qkv phase
     unsigned qcalls = 0;
 
@@ -3091,6 +3113,10 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
                 }
             }
             if (!end_phase(true)) return;
+            if (grouped && a.gdelay > 0 && grp > 0) {  // (the groups' phases out of step from the start: group g - 1 ahead of g, as the hand-over rows flow)
+                const unsigned long long t0 = wall_clock64();
+                while (wall_clock64() - t0 < (unsigned long long)(grp * a.gdelay)) __builtin_amdgcn_s_sleep(8);
+            }
             for (int l = 0; l < a.L; ++l) {
                 const ClipLayer& Lw = a.layer[l];
                 int lane_l = lane0;
@@ -3098,24 +3124,26 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
                 const int lane = lane_l;
                 // ---- norm0 -> AdaLN(tcond) -> norm1 (transformerv2.py:345-351): one wave per token row; h as x6 planes
                 //      (three rows per wave at T = 256: requested together -- one memory latency, not three in a row)
-                for (int lm0 = rank + 32 * w; lm0 < Mg; lm0 += 3 * 256) {
+                //      (grouped: the rows of the workgroup's own row tile, 24 per workgroup, three consecutive ones per wave)
+                const int ln0 = grouped ? 192 * grp + 24 * gj + 3 * w : rank + 32 * w, lnk = grouped ? 1 : 256, lns = grouped ? 768 : 3 * 256;
+                for (int lm0 = ln0; lm0 < (grouped ? ln0 + 1 : Mg); lm0 += lns) {
                     const float* ab[3];
                     int lms[3], srcs[3];
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        const int lm = min(lm0 + 256 * k, Mg - 1);  // (a missing row repeats the last one: loaded, not stored)
+                        const int lm = min(lm0 + lnk * k, Mg - 1);  // (a missing row repeats the last one: loaded, not stored)
                         const int br = lm / T, t = lm - br * T;
-                        lms[k] = lm0 + 256 * k < Mg ? lm : -1;
+                        lms[k] = lm0 + lnk * k < Mg ? lm : -1;
                         srcs[k] = l == 0 ? t : lm;
                         ab[k] = a.tc_ab + ((size_t)a.tcmap[br * B + c] * T + t) * a.tc_ld + (size_t)l * 2 * E;
                     }
                     clip_ln_rows<H3 != 0>(l == 0 ? pat_r : xres_r, l == 0, srcs, ab, Lw.n1w, Lw.n1b, xres, h3, lms, lane, Lw.s_h1);
                 }
-                if (!end_phase(true)) return;
+                if (!end_group(true)) return;
                 // ---- qkv (+ attention + residual where a tile is a head: clip_tile_attention)
                 if (fuse) {
                     const ClipGemm gq{h3,  H3 ? Lw.qkv_h3 : Lw.qkv_w3h, a.rows_pad, 3 * E, E, nullptr, nullptr, nullptr, a.rope_cos, a.rope_sin, T, xres, a.gstag ? nullptr : trace,
-                                      halo, &st->gen[xcc][0], &st->fail[0], qcalls * qrounds, a.cs, a.W, Mg, Lw.o_qkv, 0.f};
+                                      halo + (size_t)l * halo_l, &st->hand[xcc][0][0], &st->fail[0], qcalls * qrounds, a.cs, a.W, Mg, Lw.o_qkv, 0.f};
                     clip_gemm_r<ClipQUS<TIER, H3>, 2>(gq, smem_raw, rank, w, lane);
                     ++qcalls;
                 } else if constexpr (H3 != 0) {
@@ -3125,17 +3153,17 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
                                       nullptr, nullptr, nullptr, 0, 0, 0, 0};
                     clip_gemm_r<ClipQUT<TIER>, 0>(gq, smem_raw, rank, w, lane);
                 }
-                if (!end_phase(true)) return;
+                if (!end_group(true)) return;
                 // ---- attention + residual + AdaLN(cond) + norm3 (transformerv2.py:190-236, :351-361): one workgroup per chunk
                 //      of a CFG row; h as x6 planes
                 if (fuse) {  // the attention has been added to the residual stream: AdaLN(cond) + norm3, one wave per token row
-                    for (int lm0 = rank + 32 * w; lm0 < Mg; lm0 += 3 * 256) {
+                    for (int lm0 = ln0; lm0 < (grouped ? ln0 + 1 : Mg); lm0 += lns) {
                         const float* ab[3];
                         int lms[3], srcs[3];
 #pragma unroll
                         for (int k = 0; k < 3; ++k) {
-                            const int lm = min(lm0 + 256 * k, Mg - 1);
-                            lms[k] = lm0 + 256 * k < Mg ? lm : -1;
+                            const int lm = min(lm0 + lnk * k, Mg - 1);
+                            lms[k] = lm0 + lnk * k < Mg ? lm : -1;
                             srcs[k] = lm;
                             ab[k] = cond_ab + (size_t)((lm / T) * B + c) * a.cond_ld + (size_t)l * 2 * E;
                         }
@@ -3165,7 +3193,7 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
                                        xres, reinterpret_cast<float*>(h3), trace);
                     }
                 }
-                if (!end_phase(true)) return;
+                if (!end_group(true)) return;
                 // ---- MLP up + GELU
                 {
                     if (a.gstag > 0) {
@@ -3176,14 +3204,15 @@ __global__ __launch_bounds__(512) void sample_clip_kernel(ClipArgs a) {
                                       nullptr, nullptr, nullptr, 0, 0, 0, 0, Lw.o_up, Lw.s_m};
                     clip_gemm_r<ClipQUS<TIER, H3>, 1>(gu, smem_raw, rank, w, lane);
                 }
-                if (!end_phase(true)) return;
+                if (!end_group(true)) return;
                 // ---- MLP down + residual
                 {
                     const ClipGemm gd{mlp3, H3 ? Lw.mlp2_h3 : Lw.mlp2_w3, a.rows_pad, E, ME, Lw.mlp2_b, nullptr, nullptr, nullptr, nullptr, T, xres, nullptr,
                                       nullptr, nullptr, nullptr, 0, 0, 0, 0, Lw.o_dn, 0.f};
-                    clip_gemm_l<ClipDnS<TIER, H3>>(gd, smem_raw, rank, w, lane);
+                    // (grouped: the 96-row tiles 2 g, 2 g + 1 of the workgroup's own row tile x the four column tiles, dealt over its group)
+                    clip_gemm_l<ClipDnS<TIER, H3>>(gd, smem_raw, rank, w, lane, grouped ? (gj >> 1) * 8 + 2 * grp + (gj & 1) : -1);
                 }
-                if (!end_phase(true)) return;
+                if (!(l + 1 < a.L ? end_group(true) : end_phase(true))) return;  // (the sampler tail reads every group's rows)
             }
             // ---- out_proj + CFG + Euler (+ the token-major latents of the next step), fp32 MFMA: item (column tile,
             //      16-frame block) owns the three CFG rows of its frames (model.py:749-759, 777-783)
@@ -3379,6 +3408,8 @@ using namespace after;
 //   AFTER_CLIP_FUSE              1         batch sampler: qkv tiles attend in place (0: qkv rows through memory + attention items)
 //   AFTER_CLIP_STAGGER           0         batch sampler: XCD g starts g x n x 10 ns late (experiment: no effect)
 //   AFTER_CLIP_GSTAG             0         batch sampler: MLP-up of row tile tm starts tm x n x 10 ns late (experiment; -1: stamps only)
+//   AFTER_CLIP_GROUPED           1         batch sampler, four row tiles: 8-way group barriers inside a layer (0: XCD-wide barriers everywhere)
+//   AFTER_CLIP_GDELAY            0         ... group g starts every Euler step g x n x 10 ns late (measured 0 .. 8 us: nothing to gain, r6_ab_grouped.txt)
 //   AFTER_STEP_TRACE             0         persistent samplers stamp the wall clock around every XCD-local barrier
 //   AFTER_STEP_DBG               0         persistent samplers' diagnostics mask (2 no weight traffic, 8 / 16 pretend the census failed, 64 / 128 attention forms)
 //   AFTER_STEP_WARM              0,16,4    streaming sampler: sixteenths of the qkv / MLP-up / MLP-down weights warmed into the L2 by idle waves
@@ -3386,6 +3417,7 @@ struct Env {
     int attn_dbg = 0, row_groups = 0, graph = 0, fuse_tail = 1, x6 = -1, x6_minrows = -1;
     int stream_persist = -1, sample_persist = -1, sample_clip = -1, clip_minb = 0, seg_maxb = 0;
     int seg_h3 = -1, clip_h3 = -1, stream_h3 = -1, clip_fuse = -1, clip_stagger = 0, clip_gstag = 0, step_trace = 0, step_dbg = 0;
+    int clip_grouped = 1, clip_gdelay = 0;
     int warm[3] = {0, 16, 4};
 };
 Env env() {
@@ -3416,6 +3448,8 @@ Env env() {
         v.clip_fuse = geti("AFTER_CLIP_FUSE", -1);
         v.clip_stagger = geti("AFTER_CLIP_STAGGER", 0);
         v.clip_gstag = geti("AFTER_CLIP_GSTAG", 0);
+        v.clip_grouped = geti("AFTER_CLIP_GROUPED", 1);
+        v.clip_gdelay = geti("AFTER_CLIP_GDELAY", 0);
         v.step_trace = geti("AFTER_STEP_TRACE", 0);
         v.step_dbg = geti("AFTER_STEP_DBG", 0);
         if (const char* w = getenv("AFTER_STEP_WARM")) sscanf(w, "%d,%d,%d", &v.warm[0], &v.warm[1], &v.warm[2]);
@@ -4417,7 +4451,7 @@ int persist_prepare(after_denoiser* h, bool offline) {
         // the fused attention's hand-over rows and the qkv weights regrouped by head (+ 4.7 MB of planes per layer)
         float *halo = nullptr, *tmp = nullptr;
         unsigned short* w3h = nullptr;
-        const size_t nh = 8 * (rows / 192) * 8 * 2048, per = x6_elems(3 * (int)E, (int)E);
+        const size_t nh = 8 * (size_t)h->L * (rows / 192) * 8 * 2048, per = x6_elems(3 * (int)E, (int)E);  // (hand-over rows: per XCD, layer, tile)
         if (ok) {
             const Env ev = env();
             if (ev.clip_fuse != -1) h->clip_fuse = ev.clip_fuse != 0;
@@ -4756,6 +4790,7 @@ int sample_clip(after_denoiser* h, hipStream_t s, const float* x0, float* out, i
         a.dbg = ev.step_dbg | h->step_dbg;
         a.stagger = ev.clip_stagger;
         a.gstag = ev.clip_gstag;
+        a.gdelay = ev.clip_gdelay;
     }
     a.xt = h->xt;
     {
@@ -4767,6 +4802,8 @@ int sample_clip(after_denoiser* h, hipStream_t s, const float* x0, float* out, i
         a.halo = h->clip_halo;
         // a tile attends in place when a 16-row block sees its keys in itself and the 16 rows in front of it
         a.fuse = h->clip_fuse && !(a.dbg & 128) && h->W - 1 <= 16 && 16 % h->cs == 0 && h->H == 8;  // (diagnostics bit 7: the item form)
+        // row-tile groups: four 192-row tiles (T in (192, 256]), tiles that attend in place, no stagger experiment running
+        a.grouped = a.fuse && a.rows_pad == 4 * kClipRowTile && !(a.dbg & 1024) && a.gstag == 0 && env().clip_grouped != 0;
     }
     a.patch_wt = h->step_patch_wt, a.patch_b = h->patch_b, a.out_wt = h->step_out_wt, a.out_b = h->out_b;
     a.tc_ab = h->tc_ab, a.tc_ld = L * 2 * E, a.tcmap = h->maps + h->ms;

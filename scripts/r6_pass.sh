@@ -131,4 +131,9 @@ grp)  # row-tile groups of the batch kernel free-running inside a layer (8-way b
     python scripts/stream_step_trace.py --offline --clips 8 --xcd 3 2>/dev/null | grep -v amdgpu.ids | tee $O/clip_step_trace_grouped.txt | tail -22
     cp $O/default.so after_amd/lib/libafter_hip.so; rm $O/default.so
     ;;
+final2)  # final sources: the whole GPU suite, then every artefact of the round on the same lease
+    timeout 3400 python -m pytest tests -x -q -m gpu 2>&1 | tail -6 | tee $O/gpu_suite.txt
+    python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.txt
+    bash scripts/round_profiles.sh r6 > $O/round_profiles.log 2>&1
+    ;;
 esac
