@@ -136,4 +136,11 @@ final2)  # final sources: the whole GPU suite, then every artefact of the round 
     python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.txt
     bash scripts/round_profiles.sh r6 > $O/round_profiles.log 2>&1
     ;;
+kvwarm)  # streaming sampler: idle workgroups of the LayerNorm phase warm the layer's K / V ring rows (and n sixteenths of the qkv weights)
+    for rep in 1 2; do
+      for wm in "0,16,4" "1,16,4" "2,16,4" "4,16,4"; do
+        AFTER_STEP_WARM=$wm python bench.py --stream --steps 24 --warmup 4 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('AFTER_STEP_WARM=$wm:', d['ms_per_step'], 'ms per chunk')" | tee -a $O/kvwarm.txt
+      done
+    done
+    ;;
 esac
