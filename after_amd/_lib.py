@@ -137,6 +137,7 @@ SIGNATURES = {
     "after_convtm_set_tile": (None, [c_int]),
     "after_convtm_set_x6_tile": (None, [c_int]),
     "after_conv_x6_launches": (ctypes.c_longlong, []),
+    "after_conv_h3_launches": (ctypes.c_longlong, []),
     "after_conv1_act_launches": (ctypes.c_longlong, []),
     "after_gemm_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

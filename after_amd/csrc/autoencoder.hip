@@ -14,7 +14,11 @@
 #include <new>
 #include <vector>
 
+#include <cmath>
+#include <cstring>
+
 #include "conv.h"
+#include "gemm_h3_pipe.h"
 
 namespace after {
 namespace {
@@ -313,6 +317,8 @@ struct DmaConv {
     ConvTmPlan tplan;
     float* w = nullptr;
     unsigned short* w3 = nullptr;     // the same weights as bf16 planes (conv_x6.hip), where the layer has a bf16-pipe form
+    unsigned short* wh3 = nullptr;    // ... and as two fp16 pieces x ws (conv_h3_split: for inputs a GroupNorm bounds, gemm_h3_pipe.h)
+    float ws = 0.f;                   // the weights' power-of-two scale: max|w| x ws <= 2^15
     int toff_offline[kMaxTaps] = {};  // phase-0 taps of the offline plan while a cached (streaming) form is active
 };
 struct ConvBlockW {
@@ -320,6 +326,9 @@ struct ConvBlockW {
           *bias = nullptr;
     int cin = 0, cout = 0, k = 1, dil = 1;
     DmaConv d;
+    // bounds of the block's parameters (create time): |GroupNorm(x)_i| <= sqrt(n) gn_wmax + gn_bmax over a group of n elements, and
+    // |SnakeBeta(v)| <= |v| + invb_max -- what the power-of-two scale of the conv input's fp16 pieces is chosen from (run_dma)
+    float gn_wmax = 0.f, gn_bmax = 0.f, invb_max = 0.f;
     // CachedGroupNorm(stream=True): per-frame group sums of the previous gn_P frames (circular)
     float* gn_ring = nullptr;  // [max_batch][G][gn_P][2]
     int gn_P = 0;
@@ -389,6 +398,8 @@ struct after_ae {
     const float* prepared = nullptr;  // haloed input already laid out by the producer (time-major path)
     const float* next_alpha = nullptr;  // Snake of the following resampling conv: request to the next
     const float* next_invb = nullptr;   //   run_dma to emit that conv's activated input itself
+    const ConvBlockW* bound_of = nullptr;  // the ConvBlock1d whose GroupNorm -> Snake feeds the next run_dma: its parameter bounds
+    int h3_mode = 1;                    // AFTER_CONV_H3=0: GroupNorm-bounded convs of the bf16 pipe on three bf16 planes (A/B)
     size_t xp_elems = 0;
     double* stats_ring = nullptr; // [kStatSlots][stat_sub][max_batch][8][2][kStatBins] 64-bit words (conv.h: stat_bins)
     int stat_sub = 1;             // accumulator pairs per (clip, group): conv_tm_stat_sub() on the time-major path
@@ -462,6 +473,34 @@ struct WeightCursor {
         }                                                            \
     } while (0)
 
+// max |p[i]| of a device vector (create time: synchronous); NaN if anything is not finite
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ p, size_t n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float v = fabsf(p[i]);
+        bad = bad || !(v <= 3.0e38f);
+        m = fmaxf(m, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (__builtin_amdgcn_ballot_w64(bad)) m = __builtin_inff();
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));  // (non-negative floats order like their bit patterns)
+}
+float dev_absmax(const float* p, size_t n) {
+    unsigned* d = nullptr;
+    unsigned hv = 0x7fc00000u;  // NaN unless everything below succeeds
+    if (p && n && hipMalloc(&d, sizeof(unsigned)) == hipSuccess) {
+        if (hipMemset(d, 0, sizeof(unsigned)) == hipSuccess) {
+            hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0, nullptr, p, n, d);
+            if (hipGetLastError() != hipSuccess || hipMemcpy(&hv, d, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) hv = 0x7fc00000u;
+        }
+        (void)hipFree(d);
+    }
+    float v;
+    memcpy(&v, &hv, sizeof(float));
+    return v;
+}
+
 int copy_vec(after_ae* h, float** dst, const float* src, int n) {
     AE_TAKE(*dst, n);
     AFTER_HIP_CHECK(hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyDeviceToDevice));
@@ -500,6 +539,11 @@ int load_convblock(after_ae* h, WeightCursor& c, ConvBlockW& cb, int cin, int co
         AFTER_TRY(copy_vec(h, &cb.gn_b, gb, cin));
     }
     AFTER_TRY(load_snake(h, c, &cb.alpha, &cb.invb, cin));
+    if (h->norm) {
+        cb.gn_wmax = dev_absmax(cb.gn_w, (size_t)cin);
+        cb.gn_bmax = dev_absmax(cb.gn_b, (size_t)cin);
+        cb.invb_max = dev_absmax(cb.invb, (size_t)cin);
+    }
     return load_wnconv(h, c, &cb.w, &cb.bias, cout, cin, k);
 }
 
@@ -536,6 +580,15 @@ int make_dma(after_ae* h, DmaConv& d, const float* packed, int cin, int cout, in
         d.w3 = h->wd.take<unsigned short>(conv_x6_weight_elems(d.in, d.tplan));
         AFTER_REQUIRE(d.w3, AFTER_E_NOMEM, "autoencoder: conv weight arena exhausted");
         AFTER_TRY(conv_x6_split(d.w, d.w3, d.in, d.tplan, 0));
+        // the two-piece fp16 form of the same weights (used where a GroupNorm bounds the conv's input: run_dma)
+        const float wmax = dev_absmax(d.w, d.tplan.w_floats);
+        const float ws = h3_scale_for(wmax);
+        if (std::isfinite(wmax) && wmax * ws <= 32768.0f) {
+            d.wh3 = h->wd.take<unsigned short>(conv_h3_weight_elems(d.in, d.tplan));
+            AFTER_REQUIRE(d.wh3, AFTER_E_NOMEM, "autoencoder: conv weight arena exhausted");
+            AFTER_TRY(conv_h3_split(d.w, d.wh3, d.in, d.tplan, ws, 0));
+            d.ws = ws;
+        }
     }
     return AFTER_OK;
 }
@@ -555,6 +608,8 @@ int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const 
             bool want_stats, double** stats_out, float* state_base = nullptr, int x_cm = 0, int y_cm = 0,
             int stat_T = 0) {
     const int cin = d.in.Cin, cout = d.in.Cout;
+    const ConvBlockW* bw = h->bound_of;  // (consumed by this call, whatever path it takes)
+    h->bound_of = nullptr;
     float* state = nullptr;
     float* state_out = nullptr;
     if (h->pass_stream && state_base) {
@@ -617,14 +672,27 @@ int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const 
         return launch_conv1_act(c, s);
     }
     // MFMA-bound whole-clip launches run on the bf16 pipe (conv_x6.hip): their input is written as bf16 planes
-    const bool x6 = !xin && d.w3 && !h->pass_stream && !x_cm && conv_x6_wins(r, d.in, d.tplan) &&
+    // ... on TWO fp16 pieces per operand where a whole-clip GroupNorm bounds the activated input (gemm_h3_pipe.h): with n elements per
+    // (clip, group), |snake(GroupNorm(x))| <= sqrt(n) max|gamma| + max|beta| + max(1 / snake beta); the scale is the largest power of
+    // two that keeps that bound inside fp16's range -- exact, and the fp32 accumulators are scaled back in the conv's epilogue.
+    // (Snake-only inputs -- the resampling convs -- and the GroupNorm-free causal codec have no bound: they stay on three bf16 planes.)
+    float hs = 0.f;
+    if (!xin && d.wh3 && h->h3_mode && bw && stats_in && gamma && act == ACT_SNAKE && stat_T == 0 && !h->pass_gnwin && !h->pass_stream && !x_cm) {
+        const int G = cin < 8 ? cin : 8;
+        const float bound = sqrtf((float)(cin / G) * (float)Tin) * bw->gn_wmax + bw->gn_bmax + bw->invb_max;
+        const float sc = h3_scale_for(bound);
+        if (std::isfinite(bound) && bound * sc <= 32768.0f) hs = sc;
+    }
+    const bool x6 = !xin && d.w3 && !h->pass_stream && !x_cm && conv_x6_wins(r, d.in, d.tplan, hs != 0.f) &&
                     conv_x6_plane_elems(B, Tin, cin) <= h->xp3_elems;
+    if (!x6) hs = 0.f;
     if (!xin) {
         ActPadTm p;
         memset(&p, 0, sizeof(p));
         p.x = x;
         p.y = h->xp;
         p.y3 = x6 ? h->xp3 : nullptr;
+        p.hscale = hs;
         p.stats = stats_in;
         p.gamma = gamma;
         p.beta = beta;
@@ -650,7 +718,9 @@ int run_dma(after_ae* h, hipStream_t s, const DmaConv& d, const float* x, const 
                 cout, d.in.taps, d.in.phases, d.tplan.K, res != nullptr, r.stats != nullptr, r.y2 != nullptr, x6 ? "conv_x6" : "conv_tm");
     if (x6) {
         r.xp3 = h->xp3;
-        r.w3 = d.w3;
+        r.w3 = hs != 0.f ? d.wh3 : d.w3;
+        r.hscale = hs;
+        r.oscale = hs != 0.f ? 1.0f / (hs * d.ws) : 0.f;
         return launch_conv_x6(r, d.in, d.tplan, s);
     }
     return launch_conv_tm(r, d.in, d.tplan, s);
@@ -690,6 +760,7 @@ int run_convblock2(after_ae* h, hipStream_t s, const ConvBlockW& cb, const float
         return run_dma(h, s, cb.d, x, st, cb.gn_w, cb.gn_b, cb.alpha, cb.invb, ACT_SNAKE, cb.bias, res, y, B, T,
                        T, T, false, nullptr, sb, 0, 0, cb.gn_P + T);
     }
+    h->bound_of = h->norm ? &cb : nullptr;
     return run_dma(h, s, cb.d, x, h->norm ? stats_x : nullptr, cb.gn_w, cb.gn_b, cb.alpha, cb.invb,
                    ACT_SNAKE, cb.bias, res, y, B, T, T, T, want_stats, stats_y, sb);
 }
@@ -840,6 +911,10 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
     h->M = cfg->pqmf_bands;
     h->causal = cfg->causal != 0;
     h->norm = cfg->use_norm != 0;
+    {
+        const char* e = getenv("AFTER_CONV_H3");  // 0: the GroupNorm-bounded convs of the bf16 pipe stay on three bf16 planes (A/B switch)
+        h->h3_mode = e ? atoi(e) != 0 : 1;
+    }
     h->max_batch = max_batch;
     int ratio = h->M;
     for (int i = 0; i < cfg->n_stages; ++i) ratio *= cfg->factors[i];
@@ -1003,7 +1078,7 @@ extern "C" int after_ae_create(const after_ae_cfg* cfg, const float* const* weig
     // ---- per-conv geometry + GEMM-operand weights
     h->stat_sub = conv_tm_stat_sub();
     {
-        AE_TRY(h->wd.init((size_t)(wf * 2.0) * sizeof(float) + (size_t)(wf * 2.0) * 3 * sizeof(unsigned short) + (16 << 20)));
+        AE_TRY(h->wd.init((size_t)(wf * 2.0) * sizeof(float) + (size_t)(wf * 2.0) * (3 + 2) * sizeof(unsigned short) + (16 << 20)));
         const size_t Tm = h->max_samples / h->M;
         auto plan_conv = [&](DmaConv& d, const float* packed, int cin, int cout, int kk, int dil,
                              size_t T) -> int {

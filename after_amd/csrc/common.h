@@ -189,6 +189,9 @@ struct X6GemmArgs {
     unsigned long long* dbg = nullptr;
 };
 int gemm_x6_split(const float* W, int ldw, unsigned short* W3, int N, int K, hipStream_t s);
+// the same matrix x scale as TWO fp16 pieces in "h3 blocks" (gemm_h3_pipe.h: the x6 block layout with two planes; pad16(N) x 2 x K
+// unsigned shorts; scale: an exact power of two with max|W| x scale <= 2^15)
+int gemm_h3_split(const float* W, int ldw, unsigned short* W2, int N, int K, float scale, hipStream_t s);
 int gemm_x6_pick_tile(int M, int N, int K);
 int launch_gemm_x6(const X6GemmArgs& g, int tile, hipStream_t stream);
 

@@ -105,6 +105,9 @@ struct ConvTmRun {
     const float* w;    // conv_tm_repack output
     const unsigned short* xp3;  // launch_conv_x6: the same input as bf16 planes (ActPadTm::y3)
     const unsigned short* w3;   //                 conv_x6_split output
+    // the two-piece fp16 form of the same launch (gemm_h3_pipe.h; conv_x6.hip's SPLIT tiles): xp3 / w3 hold h3 blocks of the input x
+    // hs and of the weights x ws (conv_h3_split), hscale = hs (0: three bf16 planes), oscale = 1 / (hs x ws)
+    float hscale, oscale;
     const float* bias;
     const float* res;  // [B][Tout][Cout] time-major, or nullptr
     float* y;          // [B][Tout][Cout] time-major ([B][Cout][Tout] when y_cm)
@@ -132,6 +135,7 @@ struct ActPadTm {
     const float* x;       // [B][T][ldx] time-major ([B][C][T] when x_cm)
     float* y;             // [B][conv_tm_rows(T)][conv_tm_cp(C)]
     unsigned short* y3;   // instead of y: three bf16 planes in x6 blocks of [B x conv_x6_rows(T)][conv_tm_cp(C)] (conv_x6.hip)
+    float hscale;         // != 0 with y3: TWO fp16 pieces of y x hscale in h3 blocks instead (a power of two from a bound of y: gemm_h3_pipe.h)
     const double* stats;  // producer's accumulators ([sub][sub_stride], see ConvTmRun) -> GroupNorm, or nullptr
     const float* gamma;   // with stats: GroupNorm weight; without: per-channel scale (BatchNorm eval) or nullptr
     const float* beta;
@@ -178,7 +182,12 @@ size_t conv_x6_weight_elems(const ConvDmaPlanIn& in, const ConvTmPlan& p);
 bool conv_x6_eligible(const ConvDmaPlanIn& in, const ConvTmPlan& p);
 int conv_x6_split(const float* w_tm, unsigned short* w3, const ConvDmaPlanIn& in, const ConvTmPlan& p, hipStream_t s);
 int conv_x6_mode();  // AFTER_CONV_X6: 0 never, 1 by size (default), 2 wherever eligible
-bool conv_x6_wins(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan& p);
+// (h3: the launch can take the two-piece fp16 form -- its planes are no larger than the fp32 tensor, so every FILLED launch wins,
+//  whatever the width; the three-plane form only where it measured faster: the decoder's widths)
+bool conv_x6_wins(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan& p, bool h3 = false);
+// the weights of a conv_x6-eligible layer as two fp16 pieces x `scale` (h3 blocks per phase: conv_h3_weight_elems unsigned shorts)
+size_t conv_h3_weight_elems(const ConvDmaPlanIn& in, const ConvTmPlan& p);
+int conv_h3_split(const float* w_tm, unsigned short* w2, const ConvDmaPlanIn& in, const ConvTmPlan& p, float scale, hipStream_t s);
 int launch_conv_x6(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan& p, hipStream_t s);
 // sub_stride > 0: stats is a [conv_tm_stat_sub()][sub_stride] accumulator (ConvTmRun) and the blocks spread over its sub-slots
 int launch_stats_accum_tm(const float* x, double* stats, int B, int C, int T, int G, hipStream_t s, int ld = 0, int sub_stride = 0);

@@ -30,6 +30,7 @@
 
 #include "conv.h"
 #include "gemm_pipe.h"
+#include "gemm_h3_pipe.h"
 
 namespace after {
 namespace {
@@ -126,6 +127,7 @@ struct ActTmArgs {
     const float* x;       // [B][T][ldx] time-major, or [B][C][T] when x_cm
     float* y;             // [B][Tp][Cp]
     unsigned short* y3;   // instead of y: bf16 planes, x6 blocks of [B x rows16][Cp] (conv_x6.hip)
+    float hscale;         // != 0: two fp16 pieces of y x hscale in h3 blocks instead (gemm_h3_pipe.h)
     int rows16;
     const double* stats;  // [sub-slot][B][G][2][kStatBins] 64-bit words (conv.h: stat_bins) or nullptr
     const float* gamma;   // with stats: GroupNorm weight; without: per-channel scale (or nullptr)
@@ -381,6 +383,16 @@ __global__ __launch_bounds__(256) void act_pad_x6_kernel(ActTmArgs a, int nkb, i
             const float xv = v[u][k >> 2][k & 3];
             o[k] = (t >= 0 && t < a.T && c0 + k < a.C) ? act_apply(xv * sc[k] + sh[k], a.act, pa[k], pb[k]) : 0.f;
         }
+        if (a.hscale != 0.f) {  // (wave-uniform) two fp16 pieces, two planes per block
+            uint2 h0, l0, h1, l1;
+            const float hs = a.hscale;
+            h3_split4(o[0] * hs, o[1] * hs, o[2] * hs, o[3] * hs, h0, l0);
+            h3_split4(o[4] * hs, o[5] * hs, o[6] * hs, o[7] * hs, h1, l1);
+            unsigned short* bp = a.y3 + ((((size_t)b * nrb + rbI) * nkb + kb) * 2) * 512 + r * 32 + slot * 8;
+            *reinterpret_cast<uint4*>(bp) = uint4{h0.x, h0.y, h1.x, h1.y};
+            *reinterpret_cast<uint4*>(bp + 512) = uint4{l0.x, l0.y, l1.x, l1.y};
+            continue;
+        }
         uint2 h0, m0, l0, h1, m1, l1;
         x6_split4(o[0], o[1], o[2], o[3], h0, m0, l0);
         x6_split4(o[4], o[5], o[6], o[7], h1, m1, l1);
@@ -487,6 +499,16 @@ __global__ __launch_bounds__(256) void act_pad_x6_loop_kernel(ActTmArgs a, int n
             for (int k = 0; k < 8; ++k) {
                 const float xv = v[u][k >> 2][k & 3];
                 o[k] = (t >= 0 && t < a.T && c0 + k < a.C) ? act_apply(xv * sc[k] + sh[k], a.act, pa[k], pb[k]) : 0.f;
+            }
+            if (a.hscale != 0.f) {  // (wave-uniform) two fp16 pieces, two planes per block
+                uint2 h0, l0, h1, l1;
+                const float hs = a.hscale;
+                h3_split4(o[0] * hs, o[1] * hs, o[2] * hs, o[3] * hs, h0, l0);
+                h3_split4(o[4] * hs, o[5] * hs, o[6] * hs, o[7] * hs, h1, l1);
+                unsigned short* bp = a.y3 + ((((size_t)b * nrb + rbI) * nkb + kb) * 2) * 512 + r * 32 + slot * 8;
+                *reinterpret_cast<uint4*>(bp) = uint4{h0.x, h0.y, h1.x, h1.y};
+                *reinterpret_cast<uint4*>(bp + 512) = uint4{l0.x, l0.y, l1.x, l1.y};
+                continue;
             }
             uint2 h0, m0, l0, h1, m1, l1;
             x6_split4(o[0], o[1], o[2], o[3], h0, m0, l0);
@@ -1379,6 +1401,7 @@ int launch_act_pad_tm(const ActPadTm& p, hipStream_t s) {
     a.x = p.x;
     a.y = p.y;
     a.y3 = p.y3;
+    a.hscale = p.y3 ? p.hscale : 0.f;
     a.rows16 = conv_x6_rows(p.T);
     AFTER_REQUIRE(!p.y3 || !p.state, AFTER_E_INVALID, "act_pad_tm: plane output is for whole-clip passes");
     a.stats = p.stats;

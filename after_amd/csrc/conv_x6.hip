@@ -23,6 +23,7 @@
 
 #include "conv.h"
 #include "gemm_x6_pipe.h"
+#include "gemm_h3_pipe.h"
 
 namespace after {
 namespace {
@@ -41,6 +42,7 @@ struct ConvX6Args {
     int y_ld, y_coff, res_ld, res_coff;
     long long y_bs, res_bs;
     size_t w3_phase;            // elements between the phases of W3
+    float oscale;               // SPLIT tiles (two fp16 pieces per operand): 1 / (input scale x weight scale), an exact power of two
     int blk0[kMaxPhases];       // first 16-row block of tap 0, relative to the tile's own block
     int sh[kMaxPhases][3];      // row shift inside the first block, per tap
     int dblk[kMaxPhases][3];    // blocks between tap t's and tap 0's first block
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(64 * C::NW, C::WPS) void conv_x6_kernel(ConvX6Args 
     {
         int d[3];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) d[t] = (g.dblk[ph][t] - t) * g.cpb * 3072;
+        for (int t = 0; t < 3; ++t) d[t] = (g.dblk[ph][t] - t) * g.cpb * (C::NPL * 1024);
         c.doff[0] = __builtin_amdgcn_readfirstlane(d[0]);
         c.doff[1] = __builtin_amdgcn_readfirstlane(d[1] - d[0]);
         c.doff[2] = __builtin_amdgcn_readfirstlane(d[2] - d[1]);
@@ -115,13 +117,13 @@ __global__ __launch_bounds__(64 * C::NW, C::WPS) void conv_x6_kernel(ConvX6Args 
             if (q < C::GA) {
                 const int plane = q / C::AB, grp = q - plane * C::AB;
                 const int rb = min(ablk + grp, g.total_blocks - 1);  // past the tensor: a clamped block, rows unused
-                base = g.A3 + (((size_t)rb * g.cpb) * 3 + plane) * 512 + (size_t)kp * nk * 1536;
+                base = g.A3 + (((size_t)rb * g.cpb) * C::NPL + plane) * 512 + (size_t)kp * nk * (C::NPL * 512);
                 am = -1;
             } else {
                 const int qq = q - C::GA;
                 const int plane = qq / C::NBK, grp = qq - plane * C::NBK;
                 const int rb = min((n0 >> 4) + grp, (N - 1) >> 4);
-                base = w3 + (((size_t)rb * kbw + (size_t)kp * nk) * 3 + plane) * 512;
+                base = w3 + (((size_t)rb * kbw + (size_t)kp * nk) * C::NPL + plane) * 512;
                 am = 0;
             }
             c.kslab[i] = __builtin_amdgcn_readfirstlane(kp * nk);
@@ -239,6 +241,7 @@ __global__ __launch_bounds__(64 * C::NW, C::WPS) void conv_x6_kernel(ConvX6Args 
                 for (int q = 1; q < KS; ++q)
                     a4 += *reinterpret_cast<const f32x4*>(red + (((w0 + q) * MT * NT + i * NT + j) * 64 + lane) * 4);
             }
+            if constexpr (C::SPLIT) a4 = a4 * g.oscale;
             const f32x4 o = (a4 + bv) + rv[i][j];
             *reinterpret_cast<f32x4*>(yb + (size_t)trow * g.y_ld + gn) = o;
             ssum[j] += (o[0] + o[1]) + (o[2] + o[3]);
@@ -290,6 +293,13 @@ using CfgX6_128s3 = X6Cfg<8, 6, 1, 4, 2, 3, 0, 1, 0, 0, 1>; // 128 x 96 with a t
 using CfgX6_128w = X6Cfg<8, 8, 1, 4, 2, 2, 0, 1, 0, 0, 1>;   // 128 x 128: the encoder's widths (128 / 256 / 512 channels)
 using CfgX6_128w3 = X6Cfg<8, 8, 1, 4, 2, 3, 0, 1, 0, 0, 1>;  // the same with a three-stage ring (153 KB)
 using CfgX6_64k2 = X6Cfg<4, 6, 2, 1, 6, 2, 0, 1, 0, 0, 1>;  // 64 x 96, two k-parts, twelve waves: 256 workgroups for 4096 x 384
+// the same tiles on two-piece fp16 operands (SPLIT: stages of two thirds the size -- the two-stage rings become three-stage ones)
+using CfgH3_128 = X6Cfg<8, 6, 1, 4, 2, 3, 0, 1, 0, 0, 1, 0, 0, 1>;
+using CfgH3_192 = X6Cfg<12, 6, 1, 4, 2, 3, 0, 1, 0, 0, 1, 0, 0, 1>;
+using CfgH3_128n = X6Cfg<8, 4, 1, 4, 2, 3, 0, 1, 0, 0, 1, 0, 0, 1>;
+using CfgH3_96 = X6Cfg<6, 6, 1, 2, 2, 3, 0, 2, 0, 0, 1, 0, 0, 1>;
+using CfgH3_128w = X6Cfg<8, 8, 1, 4, 2, 3, 0, 1, 0, 0, 1, 0, 0, 1>;
+using CfgH3_64k2 = X6Cfg<4, 6, 2, 1, 6, 2, 0, 1, 0, 0, 1, 0, 0, 1>;
 
 template <class C>
 int launch_x6_cfg(const ConvX6Args& a, int B, hipStream_t s) {
@@ -317,6 +327,7 @@ int launch_x6_cfg(const ConvX6Args& a, int B, hipStream_t s) {
 
 int g_x6_force = -1;  // AFTER_CONV_X6: 0 = never, 1 = by size (default), 2 = wherever eligible
 long long g_x6_launches = 0;  // after_conv_x6_launches(): the tests check that the default path really takes this kernel
+long long g_h3_launches = 0;  // ... of them on two-piece fp16 operands
 int g_x6_tile = -1;   // AFTER_CONV_X6_TILE / after_convtm_set_x6_tile: 0 = by shape, 1 = 128 x 96, 2 = 192 x 96, 3 = 128 x 64
 
 }  // namespace
@@ -327,6 +338,14 @@ size_t conv_x6_weight_elems(const ConvDmaPlanIn& in, const ConvTmPlan& p) { retu
 
 bool conv_x6_eligible(const ConvDmaPlanIn& in, const ConvTmPlan& p) {
     return p.ok && in.istride == 1 && in.taps <= 3 && (in.Cout & 3) == 0 && in.phases <= kMaxPhases;
+}
+
+size_t conv_h3_weight_elems(const ConvDmaPlanIn& in, const ConvTmPlan& p) { return (size_t)in.phases * h3_elems(in.Cout, p.K); }
+
+int conv_h3_split(const float* w_tm, unsigned short* w2, const ConvDmaPlanIn& in, const ConvTmPlan& p, float scale, hipStream_t s) {
+    for (int ph = 0; ph < in.phases; ++ph)
+        AFTER_TRY(gemm_h3_split(w_tm + (size_t)ph * in.Cout * p.K, p.K, w2 + (size_t)ph * h3_elems(in.Cout, p.K), in.Cout, p.K, scale, s));
+    return AFTER_OK;
 }
 
 int conv_x6_split(const float* w_tm, unsigned short* w3, const ConvDmaPlanIn& in, const ConvTmPlan& p, hipStream_t s) {
@@ -344,13 +363,22 @@ int conv_x6_mode() {
 }
 
 // does this launch run on the bf16 pipe?  (the caller then hands act_pad_tm a plane buffer instead of the fp32 one)
-bool conv_x6_wins(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan& p) {
+bool conv_x6_wins(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan& p, bool h3) {
     const int mode = conv_x6_mode();
     if (mode == 0 || !conv_x6_eligible(in, p)) return false;
     if (r.y2 || r.y_cm || r.res_cm || r.post_scale || r.out_act || r.bias_bstride || r.x_ld || r.x_bs) return false;
     if (r.stats && (in.Cout % r.G || ((in.Cout / r.G) & 3) || r.G > 16)) return false;
     if ((r.y_ld & 3) || (r.y_coff & 3) || (r.res_ld & 3) || (r.res_coff & 3)) return false;
     if (mode >= 2) return true;
+    if (h3 && in.Cout % 96) {
+        // two fp16 pieces: the operand tensors are 4 bytes per element like the fp32 path's, and a product block is three MFMAs of 16
+        // cycles against eight of 32 -- the encoder's widths (64 / 128 / 256 / 512: the 128 x 128 and 128 x 64 tiles) win wherever the
+        // launch fills the chip (profiles/r6_ab_conv_h3_wide.txt: encode at 8 / 32 clips 4.46 -> 3.80 / 16.2 -> 13.2 ms; half-filled
+        // launches -- one clip -- lose: 1.12 -> 1.21)
+        if (in.Cout % 64) return false;
+        const int tn = (in.Cout & 127) == 0 ? 128 : 64;
+        return (double)cdiv(r.Nn, 128) * cdiv(in.Cout, tn) * r.B * in.phases >= 200 && p.K >= 192;
+    }
     // MFMA-bound launches only: enough 128 x 96 tiles to fill the chip, enough K for the ring to run
     const double wgs = (double)cdiv(r.Nn, 128) * cdiv(in.Cout, 96) * r.B * in.phases;
     // half-filled launches of the 128-row tile: the 64 x 96 tile with two k-parts wins the k = 3 convs (384 channels at
@@ -400,7 +428,9 @@ int launch_conv_x6(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan
     a.res_ld = r.res_ld > 0 ? r.res_ld : in.Cout;
     a.res_coff = r.res_coff;
     a.res_bs = r.res_bs > 0 ? r.res_bs : (long long)r.Tout * in.Cout;
-    a.w3_phase = x6_elems(in.Cout, p.K);
+    const bool h3 = r.hscale != 0.f;
+    a.w3_phase = h3 ? h3_elems(in.Cout, p.K) : x6_elems(in.Cout, p.K);
+    a.oscale = r.oscale;
     const int halo = conv_tm_halo();
     for (int ph = 0; ph < in.phases; ++ph) {
         const int s0 = halo + in.toff[ph][0];
@@ -442,6 +472,21 @@ int launch_conv_x6(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan
     }
     if (t == 6 && (p.K & 63)) t = 5;  // two k-parts need an even slab count
     ++g_x6_launches;
+    if (h3) {
+        ++g_h3_launches;
+        switch (t) {
+            case 1: return launch_x6_cfg<CfgH3_128>(a, r.B, s);
+            case 2: return launch_x6_cfg<CfgH3_192>(a, r.B, s);
+            case 3: return launch_x6_cfg<CfgH3_128n>(a, r.B, s);
+            case 4: return launch_x6_cfg<CfgH3_96>(a, r.B, s);
+            case 5: return launch_x6_cfg<CfgH3_128>(a, r.B, s);
+            case 6: return launch_x6_cfg<CfgH3_64k2>(a, r.B, s);
+            case 7: case 8: return launch_x6_cfg<CfgH3_128w>(a, r.B, s);
+            default: break;
+        }
+        set_error("conv_x6: no two-piece tile configuration %d", t);
+        return AFTER_E_INVALID;
+    }
     switch (t) {
         case 1: return launch_x6_cfg<CfgX6_128>(a, r.B, s);
         case 2: return launch_x6_cfg<CfgX6_192>(a, r.B, s);
@@ -461,3 +506,4 @@ int launch_conv_x6(const ConvTmRun& r, const ConvDmaPlanIn& in, const ConvTmPlan
 
 extern "C" void after_convtm_set_x6_tile(int id) { after::g_x6_tile = id; }
 extern "C" long long after_conv_x6_launches(void) { return after::g_x6_launches; }
+extern "C" long long after_conv_h3_launches(void) { return after::g_h3_launches; }

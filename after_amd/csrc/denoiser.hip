@@ -3316,18 +3316,6 @@ __global__ __launch_bounds__(256) void absmax_rows_kernel(const float* __restric
         atomicMax(out + 1, __float_as_uint(l1 * 1.0001f));  // (the sum's own rounding: the bound stays a bound)
     }
 }
-// W [N][K] (row stride ldw) x scale -> h3 blocks (gemm_h3_pipe.h: two fp16 pieces per element; rows padded to 16 with zeros)
-__global__ __launch_bounds__(256) void h3_split_kernel(const float* __restrict__ W, int ldw, unsigned short* __restrict__ out, int N, int K, float scale) {
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // four consecutive k of one row
-    const int k4 = K / 4;
-    const size_t rows = x6_rows_padded(N);
-    if (idx >= rows * k4) return;
-    const int r = (int)(idx / k4), k = 4 * (int)(idx % k4);
-    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (r < N) v = *reinterpret_cast<const f32x4*>(W + (size_t)r * ldw + k);
-    h3_store4(out, r, k, K, v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale);
-}
-
 __global__ __launch_bounds__(256) void tile16_kernel(const float* __restrict__ W, int ldw, float* __restrict__ out, int N, int K) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // one float4 of the output
     if (idx >= (size_t)N * K / 4) return;
@@ -4473,13 +4461,10 @@ int persist_prepare(after_denoiser* h, bool offline) {
                     const LayerW& w = h->layers[l];
                     unsigned short* base = wh3 + (pq + pu + pd) * l;
                     hipLaunchKernelGGL(qkv_by_head_kernel, dim3(3 * (unsigned)E), dim3(256), 0, nullptr, w.qkv_w, tmp, (int)E);
-                    hipLaunchKernelGGL(h3_split_kernel, dim3((unsigned)cdivll((long long)x6_rows_padded(3 * (int)E) * E / 4, 256)), dim3(256), 0, nullptr,
-                                       tmp, (int)E, base, 3 * (int)E, (int)E, h->h3_sw[l][0]);
-                    hipLaunchKernelGGL(h3_split_kernel, dim3((unsigned)cdivll((long long)x6_rows_padded((int)ME) * E / 4, 256)), dim3(256), 0, nullptr,
-                                       w.mlp0_w, (int)E, base + pq, (int)ME, (int)E, h->h3_sw[l][1]);
-                    hipLaunchKernelGGL(h3_split_kernel, dim3((unsigned)cdivll((long long)x6_rows_padded((int)E) * ME / 4, 256)), dim3(256), 0, nullptr,
-                                       w.mlp2_w, (int)ME, base + pq + pu, (int)E, (int)ME, h->h3_sw[l][2]);
-                    ok3 = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+                    ok3 = hipGetLastError() == hipSuccess && gemm_h3_split(tmp, (int)E, base, 3 * (int)E, (int)E, h->h3_sw[l][0], nullptr) == AFTER_OK &&
+                          gemm_h3_split(w.mlp0_w, (int)E, base + pq, (int)ME, (int)E, h->h3_sw[l][1], nullptr) == AFTER_OK &&
+                          gemm_h3_split(w.mlp2_w, (int)ME, base + pq + pu, (int)E, (int)ME, h->h3_sw[l][2], nullptr) == AFTER_OK &&
+                          hipDeviceSynchronize() == hipSuccess;
                 }
                 if (!ok3) {  // (not an error: the three-plane bf16 form serves the handle)
                     (void)hipGetLastError();

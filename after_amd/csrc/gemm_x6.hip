@@ -35,6 +35,7 @@
 #include "common.h"
 #include "gemm_pipe.h"
 #include "gemm_x6_pipe.h"
+#include "gemm_h3_pipe.h"
 
 namespace after {
 namespace {
@@ -853,6 +854,26 @@ constexpr X6TileInfo kX6Tiles[] = {{1, 48, 96, 2, 1},  {2, 48, 32, 4, 1},  {3, 9
                                    {11, 48, 96, 8, 1}, {12, 48, 32, 16, 1}, {15, 192, 96, 1, 1}};  // W-in-register tiles: ks = 4 x k-parts (nk % 4 == 0)
 
 }  // namespace
+
+namespace {
+// W [N][K] (row stride ldw) x scale -> h3 blocks (two fp16 pieces per element; rows padded to 16 with zeros)
+__global__ __launch_bounds__(256) void h3_split_kernel(const float* __restrict__ W, int ldw, unsigned short* __restrict__ out, int N, int K, float scale) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // four consecutive k of one row
+    const int k4 = K / 4;
+    const size_t rows = x6_rows_padded(N);
+    if (idx >= rows * k4) return;
+    const int r = (int)(idx / k4), k = 4 * (int)(idx % k4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < N) v = *reinterpret_cast<const float4*>(W + (size_t)r * ldw + k);
+    h3_store4(out, r, k, K, v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+}
+}  // namespace
+
+int gemm_h3_split(const float* W, int ldw, unsigned short* W2, int N, int K, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(h3_split_kernel, dim3((unsigned)cdivll((long long)x6_rows_padded(N) * K / 4, 256)), dim3(256), 0, s, W, ldw, W2, N, K, scale);
+    AFTER_HIP_CHECK(hipGetLastError());
+    return AFTER_OK;
+}
 
 int gemm_x6_split(const float* W, int ldw, unsigned short* W3, int N, int K, hipStream_t s) {
     hipLaunchKernelGGL(split3_kernel, dim3((unsigned)cdivll((long long)x6_rows_padded(N) * K, 256)), dim3(256), 0, s, W,

@@ -21,12 +21,15 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int swz4(int q) { return (0x78 >> (2 * q)) & 3; }
 
 template <int MB_, int NBK_, int KS_, int RS_, int CP_, int NS_, int OUT3_, int RES_, int ACC2_ = 0, int PERSIST_ = 0,
-          int CONV_ = 0, int SC1_ = 0, int TIER_ = 0>
+          int CONV_ = 0, int SC1_ = 0, int TIER_ = 0, int SPLIT_ = 0>
 struct X6Cfg {
     // TIER 1 (the opt-in bf16 tolerance tier of the batch sampler, after_denoiser_set_gemm_path(h, 3)): only the h x h product of
     // every block is issued -- bf16 operands (the top planes of the exact splits), fp32 accumulate
     static constexpr int TIER = TIER_;
-    static constexpr int SPLIT = 0, NPL = 3;  // three bf16 planes, six products (gemm_h3_pipe.h: SPLIT 1 = two fp16 pieces, three products)
+    // SPLIT 0: three bf16 planes per operand, six products per block.  SPLIT 1: TWO fp16 pieces per operand under a power-of-two
+    // scale, three products (gemm_h3_pipe.h says why and how exact; here: the every-wave-its-own-pieces ring x6_* below, for
+    // conv_x6.hip's GroupNorm-bounded convs -- the loader-wave rings x6l_* / x6r_* have their fp16 twins in gemm_h3_pipe.h)
+    static constexpr int SPLIT = SPLIT_, NPL = SPLIT_ ? 2 : 3, NPROD = SPLIT_ ? 3 : 6;
     // SC1: the DMA pieces are sc1 loads -- they miss the CU's vector L1 and are served by the XCD's L2: for operands that
     // another workgroup of the same XCD wrote earlier in the SAME kernel (the clip-per-XCD sampler of denoiser.hip)
     static constexpr int SC1 = SC1_;
@@ -45,7 +48,7 @@ struct X6Cfg {
     static constexpr int MT = MB / RS, NT = NBK / CP;   // 16x16 blocks per wave
     static constexpr int NW = KS * RS * CP;             // waves
     static constexpr int AB = MB + CONV;                 // 16-row A blocks per plane in a stage
-    static constexpr int GA = 3 * AB, GW = 3 * NBK;     // 1-KB pieces (16 rows of one plane) per k-part: A, W
+    static constexpr int GA = NPL * AB, GW = NPL * NBK; // 1-KB pieces (16 rows of one plane) per k-part: A, W
     static constexpr int PPK = GA + GW;
     static constexpr int PPKI = TIER ? AB + NBK : PPK;  // pieces a slab's loaders ISSUE (TIER 1: the h planes only; the stage keeps its layout)
     static constexpr int PART = PPK * 1024;             // bytes of one k-part of a stage
@@ -53,8 +56,8 @@ struct X6Cfg {
     static constexpr int P = KS * PPK;                  // pieces per stage
     static constexpr int LPS = (P + NW - 1) / NW;       // pieces per wave per slab (the last may be missing)
     static constexpr bool RAGGED = (P % NW) != 0;
-    static constexpr int NMMA = 6 * MT * NT;
-    static constexpr int NREAD = 3 * (MT + NT);
+    static constexpr int NMMA = NPROD * MT * NT;
+    static constexpr int NREAD = NPL * (MT + NT);
     static constexpr int NWORK = LPS + NREAD;
     static constexpr int WPS = (NW * RES + 3) / 4;      // waves per SIMD the register budget must allow
     static_assert(MB % RS == 0 && NBK % CP == 0, "tile shape");
@@ -66,7 +69,7 @@ struct X6Cfg {
 template <class C>
 struct X6State {
     f32x4 acc[C::ACC2 + 1][C::MT][C::NT];
-    u32x4 fa[2][3][C::MT], fw[2][3][C::NT];  // fragments of two consecutive slabs: [set][plane][block]
+    u32x4 fa[2][C::NPL][C::MT], fw[2][C::NPL][C::NT];  // fragments of two consecutive slabs: [set][plane][block]
     unsigned voff;                           // per-lane byte offset inside a DMA piece (lane x 16)
     unsigned long long sb[C::LPS];           // wave-uniform source address of each piece's x6 block, slab 0 of its k-part
     unsigned a_rd, w_rd;                     // per-lane LDS byte address of this wave's A / W fragments, stage 0
@@ -92,6 +95,9 @@ __device__ __forceinline__ int x6_tap(const X6State<C>& c, int slab) {
 // products in the order of increasing magnitude: (W plane, A plane), 0 = h, 1 = m, 2 = l
 constexpr int kWP[6] = {2, 0, 1, 1, 0, 0};
 constexpr int kAP[6] = {0, 2, 1, 0, 1, 0};
+// ... of the two-piece form (SPLIT 1): 0 = h, 1 = l
+constexpr int kWP3[3] = {0, 1, 0};
+constexpr int kAP3[3] = {1, 0, 0};
 
 // source address of DMA piece i of slab `slab`: consecutive K blocks of a row group are 3 KB apart; CONV: the A pieces
 // of tap t come from the row blocks doff[t] further on, their K block is the slab's channel block
@@ -101,9 +107,9 @@ __device__ __forceinline__ unsigned long long x6_src(const X6State<C>& c, int i,
         const int t = x6_tap<C>(c, slab + c.kslab[i]);
         // (sign masks instead of selects: the address must stay in scalar registers)
         const int d = (c.doff[0] + (c.doff[1] & ((0 - t) >> 31)) + (c.doff[2] & ((1 - t) >> 31))) & c.amask[i];
-        return c.sb[i] + (unsigned long long)(long long)(slab * 3072 + d);
+        return c.sb[i] + (unsigned long long)(long long)(slab * (C::NPL * 1024) + d);
     } else {
-        return c.sb[i] + (unsigned long long)((unsigned)slab * 3072u);
+        return c.sb[i] + (unsigned long long)((unsigned)slab * (unsigned)(C::NPL * 1024));
     }
 }
 
@@ -141,13 +147,13 @@ __device__ __forceinline__ void x6_side(X6State<C>& c, bool refill, bool more, i
     } else {
         constexpr int R = W - C::LPS;
         if (STEADY || more) {
-            if constexpr (R < 3 * C::MT) {
+            if constexpr (R < C::NPL * C::MT) {
                 constexpr int pl = R / C::MT, i = R % C::MT;
                 asm volatile("ds_read_b128 %0, %1 offset:%2"
                              : "=v"(c.fa[NXT][pl][i])
                              : "v"(a_next), "i"((pl * C::AB * 16 + i * 16) * 64));
             } else {
-                constexpr int R2 = R - 3 * C::MT;
+                constexpr int R2 = R - C::NPL * C::MT;
                 constexpr int pl = R2 / C::NT, j = R2 % C::NT;
                 asm volatile("ds_read_b128 %0, %1 offset:%2"
                              : "=v"(c.fw[NXT][pl][j])
@@ -174,7 +180,12 @@ __device__ __forceinline__ void x6_mma(X6State<C>& c, bool refill, bool more, in
         constexpr int p = S / (C::MT * C::NT), i = (S / C::NT) % C::MT, j = S % C::NT;
         // W fragment as srcA: the accumulator holds C^T (four consecutive columns of one row per lane)
         constexpr int AS = C::ACC2 ? CUR : 0;
-        if constexpr (!C::TIER || (kWP[p] == 0 && kAP[p] == 0))
+        if constexpr (C::SPLIT) {
+            typedef _Float16 hf16x8 __attribute__((ext_vector_type(8)));
+            c.acc[AS][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(hf16x8, c.fw[CUR][kWP3[p]][j]),
+                                                                     __builtin_bit_cast(hf16x8, c.fa[CUR][kAP3[p]][i]),
+                                                                     c.acc[AS][i][j], 0, 0, 0);
+        } else if constexpr (!C::TIER || (kWP[p] == 0 && kAP[p] == 0))
             c.acc[AS][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, c.fw[CUR][kWP[p]][j]),
                                                                       __builtin_bit_cast(bf16x8, c.fa[CUR][kAP[p]][i]),
                                                                       c.acc[AS][i][j], 0, 0, 0);
@@ -187,11 +198,11 @@ __device__ __forceinline__ void x6_mma(X6State<C>& c, bool refill, bool more, in
 
 template <class C, int SET, int I>
 __device__ __forceinline__ void x6_fence_regs(X6State<C>& c) {
-    if constexpr (I < 3 * C::MT) {
+    if constexpr (I < C::NPL * C::MT) {
         asm volatile("" : "+v"(c.fa[SET][I / C::MT][I % C::MT]));
         x6_fence_regs<C, SET, I + 1>(c);
-    } else if constexpr (I < 3 * (C::MT + C::NT)) {
-        constexpr int R = I - 3 * C::MT;
+    } else if constexpr (I < C::NPL * (C::MT + C::NT)) {
+        constexpr int R = I - C::NPL * C::MT;
         asm volatile("" : "+v"(c.fw[SET][R / C::NT][R % C::NT]));
         x6_fence_regs<C, SET, I + 1>(c);
     }
@@ -271,7 +282,7 @@ struct X6LState {
 // issue-order item W of a slab -> piece of the stage: the GW weight pieces first, then the GA activation pieces
 template <class C, int W>
 __device__ __forceinline__ void x6l_dma(const X6LState<C>& c, int slab, int stage) {
-    static_assert(C::KS == 1 && C::CONV == 0, "loader-wave ring: plain tiles without k-parts");
+    static_assert(C::KS == 1 && C::CONV == 0 && C::SPLIT == 0, "loader-wave ring: plain three-plane tiles without k-parts (fp16 twin: gemm_h3_pipe.h)");
     constexpr int GWI = C::TIER ? C::NBK : C::GW;  // (TIER 1: the issue-order list holds the h-plane pieces only)
     constexpr bool isW = W < GWI;
     constexpr int q = isW ? W : W - GWI;

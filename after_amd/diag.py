@@ -136,6 +136,11 @@ def set_conv_tile(tile_id: int):
     _lib.lib().after_convtm_set_tile(int(tile_id))
 
 
+def conv_h3_launches() -> int:
+    """... of them on two-piece fp16 operands (include/after_hip.h: after_conv_h3_launches)."""
+    return int(_lib.lib().after_conv_h3_launches())
+
+
 def conv_x6_launches() -> int:
     """Conv launches this process has sent down the bf16-pipe path (conv_x6.hip) so far."""
     return int(_lib.lib().after_conv_x6_launches())

@@ -548,6 +548,11 @@ void after_convtm_set_x6_tile(int id);
 /* number of conv launches this process has sent down the bf16-pipe path so far (diagnostic: the tests check that the
    decoder's MFMA-bound convs take it by default and that AFTER_CONV_X6=0 keeps them off it) */
 long long after_conv_x6_launches(void);
+/* ... of them on TWO fp16 pieces per operand (conv_x6.hip's SPLIT tiles, round 6): the launches whose input a whole-clip GroupNorm
+   bounds -- |snake(GroupNorm(x))| <= sqrt(n) max|gamma| + max|beta| + max(1 / snake beta) -- so that an exact power-of-two scale keeps
+   the pieces inside fp16's range (gemm_h3_pipe.h; three MFMAs per product block instead of six); AFTER_CONV_H3=0 keeps them on three
+   bf16 planes (A/B switch).  Snake-only inputs and the GroupNorm-free causal codec have no bound and stay on three planes. */
+long long after_conv_h3_launches(void);
 /* number of GroupNorm -> Snake -> Conv1d(k = 1) blocks (the second conv of a ResnetBlock1d, SimpleNetsStream.py:196-254) this
    process has run as ONE launch (conv_tm.hip: conv1_act_kernel -- no activated tensor in memory) instead of act_pad + conv;
    AFTER_AE_FUSE_K1=0 keeps them on the two launches (A/B switch) */

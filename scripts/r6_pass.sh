@@ -143,4 +143,31 @@ kvwarm)  # streaming sampler: idle workgroups of the LayerNorm phase warm the la
       done
     done
     ;;
+codech3)  # the codec's GroupNorm-bounded bf16-pipe convs on two fp16 pieces: parity (every codec test), same-box A/B, per-launch traces
+    timeout 2400 python -m pytest tests/test_autoencoder_gpu.py tests/test_conv_tm_gpu.py tests/test_baseline_size_gpu.py tests/test_dataset_embed_gpu.py tests/test_checkpoint.py tests/test_large_sizes_gpu.py -x -q 2>&1 | tail -6
+    for rep in 1 2; do
+      AFTER_CONV_H3=0 python scripts/time_codec.py --rounds 20 --batches 1,8,32 2>/dev/null | grep workload | sed "s/^/three bf16 planes: /" | tee -a $O/ab_conv_h3.txt
+      python scripts/time_codec.py --rounds 20 --batches 1,8,32 2>/dev/null | grep workload | sed "s/^/two fp16 pieces:   /" | tee -a $O/ab_conv_h3.txt
+    done
+    ;;
+codech3b)  # the rest of the codec tests; does the two-piece form pay on MORE layers (AFTER_CONV_X6=2: wherever eligible)?
+    timeout 2400 python -m pytest tests/test_baseline_size_gpu.py tests/test_dataset_embed_gpu.py tests/test_checkpoint.py tests/test_large_sizes_gpu.py tests/test_encoder_stream_gpu.py tests/test_streamer_gpu.py -x -q 2>&1 | tail -4
+    for rep in 1 2; do
+      python scripts/time_codec.py --rounds 20 --batches 1,2,8,32 2>/dev/null | grep workload | sed "s/^/by size (default):   /" | tee -a $O/ab_conv_h3_wide.txt
+      AFTER_CONV_X6=2 python scripts/time_codec.py --rounds 20 --batches 1,2,8,32 2>/dev/null | grep workload | sed "s/^/wherever eligible:   /" | tee -a $O/ab_conv_h3_wide.txt
+    done
+    AFTER_AE_TRACE=1 AFTER_CONV_X6=2 python scripts/time_codec.py --rounds 1 --batches 8 --only encode 2>&1 | grep "ae conv" | sort | uniq -c | sort -rn | head -40 | tee $O/encode_layers_x6_2.txt
+    ;;
+codech3c)  # the widened rule (filled launches of any width on two pieces): codec tests, codec timings, the bench line
+    timeout 2400 python -m pytest tests/test_autoencoder_gpu.py tests/test_baseline_size_gpu.py tests/test_dataset_embed_gpu.py tests/test_checkpoint.py tests/test_large_sizes_gpu.py -x -q 2>&1 | tail -4
+    for rep in 1 2; do
+      AFTER_CONV_H3=0 python scripts/time_codec.py --rounds 20 --batches 1,2,8,16,32 2>/dev/null | grep workload | sed "s/^/three bf16 planes: /" | tee -a $O/ab_conv_h3_final.txt
+      python scripts/time_codec.py --rounds 20 --batches 1,2,8,16,32 2>/dev/null | grep workload | sed "s/^/two fp16 pieces:   /" | tee -a $O/ab_conv_h3_final.txt
+    done
+    timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_b1.json 2> $O/bench_b1.err; echo "bench rc $?"
+    python -c "
+import json; d=json.load(open('$O/bench_b1.json')); print(d['ms_per_step'], d['value'], d['config']['sampler_path'])
+for k,v in d['legs'].items():
+    if isinstance(v,dict): print(k, v.get('ms_per_step'), v.get('value'), v.get('sampler_path'), (v.get('roofline') or {}).get('frac'), v.get('error'))"
+    ;;
 esac

@@ -54,11 +54,13 @@ def test_base_codec_full_clip_vs_oracle(base, hip_device):
     yw = oracle.ae_decode(sd, z, acfg)
     zw = oracle.ae_encode(sd, audio, acfg)
     from after_amd import diag
-    n0, m0 = diag.conv_x6_launches(), diag.conv1_act_launches()
+    n0, m0, k0 = diag.conv_x6_launches(), diag.conv1_act_launches(), diag.conv_h3_launches()
     y = ae.decode(z.to(hip_device)).cpu()
+    # ... and those behind a GroupNorm on two fp16 pieces per operand (round 6): the same oracle bar holds for THAT arithmetic
+    if os.environ.get("AFTER_CONV_X6", "1") != "0" and os.environ.get("AFTER_CONV_H3", "1") != "0":
+        assert diag.conv_h3_launches() - k0 >= 6, diag.conv_h3_launches() - k0
     # the decoder's MFMA-bound convs (384 / 192 channels at T >= 4096) run on the bf16 pipe by default (conv_x6.hip):
     # the oracle comparison below is a comparison of THAT path, not of a silent fallback to the fp32 kernel
-    import os
     if os.environ.get("AFTER_CONV_X6", "1") != "0":
         assert diag.conv_x6_launches() - n0 >= 8, diag.conv_x6_launches() - n0
     # ... and the GroupNorm -> Snake -> k = 1 convs of the last stage's ResnetBlock1ds as ONE launch each (conv1_act_kernel)
