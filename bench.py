@@ -767,16 +767,15 @@ def extra_legs(args, dev, head):
         try:
             leg = build_leg(a, dev, 1, 0, reuse=head if (a.config == args.config and not a.stream) else None)
             el, _ = time_leg(leg, warm, steps, 1, dev)
-            require_persistent(leg, a)
+            if expects_persistent(leg, a) and not leg.persistent():  # (the headline leg exits for this; a side leg says so and moves on)
+                raise RuntimeError(f"the sampler ran as '{leg.sampler_path()}', not on the persistent kernel this leg is quoted on")
             ms = el / steps * 1e3
             out[name] = {"what": what, "ms_per_step": round(ms, 3), "steps": steps, "warmup": warm,
                          "value": round(leg.n_clips * leg.unit_seconds / (ms * 1e-3), 2), "unit": "audio_s_per_wall_s",
                          "clips_per_s": None if a.stream else round(leg.n_clips / (ms * 1e-3), 2),
                          "sampler_path": leg.sampler_path(), "roofline": leg_roofline(leg), "workload": leg.workload}
             del leg
-        except SystemExit:
-            raise
-        except Exception as e:  # a leg must not take the headline line with it
+        except (Exception, SystemExit) as e:  # a leg must not take the headline line with it
             out[name] = {"what": what, "error": f"{type(e).__name__}: {e}"[:300]}
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
