@@ -21,12 +21,11 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-
          "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
-# The LDS-DMA pieces of gemm.hip / conv_tm.hip are inline asm that writes m0 (`s_mov_b32 m0`) without
-# being able to declare the clobber (hipcc rejects m0 in a clobber list).  That is safe with the
-# compiler this was validated on -- it never keeps a value in m0 across statements and re-materialises
-# it before each of its own uses -- and every tile configuration has a bit-exact regression test
-# (tests/test_gemm_gpu.py, tests/test_conv_tm_gpu.py).  A different hipcc must re-run those tests
-# before its build is trusted: the version is pinned here.
+# The kernels were tuned and validated with this hipcc: register budgets (scripts/kernel_regs.py: the persistent samplers sit
+# at 256 VGPRs with no spills in their default forms) and the bit-exact tile tests (tests/test_gemm_gpu.py,
+# tests/test_conv_tm_gpu.py).  Nothing in the sources depends on compiler internals any more -- rounds 1 - 5 wrote M0 in inline asm
+# for the LDS-DMA pieces, now `lds_dma16` (gemm_pipe.h) goes through __builtin_amdgcn_global_load_lds and the compiler owns M0 --
+# so a different hipcc only draws a note: re-run the tile tests and the register table before trusting its timings.
 TESTED_HIP = ("7.2", )
 
 
@@ -38,21 +37,17 @@ def _hipcc():
 
 
 def check_hipcc_version(hipcc):
-    """Raises unless hipcc is a validated version (override: AFTER_ALLOW_UNTESTED_HIPCC=1, then run
-    `pytest -m gpu tests/test_gemm_gpu.py tests/test_conv_tm_gpu.py` before trusting the library)."""
+    """The hipcc version string; a note on stderr when it is not one the kernels were tuned with."""
     out = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
     ver = ""
     for line in out.splitlines():
         if line.startswith("HIP version:"):
             ver = line.split(":", 1)[1].strip()
-    if any(ver.startswith(t + ".") or ver == t for t in TESTED_HIP):
-        return ver
-    if os.environ.get("AFTER_ALLOW_UNTESTED_HIPCC") == "1":
-        print(f"after_amd.build: hipcc {ver!r} is not a validated version {TESTED_HIP}: re-run the "
-              "bit-exact tile tests before trusting this build", file=sys.stderr)
-        return ver
-    raise RuntimeError(f"hipcc {ver!r} is not a validated version {TESTED_HIP} (inline-asm m0 writes, see "
-                       "after_amd/build.py); set AFTER_ALLOW_UNTESTED_HIPCC=1 and re-run the GPU tile tests")
+    if not any(ver.startswith(t + ".") or ver == t for t in TESTED_HIP):
+        print(f"after_amd.build: hipcc {ver!r} is not a version the kernels were tuned with {TESTED_HIP}: run "
+              "`pytest -m gpu tests/test_gemm_gpu.py tests/test_conv_tm_gpu.py` and scripts/kernel_regs.py on this build",
+              file=sys.stderr)
+    return ver
 
 
 def sources():

@@ -647,11 +647,8 @@ __global__ __launch_bounds__(128 * KS * RS) void conv_tm_kernel(ConvTmArgs g, in
         const int S__ = kb[w_] + (slab_);                                                            \
         int o__ = S__ * BK;                                                                          \
         if constexpr (DIL) o__ += ((S__ * magic) >> 16) * ex[w_];                                    \
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                 \
-                     :                                                                               \
-                     : "s"(lds0 + (unsigned)(((slot_) * STAGE + (wid * LPS + (w_)) * RPP * BK) * 4)), \
-                       "v"(voff[w_]), "s"(sbase[w_] + o__)                                           \
-                     : "memory"); /* m0: see gemm.hip (reserved, re-materialised by hipcc) */        \
+        lds_dma16(lds0 + (unsigned)(((slot_) * STAGE + (wid * LPS + (w_)) * RPP * BK) * 4), voff[w_],  \
+                  (unsigned long long)(uintptr_t)(sbase[w_] + o__)); /* (M0 is the compiler's: gemm_pipe.h) */ \
     }
 
     f32x4 acc[MT][NT];

@@ -514,17 +514,9 @@ __global__ __launch_bounds__(128 * KS * RS) void gemm_f32_bal_kernel(GemmArgs g,
         }
     }
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
-#define AFTER_BAL_DMA(w_, slab_, slot_)                                                          \
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                  \
-                 :                                                                                \
-                 : "s"(lds0 + (unsigned)(((slot_) * STAGE + (wid * LPS + (w_)) * RPP * BK) * 4)), \
-                   "v"(voff[w_]), "s"(sbase[w_] + (slab_) * BK)                                   \
-                 : "memory"); /* m0 is a reserved register: hipcc never keeps a value in it across \
-                                 statements (it rejects it in a clobber list), it re-materialises it \
-                                 before each of its own uses.  ASSUMPTION tied to the compiler: the    \
-                                 hipcc version is pinned in after_amd/build.py (TESTED_HIP) and every   \
-                                 tile configuration has a bit-exact test (tests/test_gemm_gpu.py) to    \
-                                 re-run after a toolchain change */
+#define AFTER_BAL_DMA(w_, slab_, slot_)                                                                         \
+    lds_dma16(lds0 + (unsigned)(((slot_) * STAGE + (wid * LPS + (w_)) * RPP * BK) * 4), voff[w_],                 \
+              (unsigned long long)(uintptr_t)(sbase[w_] + (slab_) * BK)); /* (M0 is the compiler's: gemm_pipe.h) */
 
     f32x4 acc[MT][NT];
 #pragma unroll

@@ -95,10 +95,7 @@ __device__ __forceinline__ void h3_dma(const S& c, int slab, int stage) {
     constexpr int piece = isW ? C::GA + q : q;
     const unsigned long long src = (isW ? c.w_src : c.a_src) + (unsigned long long)((unsigned)grp * c.rgs + (unsigned)plane * 1024u + (unsigned)slab * 2048u);
     const unsigned dst = c.lds0 + (unsigned)(stage * C::STAGE + piece * 1024);
-    if constexpr (C::SC1)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1" : : "s"(dst), "v"(c.voff), "s"(src) : "memory");
-    else
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(dst), "v"(c.voff), "s"(src) : "memory");
+    lds_dma16<C::SC1 ? 16 : 0>(dst, c.voff, src);
 }
 template <class C, int NL, int LID>
 struct H3Role {

@@ -8,6 +8,15 @@ namespace after {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+// One LDS-DMA piece (global_load_lds_dwordx4): every lane moves the 16 bytes at base + voff -- base wave-uniform (scalar registers:
+// the instruction's saddr), voff per lane -- to LDS address dst + lane x 16, dst wave-uniform (M0).  The builtin lets the COMPILER
+// write M0 (rounds 1 - 5 wrote it in inline asm, `s_mov_b32 m0`, which cannot declare the clobber: safe on the pinned hipcc only).
+// AUX: cache policy bits (16 = sc1: miss the vector L1, served by the XCD's L2).
+template <int AUX = 0>
+__device__ __forceinline__ void lds_dma16(unsigned dst, unsigned voff, unsigned long long base) {
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(reinterpret_cast<const char*>(base) + voff),
+                                     (lds_ptr_t)(__attribute__((address_space(3))) char*)(unsigned long)dst, 16, 0, AUX);
+}
 }  // namespace after
 
 // ---- the software pipeline of the DMA kernels as file-scope macros (hipcc rejects asm

@@ -552,11 +552,7 @@ struct X6WState {
 
 template <class C>
 __device__ __forceinline__ void x6w_dma_a(const X6WState<C>& c, int i, int slab, int stage) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                 :
-                 : "s"(c.lds0 + (unsigned)(stage * C::STAGE + (c.wid + C::NW * i) * 1024)), "v"(c.voff_a),
-                   "s"(c.sa[i] + (unsigned long long)((unsigned)slab * 3072u))
-                 : "memory");
+    lds_dma16(c.lds0 + (unsigned)(stage * C::STAGE + (c.wid + C::NW * i) * 1024), c.voff_a, c.sa[i] + (unsigned long long)((unsigned)slab * 3072u));
 }
 template <class C>
 __device__ __forceinline__ void x6w_issue_a(const X6WState<C>& c, int slab) {

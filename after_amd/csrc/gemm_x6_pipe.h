@@ -115,18 +115,7 @@ __device__ __forceinline__ unsigned long long x6_src(const X6State<C>& c, int i,
 
 template <class C>
 __device__ __forceinline__ void x6_dma(const X6State<C>& c, int i, int slab, int stage) {
-    if constexpr (C::SC1)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1"
-                     :
-                     : "s"(c.lds0 + (unsigned)(stage * C::STAGE + (c.wid + C::NW * i) * 1024)), "v"(c.voff),
-                       "s"(x6_src<C>(c, i, slab))
-                     : "memory");
-    else
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                     :
-                     : "s"(c.lds0 + (unsigned)(stage * C::STAGE + (c.wid + C::NW * i) * 1024)), "v"(c.voff),
-                       "s"(x6_src<C>(c, i, slab))
-                     : "memory");  // m0: reserved register, see gemm.hip (AFTER_BAL_DMA) and after_amd/build.py
+    lds_dma16<C::SC1 ? 16 : 0>(c.lds0 + (unsigned)(stage * C::STAGE + (c.wid + C::NW * i) * 1024), c.voff, x6_src<C>(c, i, slab));
 }
 
 template <class C>
@@ -290,10 +279,7 @@ __device__ __forceinline__ void x6l_dma(const X6LState<C>& c, int slab, int stag
     constexpr int piece = isW ? C::GA + q : q;  // position inside the stage (1-KB units)
     const unsigned long long src = (isW ? c.w_src : c.a_src) + (unsigned long long)((unsigned)grp * c.rgs + (unsigned)plane * 1024u + (unsigned)slab * 3072u);
     const unsigned dst = c.lds0 + (unsigned)(stage * C::STAGE + piece * 1024);
-    if constexpr (C::SC1)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1" : : "s"(dst), "v"(c.voff), "s"(src) : "memory");
-    else
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(dst), "v"(c.voff), "s"(src) : "memory");
+    lds_dma16<C::SC1 ? 16 : 0>(dst, c.voff, src);
 }
 
 // Roles: NL loader waves (waves 0 .. NL - 1: on different SIMDs) share a slab's pieces -- loader LID issues the issue-order
@@ -486,10 +472,7 @@ __device__ __forceinline__ void x6r_dma(const X6RState<C>& c, int slab, int stag
     constexpr int piece = isW ? C::GA + q : q;
     const unsigned long long src = (isW ? c.w_src : c.a_src) + (unsigned long long)((unsigned)grp * c.rgs + (unsigned)plane * 1024u + (unsigned)slab * 3072u);
     const unsigned dst = c.lds0 + (unsigned)(stage * C::STAGE + piece * 1024);
-    if constexpr (C::SC1)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1" : : "s"(dst), "v"(c.voff), "s"(src) : "memory");
-    else
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(dst), "v"(c.voff), "s"(src) : "memory");
+    lds_dma16<C::SC1 ? 16 : 0>(dst, c.voff, src);
 }
 template <class C, int NL, int LID, int W = 0>
 __device__ __forceinline__ void x6r_issue_mine(const X6RState<C>& c, int slab, int stage) {

@@ -131,6 +131,21 @@ grp)  # row-tile groups of the batch kernel free-running inside a layer (8-way b
     python scripts/stream_step_trace.py --offline --clips 8 --xcd 3 2>/dev/null | grep -v amdgpu.ids | tee $O/clip_step_trace_grouped.txt | tail -22
     cp $O/default.so after_amd/lib/libafter_hip.so; rm $O/default.so
     ;;
+m0)  # the LDS-DMA sites through __builtin_amdgcn_global_load_lds (compiler-managed M0) instead of inline asm: parity, same-box A/B
+    timeout 2400 python -m pytest tests/test_gemm_gpu.py tests/test_conv_tm_gpu.py tests/test_sample_clip_gpu.py tests/test_sample_persist_gpu.py tests/test_autoencoder_gpu.py tests/test_stream_persist_gpu.py -x -q 2>&1 | tail -6 | tee $O/tests.txt
+    cp after_amd/lib/libafter_hip.so $O/builtin.so
+    for rep in 1 2; do
+      for v in builtin asm; do
+        if [ $v = asm ]; then cp scripts/variants/m0asm/libafter_hip.so after_amd/lib/libafter_hip.so; else cp $O/builtin.so after_amd/lib/libafter_hip.so; fi
+        for cfg in "base 1 7" "base 8 3" "tiny 1 7"; do set -- $cfg
+          python scripts/time_sampler.py $1 $2 50 $3 2>/dev/null | tail -1 | cut -c1-100 | sed "s/^/$v $1 $2: /" | tee -a $O/ab.txt
+        done
+        timeout 600 python scripts/time_codec.py --rounds 20 --batches 1,8 2>/dev/null | grep workload | cut -c1-200 | sed "s/^/$v codec: /" | tee -a $O/ab.txt
+      done
+    done
+    cp $O/builtin.so after_amd/lib/libafter_hip.so; rm -f $O/builtin.so
+    timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -5 | tee $O/gpu_suite.txt
+    ;;
 final2)  # final sources: the whole GPU suite, then every artefact of the round on the same lease
     timeout 3400 python -m pytest tests -x -q -m gpu 2>&1 | tail -6 | tee $O/gpu_suite.txt
     python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.txt
