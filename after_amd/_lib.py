@@ -76,6 +76,7 @@ SIGNATURES = {
     "after_denoiser_set_sample_persist": (c_int, [c_void_p, c_int]),
     "after_denoiser_sample_persist": (c_int, [c_void_p, POINTER(c_int)]),
     "after_denoiser_sample_arith": (c_int, [c_void_p, POINTER(c_int)]),
+    "after_denoiser_sample_launches": (c_int, [c_void_p, POINTER(c_int)]),
     "after_denoiser_step_trace": (c_int, [c_void_p, c_void_p, c_int]),
     "after_denoiser_set_step_trace": (c_int, [c_void_p, c_int]),
     "after_denoiser_set_persist_check": (c_int, [c_void_p, c_int]),

@@ -707,7 +707,7 @@ constexpr int kSKBD = kSME / 16 / kSCW;  // MLP-down k-blocks per compute wave
 __host__ __device__ constexpr int kSRedFloats(int MB) { return (MB * 3 * 256 * kSCW > 7168 ? MB * 3 * 256 * kSCW : 7168) + 1024; }
 constexpr int kSWF = 12;            // weight fragments of a compute wave: max(3 x kSKBQ, kSNTU x kSKBQ, kSKBD)
 static_assert(3 * kSKBQ <= kSWF && kSNTU * kSKBQ <= kSWF && kSKBD <= kSWF && kSKBD % 4 == 0 && kSKBQ % 4 == 0, "weight fragment budget");
-constexpr int kSGroupRows = 96;                 // token rows one XCD can own (offline segment sampler: 3 CFG rows x 32 frames)
+constexpr int kSGroupRows = 192;                // token rows one XCD can own (offline segment sampler: two clips x 3 CFG rows x 32 frames)
 
 struct StepSync {
     unsigned arrive[8][32];  // [xcc][0]: arrivals (each word on its own 128-byte line)
@@ -744,7 +744,10 @@ struct StepKV {
 struct StepArgs {
     int rows, B, T, C, Cp, L, cs, W, nkmax, cache, cache_rows, cpg, dbg;
     int Tseg, nseg;           // offline segment sampler: frames per XCD (16 or 32), XCDs at work (T / Tseg <= 8)
-    int clip;                 // ... the clip of the call's B this launch samples (conditioning rows br * B + clip; x0 / xout / xt offset by the host)
+    int clip;                 // ... the (first) clip of the call's B this launch samples (conditioning rows CFG row * B + clip; x0 / xout / xt
+                              //     offset by the host)
+    int nclip;                // ... clips of this launch: 1, or 2 at Tseg == 16 -- an XCD then owns frames [g Tseg, (g + 1) Tseg) of BOTH clips'
+                              //     three CFG rows, local rows (clip, CFG row, frame): the 96 rows of one clip at T = 256, the weights read once
     int nsteps, cache_steps;  // Euler steps of this launch (ALL of a sample() call); ring slots per layer
     unsigned flip[4];         // bit i: which half of step i's K / V rings is current
     int warm[3];  // sixteenths of the qkv / MLP-up / MLP-down weights warmed into the L2 by idle waves (AFTER_STEP_WARM)
@@ -1888,8 +1891,9 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
     const int nseg = a.nseg;
     if (g >= nseg) return;  // (a clip of fewer than eight segments: nothing in the kernel crosses to or from this XCD)
 
-    // this XCD's frames [f0, f0 + Tseg) of the three CFG rows: local token rows lm = branch * Tseg + (frame - f0)
-    const int T = a.T, Tseg = a.Tseg, f0 = g * Tseg, Mg = 3 * Tseg;
+    // this XCD's frames [f0, f0 + Tseg) of the three CFG rows of the launch's clip(s): local token rows lm = branch * Tseg + (frame - f0),
+    // branch = 3 x clip of the launch + CFG row
+    const int T = a.T, Tseg = a.Tseg, f0 = g * Tseg, NC = a.nclip, Mg = 3 * NC * Tseg;
     float* const pat = a.pat_t + (size_t)g * kSGroupRows * E;
     float* const xres = a.xres_t + (size_t)g * kSGroupRows * E;
     const __amdgpu_buffer_rsrc_t pat_r = step_rsrc(pat), xres_r = step_rsrc(xres);
@@ -1922,13 +1926,14 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
     };
     const float* ln_ab0 = a.tc_ab;  // this wave's tcond AdaLN row (layer 0)
     if (ln_mine) {
-        const int br = ln_lm / Tseg, tl = ln_lm - br * Tseg;
-        ln_ab0 += ((size_t)a.tcmap[br * a.B + a.clip] * T + f0 + tl) * a.tc_ld;
+        const int br = ln_lm / Tseg, tl = ln_lm - br * Tseg, cl = br / 3;
+        ln_ab0 += ((size_t)a.tcmap[(br - 3 * cl) * a.B + a.clip + cl] * T + f0 + tl) * a.tc_ld;
     }
     auto ln_prefetch = [&](int l) {
         if (ln_mine) row_warm(ln_ab0 + (size_t)l * 2 * E, a.layer[l].n1w, a.layer[l].n1b);
     };
-    const int cps = Tseg / a.cs, nitems = 3 * cps;  // attention items: (CFG row, chunk of the segment)
+    const int cps = Tseg / a.cs, nitems = 3 * NC * cps;  // attention items: (branch, chunk of the segment)
+    auto cond_row = [&](int br) { return (br % 3) * a.B + a.clip + br / 3; };  // AdaLN(cond) row of a branch
 
     for (int i = 0; i < a.nsteps; ++i) {  // ---- the Euler steps of RectifiedFlow.sample (model.py:770-785)
         const float* cond_ab = a.cond_ab + (size_t)i * a.cond_step;
@@ -1936,14 +1941,15 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
         asm volatile("" : "+v"(lane_i));  // (opaque: per-lane addresses are recomputed here -- hoisted out of the loops they are
         const int lane = lane_i;         //  kernel-lifetime 64-bit register pairs, and the allocator spills them into the MFMA loops)
         auto attn_prefetch = [&](int l, int it) {  // (wave 0: one touch per workgroup)
-            if (w == 0) row_warm(cond_ab + (size_t)((it / cps) * a.B + a.clip) * a.cond_ld + (size_t)l * 2 * E, a.layer[l].n3w, a.layer[l].n3b);
+            if (w == 0) row_warm(cond_ab + (size_t)cond_row(it / cps) * a.cond_ld + (size_t)l * 2 * E, a.layer[l].n3w, a.layer[l].n3b);
         };
         tslot = 0;
         if (trace && tid == 0) {
             trace[0] = wall_clock64();
             trace[70] = __builtin_readcyclecounter();  // shader clock (s_memtime): effective clock = cycles / wall time
         }
-        // ---- patchify_and_embed for the segment's Tseg frames (shared by the three CFG rows): fp32 MFMA, K = Cp
+        // ---- patchify_and_embed for the segment's Tseg frames of every clip (shared by a clip's three CFG rows; rows (clip, frame)):
+        //      fp32 MFMA, K = Cp
         {
             const int kbp = a.Cp / 16;
             f32x4 acc[MBP];
@@ -1955,8 +1961,10 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 const f32x4 wv = wact ? *reinterpret_cast<const f32x4*>(a.patch_wt + ((size_t)(rank * kbp + w) << 8) + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
                 f32x4 av[MBP];
 #pragma unroll
-                for (int ib = 0; ib < MBP; ++ib)
-                    av[ib] = ld_l2(xt_r, (unsigned)((f0 + min(16 * ib + (lane & 15), Tseg - 1)) * a.Cp + 16 * w + 4 * (lane >> 4)));
+                for (int ib = 0; ib < MBP; ++ib) {
+                    const int pr = min(16 * ib + (lane & 15), NC * Tseg - 1), pc = pr / Tseg;
+                    av[ib] = ld_l2(xt_r, (unsigned)((pc * T + f0 + pr - pc * Tseg) * a.Cp + 16 * w + 4 * (lane >> 4)));
+                }
                 ln_prefetch(0);
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
@@ -1986,7 +1994,8 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 StepLnOpsT<E> lnops;
                 step_ln_ops(lnops, ln_ab0 + (size_t)l * 2 * E, Lw.n1w, Lw.n1b, lane);
                 lnops.hs = Lw.s_h1;
-                step_ln_row<PLN, E>(l == 0 ? pat_r : xres_r, l == 0 ? ln_lm % Tseg : ln_lm, xres, reinterpret_cast<float*>(hb3), ln_lm, lnops, lane);
+                step_ln_row<PLN, E>(l == 0 ? pat_r : xres_r, l == 0 ? ln_lm / (3 * Tseg) * Tseg + ln_lm % Tseg : ln_lm, xres,
+                                    reinterpret_cast<float*>(hb3), ln_lm, lnops, lane);
             }
             // (the reverse hazard -- the next XCD must have read this layer's keys of the PREVIOUS step before the qkv phase below
             //  overwrites the segment's last frames -- is checked one layer early, by a workgroup without an attention item during
@@ -2006,7 +2015,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
             const bool gact = WGH == 1 || h0 < NH;         // (qkv / MLP-up: this workgroup has tiles -- a constant but for E = 256 at 48 rows)
             const int rh = w / KS + h0, ks = w % KS;
             constexpr int NTD = NH * KBE >= 32 ? NH * KBE / 32 : 1, KD = KBM / 16;
-            const int rb0d = NH == 2 ? 3 * (rank & 1) : 0, tile0d = NH == 2 ? NTD * (rank >> 1) : rank;
+            const int rb0d = NH >= 2 ? 3 * (rank % NH) : 0, tile0d = NH >= 2 ? NTD * (rank / NH) : rank;
             const bool dact = NH * KBE >= 32 || tile0d < KBE;  // (MLP-down: this workgroup has tiles -- the same)
             SegBuf<3, 3> sbq;
             {
@@ -2018,13 +2027,14 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 // RoPE (rotary_embedding.py:132-173: interleaved pairs, the first 32 dims of every head) on the q and k tiles this
                 // wave finishes -- column tiles rank (q) and rank + 32 (k) with rank % 4 < 2 -- at the rows' absolute frames: the cos /
                 // sin pairs are requested behind the last operand requests of the MFMA loop and land long before the epilogue
-                float2 rcs[3][2];
+                constexpr int NQ = (9 * NHW + 7) / 8;  // tiles a wave finishes (3 column tiles x 3 row blocks per row half)
+                float2 rcs[NQ][2];
                 const bool roped = (ct & 3) < 2;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) rcs[q][0] = make_float2(1.f, 1.f), rcs[q][1] = make_float2(0.f, 0.f);
+                for (int q = 0; q < NQ; ++q) rcs[q][0] = make_float2(1.f, 1.f), rcs[q][1] = make_float2(0.f, 0.f);
                 auto rope_req = [&] {
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) {
+                    for (int q = 0; q < NQ; ++q) {
                         const int p = w + 8 * q, hh = p / 9, pp = p - 9 * hh;
                         const int lm = min(16 * (3 * (hh + h0) + pp % 3) + (lane & 15), Mg - 1), tl = lm % Tseg;
                         if (roped && gact && p < 9 * NHW && pp / 3 < 2) {
@@ -2062,21 +2072,21 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 // (wave w finishes tiles w, w + 8, w + 16: every partial is requested before the first sum -- in a loop over p each
                 //  tile paid its own LDS round trip in front of its store)
-                f32x4 os[3];
+                f32x4 os[NQ];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
+                for (int q = 0; q < NQ; ++q) {
                     const int p = w + 8 * q, hh = p / 9, pp = p - 9 * hh;
                     os[q] = p < 9 * NHW ? seg_sum<KS>(red + (size_t)hh * KS * 9 * 256, 9, pp, lane) : f32x4{0.f, 0.f, 0.f, 0.f};
                     if constexpr (H3) os[q] = os[q] * Lw.o_qkv;  // (an exact power of two)
                 }
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {  // (unconditional: tiles without RoPE carry cos = 1, sin = 0 -- no branch between the sums and the stores)
+                for (int q = 0; q < NQ; ++q) {  // (unconditional: tiles without RoPE carry cos = 1, sin = 0 -- no branch between the sums and the stores)
                     const float2 c = rcs[q][0], sn = rcs[q][1];
                     const f32x4 x = os[q];
                     os[q] = f32x4{x[0] * c.x - x[1] * sn.x, x[1] * c.x + x[0] * sn.x, x[2] * c.y - x[3] * sn.y, x[3] * c.y + x[2] * sn.y};
                 }
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
+                for (int q = 0; q < NQ; ++q) {
                     const int p = w + 8 * q, hh = p / 9, pp = p - 9 * hh, j = pp / 3;
                     const int lm = 16 * (3 * (hh + h0) + pp % 3) + (lane & 15), br = lm / Tseg, tl = lm - br * Tseg;
                     if (gact && p < 9 * NHW && lm < Mg)
@@ -2101,7 +2111,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                     __syncthreads();
                     if (!s_ok) return;
                 }
-                seg_attention<E, PLN>(StepAttn{T, a.cs, a.W, 0, a.nkmax, a.rope_cos, a.rope_sin, Lw.qkv, Lw.s_h3}, cond_ab + (size_t)(br * a.B + a.clip) * a.cond_ld + (size_t)l * 2 * E,
+                seg_attention<E, PLN>(StepAttn{T, a.cs, a.W, 0, a.nkmax, a.rope_cos, a.rope_sin, Lw.qkv, Lw.s_h3}, cond_ab + (size_t)cond_row(br) * a.cond_ld + (size_t)l * 2 * E,
                               Lw.n3w, Lw.n3b, br, br * Tseg - f0, i0f / a.cs, halo, smem, kvl, xres, reinterpret_cast<float*>(hb3), trace);
             }
             constexpr int NTU = KBM / TPW;  // MLP-up column tiles of a workgroup (3: the hidden layer is 3 E wide)
@@ -2115,10 +2125,11 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                     seg_load_a<3, NTU, NPL>(sbu, 0, hb3_r, E / 32, 3 * rh, KQ * ks, lane);
                     seg_load_w<3, NTU>(sbu, 0, Wu, KBE, ct, TPW, KQ * ks, lane);
                 }
-                // (epilogue operands before the GEMM: wave w finishes tiles p = w, w + 8, w + 16)
-                f32x4 bvs[3];
+                // (epilogue operands before the GEMM: wave w finishes tiles p = w, w + 8, w + 16 ..)
+                constexpr int NQ = (3 * NTU * NHW + 7) / 8;
+                f32x4 bvs[NQ];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
+                for (int q = 0; q < NQ; ++q) {
                     const int p = w + 8 * q, pp = p % (3 * NTU);
                     bvs[q] = gact && p < 3 * NTU * NHW ? *reinterpret_cast<const f32x4*>(Lw.mlp0_b + 16 * (ct + TPW * (pp / 3)) + 4 * (lane >> 4))
                                                        : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -2131,7 +2142,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 }
                 seg_partials<3 * NTU>(acc, red, w, lane);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
+                for (int q = 0; q < NQ; ++q) {
                     const int p = w + 8 * q;
                     if (p >= 3 * NTU * NHW || !gact) break;
                     const int hh = p / (3 * NTU), pp = p - 3 * NTU * hh, j = pp / 3, ib = pp - 3 * j, tile = ct + TPW * j;
@@ -2152,19 +2163,24 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 const __amdgpu_buffer_rsrc_t Wd = step_rsrc(H3 ? Lww.mlp2_ht : Lww.mlp2_wt);
                 if (!end_phase(true)) return;
                 // ---- MLP down + residual
-                f32x4 acc[3 * NTD], bv[1], rv[1];
+                constexpr int NQD = (3 * NTD + 7) / 8;  // tiles a wave finishes
+                f32x4 acc[3 * NTD], bv[NQD], rv[NQD];
                 if (dact) {
                     seg_load_a<3, NTD, NPL>(sbd, 0, mlp3_r, ME / 32, rb0d, KD * w, lane);
                     seg_load_w<3, NTD>(sbd, 0, Wd, KBM, tile0d, 1, KD * w, lane);
                 }
-                // (wave w < 3 NTD finishes column tile w / 3, row block w % 3: one exchange of all partials, six finishing waves at
+                // (tile p = w + 8 q < 3 NTD is column tile p / 3, row block p % 3: one exchange of all partials, six finishing waves at
                 //  96 rows -- not a round of the exchange per column tile with three)
-                const int jd = w / 3, id = w - 3 * jd;
-                const unsigned offd = (unsigned)((((rb0d + id) * KBE + tile0d + jd) << 8) + lane * 4);
-                bv[0] = rv[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (w < 3 * NTD && dact) {
-                    bv[0] = *reinterpret_cast<const f32x4*>(Lw.mlp2_b + 16 * (tile0d + jd) + 4 * (lane >> 4));
-                    rv[0] = ld_l2(xres_r, offd);
+                unsigned offd[NQD];
+#pragma unroll
+                for (int q = 0; q < NQD; ++q) {
+                    const int pd = w + 8 * q, jd = pd / 3, id = pd - 3 * jd;
+                    offd[q] = (unsigned)((((rb0d + id) * KBE + tile0d + jd) << 8) + lane * 4);
+                    bv[q] = rv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (pd < 3 * NTD && dact) {
+                        bv[q] = *reinterpret_cast<const f32x4*>(Lw.mlp2_b + 16 * (tile0d + jd) + 4 * (lane >> 4));
+                        rv[q] = ld_l2(xres_r, offd[q]);
+                    }
                 }
                 auto down_next = [&] { if (l + 1 < a.L) ln_prefetch(l + 1); };
                 if (dact) {
@@ -2175,39 +2191,43 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                     down_next();
                 }
                 seg_partials<3 * NTD>(acc, red, w, lane);
-                if (w < 3 * NTD && dact) {
-                    f32x4 o = seg_sum<8>(red, 3 * NTD, w, lane);  // (acc index = column tile x 3 + row block = w)
+#pragma unroll
+                for (int q = 0; q < NQD; ++q) {
+                    const int pd = w + 8 * q;
+                    if (pd >= 3 * NTD || !dact) break;
+                    f32x4 o = seg_sum<8>(red, 3 * NTD, pd, lane);  // (acc index = column tile x 3 + row block = pd)
                     if constexpr (H3) o = o * Lw.o_dn;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = o[r] + bv[0][r] + rv[0][r];
-                    *reinterpret_cast<f32x4*>(xres + offd) = o;
+                    for (int r = 0; r < 4; ++r) o[r] = o[r] + bv[q][r] + rv[q][r];
+                    *reinterpret_cast<f32x4*>(xres + offd[q]) = o;
                 }
             }
             if (!end_phase(w < 3 * NTD)) return;
         }
         // ---- out_proj + CFG + Euler (+ the token-major latents of the next step), fp32 MFMA: workgroup (column tile,
-        //      16-frame block) owns the three CFG rows of its frames
-        if (rank < (a.C / 16) * MBP) {
+        //      16-frame block of a clip) owns the three CFG rows of its frames (row blocks 3 TB clip + block + TB r, TB = Tseg / 16)
+        if (rank < (a.C / 16) * NC * (Tseg / 16)) {
             const int tile = rank % (a.C / 16), fb = rank / (a.C / 16);
+            const int TB = Tseg / 16, cl = fb / TB, fbl = fb - cl * TB, tb = 16 * fbl;  // 16-frame blocks of a branch; clip of the launch, block, its first frame
             f32x4 acc[3];
-            step_gemm<3, 1, KBE / 8, false>(acc, xres_r, KBE, a.out_wt, KBE, tile, KBE / 8 * w, lane, true, wact, [] {}, 0, fb, MBP);
+            step_gemm<3, 1, KBE / 8, false>(acc, xres_r, KBE, a.out_wt, KBE, tile, KBE / 8 * w, lane, true, wact, [] {}, 0, 3 * TB * cl + fbl, TB);
             const f32x4 o = seg_reduce<3>(acc, 0, red, w, lane);
             float* const outt = red + 8 * 3 * 256;  // [3 branches x 16 frames][16 columns]
             if (w < 3) *reinterpret_cast<f32x4*>(outt + (16 * w + (lane & 15)) * 16 + 4 * (lane >> 4)) = o;
             __syncthreads();
-            if (tid < 256 && 16 * fb + (tid >> 4) < Tseg) {  // model.py:749-759, 777-783
-                const int tq = tid >> 4, col = tid & 15, nn = 16 * tile + col, tl = 16 * fb + tq;
+            if (tid < 256 && tb + (tid >> 4) < Tseg) {  // model.py:749-759, 777-783
+                const int tq = tid >> 4, col = tid & 15, nn = 16 * tile + col, tl = tb + tq;
                 const float bo = a.out_b ? a.out_b[nn] : 0.f;
                 const float dfull = outt[tq * 16 + col] + bo, dmid = outt[(16 + tq) * 16 + col] + bo,
                             dnone = outt[(32 + tq) * 16 + col] + bo;
                 const float total = a.cfg[0], factor = a.cfg[1], dt = a.cfg[2];
                 const float v = dnone + total * (dmid + factor * (dfull - dmid) - dnone);
-                const size_t o1 = (size_t)nn * T + f0 + tl;
+                const size_t o1 = ((size_t)cl * a.C + nn) * T + f0 + tl;
                 const float xi = i == 0 ? a.x0[o1]
                                         : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xout_r, (unsigned)o1 * 4u, 0, 16));
                 const float xn = xi + v * dt;
                 a.xout[o1] = xn;
-                if (i + 1 < a.nsteps) a.xt[(size_t)(f0 + tl) * a.Cp + nn] = xn;
+                if (i + 1 < a.nsteps) a.xt[(size_t)(cl * T + f0 + tl) * a.Cp + nn] = xn;
             }
         }
         if (trace && tid == 0) trace[71] = __builtin_readcyclecounter();
@@ -3364,6 +3384,7 @@ template __global__ void sample_seg_kernel<3, 512, 2>(StepArgs);
 template __global__ void sample_seg_kernel<6, 512, 2>(StepArgs);
 template __global__ void sample_seg_kernel<3, 256, 2>(StepArgs);
 template __global__ void sample_seg_kernel<6, 256, 2>(StepArgs);
+template __global__ void sample_seg_kernel<12, 512, 2>(StepArgs);  // two clips of 32-frame segments (StepArgs::nclip)
 template __global__ void sample_clip_kernel<0, 0>(ClipArgs);
 template __global__ void sample_clip_kernel<1, 0>(ClipArgs);
 template __global__ void sample_clip_kernel<0, 1>(ClipArgs);
@@ -3390,6 +3411,8 @@ using namespace after;
 //   AFTER_SAMPLE_PERSIST         1         offline sampler on the persistent kernels (sample_seg_kernel / sample_clip_kernel)
 //   AFTER_SAMPLE_CLIP            1         ... batches on sample_clip_kernel; AFTER_SAMPLE_CLIP_MINB (3): fewest clips that take it
 //   AFTER_SAMPLE_SEG_MAXB        2         clips of a call served by sample_seg_kernel, one launch each
+//   AFTER_SEG_PAIR               1         ... two clips of up to 128 frames share a launch (0: never); AFTER_SAMPLE_SEG_PAIR_MAXB (2): clips of a
+//                                          call served that way
 //   AFTER_SEG_SPLIT              fp16      "bf16": the one-clip sampler's Linears on three bf16 planes instead of two fp16 pieces
 //   AFTER_CLIP_SPLIT             fp16      "bf16": the same for the batch sampler
 //   AFTER_STREAM_SPLIT           fp16      "fp32": the streaming sampler's Linears on the fp32 MFMA chain
@@ -3403,7 +3426,7 @@ using namespace after;
 //   AFTER_STEP_WARM              0,16,4    streaming sampler: sixteenths of the qkv / MLP-up / MLP-down weights warmed into the L2 by idle waves
 struct Env {
     int attn_dbg = 0, row_groups = 0, graph = 0, fuse_tail = 1, x6 = -1, x6_minrows = -1;
-    int stream_persist = -1, sample_persist = -1, sample_clip = -1, clip_minb = 0, seg_maxb = 0;
+    int stream_persist = -1, sample_persist = -1, sample_clip = -1, clip_minb = 0, seg_maxb = 0, seg_pair = 1, seg_pair_maxb = 0;
     int seg_h3 = -1, clip_h3 = -1, stream_h3 = -1, clip_fuse = -1, clip_stagger = 0, clip_gstag = 0, step_trace = 0, step_dbg = 0;
     int clip_grouped = 1, clip_gdelay = 0;
     int warm[3] = {0, 16, 4};
@@ -3430,6 +3453,8 @@ Env env() {
         v.sample_clip = geti("AFTER_SAMPLE_CLIP", -1);
         v.clip_minb = geti("AFTER_SAMPLE_CLIP_MINB", 0);
         v.seg_maxb = geti("AFTER_SAMPLE_SEG_MAXB", 0);
+        v.seg_pair = geti("AFTER_SEG_PAIR", 1);
+        v.seg_pair_maxb = geti("AFTER_SAMPLE_SEG_PAIR_MAXB", 0);
         v.seg_h3 = is("AFTER_SEG_SPLIT", "bf16");
         v.clip_h3 = is("AFTER_CLIP_SPLIT", "bf16");
         v.stream_h3 = is("AFTER_STREAM_SPLIT", "fp32");
@@ -3506,7 +3531,7 @@ struct after_denoiser {
     // after_denoiser_set_stream_persist(h, 0) keep the launch-per-kernel path.
     int persist_step = 1, n_cus = 0;
     int persist_offline = 1;  // AFTER_SAMPLE_PERSIST=0 / after_denoiser_set_sample_persist(h, 0): one clip's offline sampler by launches instead of sample_seg_kernel
-    float* seg_qkv = nullptr;  // [L][3 max_T][3E]: per-layer qkv rows of the segment sampler
+    float* seg_qkv = nullptr;  // [L][2 clips x 3 max_T][3E]: per-layer qkv rows of the segment sampler
     unsigned short* seg_act3 = nullptr;  // bf16 x 3 planes of h and of the MLP hidden layer, one slice per XCD
     bool last_seg = false;     // the last after_sample ran as sample_seg_kernel
     // clip-per-XCD offline sampler (sample_clip_kernel): per-XCD slices of the residual stream / patchify output (tiled fp32),
@@ -3521,6 +3546,9 @@ struct after_denoiser {
     int clip_h3 = 1;           // AFTER_CLIP_SPLIT=bf16 / AFTER_SEG_SPLIT=bf16: the persistent offline samplers on three bf16 planes (A/B)
     int seg_h3 = 1;
     int stream_h3 = 1;         // AFTER_STREAM_SPLIT=fp32: the persistent streaming sampler's Linears on the fp32 MFMA chain (A/B)
+    int last_launches = 0;     // persistent launches of the last after_sample
+    int seg_pair = 1;          // AFTER_SEG_PAIR=0: never two clips in one launch of sample_seg_kernel
+    int seg_pair_max_b = 2;    // AFTER_SAMPLE_SEG_PAIR_MAXB: clips of a call served by sample_seg_kernel when they go in pairs (T <= 128)
     int seg_max_b = 2;         // clips of a call the one-clip sampler serves (one launch each); AFTER_SAMPLE_SEG_MAXB
     int h3_state = 0;          // 0 not computed, 1 scales valid, -1 a bound beyond fp16's range (the bf16 form serves the handle)
     float clip_sc[8][6] = {};  // per layer: s_h1, s_h3, s_m, o_qkv, o_up, o_dn
@@ -4071,6 +4099,8 @@ extern "C" int after_denoiser_create(const after_denoiser_cfg* cfg, const float*
         if (ev.sample_clip != -1) h->persist_clip = ev.sample_clip != 0;
         if (ev.clip_minb > 0) h->clip_min_b = ev.clip_minb;
         if (ev.seg_maxb > 0) h->seg_max_b = ev.seg_maxb;
+        h->seg_pair = ev.seg_pair != 0;
+        if (ev.seg_pair_maxb > 0) h->seg_pair_max_b = ev.seg_pair_maxb;
         hipDeviceProp_t prop;
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(AFTER_E_HIP);
@@ -4228,6 +4258,14 @@ bool seg_split(const after_denoiser* h, int T, int* Tseg, int* nseg) {
             return true;
         }
     return false;
+}
+
+// two clips in one launch of sample_seg_kernel (StepArgs::nclip)
+bool seg_pair_ok(const after_denoiser* h, int T) {
+    int Tseg = 0, nseg = 0;
+    // (segments of 16 frames: the 96 rows per XCD of one clip at 32 -- every width and arithmetic; of 32 frames: 192 rows, built for the
+    //  shipped width on two-piece fp16 operands only)
+    return h->seg_pair && seg_split(h, T, &Tseg, &nseg) && (Tseg == 16 || (h->E == kSE && h->seg_h3_w && h->seg_h3 && !h->tier));
 }
 
 // One persistent kernel in flight per device and process.  The samplers spin on XCD-local barriers, i.e. they need all 256
@@ -4390,7 +4428,7 @@ int persist_prepare(after_denoiser* h, bool offline) {
         float* q = nullptr;
         unsigned short* a3 = nullptr;
         const size_t n3 = (size_t)8 * kSGroupRows * 3 * (E + ME);
-        const bool ok = hipMalloc(&q, (size_t)h->L * 3 * h->max_T * 3 * E * sizeof(float)) == hipSuccess &&
+        const bool ok = hipMalloc(&q, (size_t)h->L * 6 * h->max_T * 3 * E * sizeof(float)) == hipSuccess &&
                         hipMalloc(&a3, n3 * sizeof(unsigned short)) == hipSuccess && hipMemset(a3, 0, n3 * sizeof(unsigned short)) == hipSuccess;
         if (!ok) {
             (void)hipGetLastError();
@@ -4499,6 +4537,7 @@ int persist_prepare(after_denoiser* h, bool offline) {
                              reinterpret_cast<const void*>(sample_seg_kernel<6, 512, 1>), reinterpret_cast<const void*>(sample_seg_kernel<3, 512, 1>),
                              reinterpret_cast<const void*>(sample_seg_kernel<6, 512, 2>), reinterpret_cast<const void*>(sample_seg_kernel<3, 512, 2>),
                              reinterpret_cast<const void*>(sample_seg_kernel<6, 256, 2>), reinterpret_cast<const void*>(sample_seg_kernel<3, 256, 2>),
+                             reinterpret_cast<const void*>(sample_seg_kernel<12, 512, 2>),
                              reinterpret_cast<const void*>(persist_census_kernel)};
         for (const void* fn : fns) AFTER_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_seg));
         const void* sf[] = {reinterpret_cast<const void*>(stream_step_kernel<1>), reinterpret_cast<const void*>(stream_step_kernel<2>),
@@ -4651,30 +4690,33 @@ int sample_persistent(after_denoiser* h, hipStream_t s, const float* x0, float* 
 // no streaming caches.
 bool sample_seg_ok(const after_denoiser* h, int B, int T, int nb_steps) {
     int Tseg = 0, nseg = 0;
-    return h->persist_offline && h->step_ready && h->seg_qkv && h->cache == 0 && B >= 1 && B <= h->seg_max_b && (!h->timer.enabled || h->timer_kernel == 3) && !h->use_graph &&
+    return h->persist_offline && h->step_ready && h->seg_qkv && h->cache == 0 && B >= 1 && (B <= h->seg_max_b || (B <= h->seg_pair_max_b && seg_pair_ok(h, T))) && (!h->timer.enabled || h->timer_kernel == 3) && !h->use_graph &&
            h->x6 != 0 && persist_geometry_ok(h) && h->C / 16 <= 4 && seg_split(h, T, &Tseg, &nseg) && nb_steps >= 1 && T <= h->max_T &&
            ((size_t)h->cs * (h->E + 4) + (size_t)h->H * 2 * (h->W - 1 + h->cs) * 16) <= 7168;
 }
 
-// (clip c of the call's B clips: the kernel samples ONE clip per launch; 2 clips = two launches back to back -- 2 x 10.7 ms against
-//  25.0 by launches and 27.4 on the batch kernel with six idle XCDs, profiles/r6_clip_threshold.txt)
-int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, int T, int nb_steps, int c = 0, int B = 1) {
+// (clips c .. c + nc - 1 of the call's B clips.  nc = 2 (seg_pair_ok: segments of 16 frames): an XCD's 96 rows are the two clips'
+//  three CFG rows x 16 frames -- the row count of one clip at T = 256, the weights streamed once for both; longer clips one per
+//  launch, back to back -- 2 x 10.7 ms against 25.0 by launches and 27.4 on the batch kernel with six idle XCDs,
+//  profiles/r6_clip_threshold.txt)
+int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, int T, int nb_steps, int c = 0, int B = 1, int nc = 1) {
     int Tseg = 0, nseg = 0;
-    if (!seg_split(h, T, &Tseg, &nseg)) return AFTER_E_INVALID;
-    const int E = h->E, L = h->L, MB = 3 * Tseg / 16;
+    if (!seg_split(h, T, &Tseg, &nseg) || (nc == 2 && !seg_pair_ok(h, T)) || nc < 1 || nc > 2) return AFTER_E_INVALID;
+    const int E = h->E, L = h->L, MB = 3 * nc * Tseg / 16;
+    AFTER_REQUIRE(MB != 12 || (E == kSE && h->seg_h3_w && h->seg_h3 && !h->tier), AFTER_E_INVALID, "sample_seg: 192 rows per XCD without the two-piece form");
     const int nkmax = h->W - 1 + h->cs > h->cs ? h->W - 1 + h->cs : h->cs;
     const size_t lds = ((size_t)kSRedFloats(2) + 8 * 2 * kAttnKeyBlock * 64) * sizeof(float);
-    {
+    for (int q = 0; q < nc; ++q) {
         dim3 grid(cdiv(T, 32), cdiv(h->Cp, 32), 1);
-        hipLaunchKernelGGL(to_token_major_kernel, grid, dim3(256), 0, s, x0 + (size_t)c * h->C * T, h->xt + (size_t)c * T * h->Cp, (const int*)nullptr,
-                           h->C, T, h->Cp, 0.f);
+        hipLaunchKernelGGL(to_token_major_kernel, grid, dim3(256), 0, s, x0 + (size_t)(c + q) * h->C * T, h->xt + (size_t)(c + q) * T * h->Cp,
+                           (const int*)nullptr, h->C, T, h->Cp, 0.f);
         AFTER_HIP_CHECK(hipGetLastError());
     }
     AFTER_HIP_CHECK(hipMemsetAsync(h->step_sync, 0, offsetof(StepSync, fail), s));  // (not the sticky failure words)
     const size_t slice = (size_t)8 * kSGroupRows * E;
     StepArgs a;
     memset(&a, 0, sizeof(a));
-    a.rows = 3, a.B = B, a.clip = c, a.T = T, a.C = h->C, a.Cp = h->Cp, a.L = L;
+    a.rows = 3, a.B = B, a.clip = c, a.nclip = nc, a.T = T, a.C = h->C, a.Cp = h->Cp, a.L = L;
     a.cs = h->cs, a.W = h->W, a.nkmax = nkmax, a.cache = 0, a.cache_rows = 0, a.cpg = 1, a.Tseg = Tseg, a.nseg = nseg;
     a.nsteps = nb_steps, a.cache_steps = 0;
     a.xt = h->xt + (size_t)c * T * h->Cp;
@@ -4697,7 +4739,7 @@ int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, in
         StepLayer& sl = a.layer[l];
         sl.qkv_wt = h->step_layers[l].qkv, sl.mlp0_wt = h->step_layers[l].mlp0, sl.mlp2_wt = h->step_layers[l].mlp2;
         sl.mlp0_b = w.mlp0_b, sl.mlp2_b = w.mlp2_b, sl.n1w = w.n1w, sl.n1b = w.n1b, sl.n3w = w.n3w, sl.n3b = w.n3b;
-        sl.qkv = h->seg_qkv + (size_t)l * 3 * h->max_T * 3 * E;
+        sl.qkv = h->seg_qkv + (size_t)l * 6 * h->max_T * 3 * E;
         if (h->seg_h3_w) {
             const size_t ME_ = h->ME, per = (3 * (size_t)E * E + 2 * (size_t)E * ME_) * 2;
             const unsigned short* b = h->seg_h3_w + per * l;
@@ -4717,7 +4759,8 @@ int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, in
             if (MB == 6) hipLaunchKernelGGL((sample_seg_kernel<6, 512, 1>), dim3(h->n_cus), dim3(512), lds, s, a);
             else hipLaunchKernelGGL((sample_seg_kernel<3, 512, 1>), dim3(h->n_cus), dim3(512), lds, s, a);
         } else if (seg3 && E == kSE) {  // the default arithmetic: two-piece fp16 operands (gemm_h3_pipe.h)
-            if (MB == 6) hipLaunchKernelGGL((sample_seg_kernel<6, 512, 2>), dim3(h->n_cus), dim3(512), lds, s, a);
+            if (MB == 12) hipLaunchKernelGGL((sample_seg_kernel<12, 512, 2>), dim3(h->n_cus), dim3(512), lds, s, a);
+            else if (MB == 6) hipLaunchKernelGGL((sample_seg_kernel<6, 512, 2>), dim3(h->n_cus), dim3(512), lds, s, a);
             else hipLaunchKernelGGL((sample_seg_kernel<3, 512, 2>), dim3(h->n_cus), dim3(512), lds, s, a);
         } else if (seg3) {
             if (MB == 6) hipLaunchKernelGGL((sample_seg_kernel<6, 256, 2>), dim3(h->n_cus), dim3(512), lds, s, a);
@@ -4734,7 +4777,7 @@ int sample_seg(after_denoiser* h, hipStream_t s, const float* x0, float* out, in
     if (timed) {
         const double M = 3.0 * T, Ed = E, MEd = h->ME, Cd = h->C;
         const double wts = Ed * h->Cp + Cd * Ed + L * (3 * Ed * Ed + 2 * Ed * MEd);
-        const double fl = 2.0 * ((double)T * Ed * h->Cp + M * (Cd * Ed + L * (3 * Ed * Ed + 2 * Ed * MEd)));
+        const double fl = 2.0 * nc * ((double)T * Ed * h->Cp + M * (Cd * Ed + L * (3 * Ed * Ed + 2 * Ed * MEd)));
         h->timer.end(s, nb_steps * fl, nb_steps * 4.0 * wts);
     }
     const bool check = h->persist_check != 0;
@@ -4851,7 +4894,14 @@ int sample_enqueue(after_denoiser* h, hipStream_t s, const float* x0, const floa
     const bool capturing = (h->persist_step || h->persist_offline) && h->step_ready && stream_is_capturing(s);
     if (!capturing && sample_seg_ok(h, B, T, nb_steps)) {
         int rc = AFTER_OK;
-        for (int c = 0; c < B && rc == AFTER_OK; ++c) rc = sample_seg(h, s, x0, out, T, nb_steps, c, B);
+        // (clips in pairs where a pair fits one launch, a last odd clip alone)
+        const bool pairs = h->seg_pair && seg_pair_ok(h, T);
+        h->last_launches = 0;
+        for (int c = 0; c < B && rc == AFTER_OK;) {
+            const int nc = pairs && c + 1 < B ? 2 : 1;
+            rc = sample_seg(h, s, x0, out, T, nb_steps, c, B, nc);
+            c += nc, ++h->last_launches;
+        }
         if (rc != kStepRetry) {  // (a refused / failed launch: every clip again on the next path -- the samples are stateless)
             h->last_seg = rc == AFTER_OK;
             return rc;
@@ -4861,6 +4911,7 @@ int sample_enqueue(after_denoiser* h, hipStream_t s, const float* x0, const floa
         const int rc = sample_clip(h, s, x0, out, B, T, nb_steps);
         if (rc != kStepRetry) {
             h->last_clip = rc == AFTER_OK;
+            h->last_launches = 1;
             return rc;
         }
     }
@@ -4963,9 +5014,11 @@ extern "C" int after_sample(after_denoiser* h, const float* x0, const float* con
         if (n8 > 0 && rem > 0 && rem < h->clip_min_b && sample_clip_ok(h, n8, T, nb_steps) && !stream_is_capturing(s)) {
             AFTER_TRY(sample_enqueue(h, s, x0, cond, time_cond, out, n8, T, nb_steps, drop_value, cfg_mode));
             const bool clip_ran = h->last_clip, h3_ran = h->last_h3;
+            const int n_first = h->last_launches;
             const size_t xo = (size_t)n8 * h->C * T;
             AFTER_TRY(sample_enqueue(h, s, x0 + xo, cond + (size_t)n8 * h->ZT, time_cond + (size_t)n8 * h->ZS * T, out + xo, rem, T, nb_steps,
                                      drop_value, cfg_mode));
+            h->last_launches = (h->last_seg || h->last_clip ? h->last_launches : 0) + n_first;
             h->last_clip = clip_ran, h->last_h3 = h3_ran;
             h->last_seg = false;
             return AFTER_OK;
@@ -5062,6 +5115,12 @@ extern "C" int after_denoiser_check(after_denoiser* h, void* stream) {
 extern "C" int after_denoiser_sample_persist(after_denoiser* h, int* active) {
     AFTER_REQUIRE(h && active, AFTER_E_INVALID, "null argument");
     *active = h->last_seg ? 1 : (h->last_clip ? 2 : 0);
+    return AFTER_OK;
+}
+
+extern "C" int after_denoiser_sample_launches(after_denoiser* h, int* n) {
+    AFTER_REQUIRE(h && n, AFTER_E_INVALID, "null argument");
+    *n = (h->last_seg || h->last_clip) ? h->last_launches : 0;
     return AFTER_OK;
 }
 

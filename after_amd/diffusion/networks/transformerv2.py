@@ -439,6 +439,14 @@ class DenoiserV2(nn.Module):
         _lib.check(_lib.lib().after_denoiser_sample_persist(self._handle, ctypes.byref(a)), "after_denoiser_sample_persist")
         return int(a.value)
 
+    def sample_launches(self) -> int:
+        """Persistent launches the last cfg_sample took (0: per-op launches).  The one-clip kernel takes two clips per launch."""
+        if self._handle is None:
+            return 0
+        a = ctypes.c_int()
+        _lib.check(_lib.lib().after_denoiser_sample_launches(self._handle, ctypes.byref(a)), "after_denoiser_sample_launches")
+        return int(a.value)
+
     def sample_arith(self) -> int:
         """The arithmetic of the qkv / MLP Linears in the last cfg_sample (include/after_hip.h: after_denoiser_sample_arith): 0 the fp32
         MFMA chain, 1 three bf16 planes x six products, 2 two fp16 pieces x three products (the persistent samplers' default),

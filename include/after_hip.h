@@ -208,6 +208,10 @@ int after_denoiser_sample_persist(after_denoiser* h, int* active);
  * block (gemm_h3_pipe.h: the DEFAULT of both persistent offline samplers; measured error vs fp64 0.63 - 0.72 x the fp32 chain's,
  * tests/test_gemm_gpu.py), 3: the opt-in bf16 tolerance tier (gemm path 3).  Results are fp32 in every form. */
 int after_denoiser_sample_arith(after_denoiser* h, int* form);
+/* Persistent launches the last after_sample took (0: it ran by launches of the per-op kernels).  The one-clip kernel serves up to two clips
+ * per launch -- an XCD then owns its time segment of BOTH clips' CFG rows and the weights are streamed once for the pair (segments of 16
+ * frames: any supported width; of 32 frames: the shipped width on two-piece fp16 operands); AFTER_SEG_PAIR=0: one clip per launch. */
+int after_denoiser_sample_launches(after_denoiser* h, int* n);
 int after_denoiser_stream_persist(after_denoiser* h, int* active);
 /* mode -1 (default): the offline samplers look at their own launch (never an untouched tensor), the streaming sampler defers;
  * 1: every persistent after_sample synchronises `stream` and reports its own failure; 0: every one defers. */

@@ -146,6 +146,17 @@ m0)  # the LDS-DMA sites through __builtin_amdgcn_global_load_lds (compiler-mana
     cp $O/builtin.so after_amd/lib/libafter_hip.so; rm -f $O/builtin.so
     timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -5 | tee $O/gpu_suite.txt
     ;;
+pair)  # two clips per launch of the one-clip kernel (StepArgs::nclip, sample_seg_kernel<12, 512, 2>): parity, timings at 1 - 5 clips
+    timeout 2400 python -m pytest tests/test_sample_persist_gpu.py -x -q 2>&1 | tail -8 | tee $O/tests.txt
+    for b in 1 2 3 4 5; do
+      AFTER_SEG_PAIR=0 timeout 300 python scripts/time_sampler.py base $b 50 3 2>&1 | grep "sample " | cut -c1-70 | sed "s/^/one per launch | batch kernel from 3:  /" | tee -a $O/pair.txt
+      timeout 300 python scripts/time_sampler.py base $b 50 3 2>&1 | grep "sample " | cut -c1-70 | sed "s/^/pairs to 2:                            /" | tee -a $O/pair.txt
+      AFTER_SAMPLE_SEG_PAIR_MAXB=5 timeout 300 python scripts/time_sampler.py base $b 50 3 2>&1 | grep "sample " | cut -c1-70 | sed "s/^/pairs to 5:                            /" | tee -a $O/pair.txt
+    done
+    AFTER_T=128 timeout 300 python scripts/time_sampler.py base 2 50 3 2>&1 | grep "sample " | cut -c1-70 | sed "s/^/T = 128, pair:  /" | tee -a $O/pair.txt
+    AFTER_T=128 AFTER_SEG_PAIR=0 timeout 300 python scripts/time_sampler.py base 2 50 3 2>&1 | grep "sample " | cut -c1-70 | sed "s/^/T = 128, one per launch:  /" | tee -a $O/pair.txt
+    timeout 300 python scripts/time_sampler.py midi 2 50 3 2>&1 | grep "sample " | cut -c1-70 | sed "s/^/midi pair:  /" | tee -a $O/pair.txt
+    ;;
 final2)  # final sources: the whole GPU suite, then every artefact of the round on the same lease
     timeout 3400 python -m pytest tests -x -q -m gpu 2>&1 | tail -6 | tee $O/gpu_suite.txt
     python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.txt

@@ -41,13 +41,15 @@ def test_persistent_offline_sampler_matches_launch_path_and_oracle(T, steps, bas
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     want = oracle.sample(sd, dcfg["net"], x0, cond, tc, steps, 2.0, 1.0)
     assert max_abs(got, want) < 1e-4 and rel_l2(got, want) < 2e-5, (max_abs(got, want), rel_l2(got, want))
-    # two clips: one launch of the kernel per clip (round 6; ~1650 launches through round 5) -- each clip as if sampled alone
+    # two clips: ONE launch of the kernel for the pair (~1650 launches through round 5) -- each clip as if sampled alone (the pair's
+    # Linears split K over the waves differently: fp32 round-off apart)
     x2, c2, t2 = torch.randn(2, 64, T, generator=g).to(hip_device), torch.randn(2, 6, generator=g).to(hip_device), torch.randn(2, 12, T, generator=g).to(hip_device)
     both = net.cfg_sample(x2, c2, t2, 2, 2.0, 1.0, -4.0)
-    assert net.sample_path() == 1
+    assert net.sample_path() == 1 and net.sample_launches() == 1, (net.sample_path(), net.sample_launches())
     for c in range(2):
         alone = net.cfg_sample(x2[c:c + 1].contiguous(), c2[c:c + 1].contiguous(), t2[c:c + 1].contiguous(), 2, 2.0, 1.0, -4.0)
-        assert max_abs(both[c:c + 1].cpu(), alone.cpu()) < 2e-5, c  # (the conditioning GEMMs of a 2-clip call pick other tiles)
+        assert net.sample_launches() == 1
+        assert max_abs(both[c:c + 1].cpu(), alone.cpu()) < 2e-5, c
     # shapes the kernel does not take fall back silently: a length that is not whole 16-frame segments
     x3 = torch.randn(1, 64, T - 6, generator=g).to(hip_device)
     net.cfg_sample(x3, c2[:1].contiguous(), t2[:1, :, :T - 6].contiguous(), 2, 2.0, 1.0, -4.0)
@@ -187,3 +189,65 @@ def test_two_piece_fp16_scales_follow_the_weights(B, hip_device):
     assert torch.isfinite(got2).all() == torch.isfinite(ref2).all()
     if torch.isfinite(ref2).all():
         assert max_abs(got2, ref2) < 5e-5 * max(1.0, ref2.abs().max().item())
+
+
+def _pair_case(model, dcfg, B, T, steps, hip_device, seed, launches, cfg_mode=None, tcond_rand=False):
+    """B clips through the one-clip kernel, two per launch: against the launch path of the same handle, against every clip sampled
+    alone, and clip by clip against the CPU oracle (which samples one clip per call)."""
+    net = model.net
+    g = torch.Generator().manual_seed(seed)
+    x0 = torch.randn(B, net.n_channels, T, generator=g)
+    cond = torch.randn(B, net.cond_dim, generator=g)
+    tc = torch.rand(B, net.tcond_dim, T, generator=g) if tcond_rand else torch.randn(B, net.tcond_dim, T, generator=g)
+    kw = {} if cfg_mode is None else {"cfg_mode": cfg_mode}
+    args = (x0.to(hip_device), cond.to(hip_device), tc.to(hip_device), steps, 2.0, 1.5, -4.0)
+    net.set_sample_persist(False)
+    ref = net.cfg_sample(*args, **kw).cpu()
+    assert net.sample_path() == 0 and net.sample_launches() == 0
+    net.set_sample_persist(True)
+    got = net.cfg_sample(*args, **kw).cpu()
+    assert net.sample_path() == 1 and net.sample_launches() == launches, (net.sample_path(), net.sample_launches(), launches)
+    assert torch.equal(got, net.cfg_sample(*args, **kw).cpu()), "not reproducible"
+    assert torch.isfinite(got).all() and max_abs(got, ref) < 5e-5, max_abs(got, ref)
+    for c in range(B):
+        one = tuple(a[c:c + 1].contiguous() for a in args[:3]) + args[3:]
+        alone = net.cfg_sample(*one, **kw).cpu()
+        assert net.sample_launches() == 1
+        assert max_abs(got[c:c + 1], alone) < 2e-5, (c, max_abs(got[c:c + 1], alone))
+    if cfg_mode is None:
+        sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+        for c in range(B):
+            want = oracle.sample(sd, dcfg["net"], x0[c:c + 1], cond[c:c + 1], tc[c:c + 1], steps, 2.0, 1.5)
+            assert max_abs(got[c:c + 1], want) < 1e-4 and rel_l2(got[c:c + 1], want) < 2e-5, (c, max_abs(got[c:c + 1], want), rel_l2(got[c:c + 1], want))
+
+
+@pytest.mark.parametrize("T,steps", [(256, 5), (224, 3), (160, 2), (128, 4), (112, 2), (48, 3), (16, 2)])
+def test_two_clips_share_a_launch(T, steps, base, hip_device):
+    """StepArgs::nclip = 2: an XCD owns its time segment of BOTH clips' three CFG rows -- 192 rows at 32-frame segments
+    (sample_seg_kernel<12, 512, 2>: four row halves, two K slices per wave), 96 at 16-frame segments (the one-clip geometry of T = 256) --
+    with per-clip conditioning rows, RoPE positions, left context and Euler state."""
+    model, dcfg = base
+    _pair_case(model, dcfg, 2, T, steps, hip_device, 900 + T, 1)
+
+
+@pytest.mark.parametrize("T,launches", [(128, 1), (64, 1), (256, 2)])
+def test_two_clips_share_a_launch_tiny_width(T, launches, tiny, hip_device):
+    """Width 256: pairs at 16-frame segments; at 32-frame segments (192 rows per XCD exist for the shipped width only) one clip per launch."""
+    model, dcfg = tiny
+    _pair_case(model, dcfg, 2, T, 3, hip_device, 1300 + T, launches)
+
+
+def test_pairs_and_an_odd_clip_with_midi_cfg_rows(hip_device, monkeypatch):
+    """Three and four clips as pair + single / two pairs (AFTER_SAMPLE_SEG_PAIR_MAXB moves the hand-over to the batch kernel), the
+    CFG_MIDI row arrangement (the time-conditioning map differs per CFG row AND per clip), and AFTER_SEG_PAIR=0."""
+    from after_amd import _lib
+    monkeypatch.setenv("AFTER_SAMPLE_SEG_PAIR_MAXB", "4")
+    model, dcfg, _ = pipeline.build_models("midi", "baseAE", hip_device, seed=19)
+    _pair_case(model, dcfg, 3, 256, 3, hip_device, 1700, 2, cfg_mode=_lib.CFG_MIDI, tcond_rand=True)
+    _pair_case(model, dcfg, 4, 128, 2, hip_device, 1701, 2, cfg_mode=_lib.CFG_MIDI, tcond_rand=True)
+    model, dcfg, _ = pipeline.build_models("base", "baseAE", hip_device, seed=19)
+    _pair_case(model, dcfg, 3, 256, 2, hip_device, 1702, 2)
+    monkeypatch.setenv("AFTER_SEG_PAIR", "0")
+    monkeypatch.setenv("AFTER_SAMPLE_SEG_PAIR_MAXB", "2")
+    model, dcfg, _ = pipeline.build_models("base", "baseAE", hip_device, seed=19)
+    _pair_case(model, dcfg, 2, 256, 2, hip_device, 1703, 2)
