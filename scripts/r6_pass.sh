@@ -157,6 +157,22 @@ pair)  # two clips per launch of the one-clip kernel (StepArgs::nclip, sample_se
     AFTER_T=128 AFTER_SEG_PAIR=0 timeout 300 python scripts/time_sampler.py base 2 50 3 2>&1 | grep "sample " | cut -c1-70 | sed "s/^/T = 128, one per launch:  /" | tee -a $O/pair.txt
     timeout 300 python scripts/time_sampler.py midi 2 50 3 2>&1 | grep "sample " | cut -c1-70 | sed "s/^/midi pair:  /" | tee -a $O/pair.txt
     ;;
+pairtrace)  # per-phase stamps of the one-clip kernel with one and with two clips per launch
+    python scripts/stream_step_trace.py --offline --clips 1 2>/dev/null | grep -v amdgpu.ids | tee $O/one.txt | tail -14
+    python scripts/stream_step_trace.py --offline --clips 2 2>/dev/null | grep -v amdgpu.ids | tee $O/two.txt | tail -50
+    ;;
+stagger)  # experiment (reverted): one-clip kernel, halo chunks last in item order, the neighbour's sequence word fetched under the qkv phase, XCD start stagger
+    timeout 2400 python -m pytest tests/test_sample_persist_gpu.py tests/test_persist_protocol_gpu.py -x -q 2>&1 | tail -5 | tee $O/tests.txt
+    for rep in 1 2; do
+      for st in 0 200 400 800 1200; do
+        for cfg in "base 1" "base 2" "tiny 1"; do set -- $cfg
+          AFTER_SEG_STAGGER=$st timeout 300 python scripts/time_sampler.py $1 $2 50 5 2>&1 | grep "sample " | cut -c1-70 | sed "s/^/stagger $st: /" | tee -a $O/stagger.txt
+        done
+      done
+    done
+    AFTER_SEG_STAGGER=800 python scripts/stream_step_trace.py --offline --clips 1 2>/dev/null | grep -v amdgpu.ids | tee $O/one_800.txt | tail -6
+    AFTER_SEG_STAGGER=800 python scripts/stream_step_trace.py --offline --clips 2 2>/dev/null | grep -v amdgpu.ids | tee $O/two_800.txt | tail -6
+    ;;
 final2)  # final sources: the whole GPU suite, then every artefact of the round on the same lease
     timeout 3400 python -m pytest tests -x -q -m gpu 2>&1 | tail -6 | tee $O/gpu_suite.txt
     python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.txt

@@ -20,7 +20,7 @@ ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--xcd", type=int, default=0)
 ap.add_argument("--detail", action="store_true", help="per phase: the five slowest workgroups (index in the XCD: work us)")
 ap.add_argument("--offline", action="store_true", help="the persistent OFFLINE sampler (one clip, base, 50 steps) instead")
-ap.add_argument("--clips", type=int, default=1, help="with --offline: clips of the call (>= 5: the clip-per-XCD kernel)")
+ap.add_argument("--clips", type=int, default=1, help="with --offline: clips of the call (1 - 2: the one-clip kernel, the pair in one launch; >= 3: the clip-per-XCD kernel)")
 args = ap.parse_args()
 torch.set_grad_enabled(False)
 dev = torch.device("cuda:0")
@@ -35,6 +35,7 @@ if args.offline:
         model.net.cfg_sample(x0, cond, tc, 50, 2.0, 1.0, -4.0)
     torch.cuda.synchronize()
     assert model.net.sample_persist()
+    kernel = model.net.sample_path()  # 1: the one-clip kernel (one or two clips per launch), 2: the clip-per-XCD kernel
 else:
     model, dcfg, acfg = pipeline.build_models("cycle", "baseAE_causal", dev, seed=7)
 if not args.offline:
@@ -101,7 +102,7 @@ if not args.offline:  # the last layer's attention phase: stamps of thread 0 ins
               "rows exchanged %.2f / %.2f, LayerNorm tail stored %.2f / %.2f, arrival %.2f / %.2f" % ((int(has.sum()),) + tuple(
                   v for k in range(5) for v in (np.median(rela[:, k]), rela[:, k].max())) + (np.median(arra), arra.max())))
 
-if args.offline and args.clips == 1:  # effective shader clock over the step; inside the last layer's qkv phase (workgroup-local stamps of wave 0)
+if args.offline and kernel == 1:  # effective shader clock over the step; inside the last layer's qkv phase (workgroup-local stamps of wave 0)
     cyc = (buf[:, 71].astype(np.int64) - buf[:, 70].astype(np.int64))
     wall = (t_all[:, 2 * len(names) - 1] - t_all[:, 0]) / 100.0
     print("effective shader clock over the step: %.0f MHz (median over workgroups)" % np.median(cyc / wall))
@@ -123,7 +124,7 @@ if args.offline and args.clips == 1:  # effective shader clock over the step; in
     gw = buf[:, 72:80].astype(np.int64)
     print("qkv phase, end of each wave's MFMAs (median us after the barrier): " + " ".join("%.2f" % v for v in np.median((gw - t_all[:, 2 * ph][:, None]) / 100.0, 0)))
 
-if args.offline and args.clips > 1:  # the clip-per-XCD kernel: effective shader clock, anatomy of the last layer's qkv phase (first tile of a workgroup)
+if args.offline and kernel == 2:  # the clip-per-XCD kernel: effective shader clock, anatomy of the last layer's qkv phase (first tile of a workgroup)
     cyc = (buf[:, 71].astype(np.int64) - buf[:, 70].astype(np.int64))
     wall = (t_all[:, 2 * len(names) - 1] - t_all[:, 0]) / 100.0
     okw = wall > 0
