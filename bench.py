@@ -572,7 +572,9 @@ class Leg:
         if self.stream:
             return ("persistent (one launch per chunk: stream_step_kernel)" if self.model.net.stream_persist()
                     else "one launch per kernel (33 per Euler step)")
-        return {0: "one launch per kernel (33 per Euler step)", 1: "persistent, one clip (sample_seg_kernel)",
+        n = self.model.net.sample_launches()
+        return {0: "one launch per kernel (33 per Euler step)",
+                1: f"persistent, time segments over the XCDs (sample_seg_kernel: {self.B} clip{'s' if self.B > 1 else ''} in {n} launch{'es' if n > 1 else ''})",
                 2: "persistent, one clip per XCD (sample_clip_kernel)"}[self.model.net.sample_path()]
 
     def persistent(self):
@@ -699,14 +701,15 @@ LAUNCH_PATH_SWITCHES = ("AFTER_SAMPLE_PERSIST", "AFTER_SAMPLE_CLIP", "AFTER_STRE
 
 
 def expects_persistent(leg, args):
-    """Shapes the persistent samplers take by design: base / midi width at one clip or >= 5 clips (tiny: one clip),
-    T = 256; the streaming sampler always.  2-4 clips per GPU run by launches by design."""
+    """Shapes the persistent samplers take by design: any supported width at one or two clips (the one-clip kernel, a
+    pair per launch at the shipped width), base / midi width from three clips on (the batch kernel), T = 256; the streaming sampler
+    always."""
     if leg.stream:
         return True
     if args.bf16_tier:
         return True  # (the tier exists in the persistent kernels only: a launch-path run would publish the wrong dtype)
     e = leg.dcfg["net"]["embed_dim"]
-    return leg.B == 1 or (leg.B >= 5 and e == 512)
+    return leg.B <= 2 or e == 512
 
 
 def require_persistent(leg, args):
@@ -753,6 +756,7 @@ def extra_legs(args, dev, head):
     no CPU baseline, no counter files."""
     specs = [("b8", dict(batch_per_gpu=8), 1, 3, "BASELINE configs[2]: the per-GPU shard (8 clips) of base B=64 over 8 GPUs"),
              ("midi_b8", dict(config="midi", batch_per_gpu=8), 1, 3, "BASELINE configs[3]: midi, 8 clips"),
+             ("b2", dict(batch_per_gpu=2), 1, 4, "a ragged shard's remainder: base, 2 clips -- both in ONE launch of the one-clip kernel"),
              ("stream", dict(config="cycle", stream=True, batch_per_gpu=8), 4, 12,
               "BASELINE configs[4]: base + cycle streaming, 8 streams, 100 cached steps; one step = one 4-frame chunk of every stream"),
              ("tiny_from_audio", dict(config="tiny", from_audio=True, batch_per_gpu=1), 2, 5,
