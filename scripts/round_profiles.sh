@@ -95,6 +95,14 @@ python scripts/stream_step_trace.py --offline --clips 8 --xcd 3 2>/dev/null | gr
 python scripts/persist_check_cost.py > $O/${R}_persist_check_cost.jsonl 2>/dev/null
 python scripts/seg_context.py 2>/dev/null | tail -9 > $O/${R}_clip_breakdown_b1.txt
 python scripts/stream_step_trace.py --offline > $O/${R}_offline_step_trace.txt 2>/dev/null
+# two clips per launch of the one-clip kernel: per-phase stamps, same-box A/B against one clip per launch (T = 256 and 128, midi)
+python scripts/stream_step_trace.py --offline --clips 2 2>/dev/null | grep -v amdgpu.ids > $O/${R}_pair_step_trace.txt
+for rep in 1 2; do
+  for cfgt in "base 256" "base 128" "midi 256"; do set -- $cfgt
+    AFTER_T=$2 AFTER_SEG_PAIR=0 python scripts/time_sampler.py $1 2 50 5 2>/dev/null | tail -1 | cut -c1-75 | sed "s/^/T = $2, one clip per launch: /" >> $O/${R}_ab_pair.txt
+    AFTER_T=$2 python scripts/time_sampler.py $1 2 50 5 2>/dev/null | tail -1 | cut -c1-75 | sed "s/^/T = $2, the pair in one:      /" >> $O/${R}_ab_pair.txt
+  done
+done
 # the persistent streaming step: same-box A/B against the launch path, per-phase timeline, kernel stats of a chunk
 for p in 1 0 1 0; do
   AFTER_STREAM_PERSIST=$p python bench.py --stream --steps 24 --warmup 4 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'leg': 'stream 8x100 steps', 'AFTER_STREAM_PERSIST': $p, 'ms_per_chunk': d['ms_per_step'], 'xrt': d['value']}))" >> $O/${R}_ab_stream_persist.jsonl
