@@ -173,6 +173,13 @@ stagger)  # experiment (reverted): one-clip kernel, halo chunks last in item ord
     AFTER_SEG_STAGGER=800 python scripts/stream_step_trace.py --offline --clips 1 2>/dev/null | grep -v amdgpu.ids | tee $O/one_800.txt | tail -6
     AFTER_SEG_STAGGER=800 python scripts/stream_step_trace.py --offline --clips 2 2>/dev/null | grep -v amdgpu.ids | tee $O/two_800.txt | tail -6
     ;;
+ubench)  # the stand-alone micro-benchmarks behind the design's price list (XCD barriers, halo hand-over, L2 round trips, DMA issue rate)
+    mkdir -p gpurun_out/final_r6
+    for u in xcd_barrier xcd_local xcd_halo xcd_barrier2 l2_rtt dma_issue; do
+      [ -x scripts/ubench/$u.bin ] || hipcc --offload-arch=gfx950 -O3 scripts/ubench/$u.hip -o scripts/ubench/$u.bin
+      timeout 300 ./scripts/ubench/$u.bin > gpurun_out/final_r6/r6_$u.jsonl 2> $O/$u.err; echo "$u rc $? $(wc -c < gpurun_out/final_r6/r6_$u.jsonl) bytes"
+    done
+    ;;
 final2)  # final sources: the whole GPU suite, then every artefact of the round on the same lease
     timeout 3400 python -m pytest tests -x -q -m gpu 2>&1 | tail -6 | tee $O/gpu_suite.txt
     python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.txt

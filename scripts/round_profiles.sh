@@ -37,6 +37,9 @@ done
 X6L="dec0 k3 ,dec1 k3,dec1 k1,dec2 k3 ,dec2 k1,dec3 k3,dec3 k1,up2"
 python scripts/bench_conv.py --x6 --tiles 0 --layers "$X6L" 2>/dev/null | grep layer > $O/${R}_bench_conv_x6_b1.jsonl
 python scripts/bench_conv.py --batch 8 --x6 --tiles 0 --layers "$X6L" 2>/dev/null | grep layer > $O/${R}_bench_conv_x6_b8.jsonl
+for u in xcd_barrier xcd_local xcd_halo xcd_barrier2 l2_rtt dma_issue; do  # (the stand-alone micro-benchmarks: built where they run)
+  [ -x scripts/ubench/$u.bin ] || hipcc --offload-arch=gfx950 -O3 scripts/ubench/$u.hip -o scripts/ubench/$u.bin 2>> $O/ubench_build.err
+done
 ./scripts/ubench/xcd_barrier.bin > $O/${R}_xcd_barrier.jsonl 2>/dev/null
 ./scripts/ubench/xcd_local.bin > $O/${R}_xcd_local.jsonl 2>/dev/null
 ./scripts/ubench/xcd_halo.bin > $O/${R}_xcd_halo.jsonl 2>/dev/null

@@ -26,8 +26,8 @@ __global__ __launch_bounds__(512) void k(const float* src, int nw, unsigned long
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         if (DMA) {
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                         : : "s"(lds0 + (unsigned)((w * N + i) * 1024)), "v"((unsigned)lane * 16u), "s"(base + i * 256) : "memory");
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(base + i * 256) + lane * 16),
+                                             (lds_ptr_t)(__attribute__((address_space(3))) char*)(unsigned long)(lds0 + (unsigned)((w * N + i) * 1024)), 16, 0, 0);
         } else {
             asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v[DMA ? 0 : i]) : "v"((unsigned)lane * 16u), "s"(base + i * 256) : "memory");
         }
