@@ -180,6 +180,15 @@ ubench)  # the stand-alone micro-benchmarks behind the design's price list (XCD 
       timeout 300 ./scripts/ubench/$u.bin > gpurun_out/final_r6/r6_$u.jsonl 2> $O/$u.err; echo "$u rc $? $(wc -c < gpurun_out/final_r6/r6_$u.jsonl) bytes"
     done
     ;;
+b2prof)  # kernel stats and matrix-pipe busy fraction of the pair launch
+    mkdir -p gpurun_out/final_r6; F=gpurun_out/final_r6
+    (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/ss2 -- python $GRAFT_REPO_ROOT/scripts/time_sampler.py base 2 50 5 > $GRAFT_REPO_ROOT/$O/ss2.log 2>&1)
+    f=$(find $O/ss2 -name "*kernel_stats.csv" | head -1)
+    head -21 "$f" | cut -c1-260 | tee $F/r6_sampler_b2_kernel_stats.csv | head -6
+    rm -rf $O/ss2
+    python bench.py --pmc-mfma --batch-per-gpu 2 > $O/mfma_b2.log 2>&1; tail -3 $O/mfma_b2.log | cut -c1-300
+    cp profiles/r6_pmc_mfma_base_b2.json $F/ 2>/dev/null
+    ;;
 final2)  # final sources: the whole GPU suite, then every artefact of the round on the same lease
     timeout 3400 python -m pytest tests -x -q -m gpu 2>&1 | tail -6 | tee $O/gpu_suite.txt
     python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.txt

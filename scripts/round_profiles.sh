@@ -125,6 +125,12 @@ for b in 1 8; do
   f=$(find $O/ss$b -name "*kernel_stats.csv" | head -1)
   head -21 "$f" | cut -c1-260 > $O/${R}_sampler_b${b}_kernel_stats.csv
   rm -rf $O/ss$b
+  if [ $b = 1 ]; then  # ... and two clips in one launch of the one-clip kernel
+    (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/ss2 -- python $GRAFT_REPO_ROOT/scripts/time_sampler.py base 2 50 5 > $GRAFT_REPO_ROOT/$O/ss2.log 2>&1)
+    f=$(find $O/ss2 -name "*kernel_stats.csv" | head -1)
+    head -21 "$f" | cut -c1-260 > $O/${R}_sampler_b2_kernel_stats.csv
+    rm -rf $O/ss2
+  fi
   for w in decode encode; do
     e=pqmf_inverse; [ $w = encode ] && e=pqmf_forward
     (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/tr -- python $GRAFT_REPO_ROOT/scripts/time_codec.py --rounds 3 --batches $b --only $w > $GRAFT_REPO_ROOT/$O/tr.log 2>&1)
