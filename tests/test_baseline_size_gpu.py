@@ -102,6 +102,30 @@ def test_base_sampler_b8_shard_vs_oracle(base, hip_device):
         assert max_abs(one, got[s]) < 5e-5, i
 
 
+def test_base_sampler_two_clips_50_steps_vs_oracle(both_gemm_paths, hip_device):
+    """bench.py's leg `b2` at BASELINE's length: two clips, T = 256, 50 Euler steps in ONE launch of the one-clip kernel (192 rows per
+    XCD); both clips against the oracle and against single-clip launches of the same handle."""
+    if both_gemm_paths == "fp32mfma":
+        pytest.skip("AFTER_GEMM_X6=0 serves every call by launches")
+    model, dcfg, _ = pipeline.build_models("base", "baseAE", hip_device, seed=6)  # (its own handle: created under this leg's environment)
+    sd_net = cpu_sd(model.net)
+    ncfg = dcfg["net"]
+    g = torch.Generator().manual_seed(33)
+    B, N = 2, 50
+    x0 = torch.randn(B, 64, 256, generator=g)
+    cond = torch.randn(B, 6, generator=g)
+    tc = torch.randn(B, 12, 256, generator=g)
+    got = model.sample(x0.to(hip_device), cond.to(hip_device), tc.to(hip_device), N, 2.0, 1.0).cpu()
+    assert model.net.sample_path() == 1 and model.net.sample_launches() == 1, (model.net.sample_path(), model.net.sample_launches())
+    for i in range(B):
+        s = slice(i, i + 1)
+        want = oracle.sample(sd_net, ncfg, x0[s], cond[s], tc[s], N, 2.0, 1.0)
+        assert max_abs(got[s], want) < 1e-4, (i, max_abs(got[s], want))
+        assert rel_l2(got[s], want) < 2e-5
+        one = model.sample(x0[s].to(hip_device), cond[s].to(hip_device), tc[s].to(hip_device), N, 2.0, 1.0).cpu()
+        assert max_abs(one, got[s]) < 5e-5, i
+
+
 @pytest.mark.parametrize("mode,gt,gs", [(_lib.CFG_API, 2.0, 1.0), (_lib.CFG_MIDI, 2.0, 3.0)])
 def test_midi_b8_t256_50steps_vs_oracle(mode, gt, gs, hip_device):
     """Config 4: midi (tcond 128, window 16), B=8, T=256, 50 steps, synthetic piano roll

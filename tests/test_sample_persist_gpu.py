@@ -221,7 +221,7 @@ def _pair_case(model, dcfg, B, T, steps, hip_device, seed, launches, cfg_mode=No
             assert max_abs(got[c:c + 1], want) < 1e-4 and rel_l2(got[c:c + 1], want) < 2e-5, (c, max_abs(got[c:c + 1], want), rel_l2(got[c:c + 1], want))
 
 
-@pytest.mark.parametrize("T,steps", [(256, 5), (224, 3), (160, 2), (128, 4), (112, 2), (48, 3), (16, 2)])
+@pytest.mark.parametrize("T,steps", [(256, 5), (256, 1), (224, 3), (160, 2), (128, 4), (112, 2), (48, 3), (32, 1), (16, 2)])
 def test_two_clips_share_a_launch(T, steps, base, hip_device):
     """StepArgs::nclip = 2: an XCD owns its time segment of BOTH clips' three CFG rows -- 192 rows at 32-frame segments
     (sample_seg_kernel<12, 512, 2>: four row halves, two K slices per wave), 96 at 16-frame segments (the one-clip geometry of T = 256) --
