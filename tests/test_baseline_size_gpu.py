@@ -38,8 +38,8 @@ def cpu_sd(m):
     return {k: v.detach().cpu() for k, v in m.state_dict().items()}
 
 
-@pytest.fixture(scope="module")
-def base(hip_device):
+@pytest.fixture
+def base(hip_device, both_gemm_paths):  # (per test: the handle reads the leg's AFTER_GEMM_X6 when it is created)
     model, dcfg, acfg = pipeline.build_models("base", "baseAE", hip_device, seed=5)
     return model, dcfg, acfg
 
