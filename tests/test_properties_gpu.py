@@ -9,8 +9,8 @@ pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("both_gemm_paths")]
 torch.set_grad_enabled(False)
 
 
-@pytest.fixture(scope="module")
-def base(hip_device):
+@pytest.fixture
+def base(hip_device, both_gemm_paths):  # (per test: the handle reads the leg's AFTER_GEMM_X6 when it is created)
     model, dcfg, acfg = pipeline.build_models("base", "baseAE", hip_device, seed=1)
     g = torch.Generator().manual_seed(2)
     x = torch.randn(2, 64, 256, generator=g).to(hip_device)
