@@ -861,29 +861,35 @@ __device__ __forceinline__ bool step_barrier(StepSync* st, unsigned xcc, unsigne
 // the fabric latency -- and, eight XCDs streaming the same 54 MB of weights per step, the fabric bandwidth -- on the
 // critical path.  Wave `wi` of `nw` warms 8-KB
 // chunks wi, wi + nw, ... of [base, base + bytes): one load instruction per chunk, result discarded.
-// (Inline-asm loads: a C++ volatile load is legalised to a cache-bypassing load followed by s_waitcnt vmcnt(0) -- one
-//  fabric round trip per line.  All of them write `sink`, which stays live -- one register the compiler cannot hand to
-//  anything else -- until step_warm_done has waited for the last of them; the data is never read.)
-__device__ __forceinline__ void step_warm(unsigned& sink, const void* base, size_t bytes, int wi, int nw, int lane) {
+// The streaming kernel's touches have NO register destination: they are LDS-DMA loads (global_load_lds_dword) into a 256-byte sink in
+// LDS that nobody reads; the segment kernel's row_warm issues ordinary loads and keeps their registers until the data is back.
+// (Rounds 4 - 6 issued them as inline-asm `global_load_dword` into a "sink" VGPR bound with "+v": the compiler believes
+// that register written when the asm statement ends, so it is free to copy the variable elsewhere and hand the register to another
+// value while the load is still in flight -- the data then lands, a microsecond later, in whatever lives there.  Seen in
+// sample_seg_kernel<6, 256, .>: the RoPE index term of the qkv epilogue's prefetch shared the register; harmless while the consumer
+// ran before the data came back, a wild address -- a memory fault -- when the wave was delayed, e.g. by a second process on the GPU.
+// A C++ volatile load instead is legalised to a cache-bypassing load followed by s_waitcnt vmcnt(0): a fabric round trip per line.)
+__device__ __forceinline__ void warm_touch(unsigned* sink_lds, const void* q) {
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)q, (lds_ptr_t)sink_lds, 4, 0, 0);
+}
+
+__device__ __forceinline__ void step_warm(unsigned* sink_lds, const void* base, size_t bytes, int wi, int nw, int lane) {
     const char* p = static_cast<const char*>(base);
     for (size_t c = (size_t)wi * 8192; c < bytes; c += (size_t)nw * 8192) {
         const size_t off = c + (size_t)lane * 128;
-        const char* q = p + (off < bytes ? off : c);
-        asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(q) : "memory");
+        warm_touch(sink_lds, p + (off < bytes ? off : c));
     }
 }
 
-__device__ __forceinline__ void step_warm_done(unsigned& sink) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory"); }
+__device__ __forceinline__ void step_warm_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // The same for whole 16-column weight tiles of a tiled copy (`kblocks` 1-KB blocks each: tiles tile0 + ts j, j < nt): wave
 // `wi` of `nw` touches 8-KB chunks wi, wi + nw, ... of the nt tiles.  Nobody waits for these loads: the wave's later loads
 // return behind them (in issue order), a later s_waitcnt vmcnt(0) covers them.
-__device__ __forceinline__ void seg_warm_tiles(unsigned& sink, const float* wt, int kblocks, int tile0, int ts, int nt, int wi, int nw, int lane) {
+__device__ __forceinline__ void seg_warm_tiles(unsigned* sink_lds, const float* wt, int kblocks, int tile0, int ts, int nt, int wi, int nw, int lane) {
     const int cpt = kblocks / 8;
-    for (int c = wi; c < nt * cpt; c += nw) {
-        const char* q = reinterpret_cast<const char*>(wt + ((size_t)((tile0 + ts * (c / cpt)) * kblocks) << 8)) + (size_t)(c % cpt) * 8192 + lane * 128;
-        asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(q) : "memory");
-    }
+    for (int c = wi; c < nt * cpt; c += nw)
+        warm_touch(sink_lds, reinterpret_cast<const char*>(wt + ((size_t)((tile0 + ts * (c / cpt)) * kblocks) << 8)) + (size_t)(c % cpt) * 8192 + lane * 128);
 }
 
 // acc[j * MB + i] = (this wave's K slice: k-blocks kb0 .. kb0 + KB) of rows 16 i .. 16 i + 15 of A x column tile
@@ -1434,7 +1440,8 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
     auto end_phase = [&](bool drain) { return step_barrier(st, xcc, n, (unsigned)rank, ++round, trace, ++tslot, drain, &s_ok); };
     // the LayerNorm-phase operands of this wave's row (ln phase: row rank + 32 w) / this workgroup's attention item,
     // requested one GEMM phase early (StepLnOps)
-    unsigned warm_sink = 0;  // destination of the L2-warming loads in flight across the ln barrier (step_warm)
+    __shared__ unsigned s_warm_sink[64];  // LDS destination of the L2-warming loads (step_warm): never read
+    unsigned* const warm_sink = s_warm_sink;
     StepLnOps lnops;  // (one register set: the ln row's operands live from MLP-down to ln, the attention item's from qkv to attention)
     const int ln_lm = rank + (int)n * w;  // this wave's (first) row of the ln phases
     const bool ln_mine = ln_lm < Mg && (ln_lm % ct) / T < nclip;
@@ -1491,7 +1498,7 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
             // workgroups without a row (a warming wave next to a row's wave delays its loads: one load path per CU): warm the
             // K / V ring rows of this layer, then (part of) the qkv weights.  Waves 1 - 7 do not wait for these loads (they stored
             // nothing: no drain at the barrier) -- the short LayerNorm phase is not held up by the warmers; the loads are waited
-            // for after the qkv GEMM (`warm_sink` stays live until then).  Wave 0 carries the barrier's atomics and stays out.
+            // for after the qkv GEMM.  Wave 0 carries the barrier's atomics and stays out.
             const bool warmer = wact && rank >= Mg && w > 0 && a.warm[0] > 0;
             if (warmer) {
                 const int wi = (rank - Mg) * 7 + w - 1, nw = ((int)n - Mg) * 7;
@@ -1513,7 +1520,7 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
                     step_gemm<MB, 3, kSKBQ, false>(acc, hb_r, KBE, Lw.qkv_wt, KBE, rank, kSKBQ * w, lane, cw, wact,
                                                    [&] { if (rank < nitems) attn_prefetch(l, rank); });
                 }
-                step_warm_done(warm_sink);  // (older than the GEMM's operand loads: long landed)
+                step_warm_done();  // (older than the GEMM's operand loads: long landed)
                 step_partials<3 * MB>(acc, red, w, lane);
                 for (int p = w; p < 3 * MB && cw; p += kSCW) {
                     const int j = p / MB, ib = p - j * MB;
@@ -1541,10 +1548,10 @@ __global__ __launch_bounds__(512) void stream_step_kernel(StepArgs a) {
                 if (rb >= 0) {
                     roll(kv, qkv_r, 3 * nclip, rb, nroll);
                     if (wact) {  // (MLP-up first: it is needed first)
-                        unsigned sink = 0;
+                        unsigned* const sink = warm_sink;
                         step_warm(sink, Lw.mlp0_wt, wbytes * a.warm[1] / 16, rb * 8 + w, nroll * 8, lane);
                         step_warm(sink, Lw.mlp2_wt, wbytes * a.warm[2] / 16, rb * 8 + w, nroll * 8, lane);
-                        step_warm_done(sink);
+                        step_warm_done();
                     }
                 }
             }
@@ -1912,17 +1919,22 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
     };
     const int ln_lm = rank + (int)n * w;  // this wave's row of the ln phases (waves 0 .. 2 at 96 rows)
     const bool ln_mine = ln_lm < Mg;
-    unsigned wsink = 0;  // destination of the L2-warming loads (seg_warm_tiles, row_warm): never read
+    // the L2-warming loads of row_warm in flight: ordinary (compiler-tracked) loads whose values are "used" by an empty asm statement
+    // behind the phase's closing barrier -- the registers stay theirs until the data has landed (see warm_touch for what went wrong
+    // with an untracked destination; the LDS-DMA form of the streaming kernel cost 1.6 - 3 % here: its completion is waited for in
+    // front of the phase's LDS exchange)
+    unsigned wt_ln = 0, wt_at = 0;
+    auto warm_landed = [&] { asm volatile("" : "+v"(wt_ln), "+v"(wt_at)); };
     // The row-wise operands of a LayerNorm (AdaLN alpha | beta of the row: 4 KB; affine weight, bias: 2 KB each) come from the
     // memory-side cache.  One phase EARLY a wave touches their 64 lines into the XCD's L2 (one load instruction, nobody waits
     // for it); the phase that needs them then loads them beside its activation row at L2 latency -- carrying them through the
     // GEMM phase in registers (32 per lane) made the register allocator spill inside the MFMA loops.
-    auto row_warm = [&](const float* ab, const float* wv, const float* bv) {
+    auto row_warm = [&](const float* ab, const float* wv, const float* bv) -> unsigned {
         constexpr int LA = E / 16, LW = E / 32;  // 128-byte lines of the alpha | beta row and of a weight / bias row
         const char* q = lane0 < LA ? reinterpret_cast<const char*>(ab) + lane0 * 128
                                    : (lane0 < LA + LW ? reinterpret_cast<const char*>(wv) + (lane0 - LA) * 128
                                                       : reinterpret_cast<const char*>(bv) + ((lane0 - LA - LW) & (LW - 1)) * 128);
-        asm volatile("global_load_dword %0, %1, off" : "+v"(wsink) : "v"(q) : "memory");
+        return *reinterpret_cast<const unsigned*>(q);
     };
     const float* ln_ab0 = a.tc_ab;  // this wave's tcond AdaLN row (layer 0)
     if (ln_mine) {
@@ -1930,7 +1942,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
         ln_ab0 += ((size_t)a.tcmap[(br - 3 * cl) * a.B + a.clip + cl] * T + f0 + tl) * a.tc_ld;
     }
     auto ln_prefetch = [&](int l) {
-        if (ln_mine) row_warm(ln_ab0 + (size_t)l * 2 * E, a.layer[l].n1w, a.layer[l].n1b);
+        if (ln_mine) wt_ln = row_warm(ln_ab0 + (size_t)l * 2 * E, a.layer[l].n1w, a.layer[l].n1b);
     };
     const int cps = Tseg / a.cs, nitems = 3 * NC * cps;  // attention items: (branch, chunk of the segment)
     auto cond_row = [&](int br) { return (br % 3) * a.B + a.clip + br / 3; };  // AdaLN(cond) row of a branch
@@ -1941,7 +1953,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
         asm volatile("" : "+v"(lane_i));  // (opaque: per-lane addresses are recomputed here -- hoisted out of the loops they are
         const int lane = lane_i;         //  kernel-lifetime 64-bit register pairs, and the allocator spills them into the MFMA loops)
         auto attn_prefetch = [&](int l, int it) {  // (wave 0: one touch per workgroup)
-            if (w == 0) row_warm(cond_ab + (size_t)cond_row(it / cps) * a.cond_ld + (size_t)l * 2 * E, a.layer[l].n3w, a.layer[l].n3b);
+            if (w == 0) wt_at = row_warm(cond_ab + (size_t)cond_row(it / cps) * a.cond_ld + (size_t)l * 2 * E, a.layer[l].n3w, a.layer[l].n3b);
         };
         tslot = 0;
         if (trace && tid == 0) {
@@ -1981,6 +1993,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
             }
         }
         if (!end_phase(w < MBP)) return;
+        warm_landed();
         for (int l = 0; l < a.L; ++l) {
             const StepLayer& Lw = a.layer[l];
             const StepLayer& Lww = a.layer[SEG_DIAG & 8 ? 0 : l];  // (the layer whose Linear weights are read: see seg_load_w)
@@ -2096,6 +2109,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 if (trace && tid == 0) trace[67] = wall_clock64();
             }
             if (!end_phase(true, &st->qkv_seq[g][0], seq)) return;
+            warm_landed();
             // ---- attention + residual + AdaLN(cond) + norm3: one workgroup per chunk of a CFG row; a chunk whose window
             //      starts in front of the segment waits for the previous XCD's rows
             // (the last workgroup has no item: before the NEXT qkv phase -- sequence number seq + 1, this layer's successor or layer 0
@@ -2203,6 +2217,7 @@ __global__ __launch_bounds__(512) void sample_seg_kernel(StepArgs a) {
                 }
             }
             if (!end_phase(w < 3 * NTD)) return;
+            warm_landed();
         }
         // ---- out_proj + CFG + Euler (+ the token-major latents of the next step), fp32 MFMA: workgroup (column tile,
         //      16-frame block of a clip) owns the three CFG rows of its frames (row blocks 3 TB clip + block + TB r, TB = Tseg / 16)

@@ -841,6 +841,10 @@ def main():
     share = os.environ.get("AFTER_BENCH_SHARE_GPU") == "1"
     if share:
         local = 0
+        # several processes on ONE GPU: the persistent samplers assume the device to themselves (denoiser.hip: PersistGuard -- "kernels
+        # of other processes sharing the GPU are outside this guard: such deployments select the launch path"), and so does this hook
+        os.environ.setdefault("AFTER_SAMPLE_PERSIST", "0")
+        os.environ.setdefault("AFTER_STREAM_PERSIST", "0")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
